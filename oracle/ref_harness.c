@@ -1,0 +1,433 @@
+/* TEST INFRASTRUCTURE ONLY.
+ *
+ * ctypes-callable harness around the REAL reference (jpsdr/x264, C path, no asm).  This file is our
+ * own code; it is compiled by oracle/build_ref.sh together with the reference's library sources
+ * (taken where they lie under /root/reference) into oracle/_ref/libx264ref{8,10}.so.
+ *
+ * It includes the reference's encoder/analyse.c as a translation unit (which itself pulls in
+ * encoder/slicetype.c, analyse.c:3894) so that the static functions slicetype_frame_cost /
+ * lowres_context_init are reachable without touching the reference tree.
+ *
+ * Only tests/ and bench.py's cpu_baseline leg load the resulting library.  Nothing in the product
+ * (x264_amd/) links, loads or calls it.
+ */
+#include "encoder/analyse.c"
+
+#include <time.h>
+
+/* the templated entry point has no prototype in the reference headers (api.c:34 declares it locally) */
+x264_t *x264_encoder_open( x264_param_t *, void * );
+
+#define RH_API __attribute__((visibility("default"), force_align_arg_pointer))
+#define RH_MAX_FRAMES 512
+
+typedef struct
+{
+    x264_t *h;
+    x264_param_t param;
+    int n_frames;
+    x264_frame_t *frames[RH_MAX_FRAMES + 4];
+} rh_ctx;
+
+static void rh_log_quiet( void *p, int level, const char *fmt, va_list ap )
+{
+    if( level <= X264_LOG_ERROR )
+        vfprintf( stderr, fmt, ap );
+}
+
+RH_API int rh_bit_depth( void ) { return BIT_DEPTH; }
+
+/* opts: "key=value,key=value" applied with x264_param_parse after the preset. */
+RH_API rh_ctx *rh_open( int width, int height, const char *preset, const char *tune, const char *opts )
+{
+    rh_ctx *c = calloc( 1, sizeof(*c) );
+    if( !c )
+        return NULL;
+    if( x264_param_default_preset( &c->param, preset && preset[0] ? preset : "medium", tune && tune[0] ? tune : NULL ) < 0 )
+        goto fail;
+    c->param.i_width = width;
+    c->param.i_height = height;
+    c->param.i_csp = X264_CSP_I420;
+    c->param.i_bitdepth = BIT_DEPTH;
+    c->param.i_threads = 1;
+    c->param.i_lookahead_threads = 1;
+    c->param.b_vfr_input = 0;
+    c->param.i_fps_num = 25;
+    c->param.i_fps_den = 1;
+    c->param.pf_log = rh_log_quiet;
+    c->param.i_log_level = X264_LOG_ERROR;
+    if( opts && opts[0] )
+    {
+        char *dup = strdup( opts ), *save = NULL;
+        for( char *tok = strtok_r( dup, ",", &save ); tok; tok = strtok_r( NULL, ",", &save ) )
+        {
+            char *eq = strchr( tok, '=' );
+            if( eq ) *eq = 0;
+            if( x264_param_parse( &c->param, tok, eq ? eq + 1 : NULL ) < 0 )
+            {
+                fprintf( stderr, "rh_open: bad option %s\n", tok );
+                free( dup );
+                goto fail;
+            }
+        }
+        free( dup );
+    }
+    c->h = x264_encoder_open( &c->param, NULL );
+    if( !c->h )
+        goto fail;
+    return c;
+fail:
+    free( c );
+    return NULL;
+}
+
+RH_API void rh_close( rh_ctx *c )
+{
+    if( !c ) return;
+    for( int i = 0; i < c->n_frames; i++ )
+        if( c->frames[i] )
+            x264_frame_push_unused( c->h, c->frames[i] );
+    x264_encoder_close( c->h );
+    free( c );
+}
+
+/* effective (validated) parameters, for mirroring into our own context */
+RH_API void rh_get_config( rh_ctx *c, int *out )
+{
+    x264_t *h = c->h;
+    x264_mb_analysis_t a;
+    lowres_context_init( h, &a );
+    out[0]  = h->mb.i_mb_width;
+    out[1]  = h->mb.i_mb_height;
+    out[2]  = h->param.i_bframe;
+    out[3]  = h->param.i_bframe_adaptive;
+    out[4]  = h->param.rc.i_lookahead;
+    out[5]  = h->param.analyse.i_mv_range;
+    out[6]  = h->param.analyse.i_me_range;
+    out[7]  = h->mb.i_me_method;
+    out[8]  = h->mb.i_subpel_refine;
+    out[9]  = a.i_lambda;
+    out[10] = h->param.analyse.i_weighted_pred;
+    out[11] = h->param.analyse.b_weighted_bipred;
+    out[12] = h->param.rc.i_aq_mode;
+    out[13] = h->param.rc.b_mb_tree;
+    out[14] = h->param.i_scenecut_threshold;
+    out[15] = h->param.i_keyint_max;
+    out[16] = h->param.i_keyint_min;
+    out[17] = h->param.i_bframe_pyramid;
+    out[18] = h->param.i_bframe_bias;
+    out[19] = h->frames.i_delay;
+    out[20] = h->lookahead->i_slicetype_length;
+    out[21] = h->param.rc.i_vbv_buffer_size;
+    out[22] = h->param.b_open_gop;
+    out[23] = h->param.b_intra_refresh;
+    out[24] = h->param.analyse.i_subpel_refine;
+    out[25] = h->pixf.mbcmp[0] == h->pixf.satd[0];     /* mbcmp is SATD */
+    out[26] = h->pixf.fpelcmp[0] == h->pixf.satd[0];   /* fpelcmp is SATD */
+    out[27] = h->param.analyse.b_psy;
+    out[28] = h->param.rc.i_rc_method;
+    out[29] = h->frames.i_bframe_delay;
+    out[30] = h->param.i_frame_reference;
+    out[31] = (int)(h->param.rc.f_aq_strength * 65536.f);
+}
+
+/* cost_mv table of the lookahead qp, centred: out[i + n] for i in [-n, n], n = 2*4*mv_range */
+RH_API int rh_cost_mv( rh_ctx *c, uint16_t *out, int cap )
+{
+    x264_t *h = c->h;
+    int n = 2*4*h->param.analyse.i_mv_range;
+    if( out )
+    {
+        if( cap < 2*n+1 ) return -1;
+        for( int i = -n; i <= n; i++ )
+            out[i+n] = h->cost_mv[X264_LOOKAHEAD_QP][i];
+    }
+    return n;
+}
+
+static x264_frame_t *rh_make_frame( rh_ctx *c, const pixel *y, const pixel *u, const pixel *v, int idx )
+{
+    x264_t *h = c->h;
+    int w = h->param.i_width, ht = h->param.i_height;
+    x264_picture_t pic;
+    x264_picture_init( &pic );
+    pic.img.i_csp = X264_CSP_I420 | (BIT_DEPTH > 8 ? X264_CSP_HIGH_DEPTH : 0);
+    pic.img.i_plane = 3;
+    pixel *grey = NULL;
+    if( !u || !v )
+    {
+        grey = malloc( (size_t)(w/2+1)*(ht/2+1)*sizeof(pixel) );
+        for( int i = 0; i < (w/2+1)*(ht/2+1); i++ )
+            grey[i] = 1 << (BIT_DEPTH-1);
+        u = v = grey;
+    }
+    pic.img.plane[0] = (uint8_t*)y; pic.img.i_stride[0] = w * sizeof(pixel);
+    pic.img.plane[1] = (uint8_t*)u; pic.img.i_stride[1] = ((w+1)/2) * sizeof(pixel);
+    pic.img.plane[2] = (uint8_t*)v; pic.img.i_stride[2] = ((w+1)/2) * sizeof(pixel);
+    pic.i_pts = idx;
+    x264_frame_t *f = x264_frame_pop_unused( h, 0 );
+    if( !f || x264_frame_copy_picture( h, f, &pic ) < 0 )
+    {
+        free( grey );
+        return NULL;
+    }
+    free( grey );
+    if( w != 16*h->mb.i_mb_width || ht != 16*h->mb.i_mb_height )
+        x264_frame_expand_border_mod16( h, f );
+    f->i_frame = idx;
+    f->i_pic_struct = PIC_STRUCT_PROGRESSIVE;
+    return f;
+}
+
+/* Add a frame to the evaluation set (index = order of addition): AQ + lowres init, exactly the
+ * pre-lookahead steps of x264_encoder_encode (encoder.c:3368-3423). */
+RH_API int rh_add_frame( rh_ctx *c, const pixel *y, const pixel *u, const pixel *v )
+{
+    if( c->n_frames >= RH_MAX_FRAMES ) return -1;
+    x264_frame_t *f = rh_make_frame( c, y, u, v, c->n_frames );
+    if( !f ) return -1;
+    x264_adaptive_quant_frame( c->h, f, NULL );
+    x264_frame_init_lowres( c->h, f );
+    c->frames[c->n_frames] = f;
+    return c->n_frames++;
+}
+
+/* Direct call of the reference's static slicetype_frame_cost (slicetype.c:836). */
+RH_API int rh_frame_cost( rh_ctx *c, int p0, int p1, int b )
+{
+    x264_mb_analysis_t a;
+    lowres_context_init( c->h, &a );
+    return slicetype_frame_cost( c->h, &a, c->frames, p0, p1, b );
+}
+
+RH_API void rh_weights_analyse( rh_ctx *c, int b, int ref, int *out )
+{
+    x264_weights_analyse( c->h, c->frames[b], c->frames[ref], 1 );
+    x264_weight_t *w = c->frames[b]->weight[0];
+    out[0] = w[0].weightfn != NULL; out[1] = w[0].i_scale; out[2] = w[0].i_denom; out[3] = w[0].i_offset;
+}
+
+/* Field accessors: copy internal arrays of frame idx into caller buffers. */
+RH_API int rh_lowres_geometry( rh_ctx *c, int *out )
+{
+    x264_frame_t *f = c->frames[0];
+    if( !f ) return -1;
+    out[0] = f->i_width_lowres; out[1] = f->i_lines_lowres; out[2] = f->i_stride_lowres;
+    out[3] = PADH; out[4] = PADV;
+    return 0;
+}
+
+/* plane p of the lowres pyramid including the padded border: (lines+2*PADV) x (width+2*PADH), tight */
+RH_API void rh_get_lowres( rh_ctx *c, int idx, int p, pixel *out )
+{
+    x264_frame_t *f = c->frames[idx];
+    int w = f->i_width_lowres + 2*PADH, hh = f->i_lines_lowres + 2*PADV;
+    for( int y = 0; y < hh; y++ )
+        memcpy( out + (size_t)y*w, f->lowres[p] + (y-PADV)*f->i_stride_lowres - PADH, w*sizeof(pixel) );
+}
+
+RH_API void rh_get_frame_stats( rh_ctx *c, int idx, uint16_t *inv_qscale, uint16_t *intra_cost, uint64_t *sum_ssd )
+{
+    x264_frame_t *f = c->frames[idx];
+    int n = c->h->mb.i_mb_count;
+    if( inv_qscale ) memcpy( inv_qscale, f->i_inv_qscale_factor, n*sizeof(uint16_t) );
+    if( intra_cost ) memcpy( intra_cost, f->i_intra_cost, n*sizeof(uint16_t) );
+    if( sum_ssd ) { sum_ssd[0] = f->i_pixel_sum[0]; sum_ssd[1] = f->i_pixel_ssd[0]; }
+}
+
+RH_API int rh_get_mvs( rh_ctx *c, int idx, int list, int dist, int16_t *mvs, int *mv_costs )
+{
+    x264_frame_t *f = c->frames[idx];
+    int n = c->h->mb.i_mb_count;
+    if( !f->lowres_mvs[list][dist] ) return -1;
+    memcpy( mvs, f->lowres_mvs[list][dist], n*2*sizeof(int16_t) );
+    if( mv_costs ) memcpy( mv_costs, f->lowres_mv_costs[list][dist], n*sizeof(int) );
+    return 0;
+}
+
+RH_API int rh_get_cell( rh_ctx *c, int idx, int d0, int d1, uint16_t *lowres_costs, int *row_satds, int *summary )
+{
+    x264_frame_t *f = c->frames[idx];
+    int n = c->h->mb.i_mb_count;
+    if( !f->lowres_costs[d0][d1] ) return -1;
+    if( lowres_costs ) memcpy( lowres_costs, f->lowres_costs[d0][d1], n*sizeof(uint16_t) );
+    if( row_satds ) memcpy( row_satds, f->i_row_satds[d0][d1], c->h->mb.i_mb_height*sizeof(int) );
+    summary[0] = f->i_cost_est[d0][d1];
+    summary[1] = f->i_cost_est_aq[d0][d1];
+    summary[2] = f->i_intra_mbs[d0];
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Lookahead-only driver: the front half of x264_encoder_encode (encoder.c:3368-3454) paced exactly
+ * like the encoder (one frame consumed per call once the delay is filled), without the main encode.
+ * Per output frame (coded order) records: display index, type, and the frame's whole i_cost_est /
+ * i_cost_est_aq matrices + i_intra_mbs as they stand when the frame leaves the lookahead.
+ * Returns the number of frames output; *seconds = wall time spent inside (lowres init + lookahead).
+ * ------------------------------------------------------------------------------------------ */
+#define RH_MAT ((X264_BFRAME_MAX+2)*(X264_BFRAME_MAX+2))
+
+static int rh_drain_one( x264_t *h, int *out_idx, int *out_type, int *out_cost, int *out_cost_aq, int *out_imbs, int n_out )
+{
+    h->i_frame++;
+    if( !h->frames.current[0] )
+        x264_lookahead_get_frames( h );
+    if( !h->frames.current[0] && x264_lookahead_is_empty( h ) )
+        return -1;
+    x264_frame_t *f = x264_frame_shift( h->frames.current );
+    if( out_idx )  out_idx[n_out] = f->i_frame;
+    if( out_type ) out_type[n_out] = f->i_type;
+    if( out_cost )    memcpy( out_cost    + (size_t)n_out*RH_MAT, f->i_cost_est,    RH_MAT*sizeof(int) );
+    if( out_cost_aq ) memcpy( out_cost_aq + (size_t)n_out*RH_MAT, f->i_cost_est_aq, RH_MAT*sizeof(int) );
+    if( out_imbs )    memcpy( out_imbs + (size_t)n_out*(X264_BFRAME_MAX+2), f->i_intra_mbs, (X264_BFRAME_MAX+2)*sizeof(int) );
+    x264_frame_push_unused( h, f );
+    return 0;
+}
+
+RH_API int rh_lookahead_run( rh_ctx *c, const pixel *yuv, int n_frames, int luma_only,
+                             int *out_idx, int *out_type, int *out_cost, int *out_cost_aq, int *out_imbs,
+                             double *seconds, double *seconds_prep )
+{
+    x264_t *h = c->h;
+    int w = h->param.i_width, ht = h->param.i_height;
+    size_t ysz = (size_t)w*ht, csz = (size_t)((w+1)/2)*((ht+1)/2);
+    size_t fsz = luma_only ? ysz : ysz + 2*csz;
+    int n_out = 0;
+    double t_la = 0, t_prep = 0;
+    struct timespec t0, t1;
+    for( int i = 0; i < n_frames; i++ )
+    {
+        const pixel *y = yuv + (size_t)i*fsz;
+        clock_gettime( CLOCK_MONOTONIC, &t0 );
+        x264_frame_t *fenc = rh_make_frame( c, y, luma_only ? NULL : y+ysz, luma_only ? NULL : y+ysz+csz, 0 );
+        if( !fenc ) return -1;
+        fenc->i_frame = h->frames.i_input++;
+        fenc->i_pts = fenc->i_frame;
+        if( fenc->i_frame == 0 )
+            h->frames.i_first_pts = fenc->i_pts;
+        if( h->frames.i_bframe_delay && fenc->i_frame == h->frames.i_bframe_delay )
+            h->frames.i_bframe_delay_time = fenc->i_pts - h->frames.i_first_pts;
+        h->frames.i_second_largest_pts = h->frames.i_largest_pts;
+        h->frames.i_largest_pts = fenc->i_pts;
+        x264_adaptive_quant_frame( h, fenc, NULL );
+        clock_gettime( CLOCK_MONOTONIC, &t1 );
+        t_prep += (t1.tv_sec-t0.tv_sec) + 1e-9*(t1.tv_nsec-t0.tv_nsec);
+        clock_gettime( CLOCK_MONOTONIC, &t0 );
+        x264_frame_init_lowres( h, fenc );
+        x264_lookahead_put_frame( h, fenc );
+        if( h->frames.i_input > h->frames.i_delay + 1 - h->i_thread_frames )
+        {
+            if( rh_drain_one( h, out_idx, out_type, out_cost, out_cost_aq, out_imbs, n_out ) == 0 )
+                n_out++;
+        }
+        clock_gettime( CLOCK_MONOTONIC, &t1 );
+        t_la += (t1.tv_sec-t0.tv_sec) + 1e-9*(t1.tv_nsec-t0.tv_nsec);
+    }
+    clock_gettime( CLOCK_MONOTONIC, &t0 );
+    while( n_out < n_frames && rh_drain_one( h, out_idx, out_type, out_cost, out_cost_aq, out_imbs, n_out ) == 0 )
+        n_out++;
+    clock_gettime( CLOCK_MONOTONIC, &t1 );
+    t_la += (t1.tv_sec-t0.tv_sec) + 1e-9*(t1.tv_nsec-t0.tv_nsec);
+    if( seconds ) *seconds = t_la;
+    if( seconds_prep ) *seconds_prep = t_prep;
+    return n_out;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Primitive access (checkasm-style known answers): the C vtables filled by the reference.
+ * ------------------------------------------------------------------------------------------ */
+/* kind: 0 sad, 1 satd, 2 ssd, 3 sa8d (size 0..3) */
+RH_API int rh_pixel_cmp( rh_ctx *c, int kind, int size, pixel *a, intptr_t sa, pixel *b, intptr_t sb )
+{
+    x264_pixel_function_t *pf = &c->h->pixf;
+    switch( kind )
+    {
+        case 0: return pf->sad[size]( a, sa, b, sb );
+        case 1: return pf->satd[size]( a, sa, b, sb );
+        case 2: return pf->ssd[size]( a, sa, b, sb );
+        case 3: return pf->sa8d[size]( a, sa, b, sb );
+    }
+    return -1;
+}
+/* fenc has FENC_STRIDE; n = 3 or 4; satd != 0 selects satd_x3/x4 */
+RH_API void rh_pixel_cmp_xn( rh_ctx *c, int satd, int n, int size, pixel *fenc, pixel *ref, const int *offs, intptr_t stride, int *out )
+{
+    x264_pixel_function_t *pf = &c->h->pixf;
+    if( n == 3 )
+        (satd ? pf->satd_x3 : pf->sad_x3)[size]( fenc, ref+offs[0], ref+offs[1], ref+offs[2], stride, out );
+    else
+        (satd ? pf->satd_x4 : pf->sad_x4)[size]( fenc, ref+offs[0], ref+offs[1], ref+offs[2], ref+offs[3], stride, out );
+}
+RH_API uint64_t rh_pixel_var( rh_ctx *c, int size, pixel *a, intptr_t sa ) { return c->h->pixf.var[size]( a, sa ); }
+/* fdec points at the top-left pixel of an FDEC_STRIDE buffer with neighbours filled in */
+RH_API void rh_intra_x3_8x8c( rh_ctx *c, int satd, pixel *fenc, pixel *fdec, int *res )
+{
+    (satd ? c->h->pixf.intra_satd_x3_8x8c : c->h->pixf.intra_sad_x3_8x8c)( fenc, fdec, res );
+}
+RH_API void rh_predict_8x8c( rh_ctx *c, int mode, pixel *src ) { c->h->predict_8x8c[mode]( src ); }
+RH_API void rh_predict_8x8_filter( rh_ctx *c, pixel *src, pixel *edge, int neighbor, int filters ) { c->h->predict_8x8_filter( src, edge, neighbor, filters ); }
+RH_API void rh_predict_8x8( rh_ctx *c, int mode, pixel *src, pixel *edge ) { c->h->predict_8x8[mode]( src, edge ); }
+RH_API void rh_lowres_core( rh_ctx *c, pixel *src, pixel *d0, pixel *dh, pixel *dv, pixel *dc, intptr_t ss, intptr_t ds, int w, int hh )
+{
+    c->h->mc.frame_init_lowres_core( src, d0, dh, dv, dc, ss, ds, w, hh );
+}
+/* planes: 4 pointers to the same-geometry hpel planes; returns via dst (always materialised) */
+RH_API void rh_mc_luma( rh_ctx *c, pixel *dst, intptr_t ds, pixel *p0, pixel *p1, pixel *p2, pixel *p3, intptr_t ss,
+                        int mvx, int mvy, int w, int hh, int wt_on, int scale, int denom, int offset )
+{
+    x264_t *h = c->h;
+    pixel *src[4] = { p0, p1, p2, p3 };
+    x264_weight_t wt[3];
+    memset( wt, 0, sizeof(wt) );
+    SET_WEIGHT( wt[0], wt_on, scale, denom, offset );
+    h->mc.mc_luma( dst, ds, src, ss, mvx, mvy, w, hh, wt_on ? wt : x264_weight_none );
+}
+RH_API void rh_avg( rh_ctx *c, int size, pixel *dst, intptr_t ds, pixel *a, intptr_t sa, pixel *b, intptr_t sb, int weight )
+{
+    c->h->mc.avg[size]( dst, ds, a, sa, b, sb, weight );
+}
+/* kind: 0 sub4x4_dct 1 sub8x8_dct 2 sub16x16_dct 3 sub8x8_dct8 4 sub16x16_dct8 5 sub8x8_dct_dc 6 sub8x16_dct_dc
+ *       7 dct4x4dc (in place) 8 dct2x4dc (in place uses out as dct4x4 array [8][16]) */
+RH_API void rh_dct( rh_ctx *c, int kind, dctcoef *out, pixel *fenc, pixel *fdec )
+{
+    x264_dct_function_t *d = &c->h->dctf;
+    switch( kind )
+    {
+        case 0: d->sub4x4_dct( out, fenc, fdec ); break;
+        case 1: d->sub8x8_dct( (void*)out, fenc, fdec ); break;
+        case 2: d->sub16x16_dct( (void*)out, fenc, fdec ); break;
+        case 3: d->sub8x8_dct8( out, fenc, fdec ); break;
+        case 4: d->sub16x16_dct8( (void*)out, fenc, fdec ); break;
+        case 5: d->sub8x8_dct_dc( out, fenc, fdec ); break;
+        case 6: d->sub8x16_dct_dc( out, fenc, fdec ); break;
+        case 7: d->dct4x4dc( out ); break;
+    }
+}
+/* kind: 0 quant_4x4 1 quant_8x8 2 quant_4x4x4 3 quant_4x4_dc 4 quant_2x2_dc ; cqm list i_list, qp */
+RH_API int rh_quant( rh_ctx *c, int kind, dctcoef *coef, int i_list, int qp, int b_intra_bias )
+{
+    x264_t *h = c->h;
+    x264_quant_function_t *q = &h->quantf;
+    switch( kind )
+    {
+        case 0: return q->quant_4x4( coef, h->quant4_mf[i_list][qp], h->quant4_bias[i_list][qp] );
+        case 1: return q->quant_8x8( coef, h->quant8_mf[i_list][qp], h->quant8_bias[i_list][qp] );
+        case 2: return q->quant_4x4x4( (void*)coef, h->quant4_mf[i_list][qp], h->quant4_bias[i_list][qp] );
+        case 3: return q->quant_4x4_dc( coef, h->quant4_mf[i_list][qp][0]>>1, h->quant4_bias[i_list][qp][0]<<1 );
+        case 4: return q->quant_2x2_dc( coef, h->quant4_mf[i_list][qp][0]>>1, h->quant4_bias[i_list][qp][0]<<1 );
+    }
+    return -1;
+}
+RH_API void rh_quant_tables( rh_ctx *c, int is8, int i_list, int qp, udctcoef *mf, udctcoef *bias )
+{
+    x264_t *h = c->h;
+    int n = is8 ? 64 : 16;
+    memcpy( mf,   is8 ? h->quant8_mf[i_list][qp]   : h->quant4_mf[i_list][qp],   n*sizeof(udctcoef) );
+    memcpy( bias, is8 ? h->quant8_bias[i_list][qp] : h->quant4_bias[i_list][qp], n*sizeof(udctcoef) );
+}
+RH_API void rh_luts( float *log2_lut, float *log2_lz_lut, uint8_t *exp2_lut )
+{
+    memcpy( log2_lut, x264_log2_lut, 128*sizeof(float) );
+    memcpy( log2_lz_lut, x264_log2_lz_lut, 32*sizeof(float) );
+    memcpy( exp2_lut, x264_exp2_lut, 64 );
+}

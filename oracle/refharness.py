@@ -1,0 +1,136 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes view of oracle/_ref/libx264ref{8,10}.so (the real reference, C path).
+
+Used by tests/ (to pin the oracle restatement and the host logic) and by bench.py's cpu_baseline leg.
+The product package x264_amd never imports this module.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MAT = 18 * 18  # (X264_BFRAME_MAX+2)^2
+
+
+def lib_path(bit_depth=8):
+    return os.path.join(_HERE, "_ref", "libx264ref%d.so" % bit_depth)
+
+
+def available(bit_depth=8):
+    return os.path.exists(lib_path(bit_depth))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Ref:
+    def __init__(self, width, height, preset="medium", tune="", opts="", bit_depth=8):
+        self.lib = C.CDLL(lib_path(bit_depth))
+        L = self.lib
+        L.rh_open.restype = C.c_void_p
+        L.rh_open.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
+        self.bit_depth = bit_depth
+        self.dtype = np.uint8 if bit_depth == 8 else np.uint16
+        self.width, self.height = width, height
+        self.ctx = L.rh_open(width, height, preset.encode(), tune.encode(), opts.encode())
+        if not self.ctx:
+            raise RuntimeError("rh_open failed")
+        self.ctx = C.c_void_p(self.ctx)
+        cfg = np.zeros(32, np.int32)
+        L.rh_get_config(self.ctx, _ptr(cfg))
+        names = ["mb_w", "mb_h", "bframes", "b_adapt", "rc_lookahead", "mv_range", "me_range", "me_method",
+                 "subpel_refine", "lambda", "weightp", "weighted_bipred", "aq_mode", "mb_tree", "scenecut",
+                 "keyint_max", "keyint_min", "b_pyramid", "b_bias", "delay", "slicetype_length", "vbv",
+                 "open_gop", "intra_refresh", "subme", "mbcmp_satd", "fpelcmp_satd", "psy", "rc_method",
+                 "bframe_delay", "refs", "aq_strength_q16"]
+        self.cfg = {k: int(v) for k, v in zip(names, cfg)}
+        self.mb_w, self.mb_h = self.cfg["mb_w"], self.cfg["mb_h"]
+        self.n_mb = self.mb_w * self.mb_h
+        self.n_frames = 0
+
+    def close(self):
+        if self.ctx:
+            self.lib.rh_close(self.ctx)
+            self.ctx = None
+
+    def cost_mv(self):
+        self.lib.rh_cost_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        n = self.lib.rh_cost_mv(self.ctx, None, 0)
+        out = np.zeros(2 * n + 1, np.uint16)
+        self.lib.rh_cost_mv(self.ctx, _ptr(out), out.size)
+        return out
+
+    def add_frame(self, luma):
+        luma = np.ascontiguousarray(luma, dtype=self.dtype)
+        assert luma.shape == (self.height, self.width)
+        self.lib.rh_add_frame.argtypes = [C.c_void_p] * 4
+        r = self.lib.rh_add_frame(self.ctx, _ptr(luma), None, None)
+        assert r >= 0
+        self.n_frames = r + 1
+        return r
+
+    def frame_cost(self, p0, p1, b):
+        return self.lib.rh_frame_cost(self.ctx, p0, p1, b)
+
+    def weights_analyse(self, b, ref):
+        out = np.zeros(4, np.int32)
+        self.lib.rh_weights_analyse.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        self.lib.rh_weights_analyse(self.ctx, b, ref, _ptr(out))
+        return tuple(int(x) for x in out)
+
+    def lowres_geometry(self):
+        g = np.zeros(5, np.int32)
+        self.lib.rh_lowres_geometry.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.rh_lowres_geometry(self.ctx, _ptr(g))
+        return dict(width=int(g[0]), lines=int(g[1]), stride=int(g[2]), padh=int(g[3]), padv=int(g[4]))
+
+    def lowres(self, idx, plane):
+        g = self.lowres_geometry()
+        out = np.zeros((g["lines"] + 2 * g["padv"], g["width"] + 2 * g["padh"]), self.dtype)
+        self.lib.rh_get_lowres.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        self.lib.rh_get_lowres(self.ctx, idx, plane, _ptr(out))
+        return out
+
+    def frame_stats(self, idx):
+        inv = np.zeros(self.n_mb, np.uint16)
+        intra = np.zeros(self.n_mb, np.uint16)
+        ss = np.zeros(2, np.uint64)
+        self.lib.rh_get_frame_stats.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.rh_get_frame_stats(self.ctx, idx, _ptr(inv), _ptr(intra), _ptr(ss))
+        return inv, intra, (int(ss[0]), int(ss[1]))
+
+    def mvs(self, idx, lst, dist):
+        mv = np.zeros((self.n_mb, 2), np.int16)
+        cost = np.zeros(self.n_mb, np.int32)
+        self.lib.rh_get_mvs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        r = self.lib.rh_get_mvs(self.ctx, idx, lst, dist, _ptr(mv), _ptr(cost))
+        assert r == 0
+        return mv, cost
+
+    def cell(self, idx, d0, d1):
+        lc = np.zeros(self.n_mb, np.uint16)
+        rows = np.zeros(self.mb_h, np.int32)
+        summ = np.zeros(3, np.int32)
+        self.lib.rh_get_cell.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        r = self.lib.rh_get_cell(self.ctx, idx, d0, d1, _ptr(lc), _ptr(rows), _ptr(summ))
+        assert r == 0
+        return lc, rows, tuple(int(x) for x in summ)
+
+    def lookahead_run(self, luma_frames):
+        """luma_frames: [n, H, W]; returns dict(idx, type, cost, cost_aq, intra_mbs, seconds, seconds_prep)."""
+        fr = np.ascontiguousarray(luma_frames, dtype=self.dtype)
+        n = fr.shape[0]
+        idx = np.zeros(n, np.int32)
+        typ = np.zeros(n, np.int32)
+        cost = np.zeros((n, 18, 18), np.int32)
+        cost_aq = np.zeros((n, 18, 18), np.int32)
+        imbs = np.zeros((n, 18), np.int32)
+        sec = C.c_double(0)
+        sec_prep = C.c_double(0)
+        f = self.lib.rh_lookahead_run
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.POINTER(C.c_double)] * 2
+        r = f(self.ctx, _ptr(fr), n, 1, _ptr(idx), _ptr(typ), _ptr(cost), _ptr(cost_aq), _ptr(imbs),
+              C.byref(sec), C.byref(sec_prep))
+        assert r == n, (r, n)
+        return dict(idx=idx, type=typ, cost=cost, cost_aq=cost_aq, intra_mbs=imbs,
+                    seconds=sec.value, seconds_prep=sec_prep.value)

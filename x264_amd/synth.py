@@ -1,0 +1,52 @@
+"""Deterministic synthetic YUV 4:2:0 clips (luma only matters for the lookahead; chroma is mid-grey).
+
+Recipe follows SURVEY.md section 8(d): a smooth random field (uniform noise, 4 passes of a 5-tap box
+blur) is sampled through a window that pans by (3i mod 256, 2i mod 128) per frame, +-3 uniform noise is
+added per frame, the luma is inverted at scene changes and an optional linear fade segment exercises
+weighted prediction.
+"""
+import numpy as np
+
+
+def _box5(a, axis):
+    out = np.zeros_like(a)
+    for k in range(-2, 3):
+        out += np.roll(a, k, axis=axis)
+    return out / 5.0
+
+
+def make_clip(width, height, n_frames, seed=1, bit_depth=8, scene_cuts=(), fade=None, noise=3):
+    """Return uint8/uint16 array [n_frames, height, width] of luma samples.
+
+    scene_cuts: frame indices at which the picture is inverted (a hard cut).
+    fade: (start, length, gain_end, offset_end) -- linear fade applied over [start, start+length) and
+          held afterwards.
+    """
+    rng = np.random.default_rng(seed)
+    fh, fw = height + 128 + 8, width + 256 + 8
+    field = rng.uniform(0.0, 1.0, size=(fh, fw))
+    for _ in range(4):
+        field = _box5(_box5(field, 0), 1)
+    field -= field.min()
+    field /= max(field.max(), 1e-9)
+    # add a little high-frequency texture so SATD/intra modes are non-trivial
+    field = 0.82 * field + 0.18 * rng.uniform(0.0, 1.0, size=field.shape)
+    field = 16.0 + field * 219.0
+    cuts = sorted(set(int(c) for c in scene_cuts))
+    frames = np.empty((n_frames, height, width), dtype=np.uint8 if bit_depth == 8 else np.uint16)
+    scale = 1 << (bit_depth - 8)
+    maxv = (1 << bit_depth) - 1
+    for i in range(n_frames):
+        dx, dy = (3 * i) % 256, (2 * i) % 128
+        img = field[dy:dy + height, dx:dx + width].copy()
+        inverted = sum(1 for c in cuts if c <= i) & 1
+        if inverted:
+            img = 255.0 - img
+        if fade is not None:
+            s, ln, g1, o1 = fade
+            t = min(max((i - s + 1) / float(ln), 0.0), 1.0)
+            img = img * (1.0 + (g1 - 1.0) * t) + o1 * t
+        img = img + rng.integers(-noise, noise + 1, size=img.shape)
+        img = np.clip(np.rint(img * scale), 0, maxv)
+        frames[i] = img.astype(frames.dtype)
+    return frames
