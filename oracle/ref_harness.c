@@ -431,3 +431,8 @@ RH_API void rh_luts( float *log2_lut, float *log2_lz_lut, uint8_t *exp2_lut )
     memcpy( log2_lz_lut, x264_log2_lz_lut, 32*sizeof(float) );
     memcpy( exp2_lut, x264_exp2_lut, 64 );
 }
+RH_API void rh_get_weight( rh_ctx *c, int idx, int *out )
+{
+    x264_weight_t *w = c->frames[idx]->weight[0];
+    out[0] = w[0].weightfn != NULL; out[1] = w[0].i_scale; out[2] = w[0].i_denom; out[3] = w[0].i_offset;
+}

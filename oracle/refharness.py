@@ -78,6 +78,12 @@ class Ref:
         self.lib.rh_weights_analyse(self.ctx, b, ref, _ptr(out))
         return tuple(int(x) for x in out)
 
+    def weight(self, idx):
+        out = np.zeros(4, np.int32)
+        self.lib.rh_get_weight.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self.lib.rh_get_weight(self.ctx, idx, _ptr(out))
+        return tuple(int(x) for x in out)
+
     def lowres_geometry(self):
         g = np.zeros(5, np.int32)
         self.lib.rh_lowres_geometry.argtypes = [C.c_void_p, C.c_void_p]

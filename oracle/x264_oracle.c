@@ -1,0 +1,1190 @@
+/* TEST INFRASTRUCTURE ONLY -- see x264_oracle.h.
+ *
+ * CPU restatement of the x264 lookahead / motion-estimation hot path.  Written from the behaviour of
+ * the reference (file:line cited per function, paths relative to /root/reference); compiled twice
+ * (-DOR_DEPTH=8 / 10).  Everything here is integer arithmetic except the AQ helper at the end.
+ */
+#include "x264_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#ifndef OR_DEPTH
+#define OR_DEPTH 8
+#endif
+#if OR_DEPTH == 8
+typedef uint8_t pixel;
+typedef int16_t dctcoef;
+typedef uint16_t udctcoef;
+#define ORN(x) or8_##x
+#else
+typedef uint16_t pixel;
+typedef int32_t dctcoef;
+typedef uint32_t udctcoef;
+#define ORN(x) or10_##x
+#endif
+#define PIXEL_MAX ((1 << OR_DEPTH) - 1)
+#define DEPTH_SHIFT (OR_DEPTH - 8)
+#define COST_MAX (1 << 28)
+
+static inline int clip3( int v, int lo, int hi ) { return v < lo ? lo : v > hi ? hi : v; }
+static inline pixel clip_pixel( int v ) { return (pixel)( v < 0 ? 0 : v > PIXEL_MAX ? PIXEL_MAX : v ); }
+static inline int imin( int a, int b ) { return a < b ? a : b; }
+static inline int imax( int a, int b ) { return a > b ? a : b; }
+static inline int median3( int a, int b, int c ) /* common/base.h:232-240 */
+{
+    int lo = imin( a, b ), hi = imax( a, b );
+    return imax( lo, imin( hi, c ) );
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * M1: half-resolution planes.  common/mc.c:458-507 (x264_frame_init_lowres + frame_init_lowres_core),
+ * common/frame.c:535-554,627-631 (border expansion), frame.c:640-666 (mod16 replication).
+ * ---------------------------------------------------------------------------------------------- */
+static inline int rnd_avg( int a, int b ) { return ( a + b + 1 ) >> 1; }
+
+void ORN(lowres_core)( const pixel *src, pixel *d0, pixel *dh, pixel *dv, pixel *dc,
+                       int src_stride, int dst_stride, int w, int h )
+{
+    for( int y = 0; y < h; y++ )
+    {
+        const pixel *r0 = src + 2*y*src_stride, *r1 = r0 + src_stride, *r2 = r1 + src_stride;
+        for( int x = 0; x < w; x++ )
+        {
+            int c00 = rnd_avg( r0[2*x],   r1[2*x]   ), c10 = rnd_avg( r0[2*x+1], r1[2*x+1] ), c20 = rnd_avg( r0[2*x+2], r1[2*x+2] );
+            int c01 = rnd_avg( r1[2*x],   r2[2*x]   ), c11 = rnd_avg( r1[2*x+1], r2[2*x+1] ), c21 = rnd_avg( r1[2*x+2], r2[2*x+2] );
+            d0[y*dst_stride+x] = (pixel)rnd_avg( c00, c10 );
+            dh[y*dst_stride+x] = (pixel)rnd_avg( c10, c20 );
+            dv[y*dst_stride+x] = (pixel)rnd_avg( c01, c11 );
+            dc[y*dst_stride+x] = (pixel)rnd_avg( c11, c21 );
+        }
+    }
+}
+
+/* src is the picture as handed to the encoder (width x height, not necessarily mod 16).  The
+ * reference first replicates the last column/row out to the mod16 size and then one more
+ * column/row (mc.c:466-468); both are the same as clamping the source coordinate. */
+void ORN(lowres_init)( const pixel *src, int src_stride, int width, int height, int mb_w, int mb_h,
+                       pixel *p0, pixel *ph, pixel *pv, pixel *pc, int stride )
+{
+    const int lw = 8*mb_w, lh = 8*mb_h;
+    pixel *planes[4] = { p0, ph, pv, pc };
+    for( int y = 0; y < lh; y++ )
+    {
+        const pixel *r[3];
+        for( int k = 0; k < 3; k++ )
+            r[k] = src + (size_t)imin( 2*y+k, height-1 ) * src_stride;
+        for( int x = 0; x < lw; x++ )
+        {
+            int x0 = imin( 2*x, width-1 ), x1 = imin( 2*x+1, width-1 ), x2 = imin( 2*x+2, width-1 );
+            int c00 = rnd_avg( r[0][x0], r[1][x0] ), c10 = rnd_avg( r[0][x1], r[1][x1] ), c20 = rnd_avg( r[0][x2], r[1][x2] );
+            int c01 = rnd_avg( r[1][x0], r[2][x0] ), c11 = rnd_avg( r[1][x1], r[2][x1] ), c21 = rnd_avg( r[1][x2], r[2][x2] );
+            p0[y*stride+x] = (pixel)rnd_avg( c00, c10 );
+            ph[y*stride+x] = (pixel)rnd_avg( c10, c20 );
+            pv[y*stride+x] = (pixel)rnd_avg( c01, c11 );
+            pc[y*stride+x] = (pixel)rnd_avg( c11, c21 );
+        }
+    }
+    for( int p = 0; p < 4; p++ )
+    {
+        pixel *pl = planes[p];
+        for( int y = 0; y < lh; y++ )
+            for( int k = 1; k <= OR_PAD; k++ )
+            {
+                pl[y*stride - k] = pl[y*stride];
+                pl[y*stride + lw - 1 + k] = pl[y*stride + lw - 1];
+            }
+        for( int k = 1; k <= OR_PAD; k++ )
+        {
+            memcpy( pl - k*stride - OR_PAD, pl - OR_PAD, (lw + 2*OR_PAD) * sizeof(pixel) );
+            memcpy( pl + (lh-1+k)*stride - OR_PAD, pl + (lh-1)*stride - OR_PAD, (lw + 2*OR_PAD) * sizeof(pixel) );
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * P1/P3/P4/P8: block metrics.  common/pixel.c:55-80 (sad), :85-151 (ssd), :265-332 (satd),
+ * :334-381 (sa8d), :183-201 (var).  The reference packs two 16/32-bit lanes per word; the results
+ * are the plain sums restated here (no lane overflows for the supported depths).
+ * ---------------------------------------------------------------------------------------------- */
+int ORN(sad)( const pixel *a, int sa, const pixel *b, int sb, int w, int h )
+{
+    int s = 0;
+    for( int y = 0; y < h; y++ )
+        for( int x = 0; x < w; x++ )
+            s += abs( a[y*sa+x] - b[y*sb+x] );
+    return s;
+}
+
+int ORN(ssd)( const pixel *a, int sa, const pixel *b, int sb, int w, int h )
+{
+    int s = 0;
+    for( int y = 0; y < h; y++ )
+        for( int x = 0; x < w; x++ )
+        {
+            int d = a[y*sa+x] - b[y*sb+x];
+            s += d*d;
+        }
+    return s;
+}
+
+static inline void hadamard4( int *v, int step )
+{
+    int s01 = v[0] + v[step], d01 = v[0] - v[step], s23 = v[2*step] + v[3*step], d23 = v[2*step] - v[3*step];
+    v[0] = s01 + s23; v[step] = d01 + d23; v[2*step] = s01 - s23; v[3*step] = d01 - d23;
+}
+
+static int hadamard_abs_4x4( const pixel *a, int sa, const pixel *b, int sb )
+{
+    int d[16], s = 0;
+    for( int y = 0; y < 4; y++ )
+        for( int x = 0; x < 4; x++ )
+            d[4*y+x] = a[y*sa+x] - b[y*sb+x];
+    for( int y = 0; y < 4; y++ ) hadamard4( d + 4*y, 1 );
+    for( int x = 0; x < 4; x++ ) hadamard4( d + x, 4 );
+    for( int i = 0; i < 16; i++ ) s += abs( d[i] );
+    return s;
+}
+
+/* satd of any WxH made of 4x4 tiles: sum over tiles of (sum |H4 D H4^T|), halved per 8x4 / 4x4 unit
+ * exactly as PIXEL_SATD_C composes x264_pixel_satd_8x4 / _4x4 (pixel.c:265-332). */
+int ORN(satd)( const pixel *a, int sa, const pixel *b, int sb, int w, int h )
+{
+    int total = 0;
+    if( w == 4 )
+    {
+        for( int y = 0; y < h; y += 4 )
+            total += hadamard_abs_4x4( a + y*sa, sa, b + y*sb, sb ) >> 1;
+        return total;
+    }
+    for( int y = 0; y < h; y += 4 )
+        for( int x = 0; x < w; x += 8 )
+            total += ( hadamard_abs_4x4( a + y*sa + x, sa, b + y*sb + x, sb )
+                     + hadamard_abs_4x4( a + y*sa + x + 4, sa, b + y*sb + x + 4, sb ) ) >> 1;
+    return total;
+}
+
+static int hadamard_abs_8x8( const pixel *a, int sa, const pixel *b, int sb )
+{
+    int d[64], s = 0;
+    for( int y = 0; y < 8; y++ )
+        for( int x = 0; x < 8; x++ )
+            d[8*y+x] = a[y*sa+x] - b[y*sb+x];
+    for( int pass = 0; pass < 2; pass++ )
+    {
+        int step = pass ? 8 : 1, line = pass ? 1 : 8;
+        for( int l = 0; l < 8; l++ )
+        {
+            int *v = d + l*line;
+            for( int span = 1; span < 8; span <<= 1 )
+                for( int i = 0; i < 8; i++ )
+                    if( !(i & span) )
+                    {
+                        int p = v[i*step], q = v[(i+span)*step];
+                        v[i*step] = p + q; v[(i+span)*step] = p - q;
+                    }
+        }
+    }
+    for( int i = 0; i < 64; i++ ) s += abs( d[i] );
+    return s;
+}
+
+int ORN(sa8d)( const pixel *a, int sa, const pixel *b, int sb, int w ) /* w = 8 or 16 (square) */
+{
+    int s = 0;
+    for( int y = 0; y < w; y += 8 )
+        for( int x = 0; x < w; x += 8 )
+            s += hadamard_abs_8x8( a + y*sa + x, sa, b + y*sb + x, sb );
+    return ( s + 2 ) >> 2;
+}
+
+uint64_t ORN(var)( const pixel *a, int sa, int w, int h )
+{
+    uint32_t sum = 0, sqr = 0;
+    for( int y = 0; y < h; y++ )
+        for( int x = 0; x < w; x++ )
+        {
+            sum += a[y*sa+x];
+            sqr += a[y*sa+x] * a[y*sa+x];
+        }
+    return sum + ( (uint64_t)sqr << 32 );
+}
+
+static inline int mbcmp8x8( const or_la_cfg *c, const pixel *a, int sa, const pixel *b, int sb )
+{
+    return c->mbcmp_satd ? ORN(satd)( a, sa, b, sb, 8, 8 ) : ORN(sad)( a, sa, b, sb, 8, 8 );
+}
+static inline int fpelcmp8x8( const or_la_cfg *c, const pixel *a, int sa, const pixel *b, int sb )
+{
+    return c->fpelcmp_satd ? ORN(satd)( a, sa, b, sb, 8, 8 ) : ORN(sad)( a, sa, b, sb, 8, 8 );
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * P6/P7: intra predictors used by the lowres intra cost.  common/predict.c:221-308 (8x8 chroma
+ * dc/h/v/plane), :632-675 (edge low-pass, all neighbours available), :741-884 (modes 3..8).
+ * src points at pixel (0,0) of an OR_FDEC_STRIDE buffer whose row -1 (x = -1..15) and column -1
+ * hold the neighbours.  Written per output pixel, following H.264 8.3.2.2 / 8.3.4.
+ * ---------------------------------------------------------------------------------------------- */
+#define S(x,y) src[(y)*OR_FDEC_STRIDE+(x)]
+enum { PRED8C_DC = 0, PRED8C_H = 1, PRED8C_V = 2, PRED8C_P = 3 };
+
+void ORN(predict_8x8c)( int mode, pixel *src )
+{
+    if( mode == PRED8C_DC )
+    {
+        int t0 = 0, t1 = 0, l0 = 0, l1 = 0;
+        for( int i = 0; i < 4; i++ )
+        {
+            t0 += S(i,-1); t1 += S(i+4,-1); l0 += S(-1,i); l1 += S(-1,i+4);
+        }
+        int dc[2][2] = { { (t0+l0+4)>>3, (t1+2)>>2 }, { (l1+2)>>2, (t1+l1+4)>>3 } };
+        for( int y = 0; y < 8; y++ )
+            for( int x = 0; x < 8; x++ )
+                S(x,y) = (pixel)dc[y>>2][x>>2];
+    }
+    else if( mode == PRED8C_H )
+    {
+        for( int y = 0; y < 8; y++ )
+            for( int x = 0; x < 8; x++ )
+                S(x,y) = S(-1,y);
+    }
+    else if( mode == PRED8C_V )
+    {
+        for( int y = 0; y < 8; y++ )
+            for( int x = 0; x < 8; x++ )
+                S(x,y) = S(x,-1);
+    }
+    else
+    {
+        int H = 0, V = 0;
+        for( int i = 1; i <= 4; i++ )
+        {
+            H += i * ( S(3+i,-1) - S(3-i,-1) );
+            V += i * ( S(-1,3+i) - S(-1,3-i) );
+        }
+        int a = 16 * ( S(-1,7) + S(7,-1) ), b = ( 17*H + 16 ) >> 5, cc = ( 17*V + 16 ) >> 5;
+        for( int y = 0; y < 8; y++ )
+            for( int x = 0; x < 8; x++ )
+                S(x,y) = clip_pixel( ( a + b*(x-3) + cc*(y-3) + 16 ) >> 5 );
+    }
+}
+
+/* edge layout of the reference: edge[14-y] = left y (y=0..7), edge[15] = top-left, edge[16+x] = top x
+ * (x=0..15), edge[32] = edge[31]; edge[6] = edge[7]. */
+void ORN(predict_8x8_filter)( const pixel *src, pixel *edge )
+{
+#define F3(a,b,c) ( ( (a) + 2*(b) + (c) + 2 ) >> 2 )
+    edge[15] = (pixel)F3( S(0,-1), S(-1,-1), S(-1,0) );
+    for( int y = 0; y < 7; y++ )
+        edge[14-y] = (pixel)F3( S(-1,y-1), S(-1,y), S(-1,y+1) );
+    edge[7] = edge[6] = (pixel)( ( S(-1,6) + 3*S(-1,7) + 2 ) >> 2 );
+    for( int x = 0; x < 15; x++ )
+        edge[16+x] = (pixel)F3( S(x-1,-1), S(x,-1), S(x+1,-1) );
+    edge[31] = edge[32] = (pixel)( ( S(14,-1) + 3*S(15,-1) + 2 ) >> 2 );
+}
+
+void ORN(predict_8x8)( int mode, pixel *src, const pixel *edge )
+{
+    /* T(i): filtered top sample i (i = -1 is the corner), L(i): filtered left sample i */
+#define T(i) ( (i) < 0 ? edge[15] : edge[16+(i)] )
+#define L(i) ( (i) < 0 ? edge[15] : edge[14-(i)] )
+#define F2(a,b) ( ( (a) + (b) + 1 ) >> 1 )
+    for( int y = 0; y < 8; y++ )
+        for( int x = 0; x < 8; x++ )
+        {
+            int v;
+            switch( mode )
+            {
+                case 3: /* diagonal down-left */
+                    v = ( x == 7 && y == 7 ) ? ( T(14) + 3*T(15) + 2 ) >> 2 : F3( T(x+y), T(x+y+1), T(x+y+2) );
+                    break;
+                case 4: /* diagonal down-right */
+                    if( x > y )       v = F3( T(x-y-2), T(x-y-1), T(x-y) );
+                    else if( x < y )  v = F3( L(y-x-2), L(y-x-1), L(y-x) );
+                    else              v = F3( T(0), T(-1), L(0) );
+                    break;
+                case 5: /* vertical right */
+                {
+                    int z = 2*x - y;
+                    if( z >= 0 && !(z & 1) )  v = F2( T(x-(y>>1)-1), T(x-(y>>1)) );
+                    else if( z >= 0 )         v = F3( T(x-(y>>1)-2), T(x-(y>>1)-1), T(x-(y>>1)) );
+                    else if( z == -1 )        v = F3( L(0), T(-1), T(0) );
+                    else                      v = F3( L(y-2*x-1), L(y-2*x-2), L(y-2*x-3) );
+                    break;
+                }
+                case 6: /* horizontal down */
+                {
+                    int z = 2*y - x;
+                    if( z >= 0 && !(z & 1) )  v = F2( L(y-(x>>1)-1), L(y-(x>>1)) );
+                    else if( z >= 0 )         v = F3( L(y-(x>>1)-2), L(y-(x>>1)-1), L(y-(x>>1)) );
+                    else if( z == -1 )        v = F3( L(0), T(-1), T(0) );
+                    else                      v = F3( T(x-2*y-1), T(x-2*y-2), T(x-2*y-3) );
+                    break;
+                }
+                case 7: /* vertical left */
+                    v = ( y & 1 ) ? F3( T(x+(y>>1)), T(x+(y>>1)+1), T(x+(y>>1)+2) ) : F2( T(x+(y>>1)), T(x+(y>>1)+1) );
+                    break;
+                default: /* 8: horizontal up */
+                {
+                    int z = x + 2*y;
+                    if( z > 13 )          v = L(7);
+                    else if( z == 13 )    v = ( L(6) + 3*L(7) + 2 ) >> 2;
+                    else if( z & 1 )      v = F3( L(y+(x>>1)), L(y+(x>>1)+1), L(y+(x>>1)+2) );
+                    else                  v = F2( L(y+(x>>1)), L(y+(x>>1)+1) );
+                    break;
+                }
+            }
+            S(x,y) = (pixel)v;
+        }
+#undef T
+#undef L
+}
+
+/* res order dc, h, v (pixel.c:542-556 INTRA_MBCMP 8x8 chroma) */
+void ORN(intra_x3_8x8c)( int satd, const pixel *fenc, pixel *fdec, int res[3] )
+{
+    for( int m = 0; m < 3; m++ )
+    {
+        ORN(predict_8x8c)( m, fdec );
+        res[m] = satd ? ORN(satd)( fdec, OR_FDEC_STRIDE, fenc, OR_FENC_STRIDE, 8, 8 )
+                      : ORN(sad)( fdec, OR_FDEC_STRIDE, fenc, OR_FENC_STRIDE, 8, 8 );
+    }
+}
+#undef S
+
+/* ------------------------------------------------------------------------------------------------
+ * M2-M4: quarter-pel fetch from the four half-pel planes, averaging, explicit weights.
+ * common/mc.c:198-249 (mc_luma/get_ref), :49-111 (avg), :117-160 (mc_weight),
+ * common/tables.c:183-184 (which two planes a quarter-pel phase averages).
+ * ---------------------------------------------------------------------------------------------- */
+static inline int apply_weight( int v, const or_weight *wt )
+{
+    int off = wt->offset * ( 1 << DEPTH_SHIFT );
+    if( wt->denom >= 1 )
+        return clip_pixel( ( ( v * wt->scale + ( 1 << ( wt->denom - 1 ) ) ) >> wt->denom ) + off );
+    return clip_pixel( v * wt->scale + off );
+}
+
+/* One interpolated sample at lowres integer position (x,y) displaced by quarter-pel (mvx,mvy).
+ * Phase (fx,fy): first tap from plane (fx?H:0)+(fy==2?V:0) one row lower when fy==3; second tap
+ * from plane (fx==2?H:0)+(fy?V:0) one column further when fx==3; taps equal when fx,fy are even. */
+static inline int qpel_sample( const pixel *const planes[4], int stride, int x, int y, int mvx, int mvy, const or_weight *wt )
+{
+    int fx = mvx & 3, fy = mvy & 3;
+    int ix = x + ( mvx >> 2 ), iy = y + ( mvy >> 2 );
+    int pa = ( fx ? 1 : 0 ) + ( fy == 2 ? 2 : 0 );
+    int v = planes[pa][( iy + ( fy == 3 ) ) * stride + ix];
+    if( ( fx | fy ) & 1 )
+    {
+        int pb = ( fx == 2 ? 1 : 0 ) + ( fy ? 2 : 0 );
+        v = rnd_avg( v, planes[pb][iy * stride + ix + ( fx == 3 )] );
+    }
+    return wt && wt->on ? apply_weight( v, wt ) : v;
+}
+
+void ORN(mc_luma)( pixel *dst, int ds, const pixel *const planes[4], int stride, int mvx, int mvy, int w, int h, const or_weight *wt )
+{
+    for( int y = 0; y < h; y++ )
+        for( int x = 0; x < w; x++ )
+            dst[y*ds+x] = (pixel)qpel_sample( planes, stride, x, y, mvx, mvy, wt );
+}
+
+void ORN(avg)( pixel *dst, int ds, const pixel *a, int sa, const pixel *b, int sb, int w, int h, int weight )
+{
+    for( int y = 0; y < h; y++ )
+        for( int x = 0; x < w; x++ )
+            dst[y*ds+x] = weight == 32 ? (pixel)rnd_avg( a[y*sa+x], b[y*sb+x] )
+                                       : clip_pixel( ( a[y*sa+x]*weight + b[y*sb+x]*(64-weight) + 32 ) >> 6 );
+}
+
+/* whole padded plane 0 weighted: slicetype.c:490-500 + frame.c:825-841 */
+void ORN(weight_plane)( pixel *dst, const pixel *src, int stride, int width, int lines, const or_weight *wt )
+{
+    for( int y = -OR_PAD; y < lines + OR_PAD; y++ )
+        for( int x = -OR_PAD; x < width + OR_PAD; x++ )
+            dst[y*stride+x] = (pixel)apply_weight( src[y*stride+x], wt );
+}
+
+/* weight_cost_luma without the slice-header term: slicetype.c:191-222 */
+unsigned ORN(weight_cost)( const or_la_cfg *c, const pixel *fenc0, const pixel *ref0, const or_weight *wt, const uint16_t *intra_cost )
+{
+    unsigned cost = 0;
+    pixel buf[64];
+    for( int by = 0; by < c->mb_h; by++ )
+        for( int bx = 0; bx < c->mb_w; bx++ )
+        {
+            const pixel *r = ref0 + 8*( by*c->stride + bx ), *f = fenc0 + 8*( by*c->stride + bx );
+            int cmp;
+            if( wt && wt->on )
+            {
+                for( int i = 0; i < 64; i++ )
+                    buf[i] = (pixel)apply_weight( r[(i>>3)*c->stride + (i&7)], wt );
+                cmp = mbcmp8x8( c, buf, 8, f, c->stride );
+            }
+            else
+                cmp = mbcmp8x8( c, r, c->stride, f, c->stride );
+            cost += imin( cmp, intra_cost[by*c->mb_w+bx] );
+        }
+    return cost;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * D1/Q1: forward transforms and quantisers as vtable primitives.  common/dct.c:47-270,332-386,
+ * common/quant.c:50-104.  fenc stride 16, fdec stride 32.  Coefficient (u,v) (u horizontal
+ * frequency) of a 4x4/8x8 block lands at out[u*N+v], the reference's transposed order.
+ * ---------------------------------------------------------------------------------------------- */
+static void fdct4_1d( const int *in, int step, int *out, int ostep )
+{
+    int s03 = in[0] + in[3*step], s12 = in[step] + in[2*step], d03 = in[0] - in[3*step], d12 = in[step] - in[2*step];
+    out[0] = s03 + s12; out[ostep] = 2*d03 + d12; out[2*ostep] = s03 - s12; out[3*ostep] = d03 - 2*d12;
+}
+
+static void sub_dct4( dctcoef *out, const pixel *fenc, const pixel *fdec )
+{
+    int d[16], t[16], o[16];
+    for( int y = 0; y < 4; y++ )
+        for( int x = 0; x < 4; x++ )
+            d[4*y+x] = fenc[y*OR_FENC_STRIDE+x] - fdec[y*OR_FDEC_STRIDE+x];
+    for( int y = 0; y < 4; y++ ) fdct4_1d( d + 4*y, 1, t + y, 4 );   /* t[u*4+y] */
+    for( int u = 0; u < 4; u++ ) fdct4_1d( t + 4*u, 1, o + 4*u, 1 ); /* o[u*4+v] */
+    for( int i = 0; i < 16; i++ ) out[i] = (dctcoef)o[i];
+}
+
+static void fdct8_1d( const int *in, int step, int *out, int ostep )
+{
+    int s07 = in[0] + in[7*step], s16 = in[step] + in[6*step], s25 = in[2*step] + in[5*step], s34 = in[3*step] + in[4*step];
+    int d07 = in[0] - in[7*step], d16 = in[step] - in[6*step], d25 = in[2*step] - in[5*step], d34 = in[3*step] - in[4*step];
+    int e0 = s07 + s34, e1 = s16 + s25, e2 = s07 - s34, e3 = s16 - s25;
+    int o4 = d16 + d25 + ( d07 + ( d07 >> 1 ) );
+    int o5 = d07 - d34 - ( d25 + ( d25 >> 1 ) );
+    int o6 = d07 + d34 - ( d16 + ( d16 >> 1 ) );
+    int o7 = d16 - d25 + ( d34 + ( d34 >> 1 ) );
+    out[0] = e0 + e1;           out[ostep]   = o4 + ( o7 >> 2 );
+    out[2*ostep] = e2 + ( e3 >> 1 ); out[3*ostep] = o5 + ( o6 >> 2 );
+    out[4*ostep] = e0 - e1;     out[5*ostep] = o6 - ( o5 >> 2 );
+    out[6*ostep] = ( e2 >> 1 ) - e3; out[7*ostep] = ( o4 >> 2 ) - o7;
+}
+
+static void sub_dct8( dctcoef *out, const pixel *fenc, const pixel *fdec )
+{
+    int d[64], t[64], o[64];
+    for( int y = 0; y < 8; y++ )
+        for( int x = 0; x < 8; x++ )
+            d[8*y+x] = fenc[y*OR_FENC_STRIDE+x] - fdec[y*OR_FDEC_STRIDE+x];
+    /* the reference's first pass runs down the columns (dct.c:364-369), then along the rows */
+    for( int x = 0; x < 8; x++ ) fdct8_1d( d + x, 8, t + x, 8 );        /* t[v*8+x] */
+    for( int v = 0; v < 8; v++ ) fdct8_1d( t + 8*v, 1, o + v, 8 );      /* o[u*8+v] */
+    for( int i = 0; i < 64; i++ ) out[i] = (dctcoef)o[i];
+}
+
+static int dc_sum4( const pixel *fenc, const pixel *fdec )
+{
+    int s = 0;
+    for( int y = 0; y < 4; y++ )
+        for( int x = 0; x < 4; x++ )
+            s += fenc[y*OR_FENC_STRIDE+x] - fdec[y*OR_FDEC_STRIDE+x];
+    return s;
+}
+
+void ORN(dct)( int kind, dctcoef *out, const pixel *fenc, const pixel *fdec )
+{
+    switch( kind )
+    {
+        case 0: sub_dct4( out, fenc, fdec ); break;
+        case 1:
+            for( int i = 0; i < 4; i++ )
+                sub_dct4( out + 16*i, fenc + 4*(i&1) + 4*(i>>1)*OR_FENC_STRIDE, fdec + 4*(i&1) + 4*(i>>1)*OR_FDEC_STRIDE );
+            break;
+        case 2:
+            for( int j = 0; j < 4; j++ )
+                for( int i = 0; i < 4; i++ )
+                    sub_dct4( out + 64*j + 16*i,
+                              fenc + 8*(j&1) + 8*(j>>1)*OR_FENC_STRIDE + 4*(i&1) + 4*(i>>1)*OR_FENC_STRIDE,
+                              fdec + 8*(j&1) + 8*(j>>1)*OR_FDEC_STRIDE + 4*(i&1) + 4*(i>>1)*OR_FDEC_STRIDE );
+            break;
+        case 3: sub_dct8( out, fenc, fdec ); break;
+        case 4:
+            for( int j = 0; j < 4; j++ )
+                sub_dct8( out + 64*j, fenc + 8*(j&1) + 8*(j>>1)*OR_FENC_STRIDE, fdec + 8*(j&1) + 8*(j>>1)*OR_FDEC_STRIDE );
+            break;
+        case 5: /* sub8x8_dct_dc: 2x2 Hadamard of the four 4x4 DC sums */
+        {
+            int s[4];
+            for( int i = 0; i < 4; i++ )
+                s[i] = dc_sum4( fenc + 4*(i&1) + 4*(i>>1)*OR_FENC_STRIDE, fdec + 4*(i&1) + 4*(i>>1)*OR_FDEC_STRIDE );
+            out[0] = (dctcoef)( s[0]+s[1]+s[2]+s[3] ); out[1] = (dctcoef)( s[0]+s[1]-s[2]-s[3] );
+            out[2] = (dctcoef)( s[0]-s[1]+s[2]-s[3] ); out[3] = (dctcoef)( s[0]-s[1]-s[2]+s[3] );
+            break;
+        }
+        case 6: /* sub8x16_dct_dc: 2x4 transform of eight 4x4 DC sums (dct.c:231-270) */
+        {
+            int a[8], h0[4], h1[4];
+            for( int i = 0; i < 8; i++ )
+                a[i] = dc_sum4( fenc + 4*(i&1) + 4*(i>>1)*OR_FENC_STRIDE, fdec + 4*(i&1) + 4*(i>>1)*OR_FDEC_STRIDE );
+            for( int r = 0; r < 4; r++ ) { h0[r] = a[2*r] + a[2*r+1]; h1[r] = a[2*r] - a[2*r+1]; }
+            int p0 = h0[0]+h0[1], p1 = h0[2]+h0[3], p2 = h1[0]+h1[1], p3 = h1[2]+h1[3];
+            int q0 = h0[0]-h0[1], q1 = h0[2]-h0[3], q2 = h1[0]-h1[1], q3 = h1[2]-h1[3];
+            out[0] = (dctcoef)( p0+p1 ); out[1] = (dctcoef)( p2+p3 ); out[2] = (dctcoef)( p0-p1 ); out[3] = (dctcoef)( p2-p3 );
+            out[4] = (dctcoef)( q0-q1 ); out[5] = (dctcoef)( q2-q3 ); out[6] = (dctcoef)( q0+q1 ); out[7] = (dctcoef)( q2+q3 );
+            break;
+        }
+        case 7: /* dct4x4dc in place on out (dct.c:47-77): 4x4 Hadamard, (x+1)>>1 */
+        {
+            int d[16];
+            for( int i = 0; i < 16; i++ ) d[i] = out[i];
+            int t[16];
+            for( int i = 0; i < 4; i++ )
+            {
+                int s01 = d[4*i] + d[4*i+1], d01 = d[4*i] - d[4*i+1], s23 = d[4*i+2] + d[4*i+3], d23 = d[4*i+2] - d[4*i+3];
+                t[i] = s01 + s23; t[4+i] = s01 - s23; t[8+i] = d01 - d23; t[12+i] = d01 + d23;
+            }
+            for( int i = 0; i < 4; i++ )
+            {
+                int s01 = t[4*i] + t[4*i+1], d01 = t[4*i] - t[4*i+1], s23 = t[4*i+2] + t[4*i+3], d23 = t[4*i+2] - t[4*i+3];
+                out[4*i]   = (dctcoef)( ( s01 + s23 + 1 ) >> 1 ); out[4*i+1] = (dctcoef)( ( s01 - s23 + 1 ) >> 1 );
+                out[4*i+2] = (dctcoef)( ( d01 - d23 + 1 ) >> 1 ); out[4*i+3] = (dctcoef)( ( d01 + d23 + 1 ) >> 1 );
+            }
+            break;
+        }
+    }
+}
+
+static inline int quant_one( dctcoef *coef, uint32_t mf, uint32_t bias )
+{
+    int v = *coef;
+    if( v > 0 )
+        v = (int)( ( bias + (uint32_t)v ) * mf >> 16 );
+    else
+        v = -(int32_t)( ( bias + (uint32_t)( -v ) ) * mf >> 16 );
+    *coef = (dctcoef)v;
+    return *coef;
+}
+
+/* kind: 0 quant_4x4, 1 quant_8x8, 2 quant_4x4x4, 3 quant_4x4_dc, 4 quant_2x2_dc */
+int ORN(quant)( int kind, dctcoef *coef, const udctcoef *mf, const udctcoef *bias, int mf_dc, int bias_dc )
+{
+    int nz = 0;
+    switch( kind )
+    {
+        case 0: for( int i = 0; i < 16; i++ ) nz |= quant_one( coef+i, mf[i], bias[i] ); return !!nz;
+        case 1: for( int i = 0; i < 64; i++ ) nz |= quant_one( coef+i, mf[i], bias[i] ); return !!nz;
+        case 2:
+        {
+            int mask = 0;
+            for( int j = 0; j < 4; j++ )
+            {
+                nz = 0;
+                for( int i = 0; i < 16; i++ ) nz |= quant_one( coef+16*j+i, mf[i], bias[i] );
+                mask |= ( !!nz ) << j;
+            }
+            return mask;
+        }
+        case 3: for( int i = 0; i < 16; i++ ) nz |= quant_one( coef+i, (uint32_t)mf_dc, (uint32_t)bias_dc ); return !!nz;
+        case 4: for( int i = 0; i < 4; i++ )  nz |= quant_one( coef+i, (uint32_t)mf_dc, (uint32_t)bias_dc ); return !!nz;
+    }
+    return -1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * S2 (intra part): lowres intra cost of one 8x8 block.  encoder/slicetype.c:714-757.
+ * ---------------------------------------------------------------------------------------------- */
+static int intra_cost_block( const or_la_cfg *c, const pixel *fenc0, int bx, int by )
+{
+    pixel fenc[8*OR_FENC_STRIDE];
+    pixel nb[9*OR_FDEC_STRIDE + 8];
+    pixel edge[36];
+    pixel *pix = nb + 8 + OR_FDEC_STRIDE;
+    const pixel *src = fenc0 + 8*( by*c->stride + bx );
+    for( int y = 0; y < 8; y++ )
+        memcpy( fenc + y*OR_FENC_STRIDE, src + y*c->stride, 8*sizeof(pixel) );
+    for( int x = -1; x < 16; x++ )
+        pix[-OR_FDEC_STRIDE + x] = src[-c->stride + x];
+    for( int y = 0; y < 8; y++ )
+        pix[y*OR_FDEC_STRIDE - 1] = src[y*c->stride - 1];
+
+    int res[3];
+    /* predict_8x8_filter reads the unfiltered neighbours: take it before predictors overwrite pix */
+    if( c->subme > 1 )
+        ORN(predict_8x8_filter)( pix, edge );
+    ORN(intra_x3_8x8c)( c->mbcmp_satd, fenc, pix, res );
+    int best = imin( res[0], imin( res[1], res[2] ) );
+    if( c->subme > 1 )
+    {
+        ORN(predict_8x8c)( PRED8C_P, pix );
+        best = imin( best, mbcmp8x8( c, fenc, OR_FENC_STRIDE, pix, OR_FDEC_STRIDE ) );
+        for( int m = 3; m < 9; m++ )
+        {
+            ORN(predict_8x8)( m, pix, edge );
+            best = imin( best, mbcmp8x8( c, fenc, OR_FENC_STRIDE, pix, OR_FDEC_STRIDE ) );
+        }
+    }
+    return ( ( best + 5*c->lambda ) >> DEPTH_SHIFT ) + 4;
+}
+
+void ORN(intra_costs)( const or_la_cfg *c, const pixel *fenc0, uint16_t *intra_cost )
+{
+    for( int by = 0; by < c->mb_h; by++ )
+        for( int bx = 0; bx < c->mb_w; bx++ )
+            intra_cost[by*c->mb_w+bx] = (uint16_t)intra_cost_block( c, fenc0, bx, by );
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * S3: motion search of one 8x8 lowres block.  encoder/me.c:182-420,774-798 (x264_me_search_ref,
+ * DIA and HEX branches) and :865-992 (refine_subpel), with the predictor helpers of
+ * common/common.h:774-805.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct
+{
+    const or_la_cfg *c;
+    const pixel *fenc;          /* 8x8 block, stride OR_FENC_STRIDE */
+    const pixel *ref[4];        /* hpel planes at the block origin */
+    const pixel *ref_w;         /* weighted full-pel plane at the block origin (== ref[0] if unweighted) */
+    const or_weight *wt;
+    int stride;
+    int mvp[2];
+    int spel_min[2], spel_max[2], fpel_min[2], fpel_max[2];
+    /* results */
+    int mv[2], cost;
+} me_ctx;
+
+static inline int mv_bits( const me_ctx *m, int qx, int qy ) /* qpel units */
+{
+    return m->c->cost_mv[qx - m->mvp[0]] + m->c->cost_mv[qy - m->mvp[1]];
+}
+static inline int fpel_cost( const me_ctx *m, int fx, int fy ) /* COST_MV, me.c:63-70 */
+{
+    return fpelcmp8x8( m->c, m->fenc, OR_FENC_STRIDE, m->ref_w + fy*m->stride + fx, m->stride ) + mv_bits( m, 4*fx, 4*fy );
+}
+static inline void fetch_block( const me_ctx *m, pixel *dst, int qx, int qy )
+{
+    ORN(mc_luma)( dst, 8, m->ref, m->stride, qx, qy, 8, 8, m->wt );
+}
+static inline int qpel_cost_sad( const me_ctx *m, int qx, int qy ) /* COST_MV_HPEL / COST_MV_SAD */
+{
+    pixel blk[64];
+    fetch_block( m, blk, qx, qy );
+    return fpelcmp8x8( m->c, m->fenc, OR_FENC_STRIDE, blk, 8 ) + mv_bits( m, qx, qy );
+}
+static inline int qpel_cost_satd( const me_ctx *m, int qx, int qy ) /* COST_MV_SATD (mbcmp) */
+{
+    pixel blk[64];
+    fetch_block( m, blk, qx, qy );
+    return mbcmp8x8( m->c, m->fenc, OR_FENC_STRIDE, blk, 8 ) + mv_bits( m, qx, qy );
+}
+static inline int in_fpel_range( const me_ctx *m, int fx, int fy ) /* CHECK_MVRANGE, me.c:204-209 */
+{
+    return fx >= m->fpel_min[0] && fx <= m->fpel_max[0] && fy >= m->fpel_min[1] && fy <= m->fpel_max[1];
+}
+
+static void refine_subpel( me_ctx *m, int hpel_iters, int qpel_iters );
+
+static void me_search( me_ctx *m, const int16_t (*mvc)[2], int n_mvc )
+{
+    const or_la_cfg *c = m->c;
+    int bmx, bmy, bcost;
+    int bpred_cost = COST_MAX, bpred_mx = 0, bpred_my = 0;
+    int pmv_x, pmv_y; /* the "pmv" the reference packs: qpel (subme>=3) or fullpel */
+    int cand[8][2], n_cand;
+
+    if( c->subpel_refine >= 3 )
+    {
+        /* predictor tested at quarter-pel precision (me.c:216-275) */
+        bpred_mx = clip3( m->mvp[0], 4*m->fpel_min[0], 4*m->fpel_max[0] );
+        bpred_my = clip3( m->mvp[1], 4*m->fpel_min[1], 4*m->fpel_max[1] );
+        pmv_x = bpred_mx; pmv_y = bpred_my;
+        bpred_cost = qpel_cost_sad( m, bpred_mx, bpred_my );
+        int pmv_cost = bpred_cost;
+        n_cand = 0;
+        for( int i = 0; i < n_mvc; i++ )
+        {
+            int mx = mvc[i][0], my = mvc[i][1];
+            if( ( !mx && !my ) || ( mx == pmv_x && my == pmv_y ) )
+                continue;
+            cand[n_cand][0] = clip3( mx, 4*m->fpel_min[0], 4*m->fpel_max[0] );
+            cand[n_cand][1] = clip3( my, 4*m->fpel_min[1], 4*m->fpel_max[1] );
+            n_cand++;
+        }
+        for( int i = 0; i < n_cand; i++ ) /* first strictly-lower candidate wins; pmv wins ties */
+        {
+            int cost = qpel_cost_sad( m, cand[i][0], cand[i][1] );
+            if( cost < bpred_cost )
+            {
+                bpred_cost = cost; bpred_mx = cand[i][0]; bpred_my = cand[i][1];
+            }
+        }
+        bmx = ( bpred_mx + 2 ) >> 2;
+        bmy = ( bpred_my + 2 ) >> 2;
+        if( ( bpred_mx | bpred_my ) & 3 )
+        {
+            bcost = COST_MAX;
+            int cost = fpel_cost( m, bmx, bmy );
+            if( cost < bcost ) bcost = cost;
+        }
+        else
+            bcost = bpred_cost;
+        if( pmv_x | pmv_y )
+        {
+            if( bmx | bmy )
+            {
+                int cost = fpel_cost( m, 0, 0 );
+                if( cost < bcost ) { bcost = cost; bmx = 0; bmy = 0; }
+            }
+        }
+        else if( pmv_cost < bcost )
+        {
+            bcost = pmv_cost; bmx = 0; bmy = 0;
+        }
+    }
+    else
+    {
+        /* predictor rounded to full-pel (me.c:276-318) */
+        bmx = clip3( ( m->mvp[0] + 2 ) >> 2, m->fpel_min[0], m->fpel_max[0] );
+        bmy = clip3( ( m->mvp[1] + 2 ) >> 2, m->fpel_min[1], m->fpel_max[1] );
+        pmv_x = bmx; pmv_y = bmy;
+        bcost = fpelcmp8x8( c, m->fenc, OR_FENC_STRIDE, m->ref_w + bmy*m->stride + bmx, m->stride ); /* no mv bits */
+        n_cand = 0;
+        for( int i = 0; i < n_mvc; i++ )
+        {
+            int mx = ( mvc[i][0] + 2 ) >> 2, my = ( mvc[i][1] + 2 ) >> 2;
+            if( ( !mx && !my ) || ( mx == pmv_x && my == pmv_y ) )
+                continue;
+            cand[n_cand][0] = clip3( mx, m->fpel_min[0], m->fpel_max[0] );
+            cand[n_cand][1] = clip3( my, m->fpel_min[1], m->fpel_max[1] );
+            n_cand++;
+        }
+        for( int i = 0; i < n_cand; i++ )
+        {
+            int cost = fpel_cost( m, cand[i][0], cand[i][1] );
+            if( cost < bcost ) { bcost = cost; bmx = cand[i][0]; bmy = cand[i][1]; }
+        }
+        if( pmv_x | pmv_y )
+        {
+            int cost = fpel_cost( m, 0, 0 );
+            if( cost < bcost ) { bcost = cost; bmx = 0; bmy = 0; }
+        }
+    }
+
+    if( c->me_method == OR_ME_DIA )
+    {
+        /* radius-1 diamond, candidates in order up, down, left, right; earliest wins ties (me.c:322-342) */
+        static const int dia[4][2] = { {0,-1}, {0,1}, {-1,0}, {1,0} };
+        int iters = c->me_range;
+        do
+        {
+            int best = -1;
+            for( int k = 0; k < 4; k++ )
+            {
+                int cost = fpel_cost( m, bmx + dia[k][0], bmy + dia[k][1] );
+                if( cost < bcost ) { bcost = cost; best = k; }
+            }
+            if( best < 0 )
+                break;
+            bmx += dia[best][0]; bmy += dia[best][1];
+        } while( --iters && in_fpel_range( m, bmx, bmy ) );
+    }
+    else
+    {
+        /* hexagon (me.c:344-420): full hexagon once, then half hexagons in the direction of travel,
+         * finally the 8-neighbour square. */
+        static const int hex[6][2] = { {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2} };
+        int dir = -1;
+        for( int k = 0; k < 6; k++ )
+        {
+            int cost = fpel_cost( m, bmx + hex[k][0], bmy + hex[k][1] );
+            if( cost < bcost ) { bcost = cost; dir = k; }
+        }
+        if( dir >= 0 )
+        {
+            bmx += hex[dir][0]; bmy += hex[dir][1];
+            for( int i = ( c->me_range >> 1 ) - 1; i > 0 && in_fpel_range( m, bmx, bmy ); i-- )
+            {
+                int best = -2;
+                for( int k = -1; k <= 1; k++ )
+                {
+                    int d = ( dir + k + 6 ) % 6;
+                    int cost = fpel_cost( m, bmx + hex[d][0], bmy + hex[d][1] );
+                    if( cost < bcost ) { bcost = cost; best = k; }
+                }
+                if( best == -2 )
+                    break;
+                dir = ( dir + best + 6 ) % 6;
+                bmx += hex[dir][0]; bmy += hex[dir][1];
+            }
+        }
+        static const int sq[8][2] = { {0,-1}, {0,1}, {-1,0}, {1,0}, {-1,-1}, {-1,1}, {1,-1}, {1,1} };
+        int best = -1;
+        for( int k = 0; k < 8; k++ )
+        {
+            int cost = fpel_cost( m, bmx + sq[k][0], bmy + sq[k][1] );
+            if( cost < bcost ) { bcost = cost; best = k; }
+        }
+        if( best >= 0 ) { bmx += sq[best][0]; bmy += sq[best][1]; }
+    }
+
+    /* back to quarter-pel (me.c:774-789) */
+    if( c->subpel_refine < 3 )
+    {
+        m->cost = bcost;
+        if( bmx == pmv_x && bmy == pmv_y )
+            m->cost += mv_bits( m, 4*bmx, 4*bmy );
+        m->mv[0] = 4*bmx; m->mv[1] = 4*bmy;
+    }
+    else if( bpred_cost < bcost )
+    {
+        m->mv[0] = bpred_mx; m->mv[1] = bpred_my; m->cost = bpred_cost;
+    }
+    else
+    {
+        m->mv[0] = 4*bmx; m->mv[1] = 4*bmy; m->cost = bcost;
+    }
+
+    if( c->subpel_refine >= 2 )
+    {
+        /* subpel_iterations[i_subpel_refine][2..3], me.c:38-50: refine 2 -> {1,0}, 4 -> {1,1}...
+         * the lookahead only ever uses rows 2 and 4. */
+        static const int iters[5][2] = { {0,0}, {0,0}, {1,0}, {1,0}, {1,1} };
+        /* NOTE rows: {me_hpel, me_qpel} = subpel_iterations[r][2], [r][3] */
+        refine_subpel( m, iters[c->subpel_refine][0], iters[c->subpel_refine][1] );
+    }
+}
+
+static void refine_subpel( me_ctx *m, int hpel_iters, int qpel_iters )
+{
+    const or_la_cfg *c = m->c;
+    int bmx = m->mv[0], bmy = m->mv[1], bcost = m->cost;
+
+    if( hpel_iters )
+    {
+        if( c->subpel_refine < 3 ) /* try the sub-pel part of the predictor (me.c:889-895) */
+        {
+            int mx = clip3( m->mvp[0], m->spel_min[0]+2, m->spel_max[0]-2 );
+            int my = clip3( m->mvp[1], m->spel_min[1]+2, m->spel_max[1]-2 );
+            if( mx != bmx || my != bmy )
+            {
+                int cost = qpel_cost_sad( m, mx, my );
+                if( cost < bcost ) { bcost = cost; bmx = mx; bmy = my; }
+            }
+        }
+        /* half-pel diamond, order up, down, left, right (me.c:897-922) */
+        static const int d2[4][2] = { {0,-2}, {0,2}, {-2,0}, {2,0} };
+        for( int i = hpel_iters; i > 0; i-- )
+        {
+            int best = -1;
+            for( int k = 0; k < 4; k++ )
+            {
+                int cost = qpel_cost_sad( m, bmx + d2[k][0], bmy + d2[k][1] );
+                if( cost < bcost ) { bcost = cost; best = k; }
+            }
+            if( best < 0 )
+                break;
+            bmx += d2[best][0]; bmy += d2[best][1];
+        }
+    }
+
+    /* re-cost with mbcmp when it differs from fpelcmp (me.c:925-929) */
+    if( c->mbcmp_satd != c->fpelcmp_satd )
+        bcost = qpel_cost_satd( m, bmx, bmy );
+
+    /* quarter-pel diamond: skips the point it just came from (me.c:946-963) */
+    int bdir = -1;
+    static const int d1[4][2] = { {0,-1}, {0,1}, {-1,0}, {1,0} };
+    for( int i = qpel_iters; i > 0; i-- )
+    {
+        if( bmy <= m->spel_min[1] || bmy >= m->spel_max[1] || bmx <= m->spel_min[0] || bmx >= m->spel_max[0] )
+            break;
+        int odir = bdir, omx = bmx, omy = bmy;
+        for( int k = 0; k < 4; k++ )
+        {
+            if( ( k ^ 1 ) == odir )
+                continue;
+            int cost = qpel_cost_satd( m, omx + d1[k][0], omy + d1[k][1] );
+            if( cost < bcost ) { bcost = cost; bmx = omx + d1[k][0]; bmy = omy + d1[k][1]; bdir = k; }
+        }
+        if( bmx == omx && bmy == omy )
+            break;
+    }
+    m->cost = bcost; m->mv[0] = bmx; m->mv[1] = bmy;
+}
+
+/* mv limits of a block: slicetype.c:550-562 */
+static void block_limits( const or_la_cfg *c, int bx, int by, me_ctx *m )
+{
+    int range = 2*c->mv_range;
+    m->spel_min[0] = imax( 4*( -8*bx - 12 ), -range );
+    m->spel_max[0] = imin( 4*( 8*( c->mb_w - bx - 1 ) + 12 ), range - 1 );
+    m->spel_min[1] = imax( 4*( -8*by - 12 ), -range );
+    m->spel_max[1] = imin( 4*( 8*( c->mb_h - by - 1 ) + 12 ), range - 1 );
+    for( int k = 0; k < 2; k++ )
+    {
+        m->fpel_min[k] = m->spel_min[k] >> 2;
+        m->fpel_max[k] = m->spel_max[k] >> 2;
+    }
+}
+
+/* S2 (search part) over a whole frame: reverse raster order, predictors from the already searched
+ * right / below / below-left / below-right neighbours.  slicetype.c:654-709, :814-834. */
+void ORN(search_field)( const or_la_cfg *c, const pixel *fenc0, const pixel *const ref[4], const pixel *ref_w,
+                        const or_weight *wt, int16_t (*mvs)[2], int *mv_costs )
+{
+    const int W = c->mb_w;
+    pixel fenc[8*OR_FENC_STRIDE];
+    for( int by = c->slice_end - 1; by >= c->slice_start; by-- )
+        for( int bx = W - 1; bx >= 0; bx-- )
+        {
+            const int xy = by*W + bx, off = 8*( by*c->stride + bx );
+            me_ctx m;
+            memset( &m, 0, sizeof(m) );
+            m.c = c; m.fenc = fenc; m.stride = c->stride; m.wt = wt;
+            for( int k = 0; k < 4; k++ ) m.ref[k] = ref[k] + off;
+            m.ref_w = ( wt && wt->on ) ? ref_w + off : m.ref[0];
+            for( int y = 0; y < 8; y++ )
+                memcpy( fenc + y*OR_FENC_STRIDE, fenc0 + off + y*c->stride, 8*sizeof(pixel) );
+            block_limits( c, bx, by, &m );
+
+            int16_t mvc[4][2] = { {0,0}, {0,0}, {0,0}, {0,0} };
+            int n = 0;
+#define ADD(i) { mvc[n][0] = mvs[i][0]; mvc[n][1] = mvs[i][1]; n++; }
+            if( bx < W - 1 ) ADD( xy + 1 );
+            if( by < c->slice_end - 1 )
+            {
+                ADD( xy + W );
+                if( bx > 0 ) ADD( xy + W - 1 );
+                if( bx < W - 1 ) ADD( xy + W + 1 );
+            }
+#undef ADD
+            if( n <= 1 ) { m.mvp[0] = mvc[0][0]; m.mvp[1] = mvc[0][1]; }
+            else
+            {
+                m.mvp[0] = median3( mvc[0][0], mvc[1][0], mvc[2][0] );
+                m.mvp[1] = median3( mvc[0][1], mvc[1][1], mvc[2][1] );
+            }
+            int done = 0;
+            if( !m.mvp[0] && !m.mvp[1] )
+            {
+                /* near-zero residual shortcut on the unweighted plane (slicetype.c:684-692) */
+                m.cost = mbcmp8x8( c, fenc, OR_FENC_STRIDE, m.ref[0], c->stride );
+                if( m.cost < 64 ) { m.mv[0] = m.mv[1] = 0; done = 1; }
+            }
+            if( !done )
+            {
+                me_search( &m, (const int16_t (*)[2])mvc, n );
+                m.cost -= c->cost_mv[0];
+                if( m.mv[0] | m.mv[1] )
+                    m.cost += 5*c->lambda;
+            }
+            mvs[xy][0] = (int16_t)m.mv[0]; mvs[xy][1] = (int16_t)m.mv[1];
+            mv_costs[xy] = m.cost;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * S2 (mode selection) + S4 (reductions) for one (p0,p1,b): slicetype.c:616-652 (bidir candidates),
+ * :708-712, :758-790, :946-985.  Searches are inputs (mvs/costs per list).
+ * ---------------------------------------------------------------------------------------------- */
+static int bidir_cost( const or_la_cfg *c, const pixel *fenc, const pixel *const r0[4], const pixel *const r1[4],
+                       const int mv0[2], const int mv1[2], int bipred_weight )
+{
+    pixel a[64], b[64], avg[64];
+    if( c->subme <= 1 )
+    {
+        /* half-pel plane pick without interpolation (slicetype.c:582-589) */
+        int h0 = ( ( mv0[0] & 2 ) >> 1 ) + ( mv0[1] & 2 ), h1 = ( ( mv1[0] & 2 ) >> 1 ) + ( mv1[1] & 2 );
+        const pixel *s0 = r0[h0] + ( mv0[0] >> 2 ) + ( mv0[1] >> 2 ) * c->stride;
+        const pixel *s1 = r1[h1] + ( mv1[0] >> 2 ) + ( mv1[1] >> 2 ) * c->stride;
+        ORN(avg)( avg, 8, s0, c->stride, s1, c->stride, 8, 8, bipred_weight );
+    }
+    else
+    {
+        ORN(mc_luma)( a, 8, r0, c->stride, mv0[0], mv0[1], 8, 8, NULL );
+        ORN(mc_luma)( b, 8, r1, c->stride, mv1[0], mv1[1], 8, 8, NULL );
+        ORN(avg)( avg, 8, a, 8, b, 8, 8, 8, bipred_weight );
+    }
+    return mbcmp8x8( c, fenc, OR_FENC_STRIDE, avg, 8 );
+}
+
+void ORN(cell)( const or_la_cfg *c, const pixel *fenc0, const pixel *const ref0[4], const pixel *const ref1[4],
+                int b_bidir, int dist_scale_factor, const or_weight *wt,
+                const int16_t (*mvs0)[2], const int *costs0, const int16_t (*mvs1)[2], const int *costs1,
+                const int16_t (*ref1_l0_mvs)[2], const uint16_t *intra_cost, const uint16_t *inv_qscale,
+                int with_intra, uint16_t *lowres_costs, int *row_satds, int *row_satds_intra, or_cell_out *out )
+{
+    (void)wt;
+    const int W = c->mb_w, H = c->mb_h;
+    const int bipred_weight = c->weighted_bipred ? 64 - ( dist_scale_factor >> 2 ) : 32;
+    const int is_intra_only = !mvs0 && !mvs1; /* p0 == p1 */
+    memset( out, 0, sizeof(*out) );
+    pixel fenc[8*OR_FENC_STRIDE];
+    for( int by = H - 1; by >= 0; by-- )
+    {
+        if( row_satds ) row_satds[by] = 0;
+        if( row_satds_intra && with_intra ) row_satds_intra[by] = 0;
+        for( int bx = W - 1; bx >= 0; bx-- )
+        {
+            const int xy = by*W + bx, off = 8*( by*c->stride + bx );
+            const int scored = ( bx > 0 && bx < W-1 && by > 0 && by < H-1 ) || W <= 2 || H <= 2;
+            int bcost = COST_MAX, list_used = 0;
+            if( !is_intra_only )
+            {
+                me_ctx lim;
+                block_limits( c, bx, by, &lim );
+                for( int y = 0; y < 8; y++ )
+                    memcpy( fenc + y*OR_FENC_STRIDE, fenc0 + off + y*c->stride, 8*sizeof(pixel) );
+                const pixel *r0[4], *r1[4];
+                for( int k = 0; k < 4; k++ ) { r0[k] = ref0[k] + off; r1[k] = b_bidir ? ref1[k] + off : NULL; }
+                if( b_bidir )
+                {
+                    int dmv[2][2] = { {0,0}, {0,0} };
+                    if( ref1_l0_mvs )
+                    {
+                        int rx = ref1_l0_mvs[xy][0], ry = ref1_l0_mvs[xy][1];
+                        dmv[0][0] = ( rx*dist_scale_factor + 128 ) >> 8;
+                        dmv[0][1] = ( ry*dist_scale_factor + 128 ) >> 8;
+                        dmv[1][0] = dmv[0][0] - rx;
+                        dmv[1][1] = dmv[0][1] - ry;
+                        for( int l = 0; l < 2; l++ )
+                            for( int k = 0; k < 2; k++ )
+                            {
+                                dmv[l][k] = clip3( dmv[l][k], lim.spel_min[k], lim.spel_max[k] );
+                                if( c->subme <= 1 ) dmv[l][k] &= ~1;
+                            }
+                    }
+                    int cost = bidir_cost( c, fenc, r0, r1, dmv[0], dmv[1], bipred_weight );
+                    if( cost < bcost ) { bcost = cost; list_used = 3; }
+                    if( dmv[0][0] | dmv[0][1] | dmv[1][0] | dmv[1][1] )
+                    {
+                        static const int zero[2] = { 0, 0 };
+                        pixel avg[64];
+                        ORN(avg)( avg, 8, r0[0], c->stride, r1[0], c->stride, 8, 8, bipred_weight );
+                        (void)zero;
+                        cost = mbcmp8x8( c, fenc, OR_FENC_STRIDE, avg, 8 );
+                        if( cost < bcost ) { bcost = cost; list_used = 3; }
+                    }
+                }
+                if( costs0[xy] < bcost ) { bcost = costs0[xy]; list_used = 1; }
+                if( b_bidir )
+                {
+                    if( costs1[xy] < bcost ) { bcost = costs1[xy]; list_used = 2; }
+                    int mv0[2] = { mvs0[xy][0], mvs0[xy][1] }, mv1[2] = { mvs1[xy][0], mvs1[xy][1] };
+                    if( mv0[0] | mv0[1] | mv1[0] | mv1[1] )
+                    {
+                        int cost = 5*c->lambda + bidir_cost( c, fenc, r0, r1, mv0, mv1, bipred_weight );
+                        if( cost < bcost ) { bcost = cost; list_used = 3; }
+                    }
+                }
+            }
+            int icost = intra_cost[xy];
+            if( with_intra )
+            {
+                int icost_aq = c->aq_mode ? ( icost * inv_qscale[xy] + 128 ) >> 8 : icost;
+                if( row_satds_intra ) row_satds_intra[by] += icost_aq;
+                if( scored ) { out->intra_cost_est += icost; out->intra_cost_est_aq += icost_aq; }
+            }
+            bcost = ( bcost >> DEPTH_SHIFT ) + 4;
+            if( !b_bidir )
+            {
+                int b_intra = icost < bcost;
+                if( b_intra ) { bcost = icost; list_used = 0; }
+                if( scored ) out->intra_mbs += b_intra;
+            }
+            if( !is_intra_only )
+            {
+                int bcost_aq = c->aq_mode ? ( bcost * inv_qscale[xy] + 128 ) >> 8 : bcost;
+                if( row_satds ) row_satds[by] += bcost_aq;
+                if( scored ) { out->cost_est += bcost; out->cost_est_aq += bcost_aq; }
+            }
+            lowres_costs[xy] = (uint16_t)( imin( bcost, 0x3FFF ) + ( list_used << 14 ) );
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Adaptive-quant input stage: encoder/ratecontrol.c:225-415, aq-mode 0/1 only.
+ * Produces i_inv_qscale_factor (Q8) per MB and the luma sum / mean-removed ssd that
+ * x264_weights_analyse reads (slicetype.c:301-306).  FP32 on purpose, same expression order as
+ * the reference (which is built with -ffast-math; tests pin the bits against it).
+ * luma/cb/cr are the picture as handed in (not mod16): coordinates clamp like frame.c:640-666.
+ * ---------------------------------------------------------------------------------------------- */
+static float lut_log2( uint32_t x ) /* common/base.h:225-229 + tables.c:66-90 */
+{
+    static float lut[128];
+    static int init = 0;
+    if( !init )
+    {
+        for( int i = 0; i < 128; i++ )
+            lut[i] = (float)( floor( log2( 1.0 + i/128.0 ) * 100000.0 + 0.5 ) / 100000.0 );
+        init = 1;
+    }
+    int lz = __builtin_clz( x );
+    return lut[( x << lz >> 24 ) & 0x7f] + (float)( 31 - lz );
+}
+
+static int exp2fix8( float x ) /* common/base.h:217-223 + tables.c:58-64 */
+{
+    static uint8_t lut[64];
+    static int init = 0;
+    if( !init )
+    {
+        for( int i = 0; i < 64; i++ )
+            lut[i] = (uint8_t)floor( ( pow( 2.0, i/64.0 ) - 1.0 ) * 256.0 + 0.5 );
+        init = 1;
+    }
+    int i = (int)( x * ( -64.f/6.f ) + 512.5f );
+    if( i < 0 ) return 0;
+    if( i > 1023 ) return 0xffff;
+    return ( lut[i & 63] + 256 ) << ( i >> 6 ) >> 8;
+}
+
+uint64_t ORN(aq_frame)( const pixel *luma, int stride, int width, int height, int mb_w, int mb_h,
+                        const pixel *cb, const pixel *cr, int cstride, int aq_mode, float aq_strength,
+                        uint16_t *inv_qscale, float *qp_offset, uint64_t *ssd_out )
+{
+    uint64_t sum_y = 0, ssd_y = 0;
+    const float strength = aq_strength * 1.0397f;
+    const int cw = ( width + 1 ) >> 1, chh = ( height + 1 ) >> 1;
+    for( int my = 0; my < mb_h; my++ )
+        for( int mx = 0; mx < mb_w; mx++ )
+        {
+            uint32_t s = 0, q = 0;
+            for( int y = 0; y < 16; y++ )
+            {
+                const pixel *row = luma + (size_t)imin( 16*my + y, height-1 ) * stride;
+                for( int x = 0; x < 16; x++ )
+                {
+                    uint32_t v = row[imin( 16*mx + x, width-1 )];
+                    s += v; q += v*v;
+                }
+            }
+            sum_y += s; ssd_y += q;
+            uint32_t energy = q - (uint32_t)( (uint64_t)s * s >> 8 );
+            for( int p = 0; p < 2; p++ )
+            {
+                const pixel *pl = p ? cr : cb;
+                if( !pl ) continue;
+                uint32_t cs = 0, cq = 0;
+                for( int y = 0; y < 8; y++ )
+                {
+                    const pixel *row = pl + (size_t)imin( 8*my + y, chh-1 ) * cstride;
+                    for( int x = 0; x < 8; x++ )
+                    {
+                        uint32_t v = row[imin( 8*mx + x, cw-1 )];
+                        cs += v; cq += v*v;
+                    }
+                }
+                energy += cq - (uint32_t)( (uint64_t)cs * cs >> 6 );
+            }
+            if( aq_mode == 1 && aq_strength != 0.f )
+            {
+                float qp_adj = strength * ( lut_log2( energy > 1 ? energy : 1 ) - ( 14.427f + 2*( OR_DEPTH - 8 ) ) );
+                if( qp_offset ) qp_offset[my*mb_w+mx] = qp_adj;
+                inv_qscale[my*mb_w+mx] = (uint16_t)exp2fix8( qp_adj );
+            }
+            else
+            {
+                if( qp_offset ) qp_offset[my*mb_w+mx] = 0.f;
+                inv_qscale[my*mb_w+mx] = 256;
+            }
+        }
+    uint64_t n = (uint64_t)( 16*mb_w ) * ( 16*mb_h );
+    if( ssd_out ) *ssd_out = ssd_y - ( sum_y*sum_y + n/2 ) / n;
+    return sum_y;
+}

@@ -1,0 +1,94 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement ("oracle") of the x264 lookahead / ME hot path.
+ *
+ * Plain C restatement of the algorithms in the reference (jpsdr/x264 @ /root/reference):
+ * common/pixel.c, common/mc.c, common/predict.c, common/dct.c, common/quant.c, encoder/me.c and
+ * encoder/slicetype.c (each function below cites the file:line it follows).  It is the checker the
+ * HIP path is compared with; nothing in the product (x264_amd/) links, loads or calls it.
+ *
+ * PARITY PIN: tests/test_oracle_vs_ref.py checks every function here bit-exactly against the real
+ * reference built by oracle/build_ref.sh (oracle/_ref/libx264ref{8,10}.so), and
+ * tests/golden/ holds fixtures generated from that build for boxes without /root/reference.
+ *
+ * The file is compiled once per bit depth; symbols are prefixed or8_ / or10_.
+ */
+#ifndef X264_ORACLE_H
+#define X264_ORACLE_H
+#include <stdint.h>
+
+#define OR_PAD 32          /* lowres border, reference PADH/PADV (common/frame.h:32-33) */
+#define OR_FENC_STRIDE 16  /* common/common.h FENC_STRIDE */
+#define OR_FDEC_STRIDE 32  /* common/common.h FDEC_STRIDE */
+
+enum { OR_ME_DIA = 0, OR_ME_HEX = 1 };
+
+/* lookahead configuration (what lowres_context_init + x264_param_t give the reference) */
+typedef struct or_la_cfg
+{
+    int mb_w, mb_h;         /* 8x8 lowres blocks per row / column (= 16x16 MBs of the full frame) */
+    int stride;             /* lowres plane stride in pixels */
+    int lambda;             /* x264_lambda_tab[X264_LOOKAHEAD_QP] */
+    int me_method;          /* OR_ME_DIA / OR_ME_HEX (slicetype.c:50-59) */
+    int subpel_refine;      /* lookahead h->mb.i_subpel_refine: 2 or 4 */
+    int me_range;           /* param.analyse.i_me_range */
+    int mv_range;           /* param.analyse.i_mv_range */
+    int subme;              /* param.analyse.i_subpel_refine (user): intra extra modes, bidir path */
+    int mbcmp_satd;         /* mbcmp = SATD (subme > 1) else SAD (encoder.c:1409-1427) */
+    int fpelcmp_satd;       /* fpelcmp = SATD only for me=tesa */
+    int weighted_bipred;
+    int aq_mode;
+    int bframe_bias;
+    int slice_start, slice_end; /* i_threadslice_start/end rows (0, mb_h for lookahead_threads=1) */
+    const uint16_t *cost_mv;    /* centred table, index range +-(2*4*mv_range) */
+} or_la_cfg;
+
+typedef struct or_weight
+{
+    int on, scale, denom, offset;
+} or_weight;
+
+/* per-evaluation summary as slicetype_frame_cost leaves it (before the B *100/(120+bias) scaling) */
+typedef struct or_cell_out
+{
+    int cost_est, cost_est_aq, intra_mbs;
+    int intra_cost_est, intra_cost_est_aq; /* the [0][0] cell if intra was computed in this call */
+} or_cell_out;
+
+#define OR_DECL(D, PIX, COEF, UCOEF) \
+void or##D##_lowres_init( const PIX *src, int src_stride, int width, int height, int mb_w, int mb_h, \
+                          PIX *p0, PIX *ph, PIX *pv, PIX *pc, int stride ); \
+void or##D##_lowres_core( const PIX *src, PIX *d0, PIX *dh, PIX *dv, PIX *dc, int src_stride, int dst_stride, int w, int h ); \
+int  or##D##_sad( const PIX *a, int sa, const PIX *b, int sb, int w, int h ); \
+int  or##D##_ssd( const PIX *a, int sa, const PIX *b, int sb, int w, int h ); \
+int  or##D##_satd( const PIX *a, int sa, const PIX *b, int sb, int w, int h ); \
+int  or##D##_sa8d( const PIX *a, int sa, const PIX *b, int sb, int w ); \
+uint64_t or##D##_var( const PIX *a, int sa, int w, int h ); \
+void or##D##_predict_8x8c( int mode, PIX *src ); \
+void or##D##_predict_8x8_filter( const PIX *src, PIX *edge ); \
+void or##D##_predict_8x8( int mode, PIX *src, const PIX *edge ); \
+void or##D##_intra_x3_8x8c( int satd, const PIX *fenc, PIX *fdec, int res[3] ); \
+void or##D##_mc_luma( PIX *dst, int ds, const PIX *const planes[4], int stride, int mvx, int mvy, int w, int h, const or_weight *wt ); \
+void or##D##_avg( PIX *dst, int ds, const PIX *a, int sa, const PIX *b, int sb, int w, int h, int weight ); \
+void or##D##_weight_plane( PIX *dst, const PIX *src, int stride, int width, int lines, const or_weight *wt ); \
+unsigned or##D##_weight_cost( const or_la_cfg *c, const PIX *fenc0, const PIX *ref0, const or_weight *wt, const uint16_t *intra_cost ); \
+void or##D##_dct( int kind, COEF *out, const PIX *fenc, const PIX *fdec ); \
+int  or##D##_quant( int kind, COEF *coef, const UCOEF *mf, const UCOEF *bias, int mf_dc, int bias_dc ); \
+void or##D##_intra_costs( const or_la_cfg *c, const PIX *fenc0, uint16_t *intra_cost ); \
+void or##D##_search_field( const or_la_cfg *c, const PIX *fenc0, const PIX *const ref[4], const PIX *ref_w, \
+                           const or_weight *wt, int16_t (*mvs)[2], int *mv_costs ); \
+void or##D##_cell( const or_la_cfg *c, const PIX *fenc0, const PIX *const ref0[4], const PIX *const ref1[4], \
+                   int b_bidir, int dist_scale_factor, const or_weight *wt, \
+                   const int16_t (*mvs0)[2], const int *costs0, const int16_t (*mvs1)[2], const int *costs1, \
+                   const int16_t (*ref1_l0_mvs)[2], const uint16_t *intra_cost, const uint16_t *inv_qscale, \
+                   int with_intra, uint16_t *lowres_costs, int *row_satds, int *row_satds_intra, or_cell_out *out ); \
+uint64_t or##D##_aq_frame( const PIX *luma, int stride, int width, int height, int mb_w, int mb_h, \
+                           const PIX *cb, const PIX *cr, int cstride, int aq_mode, float aq_strength, \
+                           uint16_t *inv_qscale, float *qp_offset, uint64_t *ssd_out );
+
+OR_DECL( 8, uint8_t, int16_t, uint16_t )
+OR_DECL( 10, uint16_t, int32_t, uint32_t )
+
+/* depth independent */
+void or_cost_mv_table( uint16_t *out_centre, int n, int lambda ); /* analyse.c:143-202 */
+int  or_lambda_for_depth( int bit_depth );
+
+#endif

@@ -15,10 +15,13 @@ def _box5(a, axis):
     return out / 5.0
 
 
-def make_clip(width, height, n_frames, seed=1, bit_depth=8, scene_cuts=(), fade=None, noise=3):
+def make_clip(width, height, n_frames, seed=1, bit_depth=8, scene_cuts=(), fade=None, noise=3, pan=(3, 2),
+              texture=0.18):
     """Return uint8/uint16 array [n_frames, height, width] of luma samples.
 
     scene_cuts: frame indices at which the picture is inverted (a hard cut).
+    pan: (dx, dy) full-resolution pixels of camera pan per frame (wraps inside the field).
+    texture: share of white noise mixed into the smooth field.
     fade: (start, length, gain_end, offset_end) -- linear fade applied over [start, start+length) and
           held afterwards.
     """
@@ -30,14 +33,14 @@ def make_clip(width, height, n_frames, seed=1, bit_depth=8, scene_cuts=(), fade=
     field -= field.min()
     field /= max(field.max(), 1e-9)
     # add a little high-frequency texture so SATD/intra modes are non-trivial
-    field = 0.82 * field + 0.18 * rng.uniform(0.0, 1.0, size=field.shape)
+    field = (1.0 - texture) * field + texture * rng.uniform(0.0, 1.0, size=field.shape)
     field = 16.0 + field * 219.0
     cuts = sorted(set(int(c) for c in scene_cuts))
     frames = np.empty((n_frames, height, width), dtype=np.uint8 if bit_depth == 8 else np.uint16)
     scale = 1 << (bit_depth - 8)
     maxv = (1 << bit_depth) - 1
     for i in range(n_frames):
-        dx, dy = (3 * i) % 256, (2 * i) % 128
+        dx, dy = (pan[0] * i) % 256, (pan[1] * i) % 128
         img = field[dy:dy + height, dx:dx + width].copy()
         inverted = sum(1 for c in cuts if c <= i) & 1
         if inverted:
