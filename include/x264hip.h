@@ -1,0 +1,156 @@
+/* x264hip.h -- C ABI of the MI355X (gfx950) lookahead / motion-estimation path.
+ *
+ * Drop-in boundary for the hot path named in BASELINE.json: every entry point states the reference
+ * interface (file:line under jpsdr/x264) it replaces.  Plain pointers and sizes only; no C++ or
+ * torch types.  All functions return 0 on success and a negative X264HIP_E* code on failure, never
+ * throw, and never fall back to a CPU implementation: without a usable HIP device x264hip_open()
+ * fails with X264HIP_ENODEV.
+ *
+ * Threading: one context is driven by one thread (like the reference's single lookahead thread,
+ * encoder/lookahead.c:90-128).  The caller owns every host buffer; the context owns device memory.
+ *
+ * Bit depth: pixels are uint8_t (bit_depth 8) or uint16_t (bit_depth 10) exactly like the
+ * reference's `pixel` (common/common.h:93-105); strides are in pixels.
+ */
+#ifndef X264HIP_H
+#define X264HIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define X264HIP_OK        0
+#define X264HIP_ENODEV   -1   /* no HIP device / runtime error at open */
+#define X264HIP_EINVAL   -2   /* bad argument */
+#define X264HIP_ENOMEM   -3
+#define X264HIP_EDEVICE  -4   /* a kernel or copy failed; the context is latched broken (cf. slicetype-cl.c:44-56) */
+#define X264HIP_ETIMEOUT -5   /* in-kernel dependency wait exceeded its bound */
+#define X264HIP_ESTATE   -6   /* call sequence error (e.g. evaluation of a frame that was never put) */
+
+#define X264HIP_ME_DIA 0
+#define X264HIP_ME_HEX 1
+#define X264HIP_BFRAME_MAX 16 /* X264_BFRAME_MAX, common/base.h */
+
+typedef struct x264hip_ctx x264hip_ctx;
+
+/* What lowres_context_init() (encoder/slicetype.c:45-61) and x264_param_t give the reference's
+ * lookahead.  cost_mv is the centred table h->cost_mv[X264_LOOKAHEAD_QP] (encoder/analyse.c:151-157),
+ * valid for indices [-2*4*mv_range, +2*4*mv_range]; it is copied at open. */
+typedef struct x264hip_params
+{
+    int bit_depth;        /* 8 or 10 */
+    int width, height;    /* picture size as given to the encoder (any size; mod16 handling is internal) */
+    int bframes;          /* param.i_bframe */
+    int lambda;           /* x264_lambda_tab[X264_LOOKAHEAD_QP] */
+    int me_method;        /* X264HIP_ME_DIA / X264HIP_ME_HEX: lookahead h->mb.i_me_method */
+    int subpel_refine;    /* lookahead h->mb.i_subpel_refine: 2 or 4 */
+    int me_range;         /* param.analyse.i_me_range */
+    int mv_range;         /* param.analyse.i_mv_range */
+    int subme;            /* param.analyse.i_subpel_refine */
+    int mbcmp_satd;       /* h->pixf.mbcmp == satd (encoder.c:1409-1427) */
+    int fpelcmp_satd;     /* h->pixf.fpelcmp == satd (me=tesa) */
+    int weighted_bipred;  /* param.analyse.b_weighted_bipred */
+    int aq_mode;          /* param.rc.i_aq_mode (0 or 1) */
+    float aq_strength;    /* param.rc.f_aq_strength */
+    int bframe_bias;      /* param.i_bframe_bias */
+    int max_frames;       /* frame slots to keep resident (>= lookahead depth + bframes + 3) */
+    const uint16_t *cost_mv;
+} x264hip_params;
+
+typedef struct x264hip_weight
+{
+    int on, scale, denom, offset; /* x264_weight_t i_scale/i_denom/i_offset, weightfn != NULL (common/mc.h:235-245) */
+} x264hip_weight;
+
+/* per-evaluation outputs of slicetype_frame_cost (encoder/slicetype.c:946-991), before the
+ * B-frame *100/(120+bias) scaling which stays with the caller */
+typedef struct x264hip_cost
+{
+    int cost_est, cost_est_aq, intra_mbs;
+    int intra_cost_est, intra_cost_est_aq; /* the [0][0] cell when intra was (re)computed */
+} x264hip_cost;
+
+/* ---- context ---------------------------------------------------------------------------------
+ * Replaces x264_opencl_lookahead_init / _delete (encoder/encoder.c:1744-1753, 4208-4209,
+ * common/opencl.c:411) as the device bring-up of the coarse lookahead hook. */
+int  x264hip_open( x264hip_ctx **out, int device, const x264hip_params *params );
+void x264hip_close( x264hip_ctx *ctx );
+const char *x264hip_strerror( int code );
+int  x264hip_device_name( x264hip_ctx *ctx, char *buf, size_t cap );
+int  x264hip_synchronize( x264hip_ctx *ctx );  /* x264_opencl_flush (encoder/slicetype-cl.c:58-80) */
+
+/* ---- frame ingest ----------------------------------------------------------------------------
+ * Replaces, per input frame: x264_adaptive_quant_frame (encoder/ratecontrol.c:304-415, aq-mode 0/1),
+ * x264_frame_init_lowres + frame_init_lowres_core + x264_frame_expand_border_lowres
+ * (common/mc.c:458-507, common/frame.c:627-631) and x264_opencl_lowres_init
+ * (encoder/slicetype-cl.c:129-282).  slot is the caller's frame handle in [0, max_frames).
+ * luma may be a host or a device pointer (is_device).  cb/cr are optional 4:2:0 planes used only by
+ * AQ; inv_qscale (mb_w*mb_h, Q8) overrides the AQ result when not NULL.
+ * Resets the slot's search/cost state like mc.c:471-481. */
+int  x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, int stride, int is_device,
+                        const void *cb, const void *cr, int cstride, const uint16_t *inv_qscale );
+/* i_pixel_sum[0] / i_pixel_ssd[0] of the frame (ratecontrol.c:225-234,405-414) */
+int  x264hip_frame_stats( x264hip_ctx *ctx, int slot, uint64_t *pixel_sum, uint64_t *pixel_ssd );
+
+/* ---- evaluation ------------------------------------------------------------------------------
+ * x264hip_frame_cost replaces the body of slicetype_frame_cost after its memo check
+ * (encoder/slicetype.c:869-991: the slicetype_slice_cost / slicetype_mb_cost loops and the
+ * accumulator sums) == x264_opencl_motionsearch + x264_opencl_finalize_cost
+ * (encoder/slicetype-cl.c:407-649).
+ *   slot_p0/p1/b : frame handles; p0 == p1 == b is the intra-only evaluation.
+ *   dist_p0 = b-p0, dist_p1 = p1-b in frames.
+ *   do_search[l] : run the motion search of list l now (the caller mirrors the reference's
+ *                  lowres_mvs[l][d][0][0] == 0x7FFF first-trigger test, slicetype.c:855-867).
+ *   w            : luma weight for the list-0 search when this call triggers it as a P frame, or NULL.
+ *   with_intra   : !fenc->b_intra_calculated.
+ *   ref1_l0_valid: frames[p1]->lowres_mvs[0][p1-p0-1] has been searched (slicetype.c:629).
+ * Results stay resident (mvs, mv costs, lowres_costs, intra costs, row satds) and are fetched with
+ * the getters below, which is what the reference's deferred memcpys do (slicetype-cl.c:254-282). */
+int  x264hip_frame_cost( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b, int dist_p0, int dist_p1,
+                         const int do_search[2], const x264hip_weight *w, int with_intra, int ref1_l0_valid,
+                         x264hip_cost *out );
+
+/* weight_cost_luma without the slice-header term (encoder/slicetype.c:191-222): sum over blocks of
+ * min( mbcmp( weight(ref lowres block), fenc lowres block ), intra_cost ).  w may be NULL. */
+int  x264hip_weight_cost( x264hip_ctx *ctx, int slot_fenc, int slot_ref, const x264hip_weight *w, unsigned *cost );
+
+/* getters (device -> host); sizes in elements: n_mb = mb_w*mb_h */
+int  x264hip_get_lowres( x264hip_ctx *ctx, int slot, int plane, void *dst, int dst_stride ); /* incl. 32 px border */
+int  x264hip_get_mvs( x264hip_ctx *ctx, int slot, int list, int dist_minus1, int16_t *mvs, int *mv_costs );
+int  x264hip_get_lowres_costs( x264hip_ctx *ctx, int slot, int dist_p0, int dist_p1, uint16_t *costs, int *row_satds );
+int  x264hip_get_intra_costs( x264hip_ctx *ctx, int slot, uint16_t *intra_costs );
+int  x264hip_get_inv_qscale( x264hip_ctx *ctx, int slot, uint16_t *inv_qscale );
+int  x264hip_geometry( x264hip_ctx *ctx, int *mb_w, int *mb_h, int *lowres_stride );
+
+/* Speculative batch: enqueue, without waiting, everything that only depends on the pixels of the given
+ * frames: for every listed frame b and distance d in [1, bframes+1] the unweighted list-0 search
+ * (b -> b-d) and list-1 search (b -> b+d) whose reference is also listed.  Later x264hip_frame_cost
+ * calls pick the finished fields up instead of searching.  Never changes results. */
+int  x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *frame_numbers, int n );
+
+/* ---- vtable-granular primitives, batched -------------------------------------------------------
+ * Device counterparts of x264_pixel_function_t.sad/satd (common/pixel.h:78-84, pixel.c:55-80,265-332)
+ * over a whole field of blocks: block i of size_idx (PIXEL_16x16=0, PIXEL_8x8=3, PIXEL_4x4=6) sits at
+ * raster position i of the fenc plane and is compared with the ref plane displaced by the full-pel
+ * mv[i].  Planes are device pointers.  Used for parity and for the SAD/SATD GB/s metric. */
+int  x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx, const void *fenc_plane, const void *ref_plane,
+                              int stride, int blocks_w, int blocks_h, const int16_t *mv_dev, int *out_dev );
+/* x264_mc_functions_t.frame_init_lowres_core (common/mc.h:326-327): device pointers, same arguments */
+int  x264hip_frame_init_lowres_core( x264hip_ctx *ctx, const void *src0, void *dst0, void *dsth, void *dstv, void *dstc,
+                                     intptr_t src_stride, intptr_t dst_stride, int width, int height );
+/* x264_dct_function_t.sub4x4_dct / sub8x8_dct8 (common/dct.h:29-45) and x264_quant_function_t.quant_4x4 /
+ * quant_8x8 (common/quant.h:30-34) over n blocks laid out back to back (fenc blocks with stride 16,
+ * fdec blocks with stride 32, like FENC_STRIDE/FDEC_STRIDE).  Host pointers; a parity/microbench entry. */
+int  x264hip_dct_quant_batch( x264hip_ctx *ctx, int is8x8, int n_blocks, const void *fenc, const void *fdec,
+                              const void *mf, const void *bias, void *coefs_out, int *nz_out );
+
+/* timing of the most recent search launch in ms (HIP events on the context's stream) and counters */
+int  x264hip_last_search_ms( x264hip_ctx *ctx, float *ms, int *n_searches, int *n_blocks );
+int  x264hip_counters( x264hip_ctx *ctx, uint64_t *out, int n ); /* [0] searches [1] cells [2] cache hits [3] frames */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,184 @@
+"""GPU parity: the HIP path (through the C ABI, x264_amd/libx264hip.so) against the CPU oracle on the
+same seeded inputs.  Integer work: bit-exact."""
+import numpy as np
+import pytest
+
+from oracle.oraclelib import Oracle, PAD, Weight
+from tests.common import clip
+from x264_amd import lib
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    # name: (depth, me_method, subpel_refine, me_range, subme, mbcmp_satd, fpelcmp_satd, bframes)
+    "hex_r4": (8, 1, 4, 16, 7, 1, 0, 3),
+    "dia_r4": (8, 0, 4, 16, 8, 1, 0, 3),
+    "hex_r32": (8, 1, 4, 32, 9, 1, 0, 3),
+    "dia_r2_sad": (8, 0, 2, 16, 1, 0, 0, 3),
+    "dia_r4_subme2": (8, 0, 4, 16, 2, 1, 0, 3),
+    "hex_10bit_tesa": (10, 1, 4, 24, 10, 1, 1, 8),
+    "hex_10bit": (10, 1, 4, 16, 7, 1, 0, 3),
+}
+SEQ = [(0, 0, 0), (0, 1, 1), (0, 2, 2), (0, 2, 1), (1, 1, 1), (0, 3, 3), (0, 3, 1), (0, 3, 2), (1, 3, 2), (2, 3, 3), (3, 3, 3),
+       (1, 2, 2)]
+
+
+def _mk(depth, me_method, subpel_refine, me_range, subme, mbcmp_satd, fpelcmp_satd, bframes, W, H, mv_range=128):
+    o = Oracle(depth)
+    cfg = o.make_cfg((W + 15) // 16, (H + 15) // 16, me_method=me_method, subpel_refine=subpel_refine, me_range=me_range,
+                     mv_range=mv_range, subme=subme, mbcmp_satd=mbcmp_satd, fpelcmp_satd=fpelcmp_satd)
+    ctx = lib.Context(W, H, bit_depth=depth, bframes=bframes, me_method=me_method, subpel_refine=subpel_refine,
+                      me_range=me_range, mv_range=mv_range, subme=subme, mbcmp_satd=mbcmp_satd, fpelcmp_satd=fpelcmp_satd,
+                      max_frames=8, cost_mv=o._cost_mv)
+    return o, cfg, ctx
+
+
+def _run_sequence(o, cfg, ctx, frames, weights=None, prefetch=False):
+    """Replays SEQ with reference first-trigger semantics on the HIP context and through the oracle's pure
+    functions, comparing every produced array."""
+    nf = len(frames)
+    planes, inv, intra = [], [], []
+    for i in range(nf):
+        ctx.frame_put(i, frames[i])
+        pl = o.lowres_init(cfg, frames[i])
+        for p in range(4):
+            assert np.array_equal(ctx.lowres(i, p), pl[p][:, :8 * cfg.mb_w + 2 * PAD]), ("lowres", i, p)
+        iq, _, s, ssd = o.aq_frame(frames[i], cfg.mb_w, cfg.mb_h, 1, 1.0)
+        assert np.array_equal(ctx.inv_qscale(i), iq), ("inv_qscale", i)
+        assert ctx.frame_stats(i) == (s, ssd)
+        ic = o.intra_costs(cfg, pl)
+        assert np.array_equal(ctx.intra_costs(i), ic), ("intra", i, int((ctx.intra_costs(i) != ic).sum()))
+        planes.append(pl); inv.append(iq); intra.append(ic)
+    if prefetch:
+        ctx.prefetch(list(range(nf)), list(range(nf)))
+    fields = {}
+    intra_done = set()
+    for (p0, p1, b) in SEQ:
+        if max(p0, p1, b) >= nf:
+            continue
+        d0, d1 = b - p0, p1 - b
+        with_intra = b not in intra_done
+        if p0 == p1:
+            out = ctx.frame_cost(p0, p1, b, 0, 0, (0, 0), None, with_intra, False)
+            lc, rows, rows_i, oo = o.cell(cfg, planes[b], None, None, 128, None, None, None, None, None, intra[b], inv[b], with_intra)
+            glc, grows = ctx.lowres_costs(b, 0, 0)
+            assert np.array_equal(glc, lc)
+            assert (out.intra_cost_est, out.intra_cost_est_aq) == (oo.intra_cost_est, oo.intra_cost_est_aq)
+            if with_intra:
+                assert np.array_equal(grows, rows_i)
+            intra_done.add(b)
+            continue
+        do0 = (b, 0, d0 - 1) not in fields
+        do1 = d1 > 0 and (b, 1, d1 - 1) not in fields
+        wt = None
+        if do0 and d1 == 0 and weights and (b, p0) in weights:
+            wt = weights[(b, p0)]
+        if do0:
+            w = Weight(*wt) if wt else None
+            wplane = o.weight_plane(cfg, planes[p0][0], w) if wt else None
+            fields[(b, 0, d0 - 1)] = o.search_field(cfg, planes[b], planes[p0], w, wplane)
+        if do1:
+            fields[(b, 1, d1 - 1)] = o.search_field(cfg, planes[b], planes[p1])
+        ref1_valid = d1 > 0 and (p1, 0, d0 + d1 - 1) in fields
+        out = ctx.frame_cost(p0, p1, b, d0, d1, (do0, do1), wt, with_intra, ref1_valid)
+        m0, c0 = fields[(b, 0, d0 - 1)]
+        gm, gc = ctx.mvs(b, 0, d0 - 1)
+        assert np.array_equal(gm, m0), ("L0 mvs", p0, p1, b, int((gm != m0).any(1).sum()))
+        assert np.array_equal(gc, c0), ("L0 costs", p0, p1, b)
+        dsf = (d0 * 256 + (d0 + d1) // 2) // (d0 + d1)
+        if d1 > 0:
+            m1, c1 = fields[(b, 1, d1 - 1)]
+            gm1, gc1 = ctx.mvs(b, 1, d1 - 1)
+            assert np.array_equal(gm1, m1) and np.array_equal(gc1, c1), ("L1", p0, p1, b)
+            r1 = fields[(p1, 0, d0 + d1 - 1)][0] if ref1_valid else None
+            lc, rows, rows_i, oo = o.cell(cfg, planes[b], planes[p0], planes[p1], dsf, m0, c0, m1, c1, r1, intra[b], inv[b], with_intra)
+        else:
+            lc, rows, rows_i, oo = o.cell(cfg, planes[b], planes[p0], None, dsf, m0, c0, None, None, None, intra[b], inv[b], with_intra)
+            intra_done.add(b)
+        glc, grows = ctx.lowres_costs(b, d0, d1)
+        assert np.array_equal(glc, lc), ("lowres_costs", p0, p1, b, int((glc != lc).sum()))
+        assert np.array_equal(grows, rows), ("row_satds", p0, p1, b)
+        assert (out.cost_est, out.cost_est_aq) == (oo.cost_est, oo.cost_est_aq), ("sums", p0, p1, b)
+        if d1 == 0:
+            assert out.intra_mbs == oo.intra_mbs
+        if with_intra:
+            assert (out.intra_cost_est, out.intra_cost_est_aq) == (oo.intra_cost_est, oo.intra_cost_est_aq)
+    return len(fields)
+
+
+@pytest.mark.parametrize("cfgname", list(CONFIGS))
+@pytest.mark.parametrize("clipname", ["pan", "fastpan", "noise", "static"])
+def test_eval_sequence(cfgname, clipname):
+    depth = CONFIGS[cfgname][0]
+    W, H, nf = (352, 288, 4) if clipname == "pan" else (176, 144, 4)
+    frames = clip(clipname, W, H, nf, depth)
+    o, cfg, ctx = _mk(*CONFIGS[cfgname], W, H)
+    try:
+        assert _run_sequence(o, cfg, ctx, frames) >= 4
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("cfgname", ["hex_r4", "hex_10bit"])
+def test_weighted_search(cfgname):
+    depth = CONFIGS[cfgname][0]
+    frames = clip("fade", 176, 144, 4, depth)
+    o, cfg, ctx = _mk(*CONFIGS[cfgname], 176, 144)
+    try:
+        weights = {(1, 0): (1, 55, 6, 3), (2, 0): (1, 100, 7, -4), (3, 2): (1, 3, 0, -2)}
+        _run_sequence(o, cfg, ctx, frames, weights)
+    finally:
+        ctx.close()
+
+
+def test_prefetch_does_not_change_results():
+    frames = clip("fastpan", 176, 144, 4)
+    o, cfg, ctx = _mk(*CONFIGS["hex_r4"], 176, 144)
+    try:
+        _run_sequence(o, cfg, ctx, frames, prefetch=True)
+        assert ctx.counters()[2] > 0  # speculative fields were actually used
+    finally:
+        ctx.close()
+
+
+def test_non_mod16_and_tiny():
+    for (W, H) in ((200, 120), (32, 32), (48, 16)):
+        frames = clip("fastpan", W, H, 3)
+        o, cfg, ctx = _mk(*CONFIGS["hex_r4"], W, H)
+        try:
+            _run_sequence(o, cfg, ctx, frames)
+        finally:
+            ctx.close()
+
+
+def test_weight_cost():
+    frames = clip("fade", 176, 144, 3)
+    o, cfg, ctx = _mk(*CONFIGS["hex_r4"], 176, 144)
+    try:
+        pls = []
+        for i in range(3):
+            ctx.frame_put(i, frames[i])
+            pls.append(o.lowres_init(cfg, frames[i]))
+        ic = o.intra_costs(cfg, pls[1])
+        for wt in (None, (1, 55, 6, 3), (1, 127, 7, -128), (1, 2, 0, 5)):
+            w = Weight(*wt) if wt else None
+            assert ctx.weight_cost(1, 0, wt) == o.weight_cost(cfg, pls[1], pls[0], w, ic)
+    finally:
+        ctx.close()
+
+
+def test_1080p_search_matches_oracle():
+    """Full BASELINE config-1 geometry (1920x1080, dia): one P and one B evaluation."""
+    W, H = 1920, 1080
+    frames = clip("fastpan", W, H, 3)
+    o, cfg, ctx = _mk(8, 0, 4, 16, 8, 1, 0, 3, W, H, mv_range=512)
+    try:
+        SEQ2 = [(0, 2, 2), (0, 2, 1)]
+        global SEQ
+        old, SEQ = SEQ, SEQ2
+        try:
+            _run_sequence(o, cfg, ctx, frames)
+        finally:
+            SEQ = old
+    finally:
+        ctx.close()

@@ -1,0 +1,36 @@
+"""Builds the HIP shared library in-tree (x264_amd/libx264hip.so) for gfx950.  hipcc cross-compiles
+without a GPU, so this runs on the build host; the .so travels to the GPU box with the snapshot."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = [os.path.join(HERE, "csrc", "x264hip.hip"), os.path.join(HERE, "csrc", "lookahead_host.cpp")]
+HDR = [os.path.join(HERE, "csrc", h) for h in ("device_common.h", "me_search.h", "la_kernels.h", "lookahead_host.h")] + \
+      [os.path.join(ROOT, "include", "x264hip.h")]
+OUT = os.path.join(HERE, "libx264hip.so")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in SRC + HDR)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    srcs = [s for s in SRC if os.path.exists(s)]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(HERE, "csrc"), "-o", OUT] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

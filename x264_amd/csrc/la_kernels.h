@@ -1,0 +1,555 @@
+// la_kernels.h -- the streaming / block-parallel kernels around the search: half-resolution planes,
+// adaptive-quant statistics, intra costs, weighted planes and costs, mode selection + reductions.
+#pragma once
+#include "device_common.h"
+
+// ---- M1: lowres planes (common/mc.c:458-507) + border (common/frame.c:535-554,627-631) ----------------
+// One thread -> 4 horizontally adjacent output pixels of all four planes, addressed in the PADDED
+// domain: border pixels are produced by clamping the lowres coordinate, so there is no second pass
+// and every store is a full, aligned 4-pixel vector.  Source coordinates clamp to the picture, which
+// reproduces the mod16 replication (frame.c:640-666) and the +1 row/column duplication (mc.c:466-468).
+template <typename T>
+__device__ __forceinline__ int avg2( int a, int b ) { return ( a + b + 1 ) >> 1; }
+
+template <typename T>
+__global__ __launch_bounds__( 256 ) void lowres_kernel( const T *__restrict__ src, int src_stride, int width, int height,
+                                                        T *__restrict__ planes, int plane_elems, int stride, int lw, int lh )
+{
+    const int pw4 = ( lw + 2 * LA_PAD ) >> 2;
+    const int X4 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int Y = blockIdx.y;
+    if( X4 >= pw4 )
+        return;
+    const int y = iclip3( Y - LA_PAD, 0, lh - 1 );
+    const T *r0 = src + (size_t)imin2( 2 * y, height - 1 ) * src_stride;
+    const T *r1 = src + (size_t)imin2( 2 * y + 1, height - 1 ) * src_stride;
+    const T *r2 = src + (size_t)imin2( 2 * y + 2, height - 1 ) * src_stride;
+    T o0[4], oh[4], ov[4], oc[4];
+    const int xb = X4 * 4 - LA_PAD;
+    if( xb >= 0 && 2 * ( xb + 3 ) + 2 < width )
+    {
+        // interior: columns 2xb .. 2xb+8 are in range; vector-load 8 pixels + 1 per row
+        int a[9], b[9], c[9];
+        T va[8], vb[8], vc[8];
+        __builtin_memcpy( va, r0 + 2 * xb, 8 * sizeof( T ) );
+        __builtin_memcpy( vb, r1 + 2 * xb, 8 * sizeof( T ) );
+        __builtin_memcpy( vc, r2 + 2 * xb, 8 * sizeof( T ) );
+#pragma unroll
+        for( int i = 0; i < 8; i++ ) { a[i] = va[i]; b[i] = vb[i]; c[i] = vc[i]; }
+        a[8] = r0[2 * xb + 8]; b[8] = r1[2 * xb + 8]; c[8] = r2[2 * xb + 8];
+        int t[9], u[9];
+#pragma unroll
+        for( int i = 0; i < 9; i++ ) { t[i] = ( a[i] + b[i] + 1 ) >> 1; u[i] = ( b[i] + c[i] + 1 ) >> 1; }
+#pragma unroll
+        for( int i = 0; i < 4; i++ )
+        {
+            o0[i] = (T)( ( t[2 * i] + t[2 * i + 1] + 1 ) >> 1 );
+            oh[i] = (T)( ( t[2 * i + 1] + t[2 * i + 2] + 1 ) >> 1 );
+            ov[i] = (T)( ( u[2 * i] + u[2 * i + 1] + 1 ) >> 1 );
+            oc[i] = (T)( ( u[2 * i + 1] + u[2 * i + 2] + 1 ) >> 1 );
+        }
+    }
+    else
+    {
+#pragma unroll
+        for( int i = 0; i < 4; i++ )
+        {
+            const int x = iclip3( xb + i, 0, lw - 1 );
+            const int x0 = imin2( 2 * x, width - 1 ), x1 = imin2( 2 * x + 1, width - 1 ), x2 = imin2( 2 * x + 2, width - 1 );
+            int t0 = ( r0[x0] + r1[x0] + 1 ) >> 1, t1 = ( r0[x1] + r1[x1] + 1 ) >> 1, t2 = ( r0[x2] + r1[x2] + 1 ) >> 1;
+            int u0 = ( r1[x0] + r2[x0] + 1 ) >> 1, u1 = ( r1[x1] + r2[x1] + 1 ) >> 1, u2 = ( r1[x2] + r2[x2] + 1 ) >> 1;
+            o0[i] = (T)( ( t0 + t1 + 1 ) >> 1 ); oh[i] = (T)( ( t1 + t2 + 1 ) >> 1 );
+            ov[i] = (T)( ( u0 + u1 + 1 ) >> 1 ); oc[i] = (T)( ( u1 + u2 + 1 ) >> 1 );
+        }
+    }
+    const size_t o = (size_t)Y * stride + X4 * 4; // padded origin: plane base + 0 is padded (−32,−32)
+    __builtin_memcpy( planes + o, o0, 4 * sizeof( T ) );
+    __builtin_memcpy( planes + plane_elems + o, oh, 4 * sizeof( T ) );
+    __builtin_memcpy( planes + 2 * (size_t)plane_elems + o, ov, 4 * sizeof( T ) );
+    __builtin_memcpy( planes + 3 * (size_t)plane_elems + o, oc, 4 * sizeof( T ) );
+}
+
+// plain x264_mc_functions_t.frame_init_lowres_core signature (mc.h:326-327): no borders, caller's layout
+template <typename T>
+__global__ __launch_bounds__( 256 ) void lowres_core_kernel( const T *__restrict__ src, T *d0, T *dh, T *dv, T *dc,
+                                                             long src_stride, long dst_stride, int w, int h )
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if( x >= w )
+        return;
+    const T *r0 = src + 2 * y * src_stride, *r1 = r0 + src_stride, *r2 = r1 + src_stride;
+    int t0 = ( r0[2 * x] + r1[2 * x] + 1 ) >> 1, t1 = ( r0[2 * x + 1] + r1[2 * x + 1] + 1 ) >> 1, t2 = ( r0[2 * x + 2] + r1[2 * x + 2] + 1 ) >> 1;
+    int u0 = ( r1[2 * x] + r2[2 * x] + 1 ) >> 1, u1 = ( r1[2 * x + 1] + r2[2 * x + 1] + 1 ) >> 1, u2 = ( r1[2 * x + 2] + r2[2 * x + 2] + 1 ) >> 1;
+    d0[y * dst_stride + x] = (T)( ( t0 + t1 + 1 ) >> 1 );
+    dh[y * dst_stride + x] = (T)( ( t1 + t2 + 1 ) >> 1 );
+    dv[y * dst_stride + x] = (T)( ( u0 + u1 + 1 ) >> 1 );
+    dc[y * dst_stride + x] = (T)( ( u1 + u2 + 1 ) >> 1 );
+}
+
+// ---- adaptive-quant statistics (encoder/ratecontrol.c:225-415, aq-mode 0/1) ----------------------------
+// One wave per 16x16 macroblock: luma sum / sum of squares (+ optional 8x8 chroma), energy -> Q8 inverse
+// qscale through the reference's log2 / exp2 look-up tables; frame totals accumulate with 64-bit atomics.
+struct AqLuts
+{
+    float log2_lut[128];
+    unsigned char exp2_lut[64];
+};
+
+__device__ __forceinline__ unsigned wave_sum_u32( unsigned v )
+{
+#pragma unroll
+    for( int o = 32; o > 0; o >>= 1 )
+        v += __shfl_xor( v, o );
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__( 64 ) void aq_kernel( const T *__restrict__ luma, int stride, int width, int height, int mb_w,
+                                                   const T *__restrict__ cb, const T *__restrict__ cr, int cstride,
+                                                   int aq_on, float strength, float log2_bias, const AqLuts *luts,
+                                                   uint16_t *inv_qscale, unsigned long long *frame_sums /* [0] sum [1] ssd */ )
+{
+    const int mx = blockIdx.x, my = blockIdx.y, lane = lane_id();
+    const int ly = lane >> 2, lx = ( lane & 3 ) * 4;
+    unsigned s = 0, q = 0;
+    {
+        const T *row = luma + (size_t)imin2( 16 * my + ly, height - 1 ) * stride;
+#pragma unroll
+        for( int i = 0; i < 4; i++ )
+        {
+            unsigned v = row[imin2( 16 * mx + lx + i, width - 1 )];
+            s += v; q += v * v;
+        }
+    }
+    s = wave_sum_u32( s ); q = wave_sum_u32( q );
+    unsigned energy = q - (unsigned)( ( (unsigned long long)s * s ) >> 8 );
+    if( cb )
+    {
+        const int cw = ( width + 1 ) >> 1, ch = ( height + 1 ) >> 1;
+        const int cy = imin2( 8 * my + ( lane >> 3 ), ch - 1 ), cx = imin2( 8 * mx + ( lane & 7 ), cw - 1 );
+        unsigned vb = cb[(size_t)cy * cstride + cx], vr = cr[(size_t)cy * cstride + cx];
+        unsigned sb = wave_sum_u32( vb ), qb = wave_sum_u32( vb * vb );
+        unsigned sr = wave_sum_u32( vr ), qr = wave_sum_u32( vr * vr );
+        energy += qb - (unsigned)( ( (unsigned long long)sb * sb ) >> 6 );
+        energy += qr - (unsigned)( ( (unsigned long long)sr * sr ) >> 6 );
+    }
+    if( lane == 0 )
+    {
+        atomicAdd( &frame_sums[0], (unsigned long long)s );
+        atomicAdd( &frame_sums[1], (unsigned long long)q );
+        int out = 256;
+        if( aq_on )
+        {
+            unsigned e = energy > 1 ? energy : 1;
+            int lz = __clz( e );
+            float l2 = __fadd_rn( luts->log2_lut[( e << lz >> 24 ) & 0x7f], (float)( 31 - lz ) );
+            float qp_adj = __fmul_rn( strength, __fsub_rn( l2, log2_bias ) );
+            int i = (int)__fadd_rn( __fmul_rn( qp_adj, -64.f / 6.f ), 512.5f );
+            out = i < 0 ? 0 : i > 1023 ? 0xffff : ( ( luts->exp2_lut[i & 63] + 256 ) << ( i >> 6 ) >> 8 );
+        }
+        inv_qscale[my * mb_w + mx] = (uint16_t)out;
+    }
+}
+
+// ---- lowres intra cost (encoder/slicetype.c:714-757; predictors common/predict.c:221-308,632-884) ----
+// One wave per 8x8 block, 4 prediction modes per pass (one per 16-lane group).  The 17+8 neighbours
+// and their low-pass filtered versions sit in LDS; every lane derives its 4 predicted pixels directly
+// from the H.264 per-pixel formulas.
+struct IntraEdges
+{
+    int top[18];  // top[i+1] = p[i,-1], i = -1..15 (top[0] is the corner); top[17] pad
+    int left[8];  // p[-1,y]
+    int ft[18];   // filtered: ft[i+1] = p'[i,-1], ft[0] = p'[-1,-1]
+    int fl[8];    // filtered left p'[-1,y]
+};
+
+__device__ __forceinline__ int f3( int a, int b, int c ) { return ( a + 2 * b + c + 2 ) >> 2; }
+__device__ __forceinline__ int f2( int a, int b ) { return ( a + b + 1 ) >> 1; }
+
+__device__ __forceinline__ int intra_pred_px( const IntraEdges &E, int mode, int x, int y, int pixel_max )
+{
+#define TT( i ) E.ft[( i ) + 1]
+#define LL( i ) ( ( i ) < 0 ? E.ft[0] : E.fl[( i )] )
+    switch( mode )
+    {
+        case 0: // 8x8 chroma-style DC, four quadrants
+        {
+            int t0 = E.top[1] + E.top[2] + E.top[3] + E.top[4], t1 = E.top[5] + E.top[6] + E.top[7] + E.top[8];
+            int l0 = E.left[0] + E.left[1] + E.left[2] + E.left[3], l1 = E.left[4] + E.left[5] + E.left[6] + E.left[7];
+            return y < 4 ? ( x < 4 ? ( t0 + l0 + 4 ) >> 3 : ( t1 + 2 ) >> 2 ) : ( x < 4 ? ( l1 + 2 ) >> 2 : ( t1 + l1 + 4 ) >> 3 );
+        }
+        case 1: return E.left[y];
+        case 2: return E.top[x + 1];
+        case 3: // plane
+        {
+            int H = 0, V = 0;
+#pragma unroll
+            for( int i = 1; i <= 4; i++ )
+            {
+                H += i * ( E.top[3 + i + 1] - E.top[3 - i + 1] );
+                V += i * ( E.left[3 + i] - ( 3 - i < 0 ? E.top[0] : E.left[3 - i] ) );
+            }
+            int a = 16 * ( E.left[7] + E.top[8] ), b = ( 17 * H + 16 ) >> 5, c = ( 17 * V + 16 ) >> 5;
+            return iclip3( ( a + b * ( x - 3 ) + c * ( y - 3 ) + 16 ) >> 5, 0, pixel_max );
+        }
+        case 4: // diagonal down-left
+            return ( x == 7 && y == 7 ) ? ( TT( 14 ) + 3 * TT( 15 ) + 2 ) >> 2 : f3( TT( x + y ), TT( x + y + 1 ), TT( x + y + 2 ) );
+        case 5: // diagonal down-right
+            if( x > y ) return f3( TT( x - y - 2 ), TT( x - y - 1 ), TT( x - y ) );
+            if( x < y ) return f3( LL( y - x - 2 ), LL( y - x - 1 ), LL( y - x ) );
+            return f3( TT( 0 ), TT( -1 ), LL( 0 ) );
+        case 6: // vertical right
+        {
+            int z = 2 * x - y, k = x - ( y >> 1 );
+            if( z >= 0 && !( z & 1 ) ) return f2( TT( k - 1 ), TT( k ) );
+            if( z >= 0 ) return f3( TT( k - 2 ), TT( k - 1 ), TT( k ) );
+            if( z == -1 ) return f3( LL( 0 ), TT( -1 ), TT( 0 ) );
+            return f3( LL( y - 2 * x - 1 ), LL( y - 2 * x - 2 ), LL( y - 2 * x - 3 ) );
+        }
+        case 7: // horizontal down
+        {
+            int z = 2 * y - x, k = y - ( x >> 1 );
+            if( z >= 0 && !( z & 1 ) ) return f2( LL( k - 1 ), LL( k ) );
+            if( z >= 0 ) return f3( LL( k - 2 ), LL( k - 1 ), LL( k ) );
+            if( z == -1 ) return f3( LL( 0 ), TT( -1 ), TT( 0 ) );
+            return f3( TT( x - 2 * y - 1 ), TT( x - 2 * y - 2 ), TT( x - 2 * y - 3 ) );
+        }
+        case 8: // vertical left
+        {
+            int k = x + ( y >> 1 );
+            return ( y & 1 ) ? f3( TT( k ), TT( k + 1 ), TT( k + 2 ) ) : f2( TT( k ), TT( k + 1 ) );
+        }
+        default: // 9: horizontal up
+        {
+            int z = x + 2 * y, k = y + ( x >> 1 );
+            if( z > 13 ) return E.fl[7];
+            if( z == 13 ) return ( E.fl[6] + 3 * E.fl[7] + 2 ) >> 2;
+            return ( z & 1 ) ? f3( E.fl[k], E.fl[k + 1], E.fl[k + 2] ) : f2( E.fl[k], E.fl[k + 1] );
+        }
+    }
+#undef TT
+#undef LL
+}
+
+template <typename T>
+__global__ __launch_bounds__( 64 ) void intra_kernel( LaP P, const T *__restrict__ fenc0, uint16_t *intra_cost )
+{
+    __shared__ IntraEdges E;
+    const int lane = lane_id();
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const T *src = fenc0 + 8 * ( by * P.stride + bx );
+    if( lane < 17 )
+        E.top[lane] = src[-P.stride + lane - 1];
+    else if( lane >= 32 && lane < 40 )
+        E.left[lane - 32] = src[( lane - 32 ) * P.stride - 1];
+    __syncthreads();
+    if( lane < 17 )
+    {
+        // ft[lane] = p'[lane-1,-1]: corner, t0..t15 (predict.c:632-675 with all neighbours available)
+        int i = lane - 1, v;
+        if( i < 0 ) v = f3( E.top[1], E.top[0], E.left[0] );
+        else if( i == 15 ) v = ( E.top[15] + 3 * E.top[16] + 2 ) >> 2;
+        else v = f3( E.top[i], E.top[i + 1], E.top[i + 2] );
+        E.ft[lane] = v;
+    }
+    else if( lane >= 32 && lane < 40 )
+    {
+        int y = lane - 32, v;
+        if( y == 7 ) v = ( E.left[6] + 3 * E.left[7] + 2 ) >> 2;
+        else v = f3( y == 0 ? E.top[0] : E.left[y - 1], E.left[y], E.left[y + 1] );
+        E.fl[y] = v;
+    }
+    __syncthreads();
+    const int g = lane >> 4, l = lane & 15, q = l >> 2;
+    const int tx = ( q & 1 ) * 4, row = ( q >> 1 ) * 4 + ( l & 3 );
+    int f[4];
+    load4( src + row * P.stride + tx, f );
+    int best = COST_MAX_I;
+    const int n_modes = P.subme > 1 ? 10 : 3;
+    for( int m0 = 0; m0 < n_modes; m0 += 4 )
+    {
+        const int mode = imin2( m0 + g, 9 );
+        int d[4];
+#pragma unroll
+        for( int i = 0; i < 4; i++ )
+            d[i] = f[i] - intra_pred_px( E, mode, tx + i, row, P.pixel_max );
+        int v = block_cost8x8( d, P.mbcmp_satd );
+#pragma unroll
+        for( int k = 0; k < 4; k++ )
+            if( m0 + k < n_modes )
+                best = imin2( best, __builtin_amdgcn_readlane( v, 16 * k ) );
+    }
+    if( lane == 0 )
+        intra_cost[by * P.mb_w + bx] = (uint16_t)( ( ( best + 5 * P.lambda ) >> P.depth_shift ) + 4 );
+}
+
+// ---- explicit weights: weighted copy of padded plane 0 (slicetype.c:490-500, mc.c:117-160) -------------
+template <typename T>
+__global__ __launch_bounds__( 256 ) void weight_plane_kernel( const T *__restrict__ src, T *__restrict__ dst, int n, WtD w, int pixel_max )
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if( i < n )
+        dst[i] = (T)weight_px( src[i], w, pixel_max );
+}
+
+// weight_cost_luma (slicetype.c:191-222): four blocks per wave, sum of min( mbcmp, intra_cost )
+template <typename T>
+__global__ __launch_bounds__( 64 ) void weight_cost_kernel( LaP P, const T *__restrict__ fenc0, const T *__restrict__ ref0, WtD w,
+                                                            const uint16_t *__restrict__ intra_cost, unsigned *out )
+{
+    const int lane = lane_id();
+    const int g = lane >> 4, l = lane & 15, q = l >> 2;
+    const int tx = ( q & 1 ) * 4, row = ( q >> 1 ) * 4 + ( l & 3 );
+    const int n_mb = P.mb_w * P.mb_h;
+    const int xy = ( blockIdx.x * 4 + g );
+    int c = 0;
+    const int xyc = imin2( xy, n_mb - 1 );
+    const int bx = xyc % P.mb_w, by = xyc / P.mb_w;
+    const int off = 8 * ( by * P.stride + bx ) + row * P.stride + tx;
+    int f[4], r[4], d[4];
+    load4( fenc0 + off, f );
+    load4( ref0 + off, r );
+#pragma unroll
+    for( int i = 0; i < 4; i++ )
+        d[i] = ( w.on ? weight_px( r[i], w, P.pixel_max ) : r[i] ) - f[i];
+    c = imin2( block_cost8x8( d, P.mbcmp_satd ), (int)intra_cost[xyc] );
+    unsigned tot = 0;
+#pragma unroll
+    for( int k = 0; k < 4; k++ )
+        if( blockIdx.x * 4 + k < n_mb )
+            tot += (unsigned)__builtin_amdgcn_readlane( c, 16 * k );
+    if( lane == 0 )
+        atomicAdd( out, tot );
+}
+
+// ---- mode selection and reductions (slicetype.c:616-652,708-712,758-790,946-985) ----------------------
+struct CellArgs
+{
+    int b_bidir, dist_scale_factor, with_intra, is_intra_only, ref1_l0_valid;
+    const unsigned long long *mvq0, *mvq1, *ref1_l0; // granule arrays (low 32 bits = packed mv)
+    const int *costs0, *costs1;
+    const uint16_t *intra_cost;   // may alias lowres_costs for the intra-only cell (frame.c:283)
+    const uint16_t *inv_qscale;
+    uint16_t *lowres_costs;
+    int *row_satds, *row_satds_intra;
+    int *acc;                     // [5]: cost_est, cost_est_aq, intra_mbs, intra_cost_est, intra_cost_est_aq
+};
+
+__device__ __forceinline__ void cell_finish( const LaP &P, const CellArgs &A, int bx, int by, int xy, int bcost, int list_used )
+{
+    // executed by ONE lane per block
+    const int W = P.mb_w, H = P.mb_h;
+    const bool scored = ( bx > 0 && bx < W - 1 && by > 0 && by < H - 1 ) || W <= 2 || H <= 2;
+    const int icost = A.intra_cost[xy];
+    const int inv = P.aq_mode ? A.inv_qscale[xy] : 256;
+    if( A.with_intra )
+    {
+        int icost_aq = P.aq_mode ? ( icost * inv + 128 ) >> 8 : icost;
+        atomicAdd( &A.row_satds_intra[by], icost_aq );
+        if( scored ) { atomicAdd( &A.acc[3], icost ); atomicAdd( &A.acc[4], icost_aq ); }
+    }
+    bcost = ( bcost >> P.depth_shift ) + 4;
+    if( !A.b_bidir )
+    {
+        int b_intra = icost < bcost;
+        if( b_intra ) { bcost = icost; list_used = 0; }
+        if( scored && b_intra ) atomicAdd( &A.acc[2], 1 );
+    }
+    if( !A.is_intra_only )
+    {
+        int bcost_aq = P.aq_mode ? ( bcost * inv + 128 ) >> 8 : bcost;
+        atomicAdd( &A.row_satds[by], bcost_aq );
+        if( scored ) { atomicAdd( &A.acc[0], bcost ); atomicAdd( &A.acc[1], bcost_aq ); }
+    }
+    A.lowres_costs[xy] = (uint16_t)( imin2( bcost, 0x3FFF ) + ( list_used << 14 ) );
+}
+
+// P and intra-only cells: no pixel work, one thread per block
+__global__ __launch_bounds__( 256 ) void cell_p_kernel( LaP P, CellArgs A )
+{
+    const int xy = blockIdx.x * blockDim.x + threadIdx.x;
+    if( xy >= P.mb_w * P.mb_h )
+        return;
+    const int bx = xy % P.mb_w, by = xy / P.mb_w;
+    int bcost = COST_MAX_I, list_used = 0;
+    if( !A.is_intra_only )
+    {
+        int c0 = A.costs0[xy];
+        if( c0 < bcost ) { bcost = c0; list_used = 1; }
+    }
+    cell_finish( P, A, bx, by, xy, bcost, list_used );
+}
+
+// B cells: one wave per block; groups 0..2 evaluate the three bidirectional candidates in parallel
+template <typename T>
+__global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, CellArgs A, const T *__restrict__ fenc0, const T *__restrict__ ref0_0,
+                                                       const T *__restrict__ ref1_0 )
+{
+    const int lane = lane_id();
+    const int bx = blockIdx.x, by = blockIdx.y, xy = by * P.mb_w + bx;
+    const int g = lane >> 4, l = lane & 15, q = l >> 2;
+    const int tx = ( q & 1 ) * 4, row = ( q >> 1 ) * 4 + ( l & 3 );
+    const int off = 8 * ( by * P.stride + bx );
+    const int bipred_weight = P.weighted_bipred ? 64 - ( A.dist_scale_factor >> 2 ) : 32;
+    const int range = 2 * P.mv_range;
+    const int smin_x = imax2( 4 * ( -8 * bx - 12 ), -range ), smax_x = imin2( 4 * ( 8 * ( P.mb_w - bx - 1 ) + 12 ), range - 1 );
+    const int smin_y = imax2( 4 * ( -8 * by - 12 ), -range ), smax_y = imin2( 4 * ( 8 * ( P.mb_h - by - 1 ) + 12 ), range - 1 );
+    // candidate vectors (wave uniform)
+    int d0x = 0, d0y = 0, d1x = 0, d1y = 0;
+    if( A.ref1_l0_valid )
+    {
+        const int w = (int)(unsigned)A.ref1_l0[xy];
+        const int rx = (int)(short)( w & 0xFFFF ), ry = w >> 16;
+        d0x = ( rx * A.dist_scale_factor + 128 ) >> 8;
+        d0y = ( ry * A.dist_scale_factor + 128 ) >> 8;
+        d1x = d0x - rx; d1y = d0y - ry;
+        d0x = iclip3( d0x, smin_x, smax_x ); d0y = iclip3( d0y, smin_y, smax_y );
+        d1x = iclip3( d1x, smin_x, smax_x ); d1y = iclip3( d1y, smin_y, smax_y );
+        if( P.subme <= 1 ) { d0x &= ~1; d0y &= ~1; d1x &= ~1; d1y &= ~1; }
+    }
+    const int w0 = (int)(unsigned)A.mvq0[xy], w1 = (int)(unsigned)A.mvq1[xy];
+    int m0x = (int)(short)( w0 & 0xFFFF ), m0y = w0 >> 16, m1x = (int)(short)( w1 & 0xFFFF ), m1y = w1 >> 16;
+    const bool dmv_nz = ( d0x | d0y | d1x | d1y ) != 0, mv_nz = ( m0x | m0y | m1x | m1y ) != 0;
+    // group g's pair: 0 -> direct-style (dmv), 1 -> zero, 2/3 -> searched vectors
+    int ax = sel4( g, d0x, 0, m0x, m0x ), ay = sel4( g, d0y, 0, m0y, m0y );
+    int cx = sel4( g, d1x, 0, m1x, m1x ), cy = sel4( g, d1y, 0, m1y, m1y );
+    if( P.subme <= 1 ) { ax &= ~1; ay &= ~1; cx &= ~1; cy &= ~1; } // half-pel plane pick (slicetype.c:582-589)
+    int f[4], ra[4], rb[4], d[4];
+    load4( fenc0 + off + row * P.stride + tx, f );
+    qpel4( ref0_0 + off, P.plane_elems, P.stride, tx, row, ax, ay, ra );
+    qpel4( ref1_0 + off, P.plane_elems, P.stride, tx, row, cx, cy, rb );
+#pragma unroll
+    for( int i = 0; i < 4; i++ )
+    {
+        int v = bipred_weight == 32 ? ( ra[i] + rb[i] + 1 ) >> 1
+                                    : iclip3( ( ra[i] * bipred_weight + rb[i] * ( 64 - bipred_weight ) + 32 ) >> 6, 0, P.pixel_max );
+        d[i] = f[i] - v;
+    }
+    const int v = block_cost8x8( d, P.mbcmp_satd );
+    int bcost = COST_MAX_I, list_used = 0;
+    {
+        int c = __builtin_amdgcn_readlane( v, 0 );
+        if( c < bcost ) { bcost = c; list_used = 3; }
+    }
+    if( dmv_nz )
+    {
+        int c = __builtin_amdgcn_readlane( v, 16 );
+        if( c < bcost ) { bcost = c; list_used = 3; }
+    }
+    {
+        int c0 = A.costs0[xy], c1 = A.costs1[xy];
+        if( c0 < bcost ) { bcost = c0; list_used = 1; }
+        if( c1 < bcost ) { bcost = c1; list_used = 2; }
+    }
+    if( mv_nz )
+    {
+        int c = 5 * P.lambda + __builtin_amdgcn_readlane( v, 32 );
+        if( c < bcost ) { bcost = c; list_used = 3; }
+    }
+    if( lane == 0 )
+        cell_finish( P, A, bx, by, xy, bcost, list_used );
+}
+
+// ---- batched vtable primitives: SAD / SATD of every block of a plane against a displaced reference ----
+// One wave covers a 16x16 pixel region: a 16-lane row is an 8x8 quadrant, a DPP quad a 4x4 tile, so all
+// three block sizes reduce without LDS: 4x4 -> quad, 8x8 -> row, 16x16 -> the four rows of the wave.
+template <typename T>
+__global__ __launch_bounds__( 64 ) void pixel_cmp_batch_kernel( const T *__restrict__ fenc, const T *__restrict__ ref, int stride,
+                                                                int regions_w, int regions_h, int size /* 16, 8, 4 */, int use_satd,
+                                                                const int16_t *__restrict__ mv, int *__restrict__ out )
+{
+    const int lane = lane_id();
+    const int rx = blockIdx.x, ry = blockIdx.y;
+    const int g = lane >> 4, l = lane & 15, q = l >> 2;
+    // quadrant g at ((g&1)*8, (g>>1)*8); inside it the usual tile/row split
+    const int px = ( g & 1 ) * 8 + ( q & 1 ) * 4, py = ( g >> 1 ) * 8 + ( q >> 1 ) * 4 + ( l & 3 );
+    const int bpr = 16 / size; // blocks per region side
+    const int bw = regions_w * bpr;
+    const int bxi = rx * bpr + px / size, byi = ry * bpr + py / size;
+    const int bi = byi * bw + bxi;
+    const int mvx = mv[2 * bi], mvy = mv[2 * bi + 1];
+    int f[4], r[4], d[4];
+    const size_t o = (size_t)( ry * 16 + py ) * stride + rx * 16 + px;
+    load4( fenc + o, f );
+    load4( ref + o + mvy * stride + mvx, r );
+#pragma unroll
+    for( int i = 0; i < 4; i++ )
+        d[i] = f[i] - r[i];
+    int part = use_satd ? satd_tile_partial( d ) : iabs( d[0] ) + iabs( d[1] ) + iabs( d[2] ) + iabs( d[3] );
+    part = reduce_quad( part );
+    if( size == 4 )
+    {
+        if( ( lane & 3 ) == 0 )
+            out[bi] = use_satd ? part >> 1 : part;
+        return;
+    }
+    part += dpp_mov<DPP_ROW_ROR4>( part );
+    part += dpp_mov<DPP_ROW_ROR8>( part );
+    if( size == 8 )
+    {
+        if( l == 0 )
+            out[bi] = use_satd ? part >> 1 : part;
+        return;
+    }
+    int tot = __builtin_amdgcn_readlane( part, 0 ) + __builtin_amdgcn_readlane( part, 16 ) + __builtin_amdgcn_readlane( part, 32 ) +
+              __builtin_amdgcn_readlane( part, 48 );
+    if( lane == 0 )
+        out[bi] = use_satd ? tot >> 1 : tot;
+}
+
+// ---- D1/Q1 as batched primitives (common/dct.c:157-205,332-386, common/quant.c:50-104) -----------------
+// One thread per 4x4 (or 8x8) block; parity/microbench entry, not a production path.
+template <typename T, typename C>
+__device__ __forceinline__ void fdct4_1d_dev( const int *in, int step, int *out, int ostep )
+{
+    int s03 = in[0] + in[3 * step], s12 = in[step] + in[2 * step], d03 = in[0] - in[3 * step], d12 = in[step] - in[2 * step];
+    out[0] = s03 + s12; out[ostep] = 2 * d03 + d12; out[2 * ostep] = s03 - s12; out[3 * ostep] = d03 - 2 * d12;
+}
+__device__ __forceinline__ void fdct8_1d_dev( const int *in, int step, int *out, int ostep )
+{
+    int s07 = in[0] + in[7 * step], s16 = in[step] + in[6 * step], s25 = in[2 * step] + in[5 * step], s34 = in[3 * step] + in[4 * step];
+    int d07 = in[0] - in[7 * step], d16 = in[step] - in[6 * step], d25 = in[2 * step] - in[5 * step], d34 = in[3 * step] - in[4 * step];
+    int e0 = s07 + s34, e1 = s16 + s25, e2 = s07 - s34, e3 = s16 - s25;
+    int o4 = d16 + d25 + ( d07 + ( d07 >> 1 ) ), o5 = d07 - d34 - ( d25 + ( d25 >> 1 ) );
+    int o6 = d07 + d34 - ( d16 + ( d16 >> 1 ) ), o7 = d16 - d25 + ( d34 + ( d34 >> 1 ) );
+    out[0] = e0 + e1; out[ostep] = o4 + ( o7 >> 2 ); out[2 * ostep] = e2 + ( e3 >> 1 ); out[3 * ostep] = o5 + ( o6 >> 2 );
+    out[4 * ostep] = e0 - e1; out[5 * ostep] = o6 - ( o5 >> 2 ); out[6 * ostep] = ( e2 >> 1 ) - e3; out[7 * ostep] = ( o4 >> 2 ) - o7;
+}
+
+template <typename T, typename C, typename U>
+__global__ __launch_bounds__( 64 ) void dct_quant_kernel( int is8, int n_blocks, const T *__restrict__ fenc, const T *__restrict__ fdec,
+                                                          const U *__restrict__ mf, const U *__restrict__ bias, C *__restrict__ coefs, int *nz_out )
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if( i >= n_blocks )
+        return;
+    const int N = is8 ? 8 : 4;
+    const T *fe = fenc + (size_t)i * N * 16, *fd = fdec + (size_t)i * N * 32;
+    int d[64], t[64], o[64];
+    for( int y = 0; y < N; y++ )
+        for( int x = 0; x < N; x++ )
+            d[N * y + x] = fe[y * 16 + x] - fd[y * 32 + x];
+    if( is8 )
+    {
+        for( int x = 0; x < 8; x++ ) fdct8_1d_dev( d + x, 8, t + x, 8 );
+        for( int v = 0; v < 8; v++ ) fdct8_1d_dev( t + 8 * v, 1, o + v, 8 );
+    }
+    else
+    {
+        for( int y = 0; y < 4; y++ ) fdct4_1d_dev<T, C>( d + 4 * y, 1, t + y, 4 );
+        for( int u = 0; u < 4; u++ ) fdct4_1d_dev<T, C>( t + 4 * u, 1, o + 4 * u, 1 );
+    }
+    int nz = 0;
+    for( int k = 0; k < N * N; k++ )
+    {
+        C c = (C)o[k];
+        int v = c;
+        unsigned m = mf[k], b = bias[k];
+        if( v > 0 ) v = (int)( ( b + (unsigned)v ) * m >> 16 );
+        else v = -(int)( ( b + (unsigned)( -v ) ) * m >> 16 );
+        c = (C)v;
+        nz |= c;
+        coefs[(size_t)i * N * N + k] = c;
+    }
+    nz_out[i] = nz != 0;
+}

@@ -1,0 +1,723 @@
+// x264hip.hip -- device context and C ABI (include/x264hip.h) of the gfx950 lookahead path.
+//
+// Data layout in HBM, per frame slot (all resident for the life of the frame in the lookahead window):
+//   planes      4 x (lines+64) x stride pixels   half-res luma: full, H, V, HV half-pel planes incl. 32 px border
+//   luma        height x width pixels            staging copy of the input luma (source of lowres + AQ)
+//   inv_qscale  n_mb u16                         Q8 AQ factors (input of the cost_est_aq / row satd sums)
+//   mvq[l][d]   n_mb u64 granules {mv, tag}      lowres_mvs[l][d] of the reference + in-kernel hand-off tag
+//   mvcost[l][d] n_mb i32                        lowres_mv_costs[l][d]
+//   lowres_costs[d0][d1] n_mb u16                cell maps; [0][0] doubles as i_intra_cost (frame.c:283)
+//   row_satds[d0][d1] mb_h i32
+// plus per-slot weighted copies of a reference's plane 0, taken from a small pool.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+
+#include "x264hip.h"
+#include "device_common.h"
+#include "me_search.h"
+#include "la_kernels.h"
+
+#define HIPCK( call )                                                                                        \
+    do {                                                                                                     \
+        hipError_t e_ = ( call );                                                                            \
+        if( e_ != hipSuccess )                                                                               \
+        {                                                                                                    \
+            fprintf( stderr, "x264hip: %s failed: %s (%s:%d)\n", #call, hipGetErrorString( e_ ), __FILE__, __LINE__ ); \
+            ctx->broken = 1;                                                                                 \
+            return X264HIP_EDEVICE;                                                                          \
+        }                                                                                                    \
+    } while( 0 )
+
+struct FrameSlot
+{
+    int in_use = 0;
+    int frame_no = -1;
+    char *planes = nullptr;       // padded planes base (4 planes)
+    char *luma = nullptr;
+    uint16_t *inv_qscale = nullptr;
+    unsigned long long *frame_sums = nullptr;
+    unsigned long long *mvq[2][X264HIP_BFRAME_MAX + 1];
+    int *mvcost[2][X264HIP_BFRAME_MAX + 1];
+    uint16_t *lowres_costs = nullptr; // [(bf+2)*(bf+2)][n_mb]
+    int *row_satds = nullptr;         // [(bf+2)*(bf+2)][mb_h]
+    // host-side state of the device fields
+    unsigned char field_ready[2][X264HIP_BFRAME_MAX + 1]; // searched (any variant) and complete on the stream
+    unsigned char field_prefetched[2][X264HIP_BFRAME_MAX + 1]; // unweighted field computed speculatively, not yet claimed
+    int wplane_idx = -1;          // weighted-plane pool entry in use by this slot's current weighted search
+    uint64_t sum = 0, ssd = 0;
+    int stats_valid = 0;
+};
+
+struct x264hip_ctx
+{
+    x264hip_params p;
+    LaP P;
+    int device = 0;
+    int broken = 0;
+    int psz = 1;                  // sizeof(pixel)
+    int lw = 0, lh = 0;           // lowres dims (mod16 / 2)
+    int n_mb = 0;
+    size_t plane_bytes = 0;
+    hipStream_t stream = nullptr;
+    std::vector<FrameSlot> slots;
+    uint16_t *cost_mv_dev = nullptr; // base (not centred)
+    AqLuts *luts_dev = nullptr;
+    unsigned *sync_words = nullptr;  // device [2]
+    int *acc_dev = nullptr;          // [8]
+    int *acc_host = nullptr;         // pinned [8]
+    unsigned *sync_host = nullptr;   // pinned [2]
+    void *desc_dev = nullptr;        // SearchDesc array
+    void *desc_host = nullptr;       // pinned
+    int desc_cap = 0;
+    unsigned *wcost_dev = nullptr;
+    unsigned *wcost_host = nullptr;
+    char *staging = nullptr;         // pinned luma staging
+    size_t staging_bytes = 0;
+    std::vector<char *> wplanes;     // weighted plane pool
+    std::vector<int> wplane_owner;
+    unsigned tag_serial = 1;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    int last_n_search = 0, last_n_blocks = 0, ev_valid = 0;
+    uint64_t counters[8] = { 0 };
+};
+
+static const char *const g_errstr[] = { "ok", "no usable HIP device", "invalid argument", "out of memory", "device failure",
+                                        "in-kernel wait timed out", "bad call sequence" };
+extern "C" const char *x264hip_strerror( int code )
+{
+    int i = -code;
+    return i >= 0 && i < 7 ? g_errstr[i] : "unknown";
+}
+
+template <typename T>
+static inline T *plane_origin( x264hip_ctx *ctx, FrameSlot &s, int p )
+{
+    return (T *)( s.planes + (size_t)p * ctx->plane_bytes ) + LA_PAD * ctx->P.stride + LA_PAD;
+}
+
+static void free_all( x264hip_ctx *ctx )
+{
+    if( ctx->stream ) (void)hipStreamSynchronize( ctx->stream );
+    for( auto &s : ctx->slots )
+    {
+        (void)hipFree( s.planes ); // one allocation per slot holds everything
+    }
+    for( auto w : ctx->wplanes ) (void)hipFree( w );
+    (void)hipFree( ctx->cost_mv_dev ); (void)hipFree( ctx->luts_dev ); (void)hipFree( ctx->sync_words ); (void)hipFree( ctx->acc_dev );
+    (void)hipFree( ctx->desc_dev ); (void)hipFree( ctx->wcost_dev );
+    (void)hipHostFree( ctx->acc_host ); (void)hipHostFree( ctx->sync_host ); (void)hipHostFree( ctx->desc_host );
+    (void)hipHostFree( ctx->wcost_host ); (void)hipHostFree( ctx->staging );
+    if( ctx->ev_start ) (void)hipEventDestroy( ctx->ev_start );
+    if( ctx->ev_stop ) (void)hipEventDestroy( ctx->ev_stop );
+    if( ctx->stream ) (void)hipStreamDestroy( ctx->stream );
+}
+
+extern "C" void x264hip_close( x264hip_ctx *ctx )
+{
+    if( !ctx ) return;
+    free_all( ctx );
+    delete ctx;
+}
+
+static size_t align_up( size_t v, size_t a ) { return ( v + a - 1 ) / a * a; }
+
+extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params *params )
+{
+    if( !out || !params ) return X264HIP_EINVAL;
+    *out = nullptr;
+    const x264hip_params &p = *params;
+    if( ( p.bit_depth != 8 && p.bit_depth != 10 ) || p.width < 16 || p.height < 16 || p.bframes < 0 || p.bframes > X264HIP_BFRAME_MAX ||
+        !p.cost_mv || p.mv_range < 1 || ( p.subpel_refine != 2 && p.subpel_refine != 4 ) || p.max_frames < 2 ||
+        ( p.me_method != X264HIP_ME_DIA && p.me_method != X264HIP_ME_HEX ) || ( p.aq_mode != 0 && p.aq_mode != 1 ) )
+        return X264HIP_EINVAL;
+    int ndev = 0;
+    if( hipGetDeviceCount( &ndev ) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev )
+    {
+        fprintf( stderr, "x264hip: no usable HIP device (count=%d); this path has no CPU fallback\n", ndev );
+        return X264HIP_ENODEV;
+    }
+    if( hipSetDevice( device ) != hipSuccess )
+        return X264HIP_ENODEV;
+    x264hip_ctx *ctx = new x264hip_ctx();
+    ctx->p = p;
+    ctx->p.cost_mv = nullptr;
+    ctx->device = device;
+    ctx->psz = p.bit_depth == 8 ? 1 : 2;
+    const int mb_w = ( p.width + 15 ) / 16, mb_h = ( p.height + 15 ) / 16;
+    ctx->lw = 8 * mb_w; ctx->lh = 8 * mb_h; ctx->n_mb = mb_w * mb_h;
+    LaP &P = ctx->P;
+    P.mb_w = mb_w; P.mb_h = mb_h;
+    P.stride = (int)align_up( ctx->lw + 2 * LA_PAD, 64 );
+    P.plane_elems = P.stride * ( ctx->lh + 2 * LA_PAD );
+    ctx->plane_bytes = (size_t)P.plane_elems * ctx->psz;
+    P.lambda = p.lambda; P.me_method = p.me_method; P.subpel_refine = p.subpel_refine; P.me_range = p.me_range;
+    P.mv_range = p.mv_range; P.subme = p.subme; P.mbcmp_satd = p.mbcmp_satd; P.fpelcmp_satd = p.fpelcmp_satd;
+    P.weighted_bipred = p.weighted_bipred; P.aq_mode = p.aq_mode; P.depth_shift = p.bit_depth - 8;
+    P.pixel_max = ( 1 << p.bit_depth ) - 1;
+
+#define OPENCK( call ) do { if( ( call ) != hipSuccess ) { fprintf( stderr, "x264hip_open: %s failed\n", #call ); free_all( ctx ); delete ctx; return X264HIP_ENOMEM; } } while( 0 )
+    OPENCK( hipStreamCreateWithFlags( &ctx->stream, hipStreamNonBlocking ) );
+    OPENCK( hipEventCreate( &ctx->ev_start ) );
+    OPENCK( hipEventCreate( &ctx->ev_stop ) );
+    const int n_tab = 2 * 4 * p.mv_range;
+    OPENCK( hipMalloc( &ctx->cost_mv_dev, ( 2 * n_tab + 1 ) * sizeof( uint16_t ) ) );
+    OPENCK( hipMemcpy( ctx->cost_mv_dev, p.cost_mv - n_tab, ( 2 * n_tab + 1 ) * sizeof( uint16_t ), hipMemcpyHostToDevice ) );
+    P.cost_mv = ctx->cost_mv_dev + n_tab;
+    {
+        // the reference's 5-decimal log2 table and 8-bit exp2 table (common/tables.c:58-90), regenerated
+        AqLuts l;
+        for( int i = 0; i < 128; i++ ) l.log2_lut[i] = (float)( floor( log2( 1.0 + i / 128.0 ) * 100000.0 + 0.5 ) / 100000.0 );
+        for( int i = 0; i < 64; i++ ) l.exp2_lut[i] = (unsigned char)floor( ( pow( 2.0, i / 64.0 ) - 1.0 ) * 256.0 + 0.5 );
+        OPENCK( hipMalloc( &ctx->luts_dev, sizeof( AqLuts ) ) );
+        OPENCK( hipMemcpy( ctx->luts_dev, &l, sizeof( l ), hipMemcpyHostToDevice ) );
+    }
+    OPENCK( hipMalloc( &ctx->sync_words, 2 * sizeof( unsigned ) ) );
+    OPENCK( hipMalloc( &ctx->acc_dev, 8 * sizeof( int ) ) );
+    OPENCK( hipHostMalloc( &ctx->acc_host, 8 * sizeof( int ) ) );
+    OPENCK( hipHostMalloc( &ctx->sync_host, 2 * sizeof( unsigned ) ) );
+    OPENCK( hipMalloc( &ctx->wcost_dev, sizeof( unsigned ) ) );
+    OPENCK( hipHostMalloc( &ctx->wcost_host, sizeof( unsigned ) ) );
+    ctx->desc_cap = 2 * ( p.bframes + 1 ) * p.max_frames + 16;
+    OPENCK( hipMalloc( &ctx->desc_dev, (size_t)ctx->desc_cap * sizeof( SearchDesc<uint8_t> ) ) );
+    OPENCK( hipHostMalloc( &ctx->desc_host, (size_t)ctx->desc_cap * sizeof( SearchDesc<uint8_t> ) ) );
+    ctx->staging_bytes = (size_t)p.width * p.height * ctx->psz;
+    OPENCK( hipHostMalloc( &ctx->staging, ctx->staging_bytes ) );
+
+    const int nd = p.bframes + 1, nc = ( p.bframes + 2 ) * ( p.bframes + 2 );
+    ctx->slots.resize( p.max_frames );
+    for( auto &s : ctx->slots )
+    {
+        size_t off = 0;
+        const size_t o_planes = off; off += align_up( 4 * ctx->plane_bytes, 256 );
+        const size_t o_luma = off; off += align_up( ctx->staging_bytes, 256 );
+        const size_t o_inv = off; off += align_up( ctx->n_mb * sizeof( uint16_t ), 256 );
+        const size_t o_sums = off; off += 256;
+        const size_t o_mvq = off; off += align_up( (size_t)2 * nd * ctx->n_mb * sizeof( unsigned long long ), 256 );
+        const size_t o_mvc = off; off += align_up( (size_t)2 * nd * ctx->n_mb * sizeof( int ), 256 );
+        const size_t o_lc = off; off += align_up( (size_t)nc * ctx->n_mb * sizeof( uint16_t ), 256 );
+        const size_t o_rows = off; off += align_up( (size_t)nc * mb_h * sizeof( int ), 256 );
+        char *base = nullptr;
+        OPENCK( hipMalloc( &base, off ) );
+        OPENCK( hipMemset( base, 0, off ) );
+        s.planes = base + o_planes; s.luma = base + o_luma; s.inv_qscale = (uint16_t *)( base + o_inv );
+        s.frame_sums = (unsigned long long *)( base + o_sums );
+        for( int l = 0; l < 2; l++ )
+            for( int d = 0; d < nd; d++ )
+            {
+                s.mvq[l][d] = (unsigned long long *)( base + o_mvq ) + (size_t)( l * nd + d ) * ctx->n_mb;
+                s.mvcost[l][d] = (int *)( base + o_mvc ) + (size_t)( l * nd + d ) * ctx->n_mb;
+            }
+        s.lowres_costs = (uint16_t *)( base + o_lc );
+        s.row_satds = (int *)( base + o_rows );
+        memset( s.field_ready, 0, sizeof( s.field_ready ) );
+        memset( s.field_prefetched, 0, sizeof( s.field_prefetched ) );
+    }
+#undef OPENCK
+    *out = ctx;
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_device_name( x264hip_ctx *ctx, char *buf, size_t cap )
+{
+    if( !ctx || !buf || !cap ) return X264HIP_EINVAL;
+    hipDeviceProp_t prop;
+    HIPCK( hipGetDeviceProperties( &prop, ctx->device ) );
+    snprintf( buf, cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount );
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_synchronize( x264hip_ctx *ctx )
+{
+    if( !ctx ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    HIPCK( hipStreamSynchronize( ctx->stream ) );
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_geometry( x264hip_ctx *ctx, int *mb_w, int *mb_h, int *lowres_stride )
+{
+    if( !ctx ) return X264HIP_EINVAL;
+    if( mb_w ) *mb_w = ctx->P.mb_w;
+    if( mb_h ) *mb_h = ctx->P.mb_h;
+    if( lowres_stride ) *lowres_stride = ctx->P.stride;
+    return X264HIP_OK;
+}
+
+static inline bool slot_ok( x264hip_ctx *ctx, int s ) { return s >= 0 && s < (int)ctx->slots.size(); }
+
+// ---- frame ingest ------------------------------------------------------------------------------------
+template <typename T>
+static int frame_put_t( x264hip_ctx *ctx, FrameSlot &s, const void *luma, int stride, int is_device, const void *cb, const void *cr,
+                        int cstride, const uint16_t *inv_qscale )
+{
+    const x264hip_params &p = ctx->p;
+    const LaP &P = ctx->P;
+    const T *src = nullptr;
+    int src_stride = stride;
+    if( is_device )
+        src = (const T *)luma;
+    else
+    {
+        // make sure the staging buffer of the previous frame has been consumed
+        HIPCK( hipStreamSynchronize( ctx->stream ) );
+        for( int y = 0; y < p.height; y++ )
+            memcpy( ctx->staging + (size_t)y * p.width * sizeof( T ), (const T *)luma + (size_t)y * stride, p.width * sizeof( T ) );
+        HIPCK( hipMemcpyAsync( s.luma, ctx->staging, ctx->staging_bytes, hipMemcpyHostToDevice, ctx->stream ) );
+        src = (const T *)s.luma;
+        src_stride = p.width;
+    }
+    {
+        dim3 blk( 256 ), grd( ( ( ctx->lw + 2 * LA_PAD ) / 4 + 255 ) / 256, ctx->lh + 2 * LA_PAD );
+        lowres_kernel<T><<<grd, blk, 0, ctx->stream>>>( src, src_stride, p.width, p.height, (T *)s.planes, P.plane_elems, P.stride, ctx->lw, ctx->lh );
+    }
+    HIPCK( hipMemsetAsync( s.frame_sums, 0, 2 * sizeof( unsigned long long ), ctx->stream ) );
+    {
+        const float strength = p.aq_strength * 1.0397f;
+        const float bias = 14.427f + 2 * ( p.bit_depth - 8 );
+        const int aq_on = p.aq_mode == 1 && p.aq_strength != 0.f && !inv_qscale;
+        // chroma planes take part in the AQ energy only when the caller supplies device pointers for them
+        aq_kernel<T><<<dim3( P.mb_w, P.mb_h ), 64, 0, ctx->stream>>>( src, src_stride, p.width, p.height, P.mb_w,
+                                                                      is_device ? (const T *)cb : nullptr, is_device ? (const T *)cr : nullptr, cstride,
+                                                                      aq_on, strength, bias, ctx->luts_dev, s.inv_qscale, s.frame_sums );
+    }
+    if( inv_qscale )
+        HIPCK( hipMemcpyAsync( s.inv_qscale, inv_qscale, ctx->n_mb * sizeof( uint16_t ), hipMemcpyHostToDevice, ctx->stream ) );
+    intra_kernel<T><<<dim3( P.mb_w, P.mb_h ), 64, 0, ctx->stream>>>( P, plane_origin<T>( ctx, s, 0 ), s.lowres_costs );
+    HIPCK( hipGetLastError() );
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, int stride, int is_device, const void *cb, const void *cr,
+                                  int cstride, const uint16_t *inv_qscale )
+{
+    if( !ctx || !slot_ok( ctx, slot ) || !luma || stride < ctx->p.width ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    FrameSlot &s = ctx->slots[slot];
+    s.in_use = 1;
+    s.stats_valid = 0;
+    memset( s.field_ready, 0, sizeof( s.field_ready ) );
+    memset( s.field_prefetched, 0, sizeof( s.field_prefetched ) );
+    if( s.wplane_idx >= 0 ) { ctx->wplane_owner[s.wplane_idx] = -1; s.wplane_idx = -1; }
+    ctx->counters[3]++;
+    return ctx->p.bit_depth == 8 ? frame_put_t<uint8_t>( ctx, s, luma, stride, is_device, cb, cr, cstride, inv_qscale )
+                                 : frame_put_t<uint16_t>( ctx, s, luma, stride, is_device, cb, cr, cstride, inv_qscale );
+}
+
+extern "C" int x264hip_frame_stats( x264hip_ctx *ctx, int slot, uint64_t *pixel_sum, uint64_t *pixel_ssd )
+{
+    if( !ctx || !slot_ok( ctx, slot ) ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    FrameSlot &s = ctx->slots[slot];
+    if( !s.in_use ) return X264HIP_ESTATE;
+    if( !s.stats_valid )
+    {
+        unsigned long long v[2];
+        HIPCK( hipMemcpyAsync( v, s.frame_sums, sizeof( v ), hipMemcpyDeviceToHost, ctx->stream ) );
+        HIPCK( hipStreamSynchronize( ctx->stream ) );
+        const uint64_t n = (uint64_t)( 16 * ctx->P.mb_w ) * ( 16 * ctx->P.mb_h );
+        s.sum = v[0];
+        s.ssd = v[1] - ( v[0] * v[0] + n / 2 ) / n; // ratecontrol.c:405-414
+        s.stats_valid = 1;
+    }
+    if( pixel_sum ) *pixel_sum = s.sum;
+    if( pixel_ssd ) *pixel_ssd = s.ssd;
+    return X264HIP_OK;
+}
+
+// ---- searches ---------------------------------------------------------------------------------------
+static WtD make_wt( x264hip_ctx *ctx, const x264hip_weight *w )
+{
+    WtD d = { 0, 1, 0, 0 };
+    if( w && w->on )
+    {
+        d.on = 1; d.scale = w->scale; d.denom = w->denom; d.offset = w->offset * ( 1 << ctx->P.depth_shift );
+    }
+    return d;
+}
+
+static int acquire_wplane( x264hip_ctx *ctx, int owner_slot )
+{
+    for( size_t i = 0; i < ctx->wplanes.size(); i++ )
+        if( ctx->wplane_owner[i] < 0 ) { ctx->wplane_owner[i] = owner_slot; return (int)i; }
+    char *pl = nullptr;
+    if( hipMalloc( &pl, ctx->plane_bytes ) != hipSuccess ) return -1;
+    ctx->wplanes.push_back( pl );
+    ctx->wplane_owner.push_back( owner_slot );
+    return (int)ctx->wplanes.size() - 1;
+}
+
+struct SearchReq
+{
+    int slot_b, slot_ref, list, dist_m1;
+    WtD wt;
+};
+
+template <typename T>
+static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &reqs )
+{
+    const LaP &P = ctx->P;
+    const int n = (int)reqs.size();
+    if( !n ) return X264HIP_OK;
+    if( n > ctx->desc_cap ) return X264HIP_EINVAL;
+    // the pinned descriptor table may still be read by an in-flight copy of the previous launch
+    HIPCK( hipStreamSynchronize( ctx->stream ) );
+    SearchDesc<T> *dh = (SearchDesc<T> *)ctx->desc_host;
+    for( int i = 0; i < n; i++ )
+    {
+        const SearchReq &r = reqs[i];
+        FrameSlot &b = ctx->slots[r.slot_b], &rf = ctx->slots[r.slot_ref];
+        SearchDesc<T> d;
+        d.fenc0 = plane_origin<T>( ctx, b, 0 );
+        d.ref0 = plane_origin<T>( ctx, rf, 0 );
+        d.refw = nullptr;
+        d.wt = r.wt;
+        if( r.wt.on )
+        {
+            if( b.wplane_idx < 0 ) b.wplane_idx = acquire_wplane( ctx, r.slot_b );
+            if( b.wplane_idx < 0 ) return X264HIP_ENOMEM;
+            T *wp = (T *)ctx->wplanes[b.wplane_idx];
+            weight_plane_kernel<T><<<( P.plane_elems + 255 ) / 256, 256, 0, ctx->stream>>>( (const T *)rf.planes, wp, P.plane_elems, r.wt, P.pixel_max );
+            d.refw = wp + LA_PAD * P.stride + LA_PAD;
+        }
+        d.mvq = b.mvq[r.list][r.dist_m1];
+        d.costs = b.mvcost[r.list][r.dist_m1];
+        d.tag = ctx->tag_serial++;
+        if( !ctx->tag_serial ) ctx->tag_serial = 1;
+        d.pad = 0;
+        dh[i] = d;
+    }
+    HIPCK( hipMemcpyAsync( ctx->desc_dev, dh, (size_t)n * sizeof( SearchDesc<T> ), hipMemcpyHostToDevice, ctx->stream ) );
+    HIPCK( hipMemsetAsync( ctx->sync_words, 0, 2 * sizeof( unsigned ), ctx->stream ) );
+    HIPCK( hipEventRecord( ctx->ev_start, ctx->stream ) );
+    me_rows_kernel<T><<<n * P.mb_h, 64, 0, ctx->stream>>>( P, (const SearchDesc<T> *)ctx->desc_dev, n, ctx->sync_words, 1u << 22 );
+    HIPCK( hipEventRecord( ctx->ev_stop, ctx->stream ) );
+    HIPCK( hipGetLastError() );
+    ctx->ev_valid = 1;
+    ctx->last_n_search = n;
+    ctx->last_n_blocks = n * ctx->n_mb;
+    ctx->counters[0] += n;
+    return X264HIP_OK;
+}
+
+static int launch_searches( x264hip_ctx *ctx, const std::vector<SearchReq> &reqs )
+{
+    return ctx->p.bit_depth == 8 ? launch_searches_t<uint8_t>( ctx, reqs ) : launch_searches_t<uint16_t>( ctx, reqs );
+}
+
+static int check_kernel_error( x264hip_ctx *ctx )
+{
+    HIPCK( hipMemcpyAsync( ctx->sync_host, ctx->sync_words, 2 * sizeof( unsigned ), hipMemcpyDeviceToHost, ctx->stream ) );
+    HIPCK( hipStreamSynchronize( ctx->stream ) );
+    if( ctx->sync_host[1] )
+    {
+        ctx->broken = 1;
+        return X264HIP_ETIMEOUT;
+    }
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *frame_numbers, int n )
+{
+    if( !ctx || !slots || !frame_numbers || n < 0 ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    std::vector<SearchReq> reqs;
+    const WtD none = { 0, 1, 0, 0 };
+    for( int i = 0; i < n; i++ )
+    {
+        if( !slot_ok( ctx, slots[i] ) || !ctx->slots[slots[i]].in_use ) return X264HIP_ESTATE;
+        for( int j = 0; j < n; j++ )
+        {
+            const int d = frame_numbers[j] - frame_numbers[i]; // reference j relative to source i
+            if( !d || abs( d ) > ctx->p.bframes + 1 ) continue;
+            const int list = d > 0, dm1 = abs( d ) - 1;
+            if( list && !ctx->p.bframes ) continue;
+            FrameSlot &b = ctx->slots[slots[i]];
+            if( b.field_ready[list][dm1] || b.field_prefetched[list][dm1] ) continue;
+            b.field_prefetched[list][dm1] = 1;
+            reqs.push_back( SearchReq{ slots[i], slots[j], list, dm1, none } );
+        }
+    }
+    // split into launches that fit the descriptor table
+    for( size_t o = 0; o < reqs.size(); o += ctx->desc_cap )
+    {
+        std::vector<SearchReq> part( reqs.begin() + o, reqs.begin() + std::min( reqs.size(), o + (size_t)ctx->desc_cap ) );
+        int r = launch_searches( ctx, part );
+        if( r ) return r;
+    }
+    return X264HIP_OK;
+}
+
+// ---- evaluation -------------------------------------------------------------------------------------
+template <typename T>
+static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b, int d0, int d1, const int do_search[2],
+                         const x264hip_weight *w, int with_intra, int ref1_l0_valid, x264hip_cost *out )
+{
+    const LaP &P = ctx->P;
+    FrameSlot &b = ctx->slots[slot_b], &f0 = ctx->slots[slot_p0], &f1 = ctx->slots[slot_p1];
+    const int intra_only = d0 == 0 && d1 == 0;
+    const int b_bidir = d1 > 0;
+    const int nstride = ctx->p.bframes + 2;
+    std::vector<SearchReq> reqs;
+    if( !intra_only )
+    {
+        const WtD wt = make_wt( ctx, w );
+        if( do_search[0] )
+        {
+            if( b.field_prefetched[0][d0 - 1] && !wt.on )
+                ctx->counters[2]++;
+            else
+                reqs.push_back( SearchReq{ slot_b, slot_p0, 0, d0 - 1, wt } );
+            b.field_prefetched[0][d0 - 1] = 0;
+            b.field_ready[0][d0 - 1] = 1;
+        }
+        else if( !b.field_ready[0][d0 - 1] )
+            return X264HIP_ESTATE;
+        if( b_bidir )
+        {
+            if( do_search[1] )
+            {
+                if( b.field_prefetched[1][d1 - 1] )
+                    ctx->counters[2]++;
+                else
+                    reqs.push_back( SearchReq{ slot_b, slot_p1, 1, d1 - 1, WtD{ 0, 1, 0, 0 } } );
+                b.field_prefetched[1][d1 - 1] = 0;
+                b.field_ready[1][d1 - 1] = 1;
+            }
+            else if( !b.field_ready[1][d1 - 1] )
+                return X264HIP_ESTATE;
+            if( ref1_l0_valid && !f1.field_ready[0][d0 + d1 - 1] )
+                return X264HIP_ESTATE;
+        }
+        int r = launch_searches( ctx, reqs );
+        if( r ) return r;
+    }
+    CellArgs A;
+    memset( &A, 0, sizeof( A ) );
+    A.b_bidir = b_bidir; A.with_intra = with_intra; A.is_intra_only = intra_only; A.ref1_l0_valid = b_bidir && ref1_l0_valid;
+    A.dist_scale_factor = intra_only ? 128 : ( ( d0 << 8 ) + ( ( d0 + d1 ) >> 1 ) ) / ( d0 + d1 );
+    if( !intra_only )
+    {
+        A.mvq0 = b.mvq[0][d0 - 1]; A.costs0 = b.mvcost[0][d0 - 1];
+        if( b_bidir )
+        {
+            A.mvq1 = b.mvq[1][d1 - 1]; A.costs1 = b.mvcost[1][d1 - 1];
+            A.ref1_l0 = A.ref1_l0_valid ? f1.mvq[0][d0 + d1 - 1] : nullptr;
+        }
+    }
+    A.intra_cost = b.lowres_costs; // cell [0][0]
+    A.inv_qscale = b.inv_qscale;
+    A.lowres_costs = b.lowres_costs + (size_t)( d0 * nstride + d1 ) * ctx->n_mb;
+    A.row_satds = b.row_satds + (size_t)( d0 * nstride + d1 ) * P.mb_h;
+    A.row_satds_intra = b.row_satds;
+    A.acc = ctx->acc_dev;
+    HIPCK( hipMemsetAsync( ctx->acc_dev, 0, 8 * sizeof( int ), ctx->stream ) );
+    if( !intra_only )
+        HIPCK( hipMemsetAsync( A.row_satds, 0, P.mb_h * sizeof( int ), ctx->stream ) );
+    if( with_intra )
+        HIPCK( hipMemsetAsync( A.row_satds_intra, 0, P.mb_h * sizeof( int ), ctx->stream ) );
+    if( b_bidir )
+        cell_b_kernel<T><<<dim3( P.mb_w, P.mb_h ), 64, 0, ctx->stream>>>( P, A, plane_origin<T>( ctx, b, 0 ), plane_origin<T>( ctx, f0, 0 ),
+                                                                          plane_origin<T>( ctx, f1, 0 ) );
+    else
+        cell_p_kernel<<<( ctx->n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( P, A );
+    HIPCK( hipGetLastError() );
+    HIPCK( hipMemcpyAsync( ctx->acc_host, ctx->acc_dev, 8 * sizeof( int ), hipMemcpyDeviceToHost, ctx->stream ) );
+    if( !reqs.empty() )
+    {
+        int r = check_kernel_error( ctx );
+        if( r ) return r;
+    }
+    else
+        HIPCK( hipStreamSynchronize( ctx->stream ) );
+    out->cost_est = ctx->acc_host[0]; out->cost_est_aq = ctx->acc_host[1]; out->intra_mbs = ctx->acc_host[2];
+    out->intra_cost_est = ctx->acc_host[3]; out->intra_cost_est_aq = ctx->acc_host[4];
+    ctx->counters[1]++;
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_frame_cost( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b, int dist_p0, int dist_p1, const int do_search[2],
+                                   const x264hip_weight *w, int with_intra, int ref1_l0_valid, x264hip_cost *out )
+{
+    if( !ctx || !out || !do_search || !slot_ok( ctx, slot_p0 ) || !slot_ok( ctx, slot_p1 ) || !slot_ok( ctx, slot_b ) ) return X264HIP_EINVAL;
+    if( dist_p0 < 0 || dist_p1 < 0 || dist_p0 + dist_p1 > ctx->p.bframes + 1 || ( dist_p0 == 0 && dist_p1 != 0 ) ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( !ctx->slots[slot_b].in_use || !ctx->slots[slot_p0].in_use || !ctx->slots[slot_p1].in_use ) return X264HIP_ESTATE;
+    return ctx->p.bit_depth == 8
+               ? frame_cost_t<uint8_t>( ctx, slot_p0, slot_p1, slot_b, dist_p0, dist_p1, do_search, w, with_intra, ref1_l0_valid, out )
+               : frame_cost_t<uint16_t>( ctx, slot_p0, slot_p1, slot_b, dist_p0, dist_p1, do_search, w, with_intra, ref1_l0_valid, out );
+}
+
+extern "C" int x264hip_weight_cost( x264hip_ctx *ctx, int slot_fenc, int slot_ref, const x264hip_weight *w, unsigned *cost )
+{
+    if( !ctx || !cost || !slot_ok( ctx, slot_fenc ) || !slot_ok( ctx, slot_ref ) ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    FrameSlot &f = ctx->slots[slot_fenc], &r = ctx->slots[slot_ref];
+    if( !f.in_use || !r.in_use ) return X264HIP_ESTATE;
+    const LaP &P = ctx->P;
+    const WtD wt = make_wt( ctx, w );
+    HIPCK( hipMemsetAsync( ctx->wcost_dev, 0, sizeof( unsigned ), ctx->stream ) );
+    const int grid = ( ctx->n_mb + 3 ) / 4;
+    if( ctx->p.bit_depth == 8 )
+        weight_cost_kernel<uint8_t><<<grid, 64, 0, ctx->stream>>>( P, plane_origin<uint8_t>( ctx, f, 0 ), plane_origin<uint8_t>( ctx, r, 0 ), wt,
+                                                                   f.lowres_costs, ctx->wcost_dev );
+    else
+        weight_cost_kernel<uint16_t><<<grid, 64, 0, ctx->stream>>>( P, plane_origin<uint16_t>( ctx, f, 0 ), plane_origin<uint16_t>( ctx, r, 0 ), wt,
+                                                                    f.lowres_costs, ctx->wcost_dev );
+    HIPCK( hipGetLastError() );
+    HIPCK( hipMemcpyAsync( ctx->wcost_host, ctx->wcost_dev, sizeof( unsigned ), hipMemcpyDeviceToHost, ctx->stream ) );
+    HIPCK( hipStreamSynchronize( ctx->stream ) );
+    *cost = *ctx->wcost_host;
+    return X264HIP_OK;
+}
+
+// ---- getters ----------------------------------------------------------------------------------------
+extern "C" int x264hip_get_lowres( x264hip_ctx *ctx, int slot, int plane, void *dst, int dst_stride )
+{
+    if( !ctx || !dst || !slot_ok( ctx, slot ) || plane < 0 || plane > 3 ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    FrameSlot &s = ctx->slots[slot];
+    const int w = ctx->lw + 2 * LA_PAD, h = ctx->lh + 2 * LA_PAD;
+    HIPCK( hipMemcpy2DAsync( dst, (size_t)dst_stride * ctx->psz, s.planes + (size_t)plane * ctx->plane_bytes, (size_t)ctx->P.stride * ctx->psz,
+                             (size_t)w * ctx->psz, h, hipMemcpyDeviceToHost, ctx->stream ) );
+    HIPCK( hipStreamSynchronize( ctx->stream ) );
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_get_mvs( x264hip_ctx *ctx, int slot, int list, int dist_minus1, int16_t *mvs, int *mv_costs )
+{
+    if( !ctx || !slot_ok( ctx, slot ) || list < 0 || list > 1 || dist_minus1 < 0 || dist_minus1 > ctx->p.bframes ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    FrameSlot &s = ctx->slots[slot];
+    std::vector<unsigned long long> g( ctx->n_mb );
+    HIPCK( hipMemcpyAsync( g.data(), s.mvq[list][dist_minus1], ctx->n_mb * sizeof( unsigned long long ), hipMemcpyDeviceToHost, ctx->stream ) );
+    if( mv_costs )
+        HIPCK( hipMemcpyAsync( mv_costs, s.mvcost[list][dist_minus1], ctx->n_mb * sizeof( int ), hipMemcpyDeviceToHost, ctx->stream ) );
+    HIPCK( hipStreamSynchronize( ctx->stream ) );
+    if( mvs )
+        for( int i = 0; i < ctx->n_mb; i++ )
+        {
+            unsigned w = (unsigned)g[i];
+            mvs[2 * i] = (int16_t)( w & 0xFFFF );
+            mvs[2 * i + 1] = (int16_t)( w >> 16 );
+        }
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_get_lowres_costs( x264hip_ctx *ctx, int slot, int dist_p0, int dist_p1, uint16_t *costs, int *row_satds )
+{
+    if( !ctx || !slot_ok( ctx, slot ) || dist_p0 < 0 || dist_p1 < 0 || dist_p0 > ctx->p.bframes + 1 || dist_p1 > ctx->p.bframes + 1 ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    FrameSlot &s = ctx->slots[slot];
+    const int idx = dist_p0 * ( ctx->p.bframes + 2 ) + dist_p1;
+    if( costs )
+        HIPCK( hipMemcpyAsync( costs, s.lowres_costs + (size_t)idx * ctx->n_mb, ctx->n_mb * sizeof( uint16_t ), hipMemcpyDeviceToHost, ctx->stream ) );
+    if( row_satds )
+        HIPCK( hipMemcpyAsync( row_satds, s.row_satds + (size_t)idx * ctx->P.mb_h, ctx->P.mb_h * sizeof( int ), hipMemcpyDeviceToHost, ctx->stream ) );
+    HIPCK( hipStreamSynchronize( ctx->stream ) );
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_get_intra_costs( x264hip_ctx *ctx, int slot, uint16_t *intra_costs )
+{
+    return x264hip_get_lowres_costs( ctx, slot, 0, 0, intra_costs, nullptr );
+}
+
+extern "C" int x264hip_get_inv_qscale( x264hip_ctx *ctx, int slot, uint16_t *inv_qscale )
+{
+    if( !ctx || !slot_ok( ctx, slot ) || !inv_qscale ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    HIPCK( hipMemcpyAsync( inv_qscale, ctx->slots[slot].inv_qscale, ctx->n_mb * sizeof( uint16_t ), hipMemcpyDeviceToHost, ctx->stream ) );
+    HIPCK( hipStreamSynchronize( ctx->stream ) );
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_last_search_ms( x264hip_ctx *ctx, float *ms, int *n_searches, int *n_blocks )
+{
+    if( !ctx || !ms ) return X264HIP_EINVAL;
+    if( !ctx->ev_valid ) return X264HIP_ESTATE;
+    HIPCK( hipEventSynchronize( ctx->ev_stop ) );
+    HIPCK( hipEventElapsedTime( ms, ctx->ev_start, ctx->ev_stop ) );
+    if( n_searches ) *n_searches = ctx->last_n_search;
+    if( n_blocks ) *n_blocks = ctx->last_n_blocks;
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_counters( x264hip_ctx *ctx, uint64_t *out, int n )
+{
+    if( !ctx || !out ) return X264HIP_EINVAL;
+    for( int i = 0; i < n && i < 8; i++ ) out[i] = ctx->counters[i];
+    return X264HIP_OK;
+}
+
+// ---- batched primitives ------------------------------------------------------------------------------
+extern "C" int x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx, const void *fenc_plane, const void *ref_plane, int stride,
+                                        int blocks_w, int blocks_h, const int16_t *mv_dev, int *out_dev )
+{
+    if( !ctx || !fenc_plane || !ref_plane || !mv_dev || !out_dev ) return X264HIP_EINVAL;
+    const int size = size_idx == 0 ? 16 : size_idx == 3 ? 8 : size_idx == 6 ? 4 : 0;
+    if( !size || ( blocks_w * size ) % 16 || ( blocks_h * size ) % 16 ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    const int rw = blocks_w * size / 16, rh = blocks_h * size / 16;
+    if( ctx->p.bit_depth == 8 )
+        pixel_cmp_batch_kernel<uint8_t><<<dim3( rw, rh ), 64, 0, ctx->stream>>>( (const uint8_t *)fenc_plane, (const uint8_t *)ref_plane, stride, rw, rh,
+                                                                                 size, satd, mv_dev, out_dev );
+    else
+        pixel_cmp_batch_kernel<uint16_t><<<dim3( rw, rh ), 64, 0, ctx->stream>>>( (const uint16_t *)fenc_plane, (const uint16_t *)ref_plane, stride, rw,
+                                                                                  rh, size, satd, mv_dev, out_dev );
+    HIPCK( hipGetLastError() );
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_frame_init_lowres_core( x264hip_ctx *ctx, const void *src0, void *dst0, void *dsth, void *dstv, void *dstc,
+                                               intptr_t src_stride, intptr_t dst_stride, int width, int height )
+{
+    if( !ctx || !src0 || !dst0 || !dsth || !dstv || !dstc || width <= 0 || height <= 0 ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    dim3 grd( ( width + 255 ) / 256, height );
+    if( ctx->p.bit_depth == 8 )
+        lowres_core_kernel<uint8_t><<<grd, 256, 0, ctx->stream>>>( (const uint8_t *)src0, (uint8_t *)dst0, (uint8_t *)dsth, (uint8_t *)dstv,
+                                                                   (uint8_t *)dstc, (long)src_stride, (long)dst_stride, width, height );
+    else
+        lowres_core_kernel<uint16_t><<<grd, 256, 0, ctx->stream>>>( (const uint16_t *)src0, (uint16_t *)dst0, (uint16_t *)dsth, (uint16_t *)dstv,
+                                                                    (uint16_t *)dstc, (long)src_stride, (long)dst_stride, width, height );
+    HIPCK( hipGetLastError() );
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_dct_quant_batch( x264hip_ctx *ctx, int is8x8, int n_blocks, const void *fenc, const void *fdec, const void *mf,
+                                        const void *bias, void *coefs_out, int *nz_out )
+{
+    if( !ctx || n_blocks <= 0 || !fenc || !fdec || !mf || !bias || !coefs_out || !nz_out ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    const int N = is8x8 ? 8 : 4, psz = ctx->psz, csz = ctx->p.bit_depth == 8 ? 2 : 4;
+    const size_t fe_b = (size_t)n_blocks * N * 16 * psz, fd_b = (size_t)n_blocks * N * 32 * psz, tab_b = (size_t)N * N * csz,
+                 co_b = (size_t)n_blocks * N * N * csz;
+    char *dev = nullptr;
+    HIPCK( hipMalloc( &dev, fe_b + fd_b + 2 * tab_b + co_b + n_blocks * sizeof( int ) + 1024 ) );
+    char *d_fe = dev, *d_fd = d_fe + align_up( fe_b, 64 ), *d_mf = d_fd + align_up( fd_b, 64 ), *d_bias = d_mf + align_up( tab_b, 64 ),
+         *d_co = d_bias + align_up( tab_b, 64 ), *d_nz = d_co + align_up( co_b, 64 );
+    int rc = X264HIP_OK;
+    if( hipMemcpy( d_fe, fenc, fe_b, hipMemcpyHostToDevice ) != hipSuccess || hipMemcpy( d_fd, fdec, fd_b, hipMemcpyHostToDevice ) != hipSuccess ||
+        hipMemcpy( d_mf, mf, tab_b, hipMemcpyHostToDevice ) != hipSuccess || hipMemcpy( d_bias, bias, tab_b, hipMemcpyHostToDevice ) != hipSuccess )
+        rc = X264HIP_EDEVICE;
+    if( !rc )
+    {
+        const int grid = ( n_blocks + 63 ) / 64;
+        if( ctx->p.bit_depth == 8 )
+            dct_quant_kernel<uint8_t, int16_t, uint16_t><<<grid, 64, 0, ctx->stream>>>( is8x8, n_blocks, (const uint8_t *)d_fe, (const uint8_t *)d_fd,
+                                                                                        (const uint16_t *)d_mf, (const uint16_t *)d_bias, (int16_t *)d_co, (int *)d_nz );
+        else
+            dct_quant_kernel<uint16_t, int32_t, uint32_t><<<grid, 64, 0, ctx->stream>>>( is8x8, n_blocks, (const uint16_t *)d_fe, (const uint16_t *)d_fd,
+                                                                                         (const uint32_t *)d_mf, (const uint32_t *)d_bias, (int32_t *)d_co, (int *)d_nz );
+        if( hipStreamSynchronize( ctx->stream ) != hipSuccess || hipMemcpy( coefs_out, d_co, co_b, hipMemcpyDeviceToHost ) != hipSuccess ||
+            hipMemcpy( nz_out, d_nz, n_blocks * sizeof( int ), hipMemcpyDeviceToHost ) != hipSuccess )
+            rc = X264HIP_EDEVICE;
+    }
+    (void)hipFree( dev );
+    if( rc ) ctx->broken = 1;
+    return rc;
+}

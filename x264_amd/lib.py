@@ -1,0 +1,193 @@
+"""ctypes binding of the C ABI in include/x264hip.h (libx264hip.so).  No CPU fallback: every call
+goes to the HIP library and errors surface as X264HipError."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libx264hip.so")
+BFRAME_MAX = 16
+
+
+class X264HipError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        super().__init__("%s failed: %s (%d)" % (what, _strerror(code), code))
+
+
+class Params(C.Structure):
+    _fields_ = [("bit_depth", C.c_int), ("width", C.c_int), ("height", C.c_int), ("bframes", C.c_int), ("lambda_", C.c_int),
+                ("me_method", C.c_int), ("subpel_refine", C.c_int), ("me_range", C.c_int), ("mv_range", C.c_int),
+                ("subme", C.c_int), ("mbcmp_satd", C.c_int), ("fpelcmp_satd", C.c_int), ("weighted_bipred", C.c_int),
+                ("aq_mode", C.c_int), ("aq_strength", C.c_float), ("bframe_bias", C.c_int), ("max_frames", C.c_int),
+                ("cost_mv", C.c_void_p)]
+
+
+class Weight(C.Structure):
+    _fields_ = [("on", C.c_int), ("scale", C.c_int), ("denom", C.c_int), ("offset", C.c_int)]
+
+
+class Cost(C.Structure):
+    _fields_ = [("cost_est", C.c_int), ("cost_est_aq", C.c_int), ("intra_mbs", C.c_int), ("intra_cost_est", C.c_int),
+                ("intra_cost_est_aq", C.c_int)]
+
+
+_lib = None
+
+
+def load():
+    """Load libx264hip.so; raises if it has not been built (the product never falls back to CPU code)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("x264_amd/libx264hip.so is missing: run `python -m x264_amd.build` (needs hipcc)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.x264hip_strerror.restype = C.c_char_p
+        _lib.x264hip_open.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Params)]
+    return _lib
+
+
+def _strerror(code):
+    try:
+        return load().x264hip_strerror(code).decode()
+    except Exception:
+        return "?"
+
+
+def _ck(code, what):
+    if code != 0:
+        raise X264HipError(code, what)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def cost_mv_table(mv_range, lam):
+    """Centred cost_mv table exactly as x264_analyse_init_costs builds it (encoder/analyse.c:143-202):
+    float32 log2f, lambda*log + .5f truncated, saturated to u16.  Returns (array, centre index)."""
+    n = 2 * 4 * mv_range
+    i = np.arange(0, n + 1, dtype=np.float32)
+    logs = np.log2(i + np.float32(1.0)).astype(np.float32) * np.float32(2.0) + np.float32(1.718)
+    logs[0] = np.float32(0.718)
+    v = (np.float32(lam) * logs + np.float32(0.5)).astype(np.int64)
+    v = np.minimum(v, 65535).astype(np.uint16)
+    return np.concatenate([v[:0:-1], v]), n
+
+
+class Context:
+    """Thin object view of x264hip_ctx."""
+
+    def __init__(self, width, height, *, bit_depth=8, bframes=3, lam=None, me_method=1, subpel_refine=4, me_range=16,
+                 mv_range=512, subme=7, mbcmp_satd=1, fpelcmp_satd=0, weighted_bipred=1, aq_mode=1, aq_strength=1.0,
+                 bframe_bias=0, max_frames=64, cost_mv=None, device=0):
+        L = load()
+        lam = lam if lam is not None else (1 if bit_depth == 8 else 4)
+        if cost_mv is None:
+            cost_mv, centre = cost_mv_table(mv_range, lam)
+        else:
+            cost_mv = np.ascontiguousarray(cost_mv, np.uint16)
+            centre = (cost_mv.size - 1) // 2
+        self._cost_mv = cost_mv
+        self.params = Params(bit_depth, width, height, bframes, lam, me_method, subpel_refine, me_range, mv_range, subme,
+                             mbcmp_satd, fpelcmp_satd, weighted_bipred, aq_mode, aq_strength, bframe_bias, max_frames,
+                             cost_mv.ctypes.data + 2 * centre)
+        self.h = C.c_void_p()
+        _ck(L.x264hip_open(C.byref(self.h), device, C.byref(self.params)), "x264hip_open")
+        self.L = L
+        self.dtype = np.uint8 if bit_depth == 8 else np.uint16
+        mw, mh, st = C.c_int(), C.c_int(), C.c_int()
+        _ck(L.x264hip_geometry(self.h, C.byref(mw), C.byref(mh), C.byref(st)), "geometry")
+        self.mb_w, self.mb_h, self.stride = mw.value, mh.value, st.value
+        self.n_mb = self.mb_w * self.mb_h
+        self.bframes = bframes
+        self.width, self.height = width, height
+
+    def close(self):
+        if self.h:
+            self.L.x264hip_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        _ck(self.L.x264hip_device_name(self.h, buf, 256), "device_name")
+        return buf.value.decode()
+
+    def frame_put(self, slot, luma, inv_qscale=None, device_ptr=None, stride=None):
+        if device_ptr is not None:
+            _ck(self.L.x264hip_frame_put(self.h, slot, C.c_void_p(device_ptr), stride or self.width, 1, None, None, 0,
+                                         _p(inv_qscale)), "frame_put")
+            return
+        luma = np.ascontiguousarray(luma, self.dtype)
+        assert luma.shape == (self.height, self.width)
+        _ck(self.L.x264hip_frame_put(self.h, slot, _p(luma), self.width, 0, None, None, 0, _p(inv_qscale)), "frame_put")
+
+    def frame_stats(self, slot):
+        s, q = C.c_uint64(), C.c_uint64()
+        _ck(self.L.x264hip_frame_stats(self.h, slot, C.byref(s), C.byref(q)), "frame_stats")
+        return int(s.value), int(q.value)
+
+    def frame_cost(self, slot_p0, slot_p1, slot_b, d0, d1, do_search=(0, 0), weight=None, with_intra=False,
+                   ref1_l0_valid=False):
+        ds = (C.c_int * 2)(*[int(x) for x in do_search])
+        out = Cost()
+        w = Weight(*weight) if weight is not None else None
+        _ck(self.L.x264hip_frame_cost(self.h, slot_p0, slot_p1, slot_b, d0, d1, ds, C.byref(w) if w else None,
+                                      int(with_intra), int(ref1_l0_valid), C.byref(out)), "frame_cost")
+        return out
+
+    def weight_cost(self, slot_fenc, slot_ref, weight=None):
+        c = C.c_uint()
+        w = Weight(*weight) if weight is not None else None
+        _ck(self.L.x264hip_weight_cost(self.h, slot_fenc, slot_ref, C.byref(w) if w else None, C.byref(c)), "weight_cost")
+        return int(c.value)
+
+    def prefetch(self, slots, frame_numbers):
+        s = np.asarray(slots, np.int32)
+        f = np.asarray(frame_numbers, np.int32)
+        _ck(self.L.x264hip_prefetch(self.h, _p(s), _p(f), int(s.size)), "prefetch")
+
+    def synchronize(self):
+        _ck(self.L.x264hip_synchronize(self.h), "synchronize")
+
+    def lowres(self, slot, plane):
+        out = np.zeros((8 * self.mb_h + 64, 8 * self.mb_w + 64), self.dtype)
+        _ck(self.L.x264hip_get_lowres(self.h, slot, plane, _p(out), out.shape[1]), "get_lowres")
+        return out
+
+    def mvs(self, slot, lst, dist_m1):
+        mv = np.zeros((self.n_mb, 2), np.int16)
+        cost = np.zeros(self.n_mb, np.int32)
+        _ck(self.L.x264hip_get_mvs(self.h, slot, lst, dist_m1, _p(mv), _p(cost)), "get_mvs")
+        return mv, cost
+
+    def lowres_costs(self, slot, d0, d1):
+        lc = np.zeros(self.n_mb, np.uint16)
+        rows = np.zeros(self.mb_h, np.int32)
+        _ck(self.L.x264hip_get_lowres_costs(self.h, slot, d0, d1, _p(lc), _p(rows)), "get_lowres_costs")
+        return lc, rows
+
+    def intra_costs(self, slot):
+        return self.lowres_costs(slot, 0, 0)[0]
+
+    def inv_qscale(self, slot):
+        out = np.zeros(self.n_mb, np.uint16)
+        _ck(self.L.x264hip_get_inv_qscale(self.h, slot, _p(out)), "get_inv_qscale")
+        return out
+
+    def last_search_ms(self):
+        ms, ns, nb = C.c_float(), C.c_int(), C.c_int()
+        _ck(self.L.x264hip_last_search_ms(self.h, C.byref(ms), C.byref(ns), C.byref(nb)), "last_search_ms")
+        return ms.value, ns.value, nb.value
+
+    def counters(self):
+        out = np.zeros(8, np.uint64)
+        _ck(self.L.x264hip_counters(self.h, _p(out), 8), "counters")
+        return out
