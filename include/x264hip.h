@@ -150,6 +150,75 @@ int  x264hip_dct_quant_batch( x264hip_ctx *ctx, int is8x8, int n_blocks, const v
 int  x264hip_last_search_ms( x264hip_ctx *ctx, float *ms, int *n_searches, int *n_blocks );
 int  x264hip_counters( x264hip_ctx *ctx, uint64_t *out, int n ); /* [0] searches [1] cells [2] cache hits [3] frames */
 
+
+/* ==================================================================================================
+ * Host-side lookahead: the reference's own control flow (stays on the CPU) driving the
+ * device evaluations above.  Mirrors, with the same pacing as x264_encoder_encode
+ * (encoder/encoder.c:3417-3454):
+ *   x264hip_lookahead_put_frame  <- x264_frame_init_lowres + x264_lookahead_put_frame (encoder/lookahead.c:192)
+ *   x264hip_lookahead_get_frame  <- x264_lookahead_get_frames (lookahead.c:223) + x264_frame_shift of
+ *                                   h->frames.current, i.e. x264_slicetype_decide / x264_slicetype_analyse
+ *                                   (encoder/slicetype.c:1745,1473) with slicetype_frame_cost (:836) memoisation,
+ *                                   first-trigger weights (x264_weights_analyse :284, lookahead mode), scenecut,
+ *                                   B-adapt fast/trellis paths, and the MB-tree / final-cost evaluation order.
+ * Decisions (slice types) and every i_cost_est cell are identical to the reference's with threads=1.
+ * ================================================================================================== */
+typedef struct x264hip_lookahead x264hip_lookahead;
+
+typedef struct x264hip_la_params
+{
+    x264hip_params dev;       /* dev.max_frames is derived when 0 */
+    int keyint_max, keyint_min;
+    int scenecut_threshold;
+    int b_adapt;              /* 0 none, 1 fast, 2 trellis */
+    int b_pyramid;            /* 0 none, 1 strict, 2 normal */
+    int rc_lookahead;
+    int mb_tree;              /* drives the evaluation order, do_edges and key-frame analysis; propagation itself is not computed */
+    int weightp;              /* param.analyse.i_weighted_pred (0..2) */
+    int open_gop;
+    int frame_refs;           /* param.i_frame_reference (B-pyramid compatibility rule, slicetype.c:1819) */
+    int psy;                  /* param.analyse.b_psy (slicetype.c:1512) */
+    int rc_is_cqp;            /* rc.i_rc_method == X264_RC_CQP: skips the final cost evaluation (slicetype.c:1899) */
+} x264hip_la_params;
+
+/* pluggable evaluation backend (same contracts as the x264hip_* device entry points) */
+typedef struct x264hip_backend
+{
+    void *user;
+    int (*frame_put)( void *user, int slot, const void *luma, int stride, int is_device );
+    int (*frame_stats)( void *user, int slot, uint64_t *pixel_sum, uint64_t *pixel_ssd );
+    int (*weight_cost)( void *user, int slot_fenc, int slot_ref, const x264hip_weight *w, unsigned *cost );
+    int (*frame_cost)( void *user, int slot_p0, int slot_p1, int slot_b, int dist_p0, int dist_p1, const int do_search[2],
+                       const x264hip_weight *w, int with_intra, int ref1_l0_valid, x264hip_cost *out );
+    int (*prefetch)( void *user, const int *slots, const int *frame_numbers, int n ); /* may be NULL */
+} x264hip_backend;
+
+typedef struct x264hip_la_frame
+{
+    int frame;                /* display-order index (i_frame) */
+    int type;                 /* X264_TYPE_*: 1 IDR, 2 I, 3 P, 4 BREF, 5 B */
+    int bframes;              /* i_bframes of a non-B frame */
+    int keyframe;
+    int cost_est[X264HIP_BFRAME_MAX + 2][X264HIP_BFRAME_MAX + 2];    /* fenc->i_cost_est, -1 = never evaluated */
+    int cost_est_aq[X264HIP_BFRAME_MAX + 2][X264HIP_BFRAME_MAX + 2];
+    int intra_mbs[X264HIP_BFRAME_MAX + 2];
+} x264hip_la_frame;
+
+/* Opens a device context (x264hip_open) and the host logic on top of it.  No CPU fallback. */
+int  x264hip_lookahead_open( x264hip_lookahead **out, int device, const x264hip_la_params *params );
+/* Same host logic over a caller-supplied backend (plugin / test hook). */
+int  x264hip_lookahead_open_backend( x264hip_lookahead **out, const x264hip_la_params *params, const x264hip_backend *backend );
+void x264hip_lookahead_close( x264hip_lookahead *la );
+x264hip_ctx *x264hip_lookahead_ctx( x264hip_lookahead *la ); /* NULL for plugin backends */
+int  x264hip_lookahead_delay( x264hip_lookahead *la );       /* h->frames.i_delay */
+/* forced_type: X264_TYPE_AUTO (0) normally */
+int  x264hip_lookahead_put_frame( x264hip_lookahead *la, const void *luma, int stride, int is_device, int forced_type );
+/* One call = the lookahead part of one x264_encoder_encode call.  flush != 0 once the input has ended.
+ * *got = 1 and *out filled when a frame leaves the lookahead (coded order), 0 while the delay fills or at the end. */
+int  x264hip_lookahead_get_frame( x264hip_lookahead *la, int flush, x264hip_la_frame *out, int *got );
+/* statistics: [0] slicetype_frame_cost calls, [1] real evaluations, [2] weights analysed, [3] weights kept */
+int  x264hip_lookahead_stats( x264hip_lookahead *la, uint64_t *out, int n );
+
 #ifdef __cplusplus
 }
 #endif

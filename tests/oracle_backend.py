@@ -1,0 +1,74 @@
+"""Test-only evaluation backend: plugs the CPU oracle into the product's host lookahead logic
+(x264hip_lookahead_open_backend) so the host control flow can be tested without a GPU."""
+import ctypes as C
+
+import numpy as np
+
+from oracle.oraclelib import Oracle, Weight as OWeight
+from x264_amd import lib
+
+
+class OracleBackend:
+    def __init__(self, cfg, cost_mv=None):
+        self.cfg = cfg
+        self.o = Oracle(cfg["bit_depth"])
+        mb_w, mb_h = (cfg["width"] + 15) // 16, (cfg["height"] + 15) // 16
+        self.ocfg = self.o.make_cfg(mb_w, mb_h, me_method=cfg["la_me_method"], subpel_refine=cfg["la_subpel_refine"],
+                                    me_range=cfg["me_range"], mv_range=cfg["mv_range"], subme=cfg["subme"],
+                                    mbcmp_satd=cfg["mbcmp_satd"], fpelcmp_satd=cfg["fpelcmp_satd"],
+                                    weighted_bipred=cfg["weighted_bipred"], aq_mode=cfg["aq_mode"], lam=cfg["lam"],
+                                    bframe_bias=cfg["bframe_bias"], cost_mv=cost_mv)
+        self.slots = {}
+        self.n_eval = 0
+        self.struct = lib.Backend(None, lib.FRAME_PUT_FN(self._put), lib.FRAME_STATS_FN(self._stats),
+                                  lib.WEIGHT_COST_FN(self._wcost), lib.FRAME_COST_FN(self._cost), lib.PREFETCH_FN(0))
+
+    def _put(self, user, slot, luma, stride, is_device):
+        c = self.cfg
+        dt = self.o.dtype
+        buf = (C.c_char * (stride * c["height"] * np.dtype(dt).itemsize)).from_address(luma)
+        img = np.frombuffer(buf, dtype=dt).reshape(c["height"], stride)[:, :c["width"]].copy()
+        pl = self.o.lowres_init(self.ocfg, img)
+        inv, _, s, ssd = self.o.aq_frame(img, self.ocfg.mb_w, self.ocfg.mb_h, c["aq_mode"], c["aq_strength"])
+        self.slots[slot] = dict(planes=pl, inv=inv, sum=s, ssd=ssd, intra=self.o.intra_costs(self.ocfg, pl), fields={})
+        return 0
+
+    def _stats(self, user, slot, psum, pssd):
+        psum[0] = self.slots[slot]["sum"]
+        pssd[0] = self.slots[slot]["ssd"]
+        return 0
+
+    def _wcost(self, user, sf, sr, w, out):
+        wt = OWeight(w[0].on, w[0].scale, w[0].denom, w[0].offset) if w else None
+        out[0] = self.o.weight_cost(self.ocfg, self.slots[sf]["planes"], self.slots[sr]["planes"], wt, self.slots[sf]["intra"])
+        return 0
+
+    def _cost(self, user, s0, s1, sb, d0, d1, do_search, w, with_intra, ref1_valid, out):
+        o, cfg = self.o, self.ocfg
+        B, F0, F1 = self.slots[sb], self.slots[s0], self.slots[s1]
+        self.n_eval += 1
+        if d0 == 0 and d1 == 0:
+            lc, rows, rows_i, co = o.cell(cfg, B["planes"], None, None, 128, None, None, None, None, None, B["intra"], B["inv"],
+                                          bool(with_intra), alias_intra=True)
+        else:
+            if do_search[0]:
+                wt, wplane = None, None
+                if w and w[0].on:
+                    wt = OWeight(w[0].on, w[0].scale, w[0].denom, w[0].offset)
+                    wplane = o.weight_plane(cfg, F0["planes"][0], wt)
+                B["fields"][(0, d0 - 1)] = o.search_field(cfg, B["planes"], F0["planes"], wt, wplane)
+            if d1 > 0 and do_search[1]:
+                B["fields"][(1, d1 - 1)] = o.search_field(cfg, B["planes"], F1["planes"])
+            m0, c0 = B["fields"][(0, d0 - 1)]
+            dsf = (d0 * 256 + (d0 + d1) // 2) // (d0 + d1)
+            if d1 > 0:
+                m1, c1 = B["fields"][(1, d1 - 1)]
+                r1 = F1["fields"][(0, d0 + d1 - 1)][0] if ref1_valid else None
+                lc, rows, rows_i, co = o.cell(cfg, B["planes"], F0["planes"], F1["planes"], dsf, m0, c0, m1, c1, r1, B["intra"],
+                                              B["inv"], bool(with_intra))
+            else:
+                lc, rows, rows_i, co = o.cell(cfg, B["planes"], F0["planes"], None, dsf, m0, c0, None, None, None, B["intra"],
+                                              B["inv"], bool(with_intra))
+        out[0].cost_est, out[0].cost_est_aq, out[0].intra_mbs = co.cost_est, co.cost_est_aq, co.intra_mbs
+        out[0].intra_cost_est, out[0].intra_cost_est_aq = co.intra_cost_est, co.intra_cost_est_aq
+        return 0

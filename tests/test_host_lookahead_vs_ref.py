@@ -1,0 +1,69 @@
+"""End-to-end lookahead parity on CPU: the product's host logic (lookahead_host.cpp) driven by the oracle
+backend, against the REAL reference lookahead (oracle/_ref) -- slice types, coded order and every evaluated
+i_cost_est / i_cost_est_aq cell must be identical."""
+import numpy as np
+import pytest
+
+from oracle import refharness
+from tests.common import clip
+from tests.oracle_backend import OracleBackend
+from x264_amd import lib
+from x264_amd.synth import make_clip
+
+pytestmark = pytest.mark.skipif(not refharness.available(8), reason="oracle/_ref not built (no /root/reference)")
+
+CASES = [
+    # (preset, ref opts, cfg overrides, depth, clip kwargs, n_frames)
+    ("medium", "", {}, 8, dict(seed=1, scene_cuts=(25,), fade=(40, 8, 0.6, 10)), 60),
+    ("slow", "me=dia", dict(me="dia"), 8, dict(seed=2, scene_cuts=(13, 14, 31)), 64),
+    ("slower", "me=umh,merange=32", dict(me="umh", me_range=32), 8, dict(seed=3, pan=(9, 5), scene_cuts=(40,)), 72),
+    ("medium", "bframes=8,rc-lookahead=60", dict(bframes=8, rc_lookahead=60), 8, dict(seed=4, fade=(10, 12, 1.5, -20)), 75),
+    ("veryslow", "me=tesa", dict(me="tesa"), 10, dict(seed=5, scene_cuts=(33,)), 70),
+    ("medium", "keyint=24,min-keyint=4", dict(keyint_max=24, keyint_min=4), 8, dict(seed=6, scene_cuts=(7, 50)), 60),
+    ("veryfast", "", {}, 8, dict(seed=7, pan=(1, 1), noise=1), 40),
+    ("medium", "b-adapt=0", dict(b_adapt=0), 8, dict(seed=8), 30),
+    ("medium", "bframes=0", dict(bframes=0), 8, dict(seed=9, scene_cuts=(11,)), 30),
+    ("medium", "b-pyramid=none,weightp=0", dict(b_pyramid=0, weightp=0), 8, dict(seed=10), 40),
+    ("medium", "open-gop=1,keyint=30", dict(open_gop=1, keyint_max=30), 8, dict(seed=11), 70),
+]
+
+
+@pytest.mark.parametrize("preset,opts,over,depth,ckw,nf", CASES)
+def test_lookahead_matches_reference(preset, opts, over, depth, ckw, nf):
+    W, H = 176, 144
+    frames = make_clip(W, H, nf, bit_depth=depth, **ckw)
+    r = refharness.Ref(W, H, preset, opts=opts, bit_depth=depth)
+    try:
+        ref = r.lookahead_run(frames)
+        rc = r.cfg
+        cfg = lib.la_config(W, H, preset, bit_depth=depth, **over)
+        # the derived configuration must be what the reference validated
+        for k, rk in (("bframes", "bframes"), ("b_adapt", "b_adapt"), ("rc_lookahead", "rc_lookahead"), ("mv_range", "mv_range"),
+                      ("me_range", "me_range"), ("la_me_method", "me_method"), ("la_subpel_refine", "subpel_refine"),
+                      ("subme", "subme"), ("weightp", "weightp"), ("mb_tree", "mb_tree"), ("keyint_max", "keyint_max"),
+                      ("keyint_min", "keyint_min"), ("b_pyramid", "b_pyramid"), ("mbcmp_satd", "mbcmp_satd"),
+                      ("fpelcmp_satd", "fpelcmp_satd"), ("frame_refs", "refs"), ("open_gop", "open_gop")):
+            assert cfg[k] == rc[rk], (k, cfg[k], rc[rk])
+        be = OracleBackend(cfg)
+        la = lib.Lookahead(cfg, backend=be.struct)
+        assert la.delay == rc["delay"]
+        try:
+            outs = la.run(frames)
+        finally:
+            la.close()
+    finally:
+        r.close()
+    assert len(outs) == nf
+    got_idx = [o.frame for o in outs]
+    got_type = [o.type for o in outs]
+    assert got_idx == list(ref["idx"]), "coded order differs"
+    assert got_type == list(ref["type"]), "slice types differ"
+    nb = cfg["bframes"] + 2
+    for k, o in enumerate(outs):
+        ce = np.array([[o.cost_est[i][j] for j in range(nb)] for i in range(nb)])
+        ca = np.array([[o.cost_est_aq[i][j] for j in range(nb)] for i in range(nb)])
+        rce = ref["cost"][k][:nb, :nb]
+        assert np.array_equal(ce, rce), ("i_cost_est", k, o.frame)
+        m = rce >= 0
+        assert np.array_equal(ca[m], ref["cost_aq"][k][:nb, :nb][m]), ("i_cost_est_aq", k, o.frame)
+    assert be.n_eval > nf

@@ -1,0 +1,839 @@
+// lookahead_host.cpp -- host side of the lookahead: the slice-type decision logic of the reference
+// (encoder/slicetype.c, encoder/lookahead.c), restated over an evaluation backend.  The decisions stay
+// on the CPU ("tiny, stays on host"); every pixel-touching step goes through the
+// backend, which in the product is the HIP context of x264hip.hip (no CPU implementation exists here).
+//
+// Cited line numbers refer to jpsdr/x264 encoder/slicetype.c unless another file is named.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <deque>
+#include <vector>
+
+#include "x264hip.h"
+
+namespace {
+
+enum { T_AUTO = 0, T_IDR = 1, T_I = 2, T_P = 3, T_BREF = 4, T_B = 5, T_KEYFRAME = 6 };
+static inline bool is_i( int t ) { return t == T_I || t == T_IDR || t == T_KEYFRAME; }
+static inline bool is_b( int t ) { return t == T_B || t == T_BREF; }
+static inline bool auto_or_i( int t ) { return t == T_AUTO || is_i( t ); }
+static inline bool auto_or_b( int t ) { return t == T_AUTO || is_b( t ); }
+
+const int BMAX = X264HIP_BFRAME_MAX;
+const int LOOKAHEAD_MAX = 250; // X264_LOOKAHEAD_MAX, common/base.h:140
+const uint64_t COST_MAX64 = 1ULL << 60;
+
+struct LaFrame
+{
+    int slot = -1;
+    int i_frame = 0;
+    int i_type = T_AUTO, i_forced_type = T_AUTO;
+    int b_scenecut = 1;      // frame.c:792
+    int b_keyframe = 0;
+    int i_bframes = 0;
+    int refcount = 0;
+    int cost_est[BMAX + 2][BMAX + 2];
+    int cost_est_aq[BMAX + 2][BMAX + 2];
+    int intra_mbs[BMAX + 2];
+    bool searched[2][BMAX + 1]; // lowres_mvs[l][d][0][0] != 0x7FFF
+    bool intra_calculated = false;
+    x264hip_weight weight = { 0, 1, 0, 0 };
+    uint64_t pixel_sum = 0, pixel_ssd = 0;
+    bool stats_valid = false;
+};
+
+static int ue_size( unsigned v ) // bs_size_ue, common/bitstream.h:278 (2*floor(log2(v+1))+1)
+{
+    int n = 0;
+    for( unsigned t = v + 1; t > 1; t >>= 1 ) n++;
+    return 2 * n + 1;
+}
+static int se_size( int v ) // bs_size_se, common/bitstream.h:291
+{
+    unsigned t = v <= 0 ? (unsigned)( 1 - 2 * v ) : (unsigned)( 2 * v );
+    return ue_size( t - 1 );
+}
+static inline int clip3i( int v, int lo, int hi ) { return v < lo ? lo : v > hi ? hi : v; }
+
+struct Lookahead
+{
+    x264hip_la_params p;
+    x264hip_backend be;
+    x264hip_ctx *ctx = nullptr; // owned when opened on a device
+    int i_delay = 0, slicetype_length = 0;
+    int b_analyse_keyframe = 0;
+    int i_last_keyframe = 0;
+    int i_input = 0;
+    std::vector<LaFrame *> next;     // h->lookahead->next
+    std::deque<LaFrame *> current;   // ofbuf + h->frames.current
+    LaFrame *last_nonb = nullptr;
+    std::vector<int> free_slots;
+    std::vector<LaFrame *> pending_prefetch;
+    uint64_t stats[8] = { 0 };
+    int err = 0;
+
+    // ---- frame bookkeeping -------------------------------------------------------------------------
+    void release( LaFrame *f )
+    {
+        if( --f->refcount > 0 ) return;
+        free_slots.push_back( f->slot );
+        delete f;
+    }
+
+    int need( int rc )
+    {
+        if( rc && !err ) err = rc;
+        return rc;
+    }
+
+    // ---- slicetype_frame_cost (:836-995) -----------------------------------------------------------
+    int frame_cost( LaFrame **frames, int p0, int p1, int b )
+    {
+        LaFrame *fenc = frames[b];
+        stats[0]++;
+        if( fenc->cost_est[b - p0][p1 - b] >= 0 )
+            return fenc->cost_est[b - p0][p1 - b];
+        if( err ) return 0;
+        int do_search[2];
+        const x264hip_weight *w = nullptr;
+        do_search[0] = b != p0 && !fenc->searched[0][b - p0 - 1];
+        do_search[1] = b != p1 && !fenc->searched[1][p1 - b - 1];
+        if( do_search[0] )
+        {
+            if( p.weightp && b == p1 )
+            {
+                weights_analyse( fenc, frames[p0] );
+                if( fenc->weight.on ) w = &fenc->weight;
+            }
+            fenc->searched[0][b - p0 - 1] = true;
+        }
+        if( do_search[1] ) fenc->searched[1][p1 - b - 1] = true;
+        if( err ) return 0;
+
+        x264hip_cost out;
+        memset( &out, 0, sizeof( out ) );
+        const int with_intra = !fenc->intra_calculated;
+        const int ref1_valid = b < p1 && frames[p1]->searched[0][p1 - p0 - 1];
+        stats[1]++;
+        if( need( be.frame_cost( be.user, frames[p0]->slot, frames[p1]->slot, fenc->slot, b - p0, p1 - b, do_search, w, with_intra,
+                                 ref1_valid, &out ) ) )
+            return 0;
+        if( b == p1 )
+            fenc->intra_mbs[b - p0] = out.intra_mbs;
+        if( with_intra )
+        {
+            fenc->cost_est[0][0] = out.intra_cost_est;
+            fenc->cost_est_aq[0][0] = out.intra_cost_est_aq;
+        }
+        int score;
+        if( p0 == p1 )
+        {
+            // the [0][0] cell: the intra sums when just computed (otherwise the memo above would have hit)
+            score = with_intra ? out.intra_cost_est : 0;
+            fenc->cost_est_aq[0][0] = with_intra ? out.intra_cost_est_aq : 0;
+        }
+        else
+        {
+            score = out.cost_est;
+            fenc->cost_est_aq[b - p0][p1 - b] = out.cost_est_aq;
+        }
+        if( b != p1 )
+            score = (int)( (uint64_t)score * 100 / ( 120 + p.dev.bframe_bias ) );
+        else
+            fenc->intra_calculated = true;
+        fenc->cost_est[b - p0][p1 - b] = score;
+        return score;
+    }
+
+    // ---- x264_weights_analyse, lookahead mode (:284-501 with b_lookahead = 1) ----------------------
+    int weight_header_cost( const x264hip_weight &w ) // weight_slice_header_cost (:170-189), luma, one slice
+    {
+        int denom_cost = ue_size( w.denom ) * 2;
+        return p.dev.lambda * ( 10 + denom_cost + 2 * ( se_size( w.scale ) + se_size( w.offset ) ) );
+    }
+
+    bool frame_stats( LaFrame *f )
+    {
+        if( !f->stats_valid )
+        {
+            if( need( be.frame_stats( be.user, f->slot, &f->pixel_sum, &f->pixel_ssd ) ) ) return false;
+            f->stats_valid = true;
+        }
+        return true;
+    }
+
+    void weights_analyse( LaFrame *fenc, LaFrame *ref )
+    {
+        stats[2]++;
+        const float epsilon = 1.f / 128.f;
+        x264hip_weight &wt = fenc->weight;
+        wt.on = 0; wt.scale = 1; wt.denom = 0; wt.offset = 0;
+        if( !frame_stats( fenc ) || !frame_stats( ref ) ) return;
+        const int mb_w = ( p.dev.width + 15 ) / 16, mb_h = ( p.dev.height + 15 ) / 16;
+        const int lines = 16 * mb_h, width = 16 * mb_w;
+        const int zero_bias = !ref->pixel_ssd;
+        float fenc_var = (float)( fenc->pixel_ssd + zero_bias );
+        float ref_var = (float)( ref->pixel_ssd + zero_bias );
+        float guess_scale = sqrtf( fenc_var / ref_var );
+        float fenc_mean = (float)( (uint32_t)fenc->pixel_sum + zero_bias ) / ( lines * width ) / ( 1 << ( p.dev.bit_depth - 8 ) );
+        float ref_mean = (float)( (uint32_t)ref->pixel_sum + zero_bias ) / ( lines * width ) / ( 1 << ( p.dev.bit_depth - 8 ) );
+
+        if( fabsf( ref_mean - fenc_mean ) < 0.5f && fabsf( 1.f - guess_scale ) < epsilon )
+            return;
+        // weight_get_h264 (:64-75)
+        {
+            int s = (int)round( guess_scale * 128 );
+            wt.offset = 0; wt.denom = 7; wt.scale = s;
+            while( wt.denom > 0 && wt.scale > 127 ) { wt.denom--; wt.scale >>= 1; }
+            if( wt.scale > 127 ) wt.scale = 127;
+        }
+        int mindenom = wt.denom, minscale = wt.scale, minoff = 0, found = 0;
+        if( !fenc->intra_calculated )
+        {
+            LaFrame *one[1] = { fenc };
+            frame_cost( one, 0, 0, 0 );
+        }
+        if( err ) { wt.on = 0; return; }
+        unsigned minscore = 0, origscore = 0;
+        if( need( be.weight_cost( be.user, fenc->slot, ref->slot, nullptr, &origscore ) ) ) { wt.on = 0; return; }
+        minscore = origscore;
+        if( !minscore ) { wt.on = 0; wt.scale = 1; wt.denom = 0; wt.offset = 0; /* keeps the guessed values off */ return; }
+        {
+            // lookahead mode: one (scale, offset) candidate (:401-439 with both distances 0)
+            int i_scale = clip3i( minscale, 0, 127 );
+            int cur_scale = i_scale;
+            int cur_offset = (int)( fenc_mean - ref_mean * cur_scale / ( 1 << mindenom ) + 0.5f * 1 );
+            if( cur_offset < -128 || cur_offset > 127 )
+            {
+                cur_offset = clip3i( cur_offset, -128, 127 );
+                double v = ( 1 << mindenom ) * ( fenc_mean - cur_offset ) / ref_mean + 0.5f;
+                cur_scale = (int)( v < 0 ? 0 : v > 127 ? 127 : v );
+            }
+            int i_off = clip3i( cur_offset, -128, 127 );
+            x264hip_weight cand = { 1, cur_scale, mindenom, i_off };
+            unsigned s = 0;
+            if( need( be.weight_cost( be.user, fenc->slot, ref->slot, &cand, &s ) ) ) { wt.on = 0; return; }
+            s += weight_header_cost( cand );
+            if( s < minscore ) { minscore = s; minscale = cur_scale; minoff = i_off; found = 1; }
+        }
+        while( mindenom > 0 && !( minscale & 1 ) ) { mindenom--; minscale >>= 1; }
+        if( !found || ( minscale == 1 << mindenom && minoff == 0 ) || (float)minscore / origscore > 0.998f )
+        {
+            wt.on = 0; wt.scale = 1; wt.denom = 0; wt.offset = 0;
+            return;
+        }
+        wt.on = 1; wt.scale = minscale; wt.denom = mindenom; wt.offset = minoff;
+        stats[3]++;
+    }
+
+    // ---- slicetype_path_cost (:1288-1327) ----------------------------------------------------------
+    uint64_t path_cost( LaFrame **frames, const char *path, uint64_t threshold )
+    {
+        uint64_t cost = 0;
+        int loc = 1, cur_nonb = 0;
+        path--; // path[1] describes frames[1]
+        while( path[loc] )
+        {
+            int next_nonb = loc;
+            while( path[next_nonb] == 'B' ) next_nonb++;
+            if( path[next_nonb] == 'P' )
+                cost += frame_cost( frames, cur_nonb, next_nonb, next_nonb );
+            else
+                cost += frame_cost( frames, next_nonb, next_nonb, next_nonb );
+            if( cost > threshold ) break;
+            if( p.b_pyramid && next_nonb - cur_nonb > 2 )
+            {
+                int middle = cur_nonb + ( next_nonb - cur_nonb ) / 2;
+                cost += frame_cost( frames, cur_nonb, next_nonb, middle );
+                for( int nb = loc; nb < middle && cost < threshold; nb++ )
+                    cost += frame_cost( frames, cur_nonb, middle, nb );
+                for( int nb = middle + 1; nb < next_nonb && cost < threshold; nb++ )
+                    cost += frame_cost( frames, middle, next_nonb, nb );
+            }
+            else
+                for( int nb = loc; nb < next_nonb && cost < threshold; nb++ )
+                    cost += frame_cost( frames, cur_nonb, next_nonb, nb );
+            loc = next_nonb + 1;
+            cur_nonb = next_nonb;
+        }
+        return cost;
+    }
+
+    // ---- slicetype_path: one Viterbi step (:1333-1382) ---------------------------------------------
+    void slicetype_path( LaFrame **frames, int length, char ( *best_paths )[LOOKAHEAD_MAX + 1] )
+    {
+        char paths[2][LOOKAHEAD_MAX + 1];
+        int num_paths = p.dev.bframes + 1 < length ? p.dev.bframes + 1 : length;
+        uint64_t best_cost = COST_MAX64;
+        int best_possible = 0, idx = 0;
+        for( int path = 0; path < num_paths; path++ )
+        {
+            int len = length - ( path + 1 );
+            memcpy( paths[idx], best_paths[len % ( BMAX + 1 )], len );
+            memset( paths[idx] + len, 'B', path );
+            strcpy( paths[idx] + len + path, "P" );
+            int possible = 1;
+            for( int i = 1; i <= length; i++ )
+            {
+                int t = frames[i]->i_type;
+                if( t == T_AUTO ) continue;
+                if( is_b( t ) )
+                    possible = possible && ( i < len || i == length || paths[idx][i - 1] == 'B' );
+                else
+                {
+                    possible = possible && ( i < len || paths[idx][i - 1] != 'B' );
+                    paths[idx][i - 1] = is_i( t ) ? 'I' : 'P';
+                }
+            }
+            if( possible || !best_possible )
+            {
+                if( possible && !best_possible ) best_cost = COST_MAX64;
+                uint64_t cost = path_cost( frames, paths[idx], best_cost );
+                if( cost < best_cost )
+                {
+                    best_cost = cost; best_possible = possible; idx ^= 1;
+                }
+            }
+        }
+        memcpy( best_paths[length % ( BMAX + 1 )], paths[idx ^ 1], length );
+    }
+
+    // ---- scenecut (:1384-1468) ---------------------------------------------------------------------
+    int scenecut_internal( LaFrame **frames, int p0, int p1 )
+    {
+        LaFrame *frame = frames[p1];
+        frame_cost( frames, p0, p1, p1 );
+        int icost = frame->cost_est[0][0];
+        int pcost = frame->cost_est[p1 - p0][0];
+        float f_bias;
+        int gop_size = frame->i_frame - i_last_keyframe;
+        float thresh_max = p.scenecut_threshold / 100.0;
+        float thresh_min = thresh_max * 0.25;
+        if( p.keyint_min == p.keyint_max ) thresh_min = thresh_max;
+        if( gop_size <= p.keyint_min / 4 )
+            f_bias = thresh_min / 4;
+        else if( gop_size <= p.keyint_min )
+            f_bias = thresh_min * gop_size / p.keyint_min;
+        else
+            f_bias = thresh_min + ( thresh_max - thresh_min ) * ( gop_size - p.keyint_min ) / ( p.keyint_max - p.keyint_min );
+        return pcost >= ( 1.0 - f_bias ) * icost;
+    }
+
+    int scenecut( LaFrame **frames, int p0, int p1, int real_scenecut, int num_frames, int i_max_search )
+    {
+        if( real_scenecut && p.dev.bframes )
+        {
+            int origmaxp1 = p0 + 1;
+            if( p.b_adapt == 2 ) origmaxp1 += p.dev.bframes;
+            else origmaxp1++;
+            int maxp1 = origmaxp1 < num_frames ? origmaxp1 : num_frames;
+            for( int curp1 = p1; curp1 <= maxp1; curp1++ )
+                if( !scenecut_internal( frames, p0, curp1 ) )
+                    for( int i = curp1; i > p0; i-- )
+                        frames[i]->b_scenecut = 0;
+            for( int curp0 = p0; curp0 <= maxp1; curp0++ )
+                if( origmaxp1 > i_max_search || ( curp0 < maxp1 && scenecut_internal( frames, curp0, maxp1 ) ) )
+                    frames[curp0]->b_scenecut = 0;
+        }
+        if( !frames[p1]->b_scenecut ) return 0;
+        return scenecut_internal( frames, p0, p1 );
+    }
+
+    // ---- macroblock_tree (:1091-1184): the evaluation order only.  The propagation arithmetic
+    // (mbtree_propagate_cost/list, float) does not influence slice types or cost cells and is the next
+    // row of SURVEY 8(f); the calls below are what keeps memoisation / first-trigger state identical.
+    void macroblock_tree( LaFrame **frames, int num_frames, int b_intra )
+    {
+        int idx = !b_intra, last_nonb, cur_nonb = 1, bframes = 0;
+        int i = num_frames;
+        if( b_intra ) frame_cost( frames, 0, 0, 0 );
+        while( i > 0 && is_b( frames[i]->i_type ) ) i--;
+        last_nonb = i;
+        if( !p.rc_lookahead )
+        {
+            if( b_intra ) return;
+        }
+        else if( last_nonb < idx )
+            return;
+        while( i-- > idx )
+        {
+            cur_nonb = i;
+            while( is_b( frames[cur_nonb]->i_type ) && cur_nonb > 0 ) cur_nonb--;
+            if( cur_nonb < idx ) break;
+            frame_cost( frames, cur_nonb, last_nonb, last_nonb );
+            bframes = last_nonb - cur_nonb - 1;
+            if( p.b_pyramid && bframes > 1 )
+            {
+                int middle = ( bframes + 1 ) / 2 + cur_nonb;
+                frame_cost( frames, cur_nonb, last_nonb, middle );
+                while( i > cur_nonb )
+                {
+                    int q0 = i > middle ? middle : cur_nonb;
+                    int q1 = i < middle ? middle : last_nonb;
+                    if( i != middle ) frame_cost( frames, q0, q1, i );
+                    i--;
+                }
+            }
+            else
+                while( i > cur_nonb )
+                {
+                    frame_cost( frames, cur_nonb, last_nonb, i );
+                    i--;
+                }
+            last_nonb = cur_nonb;
+        }
+        if( !p.rc_lookahead )
+            frame_cost( frames, 0, last_nonb, last_nonb );
+    }
+
+    // ---- x264_slicetype_analyse (:1473-1743) -------------------------------------------------------
+    void analyse( int intra_minigop )
+    {
+        LaFrame *frames[LOOKAHEAD_MAX + 3] = { nullptr };
+        int num_frames, orig_num_frames, keyint_limit, framecnt;
+        int i_max_search = (int)next.size() < LOOKAHEAD_MAX ? (int)next.size() : LOOKAHEAD_MAX;
+        if( i_max_search > slicetype_length + 1 - intra_minigop ) // b_deterministic
+            i_max_search = slicetype_length + 1 - intra_minigop;
+        int keyframe = !!intra_minigop;
+        if( !last_nonb ) return;
+        frames[0] = last_nonb;
+        for( framecnt = 0; framecnt < i_max_search; framecnt++ )
+            frames[framecnt + 1] = next[framecnt];
+        if( !framecnt )
+        {
+            if( p.mb_tree ) macroblock_tree( frames, 0, keyframe );
+            return;
+        }
+        keyint_limit = p.keyint_max - frames[0]->i_frame + i_last_keyframe - 1;
+        orig_num_frames = num_frames = framecnt < keyint_limit ? framecnt : keyint_limit;
+        if( p.psy && p.mb_tree )
+            num_frames = framecnt;
+        else if( p.open_gop && num_frames < framecnt )
+            num_frames++;
+        else if( num_frames == 0 )
+        {
+            frames[1]->i_type = T_I;
+            return;
+        }
+        if( auto_or_i( frames[1]->i_type ) && p.scenecut_threshold && scenecut( frames, 0, 1, 1, orig_num_frames, i_max_search ) )
+        {
+            if( frames[1]->i_type == T_AUTO ) frames[1]->i_type = T_I;
+            return;
+        }
+        for( int j = 1; j <= num_frames; j++ )
+            if( frames[j]->i_type == T_KEYFRAME )
+                frames[j]->i_type = p.open_gop ? T_I : T_IDR;
+        for( int j = 2; j <= num_frames; j++ )
+            if( frames[j]->i_type == T_IDR && auto_or_b( frames[j - 1]->i_type ) )
+                frames[j - 1]->i_type = T_P;
+
+        int num_analysed_frames = num_frames, reset_start;
+        const int bf = p.dev.bframes;
+        if( bf )
+        {
+            if( p.b_adapt == 2 )
+            {
+                if( num_frames > 1 )
+                {
+                    static thread_local char best_paths[BMAX + 1][LOOKAHEAD_MAX + 1];
+                    memset( best_paths, 0, sizeof( best_paths ) );
+                    strcpy( best_paths[1], "P" );
+                    int best_path_index = num_frames % ( BMAX + 1 );
+                    for( int j = 2; j <= num_frames; j++ )
+                        slicetype_path( frames, j, best_paths );
+                    for( int j = 1; j < num_frames; j++ )
+                    {
+                        if( best_paths[best_path_index][j - 1] != 'B' )
+                        {
+                            if( auto_or_b( frames[j]->i_type ) ) frames[j]->i_type = T_P;
+                        }
+                        else if( frames[j]->i_type == T_AUTO )
+                            frames[j]->i_type = T_B;
+                    }
+                }
+            }
+            else if( p.b_adapt == 1 )
+            {
+                int last_nb = 0, num_b = bf;
+                char path[LOOKAHEAD_MAX + 1];
+                for( int j = 1; j < num_frames; j++ )
+                {
+                    if( j - 1 > 0 && is_b( frames[j - 1]->i_type ) )
+                        num_b--;
+                    else
+                    {
+                        last_nb = j - 1;
+                        num_b = bf;
+                    }
+                    if( !num_b )
+                    {
+                        if( auto_or_b( frames[j]->i_type ) ) frames[j]->i_type = T_P;
+                        continue;
+                    }
+                    if( frames[j]->i_type != T_AUTO ) continue;
+                    if( is_b( frames[j + 1]->i_type ) )
+                    {
+                        frames[j]->i_type = T_P;
+                        continue;
+                    }
+                    int nb = j - last_nb - 1;
+                    memset( path, 'B', nb );
+                    strcpy( path + nb, "PP" );
+                    uint64_t cost_p = path_cost( frames + last_nb, path, COST_MAX64 );
+                    strcpy( path + nb, "BP" );
+                    uint64_t cost_b = path_cost( frames + last_nb, path, cost_p );
+                    frames[j]->i_type = cost_b < cost_p ? T_B : T_P;
+                }
+            }
+            else
+            {
+                int num_b = bf;
+                for( int j = 1; j < num_frames; j++ )
+                {
+                    if( !num_b )
+                    {
+                        if( auto_or_b( frames[j]->i_type ) ) frames[j]->i_type = T_P;
+                    }
+                    else if( frames[j]->i_type == T_AUTO )
+                        frames[j]->i_type = is_b( frames[j + 1]->i_type ) ? T_P : T_B;
+                    if( is_b( frames[j]->i_type ) ) num_b--;
+                    else num_b = bf;
+                }
+            }
+            if( auto_or_b( frames[num_frames]->i_type ) )
+                frames[num_frames]->i_type = T_P;
+            int num_b = 0;
+            while( num_b < num_frames && is_b( frames[num_b + 1]->i_type ) ) num_b++;
+            for( int j = 1; j < num_b + 1; j++ )
+                if( frames[j]->i_forced_type == T_AUTO && auto_or_i( frames[j + 1]->i_forced_type ) && p.scenecut_threshold &&
+                    scenecut( frames, j, j + 1, 0, orig_num_frames, i_max_search ) )
+                {
+                    frames[j]->i_type = T_P;
+                    num_analysed_frames = j;
+                    break;
+                }
+            reset_start = keyframe ? 1 : ( num_b + 2 < num_analysed_frames + 1 ? num_b + 2 : num_analysed_frames + 1 );
+        }
+        else
+        {
+            for( int j = 1; j <= num_frames; j++ )
+                if( auto_or_b( frames[j]->i_type ) ) frames[j]->i_type = T_P;
+            reset_start = !keyframe + 1;
+        }
+        if( p.mb_tree )
+            macroblock_tree( frames, num_frames < p.keyint_max ? num_frames : p.keyint_max, keyframe );
+
+        // keyframe limit (:1680-1731), no intra refresh
+        {
+            int last_keyframe = i_last_keyframe, last_possible = 0;
+            for( int j = 1; j <= num_frames; j++ )
+            {
+                LaFrame *frm = frames[j];
+                int keyframe_dist = frm->i_frame - last_keyframe;
+                if( auto_or_i( frm->i_forced_type ) )
+                    if( p.open_gop || !is_b( frames[j - 1]->i_forced_type ) )
+                        last_possible = j;
+                if( keyframe_dist >= p.keyint_max )
+                {
+                    if( last_possible != 0 && last_possible != j )
+                    {
+                        j = last_possible;
+                        frm = frames[j];
+                        keyframe_dist = frm->i_frame - last_keyframe;
+                    }
+                    last_possible = 0;
+                    if( frm->i_type != T_IDR ) frm->i_type = p.open_gop ? T_I : T_IDR;
+                }
+                if( frm->i_type == T_I && keyframe_dist >= p.keyint_min )
+                {
+                    if( p.open_gop )
+                        last_keyframe = frm->i_frame;
+                    else if( frm->i_forced_type != T_I )
+                        frm->i_type = T_IDR;
+                }
+                if( frm->i_type == T_IDR )
+                {
+                    last_keyframe = frm->i_frame;
+                    if( j > 1 && is_b( frames[j - 1]->i_type ) ) frames[j - 1]->i_type = T_P;
+                }
+            }
+        }
+        for( int j = reset_start; j <= num_frames; j++ )
+            frames[j]->i_type = frames[j]->i_forced_type;
+    }
+
+    // ---- x264_slicetype_decide (:1745-1974), type logic and the final cost evaluations --------------
+    void decide()
+    {
+        if( next.empty() ) return;
+        if( ( p.dev.bframes && p.b_adapt ) || p.scenecut_threshold || p.mb_tree )
+            analyse( 0 );
+        int bframes, brefs;
+        LaFrame *frm;
+        for( bframes = 0, brefs = 0;; bframes++ )
+        {
+            frm = next[bframes];
+            if( frm->i_type == T_BREF && p.b_pyramid < 2 && brefs == p.b_pyramid )
+                frm->i_type = T_B;
+            else if( frm->i_type == T_BREF && p.b_pyramid == 2 && brefs && p.frame_refs <= ( brefs + 3 ) )
+                frm->i_type = T_B;
+            if( frm->i_type == T_KEYFRAME )
+                frm->i_type = p.open_gop ? T_I : T_IDR;
+            if( frm->i_frame - i_last_keyframe >= p.keyint_max )
+            {
+                if( frm->i_type == T_AUTO || frm->i_type == T_I )
+                    frm->i_type = p.open_gop && i_last_keyframe >= 0 ? T_I : T_IDR;
+                int warn = frm->i_type != T_IDR;
+                if( warn && p.open_gop ) warn &= frm->i_type != T_I;
+                if( warn )
+                    frm->i_type = p.open_gop && i_last_keyframe >= 0 ? T_I : T_IDR;
+            }
+            if( frm->i_type == T_I && frm->i_frame - i_last_keyframe >= p.keyint_min )
+            {
+                if( p.open_gop )
+                {
+                    i_last_keyframe = frm->i_frame;
+                    frm->b_keyframe = 1;
+                }
+                else
+                    frm->i_type = T_IDR;
+            }
+            if( frm->i_type == T_IDR )
+            {
+                i_last_keyframe = frm->i_frame;
+                frm->b_keyframe = 1;
+                if( bframes > 0 )
+                {
+                    bframes--;
+                    next[bframes]->i_type = T_P;
+                }
+            }
+            if( bframes == p.dev.bframes || bframes + 1 >= (int)next.size() )
+            {
+                if( frm->i_type == T_AUTO || is_b( frm->i_type ) )
+                    frm->i_type = T_P;
+            }
+            if( frm->i_type == T_BREF ) brefs++;
+            if( frm->i_type == T_AUTO )
+                frm->i_type = T_B;
+            else if( !is_b( frm->i_type ) )
+                break;
+        }
+        next[bframes]->i_bframes = bframes;
+        if( p.b_pyramid && bframes > 1 && !brefs )
+        {
+            next[( bframes - 1 ) / 2]->i_type = T_BREF;
+            brefs++;
+        }
+        // costs ahead of time for rate control (:1898-1935); VBV variants are out of scope
+        if( !p.rc_is_cqp )
+        {
+            LaFrame *frames[BMAX + 3];
+            int p1 = bframes + 1, b = bframes + 1, p0;
+            frames[0] = last_nonb;
+            for( int i = 0; i <= bframes; i++ ) frames[i + 1] = next[i];
+            p0 = is_i( next[bframes]->i_type ) ? bframes + 1 : 0;
+            frame_cost( frames, p0, p1, b );
+        }
+        // coded order (:1945-1960)
+        if( bframes )
+        {
+            std::vector<LaFrame *> tmp( bframes + 1 );
+            int idx_list[2] = { brefs + 1, 1 };
+            for( int i = 0; i < bframes; i++ )
+            {
+                int idx = idx_list[next[i]->i_type == T_BREF]++;
+                tmp[idx] = next[i];
+            }
+            tmp[0] = next[bframes];
+            for( int i = 0; i <= bframes; i++ ) next[i] = tmp[i];
+        }
+    }
+
+    // ---- x264_lookahead_get_frames, non-threaded branch (lookahead.c:223-250) -----------------------
+    void get_frames()
+    {
+        if( !current.empty() || next.empty() ) return;
+        flush_prefetch();
+        decide();
+        LaFrame *new_nonb = next[0];
+        if( last_nonb ) release( last_nonb );
+        last_nonb = new_nonb;
+        new_nonb->refcount++;
+        int shift = next[0]->i_bframes + 1;
+        for( int i = 0; i < shift; i++ ) current.push_back( next[i] );
+        next.erase( next.begin(), next.begin() + shift );
+        if( b_analyse_keyframe && is_i( last_nonb->i_type ) )
+            analyse( shift );
+    }
+
+    void flush_prefetch()
+    {
+        if( pending_prefetch.empty() || !be.prefetch ) { pending_prefetch.clear(); return; }
+        // everything resident in the window: last_nonb + next (pairs further apart than bframes+1 are skipped by the backend)
+        std::vector<int> slots, nums;
+        if( last_nonb ) { slots.push_back( last_nonb->slot ); nums.push_back( last_nonb->i_frame ); }
+        for( auto f : next ) { slots.push_back( f->slot ); nums.push_back( f->i_frame ); }
+        need( be.prefetch( be.user, slots.data(), nums.data(), (int)slots.size() ) );
+        pending_prefetch.clear();
+    }
+};
+
+// ---- device backend thunks ---------------------------------------------------------------------------
+static int dev_frame_put( void *u, int slot, const void *luma, int stride, int is_device )
+{
+    return x264hip_frame_put( (x264hip_ctx *)u, slot, luma, stride, is_device, nullptr, nullptr, 0, nullptr );
+}
+static int dev_frame_stats( void *u, int slot, uint64_t *s, uint64_t *q ) { return x264hip_frame_stats( (x264hip_ctx *)u, slot, s, q ); }
+static int dev_weight_cost( void *u, int f, int r, const x264hip_weight *w, unsigned *c ) { return x264hip_weight_cost( (x264hip_ctx *)u, f, r, w, c ); }
+static int dev_frame_cost( void *u, int p0, int p1, int b, int d0, int d1, const int ds[2], const x264hip_weight *w, int wi, int rv, x264hip_cost *o )
+{
+    return x264hip_frame_cost( (x264hip_ctx *)u, p0, p1, b, d0, d1, ds, w, wi, rv, o );
+}
+static int dev_prefetch( void *u, const int *s, const int *n, int c ) { return x264hip_prefetch( (x264hip_ctx *)u, s, n, c ); }
+
+} // namespace
+
+struct x264hip_lookahead
+{
+    Lookahead L;
+};
+
+static int la_init( x264hip_lookahead *la, const x264hip_la_params *params )
+{
+    Lookahead &L = la->L;
+    L.p = *params;
+    const x264hip_la_params &p = L.p;
+    if( p.dev.bframes < 0 || p.dev.bframes > BMAX || p.keyint_max < 1 || p.rc_lookahead < 0 || p.rc_lookahead > LOOKAHEAD_MAX ||
+        p.b_adapt < 0 || p.b_adapt > 2 || p.b_pyramid < 0 || p.b_pyramid > 2 )
+        return X264HIP_EINVAL;
+    // encoder.c:1601-1612 with one frame thread, no lookahead thread, cfr input
+    if( p.b_adapt == 2 )
+        L.i_delay = ( p.dev.bframes > 3 ? p.dev.bframes : 3 ) * 4;
+    else
+        L.i_delay = p.dev.bframes;
+    if( p.mb_tree )
+        L.i_delay = L.i_delay > p.rc_lookahead ? L.i_delay : p.rc_lookahead;
+    L.slicetype_length = L.i_delay;
+    L.b_analyse_keyframe = p.mb_tree; // lookahead.c:140-141 (no VBV, no stats read)
+    L.i_last_keyframe = -p.keyint_max;
+    return X264HIP_OK;
+}
+
+static int slots_needed( const x264hip_la_params *p )
+{
+    int delay = p->b_adapt == 2 ? ( p->dev.bframes > 3 ? p->dev.bframes : 3 ) * 4 : p->dev.bframes;
+    if( p->mb_tree && p->rc_lookahead > delay ) delay = p->rc_lookahead;
+    return delay + p->dev.bframes + 8;
+}
+
+extern "C" int x264hip_lookahead_open_backend( x264hip_lookahead **out, const x264hip_la_params *params, const x264hip_backend *backend )
+{
+    if( !out || !params || !backend || !backend->frame_put || !backend->frame_cost || !backend->frame_stats || !backend->weight_cost )
+        return X264HIP_EINVAL;
+    x264hip_lookahead *la = new x264hip_lookahead();
+    int rc = la_init( la, params );
+    if( rc ) { delete la; return rc; }
+    la->L.be = *backend;
+    int n = params->dev.max_frames > 0 ? params->dev.max_frames : slots_needed( params );
+    for( int i = n - 1; i >= 0; i-- ) la->L.free_slots.push_back( i );
+    *out = la;
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_lookahead_open( x264hip_lookahead **out, int device, const x264hip_la_params *params )
+{
+    if( !out || !params ) return X264HIP_EINVAL;
+    x264hip_la_params p = *params;
+    if( p.dev.max_frames <= 0 ) p.dev.max_frames = slots_needed( &p );
+    x264hip_ctx *ctx = nullptr;
+    int rc = x264hip_open( &ctx, device, &p.dev );
+    if( rc ) return rc;
+    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch };
+    rc = x264hip_lookahead_open_backend( out, &p, &be );
+    if( rc ) { x264hip_close( ctx ); return rc; }
+    ( *out )->L.ctx = ctx;
+    return X264HIP_OK;
+}
+
+extern "C" void x264hip_lookahead_close( x264hip_lookahead *la )
+{
+    if( !la ) return;
+    Lookahead &L = la->L;
+    for( auto f : L.next ) delete f;
+    for( auto f : L.current ) if( f != L.last_nonb ) delete f;
+    if( L.last_nonb ) delete L.last_nonb;
+    if( L.ctx ) x264hip_close( L.ctx );
+    delete la;
+}
+
+extern "C" x264hip_ctx *x264hip_lookahead_ctx( x264hip_lookahead *la ) { return la ? la->L.ctx : nullptr; }
+extern "C" int x264hip_lookahead_delay( x264hip_lookahead *la ) { return la ? la->L.i_delay : X264HIP_EINVAL; }
+
+extern "C" int x264hip_lookahead_put_frame( x264hip_lookahead *la, const void *luma, int stride, int is_device, int forced_type )
+{
+    if( !la || !luma ) return X264HIP_EINVAL;
+    Lookahead &L = la->L;
+    if( L.err ) return L.err;
+    if( L.free_slots.empty() ) return X264HIP_ESTATE;
+    LaFrame *f = new LaFrame();
+    f->slot = L.free_slots.back(); L.free_slots.pop_back();
+    f->i_frame = L.i_input++;
+    f->i_forced_type = f->i_type = forced_type;
+    f->refcount = 1;
+    memset( f->cost_est, -1, sizeof( f->cost_est ) );      // mc.c:473
+    memset( f->cost_est_aq, 0, sizeof( f->cost_est_aq ) );
+    memset( f->intra_mbs, 0, sizeof( f->intra_mbs ) );
+    memset( f->searched, 0, sizeof( f->searched ) );       // mc.c:479-481
+    int rc = L.be.frame_put( L.be.user, f->slot, luma, stride, is_device );
+    if( rc )
+    {
+        L.free_slots.push_back( f->slot );
+        delete f;
+        return L.need( rc );
+    }
+    L.next.push_back( f );
+    L.pending_prefetch.push_back( f );
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_lookahead_get_frame( x264hip_lookahead *la, int flush, x264hip_la_frame *out, int *got )
+{
+    if( !la || !out || !got ) return X264HIP_EINVAL;
+    Lookahead &L = la->L;
+    *got = 0;
+    if( L.err ) return L.err;
+    // encoder.c:3428-3433: nothing to encode while the lookahead delay fills
+    if( !flush && L.i_input <= L.i_delay + 1 - 1 )
+        return X264HIP_OK;
+    if( L.current.empty() )
+        L.get_frames();
+    if( L.err ) return L.err;
+    if( L.current.empty() )
+        return X264HIP_OK;
+    LaFrame *f = L.current.front();
+    L.current.pop_front();
+    out->frame = f->i_frame; out->type = f->i_type; out->bframes = f->i_bframes; out->keyframe = f->b_keyframe;
+    for( int i = 0; i < BMAX + 2; i++ )
+    {
+        for( int j = 0; j < BMAX + 2; j++ )
+        {
+            bool alloc = i <= L.p.dev.bframes + 1 && j <= L.p.dev.bframes + 1;
+            out->cost_est[i][j] = alloc ? f->cost_est[i][j] : -1;
+            out->cost_est_aq[i][j] = alloc ? f->cost_est_aq[i][j] : 0;
+        }
+        out->intra_mbs[i] = f->intra_mbs[i];
+    }
+    *got = 1;
+    L.release( f );
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_lookahead_stats( x264hip_lookahead *la, uint64_t *out, int n )
+{
+    if( !la || !out ) return X264HIP_EINVAL;
+    for( int i = 0; i < n && i < 8; i++ ) out[i] = la->L.stats[i];
+    return X264HIP_OK;
+}

@@ -191,3 +191,182 @@ class Context:
         out = np.zeros(8, np.uint64)
         _ck(self.L.x264hip_counters(self.h, _p(out), 8), "counters")
         return out
+
+
+# ---- host-side lookahead (x264hip_lookahead_*) -----------------------------------------------------------
+class LaParams(C.Structure):
+    _fields_ = [("dev", Params), ("keyint_max", C.c_int), ("keyint_min", C.c_int), ("scenecut_threshold", C.c_int),
+                ("b_adapt", C.c_int), ("b_pyramid", C.c_int), ("rc_lookahead", C.c_int), ("mb_tree", C.c_int),
+                ("weightp", C.c_int), ("open_gop", C.c_int), ("frame_refs", C.c_int), ("psy", C.c_int),
+                ("rc_is_cqp", C.c_int)]
+
+
+FRAME_PUT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int)
+FRAME_STATS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+WEIGHT_COST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(Weight), C.POINTER(C.c_uint))
+FRAME_COST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
+                            C.POINTER(Weight), C.c_int, C.c_int, C.POINTER(Cost))
+PREFETCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int)
+
+
+class Backend(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("frame_put", FRAME_PUT_FN), ("frame_stats", FRAME_STATS_FN),
+                ("weight_cost", WEIGHT_COST_FN), ("frame_cost", FRAME_COST_FN), ("prefetch", PREFETCH_FN)]
+
+
+class LaFrameOut(C.Structure):
+    _fields_ = [("frame", C.c_int), ("type", C.c_int), ("bframes", C.c_int), ("keyframe", C.c_int),
+                ("cost_est", (C.c_int * (BFRAME_MAX + 2)) * (BFRAME_MAX + 2)),
+                ("cost_est_aq", (C.c_int * (BFRAME_MAX + 2)) * (BFRAME_MAX + 2)),
+                ("intra_mbs", C.c_int * (BFRAME_MAX + 2))]
+
+
+# x264 presets relevant to the lookahead (common/base.c:489-609) and defaults (base.c:344-485)
+PRESETS = {
+    "medium": dict(),
+    "slow": dict(subme=8, rc_lookahead=50, frame_refs=5),
+    "slower": dict(subme=9, rc_lookahead=60, b_adapt=2, me="umh", frame_refs=8),
+    "veryslow": dict(subme=10, rc_lookahead=60, b_adapt=2, me="umh", me_range=24, bframes=8, frame_refs=16),
+    "fast": dict(subme=6, rc_lookahead=30, weightp=1, frame_refs=2),
+    "faster": dict(subme=4, rc_lookahead=20, weightp=1, frame_refs=2),
+    "veryfast": dict(subme=2, rc_lookahead=10, weightp=1, frame_refs=1),
+}
+_ME = {"dia": 0, "hex": 1, "umh": 2, "esa": 3, "tesa": 4}
+
+
+def mv_range_for(width, height, fps=25.0):
+    """param.analyse.i_mv_range as derived from the automatically chosen level (encoder/set.c
+    x264_validate_levels / encoder.c:1265-1268): the smallest level whose frame size, MB rate and DPB fit."""
+    mbs = ((width + 15) // 16) * ((height + 15) // 16)
+    # (frame_size, mbps, mv_range) of common/tables.c x264_levels, ascending
+    levels = [(99, 1485, 64), (99, 1485, 64), (396, 3000, 128), (396, 6000, 128), (396, 11880, 128), (396, 11880, 128),
+              (792, 19800, 256), (1620, 20250, 256), (1620, 40500, 256), (3600, 108000, 512), (5120, 216000, 512),
+              (8192, 245760, 512), (8192, 245760, 512), (8704, 522240, 512), (22080, 589824, 512), (36864, 983040, 512),
+              (36864, 2073600, 512), (139264, 4177920, 512), (139264, 8355840, 512), (139264, 16711680, 512)]
+    for fs, mbps, mvr in levels:
+        if mbs <= fs and mbs * fps <= mbps:
+            return mvr
+    return 512
+
+
+def la_config(width, height, preset="medium", bit_depth=8, **over):
+    """Effective lookahead configuration for an x264 preset (+ overrides), as validate_parameters and
+    lowres_context_init derive it (encoder/encoder.c:423-1407, encoder/slicetype.c:45-61)."""
+    c = dict(bframes=3, b_adapt=1, b_pyramid=2, rc_lookahead=40, me="hex", me_range=16, subme=7, weightp=2,
+             weighted_bipred=1, mb_tree=1, aq_mode=1, aq_strength=1.0, scenecut=40, keyint_max=250, keyint_min=0,
+             open_gop=0, frame_refs=3, psy=1, rc_is_cqp=0, bframe_bias=0, fps=25.0, mv_range=0)
+    c.update(PRESETS[preset])
+    c.update(over)
+    if c["keyint_min"] <= 0:
+        c["keyint_min"] = min(c["keyint_max"] // 10, int(c["fps"]))
+    c["keyint_min"] = max(1, min(c["keyint_min"], c["keyint_max"] // 2 + 1))
+    if c["mv_range"] <= 0:
+        c["mv_range"] = mv_range_for(width, height, c["fps"])
+    me = _ME[c["me"]]
+    if c["subme"] > 1:
+        c["la_me_method"] = min(1, me)
+        c["la_subpel_refine"] = 4
+    else:
+        c["la_me_method"] = 0
+        c["la_subpel_refine"] = 2
+    c["mbcmp_satd"] = int(c["subme"] > 1)
+    c["fpelcmp_satd"] = int(me == 4 and c["subme"] > 1)
+    if not c["bframes"]:
+        c["b_adapt"] = 0
+        c["b_pyramid"] = 0
+    if c["bframes"] <= 1:
+        c["b_pyramid"] = 0
+    if not c["weightp"] and c["mb_tree"] and c["psy"]:
+        c["weightp"] = -1  # X264_WEIGHTP_FAKE (encoder.c:1316-1317): the lookahead still analyses and applies weights
+    c["rc_lookahead"] = min(c["rc_lookahead"], 250)
+    c["rc_lookahead"] = min(c["rc_lookahead"], max(c["keyint_max"], c["bframes"] + 1))
+    c["width"], c["height"], c["bit_depth"] = width, height, bit_depth
+    c["lam"] = 1 if bit_depth == 8 else 4
+    return c
+
+
+def make_la_params(cfg, cost_mv=None, max_frames=0):
+    if cost_mv is None:
+        cost_mv, centre = cost_mv_table(cfg["mv_range"], cfg["lam"])
+    else:
+        cost_mv = np.ascontiguousarray(cost_mv, np.uint16)
+        centre = (cost_mv.size - 1) // 2
+    dev = Params(cfg["bit_depth"], cfg["width"], cfg["height"], cfg["bframes"], cfg["lam"], cfg["la_me_method"],
+                 cfg["la_subpel_refine"], cfg["me_range"], cfg["mv_range"], cfg["subme"], cfg["mbcmp_satd"],
+                 cfg["fpelcmp_satd"], cfg["weighted_bipred"], cfg["aq_mode"], cfg["aq_strength"], cfg["bframe_bias"],
+                 max_frames, cost_mv.ctypes.data + 2 * centre)
+    p = LaParams(dev, cfg["keyint_max"], cfg["keyint_min"], cfg["scenecut"], cfg["b_adapt"], cfg["b_pyramid"],
+                 cfg["rc_lookahead"], cfg["mb_tree"], cfg["weightp"], cfg["open_gop"], cfg["frame_refs"], cfg["psy"],
+                 cfg["rc_is_cqp"])
+    p._keep = cost_mv
+    return p
+
+
+class Lookahead:
+    """x264hip_lookahead: put frames in display order, get frames back in coded order with their types."""
+
+    def __init__(self, cfg, device=0, backend=None, cost_mv=None, max_frames=0):
+        L = load()
+        self.L = L
+        self.cfg = cfg
+        self.params = make_la_params(cfg, cost_mv, max_frames)
+        self.h = C.c_void_p()
+        if backend is None:
+            L.x264hip_lookahead_open.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(LaParams)]
+            _ck(L.x264hip_lookahead_open(C.byref(self.h), device, C.byref(self.params)), "x264hip_lookahead_open")
+        else:
+            self._backend = backend
+            L.x264hip_lookahead_open_backend.argtypes = [C.POINTER(C.c_void_p), C.POINTER(LaParams), C.POINTER(Backend)]
+            _ck(L.x264hip_lookahead_open_backend(C.byref(self.h), C.byref(self.params), C.byref(backend)),
+                "x264hip_lookahead_open_backend")
+        self.dtype = np.uint8 if cfg["bit_depth"] == 8 else np.uint16
+        L.x264hip_lookahead_ctx.restype = C.c_void_p
+        self.delay = L.x264hip_lookahead_delay(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.x264hip_lookahead_close(self.h)
+            self.h = None
+
+    def ctx_handle(self):
+        return C.c_void_p(self.L.x264hip_lookahead_ctx(self.h))
+
+    def put(self, luma=None, device_ptr=None, stride=None, forced_type=0):
+        if device_ptr is not None:
+            _ck(self.L.x264hip_lookahead_put_frame(self.h, C.c_void_p(device_ptr), stride or self.cfg["width"], 1,
+                                                   forced_type), "lookahead_put_frame")
+            return
+        luma = np.ascontiguousarray(luma, self.dtype)
+        _ck(self.L.x264hip_lookahead_put_frame(self.h, _p(luma), luma.shape[1], 0, forced_type), "lookahead_put_frame")
+
+    def get(self, flush=False):
+        out = LaFrameOut()
+        got = C.c_int(0)
+        _ck(self.L.x264hip_lookahead_get_frame(self.h, int(flush), C.byref(out), C.byref(got)), "lookahead_get_frame")
+        return out if got.value else None
+
+    def stats(self):
+        out = np.zeros(8, np.uint64)
+        _ck(self.L.x264hip_lookahead_stats(self.h, _p(out), 8), "lookahead_stats")
+        return out
+
+    def run(self, frames=None, device_ptrs=None, stride=None, paced=True):
+        """Feed a whole clip.  paced=True interleaves put/get exactly like x264_encoder_encode; paced=False puts
+        every frame first (deep prefetch) -- results are identical, only the batching differs."""
+        outs = []
+        n = len(frames) if frames is not None else len(device_ptrs)
+        for i in range(n):
+            if frames is not None:
+                self.put(frames[i])
+            else:
+                self.put(device_ptr=device_ptrs[i], stride=stride)
+            if paced:
+                o = self.get(False)
+                if o is not None:
+                    outs.append(o)
+        while len(outs) < n:
+            o = self.get(True)
+            if o is None:
+                break
+            outs.append(o)
+        return outs
