@@ -1,0 +1,140 @@
+"""Generates the committed golden fixtures from the REAL reference (oracle/_ref, built from
+/root/reference by oracle/build_ref.sh).  Run in the build container:  python tests/golden/make_golden.py
+Fixtures are data only: seeded inputs (or the recipe to regenerate them) and the reference's outputs."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import refharness  # noqa: E402
+from tests.common import clip  # noqa: E402
+from x264_amd.synth import make_clip  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+LOOKAHEAD_CASES = {
+    # name: (preset, ref opts, cfg overrides, depth, W, H, clip kwargs, n_frames)
+    "medium_cif": ("medium", "", {}, 8, 352, 288, dict(seed=1, scene_cuts=(25,), fade=(40, 8, 0.6, 10)), 60),
+    "slow_dia": ("slow", "me=dia", dict(me="dia"), 8, 176, 144, dict(seed=2, scene_cuts=(13, 14, 31)), 64),
+    "slower_umh32": ("slower", "me=umh,merange=32", dict(me="umh", me_range=32), 8, 176, 144, dict(seed=3, pan=(9, 5), scene_cuts=(40,)), 72),
+    "b8_la60": ("medium", "bframes=8,rc-lookahead=60", dict(bframes=8, rc_lookahead=60), 8, 176, 144, dict(seed=4, fade=(10, 12, 1.5, -20)), 75),
+    "veryslow_tesa_10bit": ("veryslow", "me=tesa", dict(me="tesa"), 10, 176, 144, dict(seed=5, scene_cuts=(33,)), 70),
+    "keyint24": ("medium", "keyint=24,min-keyint=4", dict(keyint_max=24, keyint_min=4), 8, 176, 144, dict(seed=6, scene_cuts=(7, 50)), 60),
+    "veryfast": ("veryfast", "", {}, 8, 176, 144, dict(seed=7, pan=(1, 1), noise=1), 40),
+    "nonmod16": ("medium", "", {}, 8, 200, 120, dict(seed=12, pan=(7, 3)), 48),
+    "slow_dia_720p": ("slow", "me=dia", dict(me="dia"), 8, 1280, 720, dict(seed=13, scene_cuts=(20,)), 58),
+}
+
+EVAL_CONFIGS = [("medium", "", 8), ("slow", "me=dia", 8), ("medium", "subme=1", 8), ("veryslow", "me=tesa", 10)]
+EVAL_SEQ = [(0, 0, 0), (0, 1, 1), (0, 2, 2), (0, 2, 1), (1, 1, 1), (0, 3, 3), (0, 3, 1), (0, 3, 2), (1, 3, 2), (2, 3, 3), (3, 3, 3)]
+
+
+def gen_lookahead():
+    for name, (preset, opts, over, depth, W, H, ckw, nf) in LOOKAHEAD_CASES.items():
+        frames = make_clip(W, H, nf, bit_depth=depth, **ckw)
+        r = refharness.Ref(W, H, preset, opts=opts, bit_depth=depth)
+        ref = r.lookahead_run(frames)
+        nb = r.cfg["bframes"] + 2
+        np.savez_compressed(os.path.join(OUT, "lookahead_%s.npz" % name), idx=ref["idx"], type=ref["type"].astype(np.int8),
+                            cost=ref["cost"][:, :nb, :nb], cost_aq=ref["cost_aq"][:, :nb, :nb],
+                            cfg=np.array([r.cfg[k] for k in sorted(r.cfg)], np.int64), cfg_keys=np.array(sorted(r.cfg)))
+        r.close()
+        print("lookahead", name, "types:", "".join("?IiPbB"[t] for t in ref["type"][:40]))
+
+
+def gen_evalseq():
+    for preset, opts, depth in EVAL_CONFIGS:
+        for clipname in ("fastpan", "noise", "fade"):
+            W, H, nf = 176, 144, 4
+            frames = clip(clipname, W, H, nf, depth)
+            r = refharness.Ref(W, H, preset, opts=opts, bit_depth=depth)
+            d = dict(cfg=np.array([r.cfg[k] for k in sorted(r.cfg)], np.int64), cfg_keys=np.array(sorted(r.cfg)))
+            for i in range(nf):
+                r.add_frame(frames[i])
+                iq, _, ss = r.frame_stats(i)
+                d["inv_%d" % i] = iq
+                d["sums_%d" % i] = np.array(ss, np.uint64)
+                d["lowres0_%d" % i] = r.lowres(i, 0)
+                d["lowres_crc_%d" % i] = np.array([int(np.uint64(r.lowres(i, p).astype(np.uint64).sum())) for p in range(4)], np.uint64)
+            for k, (p0, p1, b) in enumerate(EVAL_SEQ):
+                score = r.frame_cost(p0, p1, b)
+                lc, rows, summ = r.cell(b, b - p0, p1 - b)
+                d["lc_%d" % k] = lc
+                d["summ_%d" % k] = np.array(list(summ) + [score], np.int64)
+                d["weight_%d" % k] = np.array(r.weight(b), np.int32)
+                if b != p0:
+                    mv, c = r.mvs(b, 0, b - p0 - 1)
+                    d["mv0_%d" % k], d["c0_%d" % k] = mv, c
+                if b != p1:
+                    mv, c = r.mvs(b, 1, p1 - b - 1)
+                    d["mv1_%d" % k], d["c1_%d" % k] = mv, c
+            for i in range(nf):
+                d["intra_%d" % i] = r.frame_stats(i)[1]
+            tag = "%s_%s_%d_%s" % (preset, opts.replace("=", "").replace(",", "_") or "default", depth, clipname)
+            np.savez_compressed(os.path.join(OUT, "evalseq_%s.npz" % tag), **d)
+            r.close()
+            print("evalseq", tag)
+
+
+def gen_tables():
+    for (W, H, depth) in ((176, 144, 8), (1280, 720, 8), (1920, 1080, 8), (176, 144, 10), (3840, 2160, 10)):
+        r = refharness.Ref(W, H, "medium", bit_depth=depth)
+        np.save(os.path.join(OUT, "cost_mv_r%d_d%d.npy" % (r.cfg["mv_range"], depth)), r.cost_mv())
+        print("cost_mv", W, H, depth, r.cfg["mv_range"], r.cfg["lambda"])
+        r.close()
+
+
+def gen_primitives():
+    """Known answers of the reference's C vtables on seeded inputs (tools/checkasm.c style)."""
+    sizes = [(16, 16), (16, 8), (8, 16), (8, 8), (8, 4), (4, 8), (4, 4)]
+    for depth in (8, 10):
+        r = refharness.Ref(64, 64, "medium", bit_depth=depth)
+        L = r.lib
+        rng = np.random.default_rng(100 + depth)
+        dt = np.uint8 if depth == 8 else np.uint16
+        maxv = (1 << depth) - 1
+        a = rng.integers(0, maxv + 1, size=(48, 64)).astype(dt)
+        b = (rng.integers(0, 2, size=(48, 64)) * maxv).astype(dt)
+        L.rh_pixel_cmp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long]
+        res = np.zeros((4, 7, 3), np.int64)
+        offs = [(0, 0), (3, 5), (17, 1)]
+        for kind in range(3):
+            for si in range(7):
+                for oi, (ox, oy) in enumerate(offs):
+                    res[kind, si, oi] = L.rh_pixel_cmp(r.ctx, kind, si, C.c_void_p(a.ctypes.data), 64,
+                                                       C.c_void_p(b.ctypes.data + (oy * 64 + ox) * a.itemsize), 64)
+        for si, s in ((0, 0), (3, 3)):
+            for oi, (ox, oy) in enumerate(offs):
+                res[3, s, oi] = L.rh_pixel_cmp(r.ctx, 3, si, C.c_void_p(a.ctypes.data), 64,
+                                               C.c_void_p(b.ctypes.data + (oy * 64 + ox) * a.itemsize), 64)
+        # dct/quant
+        fenc = rng.integers(0, maxv + 1, size=(16, 16)).astype(dt)
+        fdec = rng.integers(0, maxv + 1, size=(16, 32)).astype(dt)
+        cdt = np.int16 if depth == 8 else np.int32
+        udt = np.uint16 if depth == 8 else np.uint32
+        dcts = {}
+        for kind, n in {0: 16, 1: 64, 2: 256, 3: 64, 4: 256, 5: 4, 6: 8}.items():
+            o = np.zeros(n, cdt)
+            L.rh_dct(r.ctx, kind, C.c_void_p(o.ctypes.data), C.c_void_p(fenc.ctypes.data), C.c_void_p(fdec.ctypes.data))
+            dcts["dct%d" % kind] = o
+        mf4 = np.zeros(16, udt); b4 = np.zeros(16, udt); mf8 = np.zeros(64, udt); b8 = np.zeros(64, udt)
+        L.rh_quant_tables(r.ctx, 0, 0, 26, C.c_void_p(mf4.ctypes.data), C.c_void_p(b4.ctypes.data))
+        L.rh_quant_tables(r.ctx, 1, 0, 26, C.c_void_p(mf8.ctypes.data), C.c_void_p(b8.ctypes.data))
+        q4 = dcts["dct0"].copy(); q8 = dcts["dct3"].copy()
+        L.rh_quant.restype = C.c_int
+        nz4 = L.rh_quant(r.ctx, 0, C.c_void_p(q4.ctypes.data), 0, 26, 0)
+        nz8 = L.rh_quant(r.ctx, 1, C.c_void_p(q8.ctypes.data), 0, 26, 0)
+        np.savez_compressed(os.path.join(OUT, "primitives_d%d.npz" % depth), a=a, b=b, cmp=res, offs=np.array(offs),
+                            fenc=fenc, fdec=fdec, mf4=mf4, bias4=b4, mf8=mf8, bias8=b8, q4=q4, q8=q8, nz=np.array([nz4, nz8]), **dcts)
+        r.close()
+        print("primitives", depth)
+
+
+if __name__ == "__main__":
+    gen_tables()
+    gen_primitives()
+    gen_evalseq()
+    gen_lookahead()

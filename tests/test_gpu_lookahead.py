@@ -1,0 +1,86 @@
+"""GPU end-to-end: the full lookahead (HIP evaluations + host decisions) against the golden fixtures
+generated from the reference, against the real reference build where it travelled (oracle/_ref), and
+through size-independent properties at the BASELINE sizes."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import refharness
+from tests.golden.make_golden import LOOKAHEAD_CASES
+from tests.test_golden import GOLD, check_lookahead_outputs
+from x264_amd import lib
+from x264_amd.synth import make_clip
+
+pytestmark = pytest.mark.gpu
+
+
+def _types(outs):
+    return [(o.frame, o.type) for o in outs]
+
+
+def _mats(outs, nb):
+    return [np.array([[o.cost_est[i][j] for j in range(nb)] for i in range(nb)]) for o in outs]
+
+
+@pytest.mark.parametrize("name", list(LOOKAHEAD_CASES))
+@pytest.mark.parametrize("paced", [True, False])
+def test_lookahead_vs_golden(name, paced):
+    preset, opts, over, depth, W, H, ckw, nf = LOOKAHEAD_CASES[name]
+    z = np.load(os.path.join(GOLD, "lookahead_%s.npz" % name))
+    frames = make_clip(W, H, nf, bit_depth=depth, **ckw)
+    cfg = lib.la_config(W, H, preset, bit_depth=depth, **over)
+    la = lib.Lookahead(cfg, max_frames=0 if paced else nf + 4)
+    try:
+        outs = la.run(frames, paced=paced)
+        st = la.stats()
+    finally:
+        la.close()
+    check_lookahead_outputs(outs, z, cfg["bframes"] + 2)
+    assert st[1] > nf  # real evaluations happened on the device
+
+
+@pytest.mark.skipif(not refharness.available(8), reason="oracle/_ref did not travel")
+@pytest.mark.parametrize("W,H,preset,opts,over,nf", [
+    (1920, 1080, "slow", "me=dia", dict(me="dia"), 56),          # BASELINE configs[1]
+    (3840, 2160, "slower", "me=umh,merange=32", dict(me="umh", me_range=32), 24),  # BASELINE configs[2], shortened
+])
+def test_full_size_vs_reference(W, H, preset, opts, over, nf):
+    frames = make_clip(W, H, nf, seed=21, scene_cuts=(nf // 2,), pan=(5, 3))
+    r = refharness.Ref(W, H, preset, opts=opts)
+    try:
+        ref = r.lookahead_run(frames)
+    finally:
+        r.close()
+    cfg = lib.la_config(W, H, preset, **over)
+    la = lib.Lookahead(cfg)
+    try:
+        outs = la.run(frames)
+    finally:
+        la.close()
+    nb = cfg["bframes"] + 2
+    z = dict(idx=ref["idx"], type=ref["type"], cost=ref["cost"][:, :nb, :nb], cost_aq=ref["cost_aq"][:, :nb, :nb])
+    check_lookahead_outputs(outs, z, nb)
+
+
+@pytest.mark.parametrize("W,H,preset,over,nf", [(1920, 1080, "slow", dict(me="dia"), 70), (3840, 2160, "medium", dict(bframes=8, rc_lookahead=60), 30)])
+def test_batching_invariance_full_size(W, H, preset, over, nf):
+    """Size-independent property at BASELINE sizes: encoder-paced (small batches, on-demand evaluations) and
+    deep-prefetch (one big speculative batch) runs give identical decisions and cost cells."""
+    frames = make_clip(W, H, nf, seed=33, scene_cuts=(nf // 3,), fade=(nf // 2, 6, 0.7, 8))
+    cfg = lib.la_config(W, H, preset, **over)
+    nb = cfg["bframes"] + 2
+    res = []
+    for paced in (True, False):
+        la = lib.Lookahead(cfg, max_frames=0 if paced else nf + 4)
+        try:
+            outs = la.run(frames, paced=paced)
+        finally:
+            la.close()
+        res.append(outs)
+    assert _types(res[0]) == _types(res[1])
+    for a, b in zip(_mats(res[0], nb), _mats(res[1], nb)):
+        assert np.array_equal(a, b)
+    types = [t for _, t in _types(res[0])]
+    assert types[0] == 1 and set(types) <= {1, 2, 3, 4, 5}
+    assert sorted(f for f, _ in _types(res[0])) == list(range(nf))
