@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""bench.py -- lookahead frames/s on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+A "step" is one pass of the whole lookahead hot path (lowres + AQ + intra + motion searches + cost cells +
+slice-type decision) over one clip of synthetic frames that is already resident in HBM when the timed
+region starts.  Workload at N=1: BASELINE.json configs[1] -- 1920x1080 8-bit 4:2:0, --preset slow --me dia.
+For N>1 every rank runs the same-sized, independent sequence segment (GOP-parallel sharding);
+the only exchange is an RCCL all-gather of the per-frame cost summaries.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_search(cfg):
+    """one (frame, list, distance) search reads the source plane once and the four half-pel
+    planes of its reference once (5*S) and writes mv (4 B) + mv cost (4 B) per block."""
+    mb_w, mb_h = (cfg["width"] + 15) // 16, (cfg["height"] + 15) // 16
+    S = (8 * mb_w) * (8 * mb_h) * (1 if cfg["bit_depth"] == 8 else 2)
+    return 5 * S + 8 * mb_w * mb_h
+
+
+def primitives_bench(torch, libmod, cfg, iters=30):
+    """SAD / SATD GB/s of the batched vtable primitives over all blocks of a frame pair, and lowres init GB/s."""
+    import ctypes as C
+    W, H = cfg["width"], cfg["height"]
+    out = {}
+    ctx = libmod.Context(W, H, bit_depth=8, max_frames=2, mv_range=cfg["mv_range"])
+    try:
+        Wp, Hp = (W // 16) * 16, (H // 16) * 16
+        stride = Wp + 64
+        g = torch.Generator(device="cuda").manual_seed(1)
+        fenc = torch.randint(0, 256, (Hp + 64, stride), dtype=torch.uint8, device="cuda", generator=g)
+        ref = torch.randint(0, 256, (Hp + 64, stride), dtype=torch.uint8, device="cuda", generator=g)
+        org = 32 * stride + 32
+        for size_idx, size in ((0, 16), (3, 8), (6, 4)):
+            bw, bh = Wp // size, Hp // size
+            mv = torch.randint(-16, 17, (bw * bh, 2), dtype=torch.int16, device="cuda", generator=g)
+            res = torch.zeros(bw * bh, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            for satd in (0, 1):
+                def run():
+                    rc = ctx.L.x264hip_pixel_cmp_batch(ctx.h, satd, size_idx, C.c_void_p(fenc.data_ptr() + org), C.c_void_p(ref.data_ptr() + org),
+                                                       stride, bw, bh, C.c_void_p(mv.data_ptr()), C.c_void_p(res.data_ptr()))
+                    assert rc == 0
+                run(); ctx.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    run()
+                ctx.synchronize()
+                dt = (time.perf_counter() - t0) / iters
+                nbytes = bw * bh * (2 * size * size + 4)  # SURVEY 8(d) per-block form: both blocks + the result
+                out["%s_%dx%d_GBps" % ("satd" if satd else "sad", size, size)] = round(nbytes / dt / 1e9, 1)
+        luma = torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda", generator=g)
+        torch.cuda.synchronize()
+        ctx.frame_put(0, None, device_ptr=luma.data_ptr(), stride=W); ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            ctx.frame_put(0, None, device_ptr=luma.data_ptr(), stride=W)
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        S = (8 * ctx.mb_w) * (8 * ctx.mb_h)
+        out["frame_ingest_GBps"] = round((W * H + 4 * S) / dt / 1e9, 1)  # lowres init bytes; AQ + intra ride along
+    finally:
+        ctx.close()
+    return out
+
+
+def cpu_baseline(cfg, frames, preset, opts):
+    """Reference C path (oracle/_ref, built from /root/reference) timed on this box's host cores, 1 thread;
+    falls back to the CPU port (oracle restatement behind the host logic) when the reference build is absent."""
+    n = len(frames)
+    try:
+        from oracle import refharness
+        if refharness.available(cfg["bit_depth"]):
+            r = refharness.Ref(cfg["width"], cfg["height"], preset, opts=opts, bit_depth=cfg["bit_depth"])
+            try:
+                res = r.lookahead_run(frames)
+            finally:
+                r.close()
+            return dict(value=round(n / res["seconds"], 2), unit="frames/s", cores=1, kind="reference",
+                        sample="%d frames %dx%d, reference C path (--disable-asm, no AVX2: no assembler in the build image), "
+                               "--threads 1; lowres init + lookahead only, AQ excluded (%.2f s)" % (n, cfg["width"], cfg["height"], res["seconds"]))
+    except Exception as e:  # pragma: no cover
+        print("cpu_baseline: reference unavailable (%s), using the port" % e, file=sys.stderr)
+    from tests.oracle_backend import OracleBackend
+    from x264_amd import lib
+    be = OracleBackend(cfg)
+    la = lib.Lookahead(cfg, backend=be.struct)
+    try:
+        t0 = time.perf_counter()
+        la.run(frames)
+        dt = time.perf_counter() - t0
+    finally:
+        la.close()
+    return dict(value=round(n / dt, 2), unit="frames/s", cores=1, kind="port", sample="%d frames %dx%d, oracle restatement, 1 thread" % (n, cfg["width"], cfg["height"]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=160, help="frames per step and per GPU")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--preset", default="slow")
+    ap.add_argument("--me", default="dia")
+    ap.add_argument("--paced", action="store_true", help="encoder-paced put/get instead of the deep-prefetch batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-primitives", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=96)
+    args = ap.parse_args()
+
+    import torch
+    from x264_amd import lib
+    from x264_amd.synth import make_clip
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the lookahead path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H, F = args.width, args.height, args.frames
+    cfg = lib.la_config(W, H, args.preset, me=args.me)
+    # every rank gets its own segment of the synthetic sequence (different seed = different content)
+    frames = make_clip(W, H, F, seed=100 + rank, scene_cuts=(F // 3, F // 3 + 47), fade=(2 * F // 3, 10, 0.6, 12), pan=(5, 3))
+    dev_frames = torch.from_numpy(frames).cuda(local_rank)
+    ptrs = [dev_frames[i].data_ptr() for i in range(F)]
+    torch.cuda.synchronize()
+
+    la = lib.Lookahead(cfg, device=local_rank, max_frames=F + 4)
+    ctxh = la.ctx_handle()
+    summary = torch.zeros((F, 4), dtype=torch.int32, device="cuda")
+    gathered = torch.zeros((world * F, 4), dtype=torch.int32, device="cuda") if world > 1 else None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        la.reset()
+        outs = la.run(device_ptrs=ptrs, stride=W, paced=args.paced)
+        assert len(outs) == F
+        host = np.array([[o.frame + rank * F, o.type, o.cost_est[0][0] if o.type < 3 else max(o.cost_est[1][0], 0), o.bframes] for o in outs], np.int32)
+        summary.copy_(torch.from_numpy(host), non_blocking=False)
+        if dist is not None:
+            dist.all_gather_into_tensor(gathered, summary)  # RCCL over xGMI: per-frame summaries only
+        return outs
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    lib.search_profile(la.L, ctxh, 1)
+    t0 = time.perf_counter()
+    outs = None
+    for _ in range(args.steps):
+        outs = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof_ms, prof_launches, prof_searches = lib.search_profile(la.L, ctxh, 0)
+    la_stats = la.stats()
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    types = "".join("?IiPbB"[o.type] for o in sorted(outs, key=lambda o: o.frame))
+    la.close()
+
+    if rank == 0:
+        bytes_per_search = algorithmic_bytes_per_search(cfg)
+        achieved = (prof_searches * bytes_per_search / 1e9) / (prof_ms / 1e3) if prof_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("me_rows_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "lookahead frames/sec",
+            "value": round(world * F * args.steps / dt, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "%dx%d 8-bit 4:2:0 synthetic, --preset %s --me %s (BASELINE configs[1]): full lookahead "
+                                   "(lowres+AQ+intra+ME+cost cells+slicetype decision), %d frames per step per GPU, %s" %
+                                   (W, H, args.preset, args.me, F, "encoder-paced" if args.paced else "deep-prefetch batch"),
+                       "frames_per_step": F, "bframes": cfg["bframes"], "b_adapt": cfg["b_adapt"], "rc_lookahead": cfg["rc_lookahead"],
+                       "parallelism": "gop-segments x%d" % world, "slice_types": types[:64]},
+            "roofline": {"bound": "hbm", "kernel": "me_rows_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "launches": prof_launches, "searches": prof_searches, "avg_launch_ms": round(prof_ms / max(prof_launches, 1), 4),
+                         "algorithmic_bytes_per_search": bytes_per_search},
+            "lookahead_stats": {"frame_cost_calls": int(la_stats[0]), "evaluations": int(la_stats[1]),
+                                "weights_analysed": int(la_stats[2]), "weights_kept": int(la_stats[3])},
+        }
+        if not args.no_primitives:
+            try:
+                res["primitives"] = primitives_bench(torch, lib, dict(cfg, width=3840, height=2160))
+            except Exception as e:  # pragma: no cover
+                res["primitives"] = {"error": str(e)}
+        if world == 1 and not args.no_cpu_baseline:
+            n = min(F, args.cpu_frames)
+            opts = "me=%s" % args.me
+            res["cpu_baseline"] = cpu_baseline(cfg, frames[:n], args.preset, opts)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -148,7 +148,10 @@ int  x264hip_dct_quant_batch( x264hip_ctx *ctx, int is8x8, int n_blocks, const v
 
 /* timing of the most recent search launch in ms (HIP events on the context's stream) and counters */
 int  x264hip_last_search_ms( x264hip_ctx *ctx, float *ms, int *n_searches, int *n_blocks );
-int  x264hip_counters( x264hip_ctx *ctx, uint64_t *out, int n ); /* [0] searches [1] cells [2] cache hits [3] frames */
+int  x264hip_counters( x264hip_ctx *ctx, uint64_t *out, int n );
+/* Per-launch HIP-event timing of the search kernel on the context's stream.  Returns the totals gathered
+ * since profiling was last (re)enabled; enable = 1/0 switches it and clears the totals, -1 only reads. */
+int  x264hip_search_profile( x264hip_ctx *ctx, int enable, double *total_ms, uint64_t *launches, uint64_t *searches ); /* [0] searches [1] cells [2] cache hits [3] frames */
 
 
 /* ==================================================================================================
@@ -209,6 +212,7 @@ int  x264hip_lookahead_open( x264hip_lookahead **out, int device, const x264hip_
 /* Same host logic over a caller-supplied backend (plugin / test hook). */
 int  x264hip_lookahead_open_backend( x264hip_lookahead **out, const x264hip_la_params *params, const x264hip_backend *backend );
 void x264hip_lookahead_close( x264hip_lookahead *la );
+int  x264hip_lookahead_reset( x264hip_lookahead *la ); /* start a new sequence on the same context */
 x264hip_ctx *x264hip_lookahead_ctx( x264hip_lookahead *la ); /* NULL for plugin backends */
 int  x264hip_lookahead_delay( x264hip_lookahead *la );       /* h->frames.i_delay */
 /* forced_type: X264_TYPE_AUTO (0) normally */

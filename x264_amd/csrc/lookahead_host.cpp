@@ -769,6 +769,22 @@ extern "C" void x264hip_lookahead_close( x264hip_lookahead *la )
     delete la;
 }
 
+/* forget every frame (end of a sequence); the device context and its allocations are kept */
+extern "C" int x264hip_lookahead_reset( x264hip_lookahead *la )
+{
+    if( !la ) return X264HIP_EINVAL;
+    Lookahead &L = la->L;
+    if( L.err ) return L.err;
+    for( auto f : L.next ) { L.free_slots.push_back( f->slot ); delete f; }
+    for( auto f : L.current )
+        if( f != L.last_nonb ) { L.free_slots.push_back( f->slot ); delete f; }
+    if( L.last_nonb ) { L.free_slots.push_back( L.last_nonb->slot ); delete L.last_nonb; }
+    L.next.clear(); L.current.clear(); L.last_nonb = nullptr; L.pending_prefetch.clear();
+    L.i_input = 0;
+    L.i_last_keyframe = -L.p.keyint_max;
+    return X264HIP_OK;
+}
+
 extern "C" x264hip_ctx *x264hip_lookahead_ctx( x264hip_lookahead *la ) { return la ? la->L.ctx : nullptr; }
 extern "C" int x264hip_lookahead_delay( x264hip_lookahead *la ) { return la ? la->L.i_delay : X264HIP_EINVAL; }
 

@@ -82,6 +82,11 @@ struct x264hip_ctx
     unsigned tag_serial = 1;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     int last_n_search = 0, last_n_blocks = 0, ev_valid = 0;
+    // profile ring: one event pair per search launch while profiling is on
+    std::vector<hipEvent_t> prof_ev;
+    std::vector<int> prof_n;
+    int prof_on = 0, prof_used = 0;
+    double prof_ms = 0; uint64_t prof_launches = 0, prof_searches = 0;
     uint64_t counters[8] = { 0 };
 };
 
@@ -111,6 +116,7 @@ static void free_all( x264hip_ctx *ctx )
     (void)hipFree( ctx->desc_dev ); (void)hipFree( ctx->wcost_dev );
     (void)hipHostFree( ctx->acc_host ); (void)hipHostFree( ctx->sync_host ); (void)hipHostFree( ctx->desc_host );
     (void)hipHostFree( ctx->wcost_host ); (void)hipHostFree( ctx->staging );
+    for( auto e : ctx->prof_ev ) (void)hipEventDestroy( e );
     if( ctx->ev_start ) (void)hipEventDestroy( ctx->ev_start );
     if( ctx->ev_stop ) (void)hipEventDestroy( ctx->ev_stop );
     if( ctx->stream ) (void)hipStreamDestroy( ctx->stream );
@@ -350,6 +356,26 @@ static int acquire_wplane( x264hip_ctx *ctx, int owner_slot )
     return (int)ctx->wplanes.size() - 1;
 }
 
+// fold finished event pairs of the profile ring into the running totals
+static int prof_drain( x264hip_ctx *ctx )
+{
+    if( ctx->prof_used )
+    {
+        HIPCK( hipStreamSynchronize( ctx->stream ) );
+        for( int i = 0; i < ctx->prof_used; i += 2 )
+        {
+            float ms = 0;
+            HIPCK( hipEventElapsedTime( &ms, ctx->prof_ev[i], ctx->prof_ev[i + 1] ) );
+            ctx->prof_ms += ms;
+            ctx->prof_launches++;
+            ctx->prof_searches += ctx->prof_n[i / 2];
+        }
+    }
+    ctx->prof_used = 0;
+    ctx->prof_n.clear();
+    return X264HIP_OK;
+}
+
 struct SearchReq
 {
     int slot_b, slot_ref, list, dist_m1;
@@ -392,9 +418,21 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
     }
     HIPCK( hipMemcpyAsync( ctx->desc_dev, dh, (size_t)n * sizeof( SearchDesc<T> ), hipMemcpyHostToDevice, ctx->stream ) );
     HIPCK( hipMemsetAsync( ctx->sync_words, 0, 2 * sizeof( unsigned ), ctx->stream ) );
-    HIPCK( hipEventRecord( ctx->ev_start, ctx->stream ) );
+    hipEvent_t e0 = ctx->ev_start, e1 = ctx->ev_stop;
+    if( ctx->prof_on )
+    {
+        if( ctx->prof_used + 2 > (int)ctx->prof_ev.size() )
+        {
+            int rc = prof_drain( ctx );
+            if( rc ) return rc;
+        }
+        e0 = ctx->prof_ev[ctx->prof_used]; e1 = ctx->prof_ev[ctx->prof_used + 1];
+        ctx->prof_n.push_back( n );
+        ctx->prof_used += 2;
+    }
+    HIPCK( hipEventRecord( e0, ctx->stream ) );
     me_rows_kernel<T><<<n * P.mb_h, 64, 0, ctx->stream>>>( P, (const SearchDesc<T> *)ctx->desc_dev, n, ctx->sync_words, 1u << 22 );
-    HIPCK( hipEventRecord( ctx->ev_stop, ctx->stream ) );
+    HIPCK( hipEventRecord( e1, ctx->stream ) );
     HIPCK( hipGetLastError() );
     ctx->ev_valid = 1;
     ctx->last_n_search = n;
@@ -643,6 +681,29 @@ extern "C" int x264hip_last_search_ms( x264hip_ctx *ctx, float *ms, int *n_searc
     HIPCK( hipEventElapsedTime( ms, ctx->ev_start, ctx->ev_stop ) );
     if( n_searches ) *n_searches = ctx->last_n_search;
     if( n_blocks ) *n_blocks = ctx->last_n_blocks;
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_search_profile( x264hip_ctx *ctx, int enable, double *total_ms, uint64_t *launches, uint64_t *searches )
+{
+    if( !ctx ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    int rc = prof_drain( ctx );
+    if( rc ) return rc;
+    if( total_ms ) *total_ms = ctx->prof_ms;
+    if( launches ) *launches = ctx->prof_launches;
+    if( searches ) *searches = ctx->prof_searches;
+    if( enable >= 0 )
+    {
+        ctx->prof_ms = 0; ctx->prof_launches = 0; ctx->prof_searches = 0;
+        ctx->prof_on = enable;
+        if( enable && ctx->prof_ev.empty() )
+        {
+            ctx->prof_ev.resize( 2048 );
+            for( auto &e : ctx->prof_ev )
+                HIPCK( hipEventCreate( &e ) );
+        }
+    }
     return X264HIP_OK;
 }
 

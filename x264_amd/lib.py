@@ -76,6 +76,13 @@ def cost_mv_table(mv_range, lam):
     return np.concatenate([v[:0:-1], v]), n
 
 
+def search_profile(L, ctx_handle, enable=-1):
+    """(total_ms, launches, searches) of the search kernel measured with HIP events on its own stream."""
+    ms, nl, ns = C.c_double(), C.c_uint64(), C.c_uint64()
+    _ck(L.x264hip_search_profile(ctx_handle, int(enable), C.byref(ms), C.byref(nl), C.byref(ns)), "search_profile")
+    return ms.value, int(nl.value), int(ns.value)
+
+
 class Context:
     """Thin object view of x264hip_ctx."""
 
@@ -191,6 +198,9 @@ class Context:
         out = np.zeros(8, np.uint64)
         _ck(self.L.x264hip_counters(self.h, _p(out), 8), "counters")
         return out
+
+    def search_profile(self, enable=-1):
+        return search_profile(self.L, self.h, enable)
 
 
 # ---- host-side lookahead (x264hip_lookahead_*) -----------------------------------------------------------
@@ -327,6 +337,9 @@ class Lookahead:
         if self.h:
             self.L.x264hip_lookahead_close(self.h)
             self.h = None
+
+    def reset(self):
+        _ck(self.L.x264hip_lookahead_reset(self.h), "lookahead_reset")
 
     def ctx_handle(self):
         return C.c_void_p(self.L.x264hip_lookahead_ctx(self.h))
