@@ -107,7 +107,7 @@ template <typename T>
 __global__ __launch_bounds__( 64 ) void aq_kernel( const T *__restrict__ luma, int stride, int width, int height, int mb_w,
                                                    const T *__restrict__ cb, const T *__restrict__ cr, int cstride,
                                                    int aq_on, float strength, float log2_bias, const AqLuts *luts,
-                                                   uint16_t *inv_qscale, unsigned long long *frame_sums /* [0] sum [1] ssd */ )
+                                                   uint16_t *inv_qscale, uint2 *mb_sums /* per MB: luma sum, sum of squares */ )
 {
     const int mx = blockIdx.x, my = blockIdx.y, lane = lane_id();
     const int ly = lane >> 2, lx = ( lane & 3 ) * 4;
@@ -135,8 +135,7 @@ __global__ __launch_bounds__( 64 ) void aq_kernel( const T *__restrict__ luma, i
     }
     if( lane == 0 )
     {
-        atomicAdd( &frame_sums[0], (unsigned long long)s );
-        atomicAdd( &frame_sums[1], (unsigned long long)q );
+        mb_sums[my * mb_w + mx] = make_uint2( s, q );
         int out = 256;
         if( aq_on )
         {
@@ -148,6 +147,32 @@ __global__ __launch_bounds__( 64 ) void aq_kernel( const T *__restrict__ luma, i
             out = i < 0 ? 0 : i > 1023 ? 0xffff : ( ( luts->exp2_lut[i & 63] + 256 ) << ( i >> 6 ) >> 8 );
         }
         inv_qscale[my * mb_w + mx] = (uint16_t)out;
+    }
+}
+
+// frame totals of the per-MB sums: one workgroup, no atomics
+__global__ __launch_bounds__( 1024 ) void aq_reduce_kernel( const uint2 *__restrict__ mb_sums, int n, unsigned long long *frame_sums )
+{
+    __shared__ unsigned long long sh[2][16];
+    unsigned long long s = 0, q = 0;
+    for( int i = threadIdx.x; i < n; i += blockDim.x )
+    {
+        uint2 v = mb_sums[i];
+        s += v.x; q += v.y;
+    }
+#pragma unroll
+    for( int o = 32; o > 0; o >>= 1 )
+    {
+        s += __shfl_xor( s, o );
+        q += __shfl_xor( q, o );
+    }
+    if( ( threadIdx.x & 63 ) == 0 ) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if( threadIdx.x == 0 )
+    {
+        unsigned long long ts = 0, tq = 0;
+        for( int i = 0; i < (int)( blockDim.x >> 6 ); i++ ) { ts += sh[0][i]; tq += sh[1][i]; }
+        frame_sums[0] = ts; frame_sums[1] = tq;
     }
 }
 
@@ -333,35 +358,87 @@ struct CellArgs
     uint16_t *lowres_costs;
     int *row_satds, *row_satds_intra;
     int *acc;                     // [5]: cost_est, cost_est_aq, intra_mbs, intra_cost_est, intra_cost_est_aq
+    int *blk;                     // [n_mb] scratch: final block cost | b_intra << 30, input of cell_reduce_kernel
 };
 
-__device__ __forceinline__ void cell_finish( const LaP &P, const CellArgs &A, int bx, int by, int xy, int bcost, int list_used )
+__device__ __forceinline__ void cell_finish( const LaP &P, const CellArgs &A, int xy, int bcost, int list_used )
 {
-    // executed by ONE lane per block
-    const int W = P.mb_w, H = P.mb_h;
-    const bool scored = ( bx > 0 && bx < W - 1 && by > 0 && by < H - 1 ) || W <= 2 || H <= 2;
+    // executed by ONE lane per block: final cost of the block, its map entry, and the word the reduction reads
     const int icost = A.intra_cost[xy];
-    const int inv = P.aq_mode ? A.inv_qscale[xy] : 256;
-    if( A.with_intra )
-    {
-        int icost_aq = P.aq_mode ? ( icost * inv + 128 ) >> 8 : icost;
-        atomicAdd( &A.row_satds_intra[by], icost_aq );
-        if( scored ) { atomicAdd( &A.acc[3], icost ); atomicAdd( &A.acc[4], icost_aq ); }
-    }
+    int b_intra = 0;
     bcost = ( bcost >> P.depth_shift ) + 4;
     if( !A.b_bidir )
     {
-        int b_intra = icost < bcost;
+        b_intra = icost < bcost;
         if( b_intra ) { bcost = icost; list_used = 0; }
-        if( scored && b_intra ) atomicAdd( &A.acc[2], 1 );
     }
-    if( !A.is_intra_only )
-    {
-        int bcost_aq = P.aq_mode ? ( bcost * inv + 128 ) >> 8 : bcost;
-        atomicAdd( &A.row_satds[by], bcost_aq );
-        if( scored ) { atomicAdd( &A.acc[0], bcost ); atomicAdd( &A.acc[1], bcost_aq ); }
-    }
+    A.blk[xy] = bcost | ( b_intra << 30 );
     A.lowres_costs[xy] = (uint16_t)( imin2( bcost, 0x3FFF ) + ( list_used << 14 ) );
+}
+
+// Row and frame sums of one evaluation (slicetype.c:746-757,778-788,946-985): ONE workgroup, each wave owns
+// whole block rows, no atomics, no pre-zeroing; writes row_satds[], row_satds_intra[] and acc[0..4].
+__global__ __launch_bounds__( 1024 ) void cell_reduce_kernel( LaP P, CellArgs A )
+{
+    __shared__ int sh[5][16];
+    const int W = P.mb_w, H = P.mb_h;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
+    int t[5] = { 0, 0, 0, 0, 0 };
+    for( int by = wave; by < H; by += n_waves )
+    {
+        int row = 0, row_i = 0;
+        for( int bx = lane; bx < W; bx += 64 )
+        {
+            const int xy = by * W + bx;
+            const bool scored = ( bx > 0 && bx < W - 1 && by > 0 && by < H - 1 ) || W <= 2 || H <= 2;
+            const int inv = P.aq_mode ? A.inv_qscale[xy] : 256;
+            const int w = A.blk[xy];
+            const int bcost = w & 0x3FFFFFFF, b_intra = w >> 30;
+            if( A.with_intra )
+            {
+                // for the intra-only cell the map aliases the intra costs and may just have been clamped: the
+                // unclamped value is the block word there
+                const int icost = A.is_intra_only ? bcost : A.intra_cost[xy];
+                const int icost_aq = P.aq_mode ? ( icost * inv + 128 ) >> 8 : icost;
+                row_i += icost_aq;
+                if( scored ) { t[3] += icost; t[4] += icost_aq; }
+            }
+            if( !A.b_bidir && scored )
+                t[2] += b_intra;
+            if( !A.is_intra_only )
+            {
+                const int bcost_aq = P.aq_mode ? ( bcost * inv + 128 ) >> 8 : bcost;
+                row += bcost_aq;
+                if( scored ) { t[0] += bcost; t[1] += bcost_aq; }
+            }
+        }
+#pragma unroll
+        for( int o = 32; o > 0; o >>= 1 )
+        {
+            row += __shfl_xor( row, o );
+            row_i += __shfl_xor( row_i, o );
+        }
+        if( lane == 0 )
+        {
+            if( !A.is_intra_only ) A.row_satds[by] = row;
+            if( A.with_intra ) A.row_satds_intra[by] = row_i;
+        }
+    }
+#pragma unroll
+    for( int k = 0; k < 5; k++ )
+    {
+#pragma unroll
+        for( int o = 32; o > 0; o >>= 1 )
+            t[k] += __shfl_xor( t[k], o );
+        if( lane == 0 ) sh[k][wave] = t[k];
+    }
+    __syncthreads();
+    if( threadIdx.x < 5 )
+    {
+        int v = 0;
+        for( int i = 0; i < n_waves; i++ ) v += sh[threadIdx.x][i];
+        A.acc[threadIdx.x] = v;
+    }
 }
 
 // P and intra-only cells: no pixel work, one thread per block
@@ -370,14 +447,13 @@ __global__ __launch_bounds__( 256 ) void cell_p_kernel( LaP P, CellArgs A )
     const int xy = blockIdx.x * blockDim.x + threadIdx.x;
     if( xy >= P.mb_w * P.mb_h )
         return;
-    const int bx = xy % P.mb_w, by = xy / P.mb_w;
     int bcost = COST_MAX_I, list_used = 0;
     if( !A.is_intra_only )
     {
         int c0 = A.costs0[xy];
         if( c0 < bcost ) { bcost = c0; list_used = 1; }
     }
-    cell_finish( P, A, bx, by, xy, bcost, list_used );
+    cell_finish( P, A, xy, bcost, list_used );
 }
 
 // B cells: one wave per block; groups 0..2 evaluate the three bidirectional candidates in parallel
@@ -447,7 +523,7 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, CellArgs A, const 
         if( c < bcost ) { bcost = c; list_used = 3; }
     }
     if( lane == 0 )
-        cell_finish( P, A, bx, by, xy, bcost, list_used );
+        cell_finish( P, A, xy, bcost, list_used );
 }
 
 // ---- batched vtable primitives: SAD / SATD of every block of a plane against a displaced reference ----

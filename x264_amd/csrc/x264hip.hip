@@ -40,6 +40,7 @@ struct FrameSlot
     char *luma = nullptr;
     uint16_t *inv_qscale = nullptr;
     unsigned long long *frame_sums = nullptr;
+    uint2 *mb_sums = nullptr;
     unsigned long long *mvq[2][X264HIP_BFRAME_MAX + 1];
     int *mvcost[2][X264HIP_BFRAME_MAX + 1];
     uint16_t *lowres_costs = nullptr; // [(bf+2)*(bf+2)][n_mb]
@@ -68,6 +69,7 @@ struct x264hip_ctx
     AqLuts *luts_dev = nullptr;
     unsigned *sync_words = nullptr;  // device [2]
     int *acc_dev = nullptr;          // [8]
+    int *blk_dev = nullptr;          // [n_mb] per-block result words of the cell in flight
     int *acc_host = nullptr;         // pinned [8]
     unsigned *sync_host = nullptr;   // pinned [2]
     void *desc_dev = nullptr;        // SearchDesc array
@@ -112,7 +114,7 @@ static void free_all( x264hip_ctx *ctx )
         (void)hipFree( s.planes ); // one allocation per slot holds everything
     }
     for( auto w : ctx->wplanes ) (void)hipFree( w );
-    (void)hipFree( ctx->cost_mv_dev ); (void)hipFree( ctx->luts_dev ); (void)hipFree( ctx->sync_words ); (void)hipFree( ctx->acc_dev );
+    (void)hipFree( ctx->cost_mv_dev ); (void)hipFree( ctx->luts_dev ); (void)hipFree( ctx->sync_words ); (void)hipFree( ctx->acc_dev ); (void)hipFree( ctx->blk_dev );
     (void)hipFree( ctx->desc_dev ); (void)hipFree( ctx->wcost_dev );
     (void)hipHostFree( ctx->acc_host ); (void)hipHostFree( ctx->sync_host ); (void)hipHostFree( ctx->desc_host );
     (void)hipHostFree( ctx->wcost_host ); (void)hipHostFree( ctx->staging );
@@ -183,6 +185,7 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     }
     OPENCK( hipMalloc( &ctx->sync_words, 2 * sizeof( unsigned ) ) );
     OPENCK( hipMalloc( &ctx->acc_dev, 8 * sizeof( int ) ) );
+    OPENCK( hipMalloc( &ctx->blk_dev, (size_t)ctx->n_mb * sizeof( int ) ) );
     OPENCK( hipHostMalloc( &ctx->acc_host, 8 * sizeof( int ) ) );
     OPENCK( hipHostMalloc( &ctx->sync_host, 2 * sizeof( unsigned ) ) );
     OPENCK( hipMalloc( &ctx->wcost_dev, sizeof( unsigned ) ) );
@@ -202,6 +205,7 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         const size_t o_luma = off; off += align_up( ctx->staging_bytes, 256 );
         const size_t o_inv = off; off += align_up( ctx->n_mb * sizeof( uint16_t ), 256 );
         const size_t o_sums = off; off += 256;
+        const size_t o_mbs = off; off += align_up( ctx->n_mb * sizeof( uint2 ), 256 );
         const size_t o_mvq = off; off += align_up( (size_t)2 * nd * ctx->n_mb * sizeof( unsigned long long ), 256 );
         const size_t o_mvc = off; off += align_up( (size_t)2 * nd * ctx->n_mb * sizeof( int ), 256 );
         const size_t o_lc = off; off += align_up( (size_t)nc * ctx->n_mb * sizeof( uint16_t ), 256 );
@@ -211,6 +215,7 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         OPENCK( hipMemset( base, 0, off ) );
         s.planes = base + o_planes; s.luma = base + o_luma; s.inv_qscale = (uint16_t *)( base + o_inv );
         s.frame_sums = (unsigned long long *)( base + o_sums );
+        s.mb_sums = (uint2 *)( base + o_mbs );
         for( int l = 0; l < 2; l++ )
             for( int d = 0; d < nd; d++ )
             {
@@ -280,7 +285,6 @@ static int frame_put_t( x264hip_ctx *ctx, FrameSlot &s, const void *luma, int st
         dim3 blk( 256 ), grd( ( ( ctx->lw + 2 * LA_PAD ) / 4 + 255 ) / 256, ctx->lh + 2 * LA_PAD );
         lowres_kernel<T><<<grd, blk, 0, ctx->stream>>>( src, src_stride, p.width, p.height, (T *)s.planes, P.plane_elems, P.stride, ctx->lw, ctx->lh );
     }
-    HIPCK( hipMemsetAsync( s.frame_sums, 0, 2 * sizeof( unsigned long long ), ctx->stream ) );
     {
         const float strength = p.aq_strength * 1.0397f;
         const float bias = 14.427f + 2 * ( p.bit_depth - 8 );
@@ -288,7 +292,8 @@ static int frame_put_t( x264hip_ctx *ctx, FrameSlot &s, const void *luma, int st
         // chroma planes take part in the AQ energy only when the caller supplies device pointers for them
         aq_kernel<T><<<dim3( P.mb_w, P.mb_h ), 64, 0, ctx->stream>>>( src, src_stride, p.width, p.height, P.mb_w,
                                                                       is_device ? (const T *)cb : nullptr, is_device ? (const T *)cr : nullptr, cstride,
-                                                                      aq_on, strength, bias, ctx->luts_dev, s.inv_qscale, s.frame_sums );
+                                                                      aq_on, strength, bias, ctx->luts_dev, s.inv_qscale, s.mb_sums );
+        aq_reduce_kernel<<<1, 1024, 0, ctx->stream>>>( s.mb_sums, ctx->n_mb, s.frame_sums );
     }
     if( inv_qscale )
         HIPCK( hipMemcpyAsync( s.inv_qscale, inv_qscale, ctx->n_mb * sizeof( uint16_t ), hipMemcpyHostToDevice, ctx->stream ) );
@@ -552,16 +557,13 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
     A.row_satds = b.row_satds + (size_t)( d0 * nstride + d1 ) * P.mb_h;
     A.row_satds_intra = b.row_satds;
     A.acc = ctx->acc_dev;
-    HIPCK( hipMemsetAsync( ctx->acc_dev, 0, 8 * sizeof( int ), ctx->stream ) );
-    if( !intra_only )
-        HIPCK( hipMemsetAsync( A.row_satds, 0, P.mb_h * sizeof( int ), ctx->stream ) );
-    if( with_intra )
-        HIPCK( hipMemsetAsync( A.row_satds_intra, 0, P.mb_h * sizeof( int ), ctx->stream ) );
+    A.blk = ctx->blk_dev;
     if( b_bidir )
         cell_b_kernel<T><<<dim3( P.mb_w, P.mb_h ), 64, 0, ctx->stream>>>( P, A, plane_origin<T>( ctx, b, 0 ), plane_origin<T>( ctx, f0, 0 ),
                                                                           plane_origin<T>( ctx, f1, 0 ) );
     else
         cell_p_kernel<<<( ctx->n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( P, A );
+    cell_reduce_kernel<<<1, 1024, 0, ctx->stream>>>( P, A );
     HIPCK( hipGetLastError() );
     HIPCK( hipMemcpyAsync( ctx->acc_host, ctx->acc_dev, 8 * sizeof( int ), hipMemcpyDeviceToHost, ctx->stream ) );
     if( !reqs.empty() )
