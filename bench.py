@@ -191,7 +191,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("me_rows_kernel_hbm_bytes_per_launch")
+                per_search = json.load(open(tpath)).get("me_rows_kernel_hbm_bytes_per_search")
+                # PMC pass (profiles/*_pmc_summary.json) is per search; one launch of this run carries searches/launches of them
+                traffic = round(per_search * prof_searches / max(prof_launches, 1)) if per_search and W == 1920 else None
             except Exception:
                 traffic = None
         res = {
