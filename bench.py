@@ -122,7 +122,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from x264_amd import lib
+    from x264_amd import lib, shard
     from x264_amd.synth import make_clip
 
     rank = int(os.environ.get("RANK", "0"))
@@ -159,7 +159,7 @@ def main():
         la.reset()
         outs = la.run(device_ptrs=ptrs, stride=W, paced=args.paced)
         assert len(outs) == F
-        host = np.array([[o.frame + rank * F, o.type, o.cost_est[0][0] if o.type < 3 else max(o.cost_est[1][0], 0), o.bframes] for o in outs], np.int32)
+        host = shard.summarize(outs, rank * F)
         summary.copy_(torch.from_numpy(host), non_blocking=False)
         if dist is not None:
             dist.all_gather_into_tensor(gathered, summary)  # RCCL over xGMI: per-frame summaries only

@@ -1,0 +1,52 @@
+"""The C-ABI library loads without a GPU and exports every entry point include/x264hip.h declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+from x264_amd import lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_match_header():
+    hdr = open(os.path.join(ROOT, "include", "x264hip.h")).read()
+    names = sorted(set(re.findall(r"\b(x264hip_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 25
+    L = lib.load()
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_struct_sizes_match_header():
+    # x264hip_params: 14 ints + float + 2 ints + pointer; la_frame: 4 ints + two 18x18 matrices + 18 ints
+    assert C.sizeof(lib.Params) == 17 * 4 + 4 + 8  # padded to pointer alignment
+    assert C.sizeof(lib.LaFrameOut) == (4 + 2 * 18 * 18 + 18) * 4
+    assert C.sizeof(lib.Cost) == 20 and C.sizeof(lib.Weight) == 16
+
+
+def test_invalid_arguments_are_rejected_without_a_device():
+    L = lib.load()
+    h = C.c_void_p()
+    assert L.x264hip_open(C.byref(h), 0, None) == -2
+    tab, centre = lib.cost_mv_table(128, 1)
+    p = lib.Params(9, 352, 288, 3, 1, 1, 4, 16, 128, 7, 1, 0, 1, 1, 1.0, 0, 8, tab.ctypes.data + 2 * centre)
+    assert L.x264hip_open(C.byref(h), 0, C.byref(p)) == -2  # bit depth 9
+    assert L.x264hip_strerror(-1).decode().startswith("no usable HIP device")
+
+
+def test_open_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        return
+    try:
+        lib.Context(352, 288)
+    except lib.X264HipError as e:
+        assert e.code == -1
+    else:
+        raise AssertionError("x264hip_open must not succeed without a device (no CPU fallback)")
+
+
+def test_la_config_mv_range():
+    assert lib.mv_range_for(176, 144) == 128 and lib.mv_range_for(1920, 1080) == 512 and lib.mv_range_for(3840, 2160) == 512
