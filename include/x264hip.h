@@ -69,7 +69,7 @@ typedef struct x264hip_weight
 typedef struct x264hip_cost
 {
     int cost_est, cost_est_aq, intra_mbs;
-    int intra_cost_est, intra_cost_est_aq; /* the [0][0] cell when intra was (re)computed */
+    int intra_cost_est, intra_cost_est_aq; /* the [0][0] cell; defined only when the call was made with with_intra != 0 */
 } x264hip_cost;
 
 /* ---- context ---------------------------------------------------------------------------------

@@ -63,8 +63,8 @@ def _run_sequence(o, cfg, ctx, frames, weights=None, prefetch=False):
             lc, rows, rows_i, oo = o.cell(cfg, planes[b], None, None, 128, None, None, None, None, None, intra[b], inv[b], with_intra)
             glc, grows = ctx.lowres_costs(b, 0, 0)
             assert np.array_equal(glc, lc)
-            assert (out.intra_cost_est, out.intra_cost_est_aq) == (oo.intra_cost_est, oo.intra_cost_est_aq)
-            if with_intra:
+            if with_intra:  # the intra sums are only defined when the caller asked for them
+                assert (out.intra_cost_est, out.intra_cost_est_aq) == (oo.intra_cost_est, oo.intra_cost_est_aq)
                 assert np.array_equal(grows, rows_i)
             intra_done.add(b)
             continue

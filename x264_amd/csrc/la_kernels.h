@@ -359,6 +359,9 @@ struct CellArgs
     int *row_satds, *row_satds_intra;
     int *acc;                     // [5]: cost_est, cost_est_aq, intra_mbs, intra_cost_est, intra_cost_est_aq
     int *blk;                     // [n_mb] scratch: final block cost | b_intra << 30, input of cell_reduce_kernel
+    const void *fenc0, *ref0_0, *ref1_0; // plane-0 origins (B cells)
+    int sums_only;                // reduce only: intra sums of a frame, no maps written (speculative [0][0] sums)
+    int pad_;
 };
 
 __device__ __forceinline__ void cell_finish( const LaP &P, const CellArgs &A, int xy, int bcost, int list_used )
@@ -378,9 +381,10 @@ __device__ __forceinline__ void cell_finish( const LaP &P, const CellArgs &A, in
 
 // Row and frame sums of one evaluation (slicetype.c:746-757,778-788,946-985): ONE workgroup, each wave owns
 // whole block rows, no atomics, no pre-zeroing; writes row_satds[], row_satds_intra[] and acc[0..4].
-__global__ __launch_bounds__( 1024 ) void cell_reduce_kernel( LaP P, CellArgs A )
+__global__ __launch_bounds__( 1024 ) void cell_reduce_kernel( LaP P, const CellArgs *descs, CellArgs single )
 {
     __shared__ int sh[5][16];
+    const CellArgs A = descs ? descs[blockIdx.x] : single;
     const int W = P.mb_w, H = P.mb_h;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
     int t[5] = { 0, 0, 0, 0, 0 };
@@ -392,8 +396,16 @@ __global__ __launch_bounds__( 1024 ) void cell_reduce_kernel( LaP P, CellArgs A 
             const int xy = by * W + bx;
             const bool scored = ( bx > 0 && bx < W - 1 && by > 0 && by < H - 1 ) || W <= 2 || H <= 2;
             const int inv = P.aq_mode ? A.inv_qscale[xy] : 256;
-            const int w = A.blk[xy];
+            const int w = A.sums_only ? 0 : A.blk[xy];
             const int bcost = w & 0x3FFFFFFF, b_intra = w >> 30;
+            if( A.sums_only )
+            {
+                const int icost = A.intra_cost[xy];
+                const int icost_aq = P.aq_mode ? ( icost * inv + 128 ) >> 8 : icost;
+                row_i += icost_aq;
+                if( scored ) { t[3] += icost; t[4] += icost_aq; }
+                continue;
+            }
             if( A.with_intra )
             {
                 // for the intra-only cell the map aliases the intra costs and may just have been clamped: the
@@ -420,8 +432,8 @@ __global__ __launch_bounds__( 1024 ) void cell_reduce_kernel( LaP P, CellArgs A 
         }
         if( lane == 0 )
         {
-            if( !A.is_intra_only ) A.row_satds[by] = row;
-            if( A.with_intra ) A.row_satds_intra[by] = row_i;
+            if( !A.is_intra_only && !A.sums_only ) A.row_satds[by] = row;
+            if( A.with_intra || A.sums_only ) A.row_satds_intra[by] = row_i;
         }
     }
 #pragma unroll
@@ -442,8 +454,9 @@ __global__ __launch_bounds__( 1024 ) void cell_reduce_kernel( LaP P, CellArgs A 
 }
 
 // P and intra-only cells: no pixel work, one thread per block
-__global__ __launch_bounds__( 256 ) void cell_p_kernel( LaP P, CellArgs A )
+__global__ __launch_bounds__( 256 ) void cell_p_kernel( LaP P, const CellArgs *descs, CellArgs single )
 {
+    const CellArgs A = descs ? descs[blockIdx.y] : single;
     const int xy = blockIdx.x * blockDim.x + threadIdx.x;
     if( xy >= P.mb_w * P.mb_h )
         return;
@@ -458,9 +471,10 @@ __global__ __launch_bounds__( 256 ) void cell_p_kernel( LaP P, CellArgs A )
 
 // B cells: one wave per block; groups 0..2 evaluate the three bidirectional candidates in parallel
 template <typename T>
-__global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, CellArgs A, const T *__restrict__ fenc0, const T *__restrict__ ref0_0,
-                                                       const T *__restrict__ ref1_0 )
+__global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *descs, CellArgs single )
 {
+    const CellArgs A = descs ? descs[blockIdx.z] : single;
+    const T *__restrict__ fenc0 = (const T *)A.fenc0, *__restrict__ ref0_0 = (const T *)A.ref0_0, *__restrict__ ref1_0 = (const T *)A.ref1_0;
     const int lane = lane_id();
     const int bx = blockIdx.x, by = blockIdx.y, xy = by * P.mb_w + bx;
     const int g = lane >> 4, l = lane & 15, q = l >> 2;

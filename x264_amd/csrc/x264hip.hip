@@ -32,6 +32,14 @@
         }                                                                                                    \
     } while( 0 )
 
+struct CellEntry
+{
+    unsigned char valid = 0;      // a speculative result for this cell sits in cell_acc
+    unsigned char requested = 0;  // the caller has asked for this cell: never speculate it again
+    unsigned tag0 = 0, tag1 = 0, tagr = 0; // tags of the fields the speculative evaluation consumed
+    unsigned batch = 0;
+};
+
 struct FrameSlot
 {
     int in_use = 0;
@@ -45,6 +53,9 @@ struct FrameSlot
     int *mvcost[2][X264HIP_BFRAME_MAX + 1];
     uint16_t *lowres_costs = nullptr; // [(bf+2)*(bf+2)][n_mb]
     int *row_satds = nullptr;         // [(bf+2)*(bf+2)][mb_h]
+    int *blk = nullptr;               // [(bf+2)*(bf+2)][n_mb] unclamped block cost | b_intra << 30 per cell
+    unsigned field_tag[2][X264HIP_BFRAME_MAX + 1]; // serial of the search that last wrote the field
+    std::vector<CellEntry> cells;
     // host-side state of the device fields
     unsigned char field_ready[2][X264HIP_BFRAME_MAX + 1]; // searched (any variant) and complete on the stream
     unsigned char field_prefetched[2][X264HIP_BFRAME_MAX + 1]; // unweighted field computed speculatively, not yet claimed
@@ -69,7 +80,13 @@ struct x264hip_ctx
     AqLuts *luts_dev = nullptr;
     unsigned *sync_words = nullptr;  // device [2]
     int *acc_dev = nullptr;          // [8]
-    int *blk_dev = nullptr;          // [n_mb] per-block result words of the cell in flight
+    int n_cells = 0;                 // (bframes+2)^2
+    int *cell_acc_dev = nullptr;     // [slots][n_cells][8] sums of every cell evaluation
+    int *cell_acc_host = nullptr;    // pinned mirror
+    CellArgs *cell_desc_dev = nullptr, *cell_desc_host = nullptr;
+    int cell_desc_cap = 0;
+    unsigned batch_serial = 0, batch_synced = 0;
+    unsigned long long *stats_host = nullptr; // pinned [slots][2]
     int *acc_host = nullptr;         // pinned [8]
     unsigned *sync_host = nullptr;   // pinned [2]
     void *desc_dev = nullptr;        // SearchDesc array
@@ -114,7 +131,9 @@ static void free_all( x264hip_ctx *ctx )
         (void)hipFree( s.planes ); // one allocation per slot holds everything
     }
     for( auto w : ctx->wplanes ) (void)hipFree( w );
-    (void)hipFree( ctx->cost_mv_dev ); (void)hipFree( ctx->luts_dev ); (void)hipFree( ctx->sync_words ); (void)hipFree( ctx->acc_dev ); (void)hipFree( ctx->blk_dev );
+    (void)hipFree( ctx->cost_mv_dev ); (void)hipFree( ctx->luts_dev ); (void)hipFree( ctx->sync_words ); (void)hipFree( ctx->acc_dev ); (void)hipFree( ctx->cell_acc_dev ); (void)hipFree( ctx->cell_desc_dev );
+    (void)hipHostFree( ctx->stats_host );
+    (void)hipHostFree( ctx->cell_acc_host ); (void)hipHostFree( ctx->cell_desc_host );
     (void)hipFree( ctx->desc_dev ); (void)hipFree( ctx->wcost_dev );
     (void)hipHostFree( ctx->acc_host ); (void)hipHostFree( ctx->sync_host ); (void)hipHostFree( ctx->desc_host );
     (void)hipHostFree( ctx->wcost_host ); (void)hipHostFree( ctx->staging );
@@ -184,8 +203,16 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         OPENCK( hipMemcpy( ctx->luts_dev, &l, sizeof( l ), hipMemcpyHostToDevice ) );
     }
     OPENCK( hipMalloc( &ctx->sync_words, 2 * sizeof( unsigned ) ) );
+    OPENCK( hipMemset( ctx->sync_words, 0, 2 * sizeof( unsigned ) ) ); // [1] is a sticky error word: must start clean
     OPENCK( hipMalloc( &ctx->acc_dev, 8 * sizeof( int ) ) );
-    OPENCK( hipMalloc( &ctx->blk_dev, (size_t)ctx->n_mb * sizeof( int ) ) );
+    ctx->n_cells = ( p.bframes + 2 ) * ( p.bframes + 2 );
+    OPENCK( hipMalloc( &ctx->cell_acc_dev, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
+    OPENCK( hipMemset( ctx->cell_acc_dev, 0, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
+    OPENCK( hipHostMalloc( &ctx->cell_acc_host, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
+    OPENCK( hipHostMalloc( &ctx->stats_host, (size_t)p.max_frames * 2 * sizeof( unsigned long long ) ) );
+    ctx->cell_desc_cap = 4096;
+    OPENCK( hipMalloc( &ctx->cell_desc_dev, (size_t)ctx->cell_desc_cap * sizeof( CellArgs ) ) );
+    OPENCK( hipHostMalloc( &ctx->cell_desc_host, (size_t)ctx->cell_desc_cap * sizeof( CellArgs ) ) );
     OPENCK( hipHostMalloc( &ctx->acc_host, 8 * sizeof( int ) ) );
     OPENCK( hipHostMalloc( &ctx->sync_host, 2 * sizeof( unsigned ) ) );
     OPENCK( hipMalloc( &ctx->wcost_dev, sizeof( unsigned ) ) );
@@ -210,6 +237,7 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         const size_t o_mvc = off; off += align_up( (size_t)2 * nd * ctx->n_mb * sizeof( int ), 256 );
         const size_t o_lc = off; off += align_up( (size_t)nc * ctx->n_mb * sizeof( uint16_t ), 256 );
         const size_t o_rows = off; off += align_up( (size_t)nc * mb_h * sizeof( int ), 256 );
+        const size_t o_blk = off; off += align_up( (size_t)nc * ctx->n_mb * sizeof( int ), 256 );
         char *base = nullptr;
         OPENCK( hipMalloc( &base, off ) );
         OPENCK( hipMemset( base, 0, off ) );
@@ -224,6 +252,9 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
             }
         s.lowres_costs = (uint16_t *)( base + o_lc );
         s.row_satds = (int *)( base + o_rows );
+        s.blk = (int *)( base + o_blk );
+        s.cells.assign( nc, CellEntry() );
+        memset( s.field_tag, 0, sizeof( s.field_tag ) );
         memset( s.field_ready, 0, sizeof( s.field_ready ) );
         memset( s.field_prefetched, 0, sizeof( s.field_prefetched ) );
     }
@@ -312,6 +343,8 @@ extern "C" int x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, 
     s.stats_valid = 0;
     memset( s.field_ready, 0, sizeof( s.field_ready ) );
     memset( s.field_prefetched, 0, sizeof( s.field_prefetched ) );
+    memset( s.field_tag, 0, sizeof( s.field_tag ) );
+    s.cells.assign( ctx->n_cells, CellEntry() );
     if( s.wplane_idx >= 0 ) { ctx->wplane_owner[s.wplane_idx] = -1; s.wplane_idx = -1; }
     ctx->counters[3]++;
     return ctx->p.bit_depth == 8 ? frame_put_t<uint8_t>( ctx, s, luma, stride, is_device, cb, cr, cstride, inv_qscale )
@@ -326,13 +359,25 @@ extern "C" int x264hip_frame_stats( x264hip_ctx *ctx, int slot, uint64_t *pixel_
     if( !s.in_use ) return X264HIP_ESTATE;
     if( !s.stats_valid )
     {
-        unsigned long long v[2];
-        HIPCK( hipMemcpyAsync( v, s.frame_sums, sizeof( v ), hipMemcpyDeviceToHost, ctx->stream ) );
+        // one round trip fetches the totals of every frame that does not have them yet
+        std::vector<int> pend;
+        for( int i = 0; i < (int)ctx->slots.size(); i++ )
+            if( ctx->slots[i].in_use && !ctx->slots[i].stats_valid )
+            {
+                HIPCK( hipMemcpyAsync( ctx->stats_host + 2 * i, ctx->slots[i].frame_sums, 2 * sizeof( unsigned long long ), hipMemcpyDeviceToHost, ctx->stream ) );
+                pend.push_back( i );
+            }
         HIPCK( hipStreamSynchronize( ctx->stream ) );
+        ctx->batch_synced = ctx->batch_serial;
         const uint64_t n = (uint64_t)( 16 * ctx->P.mb_w ) * ( 16 * ctx->P.mb_h );
-        s.sum = v[0];
-        s.ssd = v[1] - ( v[0] * v[0] + n / 2 ) / n; // ratecontrol.c:405-414
-        s.stats_valid = 1;
+        for( int i : pend )
+        {
+            FrameSlot &f = ctx->slots[i];
+            const unsigned long long sum = ctx->stats_host[2 * i], sq = ctx->stats_host[2 * i + 1];
+            f.sum = sum;
+            f.ssd = sq - ( sum * sum + n / 2 ) / n; // ratecontrol.c:405-414
+            f.stats_valid = 1;
+        }
     }
     if( pixel_sum ) *pixel_sum = s.sum;
     if( pixel_ssd ) *pixel_ssd = s.ssd;
@@ -387,6 +432,20 @@ struct SearchReq
     WtD wt;
 };
 
+// copy the kernel error word back, wait for the stream, latch in-kernel timeouts; every completed batch is now readable
+static int sync_stream( x264hip_ctx *ctx )
+{
+    HIPCK( hipMemcpyAsync( ctx->sync_host, ctx->sync_words, 2 * sizeof( unsigned ), hipMemcpyDeviceToHost, ctx->stream ) );
+    HIPCK( hipStreamSynchronize( ctx->stream ) );
+    ctx->batch_synced = ctx->batch_serial;
+    if( ctx->sync_host[1] )
+    {
+        ctx->broken = 1;
+        return X264HIP_ETIMEOUT;
+    }
+    return X264HIP_OK;
+}
+
 template <typename T>
 static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &reqs )
 {
@@ -395,7 +454,8 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
     if( !n ) return X264HIP_OK;
     if( n > ctx->desc_cap ) return X264HIP_EINVAL;
     // the pinned descriptor table may still be read by an in-flight copy of the previous launch
-    HIPCK( hipStreamSynchronize( ctx->stream ) );
+    int rc = sync_stream( ctx );
+    if( rc ) return rc;
     SearchDesc<T> *dh = (SearchDesc<T> *)ctx->desc_host;
     for( int i = 0; i < n; i++ )
     {
@@ -418,17 +478,18 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         d.costs = b.mvcost[r.list][r.dist_m1];
         d.tag = ctx->tag_serial++;
         if( !ctx->tag_serial ) ctx->tag_serial = 1;
+        b.field_tag[r.list][r.dist_m1] = d.tag;
         d.pad = 0;
         dh[i] = d;
     }
     HIPCK( hipMemcpyAsync( ctx->desc_dev, dh, (size_t)n * sizeof( SearchDesc<T> ), hipMemcpyHostToDevice, ctx->stream ) );
-    HIPCK( hipMemsetAsync( ctx->sync_words, 0, 2 * sizeof( unsigned ), ctx->stream ) );
+    HIPCK( hipMemsetAsync( ctx->sync_words, 0, sizeof( unsigned ), ctx->stream ) ); // ticket only: the error word is sticky
     hipEvent_t e0 = ctx->ev_start, e1 = ctx->ev_stop;
     if( ctx->prof_on )
     {
         if( ctx->prof_used + 2 > (int)ctx->prof_ev.size() )
         {
-            int rc = prof_drain( ctx );
+            rc = prof_drain( ctx );
             if( rc ) return rc;
         }
         e0 = ctx->prof_ev[ctx->prof_used]; e1 = ctx->prof_ev[ctx->prof_used + 1];
@@ -451,15 +512,87 @@ static int launch_searches( x264hip_ctx *ctx, const std::vector<SearchReq> &reqs
     return ctx->p.bit_depth == 8 ? launch_searches_t<uint8_t>( ctx, reqs ) : launch_searches_t<uint16_t>( ctx, reqs );
 }
 
-static int check_kernel_error( x264hip_ctx *ctx )
+// ---- cost cells ---------------------------------------------------------------------------------------
+// Descriptor of the cell (slot_b, d0, d1) with the fields as they stand now.  kind: 0 intra sums only, 1 real cell.
+template <typename T>
+static CellArgs make_cell( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b, int d0, int d1, int with_intra, int ref1_l0_valid,
+                           int sums_only )
 {
-    HIPCK( hipMemcpyAsync( ctx->sync_host, ctx->sync_words, 2 * sizeof( unsigned ), hipMemcpyDeviceToHost, ctx->stream ) );
-    HIPCK( hipStreamSynchronize( ctx->stream ) );
-    if( ctx->sync_host[1] )
+    const LaP &P = ctx->P;
+    FrameSlot &b = ctx->slots[slot_b], &f0 = ctx->slots[slot_p0], &f1 = ctx->slots[slot_p1];
+    const int intra_only = d0 == 0 && d1 == 0, b_bidir = d1 > 0;
+    const int idx = d0 * ( ctx->p.bframes + 2 ) + d1;
+    CellArgs A;
+    memset( &A, 0, sizeof( A ) );
+    A.b_bidir = b_bidir; A.with_intra = with_intra; A.is_intra_only = intra_only; A.ref1_l0_valid = b_bidir && ref1_l0_valid;
+    A.sums_only = sums_only;
+    A.dist_scale_factor = intra_only ? 128 : ( ( d0 << 8 ) + ( ( d0 + d1 ) >> 1 ) ) / ( d0 + d1 );
+    if( !intra_only )
     {
-        ctx->broken = 1;
-        return X264HIP_ETIMEOUT;
+        A.mvq0 = b.mvq[0][d0 - 1]; A.costs0 = b.mvcost[0][d0 - 1];
+        if( b_bidir )
+        {
+            A.mvq1 = b.mvq[1][d1 - 1]; A.costs1 = b.mvcost[1][d1 - 1];
+            A.ref1_l0 = A.ref1_l0_valid ? f1.mvq[0][d0 + d1 - 1] : nullptr;
+            A.fenc0 = plane_origin<T>( ctx, b, 0 ); A.ref0_0 = plane_origin<T>( ctx, f0, 0 ); A.ref1_0 = plane_origin<T>( ctx, f1, 0 );
+        }
     }
+    A.intra_cost = b.lowres_costs; // cell [0][0] (frame.c:283)
+    A.inv_qscale = b.inv_qscale;
+    A.lowres_costs = b.lowres_costs + (size_t)idx * ctx->n_mb;
+    A.row_satds = b.row_satds + (size_t)idx * P.mb_h;
+    A.row_satds_intra = b.row_satds;
+    A.blk = b.blk + (size_t)idx * ctx->n_mb;
+    A.acc = ctx->cell_acc_dev + ( (size_t)slot_b * ctx->n_cells + idx ) * 8;
+    return A;
+}
+
+struct SpecCell
+{
+    int slot_p0, slot_p1, slot_b, d0, d1, sums_only;
+};
+
+// one batch: all P cells, all B cells, then one reduction launch (a workgroup per cell)
+template <typename T>
+static int launch_cells_t( x264hip_ctx *ctx, const std::vector<SpecCell> &cells )
+{
+    const LaP &P = ctx->P;
+    for( size_t o = 0; o < cells.size(); o += ctx->cell_desc_cap )
+    {
+        const int n = (int)std::min( cells.size() - o, (size_t)ctx->cell_desc_cap );
+        int rc = sync_stream( ctx ); // pinned descriptor table reuse
+        if( rc ) return rc;
+        // order: [P cells | B cells | sums-only]; the reduction walks all of them
+        std::vector<const SpecCell *> ord;
+        int n_p = 0, n_b = 0;
+        for( int pass = 0; pass < 3; pass++ )
+            for( int i = 0; i < n; i++ )
+            {
+                const SpecCell &c = cells[o + i];
+                int kind = c.sums_only ? 2 : c.d1 > 0 ? 1 : 0;
+                if( kind != pass ) continue;
+                ord.push_back( &c );
+                if( pass == 0 ) n_p++;
+                if( pass == 1 ) n_b++;
+            }
+        for( int i = 0; i < n; i++ )
+        {
+            const SpecCell &c = *ord[i];
+            ctx->cell_desc_host[i] = make_cell<T>( ctx, c.slot_p0, c.slot_p1, c.slot_b, c.d0, c.d1, 1, 1, c.sums_only );
+        }
+        HIPCK( hipMemcpyAsync( ctx->cell_desc_dev, ctx->cell_desc_host, (size_t)n * sizeof( CellArgs ), hipMemcpyHostToDevice, ctx->stream ) );
+        CellArgs none;
+        memset( &none, 0, sizeof( none ) );
+        if( n_p )
+            cell_p_kernel<<<dim3( ( ctx->n_mb + 255 ) / 256, n_p ), 256, 0, ctx->stream>>>( P, ctx->cell_desc_dev, none );
+        if( n_b )
+            cell_b_kernel<T><<<dim3( P.mb_w, P.mb_h, n_b ), 64, 0, ctx->stream>>>( P, ctx->cell_desc_dev + n_p, none );
+        cell_reduce_kernel<<<n, 1024, 0, ctx->stream>>>( P, ctx->cell_desc_dev, none );
+        HIPCK( hipGetLastError() );
+    }
+    if( !cells.empty() )
+        HIPCK( hipMemcpyAsync( ctx->cell_acc_host, ctx->cell_acc_dev, (size_t)ctx->slots.size() * ctx->n_cells * 8 * sizeof( int ),
+                               hipMemcpyDeviceToHost, ctx->stream ) );
     return X264HIP_OK;
 }
 
@@ -469,15 +602,16 @@ extern "C" int x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *
     if( ctx->broken ) return X264HIP_EDEVICE;
     std::vector<SearchReq> reqs;
     const WtD none = { 0, 1, 0, 0 };
+    const int bf = ctx->p.bframes, nstride = bf + 2;
     for( int i = 0; i < n; i++ )
     {
         if( !slot_ok( ctx, slots[i] ) || !ctx->slots[slots[i]].in_use ) return X264HIP_ESTATE;
         for( int j = 0; j < n; j++ )
         {
             const int d = frame_numbers[j] - frame_numbers[i]; // reference j relative to source i
-            if( !d || abs( d ) > ctx->p.bframes + 1 ) continue;
+            if( !d || abs( d ) > bf + 1 ) continue;
             const int list = d > 0, dm1 = abs( d ) - 1;
-            if( list && !ctx->p.bframes ) continue;
+            if( list && !bf ) continue;
             FrameSlot &b = ctx->slots[slots[i]];
             if( b.field_ready[list][dm1] || b.field_prefetched[list][dm1] ) continue;
             b.field_prefetched[list][dm1] = 1;
@@ -491,6 +625,56 @@ extern "C" int x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *
         int r = launch_searches( ctx, part );
         if( r ) return r;
     }
+    // speculative cells over the fields that now exist: intra sums, P cells, B cells whose three inputs are present
+    // (unweighted speculative or already claimed fields).  Entries remember the field tags they consumed.
+    std::vector<SpecCell> cells;
+    if( getenv( "X264HIP_NO_SPEC_CELLS" ) ) return X264HIP_OK; // debugging aid: searches only
+    std::vector<int> by_number; // frame number -> index in the lists (small window: linear scans are fine)
+    auto find = [&]( int number ) { for( int k = 0; k < n; k++ ) if( frame_numbers[k] == number ) return k; return -1; };
+    auto has_field = [&]( FrameSlot &f, int list, int dm1 ) { return f.field_ready[list][dm1] || f.field_prefetched[list][dm1]; };
+    for( int i = 0; i < n; i++ )
+    {
+        FrameSlot &b = ctx->slots[slots[i]];
+        CellEntry &e0 = b.cells[0];
+        if( !e0.valid && !e0.requested )
+        {
+            e0.valid = 1; e0.batch = ctx->batch_serial + 1; e0.tag0 = e0.tag1 = e0.tagr = 0;
+            cells.push_back( SpecCell{ slots[i], slots[i], slots[i], 0, 0, 1 } );
+        }
+        for( int d0 = 1; d0 <= bf + 1; d0++ )
+        {
+            const int j0 = find( frame_numbers[i] - d0 );
+            if( j0 < 0 || !has_field( b, 0, d0 - 1 ) ) continue;
+            for( int d1 = 0; d0 + d1 <= bf + 1; d1++ )
+            {
+                CellEntry &e = b.cells[d0 * nstride + d1];
+                if( e.valid || e.requested ) continue;
+                int j1 = j0;
+                unsigned t1 = 0, tr = 0;
+                if( d1 )
+                {
+                    j1 = find( frame_numbers[i] + d1 );
+                    if( j1 < 0 || !has_field( b, 1, d1 - 1 ) ) continue;
+                    FrameSlot &f1 = ctx->slots[slots[j1]];
+                    if( !has_field( f1, 0, d0 + d1 - 1 ) ) continue;
+                    t1 = b.field_tag[1][d1 - 1];
+                    tr = f1.field_tag[0][d0 + d1 - 1];
+                }
+                e.valid = 1; e.batch = ctx->batch_serial + 1;
+                e.tag0 = b.field_tag[0][d0 - 1]; e.tag1 = t1; e.tagr = tr;
+                cells.push_back( SpecCell{ slots[j0], slots[d1 ? j1 : i], slots[i], d0, d1, 0 } );
+            }
+        }
+    }
+    if( !cells.empty() )
+    {
+        // entries carry batch_serial + 1; the serial moves only once the batch is enqueued, because the launch
+        // itself synchronises the stream (descriptor table reuse) and must not mark this batch as complete
+        int r = ctx->p.bit_depth == 8 ? launch_cells_t<uint8_t>( ctx, cells ) : launch_cells_t<uint16_t>( ctx, cells );
+        if( r ) return r;
+        ctx->batch_serial++;
+        ctx->counters[5] += cells.size();
+    }
     return X264HIP_OK;
 }
 
@@ -500,10 +684,10 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
                          const x264hip_weight *w, int with_intra, int ref1_l0_valid, x264hip_cost *out )
 {
     const LaP &P = ctx->P;
-    FrameSlot &b = ctx->slots[slot_b], &f0 = ctx->slots[slot_p0], &f1 = ctx->slots[slot_p1];
+    FrameSlot &b = ctx->slots[slot_b], &f1 = ctx->slots[slot_p1];
     const int intra_only = d0 == 0 && d1 == 0;
     const int b_bidir = d1 > 0;
-    const int nstride = ctx->p.bframes + 2;
+    const int idx = d0 * ( ctx->p.bframes + 2 ) + d1;
     std::vector<SearchReq> reqs;
     if( !intra_only )
     {
@@ -538,43 +722,45 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
         int r = launch_searches( ctx, reqs );
         if( r ) return r;
     }
-    CellArgs A;
-    memset( &A, 0, sizeof( A ) );
-    A.b_bidir = b_bidir; A.with_intra = with_intra; A.is_intra_only = intra_only; A.ref1_l0_valid = b_bidir && ref1_l0_valid;
-    A.dist_scale_factor = intra_only ? 128 : ( ( d0 << 8 ) + ( ( d0 + d1 ) >> 1 ) ) / ( d0 + d1 );
-    if( !intra_only )
+    // speculative result usable?  Same input fields (tags) as the cell would read now.
+    CellEntry &e = b.cells[idx];
+    const unsigned t0 = intra_only ? 0 : b.field_tag[0][d0 - 1];
+    const unsigned t1 = b_bidir ? b.field_tag[1][d1 - 1] : 0;
+    const unsigned tr = b_bidir && ref1_l0_valid ? f1.field_tag[0][d0 + d1 - 1] : 0;
+    const bool hit = e.valid && e.tag0 == t0 && e.tag1 == t1 && e.tagr == tr && ( !b_bidir || ref1_l0_valid );
+    e.requested = 1;
+    e.valid = 0;
+    const int *res = ctx->cell_acc_host + ( (size_t)slot_b * ctx->n_cells + idx ) * 8;
+    CellArgs A = make_cell<T>( ctx, slot_p0, slot_p1, slot_b, d0, d1, with_intra, ref1_l0_valid, 0 );
+    if( hit )
     {
-        A.mvq0 = b.mvq[0][d0 - 1]; A.costs0 = b.mvcost[0][d0 - 1];
-        if( b_bidir )
+        ctx->counters[4]++;
+        if( e.batch > ctx->batch_synced )
         {
-            A.mvq1 = b.mvq[1][d1 - 1]; A.costs1 = b.mvcost[1][d1 - 1];
-            A.ref1_l0 = A.ref1_l0_valid ? f1.mvq[0][d0 + d1 - 1] : nullptr;
+            int r = sync_stream( ctx );
+            if( r ) return r;
+        }
+        if( intra_only )
+        {
+            // the sums are known; the map still has to take the reference's 14-bit clamp (aliases the intra costs)
+            cell_p_kernel<<<dim3( ( ctx->n_mb + 255 ) / 256, 1 ), 256, 0, ctx->stream>>>( P, nullptr, A );
+            HIPCK( hipGetLastError() );
         }
     }
-    A.intra_cost = b.lowres_costs; // cell [0][0]
-    A.inv_qscale = b.inv_qscale;
-    A.lowres_costs = b.lowres_costs + (size_t)( d0 * nstride + d1 ) * ctx->n_mb;
-    A.row_satds = b.row_satds + (size_t)( d0 * nstride + d1 ) * P.mb_h;
-    A.row_satds_intra = b.row_satds;
-    A.acc = ctx->acc_dev;
-    A.blk = ctx->blk_dev;
-    if( b_bidir )
-        cell_b_kernel<T><<<dim3( P.mb_w, P.mb_h ), 64, 0, ctx->stream>>>( P, A, plane_origin<T>( ctx, b, 0 ), plane_origin<T>( ctx, f0, 0 ),
-                                                                          plane_origin<T>( ctx, f1, 0 ) );
     else
-        cell_p_kernel<<<( ctx->n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( P, A );
-    cell_reduce_kernel<<<1, 1024, 0, ctx->stream>>>( P, A );
-    HIPCK( hipGetLastError() );
-    HIPCK( hipMemcpyAsync( ctx->acc_host, ctx->acc_dev, 8 * sizeof( int ), hipMemcpyDeviceToHost, ctx->stream ) );
-    if( !reqs.empty() )
     {
-        int r = check_kernel_error( ctx );
+        if( b_bidir )
+            cell_b_kernel<T><<<dim3( P.mb_w, P.mb_h, 1 ), 64, 0, ctx->stream>>>( P, nullptr, A );
+        else
+            cell_p_kernel<<<dim3( ( ctx->n_mb + 255 ) / 256, 1 ), 256, 0, ctx->stream>>>( P, nullptr, A );
+        cell_reduce_kernel<<<1, 1024, 0, ctx->stream>>>( P, nullptr, A );
+        HIPCK( hipGetLastError() );
+        HIPCK( hipMemcpyAsync( (void *)res, A.acc, 8 * sizeof( int ), hipMemcpyDeviceToHost, ctx->stream ) );
+        int r = sync_stream( ctx );
         if( r ) return r;
     }
-    else
-        HIPCK( hipStreamSynchronize( ctx->stream ) );
-    out->cost_est = ctx->acc_host[0]; out->cost_est_aq = ctx->acc_host[1]; out->intra_mbs = ctx->acc_host[2];
-    out->intra_cost_est = ctx->acc_host[3]; out->intra_cost_est_aq = ctx->acc_host[4];
+    out->cost_est = res[0]; out->cost_est_aq = res[1]; out->intra_mbs = res[2];
+    out->intra_cost_est = res[3]; out->intra_cost_est_aq = res[4];
     ctx->counters[1]++;
     return X264HIP_OK;
 }
