@@ -72,11 +72,62 @@ __device__ __forceinline__ int sel4( int g, int a0, int a1, int a2, int a3 )
     return g == 0 ? a0 : g == 1 ? a1 : g == 2 ? a2 : a3;
 }
 
-// ---- pixel access --------------------------------------------------------------------------------
-__device__ __forceinline__ void load4( const uint8_t *p, int v[4] )
+// ---- pixel access: four pixels per lane, held as two registers of packed 16-bit values ------------------
+// gfx950 packed-math (VOP3P) works on pairs of 16-bit values, which is exactly the range this path needs:
+// 10-bit samples, differences, and 4x4 Hadamard coefficients (|c| <= 16*1023) all fit int16.  8-bit
+// samples additionally keep their raw 4-byte form for the byte-wise v_sad_u8 / v_lerp_u8 instructions.
+typedef short s16x2 __attribute__( ( ext_vector_type( 2 ) ) );
+typedef unsigned short u16x2 __attribute__( ( ext_vector_type( 2 ) ) );
+__device__ __forceinline__ s16x2 as_s2( uint32_t v ) { return __builtin_bit_cast( s16x2, v ); }
+__device__ __forceinline__ u16x2 as_u2( uint32_t v ) { return __builtin_bit_cast( u16x2, v ); }
+__device__ __forceinline__ uint32_t as_u32( s16x2 v ) { return __builtin_bit_cast( uint32_t, v ); }
+__device__ __forceinline__ uint32_t as_u32( u16x2 v ) { return __builtin_bit_cast( uint32_t, v ); }
+
+struct Px4
+{
+    uint32_t a, b; // {p0, p1}, {p2, p3} as packed u16
+    uint32_t raw;  // the same four samples as bytes (meaningful for 8-bit pixels only)
+};
+
+__device__ __forceinline__ Px4 px4_from_raw( uint32_t w )
+{
+    Px4 r;
+    r.raw = w;
+    r.a = __builtin_amdgcn_perm( 0, w, 0x0c010c00u );
+    r.b = __builtin_amdgcn_perm( 0, w, 0x0c030c02u );
+    return r;
+}
+__device__ __forceinline__ Px4 px4_from_ints( const int v[4], bool with_raw )
+{
+    Px4 r;
+    r.a = (uint32_t)v[0] | ( (uint32_t)v[1] << 16 );
+    r.b = (uint32_t)v[2] | ( (uint32_t)v[3] << 16 );
+    r.raw = with_raw ? __builtin_amdgcn_perm( r.b, r.a, 0x06040200u ) : 0;
+    return r;
+}
+__device__ __forceinline__ void px4_to_ints( const Px4 &p, int v[4] )
+{
+    v[0] = p.a & 0xFFFF; v[1] = p.a >> 16; v[2] = p.b & 0xFFFF; v[3] = p.b >> 16;
+}
+
+__device__ __forceinline__ Px4 load_px4( const uint8_t *p )
 {
     uint32_t w;
     __builtin_memcpy( &w, p, 4 ); // gfx950 global loads are byte-addressable: one global_load_dword
+    return px4_from_raw( w );
+}
+__device__ __forceinline__ Px4 load_px4( const uint16_t *p )
+{
+    uint2 w;
+    __builtin_memcpy( &w, p, 8 );
+    Px4 r;
+    r.a = w.x; r.b = w.y; r.raw = 0;
+    return r;
+}
+__device__ __forceinline__ void load4( const uint8_t *p, int v[4] )
+{
+    uint32_t w;
+    __builtin_memcpy( &w, p, 4 );
     v[0] = w & 255; v[1] = ( w >> 8 ) & 255; v[2] = ( w >> 16 ) & 255; v[3] = w >> 24;
 }
 __device__ __forceinline__ void load4( const uint16_t *p, int v[4] )
@@ -91,12 +142,37 @@ __device__ __forceinline__ int weight_px( int v, const WtD &w, int pixel_max )
     int r = w.denom >= 1 ? ( ( v * w.scale + ( 1 << ( w.denom - 1 ) ) ) >> w.denom ) + w.offset : v * w.scale + w.offset;
     return iclip3( r, 0, pixel_max );
 }
+template <typename T>
+__device__ __forceinline__ Px4 weight_px4( const Px4 &p, const WtD &w, int pixel_max )
+{
+    int v[4];
+    px4_to_ints( p, v );
+#pragma unroll
+    for( int i = 0; i < 4; i++ )
+        v[i] = weight_px( v[i], w, pixel_max );
+    return px4_from_ints( v, sizeof( T ) == 1 );
+}
+
+// rounded average of two sample quads
+__device__ __forceinline__ Px4 avg_px4( const Px4 &x, const Px4 &y, const uint8_t * )
+{
+    return px4_from_raw( __builtin_amdgcn_lerp( x.raw, y.raw, 0x01010101u ) ); // (a + b + 1) >> 1 per byte
+}
+__device__ __forceinline__ Px4 avg_px4( const Px4 &x, const Px4 &y, const uint16_t * )
+{
+    const u16x2 one = { 1, 1 };
+    Px4 r;
+    r.a = as_u32( (u16x2)( ( as_u2( x.a ) + as_u2( y.a ) + one ) >> (u16x2){ 1, 1 } ) );
+    r.b = as_u32( (u16x2)( ( as_u2( x.b ) + as_u2( y.b ) + one ) >> (u16x2){ 1, 1 } ) );
+    r.raw = 0;
+    return r;
+}
 
 // Four quarter-pel samples at lowres position (x..x+3, y) displaced by (mvx,mvy): rounded average of
 // two of the four half-pel planes (both taps coincide for full/half-pel phases, so the code path is
 // branch free).  p0 = plane 0 at the block origin; plane k is plane_elems*k further.
 template <typename T>
-__device__ __forceinline__ void qpel4( const T *p0, int plane_elems, int stride, int x, int y, int mvx, int mvy, int out[4] )
+__device__ __forceinline__ Px4 qpel_px4( const T *p0, int plane_elems, int stride, int x, int y, int mvx, int mvy )
 {
     int fx = mvx & 3, fy = mvy & 3;
     int ix = x + ( mvx >> 2 ), iy = y + ( mvy >> 2 );
@@ -104,39 +180,55 @@ __device__ __forceinline__ void qpel4( const T *p0, int plane_elems, int stride,
     int pb = ( fx == 2 ? 1 : 0 ) + ( fy ? 2 : 0 );
     const T *a = p0 + (size_t)pa * plane_elems + ( iy + ( fy == 3 ) ) * stride + ix;
     const T *b = p0 + (size_t)pb * plane_elems + iy * stride + ix + ( fx == 3 );
-    int t[4];
-    load4( a, out );
-    load4( b, t );
-#pragma unroll
-    for( int i = 0; i < 4; i++ )
-        out[i] = ( out[i] + t[i] + 1 ) >> 1;
+    return avg_px4( load_px4( a ), load_px4( b ), (const T *)nullptr );
 }
 
 // ---- block metrics on the 16-lane layout -----------------------------------------------------------
-// d[4]: this lane's 4 differences.  Returns the 8x8 block cost in every lane of the 16-lane row.
-__device__ __forceinline__ int satd_tile_partial( const int d[4] )
+// {v.lo + v.hi, v.lo - v.hi}: the one butterfly of the horizontal transform that crosses register halves,
+// as a single VOP3P multiply-add with operand-half selection (hi*{1,-1} + lo)
+__device__ __forceinline__ s16x2 cross_half_butterfly( s16x2 v )
+{
+    uint32_t r;
+    const uint32_t k = 0xFFFF0001u; // { +1, -1 }
+    asm( "v_pk_mad_i16 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"( r ) : "v"( as_u32( v ) ), "v"( k ) );
+    return as_s2( r );
+}
+
+// per-lane sum of |4x4 Hadamard coefficients| this lane holds after the quad-wide transform
+__device__ __forceinline__ int satd_partial_px4( const Px4 &f, const Px4 &r )
 {
     const int lane = lane_id();
-    // horizontal 4-point Hadamard in registers
-    int s01 = d[0] + d[1], d01 = d[0] - d[1], s23 = d[2] + d[3], d23 = d[2] - d[3];
-    int h[4] = { s01 + s23, d01 + d23, s01 - s23, d01 - d23 };
-    // vertical 4-point Hadamard across the quad (rows r = lane & 3)
-    int acc = 0;
-#pragma unroll
-    for( int i = 0; i < 4; i++ )
-    {
-        int v = h[i];
-        int p = dpp_mov<DPP_QUAD_XOR1>( v );
-        v = ( lane & 1 ) ? p - v : p + v;
-        p = dpp_mov<DPP_QUAD_XOR2>( v );
-        v = ( lane & 2 ) ? p - v : p + v;
-        acc += iabs( v );
-    }
-    return acc;
+    const s16x2 d01 = as_s2( f.a ) - as_s2( r.a ), d23 = as_s2( f.b ) - as_s2( r.b );
+    // horizontal 4-point Hadamard: {d0+d2, d1+d3}, {d0-d2, d1-d3}, then the cross-half butterflies
+    s16x2 X = cross_half_butterfly( d01 + d23 ), Y = cross_half_butterfly( d01 - d23 );
+    // vertical 4-point Hadamard across the quad (rows r = lane & 3): v' = partner + sign * v
+    const s16x2 s1 = ( lane & 1 ) ? (s16x2){ -1, -1 } : (s16x2){ 1, 1 };
+    const s16x2 s2 = ( lane & 2 ) ? (s16x2){ -1, -1 } : (s16x2){ 1, 1 };
+    X = X * s1 + as_s2( (uint32_t)dpp_mov<DPP_QUAD_XOR1>( (int)as_u32( X ) ) );
+    Y = Y * s1 + as_s2( (uint32_t)dpp_mov<DPP_QUAD_XOR1>( (int)as_u32( Y ) ) );
+    X = X * s2 + as_s2( (uint32_t)dpp_mov<DPP_QUAD_XOR2>( (int)as_u32( X ) ) );
+    Y = Y * s2 + as_s2( (uint32_t)dpp_mov<DPP_QUAD_XOR2>( (int)as_u32( Y ) ) );
+    const s16x2 ax = __builtin_elementwise_max( X, -X ), ay = __builtin_elementwise_max( Y, -Y );
+    const u16x2 sum = as_u2( as_u32( ax ) ) + as_u2( as_u32( ay ) );
+    return (int)__builtin_amdgcn_udot2( sum, (u16x2){ 1, 1 }, 0u, false );
 }
-__device__ __forceinline__ int block_cost8x8( const int d[4], int use_satd )
+__device__ __forceinline__ int sad_partial_px4( const Px4 &f, const Px4 &r, const uint8_t * )
+{
+    return (int)__builtin_amdgcn_sad_u8( f.raw, r.raw, 0u );
+}
+__device__ __forceinline__ int sad_partial16( const Px4 &f, const Px4 &r )
+{
+    const s16x2 d01 = as_s2( f.a ) - as_s2( r.a ), d23 = as_s2( f.b ) - as_s2( r.b );
+    const s16x2 a0 = __builtin_elementwise_max( d01, -d01 ), a1 = __builtin_elementwise_max( d23, -d23 );
+    return (int)__builtin_amdgcn_udot2( as_u2( as_u32( a0 ) ) + as_u2( as_u32( a1 ) ), (u16x2){ 1, 1 }, 0u, false );
+}
+__device__ __forceinline__ int sad_partial_px4( const Px4 &f, const Px4 &r, const uint16_t * ) { return sad_partial16( f, r ); }
+
+// cost of the 8x8 block this 16-lane row holds, in every lane of the row
+template <typename T>
+__device__ __forceinline__ int block_cost8x8( const Px4 &f, const Px4 &r, int use_satd )
 {
     if( use_satd )
-        return reduce16( satd_tile_partial( d ) ) >> 1;
-    return reduce16( iabs( d[0] ) + iabs( d[1] ) + iabs( d[2] ) + iabs( d[3] ) );
+        return reduce16( satd_partial_px4( f, r ) ) >> 1;
+    return reduce16( sad_partial_px4( f, r, (const T *)nullptr ) );
 }

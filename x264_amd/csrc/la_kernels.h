@@ -287,18 +287,18 @@ __global__ __launch_bounds__( 64 ) void intra_kernel( LaP P, const T *__restrict
     __syncthreads();
     const int g = lane >> 4, l = lane & 15, q = l >> 2;
     const int tx = ( q & 1 ) * 4, row = ( q >> 1 ) * 4 + ( l & 3 );
-    int f[4];
-    load4( src + row * P.stride + tx, f );
+    const Px4 f = load_px4( src + row * P.stride + tx );
     int best = COST_MAX_I;
     const int n_modes = P.subme > 1 ? 10 : 3;
     for( int m0 = 0; m0 < n_modes; m0 += 4 )
     {
         const int mode = imin2( m0 + g, 9 );
-        int d[4];
+        int pr[4];
 #pragma unroll
         for( int i = 0; i < 4; i++ )
-            d[i] = f[i] - intra_pred_px( E, mode, tx + i, row, P.pixel_max );
-        int v = block_cost8x8( d, P.mbcmp_satd );
+            pr[i] = intra_pred_px( E, mode, tx + i, row, P.pixel_max );
+        const Px4 r = px4_from_ints( pr, false );
+        int v = P.mbcmp_satd ? reduce16( satd_partial_px4( f, r ) ) >> 1 : reduce16( sad_partial16( f, r ) );
 #pragma unroll
         for( int k = 0; k < 4; k++ )
             if( m0 + k < n_modes )
@@ -331,13 +331,11 @@ __global__ __launch_bounds__( 64 ) void weight_cost_kernel( LaP P, const T *__re
     const int xyc = imin2( xy, n_mb - 1 );
     const int bx = xyc % P.mb_w, by = xyc / P.mb_w;
     const int off = 8 * ( by * P.stride + bx ) + row * P.stride + tx;
-    int f[4], r[4], d[4];
-    load4( fenc0 + off, f );
-    load4( ref0 + off, r );
-#pragma unroll
-    for( int i = 0; i < 4; i++ )
-        d[i] = ( w.on ? weight_px( r[i], w, P.pixel_max ) : r[i] ) - f[i];
-    c = imin2( block_cost8x8( d, P.mbcmp_satd ), (int)intra_cost[xyc] );
+    const Px4 f = load_px4( fenc0 + off );
+    Px4 r = load_px4( ref0 + off );
+    if( w.on )
+        r = weight_px4<T>( r, w, P.pixel_max );
+    c = imin2( block_cost8x8<T>( f, r, P.mbcmp_satd ), (int)intra_cost[xyc] );
     unsigned tot = 0;
 #pragma unroll
     for( int k = 0; k < 4; k++ )
@@ -504,18 +502,22 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
     int ax = sel4( g, d0x, 0, m0x, m0x ), ay = sel4( g, d0y, 0, m0y, m0y );
     int cx = sel4( g, d1x, 0, m1x, m1x ), cy = sel4( g, d1y, 0, m1y, m1y );
     if( P.subme <= 1 ) { ax &= ~1; ay &= ~1; cx &= ~1; cy &= ~1; } // half-pel plane pick (slicetype.c:582-589)
-    int f[4], ra[4], rb[4], d[4];
-    load4( fenc0 + off + row * P.stride + tx, f );
-    qpel4( ref0_0 + off, P.plane_elems, P.stride, tx, row, ax, ay, ra );
-    qpel4( ref1_0 + off, P.plane_elems, P.stride, tx, row, cx, cy, rb );
-#pragma unroll
-    for( int i = 0; i < 4; i++ )
+    const Px4 f = load_px4( fenc0 + off + row * P.stride + tx );
+    const Px4 ra = qpel_px4( ref0_0 + off, P.plane_elems, P.stride, tx, row, ax, ay );
+    const Px4 rb = qpel_px4( ref1_0 + off, P.plane_elems, P.stride, tx, row, cx, cy );
+    Px4 pred;
+    if( bipred_weight == 32 )
+        pred = avg_px4( ra, rb, (const T *)nullptr );
+    else
     {
-        int v = bipred_weight == 32 ? ( ra[i] + rb[i] + 1 ) >> 1
-                                    : iclip3( ( ra[i] * bipred_weight + rb[i] * ( 64 - bipred_weight ) + 32 ) >> 6, 0, P.pixel_max );
-        d[i] = f[i] - v;
+        int va[4], vb[4];
+        px4_to_ints( ra, va ); px4_to_ints( rb, vb );
+#pragma unroll
+        for( int i = 0; i < 4; i++ )
+            va[i] = iclip3( ( va[i] * bipred_weight + vb[i] * ( 64 - bipred_weight ) + 32 ) >> 6, 0, P.pixel_max );
+        pred = px4_from_ints( va, sizeof( T ) == 1 );
     }
-    const int v = block_cost8x8( d, P.mbcmp_satd );
+    const int v = block_cost8x8<T>( f, pred, P.mbcmp_satd );
     int bcost = COST_MAX_I, list_used = 0;
     {
         int c = __builtin_amdgcn_readlane( v, 0 );
@@ -558,14 +560,10 @@ __global__ __launch_bounds__( 64 ) void pixel_cmp_batch_kernel( const T *__restr
     const int bxi = rx * bpr + px / size, byi = ry * bpr + py / size;
     const int bi = byi * bw + bxi;
     const int mvx = mv[2 * bi], mvy = mv[2 * bi + 1];
-    int f[4], r[4], d[4];
     const size_t o = (size_t)( ry * 16 + py ) * stride + rx * 16 + px;
-    load4( fenc + o, f );
-    load4( ref + o + mvy * stride + mvx, r );
-#pragma unroll
-    for( int i = 0; i < 4; i++ )
-        d[i] = f[i] - r[i];
-    int part = use_satd ? satd_tile_partial( d ) : iabs( d[0] ) + iabs( d[1] ) + iabs( d[2] ) + iabs( d[3] );
+    const Px4 f = load_px4( fenc + o );
+    const Px4 r = load_px4( ref + o + mvy * stride + mvx );
+    int part = use_satd ? satd_partial_px4( f, r ) : sad_partial_px4( f, r, (const T *)nullptr );
     part = reduce_quad( part );
     if( size == 4 )
     {

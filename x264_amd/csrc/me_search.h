@@ -14,7 +14,7 @@ struct MeBlk
 {
     const T *ref0;  // reference plane 0 at the block origin (unweighted; planes 1..3 follow)
     const T *refw;  // plane used by full-pel candidates: weighted plane 0 or ref0
-    int f[4];       // this lane's 4 source pixels
+    Px4 f;          // this lane's 4 source pixels
     int tx, row;    // this lane's position inside the 8x8 block
     int g;          // candidate group 0..3
     int mvpx, mvpy;
@@ -32,12 +32,8 @@ __device__ __forceinline__ int mv_bits( const LaP &P, const MeBlk<T> &B, int qx,
 template <typename T>
 __device__ __forceinline__ int fpel_cost( const LaP &P, const MeBlk<T> &B, int cx, int cy, int with_bits )
 {
-    int r[4], d[4];
-    load4( B.refw + ( cy + B.row ) * P.stride + cx + B.tx, r );
-#pragma unroll
-    for( int i = 0; i < 4; i++ )
-        d[i] = B.f[i] - r[i];
-    int c = block_cost8x8( d, P.fpelcmp_satd );
+    const Px4 r = load_px4( B.refw + ( cy + B.row ) * P.stride + cx + B.tx );
+    int c = block_cost8x8<T>( B.f, r, P.fpelcmp_satd );
     return with_bits ? c + mv_bits( P, B, 4 * cx, 4 * cy ) : c;
 }
 
@@ -45,18 +41,10 @@ __device__ __forceinline__ int fpel_cost( const LaP &P, const MeBlk<T> &B, int c
 template <typename T>
 __device__ __forceinline__ int qpel_cost( const LaP &P, const MeBlk<T> &B, const WtD &wt, int qx, int qy, int use_satd )
 {
-    int r[4], d[4];
-    qpel4( B.ref0, P.plane_elems, P.stride, B.tx, B.row, qx, qy, r );
+    Px4 r = qpel_px4( B.ref0, P.plane_elems, P.stride, B.tx, B.row, qx, qy );
     if( wt.on )
-    {
-#pragma unroll
-        for( int i = 0; i < 4; i++ )
-            r[i] = weight_px( r[i], wt, P.pixel_max );
-    }
-#pragma unroll
-    for( int i = 0; i < 4; i++ )
-        d[i] = B.f[i] - r[i];
-    return block_cost8x8( d, use_satd ) + mv_bits( P, B, qx, qy );
+        r = weight_px4<T>( r, wt, P.pixel_max );
+    return block_cost8x8<T>( B.f, r, use_satd ) + mv_bits( P, B, qx, qy );
 }
 
 #define GRP_COST( v, k ) __builtin_amdgcn_readlane( v, 16 * ( k ) )
@@ -460,19 +448,15 @@ __global__ __launch_bounds__( 64 ) void me_rows_kernel( LaP P, const SearchDesc<
         B.fmax_x = B.smax_x >> 2;
         B.ref0 = D.ref0 + off;
         B.refw = D.wt.on ? D.refw + off : B.ref0;
-        load4( D.fenc0 + off + B.row * P.stride + B.tx, B.f );
+        B.f = load_px4( D.fenc0 + off + B.row * P.stride + B.tx );
 
         int mvx = 0, mvy = 0, cost = 0;
         bool done = false;
         if( !( B.mvpx | B.mvpy ) )
         {
             // near-zero residual shortcut on the unweighted plane (slicetype.c:684-692)
-            int r[4], d[4];
-            load4( B.ref0 + B.row * P.stride + B.tx, r );
-#pragma unroll
-            for( int i = 0; i < 4; i++ )
-                d[i] = B.f[i] - r[i];
-            cost = GRP_COST( block_cost8x8( d, P.mbcmp_satd ), 0 );
+            const Px4 r = load_px4( B.ref0 + B.row * P.stride + B.tx );
+            cost = GRP_COST( block_cost8x8<T>( B.f, r, P.mbcmp_satd ), 0 );
             done = cost < 64;
         }
         if( !done )
