@@ -497,7 +497,7 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         ctx->prof_used += 2;
     }
     HIPCK( hipEventRecord( e0, ctx->stream ) );
-    me_rows_kernel<T><<<n * P.mb_h, 64, 0, ctx->stream>>>( P, (const SearchDesc<T> *)ctx->desc_dev, n, ctx->sync_words, 1u << 22 );
+    me_rows_kernel<T><<<n * ( ( P.mb_h + ME_WG_ROWS - 1 ) / ME_WG_ROWS ), 64 * ME_WG_ROWS, 0, ctx->stream>>>( P, (const SearchDesc<T> *)ctx->desc_dev, n, ctx->sync_words, 1u << 22 );
     HIPCK( hipEventRecord( e1, ctx->stream ) );
     HIPCK( hipGetLastError() );
     ctx->ev_valid = 1;
