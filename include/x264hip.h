@@ -72,6 +72,22 @@ typedef struct x264hip_cost
     int intra_cost_est, intra_cost_est_aq; /* the [0][0] cell; defined only when the call was made with with_intra != 0 */
 } x264hip_cost;
 
+/* MB-tree step list (encoder/slicetype.c:1051-1184): the host decides the order, the backend does the per-MB work */
+#define X264HIP_MBT_ZERO      0   /* memset( frames[slot_b]->i_propagate_cost, 0 ) */
+#define X264HIP_MBT_PROPAGATE 1   /* macroblock_tree_propagate( p0, p1, b, referenced ) */
+#define X264HIP_MBT_FINISH    2   /* macroblock_tree_finish( frames[slot_b] ) -> f_qp_offset */
+typedef struct x264hip_mbtree_op
+{
+    int type;
+    int slot_b, slot_p0, slot_p1;
+    int dist_p0, dist_p1;     /* b-p0, p1-b */
+    int referenced;
+    int bipred_weight;        /* list-0 weight; list 1 uses 64 - bipred_weight */
+    float fps_factor;         /* PROPAGATE: float factor (slicetype.c:1063) */
+    int fps_factor_i;         /* FINISH: integer factor (slicetype.c:1031) */
+    float weightdelta, strength;
+} x264hip_mbtree_op;
+
 /* ---- context ---------------------------------------------------------------------------------
  * Replaces x264_opencl_lookahead_init / _delete (encoder/encoder.c:1744-1753, 4208-4209,
  * common/opencl.c:411) as the device bring-up of the coarse lookahead hook. */
@@ -130,6 +146,13 @@ int  x264hip_geometry( x264hip_ctx *ctx, int *mb_w, int *mb_h, int *lowres_strid
  * calls pick the finished fields up instead of searching.  Never changes results. */
 int  x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *frame_numbers, int n );
 
+/* MB-tree: replaces mbtree_propagate_cost / mbtree_propagate_list of x264_mc_functions_t (common/mc.h:333-338,
+ * common/mc.c:511-598) and macroblock_tree_finish (encoder/slicetype.c:1029-1049) for a whole list of steps at once.
+ * Runs asynchronously on the context's second stream; x264hip_get_qp_offsets waits for it. */
+int  x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, int n );
+int  x264hip_get_qp_offsets( x264hip_ctx *ctx, int slot, float *qp_offset );        /* f_qp_offset, n_mb floats */
+int  x264hip_get_propagate_cost( x264hip_ctx *ctx, int slot, uint16_t *propagate ); /* i_propagate_cost, n_mb */
+
 /* ---- vtable-granular primitives, batched -------------------------------------------------------
  * Device counterparts of x264_pixel_function_t.sad/satd (common/pixel.h:78-84, pixel.c:55-80,265-332)
  * over a whole field of blocks: block i of size_idx (PIXEL_16x16=0, PIXEL_8x8=3, PIXEL_4x4=6) sits at
@@ -182,7 +205,11 @@ typedef struct x264hip_la_params
     int frame_refs;           /* param.i_frame_reference (B-pyramid compatibility rule, slicetype.c:1819) */
     int psy;                  /* param.analyse.b_psy (slicetype.c:1512) */
     int rc_is_cqp;            /* rc.i_rc_method == X264_RC_CQP: skips the final cost evaluation (slicetype.c:1899) */
+    int fps_num, fps_den;     /* constant frame rate (f_duration of every frame, slicetype.c:1767-1771); 0 -> 25/1 */
+    float qcompress;          /* param.rc.f_qcompress (MB-tree strength, slicetype.c:1038); 0 -> 0.6 */
 } x264hip_la_params;
+
+
 
 /* pluggable evaluation backend (same contracts as the x264hip_* device entry points) */
 typedef struct x264hip_backend
@@ -194,6 +221,8 @@ typedef struct x264hip_backend
     int (*frame_cost)( void *user, int slot_p0, int slot_p1, int slot_b, int dist_p0, int dist_p1, const int do_search[2],
                        const x264hip_weight *w, int with_intra, int ref1_l0_valid, x264hip_cost *out );
     int (*prefetch)( void *user, const int *slots, const int *frame_numbers, int n ); /* may be NULL */
+    int (*mbtree)( void *user, const x264hip_mbtree_op *ops, int n );                   /* may be NULL: no propagation */
+    int (*get_qp_offsets)( void *user, int slot, float *qp_offset );                    /* may be NULL */
 } x264hip_backend;
 
 typedef struct x264hip_la_frame
@@ -220,6 +249,9 @@ int  x264hip_lookahead_put_frame( x264hip_lookahead *la, const void *luma, int s
 /* One call = the lookahead part of one x264_encoder_encode call.  flush != 0 once the input has ended.
  * *got = 1 and *out filled when a frame leaves the lookahead (coded order), 0 while the delay fills or at the end. */
 int  x264hip_lookahead_get_frame( x264hip_lookahead *la, int flush, x264hip_la_frame *out, int *got );
+/* same, additionally copying the frame's f_qp_offset map (mb_w*mb_h floats, MB-tree output read by rate control,
+ * encoder/ratecontrol.c:1761) when qp_offset != NULL and mb_tree is on */
+int  x264hip_lookahead_get_frame_ex( x264hip_lookahead *la, int flush, x264hip_la_frame *out, int *got, float *qp_offset );
 /* statistics: [0] slicetype_frame_cost calls, [1] real evaluations, [2] weights analysed, [3] weights kept */
 int  x264hip_lookahead_stats( x264hip_lookahead *la, uint64_t *out, int n );
 

@@ -267,6 +267,12 @@ RH_API int rh_get_cell( rh_ctx *c, int idx, int d0, int d1, uint16_t *lowres_cos
  * ------------------------------------------------------------------------------------------ */
 #define RH_MAT ((X264_BFRAME_MAX+2)*(X264_BFRAME_MAX+2))
 
+static float *rh_out_qp = NULL; /* optional [n_frames][mb_count] dump of f_qp_offset at the moment a frame leaves the lookahead */
+
+static uint16_t *rh_out_prop = NULL; /* optional [n_frames][mb_count] dump of i_propagate_cost */
+RH_API void rh_set_qp_dump( float *buf ) { rh_out_qp = buf; }
+RH_API void rh_set_prop_dump( uint16_t *buf ) { rh_out_prop = buf; }
+
 static int rh_drain_one( x264_t *h, int *out_idx, int *out_type, int *out_cost, int *out_cost_aq, int *out_imbs, int n_out )
 {
     h->i_frame++;
@@ -280,6 +286,8 @@ static int rh_drain_one( x264_t *h, int *out_idx, int *out_type, int *out_cost, 
     if( out_cost )    memcpy( out_cost    + (size_t)n_out*RH_MAT, f->i_cost_est,    RH_MAT*sizeof(int) );
     if( out_cost_aq ) memcpy( out_cost_aq + (size_t)n_out*RH_MAT, f->i_cost_est_aq, RH_MAT*sizeof(int) );
     if( out_imbs )    memcpy( out_imbs + (size_t)n_out*(X264_BFRAME_MAX+2), f->i_intra_mbs, (X264_BFRAME_MAX+2)*sizeof(int) );
+    if( rh_out_qp )   memcpy( rh_out_qp + (size_t)n_out*h->mb.i_mb_count, f->f_qp_offset, h->mb.i_mb_count*sizeof(float) );
+    if( rh_out_prop ) memcpy( rh_out_prop + (size_t)n_out*h->mb.i_mb_count, f->i_propagate_cost, h->mb.i_mb_count*sizeof(uint16_t) );
     x264_frame_push_unused( h, f );
     return 0;
 }

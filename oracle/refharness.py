@@ -122,10 +122,16 @@ class Ref:
         assert r == 0
         return lc, rows, tuple(int(x) for x in summ)
 
-    def lookahead_run(self, luma_frames):
-        """luma_frames: [n, H, W]; returns dict(idx, type, cost, cost_aq, intra_mbs, seconds, seconds_prep)."""
+    def lookahead_run(self, luma_frames, with_qp_offsets=False):
+        """luma_frames: [n, H, W]; returns dict(idx, type, cost, cost_aq, intra_mbs, seconds, seconds_prep[, qp_offset])."""
         fr = np.ascontiguousarray(luma_frames, dtype=self.dtype)
         n = fr.shape[0]
+        qp = np.zeros((n, self.n_mb), np.float32) if with_qp_offsets else None
+        prop = np.zeros((n, self.n_mb), np.uint16) if with_qp_offsets else None
+        self.lib.rh_set_qp_dump.argtypes = [C.c_void_p]
+        self.lib.rh_set_prop_dump.argtypes = [C.c_void_p]
+        self.lib.rh_set_qp_dump(_ptr(qp))
+        self.lib.rh_set_prop_dump(_ptr(prop))
         idx = np.zeros(n, np.int32)
         typ = np.zeros(n, np.int32)
         cost = np.zeros((n, 18, 18), np.int32)
@@ -138,5 +144,11 @@ class Ref:
         r = f(self.ctx, _ptr(fr), n, 1, _ptr(idx), _ptr(typ), _ptr(cost), _ptr(cost_aq), _ptr(imbs),
               C.byref(sec), C.byref(sec_prep))
         assert r == n, (r, n)
-        return dict(idx=idx, type=typ, cost=cost, cost_aq=cost_aq, intra_mbs=imbs,
-                    seconds=sec.value, seconds_prep=sec_prep.value)
+        self.lib.rh_set_qp_dump(None)
+        self.lib.rh_set_prop_dump(None)
+        out = dict(idx=idx, type=typ, cost=cost, cost_aq=cost_aq, intra_mbs=imbs,
+                   seconds=sec.value, seconds_prep=sec_prep.value)
+        if qp is not None:
+            out["qp_offset"] = qp
+            out["propagate"] = prop
+        return out

@@ -1104,7 +1104,10 @@ void ORN(cell)( const or_la_cfg *c, const pixel *fenc0, const pixel *const ref0[
  * the reference (which is built with -ffast-math; tests pin the bits against it).
  * luma/cb/cr are the picture as handed in (not mod16): coordinates clamp like frame.c:640-666.
  * ---------------------------------------------------------------------------------------------- */
-static float lut_log2( uint32_t x ) /* common/base.h:225-229 + tables.c:66-90 */
+/* x264_log2( x ) - bias.  The reference is built with -ffast-math and gcc folds the subtraction into the
+ * integer-part term: lut[mantissa] + ( lz_lut[lz] - bias ).  That association is what its bits follow
+ * (verified against oracle/_ref: 99/99 macroblocks exact, any other association < 63/99). */
+static float lut_log2_minus( uint32_t x, float bias ) /* common/base.h:225-229 + tables.c:66-90 */
 {
     static float lut[128];
     static int init = 0;
@@ -1115,7 +1118,7 @@ static float lut_log2( uint32_t x ) /* common/base.h:225-229 + tables.c:66-90 */
         init = 1;
     }
     int lz = __builtin_clz( x );
-    return lut[( x << lz >> 24 ) & 0x7f] + (float)( 31 - lz );
+    return lut[( x << lz >> 24 ) & 0x7f] + ( (float)( 31 - lz ) - bias );
 }
 
 static int exp2fix8( float x ) /* common/base.h:217-223 + tables.c:58-64 */
@@ -1174,7 +1177,7 @@ uint64_t ORN(aq_frame)( const pixel *luma, int stride, int width, int height, in
             }
             if( aq_mode == 1 && aq_strength != 0.f )
             {
-                float qp_adj = strength * ( lut_log2( energy > 1 ? energy : 1 ) - ( 14.427f + 2*( OR_DEPTH - 8 ) ) );
+                float qp_adj = strength * lut_log2_minus( energy > 1 ? energy : 1, 14.427f + 2*( OR_DEPTH - 8 ) );
                 if( qp_offset ) qp_offset[my*mb_w+mx] = qp_adj;
                 inv_qscale[my*mb_w+mx] = (uint16_t)exp2fix8( qp_adj );
             }

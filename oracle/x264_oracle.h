@@ -88,6 +88,11 @@ OR_DECL( 8, uint8_t, int16_t, uint16_t )
 OR_DECL( 10, uint16_t, int32_t, uint32_t )
 
 /* depth independent */
+void or_mbtree_propagate( int mb_w, int mb_h, const uint16_t *intra_cost, const uint16_t *lowres_costs, const uint16_t *inv_qscale,
+                          const uint16_t *propagate_in, const int16_t (*mvs0)[2], const int16_t (*mvs1)[2],
+                          uint16_t *ref0_costs, uint16_t *ref1_costs, int bipred_weight, float fps_factor );
+void or_mbtree_finish( int n_mb, const uint16_t *intra_cost, const uint16_t *inv_qscale, const uint16_t *propagate_cost,
+                       const float *qp_offset_aq, float *qp_offset, int fps_factor, float weightdelta, float strength );
 void or_cost_mv_table( uint16_t *out_centre, int n, int lambda ); /* analyse.c:143-202 */
 int  or_lambda_for_depth( int bit_depth );
 

@@ -36,11 +36,14 @@ def gen_lookahead():
     for name, (preset, opts, over, depth, W, H, ckw, nf) in LOOKAHEAD_CASES.items():
         frames = make_clip(W, H, nf, bit_depth=depth, **ckw)
         r = refharness.Ref(W, H, preset, opts=opts, bit_depth=depth)
-        ref = r.lookahead_run(frames)
+        ref = r.lookahead_run(frames, with_qp_offsets=True)
         nb = r.cfg["bframes"] + 2
+        extra = {}
+        if W * H <= 352 * 288:  # MB-tree outputs (f_qp_offset, i_propagate_cost) of every frame as it leaves the lookahead
+            extra = dict(qp_offset=ref["qp_offset"], propagate=ref["propagate"])
         np.savez_compressed(os.path.join(OUT, "lookahead_%s.npz" % name), idx=ref["idx"], type=ref["type"].astype(np.int8),
                             cost=ref["cost"][:, :nb, :nb], cost_aq=ref["cost_aq"][:, :nb, :nb],
-                            cfg=np.array([r.cfg[k] for k in sorted(r.cfg)], np.int64), cfg_keys=np.array(sorted(r.cfg)))
+                            cfg=np.array([r.cfg[k] for k in sorted(r.cfg)], np.int64), cfg_keys=np.array(sorted(r.cfg)), **extra)
         r.close()
         print("lookahead", name, "types:", "".join("?IiPbB"[t] for t in ref["type"][:40]))
 
@@ -134,7 +137,8 @@ def gen_primitives():
 
 
 if __name__ == "__main__":
-    gen_tables()
-    gen_primitives()
-    gen_evalseq()
+    if "--lookahead-only" not in sys.argv:
+        gen_tables()
+        gen_primitives()
+        gen_evalseq()
     gen_lookahead()

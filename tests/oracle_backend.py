@@ -21,7 +21,8 @@ class OracleBackend:
         self.slots = {}
         self.n_eval = 0
         self.struct = lib.Backend(None, lib.FRAME_PUT_FN(self._put), lib.FRAME_STATS_FN(self._stats),
-                                  lib.WEIGHT_COST_FN(self._wcost), lib.FRAME_COST_FN(self._cost), lib.PREFETCH_FN(0))
+                                  lib.WEIGHT_COST_FN(self._wcost), lib.FRAME_COST_FN(self._cost), lib.PREFETCH_FN(0),
+                                  lib.MBTREE_FN(self._mbtree), lib.QP_OFFSETS_FN(self._qp))
 
     def _put(self, user, slot, luma, stride, is_device):
         c = self.cfg
@@ -29,8 +30,10 @@ class OracleBackend:
         buf = (C.c_char * (stride * c["height"] * np.dtype(dt).itemsize)).from_address(luma)
         img = np.frombuffer(buf, dtype=dt).reshape(c["height"], stride)[:, :c["width"]].copy()
         pl = self.o.lowres_init(self.ocfg, img)
-        inv, _, s, ssd = self.o.aq_frame(img, self.ocfg.mb_w, self.ocfg.mb_h, c["aq_mode"], c["aq_strength"])
-        self.slots[slot] = dict(planes=pl, inv=inv, sum=s, ssd=ssd, intra=self.o.intra_costs(self.ocfg, pl), fields={})
+        inv, qp, s, ssd = self.o.aq_frame(img, self.ocfg.mb_w, self.ocfg.mb_h, c["aq_mode"], c["aq_strength"])
+        n = self.ocfg.mb_w * self.ocfg.mb_h
+        self.slots[slot] = dict(planes=pl, inv=inv, sum=s, ssd=ssd, intra=self.o.intra_costs(self.ocfg, pl), fields={}, maps={},
+                                prop=np.zeros(n, np.uint16), qp_aq=qp.copy(), qp=qp.copy())
         return 0
 
     def _stats(self, user, slot, psum, pssd):
@@ -69,6 +72,38 @@ class OracleBackend:
             else:
                 lc, rows, rows_i, co = o.cell(cfg, B["planes"], F0["planes"], None, dsf, m0, c0, None, None, None, B["intra"],
                                               B["inv"], bool(with_intra))
+        B["maps"][(d0, d1)] = lc
         out[0].cost_est, out[0].cost_est_aq, out[0].intra_mbs = co.cost_est, co.cost_est_aq, co.intra_mbs
         out[0].intra_cost_est, out[0].intra_cost_est_aq = co.intra_cost_est, co.intra_cost_est_aq
+        return 0
+
+    def _mbtree(self, user, ops, n):
+        L = self.o.lib
+        cfg = self.ocfg
+        nmb = cfg.mb_w * cfg.mb_h
+        for k in range(n):
+            op = ops[k]
+            B = self.slots[op.slot_b]
+            if op.type == 0:
+                B["prop"][:] = 0
+            elif op.type == 1:
+                F0, F1 = self.slots[op.slot_p0], self.slots[op.slot_p1]
+                lc = B["maps"][(op.dist_p0, op.dist_p1)]
+                m0 = B["fields"][(0, op.dist_p0 - 1)][0]
+                m1 = B["fields"][(1, op.dist_p1 - 1)][0] if op.dist_p1 > 0 else None
+                pin = B["prop"].copy() if op.referenced else None
+                L.or_mbtree_propagate.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_float]
+                L.or_mbtree_propagate(cfg.mb_w, cfg.mb_h, B["intra"].ctypes.data, lc.ctypes.data, B["inv"].ctypes.data,
+                                      pin.ctypes.data if pin is not None else None, m0.ctypes.data,
+                                      m1.ctypes.data if m1 is not None else None, F0["prop"].ctypes.data,
+                                      F1["prop"].ctypes.data if m1 is not None else None, op.bipred_weight, op.fps_factor)
+            else:
+                L.or_mbtree_finish.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_float, C.c_float]
+                L.or_mbtree_finish(nmb, B["intra"].ctypes.data, B["inv"].ctypes.data, B["prop"].ctypes.data, B["qp_aq"].ctypes.data,
+                                   B["qp"].ctypes.data, op.fps_factor_i, op.weightdelta, op.strength)
+        return 0
+
+    def _qp(self, user, slot, dst):
+        q = self.slots[slot]["qp"]
+        C.memmove(dst, q.ctypes.data, q.nbytes)
         return 0

@@ -119,9 +119,14 @@ def test_oracle_eval_sequence_vs_golden(path):
         assert out.cost_est_aq == summ[1]
 
 
-def check_lookahead_outputs(outs, z, nb):
+def check_lookahead_outputs(outs, z, nb, check_qp=True):
     assert [o.frame for o in outs] == [int(v) for v in z["idx"]], "coded order differs"
     assert [o.type for o in outs] == [int(v) for v in z["type"]], "slice types differ"
+    if check_qp and "qp_offset" in z and hasattr(outs[0], "qp_offset"):
+        # MB-tree / AQ output read by rate control: FP32, same operation order as the reference build -> bit-exact
+        for k, o in enumerate(outs):
+            assert np.array_equal(o.qp_offset, z["qp_offset"][k]), ("f_qp_offset", k, o.frame, o.type,
+                                                                   float(np.abs(o.qp_offset - z["qp_offset"][k]).max()))
     for k, o in enumerate(outs):
         ce = np.array([[o.cost_est[i][j] for j in range(nb)] for i in range(nb)])
         ca = np.array([[o.cost_est_aq[i][j] for j in range(nb)] for i in range(nb)])
@@ -139,7 +144,7 @@ def test_host_lookahead_vs_golden(name):
     be = OracleBackend(cfg)
     la = lib.Lookahead(cfg, backend=be.struct)
     try:
-        outs = la.run(frames)
+        outs = la.run(frames, qp_offsets=True)
     finally:
         la.close()
     check_lookahead_outputs(outs, z, cfg["bframes"] + 2)

@@ -32,7 +32,7 @@ def test_lookahead_vs_golden(name, paced):
     cfg = lib.la_config(W, H, preset, bit_depth=depth, **over)
     la = lib.Lookahead(cfg, max_frames=0 if paced else nf + 4)
     try:
-        outs = la.run(frames, paced=paced)
+        outs = la.run(frames, paced=paced, qp_offsets=True)
         st = la.stats()
     finally:
         la.close()
@@ -49,17 +49,18 @@ def test_full_size_vs_reference(W, H, preset, opts, over, nf):
     frames = make_clip(W, H, nf, seed=21, scene_cuts=(nf // 2,), pan=(5, 3))
     r = refharness.Ref(W, H, preset, opts=opts)
     try:
-        ref = r.lookahead_run(frames)
+        ref = r.lookahead_run(frames, with_qp_offsets=True)
     finally:
         r.close()
     cfg = lib.la_config(W, H, preset, **over)
     la = lib.Lookahead(cfg)
     try:
-        outs = la.run(frames)
+        outs = la.run(frames, qp_offsets=True)
     finally:
         la.close()
     nb = cfg["bframes"] + 2
-    z = dict(idx=ref["idx"], type=ref["type"], cost=ref["cost"][:, :nb, :nb], cost_aq=ref["cost_aq"][:, :nb, :nb])
+    z = dict(idx=ref["idx"], type=ref["type"], cost=ref["cost"][:, :nb, :nb], cost_aq=ref["cost_aq"][:, :nb, :nb],
+             qp_offset=ref["qp_offset"])
     check_lookahead_outputs(outs, z, nb)
 
 

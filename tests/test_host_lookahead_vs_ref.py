@@ -34,7 +34,7 @@ def test_lookahead_matches_reference(preset, opts, over, depth, ckw, nf):
     frames = make_clip(W, H, nf, bit_depth=depth, **ckw)
     r = refharness.Ref(W, H, preset, opts=opts, bit_depth=depth)
     try:
-        ref = r.lookahead_run(frames)
+        ref = r.lookahead_run(frames, with_qp_offsets=True)
         rc = r.cfg
         cfg = lib.la_config(W, H, preset, bit_depth=depth, **over)
         # the derived configuration must be what the reference validated
@@ -48,7 +48,7 @@ def test_lookahead_matches_reference(preset, opts, over, depth, ckw, nf):
         la = lib.Lookahead(cfg, backend=be.struct)
         assert la.delay == rc["delay"]
         try:
-            outs = la.run(frames)
+            outs = la.run(frames, qp_offsets=True)
         finally:
             la.close()
     finally:
@@ -66,4 +66,5 @@ def test_lookahead_matches_reference(preset, opts, over, depth, ckw, nf):
         assert np.array_equal(ce, rce), ("i_cost_est", k, o.frame)
         m = rce >= 0
         assert np.array_equal(ca[m], ref["cost_aq"][k][:nb, :nb][m]), ("i_cost_est_aq", k, o.frame)
+        assert np.array_equal(o.qp_offset, ref["qp_offset"][k]), ("f_qp_offset", k, o.frame, o.type)
     assert be.n_eval > nf

@@ -107,7 +107,8 @@ template <typename T>
 __global__ __launch_bounds__( 64 ) void aq_kernel( const T *__restrict__ luma, int stride, int width, int height, int mb_w,
                                                    const T *__restrict__ cb, const T *__restrict__ cr, int cstride,
                                                    int aq_on, float strength, float log2_bias, const AqLuts *luts,
-                                                   uint16_t *inv_qscale, uint2 *mb_sums /* per MB: luma sum, sum of squares */ )
+                                                   uint16_t *inv_qscale, uint2 *mb_sums /* per MB: luma sum, sum of squares */,
+                                                   float *qp_offset_aq, float *qp_offset )
 {
     const int mx = blockIdx.x, my = blockIdx.y, lane = lane_id();
     const int ly = lane >> 2, lx = ( lane & 3 ) * 4;
@@ -137,16 +138,20 @@ __global__ __launch_bounds__( 64 ) void aq_kernel( const T *__restrict__ luma, i
     {
         mb_sums[my * mb_w + mx] = make_uint2( s, q );
         int out = 256;
+        float qp_adj = 0.f;
         if( aq_on )
         {
             unsigned e = energy > 1 ? energy : 1;
             int lz = __clz( e );
-            float l2 = __fadd_rn( luts->log2_lut[( e << lz >> 24 ) & 0x7f], (float)( 31 - lz ) );
-            float qp_adj = __fmul_rn( strength, __fsub_rn( l2, log2_bias ) );
+            // association of the reference build (gcc -ffast-math): lut[mantissa] + ( lz_part - bias )
+            float l2 = __fadd_rn( luts->log2_lut[( e << lz >> 24 ) & 0x7f], __fsub_rn( (float)( 31 - lz ), log2_bias ) );
+            qp_adj = __fmul_rn( strength, l2 );
             int i = (int)__fadd_rn( __fmul_rn( qp_adj, -64.f / 6.f ), 512.5f );
             out = i < 0 ? 0 : i > 1023 ? 0xffff : ( ( luts->exp2_lut[i & 63] + 256 ) << ( i >> 6 ) >> 8 );
         }
         inv_qscale[my * mb_w + mx] = (uint16_t)out;
+        qp_offset_aq[my * mb_w + mx] = qp_adj; // f_qp_offset_aq = f_qp_offset = qp_adj (ratecontrol.c:392-396)
+        qp_offset[my * mb_w + mx] = qp_adj;
     }
 }
 
@@ -640,4 +645,115 @@ __global__ __launch_bounds__( 64 ) void dct_quant_kernel( int is8, int n_blocks,
         coefs[(size_t)i * N * N + k] = c;
     }
     nz_out[i] = nz != 0;
+}
+
+
+// ---- MB-tree: common/mc.c:511-598, encoder/slicetype.c:1029-1089 -------------------------
+// The host hands over the ordered step list of one macroblock_tree() call; ONE workgroup walks it (steps depend on
+// each other through the propagate buffers, a frame at a time), 1024 threads over the macroblocks of a step.  It
+// runs on its own stream beside the search work and occupies a single CU.  Propagate buffers are 32-bit
+// accumulators: the reference's saturating uint16 adds (MC_CLIP_ADD) only ever add non-negative amounts, so
+// clamping the running sum when it is read gives the same value whatever the order of the atomic adds.
+struct MbtOpDev
+{
+    int type, referenced, bipred_weight, fps_factor_i, b_bidir, pad_;
+    float fps_factor, weightdelta, strength, padf_;
+    int *prop_b, *prop_p0, *prop_p1;
+    const uint16_t *intra_cost, *lowres_costs, *inv_qscale;
+    const unsigned long long *mvq0, *mvq1;
+    const float *qp_aq;
+    float *qp;
+};
+
+__device__ __forceinline__ int prop_read( const int *p )
+{
+    int v = __hip_atomic_load( p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ); // bypass this CU's L1
+    return v < 32767 ? v : 32767;
+}
+// x264_log2( a ) - x264_log2( b ) in the association of the reference build: ( ( lut[a] - int(b) ) + int(a) ) - lut[b]
+__device__ __forceinline__ float lut_log2_diff( const AqLuts *luts, unsigned a, unsigned b )
+{
+    const int lza = __clz( a ), lzb = __clz( b );
+    const float t = __fsub_rn( luts->log2_lut[( a << lza >> 24 ) & 0x7f], (float)( 31 - lzb ) );
+    return __fsub_rn( __fadd_rn( t, (float)( 31 - lza ) ), luts->log2_lut[( b << lzb >> 24 ) & 0x7f] );
+}
+
+__global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *ops, int n_ops, const AqLuts *luts )
+{
+    const int W = P.mb_w, H = P.mb_h, n_mb = W * H;
+    for( int k = 0; k < n_ops; k++ )
+    {
+        const MbtOpDev o = ops[k];
+        if( o.type == 0 )
+        {
+            for( int i = threadIdx.x; i < n_mb; i += blockDim.x )
+                __hip_atomic_store( &o.prop_b[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+        }
+        else if( o.type == 1 )
+        {
+            for( int i = threadIdx.x; i < n_mb; i += blockDim.x )
+            {
+                const int mx = i % W, my = i / W;
+                const int ic = o.intra_cost[i];
+                const int lc = o.lowres_costs[i];
+                int inter = lc & 0x3FFF;
+                if( inter > ic ) inter = ic;
+                const float propagate_intra = (float)( ic * (int)o.inv_qscale[i] );
+                const float in = o.referenced ? (float)prop_read( &o.prop_b[i] ) : 0.f;
+                const float propagate_amount = __fadd_rn( in, __fmul_rn( propagate_intra, o.fps_factor ) );
+                const float num = (float)( ic - inter ), den = (float)ic;
+                int amount = (int)__fadd_rn( __fdiv_rn( __fmul_rn( propagate_amount, num ), den ), 0.5f );
+                if( amount > 32767 ) amount = 32767;
+                const int lists_used = lc >> 14;
+#pragma unroll
+                for( int list = 0; list < 2; list++ )
+                {
+                    if( list && !o.b_bidir ) break;
+                    if( !( lists_used & ( 1 << list ) ) ) continue;
+                    int *ref = list ? o.prop_p1 : o.prop_p0;
+                    int la = amount;
+                    if( lists_used == 3 )
+                        la = ( la * ( list ? 64 - o.bipred_weight : o.bipred_weight ) + 32 ) >> 6;
+                    const unsigned w = (unsigned)( list ? o.mvq1[i] : o.mvq0[i] );
+                    int x = (int)(short)( w & 0xFFFF ), y = (int)w >> 16;
+                    if( !( x | y ) )
+                    {
+                        atomicAdd( &ref[i], la );
+                        continue;
+                    }
+                    const unsigned mbx = (unsigned)( ( x >> 5 ) + mx ), mby = (unsigned)( ( y >> 5 ) + my );
+                    const unsigned idx0 = mbx + mby * W, idx2 = idx0 + W;
+                    x &= 31; y &= 31;
+                    const int w0 = ( ( 32 - y ) * ( 32 - x ) * la + 512 ) >> 10, w1 = ( ( 32 - y ) * x * la + 512 ) >> 10;
+                    const int w2 = ( y * ( 32 - x ) * la + 512 ) >> 10, w3 = ( y * x * la + 512 ) >> 10;
+                    if( mby < (unsigned)H )
+                    {
+                        if( mbx < (unsigned)W ) atomicAdd( &ref[idx0], w0 );
+                        if( mbx + 1 < (unsigned)W ) atomicAdd( &ref[idx0 + 1], w1 );
+                    }
+                    if( mby + 1 < (unsigned)H )
+                    {
+                        if( mbx < (unsigned)W ) atomicAdd( &ref[idx2], w2 );
+                        if( mbx + 1 < (unsigned)W ) atomicAdd( &ref[idx2 + 1], w3 );
+                    }
+                }
+            }
+        }
+        else
+        {
+            for( int i = threadIdx.x; i < n_mb; i += blockDim.x )
+            {
+                const int ic = ( (int)o.intra_cost[i] * (int)o.inv_qscale[i] + 128 ) >> 8;
+                if( ic )
+                {
+                    const int pc = ( prop_read( &o.prop_b[i] ) * o.fps_factor_i + 128 ) >> 8;
+                    const float ratio = __fadd_rn( lut_log2_diff( luts, (unsigned)( ic + pc ), (unsigned)ic ), o.weightdelta );
+                    o.qp[i] = __fsub_rn( o.qp_aq[i], __fmul_rn( o.strength, ratio ) );
+                }
+            }
+        }
+        // every step's stores and atomics have been acknowledged by L2 before the next step reads them
+        __builtin_amdgcn_s_waitcnt( 0 );
+        __syncthreads();
+    }
 }

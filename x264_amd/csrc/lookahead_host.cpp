@@ -42,6 +42,7 @@ struct LaFrame
     x264hip_weight weight = { 0, 1, 0, 0 };
     uint64_t pixel_sum = 0, pixel_ssd = 0;
     bool stats_valid = false;
+    float weighted_cost_delta[BMAX + 2]; // f_weighted_cost_delta, frame.c:798
 };
 
 static int ue_size( unsigned v ) // bs_size_ue, common/bitstream.h:278 (2*floor(log2(v+1))+1)
@@ -71,6 +72,8 @@ struct Lookahead
     LaFrame *last_nonb = nullptr;
     std::vector<int> free_slots;
     std::vector<LaFrame *> pending_prefetch;
+    float f_duration = 0.04f;   // every frame's f_duration (constant frame rate)
+    float qcompress = 0.6f;
     uint64_t stats[8] = { 0 };
     int err = 0;
 
@@ -226,6 +229,8 @@ struct Lookahead
         }
         wt.on = 1; wt.scale = minscale; wt.denom = mindenom; wt.offset = minoff;
         stats[3]++;
+        if( p.weightp < 0 ) // X264_WEIGHTP_FAKE (:462-463)
+            fenc->weighted_cost_delta[fenc->i_frame - ref->i_frame - 1] = (float)minscore / origscore;
     }
 
     // ---- slicetype_path_cost (:1288-1327) ----------------------------------------------------------
@@ -341,51 +346,111 @@ struct Lookahead
         return scenecut_internal( frames, p0, p1 );
     }
 
-    // ---- macroblock_tree (:1091-1184): the evaluation order only.  The propagation arithmetic
-    // (mbtree_propagate_cost/list, float) does not influence slice types or cost cells and is the next
-    // row of SURVEY 8(f); the calls below are what keeps memoisation / first-trigger state identical.
+    // ---- macroblock_tree (:1091-1184).  The frame-cost evaluations keep memoisation / first-trigger state
+    // identical to the reference; the propagation itself (mbtree_propagate_cost/list, macroblock_tree_finish) is
+    // recorded as a step list and handed to the backend in one call (it never feeds back into the decisions).
+    static double clip_duration( double f ) { return f < 0.01 ? 0.01 : f > 1.0 ? 1.0 : f; } // CLIP_DURATION, ratecontrol.h:34-40
+
+    void mbt_zero( std::vector<x264hip_mbtree_op> &ops, LaFrame *f )
+    {
+        x264hip_mbtree_op o;
+        memset( &o, 0, sizeof( o ) );
+        o.type = X264HIP_MBT_ZERO; o.slot_b = o.slot_p0 = o.slot_p1 = f->slot;
+        ops.push_back( o );
+    }
+    void mbt_propagate( std::vector<x264hip_mbtree_op> &ops, LaFrame **frames, float average_duration, int p0, int p1, int b, int referenced )
+    {
+        x264hip_mbtree_op o;
+        memset( &o, 0, sizeof( o ) );
+        o.type = X264HIP_MBT_PROPAGATE;
+        o.slot_b = frames[b]->slot; o.slot_p0 = frames[p0]->slot; o.slot_p1 = frames[p1]->slot;
+        o.dist_p0 = b - p0; o.dist_p1 = p1 - b; o.referenced = referenced;
+        int dsf = ( ( ( b - p0 ) << 8 ) + ( ( p1 - p0 ) >> 1 ) ) / ( p1 - p0 );
+        o.bipred_weight = p.dev.weighted_bipred ? 64 - ( dsf >> 2 ) : 32;
+        o.fps_factor = (float)( clip_duration( f_duration ) / ( clip_duration( average_duration ) * 256.0f ) * 0.5f );
+        ops.push_back( o );
+    }
+    void mbt_finish( std::vector<x264hip_mbtree_op> &ops, LaFrame *f, float average_duration, int ref0_distance )
+    {
+        x264hip_mbtree_op o;
+        memset( &o, 0, sizeof( o ) );
+        o.type = X264HIP_MBT_FINISH; o.slot_b = o.slot_p0 = o.slot_p1 = f->slot;
+        o.fps_factor_i = (int)round( clip_duration( average_duration ) / clip_duration( f_duration ) * 256 / 0.5f );
+        float weightdelta = 0.0;
+        if( ref0_distance && f->weighted_cost_delta[ref0_distance - 1] > 0 )
+            weightdelta = ( 1.0 - f->weighted_cost_delta[ref0_distance - 1] );
+        o.weightdelta = weightdelta;
+        o.strength = 5.0f * ( 1.0f - qcompress );
+        ops.push_back( o );
+    }
+
     void macroblock_tree( LaFrame **frames, int num_frames, int b_intra )
     {
         int idx = !b_intra, last_nonb, cur_nonb = 1, bframes = 0;
+        std::vector<x264hip_mbtree_op> ops;
+        float total_duration = 0.0;
+        for( int j = 0; j <= num_frames; j++ )
+            total_duration += f_duration;
+        float average_duration = total_duration / ( num_frames + 1 );
         int i = num_frames;
         if( b_intra ) frame_cost( frames, 0, 0, 0 );
         while( i > 0 && is_b( frames[i]->i_type ) ) i--;
         last_nonb = i;
         if( !p.rc_lookahead )
         {
-            if( b_intra ) return;
+            if( b_intra ) return; // lookahead-less MB-tree needs rc state that lives in the encoder; not mirrored
         }
-        else if( last_nonb < idx )
-            return;
+        else
+        {
+            if( last_nonb < idx ) return;
+            mbt_zero( ops, frames[last_nonb] );
+        }
         while( i-- > idx )
         {
             cur_nonb = i;
             while( is_b( frames[cur_nonb]->i_type ) && cur_nonb > 0 ) cur_nonb--;
             if( cur_nonb < idx ) break;
             frame_cost( frames, cur_nonb, last_nonb, last_nonb );
+            mbt_zero( ops, frames[cur_nonb] );
             bframes = last_nonb - cur_nonb - 1;
             if( p.b_pyramid && bframes > 1 )
             {
                 int middle = ( bframes + 1 ) / 2 + cur_nonb;
                 frame_cost( frames, cur_nonb, last_nonb, middle );
+                mbt_zero( ops, frames[middle] );
                 while( i > cur_nonb )
                 {
                     int q0 = i > middle ? middle : cur_nonb;
                     int q1 = i < middle ? middle : last_nonb;
-                    if( i != middle ) frame_cost( frames, q0, q1, i );
+                    if( i != middle )
+                    {
+                        frame_cost( frames, q0, q1, i );
+                        mbt_propagate( ops, frames, average_duration, q0, q1, i, 0 );
+                    }
                     i--;
                 }
+                mbt_propagate( ops, frames, average_duration, cur_nonb, last_nonb, middle, 1 );
             }
             else
                 while( i > cur_nonb )
                 {
                     frame_cost( frames, cur_nonb, last_nonb, i );
+                    mbt_propagate( ops, frames, average_duration, cur_nonb, last_nonb, i, 0 );
                     i--;
                 }
+            mbt_propagate( ops, frames, average_duration, cur_nonb, last_nonb, last_nonb, 1 );
             last_nonb = cur_nonb;
         }
         if( !p.rc_lookahead )
             frame_cost( frames, 0, last_nonb, last_nonb );
+        else
+        {
+            mbt_finish( ops, frames[last_nonb], average_duration, last_nonb );
+            if( p.b_pyramid && bframes > 1 )
+                mbt_finish( ops, frames[last_nonb + ( bframes + 1 ) / 2], average_duration, 0 );
+        }
+        if( be.mbtree && !ops.empty() && !err )
+            need( be.mbtree( be.user, ops.data(), (int)ops.size() ) );
     }
 
     // ---- x264_slicetype_analyse (:1473-1743) -------------------------------------------------------
@@ -693,6 +758,8 @@ static int dev_frame_cost( void *u, int p0, int p1, int b, int d0, int d1, const
     return x264hip_frame_cost( (x264hip_ctx *)u, p0, p1, b, d0, d1, ds, w, wi, rv, o );
 }
 static int dev_prefetch( void *u, const int *s, const int *n, int c ) { return x264hip_prefetch( (x264hip_ctx *)u, s, n, c ); }
+static int dev_mbtree( void *u, const x264hip_mbtree_op *ops, int n ) { return x264hip_mbtree( (x264hip_ctx *)u, ops, n ); }
+static int dev_qp_offsets( void *u, int slot, float *q ) { return x264hip_get_qp_offsets( (x264hip_ctx *)u, slot, q ); }
 
 } // namespace
 
@@ -718,6 +785,12 @@ static int la_init( x264hip_lookahead *la, const x264hip_la_params *params )
         L.i_delay = L.i_delay > p.rc_lookahead ? L.i_delay : p.rc_lookahead;
     L.slicetype_length = L.i_delay;
     L.b_analyse_keyframe = p.mb_tree; // lookahead.c:140-141 (no VBV, no stats read)
+    {
+        // slicetype.c:1767-1771: i_duration = 2 field units for a progressive frame, time base 1/(2*fps)
+        const int fn = p.fps_num > 0 ? p.fps_num : 25, fd = p.fps_den > 0 ? p.fps_den : 1;
+        L.f_duration = (float)( (double)2 * fd / ( 2.0 * fn ) );
+        L.qcompress = p.qcompress > 0 ? p.qcompress : 0.6f;
+    }
     L.i_last_keyframe = -p.keyint_max;
     return X264HIP_OK;
 }
@@ -751,7 +824,7 @@ extern "C" int x264hip_lookahead_open( x264hip_lookahead **out, int device, cons
     x264hip_ctx *ctx = nullptr;
     int rc = x264hip_open( &ctx, device, &p.dev );
     if( rc ) return rc;
-    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch };
+    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch, dev_mbtree, dev_qp_offsets };
     rc = x264hip_lookahead_open_backend( out, &p, &be );
     if( rc ) { x264hip_close( ctx ); return rc; }
     ( *out )->L.ctx = ctx;
@@ -803,6 +876,7 @@ extern "C" int x264hip_lookahead_put_frame( x264hip_lookahead *la, const void *l
     memset( f->cost_est_aq, 0, sizeof( f->cost_est_aq ) );
     memset( f->intra_mbs, 0, sizeof( f->intra_mbs ) );
     memset( f->searched, 0, sizeof( f->searched ) );       // mc.c:479-481
+    memset( f->weighted_cost_delta, 0, sizeof( f->weighted_cost_delta ) );
     int rc = L.be.frame_put( L.be.user, f->slot, luma, stride, is_device );
     if( rc )
     {
@@ -816,6 +890,11 @@ extern "C" int x264hip_lookahead_put_frame( x264hip_lookahead *la, const void *l
 }
 
 extern "C" int x264hip_lookahead_get_frame( x264hip_lookahead *la, int flush, x264hip_la_frame *out, int *got )
+{
+    return x264hip_lookahead_get_frame_ex( la, flush, out, got, nullptr );
+}
+
+extern "C" int x264hip_lookahead_get_frame_ex( x264hip_lookahead *la, int flush, x264hip_la_frame *out, int *got, float *qp_offset )
 {
     if( !la || !out || !got ) return X264HIP_EINVAL;
     Lookahead &L = la->L;
@@ -843,6 +922,9 @@ extern "C" int x264hip_lookahead_get_frame( x264hip_lookahead *la, int flush, x2
         out->intra_mbs[i] = f->intra_mbs[i];
     }
     *got = 1;
+    if( qp_offset && L.be.get_qp_offsets && L.p.mb_tree )
+        if( L.need( L.be.get_qp_offsets( L.be.user, f->slot, qp_offset ) ) )
+            return L.err;
     L.release( f );
     return X264HIP_OK;
 }

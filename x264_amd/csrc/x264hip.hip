@@ -54,6 +54,8 @@ struct FrameSlot
     uint16_t *lowres_costs = nullptr; // [(bf+2)*(bf+2)][n_mb]
     int *row_satds = nullptr;         // [(bf+2)*(bf+2)][mb_h]
     int *blk = nullptr;               // [(bf+2)*(bf+2)][n_mb] unclamped block cost | b_intra << 30 per cell
+    int *prop = nullptr;              // [n_mb] MB-tree i_propagate_cost accumulator
+    float *qp_aq = nullptr, *qp = nullptr; // [n_mb] f_qp_offset_aq, f_qp_offset
     unsigned field_tag[2][X264HIP_BFRAME_MAX + 1]; // serial of the search that last wrote the field
     std::vector<CellEntry> cells;
     // host-side state of the device fields
@@ -87,6 +89,13 @@ struct x264hip_ctx
     int cell_desc_cap = 0;
     unsigned batch_serial = 0, batch_synced = 0;
     unsigned long long *stats_host = nullptr; // pinned [slots][2]
+    // MB-tree: own stream, ring of pinned/device step tables
+    hipStream_t stream2 = nullptr;
+    static const int MBT_RING = 8, MBT_CAP = 1024;
+    MbtOpDev *mbt_host[8] = { nullptr }, *mbt_dev[8] = { nullptr };
+    hipEvent_t mbt_done[8] = { nullptr };
+    hipEvent_t ev_cross = nullptr, ev_mbt_last = nullptr;
+    int mbt_next = 0, mbt_pending = 0;
     int *acc_host = nullptr;         // pinned [8]
     unsigned *sync_host = nullptr;   // pinned [2]
     void *desc_dev = nullptr;        // SearchDesc array
@@ -133,6 +142,15 @@ static void free_all( x264hip_ctx *ctx )
     for( auto w : ctx->wplanes ) (void)hipFree( w );
     (void)hipFree( ctx->cost_mv_dev ); (void)hipFree( ctx->luts_dev ); (void)hipFree( ctx->sync_words ); (void)hipFree( ctx->acc_dev ); (void)hipFree( ctx->cell_acc_dev ); (void)hipFree( ctx->cell_desc_dev );
     (void)hipHostFree( ctx->stats_host );
+    if( ctx->stream2 ) (void)hipStreamSynchronize( ctx->stream2 );
+    for( int i = 0; i < x264hip_ctx::MBT_RING; i++ )
+    {
+        (void)hipHostFree( ctx->mbt_host[i] ); (void)hipFree( ctx->mbt_dev[i] );
+        if( ctx->mbt_done[i] ) (void)hipEventDestroy( ctx->mbt_done[i] );
+    }
+    if( ctx->ev_cross ) (void)hipEventDestroy( ctx->ev_cross );
+    if( ctx->ev_mbt_last ) (void)hipEventDestroy( ctx->ev_mbt_last );
+    if( ctx->stream2 ) (void)hipStreamDestroy( ctx->stream2 );
     (void)hipHostFree( ctx->cell_acc_host ); (void)hipHostFree( ctx->cell_desc_host );
     (void)hipFree( ctx->desc_dev ); (void)hipFree( ctx->wcost_dev );
     (void)hipHostFree( ctx->acc_host ); (void)hipHostFree( ctx->sync_host ); (void)hipHostFree( ctx->desc_host );
@@ -210,6 +228,15 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( hipMemset( ctx->cell_acc_dev, 0, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
     OPENCK( hipHostMalloc( &ctx->cell_acc_host, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
     OPENCK( hipHostMalloc( &ctx->stats_host, (size_t)p.max_frames * 2 * sizeof( unsigned long long ) ) );
+    OPENCK( hipStreamCreateWithFlags( &ctx->stream2, hipStreamNonBlocking ) );
+    OPENCK( hipEventCreateWithFlags( &ctx->ev_cross, hipEventDisableTiming ) );
+    OPENCK( hipEventCreateWithFlags( &ctx->ev_mbt_last, hipEventDisableTiming ) );
+    for( int i = 0; i < x264hip_ctx::MBT_RING; i++ )
+    {
+        OPENCK( hipHostMalloc( &ctx->mbt_host[i], x264hip_ctx::MBT_CAP * sizeof( MbtOpDev ) ) );
+        OPENCK( hipMalloc( &ctx->mbt_dev[i], x264hip_ctx::MBT_CAP * sizeof( MbtOpDev ) ) );
+        OPENCK( hipEventCreateWithFlags( &ctx->mbt_done[i], hipEventDisableTiming ) );
+    }
     ctx->cell_desc_cap = 4096;
     OPENCK( hipMalloc( &ctx->cell_desc_dev, (size_t)ctx->cell_desc_cap * sizeof( CellArgs ) ) );
     OPENCK( hipHostMalloc( &ctx->cell_desc_host, (size_t)ctx->cell_desc_cap * sizeof( CellArgs ) ) );
@@ -238,6 +265,9 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         const size_t o_lc = off; off += align_up( (size_t)nc * ctx->n_mb * sizeof( uint16_t ), 256 );
         const size_t o_rows = off; off += align_up( (size_t)nc * mb_h * sizeof( int ), 256 );
         const size_t o_blk = off; off += align_up( (size_t)nc * ctx->n_mb * sizeof( int ), 256 );
+        const size_t o_prop = off; off += align_up( (size_t)ctx->n_mb * sizeof( int ), 256 );
+        const size_t o_qpa = off; off += align_up( (size_t)ctx->n_mb * sizeof( float ), 256 );
+        const size_t o_qp = off; off += align_up( (size_t)ctx->n_mb * sizeof( float ), 256 );
         char *base = nullptr;
         OPENCK( hipMalloc( &base, off ) );
         OPENCK( hipMemset( base, 0, off ) );
@@ -253,6 +283,7 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         s.lowres_costs = (uint16_t *)( base + o_lc );
         s.row_satds = (int *)( base + o_rows );
         s.blk = (int *)( base + o_blk );
+        s.prop = (int *)( base + o_prop ); s.qp_aq = (float *)( base + o_qpa ); s.qp = (float *)( base + o_qp );
         s.cells.assign( nc, CellEntry() );
         memset( s.field_tag, 0, sizeof( s.field_tag ) );
         memset( s.field_ready, 0, sizeof( s.field_ready ) );
@@ -323,7 +354,7 @@ static int frame_put_t( x264hip_ctx *ctx, FrameSlot &s, const void *luma, int st
         // chroma planes take part in the AQ energy only when the caller supplies device pointers for them
         aq_kernel<T><<<dim3( P.mb_w, P.mb_h ), 64, 0, ctx->stream>>>( src, src_stride, p.width, p.height, P.mb_w,
                                                                       is_device ? (const T *)cb : nullptr, is_device ? (const T *)cr : nullptr, cstride,
-                                                                      aq_on, strength, bias, ctx->luts_dev, s.inv_qscale, s.mb_sums );
+                                                                      aq_on, strength, bias, ctx->luts_dev, s.inv_qscale, s.mb_sums, s.qp_aq, s.qp );
         aq_reduce_kernel<<<1, 1024, 0, ctx->stream>>>( s.mb_sums, ctx->n_mb, s.frame_sums );
     }
     if( inv_qscale )
@@ -339,6 +370,8 @@ extern "C" int x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, 
     if( !ctx || !slot_ok( ctx, slot ) || !luma || stride < ctx->p.width ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
     FrameSlot &s = ctx->slots[slot];
+    if( ctx->mbt_pending )
+        HIPCK( hipStreamWaitEvent( ctx->stream, ctx->ev_mbt_last, 0 ) ); // MB-tree steps may still read this slot's maps
     s.in_use = 1;
     s.stats_valid = 0;
     memset( s.field_ready, 0, sizeof( s.field_ready ) );
@@ -775,6 +808,76 @@ extern "C" int x264hip_frame_cost( x264hip_ctx *ctx, int slot_p0, int slot_p1, i
     return ctx->p.bit_depth == 8
                ? frame_cost_t<uint8_t>( ctx, slot_p0, slot_p1, slot_b, dist_p0, dist_p1, do_search, w, with_intra, ref1_l0_valid, out )
                : frame_cost_t<uint16_t>( ctx, slot_p0, slot_p1, slot_b, dist_p0, dist_p1, do_search, w, with_intra, ref1_l0_valid, out );
+}
+
+// ---- MB-tree ----------------------------------------------------------------------------------------------
+extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, int n )
+{
+    if( !ctx || !ops || n <= 0 || n > x264hip_ctx::MBT_CAP ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    const int nstride = ctx->p.bframes + 2;
+    const int r = ctx->mbt_next;
+    ctx->mbt_next = ( r + 1 ) % x264hip_ctx::MBT_RING;
+    if( ctx->mbt_pending >= x264hip_ctx::MBT_RING )
+        HIPCK( hipEventSynchronize( ctx->mbt_done[r] ) ); // the table we are about to rewrite has been consumed
+    MbtOpDev *dh = ctx->mbt_host[r];
+    for( int i = 0; i < n; i++ )
+    {
+        const x264hip_mbtree_op &o = ops[i];
+        if( !slot_ok( ctx, o.slot_b ) || !slot_ok( ctx, o.slot_p0 ) || !slot_ok( ctx, o.slot_p1 ) || o.dist_p0 < 0 || o.dist_p1 < 0 ||
+            o.dist_p0 + o.dist_p1 > ctx->p.bframes + 1 )
+            return X264HIP_EINVAL;
+        FrameSlot &b = ctx->slots[o.slot_b], &f0 = ctx->slots[o.slot_p0], &f1 = ctx->slots[o.slot_p1];
+        MbtOpDev d;
+        memset( &d, 0, sizeof( d ) );
+        d.type = o.type; d.referenced = o.referenced; d.bipred_weight = o.bipred_weight; d.fps_factor_i = o.fps_factor_i;
+        d.fps_factor = o.fps_factor; d.weightdelta = o.weightdelta; d.strength = o.strength;
+        d.b_bidir = o.dist_p1 > 0;
+        d.prop_b = b.prop; d.prop_p0 = f0.prop; d.prop_p1 = f1.prop;
+        d.intra_cost = b.lowres_costs; d.inv_qscale = b.inv_qscale;
+        d.lowres_costs = b.lowres_costs + (size_t)( o.dist_p0 * nstride + o.dist_p1 ) * ctx->n_mb;
+        if( o.type == X264HIP_MBT_PROPAGATE )
+        {
+            if( o.dist_p0 < 1 ) return X264HIP_EINVAL;
+            d.mvq0 = b.mvq[0][o.dist_p0 - 1];
+            d.mvq1 = o.dist_p1 > 0 ? b.mvq[1][o.dist_p1 - 1] : nullptr;
+        }
+        d.qp_aq = b.qp_aq; d.qp = b.qp;
+        dh[i] = d;
+    }
+    // inputs come from the main stream (cells, clamp kernels): order the MB-tree stream behind it
+    HIPCK( hipEventRecord( ctx->ev_cross, ctx->stream ) );
+    HIPCK( hipStreamWaitEvent( ctx->stream2, ctx->ev_cross, 0 ) );
+    HIPCK( hipMemcpyAsync( ctx->mbt_dev[r], dh, (size_t)n * sizeof( MbtOpDev ), hipMemcpyHostToDevice, ctx->stream2 ) );
+    mbtree_kernel<<<1, 1024, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], n, ctx->luts_dev );
+    HIPCK( hipGetLastError() );
+    HIPCK( hipEventRecord( ctx->mbt_done[r], ctx->stream2 ) );
+    HIPCK( hipEventRecord( ctx->ev_mbt_last, ctx->stream2 ) );
+    ctx->mbt_pending++;
+    ctx->counters[6]++;
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_get_qp_offsets( x264hip_ctx *ctx, int slot, float *qp_offset )
+{
+    if( !ctx || !slot_ok( ctx, slot ) || !qp_offset ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    HIPCK( hipStreamSynchronize( ctx->stream ) );
+    HIPCK( hipMemcpyAsync( qp_offset, ctx->slots[slot].qp, ctx->n_mb * sizeof( float ), hipMemcpyDeviceToHost, ctx->stream2 ) );
+    HIPCK( hipStreamSynchronize( ctx->stream2 ) );
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_get_propagate_cost( x264hip_ctx *ctx, int slot, uint16_t *propagate )
+{
+    if( !ctx || !slot_ok( ctx, slot ) || !propagate ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    std::vector<int> tmp( ctx->n_mb );
+    HIPCK( hipMemcpyAsync( tmp.data(), ctx->slots[slot].prop, ctx->n_mb * sizeof( int ), hipMemcpyDeviceToHost, ctx->stream2 ) );
+    HIPCK( hipStreamSynchronize( ctx->stream2 ) );
+    for( int i = 0; i < ctx->n_mb; i++ )
+        propagate[i] = (uint16_t)( tmp[i] < 32767 ? tmp[i] : 32767 );
+    return X264HIP_OK;
 }
 
 extern "C" int x264hip_weight_cost( x264hip_ctx *ctx, int slot_fenc, int slot_ref, const x264hip_weight *w, unsigned *cost )

@@ -208,7 +208,13 @@ class LaParams(C.Structure):
     _fields_ = [("dev", Params), ("keyint_max", C.c_int), ("keyint_min", C.c_int), ("scenecut_threshold", C.c_int),
                 ("b_adapt", C.c_int), ("b_pyramid", C.c_int), ("rc_lookahead", C.c_int), ("mb_tree", C.c_int),
                 ("weightp", C.c_int), ("open_gop", C.c_int), ("frame_refs", C.c_int), ("psy", C.c_int),
-                ("rc_is_cqp", C.c_int)]
+                ("rc_is_cqp", C.c_int), ("fps_num", C.c_int), ("fps_den", C.c_int), ("qcompress", C.c_float)]
+
+
+class MbtreeOp(C.Structure):
+    _fields_ = [("type", C.c_int), ("slot_b", C.c_int), ("slot_p0", C.c_int), ("slot_p1", C.c_int), ("dist_p0", C.c_int),
+                ("dist_p1", C.c_int), ("referenced", C.c_int), ("bipred_weight", C.c_int), ("fps_factor", C.c_float),
+                ("fps_factor_i", C.c_int), ("weightdelta", C.c_float), ("strength", C.c_float)]
 
 
 FRAME_PUT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int)
@@ -217,11 +223,14 @@ WEIGHT_COST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(We
 FRAME_COST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                             C.POINTER(Weight), C.c_int, C.c_int, C.POINTER(Cost))
 PREFETCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int)
+MBTREE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(MbtreeOp), C.c_int)
+QP_OFFSETS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float))
 
 
 class Backend(C.Structure):
     _fields_ = [("user", C.c_void_p), ("frame_put", FRAME_PUT_FN), ("frame_stats", FRAME_STATS_FN),
-                ("weight_cost", WEIGHT_COST_FN), ("frame_cost", FRAME_COST_FN), ("prefetch", PREFETCH_FN)]
+                ("weight_cost", WEIGHT_COST_FN), ("frame_cost", FRAME_COST_FN), ("prefetch", PREFETCH_FN),
+                ("mbtree", MBTREE_FN), ("get_qp_offsets", QP_OFFSETS_FN)]
 
 
 class LaFrameOut(C.Structure):
@@ -264,7 +273,8 @@ def la_config(width, height, preset="medium", bit_depth=8, **over):
     lowres_context_init derive it (encoder/encoder.c:423-1407, encoder/slicetype.c:45-61)."""
     c = dict(bframes=3, b_adapt=1, b_pyramid=2, rc_lookahead=40, me="hex", me_range=16, subme=7, weightp=2,
              weighted_bipred=1, mb_tree=1, aq_mode=1, aq_strength=1.0, scenecut=40, keyint_max=250, keyint_min=0,
-             open_gop=0, frame_refs=3, psy=1, rc_is_cqp=0, bframe_bias=0, fps=25.0, mv_range=0)
+             open_gop=0, frame_refs=3, psy=1, rc_is_cqp=0, bframe_bias=0, fps=25.0, mv_range=0, fps_num=25, fps_den=1,
+             qcompress=0.6)
     c.update(PRESETS[preset])
     c.update(over)
     if c["keyint_min"] <= 0:
@@ -307,7 +317,7 @@ def make_la_params(cfg, cost_mv=None, max_frames=0):
                  max_frames, cost_mv.ctypes.data + 2 * centre)
     p = LaParams(dev, cfg["keyint_max"], cfg["keyint_min"], cfg["scenecut"], cfg["b_adapt"], cfg["b_pyramid"],
                  cfg["rc_lookahead"], cfg["mb_tree"], cfg["weightp"], cfg["open_gop"], cfg["frame_refs"], cfg["psy"],
-                 cfg["rc_is_cqp"])
+                 cfg["rc_is_cqp"], cfg["fps_num"], cfg["fps_den"], cfg["qcompress"])
     p._keep = cost_mv
     return p
 
@@ -352,10 +362,13 @@ class Lookahead:
         luma = np.ascontiguousarray(luma, self.dtype)
         _ck(self.L.x264hip_lookahead_put_frame(self.h, _p(luma), luma.shape[1], 0, forced_type), "lookahead_put_frame")
 
-    def get(self, flush=False):
+    def get(self, flush=False, qp_offsets=False):
         out = LaFrameOut()
         got = C.c_int(0)
-        _ck(self.L.x264hip_lookahead_get_frame(self.h, int(flush), C.byref(out), C.byref(got)), "lookahead_get_frame")
+        qp = np.zeros(((self.cfg["width"] + 15) // 16) * ((self.cfg["height"] + 15) // 16), np.float32) if qp_offsets else None
+        _ck(self.L.x264hip_lookahead_get_frame_ex(self.h, int(flush), C.byref(out), C.byref(got), _p(qp)), "lookahead_get_frame")
+        if got.value and qp_offsets:
+            out.qp_offset = qp
         return out if got.value else None
 
     def stats(self):
@@ -363,7 +376,7 @@ class Lookahead:
         _ck(self.L.x264hip_lookahead_stats(self.h, _p(out), 8), "lookahead_stats")
         return out
 
-    def run(self, frames=None, device_ptrs=None, stride=None, paced=True):
+    def run(self, frames=None, device_ptrs=None, stride=None, paced=True, qp_offsets=False):
         """Feed a whole clip.  paced=True interleaves put/get exactly like x264_encoder_encode; paced=False puts
         every frame first (deep prefetch) -- results are identical, only the batching differs."""
         outs = []
@@ -374,11 +387,11 @@ class Lookahead:
             else:
                 self.put(device_ptr=device_ptrs[i], stride=stride)
             if paced:
-                o = self.get(False)
+                o = self.get(False, qp_offsets)
                 if o is not None:
                     outs.append(o)
         while len(outs) < n:
-            o = self.get(True)
+            o = self.get(True, qp_offsets)
             if o is None:
                 break
             outs.append(o)
