@@ -43,8 +43,9 @@ def _run_sequence(o, cfg, ctx, frames, weights=None, prefetch=False):
         pl = o.lowres_init(cfg, frames[i])
         for p in range(4):
             assert np.array_equal(ctx.lowres(i, p), pl[p][:, :8 * cfg.mb_w + 2 * PAD]), ("lowres", i, p)
-        iq, _, s, ssd = o.aq_frame(frames[i], cfg.mb_w, cfg.mb_h, 1, 1.0)
+        iq, qp, s, ssd = o.aq_frame(frames[i], cfg.mb_w, cfg.mb_h, 1, 1.0)
         assert np.array_equal(ctx.inv_qscale(i), iq), ("inv_qscale", i)
+        assert np.array_equal(ctx.qp_offsets(i), qp), ("f_qp_offset_aq", i)  # FP32, same operation order
         assert ctx.frame_stats(i) == (s, ssd)
         ic = o.intra_costs(cfg, pl)
         assert np.array_equal(ctx.intra_costs(i), ic), ("intra", i, int((ctx.intra_costs(i) != ic).sum()))
@@ -180,5 +181,51 @@ def test_1080p_search_matches_oracle():
             _run_sequence(o, cfg, ctx, frames)
         finally:
             SEQ = old
+    finally:
+        ctx.close()
+
+
+def test_mbtree_steps_match_oracle():
+    """x264hip_mbtree on an explicit step list (zero / propagate P and B / finish) against the oracle's
+    or_mbtree_propagate / or_mbtree_finish on the same fields and maps."""
+    import ctypes as C
+    frames = clip("fastpan", 176, 144, 3)
+    o, cfg, ctx = _mk(*CONFIGS["hex_r4"], 176, 144)
+    try:
+        n = cfg.mb_w * cfg.mb_h
+        planes, inv, intra, qp_aq = [], [], [], []
+        for i in range(3):
+            ctx.frame_put(i, frames[i])
+            planes.append(o.lowres_init(cfg, frames[i]))
+            iq, qp, _, _ = o.aq_frame(frames[i], cfg.mb_w, cfg.mb_h, 1, 1.0)
+            inv.append(iq); qp_aq.append(qp); intra.append(o.intra_costs(cfg, planes[i]))
+        # evaluations: P (0,2,2) then B (0,2,1)
+        ctx.frame_cost(0, 2, 2, 2, 0, (1, 0), None, True, False)
+        ctx.frame_cost(0, 2, 1, 1, 1, (1, 1), None, True, True)
+        f20 = o.search_field(cfg, planes[2], planes[0])
+        f10 = o.search_field(cfg, planes[1], planes[0]); f11 = o.search_field(cfg, planes[1], planes[2])
+        lcP = o.cell(cfg, planes[2], planes[0], None, 128, f20[0], f20[1], None, None, None, intra[2], inv[2], True)[0]
+        lcB = o.cell(cfg, planes[1], planes[0], planes[2], 128, f10[0], f10[1], f11[0], f11[1], f20[0], intra[1], inv[1], True)[0]
+        fps = np.float32(0.04 / (0.04 * 256.0) * 0.5)
+        ops = [lib.MbtreeOp(0, 2, 2, 2, 0, 0, 0, 0, 0.0, 0, 0.0, 0.0), lib.MbtreeOp(0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0.0, 0.0),
+               lib.MbtreeOp(1, 1, 0, 2, 1, 1, 0, 32, fps, 0, 0.0, 0.0),      # B frame 1, not referenced
+               lib.MbtreeOp(1, 2, 0, 2, 2, 0, 1, 32, fps, 0, 0.0, 0.0),      # P frame 2, referenced
+               lib.MbtreeOp(2, 0, 0, 0, 0, 0, 0, 0, 0.0, 512, 0.0, 2.0)]     # finish frame 0
+        ctx.mbtree(ops)
+        prop = [np.zeros(n, np.uint16) for _ in range(3)]
+        L = o.lib
+        L.or_mbtree_propagate.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_float]
+        L.or_mbtree_propagate(cfg.mb_w, cfg.mb_h, intra[1].ctypes.data, lcB.ctypes.data, inv[1].ctypes.data, None,
+                              f10[0].ctypes.data, f11[0].ctypes.data, prop[0].ctypes.data, prop[2].ctypes.data, 32, fps)
+        pin = prop[2].copy()
+        L.or_mbtree_propagate(cfg.mb_w, cfg.mb_h, intra[2].ctypes.data, lcP.ctypes.data, inv[2].ctypes.data, pin.ctypes.data,
+                              f20[0].ctypes.data, None, prop[0].ctypes.data, None, 32, fps)
+        qp = qp_aq[0].copy()
+        L.or_mbtree_finish.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_float, C.c_float]
+        L.or_mbtree_finish(n, intra[0].ctypes.data, inv[0].ctypes.data, prop[0].ctypes.data, qp_aq[0].ctypes.data, qp.ctypes.data, 512, 0.0, 2.0)
+        assert prop[0].max() > 0
+        for i in (0, 2):
+            assert np.array_equal(ctx.propagate_cost(i), prop[i]), ("i_propagate_cost", i)
+        assert np.array_equal(ctx.qp_offsets(0), qp), ("f_qp_offset", float(np.abs(ctx.qp_offsets(0) - qp).max()))
     finally:
         ctx.close()

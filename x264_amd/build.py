@@ -24,7 +24,9 @@ def build(force=False, verbose=False):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = [s for s in SRC if os.path.exists(s)]
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+    # -ffp-contract=off: the few FP32 expressions on this path (AQ, MB-tree) must round like the reference's
+    # separate multiply/add instructions; hipcc's default would fuse them into FMAs (1-ulp differences)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
            "-I" + os.path.join(HERE, "csrc"), "-o", OUT] + srcs
     if verbose:
         print(" ".join(cmd))

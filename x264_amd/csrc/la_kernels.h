@@ -656,7 +656,7 @@ __global__ __launch_bounds__( 64 ) void dct_quant_kernel( int is8, int n_blocks,
 // clamping the running sum when it is read gives the same value whatever the order of the atomic adds.
 struct MbtOpDev
 {
-    int type, referenced, bipred_weight, fps_factor_i, b_bidir, pad_;
+    int type, referenced, bipred_weight, fps_factor_i, b_bidir, barrier_before;
     float fps_factor, weightdelta, strength, padf_;
     int *prop_b, *prop_p0, *prop_p1;
     const uint16_t *intra_cost, *lowres_costs, *inv_qscale;
@@ -678,12 +678,66 @@ __device__ __forceinline__ float lut_log2_diff( const AqLuts *luts, unsigned a, 
     return __fsub_rn( __fadd_rn( t, (float)( 31 - lza ) ), luts->log2_lut[( b << lzb >> 24 ) & 0x7f] );
 }
 
+// one macroblock of a PROPAGATE step: mbtree_propagate_cost + both mbtree_propagate_list scatters
+__device__ __forceinline__ void mbt_propagate_mb( const MbtOpDev &o, int W, int H, int i, int ic, int lc, int inv, int in_cost,
+                                                  unsigned w0, unsigned w1 )
+{
+    const int mx = i % W, my = i / W;
+    int inter = lc & 0x3FFF;
+    if( inter > ic ) inter = ic;
+    const float propagate_intra = (float)( ic * inv );
+    const float propagate_amount = __fadd_rn( (float)in_cost, __fmul_rn( propagate_intra, o.fps_factor ) );
+    const float num = (float)( ic - inter ), den = (float)ic;
+    int amount = (int)__fadd_rn( __fdiv_rn( __fmul_rn( propagate_amount, num ), den ), 0.5f );
+    if( amount > 32767 ) amount = 32767;
+    const int lists_used = lc >> 14;
+#pragma unroll
+    for( int list = 0; list < 2; list++ )
+    {
+        if( list && !o.b_bidir ) break;
+        if( !( lists_used & ( 1 << list ) ) ) continue;
+        int *ref = list ? o.prop_p1 : o.prop_p0;
+        int la = amount;
+        if( lists_used == 3 )
+            la = ( la * ( list ? 64 - o.bipred_weight : o.bipred_weight ) + 32 ) >> 6;
+        const unsigned w = list ? w1 : w0;
+        int x = (int)(short)( w & 0xFFFF ), y = (int)w >> 16;
+        if( !( x | y ) )
+        {
+            atomicAdd( &ref[i], la );
+            continue;
+        }
+        const unsigned mbx = (unsigned)( ( x >> 5 ) + mx ), mby = (unsigned)( ( y >> 5 ) + my );
+        const unsigned idx0 = mbx + mby * W, idx2 = idx0 + W;
+        x &= 31; y &= 31;
+        const int q0 = ( ( 32 - y ) * ( 32 - x ) * la + 512 ) >> 10, q1 = ( ( 32 - y ) * x * la + 512 ) >> 10;
+        const int q2 = ( y * ( 32 - x ) * la + 512 ) >> 10, q3 = ( y * x * la + 512 ) >> 10;
+        if( mby < (unsigned)H )
+        {
+            if( mbx < (unsigned)W ) atomicAdd( &ref[idx0], q0 );
+            if( mbx + 1 < (unsigned)W ) atomicAdd( &ref[idx0 + 1], q1 );
+        }
+        if( mby + 1 < (unsigned)H )
+        {
+            if( mbx < (unsigned)W ) atomicAdd( &ref[idx2], q2 );
+            if( mbx + 1 < (unsigned)W ) atomicAdd( &ref[idx2 + 1], q3 );
+        }
+    }
+}
+
+#define MBT_UNROLL 8
 __global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *ops, int n_ops, const AqLuts *luts )
 {
     const int W = P.mb_w, H = P.mb_h, n_mb = W * H;
     for( int k = 0; k < n_ops; k++ )
     {
         const MbtOpDev o = ops[k];
+        if( o.barrier_before )
+        {
+            // everything earlier steps stored or added has been acknowledged by L2 before this step reads it
+            __builtin_amdgcn_s_waitcnt( 0 );
+            __syncthreads();
+        }
         if( o.type == 0 )
         {
             for( int i = threadIdx.x; i < n_mb; i += blockDim.x )
@@ -691,51 +745,29 @@ __global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *
         }
         else if( o.type == 1 )
         {
-            for( int i = threadIdx.x; i < n_mb; i += blockDim.x )
+            // MBT_UNROLL macroblocks per thread with all their loads in flight together: the step is one memory
+            // round trip long instead of one per macroblock
+            for( int base = threadIdx.x; base < n_mb; base += blockDim.x * MBT_UNROLL )
             {
-                const int mx = i % W, my = i / W;
-                const int ic = o.intra_cost[i];
-                const int lc = o.lowres_costs[i];
-                int inter = lc & 0x3FFF;
-                if( inter > ic ) inter = ic;
-                const float propagate_intra = (float)( ic * (int)o.inv_qscale[i] );
-                const float in = o.referenced ? (float)prop_read( &o.prop_b[i] ) : 0.f;
-                const float propagate_amount = __fadd_rn( in, __fmul_rn( propagate_intra, o.fps_factor ) );
-                const float num = (float)( ic - inter ), den = (float)ic;
-                int amount = (int)__fadd_rn( __fdiv_rn( __fmul_rn( propagate_amount, num ), den ), 0.5f );
-                if( amount > 32767 ) amount = 32767;
-                const int lists_used = lc >> 14;
+                int ic[MBT_UNROLL], lc[MBT_UNROLL], inv[MBT_UNROLL], in_cost[MBT_UNROLL];
+                unsigned w0[MBT_UNROLL], w1[MBT_UNROLL];
 #pragma unroll
-                for( int list = 0; list < 2; list++ )
+                for( int u = 0; u < MBT_UNROLL; u++ )
                 {
-                    if( list && !o.b_bidir ) break;
-                    if( !( lists_used & ( 1 << list ) ) ) continue;
-                    int *ref = list ? o.prop_p1 : o.prop_p0;
-                    int la = amount;
-                    if( lists_used == 3 )
-                        la = ( la * ( list ? 64 - o.bipred_weight : o.bipred_weight ) + 32 ) >> 6;
-                    const unsigned w = (unsigned)( list ? o.mvq1[i] : o.mvq0[i] );
-                    int x = (int)(short)( w & 0xFFFF ), y = (int)w >> 16;
-                    if( !( x | y ) )
-                    {
-                        atomicAdd( &ref[i], la );
-                        continue;
-                    }
-                    const unsigned mbx = (unsigned)( ( x >> 5 ) + mx ), mby = (unsigned)( ( y >> 5 ) + my );
-                    const unsigned idx0 = mbx + mby * W, idx2 = idx0 + W;
-                    x &= 31; y &= 31;
-                    const int w0 = ( ( 32 - y ) * ( 32 - x ) * la + 512 ) >> 10, w1 = ( ( 32 - y ) * x * la + 512 ) >> 10;
-                    const int w2 = ( y * ( 32 - x ) * la + 512 ) >> 10, w3 = ( y * x * la + 512 ) >> 10;
-                    if( mby < (unsigned)H )
-                    {
-                        if( mbx < (unsigned)W ) atomicAdd( &ref[idx0], w0 );
-                        if( mbx + 1 < (unsigned)W ) atomicAdd( &ref[idx0 + 1], w1 );
-                    }
-                    if( mby + 1 < (unsigned)H )
-                    {
-                        if( mbx < (unsigned)W ) atomicAdd( &ref[idx2], w2 );
-                        if( mbx + 1 < (unsigned)W ) atomicAdd( &ref[idx2 + 1], w3 );
-                    }
+                    const int i = base + u * blockDim.x;
+                    const bool ok = i < n_mb;
+                    const int ii = ok ? i : 0;
+                    ic[u] = o.intra_cost[ii]; lc[u] = o.lowres_costs[ii]; inv[u] = o.inv_qscale[ii];
+                    in_cost[u] = o.referenced ? prop_read( &o.prop_b[ii] ) : 0;
+                    w0[u] = (unsigned)o.mvq0[ii];
+                    w1[u] = o.b_bidir ? (unsigned)o.mvq1[ii] : 0u;
+                }
+#pragma unroll
+                for( int u = 0; u < MBT_UNROLL; u++ )
+                {
+                    const int i = base + u * blockDim.x;
+                    if( i < n_mb )
+                        mbt_propagate_mb( o, W, H, i, ic[u], lc[u], inv[u], in_cost[u], w0[u], w1[u] );
                 }
             }
         }
@@ -752,8 +784,5 @@ __global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *
                 }
             }
         }
-        // every step's stores and atomics have been acknowledged by L2 before the next step reads them
-        __builtin_amdgcn_s_waitcnt( 0 );
-        __syncthreads();
     }
 }

@@ -91,9 +91,9 @@ struct x264hip_ctx
     unsigned long long *stats_host = nullptr; // pinned [slots][2]
     // MB-tree: own stream, ring of pinned/device step tables
     hipStream_t stream2 = nullptr;
-    static const int MBT_RING = 8, MBT_CAP = 1024;
-    MbtOpDev *mbt_host[8] = { nullptr }, *mbt_dev[8] = { nullptr };
-    hipEvent_t mbt_done[8] = { nullptr };
+    static const int MBT_RING = 64, MBT_CAP = 1024;
+    MbtOpDev *mbt_host[64] = { nullptr }, *mbt_dev[64] = { nullptr };
+    hipEvent_t mbt_done[64] = { nullptr };
     hipEvent_t ev_cross = nullptr, ev_mbt_last = nullptr;
     int mbt_next = 0, mbt_pending = 0;
     int *acc_host = nullptr;         // pinned [8]
@@ -821,9 +821,17 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
     if( ctx->mbt_pending >= x264hip_ctx::MBT_RING )
         HIPCK( hipEventSynchronize( ctx->mbt_done[r] ) ); // the table we are about to rewrite has been consumed
     MbtOpDev *dh = ctx->mbt_host[r];
-    for( int i = 0; i < n; i++ )
+    // Step order on the device: every ZERO first (a buffer is always cleared before anything is added to it in the
+    // reference's order too), then the rest in order.  A barrier is only needed where a step reads what earlier
+    // steps accumulated: referenced PROPAGATEs and FINISH; runs of B-frame propagations overlap freely.
+    std::vector<int> order;
+    for( int i = 0; i < n; i++ ) if( ops[i].type == X264HIP_MBT_ZERO ) order.push_back( i );
+    const int n_zero = (int)order.size();
+    for( int i = 0; i < n; i++ ) if( ops[i].type != X264HIP_MBT_ZERO ) order.push_back( i );
+    for( int k = 0; k < n; k++ )
     {
-        const x264hip_mbtree_op &o = ops[i];
+        const int i = k;
+        const x264hip_mbtree_op &o = ops[order[k]];
         if( !slot_ok( ctx, o.slot_b ) || !slot_ok( ctx, o.slot_p0 ) || !slot_ok( ctx, o.slot_p1 ) || o.dist_p0 < 0 || o.dist_p1 < 0 ||
             o.dist_p0 + o.dist_p1 > ctx->p.bframes + 1 )
             return X264HIP_EINVAL;
@@ -833,6 +841,7 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
         d.type = o.type; d.referenced = o.referenced; d.bipred_weight = o.bipred_weight; d.fps_factor_i = o.fps_factor_i;
         d.fps_factor = o.fps_factor; d.weightdelta = o.weightdelta; d.strength = o.strength;
         d.b_bidir = o.dist_p1 > 0;
+        d.barrier_before = k == n_zero || ( o.type == X264HIP_MBT_PROPAGATE && o.referenced ) || o.type == X264HIP_MBT_FINISH;
         d.prop_b = b.prop; d.prop_p0 = f0.prop; d.prop_p1 = f1.prop;
         d.intra_cost = b.lowres_costs; d.inv_qscale = b.inv_qscale;
         d.lowres_costs = b.lowres_costs + (size_t)( o.dist_p0 * nstride + o.dist_p1 ) * ctx->n_mb;

@@ -33,6 +33,12 @@ class Cost(C.Structure):
                 ("intra_cost_est_aq", C.c_int)]
 
 
+class MbtreeOp(C.Structure):
+    _fields_ = [("type", C.c_int), ("slot_b", C.c_int), ("slot_p0", C.c_int), ("slot_p1", C.c_int), ("dist_p0", C.c_int),
+                ("dist_p1", C.c_int), ("referenced", C.c_int), ("bipred_weight", C.c_int), ("fps_factor", C.c_float),
+                ("fps_factor_i", C.c_int), ("weightdelta", C.c_float), ("strength", C.c_float)]
+
+
 _lib = None
 
 
@@ -189,6 +195,20 @@ class Context:
         _ck(self.L.x264hip_get_inv_qscale(self.h, slot, _p(out)), "get_inv_qscale")
         return out
 
+    def qp_offsets(self, slot):
+        out = np.zeros(self.n_mb, np.float32)
+        _ck(self.L.x264hip_get_qp_offsets(self.h, slot, _p(out)), "get_qp_offsets")
+        return out
+
+    def propagate_cost(self, slot):
+        out = np.zeros(self.n_mb, np.uint16)
+        _ck(self.L.x264hip_get_propagate_cost(self.h, slot, _p(out)), "get_propagate_cost")
+        return out
+
+    def mbtree(self, ops):
+        arr = (MbtreeOp * len(ops))(*ops)
+        _ck(self.L.x264hip_mbtree(self.h, arr, len(ops)), "mbtree")
+
     def last_search_ms(self):
         ms, ns, nb = C.c_float(), C.c_int(), C.c_int()
         _ck(self.L.x264hip_last_search_ms(self.h, C.byref(ms), C.byref(ns), C.byref(nb)), "last_search_ms")
@@ -209,12 +229,6 @@ class LaParams(C.Structure):
                 ("b_adapt", C.c_int), ("b_pyramid", C.c_int), ("rc_lookahead", C.c_int), ("mb_tree", C.c_int),
                 ("weightp", C.c_int), ("open_gop", C.c_int), ("frame_refs", C.c_int), ("psy", C.c_int),
                 ("rc_is_cqp", C.c_int), ("fps_num", C.c_int), ("fps_den", C.c_int), ("qcompress", C.c_float)]
-
-
-class MbtreeOp(C.Structure):
-    _fields_ = [("type", C.c_int), ("slot_b", C.c_int), ("slot_p0", C.c_int), ("slot_p1", C.c_int), ("dist_p0", C.c_int),
-                ("dist_p1", C.c_int), ("referenced", C.c_int), ("bipred_weight", C.c_int), ("fps_factor", C.c_float),
-                ("fps_factor_i", C.c_int), ("weightdelta", C.c_float), ("strength", C.c_float)]
 
 
 FRAME_PUT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int)
