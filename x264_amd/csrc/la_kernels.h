@@ -725,36 +725,59 @@ __device__ __forceinline__ void mbt_propagate_mb( const MbtOpDev &o, int W, int 
     }
 }
 
-#define MBT_UNROLL 8
-__global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *ops, int n_ops, const AqLuts *luts )
+#define MBT_UNROLL 4
+#define MBT_WGS 16
+// All MBT_WGS workgroups walk the same step list; where a step reads what earlier steps accumulated they meet at a
+// counter barrier (monotonic counter, relaxed agent-scope polling, bounded spin).  Everything exchanged between
+// steps lives in the propagate accumulators, which are only touched with agent-scope atomics, so no fences are
+// needed beyond draining this wave's outstanding operations before it arrives.
+__global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *ops, int n_ops, const AqLuts *luts,
+                                                         unsigned *bar /* [0] arrivals, [1] error */ )
 {
     const int W = P.mb_w, H = P.mb_h, n_mb = W * H;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    unsigned n_bar = 0;
     for( int k = 0; k < n_ops; k++ )
     {
         const MbtOpDev o = ops[k];
         if( o.barrier_before )
         {
-            // everything earlier steps stored or added has been acknowledged by L2 before this step reads it
             __builtin_amdgcn_s_waitcnt( 0 );
+            __syncthreads();
+            n_bar++;
+            if( threadIdx.x == 0 )
+            {
+                __hip_atomic_fetch_add( &bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+                unsigned spins = 0;
+                while( __hip_atomic_load( &bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) < n_bar * gridDim.x )
+                {
+                    __builtin_amdgcn_s_sleep( 2 );
+                    if( ++spins > ( 1u << 24 ) )
+                    {
+                        __hip_atomic_store( &bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+                        break;
+                    }
+                }
+            }
             __syncthreads();
         }
         if( o.type == 0 )
         {
-            for( int i = threadIdx.x; i < n_mb; i += blockDim.x )
+            for( int i = tid; i < n_mb; i += nthreads )
                 __hip_atomic_store( &o.prop_b[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
         }
         else if( o.type == 1 )
         {
             // MBT_UNROLL macroblocks per thread with all their loads in flight together: the step is one memory
             // round trip long instead of one per macroblock
-            for( int base = threadIdx.x; base < n_mb; base += blockDim.x * MBT_UNROLL )
+            for( int base = tid; base < n_mb; base += nthreads * MBT_UNROLL )
             {
                 int ic[MBT_UNROLL], lc[MBT_UNROLL], inv[MBT_UNROLL], in_cost[MBT_UNROLL];
                 unsigned w0[MBT_UNROLL], w1[MBT_UNROLL];
 #pragma unroll
                 for( int u = 0; u < MBT_UNROLL; u++ )
                 {
-                    const int i = base + u * blockDim.x;
+                    const int i = base + u * nthreads;
                     const bool ok = i < n_mb;
                     const int ii = ok ? i : 0;
                     ic[u] = o.intra_cost[ii]; lc[u] = o.lowres_costs[ii]; inv[u] = o.inv_qscale[ii];
@@ -765,7 +788,7 @@ __global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *
 #pragma unroll
                 for( int u = 0; u < MBT_UNROLL; u++ )
                 {
-                    const int i = base + u * blockDim.x;
+                    const int i = base + u * nthreads;
                     if( i < n_mb )
                         mbt_propagate_mb( o, W, H, i, ic[u], lc[u], inv[u], in_cost[u], w0[u], w1[u] );
                 }
@@ -773,7 +796,7 @@ __global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *
         }
         else
         {
-            for( int i = threadIdx.x; i < n_mb; i += blockDim.x )
+            for( int i = tid; i < n_mb; i += nthreads )
             {
                 const int ic = ( (int)o.intra_cost[i] * (int)o.inv_qscale[i] + 128 ) >> 8;
                 if( ic )

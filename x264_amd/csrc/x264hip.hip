@@ -96,6 +96,7 @@ struct x264hip_ctx
     hipEvent_t mbt_done[64] = { nullptr };
     hipEvent_t ev_cross = nullptr, ev_mbt_last = nullptr;
     int mbt_next = 0, mbt_pending = 0;
+    unsigned *mbt_bar = nullptr;      // device [MBT_RING][2]: barrier arrivals, error
     int *acc_host = nullptr;         // pinned [8]
     unsigned *sync_host = nullptr;   // pinned [2]
     void *desc_dev = nullptr;        // SearchDesc array
@@ -148,6 +149,7 @@ static void free_all( x264hip_ctx *ctx )
         (void)hipHostFree( ctx->mbt_host[i] ); (void)hipFree( ctx->mbt_dev[i] );
         if( ctx->mbt_done[i] ) (void)hipEventDestroy( ctx->mbt_done[i] );
     }
+    (void)hipFree( ctx->mbt_bar );
     if( ctx->ev_cross ) (void)hipEventDestroy( ctx->ev_cross );
     if( ctx->ev_mbt_last ) (void)hipEventDestroy( ctx->ev_mbt_last );
     if( ctx->stream2 ) (void)hipStreamDestroy( ctx->stream2 );
@@ -231,6 +233,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( hipStreamCreateWithFlags( &ctx->stream2, hipStreamNonBlocking ) );
     OPENCK( hipEventCreateWithFlags( &ctx->ev_cross, hipEventDisableTiming ) );
     OPENCK( hipEventCreateWithFlags( &ctx->ev_mbt_last, hipEventDisableTiming ) );
+    OPENCK( hipMalloc( &ctx->mbt_bar, x264hip_ctx::MBT_RING * 2 * sizeof( unsigned ) ) );
+    OPENCK( hipMemset( ctx->mbt_bar, 0, x264hip_ctx::MBT_RING * 2 * sizeof( unsigned ) ) );
     for( int i = 0; i < x264hip_ctx::MBT_RING; i++ )
     {
         OPENCK( hipHostMalloc( &ctx->mbt_host[i], x264hip_ctx::MBT_CAP * sizeof( MbtOpDev ) ) );
@@ -858,7 +862,8 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
     HIPCK( hipEventRecord( ctx->ev_cross, ctx->stream ) );
     HIPCK( hipStreamWaitEvent( ctx->stream2, ctx->ev_cross, 0 ) );
     HIPCK( hipMemcpyAsync( ctx->mbt_dev[r], dh, (size_t)n * sizeof( MbtOpDev ), hipMemcpyHostToDevice, ctx->stream2 ) );
-    mbtree_kernel<<<1, 1024, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], n, ctx->luts_dev );
+    HIPCK( hipMemsetAsync( ctx->mbt_bar + 2 * r, 0, sizeof( unsigned ), ctx->stream2 ) ); // arrivals; the error word is sticky
+    mbtree_kernel<<<MBT_WGS, 1024, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], n, ctx->luts_dev, ctx->mbt_bar + 2 * r );
     HIPCK( hipGetLastError() );
     HIPCK( hipEventRecord( ctx->mbt_done[r], ctx->stream2 ) );
     HIPCK( hipEventRecord( ctx->ev_mbt_last, ctx->stream2 ) );
@@ -873,7 +878,16 @@ extern "C" int x264hip_get_qp_offsets( x264hip_ctx *ctx, int slot, float *qp_off
     if( ctx->broken ) return X264HIP_EDEVICE;
     HIPCK( hipStreamSynchronize( ctx->stream ) );
     HIPCK( hipMemcpyAsync( qp_offset, ctx->slots[slot].qp, ctx->n_mb * sizeof( float ), hipMemcpyDeviceToHost, ctx->stream2 ) );
+    std::vector<unsigned> bar( x264hip_ctx::MBT_RING * 2 );
+    HIPCK( hipMemcpyAsync( bar.data(), ctx->mbt_bar, bar.size() * sizeof( unsigned ), hipMemcpyDeviceToHost, ctx->stream2 ) );
     HIPCK( hipStreamSynchronize( ctx->stream2 ) );
+    ctx->mbt_pending = 0;
+    for( int i = 0; i < x264hip_ctx::MBT_RING; i++ )
+        if( bar[2 * i + 1] )
+        {
+            ctx->broken = 1;
+            return X264HIP_ETIMEOUT;
+        }
     return X264HIP_OK;
 }
 
