@@ -107,6 +107,9 @@ int  x264hip_synchronize( x264hip_ctx *ctx );  /* x264_opencl_flush (encoder/sli
  * Resets the slot's search/cost state like mc.c:471-481. */
 int  x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, int stride, int is_device,
                         const void *cb, const void *cr, int cstride, const uint16_t *inv_qscale );
+/* The same for n frames whose luma already sits in device memory (all with the same stride): one launch per ingest
+ * kernel instead of one per frame. */
+int  x264hip_frame_put_batch( x264hip_ctx *ctx, int n, const int *slots, const void *const *luma_dev, int stride );
 /* i_pixel_sum[0] / i_pixel_ssd[0] of the frame (ratecontrol.c:225-234,405-414) */
 int  x264hip_frame_stats( x264hip_ctx *ctx, int slot, uint64_t *pixel_sum, uint64_t *pixel_ssd );
 
@@ -223,6 +226,7 @@ typedef struct x264hip_backend
     int (*prefetch)( void *user, const int *slots, const int *frame_numbers, int n ); /* may be NULL */
     int (*mbtree)( void *user, const x264hip_mbtree_op *ops, int n );                   /* may be NULL: no propagation */
     int (*get_qp_offsets)( void *user, int slot, float *qp_offset );                    /* may be NULL */
+    int (*frame_put_batch)( void *user, int n, const int *slots, const void *const *luma_dev, int stride ); /* may be NULL */
 } x264hip_backend;
 
 typedef struct x264hip_la_frame
@@ -246,6 +250,8 @@ x264hip_ctx *x264hip_lookahead_ctx( x264hip_lookahead *la ); /* NULL for plugin 
 int  x264hip_lookahead_delay( x264hip_lookahead *la );       /* h->frames.i_delay */
 /* forced_type: X264_TYPE_AUTO (0) normally */
 int  x264hip_lookahead_put_frame( x264hip_lookahead *la, const void *luma, int stride, int is_device, int forced_type );
+/* n device-resident frames at once (display order, all X264_TYPE_AUTO): batched ingest when the backend supports it */
+int  x264hip_lookahead_put_frames( x264hip_lookahead *la, int n, const void *const *luma_dev, int stride );
 /* One call = the lookahead part of one x264_encoder_encode call.  flush != 0 once the input has ended.
  * *got = 1 and *out filled when a frame leaves the lookahead (coded order), 0 while the delay fills or at the end. */
 int  x264hip_lookahead_get_frame( x264hip_lookahead *la, int flush, x264hip_la_frame *out, int *got );

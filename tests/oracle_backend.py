@@ -22,7 +22,7 @@ class OracleBackend:
         self.n_eval = 0
         self.struct = lib.Backend(None, lib.FRAME_PUT_FN(self._put), lib.FRAME_STATS_FN(self._stats),
                                   lib.WEIGHT_COST_FN(self._wcost), lib.FRAME_COST_FN(self._cost), lib.PREFETCH_FN(0),
-                                  lib.MBTREE_FN(self._mbtree), lib.QP_OFFSETS_FN(self._qp))
+                                  lib.MBTREE_FN(self._mbtree), lib.QP_OFFSETS_FN(self._qp), lib.PUT_BATCH_FN(0))
 
     def _put(self, user, slot, luma, stride, is_device):
         c = self.cfg

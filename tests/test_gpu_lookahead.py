@@ -85,3 +85,30 @@ def test_batching_invariance_full_size(W, H, preset, over, nf):
     types = [t for _, t in _types(res[0])]
     assert types[0] == 1 and set(types) <= {1, 2, 3, 4, 5}
     assert sorted(f for f, _ in _types(res[0])) == list(range(nf))
+
+
+def test_batch_ingest_device_pointers():
+    """x264hip_lookahead_put_frames (device-resident frames, batched ingest) gives the same decisions and maps as
+    frame-by-frame host ingest."""
+    import torch
+    W, H, nf = 352, 288, 40
+    frames = make_clip(W, H, nf, seed=3, scene_cuts=(17,))
+    cfg = lib.la_config(W, H, "medium")
+    la = lib.Lookahead(cfg)
+    try:
+        ref = la.run(frames, qp_offsets=True)
+    finally:
+        la.close()
+    dev = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    la = lib.Lookahead(cfg, max_frames=nf + 4)
+    try:
+        outs = la.run(device_ptrs=[dev[i].data_ptr() for i in range(nf)], stride=W, paced=False, qp_offsets=True)
+    finally:
+        la.close()
+    assert _types(outs) == _types(ref)
+    nb = cfg["bframes"] + 2
+    for a, b in zip(_mats(outs, nb), _mats(ref, nb)):
+        assert np.array_equal(a, b)
+    for a, b in zip(outs, ref):
+        assert np.array_equal(a.qp_offset, b.qp_offset)

@@ -8,13 +8,29 @@
 // domain: border pixels are produced by clamping the lowres coordinate, so there is no second pass
 // and every store is a full, aligned 4-pixel vector.  Source coordinates clamp to the picture, which
 // reproduces the mod16 replication (frame.c:640-666) and the +1 row/column duplication (mc.c:466-468).
-template <typename T>
-__device__ __forceinline__ int avg2( int a, int b ) { return ( a + b + 1 ) >> 1; }
+// per-frame ingest descriptor: a batch of frames is one launch of each ingest kernel (blockIdx.z = frame)
+struct PutDesc
+{
+    const void *src;              // full-resolution luma
+    const void *cb, *cr;          // optional chroma planes (AQ energy)
+    int src_stride, cstride;
+    void *planes;                 // 4 padded lowres planes
+    uint16_t *inv_qscale;
+    uint2 *mb_sums;
+    unsigned long long *frame_sums;
+    float *qp_aq, *qp;
+    uint16_t *intra_cost;
+    int aq_on, pad_;
+};
 
 template <typename T>
-__global__ __launch_bounds__( 256 ) void lowres_kernel( const T *__restrict__ src, int src_stride, int width, int height,
-                                                        T *__restrict__ planes, int plane_elems, int stride, int lw, int lh )
+__global__ __launch_bounds__( 256 ) void lowres_kernel( const PutDesc *descs, PutDesc single, int width, int height,
+                                                        int plane_elems, int stride, int lw, int lh )
 {
+    const PutDesc D = descs ? descs[blockIdx.z] : single;
+    const T *__restrict__ src = (const T *)D.src;
+    T *__restrict__ planes = (T *)D.planes;
+    const int src_stride = D.src_stride;
     const int pw4 = ( lw + 2 * LA_PAD ) >> 2;
     const int X4 = blockIdx.x * blockDim.x + threadIdx.x;
     const int Y = blockIdx.y;
@@ -104,12 +120,15 @@ __device__ __forceinline__ unsigned wave_sum_u32( unsigned v )
 }
 
 template <typename T>
-__global__ __launch_bounds__( 64 ) void aq_kernel( const T *__restrict__ luma, int stride, int width, int height, int mb_w,
-                                                   const T *__restrict__ cb, const T *__restrict__ cr, int cstride,
-                                                   int aq_on, float strength, float log2_bias, const AqLuts *luts,
-                                                   uint16_t *inv_qscale, uint2 *mb_sums /* per MB: luma sum, sum of squares */,
-                                                   float *qp_offset_aq, float *qp_offset )
+__global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc single, int width, int height, int mb_w,
+                                                   float strength, float log2_bias, const AqLuts *luts )
 {
+    const PutDesc D = descs ? descs[blockIdx.z] : single;
+    const T *__restrict__ luma = (const T *)D.src, *__restrict__ cb = (const T *)D.cb, *__restrict__ cr = (const T *)D.cr;
+    const int stride = D.src_stride, cstride = D.cstride, aq_on = D.aq_on;
+    uint16_t *inv_qscale = D.inv_qscale;
+    uint2 *mb_sums = D.mb_sums;
+    float *qp_offset_aq = D.qp_aq, *qp_offset = D.qp;
     const int mx = blockIdx.x, my = blockIdx.y, lane = lane_id();
     const int ly = lane >> 2, lx = ( lane & 3 ) * 4;
     unsigned s = 0, q = 0;
@@ -156,8 +175,11 @@ __global__ __launch_bounds__( 64 ) void aq_kernel( const T *__restrict__ luma, i
 }
 
 // frame totals of the per-MB sums: one workgroup, no atomics
-__global__ __launch_bounds__( 1024 ) void aq_reduce_kernel( const uint2 *__restrict__ mb_sums, int n, unsigned long long *frame_sums )
+__global__ __launch_bounds__( 1024 ) void aq_reduce_kernel( const PutDesc *descs, PutDesc single, int n )
 {
+    const PutDesc D = descs ? descs[blockIdx.x] : single;
+    const uint2 *__restrict__ mb_sums = D.mb_sums;
+    unsigned long long *frame_sums = D.frame_sums;
     __shared__ unsigned long long sh[2][16];
     unsigned long long s = 0, q = 0;
     for( int i = threadIdx.x; i < n; i += blockDim.x )
@@ -262,8 +284,11 @@ __device__ __forceinline__ int intra_pred_px( const IntraEdges &E, int mode, int
 }
 
 template <typename T>
-__global__ __launch_bounds__( 64 ) void intra_kernel( LaP P, const T *__restrict__ fenc0, uint16_t *intra_cost )
+__global__ __launch_bounds__( 64 ) void intra_kernel( LaP P, const PutDesc *descs, PutDesc single )
 {
+    const PutDesc D = descs ? descs[blockIdx.z] : single;
+    const T *__restrict__ fenc0 = (const T *)D.planes + LA_PAD * P.stride + LA_PAD;
+    uint16_t *intra_cost = D.intra_cost;
     __shared__ IntraEdges E;
     const int lane = lane_id();
     const int bx = blockIdx.x, by = blockIdx.y;
@@ -322,32 +347,35 @@ __global__ __launch_bounds__( 256 ) void weight_plane_kernel( const T *__restric
         dst[i] = (T)weight_px( src[i], w, pixel_max );
 }
 
-// weight_cost_luma (slicetype.c:191-222): four blocks per wave, sum of min( mbcmp, intra_cost )
+// weight_cost_luma (slicetype.c:191-222): sum over blocks of min( mbcmp, intra_cost ).  256-thread workgroups, four
+// blocks per wave, sixteen per workgroup; one atomic per workgroup after an LDS reduction.
 template <typename T>
-__global__ __launch_bounds__( 64 ) void weight_cost_kernel( LaP P, const T *__restrict__ fenc0, const T *__restrict__ ref0, WtD w,
-                                                            const uint16_t *__restrict__ intra_cost, unsigned *out )
+__global__ __launch_bounds__( 256 ) void weight_cost_kernel( LaP P, const T *__restrict__ fenc0, const T *__restrict__ ref0, WtD w,
+                                                             const uint16_t *__restrict__ intra_cost, unsigned *out )
 {
-    const int lane = lane_id();
+    __shared__ unsigned part[4];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int g = lane >> 4, l = lane & 15, q = l >> 2;
     const int tx = ( q & 1 ) * 4, row = ( q >> 1 ) * 4 + ( l & 3 );
     const int n_mb = P.mb_w * P.mb_h;
-    const int xy = ( blockIdx.x * 4 + g );
-    int c = 0;
-    const int xyc = imin2( xy, n_mb - 1 );
+    const int first = ( blockIdx.x * 4 + wave ) * 4;
+    const int xyc = imin2( first + g, n_mb - 1 );
     const int bx = xyc % P.mb_w, by = xyc / P.mb_w;
     const int off = 8 * ( by * P.stride + bx ) + row * P.stride + tx;
     const Px4 f = load_px4( fenc0 + off );
     Px4 r = load_px4( ref0 + off );
     if( w.on )
         r = weight_px4<T>( r, w, P.pixel_max );
-    c = imin2( block_cost8x8<T>( f, r, P.mbcmp_satd ), (int)intra_cost[xyc] );
+    const int c = imin2( block_cost8x8<T>( f, r, P.mbcmp_satd ), (int)intra_cost[xyc] );
     unsigned tot = 0;
 #pragma unroll
     for( int k = 0; k < 4; k++ )
-        if( blockIdx.x * 4 + k < n_mb )
+        if( first + k < n_mb )
             tot += (unsigned)__builtin_amdgcn_readlane( c, 16 * k );
-    if( lane == 0 )
-        atomicAdd( out, tot );
+    if( lane == 0 ) part[wave] = tot;
+    __syncthreads();
+    if( threadIdx.x == 0 )
+        atomicAdd( out, part[0] + part[1] + part[2] + part[3] );
 }
 
 // ---- mode selection and reductions (slicetype.c:616-652,708-712,758-790,946-985) ----------------------

@@ -43,6 +43,7 @@ struct LaFrame
     uint64_t pixel_sum = 0, pixel_ssd = 0;
     bool stats_valid = false;
     float weighted_cost_delta[BMAX + 2]; // f_weighted_cost_delta, frame.c:798
+    bool prefetch_submitted = false;
 };
 
 static int ue_size( unsigned v ) // bs_size_ue, common/bitstream.h:278 (2*floor(log2(v+1))+1)
@@ -734,15 +735,28 @@ struct Lookahead
             analyse( shift );
     }
 
+    // Speculative work is submitted for the part of the queue the next decisions can reach (i_delay + 1 frames)
+    // plus a chunk of read-ahead; when more frames than that are already queued (batch ingest) the following
+    // chunks are submitted while the host is busy deciding on the current one, so device and host overlap.
     void flush_prefetch()
     {
-        if( pending_prefetch.empty() || !be.prefetch ) { pending_prefetch.clear(); return; }
-        // everything resident in the window: last_nonb + next (pairs further apart than bframes+1 are skipped by the backend)
+        pending_prefetch.clear();
+        if( !be.prefetch ) return;
+        const int chunk = 64;
+        const int reach = (int)next.size() < i_delay + 2 ? (int)next.size() : i_delay + 2;
+        int submitted = 0;
+        while( submitted < (int)next.size() && next[submitted]->prefetch_submitted ) submitted++;
+        if( submitted >= reach ) return;
+        const int upto = (int)next.size() < reach + chunk ? (int)next.size() : reach + chunk;
+        // everything resident up to there: last_nonb + next[0..upto) (pairs further apart than bframes+1 are skipped by the backend)
         std::vector<int> slots, nums;
         if( last_nonb ) { slots.push_back( last_nonb->slot ); nums.push_back( last_nonb->i_frame ); }
-        for( auto f : next ) { slots.push_back( f->slot ); nums.push_back( f->i_frame ); }
+        for( int i = 0; i < upto; i++ )
+        {
+            slots.push_back( next[i]->slot ); nums.push_back( next[i]->i_frame );
+            next[i]->prefetch_submitted = true;
+        }
         need( be.prefetch( be.user, slots.data(), nums.data(), (int)slots.size() ) );
-        pending_prefetch.clear();
     }
 };
 
@@ -760,6 +774,10 @@ static int dev_frame_cost( void *u, int p0, int p1, int b, int d0, int d1, const
 static int dev_prefetch( void *u, const int *s, const int *n, int c ) { return x264hip_prefetch( (x264hip_ctx *)u, s, n, c ); }
 static int dev_mbtree( void *u, const x264hip_mbtree_op *ops, int n ) { return x264hip_mbtree( (x264hip_ctx *)u, ops, n ); }
 static int dev_qp_offsets( void *u, int slot, float *q ) { return x264hip_get_qp_offsets( (x264hip_ctx *)u, slot, q ); }
+static int dev_put_batch( void *u, int n, const int *slots, const void *const *luma, int stride )
+{
+    return x264hip_frame_put_batch( (x264hip_ctx *)u, n, slots, luma, stride );
+}
 
 } // namespace
 
@@ -824,7 +842,7 @@ extern "C" int x264hip_lookahead_open( x264hip_lookahead **out, int device, cons
     x264hip_ctx *ctx = nullptr;
     int rc = x264hip_open( &ctx, device, &p.dev );
     if( rc ) return rc;
-    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch, dev_mbtree, dev_qp_offsets };
+    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch, dev_mbtree, dev_qp_offsets, dev_put_batch };
     rc = x264hip_lookahead_open_backend( out, &p, &be );
     if( rc ) { x264hip_close( ctx ); return rc; }
     ( *out )->L.ctx = ctx;
@@ -861,12 +879,8 @@ extern "C" int x264hip_lookahead_reset( x264hip_lookahead *la )
 extern "C" x264hip_ctx *x264hip_lookahead_ctx( x264hip_lookahead *la ) { return la ? la->L.ctx : nullptr; }
 extern "C" int x264hip_lookahead_delay( x264hip_lookahead *la ) { return la ? la->L.i_delay : X264HIP_EINVAL; }
 
-extern "C" int x264hip_lookahead_put_frame( x264hip_lookahead *la, const void *luma, int stride, int is_device, int forced_type )
+static LaFrame *new_frame( Lookahead &L, int forced_type )
 {
-    if( !la || !luma ) return X264HIP_EINVAL;
-    Lookahead &L = la->L;
-    if( L.err ) return L.err;
-    if( L.free_slots.empty() ) return X264HIP_ESTATE;
     LaFrame *f = new LaFrame();
     f->slot = L.free_slots.back(); L.free_slots.pop_back();
     f->i_frame = L.i_input++;
@@ -877,11 +891,55 @@ extern "C" int x264hip_lookahead_put_frame( x264hip_lookahead *la, const void *l
     memset( f->intra_mbs, 0, sizeof( f->intra_mbs ) );
     memset( f->searched, 0, sizeof( f->searched ) );       // mc.c:479-481
     memset( f->weighted_cost_delta, 0, sizeof( f->weighted_cost_delta ) );
+    return f;
+}
+
+extern "C" int x264hip_lookahead_put_frames( x264hip_lookahead *la, int n, const void *const *luma_dev, int stride )
+{
+    if( !la || n <= 0 || !luma_dev ) return X264HIP_EINVAL;
+    Lookahead &L = la->L;
+    if( L.err ) return L.err;
+    if( !L.be.frame_put_batch )
+    {
+        for( int i = 0; i < n; i++ )
+        {
+            int rc = x264hip_lookahead_put_frame( la, luma_dev[i], stride, 1, T_AUTO );
+            if( rc ) return rc;
+        }
+        return X264HIP_OK;
+    }
+    if( (int)L.free_slots.size() < n ) return X264HIP_ESTATE;
+    std::vector<LaFrame *> fr;
+    std::vector<int> slots;
+    for( int i = 0; i < n; i++ )
+    {
+        fr.push_back( new_frame( L, T_AUTO ) );
+        slots.push_back( fr.back()->slot );
+    }
+    int rc = L.be.frame_put_batch( L.be.user, n, slots.data(), luma_dev, stride );
+    if( rc )
+    {
+        for( auto f : fr ) { L.free_slots.push_back( f->slot ); delete f; }
+        L.i_input -= n;
+        return L.need( rc );
+    }
+    for( auto f : fr ) { L.next.push_back( f ); L.pending_prefetch.push_back( f ); }
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_lookahead_put_frame( x264hip_lookahead *la, const void *luma, int stride, int is_device, int forced_type )
+{
+    if( !la || !luma ) return X264HIP_EINVAL;
+    Lookahead &L = la->L;
+    if( L.err ) return L.err;
+    if( L.free_slots.empty() ) return X264HIP_ESTATE;
+    LaFrame *f = new_frame( L, forced_type );
     int rc = L.be.frame_put( L.be.user, f->slot, luma, stride, is_device );
     if( rc )
     {
         L.free_slots.push_back( f->slot );
         delete f;
+        L.i_input--;
         return L.need( rc );
     }
     L.next.push_back( f );

@@ -86,6 +86,8 @@ struct x264hip_ctx
     int *cell_acc_dev = nullptr;     // [slots][n_cells][8] sums of every cell evaluation
     int *cell_acc_host = nullptr;    // pinned mirror
     CellArgs *cell_desc_dev = nullptr, *cell_desc_host = nullptr;
+    PutDesc *put_desc_dev = nullptr, *put_desc_host = nullptr;
+    int put_desc_cap = 256;
     int cell_desc_cap = 0;
     unsigned batch_serial = 0, batch_synced = 0;
     unsigned long long *stats_host = nullptr; // pinned [slots][2]
@@ -143,6 +145,7 @@ static void free_all( x264hip_ctx *ctx )
     for( auto w : ctx->wplanes ) (void)hipFree( w );
     (void)hipFree( ctx->cost_mv_dev ); (void)hipFree( ctx->luts_dev ); (void)hipFree( ctx->sync_words ); (void)hipFree( ctx->acc_dev ); (void)hipFree( ctx->cell_acc_dev ); (void)hipFree( ctx->cell_desc_dev );
     (void)hipHostFree( ctx->stats_host );
+    (void)hipFree( ctx->put_desc_dev ); (void)hipHostFree( ctx->put_desc_host );
     if( ctx->stream2 ) (void)hipStreamSynchronize( ctx->stream2 );
     for( int i = 0; i < x264hip_ctx::MBT_RING; i++ )
     {
@@ -241,6 +244,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         OPENCK( hipMalloc( &ctx->mbt_dev[i], x264hip_ctx::MBT_CAP * sizeof( MbtOpDev ) ) );
         OPENCK( hipEventCreateWithFlags( &ctx->mbt_done[i], hipEventDisableTiming ) );
     }
+    OPENCK( hipMalloc( &ctx->put_desc_dev, (size_t)ctx->put_desc_cap * sizeof( PutDesc ) ) );
+    OPENCK( hipHostMalloc( &ctx->put_desc_host, (size_t)ctx->put_desc_cap * sizeof( PutDesc ) ) );
     ctx->cell_desc_cap = 4096;
     OPENCK( hipMalloc( &ctx->cell_desc_dev, (size_t)ctx->cell_desc_cap * sizeof( CellArgs ) ) );
     OPENCK( hipHostMalloc( &ctx->cell_desc_host, (size_t)ctx->cell_desc_cap * sizeof( CellArgs ) ) );
@@ -327,45 +332,44 @@ extern "C" int x264hip_geometry( x264hip_ctx *ctx, int *mb_w, int *mb_h, int *lo
 static inline bool slot_ok( x264hip_ctx *ctx, int s ) { return s >= 0 && s < (int)ctx->slots.size(); }
 
 // ---- frame ingest ------------------------------------------------------------------------------------
+static PutDesc make_put_desc( x264hip_ctx *ctx, FrameSlot &s, const void *src, int src_stride, const void *cb, const void *cr, int cstride,
+                              int aq_on )
+{
+    PutDesc d;
+    memset( &d, 0, sizeof( d ) );
+    d.src = src; d.src_stride = src_stride; d.cb = cb; d.cr = cr; d.cstride = cstride;
+    d.planes = s.planes; d.inv_qscale = s.inv_qscale; d.mb_sums = s.mb_sums; d.frame_sums = s.frame_sums;
+    d.qp_aq = s.qp_aq; d.qp = s.qp; d.intra_cost = s.lowres_costs; d.aq_on = aq_on;
+    return d;
+}
+
+// lowres + AQ + intra of n frames: one launch of each kernel (blockIdx.z / blockIdx.x = frame)
 template <typename T>
-static int frame_put_t( x264hip_ctx *ctx, FrameSlot &s, const void *luma, int stride, int is_device, const void *cb, const void *cr,
-                        int cstride, const uint16_t *inv_qscale )
+static int launch_ingest_t( x264hip_ctx *ctx, const PutDesc *descs_dev, const PutDesc &single, int n )
 {
     const x264hip_params &p = ctx->p;
     const LaP &P = ctx->P;
-    const T *src = nullptr;
-    int src_stride = stride;
-    if( is_device )
-        src = (const T *)luma;
-    else
-    {
-        // make sure the staging buffer of the previous frame has been consumed
-        HIPCK( hipStreamSynchronize( ctx->stream ) );
-        for( int y = 0; y < p.height; y++ )
-            memcpy( ctx->staging + (size_t)y * p.width * sizeof( T ), (const T *)luma + (size_t)y * stride, p.width * sizeof( T ) );
-        HIPCK( hipMemcpyAsync( s.luma, ctx->staging, ctx->staging_bytes, hipMemcpyHostToDevice, ctx->stream ) );
-        src = (const T *)s.luma;
-        src_stride = p.width;
-    }
-    {
-        dim3 blk( 256 ), grd( ( ( ctx->lw + 2 * LA_PAD ) / 4 + 255 ) / 256, ctx->lh + 2 * LA_PAD );
-        lowres_kernel<T><<<grd, blk, 0, ctx->stream>>>( src, src_stride, p.width, p.height, (T *)s.planes, P.plane_elems, P.stride, ctx->lw, ctx->lh );
-    }
-    {
-        const float strength = p.aq_strength * 1.0397f;
-        const float bias = 14.427f + 2 * ( p.bit_depth - 8 );
-        const int aq_on = p.aq_mode == 1 && p.aq_strength != 0.f && !inv_qscale;
-        // chroma planes take part in the AQ energy only when the caller supplies device pointers for them
-        aq_kernel<T><<<dim3( P.mb_w, P.mb_h ), 64, 0, ctx->stream>>>( src, src_stride, p.width, p.height, P.mb_w,
-                                                                      is_device ? (const T *)cb : nullptr, is_device ? (const T *)cr : nullptr, cstride,
-                                                                      aq_on, strength, bias, ctx->luts_dev, s.inv_qscale, s.mb_sums, s.qp_aq, s.qp );
-        aq_reduce_kernel<<<1, 1024, 0, ctx->stream>>>( s.mb_sums, ctx->n_mb, s.frame_sums );
-    }
-    if( inv_qscale )
-        HIPCK( hipMemcpyAsync( s.inv_qscale, inv_qscale, ctx->n_mb * sizeof( uint16_t ), hipMemcpyHostToDevice, ctx->stream ) );
-    intra_kernel<T><<<dim3( P.mb_w, P.mb_h ), 64, 0, ctx->stream>>>( P, plane_origin<T>( ctx, s, 0 ), s.lowres_costs );
+    const float strength = p.aq_strength * 1.0397f;
+    const float bias = 14.427f + 2 * ( p.bit_depth - 8 );
+    dim3 grd( ( ( ctx->lw + 2 * LA_PAD ) / 4 + 255 ) / 256, ctx->lh + 2 * LA_PAD, n );
+    lowres_kernel<T><<<grd, 256, 0, ctx->stream>>>( descs_dev, single, p.width, p.height, P.plane_elems, P.stride, ctx->lw, ctx->lh );
+    aq_kernel<T><<<dim3( P.mb_w, P.mb_h, n ), 64, 0, ctx->stream>>>( descs_dev, single, p.width, p.height, P.mb_w, strength, bias, ctx->luts_dev );
+    aq_reduce_kernel<<<n, 1024, 0, ctx->stream>>>( descs_dev, single, ctx->n_mb );
+    intra_kernel<T><<<dim3( P.mb_w, P.mb_h, n ), 64, 0, ctx->stream>>>( P, descs_dev, single );
     HIPCK( hipGetLastError() );
     return X264HIP_OK;
+}
+
+static void slot_reset( x264hip_ctx *ctx, FrameSlot &s )
+{
+    s.in_use = 1;
+    s.stats_valid = 0;
+    memset( s.field_ready, 0, sizeof( s.field_ready ) );
+    memset( s.field_prefetched, 0, sizeof( s.field_prefetched ) );
+    memset( s.field_tag, 0, sizeof( s.field_tag ) );
+    s.cells.assign( ctx->n_cells, CellEntry() );
+    if( s.wplane_idx >= 0 ) { ctx->wplane_owner[s.wplane_idx] = -1; s.wplane_idx = -1; }
+    ctx->counters[3]++;
 }
 
 extern "C" int x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, int stride, int is_device, const void *cb, const void *cr,
@@ -376,16 +380,58 @@ extern "C" int x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, 
     FrameSlot &s = ctx->slots[slot];
     if( ctx->mbt_pending )
         HIPCK( hipStreamWaitEvent( ctx->stream, ctx->ev_mbt_last, 0 ) ); // MB-tree steps may still read this slot's maps
-    s.in_use = 1;
-    s.stats_valid = 0;
-    memset( s.field_ready, 0, sizeof( s.field_ready ) );
-    memset( s.field_prefetched, 0, sizeof( s.field_prefetched ) );
-    memset( s.field_tag, 0, sizeof( s.field_tag ) );
-    s.cells.assign( ctx->n_cells, CellEntry() );
-    if( s.wplane_idx >= 0 ) { ctx->wplane_owner[s.wplane_idx] = -1; s.wplane_idx = -1; }
-    ctx->counters[3]++;
-    return ctx->p.bit_depth == 8 ? frame_put_t<uint8_t>( ctx, s, luma, stride, is_device, cb, cr, cstride, inv_qscale )
-                                 : frame_put_t<uint16_t>( ctx, s, luma, stride, is_device, cb, cr, cstride, inv_qscale );
+    slot_reset( ctx, s );
+    const x264hip_params &p = ctx->p;
+    const void *src = luma;
+    int src_stride = stride;
+    if( !is_device )
+    {
+        // make sure the staging buffer of the previous frame has been consumed
+        HIPCK( hipStreamSynchronize( ctx->stream ) );
+        const size_t row = (size_t)p.width * ctx->psz;
+        for( int y = 0; y < p.height; y++ )
+            memcpy( ctx->staging + (size_t)y * row, (const char *)luma + (size_t)y * stride * ctx->psz, row );
+        HIPCK( hipMemcpyAsync( s.luma, ctx->staging, ctx->staging_bytes, hipMemcpyHostToDevice, ctx->stream ) );
+        src = s.luma;
+        src_stride = p.width;
+    }
+    const int aq_on = p.aq_mode == 1 && p.aq_strength != 0.f && !inv_qscale;
+    // chroma planes take part in the AQ energy only when the caller supplies device pointers for them
+    const PutDesc d = make_put_desc( ctx, s, src, src_stride, is_device ? cb : nullptr, is_device ? cr : nullptr, cstride, aq_on );
+    int rc = p.bit_depth == 8 ? launch_ingest_t<uint8_t>( ctx, nullptr, d, 1 ) : launch_ingest_t<uint16_t>( ctx, nullptr, d, 1 );
+    if( rc ) return rc;
+    if( inv_qscale )
+        HIPCK( hipMemcpyAsync( s.inv_qscale, inv_qscale, ctx->n_mb * sizeof( uint16_t ), hipMemcpyHostToDevice, ctx->stream ) );
+    return X264HIP_OK;
+}
+
+// Batch form for frames already resident on the device: one launch per ingest kernel for all n frames.
+extern "C" int x264hip_frame_put_batch( x264hip_ctx *ctx, int n, const int *slots, const void *const *luma_dev, int stride )
+{
+    if( !ctx || n <= 0 || !slots || !luma_dev || stride < ctx->p.width ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( ctx->mbt_pending )
+        HIPCK( hipStreamWaitEvent( ctx->stream, ctx->ev_mbt_last, 0 ) );
+    const x264hip_params &p = ctx->p;
+    const int aq_on = p.aq_mode == 1 && p.aq_strength != 0.f;
+    for( int o = 0; o < n; o += ctx->put_desc_cap )
+    {
+        const int m = std::min( n - o, ctx->put_desc_cap );
+        HIPCK( hipStreamSynchronize( ctx->stream ) ); // pinned descriptor table reuse
+        for( int i = 0; i < m; i++ )
+        {
+            if( !slot_ok( ctx, slots[o + i] ) || !luma_dev[o + i] ) return X264HIP_EINVAL;
+            FrameSlot &s = ctx->slots[slots[o + i]];
+            slot_reset( ctx, s );
+            ctx->put_desc_host[i] = make_put_desc( ctx, s, luma_dev[o + i], stride, nullptr, nullptr, 0, aq_on );
+        }
+        HIPCK( hipMemcpyAsync( ctx->put_desc_dev, ctx->put_desc_host, (size_t)m * sizeof( PutDesc ), hipMemcpyHostToDevice, ctx->stream ) );
+        PutDesc none;
+        memset( &none, 0, sizeof( none ) );
+        int rc = p.bit_depth == 8 ? launch_ingest_t<uint8_t>( ctx, ctx->put_desc_dev, none, m ) : launch_ingest_t<uint16_t>( ctx, ctx->put_desc_dev, none, m );
+        if( rc ) return rc;
+    }
+    return X264HIP_OK;
 }
 
 extern "C" int x264hip_frame_stats( x264hip_ctx *ctx, int slot, uint64_t *pixel_sum, uint64_t *pixel_ssd )
@@ -912,12 +958,12 @@ extern "C" int x264hip_weight_cost( x264hip_ctx *ctx, int slot_fenc, int slot_re
     const LaP &P = ctx->P;
     const WtD wt = make_wt( ctx, w );
     HIPCK( hipMemsetAsync( ctx->wcost_dev, 0, sizeof( unsigned ), ctx->stream ) );
-    const int grid = ( ctx->n_mb + 3 ) / 4;
+    const int grid = ( ctx->n_mb + 15 ) / 16;
     if( ctx->p.bit_depth == 8 )
-        weight_cost_kernel<uint8_t><<<grid, 64, 0, ctx->stream>>>( P, plane_origin<uint8_t>( ctx, f, 0 ), plane_origin<uint8_t>( ctx, r, 0 ), wt,
+        weight_cost_kernel<uint8_t><<<grid, 256, 0, ctx->stream>>>( P, plane_origin<uint8_t>( ctx, f, 0 ), plane_origin<uint8_t>( ctx, r, 0 ), wt,
                                                                    f.lowres_costs, ctx->wcost_dev );
     else
-        weight_cost_kernel<uint16_t><<<grid, 64, 0, ctx->stream>>>( P, plane_origin<uint16_t>( ctx, f, 0 ), plane_origin<uint16_t>( ctx, r, 0 ), wt,
+        weight_cost_kernel<uint16_t><<<grid, 256, 0, ctx->stream>>>( P, plane_origin<uint16_t>( ctx, f, 0 ), plane_origin<uint16_t>( ctx, r, 0 ), wt,
                                                                     f.lowres_costs, ctx->wcost_dev );
     HIPCK( hipGetLastError() );
     HIPCK( hipMemcpyAsync( ctx->wcost_host, ctx->wcost_dev, sizeof( unsigned ), hipMemcpyDeviceToHost, ctx->stream ) );

@@ -239,12 +239,13 @@ FRAME_COST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_
 PREFETCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int)
 MBTREE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(MbtreeOp), C.c_int)
 QP_OFFSETS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float))
+PUT_BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_int)
 
 
 class Backend(C.Structure):
     _fields_ = [("user", C.c_void_p), ("frame_put", FRAME_PUT_FN), ("frame_stats", FRAME_STATS_FN),
                 ("weight_cost", WEIGHT_COST_FN), ("frame_cost", FRAME_COST_FN), ("prefetch", PREFETCH_FN),
-                ("mbtree", MBTREE_FN), ("get_qp_offsets", QP_OFFSETS_FN)]
+                ("mbtree", MBTREE_FN), ("get_qp_offsets", QP_OFFSETS_FN), ("frame_put_batch", PUT_BATCH_FN)]
 
 
 class LaFrameOut(C.Structure):
@@ -376,6 +377,10 @@ class Lookahead:
         luma = np.ascontiguousarray(luma, self.dtype)
         _ck(self.L.x264hip_lookahead_put_frame(self.h, _p(luma), luma.shape[1], 0, forced_type), "lookahead_put_frame")
 
+    def put_batch(self, device_ptrs, stride=None):
+        arr = (C.c_void_p * len(device_ptrs))(*device_ptrs)
+        _ck(self.L.x264hip_lookahead_put_frames(self.h, len(device_ptrs), arr, stride or self.cfg["width"]), "lookahead_put_frames")
+
     def get(self, flush=False, qp_offsets=False):
         out = LaFrameOut()
         got = C.c_int(0)
@@ -395,7 +400,12 @@ class Lookahead:
         every frame first (deep prefetch) -- results are identical, only the batching differs."""
         outs = []
         n = len(frames) if frames is not None else len(device_ptrs)
-        for i in range(n):
+        if not paced and frames is None:
+            self.put_batch(device_ptrs, stride)  # batch ingest: one launch per ingest kernel
+            n_loop = 0
+        else:
+            n_loop = n
+        for i in range(n_loop):
             if frames is not None:
                 self.put(frames[i])
             else:
