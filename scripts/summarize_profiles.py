@@ -37,10 +37,11 @@ for k in sorted(set(fetch) | set(write)):
     out["kernels"][k] = {"launches": f[0] or w[0], "fetch_bytes_per_launch": f[1] * 1024 / max(f[0], 1), "write_bytes_per_launch": w[1] * 1024 / max(w[0], 1)}
 # calibration on a kernel with known traffic: lowres_kernel reads the 1920x1080 luma once and writes 4 padded planes
 lw = out["kernels"].get("lowres_kernel")
-known_read, known_write = 1920 * 1080, 4 * 608 * 1024
+PMC_FRAMES = 64  # bench.py --frames 64 in the PMC passes: the batched ingest runs lowres_kernel once for all of them
+known_read, known_write = 1920 * 1080 * PMC_FRAMES, 4 * 608 * 1024 * PMC_FRAMES
 cal_r = known_read / lw["fetch_bytes_per_launch"]
 cal_w = known_write / lw["write_bytes_per_launch"]
-out["calibration"] = {"kernel": "lowres_kernel", "known_read_bytes": known_read, "known_write_bytes": known_write,
+out["calibration"] = {"kernel": "lowres_kernel (one launch, %d frames)" % PMC_FRAMES, "known_read_bytes": known_read, "known_write_bytes": known_write,
                       "read_factor": cal_r, "write_factor": cal_w}
 me = out["kernels"]["me_rows_kernel"]
 mb_h = 68
