@@ -36,30 +36,32 @@ def primitives_bench(torch, libmod, cfg, iters=30):
     out = {}
     ctx = libmod.Context(W, H, bit_depth=8, max_frames=2, mv_range=cfg["mv_range"])
     try:
-        Wp, Hp = (W // 16) * 16, (H // 16) * 16
-        stride = Wp + 64
         g = torch.Generator(device="cuda").manual_seed(1)
-        fenc = torch.randint(0, 256, (Hp + 64, stride), dtype=torch.uint8, device="cuda", generator=g)
-        ref = torch.randint(0, 256, (Hp + 64, stride), dtype=torch.uint8, device="cuda", generator=g)
-        org = 32 * stride + 32
-        for size_idx, size in ((0, 16), (3, 8), (6, 4)):
-            bw, bh = Wp // size, Hp // size
-            mv = torch.randint(-16, 17, (bw * bh, 2), dtype=torch.int16, device="cuda", generator=g)
-            res = torch.zeros(bw * bh, dtype=torch.int32, device="cuda")
-            torch.cuda.synchronize()
-            for satd in (0, 1):
-                def run():
-                    rc = ctx.L.x264hip_pixel_cmp_batch(ctx.h, satd, size_idx, C.c_void_p(fenc.data_ptr() + org), C.c_void_p(ref.data_ptr() + org),
-                                                       stride, bw, bh, C.c_void_p(mv.data_ptr()), C.c_void_p(res.data_ptr()))
-                    assert rc == 0
-                run(); ctx.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(iters):
-                    run()
-                ctx.synchronize()
-                dt = (time.perf_counter() - t0) / iters
-                nbytes = bw * bh * (2 * size * size + 4)  # SURVEY 8(d) per-block form: both blocks + the result
-                out["%s_%dx%d_GBps" % ("satd" if satd else "sad", size, size)] = round(nbytes / dt / 1e9, 1)
+        # one frame pair, and a 4x4 mosaic of frame pairs (265 MB: larger than the 256 MB Infinity Cache, so the
+        # figure is an HBM rate and the launch overhead of a 3 us kernel does not dominate it)
+        for tag, mul in (("", 1), ("_x16", 4)):
+            Wp, Hp = (W // 16) * 16 * mul, (H // 16) * 16 * mul
+            stride = Wp + 64
+            fenc = torch.randint(0, 256, (Hp + 64, stride), dtype=torch.uint8, device="cuda", generator=g)
+            ref = torch.randint(0, 256, (Hp + 64, stride), dtype=torch.uint8, device="cuda", generator=g)
+            org = 32 * stride + 32
+            for size_idx, size in ((0, 16), (3, 8), (6, 4)):
+                bw, bh = Wp // size, Hp // size
+                mv = torch.randint(-16, 17, (bw * bh, 2), dtype=torch.int16, device="cuda", generator=g)
+                res = torch.zeros(bw * bh, dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()
+                for satd in (0, 1):
+                    def run():
+                        ctx.pixel_cmp_batch(satd, size_idx, fenc.data_ptr() + org, ref.data_ptr() + org, stride, bw, bh, mv.data_ptr(), res.data_ptr())
+                    run(); ctx.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(iters):
+                        run()
+                    ctx.synchronize()
+                    dt = (time.perf_counter() - t0) / iters
+                    nbytes = bw * bh * (2 * size * size + 4)  # SURVEY 8(d) per-block form: both blocks + the result
+                    out["%s_%dx%d%s_GBps" % ("satd" if satd else "sad", size, size, tag)] = round(nbytes / dt / 1e9, 1)
+            del fenc, ref
         luma = torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda", generator=g)
         torch.cuda.synchronize()
         ctx.frame_put(0, None, device_ptr=luma.data_ptr(), stride=W); ctx.synchronize()

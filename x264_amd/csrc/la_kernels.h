@@ -576,46 +576,118 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
 }
 
 // ---- batched vtable primitives: SAD / SATD of every block of a plane against a displaced reference ----
-// One wave covers a 16x16 pixel region: a 16-lane row is an 8x8 quadrant, a DPP quad a 4x4 tile, so all
-// three block sizes reduce without LDS: 4x4 -> quad, 8x8 -> row, 16x16 -> the four rows of the wave.
+// Streaming layout: a lane owns one 16-sample row segment (one 16-byte load for 8-bit pixels) of a 16x16
+// region, 16 lanes are the 16 rows of the region, a wave covers four horizontally adjacent regions, so one
+// wave-wide load instruction touches 16 full 64-byte lines of the fenc plane.  A DPP quad is four consecutive
+// rows, i.e. the rows of a 4x4 tile: the vertical Hadamard and all three block sizes reduce without LDS
+// (4x4 -> quad, 8x8 -> quad + half-row mirror, 16x16 -> + row mirror).
+#define DPP_ROW_MIRROR 0x140
+#define DPP_ROW_HALF_MIRROR 0x141
+
 template <typename T>
-__global__ __launch_bounds__( 64 ) void pixel_cmp_batch_kernel( const T *__restrict__ fenc, const T *__restrict__ ref, int stride,
-                                                                int regions_w, int regions_h, int size /* 16, 8, 4 */, int use_satd,
-                                                                const int16_t *__restrict__ mv, int *__restrict__ out )
+__device__ __forceinline__ void load_row16( const T *p, Px4 f[4] );
+template <>
+__device__ __forceinline__ void load_row16<uint8_t>( const uint8_t *p, Px4 f[4] )
+{
+    uint4 w;
+    __builtin_memcpy( &w, p, 16 );
+    f[0] = px4_from_raw( w.x ); f[1] = px4_from_raw( w.y ); f[2] = px4_from_raw( w.z ); f[3] = px4_from_raw( w.w );
+}
+template <>
+__device__ __forceinline__ void load_row16<uint16_t>( const uint16_t *p, Px4 f[4] )
+{
+    uint4 w0, w1;
+    __builtin_memcpy( &w0, p, 16 );
+    __builtin_memcpy( &w1, p + 8, 16 );
+    f[0].a = w0.x; f[0].b = w0.y; f[1].a = w0.z; f[1].b = w0.w;
+    f[2].a = w1.x; f[2].b = w1.y; f[3].a = w1.z; f[3].b = w1.w;
+    f[0].raw = f[1].raw = f[2].raw = f[3].raw = 0;
+}
+template <typename T>
+__device__ __forceinline__ void load_row8( const T *p, Px4 f[2] );
+template <>
+__device__ __forceinline__ void load_row8<uint8_t>( const uint8_t *p, Px4 f[2] )
+{
+    uint2 w;
+    __builtin_memcpy( &w, p, 8 );
+    f[0] = px4_from_raw( w.x ); f[1] = px4_from_raw( w.y );
+}
+template <>
+__device__ __forceinline__ void load_row8<uint16_t>( const uint16_t *p, Px4 f[2] )
+{
+    uint4 w;
+    __builtin_memcpy( &w, p, 16 );
+    f[0].a = w.x; f[0].b = w.y; f[1].a = w.z; f[1].b = w.w;
+    f[0].raw = f[1].raw = 0;
+}
+
+template <typename T, int SIZE, bool SATD>
+__global__ __launch_bounds__( 256 ) void pixel_cmp_batch_kernel( const T *__restrict__ fenc, const T *__restrict__ ref, int stride,
+                                                                 int regions_w, const int16_t *__restrict__ mv, int *__restrict__ out )
 {
     const int lane = lane_id();
-    const int rx = blockIdx.x, ry = blockIdx.y;
-    const int g = lane >> 4, l = lane & 15, q = l >> 2;
-    // quadrant g at ((g&1)*8, (g>>1)*8); inside it the usual tile/row split
-    const int px = ( g & 1 ) * 8 + ( q & 1 ) * 4, py = ( g >> 1 ) * 8 + ( q >> 1 ) * 4 + ( l & 3 );
-    const int bpr = 16 / size; // blocks per region side
-    const int bw = regions_w * bpr;
-    const int bxi = rx * bpr + px / size, byi = ry * bpr + py / size;
-    const int bi = byi * bw + bxi;
-    const int mvx = mv[2 * bi], mvy = mv[2 * bi + 1];
-    const size_t o = (size_t)( ry * 16 + py ) * stride + rx * 16 + px;
-    const Px4 f = load_px4( fenc + o );
-    const Px4 r = load_px4( ref + o + mvy * stride + mvx );
-    int part = use_satd ? satd_partial_px4( f, r ) : sad_partial_px4( f, r, (const T *)nullptr );
-    part = reduce_quad( part );
-    if( size == 4 )
+    const int rx0 = ( blockIdx.x * 4 + ( threadIdx.x >> 6 ) ) * 4;
+    if( rx0 >= regions_w )
+        return; // wave-uniform
+    const int rx = rx0 + ( lane >> 4 ), ry = blockIdx.y, row = lane & 15;
+    const bool live = rx < regions_w;
+    const int rxc = live ? rx : regions_w - 1; // keep every lane in the DPP exchanges
+    constexpr int BPR = 16 / SIZE;
+    const int bw = regions_w * BPR;
+    const int by = ry * BPR + row / SIZE;
+    const size_t o = (size_t)( ry * 16 + row ) * stride + rxc * 16;
+    Px4 f[4], r[4];
+    load_row16<T>( fenc + o, f );
+    int bi[BPR];
+#pragma unroll
+    for( int k = 0; k < BPR; k++ )
     {
-        if( ( lane & 3 ) == 0 )
-            out[bi] = use_satd ? part >> 1 : part;
+        bi[k] = by * bw + rxc * BPR + k;
+        int m;
+        __builtin_memcpy( &m, mv + 2 * bi[k], 4 );
+        const T *rp = ref + (long)o + ( m >> 16 ) * stride + (int16_t)m + k * SIZE;
+        if( SIZE == 16 )
+            load_row16<T>( rp, r );
+        else if( SIZE == 8 )
+            load_row8<T>( rp, r + 2 * k );
+        else
+            r[k] = load_px4( rp );
+    }
+    int part[4];
+#pragma unroll
+    for( int t = 0; t < 4; t++ )
+        part[t] = SATD ? satd_partial_px4( f[t], r[t] ) : sad_partial_px4( f[t], r[t], (const T *)nullptr );
+    if( SIZE == 4 )
+    {
+        int mine = 0, idx = 0;
+#pragma unroll
+        for( int t = 0; t < 4; t++ )
+        {
+            const int v = reduce_quad( part[t] );
+            if( ( lane & 3 ) == t ) { mine = v; idx = bi[t]; }
+        }
+        if( live )
+            out[idx] = SATD ? mine >> 1 : mine;
         return;
     }
-    part += dpp_mov<DPP_ROW_ROR4>( part );
-    part += dpp_mov<DPP_ROW_ROR8>( part );
-    if( size == 8 )
+    if( SIZE == 8 )
     {
-        if( l == 0 )
-            out[bi] = use_satd ? part >> 1 : part;
+        int v0 = reduce_quad( part[0] + part[1] ), v1 = reduce_quad( part[2] + part[3] );
+        v0 += dpp_mov<DPP_ROW_HALF_MIRROR>( v0 );
+        v1 += dpp_mov<DPP_ROW_HALF_MIRROR>( v1 );
+        const int sel = lane & 7;
+        if( live && sel < 2 )
+        {
+            const int v = sel ? v1 : v0;
+            out[bi[sel ? BPR - 1 : 0]] = SATD ? v >> 1 : v;
+        }
         return;
     }
-    int tot = __builtin_amdgcn_readlane( part, 0 ) + __builtin_amdgcn_readlane( part, 16 ) + __builtin_amdgcn_readlane( part, 32 ) +
-              __builtin_amdgcn_readlane( part, 48 );
-    if( lane == 0 )
-        out[bi] = use_satd ? tot >> 1 : tot;
+    int v = reduce_quad( part[0] + part[1] + part[2] + part[3] );
+    v += dpp_mov<DPP_ROW_HALF_MIRROR>( v );
+    v += dpp_mov<DPP_ROW_MIRROR>( v );
+    if( live && row == 0 )
+        out[bi[0]] = SATD ? v >> 1 : v;
 }
 
 // ---- D1/Q1 as batched primitives (common/dct.c:157-205,332-386, common/quant.c:50-104) -----------------

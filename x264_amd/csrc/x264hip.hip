@@ -1083,12 +1083,21 @@ extern "C" int x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx
     if( !size || ( blocks_w * size ) % 16 || ( blocks_h * size ) % 16 ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
     const int rw = blocks_w * size / 16, rh = blocks_h * size / 16;
+    const dim3 grd( ( rw + 15 ) / 16, rh );
+#define CMP_LAUNCH( T, S, D ) \
+    pixel_cmp_batch_kernel<T, S, D><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, mv_dev, out_dev )
+#define CMP_SIZE( T ) \
+    do { \
+        if( size == 16 ) { if( satd ) CMP_LAUNCH( T, 16, true ); else CMP_LAUNCH( T, 16, false ); } \
+        else if( size == 8 ) { if( satd ) CMP_LAUNCH( T, 8, true ); else CMP_LAUNCH( T, 8, false ); } \
+        else { if( satd ) CMP_LAUNCH( T, 4, true ); else CMP_LAUNCH( T, 4, false ); } \
+    } while( 0 )
     if( ctx->p.bit_depth == 8 )
-        pixel_cmp_batch_kernel<uint8_t><<<dim3( rw, rh ), 64, 0, ctx->stream>>>( (const uint8_t *)fenc_plane, (const uint8_t *)ref_plane, stride, rw, rh,
-                                                                                 size, satd, mv_dev, out_dev );
+        CMP_SIZE( uint8_t );
     else
-        pixel_cmp_batch_kernel<uint16_t><<<dim3( rw, rh ), 64, 0, ctx->stream>>>( (const uint16_t *)fenc_plane, (const uint16_t *)ref_plane, stride, rw,
-                                                                                  rh, size, satd, mv_dev, out_dev );
+        CMP_SIZE( uint16_t );
+#undef CMP_SIZE
+#undef CMP_LAUNCH
     HIPCK( hipGetLastError() );
     return X264HIP_OK;
 }

@@ -209,6 +209,25 @@ class Context:
         arr = (MbtreeOp * len(ops))(*ops)
         _ck(self.L.x264hip_mbtree(self.h, arr, len(ops)), "mbtree")
 
+    # ---- batched vtable primitives (device pointers are plain integers) ----
+    def pixel_cmp_batch(self, satd, size_idx, fenc_ptr, ref_ptr, stride, blocks_w, blocks_h, mv_ptr, out_ptr):
+        _ck(self.L.x264hip_pixel_cmp_batch(self.h, int(satd), int(size_idx), C.c_void_p(fenc_ptr), C.c_void_p(ref_ptr), int(stride),
+                                           int(blocks_w), int(blocks_h), C.c_void_p(mv_ptr), C.c_void_p(out_ptr)), "pixel_cmp_batch")
+
+    def frame_init_lowres_core(self, src_ptr, dst_ptrs, src_stride, dst_stride, width, height):
+        _ck(self.L.x264hip_frame_init_lowres_core(self.h, C.c_void_p(src_ptr), *[C.c_void_p(p) for p in dst_ptrs], C.c_ssize_t(src_stride),
+                                                  C.c_ssize_t(dst_stride), int(width), int(height)), "frame_init_lowres_core")
+
+    def dct_quant_batch(self, is8x8, fenc, fdec, mf, bias):
+        """fenc: (n, N, 16) pixels, fdec: (n, N, 32) pixels (host arrays); returns (coefs (n, N*N), nz (n,))."""
+        n, N = fenc.shape[0], 8 if is8x8 else 4
+        cdt = np.int16 if self.params.bit_depth == 8 else np.int32
+        fenc = np.ascontiguousarray(fenc, self.dtype); fdec = np.ascontiguousarray(fdec, self.dtype)
+        mf = np.ascontiguousarray(mf); bias = np.ascontiguousarray(bias)
+        coefs = np.zeros((n, N * N), cdt); nz = np.zeros(n, np.int32)
+        _ck(self.L.x264hip_dct_quant_batch(self.h, int(is8x8), n, _p(fenc), _p(fdec), _p(mf), _p(bias), _p(coefs), _p(nz)), "dct_quant_batch")
+        return coefs, nz
+
     def last_search_ms(self):
         ms, ns, nb = C.c_float(), C.c_int(), C.c_int()
         _ck(self.L.x264hip_last_search_ms(self.h, C.byref(ms), C.byref(ns), C.byref(nb)), "last_search_ms")
