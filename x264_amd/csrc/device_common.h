@@ -124,6 +124,40 @@ __device__ __forceinline__ Px4 load_px4( const uint16_t *p )
     r.a = w.x; r.b = w.y; r.raw = 0;
     return r;
 }
+// Loads through a wave-uniform base pointer plus an unsigned 32-bit byte offset: the backend emits the
+// `global_load_* v, v_off, s[base:base+1]` form (no 64-bit VALU address arithmetic, no flat aperture check).
+#define AS_GLOBAL __attribute__( ( address_space( 1 ) ) )
+__device__ __forceinline__ uint32_t gload_u32( const void *ubase, unsigned byte_off )
+{
+    uint32_t w;
+    __builtin_memcpy( &w, (const AS_GLOBAL char *)ubase + byte_off, 4 );
+    return w;
+}
+__device__ __forceinline__ uint2 gload_u64( const void *ubase, unsigned byte_off )
+{
+    uint2 w;
+    __builtin_memcpy( &w, (const AS_GLOBAL char *)ubase + byte_off, 8 );
+    return w;
+}
+__device__ __forceinline__ int gload_u16( const void *ubase, unsigned byte_off )
+{
+    uint16_t w;
+    __builtin_memcpy( &w, (const AS_GLOBAL char *)ubase + byte_off, 2 );
+    return w;
+}
+__device__ __forceinline__ Px4 load_px4_at( const uint8_t *ubase, int elem_off )
+{
+    return px4_from_raw( gload_u32( ubase, (unsigned)elem_off ) );
+}
+__device__ __forceinline__ Px4 load_px4_at( const uint16_t *ubase, int elem_off )
+{
+    const uint2 w = gload_u64( ubase, (unsigned)elem_off << 1 );
+    Px4 r;
+    r.a = w.x; r.b = w.y; r.raw = 0;
+    return r;
+}
+__device__ __forceinline__ int mad24( int a, int b, int c ) { return __mul24( a, b ) + c; }
+
 __device__ __forceinline__ void load4( const uint8_t *p, int v[4] )
 {
     uint32_t w;
@@ -181,6 +215,22 @@ __device__ __forceinline__ Px4 qpel_px4( const T *p0, int plane_elems, int strid
     const T *a = p0 + (size_t)pa * plane_elems + ( iy + ( fy == 3 ) ) * stride + ix;
     const T *b = p0 + (size_t)pb * plane_elems + iy * stride + ix + ( fx == 3 );
     return avg_px4( load_px4( a ), load_px4( b ), (const T *)nullptr );
+}
+
+// Same samples addressed as element offsets from a wave-uniform base (the start of the frame's four-plane
+// allocation): lane_off = this lane's 4 samples of the block at zero displacement, in plane 0.
+// The plane pair of each of the 16 quarter-pel phases comes from two 32-bit lookup constants.
+template <typename T>
+__device__ __forceinline__ Px4 qpel_px4_at( const T *ubase, int plane_elems, int stride, int lane_off, int mvx, int mvy )
+{
+    const int fx = mvx & 3, fy = mvy & 3;
+    const int sh = 2 * ( fx | ( fy << 2 ) );
+    // pa = (fx ? 1 : 0) + (fy == 2 ? 2 : 0), pb = (fx == 2 ? 1 : 0) + (fy ? 2 : 0), two bits per phase
+    const unsigned pa = ( 0x54FE5454u >> sh ) & 3u, pb = ( 0xBABABA10u >> sh ) & 3u;
+    const int o = lane_off + mad24( mvy >> 2, stride, mvx >> 2 );
+    const int oa = mad24( (int)pa, plane_elems, o ) + ( fy == 3 ? stride : 0 );
+    const int ob = mad24( (int)pb, plane_elems, o ) + ( fx == 3 );
+    return avg_px4( load_px4_at( ubase, oa ), load_px4_at( ubase, ob ), (const T *)nullptr );
 }
 
 // ---- block metrics on the 16-lane layout -----------------------------------------------------------

@@ -12,10 +12,12 @@
 template <typename T>
 struct MeBlk
 {
-    const T *ref0;  // reference plane 0 at the block origin (unweighted; planes 1..3 follow)
-    const T *refw;  // plane used by full-pel candidates: weighted plane 0 or ref0
+    const T *rbase; // wave-uniform: start of the reference frame's four-plane allocation (unweighted)
+    const T *wbase; // wave-uniform: plane read by full-pel candidates (weighted copy of plane 0, or rbase)
+    const uint16_t *tab; // wave-uniform: first entry of the cost_mv table
+    int lane_off;   // element offset of this lane's 4 samples of the block at zero displacement (plane 0)
+    int tab_x, tab_y; // table index of a quarter-pel component q is q + tab_x / q + tab_y
     Px4 f;          // this lane's 4 source pixels
-    int tx, row;    // this lane's position inside the 8x8 block
     int g;          // candidate group 0..3
     int mvpx, mvpy;
     int smin_x, smin_y, smax_x, smax_y; // quarter-pel limits
@@ -25,26 +27,28 @@ struct MeBlk
 template <typename T>
 __device__ __forceinline__ int mv_bits( const LaP &P, const MeBlk<T> &B, int qx, int qy )
 {
-    return P.cost_mv[qx - B.mvpx] + P.cost_mv[qy - B.mvpy];
+    return gload_u16( B.tab, 2u * (unsigned)( qx + B.tab_x ) ) + gload_u16( B.tab, 2u * (unsigned)( qy + B.tab_y ) );
 }
 
 // cost of this lane group's full-pel candidate (cx,cy); bits included when with_bits
 template <typename T>
 __device__ __forceinline__ int fpel_cost( const LaP &P, const MeBlk<T> &B, int cx, int cy, int with_bits )
 {
-    const Px4 r = load_px4( B.refw + ( cy + B.row ) * P.stride + cx + B.tx );
-    int c = block_cost8x8<T>( B.f, r, P.fpelcmp_satd );
-    return with_bits ? c + mv_bits( P, B, 4 * cx, 4 * cy ) : c;
+    // the table lookups are issued before the pixel load is consumed: one memory latency per round
+    const int bits = mv_bits( P, B, 4 * cx, 4 * cy );
+    const Px4 r = load_px4_at( B.wbase, B.lane_off + mad24( cy, P.stride, cx ) );
+    return block_cost8x8<T>( B.f, r, P.fpelcmp_satd ) + ( with_bits ? bits : 0 );
 }
 
 // cost of this lane group's quarter-pel candidate (qx,qy) with get_ref semantics (mc.c:218-249)
 template <typename T>
 __device__ __forceinline__ int qpel_cost( const LaP &P, const MeBlk<T> &B, const WtD &wt, int qx, int qy, int use_satd )
 {
-    Px4 r = qpel_px4( B.ref0, P.plane_elems, P.stride, B.tx, B.row, qx, qy );
+    const int bits = mv_bits( P, B, qx, qy );
+    Px4 r = qpel_px4_at( B.rbase, P.plane_elems, P.stride, B.lane_off, qx, qy );
     if( wt.on )
         r = weight_px4<T>( r, wt, P.pixel_max );
-    return block_cost8x8<T>( B.f, r, use_satd ) + mv_bits( P, B, qx, qy );
+    return block_cost8x8<T>( B.f, r, use_satd ) + bits;
 }
 
 #define GRP_COST( v, k ) __builtin_amdgcn_readlane( v, 16 * ( k ) )
@@ -365,16 +369,26 @@ struct SearchDesc
 // not by L2 misses, so the plain one-wave workgroup stays the default.
 #define ME_WG_ROWS 1
 template <typename T>
-__global__ __launch_bounds__( 64 * ME_WG_ROWS ) void me_rows_kernel( LaP P, const SearchDesc<T> *descs, int n_search,
+__global__ __launch_bounds__( 64 * ME_WG_ROWS ) __attribute__( ( amdgpu_waves_per_eu( 8, 8 ) ) ) void me_rows_kernel( LaP P, const SearchDesc<T> *descs, int n_search,
                                                                     unsigned *sync_words /* [0] ticket, [1] error */, unsigned spin_limit )
 {
-    __shared__ unsigned wg_ticket;
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
+#if ME_WG_ROWS == 1
+    // the ticket is wave-uniform: fetch it on lane 0 and broadcast through an SGPR so that the row index, the
+    // descriptor and everything derived from them stay scalar
+    const int wave = 0;
+    unsigned t0 = 0;
+    if( lane == 0 )
+        t0 = atomicAdd( &sync_words[0], 1u );
+    const unsigned t = __builtin_amdgcn_readfirstlane( t0 );
+#else
+    __shared__ unsigned wg_ticket;
+    const int wave = __builtin_amdgcn_readfirstlane( threadIdx.x >> 6 );
     if( threadIdx.x == 0 )
         wg_ticket = atomicAdd( &sync_words[0], 1u );
     __syncthreads();
-    const unsigned t = wg_ticket;
+    const unsigned t = __builtin_amdgcn_readfirstlane( wg_ticket );
+#endif
     const int row_groups = ( P.mb_h + ME_WG_ROWS - 1 ) / ME_WG_ROWS;
     if( t >= (unsigned)( n_search * row_groups ) )
         return;
@@ -388,11 +402,17 @@ __global__ __launch_bounds__( 64 * ME_WG_ROWS ) void me_rows_kernel( LaP P, cons
 
     MeBlk<T> B;
     B.g = lane >> 4;
+    int row_off; // this lane's 4 samples inside an 8x8 block
     {
         int l = lane & 15, q = l >> 2;
-        B.tx = ( q & 1 ) * 4;
-        B.row = ( q >> 1 ) * 4 + ( l & 3 );
+        row_off = ( ( q >> 1 ) * 4 + ( l & 3 ) ) * P.stride + ( q & 1 ) * 4;
     }
+    const int border = LA_PAD * P.stride + LA_PAD;
+    const T *fbase = D.fenc0 - border;
+    B.rbase = D.ref0 - border;
+    B.wbase = D.wt.on ? D.refw - border : B.rbase;
+    const int tab_centre = 2 * 4 * P.mv_range;
+    B.tab = P.cost_mv - tab_centre;
     const int range = 2 * P.mv_range;
     B.smin_y = imax2( 4 * ( -8 * by - 12 ), -range );
     B.smax_y = imin2( 4 * ( 8 * ( H - by - 1 ) + 12 ), range - 1 );
@@ -403,7 +423,7 @@ __global__ __launch_bounds__( 64 * ME_WG_ROWS ) void me_rows_kernel( LaP P, cons
     for( int bx = W - 1; bx >= 0; bx-- )
     {
         const int xy = by * W + bx;
-        const int off = 8 * ( by * P.stride + bx );
+        B.lane_off = border + 8 * ( by * P.stride + bx ) + row_off;
         int nbx[3] = { 0, 0, 0 }, nby[3] = { 0, 0, 0 }; // below, below-left, below-right
         if( by < H - 1 )
         {
@@ -457,16 +477,16 @@ __global__ __launch_bounds__( 64 * ME_WG_ROWS ) void me_rows_kernel( LaP P, cons
         B.smax_x = imin2( 4 * ( 8 * ( W - bx - 1 ) + 12 ), range - 1 );
         B.fmin_x = B.smin_x >> 2;
         B.fmax_x = B.smax_x >> 2;
-        B.ref0 = D.ref0 + off;
-        B.refw = D.wt.on ? D.refw + off : B.ref0;
-        B.f = load_px4( D.fenc0 + off + B.row * P.stride + B.tx );
+        B.tab_x = tab_centre - B.mvpx;
+        B.tab_y = tab_centre - B.mvpy;
+        B.f = load_px4_at( fbase, B.lane_off );
 
         int mvx = 0, mvy = 0, cost = 0;
         bool done = false;
         if( !( B.mvpx | B.mvpy ) )
         {
             // near-zero residual shortcut on the unweighted plane (slicetype.c:684-692)
-            const Px4 r = load_px4( B.ref0 + B.row * P.stride + B.tx );
+            const Px4 r = load_px4_at( B.rbase, B.lane_off );
             cost = GRP_COST( block_cost8x8<T>( B.f, r, P.mbcmp_satd ), 0 );
             done = cost < 64;
         }
