@@ -229,7 +229,9 @@ def main():
                          "launches": prof_launches, "searches": prof_searches, "avg_launch_ms": round(prof_ms / max(prof_launches, 1), 4),
                          "algorithmic_bytes_per_search": bytes_per_search},
             "lookahead_stats": {"frame_cost_calls": int(la_stats[0]), "evaluations": int(la_stats[1]),
-                                "weights_analysed": int(la_stats[2]), "weights_kept": int(la_stats[3])},
+                                "weights_analysed": int(la_stats[2]), "weights_kept": int(la_stats[3]),
+                                "host_ms": {"frame_cost": round(la_stats[4] / 1e6, 2), "weights_analyse": round(la_stats[5] / 1e6, 2),
+                                            "prefetch_mbtree": round(la_stats[6] / 1e6, 2), "api_total": round(la_stats[7] / 1e6, 2)}},
         }
         if not args.no_primitives:
             try:

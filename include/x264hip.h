@@ -258,7 +258,8 @@ int  x264hip_lookahead_get_frame( x264hip_lookahead *la, int flush, x264hip_la_f
 /* same, additionally copying the frame's f_qp_offset map (mb_w*mb_h floats, MB-tree output read by rate control,
  * encoder/ratecontrol.c:1761) when qp_offset != NULL and mb_tree is on */
 int  x264hip_lookahead_get_frame_ex( x264hip_lookahead *la, int flush, x264hip_la_frame *out, int *got, float *qp_offset );
-/* statistics: [0] slicetype_frame_cost calls, [1] real evaluations, [2] weights analysed, [3] weights kept */
+/* statistics: [0] slicetype_frame_cost calls, [1] real evaluations, [2] weights analysed, [3] weights kept,
+ * wall time in ns spent in [4] backend frame_cost, [5] weights_analyse, [6] backend prefetch + mbtree, [7] the put/get calls in total */
 int  x264hip_lookahead_stats( x264hip_lookahead *la, uint64_t *out, int n );
 
 #ifdef __cplusplus

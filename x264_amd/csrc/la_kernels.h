@@ -351,7 +351,8 @@ __global__ __launch_bounds__( 256 ) void weight_plane_kernel( const T *__restric
 // blocks per wave, sixteen per workgroup; one atomic per workgroup after an LDS reduction.
 template <typename T>
 __global__ __launch_bounds__( 256 ) void weight_cost_kernel( LaP P, const T *__restrict__ fenc0, const T *__restrict__ ref0, WtD w,
-                                                             const uint16_t *__restrict__ intra_cost, unsigned *out )
+                                                             const uint16_t *__restrict__ intra_cost, unsigned *accum /* device [2] */,
+                                                             unsigned *out_host /* pinned */ )
 {
     __shared__ unsigned part[4];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -375,7 +376,18 @@ __global__ __launch_bounds__( 256 ) void weight_cost_kernel( LaP P, const T *__r
     if( lane == 0 ) part[wave] = tot;
     __syncthreads();
     if( threadIdx.x == 0 )
-        atomicAdd( out, part[0] + part[1] + part[2] + part[3] );
+    {
+        // the workgroup that arrives last publishes the total to the host and re-arms the two counters
+        atomicAdd( &accum[0], part[0] + part[1] + part[2] + part[3] );
+        __threadfence();
+        if( atomicAdd( &accum[1], 1u ) == gridDim.x - 1 )
+        {
+            __threadfence();
+            const unsigned tot = atomicExch( &accum[0], 0u );
+            atomicExch( &accum[1], 0u );
+            __hip_atomic_store( out_host, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+        }
+    }
 }
 
 // ---- mode selection and reductions (slicetype.c:616-652,708-712,758-790,946-985) ----------------------

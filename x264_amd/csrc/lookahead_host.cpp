@@ -9,6 +9,7 @@
 #include <string.h>
 #include <math.h>
 #include <deque>
+#include <chrono>
 #include <vector>
 
 #include "x264hip.h"
@@ -24,6 +25,15 @@ static inline bool auto_or_b( int t ) { return t == T_AUTO || is_b( t ); }
 const int BMAX = X264HIP_BFRAME_MAX;
 const int LOOKAHEAD_MAX = 250; // X264_LOOKAHEAD_MAX, common/base.h:140
 const uint64_t COST_MAX64 = 1ULL << 60;
+
+// adds the wall time of its scope to a statistics slot (x264hip_lookahead_stats)
+struct ScopeNs
+{
+    uint64_t &acc;
+    std::chrono::steady_clock::time_point t0;
+    explicit ScopeNs( uint64_t &a ) : acc( a ), t0( std::chrono::steady_clock::now() ) {}
+    ~ScopeNs() { acc += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>( std::chrono::steady_clock::now() - t0 ).count(); }
+};
 
 struct LaFrame
 {
@@ -121,6 +131,7 @@ struct Lookahead
         const int with_intra = !fenc->intra_calculated;
         const int ref1_valid = b < p1 && frames[p1]->searched[0][p1 - p0 - 1];
         stats[1]++;
+        ScopeNs tm( stats[4] );
         if( need( be.frame_cost( be.user, frames[p0]->slot, frames[p1]->slot, fenc->slot, b - p0, p1 - b, do_search, w, with_intra,
                                  ref1_valid, &out ) ) )
             return 0;
@@ -201,6 +212,7 @@ struct Lookahead
         }
         if( err ) { wt.on = 0; return; }
         unsigned minscore = 0, origscore = 0;
+        ScopeNs tm( stats[5] );
         if( need( be.weight_cost( be.user, fenc->slot, ref->slot, nullptr, &origscore ) ) ) { wt.on = 0; return; }
         minscore = origscore;
         if( !minscore ) { wt.on = 0; wt.scale = 1; wt.denom = 0; wt.offset = 0; /* keeps the guessed values off */ return; }
@@ -451,6 +463,7 @@ struct Lookahead
                 mbt_finish( ops, frames[last_nonb + ( bframes + 1 ) / 2], average_duration, 0 );
         }
         if( be.mbtree && !ops.empty() && !err )
+            ScopeNs tm( stats[6] );
             need( be.mbtree( be.user, ops.data(), (int)ops.size() ) );
     }
 
@@ -756,6 +769,7 @@ struct Lookahead
             slots.push_back( next[i]->slot ); nums.push_back( next[i]->i_frame );
             next[i]->prefetch_submitted = true;
         }
+        ScopeNs tm( stats[6] );
         need( be.prefetch( be.user, slots.data(), nums.data(), (int)slots.size() ) );
     }
 };
@@ -898,6 +912,7 @@ extern "C" int x264hip_lookahead_put_frames( x264hip_lookahead *la, int n, const
 {
     if( !la || n <= 0 || !luma_dev ) return X264HIP_EINVAL;
     Lookahead &L = la->L;
+    ScopeNs tm_api( L.stats[7] );
     if( L.err ) return L.err;
     if( !L.be.frame_put_batch )
     {
@@ -931,6 +946,7 @@ extern "C" int x264hip_lookahead_put_frame( x264hip_lookahead *la, const void *l
 {
     if( !la || !luma ) return X264HIP_EINVAL;
     Lookahead &L = la->L;
+    ScopeNs tm_api( L.stats[7] );
     if( L.err ) return L.err;
     if( L.free_slots.empty() ) return X264HIP_ESTATE;
     LaFrame *f = new_frame( L, forced_type );
@@ -956,6 +972,7 @@ extern "C" int x264hip_lookahead_get_frame_ex( x264hip_lookahead *la, int flush,
 {
     if( !la || !out || !got ) return X264HIP_EINVAL;
     Lookahead &L = la->L;
+    ScopeNs tm_api( L.stats[7] );
     *got = 0;
     if( L.err ) return L.err;
     // encoder.c:3428-3433: nothing to encode while the lookahead delay fills

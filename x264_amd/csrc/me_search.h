@@ -370,7 +370,8 @@ struct SearchDesc
 #define ME_WG_ROWS 1
 template <typename T>
 __global__ __launch_bounds__( 64 * ME_WG_ROWS ) __attribute__( ( amdgpu_waves_per_eu( 8, 8 ) ) ) void me_rows_kernel( LaP P, const SearchDesc<T> *descs, int n_search,
-                                                                    unsigned *sync_words /* [0] ticket, [1] error */, unsigned spin_limit )
+                                                                    unsigned *sync_words /* [0] row ticket */,
+                                                                    unsigned *err_host /* pinned sticky timeout flag */, unsigned spin_limit )
 {
     const int lane = lane_id();
 #if ME_WG_ROWS == 1
@@ -444,7 +445,7 @@ __global__ __launch_bounds__( 64 * ME_WG_ROWS ) __attribute__( ( amdgpu_waves_pe
                 if( ++spins > spin_limit )
                 {
                     if( lane == 0 )
-                        atomicExch( &sync_words[1], 1u );
+                        __hip_atomic_store( err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
                     return;
                 }
                 __builtin_amdgcn_s_sleep( 4 );

@@ -66,6 +66,17 @@ struct FrameSlot
     int stats_valid = 0;
 };
 
+// Pinned-host / device descriptor tables are handed out round-robin; an entry is reused only after the event
+// recorded behind its last consumer has completed, so filling the next table never waits for the stream.
+struct DescRing
+{
+    static const int K = 4;
+    char *host[K] = { nullptr, nullptr, nullptr, nullptr }, *dev[K] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t ev[K] = { nullptr, nullptr, nullptr, nullptr };
+    bool used[K] = { false, false, false, false };
+    int next = 0;
+};
+
 struct x264hip_ctx
 {
     x264hip_params p;
@@ -83,10 +94,9 @@ struct x264hip_ctx
     unsigned *sync_words = nullptr;  // device [2]
     int *acc_dev = nullptr;          // [8]
     int n_cells = 0;                 // (bframes+2)^2
-    int *cell_acc_dev = nullptr;     // [slots][n_cells][8] sums of every cell evaluation
-    int *cell_acc_host = nullptr;    // pinned mirror
-    CellArgs *cell_desc_dev = nullptr, *cell_desc_host = nullptr;
-    PutDesc *put_desc_dev = nullptr, *put_desc_host = nullptr;
+    int *cell_acc_host = nullptr;    // pinned [slots][n_cells][8]: sums of every cell evaluation, written by the device directly
+    DescRing cell_ring, put_ring, search_ring;
+    unsigned *err_host = nullptr;    // pinned: sticky in-kernel timeout flag, written by the device directly
     int put_desc_cap = 256;
     int cell_desc_cap = 0;
     unsigned batch_serial = 0, batch_synced = 0;
@@ -97,15 +107,13 @@ struct x264hip_ctx
     MbtOpDev *mbt_host[64] = { nullptr }, *mbt_dev[64] = { nullptr };
     hipEvent_t mbt_done[64] = { nullptr };
     hipEvent_t ev_cross = nullptr, ev_mbt_last = nullptr;
+    hipEvent_t ev_ingest = nullptr;  // behind the most recent ingest kernels: frame totals are readable after it
     int mbt_next = 0, mbt_pending = 0;
     unsigned *mbt_bar = nullptr;      // device [MBT_RING][2]: barrier arrivals, error
     int *acc_host = nullptr;         // pinned [8]
-    unsigned *sync_host = nullptr;   // pinned [2]
-    void *desc_dev = nullptr;        // SearchDesc array
-    void *desc_host = nullptr;       // pinned
     int desc_cap = 0;
-    unsigned *wcost_dev = nullptr;
-    unsigned *wcost_host = nullptr;
+    unsigned *wcost_dev = nullptr;   // device [2]: running sum, arrivals (self-resetting)
+    unsigned *wcost_host = nullptr;  // pinned: result of the last weight_cost launch
     char *staging = nullptr;         // pinned luma staging
     size_t staging_bytes = 0;
     std::vector<char *> wplanes;     // weighted plane pool
@@ -135,6 +143,41 @@ static inline T *plane_origin( x264hip_ctx *ctx, FrameSlot &s, int p )
     return (T *)( s.planes + (size_t)p * ctx->plane_bytes ) + LA_PAD * ctx->P.stride + LA_PAD;
 }
 
+static void ring_free( DescRing &r )
+{
+    for( int i = 0; i < DescRing::K; i++ )
+    {
+        (void)hipHostFree( r.host[i] ); (void)hipFree( r.dev[i] );
+        if( r.ev[i] ) (void)hipEventDestroy( r.ev[i] );
+        r.host[i] = r.dev[i] = nullptr; r.ev[i] = nullptr;
+    }
+}
+static hipError_t ring_alloc( DescRing &r, size_t bytes )
+{
+    for( int i = 0; i < DescRing::K; i++ )
+    {
+        hipError_t e = hipHostMalloc( &r.host[i], bytes );
+        if( e == hipSuccess ) e = hipMalloc( &r.dev[i], bytes );
+        if( e == hipSuccess ) e = hipEventCreateWithFlags( &r.ev[i], hipEventDisableTiming );
+        if( e != hipSuccess ) return e;
+    }
+    return hipSuccess;
+}
+// next table pair; blocks only if the device is still K tables behind
+static int ring_acquire( DescRing &r, int *idx )
+{
+    const int i = r.next;
+    r.next = ( i + 1 ) % DescRing::K;
+    if( r.used[i] && hipEventSynchronize( r.ev[i] ) != hipSuccess ) return -1;
+    *idx = i;
+    return 0;
+}
+static int ring_commit( DescRing &r, int i, hipStream_t s )
+{
+    r.used[i] = true;
+    return hipEventRecord( r.ev[i], s ) == hipSuccess ? 0 : -1;
+}
+
 static void free_all( x264hip_ctx *ctx )
 {
     if( ctx->stream ) (void)hipStreamSynchronize( ctx->stream );
@@ -143,9 +186,10 @@ static void free_all( x264hip_ctx *ctx )
         (void)hipFree( s.planes ); // one allocation per slot holds everything
     }
     for( auto w : ctx->wplanes ) (void)hipFree( w );
-    (void)hipFree( ctx->cost_mv_dev ); (void)hipFree( ctx->luts_dev ); (void)hipFree( ctx->sync_words ); (void)hipFree( ctx->acc_dev ); (void)hipFree( ctx->cell_acc_dev ); (void)hipFree( ctx->cell_desc_dev );
+    (void)hipFree( ctx->cost_mv_dev ); (void)hipFree( ctx->luts_dev ); (void)hipFree( ctx->sync_words ); (void)hipFree( ctx->acc_dev );
+    ring_free( ctx->cell_ring ); ring_free( ctx->put_ring ); ring_free( ctx->search_ring );
+    (void)hipHostFree( ctx->err_host );
     (void)hipHostFree( ctx->stats_host );
-    (void)hipFree( ctx->put_desc_dev ); (void)hipHostFree( ctx->put_desc_host );
     if( ctx->stream2 ) (void)hipStreamSynchronize( ctx->stream2 );
     for( int i = 0; i < x264hip_ctx::MBT_RING; i++ )
     {
@@ -155,10 +199,11 @@ static void free_all( x264hip_ctx *ctx )
     (void)hipFree( ctx->mbt_bar );
     if( ctx->ev_cross ) (void)hipEventDestroy( ctx->ev_cross );
     if( ctx->ev_mbt_last ) (void)hipEventDestroy( ctx->ev_mbt_last );
+    if( ctx->ev_ingest ) (void)hipEventDestroy( ctx->ev_ingest );
     if( ctx->stream2 ) (void)hipStreamDestroy( ctx->stream2 );
-    (void)hipHostFree( ctx->cell_acc_host ); (void)hipHostFree( ctx->cell_desc_host );
-    (void)hipFree( ctx->desc_dev ); (void)hipFree( ctx->wcost_dev );
-    (void)hipHostFree( ctx->acc_host ); (void)hipHostFree( ctx->sync_host ); (void)hipHostFree( ctx->desc_host );
+    (void)hipHostFree( ctx->cell_acc_host );
+    (void)hipFree( ctx->wcost_dev );
+    (void)hipHostFree( ctx->acc_host );
     (void)hipHostFree( ctx->wcost_host ); (void)hipHostFree( ctx->staging );
     for( auto e : ctx->prof_ev ) (void)hipEventDestroy( e );
     if( ctx->ev_start ) (void)hipEventDestroy( ctx->ev_start );
@@ -225,17 +270,19 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         OPENCK( hipMalloc( &ctx->luts_dev, sizeof( AqLuts ) ) );
         OPENCK( hipMemcpy( ctx->luts_dev, &l, sizeof( l ), hipMemcpyHostToDevice ) );
     }
-    OPENCK( hipMalloc( &ctx->sync_words, 2 * sizeof( unsigned ) ) );
-    OPENCK( hipMemset( ctx->sync_words, 0, 2 * sizeof( unsigned ) ) ); // [1] is a sticky error word: must start clean
+    OPENCK( hipMalloc( &ctx->sync_words, 2 * sizeof( unsigned ) ) );   // [0]: row ticket of the search kernel
+    OPENCK( hipMemset( ctx->sync_words, 0, 2 * sizeof( unsigned ) ) );
     OPENCK( hipMalloc( &ctx->acc_dev, 8 * sizeof( int ) ) );
     ctx->n_cells = ( p.bframes + 2 ) * ( p.bframes + 2 );
-    OPENCK( hipMalloc( &ctx->cell_acc_dev, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
-    OPENCK( hipMemset( ctx->cell_acc_dev, 0, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
     OPENCK( hipHostMalloc( &ctx->cell_acc_host, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
+    memset( ctx->cell_acc_host, 0, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) );
+    OPENCK( hipHostMalloc( &ctx->err_host, sizeof( unsigned ) ) );
+    *ctx->err_host = 0;
     OPENCK( hipHostMalloc( &ctx->stats_host, (size_t)p.max_frames * 2 * sizeof( unsigned long long ) ) );
     OPENCK( hipStreamCreateWithFlags( &ctx->stream2, hipStreamNonBlocking ) );
     OPENCK( hipEventCreateWithFlags( &ctx->ev_cross, hipEventDisableTiming ) );
     OPENCK( hipEventCreateWithFlags( &ctx->ev_mbt_last, hipEventDisableTiming ) );
+    OPENCK( hipEventCreateWithFlags( &ctx->ev_ingest, hipEventDisableTiming ) );
     OPENCK( hipMalloc( &ctx->mbt_bar, x264hip_ctx::MBT_RING * 2 * sizeof( unsigned ) ) );
     OPENCK( hipMemset( ctx->mbt_bar, 0, x264hip_ctx::MBT_RING * 2 * sizeof( unsigned ) ) );
     for( int i = 0; i < x264hip_ctx::MBT_RING; i++ )
@@ -244,18 +291,15 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         OPENCK( hipMalloc( &ctx->mbt_dev[i], x264hip_ctx::MBT_CAP * sizeof( MbtOpDev ) ) );
         OPENCK( hipEventCreateWithFlags( &ctx->mbt_done[i], hipEventDisableTiming ) );
     }
-    OPENCK( hipMalloc( &ctx->put_desc_dev, (size_t)ctx->put_desc_cap * sizeof( PutDesc ) ) );
-    OPENCK( hipHostMalloc( &ctx->put_desc_host, (size_t)ctx->put_desc_cap * sizeof( PutDesc ) ) );
+    OPENCK( ring_alloc( ctx->put_ring, (size_t)ctx->put_desc_cap * sizeof( PutDesc ) ) );
     ctx->cell_desc_cap = 4096;
-    OPENCK( hipMalloc( &ctx->cell_desc_dev, (size_t)ctx->cell_desc_cap * sizeof( CellArgs ) ) );
-    OPENCK( hipHostMalloc( &ctx->cell_desc_host, (size_t)ctx->cell_desc_cap * sizeof( CellArgs ) ) );
+    OPENCK( ring_alloc( ctx->cell_ring, (size_t)ctx->cell_desc_cap * sizeof( CellArgs ) ) );
     OPENCK( hipHostMalloc( &ctx->acc_host, 8 * sizeof( int ) ) );
-    OPENCK( hipHostMalloc( &ctx->sync_host, 2 * sizeof( unsigned ) ) );
-    OPENCK( hipMalloc( &ctx->wcost_dev, sizeof( unsigned ) ) );
+    OPENCK( hipMalloc( &ctx->wcost_dev, 2 * sizeof( unsigned ) ) );
+    OPENCK( hipMemset( ctx->wcost_dev, 0, 2 * sizeof( unsigned ) ) );
     OPENCK( hipHostMalloc( &ctx->wcost_host, sizeof( unsigned ) ) );
     ctx->desc_cap = 2 * ( p.bframes + 1 ) * p.max_frames + 16;
-    OPENCK( hipMalloc( &ctx->desc_dev, (size_t)ctx->desc_cap * sizeof( SearchDesc<uint8_t> ) ) );
-    OPENCK( hipHostMalloc( &ctx->desc_host, (size_t)ctx->desc_cap * sizeof( SearchDesc<uint8_t> ) ) );
+    OPENCK( ring_alloc( ctx->search_ring, (size_t)ctx->desc_cap * sizeof( SearchDesc<uint8_t> ) ) );
     ctx->staging_bytes = (size_t)p.width * p.height * ctx->psz;
     OPENCK( hipHostMalloc( &ctx->staging, ctx->staging_bytes ) );
 
@@ -281,7 +325,7 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         OPENCK( hipMalloc( &base, off ) );
         OPENCK( hipMemset( base, 0, off ) );
         s.planes = base + o_planes; s.luma = base + o_luma; s.inv_qscale = (uint16_t *)( base + o_inv );
-        s.frame_sums = (unsigned long long *)( base + o_sums );
+        s.frame_sums = ctx->stats_host + 2 * ( &s - &ctx->slots[0] ); // pinned: read by the host after a stream sync
         s.mb_sums = (uint2 *)( base + o_mbs );
         for( int l = 0; l < 2; l++ )
             for( int d = 0; d < nd; d++ )
@@ -329,6 +373,7 @@ extern "C" int x264hip_geometry( x264hip_ctx *ctx, int *mb_w, int *mb_h, int *lo
     return X264HIP_OK;
 }
 
+static int sync_stream( x264hip_ctx *ctx );
 static inline bool slot_ok( x264hip_ctx *ctx, int s ) { return s >= 0 && s < (int)ctx->slots.size(); }
 
 // ---- frame ingest ------------------------------------------------------------------------------------
@@ -357,6 +402,7 @@ static int launch_ingest_t( x264hip_ctx *ctx, const PutDesc *descs_dev, const Pu
     aq_reduce_kernel<<<n, 1024, 0, ctx->stream>>>( descs_dev, single, ctx->n_mb );
     intra_kernel<T><<<dim3( P.mb_w, P.mb_h, n ), 64, 0, ctx->stream>>>( P, descs_dev, single );
     HIPCK( hipGetLastError() );
+    HIPCK( hipEventRecord( ctx->ev_ingest, ctx->stream ) );
     return X264HIP_OK;
 }
 
@@ -417,18 +463,21 @@ extern "C" int x264hip_frame_put_batch( x264hip_ctx *ctx, int n, const int *slot
     for( int o = 0; o < n; o += ctx->put_desc_cap )
     {
         const int m = std::min( n - o, ctx->put_desc_cap );
-        HIPCK( hipStreamSynchronize( ctx->stream ) ); // pinned descriptor table reuse
+        int ri = 0;
+        if( ring_acquire( ctx->put_ring, &ri ) ) return X264HIP_EDEVICE;
+        PutDesc *dh = (PutDesc *)ctx->put_ring.host[ri], *dd = (PutDesc *)ctx->put_ring.dev[ri];
         for( int i = 0; i < m; i++ )
         {
             if( !slot_ok( ctx, slots[o + i] ) || !luma_dev[o + i] ) return X264HIP_EINVAL;
             FrameSlot &s = ctx->slots[slots[o + i]];
             slot_reset( ctx, s );
-            ctx->put_desc_host[i] = make_put_desc( ctx, s, luma_dev[o + i], stride, nullptr, nullptr, 0, aq_on );
+            dh[i] = make_put_desc( ctx, s, luma_dev[o + i], stride, nullptr, nullptr, 0, aq_on );
         }
-        HIPCK( hipMemcpyAsync( ctx->put_desc_dev, ctx->put_desc_host, (size_t)m * sizeof( PutDesc ), hipMemcpyHostToDevice, ctx->stream ) );
+        HIPCK( hipMemcpyAsync( dd, dh, (size_t)m * sizeof( PutDesc ), hipMemcpyHostToDevice, ctx->stream ) );
         PutDesc none;
         memset( &none, 0, sizeof( none ) );
-        int rc = p.bit_depth == 8 ? launch_ingest_t<uint8_t>( ctx, ctx->put_desc_dev, none, m ) : launch_ingest_t<uint16_t>( ctx, ctx->put_desc_dev, none, m );
+        int rc = p.bit_depth == 8 ? launch_ingest_t<uint8_t>( ctx, dd, none, m ) : launch_ingest_t<uint16_t>( ctx, dd, none, m );
+        if( ring_commit( ctx->put_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
         if( rc ) return rc;
     }
     return X264HIP_OK;
@@ -442,16 +491,12 @@ extern "C" int x264hip_frame_stats( x264hip_ctx *ctx, int slot, uint64_t *pixel_
     if( !s.in_use ) return X264HIP_ESTATE;
     if( !s.stats_valid )
     {
-        // one round trip fetches the totals of every frame that does not have them yet
+        // the ingest kernels write the totals straight into pinned host memory: one wait covers every pending frame
         std::vector<int> pend;
         for( int i = 0; i < (int)ctx->slots.size(); i++ )
             if( ctx->slots[i].in_use && !ctx->slots[i].stats_valid )
-            {
-                HIPCK( hipMemcpyAsync( ctx->stats_host + 2 * i, ctx->slots[i].frame_sums, 2 * sizeof( unsigned long long ), hipMemcpyDeviceToHost, ctx->stream ) );
                 pend.push_back( i );
-            }
-        HIPCK( hipStreamSynchronize( ctx->stream ) );
-        ctx->batch_synced = ctx->batch_serial;
+        HIPCK( hipEventSynchronize( ctx->ev_ingest ) );
         const uint64_t n = (uint64_t)( 16 * ctx->P.mb_w ) * ( 16 * ctx->P.mb_h );
         for( int i : pend )
         {
@@ -515,13 +560,12 @@ struct SearchReq
     WtD wt;
 };
 
-// copy the kernel error word back, wait for the stream, latch in-kernel timeouts; every completed batch is now readable
+// wait for the stream, latch in-kernel timeouts (the flag lives in pinned host memory); every completed batch is now readable
 static int sync_stream( x264hip_ctx *ctx )
 {
-    HIPCK( hipMemcpyAsync( ctx->sync_host, ctx->sync_words, 2 * sizeof( unsigned ), hipMemcpyDeviceToHost, ctx->stream ) );
     HIPCK( hipStreamSynchronize( ctx->stream ) );
     ctx->batch_synced = ctx->batch_serial;
-    if( ctx->sync_host[1] )
+    if( *(volatile unsigned *)ctx->err_host )
     {
         ctx->broken = 1;
         return X264HIP_ETIMEOUT;
@@ -536,10 +580,9 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
     const int n = (int)reqs.size();
     if( !n ) return X264HIP_OK;
     if( n > ctx->desc_cap ) return X264HIP_EINVAL;
-    // the pinned descriptor table may still be read by an in-flight copy of the previous launch
-    int rc = sync_stream( ctx );
-    if( rc ) return rc;
-    SearchDesc<T> *dh = (SearchDesc<T> *)ctx->desc_host;
+    int rc = 0, ri = 0;
+    if( ring_acquire( ctx->search_ring, &ri ) ) return X264HIP_EDEVICE;
+    SearchDesc<T> *dh = (SearchDesc<T> *)ctx->search_ring.host[ri], *dd = (SearchDesc<T> *)ctx->search_ring.dev[ri];
     for( int i = 0; i < n; i++ )
     {
         const SearchReq &r = reqs[i];
@@ -565,8 +608,8 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         d.pad = 0;
         dh[i] = d;
     }
-    HIPCK( hipMemcpyAsync( ctx->desc_dev, dh, (size_t)n * sizeof( SearchDesc<T> ), hipMemcpyHostToDevice, ctx->stream ) );
-    HIPCK( hipMemsetAsync( ctx->sync_words, 0, sizeof( unsigned ), ctx->stream ) ); // ticket only: the error word is sticky
+    HIPCK( hipMemcpyAsync( dd, dh, (size_t)n * sizeof( SearchDesc<T> ), hipMemcpyHostToDevice, ctx->stream ) );
+    HIPCK( hipMemsetAsync( ctx->sync_words, 0, sizeof( unsigned ), ctx->stream ) ); // row ticket
     hipEvent_t e0 = ctx->ev_start, e1 = ctx->ev_stop;
     if( ctx->prof_on )
     {
@@ -580,8 +623,9 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         ctx->prof_used += 2;
     }
     HIPCK( hipEventRecord( e0, ctx->stream ) );
-    me_rows_kernel<T><<<n * ( ( P.mb_h + ME_WG_ROWS - 1 ) / ME_WG_ROWS ), 64 * ME_WG_ROWS, 0, ctx->stream>>>( P, (const SearchDesc<T> *)ctx->desc_dev, n, ctx->sync_words, 1u << 22 );
+    me_rows_kernel<T><<<n * ( ( P.mb_h + ME_WG_ROWS - 1 ) / ME_WG_ROWS ), 64 * ME_WG_ROWS, 0, ctx->stream>>>( P, dd, n, ctx->sync_words, ctx->err_host, 1u << 22 );
     HIPCK( hipEventRecord( e1, ctx->stream ) );
+    if( ring_commit( ctx->search_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
     HIPCK( hipGetLastError() );
     ctx->ev_valid = 1;
     ctx->last_n_search = n;
@@ -626,7 +670,7 @@ static CellArgs make_cell( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_
     A.row_satds = b.row_satds + (size_t)idx * P.mb_h;
     A.row_satds_intra = b.row_satds;
     A.blk = b.blk + (size_t)idx * ctx->n_mb;
-    A.acc = ctx->cell_acc_dev + ( (size_t)slot_b * ctx->n_cells + idx ) * 8;
+    A.acc = ctx->cell_acc_host + ( (size_t)slot_b * ctx->n_cells + idx ) * 8; // pinned, device-visible
     return A;
 }
 
@@ -643,8 +687,9 @@ static int launch_cells_t( x264hip_ctx *ctx, const std::vector<SpecCell> &cells 
     for( size_t o = 0; o < cells.size(); o += ctx->cell_desc_cap )
     {
         const int n = (int)std::min( cells.size() - o, (size_t)ctx->cell_desc_cap );
-        int rc = sync_stream( ctx ); // pinned descriptor table reuse
-        if( rc ) return rc;
+        int ri = 0;
+        if( ring_acquire( ctx->cell_ring, &ri ) ) return X264HIP_EDEVICE;
+        CellArgs *dh = (CellArgs *)ctx->cell_ring.host[ri], *dd = (CellArgs *)ctx->cell_ring.dev[ri];
         // order: [P cells | B cells | sums-only]; the reduction walks all of them
         std::vector<const SpecCell *> ord;
         int n_p = 0, n_b = 0;
@@ -661,21 +706,19 @@ static int launch_cells_t( x264hip_ctx *ctx, const std::vector<SpecCell> &cells 
         for( int i = 0; i < n; i++ )
         {
             const SpecCell &c = *ord[i];
-            ctx->cell_desc_host[i] = make_cell<T>( ctx, c.slot_p0, c.slot_p1, c.slot_b, c.d0, c.d1, 1, 1, c.sums_only );
+            dh[i] = make_cell<T>( ctx, c.slot_p0, c.slot_p1, c.slot_b, c.d0, c.d1, 1, 1, c.sums_only );
         }
-        HIPCK( hipMemcpyAsync( ctx->cell_desc_dev, ctx->cell_desc_host, (size_t)n * sizeof( CellArgs ), hipMemcpyHostToDevice, ctx->stream ) );
+        HIPCK( hipMemcpyAsync( dd, dh, (size_t)n * sizeof( CellArgs ), hipMemcpyHostToDevice, ctx->stream ) );
         CellArgs none;
         memset( &none, 0, sizeof( none ) );
         if( n_p )
-            cell_p_kernel<<<dim3( ( ctx->n_mb + 255 ) / 256, n_p ), 256, 0, ctx->stream>>>( P, ctx->cell_desc_dev, none );
+            cell_p_kernel<<<dim3( ( ctx->n_mb + 255 ) / 256, n_p ), 256, 0, ctx->stream>>>( P, dd, none );
         if( n_b )
-            cell_b_kernel<T><<<dim3( P.mb_w, P.mb_h, n_b ), 64, 0, ctx->stream>>>( P, ctx->cell_desc_dev + n_p, none );
-        cell_reduce_kernel<<<n, 1024, 0, ctx->stream>>>( P, ctx->cell_desc_dev, none );
+            cell_b_kernel<T><<<dim3( P.mb_w, P.mb_h, n_b ), 64, 0, ctx->stream>>>( P, dd + n_p, none );
+        cell_reduce_kernel<<<n, 1024, 0, ctx->stream>>>( P, dd, none ); // sums go straight to pinned host memory
         HIPCK( hipGetLastError() );
+        if( ring_commit( ctx->cell_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
     }
-    if( !cells.empty() )
-        HIPCK( hipMemcpyAsync( ctx->cell_acc_host, ctx->cell_acc_dev, (size_t)ctx->slots.size() * ctx->n_cells * 8 * sizeof( int ),
-                               hipMemcpyDeviceToHost, ctx->stream ) );
     return X264HIP_OK;
 }
 
@@ -751,8 +794,7 @@ extern "C" int x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *
     }
     if( !cells.empty() )
     {
-        // entries carry batch_serial + 1; the serial moves only once the batch is enqueued, because the launch
-        // itself synchronises the stream (descriptor table reuse) and must not mark this batch as complete
+        // entries carry batch_serial + 1; the serial moves only once the batch is enqueued
         int r = ctx->p.bit_depth == 8 ? launch_cells_t<uint8_t>( ctx, cells ) : launch_cells_t<uint16_t>( ctx, cells );
         if( r ) return r;
         ctx->batch_serial++;
@@ -838,7 +880,6 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
             cell_p_kernel<<<dim3( ( ctx->n_mb + 255 ) / 256, 1 ), 256, 0, ctx->stream>>>( P, nullptr, A );
         cell_reduce_kernel<<<1, 1024, 0, ctx->stream>>>( P, nullptr, A );
         HIPCK( hipGetLastError() );
-        HIPCK( hipMemcpyAsync( (void *)res, A.acc, 8 * sizeof( int ), hipMemcpyDeviceToHost, ctx->stream ) );
         int r = sync_stream( ctx );
         if( r ) return r;
     }
@@ -957,18 +998,17 @@ extern "C" int x264hip_weight_cost( x264hip_ctx *ctx, int slot_fenc, int slot_re
     if( !f.in_use || !r.in_use ) return X264HIP_ESTATE;
     const LaP &P = ctx->P;
     const WtD wt = make_wt( ctx, w );
-    HIPCK( hipMemsetAsync( ctx->wcost_dev, 0, sizeof( unsigned ), ctx->stream ) );
     const int grid = ( ctx->n_mb + 15 ) / 16;
     if( ctx->p.bit_depth == 8 )
         weight_cost_kernel<uint8_t><<<grid, 256, 0, ctx->stream>>>( P, plane_origin<uint8_t>( ctx, f, 0 ), plane_origin<uint8_t>( ctx, r, 0 ), wt,
-                                                                   f.lowres_costs, ctx->wcost_dev );
+                                                                   f.lowres_costs, ctx->wcost_dev, ctx->wcost_host );
     else
         weight_cost_kernel<uint16_t><<<grid, 256, 0, ctx->stream>>>( P, plane_origin<uint16_t>( ctx, f, 0 ), plane_origin<uint16_t>( ctx, r, 0 ), wt,
-                                                                    f.lowres_costs, ctx->wcost_dev );
+                                                                    f.lowres_costs, ctx->wcost_dev, ctx->wcost_host );
     HIPCK( hipGetLastError() );
-    HIPCK( hipMemcpyAsync( ctx->wcost_host, ctx->wcost_dev, sizeof( unsigned ), hipMemcpyDeviceToHost, ctx->stream ) );
-    HIPCK( hipStreamSynchronize( ctx->stream ) );
-    *cost = *ctx->wcost_host;
+    int rc = sync_stream( ctx );
+    if( rc ) return rc;
+    *cost = *(volatile unsigned *)ctx->wcost_host;
     return X264HIP_OK;
 }
 
