@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--preset", default="slow")
     ap.add_argument("--me", default="dia")
     ap.add_argument("--paced", action="store_true", help="encoder-paced put/get instead of the deep-prefetch batch")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="independent GOP segments in flight per GPU (one host thread + one context each): the decisions of one "
+                         "segment overlap the device work of the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-primitives", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=96)
@@ -147,13 +150,16 @@ def main():
     W, H, F = args.width, args.height, args.frames
     cfg = lib.la_config(W, H, args.preset, me=args.me)
     # every rank gets its own segment of the synthetic sequence (different seed = different content)
-    frames = make_clip(W, H, F, seed=100 + rank, scene_cuts=(F // 3, F // 3 + 47), fade=(2 * F // 3, 10, 0.6, 12), pan=(5, 3))
-    dev_frames = torch.from_numpy(frames).cuda(dev_index)
-    ptrs = [dev_frames[i].data_ptr() for i in range(F)]
+    S = max(1, args.inflight)
+    # every (rank, segment) gets its own part of the synthetic sequence (different seed = different content)
+    seg_frames, seg_dev, seg_ptrs, las = [], [], [], []
+    for sgi in range(S):
+        fr = make_clip(W, H, F, seed=100 + rank * S + sgi, scene_cuts=(F // 3, F // 3 + 47), fade=(2 * F // 3, 10, 0.6, 12), pan=(5, 3))
+        dv = torch.from_numpy(fr).cuda(dev_index)
+        seg_frames.append(fr); seg_dev.append(dv); seg_ptrs.append([dv[i].data_ptr() for i in range(F)])
+        las.append(lib.Lookahead(cfg, device=dev_index, max_frames=F + 4))
+    frames = seg_frames[0]
     torch.cuda.synchronize()
-
-    la = lib.Lookahead(cfg, device=dev_index, max_frames=F + 4)
-    ctxh = la.ctx_handle()
     gathered = [None]
 
     def barrier():
@@ -162,28 +168,44 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
+    import concurrent.futures
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=S) if S > 1 else None
+
+    def run_segment(sgi):
+        la = las[sgi]
         la.reset()
-        outs = la.run(device_ptrs=ptrs, stride=W, paced=args.paced)
+        outs = la.run(device_ptrs=seg_ptrs[sgi], stride=W, paced=args.paced)
         assert len(outs) == F
-        host = shard.summarize(outs, rank * F)
+        return outs
+
+    def step():
+        if pool is None:
+            seg_outs = [run_segment(0)]
+        else:
+            seg_outs = list(pool.map(run_segment, range(S)))  # ctypes calls release the GIL: the segments really overlap
+        host = np.concatenate([shard.summarize(o, (rank * S + sgi) * F) for sgi, o in enumerate(seg_outs)])
         if dist is not None:
             # the only exchange of the path: per-frame summaries (16 B per frame)
             gathered[0] = shard.gather_summaries(host, dist, device="cuda" if backend == "nccl" else None)
-        return outs
+        return seg_outs[0]
 
     for _ in range(args.warmup):
         step()
     barrier()
-    lib.search_profile(la.L, ctxh, 1)
+    for la in las:
+        lib.search_profile(la.L, la.ctx_handle(), 1)
     t0 = time.perf_counter()
     outs = None
     for _ in range(args.steps):
         outs = step()
     barrier()
     dt = time.perf_counter() - t0
-    prof_ms, prof_launches, prof_searches = lib.search_profile(la.L, ctxh, 0)
-    la_stats = la.stats()
+    prof_ms = prof_launches = prof_searches = 0
+    la_stats = np.zeros(8, np.uint64)
+    for la in las:
+        ms_, nl_, ns_ = lib.search_profile(la.L, la.ctx_handle(), 0)
+        prof_ms += ms_; prof_launches += nl_; prof_searches += ns_
+        la_stats += la.stats()
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -191,8 +213,11 @@ def main():
     types = "".join("?IiPbB"[o.type] for o in sorted(outs, key=lambda o: o.frame))
     if dist is not None:
         g = gathered[0]
-        assert g.shape == (world * F, 4) and sorted(g[:, 0].tolist()) == list(range(world * F)), "gathered summaries incomplete"
-    la.close()
+        assert g.shape == (world * S * F, 4) and sorted(g[:, 0].tolist()) == list(range(world * S * F)), "gathered summaries incomplete"
+    for la in las:
+        la.close()
+    if pool is not None:
+        pool.shutdown()
 
     if rank == 0:
         bytes_per_search = algorithmic_bytes_per_search(cfg)
@@ -208,7 +233,7 @@ def main():
                 traffic = None
         res = {
             "metric": "lookahead frames/sec",
-            "value": round(world * F * args.steps / dt, 2),
+            "value": round(world * S * F * args.steps / dt, 2),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -220,9 +245,10 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "%dx%d 8-bit 4:2:0 synthetic, --preset %s --me %s (BASELINE configs[1]): full lookahead "
-                                   "(lowres+AQ+intra+ME+cost cells+slicetype decision), %d frames per step per GPU, %s" %
-                                   (W, H, args.preset, args.me, F, "encoder-paced" if args.paced else "deep-prefetch batch"),
-                       "frames_per_step": F, "bframes": cfg["bframes"], "b_adapt": cfg["b_adapt"], "rc_lookahead": cfg["rc_lookahead"],
+                                   "(lowres+AQ+intra+ME+cost cells+slicetype decision+MB-tree), %d GOP segment(s) of %d frames in flight per GPU "
+                                   "per step, %s" %
+                                   (W, H, args.preset, args.me, S, F, "encoder-paced" if args.paced else "deep-prefetch batch"),
+                       "frames_per_step": S * F, "segments_in_flight": S, "bframes": cfg["bframes"], "b_adapt": cfg["b_adapt"], "rc_lookahead": cfg["rc_lookahead"],
                        "parallelism": "gop-segments x%d" % world, "slice_types": types[:64]},
             "roofline": {"bound": "hbm", "kernel": "me_rows_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

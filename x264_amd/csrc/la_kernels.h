@@ -512,79 +512,101 @@ __global__ __launch_bounds__( 256 ) void cell_p_kernel( LaP P, const CellArgs *d
     cell_finish( P, A, xy, bcost, list_used );
 }
 
-// B cells: one wave per block; groups 0..2 evaluate the three bidirectional candidates in parallel
+// B cells: a wave walks CELLB_BPW consecutive blocks of a row; groups 0..2 evaluate the three bidirectional
+// candidates of a block in parallel.  The per-block words (vectors, list costs) are fetched once by lanes
+// 0..CELLB_BPW-1 and read back with v_readlane, the results leave through the same lanes in one store, and the
+// block loop is unrolled so that the pixel loads of neighbouring blocks are in flight together.
+#define CELLB_BPW 8
 template <typename T>
 __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *descs, CellArgs single )
 {
     const CellArgs A = descs ? descs[blockIdx.z] : single;
-    const T *__restrict__ fenc0 = (const T *)A.fenc0, *__restrict__ ref0_0 = (const T *)A.ref0_0, *__restrict__ ref1_0 = (const T *)A.ref1_0;
     const int lane = lane_id();
-    const int bx = blockIdx.x, by = blockIdx.y, xy = by * P.mb_w + bx;
+    const int by = blockIdx.y, bx0 = blockIdx.x * CELLB_BPW;
+    const int nb = imin2( CELLB_BPW, P.mb_w - bx0 );
     const int g = lane >> 4, l = lane & 15, q = l >> 2;
-    const int tx = ( q & 1 ) * 4, row = ( q >> 1 ) * 4 + ( l & 3 );
-    const int off = 8 * ( by * P.stride + bx );
+    const int border = LA_PAD * P.stride + LA_PAD;
+    const T *fbase = (const T *)A.fenc0 - border, *r0base = (const T *)A.ref0_0 - border, *r1base = (const T *)A.ref1_0 - border;
+    const int row_off = border + 8 * by * P.stride + ( ( q >> 1 ) * 4 + ( l & 3 ) ) * P.stride + ( q & 1 ) * 4;
     const int bipred_weight = P.weighted_bipred ? 64 - ( A.dist_scale_factor >> 2 ) : 32;
     const int range = 2 * P.mv_range;
-    const int smin_x = imax2( 4 * ( -8 * bx - 12 ), -range ), smax_x = imin2( 4 * ( 8 * ( P.mb_w - bx - 1 ) + 12 ), range - 1 );
     const int smin_y = imax2( 4 * ( -8 * by - 12 ), -range ), smax_y = imin2( 4 * ( 8 * ( P.mb_h - by - 1 ) + 12 ), range - 1 );
-    // candidate vectors (wave uniform)
-    int d0x = 0, d0y = 0, d1x = 0, d1y = 0;
-    if( A.ref1_l0_valid )
+    // lane k holds the words of block bx0 + k
+    int w0v = 0, w1v = 0, wrv = 0, c0v = 0, c1v = 0;
+    const int xy_mine = by * P.mb_w + bx0 + imin2( lane, nb - 1 );
+    if( lane < nb )
     {
-        const int w = (int)(unsigned)A.ref1_l0[xy];
-        const int rx = (int)(short)( w & 0xFFFF ), ry = w >> 16;
-        d0x = ( rx * A.dist_scale_factor + 128 ) >> 8;
-        d0y = ( ry * A.dist_scale_factor + 128 ) >> 8;
-        d1x = d0x - rx; d1y = d0y - ry;
-        d0x = iclip3( d0x, smin_x, smax_x ); d0y = iclip3( d0y, smin_y, smax_y );
-        d1x = iclip3( d1x, smin_x, smax_x ); d1y = iclip3( d1y, smin_y, smax_y );
-        if( P.subme <= 1 ) { d0x &= ~1; d0y &= ~1; d1x &= ~1; d1y &= ~1; }
+        w0v = (int)(unsigned)A.mvq0[xy_mine]; w1v = (int)(unsigned)A.mvq1[xy_mine];
+        if( A.ref1_l0_valid ) wrv = (int)(unsigned)A.ref1_l0[xy_mine];
+        c0v = A.costs0[xy_mine]; c1v = A.costs1[xy_mine];
     }
-    const int w0 = (int)(unsigned)A.mvq0[xy], w1 = (int)(unsigned)A.mvq1[xy];
-    int m0x = (int)(short)( w0 & 0xFFFF ), m0y = w0 >> 16, m1x = (int)(short)( w1 & 0xFFFF ), m1y = w1 >> 16;
-    const bool dmv_nz = ( d0x | d0y | d1x | d1y ) != 0, mv_nz = ( m0x | m0y | m1x | m1y ) != 0;
-    // group g's pair: 0 -> direct-style (dmv), 1 -> zero, 2/3 -> searched vectors
-    int ax = sel4( g, d0x, 0, m0x, m0x ), ay = sel4( g, d0y, 0, m0y, m0y );
-    int cx = sel4( g, d1x, 0, m1x, m1x ), cy = sel4( g, d1y, 0, m1y, m1y );
-    if( P.subme <= 1 ) { ax &= ~1; ay &= ~1; cx &= ~1; cy &= ~1; } // half-pel plane pick (slicetype.c:582-589)
-    const Px4 f = load_px4( fenc0 + off + row * P.stride + tx );
-    const Px4 ra = qpel_px4( ref0_0 + off, P.plane_elems, P.stride, tx, row, ax, ay );
-    const Px4 rb = qpel_px4( ref1_0 + off, P.plane_elems, P.stride, tx, row, cx, cy );
-    Px4 pred;
-    if( bipred_weight == 32 )
-        pred = avg_px4( ra, rb, (const T *)nullptr );
-    else
+    int my_cost = 0, my_list = 0;
+#pragma unroll 2
+    for( int k = 0; k < nb; k++ )
     {
-        int va[4], vb[4];
-        px4_to_ints( ra, va ); px4_to_ints( rb, vb );
+        const int bx = bx0 + k;
+        const int smin_x = imax2( 4 * ( -8 * bx - 12 ), -range ), smax_x = imin2( 4 * ( 8 * ( P.mb_w - bx - 1 ) + 12 ), range - 1 );
+        // candidate vectors (wave uniform)
+        int d0x = 0, d0y = 0, d1x = 0, d1y = 0;
+        if( A.ref1_l0_valid )
+        {
+            const int w = __builtin_amdgcn_readlane( wrv, k );
+            const int rx = (int)(short)( w & 0xFFFF ), ry = w >> 16;
+            d0x = ( rx * A.dist_scale_factor + 128 ) >> 8;
+            d0y = ( ry * A.dist_scale_factor + 128 ) >> 8;
+            d1x = d0x - rx; d1y = d0y - ry;
+            d0x = iclip3( d0x, smin_x, smax_x ); d0y = iclip3( d0y, smin_y, smax_y );
+            d1x = iclip3( d1x, smin_x, smax_x ); d1y = iclip3( d1y, smin_y, smax_y );
+            if( P.subme <= 1 ) { d0x &= ~1; d0y &= ~1; d1x &= ~1; d1y &= ~1; }
+        }
+        const int w0 = __builtin_amdgcn_readlane( w0v, k ), w1 = __builtin_amdgcn_readlane( w1v, k );
+        const int m0x = (int)(short)( w0 & 0xFFFF ), m0y = w0 >> 16, m1x = (int)(short)( w1 & 0xFFFF ), m1y = w1 >> 16;
+        const bool dmv_nz = ( d0x | d0y | d1x | d1y ) != 0, mv_nz = ( m0x | m0y | m1x | m1y ) != 0;
+        // group g's pair: 0 -> direct-style (dmv), 1 -> zero, 2/3 -> searched vectors
+        int ax = sel4( g, d0x, 0, m0x, m0x ), ay = sel4( g, d0y, 0, m0y, m0y );
+        int cx = sel4( g, d1x, 0, m1x, m1x ), cy = sel4( g, d1y, 0, m1y, m1y );
+        if( P.subme <= 1 ) { ax &= ~1; ay &= ~1; cx &= ~1; cy &= ~1; } // half-pel plane pick (slicetype.c:582-589)
+        const int lane_off = row_off + 8 * bx;
+        const Px4 f = load_px4_at( fbase, lane_off );
+        const Px4 ra = qpel_px4_at( r0base, P.plane_elems, P.stride, lane_off, ax, ay );
+        const Px4 rb = qpel_px4_at( r1base, P.plane_elems, P.stride, lane_off, cx, cy );
+        Px4 pred;
+        if( bipred_weight == 32 )
+            pred = avg_px4( ra, rb, (const T *)nullptr );
+        else
+        {
+            int va[4], vb[4];
+            px4_to_ints( ra, va ); px4_to_ints( rb, vb );
 #pragma unroll
-        for( int i = 0; i < 4; i++ )
-            va[i] = iclip3( ( va[i] * bipred_weight + vb[i] * ( 64 - bipred_weight ) + 32 ) >> 6, 0, P.pixel_max );
-        pred = px4_from_ints( va, sizeof( T ) == 1 );
+            for( int i = 0; i < 4; i++ )
+                va[i] = iclip3( ( va[i] * bipred_weight + vb[i] * ( 64 - bipred_weight ) + 32 ) >> 6, 0, P.pixel_max );
+            pred = px4_from_ints( va, sizeof( T ) == 1 );
+        }
+        const int v = block_cost8x8<T>( f, pred, P.mbcmp_satd );
+        int bcost = COST_MAX_I, list_used = 0;
+        {
+            int c = __builtin_amdgcn_readlane( v, 0 );
+            if( c < bcost ) { bcost = c; list_used = 3; }
+        }
+        if( dmv_nz )
+        {
+            int c = __builtin_amdgcn_readlane( v, 16 );
+            if( c < bcost ) { bcost = c; list_used = 3; }
+        }
+        {
+            int c0 = __builtin_amdgcn_readlane( c0v, k ), c1 = __builtin_amdgcn_readlane( c1v, k );
+            if( c0 < bcost ) { bcost = c0; list_used = 1; }
+            if( c1 < bcost ) { bcost = c1; list_used = 2; }
+        }
+        if( mv_nz )
+        {
+            int c = 5 * P.lambda + __builtin_amdgcn_readlane( v, 32 );
+            if( c < bcost ) { bcost = c; list_used = 3; }
+        }
+        if( lane == k ) { my_cost = bcost; my_list = list_used; }
     }
-    const int v = block_cost8x8<T>( f, pred, P.mbcmp_satd );
-    int bcost = COST_MAX_I, list_used = 0;
-    {
-        int c = __builtin_amdgcn_readlane( v, 0 );
-        if( c < bcost ) { bcost = c; list_used = 3; }
-    }
-    if( dmv_nz )
-    {
-        int c = __builtin_amdgcn_readlane( v, 16 );
-        if( c < bcost ) { bcost = c; list_used = 3; }
-    }
-    {
-        int c0 = A.costs0[xy], c1 = A.costs1[xy];
-        if( c0 < bcost ) { bcost = c0; list_used = 1; }
-        if( c1 < bcost ) { bcost = c1; list_used = 2; }
-    }
-    if( mv_nz )
-    {
-        int c = 5 * P.lambda + __builtin_amdgcn_readlane( v, 32 );
-        if( c < bcost ) { bcost = c; list_used = 3; }
-    }
-    if( lane == 0 )
-        cell_finish( P, A, xy, bcost, list_used );
+    if( lane < nb )
+        cell_finish( P, A, xy_mine, my_cost, my_list );
 }
 
 // ---- batched vtable primitives: SAD / SATD of every block of a plane against a displaced reference ----

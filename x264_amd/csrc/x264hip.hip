@@ -360,6 +360,7 @@ extern "C" int x264hip_synchronize( x264hip_ctx *ctx )
 {
     if( !ctx ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     HIPCK( hipStreamSynchronize( ctx->stream ) );
     return X264HIP_OK;
 }
@@ -423,6 +424,7 @@ extern "C" int x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, 
 {
     if( !ctx || !slot_ok( ctx, slot ) || !luma || stride < ctx->p.width ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     FrameSlot &s = ctx->slots[slot];
     if( ctx->mbt_pending )
         HIPCK( hipStreamWaitEvent( ctx->stream, ctx->ev_mbt_last, 0 ) ); // MB-tree steps may still read this slot's maps
@@ -456,6 +458,7 @@ extern "C" int x264hip_frame_put_batch( x264hip_ctx *ctx, int n, const int *slot
 {
     if( !ctx || n <= 0 || !slots || !luma_dev || stride < ctx->p.width ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     if( ctx->mbt_pending )
         HIPCK( hipStreamWaitEvent( ctx->stream, ctx->ev_mbt_last, 0 ) );
     const x264hip_params &p = ctx->p;
@@ -487,6 +490,7 @@ extern "C" int x264hip_frame_stats( x264hip_ctx *ctx, int slot, uint64_t *pixel_
 {
     if( !ctx || !slot_ok( ctx, slot ) ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     FrameSlot &s = ctx->slots[slot];
     if( !s.in_use ) return X264HIP_ESTATE;
     if( !s.stats_valid )
@@ -714,7 +718,7 @@ static int launch_cells_t( x264hip_ctx *ctx, const std::vector<SpecCell> &cells 
         if( n_p )
             cell_p_kernel<<<dim3( ( ctx->n_mb + 255 ) / 256, n_p ), 256, 0, ctx->stream>>>( P, dd, none );
         if( n_b )
-            cell_b_kernel<T><<<dim3( P.mb_w, P.mb_h, n_b ), 64, 0, ctx->stream>>>( P, dd + n_p, none );
+            cell_b_kernel<T><<<dim3( ( P.mb_w + CELLB_BPW - 1 ) / CELLB_BPW, P.mb_h, n_b ), 64, 0, ctx->stream>>>( P, dd + n_p, none );
         cell_reduce_kernel<<<n, 1024, 0, ctx->stream>>>( P, dd, none ); // sums go straight to pinned host memory
         HIPCK( hipGetLastError() );
         if( ring_commit( ctx->cell_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
@@ -726,12 +730,14 @@ extern "C" int x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *
 {
     if( !ctx || !slots || !frame_numbers || n < 0 ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     std::vector<SearchReq> reqs;
     const WtD none = { 0, 1, 0, 0 };
     const int bf = ctx->p.bframes, nstride = bf + 2;
     for( int i = 0; i < n; i++ )
     {
         if( !slot_ok( ctx, slots[i] ) || !ctx->slots[slots[i]].in_use ) return X264HIP_ESTATE;
+        ctx->slots[slots[i]].frame_no = frame_numbers[i];
         for( int j = 0; j < n; j++ )
         {
             const int d = frame_numbers[j] - frame_numbers[i]; // reference j relative to source i
@@ -853,6 +859,7 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
     const unsigned t1 = b_bidir ? b.field_tag[1][d1 - 1] : 0;
     const unsigned tr = b_bidir && ref1_l0_valid ? f1.field_tag[0][d0 + d1 - 1] : 0;
     const bool hit = e.valid && e.tag0 == t0 && e.tag1 == t1 && e.tagr == tr && ( !b_bidir || ref1_l0_valid );
+    const int was_valid = e.valid;
     e.requested = 1;
     e.valid = 0;
     const int *res = ctx->cell_acc_host + ( (size_t)slot_b * ctx->n_cells + idx ) * 8;
@@ -860,6 +867,9 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
     if( hit )
     {
         ctx->counters[4]++;
+        static const bool trace_hit = getenv( "X264HIP_TRACE_MISS" ) != nullptr;
+        if( trace_hit && b_bidir )
+            fprintf( stderr, "hit b=%d d0=%d d1=%d ref1_ok=%d\n", b.frame_no, d0, d1, ref1_l0_valid );
         if( e.batch > ctx->batch_synced )
         {
             int r = sync_stream( ctx );
@@ -874,8 +884,13 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
     }
     else
     {
+        ctx->counters[b_bidir ? 7 : 6]++;
+        static const bool trace_miss = getenv( "X264HIP_TRACE_MISS" ) != nullptr;
+        if( trace_miss )
+            fprintf( stderr, "miss b=%d d0=%d d1=%d valid=%d tags have %u/%u/%u want %u/%u/%u ref1_ok=%d wi=%d search=%d,%d w=%d\n", b.frame_no, d0, d1, was_valid,
+                     e.tag0, e.tag1, e.tagr, t0, t1, tr, ref1_l0_valid, with_intra, do_search[0], do_search[1], w && w->on );
         if( b_bidir )
-            cell_b_kernel<T><<<dim3( P.mb_w, P.mb_h, 1 ), 64, 0, ctx->stream>>>( P, nullptr, A );
+            cell_b_kernel<T><<<dim3( ( P.mb_w + CELLB_BPW - 1 ) / CELLB_BPW, P.mb_h, 1 ), 64, 0, ctx->stream>>>( P, nullptr, A );
         else
             cell_p_kernel<<<dim3( ( ctx->n_mb + 255 ) / 256, 1 ), 256, 0, ctx->stream>>>( P, nullptr, A );
         cell_reduce_kernel<<<1, 1024, 0, ctx->stream>>>( P, nullptr, A );
@@ -895,6 +910,7 @@ extern "C" int x264hip_frame_cost( x264hip_ctx *ctx, int slot_p0, int slot_p1, i
     if( !ctx || !out || !do_search || !slot_ok( ctx, slot_p0 ) || !slot_ok( ctx, slot_p1 ) || !slot_ok( ctx, slot_b ) ) return X264HIP_EINVAL;
     if( dist_p0 < 0 || dist_p1 < 0 || dist_p0 + dist_p1 > ctx->p.bframes + 1 || ( dist_p0 == 0 && dist_p1 != 0 ) ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     if( !ctx->slots[slot_b].in_use || !ctx->slots[slot_p0].in_use || !ctx->slots[slot_p1].in_use ) return X264HIP_ESTATE;
     return ctx->p.bit_depth == 8
                ? frame_cost_t<uint8_t>( ctx, slot_p0, slot_p1, slot_b, dist_p0, dist_p1, do_search, w, with_intra, ref1_l0_valid, out )
@@ -906,6 +922,7 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
 {
     if( !ctx || !ops || n <= 0 || n > x264hip_ctx::MBT_CAP ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     const int nstride = ctx->p.bframes + 2;
     const int r = ctx->mbt_next;
     ctx->mbt_next = ( r + 1 ) % x264hip_ctx::MBT_RING;
@@ -963,6 +980,7 @@ extern "C" int x264hip_get_qp_offsets( x264hip_ctx *ctx, int slot, float *qp_off
 {
     if( !ctx || !slot_ok( ctx, slot ) || !qp_offset ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     HIPCK( hipStreamSynchronize( ctx->stream ) );
     HIPCK( hipMemcpyAsync( qp_offset, ctx->slots[slot].qp, ctx->n_mb * sizeof( float ), hipMemcpyDeviceToHost, ctx->stream2 ) );
     std::vector<unsigned> bar( x264hip_ctx::MBT_RING * 2 );
@@ -982,6 +1000,7 @@ extern "C" int x264hip_get_propagate_cost( x264hip_ctx *ctx, int slot, uint16_t 
 {
     if( !ctx || !slot_ok( ctx, slot ) || !propagate ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     std::vector<int> tmp( ctx->n_mb );
     HIPCK( hipMemcpyAsync( tmp.data(), ctx->slots[slot].prop, ctx->n_mb * sizeof( int ), hipMemcpyDeviceToHost, ctx->stream2 ) );
     HIPCK( hipStreamSynchronize( ctx->stream2 ) );
@@ -994,6 +1013,7 @@ extern "C" int x264hip_weight_cost( x264hip_ctx *ctx, int slot_fenc, int slot_re
 {
     if( !ctx || !cost || !slot_ok( ctx, slot_fenc ) || !slot_ok( ctx, slot_ref ) ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     FrameSlot &f = ctx->slots[slot_fenc], &r = ctx->slots[slot_ref];
     if( !f.in_use || !r.in_use ) return X264HIP_ESTATE;
     const LaP &P = ctx->P;
@@ -1017,6 +1037,7 @@ extern "C" int x264hip_get_lowres( x264hip_ctx *ctx, int slot, int plane, void *
 {
     if( !ctx || !dst || !slot_ok( ctx, slot ) || plane < 0 || plane > 3 ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     FrameSlot &s = ctx->slots[slot];
     const int w = ctx->lw + 2 * LA_PAD, h = ctx->lh + 2 * LA_PAD;
     HIPCK( hipMemcpy2DAsync( dst, (size_t)dst_stride * ctx->psz, s.planes + (size_t)plane * ctx->plane_bytes, (size_t)ctx->P.stride * ctx->psz,
@@ -1029,6 +1050,7 @@ extern "C" int x264hip_get_mvs( x264hip_ctx *ctx, int slot, int list, int dist_m
 {
     if( !ctx || !slot_ok( ctx, slot ) || list < 0 || list > 1 || dist_minus1 < 0 || dist_minus1 > ctx->p.bframes ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     FrameSlot &s = ctx->slots[slot];
     std::vector<unsigned long long> g( ctx->n_mb );
     HIPCK( hipMemcpyAsync( g.data(), s.mvq[list][dist_minus1], ctx->n_mb * sizeof( unsigned long long ), hipMemcpyDeviceToHost, ctx->stream ) );
@@ -1049,6 +1071,7 @@ extern "C" int x264hip_get_lowres_costs( x264hip_ctx *ctx, int slot, int dist_p0
 {
     if( !ctx || !slot_ok( ctx, slot ) || dist_p0 < 0 || dist_p1 < 0 || dist_p0 > ctx->p.bframes + 1 || dist_p1 > ctx->p.bframes + 1 ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     FrameSlot &s = ctx->slots[slot];
     const int idx = dist_p0 * ( ctx->p.bframes + 2 ) + dist_p1;
     if( costs )
@@ -1068,6 +1091,7 @@ extern "C" int x264hip_get_inv_qscale( x264hip_ctx *ctx, int slot, uint16_t *inv
 {
     if( !ctx || !slot_ok( ctx, slot ) || !inv_qscale ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     HIPCK( hipMemcpyAsync( inv_qscale, ctx->slots[slot].inv_qscale, ctx->n_mb * sizeof( uint16_t ), hipMemcpyDeviceToHost, ctx->stream ) );
     HIPCK( hipStreamSynchronize( ctx->stream ) );
     return X264HIP_OK;
@@ -1088,6 +1112,7 @@ extern "C" int x264hip_search_profile( x264hip_ctx *ctx, int enable, double *tot
 {
     if( !ctx ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     int rc = prof_drain( ctx );
     if( rc ) return rc;
     if( total_ms ) *total_ms = ctx->prof_ms;
@@ -1122,6 +1147,7 @@ extern "C" int x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx
     const int size = size_idx == 0 ? 16 : size_idx == 3 ? 8 : size_idx == 6 ? 4 : 0;
     if( !size || ( blocks_w * size ) % 16 || ( blocks_h * size ) % 16 ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     const int rw = blocks_w * size / 16, rh = blocks_h * size / 16;
     const dim3 grd( ( rw + 15 ) / 16, rh );
 #define CMP_LAUNCH( T, S, D ) \
@@ -1147,6 +1173,7 @@ extern "C" int x264hip_frame_init_lowres_core( x264hip_ctx *ctx, const void *src
 {
     if( !ctx || !src0 || !dst0 || !dsth || !dstv || !dstc || width <= 0 || height <= 0 ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     dim3 grd( ( width + 255 ) / 256, height );
     if( ctx->p.bit_depth == 8 )
         lowres_core_kernel<uint8_t><<<grd, 256, 0, ctx->stream>>>( (const uint8_t *)src0, (uint8_t *)dst0, (uint8_t *)dsth, (uint8_t *)dstv,
@@ -1163,6 +1190,7 @@ extern "C" int x264hip_dct_quant_batch( x264hip_ctx *ctx, int is8x8, int n_block
 {
     if( !ctx || n_blocks <= 0 || !fenc || !fdec || !mf || !bias || !coefs_out || !nz_out ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     const int N = is8x8 ? 8 : 4, psz = ctx->psz, csz = ctx->p.bit_depth == 8 ? 2 : 4;
     const size_t fe_b = (size_t)n_blocks * N * 16 * psz, fd_b = (size_t)n_blocks * N * 32 * psz, tab_b = (size_t)N * N * csz,
                  co_b = (size_t)n_blocks * N * N * csz;
