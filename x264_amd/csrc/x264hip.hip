@@ -82,6 +82,7 @@ struct x264hip_ctx
     x264hip_params p;
     LaP P;
     int device = 0;
+    int n_cu = 256;
     int broken = 0;
     int psz = 1;                  // sizeof(pixel)
     int lw = 0, lh = 0;           // lowres dims (mod16 / 2)
@@ -238,6 +239,11 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     if( hipSetDevice( device ) != hipSuccess )
         return X264HIP_ENODEV;
     x264hip_ctx *ctx = new x264hip_ctx();
+    {
+        hipDeviceProp_t prop;
+        if( hipGetDeviceProperties( &prop, device ) == hipSuccess && prop.multiProcessorCount > 0 )
+            ctx->n_cu = prop.multiProcessorCount;
+    }
     ctx->p = p;
     ctx->p.cost_mv = nullptr;
     ctx->device = device;
