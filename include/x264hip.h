@@ -134,6 +134,10 @@ int  x264hip_frame_cost( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
 /* weight_cost_luma without the slice-header term (encoder/slicetype.c:191-222): sum over blocks of
  * min( mbcmp( weight(ref lowres block), fenc lowres block ), intra_cost ).  w may be NULL. */
 int  x264hip_weight_cost( x264hip_ctx *ctx, int slot_fenc, int slot_ref, const x264hip_weight *w, unsigned *cost );
+/* Speculative form: enqueue the unweighted and the weighted cost of n (fenc, ref, weight) triples in one launch and
+ * return at once.  A later x264hip_weight_cost() for the same frames (and the same weight, or NULL) is answered
+ * from these results without a launch; anything else is computed on demand as before.  Never changes results. */
+int  x264hip_prefetch_weight_costs( x264hip_ctx *ctx, int n, const int *slot_fenc, const int *slot_ref, const x264hip_weight *w );
 
 /* getters (device -> host); sizes in elements: n_mb = mb_w*mb_h */
 int  x264hip_get_lowres( x264hip_ctx *ctx, int slot, int plane, void *dst, int dst_stride ); /* incl. 32 px border */
@@ -227,6 +231,7 @@ typedef struct x264hip_backend
     int (*mbtree)( void *user, const x264hip_mbtree_op *ops, int n );                   /* may be NULL: no propagation */
     int (*get_qp_offsets)( void *user, int slot, float *qp_offset );                    /* may be NULL */
     int (*frame_put_batch)( void *user, int n, const int *slots, const void *const *luma_dev, int stride ); /* may be NULL */
+    int (*prefetch_weight_costs)( void *user, int n, const int *slot_fenc, const int *slot_ref, const x264hip_weight *w ); /* may be NULL */
 } x264hip_backend;
 
 typedef struct x264hip_la_frame

@@ -348,13 +348,25 @@ __global__ __launch_bounds__( 256 ) void weight_plane_kernel( const T *__restric
 }
 
 // weight_cost_luma (slicetype.c:191-222): sum over blocks of min( mbcmp, intra_cost ).  256-thread workgroups, four
-// blocks per wave, sixteen per workgroup; one atomic per workgroup after an LDS reduction.
+// blocks per wave, sixteen per workgroup.  blockIdx.y picks the (fenc, ref, weight) job of a batch, blockIdx.z the
+// unweighted (0) or weighted (1) sum of a pair.  The workgroup that arrives last publishes the total to pinned host
+// memory and re-arms the two device counters of its job.
+struct WeightJob
+{
+    const void *fenc0, *ref0;     // plane-0 origins
+    const uint16_t *intra_cost;
+    WtD w;
+    unsigned *accum;              // device [2][2]: { running sum, arrivals } per z
+    unsigned *out_host;           // pinned [2]
+};
+
 template <typename T>
-__global__ __launch_bounds__( 256 ) void weight_cost_kernel( LaP P, const T *__restrict__ fenc0, const T *__restrict__ ref0, WtD w,
-                                                             const uint16_t *__restrict__ intra_cost, unsigned *accum /* device [2] */,
-                                                             unsigned *out_host /* pinned */ )
+__global__ __launch_bounds__( 256 ) void weight_cost_kernel( LaP P, const WeightJob *jobs, WeightJob single, int z_base )
 {
     __shared__ unsigned part[4];
+    const WeightJob J = jobs ? jobs[blockIdx.y] : single;
+    const int z = blockIdx.z + z_base;
+    const T *__restrict__ fenc0 = (const T *)J.fenc0, *__restrict__ ref0 = (const T *)J.ref0;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int g = lane >> 4, l = lane & 15, q = l >> 2;
     const int tx = ( q & 1 ) * 4, row = ( q >> 1 ) * 4 + ( l & 3 );
@@ -365,9 +377,10 @@ __global__ __launch_bounds__( 256 ) void weight_cost_kernel( LaP P, const T *__r
     const int off = 8 * ( by * P.stride + bx ) + row * P.stride + tx;
     const Px4 f = load_px4( fenc0 + off );
     Px4 r = load_px4( ref0 + off );
-    if( w.on )
-        r = weight_px4<T>( r, w, P.pixel_max );
-    const int c = imin2( block_cost8x8<T>( f, r, P.mbcmp_satd ), (int)intra_cost[xyc] );
+    if( z && J.w.on )
+        r = weight_px4<T>( r, J.w, P.pixel_max );
+    // the intra costs as the reference reads them here: after the 14-bit clamp of the [0][0] map (slicetype.c:712)
+    const int c = imin2( block_cost8x8<T>( f, r, P.mbcmp_satd ), imin2( (int)J.intra_cost[xyc], 0x3FFF ) );
     unsigned tot = 0;
 #pragma unroll
     for( int k = 0; k < 4; k++ )
@@ -377,15 +390,15 @@ __global__ __launch_bounds__( 256 ) void weight_cost_kernel( LaP P, const T *__r
     __syncthreads();
     if( threadIdx.x == 0 )
     {
-        // the workgroup that arrives last publishes the total to the host and re-arms the two counters
+        unsigned *accum = J.accum + 2 * z;
         atomicAdd( &accum[0], part[0] + part[1] + part[2] + part[3] );
         __threadfence();
         if( atomicAdd( &accum[1], 1u ) == gridDim.x - 1 )
         {
             __threadfence();
-            const unsigned tot = atomicExch( &accum[0], 0u );
+            const unsigned total = atomicExch( &accum[0], 0u );
             atomicExch( &accum[1], 0u );
-            __hip_atomic_store( out_host, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+            __hip_atomic_store( J.out_host + z, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
         }
     }
 }

@@ -54,6 +54,7 @@ struct LaFrame
     bool stats_valid = false;
     float weighted_cost_delta[BMAX + 2]; // f_weighted_cost_delta, frame.c:798
     bool prefetch_submitted = false;
+    bool weights_prefetched = false;
 };
 
 static int ue_size( unsigned v ) // bs_size_ue, common/bitstream.h:278 (2*floor(log2(v+1))+1)
@@ -179,13 +180,14 @@ struct Lookahead
         return true;
     }
 
-    void weights_analyse( LaFrame *fenc, LaFrame *ref )
+    // First half of x264_weights_analyse in lookahead mode (:293-330 and the candidate of :401-439): the guessed
+    // scale and the one (scale, offset) pair whose cost gets measured.  Pure host arithmetic on the frame totals,
+    // so it can also run ahead of time to queue the two cost sums speculatively.  false = no weighting to test.
+    bool weight_candidate( LaFrame *fenc, LaFrame *ref, x264hip_weight &guess, x264hip_weight &cand )
     {
-        stats[2]++;
         const float epsilon = 1.f / 128.f;
-        x264hip_weight &wt = fenc->weight;
-        wt.on = 0; wt.scale = 1; wt.denom = 0; wt.offset = 0;
-        if( !frame_stats( fenc ) || !frame_stats( ref ) ) return;
+        guess.on = 0; guess.scale = 1; guess.denom = 0; guess.offset = 0;
+        if( !frame_stats( fenc ) || !frame_stats( ref ) ) return false;
         const int mb_w = ( p.dev.width + 15 ) / 16, mb_h = ( p.dev.height + 15 ) / 16;
         const int lines = 16 * mb_h, width = 16 * mb_w;
         const int zero_bias = !ref->pixel_ssd;
@@ -196,13 +198,37 @@ struct Lookahead
         float ref_mean = (float)( (uint32_t)ref->pixel_sum + zero_bias ) / ( lines * width ) / ( 1 << ( p.dev.bit_depth - 8 ) );
 
         if( fabsf( ref_mean - fenc_mean ) < 0.5f && fabsf( 1.f - guess_scale ) < epsilon )
-            return;
+            return false;
         // weight_get_h264 (:64-75)
         {
             int s = (int)round( guess_scale * 128 );
-            wt.offset = 0; wt.denom = 7; wt.scale = s;
-            while( wt.denom > 0 && wt.scale > 127 ) { wt.denom--; wt.scale >>= 1; }
-            if( wt.scale > 127 ) wt.scale = 127;
+            guess.offset = 0; guess.denom = 7; guess.scale = s;
+            while( guess.denom > 0 && guess.scale > 127 ) { guess.denom--; guess.scale >>= 1; }
+            if( guess.scale > 127 ) guess.scale = 127;
+        }
+        // lookahead mode: one (scale, offset) candidate (:401-439 with both distances 0)
+        const int mindenom = guess.denom;
+        int cur_scale = clip3i( guess.scale, 0, 127 );
+        int cur_offset = (int)( fenc_mean - ref_mean * cur_scale / ( 1 << mindenom ) + 0.5f * 1 );
+        if( cur_offset < -128 || cur_offset > 127 )
+        {
+            cur_offset = clip3i( cur_offset, -128, 127 );
+            double v = ( 1 << mindenom ) * ( fenc_mean - cur_offset ) / ref_mean + 0.5f;
+            cur_scale = (int)( v < 0 ? 0 : v > 127 ? 127 : v );
+        }
+        cand.on = 1; cand.scale = cur_scale; cand.denom = mindenom; cand.offset = clip3i( cur_offset, -128, 127 );
+        return true;
+    }
+
+    void weights_analyse( LaFrame *fenc, LaFrame *ref )
+    {
+        stats[2]++;
+        x264hip_weight &wt = fenc->weight;
+        x264hip_weight cand;
+        if( !weight_candidate( fenc, ref, wt, cand ) )
+        {
+            wt.on = 0; wt.scale = 1; wt.denom = 0; wt.offset = 0;
+            return;
         }
         int mindenom = wt.denom, minscale = wt.scale, minoff = 0, found = 0;
         if( !fenc->intra_calculated )
@@ -217,18 +243,7 @@ struct Lookahead
         minscore = origscore;
         if( !minscore ) { wt.on = 0; wt.scale = 1; wt.denom = 0; wt.offset = 0; /* keeps the guessed values off */ return; }
         {
-            // lookahead mode: one (scale, offset) candidate (:401-439 with both distances 0)
-            int i_scale = clip3i( minscale, 0, 127 );
-            int cur_scale = i_scale;
-            int cur_offset = (int)( fenc_mean - ref_mean * cur_scale / ( 1 << mindenom ) + 0.5f * 1 );
-            if( cur_offset < -128 || cur_offset > 127 )
-            {
-                cur_offset = clip3i( cur_offset, -128, 127 );
-                double v = ( 1 << mindenom ) * ( fenc_mean - cur_offset ) / ref_mean + 0.5f;
-                cur_scale = (int)( v < 0 ? 0 : v > 127 ? 127 : v );
-            }
-            int i_off = clip3i( cur_offset, -128, 127 );
-            x264hip_weight cand = { 1, cur_scale, mindenom, i_off };
+            const int cur_scale = cand.scale, i_off = cand.offset;
             unsigned s = 0;
             if( need( be.weight_cost( be.user, fenc->slot, ref->slot, &cand, &s ) ) ) { wt.on = 0; return; }
             s += weight_header_cost( cand );
@@ -771,6 +786,31 @@ struct Lookahead
         }
         ScopeNs tm( stats[6] );
         need( be.prefetch( be.user, slots.data(), nums.data(), (int)slots.size() ) );
+        // the two cost sums of every weight test the decisions can ask for (P evaluations over 1..bframes+1 frames):
+        // queued behind the searches, answered later without a round trip
+        if( be.prefetch_weight_costs && p.weightp && !err )
+        {
+            std::vector<LaFrame *> res;
+            if( last_nonb ) res.push_back( last_nonb );
+            for( int i = 0; i < upto; i++ ) res.push_back( next[i] );
+            std::vector<int> sf, sr;
+            std::vector<x264hip_weight> ws;
+            for( LaFrame *f : res )
+            {
+                if( f->weights_prefetched || f == last_nonb ) continue;
+                f->weights_prefetched = true;
+                for( LaFrame *r : res )
+                {
+                    const int d = f->i_frame - r->i_frame;
+                    if( d < 1 || d > p.dev.bframes + 1 ) continue;
+                    x264hip_weight guess, cand;
+                    if( !weight_candidate( f, r, guess, cand ) ) continue;
+                    sf.push_back( f->slot ); sr.push_back( r->slot ); ws.push_back( cand );
+                }
+            }
+            if( !sf.empty() && !err )
+                need( be.prefetch_weight_costs( be.user, (int)sf.size(), sf.data(), sr.data(), ws.data() ) );
+        }
     }
 };
 
@@ -791,6 +831,10 @@ static int dev_qp_offsets( void *u, int slot, float *q ) { return x264hip_get_qp
 static int dev_put_batch( void *u, int n, const int *slots, const void *const *luma, int stride )
 {
     return x264hip_frame_put_batch( (x264hip_ctx *)u, n, slots, luma, stride );
+}
+static int dev_prefetch_weights( void *u, int n, const int *sf, const int *sr, const x264hip_weight *w )
+{
+    return x264hip_prefetch_weight_costs( (x264hip_ctx *)u, n, sf, sr, w );
 }
 
 } // namespace
@@ -856,7 +900,7 @@ extern "C" int x264hip_lookahead_open( x264hip_lookahead **out, int device, cons
     x264hip_ctx *ctx = nullptr;
     int rc = x264hip_open( &ctx, device, &p.dev );
     if( rc ) return rc;
-    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch, dev_mbtree, dev_qp_offsets, dev_put_batch };
+    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch, dev_mbtree, dev_qp_offsets, dev_put_batch, dev_prefetch_weights };
     rc = x264hip_lookahead_open_backend( out, &p, &be );
     if( rc ) { x264hip_close( ctx ); return rc; }
     ( *out )->L.ctx = ctx;

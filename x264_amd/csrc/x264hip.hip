@@ -36,6 +36,7 @@ struct CellEntry
 {
     unsigned char valid = 0;      // a speculative result for this cell sits in cell_acc
     unsigned char requested = 0;  // the caller has asked for this cell: never speculate it again
+    unsigned char variant = 1;    // B cells: evaluated with (1) or without (0) the list-1 reference's own L0 vectors
     unsigned tag0 = 0, tag1 = 0, tagr = 0; // tags of the fields the speculative evaluation consumed
     unsigned batch = 0;
 };
@@ -64,6 +65,7 @@ struct FrameSlot
     int wplane_idx = -1;          // weighted-plane pool entry in use by this slot's current weighted search
     uint64_t sum = 0, ssd = 0;
     int stats_valid = 0;
+    unsigned gen = 0;             // bumped whenever the slot receives a new frame
 };
 
 // Pinned-host / device descriptor tables are handed out round-robin; an entry is reused only after the event
@@ -113,8 +115,15 @@ struct x264hip_ctx
     unsigned *mbt_bar = nullptr;      // device [MBT_RING][2]: barrier arrivals, error
     int *acc_host = nullptr;         // pinned [8]
     int desc_cap = 0;
-    unsigned *wcost_dev = nullptr;   // device [2]: running sum, arrivals (self-resetting)
-    unsigned *wcost_host = nullptr;  // pinned: result of the last weight_cost launch
+    // weight costs: WCAP job entries, each with device counters [2][2] and a pinned result pair; entry 0 serves the
+    // on-demand call, the others hold speculative pairs (x264hip_prefetch_weight_costs) until their frames go away
+    static const int WCAP = 1024;
+    unsigned *wcost_dev = nullptr;   // device [WCAP][2][2]
+    unsigned *wcost_host = nullptr;  // pinned [WCAP][2]
+    DescRing wjob_ring;
+    struct WEntry { int slot_fenc = -1, slot_ref = -1; unsigned gen_fenc = 0, gen_ref = 0; x264hip_weight w; unsigned batch = 0; };
+    std::vector<WEntry> wcache;      // [WCAP], entry 0 unused
+    int wcache_next = 1;
     char *staging = nullptr;         // pinned luma staging
     size_t staging_bytes = 0;
     std::vector<char *> wplanes;     // weighted plane pool
@@ -128,6 +137,9 @@ struct x264hip_ctx
     int prof_on = 0, prof_used = 0;
     double prof_ms = 0; uint64_t prof_launches = 0, prof_searches = 0;
     uint64_t counters[8] = { 0 };
+    // how often callers asked for each B cell class with / without a searched L0 field of the list-1 reference
+    // (slicetype.c:629-642): speculation evaluates the variant asked for more often so far
+    uint32_t variant_req[( X264HIP_BFRAME_MAX + 2 ) * ( X264HIP_BFRAME_MAX + 2 )][2] = { { 0 } };
 };
 
 static const char *const g_errstr[] = { "ok", "no usable HIP device", "invalid argument", "out of memory", "device failure",
@@ -188,7 +200,7 @@ static void free_all( x264hip_ctx *ctx )
     }
     for( auto w : ctx->wplanes ) (void)hipFree( w );
     (void)hipFree( ctx->cost_mv_dev ); (void)hipFree( ctx->luts_dev ); (void)hipFree( ctx->sync_words ); (void)hipFree( ctx->acc_dev );
-    ring_free( ctx->cell_ring ); ring_free( ctx->put_ring ); ring_free( ctx->search_ring );
+    ring_free( ctx->cell_ring ); ring_free( ctx->put_ring ); ring_free( ctx->search_ring ); ring_free( ctx->wjob_ring );
     (void)hipHostFree( ctx->err_host );
     (void)hipHostFree( ctx->stats_host );
     if( ctx->stream2 ) (void)hipStreamSynchronize( ctx->stream2 );
@@ -301,9 +313,11 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     ctx->cell_desc_cap = 4096;
     OPENCK( ring_alloc( ctx->cell_ring, (size_t)ctx->cell_desc_cap * sizeof( CellArgs ) ) );
     OPENCK( hipHostMalloc( &ctx->acc_host, 8 * sizeof( int ) ) );
-    OPENCK( hipMalloc( &ctx->wcost_dev, 2 * sizeof( unsigned ) ) );
-    OPENCK( hipMemset( ctx->wcost_dev, 0, 2 * sizeof( unsigned ) ) );
-    OPENCK( hipHostMalloc( &ctx->wcost_host, sizeof( unsigned ) ) );
+    OPENCK( hipMalloc( &ctx->wcost_dev, (size_t)x264hip_ctx::WCAP * 4 * sizeof( unsigned ) ) );
+    OPENCK( hipMemset( ctx->wcost_dev, 0, (size_t)x264hip_ctx::WCAP * 4 * sizeof( unsigned ) ) );
+    OPENCK( hipHostMalloc( &ctx->wcost_host, (size_t)x264hip_ctx::WCAP * 2 * sizeof( unsigned ) ) );
+    OPENCK( ring_alloc( ctx->wjob_ring, (size_t)x264hip_ctx::WCAP * sizeof( WeightJob ) ) );
+    ctx->wcache.assign( x264hip_ctx::WCAP, x264hip_ctx::WEntry() );
     ctx->desc_cap = 2 * ( p.bframes + 1 ) * p.max_frames + 16;
     OPENCK( ring_alloc( ctx->search_ring, (size_t)ctx->desc_cap * sizeof( SearchDesc<uint8_t> ) ) );
     ctx->staging_bytes = (size_t)p.width * p.height * ctx->psz;
@@ -416,6 +430,7 @@ static int launch_ingest_t( x264hip_ctx *ctx, const PutDesc *descs_dev, const Pu
 static void slot_reset( x264hip_ctx *ctx, FrameSlot &s )
 {
     s.in_use = 1;
+    s.gen++;
     s.stats_valid = 0;
     memset( s.field_ready, 0, sizeof( s.field_ready ) );
     memset( s.field_prefetched, 0, sizeof( s.field_prefetched ) );
@@ -686,7 +701,7 @@ static CellArgs make_cell( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_
 
 struct SpecCell
 {
-    int slot_p0, slot_p1, slot_b, d0, d1, sums_only;
+    int slot_p0, slot_p1, slot_b, d0, d1, sums_only, ref1_valid;
 };
 
 // one batch: all P cells, all B cells, then one reduction launch (a workgroup per cell)
@@ -716,7 +731,7 @@ static int launch_cells_t( x264hip_ctx *ctx, const std::vector<SpecCell> &cells 
         for( int i = 0; i < n; i++ )
         {
             const SpecCell &c = *ord[i];
-            dh[i] = make_cell<T>( ctx, c.slot_p0, c.slot_p1, c.slot_b, c.d0, c.d1, 1, 1, c.sums_only );
+            dh[i] = make_cell<T>( ctx, c.slot_p0, c.slot_p1, c.slot_b, c.d0, c.d1, 1, c.ref1_valid, c.sums_only );
         }
         HIPCK( hipMemcpyAsync( dd, dh, (size_t)n * sizeof( CellArgs ), hipMemcpyHostToDevice, ctx->stream ) );
         CellArgs none;
@@ -777,7 +792,7 @@ extern "C" int x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *
         if( !e0.valid && !e0.requested )
         {
             e0.valid = 1; e0.batch = ctx->batch_serial + 1; e0.tag0 = e0.tag1 = e0.tagr = 0;
-            cells.push_back( SpecCell{ slots[i], slots[i], slots[i], 0, 0, 1 } );
+            cells.push_back( SpecCell{ slots[i], slots[i], slots[i], 0, 0, 1, 0 } );
         }
         for( int d0 = 1; d0 <= bf + 1; d0++ )
         {
@@ -787,20 +802,22 @@ extern "C" int x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *
             {
                 CellEntry &e = b.cells[d0 * nstride + d1];
                 if( e.valid || e.requested ) continue;
-                int j1 = j0;
+                int j1 = j0, variant = 1;
                 unsigned t1 = 0, tr = 0;
                 if( d1 )
                 {
                     j1 = find( frame_numbers[i] + d1 );
                     if( j1 < 0 || !has_field( b, 1, d1 - 1 ) ) continue;
                     FrameSlot &f1 = ctx->slots[slots[j1]];
-                    if( !has_field( f1, 0, d0 + d1 - 1 ) ) continue;
+                    const uint32_t *rq = ctx->variant_req[d0 * nstride + d1];
+                    variant = rq[0] > rq[1] ? 0 : 1;
+                    if( variant && !has_field( f1, 0, d0 + d1 - 1 ) ) continue;
                     t1 = b.field_tag[1][d1 - 1];
-                    tr = f1.field_tag[0][d0 + d1 - 1];
+                    tr = variant ? f1.field_tag[0][d0 + d1 - 1] : 0;
                 }
-                e.valid = 1; e.batch = ctx->batch_serial + 1;
+                e.valid = 1; e.batch = ctx->batch_serial + 1; e.variant = (unsigned char)variant;
                 e.tag0 = b.field_tag[0][d0 - 1]; e.tag1 = t1; e.tagr = tr;
-                cells.push_back( SpecCell{ slots[j0], slots[d1 ? j1 : i], slots[i], d0, d1, 0 } );
+                cells.push_back( SpecCell{ slots[j0], slots[d1 ? j1 : i], slots[i], d0, d1, 0, variant } );
             }
         }
     }
@@ -864,7 +881,9 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
     const unsigned t0 = intra_only ? 0 : b.field_tag[0][d0 - 1];
     const unsigned t1 = b_bidir ? b.field_tag[1][d1 - 1] : 0;
     const unsigned tr = b_bidir && ref1_l0_valid ? f1.field_tag[0][d0 + d1 - 1] : 0;
-    const bool hit = e.valid && e.tag0 == t0 && e.tag1 == t1 && e.tagr == tr && ( !b_bidir || ref1_l0_valid );
+    const bool hit = e.valid && e.tag0 == t0 && e.tag1 == t1 && e.tagr == tr && ( !b_bidir || e.variant == ( ref1_l0_valid ? 1 : 0 ) );
+    if( b_bidir )
+        ctx->variant_req[idx][ref1_l0_valid ? 1 : 0]++;
     const int was_valid = e.valid;
     e.requested = 1;
     e.valid = 0;
@@ -890,7 +909,7 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
     }
     else
     {
-        ctx->counters[b_bidir ? 7 : 6]++;
+        ctx->counters[7]++;
         static const bool trace_miss = getenv( "X264HIP_TRACE_MISS" ) != nullptr;
         if( trace_miss )
             fprintf( stderr, "miss b=%d d0=%d d1=%d valid=%d tags have %u/%u/%u want %u/%u/%u ref1_ok=%d wi=%d search=%d,%d w=%d\n", b.frame_no, d0, d1, was_valid,
@@ -1015,6 +1034,68 @@ extern "C" int x264hip_get_propagate_cost( x264hip_ctx *ctx, int slot, uint16_t 
     return X264HIP_OK;
 }
 
+static WeightJob make_wjob( x264hip_ctx *ctx, int entry, FrameSlot &f, FrameSlot &r, const WtD &wt )
+{
+    WeightJob j;
+    memset( &j, 0, sizeof( j ) );
+    if( ctx->p.bit_depth == 8 ) { j.fenc0 = plane_origin<uint8_t>( ctx, f, 0 ); j.ref0 = plane_origin<uint8_t>( ctx, r, 0 ); }
+    else { j.fenc0 = plane_origin<uint16_t>( ctx, f, 0 ); j.ref0 = plane_origin<uint16_t>( ctx, r, 0 ); }
+    j.intra_cost = f.lowres_costs;
+    j.w = wt;
+    j.accum = ctx->wcost_dev + 4 * entry;
+    j.out_host = ctx->wcost_host + 2 * entry;
+    return j;
+}
+
+static bool same_weight( const x264hip_weight &a, const x264hip_weight &b )
+{
+    return a.on == b.on && a.scale == b.scale && a.denom == b.denom && a.offset == b.offset;
+}
+
+extern "C" int x264hip_prefetch_weight_costs( x264hip_ctx *ctx, int n, const int *slot_fenc, const int *slot_ref, const x264hip_weight *w )
+{
+    if( !ctx || n < 0 || ( n && ( !slot_fenc || !slot_ref || !w ) ) ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    if( !n ) return X264HIP_OK;
+    if( n > x264hip_ctx::WCAP - 1 ) n = x264hip_ctx::WCAP - 1; // a cache: dropping work is always allowed
+    int ri = 0;
+    if( ring_acquire( ctx->wjob_ring, &ri ) ) return X264HIP_EDEVICE;
+    WeightJob *jh = (WeightJob *)ctx->wjob_ring.host[ri], *jd = (WeightJob *)ctx->wjob_ring.dev[ri];
+    int m = 0;
+    for( int i = 0; i < n; i++ )
+    {
+        if( !slot_ok( ctx, slot_fenc[i] ) || !slot_ok( ctx, slot_ref[i] ) ) return X264HIP_EINVAL;
+        FrameSlot &f = ctx->slots[slot_fenc[i]], &r = ctx->slots[slot_ref[i]];
+        if( !f.in_use || !r.in_use || !w[i].on ) continue;
+        const int e = ctx->wcache_next;
+        ctx->wcache_next = e + 1 < x264hip_ctx::WCAP ? e + 1 : 1;
+        x264hip_ctx::WEntry &we = ctx->wcache[e];
+        // an entry about to be reused may still be running only if more than WCAP pairs are in flight: wait then
+        if( we.slot_fenc >= 0 && we.batch > ctx->batch_synced )
+        {
+            int rc = sync_stream( ctx );
+            if( rc ) return rc;
+        }
+        we.slot_fenc = slot_fenc[i]; we.slot_ref = slot_ref[i]; we.gen_fenc = f.gen; we.gen_ref = r.gen; we.w = w[i];
+        we.batch = ctx->batch_serial + 1;
+        jh[m++] = make_wjob( ctx, e, f, r, make_wt( ctx, &w[i] ) );
+    }
+    if( !m ) return X264HIP_OK;
+    HIPCK( hipMemcpyAsync( jd, jh, (size_t)m * sizeof( WeightJob ), hipMemcpyHostToDevice, ctx->stream ) );
+    const dim3 grid( ( ctx->n_mb + 15 ) / 16, m, 2 );
+    WeightJob none;
+    memset( &none, 0, sizeof( none ) );
+    if( ctx->p.bit_depth == 8 )
+        weight_cost_kernel<uint8_t><<<grid, 256, 0, ctx->stream>>>( ctx->P, jd, none, 0 );
+    else
+        weight_cost_kernel<uint16_t><<<grid, 256, 0, ctx->stream>>>( ctx->P, jd, none, 0 );
+    HIPCK( hipGetLastError() );
+    if( ring_commit( ctx->wjob_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
+    ctx->batch_serial++;
+    return X264HIP_OK;
+}
+
 extern "C" int x264hip_weight_cost( x264hip_ctx *ctx, int slot_fenc, int slot_ref, const x264hip_weight *w, unsigned *cost )
 {
     if( !ctx || !cost || !slot_ok( ctx, slot_fenc ) || !slot_ok( ctx, slot_ref ) ) return X264HIP_EINVAL;
@@ -1022,19 +1103,32 @@ extern "C" int x264hip_weight_cost( x264hip_ctx *ctx, int slot_fenc, int slot_re
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     FrameSlot &f = ctx->slots[slot_fenc], &r = ctx->slots[slot_ref];
     if( !f.in_use || !r.in_use ) return X264HIP_ESTATE;
-    const LaP &P = ctx->P;
-    const WtD wt = make_wt( ctx, w );
-    const int grid = ( ctx->n_mb + 15 ) / 16;
+    const bool weighted = w && w->on;
+    // speculative result?  (unweighted sum: any pair of these two frames; weighted: the same weight)
+    for( int e = 1; e < x264hip_ctx::WCAP; e++ )
+    {
+        const x264hip_ctx::WEntry &we = ctx->wcache[e];
+        if( we.slot_fenc != slot_fenc || we.slot_ref != slot_ref || we.gen_fenc != f.gen || we.gen_ref != r.gen ) continue;
+        if( weighted && !same_weight( we.w, *w ) ) continue;
+        if( we.batch > ctx->batch_synced )
+        {
+            int rc = sync_stream( ctx );
+            if( rc ) return rc;
+        }
+        *cost = ( (volatile unsigned *)ctx->wcost_host )[2 * e + ( weighted ? 1 : 0 )];
+        ctx->counters[6]++;
+        return X264HIP_OK;
+    }
+    const WeightJob j = make_wjob( ctx, 0, f, r, make_wt( ctx, w ) );
+    const dim3 grid( ( ctx->n_mb + 15 ) / 16, 1, 1 );
     if( ctx->p.bit_depth == 8 )
-        weight_cost_kernel<uint8_t><<<grid, 256, 0, ctx->stream>>>( P, plane_origin<uint8_t>( ctx, f, 0 ), plane_origin<uint8_t>( ctx, r, 0 ), wt,
-                                                                   f.lowres_costs, ctx->wcost_dev, ctx->wcost_host );
+        weight_cost_kernel<uint8_t><<<grid, 256, 0, ctx->stream>>>( ctx->P, nullptr, j, weighted ? 1 : 0 );
     else
-        weight_cost_kernel<uint16_t><<<grid, 256, 0, ctx->stream>>>( P, plane_origin<uint16_t>( ctx, f, 0 ), plane_origin<uint16_t>( ctx, r, 0 ), wt,
-                                                                    f.lowres_costs, ctx->wcost_dev, ctx->wcost_host );
+        weight_cost_kernel<uint16_t><<<grid, 256, 0, ctx->stream>>>( ctx->P, nullptr, j, weighted ? 1 : 0 );
     HIPCK( hipGetLastError() );
     int rc = sync_stream( ctx );
     if( rc ) return rc;
-    *cost = *(volatile unsigned *)ctx->wcost_host;
+    *cost = ( (volatile unsigned *)ctx->wcost_host )[weighted ? 1 : 0];
     return X264HIP_OK;
 }
 

@@ -261,10 +261,14 @@ QP_OFFSETS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float))
 PUT_BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_int)
 
 
+PREFETCH_WEIGHTS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(Weight))
+
+
 class Backend(C.Structure):
     _fields_ = [("user", C.c_void_p), ("frame_put", FRAME_PUT_FN), ("frame_stats", FRAME_STATS_FN),
                 ("weight_cost", WEIGHT_COST_FN), ("frame_cost", FRAME_COST_FN), ("prefetch", PREFETCH_FN),
-                ("mbtree", MBTREE_FN), ("get_qp_offsets", QP_OFFSETS_FN), ("frame_put_batch", PUT_BATCH_FN)]
+                ("mbtree", MBTREE_FN), ("get_qp_offsets", QP_OFFSETS_FN), ("frame_put_batch", PUT_BATCH_FN),
+                ("prefetch_weight_costs", PREFETCH_WEIGHTS_FN)]
 
 
 class LaFrameOut(C.Structure):

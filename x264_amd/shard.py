@@ -11,18 +11,29 @@ def segment_bounds(n_frames, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
+_BMASK = np.zeros((18, 18), bool)
+for _i in range(1, 18):
+    for _j in range(1, 18 - _i):
+        _BMASK[_i, _j] = True
+
+
+def _bcell_max(ce):
+    return ce[_BMASK].max()
+
+
 def summarize(outs, frame_offset=0):
     """[n,4] int32 rows (display frame number, slice type, cost of the chosen cell, bframes) from lookahead outputs."""
-    rows = []
-    for o in outs:
+    rows = np.zeros((len(outs), 4), np.int32)
+    for k, o in enumerate(outs):
+        ce = np.frombuffer(o.cost_est, dtype=np.int32).reshape(18, 18)  # the ctypes array, viewed in place
         if o.type < 3:
-            cost = o.cost_est[0][0]
+            cost = ce[0, 0]
         elif o.type == 3:
-            cost = max(max(o.cost_est[d][0] for d in range(1, 18)), 0)
+            cost = max(int(ce[1:, 0].max()), 0)
         else:
-            cost = max(max(o.cost_est[i][j] for i in range(1, 18) for j in range(1, 18 - i)), 0)
-        rows.append((o.frame + frame_offset, o.type, cost, o.bframes))
-    return np.array(rows, np.int32).reshape(-1, 4)
+            cost = max(int(_bcell_max(ce)), 0)
+        rows[k] = (o.frame + frame_offset, o.type, cost, o.bframes)
+    return rows
 
 
 def gather_summaries(summary, dist, device=None):
