@@ -30,7 +30,7 @@ def per_kernel(path):
 
 fetch = per_kernel(os.path.join(src, "pmc_fetch", "run_counter_collection.csv"))
 write = per_kernel(os.path.join(src, "pmc_write", "run_counter_collection.csv"))
-out = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --no-cpu-baseline --no-primitives --steps 1 --warmup 0 --frames 64",
+out = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --no-cpu-baseline --no-primitives --steps 1 --warmup 0 --frames 64 --inflight 1 (one segment: PMC values of concurrently running kernels would mix)",
        "units": "counter values are KiB (bytes = value * 1024), one pass per counter", "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, [0, 0.0, 0]), write.get(k, [0, 0.0, 0])

@@ -363,39 +363,51 @@ struct SearchDesc
     int pad;
 };
 
-// ME_WG_ROWS consecutive rows of one search may share a workgroup (one wave each) so that their overlapping
-// reference windows meet in one CU's L1.  Measured on MI355X (1080p, 945 searches per launch): 1 row per
-// workgroup 15.1 ms, 4 rows 16.0 ms -- the kernel is bound by L1 tag throughput and dependent-load latency,
-// not by L2 misses, so the plain one-wave workgroup stays the default.
-#define ME_WG_ROWS 1
+// The searches of a launch are split into ME_QUEUES contiguous groups (neighbouring frames), one ticket counter
+// each, and a wave serves the group of the XCD it runs on: the planes of a group then live in ONE of the eight
+// L2s instead of being fetched into all of them (a row band of every frame of the launch is active at any time,
+// far more than a 4 MB L2 holds).  The XCD id is used for locality only: a wave whose own group has no rows left
+// takes rows from the other groups, so every row is claimed whatever the dispatcher's workgroup placement is,
+// and the order inside a group still guarantees that the row below holds an earlier ticket.
+#define ME_QUEUES 8
+#define ME_QUEUE_STRIDE 16 // counters 64 bytes apart
+struct MeQueues
+{
+    int base[ME_QUEUES + 1]; // searches [base[q], base[q+1]) belong to group q
+};
+
+__device__ __forceinline__ int xcc_id()
+{
+    return __builtin_amdgcn_s_getreg( 20 | ( 0 << 6 ) | ( ( 4 - 1 ) << 11 ) ) & ( ME_QUEUES - 1 ); // HW_REG_XCC_ID[3:0]
+}
+
 template <typename T>
-__global__ __launch_bounds__( 64 * ME_WG_ROWS ) __attribute__( ( amdgpu_waves_per_eu( 8, 8 ) ) ) void me_rows_kernel( LaP P, const SearchDesc<T> *descs, int n_search,
-                                                                    unsigned *sync_words /* [0] row ticket */,
+__global__ __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 8, 8 ) ) ) void me_rows_kernel( LaP P, const SearchDesc<T> *descs, MeQueues Q,
+                                                                    unsigned *tickets /* [ME_QUEUES * ME_QUEUE_STRIDE] */,
                                                                     unsigned *err_host /* pinned sticky timeout flag */, unsigned spin_limit )
 {
     const int lane = lane_id();
-#if ME_WG_ROWS == 1
     // the ticket is wave-uniform: fetch it on lane 0 and broadcast through an SGPR so that the row index, the
     // descriptor and everything derived from them stay scalar
-    const int wave = 0;
-    unsigned t0 = 0;
-    if( lane == 0 )
-        t0 = atomicAdd( &sync_words[0], 1u );
-    const unsigned t = __builtin_amdgcn_readfirstlane( t0 );
-#else
-    __shared__ unsigned wg_ticket;
-    const int wave = __builtin_amdgcn_readfirstlane( threadIdx.x >> 6 );
-    if( threadIdx.x == 0 )
-        wg_ticket = atomicAdd( &sync_words[0], 1u );
-    __syncthreads();
-    const unsigned t = __builtin_amdgcn_readfirstlane( wg_ticket );
-#endif
-    const int row_groups = ( P.mb_h + ME_WG_ROWS - 1 ) / ME_WG_ROWS;
-    if( t >= (unsigned)( n_search * row_groups ) )
-        return;
-    const int jg = t / n_search, s = t - jg * n_search;
-    const int j = jg * ME_WG_ROWS + wave;
-    if( j >= P.mb_h )
+    const int home = xcc_id();
+    int j = 0, s = -1;
+    for( int k = 0; k < ME_QUEUES && s < 0; k++ )
+    {
+        const int q = ( home + k ) & ( ME_QUEUES - 1 );
+        const int n_q = Q.base[q + 1] - Q.base[q];
+        if( !n_q )
+            continue;
+        unsigned t0 = 0;
+        if( lane == 0 )
+            t0 = atomicAdd( &tickets[q * ME_QUEUE_STRIDE], 1u );
+        const unsigned t = __builtin_amdgcn_readfirstlane( t0 );
+        if( t < (unsigned)( n_q * P.mb_h ) )
+        {
+            j = t / n_q;
+            s = Q.base[q] + ( t - j * n_q );
+        }
+    }
+    if( s < 0 )
         return;
     const int by = P.mb_h - 1 - j;
     const SearchDesc<T> D = descs[s];

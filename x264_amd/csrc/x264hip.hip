@@ -94,7 +94,7 @@ struct x264hip_ctx
     std::vector<FrameSlot> slots;
     uint16_t *cost_mv_dev = nullptr; // base (not centred)
     AqLuts *luts_dev = nullptr;
-    unsigned *sync_words = nullptr;  // device [2]
+    unsigned *sync_words = nullptr;  // device: row-ticket counters of the search kernel
     int *acc_dev = nullptr;          // [8]
     int n_cells = 0;                 // (bframes+2)^2
     int *cell_acc_host = nullptr;    // pinned [slots][n_cells][8]: sums of every cell evaluation, written by the device directly
@@ -288,8 +288,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         OPENCK( hipMalloc( &ctx->luts_dev, sizeof( AqLuts ) ) );
         OPENCK( hipMemcpy( ctx->luts_dev, &l, sizeof( l ), hipMemcpyHostToDevice ) );
     }
-    OPENCK( hipMalloc( &ctx->sync_words, 2 * sizeof( unsigned ) ) );   // [0]: row ticket of the search kernel
-    OPENCK( hipMemset( ctx->sync_words, 0, 2 * sizeof( unsigned ) ) );
+    OPENCK( hipMalloc( &ctx->sync_words, ME_QUEUES * ME_QUEUE_STRIDE * sizeof( unsigned ) ) ); // row tickets of the search kernel
+    OPENCK( hipMemset( ctx->sync_words, 0, ME_QUEUES * ME_QUEUE_STRIDE * sizeof( unsigned ) ) );
     OPENCK( hipMalloc( &ctx->acc_dev, 8 * sizeof( int ) ) );
     ctx->n_cells = ( p.bframes + 2 ) * ( p.bframes + 2 );
     OPENCK( hipHostMalloc( &ctx->cell_acc_host, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
@@ -634,7 +634,7 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         dh[i] = d;
     }
     HIPCK( hipMemcpyAsync( dd, dh, (size_t)n * sizeof( SearchDesc<T> ), hipMemcpyHostToDevice, ctx->stream ) );
-    HIPCK( hipMemsetAsync( ctx->sync_words, 0, sizeof( unsigned ), ctx->stream ) ); // row ticket
+    HIPCK( hipMemsetAsync( ctx->sync_words, 0, ME_QUEUES * ME_QUEUE_STRIDE * sizeof( unsigned ), ctx->stream ) ); // row tickets
     hipEvent_t e0 = ctx->ev_start, e1 = ctx->ev_stop;
     if( ctx->prof_on )
     {
@@ -648,7 +648,10 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         ctx->prof_used += 2;
     }
     HIPCK( hipEventRecord( e0, ctx->stream ) );
-    me_rows_kernel<T><<<n * ( ( P.mb_h + ME_WG_ROWS - 1 ) / ME_WG_ROWS ), 64 * ME_WG_ROWS, 0, ctx->stream>>>( P, dd, n, ctx->sync_words, ctx->err_host, 1u << 22 );
+    MeQueues Q;
+    for( int q = 0; q <= ME_QUEUES; q++ )
+        Q.base[q] = (int)( (long long)n * q / ME_QUEUES ); // contiguous groups: the request list is in frame order
+    me_rows_kernel<T><<<n * P.mb_h, 64, 0, ctx->stream>>>( P, dd, Q, ctx->sync_words, ctx->err_host, 1u << 22 );
     HIPCK( hipEventRecord( e1, ctx->stream ) );
     if( ring_commit( ctx->search_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
     HIPCK( hipGetLastError() );
