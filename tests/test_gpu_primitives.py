@@ -55,6 +55,7 @@ def test_pixel_cmp_batch(depth, dims):
                 mvd = torch.from_numpy(mv).cuda()
                 for satd in (0, 1):
                     out = torch.full((bw * bh,), -1, dtype=torch.int32, device="cuda")
+                    torch.cuda.synchronize()  # torch fills on its own stream; the context launches on another one
                     ctx.pixel_cmp_batch(satd, size_idx, fd.data_ptr() + org, rd.data_ptr() + org, stride, bw, bh, mvd.data_ptr(), out.data_ptr())
                     ctx.synchronize()
                     got = out.cpu().numpy()
@@ -86,6 +87,7 @@ def test_frame_init_lowres_core(depth):
             vdt = np.uint8 if depth == 8 else np.int16
             sd = torch.from_numpy(src.view(vdt)).cuda()
             dd = torch.zeros((4, h, w), dtype=sd.dtype, device="cuda")
+            torch.cuda.synchronize()  # torch fills on its own stream; the context launches on another one
             ctx.frame_init_lowres_core(sd.data_ptr(), [dd[i].data_ptr() for i in range(4)], src.shape[1], w, w, h)
             ctx.synchronize()
             got = dd.cpu().numpy().view(o.dtype)
