@@ -62,6 +62,32 @@ def primitives_bench(torch, libmod, cfg, iters=30):
                     nbytes = bw * bh * (2 * size * size + 4)  # SURVEY 8(d) per-block form: both blocks + the result
                     out["%s_%dx%d%s_GBps" % ("satd" if satd else "sad", size, size, tag)] = round(nbytes / dt / 1e9, 1)
             del fenc, ref
+        # hpel_filter (first piece) over a 4K plane: W*H read + 3*W*H written
+        hs = W + 64
+        src = torch.randint(0, 256, (H + 16, hs), dtype=torch.uint8, device="cuda", generator=g)
+        dst = torch.empty((3, H + 16, hs), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ho = 8 * hs + 32
+        def run_hpel():
+            ctx.hpel_filter(dst[0].data_ptr() + ho, dst[1].data_ptr() + ho, dst[2].data_ptr() + ho, src.data_ptr() + ho, hs, W, H)
+        run_hpel(); ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            run_hpel()
+        ctx.synchronize()
+        out["hpel_filter_GBps"] = round(4 * W * H * iters / (time.perf_counter() - t0) / 1e9, 1)
+        del src, dst
+        # the build's own copy kernel over 512 MB (read + write counted): the measured HBM rate next to the 8 TB/s vendor peak
+        a = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+        b = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ctx.device_copy(b.data_ptr(), a.data_ptr(), a.numel()); ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            ctx.device_copy(b.data_ptr(), a.data_ptr(), a.numel())
+        ctx.synchronize()
+        out["device_copy_GBps"] = round(2 * a.numel() * 10 / (time.perf_counter() - t0) / 1e9, 1)
+        del a, b
         luma = torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda", generator=g)
         torch.cuda.synchronize()
         ctx.frame_put(0, None, device_ptr=luma.data_ptr(), stride=W); ctx.synchronize()
@@ -116,6 +142,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--preset", default="slow")
+    ap.add_argument("--bit-depth", type=int, default=8, choices=(8, 10))
     ap.add_argument("--me", default="dia")
     ap.add_argument("--paced", action="store_true", help="encoder-paced put/get instead of the deep-prefetch batch")
     ap.add_argument("--inflight", type=int, default=2,
@@ -148,13 +175,14 @@ def main():
             dist.init_process_group(backend)
 
     W, H, F = args.width, args.height, args.frames
-    cfg = lib.la_config(W, H, args.preset, me=args.me)
+    cfg = lib.la_config(W, H, args.preset, bit_depth=args.bit_depth, me=args.me)
     # every rank gets its own segment of the synthetic sequence (different seed = different content)
     S = max(1, args.inflight)
     # every (rank, segment) gets its own part of the synthetic sequence (different seed = different content)
     seg_frames, seg_dev, seg_ptrs, las = [], [], [], []
     for sgi in range(S):
-        fr = make_clip(W, H, F, seed=100 + rank * S + sgi, scene_cuts=(F // 3, F // 3 + 47), fade=(2 * F // 3, 10, 0.6, 12), pan=(5, 3))
+        fr = make_clip(W, H, F, seed=100 + rank * S + sgi, bit_depth=args.bit_depth, scene_cuts=(F // 3, F // 3 + 47), fade=(2 * F // 3, 10, 0.6, 12),
+                       pan=(5, 3))
         dv = torch.from_numpy(fr).cuda(dev_index)
         seg_frames.append(fr); seg_dev.append(dv); seg_ptrs.append([dv[i].data_ptr() for i in range(F)])
         las.append(lib.Lookahead(cfg, device=dev_index, max_frames=F + 4))
@@ -242,12 +270,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8",
+            "dtype": "u8" if args.bit_depth == 8 else "u16",
             "data": "synthetic",
-            "config": {"workload": "%dx%d 8-bit 4:2:0 synthetic, --preset %s --me %s (BASELINE configs[1]): full lookahead "
+            "config": {"workload": "%dx%d %d-bit 4:2:0 synthetic, --preset %s --me %s%s: full lookahead "
                                    "(lowres+AQ+intra+ME+cost cells+slicetype decision+MB-tree), %d GOP segment(s) of %d frames in flight per GPU "
                                    "per step, %s" %
-                                   (W, H, args.preset, args.me, S, F, "encoder-paced" if args.paced else "deep-prefetch batch"),
+                                   (W, H, args.bit_depth, args.preset, args.me,
+                                    " (BASELINE configs[1])" if (W, H, args.bit_depth, args.preset, args.me) == (1920, 1080, 8, "slow", "dia") else "",
+                                    S, F, "encoder-paced" if args.paced else "deep-prefetch batch"),
                        "frames_per_step": S * F, "segments_in_flight": S, "bframes": cfg["bframes"], "b_adapt": cfg["b_adapt"], "rc_lookahead": cfg["rc_lookahead"],
                        "parallelism": "gop-segments x%d" % world, "slice_types": types[:64]},
             "roofline": {"bound": "hbm", "kernel": "me_rows_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -167,6 +167,13 @@ int  x264hip_get_propagate_cost( x264hip_ctx *ctx, int slot, uint16_t *propagate
  * mv[i].  Planes are device pointers.  Used for parity and for the SAD/SATD GB/s metric. */
 int  x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx, const void *fenc_plane, const void *ref_plane,
                               int stride, int blocks_w, int blocks_h, const int16_t *mv_dev, int *out_dev );
+/* x264_mc_functions_t.hpel_filter (common/mc.h:306-307, mc.c:172-196) without the scratch row buffer: the three
+ * half-pel planes of `src` (device pointers, element stride).  Like the reference it reads src columns -2..width+2
+ * and rows -2..height+2 and also writes dstv columns -2,-1 and width..width+2.  First piece of SURVEY 8(f) rank 3. */
+int  x264hip_hpel_filter( x264hip_ctx *ctx, void *dsth, void *dstv, void *dstc, const void *src, intptr_t stride, int width, int height );
+/* plain device-to-device copy on the context's stream (16-byte aligned): the build's own copy kernel, whose measured
+ * GB/s is the second denominator of the SAD/SATD figures next to the vendor peak */
+int  x264hip_device_copy( x264hip_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes );
 /* x264_mc_functions_t.frame_init_lowres_core (common/mc.h:326-327): device pointers, same arguments */
 int  x264hip_frame_init_lowres_core( x264hip_ctx *ctx, const void *src0, void *dst0, void *dsth, void *dstv, void *dstc,
                                      intptr_t src_stride, intptr_t dst_stride, int width, int height );

@@ -379,6 +379,10 @@ RH_API void rh_lowres_core( rh_ctx *c, pixel *src, pixel *d0, pixel *dh, pixel *
 {
     c->h->mc.frame_init_lowres_core( src, d0, dh, dv, dc, ss, ds, w, hh );
 }
+RH_API void rh_hpel_filter( rh_ctx *c, pixel *dsth, pixel *dstv, pixel *dstc, pixel *src, intptr_t stride, int w, int hh, int16_t *buf )
+{
+    c->h->mc.hpel_filter( dsth, dstv, dstc, src, stride, w, hh, buf );
+}
 /* planes: 4 pointers to the same-geometry hpel planes; returns via dst (always materialised) */
 RH_API void rh_mc_luma( rh_ctx *c, pixel *dst, intptr_t ds, pixel *p0, pixel *p1, pixel *p2, pixel *p3, intptr_t ss,
                         int mvx, int mvy, int w, int hh, int wt_on, int scale, int denom, int offset )

@@ -61,6 +61,31 @@ void ORN(lowres_core)( const pixel *src, pixel *d0, pixel *dh, pixel *dv, pixel 
     }
 }
 
+/* Half-pel planes of a full-resolution plane, common/mc.c:172-196 (hpel_filter): six-tap (1,-5,20,20,-5,1)
+ * vertically (dstv, columns -2 .. width+2), horizontally (dsth), and both (dstc: the horizontal taps run over
+ * the unrounded vertical sums, which the reference parks in an int16 row buffer, offset by -10*PIXEL_MAX for
+ * the high bit depths so that they fit). */
+static inline int tap6( int a, int b, int c, int d, int e, int f ) { return a + f - 5*( b + e ) + 20*( c + d ); }
+void ORN(hpel_filter)( pixel *dsth, pixel *dstv, pixel *dstc, const pixel *src, long stride, int width, int height, int16_t *buf )
+{
+    const int pixel_max = ( 1 << OR_DEPTH ) - 1;
+    const int pad = OR_DEPTH > 9 ? -10 * pixel_max : 0;
+    for( int y = 0; y < height; y++ )
+    {
+        for( int x = -2; x < width + 3; x++ )
+        {
+            int v = tap6( src[x-2*stride], src[x-stride], src[x], src[x+stride], src[x+2*stride], src[x+3*stride] );
+            dstv[x] = clip_pixel( ( v + 16 ) >> 5 );
+            buf[x+2] = (int16_t)( v + pad );
+        }
+        for( int x = 0; x < width; x++ )
+            dstc[x] = clip_pixel( ( tap6( buf[x], buf[x+1], buf[x+2], buf[x+3], buf[x+4], buf[x+5] ) - 32*pad + 512 ) >> 10 );
+        for( int x = 0; x < width; x++ )
+            dsth[x] = clip_pixel( ( tap6( src[x-2], src[x-1], src[x], src[x+1], src[x+2], src[x+3] ) + 16 ) >> 5 );
+        dsth += stride; dstv += stride; dstc += stride; src += stride;
+    }
+}
+
 /* src is the picture as handed to the encoder (width x height, not necessarily mod 16).  The
  * reference first replicates the last column/row out to the mod16 size and then one more
  * column/row (mc.c:466-468); both are the same as clamping the source coordinate. */

@@ -57,6 +57,7 @@ typedef struct or_cell_out
 void or##D##_lowres_init( const PIX *src, int src_stride, int width, int height, int mb_w, int mb_h, \
                           PIX *p0, PIX *ph, PIX *pv, PIX *pc, int stride ); \
 void or##D##_lowres_core( const PIX *src, PIX *d0, PIX *dh, PIX *dv, PIX *dc, int src_stride, int dst_stride, int w, int h ); \
+void or##D##_hpel_filter( PIX *dsth, PIX *dstv, PIX *dstc, const PIX *src, long stride, int width, int height, int16_t *buf ); \
 int  or##D##_sad( const PIX *a, int sa, const PIX *b, int sb, int w, int h ); \
 int  or##D##_ssd( const PIX *a, int sa, const PIX *b, int sb, int w, int h ); \
 int  or##D##_satd( const PIX *a, int sa, const PIX *b, int sb, int w, int h ); \

@@ -122,3 +122,38 @@ def test_dct_quant_batch(depth, is8):
         rnz = quant(1 if is8 else 0, _ptr(c), _ptr(mf), _ptr(bias), 0, 0)
         assert np.array_equal(coefs[i], c), i
         assert int(nz[i]) == rnz, i
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_hpel_filter(depth):
+    """x264_mc_functions_t.hpel_filter (mc.c:172-196) on whole planes, incl. the extra dstv columns; checkasm.c:1600-1640
+    exercises it with random data, here also the saturating checkerboard."""
+    import torch
+    o = Oracle(depth)
+    maxv = (1 << depth) - 1
+    rng = np.random.default_rng(21 + depth)
+    f = o.f("hpel_filter")
+    f.argtypes = [C.c_void_p] * 4 + [C.c_long, C.c_int, C.c_int, C.c_void_p]
+    ctx = lib.Context(64, 64, bit_depth=depth, max_frames=2, mv_range=32)
+    try:
+        for w, h, kind in [(64, 16, "r"), (100, 9, "r"), (37, 5, "x"), (1920, 1080, "r"), (130, 33, "x")]:
+            stride = w + 32
+            src = rng.integers(0, maxv + 1, size=(h + 8, stride)).astype(o.dtype)
+            if kind == "x":
+                src[:] = np.where((np.indices(src.shape).sum(0) & 1) == 0, 0, maxv).astype(o.dtype)
+            off = 3 * stride + 8
+            exp = [np.full((h + 8, stride), 7, o.dtype) for _ in range(3)]
+            buf = np.zeros(w + 64, np.int16)
+            f(_ptr(exp[0], off), _ptr(exp[1], off), _ptr(exp[2], off), _ptr(src, off), stride, w, h, _ptr(buf))
+            vdt = np.uint8 if depth == 8 else np.int16
+            sd = torch.from_numpy(src.view(vdt)).cuda()
+            dd = torch.full((3, h + 8, stride), 7, dtype=sd.dtype, device="cuda")
+            torch.cuda.synchronize()
+            ob = off * src.itemsize
+            ctx.hpel_filter(dd[0].data_ptr() + ob, dd[1].data_ptr() + ob, dd[2].data_ptr() + ob, sd.data_ptr() + ob, stride, w, h)
+            ctx.synchronize()
+            got = dd.cpu().numpy().view(o.dtype)
+            for k in range(3):
+                assert np.array_equal(got[k], exp[k]), (w, h, kind, "hvc"[k])
+    finally:
+        ctx.close()

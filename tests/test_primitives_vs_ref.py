@@ -152,6 +152,30 @@ def test_lowres_core(env):
         assert np.array_equal(a, b)
 
 
+def test_hpel_filter(env):
+    """oracle vs h->mc.hpel_filter incl. the five extra dstv columns (common/mc.c:172-196)"""
+    r, o, d = env
+    rng = np.random.default_rng(8)
+    maxv = (1 << d) - 1
+    L = r.lib
+    L.rh_hpel_filter.argtypes = [C.c_void_p] * 5 + [C.c_long, C.c_int, C.c_int, C.c_void_p]
+    f = o.f("hpel_filter")
+    f.argtypes = [C.c_void_p] * 4 + [C.c_long, C.c_int, C.c_int, C.c_void_p]
+    for w, h, kind in [(64, 16, "r"), (100, 9, "r"), (37, 5, "x"), (128, 32, "r"), (48, 48, "x")]:
+        stride = w + 32
+        src = rng.integers(0, maxv + 1, size=(h + 8, stride)).astype(o.dtype)
+        if kind == "x":
+            src[:] = np.where((np.indices(src.shape).sum(0) & 1) == 0, 0, maxv).astype(o.dtype)
+        off = 3 * stride + 8
+        a = [np.full((h + 8, stride), 7, o.dtype) for _ in range(3)]
+        b = [np.full((h + 8, stride), 7, o.dtype) for _ in range(3)]
+        buf = np.zeros(w + 64, np.int16)
+        L.rh_hpel_filter(r.ctx, _ptr(a[0], off), _ptr(a[1], off), _ptr(a[2], off), _ptr(src, off), stride, w, h, _ptr(buf))
+        f(_ptr(b[0], off), _ptr(b[1], off), _ptr(b[2], off), _ptr(src, off), stride, w, h, _ptr(buf))
+        for k in range(3):
+            assert np.array_equal(a[k], b[k]), (w, h, kind, k)
+
+
 def test_dct_quant(env):
     r, o, d = env
     rng = np.random.default_rng(6)

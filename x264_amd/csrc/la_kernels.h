@@ -737,6 +737,75 @@ __global__ __launch_bounds__( 256 ) void pixel_cmp_batch_kernel( const T *__rest
         out[bi[0]] = SATD ? v >> 1 : v;
 }
 
+// ---- hpel_filter (common/mc.c:172-196; x264_mc_functions_t.hpel_filter, mc.h:306-307) -------------------------
+// The three half-pel planes of a full-resolution plane: 64x16 output tiles, the source tile (+2/+3 samples each
+// way) and the unrounded vertical six-tap sums staged in LDS, so every source sample is read from HBM once per
+// tile.  dstv also gets the reference's five extra columns (-2,-1, width..width+2).  The reference's int16 row
+// buffer with its -10*PIXEL_MAX offset is only a storage trick: the offset cancels in the six taps (sum 32).
+#define HPEL_TW 64
+#define HPEL_TH 16
+template <typename T>
+__global__ __launch_bounds__( 256 ) void hpel_filter_kernel( T *__restrict__ dsth, T *__restrict__ dstv, T *__restrict__ dstc, const T *__restrict__ src,
+                                                             long stride, int width, int height, int pixel_max )
+{
+    __shared__ T s_src[HPEL_TH + 5][HPEL_TW + 6];
+    __shared__ int s_v[HPEL_TH][HPEL_TW + 6];
+    const int x0 = blockIdx.x * HPEL_TW, y0 = blockIdx.y * HPEL_TH;
+    const int t = threadIdx.x;
+    // source tile: columns x0-2 .. x0+TW+2, rows y0-2 .. y0+TH+2, never beyond what the reference itself reads
+    for( int i = t; i < ( HPEL_TH + 5 ) * ( HPEL_TW + 5 ); i += 256 )
+    {
+        const int r = i / ( HPEL_TW + 5 ), c = i - r * ( HPEL_TW + 5 );
+        const int x = imin2( x0 - 2 + c, width + 2 ), y = imin2( y0 - 2 + r, height + 2 );
+        s_src[r][c] = src[(long)y * stride + x];
+    }
+    __syncthreads();
+    for( int i = t; i < HPEL_TH * ( HPEL_TW + 5 ); i += 256 )
+    {
+        const int r = i / ( HPEL_TW + 5 ), c = i - r * ( HPEL_TW + 5 );
+        s_v[r][c] = (int)s_src[r][c] + (int)s_src[r + 5][c] - 5 * ( (int)s_src[r + 1][c] + (int)s_src[r + 4][c] ) +
+                    20 * ( (int)s_src[r + 2][c] + (int)s_src[r + 3][c] );
+    }
+    __syncthreads();
+    const int tx = t & 63;
+    const int x = x0 + tx;
+    const bool first_tile = blockIdx.x == 0, last_tile = x0 + HPEL_TW >= width;
+#pragma unroll
+    for( int pass = 0; pass < HPEL_TH / 4; pass++ )
+    {
+        const int r = ( t >> 6 ) + 4 * pass, y = y0 + r;
+        if( y >= height )
+            continue;
+        const long row = (long)y * stride;
+        if( x < width )
+        {
+            const int c = tx + 2; // column of x inside the tiles
+            const int v = s_v[r][c];
+            dstv[row + x] = (T)iclip3( ( v + 16 ) >> 5, 0, pixel_max );
+            const int cc = s_v[r][c - 2] + s_v[r][c + 3] - 5 * ( s_v[r][c - 1] + s_v[r][c + 2] ) + 20 * ( v + s_v[r][c + 1] );
+            dstc[row + x] = (T)iclip3( ( cc + 512 ) >> 10, 0, pixel_max );
+            const T *sr = s_src[r + 2];
+            const int hh = (int)sr[c - 2] + (int)sr[c + 3] - 5 * ( (int)sr[c - 1] + (int)sr[c + 2] ) + 20 * ( (int)sr[c] + (int)sr[c + 1] );
+            dsth[row + x] = (T)iclip3( ( hh + 16 ) >> 5, 0, pixel_max );
+        }
+        if( tx < 5 )
+        {
+            // the reference's extra dstv columns
+            const int xe = tx < 2 ? tx - 2 : width + tx - 2;
+            if( tx < 2 ? first_tile : last_tile )
+                dstv[row + xe] = (T)iclip3( ( s_v[r][xe - ( x0 - 2 )] + 16 ) >> 5, 0, pixel_max );
+        }
+    }
+}
+
+// Plain device copy, 16 bytes per lane: the measured HBM rate the SAD/SATD figures are quoted against
+// (vendor peak and the build's own copy kernel).
+__global__ __launch_bounds__( 256 ) void copy16_kernel( const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16 )
+{
+    for( size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x )
+        dst[i] = src[i];
+}
+
 // ---- D1/Q1 as batched primitives (common/dct.c:157-205,332-386, common/quant.c:50-104) -----------------
 // One thread per 4x4 (or 8x8) block; parity/microbench entry, not a production path.
 template <typename T, typename C>

@@ -1271,6 +1271,35 @@ extern "C" int x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx
     return X264HIP_OK;
 }
 
+extern "C" int x264hip_hpel_filter( x264hip_ctx *ctx, void *dsth, void *dstv, void *dstc, const void *src, intptr_t stride, int width, int height )
+{
+    if( !ctx || !dsth || !dstv || !dstc || !src || width <= 0 || height <= 0 || stride < width ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    const dim3 grd( ( width + HPEL_TW - 1 ) / HPEL_TW, ( height + HPEL_TH - 1 ) / HPEL_TH );
+    if( ctx->p.bit_depth == 8 )
+        hpel_filter_kernel<uint8_t><<<grd, 256, 0, ctx->stream>>>( (uint8_t *)dsth, (uint8_t *)dstv, (uint8_t *)dstc, (const uint8_t *)src, (long)stride, width, height,
+                                                                   ctx->P.pixel_max );
+    else
+        hpel_filter_kernel<uint16_t><<<grd, 256, 0, ctx->stream>>>( (uint16_t *)dsth, (uint16_t *)dstv, (uint16_t *)dstc, (const uint16_t *)src, (long)stride, width,
+                                                                    height, ctx->P.pixel_max );
+    HIPCK( hipGetLastError() );
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_device_copy( x264hip_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes )
+{
+    if( !ctx || !dst_dev || !src_dev || ( bytes & 15 ) || ( (uintptr_t)dst_dev & 15 ) || ( (uintptr_t)src_dev & 15 ) ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    const size_t n16 = bytes / 16;
+    const int grid = (int)std::min<size_t>( ( n16 + 255 ) / 256, (size_t)ctx->n_cu * 32 );
+    if( grid )
+        copy16_kernel<<<grid, 256, 0, ctx->stream>>>( (const uint4 *)src_dev, (uint4 *)dst_dev, n16 );
+    HIPCK( hipGetLastError() );
+    return X264HIP_OK;
+}
+
 extern "C" int x264hip_frame_init_lowres_core( x264hip_ctx *ctx, const void *src0, void *dst0, void *dsth, void *dstv, void *dstc,
                                                intptr_t src_stride, intptr_t dst_stride, int width, int height )
 {

@@ -214,6 +214,13 @@ class Context:
         _ck(self.L.x264hip_pixel_cmp_batch(self.h, int(satd), int(size_idx), C.c_void_p(fenc_ptr), C.c_void_p(ref_ptr), int(stride),
                                            int(blocks_w), int(blocks_h), C.c_void_p(mv_ptr), C.c_void_p(out_ptr)), "pixel_cmp_batch")
 
+    def hpel_filter(self, dsth_ptr, dstv_ptr, dstc_ptr, src_ptr, stride, width, height):
+        _ck(self.L.x264hip_hpel_filter(self.h, C.c_void_p(dsth_ptr), C.c_void_p(dstv_ptr), C.c_void_p(dstc_ptr), C.c_void_p(src_ptr),
+                                       C.c_ssize_t(stride), int(width), int(height)), "hpel_filter")
+
+    def device_copy(self, dst_ptr, src_ptr, nbytes):
+        _ck(self.L.x264hip_device_copy(self.h, C.c_void_p(dst_ptr), C.c_void_p(src_ptr), C.c_size_t(nbytes)), "device_copy")
+
     def frame_init_lowres_core(self, src_ptr, dst_ptrs, src_stride, dst_stride, width, height):
         _ck(self.L.x264hip_frame_init_lowres_core(self.h, C.c_void_p(src_ptr), *[C.c_void_p(p) for p in dst_ptrs], C.c_ssize_t(src_stride),
                                                   C.c_ssize_t(dst_stride), int(width), int(height)), "frame_init_lowres_core")
