@@ -40,19 +40,22 @@ def test_lookahead_vs_golden(name, paced):
     assert st[1] > nf  # real evaluations happened on the device
 
 
-@pytest.mark.skipif(not refharness.available(8), reason="oracle/_ref did not travel")
-@pytest.mark.parametrize("W,H,preset,opts,over,nf", [
-    (1920, 1080, "slow", "me=dia", dict(me="dia"), 56),          # BASELINE configs[1]
-    (3840, 2160, "slower", "me=umh,merange=32", dict(me="umh", me_range=32), 24),  # BASELINE configs[2], shortened
+@pytest.mark.skipif(not refharness.available(8) or not refharness.available(10), reason="oracle/_ref did not travel")
+@pytest.mark.parametrize("W,H,depth,preset,opts,over,nf", [
+    (1920, 1080, 8, "slow", "me=dia", dict(me="dia"), 56),          # BASELINE configs[1]
+    (3840, 2160, 8, "slower", "me=umh,merange=32", dict(me="umh", me_range=32), 24),  # BASELINE configs[2], shortened
+    # BASELINE configs[4] (8K 10-bit veryslow + tesa: HEX range 24, fpelcmp = SATD, bframes 8, b-adapt 2) at a quarter of
+    # the area and a dozen frames, so that the reference C path finishes in seconds
+    (3840, 2160, 10, "veryslow", "me=tesa", dict(me="tesa"), 14),
 ])
-def test_full_size_vs_reference(W, H, preset, opts, over, nf):
-    frames = make_clip(W, H, nf, seed=21, scene_cuts=(nf // 2,), pan=(5, 3))
-    r = refharness.Ref(W, H, preset, opts=opts)
+def test_full_size_vs_reference(W, H, depth, preset, opts, over, nf):
+    frames = make_clip(W, H, nf, seed=21, bit_depth=depth, scene_cuts=(nf // 2,), pan=(5, 3))
+    r = refharness.Ref(W, H, preset, opts=opts, bit_depth=depth)
     try:
         ref = r.lookahead_run(frames, with_qp_offsets=True)
     finally:
         r.close()
-    cfg = lib.la_config(W, H, preset, **over)
+    cfg = lib.la_config(W, H, preset, bit_depth=depth, **over)
     la = lib.Lookahead(cfg)
     try:
         outs = la.run(frames, qp_offsets=True)
