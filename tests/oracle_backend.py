@@ -9,8 +9,14 @@ from x264_amd import lib
 
 
 class OracleBackend:
-    def __init__(self, cfg, cost_mv=None):
+    def __init__(self, cfg, cost_mv=None, speculative=False):
+        """speculative=True also offers the optional prefetch entries (as no-op / recording stubs), so that the host's
+        ahead-of-time submission paths run on CPU: weight pairs announced through prefetch_weight_costs are remembered
+        and every later weighted weight_cost request is checked against them."""
         self.cfg = cfg
+        self.speculative = speculative
+        self.announced = set()
+        self.weighted_requests = self.weighted_predicted = 0
         self.o = Oracle(cfg["bit_depth"])
         mb_w, mb_h = (cfg["width"] + 15) // 16, (cfg["height"] + 15) // 16
         self.ocfg = self.o.make_cfg(mb_w, mb_h, me_method=cfg["la_me_method"], subpel_refine=cfg["la_subpel_refine"],
@@ -21,8 +27,18 @@ class OracleBackend:
         self.slots = {}
         self.n_eval = 0
         self.struct = lib.Backend(None, lib.FRAME_PUT_FN(self._put), lib.FRAME_STATS_FN(self._stats),
-                                  lib.WEIGHT_COST_FN(self._wcost), lib.FRAME_COST_FN(self._cost), lib.PREFETCH_FN(0),
-                                  lib.MBTREE_FN(self._mbtree), lib.QP_OFFSETS_FN(self._qp), lib.PUT_BATCH_FN(0))
+                                  lib.WEIGHT_COST_FN(self._wcost), lib.FRAME_COST_FN(self._cost),
+                                  lib.PREFETCH_FN(self._prefetch) if speculative else lib.PREFETCH_FN(0),
+                                  lib.MBTREE_FN(self._mbtree), lib.QP_OFFSETS_FN(self._qp), lib.PUT_BATCH_FN(0),
+                                  lib.PREFETCH_WEIGHTS_FN(self._prefetch_weights) if speculative else lib.PREFETCH_WEIGHTS_FN(0))
+
+    def _prefetch(self, user, slots, numbers, n):
+        return 0
+
+    def _prefetch_weights(self, user, n, sf, sr, w):
+        for i in range(n):
+            self.announced.add((sf[i], sr[i], w[i].on, w[i].scale, w[i].denom, w[i].offset))
+        return 0
 
     def _put(self, user, slot, luma, stride, is_device):
         c = self.cfg
@@ -43,6 +59,9 @@ class OracleBackend:
 
     def _wcost(self, user, sf, sr, w, out):
         wt = OWeight(w[0].on, w[0].scale, w[0].denom, w[0].offset) if w else None
+        if w and w[0].on:
+            self.weighted_requests += 1
+            self.weighted_predicted += (sf, sr, w[0].on, w[0].scale, w[0].denom, w[0].offset) in self.announced
         out[0] = self.o.weight_cost(self.ocfg, self.slots[sf]["planes"], self.slots[sr]["planes"], wt, self.slots[sf]["intra"])
         return 0
 

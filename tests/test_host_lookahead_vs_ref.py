@@ -68,3 +68,42 @@ def test_lookahead_matches_reference(preset, opts, over, depth, ckw, nf):
         assert np.array_equal(ca[m], ref["cost_aq"][k][:nb, :nb][m]), ("i_cost_est_aq", k, o.frame)
         assert np.array_equal(o.qp_offset, ref["qp_offset"][k]), ("f_qp_offset", k, o.frame, o.type)
     assert be.n_eval > nf
+
+
+@pytest.mark.parametrize("paced", [True, False])
+def test_speculative_weight_pairs_predict_every_request(paced):
+    """The host computes the (scale, offset) candidate of every weight test ahead of time and announces the pairs
+    (x264hip_prefetch_weight_costs); the decisions must not change and every weighted cost request that
+    x264_weights_analyse makes later must be one of the announced pairs (same frames, same weight)."""
+    W, H, nf = 176, 144, 70
+    frames = make_clip(W, H, nf, seed=12, fade=(8, 14, 1.6, -25), scene_cuts=(44,))
+    r = refharness.Ref(W, H, "medium", opts="")
+    try:
+        ref = r.lookahead_run(frames)
+    finally:
+        r.close()
+    cfg = lib.la_config(W, H, "medium")
+    be = OracleBackend(cfg, speculative=True)
+    la = lib.Lookahead(cfg, backend=be.struct, max_frames=nf + 4)
+    try:
+        outs = la.run(frames, paced=paced) if paced else _run_unpaced(la, frames)
+    finally:
+        la.close()
+    assert [o.frame for o in outs] == list(ref["idx"]) and [o.type for o in outs] == list(ref["type"])
+    for o, c in zip(outs, ref["cost"]):
+        got = np.array([[o.cost_est[i][j] for j in range(5)] for i in range(5)])
+        assert np.array_equal(got, c[:5, :5])
+    assert be.weighted_requests > 0, "the clip was meant to exercise weightp"
+    assert be.weighted_predicted == be.weighted_requests
+
+
+def _run_unpaced(la, frames):
+    for f in frames:
+        la.put(f)
+    outs = []
+    while True:
+        o = la.get(True)
+        if o is None:
+            break
+        outs.append(o)
+    return outs

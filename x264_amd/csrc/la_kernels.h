@@ -361,11 +361,10 @@ struct WeightJob
 };
 
 template <typename T>
-__global__ __launch_bounds__( 256 ) void weight_cost_kernel( LaP P, const WeightJob *jobs, WeightJob single, int z_base )
+__global__ __launch_bounds__( 256 ) void weight_cost_kernel( LaP P, const WeightJob *jobs, WeightJob single, int mode /* 0 unweighted, 1 weighted, 2 both */ )
 {
-    __shared__ unsigned part[4];
+    __shared__ unsigned part[2][4];
     const WeightJob J = jobs ? jobs[blockIdx.y] : single;
-    const int z = blockIdx.z + z_base;
     const T *__restrict__ fenc0 = (const T *)J.fenc0, *__restrict__ ref0 = (const T *)J.ref0;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int g = lane >> 4, l = lane & 15, q = l >> 2;
@@ -376,22 +375,30 @@ __global__ __launch_bounds__( 256 ) void weight_cost_kernel( LaP P, const Weight
     const int bx = xyc % P.mb_w, by = xyc / P.mb_w;
     const int off = 8 * ( by * P.stride + bx ) + row * P.stride + tx;
     const Px4 f = load_px4( fenc0 + off );
-    Px4 r = load_px4( ref0 + off );
-    if( z && J.w.on )
-        r = weight_px4<T>( r, J.w, P.pixel_max );
+    const Px4 r = load_px4( ref0 + off );
     // the intra costs as the reference reads them here: after the 14-bit clamp of the [0][0] map (slicetype.c:712)
-    const int c = imin2( block_cost8x8<T>( f, r, P.mbcmp_satd ), imin2( (int)J.intra_cost[xyc], 0x3FFF ) );
-    unsigned tot = 0;
+    const int icost = imin2( (int)J.intra_cost[xyc], 0x3FFF );
+    // one pass over the pixels serves both sums of a pair
 #pragma unroll
-    for( int k = 0; k < 4; k++ )
-        if( first + k < n_mb )
-            tot += (unsigned)__builtin_amdgcn_readlane( c, 16 * k );
-    if( lane == 0 ) part[wave] = tot;
-    __syncthreads();
-    if( threadIdx.x == 0 )
+    for( int z = 0; z < 2; z++ )
     {
+        if( mode != 2 && mode != z )
+            continue;
+        const Px4 rz = z && J.w.on ? weight_px4<T>( r, J.w, P.pixel_max ) : r;
+        const int c = imin2( block_cost8x8<T>( f, rz, P.mbcmp_satd ), icost );
+        unsigned tot = 0;
+#pragma unroll
+        for( int k = 0; k < 4; k++ )
+            if( first + k < n_mb )
+                tot += (unsigned)__builtin_amdgcn_readlane( c, 16 * k );
+        if( lane == 0 ) part[z][wave] = tot;
+    }
+    __syncthreads();
+    if( threadIdx.x < 2 && ( mode == 2 || mode == (int)threadIdx.x ) )
+    {
+        const int z = threadIdx.x;
         unsigned *accum = J.accum + 2 * z;
-        atomicAdd( &accum[0], part[0] + part[1] + part[2] + part[3] );
+        atomicAdd( &accum[0], part[z][0] + part[z][1] + part[z][2] + part[z][3] );
         __threadfence();
         if( atomicAdd( &accum[1], 1u ) == gridDim.x - 1 )
         {
@@ -744,57 +751,110 @@ __global__ __launch_bounds__( 256 ) void pixel_cmp_batch_kernel( const T *__rest
 // buffer with its -10*PIXEL_MAX offset is only a storage trick: the offset cancels in the six taps (sum 32).
 #define HPEL_TW 64
 #define HPEL_TH 16
+#define HPEL_LW 72 // tile columns x0-2 .. x0+69 (66..69 unused padding), a multiple of four
+__device__ __forceinline__ void unpack4( uint32_t w, int v[4], const uint8_t * ) { v[0] = w & 255; v[1] = ( w >> 8 ) & 255; v[2] = ( w >> 16 ) & 255; v[3] = w >> 24; }
+template <typename T>
+__device__ __forceinline__ void lds_row4( const T *p, int v[4] ) // four consecutive samples from a 4-sample aligned LDS position
+{
+    if( sizeof( T ) == 1 )
+    {
+        const uint32_t w = *(const uint32_t *)p;
+        v[0] = w & 255; v[1] = ( w >> 8 ) & 255; v[2] = ( w >> 16 ) & 255; v[3] = w >> 24;
+    }
+    else
+    {
+        const uint2 w = *(const uint2 *)p;
+        v[0] = w.x & 0xFFFF; v[1] = w.x >> 16; v[2] = w.y & 0xFFFF; v[3] = w.y >> 16;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store4( T *p, const int v[4] ) // four consecutive samples to global memory (any alignment)
+{
+    if( sizeof( T ) == 1 )
+    {
+        const uint32_t w = (uint32_t)v[0] | ( (uint32_t)v[1] << 8 ) | ( (uint32_t)v[2] << 16 ) | ( (uint32_t)v[3] << 24 );
+        __builtin_memcpy( p, &w, 4 );
+    }
+    else
+    {
+        const uint2 w = make_uint2( (uint32_t)v[0] | ( (uint32_t)v[1] << 16 ), (uint32_t)v[2] | ( (uint32_t)v[3] << 16 ) );
+        __builtin_memcpy( p, &w, 8 );
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__( 256 ) void hpel_filter_kernel( T *__restrict__ dsth, T *__restrict__ dstv, T *__restrict__ dstc, const T *__restrict__ src,
                                                              long stride, int width, int height, int pixel_max )
 {
-    __shared__ T s_src[HPEL_TH + 5][HPEL_TW + 6];
-    __shared__ int s_v[HPEL_TH][HPEL_TW + 6];
+    __shared__ __attribute__( ( aligned( 16 ) ) ) T s_src[HPEL_TH + 5][HPEL_LW];
+    __shared__ __attribute__( ( aligned( 16 ) ) ) int s_v[HPEL_TH][HPEL_LW];
     const int x0 = blockIdx.x * HPEL_TW, y0 = blockIdx.y * HPEL_TH;
     const int t = threadIdx.x;
     // source tile: columns x0-2 .. x0+TW+2, rows y0-2 .. y0+TH+2, never beyond what the reference itself reads
-    for( int i = t; i < ( HPEL_TH + 5 ) * ( HPEL_TW + 5 ); i += 256 )
+    for( int i = t; i < ( HPEL_TH + 5 ) * HPEL_LW; i += 256 )
     {
-        const int r = i / ( HPEL_TW + 5 ), c = i - r * ( HPEL_TW + 5 );
+        const int r = i / HPEL_LW, c = i - r * HPEL_LW;
         const int x = imin2( x0 - 2 + c, width + 2 ), y = imin2( y0 - 2 + r, height + 2 );
         s_src[r][c] = src[(long)y * stride + x];
     }
     __syncthreads();
-    for( int i = t; i < HPEL_TH * ( HPEL_TW + 5 ); i += 256 )
+    // unrounded vertical six-tap sums, four columns per thread
+    for( int i = t; i < HPEL_TH * ( HPEL_LW / 4 ); i += 256 )
     {
-        const int r = i / ( HPEL_TW + 5 ), c = i - r * ( HPEL_TW + 5 );
-        s_v[r][c] = (int)s_src[r][c] + (int)s_src[r + 5][c] - 5 * ( (int)s_src[r + 1][c] + (int)s_src[r + 4][c] ) +
-                    20 * ( (int)s_src[r + 2][c] + (int)s_src[r + 3][c] );
+        const int r = i / ( HPEL_LW / 4 ), c = 4 * ( i - r * ( HPEL_LW / 4 ) );
+        int a[6][4];
+#pragma unroll
+        for( int k = 0; k < 6; k++ )
+            lds_row4<T>( &s_src[r + k][c], a[k] );
+        int4 v;
+        v.x = a[0][0] + a[5][0] - 5 * ( a[1][0] + a[4][0] ) + 20 * ( a[2][0] + a[3][0] );
+        v.y = a[0][1] + a[5][1] - 5 * ( a[1][1] + a[4][1] ) + 20 * ( a[2][1] + a[3][1] );
+        v.z = a[0][2] + a[5][2] - 5 * ( a[1][2] + a[4][2] ) + 20 * ( a[2][2] + a[3][2] );
+        v.w = a[0][3] + a[5][3] - 5 * ( a[1][3] + a[4][3] ) + 20 * ( a[2][3] + a[3][3] );
+        *(int4 *)&s_v[r][c] = v;
     }
     __syncthreads();
-    const int tx = t & 63;
-    const int x = x0 + tx;
-    const bool first_tile = blockIdx.x == 0, last_tile = x0 + HPEL_TW >= width;
-#pragma unroll
-    for( int pass = 0; pass < HPEL_TH / 4; pass++ )
+    // four outputs per thread: tile columns c+2 .. c+5 need the sums / samples of columns c .. c+8
+    const int r = t >> 4, c = 4 * ( t & 15 ), y = y0 + r, x = x0 + c;
+    if( y < height && x < width )
     {
-        const int r = ( t >> 6 ) + 4 * pass, y = y0 + r;
-        if( y >= height )
-            continue;
         const long row = (long)y * stride;
-        if( x < width )
+        __attribute__( ( aligned( 16 ) ) ) int sv[12];
+        int ss[12];
+        *(int4 *)&sv[0] = *(const int4 *)&s_v[r][c];
+        *(int4 *)&sv[4] = *(const int4 *)&s_v[r][c + 4];
+        *(int4 *)&sv[8] = *(const int4 *)&s_v[r][c + 8];
+        lds_row4<T>( &s_src[r + 2][c], ss );
+        lds_row4<T>( &s_src[r + 2][c + 4], ss + 4 );
+        lds_row4<T>( &s_src[r + 2][c + 8], ss + 8 );
+        int ov[4], oc[4], oh[4];
+#pragma unroll
+        for( int k = 0; k < 4; k++ )
         {
-            const int c = tx + 2; // column of x inside the tiles
-            const int v = s_v[r][c];
-            dstv[row + x] = (T)iclip3( ( v + 16 ) >> 5, 0, pixel_max );
-            const int cc = s_v[r][c - 2] + s_v[r][c + 3] - 5 * ( s_v[r][c - 1] + s_v[r][c + 2] ) + 20 * ( v + s_v[r][c + 1] );
-            dstc[row + x] = (T)iclip3( ( cc + 512 ) >> 10, 0, pixel_max );
-            const T *sr = s_src[r + 2];
-            const int hh = (int)sr[c - 2] + (int)sr[c + 3] - 5 * ( (int)sr[c - 1] + (int)sr[c + 2] ) + 20 * ( (int)sr[c] + (int)sr[c + 1] );
-            dsth[row + x] = (T)iclip3( ( hh + 16 ) >> 5, 0, pixel_max );
+            ov[k] = iclip3( ( sv[k + 2] + 16 ) >> 5, 0, pixel_max );
+            oc[k] = iclip3( ( sv[k] + sv[k + 5] - 5 * ( sv[k + 1] + sv[k + 4] ) + 20 * ( sv[k + 2] + sv[k + 3] ) + 512 ) >> 10, 0, pixel_max );
+            oh[k] = iclip3( ( ss[k] + ss[k + 5] - 5 * ( ss[k + 1] + ss[k + 4] ) + 20 * ( ss[k + 2] + ss[k + 3] ) + 16 ) >> 5, 0, pixel_max );
         }
-        if( tx < 5 )
+        if( x + 4 <= width )
         {
-            // the reference's extra dstv columns
-            const int xe = tx < 2 ? tx - 2 : width + tx - 2;
-            if( tx < 2 ? first_tile : last_tile )
-                dstv[row + xe] = (T)iclip3( ( s_v[r][xe - ( x0 - 2 )] + 16 ) >> 5, 0, pixel_max );
+            store4<T>( dstv + row + x, ov );
+            store4<T>( dstc + row + x, oc );
+            store4<T>( dsth + row + x, oh );
         }
+        else
+            for( int k = 0; x + k < width; k++ )
+            {
+                dstv[row + x + k] = (T)ov[k]; dstc[row + x + k] = (T)oc[k]; dsth[row + x + k] = (T)oh[k];
+            }
+    }
+    // the reference's five extra dstv columns (-2, -1, width .. width+2)
+    if( t < 5 * HPEL_TH )
+    {
+        const int e = t % 5, re = t / 5, ye = y0 + re;
+        const bool first_tile = blockIdx.x == 0, last_tile = x0 + HPEL_TW >= width;
+        const int xe = e < 2 ? e - 2 : width + e - 2;
+        if( ye < height && ( e < 2 ? first_tile : last_tile ) )
+            dstv[(long)ye * stride + xe] = (T)iclip3( ( s_v[re][xe - ( x0 - 2 )] + 16 ) >> 5, 0, pixel_max );
     }
 }
 

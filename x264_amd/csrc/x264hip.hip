@@ -1086,13 +1086,13 @@ extern "C" int x264hip_prefetch_weight_costs( x264hip_ctx *ctx, int n, const int
     }
     if( !m ) return X264HIP_OK;
     HIPCK( hipMemcpyAsync( jd, jh, (size_t)m * sizeof( WeightJob ), hipMemcpyHostToDevice, ctx->stream ) );
-    const dim3 grid( ( ctx->n_mb + 15 ) / 16, m, 2 );
+    const dim3 grid( ( ctx->n_mb + 15 ) / 16, m, 1 );
     WeightJob none;
     memset( &none, 0, sizeof( none ) );
     if( ctx->p.bit_depth == 8 )
-        weight_cost_kernel<uint8_t><<<grid, 256, 0, ctx->stream>>>( ctx->P, jd, none, 0 );
+        weight_cost_kernel<uint8_t><<<grid, 256, 0, ctx->stream>>>( ctx->P, jd, none, 2 );
     else
-        weight_cost_kernel<uint16_t><<<grid, 256, 0, ctx->stream>>>( ctx->P, jd, none, 0 );
+        weight_cost_kernel<uint16_t><<<grid, 256, 0, ctx->stream>>>( ctx->P, jd, none, 2 );
     HIPCK( hipGetLastError() );
     if( ring_commit( ctx->wjob_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
     ctx->batch_serial++;
