@@ -77,6 +77,22 @@ def primitives_bench(torch, libmod, cfg, iters=30):
         ctx.synchronize()
         out["hpel_filter_GBps"] = round(4 * W * H * iters / (time.perf_counter() - t0) / 1e9, 1)
         del src, dst
+        # frame-level sub4x4_dct + quant_4x4 (first piece): 2*W*H read, 2*W*H (int16 coefficients) + W*H/16 written
+        fe = torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda", generator=g)
+        fp = torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda", generator=g)
+        co = torch.empty((H // 4, W // 4, 16), dtype=torch.int16, device="cuda")
+        nzb = torch.empty((H // 4, W // 4), dtype=torch.uint8, device="cuda")
+        mfq = np.full(16, 13107, np.uint16); bq = np.full(16, 21845, np.uint16)
+        torch.cuda.synchronize()
+        def run_dq():
+            ctx.frame_dct_quant4x4(fe.data_ptr(), W, fp.data_ptr(), W, W, H, mfq, bq, co.data_ptr(), nzb.data_ptr())
+        run_dq(); ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            run_dq()
+        ctx.synchronize()
+        out["frame_dct_quant4x4_GBps"] = round((4 * W * H + W * H // 16) * iters / (time.perf_counter() - t0) / 1e9, 1)
+        del fe, fp, co, nzb
         # the build's own copy kernel over 512 MB (read + write counted): the measured HBM rate next to the 8 TB/s vendor peak
         a = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
         b = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")

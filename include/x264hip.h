@@ -167,6 +167,12 @@ int  x264hip_get_propagate_cost( x264hip_ctx *ctx, int slot, uint16_t *propagate
  * mv[i].  Planes are device pointers.  Used for parity and for the SAD/SATD GB/s metric. */
 int  x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx, const void *fenc_plane, const void *ref_plane,
                               int stride, int blocks_w, int blocks_h, const int16_t *mv_dev, int *out_dev );
+/* Frame form of sub4x4_dct + quant_4x4 (common/dct.c:157-175, common/quant.c:50-62; SURVEY 8f rank 4, first piece): every
+ * 4x4 block of the device-resident plane `fenc` minus the prediction plane `fdec`, transformed and quantised with the host
+ * tables mf/bias (16 x udctcoef: uint16 for 8-bit, uint32 for 10-bit).  coefs_dev: [height/4][width/4][16] dctcoef (int16 /
+ * int32) in the reference's per-block order, 16-byte aligned; nz_dev: one byte per block = quant_4x4's return value. */
+int  x264hip_frame_dct_quant4x4( x264hip_ctx *ctx, const void *fenc, intptr_t fenc_stride, const void *fdec, intptr_t fdec_stride, int width, int height,
+                                 const void *mf, const void *bias, void *coefs_dev, uint8_t *nz_dev );
 /* x264_mc_functions_t.hpel_filter (common/mc.h:306-307, mc.c:172-196) without the scratch row buffer: the three
  * half-pel planes of `src` (device pointers, element stride).  Like the reference it reads src columns -2..width+2
  * and rows -2..height+2 and also writes dstv columns -2,-1 and width..width+2.  First piece of SURVEY 8(f) rank 3. */

@@ -157,3 +157,45 @@ def test_hpel_filter(depth):
                 assert np.array_equal(got[k], exp[k]), (w, h, kind, "hvc"[k])
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_frame_dct_quant4x4(depth):
+    """sub4x4_dct + quant_4x4 of every block of a plane pair against the oracle's per-block functions."""
+    import torch
+    o = Oracle(depth)
+    maxv = (1 << depth) - 1
+    rng = np.random.default_rng(31 + depth)
+    W, H = 1036, 68  # 259 x 17 blocks: a ragged last wave
+    fs, ds = W + 12, W + 40
+    fenc = rng.integers(0, maxv + 1, size=(H, fs)).astype(o.dtype)
+    fdec = rng.integers(0, maxv + 1, size=(H, ds)).astype(o.dtype)
+    fenc[:4, :8] = maxv; fdec[:4, :8] = 0          # saturating blocks
+    fdec[4:8, :4] = fenc[4:8, :4]                  # zero residual
+    mf = rng.integers(500, 14000, size=16).astype(o.ucoef_dtype)
+    bias = rng.integers(0, 30000, size=16).astype(o.ucoef_dtype)
+    vdt = np.uint8 if depth == 8 else np.int16
+    fd, dd = torch.from_numpy(fenc.view(vdt)).cuda(), torch.from_numpy(fdec.view(vdt)).cuda()
+    bw, bh = W // 4, H // 4
+    cdt = torch.int16 if depth == 8 else torch.int32
+    coefs = torch.full((bh, bw, 16), 77, dtype=cdt, device="cuda")
+    nz = torch.full((bh, bw), 9, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx = lib.Context(64, 64, bit_depth=depth, max_frames=2, mv_range=32)
+    try:
+        ctx.frame_dct_quant4x4(fd.data_ptr(), fs, dd.data_ptr(), ds, W, H, mf, bias, coefs.data_ptr(), nz.data_ptr())
+        ctx.synchronize()
+    finally:
+        ctx.close()
+    got, gnz = coefs.cpu().numpy(), nz.cpu().numpy()
+    dct, quant = o.f("dct"), o.f("quant", C.c_int)
+    fe16 = np.zeros((4, 16), o.dtype); fd32 = np.zeros((4, 32), o.dtype)
+    for by in range(bh):
+        for bx in range(0, bw, 3 if by else 1):
+            fe16[:, :4] = fenc[4 * by:4 * by + 4, 4 * bx:4 * bx + 4]
+            fd32[:, :4] = fdec[4 * by:4 * by + 4, 4 * bx:4 * bx + 4]
+            c = np.zeros(16, o.coef_dtype)
+            dct(0, _ptr(c), _ptr(fe16), _ptr(fd32))
+            rnz = quant(0, _ptr(c), _ptr(mf), _ptr(bias), 0, 0)
+            assert np.array_equal(got[by, bx], c), (by, bx)
+            assert int(gnz[by, bx]) == rnz, (by, bx)

@@ -924,6 +924,58 @@ __global__ __launch_bounds__( 64 ) void dct_quant_kernel( int is8, int n_blocks,
 }
 
 
+// Frame form (first piece): sub4x4_dct + quant_4x4 (dct.c:157-175, quant.c:50-62) of EVERY 4x4 block
+// of a plane against a prediction plane, both resident on the device.  One thread per block, 64 horizontally adjacent
+// blocks per wave: each of the four row loads of a wave covers 256 contiguous bytes of a plane row, the sixteen
+// coefficients of a block leave as one 32-byte (8-bit) / 64-byte store.  Coefficients are laid out
+// [block_y][block_x][16] in the reference's per-block order; nz[block] = the quant return value.
+struct QuantTab
+{
+    uint32_t mf[16], bias[16];
+};
+
+template <typename T, typename C>
+__global__ __launch_bounds__( 256 ) void frame_dct_quant4x4_kernel( const T *__restrict__ fenc, long fenc_stride, const T *__restrict__ fdec, long fdec_stride,
+                                                                    int blocks_w, int blocks_h, QuantTab q, C *__restrict__ coefs, uint8_t *__restrict__ nz_out )
+{
+    const int bx = blockIdx.x * 256 + threadIdx.x, by = blockIdx.y;
+    if( bx >= blocks_w )
+        return;
+    int d[16];
+#pragma unroll
+    for( int y = 0; y < 4; y++ )
+    {
+        int a[4], b[4];
+        load4( fenc + (long)( 4 * by + y ) * fenc_stride + 4 * bx, a );
+        load4( fdec + (long)( 4 * by + y ) * fdec_stride + 4 * bx, b );
+#pragma unroll
+        for( int x = 0; x < 4; x++ )
+            d[4 * y + x] = a[x] - b[x];
+    }
+    int t[16], o[16];
+#pragma unroll
+    for( int y = 0; y < 4; y++ ) fdct4_1d_dev<T, C>( d + 4 * y, 1, t + y, 4 );
+#pragma unroll
+    for( int u = 0; u < 4; u++ ) fdct4_1d_dev<T, C>( t + 4 * u, 1, o + 4 * u, 1 );
+    int nz = 0;
+    __attribute__( ( aligned( 16 ) ) ) C out[16];
+#pragma unroll
+    for( int k = 0; k < 16; k++ )
+    {
+        int v = (C)o[k];
+        const unsigned m = q.mf[k], b = q.bias[k];
+        if( v > 0 ) v = (int)( ( b + (unsigned)v ) * m >> 16 );
+        else v = -(int)( ( b + (unsigned)( -v ) ) * m >> 16 );
+        out[k] = (C)v;
+        nz |= out[k];
+    }
+    C *dst = coefs + ( (size_t)by * blocks_w + bx ) * 16;
+#pragma unroll
+    for( int k = 0; k < (int)( 16 * sizeof( C ) / 16 ); k++ )
+        ( (uint4 *)dst )[k] = ( (const uint4 *)out )[k];
+    nz_out[(size_t)by * blocks_w + bx] = nz != 0;
+}
+
 // ---- MB-tree: common/mc.c:511-598, encoder/slicetype.c:1029-1089 -------------------------
 // The host hands over the ordered step list of one macroblock_tree() call; ONE workgroup walks it (steps depend on
 // each other through the propagate buffers, a frame at a time), 1024 threads over the macroblocks of a step.  It

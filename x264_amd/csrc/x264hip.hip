@@ -1271,6 +1271,32 @@ extern "C" int x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx
     return X264HIP_OK;
 }
 
+extern "C" int x264hip_frame_dct_quant4x4( x264hip_ctx *ctx, const void *fenc, intptr_t fenc_stride, const void *fdec, intptr_t fdec_stride, int width, int height,
+                                           const void *mf, const void *bias, void *coefs_dev, uint8_t *nz_dev )
+{
+    if( !ctx || !fenc || !fdec || !mf || !bias || !coefs_dev || !nz_dev || width <= 0 || height <= 0 || ( width & 3 ) || ( height & 3 ) ||
+        fenc_stride < width || fdec_stride < width || ( (uintptr_t)coefs_dev & 15 ) )
+        return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    QuantTab q;
+    for( int i = 0; i < 16; i++ )
+    {
+        q.mf[i] = ctx->p.bit_depth == 8 ? ( (const uint16_t *)mf )[i] : ( (const uint32_t *)mf )[i];     // udctcoef (common/common.h)
+        q.bias[i] = ctx->p.bit_depth == 8 ? ( (const uint16_t *)bias )[i] : ( (const uint32_t *)bias )[i];
+    }
+    const int bw = width / 4, bh = height / 4;
+    const dim3 grd( ( bw + 255 ) / 256, bh );
+    if( ctx->p.bit_depth == 8 )
+        frame_dct_quant4x4_kernel<uint8_t, int16_t><<<grd, 256, 0, ctx->stream>>>( (const uint8_t *)fenc, (long)fenc_stride, (const uint8_t *)fdec, (long)fdec_stride, bw, bh, q,
+                                                                                   (int16_t *)coefs_dev, nz_dev );
+    else
+        frame_dct_quant4x4_kernel<uint16_t, int32_t><<<grd, 256, 0, ctx->stream>>>( (const uint16_t *)fenc, (long)fenc_stride, (const uint16_t *)fdec, (long)fdec_stride, bw, bh,
+                                                                                    q, (int32_t *)coefs_dev, nz_dev );
+    HIPCK( hipGetLastError() );
+    return X264HIP_OK;
+}
+
 extern "C" int x264hip_hpel_filter( x264hip_ctx *ctx, void *dsth, void *dstv, void *dstc, const void *src, intptr_t stride, int width, int height )
 {
     if( !ctx || !dsth || !dstv || !dstc || !src || width <= 0 || height <= 0 || stride < width ) return X264HIP_EINVAL;
