@@ -774,8 +774,11 @@ struct Lookahead
         const int reach = (int)next.size() < i_delay + 2 ? (int)next.size() : i_delay + 2;
         int submitted = 0;
         while( submitted < (int)next.size() && next[submitted]->prefetch_submitted ) submitted++;
-        if( submitted >= reach ) return;
-        const int upto = (int)next.size() < reach + chunk ? (int)next.size() : reach + chunk;
+        // the next chunk goes out while half a chunk of submitted frames is still ahead of the decisions: its kernels
+        // then run while the host works through those (results are waited for per batch, not per stream)
+        if( submitted >= (int)next.size() || submitted >= reach + chunk / 2 ) return;
+        const int from = submitted > reach ? submitted : reach;
+        const int upto = (int)next.size() < from + chunk ? (int)next.size() : from + chunk;
         // everything resident up to there: last_nonb + next[0..upto) (pairs further apart than bframes+1 are skipped by the backend)
         std::vector<int> slots, nums;
         if( last_nonb ) { slots.push_back( last_nonb->slot ); nums.push_back( last_nonb->i_frame ); }

@@ -103,6 +103,8 @@ struct x264hip_ctx
     int put_desc_cap = 256;
     int cell_desc_cap = 0;
     unsigned batch_serial = 0, batch_synced = 0;
+    static const int BATCH_EVS = 64;
+    hipEvent_t batch_ev[64] = { nullptr }; // batch_ev[b % 64] is recorded behind speculative batch b
     unsigned long long *stats_host = nullptr; // pinned [slots][2]
     // MB-tree: own stream, ring of pinned/device step tables
     hipStream_t stream2 = nullptr;
@@ -213,6 +215,8 @@ static void free_all( x264hip_ctx *ctx )
     if( ctx->ev_cross ) (void)hipEventDestroy( ctx->ev_cross );
     if( ctx->ev_mbt_last ) (void)hipEventDestroy( ctx->ev_mbt_last );
     if( ctx->ev_ingest ) (void)hipEventDestroy( ctx->ev_ingest );
+    for( int i = 0; i < x264hip_ctx::BATCH_EVS; i++ )
+        if( ctx->batch_ev[i] ) (void)hipEventDestroy( ctx->batch_ev[i] );
     if( ctx->stream2 ) (void)hipStreamDestroy( ctx->stream2 );
     (void)hipHostFree( ctx->cell_acc_host );
     (void)hipFree( ctx->wcost_dev );
@@ -301,6 +305,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( hipEventCreateWithFlags( &ctx->ev_cross, hipEventDisableTiming ) );
     OPENCK( hipEventCreateWithFlags( &ctx->ev_mbt_last, hipEventDisableTiming ) );
     OPENCK( hipEventCreateWithFlags( &ctx->ev_ingest, hipEventDisableTiming ) );
+    for( int i = 0; i < x264hip_ctx::BATCH_EVS; i++ )
+        OPENCK( hipEventCreateWithFlags( &ctx->batch_ev[i], hipEventDisableTiming ) );
     OPENCK( hipMalloc( &ctx->mbt_bar, x264hip_ctx::MBT_RING * 2 * sizeof( unsigned ) ) );
     OPENCK( hipMemset( ctx->mbt_bar, 0, x264hip_ctx::MBT_RING * 2 * sizeof( unsigned ) ) );
     for( int i = 0; i < x264hip_ctx::MBT_RING; i++ )
@@ -598,6 +604,28 @@ static int sync_stream( x264hip_ctx *ctx )
     return X264HIP_OK;
 }
 
+// A speculative batch has been enqueued: give it the next serial and an event to wait on.
+static int batch_close( x264hip_ctx *ctx )
+{
+    ctx->batch_serial++;
+    HIPCK( hipEventRecord( ctx->batch_ev[ctx->batch_serial % x264hip_ctx::BATCH_EVS], ctx->stream ) );
+    return X264HIP_OK;
+}
+// Wait until batch b is complete -- only that far, so that work queued behind it keeps running while the host decides.
+static int batch_wait( x264hip_ctx *ctx, unsigned b )
+{
+    if( b <= ctx->batch_synced ) return X264HIP_OK;
+    if( ctx->batch_serial - b >= (unsigned)x264hip_ctx::BATCH_EVS ) return sync_stream( ctx ); // its event has been reused
+    HIPCK( hipEventSynchronize( ctx->batch_ev[b % x264hip_ctx::BATCH_EVS] ) );
+    if( b > ctx->batch_synced ) ctx->batch_synced = b;
+    if( *(volatile unsigned *)ctx->err_host )
+    {
+        ctx->broken = 1;
+        return X264HIP_ETIMEOUT;
+    }
+    return X264HIP_OK;
+}
+
 template <typename T>
 static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &reqs )
 {
@@ -829,7 +857,8 @@ extern "C" int x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *
         // entries carry batch_serial + 1; the serial moves only once the batch is enqueued
         int r = ctx->p.bit_depth == 8 ? launch_cells_t<uint8_t>( ctx, cells ) : launch_cells_t<uint16_t>( ctx, cells );
         if( r ) return r;
-        ctx->batch_serial++;
+        r = batch_close( ctx );
+        if( r ) return r;
         ctx->counters[5] += cells.size();
     }
     return X264HIP_OK;
@@ -898,11 +927,8 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
         static const bool trace_hit = getenv( "X264HIP_TRACE_MISS" ) != nullptr;
         if( trace_hit && b_bidir )
             fprintf( stderr, "hit b=%d d0=%d d1=%d ref1_ok=%d\n", b.frame_no, d0, d1, ref1_l0_valid );
-        if( e.batch > ctx->batch_synced )
-        {
-            int r = sync_stream( ctx );
-            if( r ) return r;
-        }
+        int r = batch_wait( ctx, e.batch );
+        if( r ) return r;
         if( intra_only )
         {
             // the sums are known; the map still has to take the reference's 14-bit clamp (aliases the intra costs)
@@ -1075,9 +1101,9 @@ extern "C" int x264hip_prefetch_weight_costs( x264hip_ctx *ctx, int n, const int
         ctx->wcache_next = e + 1 < x264hip_ctx::WCAP ? e + 1 : 1;
         x264hip_ctx::WEntry &we = ctx->wcache[e];
         // an entry about to be reused may still be running only if more than WCAP pairs are in flight: wait then
-        if( we.slot_fenc >= 0 && we.batch > ctx->batch_synced )
+        if( we.slot_fenc >= 0 )
         {
-            int rc = sync_stream( ctx );
+            int rc = batch_wait( ctx, we.batch );
             if( rc ) return rc;
         }
         we.slot_fenc = slot_fenc[i]; we.slot_ref = slot_ref[i]; we.gen_fenc = f.gen; we.gen_ref = r.gen; we.w = w[i];
@@ -1095,8 +1121,7 @@ extern "C" int x264hip_prefetch_weight_costs( x264hip_ctx *ctx, int n, const int
         weight_cost_kernel<uint16_t><<<grid, 256, 0, ctx->stream>>>( ctx->P, jd, none, 2 );
     HIPCK( hipGetLastError() );
     if( ring_commit( ctx->wjob_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
-    ctx->batch_serial++;
-    return X264HIP_OK;
+    return batch_close( ctx );
 }
 
 extern "C" int x264hip_weight_cost( x264hip_ctx *ctx, int slot_fenc, int slot_ref, const x264hip_weight *w, unsigned *cost )
@@ -1113,11 +1138,8 @@ extern "C" int x264hip_weight_cost( x264hip_ctx *ctx, int slot_fenc, int slot_re
         const x264hip_ctx::WEntry &we = ctx->wcache[e];
         if( we.slot_fenc != slot_fenc || we.slot_ref != slot_ref || we.gen_fenc != f.gen || we.gen_ref != r.gen ) continue;
         if( weighted && !same_weight( we.w, *w ) ) continue;
-        if( we.batch > ctx->batch_synced )
-        {
-            int rc = sync_stream( ctx );
-            if( rc ) return rc;
-        }
+        int rc = batch_wait( ctx, we.batch );
+        if( rc ) return rc;
         *cost = ( (volatile unsigned *)ctx->wcost_host )[2 * e + ( weighted ? 1 : 0 )];
         ctx->counters[6]++;
         return X264HIP_OK;
