@@ -142,6 +142,13 @@ struct x264hip_ctx
     // how often callers asked for each B cell class with / without a searched L0 field of the list-1 reference
     // (slicetype.c:629-642): speculation evaluates the variant asked for more often so far
     uint32_t variant_req[( X264HIP_BFRAME_MAX + 2 ) * ( X264HIP_BFRAME_MAX + 2 )][2] = { { 0 } };
+    // Which field classes (list, distance) and cell classes (d0, d1) the caller's decision flow ever asks for depends on
+    // its configuration (b-adapt mode, pyramid, bframes): after a learning period classes that were never requested are
+    // no longer speculated (a later request is still served, on demand).
+    uint32_t field_req[2][X264HIP_BFRAME_MAX + 1] = { { 0 } };
+    uint32_t cell_req[( X264HIP_BFRAME_MAX + 2 ) * ( X264HIP_BFRAME_MAX + 2 )] = { 0 };
+    uint32_t n_requests = 0;
+    static const uint32_t LEARN_REQUESTS = 400;
 };
 
 static const char *const g_errstr[] = { "ok", "no usable HIP device", "invalid argument", "out of memory", "device failure",
@@ -786,6 +793,8 @@ extern "C" int x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *
     std::vector<SearchReq> reqs;
     const WtD none = { 0, 1, 0, 0 };
     const int bf = ctx->p.bframes, nstride = bf + 2;
+    static const bool no_learn = getenv( "X264HIP_NO_CLASS_LEARNING" ) != nullptr; // debugging aid: speculate everything
+    const bool learned = !no_learn && ctx->n_requests >= x264hip_ctx::LEARN_REQUESTS;
     for( int i = 0; i < n; i++ )
     {
         if( !slot_ok( ctx, slots[i] ) || !ctx->slots[slots[i]].in_use ) return X264HIP_ESTATE;
@@ -798,6 +807,7 @@ extern "C" int x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *
             if( list && !bf ) continue;
             FrameSlot &b = ctx->slots[slots[i]];
             if( b.field_ready[list][dm1] || b.field_prefetched[list][dm1] ) continue;
+            if( learned && !ctx->field_req[list][dm1] ) continue; // a class this caller never asks for
             b.field_prefetched[list][dm1] = 1;
             reqs.push_back( SearchReq{ slots[i], slots[j], list, dm1, none } );
         }
@@ -833,6 +843,7 @@ extern "C" int x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *
             {
                 CellEntry &e = b.cells[d0 * nstride + d1];
                 if( e.valid || e.requested ) continue;
+                if( learned && !ctx->cell_req[d0 * nstride + d1] ) continue;
                 int j1 = j0, variant = 1;
                 unsigned t1 = 0, tr = 0;
                 if( d1 )
@@ -875,9 +886,13 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
     const int b_bidir = d1 > 0;
     const int idx = d0 * ( ctx->p.bframes + 2 ) + d1;
     std::vector<SearchReq> reqs;
+    ctx->n_requests++;
+    ctx->cell_req[idx]++;
     if( !intra_only )
     {
         const WtD wt = make_wt( ctx, w );
+        if( do_search[0] ) ctx->field_req[0][d0 - 1]++;
+        if( b_bidir && do_search[1] ) ctx->field_req[1][d1 - 1]++;
         if( do_search[0] )
         {
             if( b.field_prefetched[0][d0 - 1] && !wt.on )
