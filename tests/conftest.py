@@ -13,6 +13,20 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session", autouse=True)
+def _torch_runtime_first():
+    """PyTorch bundles its own copy of the HIP runtime (same SONAME as /opt/rocm's, which libx264hip.so links): whichever
+    is loaded first serves both.  Tests that hand torch tensors to the library initialise torch first, as bench.py does,
+    so the order in which test modules run does not matter."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
+    yield
+
+
+@pytest.fixture(scope="session", autouse=True)
 def _build_native():
     """Build the checker (oracle) and, when the reference tree is present, oracle/_ref."""
     from oracle import oraclelib

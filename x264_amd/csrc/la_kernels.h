@@ -360,6 +360,7 @@ struct WeightJob
     unsigned *out_host;           // pinned [2]
 };
 
+#define WCOST_BLOCKS_PER_WG 128 // 4 waves x 4 blocks x 8 passes
 template <typename T>
 __global__ __launch_bounds__( 256 ) void weight_cost_kernel( LaP P, const WeightJob *jobs, WeightJob single, int mode /* 0 unweighted, 1 weighted, 2 both */ )
 {
@@ -370,29 +371,36 @@ __global__ __launch_bounds__( 256 ) void weight_cost_kernel( LaP P, const Weight
     const int g = lane >> 4, l = lane & 15, q = l >> 2;
     const int tx = ( q & 1 ) * 4, row = ( q >> 1 ) * 4 + ( l & 3 );
     const int n_mb = P.mb_w * P.mb_h;
-    const int first = ( blockIdx.x * 4 + wave ) * 4;
-    const int xyc = imin2( first + g, n_mb - 1 );
-    const int bx = xyc % P.mb_w, by = xyc / P.mb_w;
-    const int off = 8 * ( by * P.stride + bx ) + row * P.stride + tx;
-    const Px4 f = load_px4( fenc0 + off );
-    const Px4 r = load_px4( ref0 + off );
-    // the intra costs as the reference reads them here: after the 14-bit clamp of the [0][0] map (slicetype.c:712)
-    const int icost = imin2( (int)J.intra_cost[xyc], 0x3FFF );
-    // one pass over the pixels serves both sums of a pair
-#pragma unroll
-    for( int z = 0; z < 2; z++ )
+    unsigned tot[2] = { 0, 0 };
+    // a workgroup covers WCOST_BLOCKS_PER_WG consecutive blocks (few workgroups per sum = few same-address atomics)
+#pragma unroll 2
+    for( int pass = 0; pass < WCOST_BLOCKS_PER_WG / 16; pass++ )
     {
-        if( mode != 2 && mode != z )
-            continue;
-        const Px4 rz = z && J.w.on ? weight_px4<T>( r, J.w, P.pixel_max ) : r;
-        const int c = imin2( block_cost8x8<T>( f, rz, P.mbcmp_satd ), icost );
-        unsigned tot = 0;
+        const int first = blockIdx.x * WCOST_BLOCKS_PER_WG + pass * 16 + wave * 4;
+        if( first >= n_mb )
+            break;
+        const int xyc = imin2( first + g, n_mb - 1 );
+        const int bx = xyc % P.mb_w, by = xyc / P.mb_w;
+        const int off = 8 * ( by * P.stride + bx ) + row * P.stride + tx;
+        const Px4 f = load_px4( fenc0 + off );
+        const Px4 r = load_px4( ref0 + off );
+        // the intra costs as the reference reads them here: after the 14-bit clamp of the [0][0] map (slicetype.c:712)
+        const int icost = imin2( (int)J.intra_cost[xyc], 0x3FFF );
+        // one pass over the pixels serves both sums of a pair
 #pragma unroll
-        for( int k = 0; k < 4; k++ )
-            if( first + k < n_mb )
-                tot += (unsigned)__builtin_amdgcn_readlane( c, 16 * k );
-        if( lane == 0 ) part[z][wave] = tot;
+        for( int z = 0; z < 2; z++ )
+        {
+            if( mode != 2 && mode != z )
+                continue;
+            const Px4 rz = z && J.w.on ? weight_px4<T>( r, J.w, P.pixel_max ) : r;
+            const int c = imin2( block_cost8x8<T>( f, rz, P.mbcmp_satd ), icost );
+#pragma unroll
+            for( int k = 0; k < 4; k++ )
+                if( first + k < n_mb )
+                    tot[z] += (unsigned)__builtin_amdgcn_readlane( c, 16 * k );
+        }
     }
+    if( lane == 0 ) { part[0][wave] = tot[0]; part[1][wave] = tot[1]; }
     __syncthreads();
     if( threadIdx.x < 2 && ( mode == 2 || mode == (int)threadIdx.x ) )
     {

@@ -1127,7 +1127,7 @@ extern "C" int x264hip_prefetch_weight_costs( x264hip_ctx *ctx, int n, const int
     }
     if( !m ) return X264HIP_OK;
     HIPCK( hipMemcpyAsync( jd, jh, (size_t)m * sizeof( WeightJob ), hipMemcpyHostToDevice, ctx->stream ) );
-    const dim3 grid( ( ctx->n_mb + 15 ) / 16, m, 1 );
+    const dim3 grid( ( ctx->n_mb + WCOST_BLOCKS_PER_WG - 1 ) / WCOST_BLOCKS_PER_WG, m, 1 );
     WeightJob none;
     memset( &none, 0, sizeof( none ) );
     if( ctx->p.bit_depth == 8 )
@@ -1160,7 +1160,7 @@ extern "C" int x264hip_weight_cost( x264hip_ctx *ctx, int slot_fenc, int slot_re
         return X264HIP_OK;
     }
     const WeightJob j = make_wjob( ctx, 0, f, r, make_wt( ctx, w ) );
-    const dim3 grid( ( ctx->n_mb + 15 ) / 16, 1, 1 );
+    const dim3 grid( ( ctx->n_mb + WCOST_BLOCKS_PER_WG - 1 ) / WCOST_BLOCKS_PER_WG, 1, 1 );
     if( ctx->p.bit_depth == 8 )
         weight_cost_kernel<uint8_t><<<grid, 256, 0, ctx->stream>>>( ctx->P, nullptr, j, weighted ? 1 : 0 );
     else
