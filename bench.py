@@ -216,33 +216,39 @@ def main():
     import concurrent.futures
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=S) if S > 1 else None
 
-    def run_segment(sgi):
+    def run_segment(sgi, n_steps):
+        """n_steps passes of segment slot sgi, back to back.  The segment slots of a GPU are independent pipelines: they do
+        not wait for each other between steps, so one slot's decision phases drift against the other's kernel phases
+        instead of being re-aligned at every step (every step of every slot still completes inside the timed region)."""
         la = las[sgi]
-        la.reset()
-        outs = la.run(device_ptrs=seg_ptrs[sgi], stride=W, paced=args.paced)
-        assert len(outs) == F
-        return outs
+        summaries, outs = [], None
+        for k in range(n_steps):
+            la.reset()
+            outs = la.run(device_ptrs=seg_ptrs[sgi], stride=W, paced=args.paced)
+            assert len(outs) == F
+            summaries.append(shard.summarize(outs, (rank * S + sgi) * F))
+        return outs, summaries
 
-    def step():
+    def run_steps(n_steps):
+        if n_steps <= 0:
+            return None
         if pool is None:
-            seg_outs = [run_segment(0)]
+            res = [run_segment(0, n_steps)]
         else:
-            seg_outs = list(pool.map(run_segment, range(S)))  # ctypes calls release the GIL: the segments really overlap
-        host = np.concatenate([shard.summarize(o, (rank * S + sgi) * F) for sgi, o in enumerate(seg_outs)])
-        if dist is not None:
-            # the only exchange of the path: per-frame summaries (16 B per frame)
-            gathered[0] = shard.gather_summaries(host, dist, device="cuda" if backend == "nccl" else None)
-        return seg_outs[0]
+            res = list(pool.map(lambda sgi: run_segment(sgi, n_steps), range(S)))  # ctypes calls release the GIL: the slots really overlap
+        for k in range(n_steps):
+            host = np.concatenate([r[1][k] for r in res])
+            if dist is not None:
+                # the only exchange of the path: per-frame summaries (16 B per frame), one all_gather per step
+                gathered[0] = shard.gather_summaries(host, dist, device="cuda" if backend == "nccl" else None)
+        return res[0][0]
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     barrier()
     for la in las:
         lib.search_profile(la.L, la.ctx_handle(), 1)
     t0 = time.perf_counter()
-    outs = None
-    for _ in range(args.steps):
-        outs = step()
+    outs = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     prof_ms = prof_launches = prof_searches = 0
