@@ -95,7 +95,6 @@ struct x264hip_ctx
     uint16_t *cost_mv_dev = nullptr; // base (not centred)
     AqLuts *luts_dev = nullptr;
     unsigned *sync_words = nullptr;  // device: row-ticket counters of the search kernel
-    int *acc_dev = nullptr;          // [8]
     int n_cells = 0;                 // (bframes+2)^2
     int *cell_acc_host = nullptr;    // pinned [slots][n_cells][8]: sums of every cell evaluation, written by the device directly
     DescRing cell_ring, put_ring, search_ring;
@@ -115,7 +114,6 @@ struct x264hip_ctx
     hipEvent_t ev_ingest = nullptr;  // behind the most recent ingest kernels: frame totals are readable after it
     int mbt_next = 0, mbt_pending = 0;
     unsigned *mbt_bar = nullptr;      // device [MBT_RING][2]: barrier arrivals, error
-    int *acc_host = nullptr;         // pinned [8]
     int desc_cap = 0;
     // weight costs: WCAP job entries, each with device counters [2][2] and a pinned result pair; entry 0 serves the
     // on-demand call, the others hold speculative pairs (x264hip_prefetch_weight_costs) until their frames go away
@@ -208,7 +206,7 @@ static void free_all( x264hip_ctx *ctx )
         (void)hipFree( s.planes ); // one allocation per slot holds everything
     }
     for( auto w : ctx->wplanes ) (void)hipFree( w );
-    (void)hipFree( ctx->cost_mv_dev ); (void)hipFree( ctx->luts_dev ); (void)hipFree( ctx->sync_words ); (void)hipFree( ctx->acc_dev );
+    (void)hipFree( ctx->cost_mv_dev ); (void)hipFree( ctx->luts_dev ); (void)hipFree( ctx->sync_words );
     ring_free( ctx->cell_ring ); ring_free( ctx->put_ring ); ring_free( ctx->search_ring ); ring_free( ctx->wjob_ring );
     (void)hipHostFree( ctx->err_host );
     (void)hipHostFree( ctx->stats_host );
@@ -227,7 +225,6 @@ static void free_all( x264hip_ctx *ctx )
     if( ctx->stream2 ) (void)hipStreamDestroy( ctx->stream2 );
     (void)hipHostFree( ctx->cell_acc_host );
     (void)hipFree( ctx->wcost_dev );
-    (void)hipHostFree( ctx->acc_host );
     (void)hipHostFree( ctx->wcost_host ); (void)hipHostFree( ctx->staging );
     for( auto e : ctx->prof_ev ) (void)hipEventDestroy( e );
     if( ctx->ev_start ) (void)hipEventDestroy( ctx->ev_start );
@@ -301,7 +298,6 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     }
     OPENCK( hipMalloc( &ctx->sync_words, ME_QUEUES * ME_QUEUE_STRIDE * sizeof( unsigned ) ) ); // row tickets of the search kernel
     OPENCK( hipMemset( ctx->sync_words, 0, ME_QUEUES * ME_QUEUE_STRIDE * sizeof( unsigned ) ) );
-    OPENCK( hipMalloc( &ctx->acc_dev, 8 * sizeof( int ) ) );
     ctx->n_cells = ( p.bframes + 2 ) * ( p.bframes + 2 );
     OPENCK( hipHostMalloc( &ctx->cell_acc_host, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
     memset( ctx->cell_acc_host, 0, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) );
@@ -325,7 +321,6 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( ring_alloc( ctx->put_ring, (size_t)ctx->put_desc_cap * sizeof( PutDesc ) ) );
     ctx->cell_desc_cap = 4096;
     OPENCK( ring_alloc( ctx->cell_ring, (size_t)ctx->cell_desc_cap * sizeof( CellArgs ) ) );
-    OPENCK( hipHostMalloc( &ctx->acc_host, 8 * sizeof( int ) ) );
     OPENCK( hipMalloc( &ctx->wcost_dev, (size_t)x264hip_ctx::WCAP * 4 * sizeof( unsigned ) ) );
     OPENCK( hipMemset( ctx->wcost_dev, 0, (size_t)x264hip_ctx::WCAP * 4 * sizeof( unsigned ) ) );
     OPENCK( hipHostMalloc( &ctx->wcost_host, (size_t)x264hip_ctx::WCAP * 2 * sizeof( unsigned ) ) );
