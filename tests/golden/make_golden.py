@@ -130,13 +130,27 @@ def gen_primitives():
         L.rh_quant.restype = C.c_int
         nz4 = L.rh_quant(r.ctx, 0, C.c_void_p(q4.ctypes.data), 0, 26, 0)
         nz8 = L.rh_quant(r.ctx, 1, C.c_void_p(q8.ctypes.data), 0, 26, 0)
+        # hpel_filter (mc.c:172-196) of a 44x12 area inside a' (rows/columns with the margins the filter reads)
+        hw, hh, hs = 44, 12, 64
+        hsrc = rng.integers(0, maxv + 1, size=(hh + 8, hs)).astype(dt)
+        hsrc[:, 20:26] = maxv; hsrc[2:5, 30:40] = 0
+        hout = np.full((3, hh + 8, hs), 7, dt)
+        hbuf = np.zeros(hw + 64, np.int16)
+        hoff = (3 * hs + 8) * hsrc.itemsize
+        L.rh_hpel_filter.argtypes = [C.c_void_p] * 5 + [C.c_long, C.c_int, C.c_int, C.c_void_p]
+        L.rh_hpel_filter(r.ctx, hout[0].ctypes.data + hoff, hout[1].ctypes.data + hoff, hout[2].ctypes.data + hoff, hsrc.ctypes.data + hoff, hs, hw, hh,
+                         hbuf.ctypes.data)
         np.savez_compressed(os.path.join(OUT, "primitives_d%d.npz" % depth), a=a, b=b, cmp=res, offs=np.array(offs),
-                            fenc=fenc, fdec=fdec, mf4=mf4, bias4=b4, mf8=mf8, bias8=b8, q4=q4, q8=q8, nz=np.array([nz4, nz8]), **dcts)
+                            fenc=fenc, fdec=fdec, mf4=mf4, bias4=b4, mf8=mf8, bias8=b8, q4=q4, q8=q8, nz=np.array([nz4, nz8]),
+                            hpel_src=hsrc, hpel_out=hout, hpel_dims=np.array([hw, hh, hs]), **dcts)
         r.close()
         print("primitives", depth)
 
 
 if __name__ == "__main__":
+    if "--primitives-only" in sys.argv:
+        gen_primitives()
+        sys.exit(0)
     if "--lookahead-only" not in sys.argv:
         gen_tables()
         gen_primitives()

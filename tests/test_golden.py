@@ -58,6 +58,16 @@ def test_primitive_known_answers(depth):
         mfa, ba = np.ascontiguousarray(z[mf]), np.ascontiguousarray(z[bias])
         r = o.f("quant", C.c_int)(kind, C.c_void_p(c.ctypes.data), C.c_void_p(mfa.ctypes.data), C.c_void_p(ba.ctypes.data), 0, 0)
         assert np.array_equal(c, z[gold]) and r == z["nz"][nz]
+    # hpel_filter, all three planes incl. the extra dstv columns and the untouched surroundings
+    hw, hh, hs = (int(v) for v in z["hpel_dims"])
+    hsrc = np.ascontiguousarray(z["hpel_src"])
+    out = np.full((3, hh + 8, hs), 7, o.dtype)
+    buf = np.zeros(hw + 64, np.int16)
+    off = (3 * hs + 8) * hsrc.itemsize
+    f = o.f("hpel_filter")
+    f.argtypes = [C.c_void_p] * 4 + [C.c_long, C.c_int, C.c_int, C.c_void_p]
+    f(out[0].ctypes.data + off, out[1].ctypes.data + off, out[2].ctypes.data + off, hsrc.ctypes.data + off, hs, hw, hh, buf.ctypes.data)
+    assert np.array_equal(out, z["hpel_out"])
 
 
 EVALSEQ_FILES = sorted(glob.glob(os.path.join(GOLD, "evalseq_*.npz")))
