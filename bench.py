@@ -170,6 +170,10 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=96)
     args = ap.parse_args()
 
+    # Each context uses two streams (searches/cells and MB-tree).  The HIP runtime multiplexes a process's streams onto
+    # GPU_MAX_HW_QUEUES hardware queues (default 4): with two contexts in flight both MB-tree streams land on the same
+    # queue and serialise behind each other, so give every stream its own queue.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(2 * max(1, args.inflight) + 2))
     import torch
     from x264_amd import lib, shard
     from x264_amd.synth import make_clip

@@ -957,7 +957,7 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
             cell_b_kernel<T><<<dim3( ( P.mb_w + CELLB_BPW - 1 ) / CELLB_BPW, P.mb_h, 1 ), 64, 0, ctx->stream>>>( P, nullptr, A );
         else
             cell_p_kernel<<<dim3( ( ctx->n_mb + 255 ) / 256, 1 ), 256, 0, ctx->stream>>>( P, nullptr, A );
-        cell_reduce_kernel<<<1, 1024, 0, ctx->stream>>>( P, nullptr, A );
+        cell_reduce_kernel<<<1, 256, 0, ctx->stream>>>( P, nullptr, A );
         HIPCK( hipGetLastError() );
         int r = sync_stream( ctx );
         if( r ) return r;
