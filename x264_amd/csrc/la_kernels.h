@@ -1067,11 +1067,24 @@ __device__ __forceinline__ void mbt_propagate_mb( const MbtOpDev &o, int W, int 
 // counter barrier (monotonic counter, relaxed agent-scope polling, bounded spin).  Everything exchanged between
 // steps lives in the propagate accumulators, which are only touched with agent-scope atomics, so no fences are
 // needed beyond draining this wave's outstanding operations before it arrives.
-__global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *ops, int n_ops, const AqLuts *luts,
-                                                         unsigned *bar /* [0] arrivals, [1] error */ )
+__global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *ops_in, int n_ops, int stage_in_lds, const AqLuts *luts,
+                                                         unsigned *bar /* [0] arrivals, [1] error, [2] exits */ )
 {
+    extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char mbt_lds[];
     const int W = P.mb_w, H = P.mb_h, n_mb = W * H;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    const MbtOpDev *ops = ops_in;
+    if( stage_in_lds )
+    {
+        // the step list sits in pinned host memory: every workgroup pulls it into LDS with one parallel burst of reads
+        // instead of a separate copy kernel in front of every call
+        const uint32_t *src = (const uint32_t *)ops_in;
+        uint32_t *dst = (uint32_t *)mbt_lds;
+        for( int i = threadIdx.x; i < n_ops * (int)( sizeof( MbtOpDev ) / 4 ); i += blockDim.x )
+            dst[i] = __hip_atomic_load( src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+        __syncthreads();
+        ops = (const MbtOpDev *)mbt_lds;
+    }
     unsigned n_bar = 0;
     for( int k = 0; k < n_ops; k++ )
     {
@@ -1143,5 +1156,12 @@ __global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *
                 }
             }
         }
+    }
+    // the last workgroup to leave re-arms the barrier counters for the next call that uses this ring entry
+    __syncthreads();
+    if( threadIdx.x == 0 && __hip_atomic_fetch_add( &bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) == gridDim.x - 1 )
+    {
+        __hip_atomic_store( &bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+        __hip_atomic_store( &bar[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
     }
 }

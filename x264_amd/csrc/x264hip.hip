@@ -113,7 +113,7 @@ struct x264hip_ctx
     hipEvent_t ev_cross = nullptr, ev_mbt_last = nullptr;
     hipEvent_t ev_ingest = nullptr;  // behind the most recent ingest kernels: frame totals are readable after it
     int mbt_next = 0, mbt_pending = 0;
-    unsigned *mbt_bar = nullptr;      // device [MBT_RING][2]: barrier arrivals, error
+    unsigned *mbt_bar = nullptr;      // device [MBT_RING][4]: barrier arrivals, error, exits, unused
     int desc_cap = 0;
     // weight costs: WCAP job entries, each with device counters [2][2] and a pinned result pair; entry 0 serves the
     // on-demand call, the others hold speculative pairs (x264hip_prefetch_weight_costs) until their frames go away
@@ -310,8 +310,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( hipEventCreateWithFlags( &ctx->ev_ingest, hipEventDisableTiming ) );
     for( int i = 0; i < x264hip_ctx::BATCH_EVS; i++ )
         OPENCK( hipEventCreateWithFlags( &ctx->batch_ev[i], hipEventDisableTiming ) );
-    OPENCK( hipMalloc( &ctx->mbt_bar, x264hip_ctx::MBT_RING * 2 * sizeof( unsigned ) ) );
-    OPENCK( hipMemset( ctx->mbt_bar, 0, x264hip_ctx::MBT_RING * 2 * sizeof( unsigned ) ) );
+    OPENCK( hipMalloc( &ctx->mbt_bar, x264hip_ctx::MBT_RING * 4 * sizeof( unsigned ) ) );
+    OPENCK( hipMemset( ctx->mbt_bar, 0, x264hip_ctx::MBT_RING * 4 * sizeof( unsigned ) ) );
     for( int i = 0; i < x264hip_ctx::MBT_RING; i++ )
     {
         OPENCK( hipHostMalloc( &ctx->mbt_host[i], x264hip_ctx::MBT_CAP * sizeof( MbtOpDev ) ) );
@@ -1029,14 +1029,22 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
     // inputs come from the main stream (cells, clamp kernels): order the MB-tree stream behind it
     HIPCK( hipEventRecord( ctx->ev_cross, ctx->stream ) );
     HIPCK( hipStreamWaitEvent( ctx->stream2, ctx->ev_cross, 0 ) );
-    HIPCK( hipMemcpyAsync( ctx->mbt_dev[r], dh, (size_t)n * sizeof( MbtOpDev ), hipMemcpyHostToDevice, ctx->stream2 ) );
-    HIPCK( hipMemsetAsync( ctx->mbt_bar + 2 * r, 0, sizeof( unsigned ), ctx->stream2 ) ); // arrivals; the error word is sticky
-    mbtree_kernel<<<MBT_WGS, 1024, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], n, ctx->luts_dev, ctx->mbt_bar + 2 * r );
+    const size_t table_bytes = (size_t)n * sizeof( MbtOpDev );
+    // Measured (two segments in flight, 1080p): copying the step list to the device in front of the call gives 8500 frames/s,
+    // letting every workgroup pull it from pinned host memory into LDS 8070 -- sixteen PCIe read bursts per call cost more
+    // than one small copy.  The staging path stays available for experiments.
+    static const bool stage_lds = getenv( "X264HIP_MBT_STAGE_LDS" ) != nullptr;
+    if( table_bytes <= 48 * 1024 && stage_lds )
+        mbtree_kernel<<<MBT_WGS, 1024, table_bytes, ctx->stream2>>>( ctx->P, dh, n, 1, ctx->luts_dev, ctx->mbt_bar + 4 * r );
+    else
+    {
+        HIPCK( hipMemcpyAsync( ctx->mbt_dev[r], dh, table_bytes, hipMemcpyHostToDevice, ctx->stream2 ) );
+        mbtree_kernel<<<MBT_WGS, 1024, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], n, 0, ctx->luts_dev, ctx->mbt_bar + 4 * r );
+    }
     HIPCK( hipGetLastError() );
     HIPCK( hipEventRecord( ctx->mbt_done[r], ctx->stream2 ) );
     HIPCK( hipEventRecord( ctx->ev_mbt_last, ctx->stream2 ) );
     ctx->mbt_pending++;
-    ctx->counters[6]++;
     return X264HIP_OK;
 }
 
@@ -1045,14 +1053,14 @@ extern "C" int x264hip_get_qp_offsets( x264hip_ctx *ctx, int slot, float *qp_off
     if( !ctx || !slot_ok( ctx, slot ) || !qp_offset ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
-    HIPCK( hipStreamSynchronize( ctx->stream ) );
+    HIPCK( hipEventSynchronize( ctx->ev_ingest ) ); // f_qp_offset starts as the AQ offsets written at ingest (main stream)
     HIPCK( hipMemcpyAsync( qp_offset, ctx->slots[slot].qp, ctx->n_mb * sizeof( float ), hipMemcpyDeviceToHost, ctx->stream2 ) );
-    std::vector<unsigned> bar( x264hip_ctx::MBT_RING * 2 );
+    std::vector<unsigned> bar( x264hip_ctx::MBT_RING * 4 );
     HIPCK( hipMemcpyAsync( bar.data(), ctx->mbt_bar, bar.size() * sizeof( unsigned ), hipMemcpyDeviceToHost, ctx->stream2 ) );
     HIPCK( hipStreamSynchronize( ctx->stream2 ) );
     ctx->mbt_pending = 0;
     for( int i = 0; i < x264hip_ctx::MBT_RING; i++ )
-        if( bar[2 * i + 1] )
+        if( bar[4 * i + 1] )
         {
             ctx->broken = 1;
             return X264HIP_ETIMEOUT;
