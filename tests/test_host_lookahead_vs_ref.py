@@ -107,3 +107,38 @@ def _run_unpaced(la, frames):
             break
         outs.append(o)
     return outs
+
+
+def test_chunked_submission_of_a_long_queue():
+    """All frames queued up front, more than reach + chunk of them: the host submits the speculative work in chunks
+    (flush_prefetch: reach of the next decision + 64 frames, the next chunk while half a chunk is still ahead) --
+    decisions and cost cells must equal the encoder-paced reference run."""
+    W, H, nf = 64, 48, 230
+    frames = make_clip(W, H, nf, seed=13, scene_cuts=(60, 61, 150), fade=(100, 12, 0.7, 9), pan=(2, 1))
+    r = refharness.Ref(W, H, "slow", opts="me=dia")
+    try:
+        ref = r.lookahead_run(frames)
+    finally:
+        r.close()
+    cfg = lib.la_config(W, H, "slow", me="dia")
+    be = OracleBackend(cfg, speculative=True)
+    calls = []
+    orig = be._prefetch
+    def spy(user, slots, numbers, n):
+        calls.append([numbers[i] for i in range(n)])
+        return orig(user, slots, numbers, n)
+    spy_fn = lib.PREFETCH_FN(spy)  # keep the callback object alive for the lifetime of the lookahead
+    be.struct.prefetch = spy_fn
+    la = lib.Lookahead(cfg, backend=be.struct, max_frames=nf + 4)
+    try:
+        outs = _run_unpaced(la, frames)
+    finally:
+        la.close()
+    assert [o.frame for o in outs] == list(ref["idx"]) and [o.type for o in outs] == list(ref["type"])
+    for o, c in zip(outs, ref["cost"]):
+        got = np.array([[o.cost_est[i][j] for j in range(5)] for i in range(5)])
+        assert np.array_equal(got, c[:5, :5])
+    # several submissions, each extending the previous one, none after everything has been submitted
+    newest = [max(c) for c in calls]
+    assert len(calls) >= 3 and newest == sorted(newest) and newest[-1] == nf - 1
+    assert len(set(newest)) == len(newest), "a submission that added no frame"
