@@ -6,8 +6,11 @@
  * throw, and never fall back to a CPU implementation: without a usable HIP device x264hip_open()
  * fails with X264HIP_ENODEV.
  *
- * Threading: one context is driven by one thread (like the reference's single lookahead thread,
- * encoder/lookahead.c:90-128).  The caller owns every host buffer; the context owns device memory.
+ * Threading: one context is driven by one thread at a time (like the reference's single lookahead thread,
+ * encoder/lookahead.c:90-128).  Different contexts are independent and may be driven concurrently from different
+ * threads, on the same or on different devices (every call selects its context's device for the calling thread);
+ * two contexts on independent GOP segments are how one device is kept busy while a segment's decisions run on the host.
+ * The caller owns every host buffer; the context owns device memory.
  *
  * Bit depth: pixels are uint8_t (bit_depth 8) or uint16_t (bit_depth 10) exactly like the
  * reference's `pixel` (common/common.h:93-105); strides are in pixels.
