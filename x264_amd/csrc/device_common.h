@@ -228,8 +228,10 @@ __device__ __forceinline__ Px4 qpel_px4_at( const T *ubase, int plane_elems, int
     // pa = (fx ? 1 : 0) + (fy == 2 ? 2 : 0), pb = (fx == 2 ? 1 : 0) + (fy ? 2 : 0), two bits per phase
     const unsigned pa = ( 0x54FE5454u >> sh ) & 3u, pb = ( 0xBABABA10u >> sh ) & 3u;
     const int o = lane_off + mad24( mvy >> 2, stride, mvx >> 2 );
-    const int oa = mad24( (int)pa, plane_elems, o ) + ( fy == 3 ? stride : 0 );
-    const int ob = mad24( (int)pb, plane_elems, o ) + ( fx == 3 );
+    // plane_elems exceeds the SIGNED 24-bit range from 8K pictures on (3904 x 2224 = 8.7 M samples per padded lowres
+    // plane): the unsigned 24-bit multiply covers every size x264hip_open accepts (plane_elems < 2^24)
+    const int oa = (int)__umul24( pa, (unsigned)plane_elems ) + o + ( fy == 3 ? stride : 0 );
+    const int ob = (int)__umul24( pb, (unsigned)plane_elems ) + o + ( fx == 3 );
     return avg_px4( load_px4_at( ubase, oa ), load_px4_at( ubase, ob ), (const T *)nullptr );
 }
 

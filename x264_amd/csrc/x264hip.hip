@@ -275,6 +275,12 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     P.stride = (int)align_up( ctx->lw + 2 * LA_PAD, 64 );
     P.plane_elems = P.stride * ( ctx->lh + 2 * LA_PAD );
     ctx->plane_bytes = (size_t)P.plane_elems * ctx->psz;
+    if( (long long)P.stride * ( ctx->lh + 2 * LA_PAD ) >= ( 1ll << 24 ) )
+    {
+        // the kernels address samples with 24-bit multiplies and 32-bit offsets: pictures up to 8K (16 M samples per padded plane)
+        delete ctx;
+        return X264HIP_EINVAL;
+    }
     P.lambda = p.lambda; P.me_method = p.me_method; P.subpel_refine = p.subpel_refine; P.me_range = p.me_range;
     P.mv_range = p.mv_range; P.subme = p.subme; P.mbcmp_satd = p.mbcmp_satd; P.fpelcmp_satd = p.fpelcmp_satd;
     P.weighted_bipred = p.weighted_bipred; P.aq_mode = p.aq_mode; P.depth_shift = p.bit_depth - 8;
