@@ -379,6 +379,19 @@ RH_API void rh_lowres_core( rh_ctx *c, pixel *src, pixel *d0, pixel *dh, pixel *
 {
     c->h->mc.frame_init_lowres_core( src, d0, dh, dv, dc, ss, ds, w, hh );
 }
+RH_API void rh_integral_init( rh_ctx *c, int kind, uint16_t *sum8, uint16_t *sum4, pixel *pix, intptr_t stride )
+{
+    x264_t *h = c->h;
+    if( kind == 0 ) h->mc.integral_init4h( sum8, pix, stride );
+    else if( kind == 1 ) h->mc.integral_init8h( sum8, pix, stride );
+    else if( kind == 2 ) h->mc.integral_init4v( sum8, sum4, stride );
+    else h->mc.integral_init8v( sum8, stride );
+}
+/* size_idx: PIXEL_16x16 (ads4), PIXEL_16x8 (ads2), PIXEL_8x8 (ads1) */
+RH_API int rh_ads( rh_ctx *c, int size_idx, int *enc_dc, uint16_t *sums, int delta, uint16_t *cost_mvx, int16_t *mvs, int width, int thresh )
+{
+    return c->h->pixf.ads[size_idx]( enc_dc, sums, delta, cost_mvx, mvs, width, thresh );
+}
 RH_API void rh_hpel_filter( rh_ctx *c, pixel *dsth, pixel *dstv, pixel *dstc, pixel *src, intptr_t stride, int w, int hh, int16_t *buf )
 {
     c->h->mc.hpel_filter( dsth, dstv, dstc, src, stride, w, hh, buf );

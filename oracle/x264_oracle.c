@@ -86,6 +86,58 @@ void ORN(hpel_filter)( pixel *dsth, pixel *dstv, pixel *dstc, const pixel *src, 
     }
 }
 
+/* Integral image rows for the exhaustive searches, common/mc.c:424-456 (integral_init4h/8h/4v/8v): running column
+ * sums of 4- or 8-wide row sums, then differences 4 or 8 rows apart give the box sums; all arithmetic modulo 2^16. */
+void ORN(integral_init4h)( uint16_t *sum, const pixel *pix, long stride )
+{
+    int v = pix[0] + pix[1] + pix[2] + pix[3];
+    for( long x = 0; x < stride - 4; x++ )
+    {
+        sum[x] = (uint16_t)( v + sum[x - stride] );
+        v += pix[x + 4] - pix[x];
+    }
+}
+void ORN(integral_init8h)( uint16_t *sum, const pixel *pix, long stride )
+{
+    int v = 0;
+    for( int i = 0; i < 8; i++ ) v += pix[i];
+    for( long x = 0; x < stride - 8; x++ )
+    {
+        sum[x] = (uint16_t)( v + sum[x - stride] );
+        v += pix[x + 8] - pix[x];
+    }
+}
+void ORN(integral_init4v)( uint16_t *sum8, uint16_t *sum4, long stride )
+{
+    for( long x = 0; x < stride - 8; x++ )
+        sum4[x] = (uint16_t)( sum8[x + 4*stride] - sum8[x] );
+    for( long x = 0; x < stride - 8; x++ )
+        sum8[x] = (uint16_t)( sum8[x + 8*stride] + sum8[x + 8*stride + 4] - sum8[x] - sum8[x + 4] );
+}
+void ORN(integral_init8v)( uint16_t *sum8, long stride )
+{
+    for( long x = 0; x < stride - 8; x++ )
+        sum8[x] = (uint16_t)( sum8[x + 8*stride] - sum8[x] );
+}
+
+/* Successive elimination, common/pixel.c:759-803 (ads4/ads2/ads1): candidates i of a row whose lower bound
+ * sum|enc_dc - box sum| + cost_mvx[i] stays below thresh, in order. n_dc = 4, 2 or 1. */
+int ORN(ads)( int n_dc, const int *enc_dc, const uint16_t *sums, int delta, const uint16_t *cost_mvx, int16_t *mvs, int width, int thresh )
+{
+    int nmv = 0;
+    for( int i = 0; i < width; i++, sums++ )
+    {
+        int ads = abs( enc_dc[0] - sums[0] ) + cost_mvx[i];
+        if( n_dc == 2 )
+            ads += abs( enc_dc[1] - sums[delta] );
+        else if( n_dc == 4 )
+            ads += abs( enc_dc[1] - sums[8] ) + abs( enc_dc[2] - sums[delta] ) + abs( enc_dc[3] - sums[delta + 8] );
+        if( ads < thresh )
+            mvs[nmv++] = (int16_t)i;
+    }
+    return nmv;
+}
+
 /* src is the picture as handed to the encoder (width x height, not necessarily mod 16).  The
  * reference first replicates the last column/row out to the mod16 size and then one more
  * column/row (mc.c:466-468); both are the same as clamping the source coordinate. */

@@ -57,6 +57,11 @@ typedef struct or_cell_out
 void or##D##_lowres_init( const PIX *src, int src_stride, int width, int height, int mb_w, int mb_h, \
                           PIX *p0, PIX *ph, PIX *pv, PIX *pc, int stride ); \
 void or##D##_lowres_core( const PIX *src, PIX *d0, PIX *dh, PIX *dv, PIX *dc, int src_stride, int dst_stride, int w, int h ); \
+void or##D##_integral_init4h( uint16_t *sum, const PIX *pix, long stride ); \
+void or##D##_integral_init8h( uint16_t *sum, const PIX *pix, long stride ); \
+void or##D##_integral_init4v( uint16_t *sum8, uint16_t *sum4, long stride ); \
+void or##D##_integral_init8v( uint16_t *sum8, long stride ); \
+int  or##D##_ads( int n_dc, const int *enc_dc, const uint16_t *sums, int delta, const uint16_t *cost_mvx, int16_t *mvs, int width, int thresh ); \
 void or##D##_hpel_filter( PIX *dsth, PIX *dstv, PIX *dstc, const PIX *src, long stride, int width, int height, int16_t *buf ); \
 int  or##D##_sad( const PIX *a, int sa, const PIX *b, int sb, int w, int h ); \
 int  or##D##_ssd( const PIX *a, int sa, const PIX *b, int sb, int w, int h ); \

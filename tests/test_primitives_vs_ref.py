@@ -176,6 +176,54 @@ def test_hpel_filter(env):
             assert np.array_equal(a[k], b[k]), (w, h, kind, k)
 
 
+def test_integral_init_and_ads(env):
+    """oracle vs h->mc.integral_init{4h,8h,4v,8v} (checkasm.c:1745-1770 geometry: stride 96) and pixf.ads[] (checkasm.c:836-885:
+    saturating multiples of 8*PIXEL_MAX and random 14/16-bit sums)"""
+    r, o, d = env
+    rng = np.random.default_rng(9)
+    maxv = (1 << d) - 1
+    L = r.lib
+    L.rh_integral_init.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+    stride = 96
+    for trial in range(4):
+        pix = (rng.integers(0, maxv + 1, size=(4, stride)) if trial else np.full((4, stride), maxv)).astype(o.dtype)
+        base = rng.integers(0, 65536, size=(24, stride)).astype(np.uint16)
+        for kind, name in ((0, "integral_init4h"), (1, "integral_init8h")):
+            a, b = base.copy(), base.copy()
+            L.rh_integral_init(r.ctx, kind, _ptr(a, stride), None, _ptr(pix), stride)
+            f = o.f(name); f.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+            f(_ptr(b, stride), _ptr(pix), stride)
+            assert np.array_equal(a, b), name
+        a, b = base.copy(), base.copy()
+        L.rh_integral_init(r.ctx, 2, _ptr(a), _ptr(a, 14 * stride), None, stride)
+        f = o.f("integral_init4v"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        f(_ptr(b), _ptr(b, 14 * stride), stride)
+        assert np.array_equal(a, b)
+        a, b = base.copy(), base.copy()
+        L.rh_integral_init(r.ctx, 3, _ptr(a), None, None, stride)
+        f = o.f("integral_init8v"); f.argtypes = [C.c_void_p, C.c_long]
+        f(_ptr(b), stride)
+        assert np.array_equal(a, b)
+    L.rh_ads.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.rh_ads.restype = C.c_int
+    f = o.f("ads", C.c_int)
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    cost = rng.integers(0, 65536, size=32).astype(np.uint16)
+    for i in range(100):
+        size_idx, n_dc = ((0, 4), (1, 2), (3, 1))[i % 3]
+        if i < 40:
+            sums = (rng.integers(0, 9, size=72) * 8 * maxv).astype(np.uint16)
+            dc = (rng.integers(0, 9, size=4) * 8 * maxv).astype(np.int32)
+        else:
+            sums = rng.integers(0, 1 << (d + 6), size=72).astype(np.uint16)
+            dc = rng.integers(0, 1 << (d + 6), size=4).astype(np.int32)
+        thresh = int(rng.integers(0, 257)) * maxv + int(rng.integers(0, 65536))
+        ma, mb = np.zeros(48, np.int16), np.zeros(48, np.int16)
+        na = L.rh_ads(r.ctx, size_idx, _ptr(dc), _ptr(sums), 32, _ptr(cost), _ptr(ma), 28, thresh)
+        nb = f(n_dc, _ptr(dc), _ptr(sums), 32, _ptr(cost), _ptr(mb), 28, thresh)
+        assert na == nb and np.array_equal(ma[:na], mb[:nb]), (i, n_dc)
+
+
 def test_dct_quant(env):
     r, o, d = env
     rng = np.random.default_rng(6)
