@@ -27,6 +27,8 @@ typedef struct
     x264_param_t param;
     int n_frames;
     x264_frame_t *frames[RH_MAX_FRAMES + 4];
+    int n_refs;
+    x264_frame_t *refs[16];       /* reconstructed-frame style references (half-pel planes + integral) for rh_me_search */
 } rh_ctx;
 
 static void rh_log_quiet( void *p, int level, const char *fmt, va_list ap )
@@ -87,6 +89,9 @@ RH_API void rh_close( rh_ctx *c )
     for( int i = 0; i < c->n_frames; i++ )
         if( c->frames[i] )
             x264_frame_push_unused( c->h, c->frames[i] );
+    for( int i = 0; i < c->n_refs; i++ )
+        if( c->refs[i] )
+            x264_frame_push_unused( c->h, c->refs[i] );
     x264_encoder_close( c->h );
     free( c );
 }
@@ -192,6 +197,118 @@ RH_API int rh_add_frame( rh_ctx *c, const pixel *y, const pixel *u, const pixel 
     return c->n_frames++;
 }
 
+/* ---- main-encode motion search: x264_me_search_ref with any method on a full-resolution reference ----
+ * A reference frame as the encoder keeps it after reconstruction: luma plane with expanded borders, the three half-pel
+ * planes (x264_frame_filter -> mc.hpel_filter) and, when the context was opened with me=esa/tesa, the integral planes. */
+RH_API int rh_add_ref_frame( rh_ctx *c, const pixel *y )
+{
+    x264_t *h = c->h;
+    if( c->n_refs >= 16 ) return -1;
+    x264_frame_t *f = x264_frame_pop_unused( h, 1 );
+    if( !f ) return -1;
+    int w = h->param.i_width, ht = h->param.i_height;
+    for( int r = 0; r < 16*h->mb.i_mb_height; r++ )
+    {
+        const pixel *src = y + (size_t)X264_MIN( r, ht-1 ) * w;
+        pixel *dst = f->plane[0] + (size_t)r * f->i_stride[0];
+        for( int x = 0; x < 16*h->mb.i_mb_width; x++ )
+            dst[x] = src[X264_MIN( x, w-1 )];
+    }
+    for( int r = 0; r < 8*h->mb.i_mb_height; r++ )
+        for( int x = 0; x < 16*h->mb.i_mb_width; x++ )
+            f->plane[1][(size_t)r * f->i_stride[1] + x] = 1 << (BIT_DEPTH-1);
+    h->i_threadslice_start = 0;
+    h->i_threadslice_end = h->mb.i_mb_height;
+    for( int mb_y = 1; mb_y <= h->mb.i_mb_height; mb_y++ )
+    {
+        int min_y = mb_y - 1, end = mb_y == h->mb.i_mb_height;   /* the order of fdec_filter_row, encoder.c:2471-2479 */
+        x264_frame_expand_border( h, f, min_y );
+        x264_frame_filter( h, f, min_y, end );
+        x264_frame_expand_border_filtered( h, f, min_y, end );
+    }
+    c->refs[c->n_refs] = f;
+    return c->n_refs++;
+}
+
+/* fenc: the bw x bh source block in FENC layout (stride 16).  Limits as mb_analyse_init sets them (analyse.c:330-396,
+ * single frame thread).  out: mvx, mvy, cost, cost_mv. */
+RH_API int rh_me_search( rh_ctx *c, int ref, const pixel *fenc, int mb_x, int mb_y, int xoff, int yoff, int i_pixel, int subpel_refine,
+                         int me_range, const int16_t *mvp, const int16_t *mvc_in, int n_mvc, int *out )
+{
+    x264_t *h = c->h;
+    if( ref < 0 || ref >= c->n_refs ) return -1;
+    x264_frame_t *f = c->refs[ref];
+    ALIGNED_ARRAY_64( pixel, fenc_buf,[16*16] );
+    ALIGNED_ARRAY_8( int16_t, mvc,[16],[2] );
+    memcpy( fenc_buf, fenc, sizeof(fenc_buf) );
+    for( int i = 0; i < n_mvc && i < 16; i++ ) { mvc[i][0] = mvc_in[2*i]; mvc[i][1] = mvc_in[2*i+1]; }
+    h->mb.i_mb_x = mb_x; h->mb.i_mb_y = mb_y;
+    h->mb.i_qp = X264_LOOKAHEAD_QP;
+    h->fenc = c->n_frames ? c->frames[0] : f;    /* ESA reads h->fenc->i_lines[0] (me.c:641) */
+    const int i_fmv_range = 4 * h->param.analyse.i_mv_range, i_fpel_border = 6;
+    h->mb.mv_min[0] = 4*( -16*mb_x - 24 );
+    h->mb.mv_max[0] = 4*( 16*( h->mb.i_mb_width - mb_x - 1 ) + 24 );
+    h->mb.mv_min_spel[0] = X264_MAX( h->mb.mv_min[0], -i_fmv_range );
+    h->mb.mv_max_spel[0] = X264_MIN( h->mb.mv_max[0], i_fmv_range-1 );
+    h->mb.mv_limit_fpel[0][0] = (h->mb.mv_min_spel[0]>>2) + i_fpel_border;
+    h->mb.mv_limit_fpel[1][0] = (h->mb.mv_max_spel[0]>>2) - i_fpel_border;
+    h->mb.mv_min[1] = 4*( -16*mb_y - 24 );
+    h->mb.mv_max[1] = 4*( 16*( h->mb.i_mb_height - mb_y - 1 ) + 24 );
+    h->mb.mv_min_spel[1] = X264_MAX( h->mb.mv_min[1], -i_fmv_range );
+    h->mb.mv_max_spel[1] = X264_MIN( h->mb.mv_max[1], i_fmv_range-1 );
+    h->mb.mv_limit_fpel[0][1] = (h->mb.mv_min_spel[1]>>2) + i_fpel_border;
+    h->mb.mv_limit_fpel[1][1] = (h->mb.mv_max_spel[1]>>2) - i_fpel_border;
+    h->mb.i_me_method = h->param.analyse.i_me_method;
+    h->mb.i_subpel_refine = subpel_refine;
+    h->mb.b_chroma_me = 0;
+    const int saved_range = h->param.analyse.i_me_range;
+    h->param.analyse.i_me_range = me_range;
+    x264_me_t m;
+    memset( &m, 0, sizeof(m) );
+    m.i_pixel = i_pixel;
+    m.p_cost_mv = h->cost_mv[X264_LOOKAHEAD_QP];
+    m.i_ref_cost = 0;
+    m.i_ref = 0;
+    m.weight = x264_weight_none;
+    m.p_fenc[0] = fenc_buf;
+    m.i_stride[0] = f->i_stride[0];
+    const intptr_t off = 16*mb_x + xoff + ( 16*mb_y + yoff ) * (intptr_t)f->i_stride[0];
+    for( int i = 0; i < 4; i++ )
+        m.p_fref[i] = f->filtered[0][i] + off;
+    m.p_fref_w = m.p_fref[0];
+    m.integral = f->integral ? f->integral + off : NULL;
+    m.mvp[0] = mvp[0]; m.mvp[1] = mvp[1];
+    x264_me_search_ref( h, &m, mvc, n_mvc, NULL );
+    h->param.analyse.i_me_range = saved_range;
+    out[0] = m.mv[0]; out[1] = m.mv[1]; out[2] = m.cost; out[3] = m.cost_mv;
+    return 0;
+}
+
+/* the planes rh_me_search reads, for the checker: plane p (0 full, 1 H, 2 V, 3 HV) incl. PADH/PADV borders, tight */
+RH_API int rh_ref_geometry( rh_ctx *c, int *out )
+{
+    if( !c->n_refs ) return -1;
+    x264_frame_t *f = c->refs[0];
+    out[0] = f->i_width[0]; out[1] = f->i_lines[0]; out[2] = f->i_stride[0]; out[3] = PADH; out[4] = PADV; out[5] = f->integral != NULL; out[6] = PADH_ALIGN; out[7] = c->h->frames.b_have_sub8x8_esa;
+    return 0;
+}
+RH_API void rh_get_ref_plane( rh_ctx *c, int ref, int p, pixel *out )
+{
+    x264_frame_t *f = c->refs[ref];
+    int w = f->i_width[0] + 2*PADH, hh = f->i_lines[0] + 2*PADV;
+    for( int y = 0; y < hh; y++ )
+        memcpy( out + (size_t)y*w, f->filtered[0][p] + (y-PADV)*(intptr_t)f->i_stride[0] - PADH, w * sizeof(pixel) );
+}
+/* integral planes as x264_frame_filter leaves them: (lines + 2*PADV) rows x stride, upper (8x8 sums) then lower (4x4 sums) */
+RH_API int rh_get_integral( rh_ctx *c, int ref, uint16_t *out, int cap )
+{
+    x264_frame_t *f = c->refs[ref];
+    if( !f->integral ) return -1;
+    int rows = ( f->i_lines[0] + 2*PADV ) * 2, stride = f->i_stride[0];
+    if( cap < rows * stride ) return -1;
+    memcpy( out, f->integral - PADV*stride - PADH_ALIGN, (size_t)rows * stride * sizeof(uint16_t) );
+    return rows * stride;
+}
 /* Direct call of the reference's static slicetype_frame_cost (slicetype.c:836). */
 RH_API int rh_frame_cost( rh_ctx *c, int p0, int p1, int b )
 {

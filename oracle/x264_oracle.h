@@ -53,6 +53,28 @@ typedef struct or_cell_out
     int intra_cost_est, intra_cost_est_aq; /* the [0][0] cell if intra was computed in this call */
 } or_cell_out;
 
+/* one call of the main-encode motion search (x264_me_t + the h->mb limits it reads), see x264_oracle.c */
+#define OR_ME_FULL(D, PIX) \
+typedef struct or##D##_me_full \
+{ \
+    int i_pixel;                /* PIXEL_16x16 .. PIXEL_4x4 (0..6) */ \
+    int me_method;              /* 0 dia, 1 hex, 2 umh, 3 esa, 4 tesa */ \
+    int subpel_refine;          /* h->mb.i_subpel_refine */ \
+    int me_range; \
+    int mbcmp_satd, fpelcmp_satd; \
+    const PIX *fenc;            /* FENC layout, stride 16 */ \
+    const PIX *ref[4];          /* full / H / V / HV planes at the block origin */ \
+    int stride; \
+    const uint16_t *integral;   /* 8x8-sum plane at the block origin (TESA only) */ \
+    long integral_lower;        /* elements from there to the 4x4-sum plane */ \
+    int mvp[2]; \
+    int lim_min[2], lim_max[2]; /* h->mb.mv_limit_fpel */ \
+    int spel_min[2], spel_max[2]; \
+    const uint16_t *cost_mv;    /* centred */ \
+} or##D##_me_full;
+OR_ME_FULL( 8, uint8_t )
+OR_ME_FULL( 10, uint16_t )
+
 #define OR_DECL(D, PIX, COEF, UCOEF) \
 void or##D##_lowres_init( const PIX *src, int src_stride, int width, int height, int mb_w, int mb_h, \
                           PIX *p0, PIX *ph, PIX *pv, PIX *pc, int stride ); \
@@ -62,6 +84,7 @@ void or##D##_integral_init8h( uint16_t *sum, const PIX *pix, long stride ); \
 void or##D##_integral_init4v( uint16_t *sum8, uint16_t *sum4, long stride ); \
 void or##D##_integral_init8v( uint16_t *sum8, long stride ); \
 int  or##D##_ads( int n_dc, const int *enc_dc, const uint16_t *sums, int delta, const uint16_t *cost_mvx, int16_t *mvs, int width, int thresh ); \
+void or##D##_me_search_full( const or##D##_me_full *p, const int16_t (*mvc)[2], int n_mvc, int out[4] ); \
 void or##D##_hpel_filter( PIX *dsth, PIX *dstv, PIX *dstc, const PIX *src, long stride, int width, int height, int16_t *buf ); \
 int  or##D##_sad( const PIX *a, int sa, const PIX *b, int sb, int w, int h ); \
 int  or##D##_ssd( const PIX *a, int sa, const PIX *b, int sb, int w, int h ); \
