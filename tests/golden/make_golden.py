@@ -147,7 +147,68 @@ def gen_primitives():
         print("primitives", depth)
 
 
+def gen_me_full():
+    """x264_me_search_ref (main-encode form) on a small reference frame: inputs and results of 120 random calls per method."""
+    from tests.common import ME_METHODS, ME_SIZES
+    W, H = 96, 80
+    for depth in (8, 10):
+        fr = make_clip(W, H, 2, seed=77 + depth, bit_depth=depth, pan=(5, -3), noise=8, texture=0.6)
+        dt = np.uint8 if depth == 8 else np.uint16
+        store = {}
+        for me, mid in ME_METHODS.items():
+            r = refharness.Ref(W, H, "medium", opts="me=%s,partitions=all,merange=24" % me, bit_depth=depth)
+            L = r.lib
+            L.rh_add_ref_frame.argtypes = [C.c_void_p, C.c_void_p]
+            L.rh_me_search.argtypes = [C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+            L.rh_get_ref_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+            L.rh_get_integral.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+            ref = np.ascontiguousarray(fr[0])
+            L.rh_add_ref_frame(r.ctx, ref.ctypes.data)
+            geo = (C.c_int * 8)()
+            L.rh_ref_geometry(r.ctx, geo)
+            w, lines, rstride, padh, padv, has_int, padh_align, sub8 = list(geo)
+            pw, ph = w + 2 * padh, lines + 2 * padv
+            if "planes" not in store:
+                pl = np.zeros((4, ph, pw), dt)
+                for p in range(4):
+                    L.rh_get_ref_plane(r.ctx, 0, p, pl[p].ctypes.data)
+                store["planes"] = pl
+                store["cost_mv"] = r.cost_mv()
+                store["geom"] = np.array([W, H, pw, ph, padh, padv, r.cfg["mv_range"]])
+            if has_int and "integral" not in store:
+                raw = np.zeros(2 * ph * rstride, np.uint16)
+                L.rh_get_integral(r.ctx, 0, raw.ctypes.data, raw.size)
+                x0 = padh_align - padh
+                store["integral"] = np.ascontiguousarray(raw.reshape(2 * ph, rstride)[:, x0:x0 + pw])
+            rng = np.random.default_rng(1000 + mid)
+            rows = []
+            for trial in range(120):
+                i_pixel = int(rng.integers(0, 7))
+                bw, bh = ME_SIZES[i_pixel]
+                mb_x, mb_y = int(rng.integers(0, W // 16)), int(rng.integers(0, H // 16))
+                xoff, yoff = int(rng.integers(0, 16 // bw)) * bw, int(rng.integers(0, 16 // bh)) * bh
+                subme, me_range = int(rng.choice([1, 2, 3, 5, 7, 9])), int(rng.choice([8, 16, 24]))
+                mvp = rng.integers(-60, 61, size=2).astype(np.int16) if trial % 3 else np.zeros(2, np.int16)
+                n_mvc = int(rng.integers(0, 5))
+                mvc = np.ascontiguousarray(rng.integers(-90, 91, size=(4, 2)).astype(np.int16))
+                fenc = np.zeros((16, 16), dt)
+                sy, sx = 16 * mb_y + yoff, 16 * mb_x + xoff
+                fenc[:bh, :bw] = fr[1][sy:sy + bh, sx:sx + bw]
+                out = np.zeros(4, np.int32)
+                L.rh_me_search(r.ctx, 0, fenc.ctypes.data, mb_x, mb_y, xoff, yoff, i_pixel, subme, me_range, mvp.ctypes.data, mvc.ctypes.data,
+                               n_mvc, out.ctypes.data)
+                rows.append([i_pixel, mb_x, mb_y, xoff, yoff, subme, me_range, int(mvp[0]), int(mvp[1]), n_mvc] + mvc.reshape(-1).tolist() + out.tolist())
+            store["calls_%s" % me] = np.array(rows, np.int32)
+            r.close()
+        store["fenc_frame"] = fr[1]
+        np.savez_compressed(os.path.join(OUT, "me_full_d%d.npz" % depth), **store)
+        print("me_full", depth)
+
+
 if __name__ == "__main__":
+    if "--me-full-only" in sys.argv:
+        gen_me_full()
+        sys.exit(0)
     if "--primitives-only" in sys.argv:
         gen_primitives()
         sys.exit(0)
@@ -155,4 +216,5 @@ if __name__ == "__main__":
         gen_tables()
         gen_primitives()
         gen_evalseq()
+        gen_me_full()
     gen_lookahead()

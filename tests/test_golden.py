@@ -158,3 +158,26 @@ def test_host_lookahead_vs_golden(name):
     finally:
         la.close()
     check_lookahead_outputs(outs, z, cfg["bframes"] + 2)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_me_search_full_vs_golden(depth):
+    """The oracle's main-encode motion search against results recorded from x264_me_search_ref (make_golden.py gen_me_full)."""
+    from tests.common import ME_METHODS, ME_SIZES, oracle_me_search
+    z = np.load(os.path.join(GOLD, "me_full_d%d.npz" % depth))
+    o = Oracle(depth)
+    planes = [np.ascontiguousarray(z["planes"][p]) for p in range(4)]
+    integral = np.ascontiguousarray(z["integral"])
+    cost_mv = np.ascontiguousarray(z["cost_mv"])
+    frame = z["fenc_frame"]
+    for me in ME_METHODS:
+        for call in z["calls_%s" % me]:
+            i_pixel, mb_x, mb_y, xoff, yoff, subme = (int(v) for v in call[:6])
+            bw, bh = ME_SIZES[i_pixel]
+            fenc = np.zeros((16, 16), o.dtype)
+            sy, sx = 16 * mb_y + yoff, 16 * mb_x + xoff
+            fenc[:bh, :bw] = frame[sy:sy + bh, sx:sx + bw]
+            got = oracle_me_search(o, me, planes, integral if ME_METHODS[me] >= 3 else None, cost_mv, z["geom"], fenc, call)
+            want = call[18:22]
+            n = 4 if subme >= 2 else 3   # cost_mv is only defined when refine_subpel ran
+            assert np.array_equal(got[:n], want[:n]), (me, call.tolist(), got.tolist())

@@ -12,15 +12,7 @@ from x264_amd.synth import make_clip
 
 pytestmark = pytest.mark.skipif(not refharness.available(8), reason="oracle/_ref not built (no /root/reference)")
 
-SIZES = [(16, 16), (16, 8), (8, 16), (8, 8), (8, 4), (4, 8), (4, 4)]
-METHODS = {"dia": 0, "hex": 1, "umh": 2, "esa": 3, "tesa": 4}
-
-
-class MeFull(C.Structure):
-    _fields_ = [("i_pixel", C.c_int), ("me_method", C.c_int), ("subpel_refine", C.c_int), ("me_range", C.c_int),
-                ("mbcmp_satd", C.c_int), ("fpelcmp_satd", C.c_int), ("fenc", C.c_void_p), ("ref", C.c_void_p * 4), ("stride", C.c_int),
-                ("integral", C.c_void_p), ("integral_lower", C.c_long), ("mvp", C.c_int * 2), ("lim_min", C.c_int * 2),
-                ("lim_max", C.c_int * 2), ("spel_min", C.c_int * 2), ("spel_max", C.c_int * 2), ("cost_mv", C.c_void_p)]
+from tests.common import ME_METHODS as METHODS, ME_SIZES as SIZES, oracle_me_search  # noqa: E402
 
 
 def _box_sums(plane, n):
@@ -86,8 +78,11 @@ def test_me_search_full(me, clipname, depth):
         rng = np.random.default_rng(5)
         mv_range = r.cfg["mv_range"]
         mbw, mbh = W // 16, H // 16
-        f = o.f("me_search_full")
-        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        itg = None
+        if integral is not None:
+            # the oracle walks the integral plane with the reference plane's stride: hand it a view with the same geometry
+            x0 = padh_align - padh
+            itg = np.ascontiguousarray(integral[:, x0:x0 + pw])
         n_checked = 0
         for trial in range(150):
             i_pixel = int(rng.integers(0, 7)) if sub8 or METHODS[me] < 3 else int(rng.integers(0, 4))
@@ -111,31 +106,9 @@ def test_me_search_full(me, clipname, depth):
             out_r = np.zeros(4, np.int32)
             assert L.rh_me_search(r.ctx, 0, fenc.ctypes.data, mb_x, mb_y, xoff, yoff, i_pixel, subme, me_range, mvp.ctypes.data,
                                   mvc.ctypes.data, n_mvc, out_r.ctypes.data) == 0
-            m = MeFull()
-            m.i_pixel, m.me_method, m.subpel_refine, m.me_range = i_pixel, METHODS[me], subme, me_range
-            m.mbcmp_satd, m.fpelcmp_satd = 1, int(me == "tesa")
-            m.fenc = fenc.ctypes.data
-            org = (padv + sy) * pw + padh + sx
-            for p in range(4):
-                m.ref[p] = planes[p].ctypes.data + org * planes[p].itemsize
-            m.stride = pw
-            fm = 4 * mv_range
-            smin = [max(4 * (-16 * mb_x - 24), -fm), max(4 * (-16 * mb_y - 24), -fm)]
-            smax = [min(4 * (16 * (mbw - mb_x - 1) + 24), fm - 1), min(4 * (16 * (mbh - mb_y - 1) + 24), fm - 1)]
-            for k in range(2):
-                m.spel_min[k], m.spel_max[k] = smin[k], smax[k]
-                m.lim_min[k], m.lim_max[k] = (smin[k] >> 2) + 6, (smax[k] >> 2) - 6
-                m.mvp[k] = int(mvp[k])
-            m.cost_mv = cost_mv.ctypes.data + 2 * centre
-            if integral is not None:
-                # the oracle walks the integral plane with the reference plane's stride: hand it a view with the same geometry
-                itg = np.zeros((2 * ph, pw), np.uint16)
-                x0 = padh_align - padh
-                itg[:, :] = integral[:, x0:x0 + pw]
-                m.integral = itg.ctypes.data + org * 2
-                m.integral_lower = ph * pw
-            out_o = np.zeros(4, np.int32)
-            f(C.byref(m), mvc.ctypes.data, n_mvc, out_o.ctypes.data)
+            call = [i_pixel, mb_x, mb_y, xoff, yoff, subme, me_range, int(mvp[0]), int(mvp[1]), n_mvc] + \
+                   (list(mvc.reshape(-1)) + [0] * 8)[:8]
+            out_o = oracle_me_search(o, me, planes, itg, cost_mv, (W, H, pw, ph, padh, padv, mv_range), fenc, call)
             if subme < 2:
                 out_r[3] = out_o[3]  # cost_mv is only defined by refine_subpel / the subme < 3 exit
             assert np.array_equal(out_r[:3], out_o[:3]), "%s trial %d pix %d subme %d range %d mvp %s nmvc %d mb %d,%d off %d,%d ref %s oracle %s" % (me, trial, i_pixel, subme, me_range, mvp.tolist(), n_mvc, mb_x, mb_y, xoff, yoff, out_r.tolist(), out_o.tolist())
