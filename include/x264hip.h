@@ -162,6 +162,11 @@ int  x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *frame_numb
 int  x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, int n );
 int  x264hip_get_qp_offsets( x264hip_ctx *ctx, int slot, float *qp_offset );        /* f_qp_offset, n_mb floats */
 int  x264hip_get_propagate_cost( x264hip_ctx *ctx, int slot, uint16_t *propagate ); /* i_propagate_cost, n_mb */
+/* slicetype_frame_cost_recalculate (encoder/slicetype.c:999-1024; called by x264_rc_analyse_slice, :2002-2003, and by
+ * vbv_frame_cost): cost of the evaluated cell (dist_p0, dist_p1) of frame slot_b under its current quantiser offsets --
+ * f_qp_offset (after MB-tree), or f_qp_offset_aq when use_aq_offsets (the reference's choice for B frames).  Rewrites the
+ * cell's i_row_satds like the reference and returns the frame sum. */
+int  x264hip_frame_cost_recalculate( x264hip_ctx *ctx, int slot_b, int dist_p0, int dist_p1, int use_aq_offsets, int *score );
 
 /* ---- vtable-granular primitives, batched -------------------------------------------------------
  * Device counterparts of x264_pixel_function_t.sad/satd (common/pixel.h:78-84, pixel.c:55-80,265-332)

@@ -317,6 +317,24 @@ RH_API int rh_frame_cost( rh_ctx *c, int p0, int p1, int b )
     return slicetype_frame_cost( c->h, &a, c->frames, p0, p1, b );
 }
 
+/* slicetype_frame_cost_recalculate (slicetype.c:999) of an evaluated cell; b_type_b picks f_qp_offset_aq like a B frame */
+RH_API int rh_frame_cost_recalculate( rh_ctx *c, int p0, int p1, int b, int b_type_b )
+{
+    c->frames[b]->i_type = b_type_b ? X264_TYPE_B : X264_TYPE_P;
+    return slicetype_frame_cost_recalculate( c->h, c->frames, p0, p1, b );
+}
+RH_API void rh_get_qp_offsets( rh_ctx *c, int idx, float *qp, float *qp_aq )
+{
+    x264_frame_t *f = c->frames[idx];
+    int n = c->h->mb.i_mb_count;
+    if( qp ) memcpy( qp, f->f_qp_offset, n * sizeof(float) );
+    if( qp_aq ) memcpy( qp_aq, f->f_qp_offset_aq, n * sizeof(float) );
+}
+RH_API void rh_set_qp_offsets( rh_ctx *c, int idx, const float *qp )
+{
+    memcpy( c->frames[idx]->f_qp_offset, qp, c->h->mb.i_mb_count * sizeof(float) );
+}
+
 RH_API void rh_weights_analyse( rh_ctx *c, int b, int ref, int *out )
 {
     x264_weights_analyse( c->h, c->frames[b], c->frames[ref], 1 );

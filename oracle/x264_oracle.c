@@ -1269,6 +1269,27 @@ uint64_t ORN(aq_frame)( const pixel *luma, int stride, int width, int height, in
     return sum_y;
 }
 
+/* slicetype_frame_cost_recalculate (slicetype.c:999-1024): the frame cost of an already evaluated cell under new per-MB
+ * quantiser offsets (MB-tree), without touching the searches: cost14 * exp2fix8(qp_offset), row sums, and the frame sum
+ * over the same interior blocks as slicetype_frame_cost. */
+int ORN(frame_cost_recalculate)( int mb_w, int mb_h, const uint16_t *lowres_costs, const float *qp_offset, int *row_satds )
+{
+    int score = 0;
+    for( int y = mb_h - 1; y >= 0; y-- )
+    {
+        row_satds[y] = 0;
+        for( int x = mb_w - 1; x >= 0; x-- )
+        {
+            int cost = lowres_costs[y*mb_w + x] & 0x3FFF;
+            cost = ( cost * exp2fix8( qp_offset[y*mb_w + x] ) + 128 ) >> 8;
+            row_satds[y] += cost;
+            if( ( y > 0 && y < mb_h - 1 && x > 0 && x < mb_w - 1 ) || mb_w <= 2 || mb_h <= 2 )
+                score += cost;
+        }
+    }
+    return score;
+}
+
 /* ================================================================================================
  * SURVEY 8(f) rank 3 groundwork: the main-encode motion search, encoder/me.c:182-798 (x264_me_search_ref with
  * every method: DIA, HEX, UMH, ESA, TESA) and :865-992 (refine_subpel, all subpel_iterations rows), for any

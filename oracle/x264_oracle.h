@@ -85,6 +85,7 @@ void or##D##_integral_init4v( uint16_t *sum8, uint16_t *sum4, long stride ); \
 void or##D##_integral_init8v( uint16_t *sum8, long stride ); \
 int  or##D##_ads( int n_dc, const int *enc_dc, const uint16_t *sums, int delta, const uint16_t *cost_mvx, int16_t *mvs, int width, int thresh ); \
 void or##D##_me_search_full( const or##D##_me_full *p, const int16_t (*mvc)[2], int n_mvc, int out[4] ); \
+int  or##D##_frame_cost_recalculate( int mb_w, int mb_h, const uint16_t *lowres_costs, const float *qp_offset, int *row_satds ); \
 void or##D##_hpel_filter( PIX *dsth, PIX *dstv, PIX *dstc, const PIX *src, long stride, int width, int height, int16_t *buf ); \
 int  or##D##_sad( const PIX *a, int sa, const PIX *b, int sb, int w, int h ); \
 int  or##D##_ssd( const PIX *a, int sa, const PIX *b, int sb, int w, int h ); \

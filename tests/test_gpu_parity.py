@@ -229,3 +229,37 @@ def test_mbtree_steps_match_oracle():
         assert np.array_equal(ctx.qp_offsets(0), qp), ("f_qp_offset", float(np.abs(ctx.qp_offsets(0) - qp).max()))
     finally:
         ctx.close()
+
+
+@pytest.mark.xfail(strict=False, reason="x264hip_frame_cost_recalculate was written after this round's GPU budget was spent: "
+                                        "the oracle side is pinned against the reference on CPU, the device side is still to be confirmed")
+def test_frame_cost_recalculate():
+    """x264hip_frame_cost_recalculate (slicetype_frame_cost_recalculate, slicetype.c:999-1024) against the oracle on the
+    device's own maps: a P cell under f_qp_offset, a B cell under f_qp_offset_aq, and the I cell after an MB-tree finish."""
+    import ctypes as C
+    frames = clip("fastpan", 176, 144, 3)
+    o, cfg, ctx = _mk(*CONFIGS["hex_r4"], 176, 144)
+    try:
+        qp_aq = []
+        for i in range(3):
+            ctx.frame_put(i, frames[i])
+            qp_aq.append(o.aq_frame(frames[i], cfg.mb_w, cfg.mb_h, 1, 1.0)[1])
+        ctx.frame_cost(0, 0, 0, 0, 0, (0, 0), None, True, False)
+        ctx.frame_cost(0, 2, 2, 2, 0, (1, 0), None, True, False)
+        ctx.frame_cost(0, 2, 1, 1, 1, (1, 1), None, True, True)
+        fps = np.float32(0.04 / (0.04 * 256.0) * 0.5)
+        ctx.mbtree([lib.MbtreeOp(0, 2, 2, 2, 0, 0, 0, 0, 0.0, 0, 0.0, 0.0), lib.MbtreeOp(0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0.0, 0.0),
+                    lib.MbtreeOp(1, 2, 0, 2, 2, 0, 1, 32, fps, 0, 0.0, 0.0), lib.MbtreeOp(2, 0, 0, 0, 0, 0, 0, 0, 0.0, 512, 0.0, 2.0)])
+        f = o.f("frame_cost_recalculate", C.c_int)
+        f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        for slot, d0, d1, use_aq in ((2, 2, 0, False), (1, 1, 1, True), (0, 0, 0, False)):
+            lc, _ = ctx.lowres_costs(slot, d0, d1)
+            qp = np.ascontiguousarray(qp_aq[slot] if use_aq else ctx.qp_offsets(slot), np.float32)
+            rows = np.zeros(cfg.mb_h, np.int32)
+            want = f(cfg.mb_w, cfg.mb_h, lc.ctypes.data, qp.ctypes.data, rows.ctypes.data)
+            got = ctx.frame_cost_recalculate(slot, d0, d1, use_aq)
+            _, rows_dev = ctx.lowres_costs(slot, d0, d1)
+            assert got == want and np.array_equal(rows_dev, rows), (slot, d0, d1, use_aq, got, want)
+        assert not np.array_equal(ctx.qp_offsets(0), qp_aq[0])  # the finish step really changed frame 0's offsets
+    finally:
+        ctx.close()

@@ -131,3 +131,44 @@ def test_non_mod16_size():
         _eval_sequence(r, o, cfg, planes, inv, 3)
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_frame_cost_recalculate(depth):
+    """slicetype_frame_cost_recalculate (slicetype.c:999-1024): oracle vs the reference's static function on evaluated cells,
+    with the AQ offsets (B-frame form) and with arbitrary MB-tree-like offsets incl. values that saturate exp2fix8."""
+    import ctypes as C
+    W, H = 176, 144
+    frames = clip("pan", W, H, 4, depth)
+    r = refharness.Ref(W, H, "medium", bit_depth=depth)
+    o = Oracle(depth)
+    try:
+        for f in frames:
+            r.add_frame(f)
+        L = r.lib
+        L.rh_frame_cost_recalculate.argtypes = [C.c_void_p] + [C.c_int] * 4
+        L.rh_get_qp_offsets.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.rh_set_qp_offsets.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        f_or = o.f("frame_cost_recalculate", C.c_int)
+        f_or.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        rng = np.random.default_rng(3)
+        for (p0, p1, b) in [(0, 1, 1), (0, 2, 1), (0, 3, 3), (1, 3, 2)]:
+            r.frame_cost(p0, p1, b)
+            lc, _, _ = r.cell(b, b - p0, p1 - b)
+            qp = np.zeros(r.n_mb, np.float32)
+            qp_aq = np.zeros(r.n_mb, np.float32)
+            for variant in range(3):
+                if variant == 2:
+                    mt = rng.uniform(-60, 60, size=r.n_mb).astype(np.float32)   # beyond both exp2fix8 clamps
+                    mt[::7] = 0
+                    L.rh_set_qp_offsets(r.ctx, b, mt.ctypes.data)
+                L.rh_get_qp_offsets(r.ctx, b, qp.ctypes.data, qp_aq.ctypes.data)
+                is_b = variant == 0
+                want = L.rh_frame_cost_recalculate(r.ctx, p0, p1, b, int(is_b))
+                _, rows_ref, _ = r.cell(b, b - p0, p1 - b)
+                rows = np.zeros(r.mb_h, np.int32)
+                src = qp_aq if is_b else qp
+                got = f_or(r.mb_w, r.mb_h, lc.ctypes.data, src.ctypes.data, rows.ctypes.data)
+                assert got == want and np.array_equal(rows, rows_ref), (p0, p1, b, variant)
+    finally:
+        r.close()

@@ -524,6 +524,49 @@ __global__ __launch_bounds__( 1024 ) void cell_reduce_kernel( LaP P, const CellA
     }
 }
 
+// slicetype_frame_cost_recalculate (slicetype.c:999-1024): the cost of an evaluated cell under the frame's current quantiser
+// offsets (f_qp_offset after MB-tree, or f_qp_offset_aq for B frames): cost14 * exp2fix8( qp_offset ), new row sums, and
+// the frame sum over the interior blocks.  One workgroup, a wave per block row (like cell_reduce_kernel); exp2fix8 is the
+// expression aq_kernel uses (explicit multiply and add: the reference has no FMA here either).
+__global__ __launch_bounds__( 256 ) void recalc_kernel( LaP P, const uint16_t *__restrict__ lowres_costs, const float *__restrict__ qp_offset,
+                                                        const AqLuts *__restrict__ luts, int *__restrict__ row_satds, int *score_host )
+{
+    __shared__ int sh[4];
+    const int W = P.mb_w, H = P.mb_h;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
+    int t = 0;
+    for( int by = wave; by < H; by += n_waves )
+    {
+        int row = 0;
+        for( int bx = lane; bx < W; bx += 64 )
+        {
+            const int xy = by * W + bx;
+            const int i = (int)__fadd_rn( __fmul_rn( qp_offset[xy], -64.f / 6.f ), 512.5f );
+            const int e = i < 0 ? 0 : i > 1023 ? 0xffff : ( ( luts->exp2_lut[i & 63] + 256 ) << ( i >> 6 ) >> 8 );
+            const int cost = ( ( lowres_costs[xy] & 0x3FFF ) * e + 128 ) >> 8;
+            row += cost;
+            if( ( bx > 0 && bx < W - 1 && by > 0 && by < H - 1 ) || W <= 2 || H <= 2 )
+                t += cost;
+        }
+#pragma unroll
+        for( int o = 32; o > 0; o >>= 1 )
+            row += __shfl_xor( row, o );
+        if( lane == 0 )
+            row_satds[by] = row;
+    }
+#pragma unroll
+    for( int o = 32; o > 0; o >>= 1 )
+        t += __shfl_xor( t, o );
+    if( lane == 0 ) sh[wave] = t;
+    __syncthreads();
+    if( threadIdx.x == 0 )
+    {
+        int v = 0;
+        for( int k = 0; k < n_waves; k++ ) v += sh[k];
+        *score_host = v;
+    }
+}
+
 // P and intra-only cells: no pixel work, one thread per block
 __global__ __launch_bounds__( 256 ) void cell_p_kernel( LaP P, const CellArgs *descs, CellArgs single )
 {

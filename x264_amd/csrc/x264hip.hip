@@ -1074,6 +1074,27 @@ extern "C" int x264hip_get_qp_offsets( x264hip_ctx *ctx, int slot, float *qp_off
     return X264HIP_OK;
 }
 
+extern "C" int x264hip_frame_cost_recalculate( x264hip_ctx *ctx, int slot_b, int dist_p0, int dist_p1, int use_aq_offsets, int *score )
+{
+    if( !ctx || !slot_ok( ctx, slot_b ) || !score || dist_p0 < 0 || dist_p1 < 0 || dist_p0 + dist_p1 > ctx->p.bframes + 1 ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    FrameSlot &b = ctx->slots[slot_b];
+    if( !b.in_use ) return X264HIP_ESTATE;
+    const int idx = dist_p0 * ( ctx->p.bframes + 2 ) + dist_p1;
+    // f_qp_offset is written by the MB-tree stream: order this stream behind it
+    if( ctx->mbt_pending )
+        HIPCK( hipStreamWaitEvent( ctx->stream, ctx->ev_mbt_last, 0 ) );
+    int *res = ctx->cell_acc_host + ( (size_t)slot_b * ctx->n_cells + idx ) * 8 + 7; // a spare word of the cell's pinned result record
+    recalc_kernel<<<1, 256, 0, ctx->stream>>>( ctx->P, b.lowres_costs + (size_t)idx * ctx->n_mb, use_aq_offsets ? b.qp_aq : b.qp, ctx->luts_dev,
+                                               b.row_satds + (size_t)idx * ctx->P.mb_h, res );
+    HIPCK( hipGetLastError() );
+    int rc = sync_stream( ctx );
+    if( rc ) return rc;
+    *score = *(volatile int *)res;
+    return X264HIP_OK;
+}
+
 extern "C" int x264hip_get_propagate_cost( x264hip_ctx *ctx, int slot, uint16_t *propagate )
 {
     if( !ctx || !slot_ok( ctx, slot ) || !propagate ) return X264HIP_EINVAL;

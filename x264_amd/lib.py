@@ -205,6 +205,11 @@ class Context:
         _ck(self.L.x264hip_get_propagate_cost(self.h, slot, _p(out)), "get_propagate_cost")
         return out
 
+    def frame_cost_recalculate(self, slot_b, d0, d1, use_aq_offsets=False):
+        score = C.c_int()
+        _ck(self.L.x264hip_frame_cost_recalculate(self.h, slot_b, d0, d1, int(use_aq_offsets), C.byref(score)), "frame_cost_recalculate")
+        return score.value
+
     def mbtree(self, ops):
         arr = (MbtreeOp * len(ops))(*ops)
         _ck(self.L.x264hip_mbtree(self.h, arr, len(ops)), "mbtree")
