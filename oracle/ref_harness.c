@@ -501,6 +501,10 @@ RH_API void rh_pixel_cmp_xn( rh_ctx *c, int satd, int n, int size, pixel *fenc, 
     else
         (satd ? pf->satd_x4 : pf->sad_x4)[size]( fenc, ref+offs[0], ref+offs[1], ref+offs[2], ref+offs[3], stride, out );
 }
+RH_API int rh_var2( rh_ctx *c, int is8x16, pixel *fenc, pixel *fdec, int *ssd ) { return c->h->pixf.var2[is8x16 ? PIXEL_8x16 : PIXEL_8x8]( fenc, fdec, ssd ); }
+RH_API uint64_t rh_hadamard_ac( rh_ctx *c, int size, pixel *pix, intptr_t stride ) { return c->h->pixf.hadamard_ac[size]( pix, stride ); }
+RH_API int rh_vsad( rh_ctx *c, pixel *src, intptr_t stride, int height ) { return c->h->pixf.vsad( src, stride, height ); }
+RH_API int rh_asd8( rh_ctx *c, pixel *a, intptr_t sa, pixel *b, intptr_t sb, int height ) { return c->h->pixf.asd8( a, sa, b, sb, height ); }
 RH_API uint64_t rh_pixel_var( rh_ctx *c, int size, pixel *a, intptr_t sa ) { return c->h->pixf.var[size]( a, sa ); }
 /* fdec points at the top-left pixel of an FDEC_STRIDE buffer with neighbours filled in */
 RH_API void rh_intra_x3_8x8c( rh_ctx *c, int satd, pixel *fenc, pixel *fdec, int *res )

@@ -287,6 +287,61 @@ uint64_t ORN(var)( const pixel *a, int sa, int w, int h )
     return sum + ( (uint64_t)sqr << 32 );
 }
 
+/* The remaining P8 metrics (main-encode consumers): common/pixel.c:206-231 (var2_8x8 / var2_8x16 on the interleaved chroma
+ * halves of the fenc/fdec buffers), :383-435 (hadamard_ac: sums of the absolute AC coefficients of the 4x4 and 8x8
+ * Hadamard transforms of the pixels themselves), :716-723 (vsad) and :747-754 (asd8). */
+int ORN(var2)( const pixel *fenc, const pixel *fdec, int h, int ssd[2] )
+{
+    int sum_u = 0, sum_v = 0, sqr_u = 0, sqr_v = 0;
+    const int shift = h == 16 ? 7 : 6;
+    for( int y = 0; y < h; y++ )
+        for( int x = 0; x < 8; x++ )
+        {
+            int du = fenc[y*OR_FENC_STRIDE + x] - fdec[y*OR_FDEC_STRIDE + x];
+            int dv = fenc[y*OR_FENC_STRIDE + x + OR_FENC_STRIDE/2] - fdec[y*OR_FDEC_STRIDE + x + OR_FDEC_STRIDE/2];
+            sum_u += du; sum_v += dv; sqr_u += du*du; sqr_v += dv*dv;
+        }
+    ssd[0] = sqr_u; ssd[1] = sqr_v;
+    return sqr_u - (int)( (int64_t)sum_u * sum_u >> shift ) + sqr_v - (int)( (int64_t)sum_v * sum_v >> shift );
+}
+static void hadamard_ac_8x8( const pixel *pix, int stride, uint64_t *sum4, uint64_t *sum8 )
+{
+    static const pixel zero[8] = { 0 };
+    int dc = 0, s4 = 0;
+    for( int y = 0; y < 8; y++ )
+        for( int x = 0; x < 8; x++ )
+            dc += pix[y*stride + x];
+    for( int by = 0; by < 8; by += 4 )
+        for( int bx = 0; bx < 8; bx += 4 )
+            s4 += hadamard_abs_4x4( pix + by*stride + bx, stride, zero, 0 );
+    *sum4 += (uint64_t)( s4 - dc );
+    *sum8 += (uint64_t)( hadamard_abs_8x8( pix, stride, zero, 0 ) - dc );
+}
+uint64_t ORN(hadamard_ac)( const pixel *pix, int stride, int w, int h )
+{
+    uint64_t sum4 = 0, sum8 = 0;
+    for( int y = 0; y < h; y += 8 )
+        for( int x = 0; x < w; x += 8 )
+            hadamard_ac_8x8( pix + y*stride + x, stride, &sum4, &sum8 );
+    return ( ( sum8 >> 2 ) << 32 ) + ( (uint32_t)sum4 >> 1 );
+}
+int ORN(vsad)( const pixel *src, long stride, int height )
+{
+    int score = 0;
+    for( int i = 1; i < height; i++, src += stride )
+        for( int j = 0; j < 16; j++ )
+            score += abs( src[j] - src[j + stride] );
+    return score;
+}
+int ORN(asd8)( const pixel *a, long sa, const pixel *b, long sb, int height )
+{
+    int sum = 0;
+    for( int y = 0; y < height; y++ )
+        for( int x = 0; x < 8; x++ )
+            sum += a[y*sa + x] - b[y*sb + x];
+    return abs( sum );
+}
+
 static inline int mbcmp8x8( const or_la_cfg *c, const pixel *a, int sa, const pixel *b, int sb )
 {
     return c->mbcmp_satd ? ORN(satd)( a, sa, b, sb, 8, 8 ) : ORN(sad)( a, sa, b, sb, 8, 8 );

@@ -92,6 +92,10 @@ int  or##D##_ssd( const PIX *a, int sa, const PIX *b, int sb, int w, int h ); \
 int  or##D##_satd( const PIX *a, int sa, const PIX *b, int sb, int w, int h ); \
 int  or##D##_sa8d( const PIX *a, int sa, const PIX *b, int sb, int w ); \
 uint64_t or##D##_var( const PIX *a, int sa, int w, int h ); \
+int  or##D##_var2( const PIX *fenc, const PIX *fdec, int h, int ssd[2] ); \
+uint64_t or##D##_hadamard_ac( const PIX *pix, int stride, int w, int h ); \
+int  or##D##_vsad( const PIX *src, long stride, int height ); \
+int  or##D##_asd8( const PIX *a, long sa, const PIX *b, long sb, int height ); \
 void or##D##_predict_8x8c( int mode, PIX *src ); \
 void or##D##_predict_8x8_filter( const PIX *src, PIX *edge ); \
 void or##D##_predict_8x8( int mode, PIX *src, const PIX *edge ); \

@@ -176,6 +176,45 @@ def test_hpel_filter(env):
             assert np.array_equal(a[k], b[k]), (w, h, kind, k)
 
 
+def test_var2_hadamard_ac_vsad_asd8(env):
+    """the remaining P8 metrics: oracle vs pixf.var2 / hadamard_ac / vsad / asd8 on random and extreme data"""
+    r, o, d = env
+    rng = np.random.default_rng(12)
+    maxv = (1 << d) - 1
+    L = r.lib
+    L.rh_var2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rh_hadamard_ac.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
+    L.rh_hadamard_ac.restype = C.c_uint64
+    L.rh_vsad.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int]
+    L.rh_asd8.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int]
+    f_var2 = o.f("var2", C.c_int); f_var2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    f_hac = o.f("hadamard_ac", C.c_uint64); f_hac.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    f_vsad = o.f("vsad", C.c_int); f_vsad.argtypes = [C.c_void_p, C.c_long, C.c_int]
+    f_asd8 = o.f("asd8", C.c_int); f_asd8.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int]
+    for trial in range(12):
+        if trial == 0:
+            fenc = np.full((16, 16), maxv, o.dtype); fdec = np.zeros((16, 32), o.dtype)
+        elif trial == 1:
+            yy, xx = np.mgrid[0:16, 0:16]
+            fenc = (((yy ^ xx) & 1) * maxv).astype(o.dtype); fdec = np.full((16, 32), maxv // 2, o.dtype)
+        else:
+            fenc = rng.integers(0, maxv + 1, size=(16, 16)).astype(o.dtype); fdec = rng.integers(0, maxv + 1, size=(16, 32)).astype(o.dtype)
+        for is16 in (0, 1):
+            sa, sb = np.zeros(2, np.int32), np.zeros(2, np.int32)
+            assert L.rh_var2(r.ctx, is16, _ptr(fenc), _ptr(fdec), _ptr(sa)) == f_var2(_ptr(fenc), _ptr(fdec), 16 if is16 else 8, _ptr(sb))
+            assert np.array_equal(sa, sb)
+        big = rng.integers(0, maxv + 1, size=(40, 64)).astype(o.dtype) if trial else np.full((40, 64), maxv, o.dtype)
+        if trial == 1:
+            yy, xx = np.mgrid[0:40, 0:64]
+            big = (((yy ^ xx) & 1) * maxv).astype(o.dtype)
+        for size, (w, h) in ((0, (16, 16)), (1, (16, 8)), (2, (8, 16)), (3, (8, 8))):
+            assert L.rh_hadamard_ac(r.ctx, size, _ptr(big, 64 + 3), 64) == f_hac(_ptr(big, 64 + 3), 64, w, h), (trial, size)
+        for height in (16, 32, 9):
+            assert L.rh_vsad(r.ctx, _ptr(big, 5), 64, height) == f_vsad(_ptr(big, 5), 64, height)
+        for height in (8, 16, 4):
+            assert L.rh_asd8(r.ctx, _ptr(big, 2), 64, _ptr(big, 64 * 3 + 17), 64, height) == f_asd8(_ptr(big, 2), 64, _ptr(big, 64 * 3 + 17), 64, height)
+
+
 def test_integral_init_and_ads(env):
     """oracle vs h->mc.integral_init{4h,8h,4v,8v} (checkasm.c:1745-1770 geometry: stride 96) and pixf.ads[] (checkasm.c:836-885:
     saturating multiples of 8*PIXEL_MAX and random 14/16-bit sums)"""
