@@ -314,7 +314,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "me_rows_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "launches": prof_launches, "searches": prof_searches, "avg_launch_ms": round(prof_ms / max(prof_launches, 1), 4),
-                         "algorithmic_bytes_per_search": bytes_per_search},
+                         "algorithmic_bytes_per_search": bytes_per_search,
+                         "note": "not a streaming kernel: ~80% VALU-issue bound (PMC: ~550 VALU per block search, 4 clocks each), HBM traffic "
+                                 "below the algorithmic bytes; see DESIGN.md section 3"},
             "lookahead_stats": {"frame_cost_calls": int(la_stats[0]), "evaluations": int(la_stats[1]),
                                 "weights_analysed": int(la_stats[2]), "weights_kept": int(la_stats[3]),
                                 "device": {"searches": int(dev_counters[0]), "cell_requests": int(dev_counters[1]), "cell_hits": int(dev_counters[4]),

@@ -1,6 +1,6 @@
 """Quick GPU probe: device, a sanity check that parity checks bite, and first search timings."""
 import sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, '.')  # run from the repo root: python tests/tools/gpu_probe.py
 import numpy as np
 from x264_amd import lib
 from x264_amd.synth import make_clip
