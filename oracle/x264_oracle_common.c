@@ -23,10 +23,11 @@ int or_lambda_for_depth( int bit_depth ) { return bit_depth == 8 ? 1 : bit_depth
  * propagate buffers are uint16 with saturation at 32767 (MC_CLIP_ADD, common/mc.h:29).
  * ---------------------------------------------------------------------------------------------- */
 #include <string.h>
-/* x264_log2( a ) - x264_log2( b ) (common/base.h:225-229) with the association the reference build uses
- * (gcc -ffast-math): ( ( lut[a] - int(b) ) + int(a) ) - lut[b].  Pinned against oracle/_ref: 11583 of 11583
+/* x264_log2( a ) - x264_log2( b ) + w (common/base.h:225-229, slicetype.c:1045) with the association the reference
+ * build uses (gcc -O3 -ffast-math, the flags the reference configures): ( ( lut[a] - int(b) ) + ( int(a) + w ) ) - lut[b];
+ * w = weightdelta is only non-zero with weightp = FAKE (slicetype.c:462-463).  Pinned against oracle/_ref: 11583 of 11583
  * macroblocks of the f_qp_offset maps exact with this order, < 22 % with the textbook order. */
-static float oc_log2_diff( uint32_t a, uint32_t b )
+static float oc_log2_diff( uint32_t a, uint32_t b, float w )
 {
     static float lut[128];
     static int init = 0;
@@ -38,7 +39,7 @@ static float oc_log2_diff( uint32_t a, uint32_t b )
     }
     int lza = __builtin_clz( a ), lzb = __builtin_clz( b );
     float t = lut[( a << lza >> 24 ) & 0x7f] - (float)( 31 - lzb );
-    return ( t + (float)( 31 - lza ) ) - lut[( b << lzb >> 24 ) & 0x7f];
+    return ( t + ( (float)( 31 - lza ) + w ) ) - lut[( b << lzb >> 24 ) & 0x7f];
 }
 
 static inline void clip_add( uint16_t *s, int x )
@@ -112,7 +113,7 @@ void or_mbtree_finish( int n_mb, const uint16_t *intra_cost, const uint16_t *inv
         if( ic )
         {
             int pc = ( propagate_cost[i] * fps_factor + 128 ) >> 8;
-            float log2_ratio = oc_log2_diff( ic + pc, ic ) + weightdelta;
+            float log2_ratio = oc_log2_diff( ic + pc, ic, weightdelta );
             qp_offset[i] = qp_offset_aq[i] - strength * log2_ratio;
         }
     }

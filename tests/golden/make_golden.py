@@ -26,14 +26,23 @@ LOOKAHEAD_CASES = {
     "veryfast": ("veryfast", "", {}, 8, 176, 144, dict(seed=7, pan=(1, 1), noise=1), 40),
     "nonmod16": ("medium", "", {}, 8, 200, 120, dict(seed=12, pan=(7, 3)), 48),
     "slow_dia_720p": ("slow", "me=dia", dict(me="dia"), 8, 1280, 720, dict(seed=13, scene_cuts=(20,)), 58),
+    # weightp=0 + mbtree + psy = WEIGHTP_FAKE: weightdelta != 0 in macroblock_tree_finish (slicetype.c:462-463, 1032-1034)
+    "fakeweight_fade": ("fast", "bframes=4,b-adapt=2,b-pyramid=strict,keyint=12,min-keyint=0,rc-lookahead=40,weightp=0",
+                        dict(bframes=4, b_adapt=2, b_pyramid=1, keyint_max=12, keyint_min=0, rc_lookahead=40, weightp=0), 8, 176, 144,
+                        dict(seed=178, scene_cuts=(28,), pan=(3, 0), fade=(15, 10, 1.5, -4)), 48),
+    "fakeweight_opengop": ("fast", "bframes=1,b-adapt=1,keyint=24,min-keyint=0,rc-lookahead=10,weightp=0,open-gop=1",
+                           dict(bframes=1, b_adapt=1, keyint_max=24, keyint_min=0, rc_lookahead=10, weightp=0, open_gop=1), 8, 96, 80,
+                           dict(seed=840, scene_cuts=(24, 36), pan=(3, 1), fade=(2, 10, 1.5, 5)), 50),
 }
 
 EVAL_CONFIGS = [("medium", "", 8), ("slow", "me=dia", 8), ("medium", "subme=1", 8), ("veryslow", "me=tesa", 10)]
 EVAL_SEQ = [(0, 0, 0), (0, 1, 1), (0, 2, 2), (0, 2, 1), (1, 1, 1), (0, 3, 3), (0, 3, 1), (0, 3, 2), (1, 3, 2), (2, 3, 3), (3, 3, 3)]
 
 
-def gen_lookahead():
+def gen_lookahead(only=None):
     for name, (preset, opts, over, depth, W, H, ckw, nf) in LOOKAHEAD_CASES.items():
+        if only and name not in only:
+            continue
         frames = make_clip(W, H, nf, bit_depth=depth, **ckw)
         r = refharness.Ref(W, H, preset, opts=opts, bit_depth=depth)
         ref = r.lookahead_run(frames, with_qp_offsets=True)
@@ -211,6 +220,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--primitives-only" in sys.argv:
         gen_primitives()
+        sys.exit(0)
+    if "--lookahead-cases" in sys.argv:  # only the named cases (the other fixtures stay byte-identical)
+        gen_lookahead(sys.argv[sys.argv.index("--lookahead-cases") + 1].split(","))
         sys.exit(0)
     if "--lookahead-only" not in sys.argv:
         gen_tables()

@@ -25,6 +25,17 @@ CASES = [
     ("medium", "bframes=0", dict(bframes=0), 8, dict(seed=9, scene_cuts=(11,)), 30),
     ("medium", "b-pyramid=none,weightp=0", dict(b_pyramid=0, weightp=0), 8, dict(seed=10), 40),
     ("medium", "open-gop=1,keyint=30", dict(open_gop=1, keyint_max=30), 8, dict(seed=11), 70),
+    # found by randomized configuration fuzzing against oracle/_ref:
+    # weightp=0 + mbtree + psy = WEIGHTP_FAKE (encoder.c:1121-1122): the luma weight search still runs and its cost ratio
+    # enters macroblock_tree_finish as weightdelta (slicetype.c:462-463, 1032-1034)
+    ("fast", "bframes=1,b-adapt=1,b-pyramid=normal,keyint=24,min-keyint=0,rc-lookahead=10,weightp=0,open-gop=1",
+     dict(bframes=1, b_adapt=1, b_pyramid=2, keyint_max=24, keyint_min=0, rc_lookahead=10, weightp=0, open_gop=1), 8,
+     dict(seed=840, scene_cuts=(24, 36), pan=(3, 1), fade=(2, 10, 1.5, 5)), 50),
+    ("fast", "bframes=4,b-adapt=2,b-pyramid=strict,keyint=12,min-keyint=0,rc-lookahead=40,weightp=0",
+     dict(bframes=4, b_adapt=2, b_pyramid=1, keyint_max=12, keyint_min=0, rc_lookahead=40, weightp=0), 8,
+     dict(seed=178, scene_cuts=(28,), pan=(3, 0), fade=(15, 10, 1.5, -4)), 48),
+    # no B-frames: open GOPs, adaptive placement and weighted bi-prediction are switched off (encoder.c:1080-1086)
+    ("faster", "bframes=0,open-gop=1,keyint=20", dict(bframes=0, open_gop=1, keyint_max=20), 8, dict(seed=12, scene_cuts=(9,)), 45),
 ]
 
 

@@ -1049,12 +1049,13 @@ __device__ __forceinline__ int prop_read( const int *p )
     int v = __hip_atomic_load( p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ); // bypass this CU's L1
     return v < 32767 ? v : 32767;
 }
-// x264_log2( a ) - x264_log2( b ) in the association of the reference build: ( ( lut[a] - int(b) ) + int(a) ) - lut[b]
-__device__ __forceinline__ float lut_log2_diff( const AqLuts *luts, unsigned a, unsigned b )
+// x264_log2( a ) - x264_log2( b ) + w in the association of the reference build (gcc -O3 -ffast-math, the flags the
+// reference configures): ( ( lut[a] - int(b) ) + ( int(a) + w ) ) - lut[b]
+__device__ __forceinline__ float lut_log2_diff( const AqLuts *luts, unsigned a, unsigned b, float w )
 {
     const int lza = __clz( a ), lzb = __clz( b );
     const float t = __fsub_rn( luts->log2_lut[( a << lza >> 24 ) & 0x7f], (float)( 31 - lzb ) );
-    return __fsub_rn( __fadd_rn( t, (float)( 31 - lza ) ), luts->log2_lut[( b << lzb >> 24 ) & 0x7f] );
+    return __fsub_rn( __fadd_rn( t, __fadd_rn( (float)( 31 - lza ), w ) ), luts->log2_lut[( b << lzb >> 24 ) & 0x7f] );
 }
 
 // one macroblock of a PROPAGATE step: mbtree_propagate_cost + both mbtree_propagate_list scatters
@@ -1194,7 +1195,7 @@ __global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *
                 if( ic )
                 {
                     const int pc = ( prop_read( &o.prop_b[i] ) * o.fps_factor_i + 128 ) >> 8;
-                    const float ratio = __fadd_rn( lut_log2_diff( luts, (unsigned)( ic + pc ), (unsigned)ic ), o.weightdelta );
+                    const float ratio = lut_log2_diff( luts, (unsigned)( ic + pc ), (unsigned)ic, o.weightdelta );
                     o.qp[i] = __fsub_rn( o.qp_aq[i], __fmul_rn( o.strength, ratio ) );
                 }
             }

@@ -347,8 +347,11 @@ def la_config(width, height, preset="medium", bit_depth=8, **over):
     c["mbcmp_satd"] = int(c["subme"] > 1)
     c["fpelcmp_satd"] = int(me == 4 and c["subme"] > 1)
     if not c["bframes"]:
+        # encoder.c:1080-1086: no B-frames also switches off adaptive placement, weighted bi-prediction and open GOPs
         c["b_adapt"] = 0
         c["b_pyramid"] = 0
+        c["weighted_bipred"] = 0
+        c["open_gop"] = 0
     if c["bframes"] <= 1:
         c["b_pyramid"] = 0
     if not c["weightp"] and c["mb_tree"] and c["psy"]:
