@@ -41,6 +41,7 @@ typedef struct x264hip_ctx x264hip_ctx;
 /* What lowres_context_init() (encoder/slicetype.c:45-61) and x264_param_t give the reference's
  * lookahead.  cost_mv is the centred table h->cost_mv[X264_LOOKAHEAD_QP] (encoder/analyse.c:151-157),
  * valid for indices [-2*4*mv_range, +2*4*mv_range]; it is copied at open. */
+#define X264HIP_LOOKAHEAD_SLICES_MAX 16 /* X264_LOOKAHEAD_THREAD_MAX, common/common.h */
 typedef struct x264hip_params
 {
     int bit_depth;        /* 8 or 10 */
@@ -55,10 +56,16 @@ typedef struct x264hip_params
     int mbcmp_satd;       /* h->pixf.mbcmp == satd (encoder.c:1409-1427) */
     int fpelcmp_satd;     /* h->pixf.fpelcmp == satd (me=tesa) */
     int weighted_bipred;  /* param.analyse.b_weighted_bipred */
-    int aq_mode;          /* param.rc.i_aq_mode (0 or 1) */
+    int aq_mode;          /* param.rc.i_aq_mode: 0 none, 1 variance, 2 auto-variance, 3 auto-variance biased */
     float aq_strength;    /* param.rc.f_aq_strength */
     int bframe_bias;      /* param.i_bframe_bias */
     int max_frames;       /* frame slots to keep resident (>= lookahead depth + bframes + 3) */
+    int no_edges;         /* 1 = slicetype_slice_cost's do_edges == 0 (encoder/slicetype.c:823-828: no MB-tree and no VBV): the
+                           * outermost ring of blocks is never evaluated, its vectors stay zero and its intra costs 0xFFFF;
+                           * ignored (edges evaluated) for frames of at most 2 blocks in a direction.  0 = every block */
+    int lookahead_slices; /* param.i_lookahead_threads (encoder/encoder.c:1273-1300): the frame is searched in that many
+                           * horizontal bands, rows [(mb_h*i + n/2)/n, (mb_h*(i+1) + n/2)/n), and a band does not use the
+                           * vectors of the band below as predictors (slicetype.c:668,917-918).  0 or 1 = one band */
     const uint16_t *cost_mv;
 } x264hip_params;
 
@@ -281,8 +288,8 @@ int  x264hip_lookahead_put_frames( x264hip_lookahead *la, int n, const void *con
 /* One call = the lookahead part of one x264_encoder_encode call.  flush != 0 once the input has ended.
  * *got = 1 and *out filled when a frame leaves the lookahead (coded order), 0 while the delay fills or at the end. */
 int  x264hip_lookahead_get_frame( x264hip_lookahead *la, int flush, x264hip_la_frame *out, int *got );
-/* same, additionally copying the frame's f_qp_offset map (mb_w*mb_h floats, MB-tree output read by rate control,
- * encoder/ratecontrol.c:1761) when qp_offset != NULL and mb_tree is on */
+/* same, additionally copying the frame's f_qp_offset map (mb_w*mb_h floats: the AQ offsets, replaced by the MB-tree output
+ * when mb_tree is on; read by rate control, encoder/ratecontrol.c:1761) when qp_offset != NULL and aq_mode != 0 */
 int  x264hip_lookahead_get_frame_ex( x264hip_lookahead *la, int flush, x264hip_la_frame *out, int *got, float *qp_offset );
 /* statistics: [0] slicetype_frame_cost calls, [1] real evaluations, [2] weights analysed, [3] weights kept,
  * wall time in ns spent in [4] backend frame_cost, [5] weights_analyse, [6] backend prefetch + mbtree, [7] the put/get calls in total */

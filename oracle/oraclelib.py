@@ -25,7 +25,7 @@ def _lib():
 class LaCfg(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "mb_w", "mb_h", "stride", "lambda_", "me_method", "subpel_refine", "me_range", "mv_range", "subme",
-        "mbcmp_satd", "fpelcmp_satd", "weighted_bipred", "aq_mode", "bframe_bias", "slice_start", "slice_end")] + \
+        "mbcmp_satd", "fpelcmp_satd", "weighted_bipred", "aq_mode", "bframe_bias", "n_slices", "do_edges")] + \
         [("cost_mv", C.c_void_p)]
 
 
@@ -64,7 +64,8 @@ class Oracle:
 
     # ---- configuration -------------------------------------------------------------------------
     def make_cfg(self, mb_w, mb_h, *, me_method, subpel_refine, me_range, mv_range, subme, mbcmp_satd,
-                 fpelcmp_satd=0, weighted_bipred=1, aq_mode=1, bframe_bias=0, lam=None, cost_mv=None):
+                 fpelcmp_satd=0, weighted_bipred=1, aq_mode=1, bframe_bias=0, lam=None, cost_mv=None, n_slices=1,
+                 do_edges=1):
         lam = lam if lam is not None else (1 if self.d == 8 else 4)
         n = 2 * 4 * mv_range
         if cost_mv is None:
@@ -72,7 +73,8 @@ class Oracle:
             self.lib.or_cost_mv_table(C.c_void_p(cost_mv.ctypes.data + 2 * n), n, lam)
         self._cost_mv = cost_mv
         cfg = LaCfg(mb_w, mb_h, plane_stride(8 * mb_w), lam, me_method, subpel_refine, me_range, mv_range, subme,
-                    mbcmp_satd, fpelcmp_satd, weighted_bipred, aq_mode, bframe_bias, 0, mb_h,
+                    mbcmp_satd, fpelcmp_satd, weighted_bipred, aq_mode, bframe_bias, n_slices,
+                    int(bool(do_edges) or mb_w <= 2 or mb_h <= 2),
                     cost_mv.ctypes.data + 2 * n)
         cfg._keep = cost_mv
         return cfg

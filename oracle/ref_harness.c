@@ -421,8 +421,9 @@ static int rh_drain_one( x264_t *h, int *out_idx, int *out_type, int *out_cost, 
     if( out_cost )    memcpy( out_cost    + (size_t)n_out*RH_MAT, f->i_cost_est,    RH_MAT*sizeof(int) );
     if( out_cost_aq ) memcpy( out_cost_aq + (size_t)n_out*RH_MAT, f->i_cost_est_aq, RH_MAT*sizeof(int) );
     if( out_imbs )    memcpy( out_imbs + (size_t)n_out*(X264_BFRAME_MAX+2), f->i_intra_mbs, (X264_BFRAME_MAX+2)*sizeof(int) );
-    if( rh_out_qp )   memcpy( rh_out_qp + (size_t)n_out*h->mb.i_mb_count, f->f_qp_offset, h->mb.i_mb_count*sizeof(float) );
-    if( rh_out_prop ) memcpy( rh_out_prop + (size_t)n_out*h->mb.i_mb_count, f->i_propagate_cost, h->mb.i_mb_count*sizeof(uint16_t) );
+    /* (the AQ / MB-tree arrays only exist with aq-mode != 0, frame.c:286-301: the dump stays zero without them) */
+    if( rh_out_qp && f->f_qp_offset )   memcpy( rh_out_qp + (size_t)n_out*h->mb.i_mb_count, f->f_qp_offset, h->mb.i_mb_count*sizeof(float) );
+    if( rh_out_prop && f->i_propagate_cost ) memcpy( rh_out_prop + (size_t)n_out*h->mb.i_mb_count, f->i_propagate_cost, h->mb.i_mb_count*sizeof(uint16_t) );
     x264_frame_push_unused( h, f );
     return 0;
 }

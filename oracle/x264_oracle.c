@@ -755,9 +755,12 @@ static int intra_cost_block( const or_la_cfg *c, const pixel *fenc0, int bx, int
 
 void ORN(intra_costs)( const or_la_cfg *c, const pixel *fenc0, uint16_t *intra_cost )
 {
+    /* blocks slicetype_slice_cost never visits keep the 0xFFFF of frame.c:288-289 (memset -1 at allocation) */
+    const int e = !c->do_edges;
     for( int by = 0; by < c->mb_h; by++ )
         for( int bx = 0; bx < c->mb_w; bx++ )
-            intra_cost[by*c->mb_w+bx] = (uint16_t)intra_cost_block( c, fenc0, bx, by );
+            intra_cost[by*c->mb_w+bx] = ( e && ( by < 1 || by > c->mb_h - 2 || bx < 1 || bx > c->mb_w - 2 ) ) ? 0xFFFF
+                                      : (uint16_t)intra_cost_block( c, fenc0, bx, by );
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1058,10 +1061,15 @@ static void block_limits( const or_la_cfg *c, int bx, int by, me_ctx *m )
 void ORN(search_field)( const or_la_cfg *c, const pixel *fenc0, const pixel *const ref[4], const pixel *ref_w,
                         const or_weight *wt, int16_t (*mvs)[2], int *mv_costs )
 {
-    const int W = c->mb_w;
+    const int W = c->mb_w, H = c->mb_h, ns = imax( c->n_slices, 1 ), de = !!c->do_edges;
     pixel fenc[8*OR_FENC_STRIDE];
-    for( int by = c->slice_end - 1; by >= c->slice_start; by-- )
-        for( int bx = W - 1; bx >= 0; bx-- )
+    /* bands of slicetype.c:917-918; inside a band the rows and columns of slicetype.c:825-833.  Blocks that are not
+     * visited keep what the caller put into mvs / mv_costs (zeros: frame.c:283-285) */
+    for( int sl = 0; sl < ns; sl++ )
+    {
+    const int slice_start = ( H*sl + ns/2 ) / ns, slice_end = ( H*( sl + 1 ) + ns/2 ) / ns;
+    for( int by = imin( slice_end - 1, H - 2 + de ); by >= imax( slice_start, 1 - de ); by-- )
+        for( int bx = W - 2 + de; bx >= 1 - de; bx-- )
         {
             const int xy = by*W + bx, off = 8*( by*c->stride + bx );
             me_ctx m;
@@ -1077,7 +1085,7 @@ void ORN(search_field)( const or_la_cfg *c, const pixel *fenc0, const pixel *con
             int n = 0;
 #define ADD(i) { mvc[n][0] = mvs[i][0]; mvc[n][1] = mvs[i][1]; n++; }
             if( bx < W - 1 ) ADD( xy + 1 );
-            if( by < c->slice_end - 1 )
+            if( by < slice_end - 1 )
             {
                 ADD( xy + W );
                 if( bx > 0 ) ADD( xy + W - 1 );
@@ -1107,6 +1115,7 @@ void ORN(search_field)( const or_la_cfg *c, const pixel *fenc0, const pixel *con
             mvs[xy][0] = (int16_t)m.mv[0]; mvs[xy][1] = (int16_t)m.mv[1];
             mv_costs[xy] = m.cost;
         }
+    }
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1146,11 +1155,14 @@ void ORN(cell)( const or_la_cfg *c, const pixel *fenc0, const pixel *const ref0[
     const int is_intra_only = !mvs0 && !mvs1; /* p0 == p1 */
     memset( out, 0, sizeof(*out) );
     pixel fenc[8*OR_FENC_STRIDE];
+    const int de = !!c->do_edges;
     for( int by = H - 1; by >= 0; by-- )
     {
         if( row_satds ) row_satds[by] = 0;
         if( row_satds_intra && with_intra ) row_satds_intra[by] = 0;
-        for( int bx = W - 1; bx >= 0; bx-- )
+        if( !de && ( by < 1 || by > H - 2 ) )
+            continue; /* slicetype.c:825-826: the row sums of unvisited rows are the zeros of :934-935 */
+        for( int bx = W - 2 + de; bx >= 1 - de; bx-- )
         {
             const int xy = by*W + bx, off = 8*( by*c->stride + bx );
             const int scored = ( bx > 0 && bx < W-1 && by > 0 && by < H-1 ) || W <= 2 || H <= 2;
@@ -1230,7 +1242,7 @@ void ORN(cell)( const or_la_cfg *c, const pixel *fenc0, const pixel *const ref0[
 }
 
 /* ------------------------------------------------------------------------------------------------
- * Adaptive-quant input stage: encoder/ratecontrol.c:225-415, aq-mode 0/1 only.
+ * Adaptive-quant input stage: encoder/ratecontrol.c:225-415, aq-mode 0..3.
  * Produces i_inv_qscale_factor (Q8) per MB and the luma sum / mean-removed ssd that
  * x264_weights_analyse reads (slicetype.c:301-306).  FP32 on purpose, same expression order as
  * the reference (which is built with -ffast-math; tests pin the bits against it).
@@ -1276,6 +1288,8 @@ uint64_t ORN(aq_frame)( const pixel *luma, int stride, int width, int height, in
     uint64_t sum_y = 0, ssd_y = 0;
     const float strength = aq_strength * 1.0397f;
     const int cw = ( width + 1 ) >> 1, chh = ( height + 1 ) >> 1;
+    float sum_r4 = 0.f, sum_r8 = 0.f;
+    float *av_r8 = malloc( sizeof(float) * mb_w * mb_h );
     for( int my = 0; my < mb_h; my++ )
         for( int mx = 0; mx < mb_w; mx++ )
         {
@@ -1313,12 +1327,45 @@ uint64_t ORN(aq_frame)( const pixel *luma, int stride, int width, int height, in
                 if( qp_offset ) qp_offset[my*mb_w+mx] = qp_adj;
                 inv_qscale[my*mb_w+mx] = (uint16_t)exp2fix8( qp_adj );
             }
+            else if( ( aq_mode == 2 || aq_mode == 3 ) && aq_strength != 0.f )
+            {
+                /* first pass of the auto-variance modes (ratecontrol.c:354-371) as the reference build computes it
+                 * (gcc -O3 -ffast-math, disassembly of oracle/_ref): powf( x, 0.125f ) is three square roots, and the
+                 * "qp_adj * qp_adj" that is averaged is the intermediate fourth root, not a product */
+                float x = (float)(uint64_t)energy;
+#if OR_DEPTH > 8
+                x *= 1.f / ( 1 << ( 2*( OR_DEPTH - 8 ) ) );
+#endif
+                x += 1.f;
+                const float r4 = sqrtf( sqrtf( x ) ), r8 = sqrtf( r4 );
+                sum_r4 += r4;        /* sequential sums in raster order: the rounding of every step counts */
+                sum_r8 += r8;
+                av_r8[my*mb_w+mx] = r8;
+            }
             else
             {
                 if( qp_offset ) qp_offset[my*mb_w+mx] = 0.f;
                 inv_qscale[my*mb_w+mx] = 256;
             }
         }
+    if( ( aq_mode == 2 || aq_mode == 3 ) && aq_strength != 0.f )
+    {
+        /* ratecontrol.c:372-377, :380-393 in the operation order of the reference build */
+        const float cnt = (float)( mb_w*mb_h );
+        const float avg_pow2 = sum_r4 / cnt, avg = sum_r8 / cnt;
+        const float str = aq_strength * avg;
+        const float avg_adj = ( ( 14.f - avg_pow2 ) * 0.5f ) / avg + avg;
+        for( int i = 0; i < mb_w*mb_h; i++ )
+        {
+            const float q = av_r8[i];
+            float qp_adj = ( q - avg_adj ) * str;
+            if( aq_mode == 3 )
+                qp_adj = ( 1.f - 14.f / ( q*q ) ) * aq_strength + qp_adj;
+            if( qp_offset ) qp_offset[i] = qp_adj;
+            inv_qscale[i] = (uint16_t)exp2fix8( qp_adj );
+        }
+    }
+    free( av_r8 );
     uint64_t n = (uint64_t)( 16*mb_w ) * ( 16*mb_h );
     if( ssd_out ) *ssd_out = ssd_y - ( sum_y*sum_y + n/2 ) / n;
     return sum_y;

@@ -37,7 +37,8 @@ typedef struct or_la_cfg
     int weighted_bipred;
     int aq_mode;
     int bframe_bias;
-    int slice_start, slice_end; /* i_threadslice_start/end rows (0, mb_h for lookahead_threads=1) */
+    int n_slices;           /* param.i_lookahead_threads: horizontal bands searched independently (slicetype.c:917-918) */
+    int do_edges;           /* slicetype.c:823: edge blocks are evaluated only with MB-tree / VBV / frames <= 2 blocks wide or high */
     const uint16_t *cost_mv;    /* centred table, index range +-(2*4*mv_range) */
 } or_la_cfg;
 

@@ -23,7 +23,8 @@ class OracleBackend:
                                     me_range=cfg["me_range"], mv_range=cfg["mv_range"], subme=cfg["subme"],
                                     mbcmp_satd=cfg["mbcmp_satd"], fpelcmp_satd=cfg["fpelcmp_satd"],
                                     weighted_bipred=cfg["weighted_bipred"], aq_mode=cfg["aq_mode"], lam=cfg["lam"],
-                                    bframe_bias=cfg["bframe_bias"], cost_mv=cost_mv)
+                                    bframe_bias=cfg["bframe_bias"], cost_mv=cost_mv, n_slices=cfg.get("lookahead_threads", 1),
+                                    do_edges=cfg.get("do_edges", 1))
         self.slots = {}
         self.n_eval = 0
         self.struct = lib.Backend(None, lib.FRAME_PUT_FN(self._put), lib.FRAME_STATS_FN(self._stats),

@@ -36,6 +36,27 @@ CASES = [
      dict(seed=178, scene_cuts=(28,), pan=(3, 0), fade=(15, 10, 1.5, -4)), 48),
     # no B-frames: open GOPs, adaptive placement and weighted bi-prediction are switched off (encoder.c:1080-1086)
     ("faster", "bframes=0,open-gop=1,keyint=20", dict(bframes=0, open_gop=1, keyint_max=20), 8, dict(seed=12, scene_cuts=(9,)), 45),
+    # no MB-tree (qcomp=1, encoder.c:1126-1127): slicetype_slice_cost skips the outermost ring of blocks (slicetype.c:823-833),
+    # the delay shrinks to the B-frame count, and f_qp_offset is the plain AQ map
+    ("veryfast", "bframes=2,keyint=24,scenecut=80,rc-lookahead=20,aq-strength=1.5,qcomp=1,subme=7,me=dia",
+     dict(bframes=2, keyint_max=24, scenecut=80, rc_lookahead=20, aq_strength=1.5, qcompress=1.0, subme=7, me="dia"), 8,
+     dict(seed=874, pan=(4, 3)), 47),
+    ("medium", "mbtree=0,bframes=5,b-adapt=2,rc-lookahead=30", dict(mb_tree=0, bframes=5, b_adapt=2, rc_lookahead=30), 8,
+     dict(seed=14, scene_cuts=(19,), fade=(30, 8, 0.6, 5)), 50),
+    # constant QP (encoder.c:951-966): no AQ, no MB-tree, no costs ahead of time for rate control; the P-frame weight analysis of
+    # slicetype_decide still fills the intra cell (slicetype.c:1937-1943, :365-370)
+    ("slow", "bframes=1,b-adapt=0,keyint=8,scenecut=0,rc-lookahead=5,subme=1,qp=24",
+     dict(bframes=1, b_adapt=0, keyint_max=8, scenecut=0, rc_lookahead=5, subme=1, rc_is_cqp=1), 8,
+     dict(seed=526, scene_cuts=(21, 40), pan=(3, 3), fade=(9, 10, 0.6, 12)), 46),
+    # auto-variance AQ (ratecontrol.c:354-393)
+    ("medium", "aq-mode=2,aq-strength=1.5", dict(aq_mode=2, aq_strength=1.5), 8, dict(seed=15, scene_cuts=(22,)), 40),
+    ("fast", "aq-mode=3,aq-strength=0.5,qcomp=0.4", dict(aq_mode=3, aq_strength=0.5, qcompress=0.4), 10,
+     dict(seed=24, scene_cuts=(30,), pan=(2, 3), fade=(10, 10, 0.6, 15)), 44),
+    # lookahead threads: two bands searched independently (slicetype.c:668, :917-918)
+    ("medium", "threads=4,sync-lookahead=0,lookahead-threads=2", dict(threads=4, lookahead_threads=2), 8,
+     dict(seed=16, pan=(23, 11), noise=30, texture=0.9, scene_cuts=(20,)), 40),
+    # more B-frames than the key-frame interval allows (encoder.c:1074)
+    ("medium", "bframes=16,keyint=8,rc-lookahead=5", dict(bframes=16, keyint_max=8, rc_lookahead=5), 8, dict(seed=17), 40),
 ]
 
 
@@ -47,17 +68,19 @@ def test_lookahead_matches_reference(preset, opts, over, depth, ckw, nf):
     try:
         ref = r.lookahead_run(frames, with_qp_offsets=True)
         rc = r.cfg
+        rc["weighted_bipred"] = int(bool(rc["weighted_bipred"]))
         cfg = lib.la_config(W, H, preset, bit_depth=depth, **over)
         # the derived configuration must be what the reference validated
         for k, rk in (("bframes", "bframes"), ("b_adapt", "b_adapt"), ("rc_lookahead", "rc_lookahead"), ("mv_range", "mv_range"),
                       ("me_range", "me_range"), ("la_me_method", "me_method"), ("la_subpel_refine", "subpel_refine"),
                       ("subme", "subme"), ("weightp", "weightp"), ("mb_tree", "mb_tree"), ("keyint_max", "keyint_max"),
                       ("keyint_min", "keyint_min"), ("b_pyramid", "b_pyramid"), ("mbcmp_satd", "mbcmp_satd"),
-                      ("fpelcmp_satd", "fpelcmp_satd"), ("frame_refs", "refs"), ("open_gop", "open_gop")):
+                      ("fpelcmp_satd", "fpelcmp_satd"), ("frame_refs", "refs"), ("open_gop", "open_gop"), ("aq_mode", "aq_mode"),
+                      ("psy", "psy"), ("weighted_bipred", "weighted_bipred"), ("bframe_bias", "b_bias")):
             assert cfg[k] == rc[rk], (k, cfg[k], rc[rk])
         be = OracleBackend(cfg)
         la = lib.Lookahead(cfg, backend=be.struct)
-        assert la.delay == rc["delay"]
+        assert la.delay == rc["delay"] - (cfg["threads"] - 1)  # frame threads add their own latency (encoder.c:1610)
         try:
             outs = la.run(frames, qp_offsets=True)
         finally:
@@ -78,7 +101,7 @@ def test_lookahead_matches_reference(preset, opts, over, depth, ckw, nf):
         m = rce >= 0
         assert np.array_equal(ca[m], ref["cost_aq"][k][:nb, :nb][m]), ("i_cost_est_aq", k, o.frame)
         assert np.array_equal(o.qp_offset, ref["qp_offset"][k]), ("f_qp_offset", k, o.frame, o.type)
-    assert be.n_eval > nf
+    assert be.n_eval > (0 if cfg["rc_is_cqp"] else nf)  # constant QP: only the intra cells of weighted P candidates
 
 
 @pytest.mark.parametrize("paced", [True, False])
@@ -153,3 +176,46 @@ def test_chunked_submission_of_a_long_queue():
     newest = [max(c) for c in calls]
     assert len(calls) >= 3 and newest == sorted(newest) and newest[-1] == nf - 1
     assert len(set(newest)) == len(newest), "a submission that added no frame"
+
+
+PRESET_NAMES = ("ultrafast", "superfast", "veryfast", "faster", "fast", "medium", "slow", "slower", "veryslow", "placebo")
+TUNE_NAMES = ("", "film", "animation", "grain", "stillimage", "psnr", "ssim", "fastdecode", "zerolatency", "touhou")
+_CFG_KEYS = (("bframes", "bframes"), ("b_adapt", "b_adapt"), ("rc_lookahead", "rc_lookahead"), ("keyint_max", "keyint_max"),
+             ("keyint_min", "keyint_min"), ("b_pyramid", "b_pyramid"), ("weightp", "weightp"), ("open_gop", "open_gop"),
+             ("aq_mode", "aq_mode"), ("mb_tree", "mb_tree"), ("psy", "psy"), ("la_me_method", "me_method"),
+             ("la_subpel_refine", "subpel_refine"), ("mbcmp_satd", "mbcmp_satd"), ("fpelcmp_satd", "fpelcmp_satd"),
+             ("mv_range", "mv_range"), ("me_range", "me_range"), ("frame_refs", "refs"), ("scenecut", "scenecut"))
+
+
+@pytest.mark.parametrize("preset", PRESET_NAMES)
+def test_every_preset_and_tune(preset):
+    """x264_param_default_preset / x264_param_apply_tune (common/base.c:496-700) + validate_parameters for every preset x tune:
+    the derived configuration, the delay, the decisions, the cost cells and the quantiser offset maps of a short clip."""
+    W, H, nf = 176, 144, 36
+    frames = make_clip(W, H, nf, seed=5, scene_cuts=(17,), fade=(22, 8, 0.6, 8))
+    for tune in TUNE_NAMES:
+        r = refharness.Ref(W, H, preset, tune=tune)
+        try:
+            ref = r.lookahead_run(frames, with_qp_offsets=True)
+            rc = r.cfg
+        finally:
+            r.close()
+        cfg = lib.la_config(W, H, preset, tune=tune)
+        for k, rk in _CFG_KEYS:
+            assert cfg[k] == rc[rk], (preset, tune, k, cfg[k], rc[rk])
+        assert bool(cfg["weighted_bipred"]) == bool(rc["weighted_bipred"])
+        assert abs(cfg["aq_strength"] * 65536 - rc["aq_strength_q16"]) <= 1
+        be = OracleBackend(cfg)
+        la = lib.Lookahead(cfg, backend=be.struct, max_frames=nf + 4)
+        try:
+            assert la.delay == rc["delay"], (preset, tune)
+            outs = la.run(frames, qp_offsets=True)
+        finally:
+            la.close()
+        assert [o.frame for o in outs] == list(ref["idx"]), (preset, tune)
+        assert [o.type for o in outs] == list(ref["type"]), (preset, tune)
+        nb = cfg["bframes"] + 2
+        for k, o in enumerate(outs):
+            ce = np.array([[o.cost_est[i][j] for j in range(nb)] for i in range(nb)])
+            assert np.array_equal(ce, ref["cost"][k][:nb, :nb]), (preset, tune, "i_cost_est", o.frame)
+            assert np.array_equal(o.qp_offset, ref["qp_offset"][k]), (preset, tune, "f_qp_offset", o.frame)

@@ -23,8 +23,16 @@ struct LaP
     int mbcmp_satd, fpelcmp_satd, weighted_bipred, aq_mode;
     int depth_shift;  // BIT_DEPTH - 8
     int pixel_max;
+    int no_edges;     // slicetype.c:823 do_edges == 0: the outermost ring of blocks is never evaluated (no MB-tree, no VBV)
+    int n_slices;     // param.i_lookahead_threads: bands whose searches do not see each other's vectors (slicetype.c:668,917-918)
     const uint16_t *cost_mv; // centred device table
 };
+
+// a block slicetype_slice_cost visits (slicetype.c:825-833)
+__device__ __forceinline__ bool la_visited( const LaP &P, int bx, int by )
+{
+    return !P.no_edges || ( bx > 0 && bx < P.mb_w - 1 && by > 0 && by < P.mb_h - 1 );
+}
 
 struct WtD
 {

@@ -102,7 +102,7 @@ __global__ __launch_bounds__( 256 ) void lowres_core_kernel( const T *__restrict
     dc[y * dst_stride + x] = (T)( ( u1 + u2 + 1 ) >> 1 );
 }
 
-// ---- adaptive-quant statistics (encoder/ratecontrol.c:225-415, aq-mode 0/1) ----------------------------
+// ---- adaptive-quant statistics (encoder/ratecontrol.c:225-415, aq-mode 0..3) ---------------------------
 // One wave per 16x16 macroblock: luma sum / sum of squares (+ optional 8x8 chroma), energy -> Q8 inverse
 // qscale through the reference's log2 / exp2 look-up tables; frame totals accumulate with 64-bit atomics.
 struct AqLuts
@@ -121,7 +121,7 @@ __device__ __forceinline__ unsigned wave_sum_u32( unsigned v )
 
 template <typename T>
 __global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc single, int width, int height, int mb_w,
-                                                   float strength, float log2_bias, const AqLuts *luts )
+                                                   float strength, float log2_bias, const AqLuts *luts, int aq_mode, float depth_corr )
 {
     const PutDesc D = descs ? descs[blockIdx.z] : single;
     const T *__restrict__ luma = (const T *)D.src, *__restrict__ cb = (const T *)D.cb, *__restrict__ cr = (const T *)D.cr;
@@ -158,6 +158,21 @@ __global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc
         mb_sums[my * mb_w + mx] = make_uint2( s, q );
         int out = 256;
         float qp_adj = 0.f;
+        if( aq_on && aq_mode >= 2 )
+        {
+            // first pass of the auto-variance modes (ratecontrol.c:354-371) in the reference build's arithmetic (gcc -O3
+            // -ffast-math): powf( x, 0.125f ) is three correctly rounded square roots, and the "qp_adj * qp_adj" that is
+            // averaged is the intermediate fourth root.  aq_auto_kernel turns the two roots into the final values.
+            float x = __uint2float_rn( energy );
+            if( depth_corr != 1.f )
+                x = __fmul_rn( x, depth_corr );
+            x = __fadd_rn( x, 1.f );
+            const float r4 = sqrtf( sqrtf( x ) );
+            qp_offset_aq[my * mb_w + mx] = r4;
+            qp_offset[my * mb_w + mx] = sqrtf( r4 ); // sqrtf: correctly rounded (the __fsqrt_rn intrinsic is the 1-ulp native one)
+            inv_qscale[my * mb_w + mx] = 256;
+            return;
+        }
         if( aq_on )
         {
             unsigned e = energy > 1 ? energy : 1;
@@ -171,6 +186,58 @@ __global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc
         inv_qscale[my * mb_w + mx] = (uint16_t)out;
         qp_offset_aq[my * mb_w + mx] = qp_adj; // f_qp_offset_aq = f_qp_offset = qp_adj (ratecontrol.c:392-396)
         qp_offset[my * mb_w + mx] = qp_adj;
+    }
+}
+
+// Second pass of aq-mode 2 / 3 (ratecontrol.c:372-398) for one frame per workgroup.  The two averages are SEQUENTIAL
+// FP32 sums in raster order in the reference (the rounding of every step counts), so one thread adds them, out of LDS
+// tiles the whole workgroup stages; everything after the averages is per macroblock and runs on all threads.
+#define AQ_AUTO_TILE 4096
+__global__ __launch_bounds__( 1024 ) void aq_auto_kernel( const PutDesc *descs, PutDesc single, int n_mb, int aq_mode, float aq_strength,
+                                                          const AqLuts *luts )
+{
+    const PutDesc D = descs ? descs[blockIdx.x] : single;
+    if( !D.aq_on )
+        return;
+    __shared__ float t4[AQ_AUTO_TILE], t8[AQ_AUTO_TILE];
+    __shared__ float par[2];
+    float s4 = 0.f, s8 = 0.f;
+    for( int base = 0; base < n_mb; base += AQ_AUTO_TILE )
+    {
+        const int cnt = imin2( AQ_AUTO_TILE, n_mb - base );
+        for( int i = threadIdx.x; i < cnt; i += blockDim.x )
+        {
+            t4[i] = D.qp_aq[base + i];
+            t8[i] = D.qp[base + i];
+        }
+        __syncthreads();
+        if( threadIdx.x == 0 )
+            for( int i = 0; i < cnt; i++ )
+            {
+                s4 = __fadd_rn( s4, t4[i] );
+                s8 = __fadd_rn( s8, t8[i] );
+            }
+        __syncthreads();
+    }
+    if( threadIdx.x == 0 )
+    {
+        const float cnt = (float)n_mb;
+        const float avg_pow2 = __fdiv_rn( s4, cnt ), avg = __fdiv_rn( s8, cnt );
+        par[0] = __fmul_rn( aq_strength, avg );                                                                 // strength
+        par[1] = __fadd_rn( __fdiv_rn( __fmul_rn( __fsub_rn( 14.f, avg_pow2 ), 0.5f ), avg ), avg );            // avg_adj
+    }
+    __syncthreads();
+    const float str = par[0], avg_adj = par[1];
+    for( int i = threadIdx.x; i < n_mb; i += blockDim.x )
+    {
+        const float q = D.qp[i];
+        float qp_adj = __fmul_rn( __fsub_rn( q, avg_adj ), str );
+        if( aq_mode == 3 )
+            qp_adj = __fadd_rn( __fmul_rn( __fsub_rn( 1.f, __fdiv_rn( 14.f, __fmul_rn( q, q ) ) ), aq_strength ), qp_adj );
+        const int k = (int)__fadd_rn( __fmul_rn( qp_adj, -64.f / 6.f ), 512.5f );
+        D.inv_qscale[i] = (uint16_t)( k < 0 ? 0 : k > 1023 ? 0xffff : ( ( luts->exp2_lut[k & 63] + 256 ) << ( k >> 6 ) >> 8 ) );
+        D.qp_aq[i] = qp_adj;
+        D.qp[i] = qp_adj;
     }
 }
 
@@ -385,7 +452,8 @@ __global__ __launch_bounds__( 256 ) void weight_cost_kernel( LaP P, const Weight
         const Px4 f = load_px4( fenc0 + off );
         const Px4 r = load_px4( ref0 + off );
         // the intra costs as the reference reads them here: after the 14-bit clamp of the [0][0] map (slicetype.c:712)
-        const int icost = imin2( (int)J.intra_cost[xyc], 0x3FFF );
+        // (a block the evaluations never visit keeps the 0xFFFF of its allocation, frame.c:288-289)
+        const int icost = la_visited( P, bx, by ) ? imin2( (int)J.intra_cost[xyc], 0x3FFF ) : 0xFFFF;
         // one pass over the pixels serves both sums of a pair
 #pragma unroll
         for( int z = 0; z < 2; z++ )
@@ -465,6 +533,8 @@ __global__ __launch_bounds__( 1024 ) void cell_reduce_kernel( LaP P, const CellA
         for( int bx = lane; bx < W; bx += 64 )
         {
             const int xy = by * W + bx;
+            if( !la_visited( P, bx, by ) )
+                continue; // contributes to no sum (slicetype.c:825-833)
             const bool scored = ( bx > 0 && bx < W - 1 && by > 0 && by < H - 1 ) || W <= 2 || H <= 2;
             const int inv = P.aq_mode ? A.inv_qscale[xy] : 256;
             const int w = A.sums_only ? 0 : A.blk[xy];

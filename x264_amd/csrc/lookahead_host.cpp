@@ -731,6 +731,19 @@ struct Lookahead
             p0 = is_i( next[bframes]->i_type ) ? bframes + 1 : 0;
             frame_cost( frames, p0, p1, b );
         }
+        // The main-encode weight analysis of a P frame (:1937-1943, b_lookahead = 0) works on the full-resolution planes and
+        // stays with the encoder, but its first step is visible in the lookahead's own outputs: when the luma statistics
+        // call for a weight test it computes the frame's lowres intra costs if they are still missing (:365-370), which
+        // fills i_cost_est[0][0] / i_cost_est_aq[0][0] of P frames no analysis has looked at yet.
+        if( p.weightp >= 1 && next[bframes]->i_type == T_P && last_nonb && !next[bframes]->intra_calculated )
+        {
+            x264hip_weight guess, cand;
+            if( weight_candidate( next[bframes], last_nonb, guess, cand ) )
+            {
+                LaFrame *one[1] = { next[bframes] };
+                frame_cost( one, 0, 0, 0 );
+            }
+        }
         // coded order (:1945-1960)
         if( bframes )
         {
@@ -900,6 +913,7 @@ extern "C" int x264hip_lookahead_open( x264hip_lookahead **out, int device, cons
     if( !out || !params ) return X264HIP_EINVAL;
     x264hip_la_params p = *params;
     if( p.dev.max_frames <= 0 ) p.dev.max_frames = slots_needed( &p );
+    p.dev.no_edges = !p.mb_tree; // slicetype.c:823 (no VBV here): the evaluations visit the edge blocks only for MB-tree
     x264hip_ctx *ctx = nullptr;
     int rc = x264hip_open( &ctx, device, &p.dev );
     if( rc ) return rc;
@@ -1044,7 +1058,7 @@ extern "C" int x264hip_lookahead_get_frame_ex( x264hip_lookahead *la, int flush,
         out->intra_mbs[i] = f->intra_mbs[i];
     }
     *got = 1;
-    if( qp_offset && L.be.get_qp_offsets && L.p.mb_tree )
+    if( qp_offset && L.be.get_qp_offsets && ( L.p.mb_tree || L.p.dev.aq_mode ) ) // the arrays exist with AQ on (frame.c:217-226)
         if( L.need( L.be.get_qp_offsets( L.be.user, f->slot, qp_offset ) ) )
             return L.err;
     L.release( f );

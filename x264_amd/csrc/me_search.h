@@ -432,13 +432,39 @@ __global__ __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 8, 8 ) 
     B.fmin_y = B.smin_y >> 2;
     B.fmax_y = B.smax_y >> 2;
 
+    // Hb: end row of the band this row belongs to (slicetype.c:917-918); rows of one band do not see the vectors of the
+    // band below (slicetype.c:668).  One band: Hb == H.
+    int Hb = H;
+    for( int sl = P.n_slices - 1; sl >= 1; sl-- )
+    {
+        const int start = ( H * sl + P.n_slices / 2 ) / P.n_slices;
+        if( by < start )
+            Hb = start;
+    }
+    // blocks slicetype_slice_cost never visits (slicetype.c:823-833): their vectors stay zero (frame.c:283-285) and are
+    // marked ready at once, nothing reads their costs
+    const int e = P.no_edges;
+    if( e )
+    {
+        const unsigned long long unvisited = (unsigned long long)D.tag << 32;
+        const bool whole_row = by == 0 || by == H - 1;
+        for( int bx = lane; bx < W; bx += 64 )
+            if( whole_row || bx == 0 || bx == W - 1 )
+            {
+                __hip_atomic_store( D.mvq + by * W + bx, unvisited, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+                D.costs[by * W + bx] = 0;
+            }
+        if( whole_row )
+            return;
+    }
+
     int right_x = 0, right_y = 0;
-    for( int bx = W - 1; bx >= 0; bx-- )
+    for( int bx = W - 1 - e; bx >= e; bx-- )
     {
         const int xy = by * W + bx;
         B.lane_off = border + 8 * ( by * P.stride + bx ) + row_off;
         int nbx[3] = { 0, 0, 0 }, nby[3] = { 0, 0, 0 }; // below, below-left, below-right
-        if( by < H - 1 )
+        if( by < Hb - 1 )
         {
             unsigned long long gq = 0;
             const int nb = lane == 1 ? ( bx > 0 ? -1 : 0 ) : lane == 2 ? ( bx < W - 1 ? 1 : 0 ) : 0;
@@ -474,7 +500,7 @@ __global__ __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 8, 8 ) 
         // predictor list in the reference's order: right, below, below-left, below-right
         int mvcx[4] = { 0, 0, 0, 0 }, mvcy[4] = { 0, 0, 0, 0 }, n = 0;
         if( bx < W - 1 ) { mvcx[n] = right_x; mvcy[n] = right_y; n++; }
-        if( by < H - 1 )
+        if( by < Hb - 1 )
         {
             mvcx[n] = nbx[0]; mvcy[n] = nby[0]; n++;
             if( bx > 0 ) { mvcx[n] = nbx[1]; mvcy[n] = nby[1]; n++; }

@@ -248,7 +248,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     const x264hip_params &p = *params;
     if( ( p.bit_depth != 8 && p.bit_depth != 10 ) || p.width < 16 || p.height < 16 || p.bframes < 0 || p.bframes > X264HIP_BFRAME_MAX ||
         !p.cost_mv || p.mv_range < 1 || ( p.subpel_refine != 2 && p.subpel_refine != 4 ) || p.max_frames < 2 ||
-        ( p.me_method != X264HIP_ME_DIA && p.me_method != X264HIP_ME_HEX ) || ( p.aq_mode != 0 && p.aq_mode != 1 ) )
+        ( p.me_method != X264HIP_ME_DIA && p.me_method != X264HIP_ME_HEX ) || p.aq_mode < 0 || p.aq_mode > 3 ||
+        p.lookahead_slices < 0 || p.lookahead_slices > X264HIP_LOOKAHEAD_SLICES_MAX )
         return X264HIP_EINVAL;
     int ndev = 0;
     if( hipGetDeviceCount( &ndev ) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev )
@@ -285,6 +286,9 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     P.mv_range = p.mv_range; P.subme = p.subme; P.mbcmp_satd = p.mbcmp_satd; P.fpelcmp_satd = p.fpelcmp_satd;
     P.weighted_bipred = p.weighted_bipred; P.aq_mode = p.aq_mode; P.depth_shift = p.bit_depth - 8;
     P.pixel_max = ( 1 << p.bit_depth ) - 1;
+    // frames of at most two blocks in a direction are always evaluated whole (slicetype.c:823)
+    P.no_edges = p.no_edges && P.mb_w > 2 && P.mb_h > 2;
+    P.n_slices = std::max( 1, p.lookahead_slices );
 
 #define OPENCK( call ) do { if( ( call ) != hipSuccess ) { fprintf( stderr, "x264hip_open: %s failed\n", #call ); free_all( ctx ); delete ctx; return X264HIP_ENOMEM; } } while( 0 )
     OPENCK( hipStreamCreateWithFlags( &ctx->stream, hipStreamNonBlocking ) );
@@ -433,7 +437,10 @@ static int launch_ingest_t( x264hip_ctx *ctx, const PutDesc *descs_dev, const Pu
     const float bias = 14.427f + 2 * ( p.bit_depth - 8 );
     dim3 grd( ( ( ctx->lw + 2 * LA_PAD ) / 4 + 255 ) / 256, ctx->lh + 2 * LA_PAD, n );
     lowres_kernel<T><<<grd, 256, 0, ctx->stream>>>( descs_dev, single, p.width, p.height, P.plane_elems, P.stride, ctx->lw, ctx->lh );
-    aq_kernel<T><<<dim3( P.mb_w, P.mb_h, n ), 64, 0, ctx->stream>>>( descs_dev, single, p.width, p.height, P.mb_w, strength, bias, ctx->luts_dev );
+    aq_kernel<T><<<dim3( P.mb_w, P.mb_h, n ), 64, 0, ctx->stream>>>( descs_dev, single, p.width, p.height, P.mb_w, strength, bias, ctx->luts_dev,
+                                                                       p.aq_mode, 1.f / ( 1 << ( 2 * ( p.bit_depth - 8 ) ) ) );
+    if( p.aq_mode >= 2 && p.aq_strength != 0.f )
+        aq_auto_kernel<<<n, 1024, 0, ctx->stream>>>( descs_dev, single, ctx->n_mb, p.aq_mode, p.aq_strength, ctx->luts_dev );
     aq_reduce_kernel<<<n, 1024, 0, ctx->stream>>>( descs_dev, single, ctx->n_mb );
     intra_kernel<T><<<dim3( P.mb_w, P.mb_h, n ), 64, 0, ctx->stream>>>( P, descs_dev, single );
     HIPCK( hipGetLastError() );
@@ -478,7 +485,7 @@ extern "C" int x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, 
         src = s.luma;
         src_stride = p.width;
     }
-    const int aq_on = p.aq_mode == 1 && p.aq_strength != 0.f && !inv_qscale;
+    const int aq_on = p.aq_mode >= 1 && p.aq_strength != 0.f && !inv_qscale;
     // chroma planes take part in the AQ energy only when the caller supplies device pointers for them
     const PutDesc d = make_put_desc( ctx, s, src, src_stride, is_device ? cb : nullptr, is_device ? cr : nullptr, cstride, aq_on );
     int rc = p.bit_depth == 8 ? launch_ingest_t<uint8_t>( ctx, nullptr, d, 1 ) : launch_ingest_t<uint16_t>( ctx, nullptr, d, 1 );
@@ -497,7 +504,7 @@ extern "C" int x264hip_frame_put_batch( x264hip_ctx *ctx, int n, const int *slot
     if( ctx->mbt_pending )
         HIPCK( hipStreamWaitEvent( ctx->stream, ctx->ev_mbt_last, 0 ) );
     const x264hip_params &p = ctx->p;
-    const int aq_on = p.aq_mode == 1 && p.aq_strength != 0.f;
+    const int aq_on = p.aq_mode >= 1 && p.aq_strength != 0.f;
     for( int o = 0; o < n; o += ctx->put_desc_cap )
     {
         const int m = std::min( n - o, ctx->put_desc_cap );

@@ -21,7 +21,7 @@ class Params(C.Structure):
                 ("me_method", C.c_int), ("subpel_refine", C.c_int), ("me_range", C.c_int), ("mv_range", C.c_int),
                 ("subme", C.c_int), ("mbcmp_satd", C.c_int), ("fpelcmp_satd", C.c_int), ("weighted_bipred", C.c_int),
                 ("aq_mode", C.c_int), ("aq_strength", C.c_float), ("bframe_bias", C.c_int), ("max_frames", C.c_int),
-                ("cost_mv", C.c_void_p)]
+                ("no_edges", C.c_int), ("lookahead_slices", C.c_int), ("cost_mv", C.c_void_p)]
 
 
 class Weight(C.Structure):
@@ -94,7 +94,7 @@ class Context:
 
     def __init__(self, width, height, *, bit_depth=8, bframes=3, lam=None, me_method=1, subpel_refine=4, me_range=16,
                  mv_range=512, subme=7, mbcmp_satd=1, fpelcmp_satd=0, weighted_bipred=1, aq_mode=1, aq_strength=1.0,
-                 bframe_bias=0, max_frames=64, cost_mv=None, device=0):
+                 bframe_bias=0, max_frames=64, cost_mv=None, device=0, no_edges=0, lookahead_slices=1):
         L = load()
         lam = lam if lam is not None else (1 if bit_depth == 8 else 4)
         if cost_mv is None:
@@ -105,7 +105,7 @@ class Context:
         self._cost_mv = cost_mv
         self.params = Params(bit_depth, width, height, bframes, lam, me_method, subpel_refine, me_range, mv_range, subme,
                              mbcmp_satd, fpelcmp_satd, weighted_bipred, aq_mode, aq_strength, bframe_bias, max_frames,
-                             cost_mv.ctypes.data + 2 * centre)
+                             no_edges, lookahead_slices, cost_mv.ctypes.data + 2 * centre)
         self.h = C.c_void_p()
         _ck(L.x264hip_open(C.byref(self.h), device, C.byref(self.params)), "x264hip_open")
         self.L = L
@@ -304,6 +304,21 @@ PRESETS = {
     "fast": dict(subme=6, rc_lookahead=30, weightp=1, frame_refs=2),
     "faster": dict(subme=4, rc_lookahead=20, weightp=1, frame_refs=2),
     "veryfast": dict(subme=2, rc_lookahead=10, weightp=1, frame_refs=1),
+    "superfast": dict(me="dia", subme=1, rc_lookahead=0, mb_tree=0, weightp=1, frame_refs=1),
+    "ultrafast": dict(me="dia", subme=0, rc_lookahead=0, mb_tree=0, weightp=0, frame_refs=1, scenecut=0, bframes=0, b_adapt=0,
+                      aq_mode=0, weighted_bipred=0),
+    "placebo": dict(subme=11, rc_lookahead=60, b_adapt=2, me="tesa", me_range=24, bframes=16, frame_refs=16),
+}
+# x264_param_apply_tune (common/base.c:606-700), the fields the lookahead reads; applied after the preset, before overrides
+TUNES = {
+    "": {}, "film": {}, "touhou": dict(_refs_x2=1, aq_strength=1.3),
+    "animation": dict(_refs_x2=1, aq_strength=0.6, _bframes_add=2),
+    "grain": dict(aq_strength=0.5, qcompress=0.8),
+    "stillimage": dict(aq_strength=1.2),
+    "psnr": dict(aq_mode=0, psy=0),
+    "ssim": dict(aq_mode=2, psy=0),
+    "fastdecode": dict(weighted_bipred=0, weightp=0),
+    "zerolatency": dict(rc_lookahead=0, bframes=0, mb_tree=0),
 }
 _ME = {"dia": 0, "hex": 1, "umh": 2, "esa": 3, "tesa": 4}
 
@@ -323,21 +338,90 @@ def mv_range_for(width, height, fps=25.0):
     return 512
 
 
-def la_config(width, height, preset="medium", bit_depth=8, **over):
+def la_config(width, height, preset="medium", bit_depth=8, tune="", **over):
     """Effective lookahead configuration for an x264 preset (+ overrides), as validate_parameters and
     lowres_context_init derive it (encoder/encoder.c:423-1407, encoder/slicetype.c:45-61)."""
     c = dict(bframes=3, b_adapt=1, b_pyramid=2, rc_lookahead=40, me="hex", me_range=16, subme=7, weightp=2,
              weighted_bipred=1, mb_tree=1, aq_mode=1, aq_strength=1.0, scenecut=40, keyint_max=250, keyint_min=0,
              open_gop=0, frame_refs=3, psy=1, rc_is_cqp=0, bframe_bias=0, fps=25.0, mv_range=0, fps_num=25, fps_den=1,
-             qcompress=0.6)
+             qcompress=0.6, threads=1, lookahead_threads=0)
     c.update(PRESETS[preset])
+    for t in filter(None, tune.replace(",", " ").split()):
+        tv = dict(TUNES[t])
+        if tv.pop("_refs_x2", 0) and c["frame_refs"] > 1:
+            c["frame_refs"] *= 2
+        c["bframes"] += tv.pop("_bframes_add", 0)
+        c.update(tv)
     c.update(over)
-    if c["keyint_min"] <= 0:
+    clip = lambda v, lo, hi: lo if v < lo else hi if v > hi else v  # noqa: E731
+    # the order below is validate_parameters' own (encoder/encoder.c, line numbers in the comments)
+    c["keyint_max"] = clip(c["keyint_max"], 1, 1 << 30)                      # :611 (1<<30 = X264_KEYINT_MAX_INFINITE)
+    if c["keyint_max"] == 1:                                                 # :612-618
+        c["weightp"] = 0
+        c["frame_refs"] = 1
+    c["subme"] = clip(c["subme"], 0, 11)                                     # :922
+    if c["rc_is_cqp"]:                                                       # :951-966
+        c["aq_mode"] = 0
+        c["mb_tree"] = 0
+    c["frame_refs"] = clip(c["frame_refs"], 1, 16)                           # :1064
+    c["scenecut"] = max(c["scenecut"], 0)                                    # :1066-1067
+    c["bframes"] = clip(c["bframes"], 0, min(16, c["keyint_max"] - 1))       # :1074
+    c["bframe_bias"] = clip(c["bframe_bias"], -90, 100)                      # :1075
+    if c["bframes"] <= 1:                                                    # :1076-1077
+        c["b_pyramid"] = 0
+    c["b_pyramid"] = clip(c["b_pyramid"], 0, 2)
+    c["b_adapt"] = clip(c["b_adapt"], 0, 2)
+    if not c["bframes"]:                                                     # :1080-1086
+        c["b_adapt"] = 0
+        c["weighted_bipred"] = 0
+        c["open_gop"] = 0
+    if c["keyint_min"] <= 0:                                                 # :1109-1111 (0 = X264_KEYINT_MIN_AUTO)
         c["keyint_min"] = min(c["keyint_max"] // 10, int(c["fps"]))
-    c["keyint_min"] = max(1, min(c["keyint_min"], c["keyint_max"] // 2 + 1))
-    if c["mv_range"] <= 0:
+    c["keyint_min"] = clip(c["keyint_min"], 1, c["keyint_max"] // 2 + 1)
+    c["rc_lookahead"] = min(clip(c["rc_lookahead"], 0, 250), c["keyint_max"])  # :1112-1117, no VBV
+    c["qcompress"] = clip(c["qcompress"], 0.0, 1.0)                          # :1125
+    if c["keyint_max"] == 1 or c["qcompress"] == 1:                          # :1126-1127
+        c["mb_tree"] = 0
+    if c["keyint_max"] != 1 << 30 and not c["rc_lookahead"] and c["mb_tree"]:  # :1128-1133 (no intra refresh)
+        c["mb_tree"] = 0
+    me = _ME.get(c["me"], 1)                                                 # :1156-1164
+    c["me_range"] = clip(c["me_range"], 4, 1024)
+    if c["me_range"] > 16 and me <= 1:
+        c["me_range"] = 16
+    if me == 4 and c["subme"] <= 1:
+        me = 3
+    c["aq_mode"] = clip(c["aq_mode"], 0, 3)                                  # :1177-1180
+    c["aq_strength"] = clip(float(c["aq_strength"]), 0.0, 3.0)
+    if c["aq_strength"] == 0:
+        c["aq_mode"] = 0
+    if not c["aq_mode"] and c["mb_tree"]:                                    # :1233-1237: MB-tree needs the AQ arrays
+        c["aq_mode"] = 1
+        c["aq_strength"] = 0.0
+    if c["mv_range"] <= 0:                                                   # :1265-1268
         c["mv_range"] = mv_range_for(width, height, c["fps"])
-    me = _ME[c["me"]]
+    else:
+        c["mv_range"] = clip(c["mv_range"], 32, 8192)
+    c["weightp"] = clip(c["weightp"], 0, 2)                                  # :1271
+    if not c["weightp"] and c["mb_tree"] and c["psy"]:
+        c["weightp"] = -1  # X264_WEIGHTP_FAKE (:1316-1317): the lookahead still analyses and applies weights
+    c["psy"] = int(bool(c["psy"]))
+    c["mb_tree"] = int(bool(c["mb_tree"]))
+    # lookahead bands (:567-583, :1273-1300)
+    mb_h = (height + 15) // 16
+    max_sliced = max(1, mb_h // 4)
+    c["threads"] = clip(c["threads"], 1, 128)
+    if c["threads"] == 1:
+        c["lookahead_threads"] = 1
+    elif c["lookahead_threads"] <= 0:  # X264_THREADS_AUTO, frame threads
+        div = [[[6, 6, 6, 6], [3, 3, 3, 3], [4, 4, 4, 4], [6, 6, 6, 6], [12, 12, 12, 12]],
+               [[3, 2, 1, 1], [2, 1, 1, 1], [4, 3, 2, 1], [6, 4, 3, 2], [12, 9, 6, 4]]]
+        q_subme = min(c["subme"] // 3, 3) + int(c["subme"] > 1)
+        q_b = min(int((c["bframes"] - 1) / 3), 3)  # C division truncates toward zero
+        c["lookahead_threads"] = min(c["threads"] // div[int(c["b_adapt"] == 2)][q_subme][q_b], height // 128)
+    c["lookahead_threads"] = clip(c["lookahead_threads"], 1, min(max_sliced, 16))
+    # slicetype.c:823 (no VBV): whether the evaluations visit the outermost ring of blocks
+    c["do_edges"] = int(c["mb_tree"] or (width + 15) // 16 <= 2 or mb_h <= 2)
+    # lowres_context_init (slicetype.c:45-61) and mbcmp_init (encoder.c:1409-1427)
     if c["subme"] > 1:
         c["la_me_method"] = min(1, me)
         c["la_subpel_refine"] = 4
@@ -346,18 +430,6 @@ def la_config(width, height, preset="medium", bit_depth=8, **over):
         c["la_subpel_refine"] = 2
     c["mbcmp_satd"] = int(c["subme"] > 1)
     c["fpelcmp_satd"] = int(me == 4 and c["subme"] > 1)
-    if not c["bframes"]:
-        # encoder.c:1080-1086: no B-frames also switches off adaptive placement, weighted bi-prediction and open GOPs
-        c["b_adapt"] = 0
-        c["b_pyramid"] = 0
-        c["weighted_bipred"] = 0
-        c["open_gop"] = 0
-    if c["bframes"] <= 1:
-        c["b_pyramid"] = 0
-    if not c["weightp"] and c["mb_tree"] and c["psy"]:
-        c["weightp"] = -1  # X264_WEIGHTP_FAKE (encoder.c:1316-1317): the lookahead still analyses and applies weights
-    c["rc_lookahead"] = min(c["rc_lookahead"], 250)
-    c["rc_lookahead"] = min(c["rc_lookahead"], max(c["keyint_max"], c["bframes"] + 1))
     c["width"], c["height"], c["bit_depth"] = width, height, bit_depth
     c["lam"] = 1 if bit_depth == 8 else 4
     return c
@@ -372,7 +444,7 @@ def make_la_params(cfg, cost_mv=None, max_frames=0):
     dev = Params(cfg["bit_depth"], cfg["width"], cfg["height"], cfg["bframes"], cfg["lam"], cfg["la_me_method"],
                  cfg["la_subpel_refine"], cfg["me_range"], cfg["mv_range"], cfg["subme"], cfg["mbcmp_satd"],
                  cfg["fpelcmp_satd"], cfg["weighted_bipred"], cfg["aq_mode"], cfg["aq_strength"], cfg["bframe_bias"],
-                 max_frames, cost_mv.ctypes.data + 2 * centre)
+                 max_frames, int(not cfg["do_edges"]), cfg["lookahead_threads"], cost_mv.ctypes.data + 2 * centre)
     p = LaParams(dev, cfg["keyint_max"], cfg["keyint_min"], cfg["scenecut"], cfg["b_adapt"], cfg["b_pyramid"],
                  cfg["rc_lookahead"], cfg["mb_tree"], cfg["weightp"], cfg["open_gop"], cfg["frame_refs"], cfg["psy"],
                  cfg["rc_is_cqp"], cfg["fps_num"], cfg["fps_den"], cfg["qcompress"])
