@@ -134,6 +134,8 @@ RH_API void rh_get_config( rh_ctx *c, int *out )
     out[29] = h->frames.i_bframe_delay;
     out[30] = h->param.i_frame_reference;
     out[31] = (int)(h->param.rc.f_aq_strength * 65536.f);
+    out[32] = h->param.i_lookahead_threads;
+    out[33] = h->param.i_threads;
 }
 
 /* cost_mv table of the lookahead qp, centred: out[i + n] for i in [-n, n], n = 2*4*mv_range */

@@ -36,13 +36,13 @@ class Ref:
         if not self.ctx:
             raise RuntimeError("rh_open failed")
         self.ctx = C.c_void_p(self.ctx)
-        cfg = np.zeros(32, np.int32)
+        cfg = np.zeros(40, np.int32)
         L.rh_get_config(self.ctx, _ptr(cfg))
         names = ["mb_w", "mb_h", "bframes", "b_adapt", "rc_lookahead", "mv_range", "me_range", "me_method",
                  "subpel_refine", "lambda", "weightp", "weighted_bipred", "aq_mode", "mb_tree", "scenecut",
                  "keyint_max", "keyint_min", "b_pyramid", "b_bias", "delay", "slicetype_length", "vbv",
                  "open_gop", "intra_refresh", "subme", "mbcmp_satd", "fpelcmp_satd", "psy", "rc_method",
-                 "bframe_delay", "refs", "aq_strength_q16"]
+                 "bframe_delay", "refs", "aq_strength_q16", "lookahead_threads", "threads"]
         self.cfg = {k: int(v) for k, v in zip(names, cfg)}
         self.mb_w, self.mb_h = self.cfg["mb_w"], self.cfg["mb_h"]
         self.n_mb = self.mb_w * self.mb_h

@@ -35,12 +35,31 @@ LOOKAHEAD_CASES = {
                            dict(seed=840, scene_cuts=(24, 36), pan=(3, 1), fade=(2, 10, 1.5, 5)), 50),
 }
 
+# Configurations whose device paths were written after the last GPU session of round 1 (edge ring not evaluated, lookahead
+# bands, auto-variance AQ, constant QP, the two fastest presets): same fixtures and checks, but their GPU tests live in
+# tests/test_zz_gpu_new_configs.py, which sorts last, so that a failure there cannot hide the results of the other files.
+LOOKAHEAD_CASES_R2 = {
+    "no_mbtree": ("medium", "mbtree=0,bframes=5,b-adapt=2,rc-lookahead=30", dict(mb_tree=0, bframes=5, b_adapt=2, rc_lookahead=30),
+                  8, 176, 144, dict(seed=14, scene_cuts=(19,), fade=(30, 8, 0.6, 5)), 50),
+    "superfast_cif": ("superfast", "", {}, 8, 352, 288, dict(seed=18, scene_cuts=(21,), pan=(6, 2)), 40),
+    "ultrafast": ("ultrafast", "", {}, 8, 176, 144, dict(seed=19, scene_cuts=(12,)), 30),
+    "cqp": ("slow", "bframes=1,b-adapt=0,keyint=8,scenecut=0,rc-lookahead=5,subme=1,qp=24",
+            dict(bframes=1, b_adapt=0, keyint_max=8, scenecut=0, rc_lookahead=5, subme=1, rc_is_cqp=1), 8, 176, 144,
+            dict(seed=526, scene_cuts=(21, 40), pan=(3, 3), fade=(9, 10, 0.6, 12)), 46),
+    "aq2_nopsy": ("medium", "aq-mode=2,psy=0", dict(aq_mode=2, psy=0), 8, 176, 144, dict(seed=15, scene_cuts=(22,)), 40),
+    "aq3_10bit": ("fast", "aq-mode=3,aq-strength=0.5,qcomp=0.4", dict(aq_mode=3, aq_strength=0.5, qcompress=0.4), 10, 176, 144,
+                  dict(seed=24, scene_cuts=(30,), pan=(2, 3), fade=(10, 10, 0.6, 15)), 44),
+    "bands3_cif": ("medium", "threads=6,sync-lookahead=0,lookahead-threads=3", dict(threads=6, lookahead_threads=3), 8, 352, 288,
+                   dict(seed=16, pan=(23, 11), noise=30, texture=0.9, scene_cuts=(20,)), 40),
+    "bands_auto_720p": ("veryslow", "threads=24,sync-lookahead=0,lookahead-threads=auto", dict(threads=24), 8, 1280, 720, dict(seed=20, pan=(9, 4)), 20),
+}
+
 EVAL_CONFIGS = [("medium", "", 8), ("slow", "me=dia", 8), ("medium", "subme=1", 8), ("veryslow", "me=tesa", 10)]
 EVAL_SEQ = [(0, 0, 0), (0, 1, 1), (0, 2, 2), (0, 2, 1), (1, 1, 1), (0, 3, 3), (0, 3, 1), (0, 3, 2), (1, 3, 2), (2, 3, 3), (3, 3, 3)]
 
 
 def gen_lookahead(only=None):
-    for name, (preset, opts, over, depth, W, H, ckw, nf) in LOOKAHEAD_CASES.items():
+    for name, (preset, opts, over, depth, W, H, ckw, nf) in list(LOOKAHEAD_CASES.items()) + list(LOOKAHEAD_CASES_R2.items()):
         if only and name not in only:
             continue
         frames = make_clip(W, H, nf, bit_depth=depth, **ckw)

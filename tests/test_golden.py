@@ -10,7 +10,7 @@ import pytest
 
 from oracle.oraclelib import Oracle, PAD, Weight
 from tests.common import clip
-from tests.golden.make_golden import EVAL_SEQ, LOOKAHEAD_CASES
+from tests.golden.make_golden import EVAL_SEQ, LOOKAHEAD_CASES, LOOKAHEAD_CASES_R2
 from tests.oracle_backend import OracleBackend
 from x264_amd import lib
 from x264_amd.synth import make_clip
@@ -145,9 +145,9 @@ def check_lookahead_outputs(outs, z, nb, check_qp=True):
         assert np.array_equal(ca[m], z["cost_aq"][k][m]), ("i_cost_est_aq", k, o.frame)
 
 
-@pytest.mark.parametrize("name", [n for n in LOOKAHEAD_CASES])
+@pytest.mark.parametrize("name", list(LOOKAHEAD_CASES) + list(LOOKAHEAD_CASES_R2))
 def test_host_lookahead_vs_golden(name):
-    preset, opts, over, depth, W, H, ckw, nf = LOOKAHEAD_CASES[name]
+    preset, opts, over, depth, W, H, ckw, nf = {**LOOKAHEAD_CASES, **LOOKAHEAD_CASES_R2}[name]
     z = np.load(os.path.join(GOLD, "lookahead_%s.npz" % name))
     frames = make_clip(W, H, nf, bit_depth=depth, **ckw)
     cfg = lib.la_config(W, H, preset, bit_depth=depth, **over)

@@ -76,7 +76,8 @@ def test_lookahead_matches_reference(preset, opts, over, depth, ckw, nf):
                       ("subme", "subme"), ("weightp", "weightp"), ("mb_tree", "mb_tree"), ("keyint_max", "keyint_max"),
                       ("keyint_min", "keyint_min"), ("b_pyramid", "b_pyramid"), ("mbcmp_satd", "mbcmp_satd"),
                       ("fpelcmp_satd", "fpelcmp_satd"), ("frame_refs", "refs"), ("open_gop", "open_gop"), ("aq_mode", "aq_mode"),
-                      ("psy", "psy"), ("weighted_bipred", "weighted_bipred"), ("bframe_bias", "b_bias")):
+                      ("psy", "psy"), ("weighted_bipred", "weighted_bipred"), ("bframe_bias", "b_bias"),
+                      ("lookahead_threads", "lookahead_threads")):
             assert cfg[k] == rc[rk], (k, cfg[k], rc[rk])
         be = OracleBackend(cfg)
         la = lib.Lookahead(cfg, backend=be.struct)
