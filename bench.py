@@ -132,9 +132,10 @@ def cpu_baseline(cfg, frames, preset, opts):
                 res = r.lookahead_run(frames)
             finally:
                 r.close()
-            return dict(value=round(n / res["seconds"], 2), unit="frames/s", cores=1, kind="reference",
+            return dict(value=round(n / res["seconds"], 2), unit="frames/s", cores=cfg["lookahead_threads"], kind="reference",
                         sample="%d frames %dx%d, reference C path (--disable-asm, no AVX2: no assembler in the build image), "
-                               "--threads 1; lowres init + lookahead only, AQ excluded (%.2f s)" % (n, cfg["width"], cfg["height"], res["seconds"]))
+                               "%d lookahead thread(s); lowres init + lookahead only, AQ excluded (%.2f s)" %
+                               (n, cfg["width"], cfg["height"], cfg["lookahead_threads"], res["seconds"]))
     except Exception as e:  # pragma: no cover
         print("cpu_baseline: reference unavailable (%s), using the port" % e, file=sys.stderr)
     from tests.oracle_backend import OracleBackend
@@ -161,6 +162,9 @@ def main():
     ap.add_argument("--preset", default="slow")
     ap.add_argument("--bit-depth", type=int, default=8, choices=(8, 10))
     ap.add_argument("--me", default="dia")
+    ap.add_argument("--threads", type=int, default=1,
+                    help="x264 --threads of the mirrored configuration: > 1 turns on the reference's automatic lookahead bands "
+                         "(i_lookahead_threads, encoder.c:1273-1300); 1 = the --threads 1 parity configuration")
     ap.add_argument("--paced", action="store_true", help="encoder-paced put/get instead of the deep-prefetch batch")
     ap.add_argument("--inflight", type=int, default=2,
                     help="independent GOP segments in flight per GPU (one host thread + one context each): the decisions of one "
@@ -196,7 +200,7 @@ def main():
             dist.init_process_group(backend)
 
     W, H, F = args.width, args.height, args.frames
-    cfg = lib.la_config(W, H, args.preset, bit_depth=args.bit_depth, me=args.me)
+    cfg = lib.la_config(W, H, args.preset, bit_depth=args.bit_depth, me=args.me, threads=args.threads)
     # every rank gets its own segment of the synthetic sequence (different seed = different content)
     S = max(1, args.inflight)
     # every (rank, segment) gets its own part of the synthetic sequence (different seed = different content)
@@ -307,7 +311,8 @@ def main():
                                    "(lowres+AQ+intra+ME+cost cells+slicetype decision+MB-tree), %d GOP segment(s) of %d frames in flight per GPU "
                                    "per step, %s" %
                                    (W, H, args.bit_depth, args.preset, args.me,
-                                    " (BASELINE configs[1])" if (W, H, args.bit_depth, args.preset, args.me) == (1920, 1080, 8, "slow", "dia") else "",
+                                    " (BASELINE configs[1])" if (W, H, args.bit_depth, args.preset, args.me, args.threads) == (1920, 1080, 8, "slow", "dia", 1)
+                                    else " --threads %d (%d lookahead bands)" % (args.threads, cfg["lookahead_threads"]) if args.threads > 1 else "",
                                     S, F, "encoder-paced" if args.paced else "deep-prefetch batch"),
                        "frames_per_step": S * F, "segments_in_flight": S, "bframes": cfg["bframes"], "b_adapt": cfg["b_adapt"], "rc_lookahead": cfg["rc_lookahead"],
                        "parallelism": "gop-segments x%d" % world, "slice_types": types[:64]},
@@ -333,6 +338,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             n = min(F, args.cpu_frames)
             opts = "me=%s" % args.me
+            if args.threads > 1:  # same bands on the CPU side (the harness drives the lookahead synchronously)
+                opts += ",threads=%d,sync-lookahead=0,lookahead-threads=%d" % (args.threads, cfg["lookahead_threads"])
             res["cpu_baseline"] = cpu_baseline(cfg, frames[:n], args.preset, opts)
         print(json.dumps(res))
     if dist is not None:
