@@ -409,6 +409,8 @@ static float *rh_out_qp = NULL; /* optional [n_frames][mb_count] dump of f_qp_of
 static uint16_t *rh_out_prop = NULL; /* optional [n_frames][mb_count] dump of i_propagate_cost */
 RH_API void rh_set_qp_dump( float *buf ) { rh_out_qp = buf; }
 RH_API void rh_set_prop_dump( uint16_t *buf ) { rh_out_prop = buf; }
+static const int *rh_forced_types = NULL; /* optional [n_frames] x264_picture_t.i_type of every input picture (x264.h:274-280) */
+RH_API void rh_set_forced_types( const int *types ) { rh_forced_types = types; }
 
 static int rh_drain_one( x264_t *h, int *out_idx, int *out_type, int *out_cost, int *out_cost_aq, int *out_imbs, int n_out )
 {
@@ -449,6 +451,8 @@ RH_API int rh_lookahead_run( rh_ctx *c, const pixel *yuv, int n_frames, int luma
         if( !fenc ) return -1;
         fenc->i_frame = h->frames.i_input++;
         fenc->i_pts = fenc->i_frame;
+        if( rh_forced_types ) /* x264_frame_copy_picture, frame.c:392-400 */
+            fenc->i_type = fenc->i_forced_type = rh_forced_types[i] < X264_TYPE_AUTO || rh_forced_types[i] > X264_TYPE_KEYFRAME ? X264_TYPE_AUTO : rh_forced_types[i];
         if( fenc->i_frame == 0 )
             h->frames.i_first_pts = fenc->i_pts;
         if( h->frames.i_bframe_delay && fenc->i_frame == h->frames.i_bframe_delay )
@@ -459,7 +463,8 @@ RH_API int rh_lookahead_run( rh_ctx *c, const pixel *yuv, int n_frames, int luma
         clock_gettime( CLOCK_MONOTONIC, &t1 );
         t_prep += (t1.tv_sec-t0.tv_sec) + 1e-9*(t1.tv_nsec-t0.tv_nsec);
         clock_gettime( CLOCK_MONOTONIC, &t0 );
-        x264_frame_init_lowres( h, fenc );
+        if( h->frames.b_have_lowres ) /* encoder.c:3422-3423 */
+            x264_frame_init_lowres( h, fenc );
         x264_lookahead_put_frame( h, fenc );
         if( h->frames.i_input > h->frames.i_delay + 1 - h->i_thread_frames )
         {

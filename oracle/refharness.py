@@ -122,7 +122,7 @@ class Ref:
         assert r == 0
         return lc, rows, tuple(int(x) for x in summ)
 
-    def lookahead_run(self, luma_frames, with_qp_offsets=False):
+    def lookahead_run(self, luma_frames, with_qp_offsets=False, forced_types=None):
         """luma_frames: [n, H, W]; returns dict(idx, type, cost, cost_aq, intra_mbs, seconds, seconds_prep[, qp_offset])."""
         fr = np.ascontiguousarray(luma_frames, dtype=self.dtype)
         n = fr.shape[0]
@@ -132,6 +132,10 @@ class Ref:
         self.lib.rh_set_prop_dump.argtypes = [C.c_void_p]
         self.lib.rh_set_qp_dump(_ptr(qp))
         self.lib.rh_set_prop_dump(_ptr(prop))
+        self.lib.rh_set_forced_types.argtypes = [C.c_void_p]
+        ft = np.ascontiguousarray(forced_types, np.int32) if forced_types is not None else None
+        assert ft is None or ft.size == n
+        self.lib.rh_set_forced_types(_ptr(ft))
         idx = np.zeros(n, np.int32)
         typ = np.zeros(n, np.int32)
         cost = np.zeros((n, 18, 18), np.int32)
@@ -143,6 +147,7 @@ class Ref:
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.POINTER(C.c_double)] * 2
         r = f(self.ctx, _ptr(fr), n, 1, _ptr(idx), _ptr(typ), _ptr(cost), _ptr(cost_aq), _ptr(imbs),
               C.byref(sec), C.byref(sec_prep))
+        self.lib.rh_set_forced_types(None)
         assert r == n, (r, n)
         self.lib.rh_set_qp_dump(None)
         self.lib.rh_set_prop_dump(None)

@@ -220,3 +220,39 @@ def test_every_preset_and_tune(preset):
             ce = np.array([[o.cost_est[i][j] for j in range(nb)] for i in range(nb)])
             assert np.array_equal(ce, ref["cost"][k][:nb, :nb]), (preset, tune, "i_cost_est", o.frame)
             assert np.array_equal(o.qp_offset, ref["qp_offset"][k]), (preset, tune, "f_qp_offset", o.frame)
+
+
+@pytest.mark.parametrize("opts,over,forced", [
+    ("", {}, {5: 1, 11: 1, 24: 7, 38: 3}),                       # IDRs, an unknown type (= AUTO), a forced P
+    ("bframes=8,b-adapt=0,b-pyramid=strict,keyint=60", dict(bframes=8, b_adapt=0, b_pyramid=1, keyint_max=60), {30: 6, 34: 5, 35: 6}),
+    ("open-gop=1,b-pyramid=normal,bframes=5", dict(open_gop=1, b_pyramid=2, bframes=5), {9: 6, 10: 4, 11: 4, 12: 4, 20: 2, 21: 5, 33: 1}),
+    ("b-adapt=2,keyint=30", dict(b_adapt=2, keyint_max=30), {3: 5, 4: 5, 5: 5, 6: 5, 7: 5, 29: 5, 30: 5, 40: 2}),
+])
+def test_forced_picture_types(opts, over, forced):
+    """x264_picture_t.i_type of the input pictures (x264.h:274-280): forced IDR / I / P / BREF / B / KEYFRAME requests, the
+    corrections slicetype_decide applies to impossible ones (slicetype.c:1803-1885) and unknown values (frame.c:392-400)."""
+    W, H, nf = 176, 144, 50
+    frames = make_clip(W, H, nf, seed=31, scene_cuts=(17,), pan=(3, 1))
+    ft = np.zeros(nf, np.int32)
+    for k, v in forced.items():
+        ft[k] = v
+    r = refharness.Ref(W, H, "medium", opts=opts)
+    try:
+        ref = r.lookahead_run(frames, with_qp_offsets=True, forced_types=ft)
+    finally:
+        r.close()
+    cfg = lib.la_config(W, H, "medium", **over)
+    for paced in (True, False):
+        be = OracleBackend(cfg, speculative=not paced)
+        la = lib.Lookahead(cfg, backend=be.struct, max_frames=nf + 4)
+        try:
+            outs = la.run(frames, qp_offsets=True, paced=paced, forced_types=ft)
+        finally:
+            la.close()
+        assert [o.frame for o in outs] == list(ref["idx"])
+        assert [o.type for o in outs] == list(ref["type"])
+        nb = cfg["bframes"] + 2
+        for k, o in enumerate(outs):
+            ce = np.array([[o.cost_est[i][j] for j in range(nb)] for i in range(nb)])
+            assert np.array_equal(ce, ref["cost"][k][:nb, :nb]), ("i_cost_est", o.frame)
+            assert np.array_equal(o.qp_offset, ref["qp_offset"][k]), ("f_qp_offset", o.frame)

@@ -959,9 +959,13 @@ static LaFrame *new_frame( Lookahead &L, int forced_type )
     LaFrame *f = new LaFrame();
     f->slot = L.free_slots.back(); L.free_slots.pop_back();
     f->i_frame = L.i_input++;
-    f->i_forced_type = f->i_type = forced_type;
+    // an unknown picture type is taken as AUTO (x264_frame_copy_picture, frame.c:392-400)
+    f->i_forced_type = f->i_type = forced_type < T_AUTO || forced_type > T_KEYFRAME ? T_AUTO : forced_type;
     f->refcount = 1;
-    memset( f->cost_est, -1, sizeof( f->cost_est ) );      // mc.c:473
+    // encoder.c:1617-1625 b_have_lowres: constant QP without any analysis has no lowres planes, and the -1 marks are the work of
+    // x264_frame_init_lowres (mc.c:473): without it the cells keep the zeros of the frame's allocation
+    const bool have_lowres = !L.p.rc_is_cqp || L.p.b_adapt || L.p.scenecut_threshold || L.p.mb_tree || L.p.weightp;
+    memset( f->cost_est, have_lowres ? -1 : 0, sizeof( f->cost_est ) );
     memset( f->cost_est_aq, 0, sizeof( f->cost_est_aq ) );
     memset( f->intra_mbs, 0, sizeof( f->intra_mbs ) );
     memset( f->searched, 0, sizeof( f->searched ) );       // mc.c:479-481

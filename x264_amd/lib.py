@@ -510,7 +510,7 @@ class Lookahead:
         _ck(self.L.x264hip_lookahead_stats(self.h, _p(out), 8), "lookahead_stats")
         return out
 
-    def run(self, frames=None, device_ptrs=None, stride=None, paced=True, qp_offsets=False):
+    def run(self, frames=None, device_ptrs=None, stride=None, paced=True, qp_offsets=False, forced_types=None):
         """Feed a whole clip.  paced=True interleaves put/get exactly like x264_encoder_encode; paced=False puts
         every frame first (deep prefetch) -- results are identical, only the batching differs."""
         outs = []
@@ -521,10 +521,11 @@ class Lookahead:
         else:
             n_loop = n
         for i in range(n_loop):
+            ft = int(forced_types[i]) if forced_types is not None else 0
             if frames is not None:
-                self.put(frames[i])
+                self.put(frames[i], forced_type=ft)
             else:
-                self.put(device_ptr=device_ptrs[i], stride=stride)
+                self.put(device_ptr=device_ptrs[i], stride=stride, forced_type=ft)
             if paced:
                 o = self.get(False, qp_offsets)
                 if o is not None:
