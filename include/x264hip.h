@@ -242,6 +242,10 @@ typedef struct x264hip_la_params
     int rc_is_cqp;            /* rc.i_rc_method == X264_RC_CQP: skips the final cost evaluation (slicetype.c:1899) */
     int fps_num, fps_den;     /* constant frame rate (f_duration of every frame, slicetype.c:1767-1771); 0 -> 25/1 */
     float qcompress;          /* param.rc.f_qcompress (MB-tree strength, slicetype.c:1038); 0 -> 0.6 */
+    int vbv;                  /* param.rc.i_vbv_buffer_size != 0 after validation: with rc_lookahead > 0 turns on the VBV lookahead
+                               * (vbv_lookahead, slicetype.c:1224-1286; key-frame analysis, lookahead.c:140-141), the B-frame and
+                               * intra evaluations slicetype_decide adds for the row sums (:1916-1934), an MB-tree finish for every
+                               * reference (:1087-1088) and the lookahead delay of encoder.c:1607-1608 */
 } x264hip_la_params;
 
 
@@ -260,6 +264,10 @@ typedef struct x264hip_backend
     int (*get_qp_offsets)( void *user, int slot, float *qp_offset );                    /* may be NULL */
     int (*frame_put_batch)( void *user, int n, const int *slots, const void *const *luma_dev, int stride ); /* may be NULL */
     int (*prefetch_weight_costs)( void *user, int n, const int *slot_fenc, const int *slot_ref, const x264hip_weight *w ); /* may be NULL */
+    /* the two below are needed with vbv only (may be NULL otherwise); contracts of x264hip_frame_cost_recalculate and of the
+     * row_satds output of x264hip_get_lowres_costs */
+    int (*frame_cost_recalculate)( void *user, int slot_b, int dist_p0, int dist_p1, int use_aq_offsets, int *score );
+    int (*get_row_satds)( void *user, int slot, int dist_p0, int dist_p1, int *row_satds );
 } x264hip_backend;
 
 typedef struct x264hip_la_frame
@@ -291,6 +299,25 @@ int  x264hip_lookahead_get_frame( x264hip_lookahead *la, int flush, x264hip_la_f
 /* same, additionally copying the frame's f_qp_offset map (mb_w*mb_h floats: the AQ offsets, replaced by the MB-tree output
  * when mb_tree is on; read by rate control, encoder/ratecontrol.c:1761) when qp_offset != NULL and aq_mode != 0 */
 int  x264hip_lookahead_get_frame_ex( x264hip_lookahead *la, int flush, x264hip_la_frame *out, int *got, float *qp_offset );
+
+/* What VBV rate control reads from a frame leaving the lookahead besides the above (encoder/ratecontrol.c:1545-1613,
+ * 2290-2320, and x264_rc_analyse_slice, slicetype.c:1976-2030):
+ *  - i_planned_type / i_planned_satd: types and costs of the following frames in coded order, ended by type 0 (AUTO); filled by
+ *    the last analysis that saw the frame as the next non-B frame (or as the key frame just decided); n_planned = 0 for B frames
+ *  - the (dist_p0, dist_p1) cell the frame is coded with and that cell's i_row_satds, plus the intra row sums i_row_satds[0][0]
+ *    (row_satds / row_satds_intra: caller buffers of mb_h ints, may be NULL).
+ * The f_planned_cpb_duration bookkeeping (calculate_durations, slicetype.c:1200-1222) is left to the caller: it is the frame
+ * duration for progressive constant-frame-rate input. */
+#define X264HIP_LOOKAHEAD_MAX 250 /* X264_LOOKAHEAD_MAX, common/common.h */
+typedef struct x264hip_la_vbv
+{
+    int n_planned;
+    int planned_type[X264HIP_LOOKAHEAD_MAX + 1];
+    int planned_satd[X264HIP_LOOKAHEAD_MAX + 1];
+    int dist_p0, dist_p1;
+} x264hip_la_vbv;
+int  x264hip_lookahead_get_frame_vbv( x264hip_lookahead *la, int flush, x264hip_la_frame *out, int *got, float *qp_offset,
+                                      x264hip_la_vbv *vbv, int *row_satds, int *row_satds_intra );
 /* statistics: [0] slicetype_frame_cost calls, [1] real evaluations, [2] weights analysed, [3] weights kept,
  * wall time in ns spent in [4] backend frame_cost, [5] weights_analyse, [6] backend prefetch + mbtree, [7] the put/get calls in total */
 int  x264hip_lookahead_stats( x264hip_lookahead *la, uint64_t *out, int n );

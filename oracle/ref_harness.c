@@ -409,6 +409,9 @@ static float *rh_out_qp = NULL; /* optional [n_frames][mb_count] dump of f_qp_of
 static uint16_t *rh_out_prop = NULL; /* optional [n_frames][mb_count] dump of i_propagate_cost */
 RH_API void rh_set_qp_dump( float *buf ) { rh_out_qp = buf; }
 RH_API void rh_set_prop_dump( uint16_t *buf ) { rh_out_prop = buf; }
+static int *rh_out_planned_type = NULL, *rh_out_planned_satd = NULL; /* optional [n_frames][X264_LOOKAHEAD_MAX+1] */
+static int *rh_out_rows = NULL; /* optional [n_frames][(X264_BFRAME_MAX+2)^2][mb_h] dump of i_row_satds (cells that are not allocated stay untouched) */
+RH_API void rh_set_vbv_dump( int *planned_type, int *planned_satd, int *rows ) { rh_out_planned_type = planned_type; rh_out_planned_satd = planned_satd; rh_out_rows = rows; }
 static const int *rh_forced_types = NULL; /* optional [n_frames] x264_picture_t.i_type of every input picture (x264.h:274-280) */
 RH_API void rh_set_forced_types( const int *types ) { rh_forced_types = types; }
 
@@ -428,6 +431,15 @@ static int rh_drain_one( x264_t *h, int *out_idx, int *out_type, int *out_cost, 
     /* (the AQ / MB-tree arrays only exist with aq-mode != 0, frame.c:286-301: the dump stays zero without them) */
     if( rh_out_qp && f->f_qp_offset )   memcpy( rh_out_qp + (size_t)n_out*h->mb.i_mb_count, f->f_qp_offset, h->mb.i_mb_count*sizeof(float) );
     if( rh_out_prop && f->i_propagate_cost ) memcpy( rh_out_prop + (size_t)n_out*h->mb.i_mb_count, f->i_propagate_cost, h->mb.i_mb_count*sizeof(uint16_t) );
+    if( rh_out_planned_type )
+        for( int j = 0; j <= X264_LOOKAHEAD_MAX; j++ )
+            rh_out_planned_type[(size_t)n_out*(X264_LOOKAHEAD_MAX+1) + j] = f->i_planned_type[j]; /* uint8_t there */
+    if( rh_out_planned_satd ) memcpy( rh_out_planned_satd + (size_t)n_out*(X264_LOOKAHEAD_MAX+1), f->i_planned_satd, (X264_LOOKAHEAD_MAX+1)*sizeof(int) );
+    if( rh_out_rows && h->frames.b_have_lowres )
+        for( int i = 0; i <= h->param.i_bframe+1; i++ )
+            for( int j = 0; j <= h->param.i_bframe+1; j++ )
+                memcpy( rh_out_rows + ((size_t)n_out*(X264_BFRAME_MAX+2)*(X264_BFRAME_MAX+2) + i*(X264_BFRAME_MAX+2) + j)*h->mb.i_mb_height,
+                        f->i_row_satds[i][j], h->mb.i_mb_height*sizeof(int) );
     x264_frame_push_unused( h, f );
     return 0;
 }

@@ -122,7 +122,7 @@ class Ref:
         assert r == 0
         return lc, rows, tuple(int(x) for x in summ)
 
-    def lookahead_run(self, luma_frames, with_qp_offsets=False, forced_types=None):
+    def lookahead_run(self, luma_frames, with_qp_offsets=False, forced_types=None, with_vbv=False):
         """luma_frames: [n, H, W]; returns dict(idx, type, cost, cost_aq, intra_mbs, seconds, seconds_prep[, qp_offset])."""
         fr = np.ascontiguousarray(luma_frames, dtype=self.dtype)
         n = fr.shape[0]
@@ -136,6 +136,11 @@ class Ref:
         ft = np.ascontiguousarray(forced_types, np.int32) if forced_types is not None else None
         assert ft is None or ft.size == n
         self.lib.rh_set_forced_types(_ptr(ft))
+        self.lib.rh_set_vbv_dump.argtypes = [C.c_void_p] * 3
+        pt = np.zeros((n, 251), np.int32) if with_vbv else None
+        ps = np.zeros((n, 251), np.int32) if with_vbv else None
+        rows = np.full((n, 18, 18, self.mb_h), -2, np.int32) if with_vbv else None
+        self.lib.rh_set_vbv_dump(_ptr(pt), _ptr(ps), _ptr(rows))
         idx = np.zeros(n, np.int32)
         typ = np.zeros(n, np.int32)
         cost = np.zeros((n, 18, 18), np.int32)
@@ -148,6 +153,7 @@ class Ref:
         r = f(self.ctx, _ptr(fr), n, 1, _ptr(idx), _ptr(typ), _ptr(cost), _ptr(cost_aq), _ptr(imbs),
               C.byref(sec), C.byref(sec_prep))
         self.lib.rh_set_forced_types(None)
+        self.lib.rh_set_vbv_dump(None, None, None)
         assert r == n, (r, n)
         self.lib.rh_set_qp_dump(None)
         self.lib.rh_set_prop_dump(None)
@@ -156,4 +162,6 @@ class Ref:
         if qp is not None:
             out["qp_offset"] = qp
             out["propagate"] = prop
+        if with_vbv:
+            out["planned_type"], out["planned_satd"], out["row_satds"] = pt, ps, rows
         return out

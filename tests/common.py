@@ -24,7 +24,8 @@ def oracle_cfg(o, rcfg, cost_mv=None):
                       me_range=rcfg["me_range"], mv_range=rcfg["mv_range"], subme=rcfg["subme"],
                       mbcmp_satd=rcfg["mbcmp_satd"], fpelcmp_satd=rcfg["fpelcmp_satd"],
                       weighted_bipred=rcfg["weighted_bipred"], aq_mode=rcfg["aq_mode"], lam=rcfg["lambda"],
-                      bframe_bias=rcfg["b_bias"], cost_mv=cost_mv)
+                      bframe_bias=rcfg["b_bias"], cost_mv=cost_mv, n_slices=rcfg.get("lookahead_threads", 1),
+                      do_edges=int(bool(rcfg["mb_tree"] or rcfg["vbv"])))
 
 
 # ---- main-encode motion search (SURVEY 8f rank 3 groundwork): shared between the reference test and the golden test ----

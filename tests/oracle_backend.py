@@ -31,7 +31,8 @@ class OracleBackend:
                                   lib.WEIGHT_COST_FN(self._wcost), lib.FRAME_COST_FN(self._cost),
                                   lib.PREFETCH_FN(self._prefetch) if speculative else lib.PREFETCH_FN(0),
                                   lib.MBTREE_FN(self._mbtree), lib.QP_OFFSETS_FN(self._qp), lib.PUT_BATCH_FN(0),
-                                  lib.PREFETCH_WEIGHTS_FN(self._prefetch_weights) if speculative else lib.PREFETCH_WEIGHTS_FN(0))
+                                  lib.PREFETCH_WEIGHTS_FN(self._prefetch_weights) if speculative else lib.PREFETCH_WEIGHTS_FN(0),
+                                  lib.RECALC_FN(self._recalc), lib.ROW_SATDS_FN(self._rows))
 
     def _prefetch(self, user, slots, numbers, n):
         return 0
@@ -49,7 +50,7 @@ class OracleBackend:
         pl = self.o.lowres_init(self.ocfg, img)
         inv, qp, s, ssd = self.o.aq_frame(img, self.ocfg.mb_w, self.ocfg.mb_h, c["aq_mode"], c["aq_strength"])
         n = self.ocfg.mb_w * self.ocfg.mb_h
-        self.slots[slot] = dict(planes=pl, inv=inv, sum=s, ssd=ssd, intra=self.o.intra_costs(self.ocfg, pl), fields={}, maps={},
+        self.slots[slot] = dict(planes=pl, inv=inv, sum=s, ssd=ssd, intra=self.o.intra_costs(self.ocfg, pl), fields={}, maps={}, rows={},
                                 prop=np.zeros(n, np.uint16), qp_aq=qp.copy(), qp=qp.copy())
         return 0
 
@@ -93,6 +94,10 @@ class OracleBackend:
                 lc, rows, rows_i, co = o.cell(cfg, B["planes"], F0["planes"], None, dsf, m0, c0, None, None, None, B["intra"],
                                               B["inv"], bool(with_intra))
         B["maps"][(d0, d1)] = lc
+        if d0 or d1:
+            B["rows"][(d0, d1)] = rows.copy()
+        if with_intra:
+            B["rows"][(0, 0)] = rows_i.copy()
         out[0].cost_est, out[0].cost_est_aq, out[0].intra_mbs = co.cost_est, co.cost_est_aq, co.intra_mbs
         out[0].intra_cost_est, out[0].intra_cost_est_aq = co.intra_cost_est, co.intra_cost_est_aq
         return 0
@@ -126,4 +131,22 @@ class OracleBackend:
     def _qp(self, user, slot, dst):
         q = self.slots[slot]["qp"]
         C.memmove(dst, q.ctypes.data, q.nbytes)
+        return 0
+
+    def _recalc(self, user, slot_b, d0, d1, use_aq, score):
+        """slicetype_frame_cost_recalculate: rewrites the cell's row sums like the reference"""
+        B = self.slots[slot_b]
+        cfg = self.ocfg
+        rows = np.zeros(cfg.mb_h, np.int32)
+        fn = self.o.f("frame_cost_recalculate", C.c_int)
+        q = B["qp_aq"] if use_aq else B["qp"]
+        lc = B["maps"][(d0, d1)] if (d0 or d1) else B["intra"]  # lowres_costs[0][0] is the intra cost array itself (frame.c:283)
+        score[0] = fn(cfg.mb_w, cfg.mb_h, lc.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p),
+                      rows.ctypes.data_as(C.c_void_p))
+        B["rows"][(d0, d1)] = rows
+        return 0
+
+    def _rows(self, user, slot, d0, d1, dst):
+        r = self.slots[slot]["rows"][(d0, d1)]
+        C.memmove(dst, r.ctypes.data, r.nbytes)
         return 0

@@ -256,3 +256,75 @@ def test_forced_picture_types(opts, over, forced):
             ce = np.array([[o.cost_est[i][j] for j in range(nb)] for i in range(nb)])
             assert np.array_equal(ce, ref["cost"][k][:nb, :nb]), ("i_cost_est", o.frame)
             assert np.array_equal(o.qp_offset, ref["qp_offset"][k]), ("f_qp_offset", o.frame)
+
+
+@pytest.mark.parametrize("preset,opts,over", [
+    ("medium", "bitrate=500,vbv-bufsize=300,vbv-maxrate=600", dict(bitrate=500, vbv_bufsize=300, vbv_maxrate=600)),
+    ("medium", "vbv-bufsize=300,vbv-maxrate=600,mbtree=0,b-pyramid=none", dict(vbv_bufsize=300, vbv_maxrate=600, mb_tree=0, b_pyramid=0)),
+    ("veryfast", "vbv-bufsize=100,vbv-maxrate=600,aq-mode=0", dict(vbv_bufsize=100, vbv_maxrate=600, aq_mode=0)),
+    ("superfast", "bframes=5,b-adapt=1,b-pyramid=strict,keyint=60,scenecut=0,rc-lookahead=60,open-gop=1,aq-mode=3,vbv-bufsize=20,"
+     "vbv-maxrate=200,bitrate=400", dict(bframes=5, b_adapt=1, b_pyramid=1, keyint_max=60, scenecut=0, rc_lookahead=60, open_gop=1,
+                                          aq_mode=3, vbv_bufsize=20, vbv_maxrate=200, bitrate=400)),
+    ("fast", "b-adapt=2,bframes=5,vbv-bufsize=2000,vbv-maxrate=1000,rc-lookahead=20,keyint=24",
+     dict(b_adapt=2, bframes=5, vbv_bufsize=2000, vbv_maxrate=1000, rc_lookahead=20, keyint_max=24)),
+    ("medium", "vbv-bufsize=300,bitrate=400,rc-lookahead=0", dict(vbv_bufsize=300, bitrate=400, rc_lookahead=0)),
+])
+@pytest.mark.parametrize("paced", [True, False])
+def test_vbv_lookahead(preset, opts, over, paced):
+    """VBV configurations (vbv_lookahead / vbv_frame_cost, slicetype.c:1186-1286; the extra evaluations of slicetype_decide,
+    :1916-1934; the per-reference MB-tree finish, :1087-1088): decisions, cost cells, f_qp_offset, i_planned_type / i_planned_satd
+    of every non-B frame, and the i_row_satds of the cell each frame is coded with plus its intra rows."""
+    W, H, nf = 100, 70, 46
+    frames = make_clip(W, H, nf, seed=101, scene_cuts=(32, 38), pan=(2, 0), fade=(8, 10, 0.6, 14))
+    r = refharness.Ref(W, H, preset, opts=opts)
+    try:
+        ref = r.lookahead_run(frames, with_qp_offsets=True, with_vbv=True)
+        rc = r.cfg
+    finally:
+        r.close()
+    cfg = lib.la_config(W, H, preset, **over)
+    assert cfg["vbv"] == int(rc["vbv"] > 0) and cfg["rc_lookahead"] == rc["rc_lookahead"] and cfg["mv_range"] == rc["mv_range"]
+    be = OracleBackend(cfg, speculative=not paced)
+    la = lib.Lookahead(cfg, backend=be.struct, max_frames=nf + 4)
+    try:
+        assert la.delay == rc["delay"]
+        outs = la.run(frames, qp_offsets=True, vbv=True, paced=paced)
+    finally:
+        la.close()
+    assert [o.frame for o in outs] == list(ref["idx"])
+    assert [o.type for o in outs] == list(ref["type"])
+    nb = cfg["bframes"] + 2
+    for k, o in enumerate(outs):
+        ce = np.array([[o.cost_est[i][j] for j in range(nb)] for i in range(nb)])
+        assert np.array_equal(ce, ref["cost"][k][:nb, :nb]), ("i_cost_est", o.frame)
+        if cfg["aq_mode"]:
+            assert np.array_equal(o.qp_offset, ref["qp_offset"][k]), ("f_qp_offset", o.frame, o.type)
+        if o.type not in (4, 5):
+            want = []
+            for t, s in zip(ref["planned_type"][k], ref["planned_satd"][k]):
+                if t == 0:
+                    break
+                want.append((int(t), int(s)))
+            assert o.planned == want, ("i_planned_*", o.frame)
+        d0, d1 = o.own_cell
+        if o.cost_est[d0][d1] >= 0:
+            assert np.array_equal(o.row_satds, ref["row_satds"][k][d0][d1]), ("i_row_satds", o.frame, d0, d1)
+        if o.row_satds_intra[0] != -1:
+            assert np.array_equal(o.row_satds_intra, ref["row_satds"][k][0][0]), ("i_row_satds[0][0]", o.frame)
+
+
+def test_level_mv_range():
+    """param.analyse.i_mv_range of the automatically chosen level (encoder.c:1243-1268, x264_validate_levels): frame size, DPB,
+    VBV rate / buffer per profile, MB rate."""
+    for (W, H), preset, depth, (opts, over) in [
+            ((96, 80), "medium", 8, ("", {})), ((352, 288), "veryslow", 10, ("", {})), ((720, 576), "medium", 8, ("bitrate=300", dict(bitrate=300))),
+            ((1280, 720), "ultrafast", 8, ("", {})), ((1920, 1080), "slow", 8, ("", {})), ((3840, 2160), "slower", 8, ("", {})),
+            ((3840, 2160), "medium", 8, ("", {})), ((7680, 4320), "veryslow", 10, ("", {})), ((100, 2000), "medium", 8, ("", {})),
+            ((352, 288), "medium", 8, ("bitrate=3000,vbv-bufsize=6000,vbv-maxrate=9000", dict(bitrate=3000, vbv_bufsize=6000, vbv_maxrate=9000))),
+            ((176, 144), "medium", 8, ("keyint=1", dict(keyint_max=1))), ((640, 360), "placebo", 8, ("fps=60", dict(fps_num=60, fps_den=1)))]:
+        if not refharness.available(depth):
+            continue
+        r = refharness.Ref(W, H, preset, opts=opts, bit_depth=depth)
+        want = r.cfg["mv_range"]
+        r.close()
+        assert lib.la_config(W, H, preset, bit_depth=depth, **over)["mv_range"] == want, (W, H, preset, depth, opts)

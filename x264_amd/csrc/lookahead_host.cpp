@@ -55,6 +55,10 @@ struct LaFrame
     float weighted_cost_delta[BMAX + 2]; // f_weighted_cost_delta, frame.c:798
     bool prefetch_submitted = false;
     bool weights_prefetched = false;
+    // VBV lookahead (slicetype.c:1224-1286): what the frames after this one are planned to be and to cost
+    int planned_type[LOOKAHEAD_MAX + 1] = { T_AUTO };
+    int planned_satd[LOOKAHEAD_MAX + 1] = { 0 };
+    int own_d0 = 0, own_d1 = 0; // the cell the frame is coded with (distances to its references), set by decide()
 };
 
 static int ue_size( unsigned v ) // bs_size_ue, common/bitstream.h:278 (2*floor(log2(v+1))+1)
@@ -397,7 +401,10 @@ struct Lookahead
         o.bipred_weight = p.dev.weighted_bipred ? 64 - ( dsf >> 2 ) : 32;
         o.fps_factor = (float)( clip_duration( f_duration ) / ( clip_duration( average_duration ) * 256.0f ) * 0.5f );
         ops.push_back( o );
+        if( vbv_lookahead_on() && referenced ) // slicetype.c:1087-1088: VBV rate control reads f_qp_offset of every reference
+            mbt_finish( ops, frames[b], average_duration, b == p1 ? b - p0 : 0 );
     }
+    bool vbv_lookahead_on() const { return p.vbv && p.rc_lookahead; }
     void mbt_finish( std::vector<x264hip_mbtree_op> &ops, LaFrame *f, float average_duration, int ref0_distance )
     {
         x264hip_mbtree_op o;
@@ -474,12 +481,14 @@ struct Lookahead
         else
         {
             mbt_finish( ops, frames[last_nonb], average_duration, last_nonb );
-            if( p.b_pyramid && bframes > 1 )
+            if( p.b_pyramid && bframes > 1 && !p.vbv ) // :1182-1183
                 mbt_finish( ops, frames[last_nonb + ( bframes + 1 ) / 2], average_duration, 0 );
         }
         if( be.mbtree && !ops.empty() && !err )
+        {
             ScopeNs tm( stats[6] );
             need( be.mbtree( be.user, ops.data(), (int)ops.size() ) );
+        }
     }
 
     // ---- x264_slicetype_analyse (:1473-1743) -------------------------------------------------------
@@ -502,7 +511,7 @@ struct Lookahead
         }
         keyint_limit = p.keyint_max - frames[0]->i_frame + i_last_keyframe - 1;
         orig_num_frames = num_frames = framecnt < keyint_limit ? framecnt : keyint_limit;
-        if( p.psy && p.mb_tree )
+        if( ( p.psy && p.mb_tree ) || vbv_lookahead_on() )
             num_frames = framecnt;
         else if( p.open_gop && num_frames < framecnt )
             num_frames++;
@@ -654,15 +663,65 @@ struct Lookahead
                 }
             }
         }
+        if( vbv_lookahead_on() )
+            vbv_lookahead( frames, num_frames, keyframe );
         for( int j = reset_start; j <= num_frames; j++ )
             frames[j]->i_type = frames[j]->i_forced_type;
+    }
+
+    // ---- vbv_frame_cost / vbv_lookahead (:1186-1198, :1224-1286) ------------------------------------
+    // The planned types and costs of the frames after the next non-B frame, in coded order, for VBV rate control
+    // (ratecontrol.c:2290-2320).  The CPB duration bookkeeping of the reference (calculate_durations) is constant
+    // for progressive constant-frame-rate input and stays with the encoder.
+    int vbv_frame_cost( LaFrame **frames, int p0, int p1, int b )
+    {
+        int cost = frame_cost( frames, p0, p1, b );
+        if( p.dev.aq_mode )
+        {
+            if( p.mb_tree )
+            {
+                // slicetype_frame_cost_recalculate: the cell under the frame's current quantiser offsets
+                int score = 0;
+                if( !be.frame_cost_recalculate ) { need( X264HIP_EINVAL ); return 0; }
+                if( need( be.frame_cost_recalculate( be.user, frames[b]->slot, b - p0, p1 - b, is_b( frames[b]->i_type ), &score ) ) ) return 0;
+                return score;
+            }
+            return frames[b]->cost_est_aq[b - p0][p1 - b];
+        }
+        return cost;
+    }
+    void vbv_lookahead( LaFrame **frames, int num_frames, int keyframe )
+    {
+        int last_nonb = 0, cur_nonb = 1, idx = 0;
+        while( cur_nonb < num_frames && is_b( frames[cur_nonb]->i_type ) ) cur_nonb++;
+        int next_nonb = keyframe ? last_nonb : cur_nonb;
+        LaFrame *dst = frames[next_nonb];
+        while( cur_nonb < num_frames )
+        {
+            if( next_nonb != cur_nonb ) // P/I cost: not the cost of next_nonb itself
+            {
+                int p0 = is_i( frames[cur_nonb]->i_type ) ? cur_nonb : last_nonb;
+                dst->planned_satd[idx] = vbv_frame_cost( frames, p0, cur_nonb, cur_nonb );
+                dst->planned_type[idx] = frames[cur_nonb]->i_type;
+                idx++;
+            }
+            for( int i = last_nonb + 1; i < cur_nonb; i++, idx++ ) // the B-frames, coded order
+            {
+                dst->planned_satd[idx] = vbv_frame_cost( frames, last_nonb, cur_nonb, i );
+                dst->planned_type[idx] = T_B;
+            }
+            last_nonb = cur_nonb;
+            cur_nonb++;
+            while( cur_nonb <= num_frames && is_b( frames[cur_nonb]->i_type ) ) cur_nonb++;
+        }
+        dst->planned_type[idx] = T_AUTO;
     }
 
     // ---- x264_slicetype_decide (:1745-1974), type logic and the final cost evaluations --------------
     void decide()
     {
         if( next.empty() ) return;
-        if( ( p.dev.bframes && p.b_adapt ) || p.scenecut_threshold || p.mb_tree )
+        if( ( p.dev.bframes && p.b_adapt ) || p.scenecut_threshold || p.mb_tree || vbv_lookahead_on() )
             analyse( 0 );
         int bframes, brefs;
         LaFrame *frm;
@@ -730,6 +789,24 @@ struct Lookahead
             for( int i = 0; i <= bframes; i++ ) frames[i + 1] = next[i];
             p0 = is_i( next[bframes]->i_type ) ? bframes + 1 : 0;
             frame_cost( frames, p0, p1, b );
+            frames[b]->own_d0 = b - p0; frames[b]->own_d1 = 0;
+            {
+                const bool vbv_rows = ( p0 != p1 || bframes ) && p.vbv;
+                if( vbv_rows )
+                    frame_cost( frames, b, b, b ); // intra costs for the row sums (:1918-1919; memoized when already there)
+                // the cell every B-frame of the mini-GOP is coded with (:1922-1933); VBV needs their row sums now
+                int q0 = 0;
+                for( int i = 1; i <= bframes; i++ )
+                {
+                    int q1 = bframes + 1;
+                    if( frames[i]->i_type == T_B )
+                        for( q1 = i; frames[q1]->i_type == T_B; ) q1++;
+                    frames[i]->own_d0 = i - q0; frames[i]->own_d1 = q1 - i;
+                    if( vbv_rows )
+                        frame_cost( frames, q0, q1, i );
+                    if( frames[i]->i_type == T_BREF ) q0 = i;
+                }
+            }
         }
         // The main-encode weight analysis of a P frame (:1937-1943, b_lookahead = 0) works on the full-resolution planes and
         // stays with the encoder, but its first step is visible in the lookahead's own outputs: when the luma statistics
@@ -844,6 +921,8 @@ static int dev_frame_cost( void *u, int p0, int p1, int b, int d0, int d1, const
 static int dev_prefetch( void *u, const int *s, const int *n, int c ) { return x264hip_prefetch( (x264hip_ctx *)u, s, n, c ); }
 static int dev_mbtree( void *u, const x264hip_mbtree_op *ops, int n ) { return x264hip_mbtree( (x264hip_ctx *)u, ops, n ); }
 static int dev_qp_offsets( void *u, int slot, float *q ) { return x264hip_get_qp_offsets( (x264hip_ctx *)u, slot, q ); }
+static int dev_recalc( void *u, int b, int d0, int d1, int aq, int *score ) { return x264hip_frame_cost_recalculate( (x264hip_ctx *)u, b, d0, d1, aq, score ); }
+static int dev_row_satds( void *u, int slot, int d0, int d1, int *rows ) { return x264hip_get_lowres_costs( (x264hip_ctx *)u, slot, d0, d1, nullptr, rows ); }
 static int dev_put_batch( void *u, int n, const int *slots, const void *const *luma, int stride )
 {
     return x264hip_frame_put_batch( (x264hip_ctx *)u, n, slots, luma, stride );
@@ -873,10 +952,10 @@ static int la_init( x264hip_lookahead *la, const x264hip_la_params *params )
         L.i_delay = ( p.dev.bframes > 3 ? p.dev.bframes : 3 ) * 4;
     else
         L.i_delay = p.dev.bframes;
-    if( p.mb_tree )
+    if( p.mb_tree || p.vbv )
         L.i_delay = L.i_delay > p.rc_lookahead ? L.i_delay : p.rc_lookahead;
     L.slicetype_length = L.i_delay;
-    L.b_analyse_keyframe = p.mb_tree; // lookahead.c:140-141 (no VBV, no stats read)
+    L.b_analyse_keyframe = p.mb_tree || ( p.vbv && p.rc_lookahead ); // lookahead.c:140-141 (no stats read)
     {
         // slicetype.c:1767-1771: i_duration = 2 field units for a progressive frame, time base 1/(2*fps)
         const int fn = p.fps_num > 0 ? p.fps_num : 25, fd = p.fps_den > 0 ? p.fps_den : 1;
@@ -890,7 +969,7 @@ static int la_init( x264hip_lookahead *la, const x264hip_la_params *params )
 static int slots_needed( const x264hip_la_params *p )
 {
     int delay = p->b_adapt == 2 ? ( p->dev.bframes > 3 ? p->dev.bframes : 3 ) * 4 : p->dev.bframes;
-    if( p->mb_tree && p->rc_lookahead > delay ) delay = p->rc_lookahead;
+    if( ( p->mb_tree || p->vbv ) && p->rc_lookahead > delay ) delay = p->rc_lookahead;
     return delay + p->dev.bframes + 8;
 }
 
@@ -913,11 +992,11 @@ extern "C" int x264hip_lookahead_open( x264hip_lookahead **out, int device, cons
     if( !out || !params ) return X264HIP_EINVAL;
     x264hip_la_params p = *params;
     if( p.dev.max_frames <= 0 ) p.dev.max_frames = slots_needed( &p );
-    p.dev.no_edges = !p.mb_tree; // slicetype.c:823 (no VBV here): the evaluations visit the edge blocks only for MB-tree
+    p.dev.no_edges = !( p.mb_tree || p.vbv ); // slicetype.c:823: the evaluations visit the edge blocks only for MB-tree and VBV
     x264hip_ctx *ctx = nullptr;
     int rc = x264hip_open( &ctx, device, &p.dev );
     if( rc ) return rc;
-    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch, dev_mbtree, dev_qp_offsets, dev_put_batch, dev_prefetch_weights };
+    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch, dev_mbtree, dev_qp_offsets, dev_put_batch, dev_prefetch_weights, dev_recalc, dev_row_satds };
     rc = x264hip_lookahead_open_backend( out, &p, &be );
     if( rc ) { x264hip_close( ctx ); return rc; }
     ( *out )->L.ctx = ctx;
@@ -1035,6 +1114,12 @@ extern "C" int x264hip_lookahead_get_frame( x264hip_lookahead *la, int flush, x2
 
 extern "C" int x264hip_lookahead_get_frame_ex( x264hip_lookahead *la, int flush, x264hip_la_frame *out, int *got, float *qp_offset )
 {
+    return x264hip_lookahead_get_frame_vbv( la, flush, out, got, qp_offset, nullptr, nullptr, nullptr );
+}
+
+extern "C" int x264hip_lookahead_get_frame_vbv( x264hip_lookahead *la, int flush, x264hip_la_frame *out, int *got, float *qp_offset,
+                                                 x264hip_la_vbv *vbv, int *row_satds, int *row_satds_intra )
+{
     if( !la || !out || !got ) return X264HIP_EINVAL;
     Lookahead &L = la->L;
     ScopeNs tm_api( L.stats[7] );
@@ -1065,6 +1150,21 @@ extern "C" int x264hip_lookahead_get_frame_ex( x264hip_lookahead *la, int flush,
     if( qp_offset && L.be.get_qp_offsets && ( L.p.mb_tree || L.p.dev.aq_mode ) ) // the arrays exist with AQ on (frame.c:217-226)
         if( L.need( L.be.get_qp_offsets( L.be.user, f->slot, qp_offset ) ) )
             return L.err;
+    if( vbv )
+    {
+        vbv->n_planned = 0;
+        if( !is_b( f->i_type ) )
+            while( vbv->n_planned < LOOKAHEAD_MAX && f->planned_type[vbv->n_planned] != T_AUTO ) vbv->n_planned++;
+        memcpy( vbv->planned_type, f->planned_type, sizeof( vbv->planned_type ) );
+        memcpy( vbv->planned_satd, f->planned_satd, sizeof( vbv->planned_satd ) );
+        if( is_b( f->i_type ) ) vbv->planned_type[0] = T_AUTO;
+        vbv->dist_p0 = f->own_d0; vbv->dist_p1 = f->own_d1;
+    }
+    if( ( row_satds || row_satds_intra ) && !L.be.get_row_satds ) return X264HIP_EINVAL;
+    if( row_satds && f->cost_est[f->own_d0][f->own_d1] >= 0 )
+        if( L.need( L.be.get_row_satds( L.be.user, f->slot, f->own_d0, f->own_d1, row_satds ) ) ) return L.err;
+    if( row_satds_intra && f->intra_calculated )
+        if( L.need( L.be.get_row_satds( L.be.user, f->slot, 0, 0, row_satds_intra ) ) ) return L.err;
     L.release( f );
     return X264HIP_OK;
 }

@@ -264,7 +264,7 @@ class LaParams(C.Structure):
     _fields_ = [("dev", Params), ("keyint_max", C.c_int), ("keyint_min", C.c_int), ("scenecut_threshold", C.c_int),
                 ("b_adapt", C.c_int), ("b_pyramid", C.c_int), ("rc_lookahead", C.c_int), ("mb_tree", C.c_int),
                 ("weightp", C.c_int), ("open_gop", C.c_int), ("frame_refs", C.c_int), ("psy", C.c_int),
-                ("rc_is_cqp", C.c_int), ("fps_num", C.c_int), ("fps_den", C.c_int), ("qcompress", C.c_float)]
+                ("rc_is_cqp", C.c_int), ("fps_num", C.c_int), ("fps_den", C.c_int), ("qcompress", C.c_float), ("vbv", C.c_int)]
 
 
 FRAME_PUT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int)
@@ -281,11 +281,24 @@ PUT_BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.P
 PREFETCH_WEIGHTS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(Weight))
 
 
+RECALC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int))
+ROW_SATDS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int))
+
+
 class Backend(C.Structure):
     _fields_ = [("user", C.c_void_p), ("frame_put", FRAME_PUT_FN), ("frame_stats", FRAME_STATS_FN),
                 ("weight_cost", WEIGHT_COST_FN), ("frame_cost", FRAME_COST_FN), ("prefetch", PREFETCH_FN),
                 ("mbtree", MBTREE_FN), ("get_qp_offsets", QP_OFFSETS_FN), ("frame_put_batch", PUT_BATCH_FN),
-                ("prefetch_weight_costs", PREFETCH_WEIGHTS_FN)]
+                ("prefetch_weight_costs", PREFETCH_WEIGHTS_FN), ("frame_cost_recalculate", RECALC_FN),
+                ("get_row_satds", ROW_SATDS_FN)]
+
+
+LOOKAHEAD_MAX = 250
+
+
+class LaVbv(C.Structure):
+    _fields_ = [("n_planned", C.c_int), ("planned_type", C.c_int * (LOOKAHEAD_MAX + 1)), ("planned_satd", C.c_int * (LOOKAHEAD_MAX + 1)),
+                ("dist_p0", C.c_int), ("dist_p1", C.c_int)]
 
 
 class LaFrameOut(C.Structure):
@@ -306,7 +319,7 @@ PRESETS = {
     "veryfast": dict(subme=2, rc_lookahead=10, weightp=1, frame_refs=1),
     "superfast": dict(me="dia", subme=1, rc_lookahead=0, mb_tree=0, weightp=1, frame_refs=1),
     "ultrafast": dict(me="dia", subme=0, rc_lookahead=0, mb_tree=0, weightp=0, frame_refs=1, scenecut=0, bframes=0, b_adapt=0,
-                      aq_mode=0, weighted_bipred=0),
+                      aq_mode=0, weighted_bipred=0, transform_8x8=0),
     "placebo": dict(subme=11, rc_lookahead=60, b_adapt=2, me="tesa", me_range=24, bframes=16, frame_refs=16),
 }
 # x264_param_apply_tune (common/base.c:606-700), the fields the lookahead reads; applied after the preset, before overrides
@@ -323,19 +336,37 @@ TUNES = {
 _ME = {"dia": 0, "hex": 1, "umh": 2, "esa": 3, "tesa": 4}
 
 
-def mv_range_for(width, height, fps=25.0):
-    """param.analyse.i_mv_range as derived from the automatically chosen level (encoder/set.c
-    x264_validate_levels / encoder.c:1265-1268): the smallest level whose frame size, MB rate and DPB fit."""
-    mbs = ((width + 15) // 16) * ((height + 15) // 16)
-    # (frame_size, mbps, mv_range) of common/tables.c x264_levels, ascending
-    levels = [(99, 1485, 64), (99, 1485, 64), (396, 3000, 128), (396, 6000, 128), (396, 11880, 128), (396, 11880, 128),
-              (792, 19800, 256), (1620, 20250, 256), (1620, 40500, 256), (3600, 108000, 512), (5120, 216000, 512),
-              (8192, 245760, 512), (8192, 245760, 512), (8704, 522240, 512), (22080, 589824, 512), (36864, 983040, 512),
-              (36864, 2073600, 512), (139264, 4177920, 512), (139264, 8355840, 512), (139264, 16711680, 512)]
-    for fs, mbps, mvr in levels:
-        if mbs <= fs and mbs * fps <= mbps:
+# common/tables.c x264_levels (H.264 Table A-1): (level_idc, MB/s, frame MBs, DPB MBs, kbit/s, CPB kbit, mv_range)
+LEVELS = [(10, 1485, 99, 396, 64, 175, 64), (9, 1485, 99, 396, 128, 350, 64), (11, 3000, 396, 900, 192, 500, 128),
+          (12, 6000, 396, 2376, 384, 1000, 128), (13, 11880, 396, 2376, 768, 2000, 128), (20, 11880, 396, 2376, 2000, 2000, 128),
+          (21, 19800, 792, 4752, 4000, 4000, 256), (22, 20250, 1620, 8100, 4000, 4000, 256), (30, 40500, 1620, 8100, 10000, 10000, 256),
+          (31, 108000, 3600, 18000, 14000, 14000, 512), (32, 216000, 5120, 20480, 20000, 20000, 512),
+          (40, 245760, 8192, 32768, 20000, 25000, 512), (41, 245760, 8192, 32768, 50000, 62500, 512),
+          (42, 522240, 8704, 34816, 50000, 62500, 512), (50, 589824, 22080, 110400, 135000, 135000, 512),
+          (51, 983040, 36864, 184320, 240000, 240000, 512), (52, 2073600, 36864, 184320, 240000, 240000, 512),
+          (60, 4177920, 139264, 696320, 240000, 240000, 8192), (61, 8355840, 139264, 696320, 480000, 480000, 8192),
+          (62, 16711680, 139264, 696320, 800000, 800000, 8192)]
+
+
+def mv_range_for(width, height, fps_num=25, fps_den=1, bit_depth=8, frame_refs=3, bframes=3, b_pyramid=2, keyint_max=250,
+                 transform_8x8=1, bitrate=0, vbv_maxrate=0, vbv_bufsize=0):
+    """param.analyse.i_mv_range of the automatically chosen level (encoder.c:1243-1268): the first level of the table that
+    x264_validate_levels (encoder/set.c:876-913) accepts -- frame size, decoded picture buffer, VBV rate and buffer against the
+    profile's limits, macroblock rate -- or the last one."""
+    mb_w, mb_h = (width + 15) // 16, (height + 15) // 16
+    mbs = mb_w * mb_h
+    # x264_sps_init (encoder/set.c:114-157)
+    cbp_factor = 12 if bit_depth > 8 else 5 if transform_8x8 else 4
+    reorder = 2 if b_pyramid else 1 if bframes else 0
+    dec_buffering = 0 if keyint_max == 1 else min(16, max(frame_refs, 1 + reorder, 4 if b_pyramid else 1, 1))
+    if bitrate and not vbv_bufsize:  # encoder.c:1248-1249: ABR without VBV is checked as if maxrate were twice the bitrate
+        vbv_maxrate = bitrate * 2
+    for idc, mbps, frame_size, dpb, kbps, cpb, mvr in LEVELS:
+        if (frame_size >= mbs and frame_size * 8 >= mb_w * mb_w and frame_size * 8 >= mb_h * mb_h and mbs * dec_buffering <= dpb and
+                vbv_maxrate <= kbps * cbp_factor // 4 and vbv_bufsize <= cpb * cbp_factor // 4 and
+                (fps_den <= 0 or mbs * fps_num // fps_den <= mbps)):
             return mvr
-    return 512
+    return LEVELS[-1][6]
 
 
 def la_config(width, height, preset="medium", bit_depth=8, tune="", **over):
@@ -344,7 +375,7 @@ def la_config(width, height, preset="medium", bit_depth=8, tune="", **over):
     c = dict(bframes=3, b_adapt=1, b_pyramid=2, rc_lookahead=40, me="hex", me_range=16, subme=7, weightp=2,
              weighted_bipred=1, mb_tree=1, aq_mode=1, aq_strength=1.0, scenecut=40, keyint_max=250, keyint_min=0,
              open_gop=0, frame_refs=3, psy=1, rc_is_cqp=0, bframe_bias=0, fps=25.0, mv_range=0, fps_num=25, fps_den=1,
-             qcompress=0.6, threads=1, lookahead_threads=0)
+             qcompress=0.6, threads=1, lookahead_threads=0, bitrate=0, vbv_maxrate=0, vbv_bufsize=0, transform_8x8=1)
     c.update(PRESETS[preset])
     for t in filter(None, tune.replace(",", " ").split()):
         tv = dict(TUNES[t])
@@ -363,6 +394,22 @@ def la_config(width, height, preset="medium", bit_depth=8, tune="", **over):
     if c["rc_is_cqp"]:                                                       # :951-966
         c["aq_mode"] = 0
         c["mb_tree"] = 0
+    c["bitrate"] = clip(c["bitrate"], 0, 2000000)                             # :973-1009, rc method ABR when a bitrate is given
+    c["vbv_bufsize"] = clip(c["vbv_bufsize"], 0, 2000000)
+    c["vbv_maxrate"] = clip(c["vbv_maxrate"], 0, 2000000)
+    if c["vbv_bufsize"]:
+        if c["rc_is_cqp"]:
+            c["vbv_maxrate"] = c["vbv_bufsize"] = 0
+        elif not c["vbv_maxrate"]:
+            if c["bitrate"]:
+                c["vbv_maxrate"] = c["bitrate"]
+            else:
+                c["vbv_bufsize"] = 0
+        elif c["bitrate"] and c["vbv_maxrate"] < c["bitrate"]:
+            c["bitrate"] = c["vbv_maxrate"]
+    elif c["vbv_maxrate"]:
+        c["vbv_maxrate"] = 0
+    c["vbv"] = int(c["vbv_bufsize"] > 0)
     c["frame_refs"] = clip(c["frame_refs"], 1, 16)                           # :1064
     c["scenecut"] = max(c["scenecut"], 0)                                    # :1066-1067
     c["bframes"] = clip(c["bframes"], 0, min(16, c["keyint_max"] - 1))       # :1074
@@ -378,7 +425,9 @@ def la_config(width, height, preset="medium", bit_depth=8, tune="", **over):
     if c["keyint_min"] <= 0:                                                 # :1109-1111 (0 = X264_KEYINT_MIN_AUTO)
         c["keyint_min"] = min(c["keyint_max"] // 10, int(c["fps"]))
     c["keyint_min"] = clip(c["keyint_min"], 1, c["keyint_max"] // 2 + 1)
-    c["rc_lookahead"] = min(clip(c["rc_lookahead"], 0, 250), c["keyint_max"])  # :1112-1117, no VBV
+    maxrate = max(c["vbv_maxrate"], c["bitrate"])                             # :1112-1117 (float arithmetic as there)
+    bufsize = np.float32(c["vbv_bufsize"]) / np.float32(maxrate) if maxrate else np.float32(0)
+    c["rc_lookahead"] = int(min(np.float32(clip(c["rc_lookahead"], 0, 250)), max(np.float32(c["keyint_max"]), bufsize * np.float32(c["fps_num"] / c["fps_den"]))))
     c["qcompress"] = clip(c["qcompress"], 0.0, 1.0)                          # :1125
     if c["keyint_max"] == 1 or c["qcompress"] == 1:                          # :1126-1127
         c["mb_tree"] = 0
@@ -397,8 +446,10 @@ def la_config(width, height, preset="medium", bit_depth=8, tune="", **over):
     if not c["aq_mode"] and c["mb_tree"]:                                    # :1233-1237: MB-tree needs the AQ arrays
         c["aq_mode"] = 1
         c["aq_strength"] = 0.0
-    if c["mv_range"] <= 0:                                                   # :1265-1268
-        c["mv_range"] = mv_range_for(width, height, c["fps"])
+    if c["mv_range"] <= 0:                                                   # :1243-1268
+        c["mv_range"] = mv_range_for(width, height, c["fps_num"], c["fps_den"], bit_depth, c["frame_refs"], c["bframes"],
+                                     c["b_pyramid"], c["keyint_max"], c["transform_8x8"],
+                                     0 if c["rc_is_cqp"] else c["bitrate"], c["vbv_maxrate"], c["vbv_bufsize"])
     else:
         c["mv_range"] = clip(c["mv_range"], 32, 8192)
     c["weightp"] = clip(c["weightp"], 0, 2)                                  # :1271
@@ -420,7 +471,7 @@ def la_config(width, height, preset="medium", bit_depth=8, tune="", **over):
         c["lookahead_threads"] = min(c["threads"] // div[int(c["b_adapt"] == 2)][q_subme][q_b], height // 128)
     c["lookahead_threads"] = clip(c["lookahead_threads"], 1, min(max_sliced, 16))
     # slicetype.c:823 (no VBV): whether the evaluations visit the outermost ring of blocks
-    c["do_edges"] = int(c["mb_tree"] or (width + 15) // 16 <= 2 or mb_h <= 2)
+    c["do_edges"] = int(c["mb_tree"] or c["vbv"] or (width + 15) // 16 <= 2 or mb_h <= 2)
     # lowres_context_init (slicetype.c:45-61) and mbcmp_init (encoder.c:1409-1427)
     if c["subme"] > 1:
         c["la_me_method"] = min(1, me)
@@ -447,7 +498,7 @@ def make_la_params(cfg, cost_mv=None, max_frames=0):
                  max_frames, int(not cfg["do_edges"]), cfg["lookahead_threads"], cost_mv.ctypes.data + 2 * centre)
     p = LaParams(dev, cfg["keyint_max"], cfg["keyint_min"], cfg["scenecut"], cfg["b_adapt"], cfg["b_pyramid"],
                  cfg["rc_lookahead"], cfg["mb_tree"], cfg["weightp"], cfg["open_gop"], cfg["frame_refs"], cfg["psy"],
-                 cfg["rc_is_cqp"], cfg["fps_num"], cfg["fps_den"], cfg["qcompress"])
+                 cfg["rc_is_cqp"], cfg["fps_num"], cfg["fps_den"], cfg["qcompress"], cfg["vbv"])
     p._keep = cost_mv
     return p
 
@@ -496,11 +547,24 @@ class Lookahead:
         arr = (C.c_void_p * len(device_ptrs))(*device_ptrs)
         _ck(self.L.x264hip_lookahead_put_frames(self.h, len(device_ptrs), arr, stride or self.cfg["width"]), "lookahead_put_frames")
 
-    def get(self, flush=False, qp_offsets=False):
+    def get(self, flush=False, qp_offsets=False, vbv=False):
+        """vbv=True also returns what VBV rate control reads: out.planned (list of (type, satd)), out.own_cell, out.row_satds,
+        out.row_satds_intra (x264hip_lookahead_get_frame_vbv)."""
         out = LaFrameOut()
         got = C.c_int(0)
-        qp = np.zeros(((self.cfg["width"] + 15) // 16) * ((self.cfg["height"] + 15) // 16), np.float32) if qp_offsets else None
-        _ck(self.L.x264hip_lookahead_get_frame_ex(self.h, int(flush), C.byref(out), C.byref(got), _p(qp)), "lookahead_get_frame")
+        mb_h = (self.cfg["height"] + 15) // 16
+        qp = np.zeros(((self.cfg["width"] + 15) // 16) * mb_h, np.float32) if qp_offsets else None
+        if vbv:
+            v = LaVbv()
+            rows, rows_i = np.full(mb_h, -1, np.int32), np.full(mb_h, -1, np.int32)
+            _ck(self.L.x264hip_lookahead_get_frame_vbv(self.h, int(flush), C.byref(out), C.byref(got), _p(qp), C.byref(v), _p(rows),
+                                                       _p(rows_i)), "lookahead_get_frame_vbv")
+            if got.value:
+                out.planned = [(v.planned_type[i], v.planned_satd[i]) for i in range(v.n_planned)]
+                out.own_cell = (v.dist_p0, v.dist_p1)
+                out.row_satds, out.row_satds_intra = rows, rows_i
+        else:
+            _ck(self.L.x264hip_lookahead_get_frame_ex(self.h, int(flush), C.byref(out), C.byref(got), _p(qp)), "lookahead_get_frame")
         if got.value and qp_offsets:
             out.qp_offset = qp
         return out if got.value else None
@@ -510,7 +574,7 @@ class Lookahead:
         _ck(self.L.x264hip_lookahead_stats(self.h, _p(out), 8), "lookahead_stats")
         return out
 
-    def run(self, frames=None, device_ptrs=None, stride=None, paced=True, qp_offsets=False, forced_types=None):
+    def run(self, frames=None, device_ptrs=None, stride=None, paced=True, qp_offsets=False, forced_types=None, vbv=False):
         """Feed a whole clip.  paced=True interleaves put/get exactly like x264_encoder_encode; paced=False puts
         every frame first (deep prefetch) -- results are identical, only the batching differs."""
         outs = []
@@ -527,11 +591,11 @@ class Lookahead:
             else:
                 self.put(device_ptr=device_ptrs[i], stride=stride, forced_type=ft)
             if paced:
-                o = self.get(False, qp_offsets)
+                o = self.get(False, qp_offsets, vbv)
                 if o is not None:
                     outs.append(o)
         while len(outs) < n:
-            o = self.get(True, qp_offsets)
+            o = self.get(True, qp_offsets, vbv)
             if o is None:
                 break
             outs.append(o)
