@@ -51,6 +51,10 @@ LOOKAHEAD_CASES_R2 = {
                   dict(seed=24, scene_cuts=(30,), pan=(2, 3), fade=(10, 10, 0.6, 15)), 44),
     "bands3_cif": ("medium", "threads=6,sync-lookahead=0,lookahead-threads=3", dict(threads=6, lookahead_threads=3), 8, 352, 288,
                    dict(seed=16, pan=(23, 11), noise=30, texture=0.9, scene_cuts=(20,)), 40),
+    "vbv_cif": ("medium", "bitrate=500,vbv-bufsize=300,vbv-maxrate=600", dict(bitrate=500, vbv_bufsize=300, vbv_maxrate=600), 8, 352, 288,
+                dict(seed=21, scene_cuts=(23,), pan=(4, 2), fade=(30, 8, 0.6, 10)), 44),
+    "vbv_no_mbtree": ("fast", "vbv-bufsize=200,vbv-maxrate=400,mbtree=0,b-adapt=2", dict(vbv_bufsize=200, vbv_maxrate=400, mb_tree=0, b_adapt=2),
+                      8, 176, 144, dict(seed=22, scene_cuts=(15,)), 40),
     "bands_auto_720p": ("veryslow", "threads=24,sync-lookahead=0,lookahead-threads=auto", dict(threads=24), 8, 1280, 720, dict(seed=20, pan=(9, 4)), 20),
 }
 
@@ -64,11 +68,15 @@ def gen_lookahead(only=None):
             continue
         frames = make_clip(W, H, nf, bit_depth=depth, **ckw)
         r = refharness.Ref(W, H, preset, opts=opts, bit_depth=depth)
-        ref = r.lookahead_run(frames, with_qp_offsets=True)
+        vbv = bool(over.get("vbv_bufsize"))
+        ref = r.lookahead_run(frames, with_qp_offsets=True, with_vbv=vbv)
         nb = r.cfg["bframes"] + 2
         extra = {}
+        if vbv:  # what VBV rate control reads: planned types / costs, row sums of every allocated cell
+            extra = dict(planned_type=ref["planned_type"].astype(np.uint8), planned_satd=ref["planned_satd"],
+                         row_satds=ref["row_satds"][:, :nb, :nb])
         if W * H <= 352 * 288:  # MB-tree outputs (f_qp_offset, i_propagate_cost) of every frame as it leaves the lookahead
-            extra = dict(qp_offset=ref["qp_offset"], propagate=ref["propagate"])
+            extra.update(qp_offset=ref["qp_offset"], propagate=ref["propagate"])
         np.savez_compressed(os.path.join(OUT, "lookahead_%s.npz" % name), idx=ref["idx"], type=ref["type"].astype(np.int8),
                             cost=ref["cost"][:, :nb, :nb], cost_aq=ref["cost_aq"][:, :nb, :nb],
                             cfg=np.array([r.cfg[k] for k in sorted(r.cfg)], np.int64), cfg_keys=np.array(sorted(r.cfg)), **extra)

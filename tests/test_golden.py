@@ -137,6 +137,21 @@ def check_lookahead_outputs(outs, z, nb, check_qp=True):
         for k, o in enumerate(outs):
             assert np.array_equal(o.qp_offset, z["qp_offset"][k]), ("f_qp_offset", k, o.frame, o.type,
                                                                    float(np.abs(o.qp_offset - z["qp_offset"][k]).max()))
+    if "planned_type" in z and hasattr(outs[0], "planned"):
+        # VBV outputs (slicetype.c:1224-1286, :1916-1934): plans of the non-B frames, row sums of the cell each frame is coded with
+        for k, o in enumerate(outs):
+            if o.type not in (4, 5):
+                want = []
+                for t, s in zip(z["planned_type"][k], z["planned_satd"][k]):
+                    if t == 0:
+                        break
+                    want.append((int(t), int(s)))
+                assert o.planned == want, ("i_planned_type/satd", k, o.frame)
+            d0, d1 = o.own_cell
+            if o.cost_est[d0][d1] >= 0:
+                assert np.array_equal(o.row_satds, z["row_satds"][k][d0][d1]), ("i_row_satds", k, o.frame, d0, d1)
+            if o.row_satds_intra[0] != -1:
+                assert np.array_equal(o.row_satds_intra, z["row_satds"][k][0][0]), ("i_row_satds[0][0]", k, o.frame)
     for k, o in enumerate(outs):
         ce = np.array([[o.cost_est[i][j] for j in range(nb)] for i in range(nb)])
         ca = np.array([[o.cost_est_aq[i][j] for j in range(nb)] for i in range(nb)])
@@ -154,10 +169,10 @@ def test_host_lookahead_vs_golden(name):
     be = OracleBackend(cfg)
     la = lib.Lookahead(cfg, backend=be.struct)
     try:
-        outs = la.run(frames, qp_offsets=True)
+        outs = la.run(frames, qp_offsets=True, vbv=bool(cfg["vbv"]))
     finally:
         la.close()
-    check_lookahead_outputs(outs, z, cfg["bframes"] + 2)
+    check_lookahead_outputs(outs, z, cfg["bframes"] + 2, check_qp=bool(cfg["aq_mode"]))
 
 
 @pytest.mark.parametrize("depth", [8, 10])

@@ -1,6 +1,6 @@
 """GPU end-to-end for the configurations whose device paths were written after the last GPU session of round 1: edge ring
 not evaluated (no MB-tree: --no-mbtree, --qp, superfast / ultrafast, qcomp 1), lookahead bands (lookahead_threads > 1),
-auto-variance AQ (aq-mode 2 / 3), constant QP.  Same golden fixtures and checks as tests/test_gpu_lookahead.py; the file
+auto-variance AQ (aq-mode 2 / 3), constant QP, VBV lookahead.  Same golden fixtures and checks as tests/test_gpu_lookahead.py; the file
 name sorts last on purpose, so that with `pytest -x` a failure here cannot hide the results of the verified files."""
 import os
 
@@ -24,7 +24,7 @@ def test_lookahead_vs_golden_new_configs(name, paced):
     cfg = lib.la_config(W, H, preset, bit_depth=depth, **over)
     la = lib.Lookahead(cfg, max_frames=0 if paced else nf + 4)
     try:
-        outs = la.run(frames, paced=paced, qp_offsets=True)
+        outs = la.run(frames, paced=paced, qp_offsets=True, vbv=bool(cfg["vbv"]))
     finally:
         la.close()
     check_lookahead_outputs(outs, z, cfg["bframes"] + 2, check_qp=bool(cfg["aq_mode"]))
