@@ -431,15 +431,9 @@ struct Lookahead
         if( b_intra ) frame_cost( frames, 0, 0, 0 );
         while( i > 0 && is_b( frames[i]->i_type ) ) i--;
         last_nonb = i;
-        if( !p.rc_lookahead )
-        {
-            if( b_intra ) return; // lookahead-less MB-tree needs rc state that lives in the encoder; not mirrored
-        }
-        else
-        {
-            if( last_nonb < idx ) return;
-            mbt_zero( ops, frames[last_nonb] );
-        }
+        // (rc_lookahead == 0 with MB-tree on -- the extrapolating lookahead-less form, :1112-1124 -- is rejected at open)
+        if( last_nonb < idx ) return;
+        mbt_zero( ops, frames[last_nonb] );
         while( i-- > idx )
         {
             cur_nonb = i;
@@ -476,14 +470,9 @@ struct Lookahead
             mbt_propagate( ops, frames, average_duration, cur_nonb, last_nonb, last_nonb, 1 );
             last_nonb = cur_nonb;
         }
-        if( !p.rc_lookahead )
-            frame_cost( frames, 0, last_nonb, last_nonb );
-        else
-        {
-            mbt_finish( ops, frames[last_nonb], average_duration, last_nonb );
-            if( p.b_pyramid && bframes > 1 && !p.vbv ) // :1182-1183
-                mbt_finish( ops, frames[last_nonb + ( bframes + 1 ) / 2], average_duration, 0 );
-        }
+        mbt_finish( ops, frames[last_nonb], average_duration, last_nonb );
+        if( p.b_pyramid && bframes > 1 && !p.vbv ) // :1182-1183
+            mbt_finish( ops, frames[last_nonb + ( bframes + 1 ) / 2], average_duration, 0 );
         if( be.mbtree && !ops.empty() && !err )
         {
             ScopeNs tm( stats[6] );
@@ -947,6 +936,12 @@ static int la_init( x264hip_lookahead *la, const x264hip_la_params *params )
     if( p.dev.bframes < 0 || p.dev.bframes > BMAX || p.keyint_max < 1 || p.rc_lookahead < 0 || p.rc_lookahead > LOOKAHEAD_MAX ||
         p.b_adapt < 0 || p.b_adapt > 2 || p.b_pyramid < 0 || p.b_pyramid > 2 )
         return X264HIP_EINVAL;
+    if( p.mb_tree && !p.rc_lookahead )
+    {
+        // only reachable with keyint = infinite (or intra refresh, which is not mirrored either): encoder.c:1128-1133
+        fprintf( stderr, "x264hip_lookahead: lookahead-less MB-tree (rc_lookahead = 0 with MB-tree on, slicetype.c:1112-1124) is not implemented\n" );
+        return X264HIP_EINVAL;
+    }
     // encoder.c:1601-1612 with one frame thread, no lookahead thread, cfr input
     if( p.b_adapt == 2 )
         L.i_delay = ( p.dev.bframes > 3 ? p.dev.bframes : 3 ) * 4;
