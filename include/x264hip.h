@@ -304,8 +304,10 @@ int  x264hip_lookahead_get_frame_ex( x264hip_lookahead *la, int flush, x264hip_l
  * 2290-2320, and x264_rc_analyse_slice, slicetype.c:1976-2030):
  *  - i_planned_type / i_planned_satd: types and costs of the following frames in coded order, ended by type 0 (AUTO); filled by
  *    the last analysis that saw the frame as the next non-B frame (or as the key frame just decided); n_planned = 0 for B frames
- *  - the (dist_p0, dist_p1) cell the frame is coded with and that cell's i_row_satds, plus the intra row sums i_row_satds[0][0]
- *    (row_satds / row_satds_intra: caller buffers of mb_h ints, may be NULL).
+ *  - the (dist_p0, dist_p1) cell the frame is coded with, satd = the return value of x264_rc_analyse_slice for it, and that cell's
+ *    i_row_satds plus the intra row sums i_row_satds[0][0] as x264_rc_analyse_slice leaves them (with MB-tree: rewritten by
+ *    slicetype_frame_cost_recalculate); row_satds / row_satds_intra: caller buffers of mb_h ints, may be NULL.  Usable without
+ *    VBV too (n_planned = 0 then): satd is what ABR / CRF rate control reads as the frame's complexity.
  * The f_planned_cpb_duration bookkeeping (calculate_durations, slicetype.c:1200-1222) is left to the caller: it is the frame
  * duration for progressive constant-frame-rate input. */
 #define X264HIP_LOOKAHEAD_MAX 250 /* X264_LOOKAHEAD_MAX, common/common.h */
@@ -315,6 +317,9 @@ typedef struct x264hip_la_vbv
     int planned_type[X264HIP_LOOKAHEAD_MAX + 1];
     int planned_satd[X264HIP_LOOKAHEAD_MAX + 1];
     int dist_p0, dist_p1;
+    int satd;                 /* what x264_rc_analyse_slice returns for the frame (slicetype.c:1976-2009, no intra refresh): the cell's
+                               * cost, recalculated under the final f_qp_offset with MB-tree, the AQ-weighted cost otherwise; -1 when the
+                               * cell was never evaluated (constant QP) */
 } x264hip_la_vbv;
 int  x264hip_lookahead_get_frame_vbv( x264hip_lookahead *la, int flush, x264hip_la_frame *out, int *got, float *qp_offset,
                                       x264hip_la_vbv *vbv, int *row_satds, int *row_satds_intra );

@@ -412,6 +412,12 @@ RH_API void rh_set_prop_dump( uint16_t *buf ) { rh_out_prop = buf; }
 static int *rh_out_planned_type = NULL, *rh_out_planned_satd = NULL; /* optional [n_frames][X264_LOOKAHEAD_MAX+1] */
 static int *rh_out_rows = NULL; /* optional [n_frames][(X264_BFRAME_MAX+2)^2][mb_h] dump of i_row_satds (cells that are not allocated stay untouched) */
 RH_API void rh_set_vbv_dump( int *planned_type, int *planned_satd, int *rows ) { rh_out_planned_type = planned_type; rh_out_planned_satd = planned_satd; rh_out_rows = rows; }
+/* optional: run the real x264_rc_analyse_slice (slicetype.c:1976-2032) on every frame as it leaves, the way rate control does when
+ * the frame gets encoded.  For B frames the caller supplies the distances to the nearest references (cells[k] = { b-p0, p1-b } of
+ * output k; what fref_nearest gives in the encoder); out[k] = { returned cost, i_row_satd[mb_h], i_row_satds[0][0][mb_h] }. */
+static const int *rh_rc_cells = NULL;
+static int *rh_out_rc = NULL;
+RH_API void rh_set_rc_dump( const int *cells, int *out ) { rh_rc_cells = cells; rh_out_rc = out; }
 static const int *rh_forced_types = NULL; /* optional [n_frames] x264_picture_t.i_type of every input picture (x264.h:274-280) */
 RH_API void rh_set_forced_types( const int *types ) { rh_forced_types = types; }
 
@@ -440,6 +446,26 @@ static int rh_drain_one( x264_t *h, int *out_idx, int *out_type, int *out_cost, 
             for( int j = 0; j <= h->param.i_bframe+1; j++ )
                 memcpy( rh_out_rows + ((size_t)n_out*(X264_BFRAME_MAX+2)*(X264_BFRAME_MAX+2) + i*(X264_BFRAME_MAX+2) + j)*h->mb.i_mb_height,
                         f->i_row_satds[i][j], h->mb.i_mb_height*sizeof(int) );
+    /* (rate control analyses B frames only with VBV, ratecontrol.c:2472-2474; without it their cell may not even exist) */
+    if( rh_out_rc && h->param.rc.i_rc_method != X264_RC_CQP && ( !IS_X264_TYPE_B( f->i_type ) || h->param.rc.i_vbv_buffer_size ) )
+    {
+        static x264_frame_t near0, near1;
+        int mbh = h->mb.i_mb_height;
+        int *o = rh_out_rc + (size_t)n_out*(1 + 2*mbh);
+        x264_frame_t *fenc_bak = h->fenc, *fdec_bak = h->fdec;
+        h->fenc = f; h->fdec = f;
+        if( IS_X264_TYPE_B( f->i_type ) )
+        {
+            near0.i_poc = 0;
+            f->i_poc = 2*rh_rc_cells[2*n_out];
+            near1.i_poc = 2*(rh_rc_cells[2*n_out] + rh_rc_cells[2*n_out+1]);
+            h->fref_nearest[0] = &near0; h->fref_nearest[1] = &near1;
+        }
+        o[0] = x264_rc_analyse_slice( h );
+        memcpy( o + 1, f->i_row_satd, mbh*sizeof(int) );
+        memcpy( o + 1 + mbh, f->i_row_satds[0][0], mbh*sizeof(int) );
+        h->fenc = fenc_bak; h->fdec = fdec_bak;
+    }
     x264_frame_push_unused( h, f );
     return 0;
 }

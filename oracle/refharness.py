@@ -122,7 +122,9 @@ class Ref:
         assert r == 0
         return lc, rows, tuple(int(x) for x in summ)
 
-    def lookahead_run(self, luma_frames, with_qp_offsets=False, forced_types=None, with_vbv=False):
+    def lookahead_run(self, luma_frames, with_qp_offsets=False, forced_types=None, with_vbv=False, rc_cells=None):
+        """rc_cells: [n, 2] (b-p0, p1-b) per OUTPUT index -> also runs the real x264_rc_analyse_slice on every leaving frame
+        (out["rc"][k] = [cost, i_row_satd..., i_row_satds[0][0]...])."""
         """luma_frames: [n, H, W]; returns dict(idx, type, cost, cost_aq, intra_mbs, seconds, seconds_prep[, qp_offset])."""
         fr = np.ascontiguousarray(luma_frames, dtype=self.dtype)
         n = fr.shape[0]
@@ -141,6 +143,10 @@ class Ref:
         ps = np.zeros((n, 251), np.int32) if with_vbv else None
         rows = np.full((n, 18, 18, self.mb_h), -2, np.int32) if with_vbv else None
         self.lib.rh_set_vbv_dump(_ptr(pt), _ptr(ps), _ptr(rows))
+        self.lib.rh_set_rc_dump.argtypes = [C.c_void_p] * 2
+        rcc = np.ascontiguousarray(rc_cells, np.int32) if rc_cells is not None else None
+        rco = np.zeros((n, 1 + 2 * self.mb_h), np.int32) if rc_cells is not None else None
+        self.lib.rh_set_rc_dump(_ptr(rcc), _ptr(rco))
         idx = np.zeros(n, np.int32)
         typ = np.zeros(n, np.int32)
         cost = np.zeros((n, 18, 18), np.int32)
@@ -154,6 +160,7 @@ class Ref:
               C.byref(sec), C.byref(sec_prep))
         self.lib.rh_set_forced_types(None)
         self.lib.rh_set_vbv_dump(None, None, None)
+        self.lib.rh_set_rc_dump(None, None)
         assert r == n, (r, n)
         self.lib.rh_set_qp_dump(None)
         self.lib.rh_set_prop_dump(None)
@@ -164,4 +171,6 @@ class Ref:
             out["propagate"] = prop
         if with_vbv:
             out["planned_type"], out["planned_satd"], out["row_satds"] = pt, ps, rows
+        if rco is not None:
+            out["rc"] = rco
         return out

@@ -78,3 +78,21 @@ def oracle_me_search(o, me, planes, integral, cost_mv, geom, fenc, call):
     f.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_int, _C.c_void_p]
     f(_C.byref(m), mvc.ctypes.data, n_mvc, out.ctypes.data)
     return out
+
+
+def nearest_ref_cells(idx, typ):
+    """(b-p0, p1-b) of every frame of a coded-order sequence as the encoder's fref_nearest gives them (x264_rc_analyse_slice,
+    slicetype.c:1982-1991): distances to the nearest already coded reference before and after the frame in display order.
+    Independent of the host logic's own bookkeeping (which is checked against it)."""
+    cells, refs = [], []
+    for f, t in zip(idx, typ):
+        f, t = int(f), int(t)
+        if t in (4, 5):
+            cells.append((f - max(r for r in refs if r < f), min(r for r in refs if r > f) - f))
+        elif t in (1, 2):
+            cells.append((0, 0))
+        else:
+            cells.append((f - max(r for r in refs if r < f), 0))
+        if t != 5:
+            refs.append(f)
+    return cells

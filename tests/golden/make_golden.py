@@ -10,7 +10,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import refharness  # noqa: E402
-from tests.common import clip  # noqa: E402
+from tests.common import clip, nearest_ref_cells  # noqa: E402
 from x264_amd.synth import make_clip  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
@@ -69,12 +69,17 @@ def gen_lookahead(only=None):
         frames = make_clip(W, H, nf, bit_depth=depth, **ckw)
         r = refharness.Ref(W, H, preset, opts=opts, bit_depth=depth)
         vbv = bool(over.get("vbv_bufsize"))
-        ref = r.lookahead_run(frames, with_qp_offsets=True, with_vbv=vbv)
+        cells = None
+        if vbv:  # first pass for the coded order, from which the nearest references of every B frame follow
+            first = r.lookahead_run(frames)
+            cells = np.array(nearest_ref_cells(first["idx"], first["type"]), np.int32)
+            r.close()
+            r = refharness.Ref(W, H, preset, opts=opts, bit_depth=depth)
+        ref = r.lookahead_run(frames, with_qp_offsets=True, with_vbv=vbv, rc_cells=cells)
         nb = r.cfg["bframes"] + 2
         extra = {}
-        if vbv:  # what VBV rate control reads: planned types / costs, row sums of every allocated cell
-            extra = dict(planned_type=ref["planned_type"].astype(np.uint8), planned_satd=ref["planned_satd"],
-                         row_satds=ref["row_satds"][:, :nb, :nb])
+        if vbv:  # what VBV rate control reads: planned types / costs, and per frame the result of the real x264_rc_analyse_slice
+            extra = dict(planned_type=ref["planned_type"].astype(np.uint8), planned_satd=ref["planned_satd"], rc=ref["rc"], rc_cells=cells)
         if W * H <= 352 * 288:  # MB-tree outputs (f_qp_offset, i_propagate_cost) of every frame as it leaves the lookahead
             extra.update(qp_offset=ref["qp_offset"], propagate=ref["propagate"])
         np.savez_compressed(os.path.join(OUT, "lookahead_%s.npz" % name), idx=ref["idx"], type=ref["type"].astype(np.int8),

@@ -147,11 +147,13 @@ def check_lookahead_outputs(outs, z, nb, check_qp=True):
                         break
                     want.append((int(t), int(s)))
                 assert o.planned == want, ("i_planned_type/satd", k, o.frame)
-            d0, d1 = o.own_cell
-            if o.cost_est[d0][d1] >= 0:
-                assert np.array_equal(o.row_satds, z["row_satds"][k][d0][d1]), ("i_row_satds", k, o.frame, d0, d1)
-            if o.row_satds_intra[0] != -1:
-                assert np.array_equal(o.row_satds_intra, z["row_satds"][k][0][0]), ("i_row_satds[0][0]", k, o.frame)
+            # x264_rc_analyse_slice of the reference on the leaving frame: the cell, its cost and the row sums it leaves behind
+            mbh = len(o.row_satds)
+            assert o.own_cell == tuple(int(v) for v in z["rc_cells"][k]), ("cell", k, o.frame)
+            assert o.rc_satd == z["rc"][k][0], ("rc satd", k, o.frame)
+            assert np.array_equal(o.row_satds, z["rc"][k][1:1 + mbh]), ("i_row_satd", k, o.frame)
+            if o.type not in (1, 2):
+                assert np.array_equal(o.row_satds_intra, z["rc"][k][1 + mbh:]), ("i_row_satds[0][0]", k, o.frame)
     for k, o in enumerate(outs):
         ce = np.array([[o.cost_est[i][j] for j in range(nb)] for i in range(nb)])
         ca = np.array([[o.cost_est_aq[i][j] for j in range(nb)] for i in range(nb)])

@@ -1154,11 +1154,29 @@ extern "C" int x264hip_lookahead_get_frame_vbv( x264hip_lookahead *la, int flush
         memcpy( vbv->planned_satd, f->planned_satd, sizeof( vbv->planned_satd ) );
         if( is_b( f->i_type ) ) vbv->planned_type[0] = T_AUTO;
         vbv->dist_p0 = f->own_d0; vbv->dist_p1 = f->own_d1;
+        // x264_rc_analyse_slice (slicetype.c:1976-2009), the part without intra refresh: the frame's cost as rate control
+        // takes it, and with MB-tree the row sums rewritten under the final quantiser offsets
+        // (rate control analyses B frames only with VBV, ratecontrol.c:2472-2474; without it their cell may never have been evaluated)
+        int cost = is_b( f->i_type ) && !L.p.vbv ? -1 : f->cost_est[f->own_d0][f->own_d1];
+        if( cost >= 0 )
+        {
+            if( L.p.mb_tree )
+            {
+                if( !L.be.frame_cost_recalculate ) return X264HIP_EINVAL;
+                if( L.need( L.be.frame_cost_recalculate( L.be.user, f->slot, f->own_d0, f->own_d1, is_b( f->i_type ), &cost ) ) ) return L.err;
+                int unused = 0;
+                if( f->own_d0 && L.p.vbv && f->cost_est[0][0] >= 0 )
+                    if( L.need( L.be.frame_cost_recalculate( L.be.user, f->slot, 0, 0, is_b( f->i_type ), &unused ) ) ) return L.err;
+            }
+            else if( L.p.dev.aq_mode )
+                cost = f->cost_est_aq[f->own_d0][f->own_d1];
+        }
+        vbv->satd = cost;
     }
     if( ( row_satds || row_satds_intra ) && !L.be.get_row_satds ) return X264HIP_EINVAL;
     if( row_satds && f->cost_est[f->own_d0][f->own_d1] >= 0 )
         if( L.need( L.be.get_row_satds( L.be.user, f->slot, f->own_d0, f->own_d1, row_satds ) ) ) return L.err;
-    if( row_satds_intra && f->intra_calculated )
+    if( row_satds_intra && f->cost_est[0][0] >= 0 ) // computed by any evaluation that found them missing, B evaluations included (slicetype.c:714-757)
         if( L.need( L.be.get_row_satds( L.be.user, f->slot, 0, 0, row_satds_intra ) ) ) return L.err;
     L.release( f );
     return X264HIP_OK;

@@ -298,7 +298,7 @@ LOOKAHEAD_MAX = 250
 
 class LaVbv(C.Structure):
     _fields_ = [("n_planned", C.c_int), ("planned_type", C.c_int * (LOOKAHEAD_MAX + 1)), ("planned_satd", C.c_int * (LOOKAHEAD_MAX + 1)),
-                ("dist_p0", C.c_int), ("dist_p1", C.c_int)]
+                ("dist_p0", C.c_int), ("dist_p1", C.c_int), ("satd", C.c_int)]
 
 
 class LaFrameOut(C.Structure):
@@ -564,6 +564,7 @@ class Lookahead:
             if got.value:
                 out.planned = [(v.planned_type[i], v.planned_satd[i]) for i in range(v.n_planned)]
                 out.own_cell = (v.dist_p0, v.dist_p1)
+                out.rc_satd = v.satd
                 out.row_satds, out.row_satds_intra = rows, rows_i
         else:
             _ck(self.L.x264hip_lookahead_get_frame_ex(self.h, int(flush), C.byref(out), C.byref(got), _p(qp)), "lookahead_get_frame")
