@@ -49,3 +49,88 @@ def test_aq_modes_against_oracle():
             want, want_qp = o.aq_frame(fr[0], (W + 15) // 16, (H + 15) // 16, mode, strength)[:2]
             assert np.array_equal(qp, want_qp), (depth, mode, strength, float(np.abs(qp - want_qp).max()))
             assert np.array_equal(inv, want), (depth, mode, strength, int(np.abs(inv.astype(int) - want.astype(int)).max()))
+
+
+# ---- evaluation level: the same replay as tests/test_gpu_parity.py::_run_sequence, for contexts opened with no_edges /
+# lookahead_slices, comparing only what slicetype_slice_cost visits (slicetype.c:823-833) ----------------------------------
+def _replay(o, cfg, ctx, frames, visited):
+    from tests.test_gpu_parity import SEQ
+    nf = len(frames)
+    planes, inv, intra = [], [], []
+    for i in range(nf):
+        ctx.frame_put(i, frames[i])
+        pl = o.lowres_init(cfg, frames[i])
+        iq = o.aq_frame(frames[i], cfg.mb_w, cfg.mb_h, 1, 1.0)[0]
+        ic = o.intra_costs(cfg, pl)   # 0xFFFF where never visited
+        assert np.array_equal(ctx.intra_costs(i)[visited], ic[visited]), ("intra", i)
+        planes.append(pl); inv.append(iq); intra.append(ic)
+    fields, intra_done = {}, set()
+    for (p0, p1, b) in SEQ:
+        if max(p0, p1, b) >= nf:
+            continue
+        d0, d1 = b - p0, p1 - b
+        with_intra = b not in intra_done
+        if p0 == p1:
+            out = ctx.frame_cost(p0, p1, b, 0, 0, (0, 0), None, with_intra, False)
+            lc, rows, rows_i, oo = o.cell(cfg, planes[b], None, None, 128, None, None, None, None, None, intra[b].copy(), inv[b], with_intra)
+            if with_intra:
+                assert (out.intra_cost_est, out.intra_cost_est_aq) == (oo.intra_cost_est, oo.intra_cost_est_aq), ("intra sums", b)
+                assert np.array_equal(ctx.lowres_costs(b, 0, 0)[1], rows_i), ("intra rows", b)
+            intra_done.add(b)
+            continue
+        do0 = (b, 0, d0 - 1) not in fields
+        do1 = d1 > 0 and (b, 1, d1 - 1) not in fields
+        if do0:
+            fields[(b, 0, d0 - 1)] = o.search_field(cfg, planes[b], planes[p0])
+        if do1:
+            fields[(b, 1, d1 - 1)] = o.search_field(cfg, planes[b], planes[p1])
+        ref1_valid = d1 > 0 and (p1, 0, d0 + d1 - 1) in fields
+        out = ctx.frame_cost(p0, p1, b, d0, d1, (do0, do1), None, with_intra, ref1_valid)
+        m0, c0 = fields[(b, 0, d0 - 1)]
+        gm, gc = ctx.mvs(b, 0, d0 - 1)
+        assert np.array_equal(gm, m0), ("L0 mvs (zero where never searched)", p0, p1, b, int((gm != m0).any(1).sum()))
+        assert np.array_equal(gc[visited], c0[visited]), ("L0 costs", p0, p1, b)
+        dsf = (d0 * 256 + (d0 + d1) // 2) // (d0 + d1)
+        if d1 > 0:
+            m1, c1 = fields[(b, 1, d1 - 1)]
+            gm1, gc1 = ctx.mvs(b, 1, d1 - 1)
+            assert np.array_equal(gm1, m1) and np.array_equal(gc1[visited], c1[visited]), ("L1", p0, p1, b)
+            r1 = fields[(p1, 0, d0 + d1 - 1)][0] if ref1_valid else None
+            lc, rows, rows_i, oo = o.cell(cfg, planes[b], planes[p0], planes[p1], dsf, m0, c0, m1, c1, r1, intra[b], inv[b], with_intra)
+        else:
+            lc, rows, rows_i, oo = o.cell(cfg, planes[b], planes[p0], None, dsf, m0, c0, None, None, None, intra[b], inv[b], with_intra)
+            intra_done.add(b)
+        glc, grows = ctx.lowres_costs(b, d0, d1)
+        assert np.array_equal(glc[visited], lc[visited]), ("lowres_costs", p0, p1, b, int((glc[visited] != lc[visited]).sum()))
+        assert np.array_equal(grows, rows), ("row_satds", p0, p1, b)
+        assert (out.cost_est, out.cost_est_aq) == (oo.cost_est, oo.cost_est_aq), ("sums", p0, p1, b)
+        if d1 == 0:
+            assert out.intra_mbs == oo.intra_mbs
+        if with_intra:
+            assert (out.intra_cost_est, out.intra_cost_est_aq) == (oo.intra_cost_est, oo.intra_cost_est_aq)
+
+
+@pytest.mark.parametrize("no_edges,slices", [(1, 1), (0, 2), (0, 4), (1, 3)])
+@pytest.mark.parametrize("cfgname", ["hex_r4", "dia_r2_sad", "hex_10bit"])
+@pytest.mark.parametrize("clipname", ["fastpan", "noise"])
+def test_eval_sequence_ring_and_bands(cfgname, clipname, no_edges, slices):
+    from oracle.oraclelib import Oracle
+    from tests.common import clip
+    from tests.test_gpu_parity import CONFIGS
+    depth, me_method, subpel_refine, me_range, subme, mbcmp_satd, fpelcmp_satd, bframes = CONFIGS[cfgname]
+    W, H, nf = 352, 288, 4
+    frames = clip(clipname, W, H, nf, depth)
+    o = Oracle(depth)
+    mb_w, mb_h = (W + 15) // 16, (H + 15) // 16
+    cfg = o.make_cfg(mb_w, mb_h, me_method=me_method, subpel_refine=subpel_refine, me_range=me_range, mv_range=128, subme=subme,
+                     mbcmp_satd=mbcmp_satd, fpelcmp_satd=fpelcmp_satd, n_slices=slices, do_edges=not no_edges)
+    ctx = lib.Context(W, H, bit_depth=depth, bframes=bframes, me_method=me_method, subpel_refine=subpel_refine, me_range=me_range,
+                      mv_range=128, subme=subme, mbcmp_satd=mbcmp_satd, fpelcmp_satd=fpelcmp_satd, max_frames=8, cost_mv=o._cost_mv,
+                      no_edges=no_edges, lookahead_slices=slices)
+    visited = np.ones((mb_h, mb_w), bool)
+    if no_edges:
+        visited[0, :] = visited[-1, :] = visited[:, 0] = visited[:, -1] = False
+    try:
+        _replay(o, cfg, ctx, frames, visited.reshape(-1))
+    finally:
+        ctx.close()
