@@ -246,6 +246,8 @@ typedef struct x264hip_la_params
                                * (vbv_lookahead, slicetype.c:1224-1286; key-frame analysis, lookahead.c:140-141), the B-frame and
                                * intra evaluations slicetype_decide adds for the row sums (:1916-1934), an MB-tree finish for every
                                * reference (:1087-1088) and the lookahead delay of encoder.c:1607-1608 */
+    int intra_refresh;        /* param.b_intra_refresh: no key frames after the first (slicetype.c:1405,1506,1681,1831); the column
+                               * bookkeeping and the row-sum correction of x264_rc_analyse_slice (:2015-2032) stay in the encoder */
 } x264hip_la_params;
 
 

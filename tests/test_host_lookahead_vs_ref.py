@@ -55,6 +55,10 @@ CASES = [
     # lookahead threads: two bands searched independently (slicetype.c:668, :917-918)
     ("medium", "threads=4,sync-lookahead=0,lookahead-threads=2", dict(threads=4, lookahead_threads=2), 8,
      dict(seed=16, pan=(23, 11), noise=30, texture=0.9, scene_cuts=(20,)), 40),
+    # intra refresh: no key frames after the first, its own scenecut bias (slicetype.c:1405,1506,1681,1831; encoder.c:1087-1102)
+    ("medium", "intra-refresh=1,keyint=12,bframes=5,b-pyramid=normal,ref=4", dict(intra_refresh=1, keyint_max=12, bframes=5, b_pyramid=2, frame_refs=4),
+     8, dict(seed=9, scene_cuts=(13, 37), pan=(2, 1)), 60),
+    ("medium", "intra-refresh=1,keyint=10,mbtree=0", dict(intra_refresh=1, keyint_max=10, mb_tree=0), 8, dict(seed=9, scene_cuts=(13, 37), pan=(2, 1)), 60),
     # more B-frames than the key-frame interval allows (encoder.c:1074)
     ("medium", "bframes=16,keyint=8,rc-lookahead=5", dict(bframes=16, keyint_max=8, rc_lookahead=5), 8, dict(seed=17), 40),
 ]

@@ -349,7 +349,7 @@ struct Lookahead
         float thresh_max = p.scenecut_threshold / 100.0;
         float thresh_min = thresh_max * 0.25;
         if( p.keyint_min == p.keyint_max ) thresh_min = thresh_max;
-        if( gop_size <= p.keyint_min / 4 )
+        if( gop_size <= p.keyint_min / 4 || p.intra_refresh )
             f_bias = thresh_min / 4;
         else if( gop_size <= p.keyint_min )
             f_bias = thresh_min * gop_size / p.keyint_min;
@@ -499,7 +499,7 @@ struct Lookahead
             return;
         }
         keyint_limit = p.keyint_max - frames[0]->i_frame + i_last_keyframe - 1;
-        orig_num_frames = num_frames = framecnt < keyint_limit ? framecnt : keyint_limit;
+        orig_num_frames = num_frames = p.intra_refresh ? framecnt : framecnt < keyint_limit ? framecnt : keyint_limit;
         if( ( p.psy && p.mb_tree ) || vbv_lookahead_on() )
             num_frames = framecnt;
         else if( p.open_gop && num_frames < framecnt )
@@ -617,7 +617,8 @@ struct Lookahead
         if( p.mb_tree )
             macroblock_tree( frames, num_frames < p.keyint_max ? num_frames : p.keyint_max, keyframe );
 
-        // keyframe limit (:1680-1731), no intra refresh
+        // keyframe limit (:1680-1731), not with intra refresh
+        if( !p.intra_refresh )
         {
             int last_keyframe = i_last_keyframe, last_possible = 0;
             for( int j = 1; j <= num_frames; j++ )
@@ -723,7 +724,7 @@ struct Lookahead
                 frm->i_type = T_B;
             if( frm->i_type == T_KEYFRAME )
                 frm->i_type = p.open_gop ? T_I : T_IDR;
-            if( frm->i_frame - i_last_keyframe >= p.keyint_max )
+            if( ( !p.intra_refresh || frm->i_frame == 0 ) && frm->i_frame - i_last_keyframe >= p.keyint_max )
             {
                 if( frm->i_type == T_AUTO || frm->i_type == T_I )
                     frm->i_type = p.open_gop && i_last_keyframe >= 0 ? T_I : T_IDR;

@@ -264,7 +264,7 @@ class LaParams(C.Structure):
     _fields_ = [("dev", Params), ("keyint_max", C.c_int), ("keyint_min", C.c_int), ("scenecut_threshold", C.c_int),
                 ("b_adapt", C.c_int), ("b_pyramid", C.c_int), ("rc_lookahead", C.c_int), ("mb_tree", C.c_int),
                 ("weightp", C.c_int), ("open_gop", C.c_int), ("frame_refs", C.c_int), ("psy", C.c_int),
-                ("rc_is_cqp", C.c_int), ("fps_num", C.c_int), ("fps_den", C.c_int), ("qcompress", C.c_float), ("vbv", C.c_int)]
+                ("rc_is_cqp", C.c_int), ("fps_num", C.c_int), ("fps_den", C.c_int), ("qcompress", C.c_float), ("vbv", C.c_int), ("intra_refresh", C.c_int)]
 
 
 FRAME_PUT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int)
@@ -375,7 +375,7 @@ def la_config(width, height, preset="medium", bit_depth=8, tune="", **over):
     c = dict(bframes=3, b_adapt=1, b_pyramid=2, rc_lookahead=40, me="hex", me_range=16, subme=7, weightp=2,
              weighted_bipred=1, mb_tree=1, aq_mode=1, aq_strength=1.0, scenecut=40, keyint_max=250, keyint_min=0,
              open_gop=0, frame_refs=3, psy=1, rc_is_cqp=0, bframe_bias=0, fps=25.0, mv_range=0, fps_num=25, fps_den=1,
-             qcompress=0.6, threads=1, lookahead_threads=0, bitrate=0, vbv_maxrate=0, vbv_bufsize=0, transform_8x8=1)
+             qcompress=0.6, threads=1, lookahead_threads=0, bitrate=0, vbv_maxrate=0, vbv_bufsize=0, transform_8x8=1, intra_refresh=0)
     c.update(PRESETS[preset])
     for t in filter(None, tune.replace(",", " ").split()):
         tv = dict(TUNES[t])
@@ -390,6 +390,7 @@ def la_config(width, height, preset="medium", bit_depth=8, tune="", **over):
     if c["keyint_max"] == 1:                                                 # :612-618
         c["weightp"] = 0
         c["frame_refs"] = 1
+        c["intra_refresh"] = 0
     c["subme"] = clip(c["subme"], 0, 11)                                     # :922
     if c["rc_is_cqp"]:                                                       # :951-966
         c["aq_mode"] = 0
@@ -422,6 +423,11 @@ def la_config(width, height, preset="medium", bit_depth=8, tune="", **over):
         c["b_adapt"] = 0
         c["weighted_bipred"] = 0
         c["open_gop"] = 0
+    if c["intra_refresh"]:                                                   # :1087-1102
+        if c["b_pyramid"] == 2:
+            c["b_pyramid"] = 1
+        c["frame_refs"] = 1
+        c["open_gop"] = 0
     if c["keyint_min"] <= 0:                                                 # :1109-1111 (0 = X264_KEYINT_MIN_AUTO)
         c["keyint_min"] = min(c["keyint_max"] // 10, int(c["fps"]))
     c["keyint_min"] = clip(c["keyint_min"], 1, c["keyint_max"] // 2 + 1)
@@ -431,7 +437,7 @@ def la_config(width, height, preset="medium", bit_depth=8, tune="", **over):
     c["qcompress"] = clip(c["qcompress"], 0.0, 1.0)                          # :1125
     if c["keyint_max"] == 1 or c["qcompress"] == 1:                          # :1126-1127
         c["mb_tree"] = 0
-    if c["keyint_max"] != 1 << 30 and not c["rc_lookahead"] and c["mb_tree"]:  # :1128-1133 (no intra refresh)
+    if not c["intra_refresh"] and c["keyint_max"] != 1 << 30 and not c["rc_lookahead"] and c["mb_tree"]:  # :1128-1133
         c["mb_tree"] = 0
     me = _ME.get(c["me"], 1)                                                 # :1156-1164
     c["me_range"] = clip(c["me_range"], 4, 1024)
@@ -500,7 +506,7 @@ def make_la_params(cfg, cost_mv=None, max_frames=0):
                  max_frames, int(not cfg["do_edges"]), cfg["lookahead_threads"], cost_mv.ctypes.data + 2 * centre)
     p = LaParams(dev, cfg["keyint_max"], cfg["keyint_min"], cfg["scenecut"], cfg["b_adapt"], cfg["b_pyramid"],
                  cfg["rc_lookahead"], cfg["mb_tree"], cfg["weightp"], cfg["open_gop"], cfg["frame_refs"], cfg["psy"],
-                 cfg["rc_is_cqp"], cfg["fps_num"], cfg["fps_den"], cfg["qcompress"], cfg["vbv"])
+                 cfg["rc_is_cqp"], cfg["fps_num"], cfg["fps_den"], cfg["qcompress"], cfg["vbv"], cfg["intra_refresh"])
     p._keep = cost_mv
     return p
 
