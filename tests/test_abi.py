@@ -50,3 +50,28 @@ def test_open_fails_loudly_without_gpu():
 
 def test_la_config_mv_range():
     assert lib.mv_range_for(176, 144) == 128 and lib.mv_range_for(1920, 1080) == 512 and lib.mv_range_for(3840, 2160) == 512
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """Every field of every struct that crosses the C ABI: offset and total size as a C compiler lays out include/x264hip.h
+    against the ctypes mirrors in x264_amd/lib.py (the header is the contract; a silent mismatch would shift every field after it)."""
+    import subprocess
+    pairs = {"x264hip_params": lib.Params, "x264hip_weight": lib.Weight, "x264hip_cost": lib.Cost, "x264hip_mbtree_op": lib.MbtreeOp,
+             "x264hip_la_params": lib.LaParams, "x264hip_backend": lib.Backend, "x264hip_la_frame": lib.LaFrameOut,
+             "x264hip_la_vbv": lib.LaVbv}
+    rename = {"lambda_": "lambda"}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "x264hip.h"', 'int main(void){']
+    for cname, cls in pairs.items():
+        lines.append('printf("%s.sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, rename.get(fname, fname)))
+    lines.append('return 0;}')
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    want = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, cls in pairs.items():
+        assert C.sizeof(cls) == int(want[cname + ".sizeof"]), cname
+        for fname, _ in cls._fields_:
+            assert getattr(cls, fname).offset == int(want["%s.%s" % (cname, fname)]), (cname, fname)
