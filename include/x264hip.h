@@ -182,6 +182,24 @@ int  x264hip_frame_cost_recalculate( x264hip_ctx *ctx, int slot_b, int dist_p0, 
  * mv[i].  Planes are device pointers.  Used for parity and for the SAD/SATD GB/s metric. */
 int  x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx, const void *fenc_plane, const void *ref_plane,
                               int stride, int blocks_w, int blocks_h, const int16_t *mv_dev, int *out_dev );
+/* The block metrics of x264_pixel_function_t that only the main encode calls, over a raster of blocks_w x blocks_h blocks of size_idx
+ * (PIXEL_16x16 = 0 .. PIXEL_4x4 = 6, common/pixel.h:37-59) of device-resident planes sharing one stride; block (x, y) starts at
+ * pixel (x*w, y*h).  out_dev[y*blocks_w + x] (device, uint64):
+ *   SSD          ssd[size]( a, b )                   common/pixel.c:85-151     all 7 sizes
+ *   SA8D         sa8d[size]( a, b )                  :334-381                  16x16, 8x8
+ *   VAR          var[size]( a ) = sum | sqr << 32    :183-201                  16x16, 8x16, 8x8
+ *   HADAMARD_AC  hadamard_ac[size]( a )              :383-435                  16x16, 16x8, 8x16, 8x8
+ *   VSAD         vsad( a, stride, h )                :716-723                  16 wide: sizes 16x16, 16x8 (h rows)
+ *   ASD8         asd8( a, b, h )                     :747-754                  8 wide: sizes 8x16, 8x8
+ * b_plane is ignored (may be NULL) for the one-plane metrics.  Any other metric / size pair: X264HIP_EINVAL. */
+#define X264HIP_METRIC_SSD 0
+#define X264HIP_METRIC_SA8D 1
+#define X264HIP_METRIC_VAR 2
+#define X264HIP_METRIC_HADAMARD_AC 3
+#define X264HIP_METRIC_VSAD 4
+#define X264HIP_METRIC_ASD8 5
+int  x264hip_pixel_metric_batch( x264hip_ctx *ctx, int metric, int size_idx, const void *a_plane, const void *b_plane, intptr_t stride,
+                                 int blocks_w, int blocks_h, uint64_t *out_dev );
 /* Frame form of sub4x4_dct + quant_4x4 (common/dct.c:157-175, common/quant.c:50-62; SURVEY 8f rank 4, first piece): every
  * 4x4 block of the device-resident plane `fenc` minus the prediction plane `fdec`, transformed and quantised with the host
  * tables mf/bias (16 x udctcoef: uint16 for 8-bit, uint32 for 10-bit).  coefs_dev: [height/4][width/4][16] dctcoef (int16 /

@@ -1,0 +1,82 @@
+"""The arithmetic of x264_amd/csrc/block_metrics.h (the functions the batched device kernels call for ssd / sa8d / var /
+hadamard_ac / vsad / asd8) compiled for the host by tests/tools/block_metrics_host.cpp and checked against the oracle, which is
+itself pinned against the reference vtables (tests/test_primitives_vs_ref.py).  The GPU test of the same entry points is in
+tests/test_zz_gpu_new_configs.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle.oraclelib import Oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "tools", "block_metrics_host.cpp")
+OUT = os.path.join(HERE, "tools", "_build", "libbm_host.so")
+METRICS = {  # name: (id, sizes, needs second plane)
+    "ssd": (0, [(16, 16), (16, 8), (8, 16), (8, 8), (8, 4), (4, 8), (4, 4)], True),
+    "sa8d": (1, [(16, 16), (8, 8)], True),
+    "var": (2, [(16, 16), (8, 16), (8, 8)], False),
+    "hadamard_ac": (3, [(16, 16), (16, 8), (8, 16), (8, 8)], False),
+    "vsad": (4, [(16, 16), (16, 8)], False),
+    "asd8": (5, [(8, 16), (8, 8)], True),
+}
+
+
+def _lib():
+    hdr = os.path.join(HERE, "..", "x264_amd", "csrc", "block_metrics.h")
+    if not os.path.exists(OUT) or max(os.path.getmtime(SRC), os.path.getmtime(hdr)) > os.path.getmtime(OUT):
+        os.makedirs(os.path.dirname(OUT), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC])
+    return C.CDLL(OUT)
+
+
+def oracle_metric(o, name, w, h, a, sa, b, sb):
+    p = lambda x: x.ctypes.data_as(C.c_void_p)  # noqa: E731
+    if name == "ssd":
+        return o.f("ssd", C.c_int)(p(a), sa, p(b), sb, w, h)
+    if name == "sa8d":
+        return o.f("sa8d", C.c_int)(p(a), sa, p(b), sb, w)
+    if name == "var":
+        return o.f("var", C.c_uint64)(p(a), sa, w, h)
+    if name == "hadamard_ac":
+        fn = o.f("hadamard_ac", C.c_uint64)
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        return fn(p(a), sa, w, h)
+    if name == "vsad":
+        fn = o.f("vsad", C.c_int)
+        fn.argtypes = [C.c_void_p, C.c_long, C.c_int]
+        return fn(p(a), sa, h)
+    fn = o.f("asd8", C.c_int)
+    fn.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int]
+    return fn(p(a), sa, p(b), sb, h)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("name", list(METRICS))
+def test_block_metric_arithmetic(name, depth):
+    L = _lib()
+    fn = L.bm_host_u8 if depth == 8 else L.bm_host_u16
+    fn.restype = C.c_uint64
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long]
+    o = Oracle(depth)
+    rng = np.random.default_rng(7 + depth)
+    maxv = (1 << depth) - 1
+    mid, sizes, two = METRICS[name]
+    for kind in range(4):
+        if kind == 0:
+            a = rng.integers(0, maxv + 1, size=(40, 64)); b = rng.integers(0, maxv + 1, size=(40, 64))
+        elif kind == 1:   # extremes: the largest differences every accumulator has to hold
+            a = np.full((40, 64), maxv); b = np.zeros((40, 64), np.int64)
+        elif kind == 2:
+            a = (rng.integers(0, 2, size=(40, 64)) * maxv); b = maxv - a
+        else:
+            a = rng.integers(0, maxv + 1, size=(40, 64)); b = np.clip(a + rng.integers(-3, 4, size=(40, 64)), 0, maxv)
+        a = np.ascontiguousarray(a, o.dtype); b = np.ascontiguousarray(b, o.dtype)
+        for (w, h) in sizes:
+            for (ox, oy) in ((0, 0), (5, 3), (17, 9)):
+                pa, pb = a[oy:, ox:], b[oy + 1:, ox + 2:]
+                got = fn(mid, w, h, pa.ctypes.data, 64, pb.ctypes.data if two else None, 64)
+                want = oracle_metric(o, name, w, h, pa, 64, pb, 64)
+                assert got == (want & 0xFFFFFFFFFFFFFFFF if name in ("var", "hadamard_ac") else want & 0xFFFFFFFF), (name, w, h, kind, ox, oy)

@@ -134,3 +134,43 @@ def test_eval_sequence_ring_and_bands(cfgname, clipname, no_edges, slices):
         _replay(o, cfg, ctx, frames, visited.reshape(-1))
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("name", ["ssd", "sa8d", "var", "hadamard_ac", "vsad", "asd8"])
+def test_pixel_metric_batch(name, depth):
+    """x264hip_pixel_metric_batch (ssd / sa8d / var / hadamard_ac / vsad / asd8 over a raster of blocks) against the oracle,
+    block by block; the same arithmetic is checked on CPU by tests/test_block_metrics_host.py."""
+    import torch
+    from oracle.oraclelib import Oracle
+    from tests.test_block_metrics_host import METRICS, oracle_metric
+    o = Oracle(depth)
+    W, H, stride = 160, 96, 192
+    rng = np.random.default_rng(11 + depth)
+    maxv = (1 << depth) - 1
+    a = rng.integers(0, maxv + 1, size=(H, stride)).astype(o.dtype)
+    b = np.clip(a.astype(np.int64) + rng.integers(-40, 41, size=(H, stride)), 0, maxv).astype(o.dtype)
+    b[:16, :64] = maxv - a[:16, :64]  # large differences too
+    tdt = torch.uint8 if depth == 8 else torch.int16
+    da = torch.from_numpy(a.view(np.uint8 if depth == 8 else np.int16)).cuda()
+    db = torch.from_numpy(b.view(np.uint8 if depth == 8 else np.int16)).cuda()
+    assert da.dtype == tdt
+    mid, sizes, two = METRICS[name]
+    size_idx = {(16, 16): 0, (16, 8): 1, (8, 16): 2, (8, 8): 3, (8, 4): 4, (4, 8): 5, (4, 4): 6}
+    ctx = lib.Context(352, 288, bit_depth=depth, max_frames=4)
+    try:
+        for (w, h) in sizes:
+            bw, bh = W // w, H // h
+            out = torch.zeros(bw * bh, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            ctx.pixel_metric_batch(mid, size_idx[(w, h)], da.data_ptr(), db.data_ptr() if two else None, stride, bw, bh, out.data_ptr())
+            ctx.synchronize()
+            got = out.cpu().numpy().view(np.uint64)
+            for y in range(bh):
+                for x in range(bw):
+                    pa, pb = a[y * h:, x * w:], b[y * h:, x * w:]
+                    want = oracle_metric(o, name, w, h, pa, stride, pb, stride)
+                    want = want & 0xFFFFFFFFFFFFFFFF if name in ("var", "hadamard_ac") else want & 0xFFFFFFFF
+                    assert int(got[y * bw + x]) == want, (name, depth, w, h, x, y)
+    finally:
+        ctx.close()

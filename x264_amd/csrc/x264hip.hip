@@ -20,6 +20,7 @@
 #include "device_common.h"
 #include "me_search.h"
 #include "la_kernels.h"
+#include "block_metrics.h"
 
 #define HIPCK( call )                                                                                        \
     do {                                                                                                     \
@@ -1341,6 +1342,41 @@ extern "C" int x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx
         CMP_SIZE( uint16_t );
 #undef CMP_SIZE
 #undef CMP_LAUNCH
+    HIPCK( hipGetLastError() );
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_pixel_metric_batch( x264hip_ctx *ctx, int metric, int size_idx, const void *a_plane, const void *b_plane, intptr_t stride,
+                                           int blocks_w, int blocks_h, uint64_t *out_dev )
+{
+    static const int sizes[7][2] = { { 16, 16 }, { 16, 8 }, { 8, 16 }, { 8, 8 }, { 8, 4 }, { 4, 8 }, { 4, 4 } }; // PIXEL_16x16 .. PIXEL_4x4
+    if( !ctx || !a_plane || !out_dev || size_idx < 0 || size_idx > 6 || blocks_w <= 0 || blocks_h <= 0 ) return X264HIP_EINVAL;
+    const int w = sizes[size_idx][0], h = sizes[size_idx][1];
+    const bool two = metric == X264HIP_METRIC_SSD || metric == X264HIP_METRIC_SA8D || metric == X264HIP_METRIC_ASD8;
+    if( ( two && !b_plane ) || stride < (intptr_t)blocks_w * w ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    const dim3 grd( ( blocks_w + 63 ) / 64, blocks_h );
+    bool launched = false;
+#define BM_LAUNCH( T, M, W, H ) \
+    if( !launched && metric == M && w == W && h == H ) \
+    { \
+        block_metric_kernel<T, M, W, H><<<grd, 64, 0, ctx->stream>>>( (const T *)a_plane, two ? (const T *)b_plane : (const T *)nullptr, (long)stride, \
+                                                                      blocks_w, (unsigned long long *)out_dev ); \
+        launched = true; \
+    }
+#define BM_ALL( T ) \
+    BM_LAUNCH( T, BM_SSD, 16, 16 ) BM_LAUNCH( T, BM_SSD, 16, 8 ) BM_LAUNCH( T, BM_SSD, 8, 16 ) BM_LAUNCH( T, BM_SSD, 8, 8 ) \
+    BM_LAUNCH( T, BM_SSD, 8, 4 ) BM_LAUNCH( T, BM_SSD, 4, 8 ) BM_LAUNCH( T, BM_SSD, 4, 4 ) \
+    BM_LAUNCH( T, BM_SA8D, 16, 16 ) BM_LAUNCH( T, BM_SA8D, 8, 8 ) \
+    BM_LAUNCH( T, BM_VAR, 16, 16 ) BM_LAUNCH( T, BM_VAR, 8, 16 ) BM_LAUNCH( T, BM_VAR, 8, 8 ) \
+    BM_LAUNCH( T, BM_HADAMARD_AC, 16, 16 ) BM_LAUNCH( T, BM_HADAMARD_AC, 16, 8 ) BM_LAUNCH( T, BM_HADAMARD_AC, 8, 16 ) BM_LAUNCH( T, BM_HADAMARD_AC, 8, 8 ) \
+    BM_LAUNCH( T, BM_VSAD, 16, 16 ) BM_LAUNCH( T, BM_VSAD, 16, 8 ) \
+    BM_LAUNCH( T, BM_ASD8, 8, 16 ) BM_LAUNCH( T, BM_ASD8, 8, 8 )
+    if( ctx->p.bit_depth == 8 ) { BM_ALL( uint8_t ) } else { BM_ALL( uint16_t ) }
+#undef BM_ALL
+#undef BM_LAUNCH
+    if( !launched ) return X264HIP_EINVAL; // the reference has no such metric / size pair
     HIPCK( hipGetLastError() );
     return X264HIP_OK;
 }

@@ -219,6 +219,11 @@ class Context:
         _ck(self.L.x264hip_pixel_cmp_batch(self.h, int(satd), int(size_idx), C.c_void_p(fenc_ptr), C.c_void_p(ref_ptr), int(stride),
                                            int(blocks_w), int(blocks_h), C.c_void_p(mv_ptr), C.c_void_p(out_ptr)), "pixel_cmp_batch")
 
+    def pixel_metric_batch(self, metric, size_idx, a_ptr, b_ptr, stride, blocks_w, blocks_h, out_ptr):
+        self.L.x264hip_pixel_metric_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int,
+                                                      C.c_void_p]
+        _ck(self.L.x264hip_pixel_metric_batch(self.h, metric, size_idx, a_ptr, b_ptr, stride, blocks_w, blocks_h, out_ptr), "pixel_metric_batch")
+
     def frame_dct_quant4x4(self, fenc_ptr, fenc_stride, fdec_ptr, fdec_stride, width, height, mf, bias, coefs_ptr, nz_ptr):
         mf = np.ascontiguousarray(mf); bias = np.ascontiguousarray(bias)
         _ck(self.L.x264hip_frame_dct_quant4x4(self.h, C.c_void_p(fenc_ptr), C.c_ssize_t(fenc_stride), C.c_void_p(fdec_ptr), C.c_ssize_t(fdec_stride),
