@@ -1,0 +1,177 @@
+"""(Run through tests/test_zz_gpu_new_configs.py, which executes every test function of this file in its own process.)
+GPU end-to-end for the configurations whose device paths were written after the last GPU session of round 1: edge ring
+not evaluated (no MB-tree: --no-mbtree, --qp, superfast / ultrafast, qcomp 1), lookahead bands (lookahead_threads > 1),
+auto-variance AQ (aq-mode 2 / 3), constant QP, VBV lookahead, the batched main-encode block metrics.  Same golden fixtures and
+checks as tests/test_gpu_lookahead.py."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.golden.make_golden import LOOKAHEAD_CASES_R2
+from tests.test_golden import GOLD, check_lookahead_outputs
+from x264_amd import lib
+from x264_amd.synth import make_clip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", list(LOOKAHEAD_CASES_R2))
+@pytest.mark.parametrize("paced", [True, False])
+def test_lookahead_vs_golden_new_configs(name, paced):
+    preset, opts, over, depth, W, H, ckw, nf = LOOKAHEAD_CASES_R2[name]
+    z = np.load(os.path.join(GOLD, "lookahead_%s.npz" % name))
+    frames = make_clip(W, H, nf, bit_depth=depth, **ckw)
+    cfg = lib.la_config(W, H, preset, bit_depth=depth, **over)
+    la = lib.Lookahead(cfg, max_frames=0 if paced else nf + 4)
+    try:
+        outs = la.run(frames, paced=paced, qp_offsets=True, vbv=bool(cfg["vbv"]))
+    finally:
+        la.close()
+    check_lookahead_outputs(outs, z, cfg["bframes"] + 2, check_qp=bool(cfg["aq_mode"]))
+
+
+def test_aq_modes_against_oracle():
+    """x264hip_frame_put with aq-mode 2 / 3: the Q8 inverse qscale map bit for bit against the oracle (sequential FP32 sums,
+    correctly rounded roots and divisions, ratecontrol.c:354-398 in the reference build's operation order)."""
+    from oracle.oraclelib import Oracle
+    for depth in (8, 10):
+        o = Oracle(depth)
+        W, H = 352, 288
+        fr = make_clip(W, H, 2, seed=7, bit_depth=depth, noise=20, texture=0.8)
+        for mode, strength in ((2, 1.0), (3, 0.7), (2, 2.5)):
+            ctx = lib.Context(W, H, bit_depth=depth, aq_mode=mode, aq_strength=strength, max_frames=8)
+            try:
+                ctx.frame_put(0, fr[0])
+                inv = ctx.inv_qscale(0)
+                qp = ctx.qp_offsets(0)
+            finally:
+                ctx.close()
+            want, want_qp = o.aq_frame(fr[0], (W + 15) // 16, (H + 15) // 16, mode, strength)[:2]
+            assert np.array_equal(qp, want_qp), (depth, mode, strength, float(np.abs(qp - want_qp).max()))
+            assert np.array_equal(inv, want), (depth, mode, strength, int(np.abs(inv.astype(int) - want.astype(int)).max()))
+
+
+# ---- evaluation level: the same replay as tests/test_gpu_parity.py::_run_sequence, for contexts opened with no_edges /
+# lookahead_slices, comparing only what slicetype_slice_cost visits (slicetype.c:823-833) ----------------------------------
+def _replay(o, cfg, ctx, frames, visited):
+    from tests.test_gpu_parity import SEQ
+    nf = len(frames)
+    planes, inv, intra = [], [], []
+    for i in range(nf):
+        ctx.frame_put(i, frames[i])
+        pl = o.lowres_init(cfg, frames[i])
+        iq = o.aq_frame(frames[i], cfg.mb_w, cfg.mb_h, 1, 1.0)[0]
+        ic = o.intra_costs(cfg, pl)   # 0xFFFF where never visited
+        assert np.array_equal(ctx.intra_costs(i)[visited], ic[visited]), ("intra", i)
+        planes.append(pl); inv.append(iq); intra.append(ic)
+    fields, intra_done = {}, set()
+    for (p0, p1, b) in SEQ:
+        if max(p0, p1, b) >= nf:
+            continue
+        d0, d1 = b - p0, p1 - b
+        with_intra = b not in intra_done
+        if p0 == p1:
+            out = ctx.frame_cost(p0, p1, b, 0, 0, (0, 0), None, with_intra, False)
+            lc, rows, rows_i, oo = o.cell(cfg, planes[b], None, None, 128, None, None, None, None, None, intra[b].copy(), inv[b], with_intra)
+            if with_intra:
+                assert (out.intra_cost_est, out.intra_cost_est_aq) == (oo.intra_cost_est, oo.intra_cost_est_aq), ("intra sums", b)
+                assert np.array_equal(ctx.lowres_costs(b, 0, 0)[1], rows_i), ("intra rows", b)
+            intra_done.add(b)
+            continue
+        do0 = (b, 0, d0 - 1) not in fields
+        do1 = d1 > 0 and (b, 1, d1 - 1) not in fields
+        if do0:
+            fields[(b, 0, d0 - 1)] = o.search_field(cfg, planes[b], planes[p0])
+        if do1:
+            fields[(b, 1, d1 - 1)] = o.search_field(cfg, planes[b], planes[p1])
+        ref1_valid = d1 > 0 and (p1, 0, d0 + d1 - 1) in fields
+        out = ctx.frame_cost(p0, p1, b, d0, d1, (do0, do1), None, with_intra, ref1_valid)
+        m0, c0 = fields[(b, 0, d0 - 1)]
+        gm, gc = ctx.mvs(b, 0, d0 - 1)
+        assert np.array_equal(gm, m0), ("L0 mvs (zero where never searched)", p0, p1, b, int((gm != m0).any(1).sum()))
+        assert np.array_equal(gc[visited], c0[visited]), ("L0 costs", p0, p1, b)
+        dsf = (d0 * 256 + (d0 + d1) // 2) // (d0 + d1)
+        if d1 > 0:
+            m1, c1 = fields[(b, 1, d1 - 1)]
+            gm1, gc1 = ctx.mvs(b, 1, d1 - 1)
+            assert np.array_equal(gm1, m1) and np.array_equal(gc1[visited], c1[visited]), ("L1", p0, p1, b)
+            r1 = fields[(p1, 0, d0 + d1 - 1)][0] if ref1_valid else None
+            lc, rows, rows_i, oo = o.cell(cfg, planes[b], planes[p0], planes[p1], dsf, m0, c0, m1, c1, r1, intra[b], inv[b], with_intra)
+        else:
+            lc, rows, rows_i, oo = o.cell(cfg, planes[b], planes[p0], None, dsf, m0, c0, None, None, None, intra[b], inv[b], with_intra)
+            intra_done.add(b)
+        glc, grows = ctx.lowres_costs(b, d0, d1)
+        assert np.array_equal(glc[visited], lc[visited]), ("lowres_costs", p0, p1, b, int((glc[visited] != lc[visited]).sum()))
+        assert np.array_equal(grows, rows), ("row_satds", p0, p1, b)
+        assert (out.cost_est, out.cost_est_aq) == (oo.cost_est, oo.cost_est_aq), ("sums", p0, p1, b)
+        if d1 == 0:
+            assert out.intra_mbs == oo.intra_mbs
+        if with_intra:
+            assert (out.intra_cost_est, out.intra_cost_est_aq) == (oo.intra_cost_est, oo.intra_cost_est_aq)
+
+
+@pytest.mark.parametrize("no_edges,slices", [(1, 1), (0, 2), (0, 4), (1, 3)])
+@pytest.mark.parametrize("cfgname", ["hex_r4", "dia_r2_sad", "hex_10bit"])
+@pytest.mark.parametrize("clipname", ["fastpan", "noise"])
+def test_eval_sequence_ring_and_bands(cfgname, clipname, no_edges, slices):
+    from oracle.oraclelib import Oracle
+    from tests.common import clip
+    from tests.test_gpu_parity import CONFIGS
+    depth, me_method, subpel_refine, me_range, subme, mbcmp_satd, fpelcmp_satd, bframes = CONFIGS[cfgname]
+    W, H, nf = 352, 288, 4
+    frames = clip(clipname, W, H, nf, depth)
+    o = Oracle(depth)
+    mb_w, mb_h = (W + 15) // 16, (H + 15) // 16
+    cfg = o.make_cfg(mb_w, mb_h, me_method=me_method, subpel_refine=subpel_refine, me_range=me_range, mv_range=128, subme=subme,
+                     mbcmp_satd=mbcmp_satd, fpelcmp_satd=fpelcmp_satd, n_slices=slices, do_edges=not no_edges)
+    ctx = lib.Context(W, H, bit_depth=depth, bframes=bframes, me_method=me_method, subpel_refine=subpel_refine, me_range=me_range,
+                      mv_range=128, subme=subme, mbcmp_satd=mbcmp_satd, fpelcmp_satd=fpelcmp_satd, max_frames=8, cost_mv=o._cost_mv,
+                      no_edges=no_edges, lookahead_slices=slices)
+    visited = np.ones((mb_h, mb_w), bool)
+    if no_edges:
+        visited[0, :] = visited[-1, :] = visited[:, 0] = visited[:, -1] = False
+    try:
+        _replay(o, cfg, ctx, frames, visited.reshape(-1))
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("name", ["ssd", "sa8d", "var", "hadamard_ac", "vsad", "asd8"])
+def test_pixel_metric_batch(name, depth):
+    """x264hip_pixel_metric_batch (ssd / sa8d / var / hadamard_ac / vsad / asd8 over a raster of blocks) against the oracle,
+    block by block; the same arithmetic is checked on CPU by tests/test_block_metrics_host.py."""
+    import torch
+    from oracle.oraclelib import Oracle
+    from tests.test_block_metrics_host import METRICS, oracle_metric
+    o = Oracle(depth)
+    W, H, stride = 160, 96, 192
+    rng = np.random.default_rng(11 + depth)
+    maxv = (1 << depth) - 1
+    a = rng.integers(0, maxv + 1, size=(H, stride)).astype(o.dtype)
+    b = np.clip(a.astype(np.int64) + rng.integers(-40, 41, size=(H, stride)), 0, maxv).astype(o.dtype)
+    b[:16, :64] = maxv - a[:16, :64]  # large differences too
+    tdt = torch.uint8 if depth == 8 else torch.int16
+    da = torch.from_numpy(a.view(np.uint8 if depth == 8 else np.int16)).cuda()
+    db = torch.from_numpy(b.view(np.uint8 if depth == 8 else np.int16)).cuda()
+    assert da.dtype == tdt
+    mid, sizes, two = METRICS[name]
+    size_idx = {(16, 16): 0, (16, 8): 1, (8, 16): 2, (8, 8): 3, (8, 4): 4, (4, 8): 5, (4, 4): 6}
+    ctx = lib.Context(352, 288, bit_depth=depth, max_frames=4)
+    try:
+        for (w, h) in sizes:
+            bw, bh = W // w, H // h
+            out = torch.zeros(bw * bh, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            ctx.pixel_metric_batch(mid, size_idx[(w, h)], da.data_ptr(), db.data_ptr() if two else None, stride, bw, bh, out.data_ptr())
+            ctx.synchronize()
+            got = out.cpu().numpy().view(np.uint64)
+            for y in range(bh):
+                for x in range(bw):
+                    pa, pb = a[y * h:, x * w:], b[y * h:, x * w:]
+                    want = oracle_metric(o, name, w, h, pa, stride, pb, stride)
+                    want = want & 0xFFFFFFFFFFFFFFFF if name in ("var", "hadamard_ac") else want & 0xFFFFFFFF
+                    assert int(got[y * bw + x]) == want, (name, depth, w, h, x, y)
+    finally:
+        ctx.close()
