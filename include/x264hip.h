@@ -206,6 +206,10 @@ int  x264hip_pixel_metric_batch( x264hip_ctx *ctx, int metric, int size_idx, con
  * int32) in the reference's per-block order, 16-byte aligned; nz_dev: one byte per block = quant_4x4's return value. */
 int  x264hip_frame_dct_quant4x4( x264hip_ctx *ctx, const void *fenc, intptr_t fenc_stride, const void *fdec, intptr_t fdec_stride, int width, int height,
                                  const void *mf, const void *bias, void *coefs_dev, uint8_t *nz_dev );
+/* Same for sub8x8_dct8 + quant_8x8 (common/dct.c:332-366, common/quant.c:64-72): every 8x8 block; mf/bias hold 64 udctcoef;
+ * coefs_dev: [height/8][width/8][64] dctcoef in the reference's per-block order; nz_dev: quant_8x8's return value per block. */
+int  x264hip_frame_dct_quant8x8( x264hip_ctx *ctx, const void *fenc, intptr_t fenc_stride, const void *fdec, intptr_t fdec_stride, int width, int height,
+                                 const void *mf, const void *bias, void *coefs_dev, uint8_t *nz_dev );
 /* x264_mc_functions_t.hpel_filter (common/mc.h:306-307, mc.c:172-196) without the scratch row buffer: the three
  * half-pel planes of `src` (device pointers, element stride).  Like the reference it reads src columns -2..width+2
  * and rows -2..height+2 and also writes dstv columns -2,-1 and width..width+2.  First piece of SURVEY 8(f) rank 3. */

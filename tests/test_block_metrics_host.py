@@ -25,8 +25,8 @@ METRICS = {  # name: (id, sizes, needs second plane)
 
 
 def _lib():
-    hdr = os.path.join(HERE, "..", "x264_amd", "csrc", "block_metrics.h")
-    if not os.path.exists(OUT) or max(os.path.getmtime(SRC), os.path.getmtime(hdr)) > os.path.getmtime(OUT):
+    hdrs = [os.path.join(HERE, "..", "x264_amd", "csrc", h) for h in ("block_metrics.h", "dct_quant_block.h")]
+    if not os.path.exists(OUT) or max([os.path.getmtime(SRC)] + [os.path.getmtime(h) for h in hdrs]) > os.path.getmtime(OUT):
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC])
     return C.CDLL(OUT)
@@ -80,3 +80,37 @@ def test_block_metric_arithmetic(name, depth):
                 got = fn(mid, w, h, pa.ctypes.data, 64, pb.ctypes.data if two else None, 64)
                 want = oracle_metric(o, name, w, h, pa, 64, pb, 64)
                 assert got == (want & 0xFFFFFFFFFFFFFFFF if name in ("var", "hadamard_ac") else want & 0xFFFFFFFF), (name, w, h, kind, ox, oy)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_dct_quant8x8_block_arithmetic(depth):
+    """dq_block8x8 (x264_amd/csrc/dct_quant_block.h, the body of frame_dct_quant8x8_kernel) against the oracle's sub8x8_dct8 +
+    quant_8x8 (pinned against the reference vtables in tests/test_primitives_vs_ref.py)."""
+    L = _lib()
+    fn = L.dq8x8_host_u8 if depth == 8 else L.dq8x8_host_u16
+    fn.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p]
+    o = Oracle(depth)
+    dct, quant = o.f("dct"), o.f("quant", C.c_int)
+    rng = np.random.default_rng(3 + depth)
+    maxv = (1 << depth) - 1
+    p = lambda x: x.ctypes.data_as(C.c_void_p)  # noqa: E731
+    for trial in range(60):
+        fe = rng.integers(0, maxv + 1, size=(8, 24)).astype(o.dtype)
+        fd = rng.integers(0, maxv + 1, size=(8, 40)).astype(o.dtype)
+        if trial == 0:
+            fe[:] = maxv; fd[:] = 0
+        elif trial == 1:
+            fd[:, :8] = fe[:, :8]
+        elif trial == 2:
+            fe[:, :8] = (np.indices((8, 8)).sum(0) % 2) * maxv; fd[:] = maxv // 2
+        mf = rng.integers(300, 14000, size=64).astype(np.uint32)
+        bias = rng.integers(0, 30000, size=64).astype(np.uint32)
+        out = np.zeros(64, o.coef_dtype)
+        nz = fn(p(fe), 24, p(fd), 40, p(mf), p(bias), p(out))
+        fe16 = np.zeros((8, 16), o.dtype); fd32 = np.zeros((8, 32), o.dtype)
+        fe16[:, :8] = fe[:, :8]; fd32[:, :8] = fd[:, :8]
+        c = np.zeros(64, o.coef_dtype)
+        dct(3, p(c), p(fe16), p(fd32))
+        rnz = quant(1, p(c), p(mf.astype(o.ucoef_dtype)), p(bias.astype(o.ucoef_dtype)), 0, 0)
+        assert np.array_equal(out, c), trial
+        assert nz == rnz, trial

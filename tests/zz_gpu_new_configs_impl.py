@@ -175,3 +175,48 @@ def test_pixel_metric_batch(name, depth):
                     assert int(got[y * bw + x]) == want, (name, depth, w, h, x, y)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_frame_dct_quant8x8(depth):
+    """sub8x8_dct8 + quant_8x8 of every 8x8 block of a plane pair (x264hip_frame_dct_quant8x8) against the oracle's per-block
+    functions; the block arithmetic is also checked on CPU (tests/test_block_metrics_host.py)."""
+    import ctypes as C
+    import torch
+    from oracle.oraclelib import Oracle
+    o = Oracle(depth)
+    maxv = (1 << depth) - 1
+    rng = np.random.default_rng(41 + depth)
+    W, H = 1032, 72  # 129 x 9 blocks: a ragged last wave
+    fs, ds = W + 12, W + 40
+    fenc = rng.integers(0, maxv + 1, size=(H, fs)).astype(o.dtype)
+    fdec = rng.integers(0, maxv + 1, size=(H, ds)).astype(o.dtype)
+    fenc[:8, :8] = maxv; fdec[:8, :8] = 0
+    fdec[8:16, :8] = fenc[8:16, :8]
+    mf = rng.integers(300, 14000, size=64).astype(o.ucoef_dtype)
+    bias = rng.integers(0, 30000, size=64).astype(o.ucoef_dtype)
+    vdt = np.uint8 if depth == 8 else np.int16
+    fd, dd = torch.from_numpy(fenc.view(vdt)).cuda(), torch.from_numpy(fdec.view(vdt)).cuda()
+    bw, bh = W // 8, H // 8
+    coefs = torch.full((bh, bw, 64), 77, dtype=torch.int16 if depth == 8 else torch.int32, device="cuda")
+    nz = torch.full((bh, bw), 9, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx = lib.Context(64, 64, bit_depth=depth, max_frames=2, mv_range=32)
+    try:
+        ctx.frame_dct_quant8x8(fd.data_ptr(), fs, dd.data_ptr(), ds, W, H, mf, bias, coefs.data_ptr(), nz.data_ptr())
+        ctx.synchronize()
+    finally:
+        ctx.close()
+    got, gnz = coefs.cpu().numpy(), nz.cpu().numpy()
+    p = lambda x: x.ctypes.data_as(C.c_void_p)  # noqa: E731
+    dct, quant = o.f("dct"), o.f("quant", C.c_int)
+    fe16 = np.zeros((8, 16), o.dtype); fd32 = np.zeros((8, 32), o.dtype)
+    for by in range(bh):
+        for bx in range(0, bw, 3 if by else 1):
+            fe16[:, :8] = fenc[8 * by:8 * by + 8, 8 * bx:8 * bx + 8]
+            fd32[:, :8] = fdec[8 * by:8 * by + 8, 8 * bx:8 * bx + 8]
+            c = np.zeros(64, o.coef_dtype)
+            dct(3, p(c), p(fe16), p(fd32))
+            rnz = quant(1, p(c), p(mf), p(bias), 0, 0)
+            assert np.array_equal(got[by, bx], c), (by, bx)
+            assert int(gnz[by, bx]) == rnz, (by, bx)

@@ -21,6 +21,7 @@
 #include "me_search.h"
 #include "la_kernels.h"
 #include "block_metrics.h"
+#include "dct_quant_block.h"
 
 #define HIPCK( call )                                                                                        \
     do {                                                                                                     \
@@ -1403,6 +1404,32 @@ extern "C" int x264hip_frame_dct_quant4x4( x264hip_ctx *ctx, const void *fenc, i
     else
         frame_dct_quant4x4_kernel<uint16_t, int32_t><<<grd, 256, 0, ctx->stream>>>( (const uint16_t *)fenc, (long)fenc_stride, (const uint16_t *)fdec, (long)fdec_stride, bw, bh,
                                                                                     q, (int32_t *)coefs_dev, nz_dev );
+    HIPCK( hipGetLastError() );
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_frame_dct_quant8x8( x264hip_ctx *ctx, const void *fenc, intptr_t fenc_stride, const void *fdec, intptr_t fdec_stride, int width, int height,
+                                           const void *mf, const void *bias, void *coefs_dev, uint8_t *nz_dev )
+{
+    if( !ctx || !fenc || !fdec || !mf || !bias || !coefs_dev || !nz_dev || width <= 0 || height <= 0 || ( width & 7 ) || ( height & 7 ) ||
+        fenc_stride < width || fdec_stride < width )
+        return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    QuantTab8 q;
+    for( int i = 0; i < 64; i++ )
+    {
+        q.mf[i] = ctx->p.bit_depth == 8 ? ( (const uint16_t *)mf )[i] : ( (const uint32_t *)mf )[i];     // udctcoef (common/common.h)
+        q.bias[i] = ctx->p.bit_depth == 8 ? ( (const uint16_t *)bias )[i] : ( (const uint32_t *)bias )[i];
+    }
+    const int bw = width / 8, bh = height / 8;
+    const dim3 grd( ( bw + 63 ) / 64, bh );
+    if( ctx->p.bit_depth == 8 )
+        frame_dct_quant8x8_kernel<uint8_t, int16_t><<<grd, 64, 0, ctx->stream>>>( (const uint8_t *)fenc, (long)fenc_stride, (const uint8_t *)fdec, (long)fdec_stride, bw, q,
+                                                                                  (int16_t *)coefs_dev, nz_dev );
+    else
+        frame_dct_quant8x8_kernel<uint16_t, int32_t><<<grd, 64, 0, ctx->stream>>>( (const uint16_t *)fenc, (long)fenc_stride, (const uint16_t *)fdec, (long)fdec_stride, bw, q,
+                                                                                   (int32_t *)coefs_dev, nz_dev );
     HIPCK( hipGetLastError() );
     return X264HIP_OK;
 }

@@ -229,6 +229,11 @@ class Context:
         _ck(self.L.x264hip_frame_dct_quant4x4(self.h, C.c_void_p(fenc_ptr), C.c_ssize_t(fenc_stride), C.c_void_p(fdec_ptr), C.c_ssize_t(fdec_stride),
                                               int(width), int(height), _p(mf), _p(bias), C.c_void_p(coefs_ptr), C.c_void_p(nz_ptr)), "frame_dct_quant4x4")
 
+    def frame_dct_quant8x8(self, fenc_ptr, fenc_stride, fdec_ptr, fdec_stride, width, height, mf, bias, coefs_ptr, nz_ptr):
+        mf = np.ascontiguousarray(mf); bias = np.ascontiguousarray(bias)
+        _ck(self.L.x264hip_frame_dct_quant8x8(self.h, C.c_void_p(fenc_ptr), C.c_ssize_t(fenc_stride), C.c_void_p(fdec_ptr), C.c_ssize_t(fdec_stride),
+                                              int(width), int(height), _p(mf), _p(bias), C.c_void_p(coefs_ptr), C.c_void_p(nz_ptr)), "frame_dct_quant8x8")
+
     def hpel_filter(self, dsth_ptr, dstv_ptr, dstc_ptr, src_ptr, stride, width, height):
         _ck(self.L.x264hip_hpel_filter(self.h, C.c_void_p(dsth_ptr), C.c_void_p(dstv_ptr), C.c_void_p(dstc_ptr), C.c_void_p(src_ptr),
                                        C.c_ssize_t(stride), int(width), int(height)), "hpel_filter")
