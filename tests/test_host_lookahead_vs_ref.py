@@ -374,3 +374,68 @@ def test_rc_analyse_slice_outputs(preset, opts, over):
         assert o.own_cell == cells[k], (o.frame, o.type)
         assert o.rc_satd == (-1 if o.type in (4, 5) else ref["rc"][k][0]), (o.frame, o.type)
         assert o.planned == []
+
+
+def _run_collect(la, frames, **kw):
+    outs = la.run(frames, qp_offsets=True, **kw)
+    return [(o.frame, o.type, o.bframes, o.keyframe) for o in outs], \
+           [np.array(o.cost_est) for o in outs], [o.qp_offset.copy() for o in outs]
+
+
+@pytest.mark.parametrize("preset,over", [("medium", {}), ("fast", dict(b_adapt=2, bframes=5, open_gop=1, keyint_max=30))])
+def test_reset_starts_a_new_sequence(preset, over):
+    """x264hip_lookahead_reset: after a complete sequence, and in the middle of one (frames still queued and undecided), the next
+    sequence gives exactly what a fresh context gives -- frame numbering, key-frame distance, last_nonb and slot bookkeeping all
+    start over (bench.py reuses one context per GOP segment this way)."""
+    W, H = 176, 144
+    a = make_clip(W, H, 37, seed=51, scene_cuts=(14,), pan=(4, 1))
+    b = make_clip(W, H, 45, seed=52, scene_cuts=(30,), fade=(8, 8, 1.5, -10))
+    cfg = lib.la_config(W, H, preset, **over)
+    fresh = lib.Lookahead(cfg, backend=OracleBackend(cfg).struct, max_frames=64)
+    try:
+        want = _run_collect(fresh, b)
+    finally:
+        fresh.close()
+    be = OracleBackend(cfg)
+    la = lib.Lookahead(cfg, backend=be.struct, max_frames=64)
+    try:
+        _run_collect(la, a)                    # a whole sequence, drained
+        la.reset()
+        got = _run_collect(la, b, paced=False)
+        for i in range(20):                    # a sequence abandoned half way: frames queued, some decided, none drained
+            la.put(a[i])
+            la.get()
+        la.reset()
+        got2 = _run_collect(la, b)
+    finally:
+        la.close()
+    for g in (got, got2):
+        assert g[0] == want[0]
+        assert all(np.array_equal(x, y) for x, y in zip(g[1], want[1]))
+        assert all(np.array_equal(x, y) for x, y in zip(g[2], want[2]))
+
+
+def test_api_misuse_is_reported():
+    W, H = 96, 80
+    cfg = lib.la_config(W, H, "medium")
+    be = OracleBackend(cfg)
+    la = lib.Lookahead(cfg, backend=be.struct, max_frames=cfg["rc_lookahead"] + cfg["bframes"] + 8)
+    try:
+        assert la.get() is None and la.get(flush=True) is None            # nothing queued: not an error, just nothing
+        fr = make_clip(W, H, 80, seed=1)
+        with pytest.raises(lib.X264HipError):                             # more frames than slots without draining
+            for i in range(80):
+                la.put(fr[i])
+        la.reset()                                                        # the context stays usable
+        outs = la.run(fr[:30])
+        assert [o.frame for o in sorted(outs, key=lambda o: o.frame)] == list(range(30))
+    finally:
+        la.close()
+    with pytest.raises(ValueError):
+        lib.la_config(W, H, "medium", keyint_max=1 << 30, rc_lookahead=0)  # lookahead-less MB-tree
+    import ctypes as C
+    L = lib.load()
+    h = C.c_void_p()
+    p = lib.make_la_params(cfg)
+    p.b_adapt = 3
+    assert L.x264hip_lookahead_open_backend(C.byref(h), C.byref(p), C.byref(be.struct)) == -2
