@@ -268,6 +268,10 @@ typedef struct x264hip_la_params
                                * (vbv_lookahead, slicetype.c:1224-1286; key-frame analysis, lookahead.c:140-141), the B-frame and
                                * intra evaluations slicetype_decide adds for the row sums (:1916-1934), an MB-tree finish for every
                                * reference (:1087-1088) and the lookahead delay of encoder.c:1607-1608 */
+    int vfr_input;            /* param.b_vfr_input: frame durations come from the time stamps given to x264hip_lookahead_put_frame_pts
+                               * (slicetype.c:1755-1771; MB-tree weighs frames by duration, :1031,1063,1098-1101), and the delay grows
+                               * by one frame (encoder.c:1612) */
+    int timebase_num, timebase_den; /* param.i_timebase_num/den for vfr_input; 0 -> fps_den / fps_num (encoder.c:1119-1123) */
     int intra_refresh;        /* param.b_intra_refresh: no key frames after the first (slicetype.c:1405,1506,1681,1831); the column
                                * bookkeeping and the row-sum correction of x264_rc_analyse_slice (:2015-2032) stay in the encoder */
 } x264hip_la_params;
@@ -319,6 +323,8 @@ int  x264hip_lookahead_put_frame( x264hip_lookahead *la, const void *luma, int s
 int  x264hip_lookahead_put_frames( x264hip_lookahead *la, int n, const void *const *luma_dev, int stride );
 /* One call = the lookahead part of one x264_encoder_encode call.  flush != 0 once the input has ended.
  * *got = 1 and *out filled when a frame leaves the lookahead (coded order), 0 while the delay fills or at the end. */
+/* same with the picture's time stamp (x264_picture_t.i_pts, in timebase units); x264hip_lookahead_put_frame uses the frame number */
+int  x264hip_lookahead_put_frame_pts( x264hip_lookahead *la, const void *luma, int stride, int is_device, int forced_type, int64_t pts );
 int  x264hip_lookahead_get_frame( x264hip_lookahead *la, int flush, x264hip_la_frame *out, int *got );
 /* same, additionally copying the frame's f_qp_offset map (mb_w*mb_h floats: the AQ offsets, replaced by the MB-tree output
  * when mb_tree is on; read by rate control, encoder/ratecontrol.c:1761) when qp_offset != NULL and aq_mode != 0 */

@@ -65,6 +65,17 @@ RH_API rh_ctx *rh_open( int width, int height, const char *preset, const char *t
         {
             char *eq = strchr( tok, '=' );
             if( eq ) *eq = 0;
+            if( !strcmp( tok, "vfr-input" ) ) /* a field of x264_param_t without an option name (x264.h: b_vfr_input) */
+            {
+                c->param.b_vfr_input = eq ? atoi( eq + 1 ) : 1;
+                continue;
+            }
+            if( !strcmp( tok, "timebase" ) && eq ) /* i_timebase_num / i_timebase_den: set by the CLI, not an option of x264_param_parse */
+            {
+                unsigned a = 0, b = 0;
+                if( sscanf( eq + 1, "%u/%u", &a, &b ) == 2 ) { c->param.i_timebase_num = a; c->param.i_timebase_den = b; }
+                continue;
+            }
             if( x264_param_parse( &c->param, tok, eq ? eq + 1 : NULL ) < 0 )
             {
                 fprintf( stderr, "rh_open: bad option %s\n", tok );
@@ -418,6 +429,8 @@ RH_API void rh_set_vbv_dump( int *planned_type, int *planned_satd, int *rows ) {
 static const int *rh_rc_cells = NULL;
 static int *rh_out_rc = NULL;
 RH_API void rh_set_rc_dump( const int *cells, int *out ) { rh_rc_cells = cells; rh_out_rc = out; }
+static const int64_t *rh_pts = NULL; /* optional [n_frames] x264_picture_t.i_pts (default: the frame index) */
+RH_API void rh_set_pts( const int64_t *pts ) { rh_pts = pts; }
 static const int *rh_forced_types = NULL; /* optional [n_frames] x264_picture_t.i_type of every input picture (x264.h:274-280) */
 RH_API void rh_set_forced_types( const int *types ) { rh_forced_types = types; }
 
@@ -488,7 +501,7 @@ RH_API int rh_lookahead_run( rh_ctx *c, const pixel *yuv, int n_frames, int luma
         x264_frame_t *fenc = rh_make_frame( c, y, luma_only ? NULL : y+ysz, luma_only ? NULL : y+ysz+csz, 0 );
         if( !fenc ) return -1;
         fenc->i_frame = h->frames.i_input++;
-        fenc->i_pts = fenc->i_frame;
+        fenc->i_pts = rh_pts ? rh_pts[i] : fenc->i_frame;
         if( rh_forced_types ) /* x264_frame_copy_picture, frame.c:392-400 */
             fenc->i_type = fenc->i_forced_type = rh_forced_types[i] < X264_TYPE_AUTO || rh_forced_types[i] > X264_TYPE_KEYFRAME ? X264_TYPE_AUTO : rh_forced_types[i];
         if( fenc->i_frame == 0 )

@@ -439,3 +439,41 @@ def test_api_misuse_is_reported():
     p = lib.make_la_params(cfg)
     p.b_adapt = 3
     assert L.x264hip_lookahead_open_backend(C.byref(h), C.byref(p), C.byref(be.struct)) == -2
+
+
+@pytest.mark.parametrize("preset,opts,over,stamps,paced", [
+    ("medium", "vfr-input=1", dict(vfr_input=1), "frames", True),
+    ("medium", "vfr-input=1", dict(vfr_input=1), "steps", True),
+    ("medium", "vfr-input=1,timebase=1/1000", dict(vfr_input=1, timebase_num=1, timebase_den=1000), "ms", True),
+    ("fast", "vfr-input=1,timebase=1/1000,b-adapt=2,bframes=5,fps=30000/1001",
+     dict(vfr_input=1, timebase_num=1, timebase_den=1000, b_adapt=2, bframes=5, fps_num=30000, fps_den=1001), "ms", False),
+    ("medium", "vfr-input=1,timebase=1001/30000,vbv-bufsize=300,vbv-maxrate=600",
+     dict(vfr_input=1, timebase_num=1001, timebase_den=30000, vbv_bufsize=300, vbv_maxrate=600), "steps", True),
+])
+def test_vfr_input_durations(preset, opts, over, stamps, paced):
+    """b_vfr_input: frame durations from the time stamps (slicetype.c:1755-1771) weigh the MB-tree propagation (:1031,1063,
+    1098-1101); one more frame of delay (encoder.c:1612).  Decisions, cost cells and f_qp_offset against the reference."""
+    W, H, nf = 176, 144, 50
+    rng = np.random.default_rng(1)
+    pts = {"frames": np.arange(nf), "steps": np.cumsum(rng.choice([1, 1, 2, 3], size=nf)),
+           "ms": np.cumsum(rng.choice([33, 34, 40, 66, 17], size=nf))}[stamps].astype(np.int64)
+    frames = make_clip(W, H, nf, seed=7, scene_cuts=(23,), pan=(3, 1))
+    r = refharness.Ref(W, H, preset, opts=opts)
+    try:
+        ref = r.lookahead_run(frames, with_qp_offsets=True, pts=pts)
+        rc = r.cfg
+    finally:
+        r.close()
+    cfg = lib.la_config(W, H, preset, **over)
+    la = lib.Lookahead(cfg, backend=OracleBackend(cfg).struct, max_frames=nf + 6)
+    try:
+        assert la.delay == rc["delay"]
+        outs = la.run(frames, qp_offsets=True, pts=pts, paced=paced)
+    finally:
+        la.close()
+    assert [o.frame for o in outs] == list(ref["idx"])
+    assert [o.type for o in outs] == list(ref["type"])
+    nb = cfg["bframes"] + 2
+    for k, o in enumerate(outs):
+        assert np.array_equal(np.array(o.cost_est)[:nb, :nb], ref["cost"][k][:nb, :nb]), o.frame
+        assert np.array_equal(o.qp_offset, ref["qp_offset"][k]), ("f_qp_offset", o.frame, o.type)

@@ -59,6 +59,9 @@ struct LaFrame
     int planned_type[LOOKAHEAD_MAX + 1] = { T_AUTO };
     int planned_satd[LOOKAHEAD_MAX + 1] = { 0 };
     int own_d0 = 0, own_d1 = 0; // the cell the frame is coded with (distances to its references), set by decide()
+    int64_t pts = 0;
+    int i_duration = 2;         // field units (slicetype.c:1759-1768)
+    float f_duration = 0.04f;   // seconds, as MB-tree reads it (:1769-1771)
 };
 
 static int ue_size( unsigned v ) // bs_size_ue, common/bitstream.h:278 (2*floor(log2(v+1))+1)
@@ -88,7 +91,9 @@ struct Lookahead
     LaFrame *last_nonb = nullptr;
     std::vector<int> free_slots;
     std::vector<LaFrame *> pending_prefetch;
-    float f_duration = 0.04f;   // every frame's f_duration (constant frame rate)
+    float f_duration = 0.04f;   // a frame's f_duration at constant frame rate
+    int64_t i_prev_duration = 2, i_prev_duration0 = 2; // encoder.c:1644
+    uint32_t units_in_tick = 1, time_scale = 50; // sps->vui (encoder/set.c:223-224)
     float qcompress = 0.6f;
     uint64_t stats[8] = { 0 };
     int err = 0;
@@ -399,7 +404,7 @@ struct Lookahead
         o.dist_p0 = b - p0; o.dist_p1 = p1 - b; o.referenced = referenced;
         int dsf = ( ( ( b - p0 ) << 8 ) + ( ( p1 - p0 ) >> 1 ) ) / ( p1 - p0 );
         o.bipred_weight = p.dev.weighted_bipred ? 64 - ( dsf >> 2 ) : 32;
-        o.fps_factor = (float)( clip_duration( f_duration ) / ( clip_duration( average_duration ) * 256.0f ) * 0.5f );
+        o.fps_factor = (float)( clip_duration( frames[b]->f_duration ) / ( clip_duration( average_duration ) * 256.0f ) * 0.5f );
         ops.push_back( o );
         if( vbv_lookahead_on() && referenced ) // slicetype.c:1087-1088: VBV rate control reads f_qp_offset of every reference
             mbt_finish( ops, frames[b], average_duration, b == p1 ? b - p0 : 0 );
@@ -410,7 +415,7 @@ struct Lookahead
         x264hip_mbtree_op o;
         memset( &o, 0, sizeof( o ) );
         o.type = X264HIP_MBT_FINISH; o.slot_b = o.slot_p0 = o.slot_p1 = f->slot;
-        o.fps_factor_i = (int)round( clip_duration( average_duration ) / clip_duration( f_duration ) * 256 / 0.5f );
+        o.fps_factor_i = (int)round( clip_duration( average_duration ) / clip_duration( f->f_duration ) * 256 / 0.5f );
         float weightdelta = 0.0;
         if( ref0_distance && f->weighted_cost_delta[ref0_distance - 1] > 0 )
             weightdelta = ( 1.0 - f->weighted_cost_delta[ref0_distance - 1] );
@@ -425,7 +430,7 @@ struct Lookahead
         std::vector<x264hip_mbtree_op> ops;
         float total_duration = 0.0;
         for( int j = 0; j <= num_frames; j++ )
-            total_duration += f_duration;
+            total_duration += frames[j]->f_duration;
         float average_duration = total_duration / ( num_frames + 1 );
         int i = num_frames;
         if( b_intra ) frame_cost( frames, 0, 0, 0 );
@@ -711,6 +716,17 @@ struct Lookahead
     void decide()
     {
         if( next.empty() ) return;
+        // frame durations (:1755-1771): from the time stamps with VFR input (the last queued frame repeats the previous duration),
+        // two field units otherwise
+        for( size_t i = 0; i < next.size(); i++ )
+        {
+            if( p.vfr_input )
+                next[i]->i_duration = i + 1 < next.size() ? (int)( 2 * ( next[i + 1]->pts - next[i]->pts ) ) : (int)i_prev_duration;
+            else
+                next[i]->i_duration = 2;
+            i_prev_duration = next[i]->i_duration;
+            next[i]->f_duration = (float)( (double)next[i]->i_duration * units_in_tick / time_scale );
+        }
         if( ( p.dev.bframes && p.b_adapt ) || p.scenecut_threshold || p.mb_tree || vbv_lookahead_on() )
             analyse( 0 );
         int bframes, brefs;
@@ -951,11 +967,22 @@ static int la_init( x264hip_lookahead *la, const x264hip_la_params *params )
     if( p.mb_tree || p.vbv )
         L.i_delay = L.i_delay > p.rc_lookahead ? L.i_delay : p.rc_lookahead;
     L.slicetype_length = L.i_delay;
+    L.i_delay += !!p.vfr_input; // encoder.c:1612: one more frame until the duration of the first is known
     L.b_analyse_keyframe = p.mb_tree || ( p.vbv && p.rc_lookahead ); // lookahead.c:140-141 (no stats read)
     {
         // slicetype.c:1767-1771: i_duration = 2 field units for a progressive frame, time base 1/(2*fps)
         const int fn = p.fps_num > 0 ? p.fps_num : 25, fd = p.fps_den > 0 ? p.fps_den : 1;
         L.f_duration = (float)( (double)2 * fd / ( 2.0 * fn ) );
+        // timebase (encoder.c:1119-1123, :1559-1560) and the VUI timing it becomes (set.c:223-224); encoder.c:1644
+        auto gcd = []( uint64_t a, uint64_t b ) { while( b ) { uint64_t t = a % b; a = b; b = t; } return a; };
+        uint64_t rfn = fn, rfd = fd, g = gcd( rfn, rfd );
+        rfn /= g; rfd /= g;
+        uint64_t tn = p.vfr_input && p.timebase_num > 0 && p.timebase_den > 0 ? p.timebase_num : rfd;
+        uint64_t td = p.vfr_input && p.timebase_num > 0 && p.timebase_den > 0 ? p.timebase_den : rfn;
+        g = gcd( tn, td ); tn /= g; td /= g;
+        if( td * 2 > 0xFFFFFFFFull ) return X264HIP_EINVAL;
+        L.units_in_tick = (uint32_t)tn; L.time_scale = (uint32_t)( td * 2 );
+        L.i_prev_duration = L.i_prev_duration0 = (int64_t)( ( rfd * L.time_scale ) / ( rfn * L.units_in_tick ) );
         L.qcompress = p.qcompress > 0 ? p.qcompress : 0.6f;
     }
     L.i_last_keyframe = -p.keyint_max;
@@ -966,7 +993,7 @@ static int slots_needed( const x264hip_la_params *p )
 {
     int delay = p->b_adapt == 2 ? ( p->dev.bframes > 3 ? p->dev.bframes : 3 ) * 4 : p->dev.bframes;
     if( ( p->mb_tree || p->vbv ) && p->rc_lookahead > delay ) delay = p->rc_lookahead;
-    return delay + p->dev.bframes + 8;
+    return delay + p->dev.bframes + 8 + !!p->vfr_input;
 }
 
 extern "C" int x264hip_lookahead_open_backend( x264hip_lookahead **out, const x264hip_la_params *params, const x264hip_backend *backend )
@@ -1023,6 +1050,7 @@ extern "C" int x264hip_lookahead_reset( x264hip_lookahead *la )
     L.next.clear(); L.current.clear(); L.last_nonb = nullptr; L.pending_prefetch.clear();
     L.i_input = 0;
     L.i_last_keyframe = -L.p.keyint_max;
+    L.i_prev_duration = L.i_prev_duration0;
     return X264HIP_OK;
 }
 
@@ -1084,12 +1112,20 @@ extern "C" int x264hip_lookahead_put_frames( x264hip_lookahead *la, int n, const
 
 extern "C" int x264hip_lookahead_put_frame( x264hip_lookahead *la, const void *luma, int stride, int is_device, int forced_type )
 {
+    // x264_picture_t.i_pts defaults to the frame number here (what the CLI gives constant-frame-rate input)
+    return x264hip_lookahead_put_frame_pts( la, luma, stride, is_device, forced_type, la ? la->L.i_input : 0 );
+}
+
+extern "C" int x264hip_lookahead_put_frame_pts( x264hip_lookahead *la, const void *luma, int stride, int is_device, int forced_type, int64_t pts )
+{
     if( !la || !luma ) return X264HIP_EINVAL;
     Lookahead &L = la->L;
     ScopeNs tm_api( L.stats[7] );
     if( L.err ) return L.err;
     if( L.free_slots.empty() ) return X264HIP_ESTATE;
     LaFrame *f = new_frame( L, forced_type );
+    f->pts = pts;
+    f->f_duration = L.f_duration;
     int rc = L.be.frame_put( L.be.user, f->slot, luma, stride, is_device );
     if( rc )
     {

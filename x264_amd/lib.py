@@ -274,7 +274,8 @@ class LaParams(C.Structure):
     _fields_ = [("dev", Params), ("keyint_max", C.c_int), ("keyint_min", C.c_int), ("scenecut_threshold", C.c_int),
                 ("b_adapt", C.c_int), ("b_pyramid", C.c_int), ("rc_lookahead", C.c_int), ("mb_tree", C.c_int),
                 ("weightp", C.c_int), ("open_gop", C.c_int), ("frame_refs", C.c_int), ("psy", C.c_int),
-                ("rc_is_cqp", C.c_int), ("fps_num", C.c_int), ("fps_den", C.c_int), ("qcompress", C.c_float), ("vbv", C.c_int), ("intra_refresh", C.c_int)]
+                ("rc_is_cqp", C.c_int), ("fps_num", C.c_int), ("fps_den", C.c_int), ("qcompress", C.c_float), ("vbv", C.c_int), ("vfr_input", C.c_int), ("timebase_num", C.c_int),
+                ("timebase_den", C.c_int), ("intra_refresh", C.c_int)]
 
 
 FRAME_PUT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int)
@@ -385,7 +386,7 @@ def la_config(width, height, preset="medium", bit_depth=8, tune="", **over):
     c = dict(bframes=3, b_adapt=1, b_pyramid=2, rc_lookahead=40, me="hex", me_range=16, subme=7, weightp=2,
              weighted_bipred=1, mb_tree=1, aq_mode=1, aq_strength=1.0, scenecut=40, keyint_max=250, keyint_min=0,
              open_gop=0, frame_refs=3, psy=1, rc_is_cqp=0, bframe_bias=0, fps=25.0, mv_range=0, fps_num=25, fps_den=1,
-             qcompress=0.6, threads=1, lookahead_threads=0, bitrate=0, vbv_maxrate=0, vbv_bufsize=0, transform_8x8=1, intra_refresh=0)
+             qcompress=0.6, threads=1, lookahead_threads=0, bitrate=0, vbv_maxrate=0, vbv_bufsize=0, transform_8x8=1, intra_refresh=0, vfr_input=0, timebase_num=0, timebase_den=0)
     c.update(PRESETS[preset])
     for t in filter(None, tune.replace(",", " ").split()):
         tv = dict(TUNES[t])
@@ -516,7 +517,7 @@ def make_la_params(cfg, cost_mv=None, max_frames=0):
                  max_frames, int(not cfg["do_edges"]), cfg["lookahead_threads"], cost_mv.ctypes.data + 2 * centre)
     p = LaParams(dev, cfg["keyint_max"], cfg["keyint_min"], cfg["scenecut"], cfg["b_adapt"], cfg["b_pyramid"],
                  cfg["rc_lookahead"], cfg["mb_tree"], cfg["weightp"], cfg["open_gop"], cfg["frame_refs"], cfg["psy"],
-                 cfg["rc_is_cqp"], cfg["fps_num"], cfg["fps_den"], cfg["qcompress"], cfg["vbv"], cfg["intra_refresh"])
+                 cfg["rc_is_cqp"], cfg["fps_num"], cfg["fps_den"], cfg["qcompress"], cfg["vbv"], cfg["vfr_input"], cfg["timebase_num"], cfg["timebase_den"], cfg["intra_refresh"])
     p._keep = cost_mv
     return p
 
@@ -553,7 +554,16 @@ class Lookahead:
     def ctx_handle(self):
         return C.c_void_p(self.L.x264hip_lookahead_ctx(self.h))
 
-    def put(self, luma=None, device_ptr=None, stride=None, forced_type=0):
+    def put(self, luma=None, device_ptr=None, stride=None, forced_type=0, pts=None):
+        if pts is not None:
+            self.L.x264hip_lookahead_put_frame_pts.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64]
+            if device_ptr is not None:
+                src, st, dev = C.c_void_p(device_ptr), stride or self.cfg["width"], 1
+            else:
+                luma = np.ascontiguousarray(luma, self.dtype)
+                src, st, dev = _p(luma), luma.shape[1], 0
+            _ck(self.L.x264hip_lookahead_put_frame_pts(self.h, src, st, dev, forced_type, int(pts)), "lookahead_put_frame_pts")
+            return
         if device_ptr is not None:
             _ck(self.L.x264hip_lookahead_put_frame(self.h, C.c_void_p(device_ptr), stride or self.cfg["width"], 1,
                                                    forced_type), "lookahead_put_frame")
@@ -593,7 +603,7 @@ class Lookahead:
         _ck(self.L.x264hip_lookahead_stats(self.h, _p(out), 8), "lookahead_stats")
         return out
 
-    def run(self, frames=None, device_ptrs=None, stride=None, paced=True, qp_offsets=False, forced_types=None, vbv=False):
+    def run(self, frames=None, device_ptrs=None, stride=None, paced=True, qp_offsets=False, forced_types=None, vbv=False, pts=None):
         """Feed a whole clip.  paced=True interleaves put/get exactly like x264_encoder_encode; paced=False puts
         every frame first (deep prefetch) -- results are identical, only the batching differs."""
         outs = []
@@ -605,10 +615,11 @@ class Lookahead:
             n_loop = n
         for i in range(n_loop):
             ft = int(forced_types[i]) if forced_types is not None else 0
+            ts = None if pts is None else int(pts[i])
             if frames is not None:
-                self.put(frames[i], forced_type=ft)
+                self.put(frames[i], forced_type=ft, pts=ts)
             else:
-                self.put(device_ptr=device_ptrs[i], stride=stride, forced_type=ft)
+                self.put(device_ptr=device_ptrs[i], stride=stride, forced_type=ft, pts=ts)
             if paced:
                 o = self.get(False, qp_offsets, vbv)
                 if o is not None:
