@@ -1154,6 +1154,9 @@ extern "C" int x264hip_lookahead_get_frame_vbv( x264hip_lookahead *la, int flush
 {
     if( !la || !out || !got ) return X264HIP_EINVAL;
     Lookahead &L = la->L;
+    // the backend entries the extra outputs need are checked before a frame is taken off the queue
+    if( ( vbv && L.p.mb_tree && !L.be.frame_cost_recalculate ) || ( ( row_satds || row_satds_intra ) && !L.be.get_row_satds ) )
+        return X264HIP_EINVAL;
     ScopeNs tm_api( L.stats[7] );
     *got = 0;
     if( L.err ) return L.err;
@@ -1199,7 +1202,6 @@ extern "C" int x264hip_lookahead_get_frame_vbv( x264hip_lookahead *la, int flush
         {
             if( L.p.mb_tree )
             {
-                if( !L.be.frame_cost_recalculate ) return X264HIP_EINVAL;
                 if( L.need( L.be.frame_cost_recalculate( L.be.user, f->slot, f->own_d0, f->own_d1, is_b( f->i_type ), &cost ) ) ) return L.err;
                 int unused = 0;
                 if( f->own_d0 && L.p.vbv && f->cost_est[0][0] >= 0 )
@@ -1210,7 +1212,6 @@ extern "C" int x264hip_lookahead_get_frame_vbv( x264hip_lookahead *la, int flush
         }
         vbv->satd = cost;
     }
-    if( ( row_satds || row_satds_intra ) && !L.be.get_row_satds ) return X264HIP_EINVAL;
     if( row_satds && f->cost_est[f->own_d0][f->own_d1] >= 0 )
         if( L.need( L.be.get_row_satds( L.be.user, f->slot, f->own_d0, f->own_d1, row_satds ) ) ) return L.err;
     if( row_satds_intra && f->cost_est[0][0] >= 0 ) // computed by any evaluation that found them missing, B evaluations included (slicetype.c:714-757)
