@@ -182,6 +182,34 @@ int  x264hip_frame_cost_recalculate( x264hip_ctx *ctx, int slot_b, int dist_p0, 
  * mv[i].  Planes are device pointers.  Used for parity and for the SAD/SATD GB/s metric. */
 int  x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx, const void *fenc_plane, const void *ref_plane,
                               int stride, int blocks_w, int blocks_h, const int16_t *mv_dev, int *out_dev );
+/* ---- main-encode motion search, functional baseline --------------------------------------------------
+ * x264_me_search_ref (encoder/me.c:182-798: DIA, HEX, UMH, ESA, TESA) + refine_subpel (:865-992) for a batch of independent
+ * requests -- what analyse.c hands to x264_me_search_ref for one partition (x264_me_t, common/me.h:33-56, plus the limits of
+ * h->mb.mv_limit_fpel / mv_min_spel / mv_max_spel): luma only, one reference per request, no weights.  Planes are device
+ * pointers to pixel (0,0); the reference planes are the four half-pel planes x264_frame_filter produces (common/mc.c:704-784),
+ * padded far enough for the limits given.  integral_dev: element (0,0) of the 8x8-sum plane with the reference stride,
+ * integral_lower elements from there to the 4x4-sum plane (frame.c:240-256); only read by TESA requests.  cost_mv_dev: the centred
+ * cost table of the request's qp (h->cost_mv[qp], analyse.c:151-157) on the device.  out[i] = { mv x, mv y (quarter-pel), cost,
+ * cost_mv } as x264_me_search_ref leaves them in x264_me_t.  One thread per request: bit-exact, not tuned. */
+#define X264HIP_ME_MVC_MAX 10
+typedef struct x264hip_me_request
+{
+    int i_pixel;              /* PIXEL_16x16 = 0 .. PIXEL_4x4 = 6 */
+    int me_method;            /* X264_ME_DIA = 0, HEX, UMH, ESA, TESA = 4 */
+    int subpel_refine;        /* h->mb.i_subpel_refine (0..11) */
+    int me_range;
+    int mbcmp_satd, fpelcmp_satd; /* h->pixf.mbcmp / fpelcmp are SATD (encoder.c:1409-1427) */
+    int x, y;                 /* block origin in luma samples */
+    int mvp[2];               /* quarter-pel predictor */
+    int lim_min[2], lim_max[2];   /* h->mb.mv_limit_fpel */
+    int spel_min[2], spel_max[2]; /* h->mb.mv_min_spel / mv_max_spel */
+    int n_mvc;                /* candidates in mvc (x264_me_search_ref's mvc / i_mvc) */
+    int16_t mvc[X264HIP_ME_MVC_MAX][2];
+} x264hip_me_request;
+int  x264hip_me_search_batch( x264hip_ctx *ctx, int n, const x264hip_me_request *reqs, const void *fenc_plane_dev, intptr_t fenc_stride,
+                              const void *const ref_planes_dev[4], intptr_t ref_stride, const uint16_t *integral_dev, intptr_t integral_lower,
+                              const uint16_t *cost_mv_dev, int *out );
+
 /* The block metrics of x264_pixel_function_t that only the main encode calls, over a raster of blocks_w x blocks_h blocks of size_idx
  * (PIXEL_16x16 = 0 .. PIXEL_4x4 = 6, common/pixel.h:37-59) of device-resident planes sharing one stride; block (x, y) starts at
  * pixel (x*w, y*h).  out_dev[y*blocks_w + x] (device, uint64):

@@ -22,3 +22,33 @@ extern "C" uint64_t bm_host_u16( int metric, int w, int h, const uint16_t *a, lo
 
 extern "C" int dq8x8_host_u8( const uint8_t *fe, long fs, const uint8_t *fd, long ds, const uint32_t *mf, const uint32_t *bias, int16_t *out ) { return dq_block8x8<uint8_t, int16_t>( fe, fs, fd, ds, mf, bias, out ); }
 extern "C" int dq8x8_host_u16( const uint16_t *fe, long fs, const uint16_t *fd, long ds, const uint32_t *mf, const uint32_t *bias, int32_t *out ) { return dq_block8x8<uint16_t, int32_t>( fe, fs, fd, ds, mf, bias, out ); }
+
+// the main-encode motion search of x264_amd/csrc/me_full.h (body of me_full_kernel) on host memory
+#include <stdlib.h>
+#include "../../x264_amd/csrc/me_full.h"
+struct MfHostReq  // C layout handed over by the Python test (pointers as given)
+{
+    int i_pixel, me_method, subpel_refine, me_range, mbcmp_satd, fpelcmp_satd;
+    const void *fenc; int fenc_stride;
+    const void *ref[4]; int stride;
+    const uint16_t *integral; long integral_lower;
+    int mvp[2], lim_min[2], lim_max[2], spel_min[2], spel_max[2];
+    const uint16_t *cost_mv;
+};
+template <typename T>
+static void mf_run( const MfHostReq *h, const int16_t *mvc, int n_mvc, int *out )
+{
+    MfReq<T> r;
+    r.i_pixel = h->i_pixel; r.me_method = h->me_method; r.subpel_refine = h->subpel_refine; r.me_range = h->me_range;
+    r.mbcmp_satd = h->mbcmp_satd; r.fpelcmp_satd = h->fpelcmp_satd;
+    r.fenc = (const T *)h->fenc; r.fenc_stride = h->fenc_stride;
+    for( int k = 0; k < 4; k++ ) r.ref[k] = (const T *)h->ref[k];
+    r.stride = h->stride; r.integral = h->integral; r.integral_lower = h->integral_lower;
+    for( int k = 0; k < 2; k++ ) { r.mvp[k] = h->mvp[k]; r.lim_min[k] = h->lim_min[k]; r.lim_max[k] = h->lim_max[k]; r.spel_min[k] = h->spel_min[k]; r.spel_max[k] = h->spel_max[k]; }
+    r.cost_mv = h->cost_mv;
+    r.scratch = malloc( (size_t)MF_TESA_ROWS_MAX * MF_TESA_WIDTH_MAX * 12 );
+    mefull::mf_me_search_full<T>( &r, (const int16_t( * )[2])mvc, n_mvc, out );
+    free( r.scratch );
+}
+extern "C" void mf_host_u8( const MfHostReq *h, const int16_t *mvc, int n_mvc, int *out ) { mf_run<uint8_t>( h, mvc, n_mvc, out ); }
+extern "C" void mf_host_u16( const MfHostReq *h, const int16_t *mvc, int n_mvc, int *out ) { mf_run<uint16_t>( h, mvc, n_mvc, out ); }

@@ -220,3 +220,51 @@ def test_frame_dct_quant8x8(depth):
             rnz = quant(1, p(c), p(mf), p(bias), 0, 0)
             assert np.array_equal(got[by, bx], c), (by, bx)
             assert int(gnz[by, bx]) == rnz, (by, bx)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_me_search_batch(depth):
+    """x264hip_me_search_batch (x264_me_search_ref with DIA / HEX / UMH / ESA / TESA + refine_subpel, one thread per request) on the
+    calls recorded from the reference (tests/golden/me_full_d{8,10}.npz); the same code passes them on CPU
+    (tests/test_me_full_host.py)."""
+    import torch
+    from tests.common import ME_METHODS
+    from tests.test_me_full_host import request_geometry
+    z = np.load(os.path.join(GOLD, "me_full_d%d.npz" % depth))
+    W, H, pw, ph, padh, padv, mv_range = (int(v) for v in z["geom"])
+    vdt = np.uint8 if depth == 8 else np.int16
+    isz = 1 if depth == 8 else 2
+    planes = [torch.from_numpy(np.ascontiguousarray(z["planes"][p]).view(vdt)).cuda() for p in range(4)]
+    frame = torch.from_numpy(np.ascontiguousarray(z["fenc_frame"], np.uint8 if depth == 8 else np.uint16).view(vdt)).cuda()
+    integral = torch.from_numpy(np.ascontiguousarray(z["integral"]).view(np.int16)).cuda()
+    cost_mv = np.ascontiguousarray(z["cost_mv"])
+    centre = (cost_mv.size - 1) // 2
+    cmv = torch.from_numpy(cost_mv.view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    org0 = padv * pw + padh
+    reqs, want, subs = [], [], []
+    for me in ME_METHODS:
+        for call in z["calls_%s" % me]:
+            i_pixel, mb_x, mb_y, xoff, yoff, subme, me_range, mvpx, mvpy, n_mvc = (int(v) for v in call[:10])
+            smin, smax, lim_min, lim_max, sx, sy, org = request_geometry(z["geom"], call)
+            q = lib.MeRequest()
+            q.i_pixel, q.me_method, q.subpel_refine, q.me_range = i_pixel, ME_METHODS[me], subme, me_range
+            q.mbcmp_satd, q.fpelcmp_satd = 1, int(me == "tesa")
+            q.x, q.y = sx, sy
+            for k in range(2):
+                q.mvp[k] = (mvpx, mvpy)[k]
+                q.lim_min[k], q.lim_max[k], q.spel_min[k], q.spel_max[k] = lim_min[k], lim_max[k], smin[k], smax[k]
+            q.n_mvc = n_mvc
+            for i in range(4):
+                q.mvc[i][0], q.mvc[i][1] = int(call[10 + 2 * i]), int(call[11 + 2 * i])
+            reqs.append(q); want.append(call[18:22]); subs.append(subme)
+    ctx = lib.Context(64, 64, bit_depth=depth, max_frames=2, mv_range=32)
+    try:
+        got = ctx.me_search_batch(reqs, frame.data_ptr(), frame.shape[1], [p.data_ptr() + org0 * isz for p in planes], pw,
+                                  integral.data_ptr() + org0 * 2, ph * pw, cmv.data_ptr() + 2 * centre)
+    finally:
+        ctx.close()
+    for k in range(len(reqs)):
+        n = 4 if subs[k] >= 2 else 3
+        assert np.array_equal(got[k][:n], want[k][:n]), (k, got[k].tolist(), [int(v) for v in want[k]])
+    assert len(reqs) >= 500

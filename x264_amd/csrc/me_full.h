@@ -1,0 +1,672 @@
+// Main-encode motion search: x264_me_search_ref with DIA / HEX / UMH / ESA / TESA and refine_subpel
+// (encoder/me.c:182-798, :865-992) for any partition size, luma only, one reference, no weights -- as a FUNCTIONAL device baseline:
+// one thread per request, the search written as plain C++ (BM_HD: the same functions are compiled for the host by tests/tools and
+// checked against the oracle and the golden recordings of the reference without a GPU).  It exists so that the main-encode
+// search has a bit-exact device implementation to build the parallel version against (candidates across lanes, requests
+// across waves: DESIGN.md section 8); it is NOT tuned -- divergent control flow, per-thread interpolation buffers in scratch.
+#pragma once
+#include <stdint.h>
+
+#ifndef BM_HD
+#define BM_HD __host__ __device__ __forceinline__
+#endif
+
+#define MF_COST_MAX ( 1 << 28 )
+#define MF_TESA_WIDTH_MAX 160   // ( 2 * me_range + 4 ) & ~3 columns, me_range <= 64 ... plus rounding
+#define MF_TESA_ROWS_MAX 132    // 2 * me_range + 1 rows + 1
+
+BM_HD int clip3( int v, int lo, int hi ) { return v < lo ? lo : v > hi ? hi : v; }
+BM_HD int imin( int a, int b ) { return a < b ? a : b; }
+BM_HD int imax( int a, int b ) { return a > b ? a : b; }
+BM_HD int rnd_avg( int a, int b ) { return ( a + b + 1 ) >> 1; }
+BM_HD int mf_abs( int v ) { return v < 0 ? -v : v; }
+
+// one call of the search (x264_me_t + the h->mb limits it reads); every pointer is addressable by the code that runs the search
+template <typename T>
+struct MfReq
+{
+    int i_pixel;                // PIXEL_16x16 .. PIXEL_4x4 (0..6)
+    int me_method;              // 0 dia, 1 hex, 2 umh, 3 esa, 4 tesa
+    int subpel_refine;          // h->mb.i_subpel_refine
+    int me_range;
+    int mbcmp_satd, fpelcmp_satd;
+    const T *fenc;              // the block to match
+    int fenc_stride;
+    const T *ref[4];            // full / H / V / HV planes at the block origin
+    int stride;
+    const uint16_t *integral;   // 8x8-sum plane at the block origin (TESA only)
+    long integral_lower;        // elements from there to the 4x4-sum plane
+    int mvp[2];
+    int lim_min[2], lim_max[2]; // h->mb.mv_limit_fpel
+    int spel_min[2], spel_max[2];
+    const uint16_t *cost_mv;    // centred
+    void *scratch;              // TESA: MF_TESA_ROWS_MAX * MF_TESA_WIDTH_MAX entries of 12 bytes
+};
+
+namespace mefull {
+
+template <typename T>
+BM_HD int mf_sad( const T *a, int sa, const T *b, int sb, int w, int h )
+{
+    int s = 0;
+    for( int y = 0; y < h; y++ )
+        for( int x = 0; x < w; x++ )
+            s += mf_abs( a[y*sa+x] - b[y*sb+x] );
+    return s;
+}
+
+template <typename T>
+BM_HD int mf_ssd( const T *a, int sa, const T *b, int sb, int w, int h )
+{
+    int s = 0;
+    for( int y = 0; y < h; y++ )
+        for( int x = 0; x < w; x++ )
+        {
+            int d = a[y*sa+x] - b[y*sb+x];
+            s += d*d;
+        }
+    return s;
+}
+
+BM_HD void hadamard4( int *v, int step )
+{
+    int s01 = v[0] + v[step], d01 = v[0] - v[step], s23 = v[2*step] + v[3*step], d23 = v[2*step] - v[3*step];
+    v[0] = s01 + s23; v[step] = d01 + d23; v[2*step] = s01 - s23; v[3*step] = d01 - d23;
+}
+
+template <typename T>
+BM_HD int hadamard_abs_4x4( const T *a, int sa, const T *b, int sb )
+{
+    int d[16], s = 0;
+    for( int y = 0; y < 4; y++ )
+        for( int x = 0; x < 4; x++ )
+            d[4*y+x] = a[y*sa+x] - b[y*sb+x];
+    for( int y = 0; y < 4; y++ ) hadamard4( d + 4*y, 1 );
+    for( int x = 0; x < 4; x++ ) hadamard4( d + x, 4 );
+    for( int i = 0; i < 16; i++ ) s += mf_abs( d[i] );
+    return s;
+}
+
+/* satd of any WxH made of 4x4 tiles: sum over tiles of (sum |H4 D H4^T|), halved per 8x4 / 4x4 unit
+ * exactly as PIXEL_SATD_C composes x264_pixel_satd_8x4 / _4x4 (T.c:265-332). */
+template <typename T>
+BM_HD int mf_satd( const T *a, int sa, const T *b, int sb, int w, int h )
+{
+    int total = 0;
+    if( w == 4 )
+    {
+        for( int y = 0; y < h; y += 4 )
+            total += hadamard_abs_4x4( a + y*sa, sa, b + y*sb, sb ) >> 1;
+        return total;
+    }
+    for( int y = 0; y < h; y += 4 )
+        for( int x = 0; x < w; x += 8 )
+            total += ( hadamard_abs_4x4( a + y*sa + x, sa, b + y*sb + x, sb )
+                     + hadamard_abs_4x4( a + y*sa + x + 4, sa, b + y*sb + x + 4, sb ) ) >> 1;
+    return total;
+}
+
+
+/* Successive elimination, common/T.c:759-803 (ads4/ads2/ads1): candidates i of a row whose lower bound
+ * sum|enc_dc - box sum| + cost_mvx[i] stays below thresh, in order. n_dc = 4, 2 or 1. */
+BM_HD int mf_ads( int n_dc, const int *enc_dc, const uint16_t *sums, int delta, const uint16_t *cost_mvx, int16_t *mvs, int width, int thresh )
+{
+    int nmv = 0;
+    for( int i = 0; i < width; i++, sums++ )
+    {
+        int ads = mf_abs( enc_dc[0] - sums[0] ) + cost_mvx[i];
+        if( n_dc == 2 )
+            ads += mf_abs( enc_dc[1] - sums[delta] );
+        else if( n_dc == 4 )
+            ads += mf_abs( enc_dc[1] - sums[8] ) + mf_abs( enc_dc[2] - sums[delta] ) + mf_abs( enc_dc[3] - sums[delta + 8] );
+        if( ads < thresh )
+            mvs[nmv++] = (int16_t)i;
+    }
+    return nmv;
+}
+
+
+/* One interpolated sample at lowres integer position (x,y) displaced by quarter-pel (mvx,mvy).
+ * Phase (fx,fy): first tap from plane (fx?H:0)+(fy==2?V:0) one row lower when fy==3; second tap
+ * from plane (fx==2?H:0)+(fy?V:0) one column further when fx==3; taps equal when fx,fy are even. */
+template <typename T>
+BM_HD int qpel_sample( const T *const planes[4], int stride, int x, int y, int mvx, int mvy, const void *wt )
+{
+    int fx = mvx & 3, fy = mvy & 3;
+    int ix = x + ( mvx >> 2 ), iy = y + ( mvy >> 2 );
+    int pa = ( fx ? 1 : 0 ) + ( fy == 2 ? 2 : 0 );
+    int v = planes[pa][( iy + ( fy == 3 ) ) * stride + ix];
+    if( ( fx | fy ) & 1 )
+    {
+        int pb = ( fx == 2 ? 1 : 0 ) + ( fy ? 2 : 0 );
+        v = rnd_avg( v, planes[pb][iy * stride + ix + ( fx == 3 )] );
+    }
+    return v;
+}
+
+template <typename T>
+BM_HD void mf_mc_luma( T *dst, int ds, const T *const planes[4], int stride, int mvx, int mvy, int w, int h, const void *wt )
+{
+    for( int y = 0; y < h; y++ )
+        for( int x = 0; x < w; x++ )
+            dst[y*ds+x] = (T)qpel_sample( planes, stride, x, y, mvx, mvy, wt );
+}
+
+
+template <typename T>
+struct Mef
+{
+    const MfReq<T> *p;
+    int bw, bh;
+    int bmx, bmy, bcost;
+};
+
+template <typename T>
+BM_HD int mef_fpelcmp( const Mef<T> *s, const T *b, int sb )
+{
+    return s->p->fpelcmp_satd ? mf_satd( s->p->fenc, s->p->fenc_stride, b, sb, s->bw, s->bh ) : mf_sad( s->p->fenc, s->p->fenc_stride, b, sb, s->bw, s->bh );
+}
+template <typename T>
+BM_HD int mef_mbcmp( const Mef<T> *s, const T *b, int sb )
+{
+    return s->p->mbcmp_satd ? mf_satd( s->p->fenc, s->p->fenc_stride, b, sb, s->bw, s->bh ) : mf_sad( s->p->fenc, s->p->fenc_stride, b, sb, s->bw, s->bh );
+}
+template <typename T>
+BM_HD int mef_bits_q( const Mef<T> *s, int qx, int qy ) { return s->p->cost_mv[qx - s->p->mvp[0]] + s->p->cost_mv[qy - s->p->mvp[1]]; }
+template <typename T>
+BM_HD int mef_bits_f( const Mef<T> *s, int fx, int fy ) { return mef_bits_q( s, 4*fx, 4*fy ); } /* BITS_MVD */
+template <typename T>
+BM_HD int mef_cost_f( const Mef<T> *s, int fx, int fy ) /* the cost COST_MV computes */
+{
+    return mef_fpelcmp( s, s->p->ref[0] + (long)fy * s->p->stride + fx, s->p->stride ) + mef_bits_f( s, fx, fy );
+}
+template <typename T>
+BM_HD void mef_try_f( Mef<T> *s, int fx, int fy ) /* COST_MV */
+{
+    int c = mef_cost_f( s, fx, fy );
+    if( c < s->bcost ) { s->bcost = c; s->bmx = fx; s->bmy = fy; }
+}
+template <typename T>
+BM_HD int mef_cost_q( const Mef<T> *s, int qx, int qy, int use_mbcmp ) /* COST_MV_HPEL / COST_MV_SAD / COST_MV_SATD */
+{
+    T pix[16*16];
+    mf_mc_luma( pix, 16, s->p->ref, s->p->stride, qx, qy, s->bw, s->bh, NULL );
+    return ( use_mbcmp ? mef_mbcmp( s, pix, 16 ) : mef_fpelcmp( s, pix, 16 ) ) + mef_bits_q( s, qx, qy );
+}
+template <typename T>
+BM_HD int mef_in_range( const Mef<T> *s, int fx, int fy ) /* CHECK_MVRANGE */
+{
+    return fx >= s->p->lim_min[0] && fx <= s->p->lim_max[0] && fy >= s->p->lim_min[1] && fy <= s->p->lim_max[1];
+}
+/* COST_MV_X4 relative to (omx, omy), candidates applied in order */
+template <typename T>
+BM_HD void mef_x4( Mef<T> *s, int omx, int omy, const int d[4][2] )
+{
+    for( int k = 0; k < 4; k++ )
+        mef_try_f( s, omx + d[k][0], omy + d[k][1] );
+}
+template <typename T>
+BM_HD void mef_cross( Mef<T> *s, int omx, int omy, int start, int x_max, int y_max ) /* CROSS, me.c:139-166 */
+{
+    const MfReq<T> *p = s->p;
+    int i = start;
+    if( x_max <= imin( p->lim_max[0] - omx, omx - p->lim_min[0] ) )
+        for( ; i < x_max - 2; i += 4 )
+        {
+            const int d[4][2] = { { i, 0 }, { -i, 0 }, { i+2, 0 }, { -i-2, 0 } };
+            mef_x4( s, omx, omy, d );
+        }
+    for( ; i < x_max; i += 2 )
+    {
+        if( omx + i <= p->lim_max[0] ) mef_try_f( s, omx + i, omy );
+        if( omx - i >= p->lim_min[0] ) mef_try_f( s, omx - i, omy );
+    }
+    i = start;
+    if( y_max <= imin( p->lim_max[1] - omy, omy - p->lim_min[1] ) )
+        for( ; i < y_max - 2; i += 4 )
+        {
+            const int d[4][2] = { { 0, i }, { 0, -i }, { 0, i+2 }, { 0, -i-2 } };
+            mef_x4( s, omx, omy, d );
+        }
+    for( ; i < y_max; i += 2 )
+    {
+        if( omy + i <= p->lim_max[1] ) mef_try_f( s, omx, omy + i );
+        if( omy - i >= p->lim_min[1] ) mef_try_f( s, omx, omy - i );
+    }
+}
+
+template <typename T>
+BM_HD void mef_hex2( Mef<T> *s, int me_range ) /* the HEX branch incl. the square refine, me.c:344-420 */
+{
+    const int8_t hex2[8][2] = { {-1,-2}, {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2}, {-2,0} };
+    const uint8_t mod6m1[8] = { 5,0,1,2,3,4,5,0 };
+    const int8_t square1[9][2] = { {0,0}, {0,-1}, {0,1}, {-1,0}, {1,0}, {-1,-1}, {-1,1}, {1,-1}, {1,1} };
+    const int8_t first[6][2] = { {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2} };
+    int bmx = s->bmx, bmy = s->bmy, bcost = s->bcost, dir = -1;
+    for( int k = 0; k < 6; k++ ) /* packed (cost<<3)+k+2 with COPY1_IF_LT: lowest cost, first on ties */
+    {
+        int c = mef_cost_f( s, bmx + first[k][0], bmy + first[k][1] );
+        if( c < bcost ) { bcost = c; dir = k; }
+    }
+    if( dir >= 0 )
+    {
+        bmx += hex2[dir+1][0]; bmy += hex2[dir+1][1];
+        s->bmx = bmx; s->bmy = bmy;
+        for( int i = ( me_range >> 1 ) - 1; i > 0 && mef_in_range( s, bmx, bmy ); i-- )
+        {
+            int best = -1;
+            for( int k = 0; k < 3; k++ )
+            {
+                int c = mef_cost_f( s, bmx + hex2[dir+k][0], bmy + hex2[dir+k][1] );
+                if( c < bcost ) { bcost = c; best = k; }
+            }
+            if( best < 0 )
+                break;
+            dir += best - 1;
+            dir = mod6m1[dir+1];
+            bmx += hex2[dir+1][0]; bmy += hex2[dir+1][1];
+        }
+    }
+    int sq = 0;
+    for( int k = 1; k <= 8; k++ )
+    {
+        int c = mef_cost_f( s, bmx + square1[k][0], bmy + square1[k][1] );
+        if( c < bcost ) { bcost = c; sq = k; }
+    }
+    s->bmx = bmx + square1[sq][0]; s->bmy = bmy + square1[sq][1]; s->bcost = bcost;
+}
+
+typedef struct { int sad; int mx, my; } mef_mvsad;
+
+template <typename T>
+BM_HD void mef_refine_subpel( Mef<T> *s, int mv[2], int *cost, int *cost_mv, int hpel_iters, int qpel_iters )
+{
+    const MfReq<T> *p = s->p;
+    int bmx = mv[0], bmy = mv[1], bcost = *cost;
+    if( hpel_iters )
+    {
+        if( p->subpel_refine < 3 )
+        {
+            int mx = clip3( p->mvp[0], p->spel_min[0] + 2, p->spel_max[0] - 2 );
+            int my = clip3( p->mvp[1], p->spel_min[1] + 2, p->spel_max[1] - 2 );
+            if( ( mx - bmx ) | ( my - bmy ) )
+            {
+                int c = mef_cost_q( s, mx, my, 0 );
+                if( c < bcost ) { bcost = c; bmx = mx; bmy = my; }
+            }
+        }
+        const int d2[4][2] = { {0,-2}, {0,2}, {-2,0}, {2,0} };
+        for( int i = hpel_iters; i > 0; i-- )
+        {
+            int best = -1, omx = bmx, omy = bmy;
+            for( int k = 0; k < 4; k++ )
+            {
+                int c = mef_cost_q( s, omx + d2[k][0], omy + d2[k][1], 0 );
+                if( c < bcost ) { bcost = c; best = k; }
+            }
+            if( best < 0 )
+                break;
+            bmx = omx + d2[best][0]; bmy = omy + d2[best][1];
+        }
+    }
+    if( p->mbcmp_satd != p->fpelcmp_satd ) /* h->pixf.mbcmp_unaligned[0] != h->pixf.fpelcmp[0] */
+        bcost = mef_cost_q( s, bmx, bmy, 1 );
+    const int d1[4][2] = { {0,-1}, {0,1}, {-1,0}, {1,0} };
+    if( p->subpel_refine != 1 )
+    {
+        int bdir = -1;
+        for( int i = qpel_iters; i > 0; i-- )
+        {
+            if( bmy <= p->spel_min[1] || bmy >= p->spel_max[1] || bmx <= p->spel_min[0] || bmx >= p->spel_max[0] )
+                break;
+            int odir = bdir, omx = bmx, omy = bmy;
+            for( int k = 0; k < 4; k++ )
+            {
+                if( ( k ^ 1 ) == odir )
+                    continue;
+                int c = mef_cost_q( s, omx + d1[k][0], omy + d1[k][1], 1 );
+                if( c < bcost ) { bcost = c; bmx = omx + d1[k][0]; bmy = omy + d1[k][1]; bdir = k; }
+            }
+            if( bmx == omx && bmy == omy )
+                break;
+        }
+    }
+    else if( bmy > p->spel_min[1] && bmy < p->spel_max[1] && bmx > p->spel_min[0] && bmx < p->spel_max[0] )
+    {
+        int omx = bmx, omy = bmy; /* subme 1: one quarter-pel diamond with fpelcmp */
+        for( int k = 0; k < 4; k++ )
+        {
+            int c = mef_cost_q( s, omx + d1[k][0], omy + d1[k][1], 0 );
+            if( c < bcost ) { bcost = c; bmx = omx + d1[k][0]; bmy = omy + d1[k][1]; }
+        }
+    }
+    mv[0] = bmx; mv[1] = bmy; *cost = bcost;
+    *cost_mv = mef_bits_q( s, bmx, bmy );
+}
+
+template <typename T>
+BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_mvc, int out[4] )
+{
+    const uint8_t mef_size[7][2] = { {16,16}, {16,8}, {8,16}, {8,8}, {8,4}, {4,8}, {4,4} };
+    const uint8_t mef_subpel_iterations[12][4] = /* me.c:38-50 */
+        { {0,0,0,0}, {1,1,0,0}, {0,1,1,0}, {0,2,1,0}, {0,2,1,1}, {0,2,1,2}, {0,0,2,2}, {0,0,2,2}, {0,0,4,10}, {0,0,4,10}, {0,0,4,10}, {0,0,4,10} };
+    Mef<T> S, *s = &S;
+    s->p = p; s->bw = mef_size[p->i_pixel][0]; s->bh = mef_size[p->i_pixel][1];
+    const int mv_x_min = p->lim_min[0], mv_y_min = p->lim_min[1], mv_x_max = p->lim_max[0], mv_y_max = p->lim_max[1];
+    int me_range = p->me_range;
+    int bpred_cost = MF_COST_MAX, bpred_mx = 0, bpred_my = 0, pmx, pmy, pmv_nonzero;
+    s->bcost = MF_COST_MAX; s->bmx = s->bmy = 0;
+    int pmv_q[2];
+
+    if( p->subpel_refine >= 3 )
+    {
+        bpred_mx = clip3( p->mvp[0], 4*mv_x_min, 4*mv_x_max );
+        bpred_my = clip3( p->mvp[1], 4*mv_y_min, 4*mv_y_max );
+        pmv_q[0] = bpred_mx; pmv_q[1] = bpred_my;
+        pmv_nonzero = ( bpred_mx | bpred_my ) != 0;
+        pmx = ( bpred_mx + 2 ) >> 2; pmy = ( bpred_my + 2 ) >> 2;
+        bpred_cost = mef_cost_q( s, bpred_mx, bpred_my, 0 );
+        const int pmv_cost = bpred_cost;
+        for( int i = 0; i < n_mvc; i++ ) /* x264_predictor_clip + the packed minimum (first of equal costs wins) */
+        {
+            int mx = mvc[i][0], my = mvc[i][1];
+            if( ( !mx && !my ) || ( mx == pmv_q[0] && my == pmv_q[1] ) )
+                continue;
+            mx = clip3( mx, 4*mv_x_min, 4*mv_x_max ); my = clip3( my, 4*mv_y_min, 4*mv_y_max );
+            int c = mef_cost_q( s, mx, my, 0 );
+            if( c < bpred_cost ) { bpred_cost = c; bpred_mx = mx; bpred_my = my; }
+        }
+        s->bmx = ( bpred_mx + 2 ) >> 2; s->bmy = ( bpred_my + 2 ) >> 2;
+        if( ( bpred_mx | bpred_my ) & 3 )
+            mef_try_f( s, s->bmx, s->bmy ); /* bcost is MF_COST_MAX here: always taken */
+        else
+            s->bcost = bpred_cost;
+        if( pmv_nonzero )
+        {
+            if( s->bmx | s->bmy ) mef_try_f( s, 0, 0 );
+        }
+        else if( pmv_cost < s->bcost ) { s->bcost = pmv_cost; s->bmx = 0; s->bmy = 0; }
+    }
+    else
+    {
+        s->bmx = pmx = clip3( ( p->mvp[0] + 2 ) >> 2, mv_x_min, mv_x_max );
+        s->bmy = pmy = clip3( ( p->mvp[1] + 2 ) >> 2, mv_y_min, mv_y_max );
+        pmv_q[0] = pmx; pmv_q[1] = pmy; /* full-pel units in this branch */
+        pmv_nonzero = ( pmx | pmy ) != 0;
+        s->bcost = mef_fpelcmp( s, p->ref[0] + (long)s->bmy * p->stride + s->bmx, p->stride ); /* no mv bits for the rounded predictor */
+        for( int i = 0; i < n_mvc; i++ ) /* x264_predictor_roundclip */
+        {
+            int mx = ( mvc[i][0] + 2 ) >> 2, my = ( mvc[i][1] + 2 ) >> 2;
+            if( ( !mx && !my ) || ( mx == pmx && my == pmy ) )
+                continue;
+            mx = clip3( mx, mv_x_min, mv_x_max ); my = clip3( my, mv_y_min, mv_y_max );
+            int c = mef_cost_f( s, mx, my );
+            if( c < s->bcost ) { s->bcost = c; s->bmx = mx; s->bmy = my; }
+        }
+        if( pmv_nonzero )
+            mef_try_f( s, 0, 0 );
+    }
+
+    switch( p->me_method )
+    {
+        case 0: /* DIA, me.c:322-342 */
+        {
+            const int d[4][2] = { {0,-1}, {0,1}, {-1,0}, {1,0} };
+            int i = me_range;
+            do
+            {
+                int best = -1, bmx = s->bmx, bmy = s->bmy;
+                for( int k = 0; k < 4; k++ )
+                {
+                    int c = mef_cost_f( s, bmx + d[k][0], bmy + d[k][1] );
+                    if( c < s->bcost ) { s->bcost = c; best = k; }
+                }
+                if( best < 0 )
+                    break;
+                s->bmx = bmx + d[best][0]; s->bmy = bmy + d[best][1];
+            } while( --i && mef_in_range( s, s->bmx, s->bmy ) );
+            break;
+        }
+        case 1:
+            mef_hex2( s, me_range );
+            break;
+        case 2: /* UMH, me.c:422-618 */
+        {
+            const uint8_t pixel_size_shift[7] = { 0, 1, 1, 2, 3, 3, 4 };
+            const int dia1[4][2] = { {0,-1}, {0,1}, {-1,0}, {1,0} };
+            int ucost1, ucost2, cross_start = 1, omx, omy;
+            ucost1 = s->bcost;
+            mef_x4( s, pmx, pmy, dia1 );
+            if( pmx | pmy )
+                mef_x4( s, 0, 0, dia1 );
+            omx = ( pmx | pmy ) ? 0 : pmx; omy = ( pmx | pmy ) ? 0 : pmy; /* what DIA1_ITER left in omx/omy */
+            if( p->i_pixel == 6 ) /* PIXEL_4x4 */
+            {
+                mef_hex2( s, me_range );
+                break;
+            }
+            ucost2 = s->bcost;
+            if( ( s->bmx | s->bmy ) && ( ( s->bmx - pmx ) | ( s->bmy - pmy ) ) )
+            {
+                omx = s->bmx; omy = s->bmy;
+                mef_x4( s, omx, omy, dia1 );
+            }
+            if( s->bcost == ucost2 )
+                cross_start = 3;
+            omx = s->bmx; omy = s->bmy;
+#define MEF_SAD_THRESH( v ) ( s->bcost < ( (v) >> pixel_size_shift[p->i_pixel] ) )
+            int done = 0;
+            if( s->bcost == ucost2 && MEF_SAD_THRESH( 2000 ) )
+            {
+                const int o1[4][2] = { {0,-2}, {-1,-1}, {1,-1}, {-2,0} }, o2[4][2] = { {2,0}, {-1,1}, {1,1}, {0,2} };
+                mef_x4( s, omx, omy, o1 );
+                mef_x4( s, omx, omy, o2 );
+                if( s->bcost == ucost1 && MEF_SAD_THRESH( 500 ) )
+                    done = 1;
+                else if( s->bcost == ucost2 )
+                {
+                    int range = ( me_range >> 1 ) | 1;
+                    const int o3[4][2] = { {-1,-2}, {1,-2}, {-2,-1}, {2,-1} }, o4[4][2] = { {-2,1}, {2,1}, {-1,2}, {1,2} };
+                    mef_cross( s, omx, omy, 3, range, range );
+                    mef_x4( s, omx, omy, o3 );
+                    mef_x4( s, omx, omy, o4 );
+                    if( s->bcost == ucost2 )
+                        done = 1;
+                    else
+                        cross_start = range + 2;
+                }
+            }
+            if( done )
+                break;
+            if( n_mvc )
+            {
+                const uint8_t range_mul[4][4] = { {3,3,4,4}, {3,4,4,4}, {4,4,4,5}, {4,4,5,6} };
+                int mvd, denom = 1;
+                if( n_mvc == 1 )
+                    mvd = p->i_pixel == 0 ? 25 : mf_abs( p->mvp[0] - mvc[0][0] ) + mf_abs( p->mvp[1] - mvc[0][1] );
+                else
+                {
+                    denom = n_mvc - 1;
+                    mvd = 0;
+                    if( p->i_pixel != 0 )
+                    {
+                        mvd = mf_abs( p->mvp[0] - mvc[0][0] ) + mf_abs( p->mvp[1] - mvc[0][1] );
+                        denom++;
+                    }
+                    for( int i = 0; i < n_mvc - 1; i++ ) /* x264_predictor_difference */
+                        mvd += mf_abs( mvc[i][0] - mvc[i+1][0] ) + mf_abs( mvc[i][1] - mvc[i+1][1] );
+                }
+                int sad_ctx = MEF_SAD_THRESH( 1000 ) ? 0 : MEF_SAD_THRESH( 2000 ) ? 1 : MEF_SAD_THRESH( 4000 ) ? 2 : 3;
+                int mvd_ctx = mvd < 10*denom ? 0 : mvd < 20*denom ? 1 : mvd < 40*denom ? 2 : 3;
+                me_range = me_range * range_mul[mvd_ctx][sad_ctx] >> 2;
+            }
+#undef MEF_SAD_THRESH
+            mef_cross( s, omx, omy, cross_start, me_range, me_range >> 1 );
+            {
+                const int o5[4][2] = { {-2,-2}, {-2,2}, {2,-2}, {2,2} };
+                mef_x4( s, omx, omy, o5 );
+            }
+            omx = s->bmx; omy = s->bmy;
+            int i = 1;
+            do
+            {
+                const int8_t hex4[16][2] = { {0,-4}, {0,4}, {-2,-3}, {2,-3}, {-4,-2}, {4,-2}, {-4,-1}, {4,-1},
+                                                    {-4,0}, {4,0}, {-4,1}, {4,1}, {-4,2}, {4,2}, {-2,3}, {2,3} };
+                const int near_edge = 4*i > imin( imin( mv_x_max - omx, omx - mv_x_min ), imin( mv_y_max - omy, omy - mv_y_min ) );
+                for( int j = 0; j < 16; j++ )
+                {
+                    int mx = omx + hex4[j][0]*i, my = omy + hex4[j][1]*i;
+                    if( !near_edge || mef_in_range( s, mx, my ) )
+                        mef_try_f( s, mx, my );
+                }
+            } while( ++i <= me_range >> 2 );
+            if( s->bmy <= mv_y_max && s->bmy >= mv_y_min && s->bmx <= mv_x_max && s->bmx >= mv_x_min )
+                mef_hex2( s, me_range );
+            break;
+        }
+        default: /* ESA (3) / TESA (4), me.c:620-772 */
+        {
+            const int min_x = imax( s->bmx - me_range, mv_x_min ), min_y = imax( s->bmy - me_range, mv_y_min );
+            const int max_x = imin( s->bmx + me_range, mv_x_max ), max_y = imin( s->bmy + me_range, mv_y_max );
+            const int width = ( max_x - min_x + 3 ) & ~3;
+            if( p->me_method == 3 )
+            {
+                /* successive elimination only discards candidates that cannot beat the current best (sum|d| >= |sum d|),
+                 * so the result is the plain exhaustive scan in its order -- including the up to three columns past
+                 * max_x that rounding the width to a multiple of four adds */
+                for( int my = min_y; my <= max_y; my++ )
+                {
+                    if( s->bcost <= p->cost_mv[4*my - p->mvp[1]] )
+                        continue;
+                    for( int mx = min_x; mx < min_x + width; mx++ )
+                        mef_try_f( s, mx, my );
+                }
+                break;
+            }
+            /* TESA: ADS threshold, SAD threshold, keep the best few SADs, then SATD */
+            const uint16_t *sums_base = p->integral;
+            int enc_dc[4];
+            const int small = p->i_pixel > 3; /* sad_size: 8x8 quadrants for sizes >= 8x8, else 4x4 */
+            int delta = small ? 4 : 8;
+            {
+                const T *f = p->fenc;
+                const int q[4][2] = { {0,0}, {delta,0}, {0,delta}, {delta,delta} };
+                for( int k = 0; k < 4; k++ )
+                {
+                    int sum = 0;
+                    for( int y = 0; y < delta; y++ )
+                        for( int x = 0; x < delta; x++ )
+                            sum += f[( q[k][1] + y ) * p->fenc_stride + q[k][0] + x];
+                    enc_dc[k] = sum;
+                }
+            }
+            if( small )
+                sums_base += p->integral_lower;
+            int ads_n; /* ads[i_pixel]: 16x16 -> ads4; 16x8, 8x16, 8x4, 4x8 -> ads2; 8x8, 4x4 -> ads1 */
+            if( p->i_pixel == 0 ) ads_n = 4; else if( p->i_pixel == 3 || p->i_pixel == 6 ) ads_n = 1; else ads_n = 2;
+            if( p->i_pixel == 0 || p->i_pixel == 2 || p->i_pixel == 5 )
+                delta *= p->stride;
+            if( p->i_pixel == 2 || p->i_pixel == 5 )
+                enc_dc[1] = enc_dc[2];
+            // candidate list of the SAD stage: in the request's scratch area (MF_TESA_ROWS_MAX x MF_TESA_WIDTH_MAX entries)
+            mef_mvsad *mvsads = (mef_mvsad *)p->scratch;
+            int16_t xs[MF_TESA_WIDTH_MAX + 64];
+            uint16_t cost_fpel_mvx[MF_TESA_WIDTH_MAX + 4];
+            for( int x = 0; x < width; x++ )
+                cost_fpel_mvx[x] = p->cost_mv[4*( min_x + x ) - p->mvp[0]];
+            int nmvsad = 0, limit;
+            int sad_thresh = me_range <= 16 ? 10 : me_range <= 24 ? 11 : 12;
+            int bsad = mf_sad( p->fenc, p->fenc_stride, p->ref[0] + (long)s->bmy * p->stride + s->bmx, p->stride, s->bw, s->bh ) + mef_bits_f( s, s->bmx, s->bmy );
+            for( int my = min_y; my <= max_y; my++ )
+            {
+                int ycost = p->cost_mv[4*my - p->mvp[1]];
+                if( bsad <= ycost )
+                    continue;
+                bsad -= ycost;
+                int xn = mf_ads( ads_n, enc_dc, sums_base + min_x + (long)my * p->stride, delta, cost_fpel_mvx, xs, width, bsad * 17 >> 4 );
+                for( int i = 0; i < xn; i++ )
+                {
+                    int mx = min_x + xs[i];
+                    /* the reference indexes its x-cost table with the offset from min_x here (me.c:671,688: cost_fpel_mvx[xs[i]],
+                     * not cost_fpel_mvx[min_x + xs[i]] as in the ads call), so the SAD stage charges the cost of column xs[i] */
+                    int sad = mf_sad( p->fenc, p->fenc_stride, p->ref[0] + (long)my * p->stride + mx, p->stride, s->bw, s->bh ) +
+                              p->cost_mv[4 * xs[i] - p->mvp[0]];
+                    if( sad < bsad * sad_thresh >> 3 )
+                    {
+                        if( sad < bsad ) bsad = sad;
+                        mvsads[nmvsad].sad = sad + ycost; mvsads[nmvsad].mx = mx; mvsads[nmvsad].my = my;
+                        nmvsad++;
+                    }
+                }
+                bsad += ycost;
+            }
+            limit = me_range >> 1;
+            sad_thresh = bsad * sad_thresh >> 3;
+            while( nmvsad > limit*2 && sad_thresh > bsad )
+            {
+                int i = 0;
+                sad_thresh = ( sad_thresh + bsad ) >> 1;
+                while( i < nmvsad && mvsads[i].sad <= sad_thresh )
+                    i++;
+                for( int j = i; j < nmvsad; j++ )
+                {
+                    mvsads[i] = mvsads[j];
+                    if( mvsads[j].sad <= sad_thresh ) /* i += (sad - (sad_thresh+1)) >> 31 with the sign trick */
+                        i++;
+                }
+                nmvsad = i;
+            }
+            while( nmvsad > limit )
+            {
+                int bi = 0;
+                for( int i = 1; i < nmvsad; i++ )
+                    if( mvsads[i].sad > mvsads[bi].sad )
+                        bi = i;
+                nmvsad--;
+                mvsads[bi] = mvsads[nmvsad];
+            }
+            for( int i = 0; i < nmvsad; i++ )
+                mef_try_f( s, mvsads[i].mx, mvsads[i].my );
+            break;
+        }
+    }
+
+    /* -> quarter-pel vector, me.c:774-789 */
+    int mv[2], cost, cost_mv = 0;
+    if( p->subpel_refine < 3 )
+    {
+        cost_mv = mef_bits_f( s, s->bmx, s->bmy );
+        cost = s->bcost;
+        if( s->bmx == pmv_q[0] && s->bmy == pmv_q[1] )
+            cost += cost_mv;
+        mv[0] = 4 * s->bmx; mv[1] = 4 * s->bmy;
+    }
+    else if( bpred_cost < s->bcost )
+    {
+        mv[0] = bpred_mx; mv[1] = bpred_my; cost = bpred_cost;
+    }
+    else
+    {
+        mv[0] = 4 * s->bmx; mv[1] = 4 * s->bmy; cost = s->bcost;
+    }
+    if( p->subpel_refine >= 2 )
+        mef_refine_subpel( s, mv, &cost, &cost_mv, mef_subpel_iterations[p->subpel_refine][2], mef_subpel_iterations[p->subpel_refine][3] );
+    out[0] = mv[0]; out[1] = mv[1]; out[2] = cost; out[3] = cost_mv;
+}
+} // namespace mefull
+
+#ifdef __HIPCC__
+// request table in device memory; candidates per request in mvc[i][MF_MVC_MAX][2]
+#define MF_MVC_MAX 10
+template <typename T>
+__global__ __launch_bounds__( 64 ) void me_full_kernel( const MfReq<T> *reqs, const int16_t *mvc, const int *n_mvc, int n, int *out )
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if( i >= n )
+        return;
+    int res[4];
+    mefull::mf_me_search_full<T>( &reqs[i], (const int16_t( * )[2])( mvc + (long)i * MF_MVC_MAX * 2 ), n_mvc[i], res );
+    for( int k = 0; k < 4; k++ )
+        out[4 * i + k] = res[k];
+}
+#endif

@@ -22,6 +22,7 @@
 #include "la_kernels.h"
 #include "block_metrics.h"
 #include "dct_quant_block.h"
+#include "me_full.h"
 
 #define HIPCK( call )                                                                                        \
     do {                                                                                                     \
@@ -1345,6 +1346,89 @@ extern "C" int x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx
 #undef CMP_LAUNCH
     HIPCK( hipGetLastError() );
     return X264HIP_OK;
+}
+
+template <typename T>
+static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request *reqs, const void *fenc_plane, intptr_t fenc_stride,
+                              const void *const ref_planes[4], intptr_t ref_stride, const uint16_t *integral, intptr_t integral_lower,
+                              const uint16_t *cost_mv, int *out )
+{
+    std::vector<MfReq<T>> table( n );
+    std::vector<int16_t> mvc( (size_t)n * MF_MVC_MAX * 2, 0 );
+    std::vector<int> n_mvc( n );
+    const size_t scratch_bytes = (size_t)MF_TESA_ROWS_MAX * MF_TESA_WIDTH_MAX * 12;
+    int n_tesa = 0;
+    for( int i = 0; i < n; i++ )
+        n_tesa += reqs[i].me_method == 4;
+    char *scratch = nullptr;
+    MfReq<T> *table_dev = nullptr;
+    int16_t *mvc_dev = nullptr;
+    int *n_mvc_dev = nullptr, *out_dev = nullptr;
+    int rc = X264HIP_OK;
+#define MECK( call ) do { if( ( call ) != hipSuccess ) { rc = X264HIP_ENOMEM; goto done; } } while( 0 )
+    if( n_tesa ) MECK( hipMalloc( &scratch, scratch_bytes * n_tesa ) );
+    for( int i = 0, t = 0; i < n; i++ )
+    {
+        const x264hip_me_request &q = reqs[i];
+        MfReq<T> &r = table[i];
+        r.i_pixel = q.i_pixel; r.me_method = q.me_method; r.subpel_refine = q.subpel_refine; r.me_range = q.me_range;
+        r.mbcmp_satd = q.mbcmp_satd; r.fpelcmp_satd = q.fpelcmp_satd;
+        r.fenc = (const T *)fenc_plane + (long)q.y * fenc_stride + q.x; r.fenc_stride = (int)fenc_stride;
+        for( int k = 0; k < 4; k++ )
+            r.ref[k] = (const T *)ref_planes[k] + (long)q.y * ref_stride + q.x;
+        r.stride = (int)ref_stride;
+        r.integral = integral ? integral + (long)q.y * ref_stride + q.x : nullptr;
+        r.integral_lower = (long)integral_lower;
+        for( int k = 0; k < 2; k++ )
+        {
+            r.mvp[k] = q.mvp[k]; r.lim_min[k] = q.lim_min[k]; r.lim_max[k] = q.lim_max[k];
+            r.spel_min[k] = q.spel_min[k]; r.spel_max[k] = q.spel_max[k];
+        }
+        r.cost_mv = cost_mv;
+        r.scratch = q.me_method == 4 ? scratch + scratch_bytes * t++ : nullptr;
+        n_mvc[i] = q.n_mvc;
+        memcpy( &mvc[(size_t)i * MF_MVC_MAX * 2], q.mvc, sizeof( q.mvc ) );
+    }
+    MECK( hipMalloc( &table_dev, sizeof( MfReq<T> ) * n ) );
+    MECK( hipMalloc( &mvc_dev, mvc.size() * sizeof( int16_t ) ) );
+    MECK( hipMalloc( &n_mvc_dev, sizeof( int ) * n ) );
+    MECK( hipMalloc( &out_dev, sizeof( int ) * 4 * n ) );
+    MECK( hipMemcpyAsync( table_dev, table.data(), sizeof( MfReq<T> ) * n, hipMemcpyHostToDevice, ctx->stream ) );
+    MECK( hipMemcpyAsync( mvc_dev, mvc.data(), mvc.size() * sizeof( int16_t ), hipMemcpyHostToDevice, ctx->stream ) );
+    MECK( hipMemcpyAsync( n_mvc_dev, n_mvc.data(), sizeof( int ) * n, hipMemcpyHostToDevice, ctx->stream ) );
+    me_full_kernel<T><<<( n + 63 ) / 64, 64, 0, ctx->stream>>>( table_dev, mvc_dev, n_mvc_dev, n, out_dev );
+    MECK( hipGetLastError() );
+    MECK( hipMemcpyAsync( out, out_dev, sizeof( int ) * 4 * n, hipMemcpyDeviceToHost, ctx->stream ) );
+    if( hipStreamSynchronize( ctx->stream ) != hipSuccess ) rc = X264HIP_EDEVICE;
+done:
+#undef MECK
+    if( scratch ) (void)hipFree( scratch );
+    if( table_dev ) (void)hipFree( table_dev );
+    if( mvc_dev ) (void)hipFree( mvc_dev );
+    if( n_mvc_dev ) (void)hipFree( n_mvc_dev );
+    if( out_dev ) (void)hipFree( out_dev );
+    return rc;
+}
+
+extern "C" int x264hip_me_search_batch( x264hip_ctx *ctx, int n, const x264hip_me_request *reqs, const void *fenc_plane_dev, intptr_t fenc_stride,
+                                        const void *const ref_planes_dev[4], intptr_t ref_stride, const uint16_t *integral_dev, intptr_t integral_lower,
+                                        const uint16_t *cost_mv_dev, int *out )
+{
+    if( !ctx || n <= 0 || !reqs || !fenc_plane_dev || !ref_planes_dev || !cost_mv_dev || !out ) return X264HIP_EINVAL;
+    for( int k = 0; k < 4; k++ )
+        if( !ref_planes_dev[k] ) return X264HIP_EINVAL;
+    for( int i = 0; i < n; i++ )
+    {
+        const x264hip_me_request &q = reqs[i];
+        if( q.i_pixel < 0 || q.i_pixel > 6 || q.me_method < 0 || q.me_method > 4 || q.subpel_refine < 0 || q.subpel_refine > 11 ||
+            q.n_mvc < 0 || q.n_mvc > X264HIP_ME_MVC_MAX || q.me_range < 1 || ( q.me_method == 4 && ( !integral_dev || q.me_range > 64 ) ) )
+            return X264HIP_EINVAL;
+    }
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    return ctx->p.bit_depth == 8
+           ? me_search_batch_t<uint8_t>( ctx, n, reqs, fenc_plane_dev, fenc_stride, ref_planes_dev, ref_stride, integral_dev, integral_lower, cost_mv_dev, out )
+           : me_search_batch_t<uint16_t>( ctx, n, reqs, fenc_plane_dev, fenc_stride, ref_planes_dev, ref_stride, integral_dev, integral_lower, cost_mv_dev, out );
 }
 
 extern "C" int x264hip_pixel_metric_batch( x264hip_ctx *ctx, int metric, int size_idx, const void *a_plane, const void *b_plane, intptr_t stride,

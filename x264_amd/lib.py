@@ -33,6 +33,17 @@ class Cost(C.Structure):
                 ("intra_cost_est_aq", C.c_int)]
 
 
+ME_MVC_MAX = 10
+
+
+class MeRequest(C.Structure):
+    """x264hip_me_request"""
+    _fields_ = [("i_pixel", C.c_int), ("me_method", C.c_int), ("subpel_refine", C.c_int), ("me_range", C.c_int), ("mbcmp_satd", C.c_int),
+                ("fpelcmp_satd", C.c_int), ("x", C.c_int), ("y", C.c_int), ("mvp", C.c_int * 2), ("lim_min", C.c_int * 2),
+                ("lim_max", C.c_int * 2), ("spel_min", C.c_int * 2), ("spel_max", C.c_int * 2), ("n_mvc", C.c_int),
+                ("mvc", (C.c_int16 * 2) * ME_MVC_MAX)]
+
+
 class MbtreeOp(C.Structure):
     _fields_ = [("type", C.c_int), ("slot_b", C.c_int), ("slot_p0", C.c_int), ("slot_p1", C.c_int), ("dist_p0", C.c_int),
                 ("dist_p1", C.c_int), ("referenced", C.c_int), ("bipred_weight", C.c_int), ("fps_factor", C.c_float),
@@ -218,6 +229,18 @@ class Context:
     def pixel_cmp_batch(self, satd, size_idx, fenc_ptr, ref_ptr, stride, blocks_w, blocks_h, mv_ptr, out_ptr):
         _ck(self.L.x264hip_pixel_cmp_batch(self.h, int(satd), int(size_idx), C.c_void_p(fenc_ptr), C.c_void_p(ref_ptr), int(stride),
                                            int(blocks_w), int(blocks_h), C.c_void_p(mv_ptr), C.c_void_p(out_ptr)), "pixel_cmp_batch")
+
+    def me_search_batch(self, reqs, fenc_ptr, fenc_stride, ref_ptrs, ref_stride, integral_ptr, integral_lower, cost_mv_ptr):
+        """reqs: list of MeRequest; pointers are device addresses of pixel / element (0,0).  Returns int32 [n, 4]."""
+        n = len(reqs)
+        arr = (MeRequest * n)(*reqs)
+        refs = (C.c_void_p * 4)(*ref_ptrs)
+        out = np.zeros((n, 4), np.int32)
+        self.L.x264hip_me_search_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t,
+                                                   C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_void_p]
+        _ck(self.L.x264hip_me_search_batch(self.h, n, arr, fenc_ptr, fenc_stride, refs, ref_stride, integral_ptr, integral_lower,
+                                           cost_mv_ptr, _p(out)), "me_search_batch")
+        return out
 
     def pixel_metric_batch(self, metric, size_idx, a_ptr, b_ptr, stride, blocks_w, blocks_h, out_ptr):
         self.L.x264hip_pixel_metric_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int,
