@@ -191,6 +191,11 @@ int  x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx, const vo
  * integral_lower elements from there to the 4x4-sum plane (frame.c:240-256); only read by TESA requests.  cost_mv_dev: the centred
  * cost table of the request's qp (h->cost_mv[qp], analyse.c:151-157) on the device.  out[i] = { mv x, mv y (quarter-pel), cost,
  * cost_mv } as x264_me_search_ref leaves them in x264_me_t.  One thread per request: bit-exact, not tuned. */
+/* The integral planes x264_frame_filter keeps for the exhaustive searches (common/mc.c:424-456, :757-783; frame.c:240-256): for the
+ * padded luma plane starting at plane_dev (width x height samples, device memory), sum8[y*stride + x] = the sum of the 8x8 box
+ * whose top-left sample is (x, y), modulo 2^16, and sum4 the same for 4x4 boxes.  Entries whose box would leave the plane are not
+ * written (the reference leaves partial sums there; no search reads them). */
+int  x264hip_integral_init( x264hip_ctx *ctx, const void *plane_dev, intptr_t stride, int width, int height, uint16_t *sum8_dev, uint16_t *sum4_dev );
 #define X264HIP_ME_MVC_MAX 10
 typedef struct x264hip_me_request
 {

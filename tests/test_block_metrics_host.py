@@ -25,7 +25,7 @@ METRICS = {  # name: (id, sizes, needs second plane)
 
 
 def _lib():
-    hdrs = [os.path.join(HERE, "..", "x264_amd", "csrc", h) for h in ("block_metrics.h", "dct_quant_block.h")]
+    hdrs = [os.path.join(HERE, "..", "x264_amd", "csrc", h) for h in ("block_metrics.h", "dct_quant_block.h", "me_full.h", "integral.h")]
     if not os.path.exists(OUT) or max([os.path.getmtime(SRC)] + [os.path.getmtime(h) for h in hdrs]) > os.path.getmtime(OUT):
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC])
@@ -114,3 +114,27 @@ def test_dct_quant8x8_block_arithmetic(depth):
         rnz = quant(1, p(c), p(mf.astype(o.ucoef_dtype)), p(bias.astype(o.ucoef_dtype)), 0, 0)
         assert np.array_equal(out, c), trial
         assert nz == rnz, trial
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_integral_planes_vs_reference_recording(depth):
+    """integral.h (the two passes of integral_rows_kernel / integral_cols_kernel) against the integral planes the reference built
+    for the recorded searches (tests/golden/me_full_d*.npz, x264_frame_filter): every entry whose whole box lies inside the padded
+    plane below the first row (row 0 of the reference's buffer is its zero row, tests/test_me_full_vs_ref.py)."""
+    L = _lib()
+    fn = L.ii_host_u8 if depth == 8 else L.ii_host_u16
+    fn.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    z = np.load(os.path.join(HERE, "golden", "me_full_d%d.npz" % depth))
+    plane = np.ascontiguousarray(z["planes"][0])
+    ph, pw = plane.shape
+    ref = np.ascontiguousarray(z["integral"])          # [2*ph][pw]: 8x8 sums, then 4x4 sums
+    s8 = np.zeros((ph, pw), np.uint16); s4 = np.zeros((ph, pw), np.uint16)
+    fn(plane.ctypes.data, pw, pw, ph, s8.ctypes.data, s4.ctypes.data)
+    assert np.array_equal(s8[1:ph - 8, :pw - 8], ref[1:ph - 8, :pw - 8])
+    assert np.array_equal(s4[1:ph - 8, :pw - 8], ref[ph + 1:2 * ph - 8, :pw - 8])
+    # and against plain box sums everywhere a box fits
+    p = plane.astype(np.int64)
+    c = np.zeros((ph + 1, pw + 1), np.int64); c[1:, 1:] = p.cumsum(0).cumsum(1)
+    for n, got in ((8, s8), (4, s4)):
+        box = (c[n:, n:] - c[:-n, n:] - c[n:, :-n] + c[:-n, :-n]) & 0xFFFF
+        assert np.array_equal(got[:ph - n + 1, :pw - n + 1], box)

@@ -52,3 +52,23 @@ static void mf_run( const MfHostReq *h, const int16_t *mvc, int n_mvc, int *out 
 }
 extern "C" void mf_host_u8( const MfHostReq *h, const int16_t *mvc, int n_mvc, int *out ) { mf_run<uint8_t>( h, mvc, n_mvc, out ); }
 extern "C" void mf_host_u16( const MfHostReq *h, const int16_t *mvc, int n_mvc, int *out ) { mf_run<uint16_t>( h, mvc, n_mvc, out ); }
+
+// integral planes (x264_amd/csrc/integral.h): the two passes of the device kernels run as loops over host memory
+#include "../../x264_amd/csrc/integral.h"
+template <typename T>
+static void ii_run( const T *plane, long stride, int width, int height, uint16_t *sum8, uint16_t *sum4 )
+{
+    uint16_t *h8 = (uint16_t *)calloc( (size_t)stride * height, 2 ), *h4 = (uint16_t *)calloc( (size_t)stride * height, 2 );
+    for( int y = 0; y < height; y++ )
+        for( int x = 0; x < width; x++ )
+            ii_row_sums<T>( plane + (long)y * stride, x, width, h8 + (long)y * stride + x, h4 + (long)y * stride + x );
+    for( int y = 0; y < height; y++ )
+        for( int x = 0; x < width; x++ )
+        {
+            if( x + 8 <= width && y + 8 <= height ) sum8[(long)y * stride + x] = ii_col_sum( h8 + (long)y * stride + x, stride, 8 );
+            if( x + 4 <= width && y + 4 <= height ) sum4[(long)y * stride + x] = ii_col_sum( h4 + (long)y * stride + x, stride, 4 );
+        }
+    free( h8 ); free( h4 );
+}
+extern "C" void ii_host_u8( const uint8_t *plane, long stride, int width, int height, uint16_t *sum8, uint16_t *sum4 ) { ii_run<uint8_t>( plane, stride, width, height, sum8, sum4 ); }
+extern "C" void ii_host_u16( const uint16_t *plane, long stride, int width, int height, uint16_t *sum8, uint16_t *sum4 ) { ii_run<uint16_t>( plane, stride, width, height, sum8, sum4 ); }

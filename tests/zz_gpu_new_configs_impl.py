@@ -268,3 +268,31 @@ def test_me_search_batch(depth):
         n = 4 if subs[k] >= 2 else 3
         assert np.array_equal(got[k][:n], want[k][:n]), (k, got[k].tolist(), [int(v) for v in want[k]])
     assert len(reqs) >= 500
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_integral_init(depth):
+    """x264hip_integral_init against the integral planes the reference built (x264_frame_filter, recorded in the golden file) and
+    against plain box sums; then the TESA requests of the recording run on the DEVICE-built planes."""
+    import torch
+    z = np.load(os.path.join(GOLD, "me_full_d%d.npz" % depth))
+    plane = np.ascontiguousarray(z["planes"][0])
+    ph, pw = plane.shape
+    ref = np.ascontiguousarray(z["integral"])
+    vdt = np.uint8 if depth == 8 else np.int16
+    dp = torch.from_numpy(plane.view(vdt)).cuda()
+    out = torch.zeros((2 * ph, pw), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    ctx = lib.Context(64, 64, bit_depth=depth, max_frames=2, mv_range=32)
+    try:
+        ctx.integral_init(dp.data_ptr(), pw, pw, ph, out.data_ptr(), out.data_ptr() + 2 * ph * pw)
+    finally:
+        ctx.close()
+    got = out.cpu().numpy().view(np.uint16)
+    assert np.array_equal(got[1:ph - 8, :pw - 8], ref[1:ph - 8, :pw - 8])
+    assert np.array_equal(got[ph + 1:2 * ph - 8, :pw - 8], ref[ph + 1:2 * ph - 8, :pw - 8])
+    p = plane.astype(np.int64)
+    c = np.zeros((ph + 1, pw + 1), np.int64); c[1:, 1:] = p.cumsum(0).cumsum(1)
+    for n, base in ((8, 0), (4, ph)):
+        box = (c[n:, n:] - c[:-n, n:] - c[n:, :-n] + c[:-n, :-n]) & 0xFFFF
+        assert np.array_equal(got[base:base + ph - n + 1, :pw - n + 1], box)

@@ -23,6 +23,7 @@
 #include "block_metrics.h"
 #include "dct_quant_block.h"
 #include "me_full.h"
+#include "integral.h"
 
 #define HIPCK( call )                                                                                        \
     do {                                                                                                     \
@@ -1429,6 +1430,25 @@ extern "C" int x264hip_me_search_batch( x264hip_ctx *ctx, int n, const x264hip_m
     return ctx->p.bit_depth == 8
            ? me_search_batch_t<uint8_t>( ctx, n, reqs, fenc_plane_dev, fenc_stride, ref_planes_dev, ref_stride, integral_dev, integral_lower, cost_mv_dev, out )
            : me_search_batch_t<uint16_t>( ctx, n, reqs, fenc_plane_dev, fenc_stride, ref_planes_dev, ref_stride, integral_dev, integral_lower, cost_mv_dev, out );
+}
+
+extern "C" int x264hip_integral_init( x264hip_ctx *ctx, const void *plane_dev, intptr_t stride, int width, int height, uint16_t *sum8_dev, uint16_t *sum4_dev )
+{
+    if( !ctx || !plane_dev || !sum8_dev || !sum4_dev || width < 8 || height < 8 || stride < width ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    uint16_t *h = nullptr; // row sums of 8 and of 4, one plane each
+    const size_t plane = (size_t)stride * height;
+    if( hipMalloc( &h, 2 * plane * sizeof( uint16_t ) ) != hipSuccess ) return X264HIP_ENOMEM;
+    const dim3 grd( ( width + 255 ) / 256, height );
+    if( ctx->p.bit_depth == 8 )
+        integral_rows_kernel<uint8_t><<<grd, 256, 0, ctx->stream>>>( (const uint8_t *)plane_dev, (long)stride, width, height, h, h + plane );
+    else
+        integral_rows_kernel<uint16_t><<<grd, 256, 0, ctx->stream>>>( (const uint16_t *)plane_dev, (long)stride, width, height, h, h + plane );
+    integral_cols_kernel<<<grd, 256, 0, ctx->stream>>>( h, h + plane, (long)stride, width, height, sum8_dev, sum4_dev );
+    int rc = hipGetLastError() == hipSuccess && hipStreamSynchronize( ctx->stream ) == hipSuccess ? X264HIP_OK : X264HIP_EDEVICE;
+    (void)hipFree( h );
+    return rc;
 }
 
 extern "C" int x264hip_pixel_metric_batch( x264hip_ctx *ctx, int metric, int size_idx, const void *a_plane, const void *b_plane, intptr_t stride,

@@ -242,6 +242,10 @@ class Context:
                                            cost_mv_ptr, _p(out)), "me_search_batch")
         return out
 
+    def integral_init(self, plane_ptr, stride, width, height, sum8_ptr, sum4_ptr):
+        self.L.x264hip_integral_init.argtypes = [C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _ck(self.L.x264hip_integral_init(self.h, plane_ptr, stride, width, height, sum8_ptr, sum4_ptr), "integral_init")
+
     def pixel_metric_batch(self, metric, size_idx, a_ptr, b_ptr, stride, blocks_w, blocks_h, out_ptr):
         self.L.x264hip_pixel_metric_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int,
                                                       C.c_void_p]
