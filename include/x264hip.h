@@ -196,6 +196,14 @@ int  x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx, const vo
  * whose top-left sample is (x, y), modulo 2^16, and sum4 the same for 4x4 boxes.  Entries whose box would leave the plane are not
  * written (the reference leaves partial sums there; no search reads them). */
 int  x264hip_integral_init( x264hip_ctx *ctx, const void *plane_dev, intptr_t stride, int width, int height, uint16_t *sum8_dev, uint16_t *sum4_dev );
+/* What a reconstructed frame goes through before it serves as a reference, for a whole frame: x264_frame_expand_border,
+ * x264_frame_filter (hpel planes + integral planes, common/mc.c:704-784) and x264_frame_expand_border_filtered (common/frame.c:
+ * 556-623).  luma_dev: the width x height picture (mod-16 size); planes_dev[0..3]: pixel (0,0) of the padded full / H / V / HV
+ * planes (padh / padv samples of border on every side, PADH / PADV of the reference = 32); sum8_dev / sum4_dev: element
+ * (-padh,-padv)-relative origin, i.e. the first element of integral planes laid out like the padded luma plane (both NULL: no
+ * integral planes). */
+int  x264hip_frame_filter( x264hip_ctx *ctx, const void *luma_dev, intptr_t luma_stride, int width, int height, void *const planes_dev[4], intptr_t stride,
+                           int padh, int padv, uint16_t *sum8_dev, uint16_t *sum4_dev );
 #define X264HIP_ME_MVC_MAX 10
 typedef struct x264hip_me_request
 {

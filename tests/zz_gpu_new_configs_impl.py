@@ -296,3 +296,36 @@ def test_integral_init(depth):
     for n, base in ((8, 0), (4, ph)):
         box = (c[n:, n:] - c[:-n, n:] - c[n:, :-n] + c[:-n, :-n]) & 0xFFFF
         assert np.array_equal(got[base:base + ph - n + 1, :pw - n + 1], box)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_frame_filter(depth):
+    """x264hip_frame_filter (border expansion + hpel planes + their borders + integral planes of a whole frame) against the four
+    padded planes and the integral planes recorded from the reference (x264_frame_expand_border -> x264_frame_filter ->
+    x264_frame_expand_border_filtered run row by row like the encoder does, oracle/ref_harness.c:rh_add_ref_frame)."""
+    import torch
+    z = np.load(os.path.join(GOLD, "me_full_d%d.npz" % depth))
+    W, H, pw, ph, padh, padv, _ = (int(v) for v in z["geom"])
+    gold = z["planes"]
+    vdt = np.uint8 if depth == 8 else np.int16
+    isz = 1 if depth == 8 else 2
+    pic = np.ascontiguousarray(gold[0][padv:padv + H, padh:padh + W])
+    dpic = torch.from_numpy(pic.view(vdt)).cuda()
+    planes = torch.full((4, ph, pw), 0x55, dtype=torch.uint8 if depth == 8 else torch.int16, device="cuda")
+    integ = torch.zeros((2 * ph, pw), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    org0 = (padv * pw + padh) * isz
+    ctx = lib.Context(64, 64, bit_depth=depth, max_frames=2, mv_range=32)
+    try:
+        ctx.frame_filter(dpic.data_ptr(), W, W, H, [planes[k].data_ptr() + org0 for k in range(4)], pw, padh, padv,
+                         integ.data_ptr(), integ.data_ptr() + 2 * ph * pw)
+        ctx.synchronize()
+    finally:
+        ctx.close()
+    got = planes.cpu().numpy().view(np.uint8 if depth == 8 else np.uint16)
+    for k in range(4):
+        assert np.array_equal(got[k], gold[k]), ("plane", k, int((got[k] != gold[k]).sum()))
+    gi = integ.cpu().numpy().view(np.uint16)
+    ref = z["integral"]
+    assert np.array_equal(gi[1:ph - 8, :pw - 8], ref[1:ph - 8, :pw - 8])
+    assert np.array_equal(gi[ph + 1:2 * ph - 8, :pw - 8], ref[ph + 1:2 * ph - 8, :pw - 8])

@@ -37,6 +37,23 @@ BM_HD uint16_t ii_col_sum( const uint16_t *h, long stride, int n )
 }
 
 #ifdef __HIPCC__
+// Border replication of x264_frame_expand_border / x264_frame_expand_border_filtered (common/frame.c:535-623) for a whole padded
+// plane at once: every sample outside the rectangle [x0, x1] x [y0, y1] becomes the nearest sample of the rectangle.  src == dst
+// is allowed (only samples outside the rectangle are written, only samples inside it are read); with src != dst the rectangle is
+// copied as well (src addressed with its own stride and origin).
+template <typename T>
+__global__ __launch_bounds__( 256 ) void expand_border_kernel( T *__restrict__ dst, long dst_stride, const T *src, long src_stride, int in_place,
+                                                              int x0, int x1, int y0, int y1, int xmin, int xmax, int ymin )
+{
+    const int x = xmin + blockIdx.x * 256 + threadIdx.x, y = ymin + blockIdx.y;
+    if( x > xmax )
+        return;
+    const int cx = x < x0 ? x0 : x > x1 ? x1 : x, cy = y < y0 ? y0 : y > y1 ? y1 : y;
+    if( in_place && cx == x && cy == y )
+        return;
+    dst[(long)y * dst_stride + x] = src[(long)cy * src_stride + cx];
+}
+
 template <typename T>
 __global__ __launch_bounds__( 256 ) void integral_rows_kernel( const T *__restrict__ plane, long stride, int width, int height,
                                                                uint16_t *__restrict__ h8, uint16_t *__restrict__ h4 )

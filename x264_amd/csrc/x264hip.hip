@@ -1554,6 +1554,51 @@ extern "C" int x264hip_hpel_filter( x264hip_ctx *ctx, void *dsth, void *dstv, vo
     return X264HIP_OK;
 }
 
+// x264_frame_filter for a whole frame (common/mc.c:704-784) with the border work around it (x264_frame_expand_border,
+// x264_frame_expand_border_filtered, common/frame.c:556-623): what a reconstructed frame goes through before it can serve as a
+// reference.  The reference does this macroblock row by macroblock row as rows finish; every output depends only on the luma
+// samples, so the whole-frame order gives the same planes (checked against planes recorded from the reference).
+template <typename T>
+static int frame_filter_t( x264hip_ctx *ctx, const T *luma, intptr_t luma_stride, int width, int height, T *const planes[4], intptr_t stride, int padh, int padv,
+                           uint16_t *sum8, uint16_t *sum4 )
+{
+    const int pw = width + 2 * padh, ph = height + 2 * padv;
+    const dim3 grd( ( pw + 255 ) / 256, ph );
+    // 1. the picture into plane 0, its border replicated (x264_frame_expand_border)
+    expand_border_kernel<T><<<grd, 256, 0, ctx->stream>>>( planes[0], (long)stride, luma, (long)luma_stride, 0, 0, width - 1, 0, height - 1, -padh, width + padh - 1, -padv );
+    // 2. the three half-pel planes over the picture plus 8 samples all round (mc.c:706-726)
+    const long offs = -8 * (long)stride - 8;
+    hpel_filter_kernel<T><<<dim3( ( width + 16 + HPEL_TW - 1 ) / HPEL_TW, ( height + 16 + HPEL_TH - 1 ) / HPEL_TH ), 256, 0, ctx->stream>>>(
+        planes[1] + offs, planes[2] + offs, planes[3] + offs, planes[0] + offs, (long)stride, width + 16, height + 16, ctx->P.pixel_max );
+    // 3. their borders from the last trustworthy filtered samples: 4 columns / 8 rows outside the picture (frame.c:599-623)
+    for( int k = 1; k < 4; k++ )
+        expand_border_kernel<T><<<grd, 256, 0, ctx->stream>>>( planes[k], (long)stride, planes[k], (long)stride, 1, -4, width + 3, -8, height + 7, -padh, width + padh - 1, -padv );
+    HIPCK( hipGetLastError() );
+    // 4. the integral planes of the padded luma plane (mc.c:757-783)
+    if( sum8 && sum4 )
+        return x264hip_integral_init( ctx, planes[0] - (long)padv * stride - padh, stride, pw, ph, sum8, sum4 );
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_frame_filter( x264hip_ctx *ctx, const void *luma_dev, intptr_t luma_stride, int width, int height, void *const planes_dev[4], intptr_t stride,
+                                     int padh, int padv, uint16_t *sum8_dev, uint16_t *sum4_dev )
+{
+    if( !ctx || !luma_dev || !planes_dev || width < 16 || height < 16 || luma_stride < width || padh < 8 || padv < 8 || stride < width + 2 * padh ||
+        ( !sum8_dev ) != ( !sum4_dev ) )
+        return X264HIP_EINVAL;
+    for( int k = 0; k < 4; k++ )
+        if( !planes_dev[k] ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    if( ctx->p.bit_depth == 8 )
+    {
+        uint8_t *pl[4] = { (uint8_t *)planes_dev[0], (uint8_t *)planes_dev[1], (uint8_t *)planes_dev[2], (uint8_t *)planes_dev[3] };
+        return frame_filter_t<uint8_t>( ctx, (const uint8_t *)luma_dev, luma_stride, width, height, pl, stride, padh, padv, sum8_dev, sum4_dev );
+    }
+    uint16_t *pl[4] = { (uint16_t *)planes_dev[0], (uint16_t *)planes_dev[1], (uint16_t *)planes_dev[2], (uint16_t *)planes_dev[3] };
+    return frame_filter_t<uint16_t>( ctx, (const uint16_t *)luma_dev, luma_stride, width, height, pl, stride, padh, padv, sum8_dev, sum4_dev );
+}
+
 extern "C" int x264hip_device_copy( x264hip_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes )
 {
     if( !ctx || !dst_dev || !src_dev || ( bytes & 15 ) || ( (uintptr_t)dst_dev & 15 ) || ( (uintptr_t)src_dev & 15 ) ) return X264HIP_EINVAL;

@@ -242,6 +242,12 @@ class Context:
                                            cost_mv_ptr, _p(out)), "me_search_batch")
         return out
 
+    def frame_filter(self, luma_ptr, luma_stride, width, height, plane_ptrs, stride, padh, padv, sum8_ptr=None, sum4_ptr=None):
+        self.L.x264hip_frame_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int,
+                                                C.c_void_p, C.c_void_p]
+        pl = (C.c_void_p * 4)(*plane_ptrs)
+        _ck(self.L.x264hip_frame_filter(self.h, luma_ptr, luma_stride, width, height, pl, stride, padh, padv, sum8_ptr, sum4_ptr), "frame_filter")
+
     def integral_init(self, plane_ptr, stride, width, height, sum8_ptr, sum4_ptr):
         self.L.x264hip_integral_init.argtypes = [C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _ck(self.L.x264hip_integral_init(self.h, plane_ptr, stride, width, height, sum8_ptr, sum4_ptr), "integral_init")
