@@ -138,3 +138,28 @@ def test_integral_planes_vs_reference_recording(depth):
     for n, got in ((8, s8), (4, s4)):
         box = (c[n:, n:] - c[:-n, n:] - c[n:, :-n] + c[:-n, :-n]) & 0xFFFF
         assert np.array_equal(got[:ph - n + 1, :pw - n + 1], box)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_whole_frame_filter_order_vs_reference_recording(depth):
+    """The composition x264hip_frame_filter runs on the device -- replicate the picture's border, hpel_filter over the picture plus
+    8 samples all round, then every filtered sample outside [-4, W+3] x [-8, H+7] from the nearest one inside -- gives exactly the
+    four padded planes the reference produced row by row (x264_frame_expand_border / x264_frame_filter /
+    x264_frame_expand_border_filtered, recorded in the golden file).  hpel_filter itself: the oracle's (pinned against the vtable)."""
+    z = np.load(os.path.join(HERE, "golden", "me_full_d%d.npz" % depth))
+    W, H, pw, ph, padh, padv, _ = (int(v) for v in z["geom"])
+    o = Oracle(depth)
+    gold = z["planes"]
+    pic = gold[0][padv:padv + H, padh:padh + W]
+    luma = np.ascontiguousarray(np.pad(pic, ((padv, padv), (padh, padh)), mode="edge"))
+    assert np.array_equal(luma, gold[0])
+    f = o.f("hpel_filter")
+    f.argtypes = [C.c_void_p] * 4 + [C.c_long, C.c_int, C.c_int, C.c_void_p]
+    outs = [np.zeros_like(luma) for _ in range(3)]
+    off = ((padv - 8) * pw + padh - 8) * luma.itemsize
+    buf = np.zeros(W + 16 + 64, np.int16)
+    f(outs[0].ctypes.data + off, outs[1].ctypes.data + off, outs[2].ctypes.data + off, luma.ctypes.data + off, pw, W + 16, H + 16, buf.ctypes.data)
+    ys = np.clip(np.arange(-padv, H + padv), -8, H + 7) + padv
+    xs = np.clip(np.arange(-padh, W + padh), -4, W + 3) + padh
+    for k in range(3):
+        assert np.array_equal(outs[k][np.ix_(ys, xs)], gold[k + 1]), k + 1
