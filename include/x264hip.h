@@ -86,6 +86,8 @@ typedef struct x264hip_cost
 #define X264HIP_MBT_ZERO      0   /* memset( frames[slot_b]->i_propagate_cost, 0 ) */
 #define X264HIP_MBT_PROPAGATE 1   /* macroblock_tree_propagate( p0, p1, b, referenced ) */
 #define X264HIP_MBT_FINISH    2   /* macroblock_tree_finish( frames[slot_b] ) -> f_qp_offset */
+#define X264HIP_MBT_SWAP      3   /* XCHG( frames[slot_b]->i_propagate_cost, frames[slot_p0]->i_propagate_cost ): lookahead-less MB-tree */
+#define X264HIP_MBT_RESET_QP  4   /* memcpy( frames[slot_b]->f_qp_offset, f_qp_offset_aq ) (slicetype.c:1119-1120) */
 typedef struct x264hip_mbtree_op
 {
     int type;

@@ -109,7 +109,12 @@ class OracleBackend:
         for k in range(n):
             op = ops[k]
             B = self.slots[op.slot_b]
-            if op.type == 0:
+            if op.type == 3:      # X264HIP_MBT_SWAP: the two frames exchange their accumulators
+                A = self.slots[op.slot_p0]
+                B["prop"], A["prop"] = A["prop"], B["prop"]
+            elif op.type == 4:    # X264HIP_MBT_RESET_QP
+                B["qp"][:] = B["qp_aq"]
+            elif op.type == 0:
                 B["prop"][:] = 0
             elif op.type == 1:
                 F0, F1 = self.slots[op.slot_p0], self.slots[op.slot_p1]

@@ -59,6 +59,13 @@ CASES = [
     ("medium", "intra-refresh=1,keyint=12,bframes=5,b-pyramid=normal,ref=4", dict(intra_refresh=1, keyint_max=12, bframes=5, b_pyramid=2, frame_refs=4),
      8, dict(seed=9, scene_cuts=(13, 37), pan=(2, 1)), 60),
     ("medium", "intra-refresh=1,keyint=10,mbtree=0", dict(intra_refresh=1, keyint_max=10, mb_tree=0), 8, dict(seed=9, scene_cuts=(13, 37), pan=(2, 1)), 60),
+    # lookahead-less MB-tree (rc-lookahead 0 is only kept with infinite keyint or intra refresh, encoder.c:1128-1133): the propagation
+    # is extrapolated across calls by exchanging accumulators with the window's first frame (slicetype.c:1112-1124, :1173-1178)
+    ("medium", "keyint=infinite,rc-lookahead=0", dict(keyint_max=1 << 30, rc_lookahead=0), 8, dict(seed=3, scene_cuts=(21,), pan=(3, 1)), 40),
+    ("medium", "intra-refresh=1,rc-lookahead=0,keyint=30", dict(intra_refresh=1, rc_lookahead=0, keyint_max=30), 8,
+     dict(seed=3, scene_cuts=(21,), pan=(3, 1)), 40),
+    ("fast", "keyint=infinite,rc-lookahead=0,bframes=0", dict(keyint_max=1 << 30, rc_lookahead=0, bframes=0), 8,
+     dict(seed=3, scene_cuts=(21,), pan=(3, 1)), 40),
     # more B-frames than the key-frame interval allows (encoder.c:1074)
     ("medium", "bframes=16,keyint=8,rc-lookahead=5", dict(bframes=16, keyint_max=8, rc_lookahead=5), 8, dict(seed=17), 40),
 ]
@@ -431,8 +438,6 @@ def test_api_misuse_is_reported():
         assert [o.frame for o in sorted(outs, key=lambda o: o.frame)] == list(range(30))
     finally:
         la.close()
-    with pytest.raises(ValueError):
-        lib.la_config(W, H, "medium", keyint_max=1 << 30, rc_lookahead=0)  # lookahead-less MB-tree
     import ctypes as C
     L = lib.load()
     h = C.c_void_p()

@@ -395,6 +395,13 @@ struct Lookahead
         o.type = X264HIP_MBT_ZERO; o.slot_b = o.slot_p0 = o.slot_p1 = f->slot;
         ops.push_back( o );
     }
+    void mbt_simple( std::vector<x264hip_mbtree_op> &ops, int type, LaFrame *a, LaFrame *b )
+    {
+        x264hip_mbtree_op o;
+        memset( &o, 0, sizeof( o ) );
+        o.type = type; o.slot_b = a->slot; o.slot_p0 = o.slot_p1 = b->slot;
+        ops.push_back( o );
+    }
     void mbt_propagate( std::vector<x264hip_mbtree_op> &ops, LaFrame **frames, float average_duration, int p0, int p1, int b, int referenced )
     {
         x264hip_mbtree_op o;
@@ -436,9 +443,26 @@ struct Lookahead
         if( b_intra ) frame_cost( frames, 0, 0, 0 );
         while( i > 0 && is_b( frames[i]->i_type ) ) i--;
         last_nonb = i;
-        // (rc_lookahead == 0 with MB-tree on -- the extrapolating lookahead-less form, :1112-1124 -- is rejected at open)
-        if( last_nonb < idx ) return;
-        mbt_zero( ops, frames[last_nonb] );
+        // Lookahead-less MB-tree (:1112-1124): the accumulators of the frame that starts the window were left behind by the
+        // previous call and serve as the extrapolated future of frames[last_nonb]
+        const bool lookaheadless = !p.rc_lookahead;
+        if( lookaheadless )
+        {
+            if( b_intra )
+            {
+                mbt_zero( ops, frames[0] );
+                mbt_simple( ops, X264HIP_MBT_RESET_QP, frames[0], frames[0] );
+                if( be.mbtree && !err ) need( be.mbtree( be.user, ops.data(), (int)ops.size() ) );
+                return;
+            }
+            mbt_simple( ops, X264HIP_MBT_SWAP, frames[last_nonb], frames[0] );
+            mbt_zero( ops, frames[0] );
+        }
+        else
+        {
+            if( last_nonb < idx ) return;
+            mbt_zero( ops, frames[last_nonb] );
+        }
         while( i-- > idx )
         {
             cur_nonb = i;
@@ -474,6 +498,12 @@ struct Lookahead
                 }
             mbt_propagate( ops, frames, average_duration, cur_nonb, last_nonb, last_nonb, 1 );
             last_nonb = cur_nonb;
+        }
+        if( lookaheadless ) // :1173-1178
+        {
+            frame_cost( frames, 0, last_nonb, last_nonb );
+            mbt_propagate( ops, frames, average_duration, 0, last_nonb, last_nonb, 1 );
+            mbt_simple( ops, X264HIP_MBT_SWAP, frames[last_nonb], frames[0] );
         }
         mbt_finish( ops, frames[last_nonb], average_duration, last_nonb );
         if( p.b_pyramid && bframes > 1 && !p.vbv ) // :1182-1183
@@ -953,12 +983,7 @@ static int la_init( x264hip_lookahead *la, const x264hip_la_params *params )
     if( p.dev.bframes < 0 || p.dev.bframes > BMAX || p.keyint_max < 1 || p.rc_lookahead < 0 || p.rc_lookahead > LOOKAHEAD_MAX ||
         p.b_adapt < 0 || p.b_adapt > 2 || p.b_pyramid < 0 || p.b_pyramid > 2 )
         return X264HIP_EINVAL;
-    if( p.mb_tree && !p.rc_lookahead )
-    {
-        // only reachable with keyint = infinite (or intra refresh, which is not mirrored either): encoder.c:1128-1133
-        fprintf( stderr, "x264hip_lookahead: lookahead-less MB-tree (rc_lookahead = 0 with MB-tree on, slicetype.c:1112-1124) is not implemented\n" );
-        return X264HIP_EINVAL;
-    }
+
     // encoder.c:1601-1612 with one frame thread, no lookahead thread, cfr input
     if( p.b_adapt == 2 )
         L.i_delay = ( p.dev.bframes > 3 ? p.dev.bframes : 3 ) * 4;

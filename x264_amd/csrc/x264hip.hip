@@ -1010,28 +1010,45 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
     if( ctx->mbt_pending >= x264hip_ctx::MBT_RING )
         HIPCK( hipEventSynchronize( ctx->mbt_done[r] ) ); // the table we are about to rewrite has been consumed
     MbtOpDev *dh = ctx->mbt_host[r];
+    // The lookahead-less form exchanges the accumulators of two frames (X264HIP_MBT_SWAP): that is a swap of the two slots' buffer
+    // pointers, applied here in the caller's order, so that every step below addresses the buffer the reference would.  RESET_QP
+    // is a device-to-device copy queued behind the kernel (it only ever comes with a ZERO of the same frame, slicetype.c:1117-1121).
+    std::vector<int *> res_b( n ), res_p0( n ), res_p1( n );
+    std::vector<int> resets;
+    for( int i = 0; i < n; i++ )
+    {
+        const x264hip_mbtree_op &o = ops[i];
+        if( !slot_ok( ctx, o.slot_b ) || !slot_ok( ctx, o.slot_p0 ) || !slot_ok( ctx, o.slot_p1 ) || o.type < 0 || o.type > X264HIP_MBT_RESET_QP )
+            return X264HIP_EINVAL;
+        if( o.type == X264HIP_MBT_SWAP )
+            std::swap( ctx->slots[o.slot_b].prop, ctx->slots[o.slot_p0].prop );
+        else if( o.type == X264HIP_MBT_RESET_QP )
+            resets.push_back( o.slot_b );
+        res_b[i] = ctx->slots[o.slot_b].prop; res_p0[i] = ctx->slots[o.slot_p0].prop; res_p1[i] = ctx->slots[o.slot_p1].prop;
+    }
     // Step order on the device: every ZERO first (a buffer is always cleared before anything is added to it in the
     // reference's order too), then the rest in order.  A barrier is only needed where a step reads what earlier
     // steps accumulated: referenced PROPAGATEs and FINISH; runs of B-frame propagations overlap freely.
     std::vector<int> order;
     for( int i = 0; i < n; i++ ) if( ops[i].type == X264HIP_MBT_ZERO ) order.push_back( i );
     const int n_zero = (int)order.size();
-    for( int i = 0; i < n; i++ ) if( ops[i].type != X264HIP_MBT_ZERO ) order.push_back( i );
+    for( int i = 0; i < n; i++ ) if( ops[i].type == X264HIP_MBT_PROPAGATE || ops[i].type == X264HIP_MBT_FINISH ) order.push_back( i );
+    const int n_host = n;
+    n = (int)order.size(); // steps that run on the device
     for( int k = 0; k < n; k++ )
     {
         const int i = k;
         const x264hip_mbtree_op &o = ops[order[k]];
-        if( !slot_ok( ctx, o.slot_b ) || !slot_ok( ctx, o.slot_p0 ) || !slot_ok( ctx, o.slot_p1 ) || o.dist_p0 < 0 || o.dist_p1 < 0 ||
-            o.dist_p0 + o.dist_p1 > ctx->p.bframes + 1 )
+        if( o.dist_p0 < 0 || o.dist_p1 < 0 || o.dist_p0 + o.dist_p1 > ctx->p.bframes + 1 )
             return X264HIP_EINVAL;
-        FrameSlot &b = ctx->slots[o.slot_b], &f0 = ctx->slots[o.slot_p0], &f1 = ctx->slots[o.slot_p1];
+        FrameSlot &b = ctx->slots[o.slot_b];
         MbtOpDev d;
         memset( &d, 0, sizeof( d ) );
         d.type = o.type; d.referenced = o.referenced; d.bipred_weight = o.bipred_weight; d.fps_factor_i = o.fps_factor_i;
         d.fps_factor = o.fps_factor; d.weightdelta = o.weightdelta; d.strength = o.strength;
         d.b_bidir = o.dist_p1 > 0;
         d.barrier_before = k == n_zero || ( o.type == X264HIP_MBT_PROPAGATE && o.referenced ) || o.type == X264HIP_MBT_FINISH;
-        d.prop_b = b.prop; d.prop_p0 = f0.prop; d.prop_p1 = f1.prop;
+        d.prop_b = res_b[order[k]]; d.prop_p0 = res_p0[order[k]]; d.prop_p1 = res_p1[order[k]];
         d.intra_cost = b.lowres_costs; d.inv_qscale = b.inv_qscale;
         d.lowres_costs = b.lowres_costs + (size_t)( o.dist_p0 * nstride + o.dist_p1 ) * ctx->n_mb;
         if( o.type == X264HIP_MBT_PROPAGATE )
@@ -1046,6 +1063,9 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
     // inputs come from the main stream (cells, clamp kernels): order the MB-tree stream behind it
     HIPCK( hipEventRecord( ctx->ev_cross, ctx->stream ) );
     HIPCK( hipStreamWaitEvent( ctx->stream2, ctx->ev_cross, 0 ) );
+    (void)n_host;
+    if( n > 0 )
+    {
     const size_t table_bytes = (size_t)n * sizeof( MbtOpDev );
     // Measured (two segments in flight, 1080p): copying the step list to the device in front of the call gives 8500 frames/s,
     // letting every workgroup pull it from pinned host memory into LDS 8070 -- sixteen PCIe read bursts per call cost more
@@ -1059,6 +1079,9 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
         mbtree_kernel<<<MBT_WGS, 1024, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], n, 0, ctx->luts_dev, ctx->mbt_bar + 4 * r );
     }
     HIPCK( hipGetLastError() );
+    }
+    for( int slot : resets )
+        HIPCK( hipMemcpyAsync( ctx->slots[slot].qp, ctx->slots[slot].qp_aq, ctx->n_mb * sizeof( float ), hipMemcpyDeviceToDevice, ctx->stream2 ) );
     HIPCK( hipEventRecord( ctx->mbt_done[r], ctx->stream2 ) );
     HIPCK( hipEventRecord( ctx->ev_mbt_last, ctx->stream2 ) );
     ctx->mbt_pending++;

@@ -489,8 +489,6 @@ def la_config(width, height, preset="medium", bit_depth=8, tune="", **over):
         c["me_range"] = 16
     if me == 4 and c["subme"] <= 1:
         me = 3
-    if c["mb_tree"] and not c["rc_lookahead"]:
-        raise ValueError("lookahead-less MB-tree (rc-lookahead=0 with keyint=infinite, slicetype.c:1112-1124) is not implemented")
     c["aq_mode"] = clip(c["aq_mode"], 0, 3)                                  # :1177-1180
     c["aq_strength"] = clip(float(c["aq_strength"]), 0.0, 3.0)
     if c["aq_strength"] == 0:
