@@ -23,7 +23,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.xfail(reason="device path not yet run
 def test_in_own_process(function):
     cmd = [sys.executable, "-m", "pytest", "%s::%s" % (IMPL, function), "-q", "-m", "gpu", "-p", "no:cacheprovider"]
     try:
-        r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     except subprocess.TimeoutExpired as e:
         print((e.stdout or b"").decode(errors="replace")[-4000:])
         pytest.fail("%s timed out" % function)
