@@ -1380,18 +1380,20 @@ static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request 
     std::vector<MfReq<T>> table( n );
     std::vector<int16_t> mvc( (size_t)n * MF_MVC_MAX * 2, 0 );
     std::vector<int> n_mvc( n );
-    const size_t scratch_bytes = (size_t)MF_TESA_ROWS_MAX * MF_TESA_WIDTH_MAX * 12;
-    int n_tesa = 0;
+    // TESA keeps the candidates that pass its SAD threshold: at most ( width + 4 ) * ( rows + 1 ) of them, 12 bytes each, with
+    // width <= 2 * me_range + 4 and rows <= 2 * me_range + 1 (me.c:651-655)
+    auto tesa_bytes = []( int me_range ) { return (size_t)( 2 * me_range + 8 ) * ( 2 * me_range + 2 ) * 12; };
+    size_t scratch_total = 0;
     for( int i = 0; i < n; i++ )
-        n_tesa += reqs[i].me_method == 4;
+        if( reqs[i].me_method == 4 ) scratch_total += tesa_bytes( reqs[i].me_range );
     char *scratch = nullptr;
     MfReq<T> *table_dev = nullptr;
     int16_t *mvc_dev = nullptr;
     int *n_mvc_dev = nullptr, *out_dev = nullptr;
     int rc = X264HIP_OK;
 #define MECK( call ) do { if( ( call ) != hipSuccess ) { rc = X264HIP_ENOMEM; goto done; } } while( 0 )
-    if( n_tesa ) MECK( hipMalloc( &scratch, scratch_bytes * n_tesa ) );
-    for( int i = 0, t = 0; i < n; i++ )
+    if( scratch_total ) MECK( hipMalloc( &scratch, scratch_total ) );
+    for( size_t i = 0, t = 0; i < (size_t)n; i++ )
     {
         const x264hip_me_request &q = reqs[i];
         MfReq<T> &r = table[i];
@@ -1409,7 +1411,8 @@ static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request 
             r.spel_min[k] = q.spel_min[k]; r.spel_max[k] = q.spel_max[k];
         }
         r.cost_mv = cost_mv;
-        r.scratch = q.me_method == 4 ? scratch + scratch_bytes * t++ : nullptr;
+        r.scratch = q.me_method == 4 ? scratch + t : nullptr;
+        if( q.me_method == 4 ) t += tesa_bytes( q.me_range );
         n_mvc[i] = q.n_mvc;
         memcpy( &mvc[(size_t)i * MF_MVC_MAX * 2], q.mvc, sizeof( q.mvc ) );
     }
