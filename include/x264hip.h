@@ -339,6 +339,9 @@ typedef struct x264hip_backend
      * row_satds output of x264hip_get_lowres_costs */
     int (*frame_cost_recalculate)( void *user, int slot_b, int dist_p0, int dist_p1, int use_aq_offsets, int *score );
     int (*get_row_satds)( void *user, int slot, int dist_p0, int dist_p1, int *row_satds );
+    /* frame_put with the 4:2:0 chroma planes (contract of x264hip_frame_put's cb / cr / cstride): needed by
+     * x264hip_lookahead_put_picture, may be NULL otherwise */
+    int (*frame_put_yuv)( void *user, int slot, const void *luma, int stride, const void *cb, const void *cr, int cstride, int is_device );
 } x264hip_backend;
 
 typedef struct x264hip_la_frame
@@ -366,6 +369,10 @@ int  x264hip_lookahead_put_frame( x264hip_lookahead *la, const void *luma, int s
 int  x264hip_lookahead_put_frames( x264hip_lookahead *la, int n, const void *const *luma_dev, int stride );
 /* One call = the lookahead part of one x264_encoder_encode call.  flush != 0 once the input has ended.
  * *got = 1 and *out filled when a frame leaves the lookahead (coded order), 0 while the delay fills or at the end. */
+/* The whole 4:2:0 picture: adaptive quantisation measures the AC energy of luma AND chroma (ac_energy_mb, ratecontrol.c:258-276), so
+ * the chroma planes are needed for the reference's i_inv_qscale_factor / f_qp_offset on real content (luma-only input is treated as
+ * flat chroma: no chroma energy).  planes = { Y, Cb, Cr }, strides in samples, host or device pointers (is_device). */
+int  x264hip_lookahead_put_picture( x264hip_lookahead *la, const void *const planes[3], const int strides[3], int is_device, int forced_type, int64_t pts );
 /* same with the picture's time stamp (x264_picture_t.i_pts, in timebase units); x264hip_lookahead_put_frame uses the frame number */
 int  x264hip_lookahead_put_frame_pts( x264hip_lookahead *la, const void *luma, int stride, int is_device, int forced_type, int64_t pts );
 int  x264hip_lookahead_get_frame( x264hip_lookahead *la, int flush, x264hip_la_frame *out, int *got );

@@ -60,11 +60,15 @@ class Ref:
         self.lib.rh_cost_mv(self.ctx, _ptr(out), out.size)
         return out
 
-    def add_frame(self, luma):
+    def add_frame(self, luma, cb=None, cr=None):
+        """cb / cr: the I420 chroma planes [(H+1)//2, (W+1)//2] (default: mid-grey, i.e. no chroma energy in AQ)"""
         luma = np.ascontiguousarray(luma, dtype=self.dtype)
         assert luma.shape == (self.height, self.width)
         self.lib.rh_add_frame.argtypes = [C.c_void_p] * 4
-        r = self.lib.rh_add_frame(self.ctx, _ptr(luma), None, None)
+        if cb is not None:
+            cb = np.ascontiguousarray(cb, dtype=self.dtype); cr = np.ascontiguousarray(cr, dtype=self.dtype)
+            assert cb.shape == cr.shape == ((self.height + 1) // 2, (self.width + 1) // 2)
+        r = self.lib.rh_add_frame(self.ctx, _ptr(luma), _ptr(cb), _ptr(cr))
         assert r >= 0
         self.n_frames = r + 1
         return r
@@ -122,12 +126,17 @@ class Ref:
         assert r == 0
         return lc, rows, tuple(int(x) for x in summ)
 
-    def lookahead_run(self, luma_frames, with_qp_offsets=False, forced_types=None, with_vbv=False, rc_cells=None, pts=None):
+    def lookahead_run(self, luma_frames, with_qp_offsets=False, forced_types=None, with_vbv=False, rc_cells=None, pts=None, chroma=None):
         """rc_cells: [n, 2] (b-p0, p1-b) per OUTPUT index -> also runs the real x264_rc_analyse_slice on every leaving frame
         (out["rc"][k] = [cost, i_row_satd..., i_row_satds[0][0]...])."""
         """luma_frames: [n, H, W]; returns dict(idx, type, cost, cost_aq, intra_mbs, seconds, seconds_prep[, qp_offset])."""
         fr = np.ascontiguousarray(luma_frames, dtype=self.dtype)
         n = fr.shape[0]
+        luma_only = 1
+        if chroma is not None:  # (cb, cr): [n, (H+1)//2, (W+1)//2] each -> one Y, Cb, Cr record per frame
+            cb, cr = (np.ascontiguousarray(c, dtype=self.dtype).reshape(n, -1) for c in chroma)
+            fr = np.ascontiguousarray(np.concatenate([fr.reshape(n, -1), cb, cr], axis=1))
+            luma_only = 0
         qp = np.zeros((n, self.n_mb), np.float32) if with_qp_offsets else None
         prop = np.zeros((n, self.n_mb), np.uint16) if with_qp_offsets else None
         self.lib.rh_set_qp_dump.argtypes = [C.c_void_p]
@@ -159,7 +168,7 @@ class Ref:
         sec_prep = C.c_double(0)
         f = self.lib.rh_lookahead_run
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.POINTER(C.c_double)] * 2
-        r = f(self.ctx, _ptr(fr), n, 1, _ptr(idx), _ptr(typ), _ptr(cost), _ptr(cost_aq), _ptr(imbs),
+        r = f(self.ctx, _ptr(fr), n, luma_only, _ptr(idx), _ptr(typ), _ptr(cost), _ptr(cost_aq), _ptr(imbs),
               C.byref(sec), C.byref(sec_prep))
         self.lib.rh_set_forced_types(None)
         self.lib.rh_set_pts(None)

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from oracle import refharness  # noqa: E402
 from tests.common import clip, nearest_ref_cells  # noqa: E402
-from x264_amd.synth import make_clip  # noqa: E402
+from x264_amd.synth import make_chroma, make_clip  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 
@@ -55,6 +55,8 @@ LOOKAHEAD_CASES_R2 = {
                 dict(seed=21, scene_cuts=(23,), pan=(4, 2), fade=(30, 8, 0.6, 10)), 44),
     "vbv_no_mbtree": ("fast", "vbv-bufsize=200,vbv-maxrate=400,mbtree=0,b-adapt=2", dict(vbv_bufsize=200, vbv_maxrate=400, mb_tree=0, b_adapt=2),
                       8, 176, 144, dict(seed=22, scene_cuts=(15,)), 40),
+    # whole 4:2:0 pictures: the chroma planes (x264_amd.synth.make_chroma, same seed as the luma clip) enter adaptive quantisation
+    "chroma_aq": ("medium", "", dict(_chroma=1), 8, 352, 288, dict(seed=23, scene_cuts=(19,), pan=(4, 1)), 40),
     "bands_auto_720p": ("veryslow", "threads=24,sync-lookahead=0,lookahead-threads=auto", dict(threads=24), 8, 1280, 720, dict(seed=20, pan=(9, 4)), 20),
 }
 
@@ -75,7 +77,8 @@ def gen_lookahead(only=None):
             cells = np.array(nearest_ref_cells(first["idx"], first["type"]), np.int32)
             r.close()
             r = refharness.Ref(W, H, preset, opts=opts, bit_depth=depth)
-        ref = r.lookahead_run(frames, with_qp_offsets=True, with_vbv=vbv, rc_cells=cells)
+        chroma = make_chroma(W, H, nf, seed=ckw.get("seed", 1), bit_depth=depth) if over.get("_chroma") else None
+        ref = r.lookahead_run(frames, with_qp_offsets=True, with_vbv=vbv, rc_cells=cells, chroma=chroma)
         nb = r.cfg["bframes"] + 2
         extra = {}
         if vbv:  # what VBV rate control reads: planned types / costs, and per frame the result of the real x264_rc_analyse_slice

@@ -32,7 +32,7 @@ class OracleBackend:
                                   lib.PREFETCH_FN(self._prefetch) if speculative else lib.PREFETCH_FN(0),
                                   lib.MBTREE_FN(self._mbtree), lib.QP_OFFSETS_FN(self._qp), lib.PUT_BATCH_FN(0),
                                   lib.PREFETCH_WEIGHTS_FN(self._prefetch_weights) if speculative else lib.PREFETCH_WEIGHTS_FN(0),
-                                  lib.RECALC_FN(self._recalc), lib.ROW_SATDS_FN(self._rows))
+                                  lib.RECALC_FN(self._recalc), lib.ROW_SATDS_FN(self._rows), lib.FRAME_PUT_YUV_FN(self._put_yuv))
 
     def _prefetch(self, user, slots, numbers, n):
         return 0
@@ -42,13 +42,21 @@ class OracleBackend:
             self.announced.add((sf[i], sr[i], w[i].on, w[i].scale, w[i].denom, w[i].offset))
         return 0
 
-    def _put(self, user, slot, luma, stride, is_device):
-        c = self.cfg
+    def _plane(self, addr, stride, w, h):
         dt = self.o.dtype
-        buf = (C.c_char * (stride * c["height"] * np.dtype(dt).itemsize)).from_address(luma)
-        img = np.frombuffer(buf, dtype=dt).reshape(c["height"], stride)[:, :c["width"]].copy()
+        buf = (C.c_char * (stride * h * np.dtype(dt).itemsize)).from_address(addr)
+        return np.frombuffer(buf, dtype=dt).reshape(h, stride)[:, :w].copy()
+
+    def _put_yuv(self, user, slot, luma, stride, cb, cr, cstride, is_device):
+        c = self.cfg
+        cw, ch = (c["width"] + 1) // 2, (c["height"] + 1) // 2
+        return self._put(user, slot, luma, stride, is_device, self._plane(cb, cstride, cw, ch), self._plane(cr, cstride, cw, ch))
+
+    def _put(self, user, slot, luma, stride, is_device, cb=None, cr=None):
+        c = self.cfg
+        img = self._plane(luma, stride, c["width"], c["height"])
         pl = self.o.lowres_init(self.ocfg, img)
-        inv, qp, s, ssd = self.o.aq_frame(img, self.ocfg.mb_w, self.ocfg.mb_h, c["aq_mode"], c["aq_strength"])
+        inv, qp, s, ssd = self.o.aq_frame(img, self.ocfg.mb_w, self.ocfg.mb_h, c["aq_mode"], c["aq_strength"], cb, cr)
         n = self.ocfg.mb_w * self.ocfg.mb_h
         self.slots[slot] = dict(planes=pl, inv=inv, sum=s, ssd=ssd, intra=self.o.intra_costs(self.ocfg, pl), fields={}, maps={}, rows={},
                                 prop=np.zeros(n, np.uint16), qp_aq=qp.copy(), qp=qp.copy())

@@ -13,7 +13,7 @@ from tests.common import clip
 from tests.golden.make_golden import EVAL_SEQ, LOOKAHEAD_CASES, LOOKAHEAD_CASES_R2
 from tests.oracle_backend import OracleBackend
 from x264_amd import lib
-from x264_amd.synth import make_clip
+from x264_amd.synth import make_chroma, make_clip
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -167,11 +167,13 @@ def test_host_lookahead_vs_golden(name):
     preset, opts, over, depth, W, H, ckw, nf = {**LOOKAHEAD_CASES, **LOOKAHEAD_CASES_R2}[name]
     z = np.load(os.path.join(GOLD, "lookahead_%s.npz" % name))
     frames = make_clip(W, H, nf, bit_depth=depth, **ckw)
+    over = dict(over)
+    chroma = make_chroma(W, H, nf, seed=ckw.get("seed", 1), bit_depth=depth) if over.pop("_chroma", 0) else None
     cfg = lib.la_config(W, H, preset, bit_depth=depth, **over)
     be = OracleBackend(cfg)
     la = lib.Lookahead(cfg, backend=be.struct)
     try:
-        outs = la.run(frames, qp_offsets=True, vbv=bool(cfg["vbv"]))
+        outs = la.run(frames, qp_offsets=True, vbv=bool(cfg["vbv"]), chroma=chroma)
     finally:
         la.close()
     check_lookahead_outputs(outs, z, cfg["bframes"] + 2, check_qp=bool(cfg["aq_mode"]))

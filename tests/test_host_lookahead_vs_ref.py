@@ -482,3 +482,38 @@ def test_vfr_input_durations(preset, opts, over, stamps, paced):
     for k, o in enumerate(outs):
         assert np.array_equal(np.array(o.cost_est)[:nb, :nb], ref["cost"][k][:nb, :nb]), o.frame
         assert np.array_equal(o.qp_offset, ref["qp_offset"][k]), ("f_qp_offset", o.frame, o.type)
+
+
+@pytest.mark.parametrize("preset,opts,over,depth,W,H", [
+    ("medium", "", {}, 8, 176, 144),
+    ("medium", "aq-mode=2", dict(aq_mode=2), 10, 176, 144),
+    ("fast", "aq-mode=3,mbtree=0", dict(aq_mode=3, mb_tree=0), 8, 100, 70),
+])
+def test_chroma_planes_enter_adaptive_quant(preset, opts, over, depth, W, H):
+    """x264hip_lookahead_put_picture: adaptive quantisation adds the AC energy of Cb and Cr to the luma energy of every macroblock
+    (ac_energy_mb, ratecontrol.c:258-276), so i_inv_qscale_factor, the AQ-weighted costs, MB-tree and f_qp_offset all depend on the
+    chroma planes.  Against the reference fed with the same 4:2:0 pictures (and the reference fed with grey chroma differs)."""
+    from x264_amd.synth import make_chroma
+    nf = 40
+    frames = make_clip(W, H, nf, seed=9, bit_depth=depth, scene_cuts=(17,), pan=(3, 1))
+    chroma = make_chroma(W, H, nf, seed=9, bit_depth=depth)
+    r = refharness.Ref(W, H, preset, opts=opts, bit_depth=depth)
+    ref = r.lookahead_run(frames, with_qp_offsets=True, chroma=chroma)
+    r.close()
+    r = refharness.Ref(W, H, preset, opts=opts, bit_depth=depth)
+    grey = r.lookahead_run(frames, with_qp_offsets=True)
+    r.close()
+    assert not np.array_equal(ref["qp_offset"], grey["qp_offset"])
+    cfg = lib.la_config(W, H, preset, bit_depth=depth, **over)
+    la = lib.Lookahead(cfg, backend=OracleBackend(cfg).struct, max_frames=nf + 4)
+    try:
+        outs = la.run(frames, qp_offsets=True, chroma=chroma)
+    finally:
+        la.close()
+    assert [o.frame for o in outs] == list(ref["idx"]) and [o.type for o in outs] == list(ref["type"])
+    nb = cfg["bframes"] + 2
+    for k, o in enumerate(outs):
+        assert np.array_equal(np.array(o.cost_est)[:nb, :nb], ref["cost"][k][:nb, :nb])
+        m = ref["cost"][k][:nb, :nb] >= 0
+        assert np.array_equal(np.array(o.cost_est_aq)[:nb, :nb][m], ref["cost_aq"][k][:nb, :nb][m])
+        assert np.array_equal(o.qp_offset, ref["qp_offset"][k])

@@ -172,3 +172,26 @@ def test_frame_cost_recalculate(depth):
                 assert got == want and np.array_equal(rows, rows_ref), (p0, p1, b, variant)
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_adaptive_quant_with_chroma(depth):
+    """x264_adaptive_quant_frame on whole 4:2:0 pictures (luma + Cb + Cr energy, ratecontrol.c:258-276; aq-mode 1, 2, 3; non-mod16
+    sizes): i_inv_qscale_factor and the luma sum / ssd the weight analysis reads."""
+    if not refharness.available(depth):
+        pytest.skip("no reference build for this depth")
+    from x264_amd.synth import make_chroma, make_clip
+    o = Oracle(depth)
+    for (W, H) in ((176, 144), (100, 70)):
+        y = make_clip(W, H, 1, seed=5, bit_depth=depth, noise=20)[0]
+        cb, cr = (c[0] for c in make_chroma(W, H, 1, seed=5, bit_depth=depth))
+        for mode, strength in ((1, 1.0), (2, 1.0), (3, 0.6)):
+            r = refharness.Ref(W, H, "medium", opts="aq-mode=%d,aq-strength=%g" % (mode, strength), bit_depth=depth)
+            try:
+                r.add_frame(y, cb, cr)
+                iq, _, ss = r.frame_stats(0)
+            finally:
+                r.close()
+            iq_o, _, s, ssd = o.aq_frame(y, (W + 15) // 16, (H + 15) // 16, mode, strength, cb, cr)
+            assert np.array_equal(iq, iq_o), (W, H, mode)
+            assert (s, ssd) == ss

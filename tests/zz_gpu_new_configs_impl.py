@@ -11,7 +11,7 @@ import pytest
 from tests.golden.make_golden import LOOKAHEAD_CASES_R2
 from tests.test_golden import GOLD, check_lookahead_outputs
 from x264_amd import lib
-from x264_amd.synth import make_clip
+from x264_amd.synth import make_chroma, make_clip
 
 pytestmark = pytest.mark.gpu
 
@@ -22,10 +22,12 @@ def test_lookahead_vs_golden_new_configs(name, paced):
     preset, opts, over, depth, W, H, ckw, nf = LOOKAHEAD_CASES_R2[name]
     z = np.load(os.path.join(GOLD, "lookahead_%s.npz" % name))
     frames = make_clip(W, H, nf, bit_depth=depth, **ckw)
+    over = dict(over)
+    chroma = make_chroma(W, H, nf, seed=ckw.get("seed", 1), bit_depth=depth) if over.pop("_chroma", 0) else None
     cfg = lib.la_config(W, H, preset, bit_depth=depth, **over)
     la = lib.Lookahead(cfg, max_frames=0 if paced else nf + 4)
     try:
-        outs = la.run(frames, paced=paced, qp_offsets=True, vbv=bool(cfg["vbv"]))
+        outs = la.run(frames, paced=paced, qp_offsets=True, vbv=bool(cfg["vbv"]), chroma=chroma)
     finally:
         la.close()
     check_lookahead_outputs(outs, z, cfg["bframes"] + 2, check_qp=bool(cfg["aq_mode"]))
@@ -329,3 +331,35 @@ def test_frame_filter(depth):
     ref = z["integral"]
     assert np.array_equal(gi[1:ph - 8, :pw - 8], ref[1:ph - 8, :pw - 8])
     assert np.array_equal(gi[ph + 1:2 * ph - 8, :pw - 8], ref[ph + 1:2 * ph - 8, :pw - 8])
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_frame_put_with_chroma(depth):
+    """x264hip_frame_put with the 4:2:0 chroma planes -- from host buffers (staged like the luma) and from device memory -- against
+    the oracle's adaptive quantisation of the whole picture (pinned against x264_adaptive_quant_frame in
+    tests/test_oracle_vs_ref.py::test_adaptive_quant_with_chroma): aq-mode 1, 2, 3, a non-mod16 size."""
+    import ctypes as C
+    import torch
+    from oracle.oraclelib import Oracle
+    o = Oracle(depth)
+    vdt = np.uint8 if depth == 8 else np.int16
+    for (W, H) in ((352, 288), (100, 70)):
+        y = make_clip(W, H, 1, seed=5, bit_depth=depth, noise=20)[0]
+        cb, cr = (np.ascontiguousarray(c[0]) for c in make_chroma(W, H, 1, seed=5, bit_depth=depth))
+        cw = (W + 1) // 2
+        for mode, strength in ((1, 1.0), (2, 1.0), (3, 0.6)):
+            want_inv, want_qp = o.aq_frame(y, (W + 15) // 16, (H + 15) // 16, mode, strength, cb, cr)[:2]
+            ctx = lib.Context(W, H, bit_depth=depth, aq_mode=mode, aq_strength=strength, max_frames=4)
+            try:
+                L = ctx.L
+                L.x264hip_frame_put.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+                yy = np.ascontiguousarray(y, o.dtype)
+                assert L.x264hip_frame_put(ctx.h, 0, yy.ctypes.data, W, 0, cb.ctypes.data, cr.ctypes.data, cw, None) == 0   # host buffers
+                dy, dcb, dcr = (torch.from_numpy(a.view(vdt)).cuda() for a in (yy, cb, cr))
+                torch.cuda.synchronize()
+                assert L.x264hip_frame_put(ctx.h, 1, dy.data_ptr(), W, 1, dcb.data_ptr(), dcr.data_ptr(), cw, None) == 0    # device memory
+                for slot in (0, 1):
+                    assert np.array_equal(ctx.qp_offsets(slot), want_qp), (W, H, mode, slot)
+                    assert np.array_equal(ctx.inv_qscale(slot), want_inv), (W, H, mode, slot)
+            finally:
+                ctx.close()

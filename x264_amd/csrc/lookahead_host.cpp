@@ -959,6 +959,10 @@ static int dev_mbtree( void *u, const x264hip_mbtree_op *ops, int n ) { return x
 static int dev_qp_offsets( void *u, int slot, float *q ) { return x264hip_get_qp_offsets( (x264hip_ctx *)u, slot, q ); }
 static int dev_recalc( void *u, int b, int d0, int d1, int aq, int *score ) { return x264hip_frame_cost_recalculate( (x264hip_ctx *)u, b, d0, d1, aq, score ); }
 static int dev_row_satds( void *u, int slot, int d0, int d1, int *rows ) { return x264hip_get_lowres_costs( (x264hip_ctx *)u, slot, d0, d1, nullptr, rows ); }
+static int dev_frame_put_yuv( void *u, int slot, const void *luma, int stride, const void *cb, const void *cr, int cstride, int is_device )
+{
+    return x264hip_frame_put( (x264hip_ctx *)u, slot, luma, stride, is_device, cb, cr, cstride, nullptr );
+}
 static int dev_put_batch( void *u, int n, const int *slots, const void *const *luma, int stride )
 {
     return x264hip_frame_put_batch( (x264hip_ctx *)u, n, slots, luma, stride );
@@ -1044,7 +1048,7 @@ extern "C" int x264hip_lookahead_open( x264hip_lookahead **out, int device, cons
     x264hip_ctx *ctx = nullptr;
     int rc = x264hip_open( &ctx, device, &p.dev );
     if( rc ) return rc;
-    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch, dev_mbtree, dev_qp_offsets, dev_put_batch, dev_prefetch_weights, dev_recalc, dev_row_satds };
+    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch, dev_mbtree, dev_qp_offsets, dev_put_batch, dev_prefetch_weights, dev_recalc, dev_row_satds, dev_frame_put_yuv };
     rc = x264hip_lookahead_open_backend( out, &p, &be );
     if( rc ) { x264hip_close( ctx ); return rc; }
     ( *out )->L.ctx = ctx;
@@ -1143,7 +1147,18 @@ extern "C" int x264hip_lookahead_put_frame( x264hip_lookahead *la, const void *l
 
 extern "C" int x264hip_lookahead_put_frame_pts( x264hip_lookahead *la, const void *luma, int stride, int is_device, int forced_type, int64_t pts )
 {
-    if( !la || !luma ) return X264HIP_EINVAL;
+    const void *planes[3] = { luma, nullptr, nullptr };
+    const int strides[3] = { stride, 0, 0 };
+    return x264hip_lookahead_put_picture( la, planes, strides, is_device, forced_type, pts );
+}
+
+extern "C" int x264hip_lookahead_put_picture( x264hip_lookahead *la, const void *const planes[3], const int strides[3], int is_device, int forced_type, int64_t pts )
+{
+    if( !la || !planes || !strides || !planes[0] || ( !planes[1] ) != ( !planes[2] ) ) return X264HIP_EINVAL;
+    const void *luma = planes[0];
+    const int stride = strides[0];
+    const bool with_chroma = planes[1] != nullptr;
+    if( with_chroma && ( !la->L.be.frame_put_yuv || strides[1] != strides[2] ) ) return X264HIP_EINVAL;
     Lookahead &L = la->L;
     ScopeNs tm_api( L.stats[7] );
     if( L.err ) return L.err;
@@ -1151,7 +1166,8 @@ extern "C" int x264hip_lookahead_put_frame_pts( x264hip_lookahead *la, const voi
     LaFrame *f = new_frame( L, forced_type );
     f->pts = pts;
     f->f_duration = L.f_duration;
-    int rc = L.be.frame_put( L.be.user, f->slot, luma, stride, is_device );
+    int rc = with_chroma ? L.be.frame_put_yuv( L.be.user, f->slot, luma, stride, planes[1], planes[2], strides[1], is_device )
+                         : L.be.frame_put( L.be.user, f->slot, luma, stride, is_device );
     if( rc )
     {
         L.free_slots.push_back( f->slot );

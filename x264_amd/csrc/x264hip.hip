@@ -129,6 +129,7 @@ struct x264hip_ctx
     std::vector<WEntry> wcache;      // [WCAP], entry 0 unused
     int wcache_next = 1;
     char *staging = nullptr;         // pinned luma staging
+    char *chroma_staging = nullptr, *chroma_dev = nullptr; // host-buffer ingest with chroma: pinned + device copies of Cb and Cr (allocated on first use)
     size_t staging_bytes = 0;
     std::vector<char *> wplanes;     // weighted plane pool
     std::vector<int> wplane_owner;
@@ -230,6 +231,8 @@ static void free_all( x264hip_ctx *ctx )
     (void)hipHostFree( ctx->cell_acc_host );
     (void)hipFree( ctx->wcost_dev );
     (void)hipHostFree( ctx->wcost_host ); (void)hipHostFree( ctx->staging );
+    if( ctx->chroma_staging ) (void)hipHostFree( ctx->chroma_staging );
+    if( ctx->chroma_dev ) (void)hipFree( ctx->chroma_dev );
     for( auto e : ctx->prof_ev ) (void)hipEventDestroy( e );
     if( ctx->ev_start ) (void)hipEventDestroy( ctx->ev_start );
     if( ctx->ev_stop ) (void)hipEventDestroy( ctx->ev_stop );
@@ -488,10 +491,30 @@ extern "C" int x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, 
         HIPCK( hipMemcpyAsync( s.luma, ctx->staging, ctx->staging_bytes, hipMemcpyHostToDevice, ctx->stream ) );
         src = s.luma;
         src_stride = p.width;
+        if( cb && cr )
+        {
+            // the two chroma planes (4:2:0) follow through their own staging pair; the stream was drained above, so the device copy
+            // of the previous frame's chroma has been consumed
+            const int cw = ( p.width + 1 ) >> 1, ch = ( p.height + 1 ) >> 1;
+            const size_t crow = (size_t)cw * ctx->psz, cplane = crow * ch;
+            if( cstride < cw ) return X264HIP_EINVAL;
+            if( !ctx->chroma_staging )
+            {
+                HIPCK( hipHostMalloc( &ctx->chroma_staging, 2 * cplane ) );
+                HIPCK( hipMalloc( &ctx->chroma_dev, 2 * cplane ) );
+            }
+            for( int y = 0; y < ch; y++ )
+            {
+                memcpy( ctx->chroma_staging + (size_t)y * crow, (const char *)cb + (size_t)y * cstride * ctx->psz, crow );
+                memcpy( ctx->chroma_staging + cplane + (size_t)y * crow, (const char *)cr + (size_t)y * cstride * ctx->psz, crow );
+            }
+            HIPCK( hipMemcpyAsync( ctx->chroma_dev, ctx->chroma_staging, 2 * cplane, hipMemcpyHostToDevice, ctx->stream ) );
+            cb = ctx->chroma_dev; cr = ctx->chroma_dev + cplane; cstride = cw;
+        }
     }
     const int aq_on = p.aq_mode >= 1 && p.aq_strength != 0.f && !inv_qscale;
-    // chroma planes take part in the AQ energy only when the caller supplies device pointers for them
-    const PutDesc d = make_put_desc( ctx, s, src, src_stride, is_device ? cb : nullptr, is_device ? cr : nullptr, cstride, aq_on );
+    // the chroma planes take part in the AQ energy (ac_energy_mb, ratecontrol.c:258-276) when the caller supplies them
+    const PutDesc d = make_put_desc( ctx, s, src, src_stride, cb, cr, cstride, aq_on );
     int rc = p.bit_depth == 8 ? launch_ingest_t<uint8_t>( ctx, nullptr, d, 1 ) : launch_ingest_t<uint16_t>( ctx, nullptr, d, 1 );
     if( rc ) return rc;
     if( inv_qscale )

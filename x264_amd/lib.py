@@ -327,6 +327,7 @@ PREFETCH_WEIGHTS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_in
 
 RECALC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int))
 ROW_SATDS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int))
+FRAME_PUT_YUV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
 
 
 class Backend(C.Structure):
@@ -334,7 +335,7 @@ class Backend(C.Structure):
                 ("weight_cost", WEIGHT_COST_FN), ("frame_cost", FRAME_COST_FN), ("prefetch", PREFETCH_FN),
                 ("mbtree", MBTREE_FN), ("get_qp_offsets", QP_OFFSETS_FN), ("frame_put_batch", PUT_BATCH_FN),
                 ("prefetch_weight_costs", PREFETCH_WEIGHTS_FN), ("frame_cost_recalculate", RECALC_FN),
-                ("get_row_satds", ROW_SATDS_FN)]
+                ("get_row_satds", ROW_SATDS_FN), ("frame_put_yuv", FRAME_PUT_YUV_FN)]
 
 
 LOOKAHEAD_MAX = 250
@@ -573,6 +574,7 @@ class Lookahead:
         self.dtype = np.uint8 if cfg["bit_depth"] == 8 else np.uint16
         L.x264hip_lookahead_ctx.restype = C.c_void_p
         self.delay = L.x264hip_lookahead_delay(self.h)
+        self._n_put = 0
 
     def close(self):
         if self.h:
@@ -581,11 +583,27 @@ class Lookahead:
 
     def reset(self):
         _ck(self.L.x264hip_lookahead_reset(self.h), "lookahead_reset")
+        self._n_put = 0
 
     def ctx_handle(self):
         return C.c_void_p(self.L.x264hip_lookahead_ctx(self.h))
 
+    def put_picture(self, y, cb, cr, forced_type=0, pts=None, device=False, strides=None):
+        """the whole 4:2:0 picture (x264hip_lookahead_put_picture): numpy planes, or device addresses with strides=(ys, cs)"""
+        self.L.x264hip_lookahead_put_picture.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64]
+        if device:
+            ptrs, st = (C.c_void_p * 3)(y, cb, cr), (C.c_int * 3)(strides[0], strides[1], strides[1])
+        else:
+            y, cb, cr = (np.ascontiguousarray(a, self.dtype) for a in (y, cb, cr))
+            ptrs = (C.c_void_p * 3)(y.ctypes.data, cb.ctypes.data, cr.ctypes.data)
+            st = (C.c_int * 3)(y.shape[1], cb.shape[1], cr.shape[1])
+            self._keep_pic = (y, cb, cr)
+        ts = int(pts) if pts is not None else self._n_put
+        _ck(self.L.x264hip_lookahead_put_picture(self.h, ptrs, st, int(device), forced_type, ts), "lookahead_put_picture")
+        self._n_put += 1
+
     def put(self, luma=None, device_ptr=None, stride=None, forced_type=0, pts=None):
+        self._n_put += 1
         if pts is not None:
             self.L.x264hip_lookahead_put_frame_pts.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64]
             if device_ptr is not None:
@@ -634,7 +652,7 @@ class Lookahead:
         _ck(self.L.x264hip_lookahead_stats(self.h, _p(out), 8), "lookahead_stats")
         return out
 
-    def run(self, frames=None, device_ptrs=None, stride=None, paced=True, qp_offsets=False, forced_types=None, vbv=False, pts=None):
+    def run(self, frames=None, device_ptrs=None, stride=None, paced=True, qp_offsets=False, forced_types=None, vbv=False, pts=None, chroma=None):
         """Feed a whole clip.  paced=True interleaves put/get exactly like x264_encoder_encode; paced=False puts
         every frame first (deep prefetch) -- results are identical, only the batching differs."""
         outs = []
@@ -647,7 +665,9 @@ class Lookahead:
         for i in range(n_loop):
             ft = int(forced_types[i]) if forced_types is not None else 0
             ts = None if pts is None else int(pts[i])
-            if frames is not None:
+            if chroma is not None:
+                self.put_picture(frames[i], chroma[0][i], chroma[1][i], forced_type=ft, pts=ts)
+            elif frames is not None:
                 self.put(frames[i], forced_type=ft, pts=ts)
             else:
                 self.put(device_ptr=device_ptrs[i], stride=stride, forced_type=ft, pts=ts)

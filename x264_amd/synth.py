@@ -53,3 +53,18 @@ def make_clip(width, height, n_frames, seed=1, bit_depth=8, scene_cuts=(), fade=
         img = np.clip(np.rint(img * scale), 0, maxv)
         frames[i] = img.astype(frames.dtype)
     return frames
+
+
+def make_chroma(width, height, n_frames, seed=0, bit_depth=8):
+    """Deterministic Cb / Cr planes [n, (H+1)//2, (W+1)//2] for a 4:2:0 clip: a random texture that drifts frame by frame plus
+    per-frame noise of different strength in the two planes, so that the chroma AC energy of a macroblock (which adaptive
+    quantisation adds to the luma energy, ratecontrol.c:258-276) varies over the picture and over time."""
+    rng = np.random.default_rng(1000 + seed)
+    maxv = (1 << bit_depth) - 1
+    dt = np.uint8 if bit_depth == 8 else np.uint16
+    cw, ch = (width + 1) // 2, (height + 1) // 2
+    base = rng.integers(0, maxv + 1, size=(ch, cw))
+    smooth = (base + np.roll(base, 1, 0) + np.roll(base, 1, 1) + np.roll(base, (1, 1), (0, 1))) // 4
+    cb = np.stack([np.clip(np.roll(smooth, i, axis=1) + rng.integers(-9, 10, size=(ch, cw)), 0, maxv) for i in range(n_frames)])
+    cr = np.stack([np.clip(np.roll(base, 2 * i, axis=0) // 2 + maxv // 4 + rng.integers(-30, 31, size=(ch, cw)), 0, maxv) for i in range(n_frames)])
+    return cb.astype(dt), cr.astype(dt)
