@@ -122,6 +122,9 @@ int  x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, int stride
 /* The same for n frames whose luma already sits in device memory (all with the same stride): one launch per ingest
  * kernel instead of one per frame. */
 int  x264hip_frame_put_batch( x264hip_ctx *ctx, int n, const int *slots, const void *const *luma_dev, int stride );
+/* same with the 4:2:0 chroma planes of every frame (device pointers; both arrays NULL = luma only) */
+int  x264hip_frame_put_batch_yuv( x264hip_ctx *ctx, int n, const int *slots, const void *const *luma_dev, int stride,
+                                  const void *const *cb_dev, const void *const *cr_dev, int cstride );
 /* i_pixel_sum[0] / i_pixel_ssd[0] of the frame (ratecontrol.c:225-234,405-414) */
 int  x264hip_frame_stats( x264hip_ctx *ctx, int slot, uint64_t *pixel_sum, uint64_t *pixel_ssd );
 
@@ -342,6 +345,8 @@ typedef struct x264hip_backend
     /* frame_put with the 4:2:0 chroma planes (contract of x264hip_frame_put's cb / cr / cstride): needed by
      * x264hip_lookahead_put_picture, may be NULL otherwise */
     int (*frame_put_yuv)( void *user, int slot, const void *luma, int stride, const void *cb, const void *cr, int cstride, int is_device );
+    int (*frame_put_batch_yuv)( void *user, int n, const int *slots, const void *const *luma_dev, int stride, const void *const *cb_dev,
+                                const void *const *cr_dev, int cstride ); /* may be NULL: the pictures go in one by one */
 } x264hip_backend;
 
 typedef struct x264hip_la_frame
@@ -367,6 +372,10 @@ int  x264hip_lookahead_delay( x264hip_lookahead *la );       /* h->frames.i_dela
 int  x264hip_lookahead_put_frame( x264hip_lookahead *la, const void *luma, int stride, int is_device, int forced_type );
 /* n device-resident frames at once (display order, all X264_TYPE_AUTO): batched ingest when the backend supports it */
 int  x264hip_lookahead_put_frames( x264hip_lookahead *la, int n, const void *const *luma_dev, int stride );
+/* batch form of x264hip_lookahead_put_picture for device-resident 4:2:0 pictures: cb_dev / cr_dev NULL = luma only; types (forced
+ * picture types) and pts may be NULL (AUTO / the frame numbers) */
+int  x264hip_lookahead_put_pictures( x264hip_lookahead *la, int n, const void *const *luma_dev, int stride, const void *const *cb_dev,
+                                     const void *const *cr_dev, int cstride, const int *types, const int64_t *pts );
 /* One call = the lookahead part of one x264_encoder_encode call.  flush != 0 once the input has ended.
  * *got = 1 and *out filled when a frame leaves the lookahead (coded order), 0 while the delay fills or at the end. */
 /* The whole 4:2:0 picture: adaptive quantisation measures the AC energy of luma AND chroma (ac_energy_mb, ratecontrol.c:258-276), so

@@ -32,7 +32,7 @@ class OracleBackend:
                                   lib.PREFETCH_FN(self._prefetch) if speculative else lib.PREFETCH_FN(0),
                                   lib.MBTREE_FN(self._mbtree), lib.QP_OFFSETS_FN(self._qp), lib.PUT_BATCH_FN(0),
                                   lib.PREFETCH_WEIGHTS_FN(self._prefetch_weights) if speculative else lib.PREFETCH_WEIGHTS_FN(0),
-                                  lib.RECALC_FN(self._recalc), lib.ROW_SATDS_FN(self._rows), lib.FRAME_PUT_YUV_FN(self._put_yuv))
+                                  lib.RECALC_FN(self._recalc), lib.ROW_SATDS_FN(self._rows), lib.FRAME_PUT_YUV_FN(self._put_yuv), lib.PUT_BATCH_YUV_FN(0))
 
     def _prefetch(self, user, slots, numbers, n):
         return 0

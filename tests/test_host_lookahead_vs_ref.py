@@ -517,3 +517,36 @@ def test_chroma_planes_enter_adaptive_quant(preset, opts, over, depth, W, H):
         m = ref["cost"][k][:nb, :nb] >= 0
         assert np.array_equal(np.array(o.cost_est_aq)[:nb, :nb][m], ref["cost_aq"][k][:nb, :nb][m])
         assert np.array_equal(o.qp_offset, ref["qp_offset"][k])
+
+
+def test_put_pictures_batch_equals_one_by_one():
+    """x264hip_lookahead_put_pictures (all pictures of a clip in one call, with chroma, forced types and time stamps) gives what
+    x264hip_lookahead_put_picture gives picture by picture."""
+    from x264_amd.synth import make_chroma
+    W, H, nf = 176, 144, 36
+    frames = make_clip(W, H, nf, seed=61, scene_cuts=(15,), pan=(2, 2))
+    cb, cr = make_chroma(W, H, nf, seed=61)
+    types = np.zeros(nf, np.int32); types[10] = 1; types[20] = 5
+    pts = np.cumsum(np.random.default_rng(2).choice([1, 2, 3], size=nf)).astype(np.int64)
+    cfg = lib.la_config(W, H, "medium", vfr_input=1)
+    res = []
+    for batch in (False, True):
+        la = lib.Lookahead(cfg, backend=OracleBackend(cfg).struct, max_frames=nf + 6)
+        try:
+            if batch:
+                la.put_pictures([f.ctypes.data for f in frames], W, [c.ctypes.data for c in cb], [c.ctypes.data for c in cr], cb.shape[2], types, pts)
+                outs = []
+                while True:
+                    o = la.get(True, True)
+                    if o is None:
+                        break
+                    outs.append(o)
+            else:
+                outs = la.run(frames, qp_offsets=True, chroma=(cb, cr), forced_types=types, pts=pts, paced=False)
+        finally:
+            la.close()
+        res.append(outs)
+    assert len(res[0]) == len(res[1]) == nf
+    for a, b in zip(*res):
+        assert (a.frame, a.type) == (b.frame, b.type)
+        assert np.array_equal(np.array(a.cost_est), np.array(b.cost_est)) and np.array_equal(a.qp_offset, b.qp_offset)

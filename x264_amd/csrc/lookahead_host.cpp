@@ -963,6 +963,10 @@ static int dev_frame_put_yuv( void *u, int slot, const void *luma, int stride, c
 {
     return x264hip_frame_put( (x264hip_ctx *)u, slot, luma, stride, is_device, cb, cr, cstride, nullptr );
 }
+static int dev_put_batch_yuv( void *u, int n, const int *slots, const void *const *luma, int stride, const void *const *cb, const void *const *cr, int cstride )
+{
+    return x264hip_frame_put_batch_yuv( (x264hip_ctx *)u, n, slots, luma, stride, cb, cr, cstride );
+}
 static int dev_put_batch( void *u, int n, const int *slots, const void *const *luma, int stride )
 {
     return x264hip_frame_put_batch( (x264hip_ctx *)u, n, slots, luma, stride );
@@ -1048,7 +1052,7 @@ extern "C" int x264hip_lookahead_open( x264hip_lookahead **out, int device, cons
     x264hip_ctx *ctx = nullptr;
     int rc = x264hip_open( &ctx, device, &p.dev );
     if( rc ) return rc;
-    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch, dev_mbtree, dev_qp_offsets, dev_put_batch, dev_prefetch_weights, dev_recalc, dev_row_satds, dev_frame_put_yuv };
+    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch, dev_mbtree, dev_qp_offsets, dev_put_batch, dev_prefetch_weights, dev_recalc, dev_row_satds, dev_frame_put_yuv, dev_put_batch_yuv };
     rc = x264hip_lookahead_open_backend( out, &p, &be );
     if( rc ) { x264hip_close( ctx ); return rc; }
     ( *out )->L.ctx = ctx;
@@ -1093,6 +1097,8 @@ static LaFrame *new_frame( Lookahead &L, int forced_type )
     f->i_frame = L.i_input++;
     // an unknown picture type is taken as AUTO (x264_frame_copy_picture, frame.c:392-400)
     f->i_forced_type = f->i_type = forced_type < T_AUTO || forced_type > T_KEYFRAME ? T_AUTO : forced_type;
+    f->pts = f->i_frame;
+    f->f_duration = L.f_duration;
     f->refcount = 1;
     // encoder.c:1617-1625 b_have_lowres: constant QP without any analysis has no lowres planes, and the -1 marks are the work of
     // x264_frame_init_lowres (mc.c:473): without it the cells keep the zeros of the frame's allocation
@@ -1107,15 +1113,23 @@ static LaFrame *new_frame( Lookahead &L, int forced_type )
 
 extern "C" int x264hip_lookahead_put_frames( x264hip_lookahead *la, int n, const void *const *luma_dev, int stride )
 {
-    if( !la || n <= 0 || !luma_dev ) return X264HIP_EINVAL;
+    return x264hip_lookahead_put_pictures( la, n, luma_dev, stride, nullptr, nullptr, 0, nullptr, nullptr );
+}
+
+extern "C" int x264hip_lookahead_put_pictures( x264hip_lookahead *la, int n, const void *const *luma_dev, int stride, const void *const *cb_dev,
+                                               const void *const *cr_dev, int cstride, const int *types, const int64_t *pts )
+{
+    if( !la || n <= 0 || !luma_dev || ( !cb_dev ) != ( !cr_dev ) ) return X264HIP_EINVAL;
     Lookahead &L = la->L;
     ScopeNs tm_api( L.stats[7] );
     if( L.err ) return L.err;
-    if( !L.be.frame_put_batch )
+    if( cb_dev ? !L.be.frame_put_batch_yuv : !L.be.frame_put_batch )
     {
         for( int i = 0; i < n; i++ )
         {
-            int rc = x264hip_lookahead_put_frame( la, luma_dev[i], stride, 1, T_AUTO );
+            const void *planes[3] = { luma_dev[i], cb_dev ? cb_dev[i] : nullptr, cb_dev ? cr_dev[i] : nullptr };
+            const int strides[3] = { stride, cstride, cstride };
+            int rc = x264hip_lookahead_put_picture( la, planes, strides, 1, types ? types[i] : T_AUTO, pts ? pts[i] : L.i_input );
             if( rc ) return rc;
         }
         return X264HIP_OK;
@@ -1125,10 +1139,12 @@ extern "C" int x264hip_lookahead_put_frames( x264hip_lookahead *la, int n, const
     std::vector<int> slots;
     for( int i = 0; i < n; i++ )
     {
-        fr.push_back( new_frame( L, T_AUTO ) );
+        fr.push_back( new_frame( L, types ? types[i] : T_AUTO ) );
+        fr.back()->pts = pts ? pts[i] : fr.back()->i_frame;
         slots.push_back( fr.back()->slot );
     }
-    int rc = L.be.frame_put_batch( L.be.user, n, slots.data(), luma_dev, stride );
+    int rc = cb_dev ? L.be.frame_put_batch_yuv( L.be.user, n, slots.data(), luma_dev, stride, cb_dev, cr_dev, cstride )
+                    : L.be.frame_put_batch( L.be.user, n, slots.data(), luma_dev, stride );
     if( rc )
     {
         for( auto f : fr ) { L.free_slots.push_back( f->slot ); delete f; }

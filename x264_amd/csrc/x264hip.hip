@@ -525,7 +525,15 @@ extern "C" int x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, 
 // Batch form for frames already resident on the device: one launch per ingest kernel for all n frames.
 extern "C" int x264hip_frame_put_batch( x264hip_ctx *ctx, int n, const int *slots, const void *const *luma_dev, int stride )
 {
-    if( !ctx || n <= 0 || !slots || !luma_dev || stride < ctx->p.width ) return X264HIP_EINVAL;
+    return x264hip_frame_put_batch_yuv( ctx, n, slots, luma_dev, stride, nullptr, nullptr, 0 );
+}
+
+extern "C" int x264hip_frame_put_batch_yuv( x264hip_ctx *ctx, int n, const int *slots, const void *const *luma_dev, int stride,
+                                            const void *const *cb_dev, const void *const *cr_dev, int cstride )
+{
+    if( !ctx || n <= 0 || !slots || !luma_dev || stride < ctx->p.width || ( !cb_dev ) != ( !cr_dev ) ||
+        ( cb_dev && cstride < ( ctx->p.width + 1 ) / 2 ) )
+        return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     if( ctx->mbt_pending )
@@ -543,7 +551,7 @@ extern "C" int x264hip_frame_put_batch( x264hip_ctx *ctx, int n, const int *slot
             if( !slot_ok( ctx, slots[o + i] ) || !luma_dev[o + i] ) return X264HIP_EINVAL;
             FrameSlot &s = ctx->slots[slots[o + i]];
             slot_reset( ctx, s );
-            dh[i] = make_put_desc( ctx, s, luma_dev[o + i], stride, nullptr, nullptr, 0, aq_on );
+            dh[i] = make_put_desc( ctx, s, luma_dev[o + i], stride, cb_dev ? cb_dev[o + i] : nullptr, cb_dev ? cr_dev[o + i] : nullptr, cstride, aq_on );
         }
         HIPCK( hipMemcpyAsync( dd, dh, (size_t)m * sizeof( PutDesc ), hipMemcpyHostToDevice, ctx->stream ) );
         PutDesc none;

@@ -327,6 +327,8 @@ PREFETCH_WEIGHTS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_in
 
 RECALC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int))
 ROW_SATDS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int))
+PUT_BATCH_YUV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p),
+                                C.POINTER(C.c_void_p), C.c_int)
 FRAME_PUT_YUV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
 
 
@@ -335,7 +337,8 @@ class Backend(C.Structure):
                 ("weight_cost", WEIGHT_COST_FN), ("frame_cost", FRAME_COST_FN), ("prefetch", PREFETCH_FN),
                 ("mbtree", MBTREE_FN), ("get_qp_offsets", QP_OFFSETS_FN), ("frame_put_batch", PUT_BATCH_FN),
                 ("prefetch_weight_costs", PREFETCH_WEIGHTS_FN), ("frame_cost_recalculate", RECALC_FN),
-                ("get_row_satds", ROW_SATDS_FN), ("frame_put_yuv", FRAME_PUT_YUV_FN)]
+                ("get_row_satds", ROW_SATDS_FN), ("frame_put_yuv", FRAME_PUT_YUV_FN),
+                ("frame_put_batch_yuv", PUT_BATCH_YUV_FN)]
 
 
 LOOKAHEAD_MAX = 250
@@ -619,6 +622,18 @@ class Lookahead:
             return
         luma = np.ascontiguousarray(luma, self.dtype)
         _ck(self.L.x264hip_lookahead_put_frame(self.h, _p(luma), luma.shape[1], 0, forced_type), "lookahead_put_frame")
+
+    def put_pictures(self, y_ptrs, stride, cb_ptrs=None, cr_ptrs=None, cstride=0, types=None, pts=None):
+        """x264hip_lookahead_put_pictures: device-resident pictures in one call"""
+        n = len(y_ptrs)
+        arr = lambda p: (C.c_void_p * n)(*p) if p is not None else None  # noqa: E731
+        ty = (C.c_int * n)(*[int(t) for t in types]) if types is not None else None
+        ts = (C.c_int64 * n)(*[int(t) for t in pts]) if pts is not None else None
+        self.L.x264hip_lookahead_put_pictures.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                          C.c_void_p]
+        _ck(self.L.x264hip_lookahead_put_pictures(self.h, n, arr(y_ptrs), stride, arr(cb_ptrs), arr(cr_ptrs), cstride, ty, ts),
+            "lookahead_put_pictures")
+        self._n_put += n
 
     def put_batch(self, device_ptrs, stride=None):
         arr = (C.c_void_p * len(device_ptrs))(*device_ptrs)
