@@ -363,3 +363,31 @@ def test_frame_put_with_chroma(depth):
                     assert np.array_equal(ctx.inv_qscale(slot), want_inv), (W, H, mode, slot)
             finally:
                 ctx.close()
+
+
+def test_put_pictures_device_batch():
+    """x264hip_lookahead_put_pictures with device-resident 4:2:0 pictures (one ingest launch for the whole clip, chroma included)
+    against the golden run of the same clip fed picture by picture from host buffers."""
+    import torch
+    name = "chroma_aq"
+    preset, opts, over, depth, W, H, ckw, nf = LOOKAHEAD_CASES_R2[name]
+    z = np.load(os.path.join(GOLD, "lookahead_%s.npz" % name))
+    frames = make_clip(W, H, nf, bit_depth=depth, **ckw)
+    cb, cr = make_chroma(W, H, nf, seed=ckw.get("seed", 1), bit_depth=depth)
+    over = dict(over); over.pop("_chroma")
+    cfg = lib.la_config(W, H, preset, bit_depth=depth, **over)
+    dy, dcb, dcr = torch.from_numpy(frames).cuda(), torch.from_numpy(cb).cuda(), torch.from_numpy(cr).cuda()
+    torch.cuda.synchronize()
+    la = lib.Lookahead(cfg, max_frames=nf + 4)
+    try:
+        la.put_pictures([dy[i].data_ptr() for i in range(nf)], W, [dcb[i].data_ptr() for i in range(nf)], [dcr[i].data_ptr() for i in range(nf)],
+                        cb.shape[2])
+        outs = []
+        while True:
+            o = la.get(True, True)
+            if o is None:
+                break
+            outs.append(o)
+    finally:
+        la.close()
+    check_lookahead_outputs(outs, z, cfg["bframes"] + 2)
