@@ -66,6 +66,8 @@ typedef struct x264hip_params
     int lookahead_slices; /* param.i_lookahead_threads (encoder/encoder.c:1273-1300): the frame is searched in that many
                            * horizontal bands, rows [(mb_h*i + n/2)/n, (mb_h*(i+1) + n/2)/n), and a band does not use the
                            * vectors of the band below as predictors (slicetype.c:668,917-918).  0 or 1 = one band */
+    int chroma_format;    /* of the Cb / Cr planes handed to frame_put: 0 or 1 = 4:2:0, 2 = 4:2:2, 3 = 4:4:4 (CHROMA_420/422/444; only
+                           * adaptive quantisation looks at chroma: block size and shift of ac_energy_plane, ratecontrol.c:238-256) */
     const uint16_t *cost_mv;
 } x264hip_params;
 

@@ -70,6 +70,11 @@ RH_API rh_ctx *rh_open( int width, int height, const char *preset, const char *t
                 c->param.b_vfr_input = eq ? atoi( eq + 1 ) : 1;
                 continue;
             }
+            if( !strcmp( tok, "csp" ) && eq ) /* i_csp is set by the CLI from --output-csp, not by x264_param_parse */
+            {
+                c->param.i_csp = !strcmp( eq + 1, "i444" ) ? X264_CSP_I444 : !strcmp( eq + 1, "i422" ) ? X264_CSP_I422 : X264_CSP_I420;
+                continue;
+            }
             if( !strcmp( tok, "timebase" ) && eq ) /* i_timebase_num / i_timebase_den: set by the CLI, not an option of x264_param_parse */
             {
                 unsigned a = 0, b = 0;
@@ -169,19 +174,22 @@ static x264_frame_t *rh_make_frame( rh_ctx *c, const pixel *y, const pixel *u, c
     int w = h->param.i_width, ht = h->param.i_height;
     x264_picture_t pic;
     x264_picture_init( &pic );
-    pic.img.i_csp = X264_CSP_I420 | (BIT_DEPTH > 8 ? X264_CSP_HIGH_DEPTH : 0);
+    /* planar input in the colour space the context was opened with ("csp=i422" / "csp=i444" in the option string; default I420) */
+    int csp = h->param.i_csp & X264_CSP_MASK;
+    int cw = csp == X264_CSP_I444 ? w : (w+1)/2, chh = csp == X264_CSP_I420 ? (ht+1)/2 : ht;
+    pic.img.i_csp = csp | (BIT_DEPTH > 8 ? X264_CSP_HIGH_DEPTH : 0);
     pic.img.i_plane = 3;
     pixel *grey = NULL;
     if( !u || !v )
     {
-        grey = malloc( (size_t)(w/2+1)*(ht/2+1)*sizeof(pixel) );
-        for( int i = 0; i < (w/2+1)*(ht/2+1); i++ )
+        grey = malloc( (size_t)(cw+1)*(chh+1)*sizeof(pixel) );
+        for( int i = 0; i < (cw+1)*(chh+1); i++ )
             grey[i] = 1 << (BIT_DEPTH-1);
         u = v = grey;
     }
     pic.img.plane[0] = (uint8_t*)y; pic.img.i_stride[0] = w * sizeof(pixel);
-    pic.img.plane[1] = (uint8_t*)u; pic.img.i_stride[1] = ((w+1)/2) * sizeof(pixel);
-    pic.img.plane[2] = (uint8_t*)v; pic.img.i_stride[2] = ((w+1)/2) * sizeof(pixel);
+    pic.img.plane[1] = (uint8_t*)u; pic.img.i_stride[1] = cw * sizeof(pixel);
+    pic.img.plane[2] = (uint8_t*)v; pic.img.i_stride[2] = cw * sizeof(pixel);
     pic.i_pts = idx;
     x264_frame_t *f = x264_frame_pop_unused( h, 0 );
     if( !f || x264_frame_copy_picture( h, f, &pic ) < 0 )
@@ -489,7 +497,8 @@ RH_API int rh_lookahead_run( rh_ctx *c, const pixel *yuv, int n_frames, int luma
 {
     x264_t *h = c->h;
     int w = h->param.i_width, ht = h->param.i_height;
-    size_t ysz = (size_t)w*ht, csz = (size_t)((w+1)/2)*((ht+1)/2);
+    int csp_ = h->param.i_csp & X264_CSP_MASK;
+    size_t ysz = (size_t)w*ht, csz = (size_t)(csp_ == X264_CSP_I444 ? w : (w+1)/2)*(csp_ == X264_CSP_I420 ? (ht+1)/2 : ht);
     size_t fsz = luma_only ? ysz : ysz + 2*csz;
     int n_out = 0;
     double t_la = 0, t_prep = 0;

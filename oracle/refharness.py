@@ -67,7 +67,7 @@ class Ref:
         self.lib.rh_add_frame.argtypes = [C.c_void_p] * 4
         if cb is not None:
             cb = np.ascontiguousarray(cb, dtype=self.dtype); cr = np.ascontiguousarray(cr, dtype=self.dtype)
-            assert cb.shape == cr.shape == ((self.height + 1) // 2, (self.width + 1) // 2)
+            assert cb.shape == cr.shape  # (H+1)//2 x (W+1)//2 for I420, H x (W+1)//2 for I422, H x W for I444 (csp= option)
         r = self.lib.rh_add_frame(self.ctx, _ptr(luma), _ptr(cb), _ptr(cr))
         assert r >= 0
         self.n_frames = r + 1

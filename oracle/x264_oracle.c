@@ -1285,9 +1285,20 @@ uint64_t ORN(aq_frame)( const pixel *luma, int stride, int width, int height, in
                         const pixel *cb, const pixel *cr, int cstride, int aq_mode, float aq_strength,
                         uint16_t *inv_qscale, float *qp_offset, uint64_t *ssd_out )
 {
+    return ORN(aq_frame_fmt)( luma, stride, width, height, mb_w, mb_h, cb, cr, cstride, aq_mode, aq_strength, inv_qscale, qp_offset, ssd_out, 1 );
+}
+
+/* chroma_format: 1 = 4:2:0 (8x8 chroma per macroblock and plane, shift 6), 2 = 4:2:2 (8x16, shift 7), 3 = 4:4:4 (16x16 like luma,
+ * shift 8): ac_energy_plane / ac_energy_mb, ratecontrol.c:238-296 */
+uint64_t ORN(aq_frame_fmt)( const pixel *luma, int stride, int width, int height, int mb_w, int mb_h,
+                            const pixel *cb, const pixel *cr, int cstride, int aq_mode, float aq_strength,
+                            uint16_t *inv_qscale, float *qp_offset, uint64_t *ssd_out, int chroma_format )
+{
     uint64_t sum_y = 0, ssd_y = 0;
     const float strength = aq_strength * 1.0397f;
-    const int cw = ( width + 1 ) >> 1, chh = ( height + 1 ) >> 1;
+    const int c444 = chroma_format == 3, c420 = chroma_format != 2 && chroma_format != 3;
+    const int cw = c444 ? width : ( width + 1 ) >> 1, chh = c420 ? ( height + 1 ) >> 1 : height;
+    const int cbw = c444 ? 16 : 8, cbh = c420 ? 8 : 16, cshift = c444 ? 8 : c420 ? 6 : 7;
     float sum_r4 = 0.f, sum_r8 = 0.f;
     float *av_r8 = malloc( sizeof(float) * mb_w * mb_h );
     for( int my = 0; my < mb_h; my++ )
@@ -1310,16 +1321,16 @@ uint64_t ORN(aq_frame)( const pixel *luma, int stride, int width, int height, in
                 const pixel *pl = p ? cr : cb;
                 if( !pl ) continue;
                 uint32_t cs = 0, cq = 0;
-                for( int y = 0; y < 8; y++ )
+                for( int y = 0; y < cbh; y++ )
                 {
-                    const pixel *row = pl + (size_t)imin( 8*my + y, chh-1 ) * cstride;
-                    for( int x = 0; x < 8; x++ )
+                    const pixel *row = pl + (size_t)imin( cbh*my + y, chh-1 ) * cstride;
+                    for( int x = 0; x < cbw; x++ )
                     {
-                        uint32_t v = row[imin( 8*mx + x, cw-1 )];
+                        uint32_t v = row[imin( cbw*mx + x, cw-1 )];
                         cs += v; cq += v*v;
                     }
                 }
-                energy += cq - (uint32_t)( (uint64_t)cs * cs >> 6 );
+                energy += cq - (uint32_t)( (uint64_t)cs * cs >> cshift );
             }
             if( aq_mode == 1 && aq_strength != 0.f )
             {

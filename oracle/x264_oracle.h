@@ -117,7 +117,10 @@ void or##D##_cell( const or_la_cfg *c, const PIX *fenc0, const PIX *const ref0[4
                    int with_intra, uint16_t *lowres_costs, int *row_satds, int *row_satds_intra, or_cell_out *out ); \
 uint64_t or##D##_aq_frame( const PIX *luma, int stride, int width, int height, int mb_w, int mb_h, \
                            const PIX *cb, const PIX *cr, int cstride, int aq_mode, float aq_strength, \
-                           uint16_t *inv_qscale, float *qp_offset, uint64_t *ssd_out );
+                           uint16_t *inv_qscale, float *qp_offset, uint64_t *ssd_out ); \
+uint64_t or##D##_aq_frame_fmt( const PIX *luma, int stride, int width, int height, int mb_w, int mb_h, \
+                               const PIX *cb, const PIX *cr, int cstride, int aq_mode, float aq_strength, \
+                               uint16_t *inv_qscale, float *qp_offset, uint64_t *ssd_out, int chroma_format );
 
 OR_DECL( 8, uint8_t, int16_t, uint16_t )
 OR_DECL( 10, uint16_t, int32_t, uint32_t )

@@ -49,14 +49,17 @@ class OracleBackend:
 
     def _put_yuv(self, user, slot, luma, stride, cb, cr, cstride, is_device):
         c = self.cfg
-        cw, ch = (c["width"] + 1) // 2, (c["height"] + 1) // 2
+        fmt = c.get("chroma_format", 1)
+        cw = c["width"] if fmt == 3 else (c["width"] + 1) // 2
+        ch = c["height"] if fmt >= 2 else (c["height"] + 1) // 2
         return self._put(user, slot, luma, stride, is_device, self._plane(cb, cstride, cw, ch), self._plane(cr, cstride, cw, ch))
 
     def _put(self, user, slot, luma, stride, is_device, cb=None, cr=None):
         c = self.cfg
         img = self._plane(luma, stride, c["width"], c["height"])
         pl = self.o.lowres_init(self.ocfg, img)
-        inv, qp, s, ssd = self.o.aq_frame(img, self.ocfg.mb_w, self.ocfg.mb_h, c["aq_mode"], c["aq_strength"], cb, cr)
+        inv, qp, s, ssd = self.o.aq_frame(img, self.ocfg.mb_w, self.ocfg.mb_h, c["aq_mode"], c["aq_strength"], cb, cr,
+                                            chroma_format=c.get("chroma_format", 1))
         n = self.ocfg.mb_w * self.ocfg.mb_h
         self.slots[slot] = dict(planes=pl, inv=inv, sum=s, ssd=ssd, intra=self.o.intra_costs(self.ocfg, pl), fields={}, maps={}, rows={},
                                 prop=np.zeros(n, np.uint16), qp_aq=qp.copy(), qp=qp.copy())

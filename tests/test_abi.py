@@ -20,8 +20,8 @@ def test_exports_match_header():
 
 
 def test_struct_sizes_match_header():
-    # x264hip_params: 14 ints + float + 4 ints + pointer; la_frame: 4 ints + two 18x18 matrices + 18 ints
-    assert C.sizeof(lib.Params) == 19 * 4 + 4 + 8  # padded to pointer alignment
+    # x264hip_params: 14 ints + float + 5 ints + pointer; la_frame: 4 ints + two 18x18 matrices + 18 ints
+    assert C.sizeof(lib.Params) == 20 * 4 + 8
     assert C.sizeof(lib.LaFrameOut) == (4 + 2 * 18 * 18 + 18) * 4
     assert C.sizeof(lib.Cost) == 20 and C.sizeof(lib.Weight) == 16
 
@@ -31,7 +31,7 @@ def test_invalid_arguments_are_rejected_without_a_device():
     h = C.c_void_p()
     assert L.x264hip_open(C.byref(h), 0, None) == -2
     tab, centre = lib.cost_mv_table(128, 1)
-    p = lib.Params(9, 352, 288, 3, 1, 1, 4, 16, 128, 7, 1, 0, 1, 1, 1.0, 0, 8, 0, 1, tab.ctypes.data + 2 * centre)
+    p = lib.Params(9, 352, 288, 3, 1, 1, 4, 16, 128, 7, 1, 0, 1, 1, 1.0, 0, 8, 0, 1, 1, tab.ctypes.data + 2 * centre)
     assert L.x264hip_open(C.byref(h), 0, C.byref(p)) == -2  # bit depth 9
     assert L.x264hip_strerror(-1).decode().startswith("no usable HIP device")
 

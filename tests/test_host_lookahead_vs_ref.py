@@ -550,3 +550,37 @@ def test_put_pictures_batch_equals_one_by_one():
     for a, b in zip(*res):
         assert (a.frame, a.type) == (b.frame, b.type)
         assert np.array_equal(np.array(a.cost_est), np.array(b.cost_est)) and np.array_equal(a.qp_offset, b.qp_offset)
+
+
+@pytest.mark.parametrize("csp,fmt,depth,opts,over,W,H", [
+    ("i422", 2, 8, "", {}, 176, 144), ("i444", 3, 8, "", {}, 176, 144),
+    ("i422", 2, 10, "aq-mode=3", dict(aq_mode=3), 176, 144), ("i444", 3, 8, "aq-mode=2,bitrate=3000", dict(aq_mode=2, bitrate=3000), 100, 70),
+])
+def test_chroma_formats(csp, fmt, depth, opts, over, W, H):
+    """4:2:2 and 4:4:4 pictures: adaptive quantisation measures 8x16 resp. 16x16 chroma blocks with their own shifts
+    (ac_energy_plane, ratecontrol.c:238-256) and the profile raises the level limits (set.c:881-883); the rest of the lookahead only
+    reads luma.  Decisions and f_qp_offset against the reference opened with that colour space."""
+    nf = 36
+    frames = make_clip(W, H, nf, seed=9, bit_depth=depth, scene_cuts=(17,), pan=(3, 1))
+    maxv = (1 << depth) - 1
+    rng = np.random.default_rng(3)
+    dt = np.uint8 if depth == 8 else np.uint16
+    cw, ch = (W if fmt == 3 else (W + 1) // 2), H
+    cb = rng.integers(0, maxv + 1, size=(nf, ch, cw)).astype(dt)
+    cr = np.clip(rng.normal(maxv / 2, maxv / 6, size=(nf, ch, cw)), 0, maxv).astype(dt)
+    r = refharness.Ref(W, H, "medium", opts="csp=%s" % csp + ("," + opts if opts else ""), bit_depth=depth)
+    try:
+        ref = r.lookahead_run(frames, with_qp_offsets=True, chroma=(cb, cr))
+        rc = r.cfg
+    finally:
+        r.close()
+    cfg = lib.la_config(W, H, "medium", bit_depth=depth, chroma_format=fmt, **over)
+    assert cfg["mv_range"] == rc["mv_range"]
+    la = lib.Lookahead(cfg, backend=OracleBackend(cfg).struct, max_frames=nf + 4)
+    try:
+        outs = la.run(frames, qp_offsets=True, chroma=(cb, cr))
+    finally:
+        la.close()
+    assert [o.frame for o in outs] == list(ref["idx"]) and [o.type for o in outs] == list(ref["type"])
+    for k, o in enumerate(outs):
+        assert np.array_equal(o.qp_offset, ref["qp_offset"][k]), (o.frame, o.type)

@@ -343,13 +343,20 @@ def test_frame_put_with_chroma(depth):
     from oracle.oraclelib import Oracle
     o = Oracle(depth)
     vdt = np.uint8 if depth == 8 else np.int16
-    for (W, H) in ((352, 288), (100, 70)):
+    maxv = (1 << depth) - 1
+    for (W, H, fmt) in ((352, 288, 1), (100, 70, 1), (176, 144, 2), (100, 70, 3)):
         y = make_clip(W, H, 1, seed=5, bit_depth=depth, noise=20)[0]
-        cb, cr = (np.ascontiguousarray(c[0]) for c in make_chroma(W, H, 1, seed=5, bit_depth=depth))
-        cw = (W + 1) // 2
+        if fmt == 1:
+            cb, cr = (np.ascontiguousarray(c[0]) for c in make_chroma(W, H, 1, seed=5, bit_depth=depth))
+        else:   # 4:2:2: (W+1)//2 x H, 4:4:4: W x H
+            rng = np.random.default_rng(W + fmt)
+            shape = (H, W if fmt == 3 else (W + 1) // 2)
+            cb = rng.integers(0, maxv + 1, size=shape).astype(o.dtype)
+            cr = np.clip(rng.normal(maxv / 2, maxv / 6, size=shape), 0, maxv).astype(o.dtype)
+        cw = cb.shape[1]
         for mode, strength in ((1, 1.0), (2, 1.0), (3, 0.6)):
-            want_inv, want_qp = o.aq_frame(y, (W + 15) // 16, (H + 15) // 16, mode, strength, cb, cr)[:2]
-            ctx = lib.Context(W, H, bit_depth=depth, aq_mode=mode, aq_strength=strength, max_frames=4)
+            want_inv, want_qp = o.aq_frame(y, (W + 15) // 16, (H + 15) // 16, mode, strength, cb, cr, chroma_format=fmt)[:2]
+            ctx = lib.Context(W, H, bit_depth=depth, aq_mode=mode, aq_strength=strength, max_frames=4, chroma_format=fmt)
             try:
                 L = ctx.L
                 L.x264hip_frame_put.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]

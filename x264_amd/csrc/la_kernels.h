@@ -121,7 +121,7 @@ __device__ __forceinline__ unsigned wave_sum_u32( unsigned v )
 
 template <typename T>
 __global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc single, int width, int height, int mb_w,
-                                                   float strength, float log2_bias, const AqLuts *luts, int aq_mode, float depth_corr )
+                                                   float strength, float log2_bias, const AqLuts *luts, int aq_mode, float depth_corr, int chroma_format )
 {
     const PutDesc D = descs ? descs[blockIdx.z] : single;
     const T *__restrict__ luma = (const T *)D.src, *__restrict__ cb = (const T *)D.cb, *__restrict__ cr = (const T *)D.cr;
@@ -145,13 +145,22 @@ __global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc
     unsigned energy = q - (unsigned)( ( (unsigned long long)s * s ) >> 8 );
     if( cb )
     {
-        const int cw = ( width + 1 ) >> 1, ch = ( height + 1 ) >> 1;
-        const int cy = imin2( 8 * my + ( lane >> 3 ), ch - 1 ), cx = imin2( 8 * mx + ( lane & 7 ), cw - 1 );
-        unsigned vb = cb[(size_t)cy * cstride + cx], vr = cr[(size_t)cy * cstride + cx];
-        unsigned sb = wave_sum_u32( vb ), qb = wave_sum_u32( vb * vb );
-        unsigned sr = wave_sum_u32( vr ), qr = wave_sum_u32( vr * vr );
-        energy += qb - (unsigned)( ( (unsigned long long)sb * sb ) >> 6 );
-        energy += qr - (unsigned)( ( (unsigned long long)sr * sr ) >> 6 );
+        // chroma part of ac_energy_mb (ratecontrol.c:238-296): per plane an 8x8 block with shift 6 (4:2:0), 8x16 with shift 7
+        // (4:2:2) or 16x16 with shift 8 (4:4:4); coordinates clamp like the mod-16 border replication
+        const int c444 = chroma_format == 3, c420 = chroma_format < 2;
+        const int cw = c444 ? width : ( width + 1 ) >> 1, ch = c420 ? ( height + 1 ) >> 1 : height;
+        const int lbw = c444 ? 4 : 3, bw = 1 << lbw, bh = c420 ? 8 : 16, n = ( bw * bh ) >> 6, shift = c444 ? 8 : c420 ? 6 : 7;
+        unsigned sb = 0, qb = 0, sr = 0, qr = 0;
+        for( int k = 0; k < n; k++ )
+        {
+            const int idx = lane + 64 * k;
+            const int cy = imin2( bh * my + ( idx >> lbw ), ch - 1 ), cx = imin2( bw * mx + ( idx & ( bw - 1 ) ), cw - 1 );
+            const unsigned vb = cb[(size_t)cy * cstride + cx], vr = cr[(size_t)cy * cstride + cx];
+            sb += vb; qb += vb * vb; sr += vr; qr += vr * vr;
+        }
+        sb = wave_sum_u32( sb ); qb = wave_sum_u32( qb ); sr = wave_sum_u32( sr ); qr = wave_sum_u32( qr );
+        energy += qb - (unsigned)( ( (unsigned long long)sb * sb ) >> shift );
+        energy += qr - (unsigned)( ( (unsigned long long)sr * sr ) >> shift );
     }
     if( lane == 0 )
     {

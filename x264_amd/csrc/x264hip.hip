@@ -256,7 +256,7 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     if( ( p.bit_depth != 8 && p.bit_depth != 10 ) || p.width < 16 || p.height < 16 || p.bframes < 0 || p.bframes > X264HIP_BFRAME_MAX ||
         !p.cost_mv || p.mv_range < 1 || ( p.subpel_refine != 2 && p.subpel_refine != 4 ) || p.max_frames < 2 ||
         ( p.me_method != X264HIP_ME_DIA && p.me_method != X264HIP_ME_HEX ) || p.aq_mode < 0 || p.aq_mode > 3 ||
-        p.lookahead_slices < 0 || p.lookahead_slices > X264HIP_LOOKAHEAD_SLICES_MAX )
+        p.lookahead_slices < 0 || p.lookahead_slices > X264HIP_LOOKAHEAD_SLICES_MAX || p.chroma_format < 0 || p.chroma_format > 3 )
         return X264HIP_EINVAL;
     int ndev = 0;
     if( hipGetDeviceCount( &ndev ) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev )
@@ -445,7 +445,7 @@ static int launch_ingest_t( x264hip_ctx *ctx, const PutDesc *descs_dev, const Pu
     dim3 grd( ( ( ctx->lw + 2 * LA_PAD ) / 4 + 255 ) / 256, ctx->lh + 2 * LA_PAD, n );
     lowres_kernel<T><<<grd, 256, 0, ctx->stream>>>( descs_dev, single, p.width, p.height, P.plane_elems, P.stride, ctx->lw, ctx->lh );
     aq_kernel<T><<<dim3( P.mb_w, P.mb_h, n ), 64, 0, ctx->stream>>>( descs_dev, single, p.width, p.height, P.mb_w, strength, bias, ctx->luts_dev,
-                                                                       p.aq_mode, 1.f / ( 1 << ( 2 * ( p.bit_depth - 8 ) ) ) );
+                                                                       p.aq_mode, 1.f / ( 1 << ( 2 * ( p.bit_depth - 8 ) ) ), p.chroma_format );
     if( p.aq_mode >= 2 && p.aq_strength != 0.f )
         aq_auto_kernel<<<n, 1024, 0, ctx->stream>>>( descs_dev, single, ctx->n_mb, p.aq_mode, p.aq_strength, ctx->luts_dev );
     aq_reduce_kernel<<<n, 1024, 0, ctx->stream>>>( descs_dev, single, ctx->n_mb );
@@ -495,7 +495,7 @@ extern "C" int x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, 
         {
             // the two chroma planes (4:2:0) follow through their own staging pair; the stream was drained above, so the device copy
             // of the previous frame's chroma has been consumed
-            const int cw = ( p.width + 1 ) >> 1, ch = ( p.height + 1 ) >> 1;
+            const int cw = p.chroma_format == 3 ? p.width : ( p.width + 1 ) >> 1, ch = p.chroma_format >= 2 ? p.height : ( p.height + 1 ) >> 1;
             const size_t crow = (size_t)cw * ctx->psz, cplane = crow * ch;
             if( cstride < cw ) return X264HIP_EINVAL;
             if( !ctx->chroma_staging )
@@ -532,7 +532,7 @@ extern "C" int x264hip_frame_put_batch_yuv( x264hip_ctx *ctx, int n, const int *
                                             const void *const *cb_dev, const void *const *cr_dev, int cstride )
 {
     if( !ctx || n <= 0 || !slots || !luma_dev || stride < ctx->p.width || ( !cb_dev ) != ( !cr_dev ) ||
-        ( cb_dev && cstride < ( ctx->p.width + 1 ) / 2 ) )
+        ( cb_dev && cstride < ( ctx->p.chroma_format == 3 ? ctx->p.width : ( ctx->p.width + 1 ) / 2 ) ) )
         return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread

@@ -21,7 +21,7 @@ class Params(C.Structure):
                 ("me_method", C.c_int), ("subpel_refine", C.c_int), ("me_range", C.c_int), ("mv_range", C.c_int),
                 ("subme", C.c_int), ("mbcmp_satd", C.c_int), ("fpelcmp_satd", C.c_int), ("weighted_bipred", C.c_int),
                 ("aq_mode", C.c_int), ("aq_strength", C.c_float), ("bframe_bias", C.c_int), ("max_frames", C.c_int),
-                ("no_edges", C.c_int), ("lookahead_slices", C.c_int), ("cost_mv", C.c_void_p)]
+                ("no_edges", C.c_int), ("lookahead_slices", C.c_int), ("chroma_format", C.c_int), ("cost_mv", C.c_void_p)]
 
 
 class Weight(C.Structure):
@@ -105,7 +105,7 @@ class Context:
 
     def __init__(self, width, height, *, bit_depth=8, bframes=3, lam=None, me_method=1, subpel_refine=4, me_range=16,
                  mv_range=512, subme=7, mbcmp_satd=1, fpelcmp_satd=0, weighted_bipred=1, aq_mode=1, aq_strength=1.0,
-                 bframe_bias=0, max_frames=64, cost_mv=None, device=0, no_edges=0, lookahead_slices=1):
+                 bframe_bias=0, max_frames=64, cost_mv=None, device=0, no_edges=0, lookahead_slices=1, chroma_format=1):
         L = load()
         lam = lam if lam is not None else (1 if bit_depth == 8 else 4)
         if cost_mv is None:
@@ -116,7 +116,7 @@ class Context:
         self._cost_mv = cost_mv
         self.params = Params(bit_depth, width, height, bframes, lam, me_method, subpel_refine, me_range, mv_range, subme,
                              mbcmp_satd, fpelcmp_satd, weighted_bipred, aq_mode, aq_strength, bframe_bias, max_frames,
-                             no_edges, lookahead_slices, cost_mv.ctypes.data + 2 * centre)
+                             no_edges, lookahead_slices, chroma_format, cost_mv.ctypes.data + 2 * centre)
         self.h = C.c_void_p()
         _ck(L.x264hip_open(C.byref(self.h), device, C.byref(self.params)), "x264hip_open")
         self.L = L
@@ -397,14 +397,14 @@ LEVELS = [(10, 1485, 99, 396, 64, 175, 64), (9, 1485, 99, 396, 128, 350, 64), (1
 
 
 def mv_range_for(width, height, fps_num=25, fps_den=1, bit_depth=8, frame_refs=3, bframes=3, b_pyramid=2, keyint_max=250,
-                 transform_8x8=1, bitrate=0, vbv_maxrate=0, vbv_bufsize=0):
+                 transform_8x8=1, bitrate=0, vbv_maxrate=0, vbv_bufsize=0, chroma_format=1):
     """param.analyse.i_mv_range of the automatically chosen level (encoder.c:1243-1268): the first level of the table that
     x264_validate_levels (encoder/set.c:876-913) accepts -- frame size, decoded picture buffer, VBV rate and buffer against the
     profile's limits, macroblock rate -- or the last one."""
     mb_w, mb_h = (width + 15) // 16, (height + 15) // 16
     mbs = mb_w * mb_h
     # x264_sps_init (encoder/set.c:114-157)
-    cbp_factor = 12 if bit_depth > 8 else 5 if transform_8x8 else 4
+    cbp_factor = 16 if chroma_format >= 2 else 12 if bit_depth > 8 else 5 if transform_8x8 else 4
     reorder = 2 if b_pyramid else 1 if bframes else 0
     dec_buffering = 0 if keyint_max == 1 else min(16, max(frame_refs, 1 + reorder, 4 if b_pyramid else 1, 1))
     if bitrate and not vbv_bufsize:  # encoder.c:1248-1249: ABR without VBV is checked as if maxrate were twice the bitrate
@@ -423,7 +423,7 @@ def la_config(width, height, preset="medium", bit_depth=8, tune="", **over):
     c = dict(bframes=3, b_adapt=1, b_pyramid=2, rc_lookahead=40, me="hex", me_range=16, subme=7, weightp=2,
              weighted_bipred=1, mb_tree=1, aq_mode=1, aq_strength=1.0, scenecut=40, keyint_max=250, keyint_min=0,
              open_gop=0, frame_refs=3, psy=1, rc_is_cqp=0, bframe_bias=0, fps=25.0, mv_range=0, fps_num=25, fps_den=1,
-             qcompress=0.6, threads=1, lookahead_threads=0, bitrate=0, vbv_maxrate=0, vbv_bufsize=0, transform_8x8=1, intra_refresh=0, vfr_input=0, timebase_num=0, timebase_den=0)
+             qcompress=0.6, threads=1, lookahead_threads=0, bitrate=0, vbv_maxrate=0, vbv_bufsize=0, transform_8x8=1, intra_refresh=0, vfr_input=0, timebase_num=0, timebase_den=0, chroma_format=1)
     c.update(PRESETS[preset])
     for t in filter(None, tune.replace(",", " ").split()):
         tv = dict(TUNES[t])
@@ -503,7 +503,7 @@ def la_config(width, height, preset="medium", bit_depth=8, tune="", **over):
     if c["mv_range"] <= 0:                                                   # :1243-1268
         c["mv_range"] = mv_range_for(width, height, c["fps_num"], c["fps_den"], bit_depth, c["frame_refs"], c["bframes"],
                                      c["b_pyramid"], c["keyint_max"], c["transform_8x8"],
-                                     0 if c["rc_is_cqp"] else c["bitrate"], c["vbv_maxrate"], c["vbv_bufsize"])
+                                     0 if c["rc_is_cqp"] else c["bitrate"], c["vbv_maxrate"], c["vbv_bufsize"], c["chroma_format"])
     else:
         c["mv_range"] = clip(c["mv_range"], 32, 8192)
     c["weightp"] = clip(c["weightp"], 0, 2)                                  # :1271
@@ -549,7 +549,7 @@ def make_la_params(cfg, cost_mv=None, max_frames=0):
     dev = Params(cfg["bit_depth"], cfg["width"], cfg["height"], cfg["bframes"], cfg["lam"], cfg["la_me_method"],
                  cfg["la_subpel_refine"], cfg["me_range"], cfg["mv_range"], cfg["subme"], cfg["mbcmp_satd"],
                  cfg["fpelcmp_satd"], cfg["weighted_bipred"], cfg["aq_mode"], cfg["aq_strength"], cfg["bframe_bias"],
-                 max_frames, int(not cfg["do_edges"]), cfg["lookahead_threads"], cost_mv.ctypes.data + 2 * centre)
+                 max_frames, int(not cfg["do_edges"]), cfg["lookahead_threads"], cfg["chroma_format"], cost_mv.ctypes.data + 2 * centre)
     p = LaParams(dev, cfg["keyint_max"], cfg["keyint_min"], cfg["scenecut"], cfg["b_adapt"], cfg["b_pyramid"],
                  cfg["rc_lookahead"], cfg["mb_tree"], cfg["weightp"], cfg["open_gop"], cfg["frame_refs"], cfg["psy"],
                  cfg["rc_is_cqp"], cfg["fps_num"], cfg["fps_den"], cfg["qcompress"], cfg["vbv"], cfg["vfr_input"], cfg["timebase_num"], cfg["timebase_den"], cfg["intra_refresh"])
