@@ -75,3 +75,16 @@ def test_struct_layouts_match_header(tmp_path):
         assert C.sizeof(cls) == int(want[cname + ".sizeof"]), cname
         for fname, _ in cls._fields_:
             assert getattr(cls, fname).offset == int(want["%s.%s" % (cname, fname)]), (cname, fname)
+
+
+def test_new_entries_reject_null_arguments_without_a_device():
+    """every entry added for the next rows validates its arguments before touching the device (X264HIP_EINVAL = -2)"""
+    L = lib.load()
+    for name, nargs in (("x264hip_me_search_batch", 11), ("x264hip_pixel_metric_batch", 9), ("x264hip_frame_dct_quant8x8", 11),
+                        ("x264hip_integral_init", 7), ("x264hip_frame_filter", 11), ("x264hip_frame_put_batch_yuv", 8),
+                        ("x264hip_lookahead_put_picture", 6), ("x264hip_lookahead_put_pictures", 9), ("x264hip_lookahead_get_frame_vbv", 8),
+                        ("x264hip_lookahead_put_frame_pts", 6)):
+        fn = getattr(L, name)
+        fn.restype = C.c_int
+        fn.argtypes = None
+        assert fn(*([None] * nargs)) == -2, name
