@@ -175,6 +175,11 @@ int  x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *frame_numb
  * Runs asynchronously on the context's second stream; x264hip_get_qp_offsets waits for it. */
 int  x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, int n );
 int  x264hip_get_qp_offsets( x264hip_ctx *ctx, int slot, float *qp_offset );        /* f_qp_offset, n_mb floats */
+/* x264_picture_t.prop.quant_offsets for a frame already put (x264_adaptive_quant_frame, ratecontrol.c:318-326,396-397): adds one
+ * float per macroblock to f_qp_offset / f_qp_offset_aq and recomputes i_inv_qscale_factor = x264_exp2fix8( offset ).  Done through
+ * the host (the maps come back, the offsets are added in FP32 like the reference does, the three maps go up again): meant for the
+ * occasional region-of-interest picture, not for every frame.  No effect with aq_mode 0. */
+int  x264hip_frame_add_quant_offsets( x264hip_ctx *ctx, int slot, const float *quant_offsets );
 int  x264hip_get_propagate_cost( x264hip_ctx *ctx, int slot, uint16_t *propagate ); /* i_propagate_cost, n_mb */
 /* slicetype_frame_cost_recalculate (encoder/slicetype.c:999-1024; called by x264_rc_analyse_slice, :2002-2003, and by
  * vbv_frame_cost): cost of the evaluated cell (dist_p0, dist_p1) of frame slot_b under its current quantiser offsets --
@@ -347,6 +352,9 @@ typedef struct x264hip_backend
     /* frame_put with the 4:2:0 chroma planes (contract of x264hip_frame_put's cb / cr / cstride): needed by
      * x264hip_lookahead_put_picture, may be NULL otherwise */
     int (*frame_put_yuv)( void *user, int slot, const void *luma, int stride, const void *cb, const void *cr, int cstride, int is_device );
+    /* adds the caller's per-macroblock offsets to the AQ maps of a frame just put (f_qp_offset, f_qp_offset_aq, i_inv_qscale_factor):
+     * contract of x264hip_frame_add_quant_offsets; needed only for pictures that carry quant_offsets */
+    int (*add_quant_offsets)( void *user, int slot, const float *quant_offsets );
     int (*frame_put_batch_yuv)( void *user, int n, const int *slots, const void *const *luma_dev, int stride, const void *const *cb_dev,
                                 const void *const *cr_dev, int cstride ); /* may be NULL: the pictures go in one by one */
 } x264hip_backend;
@@ -384,6 +392,19 @@ int  x264hip_lookahead_put_pictures( x264hip_lookahead *la, int n, const void *c
  * the chroma planes are needed for the reference's i_inv_qscale_factor / f_qp_offset on real content (luma-only input is treated as
  * flat chroma: no chroma energy).  planes = { Y, Cb, Cr }, strides in samples, host or device pointers (is_device). */
 int  x264hip_lookahead_put_picture( x264hip_lookahead *la, const void *const planes[3], const int strides[3], int is_device, int forced_type, int64_t pts );
+/* The general form, shaped like the x264_picture_t fields the lookahead reads (x264.h): planes / strides as above (Cb, Cr may be
+ * NULL), i_type, i_pts, and prop.quant_offsets -- one float per macroblock added to the adaptive-quantisation offset of the
+ * picture (ratecontrol.c:318-326,396-397; NULL = none; host memory, consumed before the call returns). */
+typedef struct x264hip_picture
+{
+    const void *planes[3];
+    int strides[3];
+    int is_device;
+    int i_type;
+    int64_t i_pts;
+    const float *quant_offsets;
+} x264hip_picture;
+int  x264hip_lookahead_put( x264hip_lookahead *la, const x264hip_picture *pic );
 /* same with the picture's time stamp (x264_picture_t.i_pts, in timebase units); x264hip_lookahead_put_frame uses the frame number */
 int  x264hip_lookahead_put_frame_pts( x264hip_lookahead *la, const void *luma, int stride, int is_device, int forced_type, int64_t pts );
 int  x264hip_lookahead_get_frame( x264hip_lookahead *la, int flush, x264hip_la_frame *out, int *got );

@@ -141,7 +141,7 @@ class Oracle:
                        C.byref(out))
         return lc, rows, rows_i, out
 
-    def aq_frame(self, luma, mb_w, mb_h, aq_mode=1, aq_strength=1.0, cb=None, cr=None, chroma_format=1):
+    def aq_frame(self, luma, mb_w, mb_h, aq_mode=1, aq_strength=1.0, cb=None, cr=None, chroma_format=1, quant_offsets=None):
         luma = np.ascontiguousarray(luma, self.dtype)
         h, w = luma.shape
         inv = np.zeros(mb_w * mb_h, np.uint16)
@@ -149,8 +149,8 @@ class Oracle:
         ssd = C.c_uint64(0)
         fn = self.f("aq_frame_fmt", C.c_uint64)
         fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
-                       C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+                       C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_int, C.c_void_p]
         cstride = cb.shape[1] if cb is not None else (w + 1) // 2
         s = fn(_p(luma), w, w, h, mb_w, mb_h, _p(cb), _p(cr), cstride, aq_mode, aq_strength, _p(inv), _p(qp),
-               C.byref(ssd), chroma_format)
+               C.byref(ssd), chroma_format, _p(np.ascontiguousarray(quant_offsets, np.float32)) if quant_offsets is not None else None)
         return inv, qp, int(s), int(ssd.value)

@@ -205,6 +205,9 @@ static x264_frame_t *rh_make_frame( rh_ctx *c, const pixel *y, const pixel *u, c
     return f;
 }
 
+static const float *rh_quant_offsets = NULL; /* optional [n_frames][mb_count] x264_picture_t.prop.quant_offsets (rh_add_frame: one frame's worth) */
+RH_API void rh_set_quant_offsets( const float *q ) { rh_quant_offsets = q; }
+
 /* Add a frame to the evaluation set (index = order of addition): AQ + lowres init, exactly the
  * pre-lookahead steps of x264_encoder_encode (encoder.c:3368-3423). */
 RH_API int rh_add_frame( rh_ctx *c, const pixel *y, const pixel *u, const pixel *v )
@@ -212,7 +215,7 @@ RH_API int rh_add_frame( rh_ctx *c, const pixel *y, const pixel *u, const pixel 
     if( c->n_frames >= RH_MAX_FRAMES ) return -1;
     x264_frame_t *f = rh_make_frame( c, y, u, v, c->n_frames );
     if( !f ) return -1;
-    x264_adaptive_quant_frame( c->h, f, NULL );
+    x264_adaptive_quant_frame( c->h, f, (float*)rh_quant_offsets );
     x264_frame_init_lowres( c->h, f );
     c->frames[c->n_frames] = f;
     return c->n_frames++;
@@ -519,7 +522,7 @@ RH_API int rh_lookahead_run( rh_ctx *c, const pixel *yuv, int n_frames, int luma
             h->frames.i_bframe_delay_time = fenc->i_pts - h->frames.i_first_pts;
         h->frames.i_second_largest_pts = h->frames.i_largest_pts;
         h->frames.i_largest_pts = fenc->i_pts;
-        x264_adaptive_quant_frame( h, fenc, NULL );
+        x264_adaptive_quant_frame( h, fenc, rh_quant_offsets ? (float*)rh_quant_offsets + (size_t)i*h->mb.i_mb_count : NULL );
         clock_gettime( CLOCK_MONOTONIC, &t1 );
         t_prep += (t1.tv_sec-t0.tv_sec) + 1e-9*(t1.tv_nsec-t0.tv_nsec);
         clock_gettime( CLOCK_MONOTONIC, &t0 );

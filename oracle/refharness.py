@@ -126,7 +126,7 @@ class Ref:
         assert r == 0
         return lc, rows, tuple(int(x) for x in summ)
 
-    def lookahead_run(self, luma_frames, with_qp_offsets=False, forced_types=None, with_vbv=False, rc_cells=None, pts=None, chroma=None):
+    def lookahead_run(self, luma_frames, with_qp_offsets=False, forced_types=None, with_vbv=False, rc_cells=None, pts=None, chroma=None, quant_offsets=None):
         """rc_cells: [n, 2] (b-p0, p1-b) per OUTPUT index -> also runs the real x264_rc_analyse_slice on every leaving frame
         (out["rc"][k] = [cost, i_row_satd..., i_row_satds[0][0]...])."""
         """luma_frames: [n, H, W]; returns dict(idx, type, cost, cost_aq, intra_mbs, seconds, seconds_prep[, qp_offset])."""
@@ -143,6 +143,10 @@ class Ref:
         self.lib.rh_set_prop_dump.argtypes = [C.c_void_p]
         self.lib.rh_set_qp_dump(_ptr(qp))
         self.lib.rh_set_prop_dump(_ptr(prop))
+        self.lib.rh_set_quant_offsets.argtypes = [C.c_void_p]
+        qo = np.ascontiguousarray(quant_offsets, np.float32) if quant_offsets is not None else None
+        assert qo is None or qo.shape == (n, self.n_mb)
+        self.lib.rh_set_quant_offsets(_ptr(qo))
         self.lib.rh_set_pts.argtypes = [C.c_void_p]
         ptsa = np.ascontiguousarray(pts, np.int64) if pts is not None else None
         self.lib.rh_set_pts(_ptr(ptsa))
@@ -171,6 +175,7 @@ class Ref:
         r = f(self.ctx, _ptr(fr), n, luma_only, _ptr(idx), _ptr(typ), _ptr(cost), _ptr(cost_aq), _ptr(imbs),
               C.byref(sec), C.byref(sec_prep))
         self.lib.rh_set_forced_types(None)
+        self.lib.rh_set_quant_offsets(None)
         self.lib.rh_set_pts(None)
         self.lib.rh_set_vbv_dump(None, None, None)
         self.lib.rh_set_rc_dump(None, None)

@@ -1285,15 +1285,16 @@ uint64_t ORN(aq_frame)( const pixel *luma, int stride, int width, int height, in
                         const pixel *cb, const pixel *cr, int cstride, int aq_mode, float aq_strength,
                         uint16_t *inv_qscale, float *qp_offset, uint64_t *ssd_out )
 {
-    return ORN(aq_frame_fmt)( luma, stride, width, height, mb_w, mb_h, cb, cr, cstride, aq_mode, aq_strength, inv_qscale, qp_offset, ssd_out, 1 );
+    return ORN(aq_frame_fmt)( luma, stride, width, height, mb_w, mb_h, cb, cr, cstride, aq_mode, aq_strength, inv_qscale, qp_offset, ssd_out, 1, NULL );
 }
 
 /* chroma_format: 1 = 4:2:0 (8x8 chroma per macroblock and plane, shift 6), 2 = 4:2:2 (8x16, shift 7), 3 = 4:4:4 (16x16 like luma,
  * shift 8): ac_energy_plane / ac_energy_mb, ratecontrol.c:238-296 */
 uint64_t ORN(aq_frame_fmt)( const pixel *luma, int stride, int width, int height, int mb_w, int mb_h,
                             const pixel *cb, const pixel *cr, int cstride, int aq_mode, float aq_strength,
-                            uint16_t *inv_qscale, float *qp_offset, uint64_t *ssd_out, int chroma_format )
+                            uint16_t *inv_qscale, float *qp_offset, uint64_t *ssd_out, int chroma_format, const float *quant_offsets )
 {
+    /* quant_offsets: x264_picture_t.prop.quant_offsets, one float per macroblock added to the AQ offset (ratecontrol.c:318-326,396-397) */
     uint64_t sum_y = 0, ssd_y = 0;
     const float strength = aq_strength * 1.0397f;
     const int c444 = chroma_format == 3, c420 = chroma_format != 2 && chroma_format != 3;
@@ -1335,6 +1336,7 @@ uint64_t ORN(aq_frame_fmt)( const pixel *luma, int stride, int width, int height
             if( aq_mode == 1 && aq_strength != 0.f )
             {
                 float qp_adj = strength * lut_log2_minus( energy > 1 ? energy : 1, 14.427f + 2*( OR_DEPTH - 8 ) );
+                if( quant_offsets ) qp_adj += quant_offsets[my*mb_w+mx];
                 if( qp_offset ) qp_offset[my*mb_w+mx] = qp_adj;
                 inv_qscale[my*mb_w+mx] = (uint16_t)exp2fix8( qp_adj );
             }
@@ -1355,8 +1357,10 @@ uint64_t ORN(aq_frame_fmt)( const pixel *luma, int stride, int width, int height
             }
             else
             {
-                if( qp_offset ) qp_offset[my*mb_w+mx] = 0.f;
-                inv_qscale[my*mb_w+mx] = 256;
+                /* AQ off, or on with strength 0 (the MB-tree case): only the caller's offsets remain (:316-334) */
+                float qp_adj = aq_mode && quant_offsets ? quant_offsets[my*mb_w+mx] : 0.f;
+                if( qp_offset ) qp_offset[my*mb_w+mx] = qp_adj;
+                inv_qscale[my*mb_w+mx] = aq_mode && quant_offsets ? (uint16_t)exp2fix8( qp_adj ) : 256;
             }
         }
     if( ( aq_mode == 2 || aq_mode == 3 ) && aq_strength != 0.f )
@@ -1372,6 +1376,7 @@ uint64_t ORN(aq_frame_fmt)( const pixel *luma, int stride, int width, int height
             float qp_adj = ( q - avg_adj ) * str;
             if( aq_mode == 3 )
                 qp_adj = ( 1.f - 14.f / ( q*q ) ) * aq_strength + qp_adj;
+            if( quant_offsets ) qp_adj += quant_offsets[i];
             if( qp_offset ) qp_offset[i] = qp_adj;
             inv_qscale[i] = (uint16_t)exp2fix8( qp_adj );
         }

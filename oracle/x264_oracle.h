@@ -120,7 +120,7 @@ uint64_t or##D##_aq_frame( const PIX *luma, int stride, int width, int height, i
                            uint16_t *inv_qscale, float *qp_offset, uint64_t *ssd_out ); \
 uint64_t or##D##_aq_frame_fmt( const PIX *luma, int stride, int width, int height, int mb_w, int mb_h, \
                                const PIX *cb, const PIX *cr, int cstride, int aq_mode, float aq_strength, \
-                               uint16_t *inv_qscale, float *qp_offset, uint64_t *ssd_out, int chroma_format );
+                               uint16_t *inv_qscale, float *qp_offset, uint64_t *ssd_out, int chroma_format, const float *quant_offsets );
 
 OR_DECL( 8, uint8_t, int16_t, uint16_t )
 OR_DECL( 10, uint16_t, int32_t, uint32_t )

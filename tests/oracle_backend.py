@@ -32,7 +32,7 @@ class OracleBackend:
                                   lib.PREFETCH_FN(self._prefetch) if speculative else lib.PREFETCH_FN(0),
                                   lib.MBTREE_FN(self._mbtree), lib.QP_OFFSETS_FN(self._qp), lib.PUT_BATCH_FN(0),
                                   lib.PREFETCH_WEIGHTS_FN(self._prefetch_weights) if speculative else lib.PREFETCH_WEIGHTS_FN(0),
-                                  lib.RECALC_FN(self._recalc), lib.ROW_SATDS_FN(self._rows), lib.FRAME_PUT_YUV_FN(self._put_yuv), lib.PUT_BATCH_YUV_FN(0))
+                                  lib.RECALC_FN(self._recalc), lib.ROW_SATDS_FN(self._rows), lib.FRAME_PUT_YUV_FN(self._put_yuv), lib.ADD_QOFFS_FN(self._add_qoffs), lib.PUT_BATCH_YUV_FN(0))
 
     def _prefetch(self, user, slots, numbers, n):
         return 0
@@ -62,7 +62,7 @@ class OracleBackend:
                                             chroma_format=c.get("chroma_format", 1))
         n = self.ocfg.mb_w * self.ocfg.mb_h
         self.slots[slot] = dict(planes=pl, inv=inv, sum=s, ssd=ssd, intra=self.o.intra_costs(self.ocfg, pl), fields={}, maps={}, rows={},
-                                prop=np.zeros(n, np.uint16), qp_aq=qp.copy(), qp=qp.copy())
+                                prop=np.zeros(n, np.uint16), qp_aq=qp.copy(), qp=qp.copy(), img=img, cb=cb, cr=cr)
         return 0
 
     def _stats(self, user, slot, psum, pssd):
@@ -165,4 +165,14 @@ class OracleBackend:
     def _rows(self, user, slot, d0, d1, dst):
         r = self.slots[slot]["rows"][(d0, d1)]
         C.memmove(dst, r.ctypes.data, r.nbytes)
+        return 0
+
+    def _add_qoffs(self, user, slot, q):
+        """x264_picture_t.prop.quant_offsets: the oracle's AQ of the stored picture again, with the offsets"""
+        B, c = self.slots[slot], self.cfg
+        n = self.ocfg.mb_w * self.ocfg.mb_h
+        offs = np.ctypeslib.as_array(q, shape=(n,)).copy()
+        inv, qp, _, _ = self.o.aq_frame(B["img"], self.ocfg.mb_w, self.ocfg.mb_h, c["aq_mode"], c["aq_strength"], B["cb"], B["cr"],
+                                        chroma_format=c.get("chroma_format", 1), quant_offsets=offs)
+        B["inv"], B["qp_aq"], B["qp"] = inv, qp.copy(), qp.copy()
         return 0

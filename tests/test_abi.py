@@ -58,7 +58,7 @@ def test_struct_layouts_match_header(tmp_path):
     import subprocess
     pairs = {"x264hip_params": lib.Params, "x264hip_weight": lib.Weight, "x264hip_cost": lib.Cost, "x264hip_mbtree_op": lib.MbtreeOp,
              "x264hip_la_params": lib.LaParams, "x264hip_backend": lib.Backend, "x264hip_la_frame": lib.LaFrameOut,
-             "x264hip_la_vbv": lib.LaVbv, "x264hip_me_request": lib.MeRequest}
+             "x264hip_la_vbv": lib.LaVbv, "x264hip_me_request": lib.MeRequest, "x264hip_picture": lib.Picture}
     rename = {"lambda_": "lambda"}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "x264hip.h"', 'int main(void){']
     for cname, cls in pairs.items():

@@ -584,3 +584,44 @@ def test_chroma_formats(csp, fmt, depth, opts, over, W, H):
     assert [o.frame for o in outs] == list(ref["idx"]) and [o.type for o in outs] == list(ref["type"])
     for k, o in enumerate(outs):
         assert np.array_equal(o.qp_offset, ref["qp_offset"][k]), (o.frame, o.type)
+
+
+@pytest.mark.parametrize("preset,opts,over,depth", [
+    ("medium", "", {}, 8), ("fast", "aq-mode=3,b-adapt=2", dict(aq_mode=3, b_adapt=2), 10),
+    ("medium", "aq-strength=0", dict(aq_strength=0.0), 8),       # AQ "on with strength 0" for MB-tree: only the caller's offsets remain
+    ("superfast", "", {}, 8),
+])
+def test_picture_quant_offsets(preset, opts, over, depth):
+    """x264_picture_t.prop.quant_offsets (x264hip_picture.quant_offsets): per-macroblock offsets added to the adaptive-quantisation
+    offsets of the picture (ratecontrol.c:318-326,396-397) -- they move i_inv_qscale_factor, the AQ-weighted costs, MB-tree and
+    f_qp_offset.  Against the reference given the same offsets (region-of-interest style: a box of negative offsets that moves)."""
+    from x264_amd.synth import make_chroma
+    W, H, nf = 176, 144, 36
+    frames = make_clip(W, H, nf, seed=71, bit_depth=depth, scene_cuts=(16,), pan=(2, 1))
+    chroma = make_chroma(W, H, nf, seed=71, bit_depth=depth)
+    mb_w, mb_h = (W + 15) // 16, (H + 15) // 16
+    offs = np.zeros((nf, mb_h, mb_w), np.float32)
+    rng = np.random.default_rng(5)
+    for i in range(nf):
+        x0 = (i // 3) % (mb_w - 3)
+        offs[i, 2:6, x0:x0 + 4] = -6.0 + rng.normal(0, 0.5, size=(4, 4)).astype(np.float32)
+        offs[i, 0, :] = 2.5
+    offs = offs.reshape(nf, -1)
+    r = refharness.Ref(W, H, preset, opts=opts, bit_depth=depth)
+    try:
+        ref = r.lookahead_run(frames, with_qp_offsets=True, chroma=chroma, quant_offsets=offs)
+    finally:
+        r.close()
+    cfg = lib.la_config(W, H, preset, bit_depth=depth, **over)
+    la = lib.Lookahead(cfg, backend=OracleBackend(cfg).struct, max_frames=nf + 4)
+    try:
+        outs = la.run(frames, qp_offsets=True, chroma=chroma, quant_offsets=offs)
+    finally:
+        la.close()
+    assert [o.frame for o in outs] == list(ref["idx"]) and [o.type for o in outs] == list(ref["type"])
+    nb = cfg["bframes"] + 2
+    for k, o in enumerate(outs):
+        assert np.array_equal(np.array(o.cost_est)[:nb, :nb], ref["cost"][k][:nb, :nb])
+        m = ref["cost"][k][:nb, :nb] >= 0
+        assert np.array_equal(np.array(o.cost_est_aq)[:nb, :nb][m], ref["cost_aq"][k][:nb, :nb][m])
+        assert np.array_equal(o.qp_offset, ref["qp_offset"][k]), (o.frame, o.type)

@@ -13,7 +13,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 IMPL = os.path.join("tests", "zz_gpu_new_configs_impl.py")
-FUNCTIONS = ["test_aq_modes_against_oracle", "test_pixel_metric_batch", "test_frame_dct_quant8x8", "test_me_search_batch", "test_integral_init", "test_frame_filter", "test_frame_put_with_chroma", "test_put_pictures_device_batch", "test_eval_sequence_ring_and_bands",
+FUNCTIONS = ["test_aq_modes_against_oracle", "test_pixel_metric_batch", "test_frame_dct_quant8x8", "test_me_search_batch", "test_integral_init", "test_frame_filter", "test_frame_put_with_chroma", "test_put_pictures_device_batch", "test_frame_add_quant_offsets", "test_eval_sequence_ring_and_bands",
              "test_lookahead_vs_golden_new_configs"]
 
 pytestmark = [pytest.mark.gpu, pytest.mark.xfail(reason="device path not yet run on hardware (written after the last GPU session)", strict=False)]

@@ -398,3 +398,27 @@ def test_put_pictures_device_batch():
     finally:
         la.close()
     check_lookahead_outputs(outs, z, cfg["bframes"] + 2)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_frame_add_quant_offsets(depth):
+    """x264hip_frame_add_quant_offsets (x264_picture_t.prop.quant_offsets) against the oracle's AQ with the same offsets: aq-mode 1
+    and 3, and AQ on with strength 0 (what MB-tree forces when AQ is off)."""
+    import ctypes as C
+    from oracle.oraclelib import Oracle
+    o = Oracle(depth)
+    W, H = 352, 288
+    mb_w, mb_h = (W + 15) // 16, (H + 15) // 16
+    y = make_clip(W, H, 1, seed=5, bit_depth=depth, noise=20)[0]
+    offs = np.random.default_rng(9).normal(0, 3, size=mb_w * mb_h).astype(np.float32)
+    for mode, strength in ((1, 1.0), (3, 0.7), (1, 0.0)):
+        want_inv, want_qp = o.aq_frame(y, mb_w, mb_h, mode, strength, quant_offsets=offs)[:2]
+        ctx = lib.Context(W, H, bit_depth=depth, aq_mode=mode, aq_strength=strength, max_frames=4)
+        try:
+            ctx.frame_put(0, y)
+            ctx.L.x264hip_frame_add_quant_offsets.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+            assert ctx.L.x264hip_frame_add_quant_offsets(ctx.h, 0, offs.ctypes.data) == 0
+            assert np.array_equal(ctx.qp_offsets(0), want_qp), (mode, strength)
+            assert np.array_equal(ctx.inv_qscale(0), want_inv), (mode, strength)
+        finally:
+            ctx.close()

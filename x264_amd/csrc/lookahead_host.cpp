@@ -963,6 +963,7 @@ static int dev_frame_put_yuv( void *u, int slot, const void *luma, int stride, c
 {
     return x264hip_frame_put( (x264hip_ctx *)u, slot, luma, stride, is_device, cb, cr, cstride, nullptr );
 }
+static int dev_add_quant_offsets( void *u, int slot, const float *q ) { return x264hip_frame_add_quant_offsets( (x264hip_ctx *)u, slot, q ); }
 static int dev_put_batch_yuv( void *u, int n, const int *slots, const void *const *luma, int stride, const void *const *cb, const void *const *cr, int cstride )
 {
     return x264hip_frame_put_batch_yuv( (x264hip_ctx *)u, n, slots, luma, stride, cb, cr, cstride );
@@ -1052,7 +1053,7 @@ extern "C" int x264hip_lookahead_open( x264hip_lookahead **out, int device, cons
     x264hip_ctx *ctx = nullptr;
     int rc = x264hip_open( &ctx, device, &p.dev );
     if( rc ) return rc;
-    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch, dev_mbtree, dev_qp_offsets, dev_put_batch, dev_prefetch_weights, dev_recalc, dev_row_satds, dev_frame_put_yuv, dev_put_batch_yuv };
+    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch, dev_mbtree, dev_qp_offsets, dev_put_batch, dev_prefetch_weights, dev_recalc, dev_row_satds, dev_frame_put_yuv, dev_add_quant_offsets, dev_put_batch_yuv };
     rc = x264hip_lookahead_open_backend( out, &p, &be );
     if( rc ) { x264hip_close( ctx ); return rc; }
     ( *out )->L.ctx = ctx;
@@ -1170,7 +1171,21 @@ extern "C" int x264hip_lookahead_put_frame_pts( x264hip_lookahead *la, const voi
 
 extern "C" int x264hip_lookahead_put_picture( x264hip_lookahead *la, const void *const planes[3], const int strides[3], int is_device, int forced_type, int64_t pts )
 {
-    if( !la || !planes || !strides || !planes[0] || ( !planes[1] ) != ( !planes[2] ) ) return X264HIP_EINVAL;
+    if( !planes || !strides ) return X264HIP_EINVAL;
+    x264hip_picture pic;
+    for( int k = 0; k < 3; k++ ) { pic.planes[k] = planes[k]; pic.strides[k] = strides[k]; }
+    pic.is_device = is_device; pic.i_type = forced_type; pic.i_pts = pts; pic.quant_offsets = nullptr;
+    return x264hip_lookahead_put( la, &pic );
+}
+
+extern "C" int x264hip_lookahead_put( x264hip_lookahead *la, const x264hip_picture *pic )
+{
+    if( !la || !pic ) return X264HIP_EINVAL;
+    const void *const *planes = pic->planes;
+    const int *strides = pic->strides;
+    const int is_device = pic->is_device, forced_type = pic->i_type;
+    const int64_t pts = pic->i_pts;
+    if( !planes[0] || ( !planes[1] ) != ( !planes[2] ) || ( pic->quant_offsets && !la->L.be.add_quant_offsets ) ) return X264HIP_EINVAL;
     const void *luma = planes[0];
     const int stride = strides[0];
     const bool with_chroma = planes[1] != nullptr;
@@ -1184,6 +1199,8 @@ extern "C" int x264hip_lookahead_put_picture( x264hip_lookahead *la, const void 
     f->f_duration = L.f_duration;
     int rc = with_chroma ? L.be.frame_put_yuv( L.be.user, f->slot, luma, stride, planes[1], planes[2], strides[1], is_device )
                          : L.be.frame_put( L.be.user, f->slot, luma, stride, is_device );
+    if( !rc && pic->quant_offsets )
+        rc = L.be.add_quant_offsets( L.be.user, f->slot, pic->quant_offsets );
     if( rc )
     {
         L.free_slots.push_back( f->slot );

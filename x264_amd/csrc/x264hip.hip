@@ -1160,6 +1160,34 @@ extern "C" int x264hip_frame_cost_recalculate( x264hip_ctx *ctx, int slot_b, int
     return X264HIP_OK;
 }
 
+extern "C" int x264hip_frame_add_quant_offsets( x264hip_ctx *ctx, int slot, const float *quant_offsets )
+{
+    if( !ctx || !slot_ok( ctx, slot ) || !quant_offsets ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    if( !ctx->p.aq_mode ) return X264HIP_OK; // the reference has no offset maps without AQ (frame.c:217-226)
+    FrameSlot &s = ctx->slots[slot];
+    const int n = ctx->n_mb;
+    std::vector<float> qp( n );
+    std::vector<uint16_t> inv( n );
+    HIPCK( hipMemcpyAsync( qp.data(), s.qp_aq, n * sizeof( float ), hipMemcpyDeviceToHost, ctx->stream ) );
+    HIPCK( hipStreamSynchronize( ctx->stream ) );
+    uint8_t exp2_lut[64]; // the table behind x264_exp2fix8 (common/base.h:217-223): round( ( 2^(i/64) - 1 ) * 256 )
+    for( int i = 0; i < 64; i++ )
+        exp2_lut[i] = (uint8_t)floor( ( pow( 2.0, i / 64.0 ) - 1.0 ) * 256.0 + 0.5 );
+    for( int i = 0; i < n; i++ )
+    {
+        qp[i] += quant_offsets[i];                                         // qp_adj += quant_offsets[mb_xy]
+        const int k = (int)( qp[i] * ( -64.f / 6.f ) + 512.5f );           // x264_exp2fix8, common/base.h:217-223
+        inv[i] = (uint16_t)( k < 0 ? 0 : k > 1023 ? 0xffff : ( ( exp2_lut[k & 63] + 256 ) << ( k >> 6 ) >> 8 ) );
+    }
+    HIPCK( hipMemcpyAsync( s.qp_aq, qp.data(), n * sizeof( float ), hipMemcpyHostToDevice, ctx->stream ) );
+    HIPCK( hipMemcpyAsync( s.qp, qp.data(), n * sizeof( float ), hipMemcpyHostToDevice, ctx->stream ) );
+    HIPCK( hipMemcpyAsync( s.inv_qscale, inv.data(), n * sizeof( uint16_t ), hipMemcpyHostToDevice, ctx->stream ) );
+    HIPCK( hipStreamSynchronize( ctx->stream ) ); // the host vectors go out of scope
+    return X264HIP_OK;
+}
+
 extern "C" int x264hip_get_propagate_cost( x264hip_ctx *ctx, int slot, uint16_t *propagate )
 {
     if( !ctx || !slot_ok( ctx, slot ) || !propagate ) return X264HIP_EINVAL;

@@ -327,6 +327,7 @@ PREFETCH_WEIGHTS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_in
 
 RECALC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int))
 ROW_SATDS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int))
+ADD_QOFFS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float))
 PUT_BATCH_YUV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p),
                                 C.POINTER(C.c_void_p), C.c_int)
 FRAME_PUT_YUV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
@@ -338,7 +339,13 @@ class Backend(C.Structure):
                 ("mbtree", MBTREE_FN), ("get_qp_offsets", QP_OFFSETS_FN), ("frame_put_batch", PUT_BATCH_FN),
                 ("prefetch_weight_costs", PREFETCH_WEIGHTS_FN), ("frame_cost_recalculate", RECALC_FN),
                 ("get_row_satds", ROW_SATDS_FN), ("frame_put_yuv", FRAME_PUT_YUV_FN),
-                ("frame_put_batch_yuv", PUT_BATCH_YUV_FN)]
+                ("add_quant_offsets", ADD_QOFFS_FN), ("frame_put_batch_yuv", PUT_BATCH_YUV_FN)]
+
+
+class Picture(C.Structure):
+    """x264hip_picture"""
+    _fields_ = [("planes", C.c_void_p * 3), ("strides", C.c_int * 3), ("is_device", C.c_int), ("i_type", C.c_int), ("i_pts", C.c_int64),
+                ("quant_offsets", C.c_void_p)]
 
 
 LOOKAHEAD_MAX = 250
@@ -591,6 +598,23 @@ class Lookahead:
     def ctx_handle(self):
         return C.c_void_p(self.L.x264hip_lookahead_ctx(self.h))
 
+    def put_pic(self, y, cb=None, cr=None, forced_type=0, pts=None, quant_offsets=None):
+        """x264hip_lookahead_put: host planes (cb / cr optional) plus the picture's quant_offsets (float per macroblock)"""
+        pic = Picture()
+        keep = [np.ascontiguousarray(y, self.dtype)]
+        pic.planes[0], pic.strides[0] = keep[0].ctypes.data, keep[0].shape[1]
+        if cb is not None:
+            keep += [np.ascontiguousarray(cb, self.dtype), np.ascontiguousarray(cr, self.dtype)]
+            pic.planes[1], pic.planes[2] = keep[1].ctypes.data, keep[2].ctypes.data
+            pic.strides[1] = pic.strides[2] = keep[1].shape[1]
+        pic.i_type, pic.i_pts = forced_type, int(pts) if pts is not None else self._n_put
+        if quant_offsets is not None:
+            keep.append(np.ascontiguousarray(quant_offsets, np.float32))
+            pic.quant_offsets = keep[-1].ctypes.data
+        self.L.x264hip_lookahead_put.argtypes = [C.c_void_p, C.c_void_p]
+        _ck(self.L.x264hip_lookahead_put(self.h, C.byref(pic)), "lookahead_put")
+        self._n_put += 1
+
     def put_picture(self, y, cb, cr, forced_type=0, pts=None, device=False, strides=None):
         """the whole 4:2:0 picture (x264hip_lookahead_put_picture): numpy planes, or device addresses with strides=(ys, cs)"""
         self.L.x264hip_lookahead_put_picture.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64]
@@ -667,7 +691,7 @@ class Lookahead:
         _ck(self.L.x264hip_lookahead_stats(self.h, _p(out), 8), "lookahead_stats")
         return out
 
-    def run(self, frames=None, device_ptrs=None, stride=None, paced=True, qp_offsets=False, forced_types=None, vbv=False, pts=None, chroma=None):
+    def run(self, frames=None, device_ptrs=None, stride=None, paced=True, qp_offsets=False, forced_types=None, vbv=False, pts=None, chroma=None, quant_offsets=None):
         """Feed a whole clip.  paced=True interleaves put/get exactly like x264_encoder_encode; paced=False puts
         every frame first (deep prefetch) -- results are identical, only the batching differs."""
         outs = []
@@ -680,7 +704,10 @@ class Lookahead:
         for i in range(n_loop):
             ft = int(forced_types[i]) if forced_types is not None else 0
             ts = None if pts is None else int(pts[i])
-            if chroma is not None:
+            if quant_offsets is not None:
+                self.put_pic(frames[i], None if chroma is None else chroma[0][i], None if chroma is None else chroma[1][i], forced_type=ft, pts=ts,
+                             quant_offsets=quant_offsets[i])
+            elif chroma is not None:
                 self.put_picture(frames[i], chroma[0][i], chroma[1][i], forced_type=ft, pts=ts)
             elif frames is not None:
                 self.put(frames[i], forced_type=ft, pts=ts)
