@@ -483,6 +483,9 @@ def la_config(width, height, preset="medium", bit_depth=8, tune="", **over):
             c["b_pyramid"] = 1
         c["frame_refs"] = 1
         c["open_gop"] = 0
+    if "fps" in over and "fps_num" not in over:                              # a plain frame rate: x264_param_parse's "fps" (base.c:1056-1065)
+        c["fps_num"], c["fps_den"] = int(round(float(c["fps"]) * 1000)), 1000
+    c["fps"] = float(np.float32(c["fps_num"]) / np.float32(c["fps_den"]))     # :1107 float fps
     if c["keyint_min"] <= 0:                                                 # :1109-1111 (0 = X264_KEYINT_MIN_AUTO)
         c["keyint_min"] = min(c["keyint_max"] // 10, int(c["fps"]))
     c["keyint_min"] = clip(c["keyint_min"], 1, c["keyint_max"] // 2 + 1)
