@@ -376,6 +376,8 @@ int  x264hip_lookahead_open( x264hip_lookahead **out, int device, const x264hip_
 int  x264hip_lookahead_open_backend( x264hip_lookahead **out, const x264hip_la_params *params, const x264hip_backend *backend );
 void x264hip_lookahead_close( x264hip_lookahead *la );
 int  x264hip_lookahead_reset( x264hip_lookahead *la ); /* start a new sequence on the same context */
+/* pictures put but not yet returned by get_frame (the lookahead's share of x264_encoder_delayed_frames, encoder.c:4480-4500) */
+int  x264hip_lookahead_delayed_frames( x264hip_lookahead *la );
 x264hip_ctx *x264hip_lookahead_ctx( x264hip_lookahead *la ); /* NULL for plugin backends */
 int  x264hip_lookahead_delay( x264hip_lookahead *la );       /* h->frames.i_delay */
 /* forced_type: X264_TYPE_AUTO (0) normally */

@@ -429,13 +429,19 @@ def test_api_misuse_is_reported():
     la = lib.Lookahead(cfg, backend=be.struct, max_frames=cfg["rc_lookahead"] + cfg["bframes"] + 8)
     try:
         assert la.get() is None and la.get(flush=True) is None            # nothing queued: not an error, just nothing
+        assert la.L.x264hip_lookahead_delayed_frames(la.h) == 0
         fr = make_clip(W, H, 80, seed=1)
         with pytest.raises(lib.X264HipError):                             # more frames than slots without draining
             for i in range(80):
                 la.put(fr[i])
         la.reset()                                                        # the context stays usable
+        for i in range(10):
+            la.put(fr[i])
+        assert la.L.x264hip_lookahead_delayed_frames(la.h) == 10
+        la.reset()
         outs = la.run(fr[:30])
         assert [o.frame for o in sorted(outs, key=lambda o: o.frame)] == list(range(30))
+        assert la.L.x264hip_lookahead_delayed_frames(la.h) == 0
     finally:
         la.close()
     import ctypes as C

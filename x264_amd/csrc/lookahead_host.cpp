@@ -1088,6 +1088,11 @@ extern "C" int x264hip_lookahead_reset( x264hip_lookahead *la )
     return X264HIP_OK;
 }
 
+extern "C" int x264hip_lookahead_delayed_frames( x264hip_lookahead *la )
+{
+    return la ? (int)( la->L.next.size() + la->L.current.size() ) : X264HIP_EINVAL;
+}
+
 extern "C" x264hip_ctx *x264hip_lookahead_ctx( x264hip_lookahead *la ) { return la ? la->L.ctx : nullptr; }
 extern "C" int x264hip_lookahead_delay( x264hip_lookahead *la ) { return la ? la->L.i_delay : X264HIP_EINVAL; }
 
