@@ -27,5 +27,13 @@ def test_in_own_process(function):
     except subprocess.TimeoutExpired as e:
         print((e.stdout or b"").decode(errors="replace")[-4000:])
         pytest.fail("%s timed out" % function)
-    print(r.stdout.decode(errors="replace")[-6000:])
+    text = r.stdout.decode(errors="replace")
+    print(text[-6000:])
+    try:  # keep the child's report where a gpurun call brings it back (xfailed tests do not show their output by default)
+        d = os.path.join(ROOT, "gpurun_out", "zz_new_configs")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, function + ".log"), "w") as f:
+            f.write(text)
+    except OSError:
+        pass
     assert r.returncode == 0, "%s: pytest exit code %d" % (function, r.returncode)
