@@ -1383,8 +1383,11 @@ uint64_t ORN(aq_frame_fmt)( const pixel *luma, int stride, int width, int height
     }
     free( av_r8 );
     uint64_t n = (uint64_t)( 16*mb_w ) * ( 16*mb_h );
-    if( ssd_out ) *ssd_out = ssd_y - ( sum_y*sum_y + n/2 ) / n;
-    return sum_y;
+    /* i_pixel_sum is uint32_t in the reference (common/frame.h:140): the total has wrapped mod 2^32 before ratecontrol.c:410-414
+     * squares it (bright 10-bit pictures from ~4.2 Mpx on) */
+    const uint64_t s32 = (uint32_t)sum_y;
+    if( ssd_out ) *ssd_out = ssd_y - ( s32*s32 + n/2 ) / n;
+    return s32; /* i_pixel_sum[0] as the reference stores it */
 }
 
 /* slicetype_frame_cost_recalculate (slicetype.c:999-1024): the frame cost of an already evaluated cell under new per-MB

@@ -37,7 +37,7 @@ LOOKAHEAD_CASES = {
 
 # Configurations whose device paths were written after the last GPU session of round 1 (edge ring not evaluated, lookahead
 # bands, auto-variance AQ, constant QP, the two fastest presets): same fixtures and checks, but their GPU tests live in
-# tests/test_zz_gpu_new_configs.py, which sorts last, so that a failure there cannot hide the results of the other files.
+# tests/test_gpu_configs.py.
 LOOKAHEAD_CASES_R2 = {
     "no_mbtree": ("medium", "mbtree=0,bframes=5,b-adapt=2,rc-lookahead=30", dict(mb_tree=0, bframes=5, b_adapt=2, rc_lookahead=30),
                   8, 176, 144, dict(seed=14, scene_cuts=(19,), fade=(30, 8, 0.6, 5)), 50),

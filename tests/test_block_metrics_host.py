@@ -1,7 +1,7 @@
 """The arithmetic of x264_amd/csrc/block_metrics.h (the functions the batched device kernels call for ssd / sa8d / var /
 hadamard_ac / vsad / asd8) compiled for the host by tests/tools/block_metrics_host.cpp and checked against the oracle, which is
 itself pinned against the reference vtables (tests/test_primitives_vs_ref.py).  The GPU test of the same entry points is in
-tests/test_zz_gpu_new_configs.py."""
+tests/test_gpu_configs.py."""
 import ctypes as C
 import os
 import subprocess

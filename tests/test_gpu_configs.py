@@ -1,5 +1,4 @@
-"""(Run through tests/test_zz_gpu_new_configs.py, which executes every test function of this file in its own process.)
-GPU end-to-end for the configurations whose device paths were written after the last GPU session of round 1: edge ring
+"""GPU end-to-end for the configurations beyond the BASELINE ones (all verified on hardware since round 1): edge ring
 not evaluated (no MB-tree: --no-mbtree, --qp, superfast / ultrafast, qcomp 1), lookahead bands (lookahead_threads > 1),
 auto-variance AQ (aq-mode 2 / 3), constant QP, VBV lookahead, the batched main-encode block metrics.  Same golden fixtures and
 checks as tests/test_gpu_lookahead.py."""

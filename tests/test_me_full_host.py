@@ -1,7 +1,7 @@
 """The main-encode motion search of x264_amd/csrc/me_full.h (the body of me_full_kernel: x264_me_search_ref with DIA / HEX / UMH /
 ESA / TESA + refine_subpel, one thread per request) compiled for the host by tests/tools/block_metrics_host.cpp, against the
 results recorded from the reference (tests/golden/me_full_d{8,10}.npz, 2 x 600 calls over all methods, partition sizes and subme
-levels).  The GPU test of the same code is tests/zz_gpu_new_configs_impl.py::test_me_search_batch."""
+levels).  The GPU test of the same code is tests/test_gpu_configs.py::test_me_search_batch."""
 import ctypes as C
 import os
 

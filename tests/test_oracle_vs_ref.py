@@ -195,3 +195,25 @@ def test_adaptive_quant_with_chroma(depth):
             iq_o, _, s, ssd = o.aq_frame(y, (W + 15) // 16, (H + 15) // 16, mode, strength, cb, cr)
             assert np.array_equal(iq, iq_o), (W, H, mode)
             assert (s, ssd) == ss
+
+
+def test_pixel_sum_wraps_like_the_reference():
+    """i_pixel_sum is a uint32_t (common/frame.h:140): on a bright 10-bit 4K picture the luma total exceeds 2^32 and the
+    reference squares the WRAPPED value when it removes the mean from i_pixel_ssd (ratecontrol.c:405-414).  The oracle (and
+    x264hip_frame_stats, which the GPU suite compares with the oracle) must reproduce exactly that."""
+    if not refharness.available(10):
+        pytest.skip("no reference build for this depth")
+    W, H = 3840, 2160
+    rng = np.random.default_rng(3)
+    y = (900 + rng.integers(0, 100, (H, W))).astype(np.uint16)
+    assert int(y.astype(np.uint64).sum()) > 1 << 32
+    r = refharness.Ref(W, H, "medium", bit_depth=10)
+    try:
+        r.add_frame(y)
+        iq, _, ss = r.frame_stats(0)
+    finally:
+        r.close()
+    o = Oracle(10)
+    iq_o, _, s, ssd = o.aq_frame(y, (W + 15) // 16, (H + 15) // 16, 1, 1.0)
+    assert np.array_equal(iq, iq_o)
+    assert (s, ssd) == ss

@@ -7,8 +7,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, "csrc", "x264hip.hip"), os.path.join(HERE, "csrc", "lookahead_host.cpp")]
-HDR = [os.path.join(HERE, "csrc", h) for h in ("device_common.h", "me_search.h", "la_kernels.h", "lookahead_host.h")] + \
-      [os.path.join(ROOT, "include", "x264hip.h")]
+import glob
+HDR = sorted(glob.glob(os.path.join(HERE, "csrc", "*.h"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
 OUT = os.path.join(HERE, "libx264hip.so")
 
 

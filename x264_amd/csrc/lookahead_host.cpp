@@ -1249,6 +1249,8 @@ extern "C" int x264hip_lookahead_get_frame_vbv( x264hip_lookahead *la, int flush
         return X264HIP_OK;
     LaFrame *f = L.current.front();
     L.current.pop_front();
+    // the frame has left the queue: whatever happens below (a backend error while fetching the extra outputs), its slot goes back
+    struct Release { Lookahead &L; LaFrame *f; ~Release() { L.release( f ); } } release_on_exit{ L, f };
     out->frame = f->i_frame; out->type = f->i_type; out->bframes = f->i_bframes; out->keyframe = f->b_keyframe;
     for( int i = 0; i < BMAX + 2; i++ )
     {
@@ -1295,7 +1297,6 @@ extern "C" int x264hip_lookahead_get_frame_vbv( x264hip_lookahead *la, int flush
         if( L.need( L.be.get_row_satds( L.be.user, f->slot, f->own_d0, f->own_d1, row_satds ) ) ) return L.err;
     if( row_satds_intra && f->cost_est[0][0] >= 0 ) // computed by any evaluation that found them missing, B evaluations included (slicetype.c:714-757)
         if( L.need( L.be.get_row_satds( L.be.user, f->slot, 0, 0, row_satds_intra ) ) ) return L.err;
-    L.release( f );
     return X264HIP_OK;
 }
 

@@ -471,7 +471,8 @@ static void slot_reset( x264hip_ctx *ctx, FrameSlot &s )
 extern "C" int x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, int stride, int is_device, const void *cb, const void *cr,
                                   int cstride, const uint16_t *inv_qscale )
 {
-    if( !ctx || !slot_ok( ctx, slot ) || !luma || stride < ctx->p.width ) return X264HIP_EINVAL;
+    if( !ctx || !slot_ok( ctx, slot ) || !luma || stride < ctx->p.width || ( !cb ) != ( !cr ) ) return X264HIP_EINVAL;
+    if( cb && cstride < ( ctx->p.chroma_format == 3 ? ctx->p.width : ( ctx->p.width + 1 ) >> 1 ) ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     FrameSlot &s = ctx->slots[slot];
@@ -497,7 +498,6 @@ extern "C" int x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, 
             // of the previous frame's chroma has been consumed
             const int cw = p.chroma_format == 3 ? p.width : ( p.width + 1 ) >> 1, ch = p.chroma_format >= 2 ? p.height : ( p.height + 1 ) >> 1;
             const size_t crow = (size_t)cw * ctx->psz, cplane = crow * ch;
-            if( cstride < cw ) return X264HIP_EINVAL;
             if( !ctx->chroma_staging )
             {
                 HIPCK( hipHostMalloc( &ctx->chroma_staging, 2 * cplane ) );
@@ -583,8 +583,10 @@ extern "C" int x264hip_frame_stats( x264hip_ctx *ctx, int slot, uint64_t *pixel_
         {
             FrameSlot &f = ctx->slots[i];
             const unsigned long long sum = ctx->stats_host[2 * i], sq = ctx->stats_host[2 * i + 1];
-            f.sum = sum;
-            f.ssd = sq - ( sum * sum + n / 2 ) / n; // ratecontrol.c:405-414
+            f.sum = (uint32_t)sum;
+            // i_pixel_sum is a uint32_t in the reference (common/frame.h:140): the total has wrapped before it is squared
+            const uint64_t s32 = (uint32_t)sum;
+            f.ssd = sq - ( s32 * s32 + n / 2 ) / n; // ratecontrol.c:405-414
             f.stats_valid = 1;
         }
     }
@@ -1036,6 +1038,16 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     const int nstride = ctx->p.bframes + 2;
+    // validate the whole list first: nothing below (accumulator swaps, the ring entry) may happen for a list that is rejected
+    for( int i = 0; i < n; i++ )
+    {
+        const x264hip_mbtree_op &o = ops[i];
+        if( !slot_ok( ctx, o.slot_b ) || !slot_ok( ctx, o.slot_p0 ) || !slot_ok( ctx, o.slot_p1 ) || o.type < 0 || o.type > X264HIP_MBT_RESET_QP )
+            return X264HIP_EINVAL;
+        if( o.type == X264HIP_MBT_PROPAGATE || o.type == X264HIP_MBT_FINISH )
+            if( o.dist_p0 < 0 || o.dist_p1 < 0 || o.dist_p0 + o.dist_p1 > ctx->p.bframes + 1 || ( o.type == X264HIP_MBT_PROPAGATE && o.dist_p0 < 1 ) )
+                return X264HIP_EINVAL;
+    }
     const int r = ctx->mbt_next;
     ctx->mbt_next = ( r + 1 ) % x264hip_ctx::MBT_RING;
     if( ctx->mbt_pending >= x264hip_ctx::MBT_RING )
@@ -1049,8 +1061,6 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
     for( int i = 0; i < n; i++ )
     {
         const x264hip_mbtree_op &o = ops[i];
-        if( !slot_ok( ctx, o.slot_b ) || !slot_ok( ctx, o.slot_p0 ) || !slot_ok( ctx, o.slot_p1 ) || o.type < 0 || o.type > X264HIP_MBT_RESET_QP )
-            return X264HIP_EINVAL;
         if( o.type == X264HIP_MBT_SWAP )
             std::swap( ctx->slots[o.slot_b].prop, ctx->slots[o.slot_p0].prop );
         else if( o.type == X264HIP_MBT_RESET_QP )
@@ -1070,8 +1080,6 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
     {
         const int i = k;
         const x264hip_mbtree_op &o = ops[order[k]];
-        if( o.dist_p0 < 0 || o.dist_p1 < 0 || o.dist_p0 + o.dist_p1 > ctx->p.bframes + 1 )
-            return X264HIP_EINVAL;
         FrameSlot &b = ctx->slots[o.slot_b];
         MbtOpDev d;
         memset( &d, 0, sizeof( d ) );
@@ -1084,7 +1092,6 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
         d.lowres_costs = b.lowres_costs + (size_t)( o.dist_p0 * nstride + o.dist_p1 ) * ctx->n_mb;
         if( o.type == X264HIP_MBT_PROPAGATE )
         {
-            if( o.dist_p0 < 1 ) return X264HIP_EINVAL;
             d.mvq0 = b.mvq[0][o.dist_p0 - 1];
             d.mvq1 = o.dist_p1 > 0 ? b.mvq[1][o.dist_p1 - 1] : nullptr;
         }
