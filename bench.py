@@ -120,24 +120,33 @@ def primitives_bench(torch, libmod, cfg, iters=30):
     return out
 
 
-def cpu_baseline(cfg, frames, preset, opts):
-    """Reference C path (oracle/_ref, built from /root/reference) timed on this box's host cores, 1 thread;
-    falls back to the CPU port (oracle restatement behind the host logic) when the reference build is absent."""
+def cpu_baseline(cfg, frames, preset, opts, lookahead_threads=None):
+    """Reference C path (oracle/_ref, built from /root/reference) timed on this box's host cores;
+    falls back to the CPU port (oracle restatement behind the host logic) when the reference build is absent.
+    lookahead_threads: None = the configuration as given (1 thread for the parity configuration); N > 1 = the reference's own
+    lookahead threading (i_lookahead_threads bands of a frame searched concurrently, encoder/encoder.c:1273-1300,
+    slicetype.c:917-944) -- a different configuration as far as results go (bands do not see each other's vectors)."""
     n = len(frames)
     try:
         from oracle import refharness
         if refharness.available(cfg["bit_depth"]):
+            nt = cfg["lookahead_threads"]
+            if lookahead_threads and lookahead_threads > 1:
+                nt = lookahead_threads
+                opts += ",threads=%d,sync-lookahead=0,lookahead-threads=%d" % (max(nt, 2), nt)
             r = refharness.Ref(cfg["width"], cfg["height"], preset, opts=opts, bit_depth=cfg["bit_depth"])
             try:
                 res = r.lookahead_run(frames)
             finally:
                 r.close()
-            return dict(value=round(n / res["seconds"], 2), unit="frames/s", cores=cfg["lookahead_threads"], kind="reference",
+            return dict(value=round(n / res["seconds"], 2), unit="frames/s", cores=nt, kind="reference", host_cores=os.cpu_count(),
                         sample="%d frames %dx%d, reference C path (--disable-asm, no AVX2: no assembler in the build image), "
                                "%d lookahead thread(s); lowres init + lookahead only, AQ excluded (%.2f s)" %
-                               (n, cfg["width"], cfg["height"], cfg["lookahead_threads"], res["seconds"]))
+                               (n, cfg["width"], cfg["height"], nt, res["seconds"]))
     except Exception as e:  # pragma: no cover
         print("cpu_baseline: reference unavailable (%s), using the port" % e, file=sys.stderr)
+    if lookahead_threads and lookahead_threads > 1:
+        return None  # the port is single-threaded
     from tests.oracle_backend import OracleBackend
     from x264_amd import lib
     be = OracleBackend(cfg)
@@ -151,6 +160,101 @@ def cpu_baseline(cfg, frames, preset, opts):
     return dict(value=round(n / dt, 2), unit="frames/s", cores=1, kind="port", sample="%d frames %dx%d, oracle restatement, 1 thread" % (n, cfg["width"], cfg["height"]))
 
 
+def make_clip_device(torch, W, H, F, seed, bit_depth=8, scene_cuts=(), pan=(5, 3), noise=3, texture=0.18):
+    """The synthetic recipe of x264_amd/synth.py (smooth random field, per-frame pan, +-noise, inversion at scene cuts) generated
+    on the device with torch: used for the 4K workload, where the numpy generator would take longer than the benchmark."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    fh, fw = H + 128 + 8, W + 256 + 8
+    field = torch.rand((1, 1, fh, fw), generator=g, device="cuda", dtype=torch.float32)
+    for _ in range(4):
+        field = torch.nn.functional.avg_pool2d(field, 5, stride=1, padding=2, count_include_pad=False)
+    field = field[0, 0]
+    field = (field - field.min()) / max(float(field.max() - field.min()), 1e-9)
+    field = (1.0 - texture) * field + texture * torch.rand(field.shape, generator=g, device="cuda")
+    field = 16.0 + field * 219.0
+    cuts = sorted(set(int(c) for c in scene_cuts))
+    scale, maxv = 1 << (bit_depth - 8), (1 << bit_depth) - 1
+    out = torch.empty((F, H, W), dtype=torch.uint8 if bit_depth == 8 else torch.int16, device="cuda")
+    for i in range(F):
+        dx, dy = (pan[0] * i) % 256, (pan[1] * i) % 128
+        img = field[dy:dy + H, dx:dx + W]
+        if sum(1 for c in cuts if c <= i) & 1:
+            img = 255.0 - img
+        img = img + torch.randint(-noise, noise + 1, img.shape, generator=g, device="cuda")
+        out[i] = torch.clamp(torch.round(img * scale), 0, maxv).to(out.dtype)
+    return out
+
+
+def outputs_signature(outs, nb):
+    """(frame, type) in coded order + every cost cell: what two runs of the same clip must agree on"""
+    return [(o.frame, o.type, tuple(o.cost_est[i][j] for i in range(nb) for j in range(nb))) for o in outs]
+
+
+class Workload:
+    """S independent GOP segments of F frames resident in HBM on this rank's GPU, one lookahead context (and host thread) each."""
+
+    def __init__(self, torch, lib, shard, cfg, dev_index, rank, S, F, seg_dev, paced, dist=None, backend="nccl", world=1):
+        import concurrent.futures
+        self.torch, self.lib, self.shard, self.cfg, self.rank, self.S, self.F, self.world = torch, lib, shard, cfg, rank, S, F, world
+        self.W = cfg["width"]
+        self.seg_dev = seg_dev
+        self.seg_ptrs = [[dv[i].data_ptr() for i in range(F)] for dv in seg_dev]
+        self.las = [lib.Lookahead(cfg, device=dev_index, max_frames=F + 4) for _ in range(S)]
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=S) if S > 1 else None
+        self.paced = paced
+        self.dist, self.backend = dist, backend
+        self.gathered = None
+
+    def run_segment(self, sgi, n_steps, paced):
+        """n_steps passes of segment slot sgi, back to back.  The segment slots of a GPU are independent pipelines: they do
+        not wait for each other between steps, so one slot's decision phases drift against the other's kernel phases
+        instead of being re-aligned at every step (every step of every slot still completes inside the timed region)."""
+        la = self.las[sgi]
+        summaries, outs = [], None
+        for k in range(n_steps):
+            la.reset()
+            outs = la.run(device_ptrs=self.seg_ptrs[sgi], stride=self.W, paced=paced)
+            assert len(outs) == self.F
+            summaries.append(self.shard.summarize(outs, (self.rank * self.S + sgi) * self.F))
+        return outs, summaries
+
+    def run_steps(self, n_steps, paced=None):
+        """returns the outputs of the last step of every segment slot"""
+        paced = self.paced if paced is None else paced
+        if n_steps <= 0:
+            return None
+        if self.pool is None:
+            res = [self.run_segment(0, n_steps, paced)]
+        else:
+            res = list(self.pool.map(lambda sgi: self.run_segment(sgi, n_steps, paced), range(self.S)))  # ctypes calls release the GIL
+        for k in range(n_steps):
+            host = np.concatenate([r[1][k] for r in res])
+            if self.dist is not None:
+                # the only exchange of the path: per-frame summaries (16 B per frame), one all_gather per step
+                self.gathered = self.shard.gather_summaries(host, self.dist, device="cuda" if self.backend == "nccl" else None)
+        return [r[0] for r in res]
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def timed(self, steps, warmup, paced=None):
+        self.run_steps(warmup, paced)
+        self.barrier()
+        t0 = time.perf_counter()
+        outs = self.run_steps(steps, paced)
+        self.barrier()
+        return time.perf_counter() - t0, outs
+
+    def close(self):
+        for la in self.las:
+            la.close()
+        if self.pool is not None:
+            self.pool.shutdown()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,6 +266,7 @@ def main():
     ap.add_argument("--preset", default="slow")
     ap.add_argument("--bit-depth", type=int, default=8, choices=(8, 10))
     ap.add_argument("--me", default="dia")
+    ap.add_argument("--me-range", type=int, default=0)
     ap.add_argument("--threads", type=int, default=1,
                     help="x264 --threads of the mirrored configuration: > 1 turns on the reference's automatic lookahead bands "
                          "(i_lookahead_threads, encoder.c:1273-1300); 1 = the --threads 1 parity configuration")
@@ -171,6 +276,10 @@ def main():
                          "segment overlap the device work of the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-primitives", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the additional lines (paced figure, 4K configs[2], threaded CPU baseline)")
+    ap.add_argument("--no-check", action="store_true", help="skip the untimed verification pass in the other batching mode (profiling runs only: "
+                                                              "its launches would mix into the per-kernel counters)")
+    ap.add_argument("--device-clip", action="store_true", help="generate the clips on the device (no CPU baseline possible)")
     ap.add_argument("--cpu-frames", type=int, default=96)
     args = ap.parse_args()
 
@@ -200,65 +309,37 @@ def main():
             dist.init_process_group(backend)
 
     W, H, F = args.width, args.height, args.frames
-    cfg = lib.la_config(W, H, args.preset, bit_depth=args.bit_depth, me=args.me, threads=args.threads)
-    # every rank gets its own segment of the synthetic sequence (different seed = different content)
+    over = dict(me=args.me, threads=args.threads)
+    if args.me_range:
+        over["me_range"] = args.me_range
+    cfg = lib.la_config(W, H, args.preset, bit_depth=args.bit_depth, **over)
+    nb = cfg["bframes"] + 2
     S = max(1, args.inflight)
     # every (rank, segment) gets its own part of the synthetic sequence (different seed = different content)
-    seg_frames, seg_dev, seg_ptrs, las = [], [], [], []
+    seg_frames, seg_dev = [], []
     for sgi in range(S):
-        fr = make_clip(W, H, F, seed=100 + rank * S + sgi, bit_depth=args.bit_depth, scene_cuts=(F // 3, F // 3 + 47), fade=(2 * F // 3, 10, 0.6, 12),
-                       pan=(5, 3))
-        dv = torch.from_numpy(fr).cuda(dev_index)
-        seg_frames.append(fr); seg_dev.append(dv); seg_ptrs.append([dv[i].data_ptr() for i in range(F)])
-        las.append(lib.Lookahead(cfg, device=dev_index, max_frames=F + 4))
+        if args.device_clip:
+            dv = make_clip_device(torch, W, H, F, 100 + rank * S + sgi, args.bit_depth, scene_cuts=(F // 3, F // 3 + 47))
+            fr = None
+        else:
+            fr = make_clip(W, H, F, seed=100 + rank * S + sgi, bit_depth=args.bit_depth, scene_cuts=(F // 3, F // 3 + 47), fade=(2 * F // 3, 10, 0.6, 12),
+                           pan=(5, 3))
+            dv = torch.from_numpy(fr).cuda(dev_index)
+        seg_frames.append(fr); seg_dev.append(dv)
     frames = seg_frames[0]
     torch.cuda.synchronize()
-    gathered = [None]
+    wl = Workload(torch, lib, shard, cfg, dev_index, rank, S, F, seg_dev, args.paced, dist, backend, world)
+    las = wl.las
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    import concurrent.futures
-    pool = concurrent.futures.ThreadPoolExecutor(max_workers=S) if S > 1 else None
-
-    def run_segment(sgi, n_steps):
-        """n_steps passes of segment slot sgi, back to back.  The segment slots of a GPU are independent pipelines: they do
-        not wait for each other between steps, so one slot's decision phases drift against the other's kernel phases
-        instead of being re-aligned at every step (every step of every slot still completes inside the timed region)."""
-        la = las[sgi]
-        summaries, outs = [], None
-        for k in range(n_steps):
-            la.reset()
-            outs = la.run(device_ptrs=seg_ptrs[sgi], stride=W, paced=args.paced)
-            assert len(outs) == F
-            summaries.append(shard.summarize(outs, (rank * S + sgi) * F))
-        return outs, summaries
-
-    def run_steps(n_steps):
-        if n_steps <= 0:
-            return None
-        if pool is None:
-            res = [run_segment(0, n_steps)]
-        else:
-            res = list(pool.map(lambda sgi: run_segment(sgi, n_steps), range(S)))  # ctypes calls release the GIL: the slots really overlap
-        for k in range(n_steps):
-            host = np.concatenate([r[1][k] for r in res])
-            if dist is not None:
-                # the only exchange of the path: per-frame summaries (16 B per frame), one all_gather per step
-                gathered[0] = shard.gather_summaries(host, dist, device="cuda" if backend == "nccl" else None)
-        return res[0][0]
-
-    run_steps(args.warmup)
-    barrier()
+    wl.run_steps(args.warmup)
+    wl.barrier()
     for la in las:
         lib.search_profile(la.L, la.ctx_handle(), 1)
     t0 = time.perf_counter()
-    outs = run_steps(args.steps)
-    barrier()
+    outs_all = wl.run_steps(args.steps)
+    wl.barrier()
     dt = time.perf_counter() - t0
+    outs = outs_all[0]
     prof_ms = prof_launches = prof_searches = 0
     la_stats = np.zeros(8, np.uint64)
     dev_counters = np.zeros(8, np.uint64)
@@ -275,23 +356,36 @@ def main():
     dt = float(tmax.item())
     types = "".join("?IiPbB"[o.type] for o in sorted(outs, key=lambda o: o.frame))
     if dist is not None:
-        g = gathered[0]
+        g = wl.gathered
         assert g.shape == (world * S * F, 4) and sorted(g[:, 0].tolist()) == list(range(world * S * F)), "gathered summaries incomplete"
-    for la in las:
-        la.close()
-    if pool is not None:
-        pool.shutdown()
+
+    # ---- what was timed is what the reference would decide: one untimed pass of every segment in the other batching mode
+    # (encoder-paced when the timed passes were deep-prefetch batches and vice versa) must give the same frame types and the
+    # same cost cells, frame for frame; its wall time is the figure of the other mode.
+    other_paced = not args.paced
+    other_fps = None
+    if not args.no_check:
+        dt_other, outs_other = wl.timed(1, 0, paced=other_paced)
+        for sgi in range(S):
+            a, b = outputs_signature(outs_all[sgi], nb), outputs_signature(outs_other[sgi], nb)
+            assert a == b, "segment %d: %s and %s passes disagree (first difference at output %d)" % (
+                sgi, "paced" if args.paced else "batched", "paced" if other_paced else "batched", next(i for i, (x, y) in enumerate(zip(a, b)) if x != y))
+        other_fps = round(S * F / dt_other, 2)
+    wl.close()
 
     if rank == 0:
         bytes_per_search = algorithmic_bytes_per_search(cfg)
         achieved = (prof_searches * bytes_per_search / 1e9) / (prof_ms / 1e3) if prof_ms > 0 else 0.0
-        traffic = None
+        traffic = tsrc = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                per_search = json.load(open(tpath)).get("me_rows_kernel_hbm_bytes_per_search")
-                # PMC pass (profiles/*_pmc_summary.json) is per search; one launch of this run carries searches/launches of them
+                tj = json.load(open(tpath))
+                per_search = tj.get("me_rows_kernel_hbm_bytes_per_search")
+                # PMC passes are separate runs of this command (profiles/*_pmc_summary.json), reduced to bytes per search; one launch of
+                # THIS run carried searches/launches of them
                 traffic = round(per_search * prof_searches / max(prof_launches, 1)) if per_search and W == 1920 else None
+                tsrc = "%s: FETCH_SIZE + WRITE_SIZE passes of this command under rocprofv3 (not this run), per search x this run's searches per launch" % tj.get("source")
             except Exception:
                 traffic = None
         res = {
@@ -316,12 +410,15 @@ def main():
                                     S, F, "encoder-paced" if args.paced else "deep-prefetch batch"),
                        "frames_per_step": S * F, "segments_in_flight": S, "bframes": cfg["bframes"], "b_adapt": cfg["b_adapt"], "rc_lookahead": cfg["rc_lookahead"],
                        "parallelism": "gop-segments x%d" % world, "slice_types": types[:64]},
+            "checked": None if args.no_check else "types + every cost cell of the timed passes == one untimed %s pass of the same segments" % ("encoder-paced" if other_paced else "batched"),
+            ("paced_fps" if other_paced else "batched_fps"): other_fps,
             "roofline": {"bound": "hbm", "kernel": "me_rows_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
                          "launches": prof_launches, "searches": prof_searches, "avg_launch_ms": round(prof_ms / max(prof_launches, 1), 4),
+                         "us_per_search": round(prof_ms * 1e3 / max(prof_searches, 1), 3),
                          "algorithmic_bytes_per_search": bytes_per_search,
-                         "note": "not a streaming kernel: ~80% VALU-issue bound (PMC: ~550 VALU per block search, 4 clocks each), HBM traffic "
-                                 "below the algorithmic bytes; see DESIGN.md section 3"},
+                         "note": "not a streaming kernel (dependent candidate rounds per block): HBM traffic is below the algorithmic bytes; the "
+                                 "ceiling that binds and its counters are in profiles/ (DESIGN.md section 3)"},
             "lookahead_stats": {"frame_cost_calls": int(la_stats[0]), "evaluations": int(la_stats[1]),
                                 "weights_analysed": int(la_stats[2]), "weights_kept": int(la_stats[3]),
                                 "device": {"searches": int(dev_counters[0]), "cell_requests": int(dev_counters[1]), "cell_hits": int(dev_counters[4]),
@@ -330,21 +427,71 @@ def main():
                                 "host_ms": {"frame_cost": round(la_stats[4] / 1e6, 2), "weights_analyse": round(la_stats[5] / 1e6, 2),
                                             "prefetch_mbtree": round(la_stats[6] / 1e6, 2), "api_total": round(la_stats[7] / 1e6, 2)}},
         }
+        ipath = os.path.join(ROOT, "profiles", "search_issue.json")
+        if os.path.exists(ipath):
+            try:
+                res["roofline_issue"] = issue_roofline(json.load(open(ipath)), prof_ms, prof_searches, cfg)
+            except Exception as e:  # pragma: no cover
+                res["roofline_issue"] = {"error": str(e)}
+        if world == 1 and not args.no_extra and (W, H) == (1920, 1080):
+            # BASELINE configs[2]: 3840x2160, --preset slower --me umh --merange 32 (the lookahead searches with HEX, range 32, b-adapt 2,
+            # rc-lookahead 60), clips generated on the device; same check (batched == paced) as above
+            try:
+                F4 = 64
+                cfg4 = lib.la_config(3840, 2160, "slower", bit_depth=8, me="umh", me_range=32)
+                dev4 = [make_clip_device(torch, 3840, 2160, F4, 300 + sgi, 8, scene_cuts=(F4 // 3,)) for sgi in range(S)]
+                wl4 = Workload(torch, lib, shard, cfg4, dev_index, 0, S, F4, dev4, False)
+                try:
+                    dt4, o4 = wl4.timed(2, 1)
+                    dtp4, op4 = wl4.timed(1, 0, paced=True)
+                    nb4 = cfg4["bframes"] + 2
+                    for sgi in range(S):
+                        assert outputs_signature(o4[sgi], nb4) == outputs_signature(op4[sgi], nb4), "4K: batched and paced passes disagree"
+                finally:
+                    wl4.close()
+                del dev4
+                res["configs2_4k"] = {"workload": "3840x2160 8-bit, --preset slower --me umh --merange 32 (BASELINE configs[2]), %d segment(s) of %d frames "
+                                                  "in flight, clips generated on the device" % (S, F4),
+                                      "value": round(S * F4 * 2 / dt4, 2), "unit": "frames/s", "paced_fps": round(S * F4 / dtp4, 2),
+                                      "checked": "batched == paced (types + cost cells)"}
+            except Exception as e:  # pragma: no cover
+                res["configs2_4k"] = {"error": str(e)}
         if not args.no_primitives:
             try:
                 res["primitives"] = primitives_bench(torch, lib, dict(cfg, width=3840, height=2160))
             except Exception as e:  # pragma: no cover
                 res["primitives"] = {"error": str(e)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and frames is not None:
             n = min(F, args.cpu_frames)
             opts = "me=%s" % args.me
+            if args.me_range:
+                opts += ",merange=%d" % args.me_range
             if args.threads > 1:  # same bands on the CPU side (the harness drives the lookahead synchronously)
                 opts += ",threads=%d,sync-lookahead=0,lookahead-threads=%d" % (args.threads, cfg["lookahead_threads"])
             res["cpu_baseline"] = cpu_baseline(cfg, frames[:n], args.preset, opts)
+            if not args.no_extra and args.threads == 1:
+                # the same clip with the reference's own lookahead threading on all host cores (bands of a frame in parallel; at most
+                # X264_LOOKAHEAD_THREAD_MAX = 16, and at most mb_h / 4 ... of them)
+                nt = max(2, min(16, os.cpu_count() or 2))
+                mt = cpu_baseline(cfg, frames[:n], args.preset, opts, lookahead_threads=nt)
+                if mt:
+                    res["cpu_baseline_threads"] = mt
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def issue_roofline(prof, prof_ms, prof_searches, cfg):
+    """Second roofline of the search kernel, against the ceiling that binds it: vector-ALU issue slots.  profiles/search_issue.json
+    holds wave-level VALU instructions per block search from the SQ_INSTS_VALU pass of this command; a wave64 VALU instruction
+    occupies its SIMD for 2 cycles (MI355X_MICROARCH.md: SIMD-32), 1024 SIMDs at 2.4 GHz."""
+    blocks = ((cfg["width"] + 15) // 16) * ((cfg["height"] + 15) // 16)
+    valu = prof["valu_per_block"]
+    achieved = prof_searches * blocks * valu / (prof_ms / 1e3) if prof_ms > 0 else 0.0
+    peak = 1024 * 2.4e9 / 2
+    return {"bound": "valu-issue", "kernel": "me_rows_kernel", "achieved": round(achieved / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-instr/s",
+            "frac": round(achieved / peak, 4), "valu_per_block": valu, "source": prof.get("source")}
 
 
 if __name__ == "__main__":

@@ -90,6 +90,30 @@ def test_batching_invariance_full_size(W, H, preset, over, nf):
     assert sorted(f for f, _ in _types(res[0])) == list(range(nf))
 
 
+def test_batching_invariance_8k_10bit():
+    """BASELINE configs[4] (7680x4320 10-bit, --preset veryslow --me tesa): encoder-paced and deep-prefetch runs of a dozen frames
+    give identical decisions, cost cells and quantiser offsets."""
+    from tests.test_gpu_parity import upscaled_clip
+    W, H, nf = 7680, 4320, 12
+    frames = upscaled_clip(W, H, nf, 10, seed=44, scene_cuts=(7,), pan=(5, 3))
+    cfg = lib.la_config(W, H, "veryslow", bit_depth=10, me="tesa")
+    assert (cfg["bframes"], cfg["b_adapt"], cfg["fpelcmp_satd"], cfg["me_range"]) == (8, 2, 1, 24)
+    nb = cfg["bframes"] + 2
+    res = []
+    for paced in (True, False):
+        la = lib.Lookahead(cfg, max_frames=nf + 12)
+        try:
+            res.append(la.run(frames, paced=paced, qp_offsets=True))
+        finally:
+            la.close()
+    assert _types(res[0]) == _types(res[1])
+    for a, b in zip(_mats(res[0], nb), _mats(res[1], nb)):
+        assert np.array_equal(a, b)
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a.qp_offset, b.qp_offset)
+    assert sorted(f for f, _ in _types(res[0])) == list(range(nf))
+
+
 def test_batch_ingest_device_pointers():
     """x264hip_lookahead_put_frames (device-resident frames, batched ingest) gives the same decisions and maps as
     frame-by-frame host ingest."""

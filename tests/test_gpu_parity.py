@@ -261,3 +261,56 @@ def test_frame_cost_recalculate():
         assert not np.array_equal(ctx.qp_offsets(0), qp_aq[0])  # the finish step really changed frame 0's offsets
     finally:
         ctx.close()
+
+
+def upscaled_clip(W, H, n, depth, factor=4, **kw):
+    """A picture sequence of BASELINE configs[4] size without minutes of numpy filtering: a (W/factor x H/factor) synthetic clip
+    enlarged by sample repetition plus a little per-sample noise (so that neighbouring blocks differ and sub-pel positions matter)."""
+    from x264_amd.synth import make_clip
+    small = make_clip(W // factor, H // factor, n, bit_depth=depth, **kw)
+    rng = np.random.default_rng(kw.get("seed", 1))
+    out = np.empty((n, H, W), small.dtype)
+    hi = (1 << depth) - 1
+    for i in range(n):
+        big = np.repeat(np.repeat(small[i], factor, axis=0), factor, axis=1).astype(np.int32)
+        big += rng.integers(-6, 7, big.shape, dtype=np.int32)
+        out[i] = np.clip(big, 0, hi).astype(small.dtype)
+    return out
+
+
+def test_8k_10bit_search_matches_oracle():
+    """BASELINE configs[4] geometry (7680x4320 10-bit, veryslow + tesa: HEX range 24, fpelcmp = SATD, bframes 8, level 6.x mv range):
+    lowres planes, AQ, intra costs, one P and one B evaluation, every array against the oracle.  8.7 M samples per padded lowres
+    plane: the size where 24-bit offset arithmetic would first go wrong."""
+    W, H = 7680, 4320
+    frames = upscaled_clip(W, H, 3, 10, seed=5, pan=(17, -9), noise=9, texture=0.35)
+    o, cfg, ctx = _mk(10, 1, 4, 24, 10, 1, 1, 8, W, H, mv_range=8192)
+    try:
+        global SEQ
+        old, SEQ = SEQ, [(0, 2, 2), (0, 2, 1)]
+        try:
+            assert _run_sequence(o, cfg, ctx, frames) == 3
+        finally:
+            SEQ = old
+    finally:
+        ctx.close()
+
+
+def test_bright_10bit_4k_frame_stats():
+    """Luma total above 2^32: i_pixel_sum wraps like the reference's uint32_t before the mean is removed from the ssd
+    (common/frame.h:140, ratecontrol.c:405-414; pinned against the reference in tests/test_oracle_vs_ref.py)."""
+    W, H = 3840, 2160
+    rng = np.random.default_rng(3)
+    y = (900 + rng.integers(0, 100, (H, W))).astype(np.uint16)
+    o = Oracle(10)
+    ctx = lib.Context(W, H, bit_depth=10, max_frames=2)
+    try:
+        ctx.frame_put(0, y)
+        got = ctx.frame_stats(0)
+        inv = ctx.inv_qscale(0)
+    finally:
+        ctx.close()
+    iq, _, s, ssd = o.aq_frame(y, (W + 15) // 16, (H + 15) // 16, 1, 1.0)
+    assert int(y.astype(np.uint64).sum()) > 1 << 32
+    assert got == (s, ssd)
+    assert np.array_equal(inv, iq)
