@@ -65,7 +65,8 @@ if blocks:
             d["avg_wave_quad_cycles"] = round(wc / c["SQ_WAVES"], 1)
     if "SQ_INSTS_VALU" in c and ns:
         # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles; 1024 SIMDs; clock from GRBM_GUI_ACTIVE / wall when collected
-        clk = c.get("GRBM_GUI_ACTIVE", 0) / (dur_ns[0] if dur_ns else ns) if c.get("GRBM_GUI_ACTIVE") else 2.4
+        # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs
+        clk = c.get("GRBM_GUI_ACTIVE", 0) / 8 / (dur_ns[0] if dur_ns else ns) if c.get("GRBM_GUI_ACTIVE") else 2.4
         d["effective_clock_GHz"] = round(clk, 3)
         d["valu_issue_utilisation"] = round(c["SQ_INSTS_VALU"] * 2 / (1024 * ns * clk), 4)
         if "SQ_INSTS_SALU" in c:
