@@ -1,0 +1,115 @@
+// TEST INFRASTRUCTURE: compiles x264_amd/csrc/me_logic.h (the block-search logic the device kernel runs per 16-lane group) for
+// the host with a scalar evaluator, so that its candidate order, tie-breaking and early exits can be checked against the oracle's
+// whole-field search (or{8,10}_search_field) without a GPU.  Pixel costs come from the oracle's own metrics (liboracle.so): only
+// the logic is under test here; the device evaluator (loads, DPP reductions) is covered by the -m gpu parity tests.
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+#define ME_HD inline
+#include "me_logic.h"
+extern "C" {
+#include "x264_oracle.h"
+}
+
+template <typename T> struct Ops;
+template <> struct Ops<uint8_t>
+{
+    static int sad( const uint8_t *a, int sa, const uint8_t *b, int sb ) { return or8_sad( a, sa, b, sb, 8, 8 ); }
+    static int satd( const uint8_t *a, int sa, const uint8_t *b, int sb ) { return or8_satd( a, sa, b, sb, 8, 8 ); }
+    static void mc( uint8_t *d, const uint8_t *const pl[4], int stride, int x, int y, const or_weight *w ) { or8_mc_luma( d, 8, pl, stride, x, y, 8, 8, w ); }
+};
+template <> struct Ops<uint16_t>
+{
+    static int sad( const uint16_t *a, int sa, const uint16_t *b, int sb ) { return or10_sad( a, sa, b, sb, 8, 8 ); }
+    static int satd( const uint16_t *a, int sa, const uint16_t *b, int sb ) { return or10_satd( a, sa, b, sb, 8, 8 ); }
+    static void mc( uint16_t *d, const uint16_t *const pl[4], int stride, int x, int y, const or_weight *w ) { or10_mc_luma( d, 8, pl, stride, x, y, 8, 8, w ); }
+};
+
+template <typename T>
+struct HostEval
+{
+    const or_la_cfg *c;
+    const T *fenc;          // block origin in the source plane
+    const T *ref[4];        // block origin in the four half-pel planes of the reference
+    const T *ref_w;         // block origin in the plane full-pel candidates read
+    const or_weight *wt;
+    int mvpx, mvpy;
+    int n_fpel = 0, n_qpel = 0;
+    int cmp( int satd, const T *b, int sb ) const { return satd ? Ops<T>::satd( fenc, c->stride, b, sb ) : Ops<T>::sad( fenc, c->stride, b, sb ); }
+    int fpel( int x, int y ) { n_fpel++; return cmp( c->fpelcmp_satd, ref_w + y * c->stride + x, c->stride ); }
+    int qpel( int qx, int qy, int use_satd )
+    {
+        T buf[64];
+        n_qpel++;
+        Ops<T>::mc( buf, ref, c->stride, qx, qy, wt && wt->on ? wt : nullptr );
+        return cmp( use_satd, buf, 8 );
+    }
+    int bits( int qx, int qy ) const { return c->cost_mv[qx - mvpx] + c->cost_mv[qy - mvpy]; }
+    bool any( bool v ) const { return v; }
+};
+
+template <typename T>
+static void search_field( const or_la_cfg *c, const T *fenc0, const T *const ref[4], const T *ref_w, const or_weight *wt,
+                          int16_t ( *mvs )[2], int *mv_costs, long *evals )
+{
+    const int W = c->mb_w, H = c->mb_h, ns = c->n_slices > 1 ? c->n_slices : 1;
+    const bool no_edges = !c->do_edges && W > 2 && H > 2;
+    MeCfg C = { c->me_method == OR_ME_HEX, c->subpel_refine >= 3, c->me_range, c->mbcmp_satd, c->fpelcmp_satd };
+    std::vector<int> packed( (size_t)W * H, 0 );
+    for( int by = H - 1; by >= 0; by-- )
+    {
+        int band_end = H;
+        for( int sl = ns - 1; sl >= 1; sl-- )
+        {
+            const int start = ( H * sl + ns / 2 ) / ns;
+            if( by < start ) band_end = start;
+        }
+        for( int bx = W - 1; bx >= 0; bx-- )
+        {
+            const int xy = by * W + bx, off = 8 * ( by * c->stride + bx );
+            if( no_edges && !( bx > 0 && bx < W - 1 && by > 0 && by < H - 1 ) )
+                continue; // never visited: vectors and costs stay zero
+            MeLim L;
+            melogic::block_limits( L, bx, by, W, H, c->mv_range );
+            const bool has_below = by < band_end - 1;
+            int mvcx[4], mvcy[4];
+            const int n = melogic::neighbour_list( bx, W, has_below, bx < W - 1 ? packed[xy + 1] : 0, has_below ? packed[xy + W] : 0,
+                                                   has_below && bx > 0 ? packed[xy + W - 1] : 0, has_below && bx < W - 1 ? packed[xy + W + 1] : 0, mvcx, mvcy );
+            int mvpx, mvpy;
+            if( n <= 1 ) { mvpx = mvcx[0]; mvpy = mvcy[0]; }
+            else { mvpx = melogic::median3( mvcx[0], mvcx[1], mvcx[2] ); mvpy = melogic::median3( mvcy[0], mvcy[1], mvcy[2] ); }
+            HostEval<T> ev;
+            ev.c = c; ev.fenc = fenc0 + off; ev.wt = wt; ev.mvpx = mvpx; ev.mvpy = mvpy;
+            for( int k = 0; k < 4; k++ ) ev.ref[k] = ref[k] + off;
+            ev.ref_w = wt && wt->on ? ref_w + off : ev.ref[0];
+            int mvx = 0, mvy = 0, cost = 0;
+            bool done = false;
+            if( !( mvpx | mvpy ) )
+            {
+                cost = ev.cmp( c->mbcmp_satd, ev.ref[0], c->stride ); // slicetype.c:684-692
+                done = cost < 64;
+            }
+            if( !done )
+            {
+                melogic::search( C, L, ev, mvpx, mvpy, n, mvcx, mvcy, mvx, mvy, cost );
+                cost -= c->cost_mv[0];
+                if( mvx | mvy ) cost += 5 * c->lambda;
+            }
+            if( evals ) { evals[0] += ev.n_fpel; evals[1] += ev.n_qpel; }
+            packed[xy] = ( mvx & 0xFFFF ) | ( mvy << 16 );
+            mvs[xy][0] = (int16_t)mvx; mvs[xy][1] = (int16_t)mvy;
+            mv_costs[xy] = cost;
+        }
+    }
+}
+
+extern "C" void mel8_search_field( const or_la_cfg *c, const uint8_t *fenc0, const uint8_t *const ref[4], const uint8_t *ref_w, const or_weight *wt,
+                                   int16_t ( *mvs )[2], int *mv_costs, long *evals )
+{
+    search_field<uint8_t>( c, fenc0, ref, ref_w, wt, mvs, mv_costs, evals );
+}
+extern "C" void mel10_search_field( const or_la_cfg *c, const uint16_t *fenc0, const uint16_t *const ref[4], const uint16_t *ref_w, const or_weight *wt,
+                                    int16_t ( *mvs )[2], int *mv_costs, long *evals )
+{
+    search_field<uint16_t>( c, fenc0, ref, ref_w, wt, mvs, mv_costs, evals );
+}

@@ -51,6 +51,58 @@ ME_HD int mod6( int v ) { return v < 0 ? v + 6 : v >= 6 ? v - 6 : v; }
 ME_HD int dia_dx( int k ) { return k == 2 ? -1 : k == 3 ? 1 : 0; }
 ME_HD int dia_dy( int k ) { return k == 0 ? -1 : k == 1 ? 1 : 0; }
 
+// motion vector limits of block (bx, by) of a W x H block picture (slicetype.c:518-531 with the lowres 8x8 geometry): the block may
+// leave the picture by 12 samples (the padded border is 32), and never by more than the level's vertical / horizontal range
+ME_HD void block_limits( MeLim &L, int bx, int by, int W, int H, int mv_range )
+{
+    const int range = 2 * mv_range;
+    L.smin_x = 4 * ( -8 * bx - 12 ); if( L.smin_x < -range ) L.smin_x = -range;
+    L.smin_y = 4 * ( -8 * by - 12 ); if( L.smin_y < -range ) L.smin_y = -range;
+    L.smax_x = 4 * ( 8 * ( W - bx - 1 ) + 12 ); if( L.smax_x > range - 1 ) L.smax_x = range - 1;
+    L.smax_y = 4 * ( 8 * ( H - by - 1 ) + 12 ); if( L.smax_y > range - 1 ) L.smax_y = range - 1;
+    L.fmin_x = L.smin_x >> 2; L.fmin_y = L.smin_y >> 2;
+    L.fmax_x = L.smax_x >> 2; L.fmax_y = L.smax_y >> 2;
+}
+
+ME_HD int median3( int a, int b, int c )
+{
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    const int m = hi < c ? hi : c;
+    return lo > m ? lo : m;
+}
+
+// The neighbour list of slicetype_mb_cost (slicetype.c:662-680): right, below, below-left, below-right, as far as they exist
+// (has_below: the row below belongs to the same band and has been searched).  Returns the count; absent entries are zero.
+ME_HD int neighbour_list( int bx, int W, bool has_below, int right, int below, int below_left, int below_right, int mvcx[4], int mvcy[4] )
+{
+    int n = 0;
+    int v[4] = { 0, 0, 0, 0 };
+    // compaction without dynamic indexing: each candidate lands in slot n, n is at most 3 here
+    if( bx < W - 1 ) { v[0] = right; n = 1; }
+    if( has_below )
+    {
+        if( n == 0 ) v[0] = below; else v[1] = below;
+        n++;
+        if( bx > 0 )
+        {
+            if( n == 1 ) v[1] = below_left; else v[2] = below_left;
+            n++;
+        }
+        if( bx < W - 1 )
+        {
+            if( n == 2 ) v[2] = below_right; else v[3] = below_right; // n == 1 cannot happen: bx < W-1 put `right` first
+            n++;
+        }
+    }
+#pragma unroll
+    for( int i = 0; i < 4; i++ )
+    {
+        mvcx[i] = (int)(short)( v[i] & 0xFFFF );
+        mvcy[i] = v[i] >> 16;
+    }
+    return n;
+}
+
 template <class E>
 ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, int n_mvc, const int mvcx[4], const int mvcy[4],
                    int &out_mvx, int &out_mvy, int &out_cost )

@@ -731,7 +731,25 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
     MeQueues Q;
     for( int q = 0; q <= ME_QUEUES; q++ )
         Q.base[q] = (int)( (long long)n * q / ME_QUEUES ); // contiguous groups: the request list is in frame order
-    me_rows_kernel<T><<<n * P.mb_h, 64, 0, ctx->stream>>>( P, dd, Q, ctx->sync_words, ctx->err_host, 1u << 22 );
+    {
+        // one wave per (search, group of ME_ROWS block rows); the kernel is specialised on the search pattern and the sub-pel depth
+        const int n_waves = n * ( ( P.mb_h + ME_ROWS - 1 ) / ME_ROWS );
+        const bool hex = P.me_method == X264HIP_ME_HEX, r4 = P.subpel_refine >= 3;
+        const int mode = !r4 && !P.mbcmp_satd && !P.fpelcmp_satd ? 0 : r4 && P.mbcmp_satd ? ( P.fpelcmp_satd ? 2 : 1 ) : 3;
+#define ME_LAUNCH( HEXV, MODEV ) me_rows_kernel<T, HEXV, MODEV><<<n_waves, 64, 0, ctx->stream>>>( P, dd, Q, ctx->sync_words, ctx->err_host, 1u << 22 )
+        switch( 4 * hex + mode )
+        {
+            case 0: ME_LAUNCH( 0, 0 ); break;
+            case 1: ME_LAUNCH( 0, 1 ); break;
+            case 2: ME_LAUNCH( 0, 2 ); break;
+            case 3: ME_LAUNCH( 0, 3 ); break;
+            case 4: ME_LAUNCH( 1, 0 ); break;
+            case 5: ME_LAUNCH( 1, 1 ); break;
+            case 6: ME_LAUNCH( 1, 2 ); break;
+            default: ME_LAUNCH( 1, 3 ); break;
+        }
+#undef ME_LAUNCH
+    }
     HIPCK( hipEventRecord( e1, ctx->stream ) );
     if( ring_commit( ctx->search_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
     HIPCK( hipGetLastError() );
