@@ -189,9 +189,10 @@ int  x264hip_frame_cost_recalculate( x264hip_ctx *ctx, int slot_b, int dist_p0, 
 
 /* ---- vtable-granular primitives, batched -------------------------------------------------------
  * Device counterparts of x264_pixel_function_t.sad/satd (common/pixel.h:78-84, pixel.c:55-80,265-332)
- * over a whole field of blocks: block i of size_idx (PIXEL_16x16=0, PIXEL_8x8=3, PIXEL_4x4=6) sits at
+ * over a whole field of blocks: block i of size_idx sits at
  * raster position i of the fenc plane and is compared with the ref plane displaced by the full-pel
- * mv[i].  Planes are device pointers.  Used for parity and for the SAD/SATD GB/s metric. */
+ * mv[i].  All seven partition sizes (PIXEL_16x16 = 0, 16x8, 8x16, 8x8, 8x4, 4x8, PIXEL_4x4 = 6); the compared area must be a multiple
+ * of 16 samples in both directions.  Planes are device pointers.  Used for parity and for the SAD/SATD GB/s metric. */
 int  x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx, const void *fenc_plane, const void *ref_plane,
                               int stride, int blocks_w, int blocks_h, const int16_t *mv_dev, int *out_dev );
 /* ---- main-encode motion search, functional baseline --------------------------------------------------
@@ -278,6 +279,67 @@ int  x264hip_frame_init_lowres_core( x264hip_ctx *ctx, const void *src0, void *d
  * fdec blocks with stride 32, like FENC_STRIDE/FDEC_STRIDE).  Host pointers; a parity/microbench entry. */
 int  x264hip_dct_quant_batch( x264hip_ctx *ctx, int is8x8, int n_blocks, const void *fenc, const void *fdec,
                               const void *mf, const void *bias, void *coefs_out, int *nz_out );
+
+/* The remaining entries of x264_dct_function_t (common/dct.h:29-59) and x264_quant_function_t (common/quant.h:30-45) in batch
+ * form: n independent calls on the reference's macroblock-local buffers.  Host pointers.
+ *   fenc: n buffers of 16 rows x FENC_STRIDE (16) pixels, fdec: n buffers of 16 rows x FDEC_STRIDE (32) pixels (a kind that works
+ *   on a smaller block reads the top-left part); coefs: n x (coefficients of the kind) dctcoef (int16 / int32 for 8 / 10 bit) in
+ *   the reference's per-call order.
+ *   DCT kinds  0 sub4x4_dct (16)   1 sub8x8_dct (4 x 16)    2 sub16x16_dct (16 x 16)   3 sub8x8_dct8 (64)   4 sub16x16_dct8 (4 x 64)
+ *              5 sub8x8_dct_dc (4) 6 sub8x16_dct_dc (8)     7 dct4x4dc (16, in place)  8 dct2x4dc (8 DC values, in place)
+ *              (dct.c:47-270, 332-386); the in-place kinds take their input in coefs, fenc / fdec may be NULL.
+ *   QUANT kinds 0 quant_4x4  1 quant_8x8  2 quant_4x4x4 (64 coefficients, nz = 4-bit mask)  3 quant_4x4_dc  4 quant_2x2_dc (quant.c:50-104);
+ *              mf / bias: 16 (64 for kind 1) udctcoef (uint16 / uint32); the DC kinds use mf_dc / bias_dc.  nz[i] = the entry's return value. */
+int  x264hip_dct_batch( x264hip_ctx *ctx, int kind, int n, const void *fenc, const void *fdec, void *coefs );
+int  x264hip_quant_batch( x264hip_ctx *ctx, int kind, int n, void *coefs, const void *mf, const void *bias, int mf_dc, int bias_dc, int *nz );
+/* x264_pixel_function_t.var2[PIXEL_8x8 / PIXEL_8x16] (common/pixel.c:206-231): the chroma halves of n fenc / fdec buffers as above
+ * (U at column 0, V at column stride / 2); var[i] = the return value, ssd[2*i .. 2*i+1] = the two ssd outputs. */
+int  x264hip_var2_batch( x264hip_ctx *ctx, int height, int n, const void *fenc, const void *fdec, int *var, int *ssd );
+/* x264_pixel_function_t.ads[] (successive elimination, common/pixel.c:756-803): n calls, each over `width` horizontally adjacent
+ * candidates; one wave per call keeps the reference's output order (ballot + prefix count).  A call reads sums[sums_off ...] (the
+ * integral plane row, x264hip_integral_init), cost_mvx[cost_off ...] and writes the surviving candidate indices to
+ * mvs[mvs_off ...]; counts[i] = the return value. */
+typedef struct x264hip_ads_call
+{
+    int n_dc, delta, width, thresh;  /* n_dc 1 / 2 / 4 = ads1 / ads2 / ads4 */
+    int enc_dc[4];
+    long long sums_off, cost_off, mvs_off;
+} x264hip_ads_call;
+int  x264hip_ads_batch( x264hip_ctx *ctx, int n, const x264hip_ads_call *calls, const uint16_t *sums, size_t n_sums, const uint16_t *cost_mvx, size_t n_cost,
+                        int16_t *mvs, size_t n_mvs, int *counts );
+
+/* ---- vtable-shaped boundary -------------------------------------------------------------------------------------------------
+ * The reference fills its function tables once per encoder: x264_pixel_init( cpu, &h->pixf ) (common/pixel.h:146-147),
+ * x264_mc_init( cpu, &h->mc, cpu_independent ) (common/mc.h:342-343), x264_dct_init (common/dct.h:72-73), x264_quant_init
+ * (common/quant.h:72-73), at encoder/encoder.c:1655-1667.  What this library can stand behind such a table:
+ *
+ *  - x264_mc_functions_t: the members that work on whole planes or macroblock rows -- plane_copy (mc.h:292), hpel_filter
+ *    (:306-307), frame_init_lowres_core (:326-327), mbtree_propagate_cost / mbtree_propagate_list (:333-337).  x264hip_mc_fill
+ *    writes functions with EXACTLY the reference's signatures into the struct below (same member names, `pixel` = uint8_t or
+ *    uint16_t by the context's bit depth, as in the reference's bit-depth templating, common/common.h:33).  A maintainer calls it
+ *    right after x264_mc_init and copies the five pointers into h->mc.  The pointers the encoder passes are host pointers: every
+ *    call stages its operands through device memory, so these members are drop-in correct, not fast; the fast forms are the
+ *    x264hip_* entries above that take device pointers (x264hip_hpel_filter, x264hip_frame_init_lowres_core, x264hip_mbtree, ...).
+ *    The functions have no context argument (neither have the reference's), so one context per process is bound by the last
+ *    x264hip_mc_fill call; they return void, a device failure latches the context like x264_opencl_t.b_fatal_error.
+ *  - x264_pixel_function_t / x264_dct_function_t / x264_quant_function_t: every member is a per-block call (an 8x8 SAD reads 128
+ *    bytes and returns an int); behind a host function pointer each call would cost a PCIe round trip (~10 us) for ~10 ns of work,
+ *    and the reference calls them millions of times per frame from a serial loop.  They are therefore exported in BATCH form only
+ *    -- x264hip_pixel_cmp_batch (sad / satd, all 7 sizes), x264hip_pixel_metric_batch (ssd, sa8d, var, hadamard_ac, vsad, asd8),
+ *    x264hip_var2_batch, x264hip_ads_batch, x264hip_dct_batch (all 9 dctf entries), x264hip_quant_batch (all 5 quantf entries) --
+ *    and the hot callers of those tables on this path (slicetype_mb_cost, x264_me_search_ref) run on the device as a whole behind
+ *    the coarse hook (x264hip_frame_cost), which is where the reference's own accelerator boundary is (slicetype.c:878-897). */
+typedef struct x264hip_mc_functions
+{
+    void (*plane_copy)( void *dst, intptr_t i_dst, void *src, intptr_t i_src, int w, int h );
+    void (*hpel_filter)( void *dsth, void *dstv, void *dstc, void *src, intptr_t i_stride, int i_width, int i_height, int16_t *buf );
+    void (*frame_init_lowres_core)( void *src0, void *dst0, void *dsth, void *dstv, void *dstc, intptr_t src_stride, intptr_t dst_stride, int width, int height );
+    void (*mbtree_propagate_cost)( int16_t *dst, uint16_t *propagate_in, uint16_t *intra_costs, uint16_t *inter_costs, uint16_t *inv_qscales, float *fps_factor, int len );
+    void (*mbtree_propagate_list)( void *h, uint16_t *ref_costs, int16_t (*mvs)[2], int16_t *propagate_amount, uint16_t *lowres_costs, int bipred_weight, int mb_y,
+                                   int len, int list );
+} x264hip_mc_functions;
+int  x264hip_mc_fill( x264hip_ctx *ctx, x264hip_mc_functions *pf );
+void x264hip_mc_unbind( x264hip_ctx *ctx ); /* done by x264hip_close as well */
 
 /* timing of the most recent search launch in ms (HIP events on the context's stream) and counters */
 int  x264hip_last_search_ms( x264hip_ctx *ctx, float *ms, int *n_searches, int *n_blocks );

@@ -636,6 +636,15 @@ RH_API void rh_dct( rh_ctx *c, int kind, dctcoef *out, pixel *fenc, pixel *fdec 
         case 5: d->sub8x8_dct_dc( out, fenc, fdec ); break;
         case 6: d->sub8x16_dct_dc( out, fenc, fdec ); break;
         case 7: d->dct4x4dc( out ); break;
+        case 8: /* dct2x4dc( dct[8], dct4x4[8][16] ): `out` holds the eight DC values; results come back in place */
+        {
+            dctcoef blocks[8][16], dc[8];
+            memset( blocks, 0, sizeof(blocks) );
+            for( int i = 0; i < 8; i++ ) blocks[i][0] = out[i];
+            d->dct2x4dc( dc, blocks );
+            for( int i = 0; i < 8; i++ ) out[i] = dc[i];
+            break;
+        }
     }
 }
 /* kind: 0 quant_4x4 1 quant_8x8 2 quant_4x4x4 3 quant_4x4_dc 4 quant_2x2_dc ; cqm list i_list, qp */

@@ -678,6 +678,15 @@ void ORN(dct)( int kind, dctcoef *out, const pixel *fenc, const pixel *fdec )
             }
             break;
         }
+        case 8: /* dct2x4dc in place on the eight DC values in out[0..7] (dct.c:109-143) */
+        {
+            int a0 = out[0] + out[1], a1 = out[2] + out[3], a2 = out[4] + out[5], a3 = out[6] + out[7];
+            int a4 = out[0] - out[1], a5 = out[2] - out[3], a6 = out[4] - out[5], a7 = out[6] - out[7];
+            int b0 = a0 + a1, b1 = a2 + a3, b2 = a4 + a5, b3 = a6 + a7, b4 = a0 - a1, b5 = a2 - a3, b6 = a4 - a5, b7 = a6 - a7;
+            out[0] = (dctcoef)( b0 + b1 ); out[1] = (dctcoef)( b2 + b3 ); out[2] = (dctcoef)( b0 - b1 ); out[3] = (dctcoef)( b2 - b3 );
+            out[4] = (dctcoef)( b4 - b5 ); out[5] = (dctcoef)( b6 - b7 ); out[6] = (dctcoef)( b4 + b5 ); out[7] = (dctcoef)( b6 + b7 );
+            break;
+        }
     }
 }
 

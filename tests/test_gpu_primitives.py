@@ -49,8 +49,8 @@ def test_pixel_cmp_batch(depth, dims):
             rd = torch.from_numpy(r.view(np.uint8 if depth == 8 else np.int16)).cuda()
             assert fd.dtype == tdt
             org = (PAD * stride + PAD) * f.itemsize
-            for size_idx, size in ((0, 16), (3, 8), (6, 4)):
-                bw, bh = W // size, H // size
+            for size_idx, (sw, sh) in enumerate(((16, 16), (16, 8), (8, 16), (8, 8), (8, 4), (4, 8), (4, 4))):  # PIXEL_16x16 .. PIXEL_4x4
+                bw, bh = W // sw, H // sh
                 mv = rng.integers(-PAD, PAD - 15, size=(bw * bh, 2)).astype(np.int16)
                 mvd = torch.from_numpy(mv).cuda()
                 for satd in (0, 1):
@@ -64,9 +64,9 @@ def test_pixel_cmp_batch(depth, dims):
                     step = 1 if bw * bh <= 4096 else 37
                     for bi in range(0, bw * bh, step):
                         by, bx = divmod(bi, bw)
-                        a = _ptr(f, (PAD + by * size) * stride + PAD + bx * size)
-                        b = _ptr(r, (PAD + by * size + int(mv[bi, 1])) * stride + PAD + bx * size + int(mv[bi, 0]))
-                        assert got[bi] == fn(a, stride, b, stride, size, size), (kind, size, satd, bi)
+                        a = _ptr(f, (PAD + by * sh) * stride + PAD + bx * sw)
+                        b = _ptr(r, (PAD + by * sh + int(mv[bi, 1])) * stride + PAD + bx * sw + int(mv[bi, 0]))
+                        assert got[bi] == fn(a, stride, b, stride, sw, sh), (kind, sw, sh, satd, bi)
                     assert (got >= 0).all()
     finally:
         ctx.close()
@@ -199,3 +199,152 @@ def test_frame_dct_quant4x4(depth):
             rnz = quant(0, _ptr(c), _ptr(mf), _ptr(bias), 0, 0)
             assert np.array_equal(got[by, bx], c), (by, bx)
             assert int(gnz[by, bx]) == rnz, (by, bx)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_vtable_batches(depth):
+    """x264hip_dct_batch / quant_batch / var2_batch / ads_batch: every remaining entry of x264_dct_function_t and
+    x264_quant_function_t, var2 and ads of x264_pixel_function_t, on checkasm-style inputs (tools/checkasm.c:361-888, 890-1224)
+    against the oracle (pinned against the reference vtables in tests/test_primitives_vs_ref.py)."""
+    from tests.test_vtable_blocks_host import DCT_COEFS, QUANT_COEFS
+    o = Oracle(depth)
+    rng = np.random.default_rng(77 + depth)
+    maxv = (1 << depth) - 1
+    n = 300
+    ctx = lib.Context(64, 64, bit_depth=depth, max_frames=2, mv_range=32)
+    try:
+        fenc = rng.integers(0, maxv + 1, size=(n, 16, 16)).astype(o.dtype)
+        fdec = rng.integers(0, maxv + 1, size=(n, 16, 32)).astype(o.dtype)
+        fenc[0] = maxv; fdec[0] = 0; fenc[1] = 0; fdec[1] = maxv  # largest differences of either sign
+        fdec[2, :, :16] = fenc[2]
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        for kind in range(7):
+            got = ctx.dct_batch(kind, fenc, fdec)
+            for i in range(n):
+                want = np.zeros(DCT_COEFS[kind], o.coef_dtype)
+                o.f("dct")(kind, p(want), p(fenc[i]), p(fdec[i]))
+                assert np.array_equal(got[i], want), ("dct", kind, i)
+        for kind in (7, 8):
+            co = rng.integers(-(40000 if depth == 10 else 8000), 8000, size=(n, DCT_COEFS[kind])).astype(o.coef_dtype)
+            got = ctx.dct_batch(kind, coefs=co)
+            for i in range(n):
+                want = co[i].copy()
+                o.f("dct")(kind, p(want), None, None)
+                assert np.array_equal(got[i], want), ("dct", kind, i)
+        lim = 30000 if depth == 8 else 1 << 20
+        for kind, nc in QUANT_COEFS.items():
+            nt = 64 if kind == 1 else 16
+            mf = rng.integers(1, 30000 if depth == 8 else 1 << 18, size=nt).astype(o.ucoef_dtype)
+            bias = rng.integers(0, 30000, size=nt).astype(o.ucoef_dtype)
+            co = rng.integers(-lim, lim + 1, size=(n, nc)).astype(o.coef_dtype)
+            co[: n // 3] = rng.integers(-3, 4, size=(n // 3, nc))  # many all-zero results: exercises the nz flags / masks
+            got, nz = ctx.quant_batch(kind, co, mf, bias, int(mf[0]) >> 1, int(bias[0]) << 1)
+            for i in range(n):
+                want = co[i].copy()
+                r = o.f("quant", C.c_int)(kind, p(want), p(mf), p(bias), int(mf[0]) >> 1, int(bias[0]) << 1)
+                assert np.array_equal(got[i], want) and nz[i] == r, ("quant", kind, i)
+        for h in (8, 16):
+            var, ssd = ctx.var2_batch(h, fenc, fdec)
+            for i in range(n):
+                s = np.zeros(2, np.int32)
+                r = o.f("var2", C.c_int)(p(fenc[i]), p(fdec[i]), h, p(s))
+                assert var[i] == r and np.array_equal(ssd[i], s), ("var2", h, i)
+        # ads: rows of different widths (more and less than one wave), the three forms, thresholds from "none" to "all"
+        sums = rng.integers(0, 1 << 16, size=5000).astype(np.uint16)
+        cost = rng.integers(0, 200, size=2000).astype(np.uint16)
+        calls, off = [], 0
+        for i in range(90):
+            width = int(rng.integers(1, 200))
+            calls.append(dict(n_dc=(1, 2, 4)[i % 3], delta=32, width=width, thresh=int(rng.integers(0, 140000)),
+                              enc_dc=rng.integers(0, 1 << 16, size=4), sums_off=int(rng.integers(0, 4000)), cost_off=int(rng.integers(0, 1700)), mvs_off=off))
+            off += width
+        mvs, counts = ctx.ads_batch(calls, sums, cost, off)
+        f = o.f("ads", C.c_int)
+        for c, cnt in zip(calls, counts):
+            want = np.zeros(c["width"], np.int16)
+            dc = np.ascontiguousarray(c["enc_dc"], np.int32)
+            r = f(c["n_dc"], p(dc), p(sums[c["sums_off"]:]), c["delta"], p(cost[c["cost_off"]:]), p(want), c["width"], c["thresh"])
+            assert cnt == r and np.array_equal(mvs[c["mvs_off"]:c["mvs_off"] + r], want[:r]), c
+    finally:
+        ctx.close()
+
+
+class McFunctions(C.Structure):
+    """x264hip_mc_functions: the coarse members of x264_mc_functions_t with the reference's exact signatures"""
+    _fields_ = [
+        ("plane_copy", C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int)),
+        ("hpel_filter", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p)),
+        ("frame_init_lowres_core", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int)),
+        ("mbtree_propagate_cost", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int)),
+        ("mbtree_propagate_list", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int)),
+    ]
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_mc_fill_exact_signature_members(depth):
+    """x264hip_mc_fill: the frame- and row-granular members of x264_mc_functions_t (mc.h:292,306-307,326-327,333-337) called
+    through the function pointers with HOST buffers, exactly like the encoder calls h->mc.*, against the oracle."""
+    o = Oracle(depth)
+    maxv = (1 << depth) - 1
+    rng = np.random.default_rng(91 + depth)
+    W, H = 352, 288
+    mb_w, mb_h = W // 16, H // 16
+    ctx = lib.Context(W, H, bit_depth=depth, max_frames=2, mv_range=32)
+    try:
+        pf = McFunctions()
+        ctx.L.x264hip_mc_fill.argtypes = [C.c_void_p, C.POINTER(McFunctions)]
+        assert ctx.L.x264hip_mc_fill(ctx.h, C.byref(pf)) == 0
+        # plane_copy
+        src = rng.integers(0, maxv + 1, size=(37, 120)).astype(o.dtype)
+        dst = np.full((37, 140), 9, o.dtype)
+        pf.plane_copy(_ptr(dst), 140, _ptr(src), 120, 101, 37)
+        assert np.array_equal(dst[:, :101], src[:, :101]) and (dst[:, 101:] == 9).all()
+        # frame_init_lowres_core
+        w, h = 104, 21
+        src = rng.integers(0, maxv + 1, size=(2 * h + 2, 2 * w + 16)).astype(o.dtype)
+        exp = np.zeros((4, h, w + 8), o.dtype); got = np.zeros_like(exp)
+        o.f("lowres_core")(_ptr(src), _ptr(exp[0]), _ptr(exp[1]), _ptr(exp[2]), _ptr(exp[3]), src.shape[1], w + 8, w, h)
+        pf.frame_init_lowres_core(_ptr(src), _ptr(got[0]), _ptr(got[1]), _ptr(got[2]), _ptr(got[3]), src.shape[1], w + 8, w, h)
+        assert np.array_equal(got, exp)
+        # hpel_filter, incl. the extra dstv columns
+        f = o.f("hpel_filter")
+        f.argtypes = [C.c_void_p] * 4 + [C.c_long, C.c_int, C.c_int, C.c_void_p]
+        w, h = 100, 19
+        stride = w + 32
+        src = rng.integers(0, maxv + 1, size=(h + 8, stride)).astype(o.dtype)
+        off = 3 * stride + 8
+        exp = [np.full((h + 8, stride), 7, o.dtype) for _ in range(3)]
+        got = [np.full((h + 8, stride), 7, o.dtype) for _ in range(3)]
+        buf = np.zeros(w + 64, np.int16)
+        f(_ptr(exp[0], off), _ptr(exp[1], off), _ptr(exp[2], off), _ptr(src, off), stride, w, h, _ptr(buf))
+        pf.hpel_filter(_ptr(got[0], off), _ptr(got[1], off), _ptr(got[2], off), _ptr(src, off), stride, w, h, _ptr(buf))
+        for k in range(3):
+            assert np.array_equal(got[k], exp[k]), "hvc"[k]
+        # mbtree_propagate_cost + mbtree_propagate_list, row by row like macroblock_tree_propagate (slicetype.c:1051-1089),
+        # against the oracle's whole-frame propagation
+        n = mb_w * mb_h
+        intra = rng.integers(1, 0x3FFF, size=n).astype(np.uint16)
+        lists = rng.integers(1, 4, size=n).astype(np.uint16)
+        lc = (np.minimum(rng.integers(0, 0x3FFF, size=n), intra) | (lists << 14)).astype(np.uint16)
+        inv = rng.integers(64, 1024, size=n).astype(np.uint16)
+        pin = rng.integers(0, 20000, size=n).astype(np.uint16)
+        mv0 = rng.integers(-200, 200, size=(n, 2)).astype(np.int16); mv1 = rng.integers(-200, 200, size=(n, 2)).astype(np.int16)
+        mv0[::7] = 0
+        fps = np.float32(0.04 / (0.04 * 256.0) * 0.5)
+        want = [rng.integers(0, 30000, size=n).astype(np.uint16) for _ in range(2)]
+        have = [w_.copy() for w_ in want]
+        L = o.lib
+        L.or_mbtree_propagate.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_float]
+        L.or_mbtree_propagate(mb_w, mb_h, _ptr(intra), _ptr(lc), _ptr(inv), _ptr(pin), _ptr(mv0), _ptr(mv1), _ptr(want[0]), _ptr(want[1]), 40, fps)
+        fpsf = C.c_float(float(fps))
+        for y in range(mb_h):
+            s = slice(y * mb_w, (y + 1) * mb_w)
+            amount = np.zeros(mb_w, np.int16)
+            row = [np.ascontiguousarray(a[s]) for a in (pin, intra, lc, inv)]
+            pf.mbtree_propagate_cost(_ptr(amount), _ptr(row[0]), _ptr(row[1]), _ptr(row[2]), _ptr(row[3]), C.byref(fpsf), mb_w)
+            for lst, mv in ((0, mv0), (1, mv1)):
+                mvr = np.ascontiguousarray(mv[s])
+                pf.mbtree_propagate_list(None, _ptr(have[lst]), _ptr(mvr), _ptr(amount), _ptr(row[2]), 40 if lst == 0 else 24, y, mb_w, lst)
+        assert np.array_equal(have[0], want[0]) and np.array_equal(have[1], want[1])
+    finally:
+        ctx.close()

@@ -280,6 +280,10 @@ def test_dct_quant(env):
             L.rh_dct(r.ctx, 7, _ptr(a), None, None)
             o.f("dct")(7, _ptr(b), None, None)
             assert np.array_equal(a, b)
+            a = rng.integers(-4000, 4000, size=8).astype(o.coef_dtype); b = a.copy()  # dct2x4dc (4:2:2 chroma DC)
+            L.rh_dct(r.ctx, 8, _ptr(a), None, None)
+            o.f("dct")(8, _ptr(b), None, None)
+            assert np.array_equal(a, b)
     L.rh_quant.restype = C.c_int
     for i_list in range(4):
         for qp in range(0, 52 + 6 * (d - 8), 3):

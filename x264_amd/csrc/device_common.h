@@ -242,7 +242,6 @@ __device__ __forceinline__ Px4 qpel_px4_at( const T *ubase, int plane_elems, int
     const int ob = (int)__umul24( pb, (unsigned)plane_elems ) + o + ( fx == 3 );
     return avg_px4( load_px4_at( ubase, oa ), load_px4_at( ubase, ob ), (const T *)nullptr );
 }
-
 // ---- block metrics on the 16-lane layout -----------------------------------------------------------
 // {v.lo + v.hi, v.lo - v.hi}: the one butterfly of the horizontal transform that crosses register halves,
 // as a single VOP3P multiply-add with operand-half selection (hi*{1,-1} + lo)

@@ -805,7 +805,10 @@ __device__ __forceinline__ void load_row8<uint16_t>( const uint16_t *p, Px4 f[2]
     f[0].raw = f[1].raw = 0;
 }
 
-template <typename T, int SIZE, bool SATD>
+// All seven partition sizes of x264_pixel_function_t.sad / .satd (common/pixel.h:37-59): BW x BH in {16,8,4} x {16,8,4} with
+// 16x4 / 4x16 excluded.  A 16-lane group holds a 16x16 region of the planes, lane = row, four Px4 per lane; a region contains
+// (16/BW) x (16/BH) blocks.  Every block of the field has its own full-pel displacement (mv[block], raster order of blocks).
+template <typename T, int BW, int BH, bool SATD>
 __global__ __launch_bounds__( 256 ) void pixel_cmp_batch_kernel( const T *__restrict__ fenc, const T *__restrict__ ref, int stride,
                                                                  int regions_w, const int16_t *__restrict__ mv, int *__restrict__ out )
 {
@@ -816,23 +819,21 @@ __global__ __launch_bounds__( 256 ) void pixel_cmp_batch_kernel( const T *__rest
     const int rx = rx0 + ( lane >> 4 ), ry = blockIdx.y, row = lane & 15;
     const bool live = rx < regions_w;
     const int rxc = live ? rx : regions_w - 1; // keep every lane in the DPP exchanges
-    constexpr int BPR = 16 / SIZE;
-    const int bw = regions_w * BPR;
-    const int by = ry * BPR + row / SIZE;
+    constexpr int NX = 16 / BW, NY = 16 / BH;  // blocks of a region per row of blocks / per column
+    const int bw = regions_w * NX;             // blocks per row of the field
+    const int by = ry * NY + row / BH;
     const size_t o = (size_t)( ry * 16 + row ) * stride + rxc * 16;
     Px4 f[4], r[4];
     load_row16<T>( fenc + o, f );
-    int bi[BPR];
 #pragma unroll
-    for( int k = 0; k < BPR; k++ )
+    for( int k = 0; k < NX; k++ )
     {
-        bi[k] = by * bw + rxc * BPR + k;
         int m;
-        __builtin_memcpy( &m, mv + 2 * bi[k], 4 );
-        const T *rp = ref + (long)o + ( m >> 16 ) * stride + (int16_t)m + k * SIZE;
-        if( SIZE == 16 )
+        __builtin_memcpy( &m, mv + 2 * ( by * bw + rxc * NX + k ), 4 );
+        const T *rp = ref + (long)o + ( m >> 16 ) * stride + (int16_t)m + k * BW;
+        if( BW == 16 )
             load_row16<T>( rp, r );
-        else if( SIZE == 8 )
+        else if( BW == 8 )
             load_row8<T>( rp, r + 2 * k );
         else
             r[k] = load_px4( rp );
@@ -841,37 +842,22 @@ __global__ __launch_bounds__( 256 ) void pixel_cmp_batch_kernel( const T *__rest
 #pragma unroll
     for( int t = 0; t < 4; t++ )
         part[t] = SATD ? satd_partial_px4( f[t], r[t] ) : sad_partial_px4( f[t], r[t], (const T *)nullptr );
-    if( SIZE == 4 )
-    {
-        int mine = 0, idx = 0;
+    // per block of this row of blocks: the 4-sample columns it spans, then the BH rows (quad, half row, row of 16 lanes)
+    int mine = 0;
 #pragma unroll
-        for( int t = 0; t < 4; t++ )
-        {
-            const int v = reduce_quad( part[t] );
-            if( ( lane & 3 ) == t ) { mine = v; idx = bi[t]; }
-        }
-        if( live )
-            out[idx] = SATD ? mine >> 1 : mine;
-        return;
-    }
-    if( SIZE == 8 )
+    for( int k = 0; k < NX; k++ )
     {
-        int v0 = reduce_quad( part[0] + part[1] ), v1 = reduce_quad( part[2] + part[3] );
-        v0 += dpp_mov<DPP_ROW_HALF_MIRROR>( v0 );
-        v1 += dpp_mov<DPP_ROW_HALF_MIRROR>( v1 );
-        const int sel = lane & 7;
-        if( live && sel < 2 )
-        {
-            const int v = sel ? v1 : v0;
-            out[bi[sel ? BPR - 1 : 0]] = SATD ? v >> 1 : v;
-        }
-        return;
+        int v = 0;
+#pragma unroll
+        for( int t = 0; t < BW / 4; t++ )
+            v += part[k * ( BW / 4 ) + t];
+        v = reduce_quad( v );
+        if( BH >= 8 ) v += dpp_mov<DPP_ROW_HALF_MIRROR>( v );
+        if( BH == 16 ) v += dpp_mov<DPP_ROW_MIRROR>( v );
+        if( ( row % BH ) == k ) mine = v; // lane k of the block's rows writes block k (NX <= 4 <= BH)
     }
-    int v = reduce_quad( part[0] + part[1] + part[2] + part[3] );
-    v += dpp_mov<DPP_ROW_HALF_MIRROR>( v );
-    v += dpp_mov<DPP_ROW_MIRROR>( v );
-    if( live && row == 0 )
-        out[bi[0]] = SATD ? v >> 1 : v;
+    if( live && ( row % BH ) < NX )
+        out[by * bw + rxc * NX + ( row % BH )] = SATD ? mine >> 1 : mine;
 }
 
 // ---- hpel_filter (common/mc.c:172-196; x264_mc_functions_t.hpel_filter, mc.h:306-307) -------------------------
@@ -1287,4 +1273,67 @@ __global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *
         __hip_atomic_store( &bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
         __hip_atomic_store( &bar[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
     }
+}
+
+// ---- row forms of the MB-tree entries of x264_mc_functions_t (common/mc.c:511-598), for the exact-signature vtable members that
+// x264hip_mc_fill hands out.  The fused step kernel above is what the lookahead itself uses.
+__global__ __launch_bounds__( 256 ) void mbt_cost_row_kernel( int16_t *__restrict__ dst, const uint16_t *__restrict__ propagate_in, const uint16_t *__restrict__ intra_costs,
+                                                              const uint16_t *__restrict__ inter_costs, const uint16_t *__restrict__ inv_qscales, float fps_factor, int len )
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if( i >= len )
+        return;
+    const int ic = intra_costs[i];
+    int inter = inter_costs[i] & 0x3FFF; // LOWRES_COST_MASK
+    if( inter > ic ) inter = ic;
+    const float propagate_intra = (float)( ic * (int)inv_qscales[i] );
+    const float propagate_amount = __fadd_rn( (float)propagate_in[i], __fmul_rn( propagate_intra, fps_factor ) );
+    int amount = (int)__fadd_rn( __fdiv_rn( __fmul_rn( propagate_amount, (float)( ic - inter ) ), (float)ic ), 0.5f );
+    dst[i] = (int16_t)( amount > 32767 ? 32767 : amount );
+}
+// ref_costs32: the frame's accumulators widened to 32 bits for the duration of the call (saturating adds of non-negative amounts
+// commute: the clamp is applied when the array is narrowed again)
+__global__ __launch_bounds__( 256 ) void mbt_list_row_kernel( int *__restrict__ ref_costs32, const int16_t *__restrict__ mvs, const int16_t *__restrict__ propagate_amount,
+                                                              const uint16_t *__restrict__ lowres_costs, int bipred_weight, int mb_y, int len, int list, int W, int H )
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if( i >= len )
+        return;
+    const int lists_used = lowres_costs[i] >> 14;
+    if( !( lists_used & ( 1 << list ) ) )
+        return;
+    int la = propagate_amount[i];
+    if( lists_used == 3 )
+        la = ( la * bipred_weight + 32 ) >> 6;
+    int x = mvs[2 * i], y = mvs[2 * i + 1];
+    if( !( x | y ) )
+    {
+        atomicAdd( &ref_costs32[mb_y * W + i], la );
+        return;
+    }
+    const unsigned mbx = (unsigned)( ( x >> 5 ) + i ), mby = (unsigned)( ( y >> 5 ) + mb_y );
+    const unsigned idx0 = mbx + mby * W, idx2 = idx0 + W;
+    x &= 31; y &= 31;
+    const int q0 = ( ( 32 - y ) * ( 32 - x ) * la + 512 ) >> 10, q1 = ( ( 32 - y ) * x * la + 512 ) >> 10;
+    const int q2 = ( y * ( 32 - x ) * la + 512 ) >> 10, q3 = ( y * x * la + 512 ) >> 10;
+    if( mby < (unsigned)H )
+    {
+        if( mbx < (unsigned)W ) atomicAdd( &ref_costs32[idx0], q0 );
+        if( mbx + 1 < (unsigned)W ) atomicAdd( &ref_costs32[idx0 + 1], q1 );
+    }
+    if( mby + 1 < (unsigned)H )
+    {
+        if( mbx < (unsigned)W ) atomicAdd( &ref_costs32[idx2], q2 );
+        if( mbx + 1 < (unsigned)W ) atomicAdd( &ref_costs32[idx2 + 1], q3 );
+    }
+}
+__global__ __launch_bounds__( 256 ) void widen_u16_kernel( int *__restrict__ dst, const uint16_t *__restrict__ src, int n )
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if( i < n ) dst[i] = src[i];
+}
+__global__ __launch_bounds__( 256 ) void narrow_clip15_kernel( uint16_t *__restrict__ dst, const int *__restrict__ src, int n )
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if( i < n ) dst[i] = (uint16_t)( src[i] < 32767 ? src[i] : 32767 );
 }

@@ -54,9 +54,16 @@ __device__ __forceinline__ int xcc_id()
 }
 
 // the evaluator of me_logic.h on the 16-lane block geometry: every cost is the same in the 16 lanes of a group
-template <typename T>
+// mv costs come from the cost_mv table (h->cost_mv[X264_LOOKAHEAD_QP], analyse.c:151-157), indexed by the quarter-pel difference to
+// the block's predictor.  Two table loads per candidate made the vector-memory pipe the busiest unit of the kernel (every wave64 load
+// instruction occupies the address unit for 16 cycles whatever it fetches), so each wave keeps the entries for differences of
+// less than ME_TAB_HALF quarter-pels in LDS; a block whose candidates could reach beyond that window (predictor hundreds of
+// samples long) is searched with the table in memory instead.
+#define ME_TAB_HALF 1024
+template <typename T, int LDS_TAB>
 struct GroupEval
 {
+    const uint16_t *lds_tab; // this wave's window: entry ME_TAB_HALF + d is the cost of difference d
     const T *rbase;      // wave-uniform: start of the reference frame's four-plane allocation (unweighted)
     const T *wbase;      // wave-uniform: plane read by full-pel candidates (weighted copy of plane 0, or rbase)
     const uint16_t *tab; // wave-uniform: first entry of the cost_mv table
@@ -69,6 +76,8 @@ struct GroupEval
 
     __device__ __forceinline__ int bits( int qx, int qy ) const
     {
+        if( LDS_TAB ) // tab_x / tab_y address the window around a zero mv difference that sits in LDS (me_rows_kernel)
+            return lds_tab[qx + tab_x] + lds_tab[qy + tab_y];
         return gload_u16( tab, 2u * (unsigned)( qx + tab_x ) ) + gload_u16( tab, 2u * (unsigned)( qy + tab_y ) );
     }
     __device__ __forceinline__ int fpel( int x, int y ) const
@@ -97,11 +106,20 @@ __device__ __forceinline__ int from_group_below( int v, int lane )
 //   1  sub-pel depth 4, mbcmp = SATD, fpelcmp = SAD      (subme >= 2)
 //   2  sub-pel depth 4, mbcmp = fpelcmp = SATD           (subme >= 2 with --me tesa)
 //   3  any other combination a caller configures: depth and metrics read from the parameters at run time
+#ifndef ME_MIN_WAVES
+#define ME_MIN_WAVES 4
+#endif
 template <typename T, int HEX, int MODE>
-__global__ __launch_bounds__( 64 ) void me_rows_kernel( LaP P, const SearchDesc<T> *descs, MeQueues Q, unsigned *tickets /* [ME_QUEUES * ME_QUEUE_STRIDE] */,
-                                                         unsigned *err_host /* pinned sticky timeout flag */, unsigned spin_limit )
+__global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, const SearchDesc<T> *descs, MeQueues Q, unsigned *tickets /* [ME_QUEUES * ME_QUEUE_STRIDE] */,
+                                                         unsigned *err_host /* pinned sticky timeout flag */, unsigned spin_limit,
+                                                         unsigned long long *prof /* ME_PROFILE builds: cycle accumulators, else unused */ )
 {
     const int lane = lane_id();
+#ifdef ME_PROFILE
+    unsigned long long pf_wait = 0, pf_pre = 0, pf_search = 0, pf_store = 0, pf_spins = 0, pf_steps = 0;
+    const unsigned long long pf_begin = __builtin_amdgcn_s_memtime();
+#define PF_NOW() __builtin_amdgcn_s_memtime()
+#endif
     const int W = P.mb_w, H = P.mb_h;
     const int n_rowgroups = ( H + ME_ROWS - 1 ) / ME_ROWS;
     // the ticket is wave-uniform: fetch it on lane 0 and broadcast through an SGPR so that the row group, the descriptor and
@@ -132,12 +150,24 @@ __global__ __launch_bounds__( 64 ) void me_rows_kernel( LaP P, const SearchDesc<
     const int by = by0 - g;               // this group's row
     const bool row_ok = by >= 0;
 
+    // the cost table window of this wave
+    __shared__ uint16_t tab_window[2 * ME_TAB_HALF];
+    {
+        const int centre = 2 * 4 * P.mv_range; // P.cost_mv is centred: valid differences are -centre .. +centre
+        for( int i = lane; i < 2 * ME_TAB_HALF; i += 64 )
+        {
+            const int d = i - ME_TAB_HALF;
+            tab_window[i] = d >= -centre && d <= centre ? P.cost_mv[d] : (uint16_t)0;
+        }
+        __syncthreads(); // one wave per workgroup: orders the LDS writes before the first block's reads
+    }
     MeCfg C;
     C.hex = HEX; C.me_range = P.me_range;
     C.refine4 = MODE == 3 ? P.subpel_refine >= 3 : MODE >= 1;
     C.mbcmp_satd = MODE == 3 ? P.mbcmp_satd : MODE >= 1;
     C.fpelcmp_satd = MODE == 3 ? P.fpelcmp_satd : MODE == 2;
-    GroupEval<T> ev;
+    GroupEval<T, 0> ev;
+    ev.lds_tab = tab_window;
     const int border = LA_PAD * P.stride + LA_PAD;
     const T *fbase = D.fenc0 - border;
     ev.rbase = D.ref0 - border;
@@ -169,6 +199,9 @@ __global__ __launch_bounds__( 64 ) void me_rows_kernel( LaP P, const SearchDesc<
     {
         const int bx = W - 1 - ( t - 2 * g );
         const bool active = row_ok && bx >= 0 && bx < W;
+#ifdef ME_PROFILE
+        const unsigned long long pf_t0 = PF_NOW();
+#endif
         // the row below: (x-1, y+1), (x, y+1), (x+1, y+1) are what the group below found one, two and three steps ago
         int below_left = from_group_below( r1, lane ), below = from_group_below( r2, lane ), below_right = from_group_below( r3, lane );
         {
@@ -198,6 +231,9 @@ __global__ __launch_bounds__( 64 ) void me_rows_kernel( LaP P, const SearchDesc<
                         return;
                     }
                     __builtin_amdgcn_s_sleep( 4 );
+#ifdef ME_PROFILE
+                    pf_spins++;
+#endif
                 }
                 const int lo = (int)(unsigned)gq;
                 const int w0 = __builtin_amdgcn_readlane( lo, 0 ), w1 = __builtin_amdgcn_readlane( lo, 1 ), w2 = __builtin_amdgcn_readlane( lo, 2 );
@@ -205,6 +241,10 @@ __global__ __launch_bounds__( 64 ) void me_rows_kernel( LaP P, const SearchDesc<
             }
         }
         int mvx = 0, mvy = 0, cost = 0;
+#ifdef ME_PROFILE
+        const unsigned long long pf_t1 = PF_NOW();
+        unsigned long long pf_t2 = pf_t1, pf_t3 = pf_t1;
+#endif
         if( active )
         {
             const int xy = by * W + bx;
@@ -233,14 +273,41 @@ __global__ __launch_bounds__( 64 ) void me_rows_kernel( LaP P, const SearchDesc<
                     cost = block_cost8x8<T>( ev.f, r, C.mbcmp_satd );
                     done = cost < 64;
                 }
+#ifdef ME_PROFILE
+                pf_t2 = PF_NOW();
+#endif
                 if( !done )
                 {
+                    // how far from the predictor can a candidate of this block be?  The start candidates (zero, the neighbours, the
+                    // predictor clipped to the full-pel and to the sub-pel limits) plus what the pattern search and the sub-pel
+                    // refinement can move away from them: me_range full-pel steps (DIA; HEX: me_range + 1) + 3 quarter-pels
+                    int reach = imax2( iabs( mvpx ), iabs( mvpy ) );
+#pragma unroll
+                    for( int i = 0; i < 4; i++ )
+                        if( i < n )
+                            reach = imax2( reach, imax2( iabs( mvcx[i] - mvpx ), iabs( mvcy[i] - mvpy ) ) );
+                    reach = imax2( reach, imax2( iabs( iclip3( mvpx, 4 * L.fmin_x, 4 * L.fmax_x ) - mvpx ), iabs( iclip3( mvpy, 4 * L.fmin_y, 4 * L.fmax_y ) - mvpy ) ) );
+                    reach = imax2( reach, imax2( iabs( iclip3( mvpx, L.smin_x + 2, L.smax_x - 2 ) - mvpx ), iabs( iclip3( mvpy, L.smin_y + 2, L.smax_y - 2 ) - mvpy ) ) );
+                    const bool far = reach + 4 * ( P.me_range + 4 ) >= ME_TAB_HALF;
+                    if( __builtin_amdgcn_ballot_w64( far ) == 0ull )
+                    {
+                        GroupEval<T, 1> evl;
+                        evl.lds_tab = tab_window; evl.rbase = ev.rbase; evl.wbase = ev.wbase; evl.tab = ev.tab; evl.plane_elems = ev.plane_elems;
+                        evl.stride = ev.stride; evl.pixel_max = ev.pixel_max; evl.fpelcmp_satd = ev.fpelcmp_satd; evl.wt = ev.wt;
+                        evl.lane_off = ev.lane_off; evl.f = ev.f;
+                        evl.tab_x = ME_TAB_HALF - mvpx; evl.tab_y = ME_TAB_HALF - mvpy;
+                        melogic::search( C, L, evl, mvpx, mvpy, n, mvcx, mvcy, mvx, mvy, cost );
+                    }
+                    else
                     melogic::search( C, L, ev, mvpx, mvpy, n, mvcx, mvcy, mvx, mvy, cost );
                     cost -= zero_bits;
                     if( mvx | mvy )
                         cost += 5 * P.lambda;
                 }
             }
+#ifdef ME_PROFILE
+            pf_t3 = PF_NOW();
+#endif
             // blocks slicetype_slice_cost never visits (slicetype.c:823-833) keep zero vectors (frame.c:283-285)
             if( ( lane & 15 ) == 0 )
             {
@@ -254,5 +321,20 @@ __global__ __launch_bounds__( 64 ) void me_rows_kernel( LaP P, const SearchDesc<
         }
         r3 = r2; r2 = r1;
         r1 = ( mvx & 0xFFFF ) | ( mvy << 16 );
+#ifdef ME_PROFILE
+        {
+            // wave-level view: the slowest group of the step (times are taken by whichever lane reads the counter last)
+            const unsigned long long pf_t4 = PF_NOW();
+            const unsigned long long a2 = __builtin_amdgcn_readfirstlane( (unsigned)( pf_t2 - pf_t1 ) ), a3 = __builtin_amdgcn_readfirstlane( (unsigned)( pf_t3 - pf_t2 ) );
+            pf_wait += pf_t1 - pf_t0; pf_pre += a2; pf_search += a3; pf_store += pf_t4 - pf_t1 - a2 - a3; pf_steps++;
+        }
+#endif
     }
+#ifdef ME_PROFILE
+    if( lane == 0 && prof )
+    {
+        atomicAdd( prof + 0, PF_NOW() - pf_begin ); atomicAdd( prof + 1, pf_wait ); atomicAdd( prof + 2, pf_pre ); atomicAdd( prof + 3, pf_search );
+        atomicAdd( prof + 4, pf_store ); atomicAdd( prof + 5, pf_spins ); atomicAdd( prof + 6, pf_steps ); atomicAdd( prof + 7, 1ull );
+    }
+#endif
 }

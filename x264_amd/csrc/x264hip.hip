@@ -24,6 +24,7 @@
 #include "dct_quant_block.h"
 #include "me_full.h"
 #include "integral.h"
+#include "vtable_blocks.h"
 
 #define HIPCK( call )                                                                                        \
     do {                                                                                                     \
@@ -99,6 +100,7 @@ struct x264hip_ctx
     uint16_t *cost_mv_dev = nullptr; // base (not centred)
     AqLuts *luts_dev = nullptr;
     unsigned *sync_words = nullptr;  // device: row-ticket counters of the search kernel
+    unsigned long long *me_prof = nullptr; // ME_PROFILE builds: 8 cycle accumulators of the search kernel (device), else unused
     int n_cells = 0;                 // (bframes+2)^2
     int *cell_acc_host = nullptr;    // pinned [slots][n_cells][8]: sums of every cell evaluation, written by the device directly
     DescRing cell_ring, put_ring, search_ring;
@@ -239,9 +241,23 @@ static void free_all( x264hip_ctx *ctx )
     if( ctx->stream ) (void)hipStreamDestroy( ctx->stream );
 }
 
+extern "C" void x264hip_mc_unbind( x264hip_ctx *ctx );
 extern "C" void x264hip_close( x264hip_ctx *ctx )
 {
     if( !ctx ) return;
+    x264hip_mc_unbind( ctx );
+#ifdef ME_PROFILE
+    if( ctx->me_prof )
+    {
+        unsigned long long v[8] = { 0 };
+        (void)hipStreamSynchronize( ctx->stream );
+        (void)hipMemcpy( v, ctx->me_prof, sizeof( v ), hipMemcpyDeviceToHost );
+        if( v[7] )
+            fprintf( stderr, "ME_PROFILE waves %llu steps/wave %.1f cycles/wave %.0f | per step: wait-below %.0f pre %.0f search %.0f store+rest %.0f | spins/step %.3f\n", v[7],
+                     (double)v[6] / v[7], (double)v[0] / v[7], (double)v[1] / v[6], (double)v[2] / v[6], (double)v[3] / v[6], (double)v[4] / v[6], (double)v[5] / v[6] );
+        (void)hipFree( ctx->me_prof );
+    }
+#endif
     free_all( ctx );
     delete ctx;
 }
@@ -315,6 +331,10 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     }
     OPENCK( hipMalloc( &ctx->sync_words, ME_QUEUES * ME_QUEUE_STRIDE * sizeof( unsigned ) ) ); // row tickets of the search kernel
     OPENCK( hipMemset( ctx->sync_words, 0, ME_QUEUES * ME_QUEUE_STRIDE * sizeof( unsigned ) ) );
+#ifdef ME_PROFILE
+    OPENCK( hipMalloc( &ctx->me_prof, 8 * sizeof( unsigned long long ) ) );
+    OPENCK( hipMemset( ctx->me_prof, 0, 8 * sizeof( unsigned long long ) ) );
+#endif
     ctx->n_cells = ( p.bframes + 2 ) * ( p.bframes + 2 );
     OPENCK( hipHostMalloc( &ctx->cell_acc_host, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
     memset( ctx->cell_acc_host, 0, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) );
@@ -736,7 +756,7 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         const int n_waves = n * ( ( P.mb_h + ME_ROWS - 1 ) / ME_ROWS );
         const bool hex = P.me_method == X264HIP_ME_HEX, r4 = P.subpel_refine >= 3;
         const int mode = !r4 && !P.mbcmp_satd && !P.fpelcmp_satd ? 0 : r4 && P.mbcmp_satd ? ( P.fpelcmp_satd ? 2 : 1 ) : 3;
-#define ME_LAUNCH( HEXV, MODEV ) me_rows_kernel<T, HEXV, MODEV><<<n_waves, 64, 0, ctx->stream>>>( P, dd, Q, ctx->sync_words, ctx->err_host, 1u << 22 )
+#define ME_LAUNCH( HEXV, MODEV ) me_rows_kernel<T, HEXV, MODEV><<<n_waves, 64, 0, ctx->stream>>>( P, dd, Q, ctx->sync_words, ctx->err_host, 1u << 22, ctx->me_prof )
         switch( 4 * hex + mode )
         {
             case 0: ME_LAUNCH( 0, 0 ); break;
@@ -1432,24 +1452,35 @@ extern "C" int x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx
                                         int blocks_w, int blocks_h, const int16_t *mv_dev, int *out_dev )
 {
     if( !ctx || !fenc_plane || !ref_plane || !mv_dev || !out_dev ) return X264HIP_EINVAL;
-    const int size = size_idx == 0 ? 16 : size_idx == 3 ? 8 : size_idx == 6 ? 4 : 0;
-    if( !size || ( blocks_w * size ) % 16 || ( blocks_h * size ) % 16 ) return X264HIP_EINVAL;
+    static const int sz_w[7] = { 16, 16, 8, 8, 8, 4, 4 }, sz_h[7] = { 16, 8, 16, 8, 4, 8, 4 }; // common/pixel.h:37-59, PIXEL_16x16 .. PIXEL_4x4
+    if( size_idx < 0 || size_idx > 6 || blocks_w <= 0 || blocks_h <= 0 ) return X264HIP_EINVAL;
+    const int bwid = sz_w[size_idx], bhgt = sz_h[size_idx];
+    if( ( blocks_w * bwid ) % 16 || ( blocks_h * bhgt ) % 16 ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
-    const int rw = blocks_w * size / 16, rh = blocks_h * size / 16;
+    const int rw = blocks_w * bwid / 16, rh = blocks_h * bhgt / 16;
     const dim3 grd( ( rw + 15 ) / 16, rh );
-#define CMP_LAUNCH( T, S, D ) \
-    pixel_cmp_batch_kernel<T, S, D><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, mv_dev, out_dev )
+#define CMP_LAUNCH( T, BW, BH, D ) \
+    pixel_cmp_batch_kernel<T, BW, BH, D><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, mv_dev, out_dev )
+#define CMP_METRIC( T, BW, BH ) do { if( satd ) CMP_LAUNCH( T, BW, BH, true ); else CMP_LAUNCH( T, BW, BH, false ); } while( 0 )
 #define CMP_SIZE( T ) \
     do { \
-        if( size == 16 ) { if( satd ) CMP_LAUNCH( T, 16, true ); else CMP_LAUNCH( T, 16, false ); } \
-        else if( size == 8 ) { if( satd ) CMP_LAUNCH( T, 8, true ); else CMP_LAUNCH( T, 8, false ); } \
-        else { if( satd ) CMP_LAUNCH( T, 4, true ); else CMP_LAUNCH( T, 4, false ); } \
+        switch( size_idx ) \
+        { \
+            case 0: CMP_METRIC( T, 16, 16 ); break; \
+            case 1: CMP_METRIC( T, 16, 8 ); break; \
+            case 2: CMP_METRIC( T, 8, 16 ); break; \
+            case 3: CMP_METRIC( T, 8, 8 ); break; \
+            case 4: CMP_METRIC( T, 8, 4 ); break; \
+            case 5: CMP_METRIC( T, 4, 8 ); break; \
+            default: CMP_METRIC( T, 4, 4 ); break; \
+        } \
     } while( 0 )
     if( ctx->p.bit_depth == 8 )
         CMP_SIZE( uint8_t );
     else
         CMP_SIZE( uint16_t );
+#undef CMP_METRIC
 #undef CMP_SIZE
 #undef CMP_LAUNCH
     HIPCK( hipGetLastError() );
@@ -1772,4 +1803,281 @@ extern "C" int x264hip_dct_quant_batch( x264hip_ctx *ctx, int is8x8, int n_block
     (void)hipFree( dev );
     if( rc ) ctx->broken = 1;
     return rc;
+}
+
+// ---- the remaining per-macroblock vtable entries in batch form (vtable_blocks.h): host buffers staged through one device allocation ----
+namespace {
+struct Staged
+{
+    char *dev = nullptr;
+    std::vector<size_t> off;
+    size_t total = 0;
+    size_t add( size_t bytes ) { off.push_back( total ); total += align_up( bytes ? bytes : 1, 256 ); return off.size() - 1; }
+    char *at( size_t i ) const { return dev + off[i]; }
+    ~Staged() { if( dev ) (void)hipFree( dev ); }
+};
+}
+
+extern "C" int x264hip_dct_batch( x264hip_ctx *ctx, int kind, int n, const void *fenc, const void *fdec, void *coefs )
+{
+    if( !ctx || n <= 0 || !coefs || !vt_dct_coefs( kind ) || ( !vt_dct_in_place( kind ) && ( !fenc || !fdec ) ) ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    const int psz = ctx->psz, csz = ctx->p.bit_depth == 8 ? 2 : 4;
+    const size_t fe_b = (size_t)n * 16 * VT_FENC_STRIDE * psz, fd_b = (size_t)n * 16 * VT_FDEC_STRIDE * psz, co_b = (size_t)n * vt_dct_coefs( kind ) * csz;
+    Staged st;
+    const size_t i_fe = st.add( fe_b ), i_fd = st.add( fd_b ), i_co = st.add( co_b );
+    HIPCK( hipMalloc( &st.dev, st.total ) );
+    if( vt_dct_in_place( kind ) )
+        HIPCK( hipMemcpy( st.at( i_co ), coefs, co_b, hipMemcpyHostToDevice ) );
+    else
+    {
+        HIPCK( hipMemcpy( st.at( i_fe ), fenc, fe_b, hipMemcpyHostToDevice ) );
+        HIPCK( hipMemcpy( st.at( i_fd ), fdec, fd_b, hipMemcpyHostToDevice ) );
+    }
+    const int grid = ( n + 63 ) / 64;
+    if( ctx->p.bit_depth == 8 )
+        vt_dct_kernel<uint8_t, int16_t><<<grid, 64, 0, ctx->stream>>>( kind, n, (const uint8_t *)st.at( i_fe ), (const uint8_t *)st.at( i_fd ), (int16_t *)st.at( i_co ) );
+    else
+        vt_dct_kernel<uint16_t, int32_t><<<grid, 64, 0, ctx->stream>>>( kind, n, (const uint16_t *)st.at( i_fe ), (const uint16_t *)st.at( i_fd ), (int32_t *)st.at( i_co ) );
+    HIPCK( hipGetLastError() );
+    HIPCK( hipStreamSynchronize( ctx->stream ) );
+    HIPCK( hipMemcpy( coefs, st.at( i_co ), co_b, hipMemcpyDeviceToHost ) );
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_quant_batch( x264hip_ctx *ctx, int kind, int n, void *coefs, const void *mf, const void *bias, int mf_dc, int bias_dc, int *nz )
+{
+    const bool dc = kind == VT_QUANT_4X4_DC || kind == VT_QUANT_2X2_DC;
+    if( !ctx || n <= 0 || !coefs || !nz || !vt_quant_coefs( kind ) || ( !dc && ( !mf || !bias ) ) ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    const int csz = ctx->p.bit_depth == 8 ? 2 : 4; // dctcoef and udctcoef have the same size (common/common.h:93-105)
+    const int n_tab = kind == VT_QUANT_8X8 ? 64 : 16;
+    const size_t co_b = (size_t)n * vt_quant_coefs( kind ) * csz, tab_b = (size_t)n_tab * csz;
+    Staged st;
+    const size_t i_co = st.add( co_b ), i_mf = st.add( tab_b ), i_bias = st.add( tab_b ), i_nz = st.add( (size_t)n * sizeof( int ) );
+    HIPCK( hipMalloc( &st.dev, st.total ) );
+    HIPCK( hipMemcpy( st.at( i_co ), coefs, co_b, hipMemcpyHostToDevice ) );
+    if( !dc )
+    {
+        HIPCK( hipMemcpy( st.at( i_mf ), mf, tab_b, hipMemcpyHostToDevice ) );
+        HIPCK( hipMemcpy( st.at( i_bias ), bias, tab_b, hipMemcpyHostToDevice ) );
+    }
+    const int grid = ( n + 63 ) / 64;
+    if( ctx->p.bit_depth == 8 )
+        vt_quant_kernel<int16_t, uint16_t><<<grid, 64, 0, ctx->stream>>>( kind, n, (int16_t *)st.at( i_co ), (const uint16_t *)st.at( i_mf ), (const uint16_t *)st.at( i_bias ),
+                                                                          mf_dc, bias_dc, (int *)st.at( i_nz ) );
+    else
+        vt_quant_kernel<int32_t, uint32_t><<<grid, 64, 0, ctx->stream>>>( kind, n, (int32_t *)st.at( i_co ), (const uint32_t *)st.at( i_mf ), (const uint32_t *)st.at( i_bias ),
+                                                                          mf_dc, bias_dc, (int *)st.at( i_nz ) );
+    HIPCK( hipGetLastError() );
+    HIPCK( hipStreamSynchronize( ctx->stream ) );
+    HIPCK( hipMemcpy( coefs, st.at( i_co ), co_b, hipMemcpyDeviceToHost ) );
+    HIPCK( hipMemcpy( nz, st.at( i_nz ), (size_t)n * sizeof( int ), hipMemcpyDeviceToHost ) );
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_var2_batch( x264hip_ctx *ctx, int height, int n, const void *fenc, const void *fdec, int *var, int *ssd )
+{
+    if( !ctx || n <= 0 || !fenc || !fdec || !var || !ssd || ( height != 8 && height != 16 ) ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    const size_t fe_b = (size_t)n * 16 * VT_FENC_STRIDE * ctx->psz, fd_b = (size_t)n * 16 * VT_FDEC_STRIDE * ctx->psz;
+    Staged st;
+    const size_t i_fe = st.add( fe_b ), i_fd = st.add( fd_b ), i_var = st.add( (size_t)n * sizeof( int ) ), i_ssd = st.add( (size_t)n * 2 * sizeof( int ) );
+    HIPCK( hipMalloc( &st.dev, st.total ) );
+    HIPCK( hipMemcpy( st.at( i_fe ), fenc, fe_b, hipMemcpyHostToDevice ) );
+    HIPCK( hipMemcpy( st.at( i_fd ), fdec, fd_b, hipMemcpyHostToDevice ) );
+    const int grid = ( n + 63 ) / 64;
+    if( ctx->p.bit_depth == 8 )
+        vt_var2_kernel<uint8_t><<<grid, 64, 0, ctx->stream>>>( height, n, (const uint8_t *)st.at( i_fe ), (const uint8_t *)st.at( i_fd ), (int *)st.at( i_var ), (int *)st.at( i_ssd ) );
+    else
+        vt_var2_kernel<uint16_t><<<grid, 64, 0, ctx->stream>>>( height, n, (const uint16_t *)st.at( i_fe ), (const uint16_t *)st.at( i_fd ), (int *)st.at( i_var ), (int *)st.at( i_ssd ) );
+    HIPCK( hipGetLastError() );
+    HIPCK( hipStreamSynchronize( ctx->stream ) );
+    HIPCK( hipMemcpy( var, st.at( i_var ), (size_t)n * sizeof( int ), hipMemcpyDeviceToHost ) );
+    HIPCK( hipMemcpy( ssd, st.at( i_ssd ), (size_t)n * 2 * sizeof( int ), hipMemcpyDeviceToHost ) );
+    return X264HIP_OK;
+}
+
+static_assert( sizeof( x264hip_ads_call ) == sizeof( VtAdsCall ), "x264hip_ads_call mirrors VtAdsCall" );
+extern "C" int x264hip_ads_batch( x264hip_ctx *ctx, int n, const x264hip_ads_call *calls, const uint16_t *sums, size_t n_sums, const uint16_t *cost_mvx, size_t n_cost,
+                                  int16_t *mvs, size_t n_mvs, int *counts )
+{
+    if( !ctx || n <= 0 || !calls || !sums || !cost_mvx || !mvs || !counts ) return X264HIP_EINVAL;
+    for( int i = 0; i < n; i++ )
+    {
+        const x264hip_ads_call &c = calls[i];
+        const long long span = ( c.n_dc == 4 ? c.delta + 8 : c.n_dc == 2 ? c.delta : 0 ) + c.width;
+        if( ( c.n_dc != 1 && c.n_dc != 2 && c.n_dc != 4 ) || c.width < 0 || c.delta < 0 || c.sums_off < 0 || c.cost_off < 0 || c.mvs_off < 0 ||
+            c.sums_off + span > (long long)n_sums || c.cost_off + c.width > (long long)n_cost || c.mvs_off + c.width > (long long)n_mvs )
+            return X264HIP_EINVAL;
+    }
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    Staged st;
+    const size_t i_calls = st.add( (size_t)n * sizeof( VtAdsCall ) ), i_sums = st.add( n_sums * 2 ), i_cost = st.add( n_cost * 2 ), i_mvs = st.add( n_mvs * 2 ),
+                 i_cnt = st.add( (size_t)n * sizeof( int ) );
+    HIPCK( hipMalloc( &st.dev, st.total ) );
+    HIPCK( hipMemcpy( st.at( i_calls ), calls, (size_t)n * sizeof( VtAdsCall ), hipMemcpyHostToDevice ) );
+    HIPCK( hipMemcpy( st.at( i_sums ), sums, n_sums * 2, hipMemcpyHostToDevice ) );
+    HIPCK( hipMemcpy( st.at( i_cost ), cost_mvx, n_cost * 2, hipMemcpyHostToDevice ) );
+    HIPCK( hipMemset( st.at( i_mvs ), 0, n_mvs * 2 ) );
+    vt_ads_kernel<<<n, 64, 0, ctx->stream>>>( n, (const VtAdsCall *)st.at( i_calls ), (const uint16_t *)st.at( i_sums ), (const uint16_t *)st.at( i_cost ),
+                                             (int16_t *)st.at( i_mvs ), (int *)st.at( i_cnt ) );
+    HIPCK( hipGetLastError() );
+    HIPCK( hipStreamSynchronize( ctx->stream ) );
+    HIPCK( hipMemcpy( mvs, st.at( i_mvs ), n_mvs * 2, hipMemcpyDeviceToHost ) );
+    HIPCK( hipMemcpy( counts, st.at( i_cnt ), (size_t)n * sizeof( int ), hipMemcpyDeviceToHost ) );
+    return X264HIP_OK;
+}
+
+// ---- x264_mc_functions_t members with the reference's exact signatures (common/mc.h:292,306-307,326-327,333-337) -----------------------
+// The vtable functions of the reference carry no context argument, so the filler binds them to one context per process; the
+// pointers are HOST pointers like the ones the encoder passes, staged through device memory on every call (correct and
+// signature-compatible; a caller that cares about speed keeps its planes on the device and uses the x264hip_* entries that take
+// device pointers).  The functions return void like the originals: a device failure latches the context (x264hip_synchronize and
+// every other call then return X264HIP_EDEVICE), which is how slicetype-cl.c:44-56 reports errors as well.
+namespace {
+x264hip_ctx *g_vt_ctx = nullptr;
+
+struct VtFail {};
+#define VTCK( call ) do { if( ( call ) != hipSuccess ) throw VtFail(); } while( 0 )
+#define VTRC( call ) do { if( ( call ) != X264HIP_OK ) throw VtFail(); } while( 0 )
+
+template <typename F>
+void vt_guard( F body )
+{
+    x264hip_ctx *ctx = g_vt_ctx;
+    if( !ctx || ctx->broken ) return;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) { ctx->broken = 1; return; }
+    try { body( ctx ); }
+    catch( const VtFail & ) { ctx->broken = 1; }
+    catch( ... ) { ctx->broken = 1; }
+}
+
+void vt_plane_copy( void *dst, intptr_t i_dst, void *src, intptr_t i_src, int w, int h )
+{
+    vt_guard( [&]( x264hip_ctx *ctx ) {
+        if( w <= 0 || h <= 0 ) return;
+        const size_t row = (size_t)w * ctx->psz, pitch = align_up( row, 16 );
+        Staged st;
+        const size_t a = st.add( pitch * h ), b = st.add( pitch * h );
+        VTCK( hipMalloc( &st.dev, st.total ) );
+        VTCK( hipMemcpy2D( st.at( a ), pitch, src, (size_t)i_src * ctx->psz, row, h, hipMemcpyHostToDevice ) );
+        VTRC( x264hip_device_copy( ctx, st.at( b ), st.at( a ), pitch * h ) );
+        VTCK( hipStreamSynchronize( ctx->stream ) );
+        VTCK( hipMemcpy2D( dst, (size_t)i_dst * ctx->psz, st.at( b ), pitch, row, h, hipMemcpyDeviceToHost ) );
+    } );
+}
+
+void vt_hpel_filter( void *dsth, void *dstv, void *dstc, void *src, intptr_t stride, int width, int height, int16_t *buf )
+{
+    (void)buf; // the C version's scratch row; the kernel keeps its intermediate sums in LDS
+    vt_guard( [&]( x264hip_ctx *ctx ) {
+        if( width <= 0 || height <= 0 ) return;
+        const int psz = ctx->psz;
+        // the four planes get the caller's geometry on the device: rows -2 .. height+2 of `stride` samples, 8 samples of slack in front
+        const size_t rows = height + 5, plane_b = ( rows * stride + 16 ) * psz;
+        Staged st;
+        const size_t i_s = st.add( plane_b ), i_h = st.add( plane_b ), i_v = st.add( plane_b ), i_c = st.add( plane_b );
+        VTCK( hipMalloc( &st.dev, st.total ) );
+        auto org = [&]( size_t i ) { return st.at( i ) + ( (size_t)2 * stride + 8 ) * psz; }; // sample (0,0)
+        // what the C version reads: columns -2 .. width+2 of rows -2 .. height+2 (mc.c:172-196)
+        VTCK( hipMemcpy2D( org( i_s ) - ( 2 * stride + 2 ) * psz, (size_t)stride * psz, (const char *)src - ( 2 * stride + 2 ) * psz, (size_t)stride * psz,
+                           (size_t)( width + 5 ) * psz, rows, hipMemcpyHostToDevice ) );
+        VTRC( x264hip_hpel_filter( ctx, org( i_h ), org( i_v ), org( i_c ), org( i_s ), stride, width, height ) );
+        VTCK( hipStreamSynchronize( ctx->stream ) );
+        VTCK( hipMemcpy2D( dsth, (size_t)stride * psz, org( i_h ), (size_t)stride * psz, (size_t)width * psz, height, hipMemcpyDeviceToHost ) );
+        VTCK( hipMemcpy2D( dstc, (size_t)stride * psz, org( i_c ), (size_t)stride * psz, (size_t)width * psz, height, hipMemcpyDeviceToHost ) );
+        // dstv also receives columns -2, -1 and width .. width+2 (the C version filters them for the centre plane and stores them)
+        VTCK( hipMemcpy2D( (char *)dstv - 2 * psz, (size_t)stride * psz, org( i_v ) - 2 * psz, (size_t)stride * psz, (size_t)( width + 5 ) * psz, height, hipMemcpyDeviceToHost ) );
+    } );
+}
+
+void vt_frame_init_lowres_core( void *src0, void *dst0, void *dsth, void *dstv, void *dstc, intptr_t src_stride, intptr_t dst_stride, int width, int height )
+{
+    vt_guard( [&]( x264hip_ctx *ctx ) {
+        if( width <= 0 || height <= 0 ) return;
+        const int psz = ctx->psz;
+        // reads rows 0 .. 2*height and columns 0 .. 2*width of the source (mc.c:484-507)
+        const size_t s_rows = 2 * (size_t)height + 1, s_row_b = ( 2 * (size_t)width + 1 ) * psz, s_pitch = align_up( s_row_b, 16 );
+        const size_t d_row_b = (size_t)width * psz, d_pitch = align_up( d_row_b, 16 );
+        Staged st;
+        const size_t i_s = st.add( s_pitch * s_rows ), i0 = st.add( d_pitch * height ), i1 = st.add( d_pitch * height ), i2 = st.add( d_pitch * height ),
+                     i3 = st.add( d_pitch * height );
+        VTCK( hipMalloc( &st.dev, st.total ) );
+        VTCK( hipMemcpy2D( st.at( i_s ), s_pitch, src0, (size_t)src_stride * psz, s_row_b, s_rows, hipMemcpyHostToDevice ) );
+        VTRC( x264hip_frame_init_lowres_core( ctx, st.at( i_s ), st.at( i0 ), st.at( i1 ), st.at( i2 ), st.at( i3 ), (intptr_t)( s_pitch / psz ), (intptr_t)( d_pitch / psz ),
+                                              width, height ) );
+        VTCK( hipStreamSynchronize( ctx->stream ) );
+        void *dst[4] = { dst0, dsth, dstv, dstc };
+        const size_t idx[4] = { i0, i1, i2, i3 };
+        for( int k = 0; k < 4; k++ )
+            VTCK( hipMemcpy2D( dst[k], (size_t)dst_stride * psz, st.at( idx[k] ), d_pitch, d_row_b, height, hipMemcpyDeviceToHost ) );
+    } );
+}
+
+void vt_mbtree_propagate_cost( int16_t *dst, uint16_t *propagate_in, uint16_t *intra_costs, uint16_t *inter_costs, uint16_t *inv_qscales, float *fps_factor, int len )
+{
+    vt_guard( [&]( x264hip_ctx *ctx ) {
+        if( len <= 0 ) return;
+        const size_t b = (size_t)len * 2;
+        Staged st;
+        const size_t i_d = st.add( b ), i_p = st.add( b ), i_i = st.add( b ), i_e = st.add( b ), i_q = st.add( b );
+        VTCK( hipMalloc( &st.dev, st.total ) );
+        VTCK( hipMemcpy( st.at( i_p ), propagate_in, b, hipMemcpyHostToDevice ) );
+        VTCK( hipMemcpy( st.at( i_i ), intra_costs, b, hipMemcpyHostToDevice ) );
+        VTCK( hipMemcpy( st.at( i_e ), inter_costs, b, hipMemcpyHostToDevice ) );
+        VTCK( hipMemcpy( st.at( i_q ), inv_qscales, b, hipMemcpyHostToDevice ) );
+        mbt_cost_row_kernel<<<( len + 255 ) / 256, 256, 0, ctx->stream>>>( (int16_t *)st.at( i_d ), (const uint16_t *)st.at( i_p ), (const uint16_t *)st.at( i_i ),
+                                                                         (const uint16_t *)st.at( i_e ), (const uint16_t *)st.at( i_q ), *fps_factor, len );
+        VTCK( hipGetLastError() );
+        VTCK( hipStreamSynchronize( ctx->stream ) );
+        VTCK( hipMemcpy( dst, st.at( i_d ), b, hipMemcpyDeviceToHost ) );
+    } );
+}
+
+void vt_mbtree_propagate_list( void *h, uint16_t *ref_costs, int16_t ( *mvs )[2], int16_t *propagate_amount, uint16_t *lowres_costs, int bipred_weight, int mb_y, int len,
+                               int list )
+{
+    (void)h; // x264_t *: the C version reads the macroblock geometry from it; here that is the bound context's
+    vt_guard( [&]( x264hip_ctx *ctx ) {
+        const int W = ctx->P.mb_w, H = ctx->P.mb_h, n_mb = W * H;
+        if( len <= 0 || len > W || mb_y < 0 || mb_y >= H ) throw VtFail();
+        Staged st;
+        const size_t i_r16 = st.add( (size_t)n_mb * 2 ), i_r32 = st.add( (size_t)n_mb * 4 ), i_mv = st.add( (size_t)len * 4 ), i_pa = st.add( (size_t)len * 2 ),
+                     i_lc = st.add( (size_t)len * 2 );
+        VTCK( hipMalloc( &st.dev, st.total ) );
+        VTCK( hipMemcpy( st.at( i_r16 ), ref_costs, (size_t)n_mb * 2, hipMemcpyHostToDevice ) );
+        VTCK( hipMemcpy( st.at( i_mv ), mvs, (size_t)len * 4, hipMemcpyHostToDevice ) );
+        VTCK( hipMemcpy( st.at( i_pa ), propagate_amount, (size_t)len * 2, hipMemcpyHostToDevice ) );
+        VTCK( hipMemcpy( st.at( i_lc ), lowres_costs, (size_t)len * 2, hipMemcpyHostToDevice ) );
+        widen_u16_kernel<<<( n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( (int *)st.at( i_r32 ), (const uint16_t *)st.at( i_r16 ), n_mb );
+        mbt_list_row_kernel<<<( len + 255 ) / 256, 256, 0, ctx->stream>>>( (int *)st.at( i_r32 ), (const int16_t *)st.at( i_mv ), (const int16_t *)st.at( i_pa ),
+                                                                         (const uint16_t *)st.at( i_lc ), bipred_weight, mb_y, len, list, W, H );
+        narrow_clip15_kernel<<<( n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( (uint16_t *)st.at( i_r16 ), (const int *)st.at( i_r32 ), n_mb );
+        VTCK( hipGetLastError() );
+        VTCK( hipStreamSynchronize( ctx->stream ) );
+        VTCK( hipMemcpy( ref_costs, st.at( i_r16 ), (size_t)n_mb * 2, hipMemcpyDeviceToHost ) );
+    } );
+}
+} // namespace
+
+extern "C" int x264hip_mc_fill( x264hip_ctx *ctx, x264hip_mc_functions *pf )
+{
+    if( !ctx || !pf ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    g_vt_ctx = ctx;
+    pf->plane_copy = vt_plane_copy;
+    pf->hpel_filter = vt_hpel_filter;
+    pf->frame_init_lowres_core = vt_frame_init_lowres_core;
+    pf->mbtree_propagate_cost = vt_mbtree_propagate_cost;
+    pf->mbtree_propagate_list = vt_mbtree_propagate_list;
+    return X264HIP_OK;
+}
+extern "C" void x264hip_mc_unbind( x264hip_ctx *ctx )
+{
+    if( g_vt_ctx == ctx ) g_vt_ctx = nullptr;
 }

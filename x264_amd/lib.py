@@ -57,9 +57,10 @@ def load():
     """Load libx264hip.so; raises if it has not been built (the product never falls back to CPU code)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError("x264_amd/libx264hip.so is missing: run `python -m x264_amd.build` (needs hipcc)")
-        _lib = C.CDLL(LIB_PATH)
+        path = os.environ.get("X264HIP_LIB", LIB_PATH)  # X264HIP_LIB: an alternative build of the same library (profiling builds)
+        if not os.path.exists(path):
+            raise ImportError("%s is missing: run `python -m x264_amd.build` (needs hipcc)" % path)
+        _lib = C.CDLL(path)
         _lib.x264hip_strerror.restype = C.c_char_p
         _lib.x264hip_open.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Params)]
     return _lib
@@ -288,6 +289,59 @@ class Context:
         _ck(self.L.x264hip_dct_quant_batch(self.h, int(is8x8), n, _p(fenc), _p(fdec), _p(mf), _p(bias), _p(coefs), _p(nz)), "dct_quant_batch")
         return coefs, nz
 
+    # ---- the remaining vtable entries in batch form (x264hip_dct_batch / quant_batch / var2_batch / ads_batch) ----
+    DCT_COEFS = {0: 16, 1: 64, 2: 256, 3: 64, 4: 256, 5: 4, 6: 8, 7: 16, 8: 8}
+    QUANT_COEFS = {0: 16, 1: 64, 2: 64, 3: 16, 4: 4}
+
+    def dct_batch(self, kind, fenc=None, fdec=None, coefs=None):
+        """fenc (n,16,16) / fdec (n,16,32) pixel buffers; kinds 7, 8 transform `coefs` (n, 16 / 8) in place.  Returns coefs (n, count)."""
+        cdt = np.int16 if self.params.bit_depth == 8 else np.int32
+        if kind >= 7:
+            out = np.ascontiguousarray(coefs, cdt).copy()
+            n = out.shape[0]
+            _ck(self.L.x264hip_dct_batch(self.h, kind, n, None, None, _p(out)), "dct_batch")
+            return out
+        fenc = np.ascontiguousarray(fenc, self.dtype); fdec = np.ascontiguousarray(fdec, self.dtype)
+        n = fenc.shape[0]
+        assert fenc.shape[1:] == (16, 16) and fdec.shape[1:] == (16, 32)
+        out = np.zeros((n, self.DCT_COEFS[kind]), cdt)
+        _ck(self.L.x264hip_dct_batch(self.h, kind, n, _p(fenc), _p(fdec), _p(out)), "dct_batch")
+        return out
+
+    def quant_batch(self, kind, coefs, mf=None, bias=None, mf_dc=0, bias_dc=0):
+        cdt = np.int16 if self.params.bit_depth == 8 else np.int32
+        udt = np.uint16 if self.params.bit_depth == 8 else np.uint32
+        out = np.ascontiguousarray(coefs, cdt).copy()
+        n = out.shape[0]
+        assert out.shape[1] == self.QUANT_COEFS[kind]
+        nz = np.zeros(n, np.int32)
+        mf = np.ascontiguousarray(mf, udt) if mf is not None else None
+        bias = np.ascontiguousarray(bias, udt) if bias is not None else None
+        _ck(self.L.x264hip_quant_batch(self.h, kind, n, _p(out), _p(mf), _p(bias), int(mf_dc), int(bias_dc), _p(nz)), "quant_batch")
+        return out, nz
+
+    def var2_batch(self, height, fenc, fdec):
+        fenc = np.ascontiguousarray(fenc, self.dtype); fdec = np.ascontiguousarray(fdec, self.dtype)
+        n = fenc.shape[0]
+        var = np.zeros(n, np.int32); ssd = np.zeros((n, 2), np.int32)
+        _ck(self.L.x264hip_var2_batch(self.h, int(height), n, _p(fenc), _p(fdec), _p(var), _p(ssd)), "var2_batch")
+        return var, ssd
+
+    def ads_batch(self, calls, sums, cost_mvx, n_mvs):
+        """calls: list of dicts(n_dc, delta, width, thresh, enc_dc[<=4], sums_off, cost_off, mvs_off); returns (mvs, counts)."""
+        arr = (AdsCall * len(calls))()
+        for a, c in zip(arr, calls):
+            a.n_dc, a.delta, a.width, a.thresh = c["n_dc"], c["delta"], c["width"], c["thresh"]
+            for k, v in enumerate(c["enc_dc"]):
+                a.enc_dc[k] = int(v)
+            a.sums_off, a.cost_off, a.mvs_off = c["sums_off"], c["cost_off"], c["mvs_off"]
+        sums = np.ascontiguousarray(sums, np.uint16); cost_mvx = np.ascontiguousarray(cost_mvx, np.uint16)
+        mvs = np.zeros(n_mvs, np.int16); counts = np.zeros(len(calls), np.int32)
+        self.L.x264hip_ads_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        _ck(self.L.x264hip_ads_batch(self.h, len(calls), C.cast(arr, C.c_void_p), _p(sums), sums.size, _p(cost_mvx), cost_mvx.size, _p(mvs), mvs.size, _p(counts)),
+            "ads_batch")
+        return mvs, counts
+
     def last_search_ms(self):
         ms, ns, nb = C.c_float(), C.c_int(), C.c_int()
         _ck(self.L.x264hip_last_search_ms(self.h, C.byref(ms), C.byref(ns), C.byref(nb)), "last_search_ms")
@@ -300,6 +354,12 @@ class Context:
 
     def search_profile(self, enable=-1):
         return search_profile(self.L, self.h, enable)
+
+
+class AdsCall(C.Structure):
+    """x264hip_ads_call"""
+    _fields_ = [("n_dc", C.c_int), ("delta", C.c_int), ("width", C.c_int), ("thresh", C.c_int), ("enc_dc", C.c_int * 4),
+                ("sums_off", C.c_longlong), ("cost_off", C.c_longlong), ("mvs_off", C.c_longlong)]
 
 
 # ---- host-side lookahead (x264hip_lookahead_*) -----------------------------------------------------------
