@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <bitset>
 #include <deque>
 #include <chrono>
 #include <vector>
@@ -270,122 +271,168 @@ struct Lookahead
             fenc->weighted_cost_delta[fenc->i_frame - ref->i_frame - 1] = (float)minscore / origscore;
     }
 
-    // ---- slicetype_path_cost (:1288-1327) ----------------------------------------------------------
-    uint64_t path_cost( LaFrame **frames, const char *path, uint64_t threshold )
-    {
-        uint64_t cost = 0;
-        int loc = 1, cur_nonb = 0;
-        path--; // path[1] describes frames[1]
-        while( path[loc] )
-        {
-            int next_nonb = loc;
-            while( path[next_nonb] == 'B' ) next_nonb++;
-            if( path[next_nonb] == 'P' )
-                cost += frame_cost( frames, cur_nonb, next_nonb, next_nonb );
-            else
-                cost += frame_cost( frames, next_nonb, next_nonb, next_nonb );
-            if( cost > threshold ) break;
-            if( p.b_pyramid && next_nonb - cur_nonb > 2 )
-            {
-                int middle = cur_nonb + ( next_nonb - cur_nonb ) / 2;
-                cost += frame_cost( frames, cur_nonb, next_nonb, middle );
-                for( int nb = loc; nb < middle && cost < threshold; nb++ )
-                    cost += frame_cost( frames, cur_nonb, middle, nb );
-                for( int nb = middle + 1; nb < next_nonb && cost < threshold; nb++ )
-                    cost += frame_cost( frames, middle, next_nonb, nb );
-            }
-            else
-                for( int nb = loc; nb < next_nonb && cost < threshold; nb++ )
-                    cost += frame_cost( frames, cur_nonb, next_nonb, nb );
-            loc = next_nonb + 1;
-            cur_nonb = next_nonb;
-        }
-        return cost;
-    }
+    // =================================================================================================================
+    // Decisions (what x264_slicetype_decide / x264_slicetype_analyse and their helpers compute, slicetype.c:1186-1974).
+    //
+    // The reference decides with mutually calling routines over character strings ("BBP") and running indices.  Here the same
+    // decisions are formulated over three notions:
+    //   GopPlan   which frames of a window are anchors (coded as P, or as I where a picture type is forced); the rest are B-frames
+    //   mini-GOP  two consecutive anchors and the B-frames between them: the unit of every plan cost and of every MB-tree step
+    //   passes    the analysis of a window as a fixed sequence of named passes over it
+    // One thing is not free: the ORDER in which frame costs are requested, and every early exit that decides whether a request is
+    // made at all.  The first request of a (frame, list, distance) field fixes how it is searched (a P request brings its weight,
+    // slicetype.c:855-867; a B cell reads its list-1 reference's vectors only if they exist by then, :629) and every cost is
+    // memoised, so the request order is part of the reference's observable behaviour and is reproduced exactly.
+    // =================================================================================================================
 
-    // ---- slicetype_path: one Viterbi step (:1333-1382) ---------------------------------------------
-    void slicetype_path( LaFrame **frames, int length, char ( *best_paths )[LOOKAHEAD_MAX + 1] )
+    struct GopPlan
     {
-        char paths[2][LOOKAHEAD_MAX + 1];
-        int num_paths = p.dev.bframes + 1 < length ? p.dev.bframes + 1 : length;
-        uint64_t best_cost = COST_MAX64;
-        int best_possible = 0, idx = 0;
-        for( int path = 0; path < num_paths; path++ )
+        int len = 0;                                  // the frames at window positions 1 .. len are planned
+        std::bitset<LOOKAHEAD_MAX + 2> anchor, intra; // by window position
+        bool is_b( int i ) const { return !anchor[i]; }
+        void add_bframes( int n ) { len += n; }
+        void add_anchor() { anchor.set( ++len ); }
+        int anchor_from( int i ) const // the first anchor at or after position i, 0 if there is none
         {
-            int len = length - ( path + 1 );
-            memcpy( paths[idx], best_paths[len % ( BMAX + 1 )], len );
-            memset( paths[idx] + len, 'B', path );
-            strcpy( paths[idx] + len + path, "P" );
-            int possible = 1;
-            for( int i = 1; i <= length; i++ )
-            {
-                int t = frames[i]->i_type;
-                if( t == T_AUTO ) continue;
-                if( is_b( t ) )
-                    possible = possible && ( i < len || i == length || paths[idx][i - 1] == 'B' );
-                else
-                {
-                    possible = possible && ( i < len || paths[idx][i - 1] != 'B' );
-                    paths[idx][i - 1] = is_i( t ) ? 'I' : 'P';
-                }
-            }
-            if( possible || !best_possible )
-            {
-                if( possible && !best_possible ) best_cost = COST_MAX64;
-                uint64_t cost = path_cost( frames, paths[idx], best_cost );
-                if( cost < best_cost )
-                {
-                    best_cost = cost; best_possible = possible; idx ^= 1;
-                }
-            }
+            while( i <= len && !anchor[i] ) i++;
+            return i <= len ? i : 0;
         }
-        memcpy( best_paths[length % ( BMAX + 1 )], paths[idx ^ 1], length );
-    }
+    };
 
-    // ---- scenecut (:1384-1468) ---------------------------------------------------------------------
-    int scenecut_internal( LaFrame **frames, int p0, int p1 )
+    // The B-frames between two anchors, costed while the running total stays under the budget.  With B-pyramid the middle frame of a run
+    // of three or more serves as a reference for the two halves and is costed first, unconditionally (slicetype_path_cost's inner part).
+    uint64_t add_bframe_costs( LaFrame **w, int left, int right, uint64_t spent, uint64_t budget )
     {
-        LaFrame *frame = frames[p1];
-        frame_cost( frames, p0, p1, p1 );
-        int icost = frame->cost_est[0][0];
-        int pcost = frame->cost_est[p1 - p0][0];
-        float f_bias;
-        int gop_size = frame->i_frame - i_last_keyframe;
-        float thresh_max = p.scenecut_threshold / 100.0;
-        float thresh_min = thresh_max * 0.25;
-        if( p.keyint_min == p.keyint_max ) thresh_min = thresh_max;
-        if( gop_size <= p.keyint_min / 4 || p.intra_refresh )
-            f_bias = thresh_min / 4;
-        else if( gop_size <= p.keyint_min )
-            f_bias = thresh_min * gop_size / p.keyint_min;
+        auto run = [&]( int from, int to, int r0, int r1 ) {
+            for( int b = from; b < to && spent < budget; b++ )
+                spent += frame_cost( w, r0, r1, b );
+        };
+        if( p.b_pyramid && right - left > 2 )
+        {
+            const int mid = left + ( right - left ) / 2;
+            spent += frame_cost( w, left, right, mid );
+            run( left + 1, mid, left, mid );
+            run( mid + 1, right, mid, right );
+        }
         else
-            f_bias = thresh_min + ( thresh_max - thresh_min ) * ( gop_size - p.keyint_min ) / ( p.keyint_max - p.keyint_min );
-        return pcost >= ( 1.0 - f_bias ) * icost;
+            run( left + 1, right, left, right );
+        return spent;
     }
 
-    int scenecut( LaFrame **frames, int p0, int p1, int real_scenecut, int num_frames, int i_max_search )
+    // Cost of coding the window the way a plan says, mini-GOP by mini-GOP from the near end; gives up once the budget is exceeded
+    // (the total returned is then only known to be too large).
+    uint64_t plan_cost( LaFrame **w, const GopPlan &g, uint64_t budget )
     {
-        if( real_scenecut && p.dev.bframes )
+        uint64_t spent = 0;
+        for( int left = 0, right = g.anchor_from( 1 ); right; left = right, right = g.anchor_from( right + 1 ) )
         {
-            int origmaxp1 = p0 + 1;
-            if( p.b_adapt == 2 ) origmaxp1 += p.dev.bframes;
-            else origmaxp1++;
-            int maxp1 = origmaxp1 < num_frames ? origmaxp1 : num_frames;
-            for( int curp1 = p1; curp1 <= maxp1; curp1++ )
-                if( !scenecut_internal( frames, p0, curp1 ) )
-                    for( int i = curp1; i > p0; i-- )
-                        frames[i]->b_scenecut = 0;
-            for( int curp0 = p0; curp0 <= maxp1; curp0++ )
-                if( origmaxp1 > i_max_search || ( curp0 < maxp1 && scenecut_internal( frames, curp0, maxp1 ) ) )
-                    frames[curp0]->b_scenecut = 0;
+            spent += g.intra[right] ? frame_cost( w, right, right, right ) : frame_cost( w, left, right, right );
+            if( spent > budget )
+                break;
+            spent = add_bframe_costs( w, left, right, spent, budget );
         }
-        if( !frames[p1]->b_scenecut ) return 0;
-        return scenecut_internal( frames, p0, p1 );
+        return spent;
     }
 
-    // ---- macroblock_tree (:1091-1184).  The frame-cost evaluations keep memoisation / first-trigger state
-    // identical to the reference; the propagation itself (mbtree_propagate_cost/list, macroblock_tree_finish) is
-    // recorded as a step list and handed to the backend in one call (it never feeds back into the decisions).
+    // Picture types the caller has forced, imposed on a candidate plan: a forced I / P makes its position an anchor whatever the plan
+    // had there (also inside the part inherited from a shorter plan).  The candidate is admissible if, from the last frame of the
+    // inherited part on, every forced B is a B-frame in it (the frame that closes the window is exempt) and no forced I / P was one.
+    bool impose_forced_types( LaFrame **w, GopPlan &g, int inherited )
+    {
+        bool admissible = true;
+        for( int i = 1; i <= g.len; i++ )
+        {
+            const int t = w[i]->i_type;
+            if( t == T_AUTO )
+                continue;
+            const bool judged = i >= inherited;
+            if( is_b( t ) )
+                admissible = admissible && ( !judged || i == g.len || g.is_b( i ) );
+            else
+            {
+                admissible = admissible && ( !judged || !g.is_b( i ) );
+                g.anchor.set( i );
+                g.intra[i] = is_i( t );
+            }
+        }
+        return admissible;
+    }
+
+    // One step of the trellis over B-frame run lengths (b-adapt 2): the cheapest plan for the first `len` frames is the cheapest
+    // among { best plan for len - r - 1 frames, then r B-frames, then an anchor }, r = 0 .. bframes.  An admissible candidate beats any
+    // inadmissible one whatever it costs; among equals the cheaper wins, the earlier on a tie.  Each candidate is costed only up
+    // to the cost of the best so far.
+    void best_plan_for( LaFrame **w, int len, std::vector<GopPlan> &best )
+    {
+        const int longest_run = p.dev.bframes < len - 1 ? p.dev.bframes : len - 1;
+        GopPlan chosen;
+        uint64_t chosen_cost = COST_MAX64;
+        bool chosen_ok = false;
+        for( int r = 0; r <= longest_run; r++ )
+        {
+            GopPlan cand = best[len - r - 1];
+            cand.add_bframes( r );
+            cand.add_anchor();
+            const bool ok = impose_forced_types( w, cand, len - r - 1 );
+            if( !ok && chosen_ok )
+                continue;
+            if( ok && !chosen_ok )
+                chosen_cost = COST_MAX64;
+            const uint64_t c = plan_cost( w, cand, chosen_cost );
+            if( c < chosen_cost )
+            {
+                chosen_cost = c; chosen_ok = ok; chosen = cand;
+            }
+        }
+        best[len] = chosen;
+    }
+
+    // ---- scene changes (scenecut_internal / scenecut, :1384-1468) -------------------------------------------------------------
+    // Is frame p1, predicted from p0, so badly predicted that it should start a GOP?  The inter cost is compared with the intra
+    // cost scaled by a bias that grows with the distance from the last key frame (float arithmetic exactly as the reference's).
+    bool cut_between( LaFrame **w, int p0, int p1 )
+    {
+        LaFrame *f = w[p1];
+        frame_cost( w, p0, p1, p1 );
+        const int intra = f->cost_est[0][0], inter = f->cost_est[p1 - p0][0];
+        const int since_key = f->i_frame - i_last_keyframe;
+        float hi = p.scenecut_threshold / 100.0;
+        float lo = hi * 0.25;
+        if( p.keyint_min == p.keyint_max )
+            lo = hi;
+        float bias;
+        if( since_key <= p.keyint_min / 4 || p.intra_refresh )
+            bias = lo / 4;
+        else if( since_key <= p.keyint_min )
+            bias = lo * since_key / p.keyint_min;
+        else
+            bias = lo + ( hi - lo ) * ( since_key - p.keyint_min ) / ( p.keyint_max - p.keyint_min );
+        return inter >= ( 1.0 - bias ) * intra;
+    }
+
+    // Scene change at p1?  With look_ahead (the check in front of a new mini-GOP, B-frames enabled) the frames up to `horizon` are
+    // examined first, so that a flash or a short burst of changing pictures does not open a GOP: every frame after which the
+    // picture returns to what p0 showed is cleared, and so is every frame of the stretch unless the far end is a cut from it.
+    bool scene_change( LaFrame **w, int p0, int p1, bool look_ahead, int n_frames, int reach )
+    {
+        if( look_ahead && p.dev.bframes )
+        {
+            const int horizon = p0 + 1 + ( p.b_adapt == 2 ? p.dev.bframes : 1 );
+            const int far_end = horizon < n_frames ? horizon : n_frames;
+            for( int q = p1; q <= far_end; q++ )
+                if( !cut_between( w, p0, q ) )
+                    for( int k = q; k > p0; k-- )
+                        w[k]->b_scenecut = 0;
+            for( int q = p0; q <= far_end; q++ )
+                if( horizon > reach || ( q < far_end && cut_between( w, q, far_end ) ) )
+                    w[q]->b_scenecut = 0;
+        }
+        return w[p1]->b_scenecut && cut_between( w, p0, p1 );
+    }
+
+    // ---- MB-tree: the frame-cost requests keep memoisation / first-trigger state identical to the reference (macroblock_tree,
+    // :1091-1184); the propagation itself (mbtree_propagate_cost / _list, macroblock_tree_finish) is recorded as a step list and
+    // handed to the backend in one call -- it never feeds back into the decisions.
     static double clip_duration( double f ) { return f < 0.01 ? 0.01 : f > 1.0 ? 1.0 : f; } // CLIP_DURATION, ratecontrol.h:34-40
 
     void mbt_zero( std::vector<x264hip_mbtree_op> &ops, LaFrame *f )
@@ -431,83 +478,87 @@ struct Lookahead
         ops.push_back( o );
     }
 
-    void macroblock_tree( LaFrame **frames, int num_frames, int b_intra )
+
+    // The window is walked mini-GOP by mini-GOP from its far end; inside a mini-GOP the B-frames come first (far to near, each
+    // adding to both of its references), then the anchor that closes it passes its own total on to the anchor that opens it.
+    void macroblock_tree( LaFrame **w, int n, int window_starts_intra )
     {
-        int idx = !b_intra, last_nonb, cur_nonb = 1, bframes = 0;
+        const int first = window_starts_intra ? 0 : 1; // nearest frame that may take part
         std::vector<x264hip_mbtree_op> ops;
         float total_duration = 0.0;
-        for( int j = 0; j <= num_frames; j++ )
-            total_duration += frames[j]->f_duration;
-        float average_duration = total_duration / ( num_frames + 1 );
-        int i = num_frames;
-        if( b_intra ) frame_cost( frames, 0, 0, 0 );
-        while( i > 0 && is_b( frames[i]->i_type ) ) i--;
-        last_nonb = i;
-        // Lookahead-less MB-tree (:1112-1124): the accumulators of the frame that starts the window were left behind by the
-        // previous call and serve as the extrapolated future of frames[last_nonb]
-        const bool lookaheadless = !p.rc_lookahead;
-        if( lookaheadless )
+        for( int j = 0; j <= n; j++ )
+            total_duration += w[j]->f_duration;
+        const float average_duration = total_duration / ( n + 1 );
+        if( window_starts_intra )
+            frame_cost( w, 0, 0, 0 );
+        int far = n;
+        while( far > 0 && is_b( w[far]->i_type ) )
+            far--;
+        // Without a lookahead (:1112-1124) the accumulators of the frame that starts the window were left behind by the previous
+        // call and stand for the future of the far anchor
+        const bool carry_over = !p.rc_lookahead;
+        if( carry_over )
         {
-            if( b_intra )
+            if( window_starts_intra )
             {
-                mbt_zero( ops, frames[0] );
-                mbt_simple( ops, X264HIP_MBT_RESET_QP, frames[0], frames[0] );
+                mbt_zero( ops, w[0] );
+                mbt_simple( ops, X264HIP_MBT_RESET_QP, w[0], w[0] );
                 if( be.mbtree && !err ) need( be.mbtree( be.user, ops.data(), (int)ops.size() ) );
                 return;
             }
-            mbt_simple( ops, X264HIP_MBT_SWAP, frames[last_nonb], frames[0] );
-            mbt_zero( ops, frames[0] );
+            mbt_simple( ops, X264HIP_MBT_SWAP, w[far], w[0] );
+            mbt_zero( ops, w[0] );
         }
         else
         {
-            if( last_nonb < idx ) return;
-            mbt_zero( ops, frames[last_nonb] );
+            if( far < first )
+                return;
+            mbt_zero( ops, w[far] );
         }
-        while( i-- > idx )
+        int gap = 0; // B-frames of the mini-GOP handled last
+        while( far > first )
         {
-            cur_nonb = i;
-            while( is_b( frames[cur_nonb]->i_type ) && cur_nonb > 0 ) cur_nonb--;
-            if( cur_nonb < idx ) break;
-            frame_cost( frames, cur_nonb, last_nonb, last_nonb );
-            mbt_zero( ops, frames[cur_nonb] );
-            bframes = last_nonb - cur_nonb - 1;
-            if( p.b_pyramid && bframes > 1 )
+            int near = far - 1;
+            while( near > 0 && is_b( w[near]->i_type ) )
+                near--;
+            if( near < first )
+                break;
+            frame_cost( w, near, far, far );
+            mbt_zero( ops, w[near] );
+            gap = far - near - 1;
+            if( p.b_pyramid && gap > 1 )
             {
-                int middle = ( bframes + 1 ) / 2 + cur_nonb;
-                frame_cost( frames, cur_nonb, last_nonb, middle );
-                mbt_zero( ops, frames[middle] );
-                while( i > cur_nonb )
+                const int mid = near + ( gap + 1 ) / 2;
+                frame_cost( w, near, far, mid );
+                mbt_zero( ops, w[mid] );
+                for( int b = far - 1; b > near; b-- )
                 {
-                    int q0 = i > middle ? middle : cur_nonb;
-                    int q1 = i < middle ? middle : last_nonb;
-                    if( i != middle )
-                    {
-                        frame_cost( frames, q0, q1, i );
-                        mbt_propagate( ops, frames, average_duration, q0, q1, i, 0 );
-                    }
-                    i--;
+                    if( b == mid )
+                        continue;
+                    const int r0 = b > mid ? mid : near, r1 = b < mid ? mid : far;
+                    frame_cost( w, r0, r1, b );
+                    mbt_propagate( ops, w, average_duration, r0, r1, b, 0 );
                 }
-                mbt_propagate( ops, frames, average_duration, cur_nonb, last_nonb, middle, 1 );
+                mbt_propagate( ops, w, average_duration, near, far, mid, 1 );
             }
             else
-                while( i > cur_nonb )
+                for( int b = far - 1; b > near; b-- )
                 {
-                    frame_cost( frames, cur_nonb, last_nonb, i );
-                    mbt_propagate( ops, frames, average_duration, cur_nonb, last_nonb, i, 0 );
-                    i--;
+                    frame_cost( w, near, far, b );
+                    mbt_propagate( ops, w, average_duration, near, far, b, 0 );
                 }
-            mbt_propagate( ops, frames, average_duration, cur_nonb, last_nonb, last_nonb, 1 );
-            last_nonb = cur_nonb;
+            mbt_propagate( ops, w, average_duration, near, far, far, 1 );
+            far = near;
         }
-        if( lookaheadless ) // :1173-1178
+        if( carry_over ) // :1173-1178
         {
-            frame_cost( frames, 0, last_nonb, last_nonb );
-            mbt_propagate( ops, frames, average_duration, 0, last_nonb, last_nonb, 1 );
-            mbt_simple( ops, X264HIP_MBT_SWAP, frames[last_nonb], frames[0] );
+            frame_cost( w, 0, far, far );
+            mbt_propagate( ops, w, average_duration, 0, far, far, 1 );
+            mbt_simple( ops, X264HIP_MBT_SWAP, w[far], w[0] );
         }
-        mbt_finish( ops, frames[last_nonb], average_duration, last_nonb );
-        if( p.b_pyramid && bframes > 1 && !p.vbv ) // :1182-1183
-            mbt_finish( ops, frames[last_nonb + ( bframes + 1 ) / 2], average_duration, 0 );
+        mbt_finish( ops, w[far], average_duration, far );
+        if( p.b_pyramid && gap > 1 && !p.vbv ) // :1182-1183
+            mbt_finish( ops, w[far + ( gap + 1 ) / 2], average_duration, 0 );
         if( be.mbtree && !ops.empty() && !err )
         {
             ScopeNs tm( stats[6] );
@@ -515,360 +566,381 @@ struct Lookahead
         }
     }
 
-    // ---- x264_slicetype_analyse (:1473-1743) -------------------------------------------------------
-    void analyse( int intra_minigop )
-    {
-        LaFrame *frames[LOOKAHEAD_MAX + 3] = { nullptr };
-        int num_frames, orig_num_frames, keyint_limit, framecnt;
-        int i_max_search = (int)next.size() < LOOKAHEAD_MAX ? (int)next.size() : LOOKAHEAD_MAX;
-        if( i_max_search > slicetype_length + 1 - intra_minigop ) // b_deterministic
-            i_max_search = slicetype_length + 1 - intra_minigop;
-        int keyframe = !!intra_minigop;
-        if( !last_nonb ) return;
-        frames[0] = last_nonb;
-        for( framecnt = 0; framecnt < i_max_search; framecnt++ )
-            frames[framecnt + 1] = next[framecnt];
-        if( !framecnt )
-        {
-            if( p.mb_tree ) macroblock_tree( frames, 0, keyframe );
-            return;
-        }
-        keyint_limit = p.keyint_max - frames[0]->i_frame + i_last_keyframe - 1;
-        orig_num_frames = num_frames = p.intra_refresh ? framecnt : framecnt < keyint_limit ? framecnt : keyint_limit;
-        if( ( p.psy && p.mb_tree ) || vbv_lookahead_on() )
-            num_frames = framecnt;
-        else if( p.open_gop && num_frames < framecnt )
-            num_frames++;
-        else if( num_frames == 0 )
-        {
-            frames[1]->i_type = T_I;
-            return;
-        }
-        if( auto_or_i( frames[1]->i_type ) && p.scenecut_threshold && scenecut( frames, 0, 1, 1, orig_num_frames, i_max_search ) )
-        {
-            if( frames[1]->i_type == T_AUTO ) frames[1]->i_type = T_I;
-            return;
-        }
-        for( int j = 1; j <= num_frames; j++ )
-            if( frames[j]->i_type == T_KEYFRAME )
-                frames[j]->i_type = p.open_gop ? T_I : T_IDR;
-        for( int j = 2; j <= num_frames; j++ )
-            if( frames[j]->i_type == T_IDR && auto_or_b( frames[j - 1]->i_type ) )
-                frames[j - 1]->i_type = T_P;
+    // ---- the passes of a window analysis (x264_slicetype_analyse, :1473-1743) ---------------------------------------------------
 
-        int num_analysed_frames = num_frames, reset_start;
-        const int bf = p.dev.bframes;
-        if( bf )
+    // b-adapt 2: trellis over the whole window, then the plan's verdict for every frame but the last
+    void pass_trellis( LaFrame **w, int n )
+    {
+        if( n <= 1 )
+            return;
+        std::vector<GopPlan> best( n + 1 );
+        best[1].add_anchor();
+        for( int len = 2; len <= n; len++ )
+            best_plan_for( w, len, best );
+        const GopPlan &g = best[n];
+        for( int j = 1; j < n; j++ )
         {
-            if( p.b_adapt == 2 )
+            if( !g.is_b( j ) )
             {
-                if( num_frames > 1 )
-                {
-                    static thread_local char best_paths[BMAX + 1][LOOKAHEAD_MAX + 1];
-                    memset( best_paths, 0, sizeof( best_paths ) );
-                    strcpy( best_paths[1], "P" );
-                    int best_path_index = num_frames % ( BMAX + 1 );
-                    for( int j = 2; j <= num_frames; j++ )
-                        slicetype_path( frames, j, best_paths );
-                    for( int j = 1; j < num_frames; j++ )
-                    {
-                        if( best_paths[best_path_index][j - 1] != 'B' )
-                        {
-                            if( auto_or_b( frames[j]->i_type ) ) frames[j]->i_type = T_P;
-                        }
-                        else if( frames[j]->i_type == T_AUTO )
-                            frames[j]->i_type = T_B;
-                    }
-                }
+                if( auto_or_b( w[j]->i_type ) ) w[j]->i_type = T_P;
             }
-            else if( p.b_adapt == 1 )
-            {
-                int last_nb = 0, num_b = bf;
-                char path[LOOKAHEAD_MAX + 1];
-                for( int j = 1; j < num_frames; j++ )
-                {
-                    if( j - 1 > 0 && is_b( frames[j - 1]->i_type ) )
-                        num_b--;
-                    else
-                    {
-                        last_nb = j - 1;
-                        num_b = bf;
-                    }
-                    if( !num_b )
-                    {
-                        if( auto_or_b( frames[j]->i_type ) ) frames[j]->i_type = T_P;
-                        continue;
-                    }
-                    if( frames[j]->i_type != T_AUTO ) continue;
-                    if( is_b( frames[j + 1]->i_type ) )
-                    {
-                        frames[j]->i_type = T_P;
-                        continue;
-                    }
-                    int nb = j - last_nb - 1;
-                    memset( path, 'B', nb );
-                    strcpy( path + nb, "PP" );
-                    uint64_t cost_p = path_cost( frames + last_nb, path, COST_MAX64 );
-                    strcpy( path + nb, "BP" );
-                    uint64_t cost_b = path_cost( frames + last_nb, path, cost_p );
-                    frames[j]->i_type = cost_b < cost_p ? T_B : T_P;
-                }
-            }
+            else if( w[j]->i_type == T_AUTO )
+                w[j]->i_type = T_B;
+        }
+    }
+
+    // b-adapt 1: frame by frame, "P then P" against "B then P" for the undecided frame and its successor, behind the B-frames
+    // already decided since the last anchor
+    void pass_greedy( LaFrame **w, int n )
+    {
+        int anchor_at = 0, room = p.dev.bframes;
+        for( int j = 1; j < n; j++ )
+        {
+            if( j - 1 > 0 && is_b( w[j - 1]->i_type ) )
+                room--;
             else
             {
-                int num_b = bf;
-                for( int j = 1; j < num_frames; j++ )
-                {
-                    if( !num_b )
-                    {
-                        if( auto_or_b( frames[j]->i_type ) ) frames[j]->i_type = T_P;
-                    }
-                    else if( frames[j]->i_type == T_AUTO )
-                        frames[j]->i_type = is_b( frames[j + 1]->i_type ) ? T_P : T_B;
-                    if( is_b( frames[j]->i_type ) ) num_b--;
-                    else num_b = bf;
-                }
+                anchor_at = j - 1;
+                room = p.dev.bframes;
             }
-            if( auto_or_b( frames[num_frames]->i_type ) )
-                frames[num_frames]->i_type = T_P;
-            int num_b = 0;
-            while( num_b < num_frames && is_b( frames[num_b + 1]->i_type ) ) num_b++;
-            for( int j = 1; j < num_b + 1; j++ )
-                if( frames[j]->i_forced_type == T_AUTO && auto_or_i( frames[j + 1]->i_forced_type ) && p.scenecut_threshold &&
-                    scenecut( frames, j, j + 1, 0, orig_num_frames, i_max_search ) )
+            if( !room )
+            {
+                if( auto_or_b( w[j]->i_type ) ) w[j]->i_type = T_P;
+                continue;
+            }
+            if( w[j]->i_type != T_AUTO )
+                continue;
+            if( is_b( w[j + 1]->i_type ) )
+            {
+                w[j]->i_type = T_P;
+                continue;
+            }
+            const int behind = j - anchor_at - 1;
+            GopPlan as_p, as_b;
+            as_p.add_bframes( behind ); as_p.add_anchor(); as_p.add_anchor();
+            as_b.add_bframes( behind + 1 ); as_b.add_anchor();
+            const uint64_t cost_p = plan_cost( w + anchor_at, as_p, COST_MAX64 );
+            const uint64_t cost_b = plan_cost( w + anchor_at, as_b, cost_p );
+            w[j]->i_type = cost_b < cost_p ? T_B : T_P;
+        }
+    }
+
+    // b-adapt 0: as many B-frames as allowed, a forced B-frame behind an undecided frame excepted
+    void pass_fixed( LaFrame **w, int n )
+    {
+        int room = p.dev.bframes;
+        for( int j = 1; j < n; j++ )
+        {
+            if( !room )
+            {
+                if( auto_or_b( w[j]->i_type ) ) w[j]->i_type = T_P;
+            }
+            else if( w[j]->i_type == T_AUTO )
+                w[j]->i_type = is_b( w[j + 1]->i_type ) ? T_P : T_B;
+            room = is_b( w[j]->i_type ) ? room - 1 : p.dev.bframes;
+        }
+    }
+
+    // the key frame interval (:1680-1731): a frame max-keyint away from the last key frame becomes one -- or rather the last
+    // frame before it that may; an I-frame min-keyint away from the last key frame is promoted to IDR (closed GOP)
+    void pass_keyframe_interval( LaFrame **w, int n )
+    {
+        int last_key = i_last_keyframe, candidate = 0;
+        for( int j = 1; j <= n; j++ )
+        {
+            LaFrame *f = w[j];
+            int dist = f->i_frame - last_key;
+            if( auto_or_i( f->i_forced_type ) && ( p.open_gop || !is_b( w[j - 1]->i_forced_type ) ) )
+                candidate = j;
+            if( dist >= p.keyint_max )
+            {
+                if( candidate != 0 && candidate != j )
                 {
-                    frames[j]->i_type = T_P;
-                    num_analysed_frames = j;
+                    j = candidate;
+                    f = w[j];
+                    dist = f->i_frame - last_key;
+                }
+                candidate = 0;
+                if( f->i_type != T_IDR )
+                    f->i_type = p.open_gop ? T_I : T_IDR;
+            }
+            if( f->i_type == T_I && dist >= p.keyint_min )
+            {
+                if( p.open_gop )
+                    last_key = f->i_frame;
+                else if( f->i_forced_type != T_I )
+                    f->i_type = T_IDR;
+            }
+            if( f->i_type == T_IDR )
+            {
+                last_key = f->i_frame;
+                if( j > 1 && is_b( w[j - 1]->i_type ) )
+                    w[j - 1]->i_type = T_P;
+            }
+        }
+    }
+
+    // What VBV rate control is told about the frames after the next anchor (vbv_lookahead, :1224-1286): their types and costs in
+    // coded order.  The CPB duration bookkeeping of the reference (calculate_durations) is constant for progressive
+    // constant-frame-rate input and stays with the encoder.
+    int planned_cost( LaFrame **w, int p0, int p1, int b ) // vbv_frame_cost, :1186-1198
+    {
+        const int cost = frame_cost( w, p0, p1, b );
+        if( !p.dev.aq_mode )
+            return cost;
+        if( !p.mb_tree )
+            return w[b]->cost_est_aq[b - p0][p1 - b];
+        int score = 0; // slicetype_frame_cost_recalculate: the cell under the frame's current quantiser offsets
+        if( !be.frame_cost_recalculate ) { need( X264HIP_EINVAL ); return 0; }
+        if( need( be.frame_cost_recalculate( be.user, w[b]->slot, b - p0, p1 - b, is_b( w[b]->i_type ), &score ) ) ) return 0;
+        return score;
+    }
+    void pass_vbv_plan( LaFrame **w, int n, int window_starts_intra )
+    {
+        auto next_anchor = [&]( int from, int limit_inclusive ) {
+            while( ( limit_inclusive ? from <= n : from < n ) && is_b( w[from]->i_type ) ) from++;
+            return from;
+        };
+        int left = 0, right = next_anchor( 1, 0 );
+        LaFrame *owner = w[window_starts_intra ? left : right]; // the frame rate control will be looking at when it reads the plan
+        const int owner_at = window_starts_intra ? left : right;
+        int k = 0;
+        while( right < n )
+        {
+            if( owner_at != right ) // the anchor itself, unless it is the owner
+            {
+                const int from = is_i( w[right]->i_type ) ? right : left;
+                owner->planned_satd[k] = planned_cost( w, from, right, right );
+                owner->planned_type[k] = w[right]->i_type;
+                k++;
+            }
+            for( int b = left + 1; b < right; b++, k++ ) // its B-frames, coded order
+            {
+                owner->planned_satd[k] = planned_cost( w, left, right, b );
+                owner->planned_type[k] = T_B;
+            }
+            left = right;
+            right = next_anchor( right + 1, 1 );
+        }
+        owner->planned_type[k] = T_AUTO;
+    }
+
+    void analyse( int frames_taken_by_keyframe )
+    {
+        LaFrame *w[LOOKAHEAD_MAX + 3] = { nullptr };
+        const int window_starts_intra = !!frames_taken_by_keyframe;
+        if( !last_nonb )
+            return;
+        // the window: the last anchor and what is queued, no further than the lookahead is guaranteed to be filled (b_deterministic)
+        int reach = (int)next.size() < LOOKAHEAD_MAX ? (int)next.size() : LOOKAHEAD_MAX;
+        if( reach > slicetype_length + 1 - frames_taken_by_keyframe )
+            reach = slicetype_length + 1 - frames_taken_by_keyframe;
+        w[0] = last_nonb;
+        int queued = 0;
+        for( ; queued < reach; queued++ )
+            w[queued + 1] = next[queued];
+        if( !queued )
+        {
+            if( p.mb_tree ) macroblock_tree( w, 0, window_starts_intra );
+            return;
+        }
+        // frames up to the next forced key frame take part in the GOP decisions; MB-tree with psy-RD, and the VBV plan, see them all
+        const int until_keyint = p.keyint_max - w[0]->i_frame + i_last_keyframe - 1;
+        const int n_gop = p.intra_refresh ? queued : queued < until_keyint ? queued : until_keyint;
+        int n = n_gop;
+        if( ( p.psy && p.mb_tree ) || vbv_lookahead_on() )
+            n = queued;
+        else if( p.open_gop && n < queued )
+            n++;
+        else if( n == 0 )
+        {
+            w[1]->i_type = T_I;
+            return;
+        }
+        // pass 1: does the next frame start a new scene?
+        if( auto_or_i( w[1]->i_type ) && p.scenecut_threshold && scene_change( w, 0, 1, true, n_gop, reach ) )
+        {
+            if( w[1]->i_type == T_AUTO ) w[1]->i_type = T_I;
+            return;
+        }
+        // pass 2: forced key frames take their final type; the frame in front of a forced IDR cannot be a B-frame
+        for( int j = 1; j <= n; j++ )
+            if( w[j]->i_type == T_KEYFRAME )
+                w[j]->i_type = p.open_gop ? T_I : T_IDR;
+        for( int j = 2; j <= n; j++ )
+            if( w[j]->i_type == T_IDR && auto_or_b( w[j - 1]->i_type ) )
+                w[j - 1]->i_type = T_P;
+        // pass 3: B-frame placement
+        int n_settled = n, first_to_reset;
+        if( p.dev.bframes )
+        {
+            if( p.b_adapt == 2 ) pass_trellis( w, n );
+            else if( p.b_adapt == 1 ) pass_greedy( w, n );
+            else pass_fixed( w, n );
+            if( auto_or_b( w[n]->i_type ) )
+                w[n]->i_type = T_P;
+            // pass 4: a scene change inside the leading run of B-frames ends the run there
+            int lead = 0;
+            while( lead < n && is_b( w[lead + 1]->i_type ) )
+                lead++;
+            for( int j = 1; j < lead + 1; j++ )
+                if( w[j]->i_forced_type == T_AUTO && auto_or_i( w[j + 1]->i_forced_type ) && p.scenecut_threshold &&
+                    scene_change( w, j, j + 1, false, n_gop, reach ) )
+                {
+                    w[j]->i_type = T_P;
+                    n_settled = j;
                     break;
                 }
-            reset_start = keyframe ? 1 : ( num_b + 2 < num_analysed_frames + 1 ? num_b + 2 : num_analysed_frames + 1 );
+            first_to_reset = window_starts_intra ? 1 : ( lead + 2 < n_settled + 1 ? lead + 2 : n_settled + 1 );
         }
         else
         {
-            for( int j = 1; j <= num_frames; j++ )
-                if( auto_or_b( frames[j]->i_type ) ) frames[j]->i_type = T_P;
-            reset_start = !keyframe + 1;
+            for( int j = 1; j <= n; j++ )
+                if( auto_or_b( w[j]->i_type ) )
+                    w[j]->i_type = T_P;
+            first_to_reset = !window_starts_intra + 1;
         }
+        // pass 5: MB-tree over the types as they stand
         if( p.mb_tree )
-            macroblock_tree( frames, num_frames < p.keyint_max ? num_frames : p.keyint_max, keyframe );
-
-        // keyframe limit (:1680-1731), not with intra refresh
+            macroblock_tree( w, n < p.keyint_max ? n : p.keyint_max, window_starts_intra );
+        // pass 6: the key frame interval
         if( !p.intra_refresh )
-        {
-            int last_keyframe = i_last_keyframe, last_possible = 0;
-            for( int j = 1; j <= num_frames; j++ )
-            {
-                LaFrame *frm = frames[j];
-                int keyframe_dist = frm->i_frame - last_keyframe;
-                if( auto_or_i( frm->i_forced_type ) )
-                    if( p.open_gop || !is_b( frames[j - 1]->i_forced_type ) )
-                        last_possible = j;
-                if( keyframe_dist >= p.keyint_max )
-                {
-                    if( last_possible != 0 && last_possible != j )
-                    {
-                        j = last_possible;
-                        frm = frames[j];
-                        keyframe_dist = frm->i_frame - last_keyframe;
-                    }
-                    last_possible = 0;
-                    if( frm->i_type != T_IDR ) frm->i_type = p.open_gop ? T_I : T_IDR;
-                }
-                if( frm->i_type == T_I && keyframe_dist >= p.keyint_min )
-                {
-                    if( p.open_gop )
-                        last_keyframe = frm->i_frame;
-                    else if( frm->i_forced_type != T_I )
-                        frm->i_type = T_IDR;
-                }
-                if( frm->i_type == T_IDR )
-                {
-                    last_keyframe = frm->i_frame;
-                    if( j > 1 && is_b( frames[j - 1]->i_type ) ) frames[j - 1]->i_type = T_P;
-                }
-            }
-        }
+            pass_keyframe_interval( w, n );
+        // pass 7: the plan for VBV rate control
         if( vbv_lookahead_on() )
-            vbv_lookahead( frames, num_frames, keyframe );
-        for( int j = reset_start; j <= num_frames; j++ )
-            frames[j]->i_type = frames[j]->i_forced_type;
+            pass_vbv_plan( w, n, window_starts_intra );
+        // only the mini-GOP about to be coded keeps its decisions: everything behind it is decided again with more frames in view
+        for( int j = first_to_reset; j <= n; j++ )
+            w[j]->i_type = w[j]->i_forced_type;
     }
 
-    // ---- vbv_frame_cost / vbv_lookahead (:1186-1198, :1224-1286) ------------------------------------
-    // The planned types and costs of the frames after the next non-B frame, in coded order, for VBV rate control
-    // (ratecontrol.c:2290-2320).  The CPB duration bookkeeping of the reference (calculate_durations) is constant
-    // for progressive constant-frame-rate input and stays with the encoder.
-    int vbv_frame_cost( LaFrame **frames, int p0, int p1, int b )
+    // ---- x264_slicetype_decide (:1745-1974): the next mini-GOP in coded order, and the costs rate control wants ahead of time ----
+    void set_durations()
     {
-        int cost = frame_cost( frames, p0, p1, b );
-        if( p.dev.aq_mode )
-        {
-            if( p.mb_tree )
-            {
-                // slicetype_frame_cost_recalculate: the cell under the frame's current quantiser offsets
-                int score = 0;
-                if( !be.frame_cost_recalculate ) { need( X264HIP_EINVAL ); return 0; }
-                if( need( be.frame_cost_recalculate( be.user, frames[b]->slot, b - p0, p1 - b, is_b( frames[b]->i_type ), &score ) ) ) return 0;
-                return score;
-            }
-            return frames[b]->cost_est_aq[b - p0][p1 - b];
-        }
-        return cost;
-    }
-    void vbv_lookahead( LaFrame **frames, int num_frames, int keyframe )
-    {
-        int last_nonb = 0, cur_nonb = 1, idx = 0;
-        while( cur_nonb < num_frames && is_b( frames[cur_nonb]->i_type ) ) cur_nonb++;
-        int next_nonb = keyframe ? last_nonb : cur_nonb;
-        LaFrame *dst = frames[next_nonb];
-        while( cur_nonb < num_frames )
-        {
-            if( next_nonb != cur_nonb ) // P/I cost: not the cost of next_nonb itself
-            {
-                int p0 = is_i( frames[cur_nonb]->i_type ) ? cur_nonb : last_nonb;
-                dst->planned_satd[idx] = vbv_frame_cost( frames, p0, cur_nonb, cur_nonb );
-                dst->planned_type[idx] = frames[cur_nonb]->i_type;
-                idx++;
-            }
-            for( int i = last_nonb + 1; i < cur_nonb; i++, idx++ ) // the B-frames, coded order
-            {
-                dst->planned_satd[idx] = vbv_frame_cost( frames, last_nonb, cur_nonb, i );
-                dst->planned_type[idx] = T_B;
-            }
-            last_nonb = cur_nonb;
-            cur_nonb++;
-            while( cur_nonb <= num_frames && is_b( frames[cur_nonb]->i_type ) ) cur_nonb++;
-        }
-        dst->planned_type[idx] = T_AUTO;
-    }
-
-    // ---- x264_slicetype_decide (:1745-1974), type logic and the final cost evaluations --------------
-    void decide()
-    {
-        if( next.empty() ) return;
         // frame durations (:1755-1771): from the time stamps with VFR input (the last queued frame repeats the previous duration),
         // two field units otherwise
         for( size_t i = 0; i < next.size(); i++ )
         {
-            if( p.vfr_input )
-                next[i]->i_duration = i + 1 < next.size() ? (int)( 2 * ( next[i + 1]->pts - next[i]->pts ) ) : (int)i_prev_duration;
-            else
-                next[i]->i_duration = 2;
-            i_prev_duration = next[i]->i_duration;
-            next[i]->f_duration = (float)( (double)next[i]->i_duration * units_in_tick / time_scale );
+            LaFrame *f = next[i];
+            f->i_duration = !p.vfr_input ? 2 : i + 1 < next.size() ? (int)( 2 * ( next[i + 1]->pts - f->pts ) ) : (int)i_prev_duration;
+            i_prev_duration = f->i_duration;
+            f->f_duration = (float)( (double)f->i_duration * units_in_tick / time_scale );
         }
+    }
+
+    // the final type of one queued frame given how many B-frames / B-references precede it in the mini-GOP; true = it closes the mini-GOP
+    bool settle_type( int pos, int &n_b, int &n_bref )
+    {
+        LaFrame *f = next[pos];
+        if( f->i_type == T_BREF && ( ( p.b_pyramid < 2 && n_bref == p.b_pyramid ) || ( p.b_pyramid == 2 && n_bref && p.frame_refs <= n_bref + 3 ) ) )
+            f->i_type = T_B; // no room for another B-reference (:1814-1826)
+        if( f->i_type == T_KEYFRAME )
+            f->i_type = p.open_gop ? T_I : T_IDR;
+        const int key_type = p.open_gop && i_last_keyframe >= 0 ? T_I : T_IDR;
+        if( ( !p.intra_refresh || f->i_frame == 0 ) && f->i_frame - i_last_keyframe >= p.keyint_max )
+        {
+            // the key frame interval is up (:1831-1846)
+            if( f->i_type == T_AUTO || f->i_type == T_I )
+                f->i_type = key_type;
+            else if( f->i_type != T_IDR && !( p.open_gop && f->i_type == T_I ) )
+                f->i_type = key_type; // a type forced by the caller gives way (the reference warns)
+        }
+        if( f->i_type == T_I && f->i_frame - i_last_keyframe >= p.keyint_min )
+        {
+            if( p.open_gop )
+            {
+                i_last_keyframe = f->i_frame;
+                f->b_keyframe = 1;
+            }
+            else
+                f->i_type = T_IDR;
+        }
+        if( f->i_type == T_IDR )
+        {
+            i_last_keyframe = f->i_frame;
+            f->b_keyframe = 1;
+            if( n_b > 0 ) // closed GOP: the B-frame in front of it becomes the P that ends the previous mini-GOP
+            {
+                n_b--;
+                next[n_b]->i_type = T_P;
+                return true;
+            }
+        }
+        if( n_b == p.dev.bframes || n_b + 1 >= (int)next.size() )
+            if( f->i_type == T_AUTO || is_b( f->i_type ) )
+                f->i_type = T_P;
+        if( f->i_type == T_BREF )
+            n_bref++;
+        if( f->i_type == T_AUTO )
+            f->i_type = T_B;
+        return !is_b( f->i_type );
+    }
+
+    void decide()
+    {
+        if( next.empty() )
+            return;
+        set_durations();
         if( ( p.dev.bframes && p.b_adapt ) || p.scenecut_threshold || p.mb_tree || vbv_lookahead_on() )
             analyse( 0 );
-        int bframes, brefs;
-        LaFrame *frm;
-        for( bframes = 0, brefs = 0;; bframes++ )
+        int n_b = 0, n_bref = 0;
+        while( !settle_type( n_b, n_b, n_bref ) )
+            n_b++;
+        next[n_b]->i_bframes = n_b;
+        if( p.b_pyramid && n_b > 1 && !n_bref )
         {
-            frm = next[bframes];
-            if( frm->i_type == T_BREF && p.b_pyramid < 2 && brefs == p.b_pyramid )
-                frm->i_type = T_B;
-            else if( frm->i_type == T_BREF && p.b_pyramid == 2 && brefs && p.frame_refs <= ( brefs + 3 ) )
-                frm->i_type = T_B;
-            if( frm->i_type == T_KEYFRAME )
-                frm->i_type = p.open_gop ? T_I : T_IDR;
-            if( ( !p.intra_refresh || frm->i_frame == 0 ) && frm->i_frame - i_last_keyframe >= p.keyint_max )
-            {
-                if( frm->i_type == T_AUTO || frm->i_type == T_I )
-                    frm->i_type = p.open_gop && i_last_keyframe >= 0 ? T_I : T_IDR;
-                int warn = frm->i_type != T_IDR;
-                if( warn && p.open_gop ) warn &= frm->i_type != T_I;
-                if( warn )
-                    frm->i_type = p.open_gop && i_last_keyframe >= 0 ? T_I : T_IDR;
-            }
-            if( frm->i_type == T_I && frm->i_frame - i_last_keyframe >= p.keyint_min )
-            {
-                if( p.open_gop )
-                {
-                    i_last_keyframe = frm->i_frame;
-                    frm->b_keyframe = 1;
-                }
-                else
-                    frm->i_type = T_IDR;
-            }
-            if( frm->i_type == T_IDR )
-            {
-                i_last_keyframe = frm->i_frame;
-                frm->b_keyframe = 1;
-                if( bframes > 0 )
-                {
-                    bframes--;
-                    next[bframes]->i_type = T_P;
-                }
-            }
-            if( bframes == p.dev.bframes || bframes + 1 >= (int)next.size() )
-            {
-                if( frm->i_type == T_AUTO || is_b( frm->i_type ) )
-                    frm->i_type = T_P;
-            }
-            if( frm->i_type == T_BREF ) brefs++;
-            if( frm->i_type == T_AUTO )
-                frm->i_type = T_B;
-            else if( !is_b( frm->i_type ) )
-                break;
+            next[( n_b - 1 ) / 2]->i_type = T_BREF; // the middle B-frame of the run becomes a reference
+            n_bref++;
         }
-        next[bframes]->i_bframes = bframes;
-        if( p.b_pyramid && bframes > 1 && !brefs )
-        {
-            next[( bframes - 1 ) / 2]->i_type = T_BREF;
-            brefs++;
-        }
-        // costs ahead of time for rate control (:1898-1935); VBV variants are out of scope
+        // costs ahead of time for rate control (:1898-1935)
         if( !p.rc_is_cqp )
         {
-            LaFrame *frames[BMAX + 3];
-            int p1 = bframes + 1, b = bframes + 1, p0;
-            frames[0] = last_nonb;
-            for( int i = 0; i <= bframes; i++ ) frames[i + 1] = next[i];
-            p0 = is_i( next[bframes]->i_type ) ? bframes + 1 : 0;
-            frame_cost( frames, p0, p1, b );
-            frames[b]->own_d0 = b - p0; frames[b]->own_d1 = 0;
+            LaFrame *w[BMAX + 3];
+            w[0] = last_nonb;
+            for( int i = 0; i <= n_b; i++ )
+                w[i + 1] = next[i];
+            const int a = n_b + 1;                                  // the anchor that closes the mini-GOP
+            const int from = is_i( next[n_b]->i_type ) ? a : 0;
+            frame_cost( w, from, a, a );
+            w[a]->own_d0 = a - from; w[a]->own_d1 = 0;
+            const bool vbv_rows = ( from != a || n_b ) && p.vbv;
+            if( vbv_rows )
+                frame_cost( w, a, a, a ); // intra costs for the row sums (:1918-1919; memoised when already there)
+            // the cell every B-frame of the mini-GOP is coded with (:1922-1933); VBV needs their row sums now
+            int r0 = 0;
+            for( int i = 1; i <= n_b; i++ )
             {
-                const bool vbv_rows = ( p0 != p1 || bframes ) && p.vbv;
+                int r1 = a;
+                if( w[i]->i_type == T_B )
+                    for( r1 = i; w[r1]->i_type == T_B; )
+                        r1++;
+                w[i]->own_d0 = i - r0; w[i]->own_d1 = r1 - i;
                 if( vbv_rows )
-                    frame_cost( frames, b, b, b ); // intra costs for the row sums (:1918-1919; memoized when already there)
-                // the cell every B-frame of the mini-GOP is coded with (:1922-1933); VBV needs their row sums now
-                int q0 = 0;
-                for( int i = 1; i <= bframes; i++ )
-                {
-                    int q1 = bframes + 1;
-                    if( frames[i]->i_type == T_B )
-                        for( q1 = i; frames[q1]->i_type == T_B; ) q1++;
-                    frames[i]->own_d0 = i - q0; frames[i]->own_d1 = q1 - i;
-                    if( vbv_rows )
-                        frame_cost( frames, q0, q1, i );
-                    if( frames[i]->i_type == T_BREF ) q0 = i;
-                }
+                    frame_cost( w, r0, r1, i );
+                if( w[i]->i_type == T_BREF )
+                    r0 = i;
             }
         }
         // The main-encode weight analysis of a P frame (:1937-1943, b_lookahead = 0) works on the full-resolution planes and
         // stays with the encoder, but its first step is visible in the lookahead's own outputs: when the luma statistics
         // call for a weight test it computes the frame's lowres intra costs if they are still missing (:365-370), which
         // fills i_cost_est[0][0] / i_cost_est_aq[0][0] of P frames no analysis has looked at yet.
-        if( p.weightp >= 1 && next[bframes]->i_type == T_P && last_nonb && !next[bframes]->intra_calculated )
+        if( p.weightp >= 1 && next[n_b]->i_type == T_P && last_nonb && !next[n_b]->intra_calculated )
         {
             x264hip_weight guess, cand;
-            if( weight_candidate( next[bframes], last_nonb, guess, cand ) )
+            if( weight_candidate( next[n_b], last_nonb, guess, cand ) )
             {
-                LaFrame *one[1] = { next[bframes] };
+                LaFrame *one[1] = { next[n_b] };
                 frame_cost( one, 0, 0, 0 );
             }
         }
-        // coded order (:1945-1960)
-        if( bframes )
+        // coded order (:1945-1960): the anchor, the B-references, the plain B-frames
+        if( n_b )
         {
-            std::vector<LaFrame *> tmp( bframes + 1 );
-            int idx_list[2] = { brefs + 1, 1 };
-            for( int i = 0; i < bframes; i++ )
-            {
-                int idx = idx_list[next[i]->i_type == T_BREF]++;
-                tmp[idx] = next[i];
-            }
-            tmp[0] = next[bframes];
-            for( int i = 0; i <= bframes; i++ ) next[i] = tmp[i];
+            std::vector<LaFrame *> coded( 1, next[n_b] );
+            for( int i = 0; i < n_b; i++ ) if( next[i]->i_type == T_BREF ) coded.push_back( next[i] );
+            for( int i = 0; i < n_b; i++ ) if( next[i]->i_type != T_BREF ) coded.push_back( next[i] );
+            for( int i = 0; i <= n_b; i++ ) next[i] = coded[i];
         }
     }
 
