@@ -274,6 +274,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=2,
                     help="independent GOP segments in flight per GPU (one host thread + one context each): the decisions of one "
                          "segment overlap the device work of the other")
+    ap.add_argument("--shard", default="segments", choices=("segments", "window"),
+                    help="N > 1: 'segments' = an independent GOP segment per rank (weak scaling, the default line); 'window' = ONE stream whose "
+                         "lookahead window is sharded over the ranks (SURVEY 8e / BASELINE configs[3], strong scaling) as the primary value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-primitives", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the additional lines (paced figure, 4K configs[2], threaded CPU baseline)")
@@ -373,6 +376,15 @@ def main():
         other_fps = round(S * F / dt_other, 2)
     wl.close()
 
+    window = None
+    if ( world > 1 and not args.no_extra ) or args.shard == "window":
+        try:
+            window = window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend)
+        except Exception as e:  # pragma: no cover
+            if args.shard == "window":
+                raise
+            window = {"error": repr(e)} if rank == 0 else None
+
     if rank == 0:
         bytes_per_search = algorithmic_bytes_per_search(cfg)
         achieved = (prof_searches * bytes_per_search / 1e9) / (prof_ms / 1e3) if prof_ms > 0 else 0.0
@@ -433,6 +445,13 @@ def main():
                 res["roofline_issue"] = issue_roofline(json.load(open(ipath)), prof_ms, prof_searches, cfg)
             except Exception as e:  # pragma: no cover
                 res["roofline_issue"] = {"error": str(e)}
+        if window is not None:
+            res["window_shard"] = window
+            if args.shard == "window" and "value" in window:
+                # the one-stream figure as the primary value (strong scaling); the segment figure stays in the line
+                res["segments_value"] = res["value"]
+                res.update(value=window["value"], scaling="strong", ms_per_step=round(window["seconds"] * 1e3, 3))
+                res["config"] = {"workload": window["workload"], "parallelism": "window x%d" % world}
         if world == 1 and not args.no_extra and (W, H) == (1920, 1080):
             # BASELINE configs[2]: 3840x2160, --preset slower --me umh --merange 32 (the lookahead searches with HEX, range 32, b-adapt 2,
             # rc-lookahead 60), clips generated on the device; same check (batched == paced) as above
@@ -480,6 +499,44 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend, steps=2, frames=250):
+    """BASELINE configs[3]: 3840x2160, one 250-frame GOP, --rc-lookahead 60 --bframes 8, ONE stream over all ranks: rank b % N searches
+    frame b, the fields are gathered to rank 0 (RCCL over xGMI), which decides.  Strong scaling: the same 250 frames at every N.
+    Returns the result object on rank 0 (None elsewhere).  The N > 1 result is checked against a single-rank pass of rank 0."""
+    W, H = 3840, 2160
+    cfg = lib.la_config(W, H, "medium", bit_depth=8, bframes=8, rc_lookahead=60, keyint_max=250)
+    clip = make_clip_device(torch, W, H, frames, 4242, 8, scene_cuts=(frames // 3,))  # the same seed on every rank: the same pictures
+    nb = cfg["bframes"] + 2
+    on_dev = backend == "nccl"
+    best = None
+    outs = None
+    for k in range(steps + 1):  # one warm-up pass
+        outs, dt, stats = shard.run_window_shard(torch, lib, dist if world > 1 else None, rank, world, dev_index, cfg, clip, on_dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if k > 0:
+            best = float(t.item()) if best is None else min(best, float(t.item()))
+    res = None
+    if rank == 0:
+        checked = None
+        if world > 1:
+            ref, _, _ = shard.run_window_shard(torch, lib, None, 0, 1, dev_index, cfg, clip, on_dev)
+            assert outputs_signature(outs, nb) == outputs_signature(ref, nb), "window shard: decisions or cost cells differ from the single-rank run"
+            checked = "types + every cost cell == single-rank run of the same stream"
+        res = {"workload": "3840x2160 8-bit, one %d-frame GOP, --rc-lookahead 60 --bframes 8 (BASELINE configs[3]); ONE stream, frame b searched on rank "
+                           "b %% N, fields gathered to rank 0" % frames,
+               "value": round(frames / best, 2), "unit": "frames/s", "n_gpus": world, "scaling": "strong", "seconds": round(best, 4),
+               "fields_searched_rank0": stats["fields_searched"], "fields_imported_rank0": stats["fields_imported"],
+               "bytes_gathered": stats["bytes_gathered"], "checked": checked}
+    elif world > 1:
+        pass
+    if world > 1:
+        dist.barrier()  # rank 0's verification pass
+    del clip
+    return res
 
 
 def issue_roofline(prof, prof_ms, prof_searches, cfg):

@@ -170,6 +170,24 @@ int  x264hip_geometry( x264hip_ctx *ctx, int *mb_w, int *mb_h, int *lowres_strid
  * calls pick the finished fields up instead of searching.  Never changes results. */
 int  x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *frame_numbers, int n );
 
+/* The two halves of x264hip_prefetch separately: flags = X264HIP_PREFETCH_CELLS_ONLY skips the searches (the fields are expected
+ * to arrive through x264hip_import_field) and only enqueues the speculative cost cells over the fields that exist. */
+#define X264HIP_PREFETCH_CELLS_ONLY 1
+int  x264hip_prefetch_ex( x264hip_ctx *ctx, const int *slots, const int *frame_numbers, int n, int flags );
+
+/* ---- one lookahead window over several GPUs (x264_amd/shard.py) -----------------------------------------------------
+ * The frames of a window are dealt round-robin to the ranks of a node; a rank runs the unweighted searches of the frames it owns
+ * (x264hip_search_fields: like the search half of x264hip_prefetch, for an explicit list of (frame, reference, list, distance)),
+ * packs each finished field as n_mb x { mvx | mvy << 16, mv cost } int32 pairs (x264hip_export_field, device buffer) for the
+ * collective that carries it to the deciding rank, which takes it in with x264hip_import_field: the field then counts as
+ * speculatively computed there, exactly as if that context had searched it (a field the context already has is left alone).
+ * x264hip_field_classes: which (list, distance) classes this context would speculate (bit d of mask_l = distance d + 1), so that
+ * the deciding rank can tell the others. */
+int  x264hip_search_fields( x264hip_ctx *ctx, int n, const int *slot_b, const int *slot_ref, const int *list, const int *dist_minus1 );
+int  x264hip_export_field( x264hip_ctx *ctx, int slot, int list, int dist_minus1, void *dst_dev );
+int  x264hip_import_field( x264hip_ctx *ctx, int slot, int list, int dist_minus1, const void *src_dev );
+int  x264hip_field_classes( x264hip_ctx *ctx, unsigned *mask_l0, unsigned *mask_l1 );
+
 /* MB-tree: replaces mbtree_propagate_cost / mbtree_propagate_list of x264_mc_functions_t (common/mc.h:333-338,
  * common/mc.c:511-598) and macroblock_tree_finish (encoder/slicetype.c:1029-1049) for a whole list of steps at once.
  * Runs asynchronously on the context's second stream; x264hip_get_qp_offsets waits for it. */
@@ -434,6 +452,12 @@ typedef struct x264hip_la_frame
 
 /* Opens a device context (x264hip_open) and the host logic on top of it.  No CPU fallback. */
 int  x264hip_lookahead_open( x264hip_lookahead **out, int device, const x264hip_la_params *params );
+/* The device lookahead with its speculative submissions routed through the caller: hook( user, slots, frame_numbers, n ) is called
+ * where the host logic would call x264hip_prefetch (same arguments: every resident frame the next decisions can reach) and is
+ * expected to make those fields and cells available by its own means -- x264_amd/shard.py searches them on several GPUs and
+ * finishes with x264hip_import_field + x264hip_prefetch_ex( CELLS_ONLY ).  Never changes results. */
+typedef int (*x264hip_prefetch_hook)( void *user, const int *slots, const int *frame_numbers, int n );
+int  x264hip_lookahead_open_hooked( x264hip_lookahead **out, int device, const x264hip_la_params *params, x264hip_prefetch_hook hook, void *user );
 /* Same host logic over a caller-supplied backend (plugin / test hook). */
 int  x264hip_lookahead_open_backend( x264hip_lookahead **out, const x264hip_la_params *params, const x264hip_backend *backend );
 void x264hip_lookahead_close( x264hip_lookahead *la );

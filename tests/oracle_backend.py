@@ -27,6 +27,8 @@ class OracleBackend:
                                     do_edges=cfg.get("do_edges", 1))
         self.slots = {}
         self.n_eval = 0
+        self.on_prefetch = None
+        self.spec_used = self.searched_here = 0   # unweighted fields taken from the speculative store / searched by this backend itself
         self.struct = lib.Backend(None, lib.FRAME_PUT_FN(self._put), lib.FRAME_STATS_FN(self._stats),
                                   lib.WEIGHT_COST_FN(self._wcost), lib.FRAME_COST_FN(self._cost),
                                   lib.PREFETCH_FN(self._prefetch) if speculative else lib.PREFETCH_FN(0),
@@ -35,6 +37,8 @@ class OracleBackend:
                                   lib.RECALC_FN(self._recalc), lib.ROW_SATDS_FN(self._rows), lib.FRAME_PUT_YUV_FN(self._put_yuv), lib.ADD_QOFFS_FN(self._add_qoffs), lib.PUT_BATCH_YUV_FN(0))
 
     def _prefetch(self, user, slots, numbers, n):
+        if self.on_prefetch is not None:  # window sharding (x264_amd/shard.py): the speculative searches of this chunk, spread over ranks
+            self.on_prefetch([slots[i] for i in range(n)], [numbers[i] for i in range(n)])
         return 0
 
     def _prefetch_weights(self, user, n, sf, sr, w):
@@ -56,12 +60,15 @@ class OracleBackend:
 
     def _put(self, user, slot, luma, stride, is_device, cb=None, cr=None):
         c = self.cfg
-        img = self._plane(luma, stride, c["width"], c["height"])
+        return self.put_array(slot, self._plane(luma, stride, c["width"], c["height"]), cb, cr)
+
+    def put_array(self, slot, img, cb=None, cr=None):
+        c = self.cfg
         pl = self.o.lowres_init(self.ocfg, img)
         inv, qp, s, ssd = self.o.aq_frame(img, self.ocfg.mb_w, self.ocfg.mb_h, c["aq_mode"], c["aq_strength"], cb, cr,
                                             chroma_format=c.get("chroma_format", 1))
         n = self.ocfg.mb_w * self.ocfg.mb_h
-        self.slots[slot] = dict(planes=pl, inv=inv, sum=s, ssd=ssd, intra=self.o.intra_costs(self.ocfg, pl), fields={}, maps={}, rows={},
+        self.slots[slot] = dict(planes=pl, inv=inv, sum=s, ssd=ssd, intra=self.o.intra_costs(self.ocfg, pl), fields={}, spec={}, maps={}, rows={},
                                 prop=np.zeros(n, np.uint16), qp_aq=qp.copy(), qp=qp.copy(), img=img, cb=cb, cr=cr)
         return 0
 
@@ -91,9 +98,19 @@ class OracleBackend:
                 if w and w[0].on:
                     wt = OWeight(w[0].on, w[0].scale, w[0].denom, w[0].offset)
                     wplane = o.weight_plane(cfg, F0["planes"][0], wt)
-                B["fields"][(0, d0 - 1)] = o.search_field(cfg, B["planes"], F0["planes"], wt, wplane)
+                if wt is None and (0, d0 - 1) in B["spec"]:  # a speculative (possibly imported) field, like the device's claimed fields
+                    B["fields"][(0, d0 - 1)] = B["spec"][(0, d0 - 1)]
+                    self.spec_used += 1
+                else:
+                    B["fields"][(0, d0 - 1)] = o.search_field(cfg, B["planes"], F0["planes"], wt, wplane)
+                    self.searched_here += wt is None
             if d1 > 0 and do_search[1]:
-                B["fields"][(1, d1 - 1)] = o.search_field(cfg, B["planes"], F1["planes"])
+                if (1, d1 - 1) in B["spec"]:
+                    B["fields"][(1, d1 - 1)] = B["spec"][(1, d1 - 1)]
+                    self.spec_used += 1
+                else:
+                    B["fields"][(1, d1 - 1)] = o.search_field(cfg, B["planes"], F1["planes"])
+                    self.searched_here += 1
             m0, c0 = B["fields"][(0, d0 - 1)]
             dsf = (d0 * 256 + (d0 + d1) // 2) // (d0 + d1)
             if d1 > 0:
@@ -176,3 +193,48 @@ class OracleBackend:
                                         chroma_format=c.get("chroma_format", 1), quant_offsets=offs)
         B["inv"], B["qp_aq"], B["qp"] = inv, qp.copy(), qp.copy()
         return 0
+
+
+class OracleShardAdapter:
+    """x264_amd.shard.WindowShard over the oracle backend (CPU tests of the multi-rank protocol): the same duck-typed interface as
+    HipAdapter, fields kept in the backend's speculative store."""
+
+    def __init__(self, be, clip, own_ingest):
+        self.be, self.clip, self.own_ingest = be, clip, own_ingest
+        self.n_mb, self.bframes = be.ocfg.mb_w * be.ocfg.mb_h, be.cfg["bframes"]
+
+    def ingest(self, slot, number):
+        if self.own_ingest:
+            self.be.put_array(slot, self.clip[number])
+
+    def classes(self):
+        return (1 << (self.bframes + 1)) - 1, (1 << (self.bframes + 1)) - 1
+
+    def search(self, reqs):
+        for sb, sr, lst, dm1 in reqs:
+            B, R = self.be.slots[sb], self.be.slots[sr]
+            if (lst, dm1) not in B["spec"] and (lst, dm1) not in B["fields"]:
+                B["spec"][(lst, dm1)] = self.be.o.search_field(self.be.ocfg, B["planes"], R["planes"])
+
+    def export(self, keys):
+        import torch
+        out = np.zeros((len(keys), self.n_mb, 2), np.int32)
+        for i, (slot, lst, dm1) in enumerate(keys):
+            B = self.be.slots[slot]
+            mv, cost = B["spec"].get((lst, dm1)) or B["fields"][(lst, dm1)]
+            out[i, :, 0] = (mv[:, 0].astype(np.int32) & 0xFFFF) | (mv[:, 1].astype(np.int32) << 16)
+            out[i, :, 1] = cost
+        return torch.from_numpy(out)
+
+    def import_(self, keys, t):
+        a = t.numpy()
+        for i, (slot, lst, dm1) in enumerate(keys):
+            B = self.be.slots[slot]
+            if (lst, dm1) in B["spec"] or (lst, dm1) in B["fields"]:
+                continue
+            w = a[i, :, 0]
+            mv = np.stack([(w & 0xFFFF).astype(np.uint16).view(np.int16), (w >> 16).astype(np.int16)], axis=1).astype(np.int16)
+            B["spec"][(lst, dm1)] = (np.ascontiguousarray(mv), np.ascontiguousarray(a[i, :, 1], np.int32))
+
+    def finish(self, slots, numbers):
+        pass

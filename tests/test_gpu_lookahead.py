@@ -139,3 +139,55 @@ def test_batch_ingest_device_pointers():
         assert np.array_equal(a, b)
     for a, b in zip(outs, ref):
         assert np.array_equal(a.qp_offset, b.qp_offset)
+
+
+def _shard_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from x264_amd import lib as L2, shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    W, H, nf = 704, 576, 70
+    frames = make_clip(W, H, nf, seed=12, scene_cuts=(23,), fade=(40, 8, 0.7, 6), pan=(4, 2))
+    cfg = L2.la_config(W, H, "medium", bframes=8, rc_lookahead=60)
+    dev = torch.from_numpy(frames).cuda()
+    outs, dt, stats = shard.run_window_shard(torch, L2, dist, rank, world, 0, cfg, dev, exchange_on_device=False, qp_offsets=True)
+    if rank == 0:
+        q.put(dict(sig=[(o.frame, o.type, [o.cost_est[i][j] for i in range(10) for j in range(10)], o.qp_offset.tobytes()) for o in outs], stats=stats))
+    else:
+        q.put(dict(stats=stats))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_window_shard_two_ranks_on_one_gpu():
+    """SURVEY 8(e) on the device: two processes share one lookahead window (here also one GPU, gloo carrying the fields): rank 1
+    searches the odd frames, rank 0 imports its fields, decides and runs cells + MB-tree.  Decisions, cost cells and f_qp_offset
+    must equal the plain single-context run (BASELINE configs[3] options: --bframes 8 --rc-lookahead 60)."""
+    import socket
+    import torch.multiprocessing as mp
+    W, H, nf = 704, 576, 70
+    frames = make_clip(W, H, nf, seed=12, scene_cuts=(23,), fade=(40, 8, 0.7, 6), pan=(4, 2))
+    cfg = lib.la_config(W, H, "medium", bframes=8, rc_lookahead=60)
+    la = lib.Lookahead(cfg, max_frames=nf + 4)
+    try:
+        ref = la.run(frames, paced=False, qp_offsets=True)
+    finally:
+        la.close()
+    want = [(o.frame, o.type, [o.cost_est[i][j] for i in range(10) for j in range(10)], o.qp_offset.tobytes()) for o in ref]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    r0 = next(g for g in got if "sig" in g)
+    r1 = next(g for g in got if "sig" not in g)
+    assert r0["sig"] == want
+    assert r1["stats"]["fields_searched"] > 100 and r0["stats"]["fields_imported"] == r1["stats"]["fields_searched"]

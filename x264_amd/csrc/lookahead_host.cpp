@@ -98,6 +98,8 @@ struct Lookahead
     float qcompress = 0.6f;
     uint64_t stats[8] = { 0 };
     int err = 0;
+    x264hip_prefetch_hook prefetch_hook = nullptr; // x264hip_lookahead_open_hooked
+    void *prefetch_hook_user = nullptr;
 
     // ---- frame bookkeeping -------------------------------------------------------------------------
     void release( LaFrame *f )
@@ -986,7 +988,10 @@ struct Lookahead
             next[i]->prefetch_submitted = true;
         }
         ScopeNs tm( stats[6] );
-        need( be.prefetch( be.user, slots.data(), nums.data(), (int)slots.size() ) );
+        if( prefetch_hook )
+            need( prefetch_hook( prefetch_hook_user, slots.data(), nums.data(), (int)slots.size() ) );
+        else
+            need( be.prefetch( be.user, slots.data(), nums.data(), (int)slots.size() ) );
         // the two cost sums of every weight test the decisions can ask for (P evaluations over 1..bframes+1 frames):
         // queued behind the searches, answered later without a round trip
         if( be.prefetch_weight_costs && p.weightp && !err )
@@ -1129,6 +1134,15 @@ extern "C" int x264hip_lookahead_open( x264hip_lookahead **out, int device, cons
     rc = x264hip_lookahead_open_backend( out, &p, &be );
     if( rc ) { x264hip_close( ctx ); return rc; }
     ( *out )->L.ctx = ctx;
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_lookahead_open_hooked( x264hip_lookahead **out, int device, const x264hip_la_params *params, x264hip_prefetch_hook hook, void *user )
+{
+    int rc = x264hip_lookahead_open( out, device, params );
+    if( rc ) return rc;
+    ( *out )->L.prefetch_hook = hook;
+    ( *out )->L.prefetch_hook_user = user;
     return X264HIP_OK;
 }
 

@@ -870,6 +870,11 @@ static int launch_cells_t( x264hip_ctx *ctx, const std::vector<SpecCell> &cells 
 
 extern "C" int x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *frame_numbers, int n )
 {
+    return x264hip_prefetch_ex( ctx, slots, frame_numbers, n, 0 );
+}
+
+extern "C" int x264hip_prefetch_ex( x264hip_ctx *ctx, const int *slots, const int *frame_numbers, int n, int flags )
+{
     if( !ctx || !slots || !frame_numbers || n < 0 ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
@@ -891,6 +896,7 @@ extern "C" int x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *
             FrameSlot &b = ctx->slots[slots[i]];
             if( b.field_ready[list][dm1] || b.field_prefetched[list][dm1] ) continue;
             if( learned && !ctx->field_req[list][dm1] ) continue; // a class this caller never asks for
+            if( flags & X264HIP_PREFETCH_CELLS_ONLY ) continue;     // the fields come from elsewhere (x264hip_import_field)
             b.field_prefetched[list][dm1] = 1;
             reqs.push_back( SearchReq{ slots[i], slots[j], list, dm1, none } );
         }
@@ -2080,4 +2086,93 @@ extern "C" int x264hip_mc_fill( x264hip_ctx *ctx, x264hip_mc_functions *pf )
 extern "C" void x264hip_mc_unbind( x264hip_ctx *ctx )
 {
     if( g_vt_ctx == ctx ) g_vt_ctx = nullptr;
+}
+
+// ---- one lookahead window sharded over several GPUs: the unweighted motion searches of a frame run on the rank that
+// owns it, the finished fields travel to the deciding rank (x264_amd/shard.py drives the exchange with torch.distributed / RCCL) --------
+__global__ __launch_bounds__( 256 ) void export_field_kernel( const unsigned long long *__restrict__ mvq, const int *__restrict__ costs, int2 *__restrict__ dst, int n )
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if( i < n )
+        dst[i] = make_int2( (int)(unsigned)mvq[i], costs[i] );
+}
+__global__ __launch_bounds__( 256 ) void import_field_kernel( unsigned long long *__restrict__ mvq, int *__restrict__ costs, const int2 *__restrict__ src, unsigned tag, int n )
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if( i < n )
+    {
+        const int2 v = src[i];
+        mvq[i] = ( (unsigned long long)tag << 32 ) | (unsigned)v.x;
+        costs[i] = v.y;
+    }
+}
+
+extern "C" int x264hip_search_fields( x264hip_ctx *ctx, int n, const int *slot_b, const int *slot_ref, const int *list, const int *dist_minus1 )
+{
+    if( !ctx || n < 0 || ( n && ( !slot_b || !slot_ref || !list || !dist_minus1 ) ) ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    std::vector<SearchReq> reqs;
+    const WtD none = { 0, 1, 0, 0 };
+    for( int i = 0; i < n; i++ )
+    {
+        if( !slot_ok( ctx, slot_b[i] ) || !slot_ok( ctx, slot_ref[i] ) || list[i] < 0 || list[i] > 1 || dist_minus1[i] < 0 || dist_minus1[i] > ctx->p.bframes )
+            return X264HIP_EINVAL;
+        FrameSlot &b = ctx->slots[slot_b[i]];
+        if( !b.in_use || !ctx->slots[slot_ref[i]].in_use ) return X264HIP_ESTATE;
+        if( b.field_ready[list[i]][dist_minus1[i]] || b.field_prefetched[list[i]][dist_minus1[i]] ) continue;
+        b.field_prefetched[list[i]][dist_minus1[i]] = 1;
+        reqs.push_back( SearchReq{ slot_b[i], slot_ref[i], list[i], dist_minus1[i], none } );
+    }
+    for( size_t o = 0; o < reqs.size(); o += ctx->desc_cap )
+    {
+        std::vector<SearchReq> part( reqs.begin() + o, reqs.begin() + std::min( reqs.size(), o + (size_t)ctx->desc_cap ) );
+        int r = launch_searches( ctx, part );
+        if( r ) return r;
+    }
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_export_field( x264hip_ctx *ctx, int slot, int list, int dist_minus1, void *dst_dev )
+{
+    if( !ctx || !slot_ok( ctx, slot ) || list < 0 || list > 1 || dist_minus1 < 0 || dist_minus1 > ctx->p.bframes || !dst_dev ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    FrameSlot &s = ctx->slots[slot];
+    if( !s.field_ready[list][dist_minus1] && !s.field_prefetched[list][dist_minus1] ) return X264HIP_ESTATE;
+    export_field_kernel<<<( ctx->n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( s.mvq[list][dist_minus1], s.mvcost[list][dist_minus1], (int2 *)dst_dev, ctx->n_mb );
+    HIPCK( hipGetLastError() );
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_import_field( x264hip_ctx *ctx, int slot, int list, int dist_minus1, const void *src_dev )
+{
+    if( !ctx || !slot_ok( ctx, slot ) || list < 0 || list > 1 || dist_minus1 < 0 || dist_minus1 > ctx->p.bframes || !src_dev ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    FrameSlot &s = ctx->slots[slot];
+    if( !s.in_use ) return X264HIP_ESTATE;
+    if( s.field_ready[list][dist_minus1] || s.field_prefetched[list][dist_minus1] )
+        return X264HIP_OK; // this context already has the field (searched here on demand): identical by construction, keep it
+    const unsigned tag = ctx->tag_serial++;
+    if( !ctx->tag_serial ) ctx->tag_serial = 1;
+    import_field_kernel<<<( ctx->n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( s.mvq[list][dist_minus1], s.mvcost[list][dist_minus1], (const int2 *)src_dev, tag, ctx->n_mb );
+    HIPCK( hipGetLastError() );
+    s.field_tag[list][dist_minus1] = tag;
+    s.field_prefetched[list][dist_minus1] = 1;
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_field_classes( x264hip_ctx *ctx, unsigned *mask_l0, unsigned *mask_l1 )
+{
+    if( !ctx || !mask_l0 || !mask_l1 ) return X264HIP_EINVAL;
+    static const bool no_learn = getenv( "X264HIP_NO_CLASS_LEARNING" ) != nullptr;
+    const bool learned = !no_learn && ctx->n_requests >= x264hip_ctx::LEARN_REQUESTS;
+    unsigned m[2] = { 0, 0 };
+    for( int l = 0; l < 2; l++ )
+        for( int d = 0; d <= ctx->p.bframes; d++ )
+            if( !learned || ctx->field_req[l][d] )
+                m[l] |= 1u << d;
+    *mask_l0 = m[0]; *mask_l1 = m[1];
+    return X264HIP_OK;
 }

@@ -630,13 +630,28 @@ def make_la_params(cfg, cost_mv=None, max_frames=0):
 class Lookahead:
     """x264hip_lookahead: put frames in display order, get frames back in coded order with their types."""
 
-    def __init__(self, cfg, device=0, backend=None, cost_mv=None, max_frames=0):
+    def __init__(self, cfg, device=0, backend=None, cost_mv=None, max_frames=0, prefetch_hook=None):
+        """prefetch_hook( slots, frame_numbers ): device lookahead whose speculative submissions go through the caller
+        (x264hip_lookahead_open_hooked; x264_amd/shard.py spreads them over several GPUs)."""
         L = load()
         self.L = L
         self.cfg = cfg
         self.params = make_la_params(cfg, cost_mv, max_frames)
         self.h = C.c_void_p()
-        if backend is None:
+        if prefetch_hook is not None:
+            def _hook(user, slots, numbers, n):
+                try:
+                    prefetch_hook([slots[i] for i in range(n)], [numbers[i] for i in range(n)])
+                    return 0
+                except Exception as e:  # never let an exception cross the C ABI
+                    import traceback
+                    traceback.print_exc()
+                    self._hook_error = e
+                    return -4
+            self._hook = PREFETCH_FN(_hook)
+            L.x264hip_lookahead_open_hooked.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(LaParams), PREFETCH_FN, C.c_void_p]
+            _ck(L.x264hip_lookahead_open_hooked(C.byref(self.h), device, C.byref(self.params), self._hook, None), "x264hip_lookahead_open_hooked")
+        elif backend is None:
             L.x264hip_lookahead_open.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(LaParams)]
             _ck(L.x264hip_lookahead_open(C.byref(self.h), device, C.byref(self.params)), "x264hip_lookahead_open")
         else:
