@@ -105,6 +105,49 @@ def primitives_bench(torch, libmod, cfg, iters=30):
         ctx.synchronize()
         out["device_copy_GBps"] = round(2 * a.numel() * 10 / (time.perf_counter() - t0) / 1e9, 1)
         del a, b
+        # main-encode motion search: every 16x16 macroblock of a 1920x1072 frame pair searched in one batch, searches/s.
+        # esa / tesa: one wave per request (cooperative exhaustive scan, me_range 16); umh: one thread per request
+        try:
+            mw, mh, padh, padv, mvr = 1920, 1072, 32, 32, 64
+            pw, ph = mw + 2 * padh, mh + 2 * padv
+            base = torch.rand((1, 1, mh + 16, mw + 16), generator=g, device="cuda")
+            base = torch.nn.functional.avg_pool2d(base, 5, stride=1, padding=2)[0, 0]
+            base = (base - base.min()) / float(base.max() - base.min()) * 255.0
+            fenc_l = (base[3:3 + mh, 2:2 + mw] + torch.randint(-3, 4, (mh, mw), generator=g, device="cuda")).clamp(0, 255).to(torch.uint8).contiguous()
+            ref_l = (base[:mh, :mw] + torch.randint(-3, 4, (mh, mw), generator=g, device="cuda")).clamp(0, 255).to(torch.uint8).contiguous()
+            planes = torch.zeros((4, ph, pw), dtype=torch.uint8, device="cuda")
+            integ = torch.zeros((2 * ph, pw), dtype=torch.int16, device="cuda")
+            table, centre = libmod.cost_mv_table(mvr, 1)
+            cmv = torch.from_numpy(table.view(np.int16)).cuda()
+            torch.cuda.synchronize()
+            org = padv * pw + padh
+            ctx.frame_filter(ref_l.data_ptr(), mw, mw, mh, [planes[k].data_ptr() + org for k in range(4)], pw, padh, padv, integ.data_ptr(), integ.data_ptr() + 2 * ph * pw)
+            ctx.synchronize()
+            mbw, mbh = mw // 16, mh // 16
+            for name, method in (("esa", 3), ("tesa", 4), ("umh", 2)):
+                reqs = []
+                for my in range(mbh):
+                    for mx in range(mbw):
+                        q = libmod.MeRequest()
+                        q.i_pixel, q.me_method, q.subpel_refine, q.me_range, q.mbcmp_satd, q.fpelcmp_satd = 0, method, 7, 16, 1, int(method == 4)
+                        q.x, q.y = 16 * mx, 16 * my
+                        fm = 4 * mvr
+                        smin = [max(4 * (-16 * mx - 24), -fm), max(4 * (-16 * my - 24), -fm)]
+                        smax = [min(4 * (16 * (mbw - mx - 1) + 24), fm - 1), min(4 * (16 * (mbh - my - 1) + 24), fm - 1)]
+                        for k in range(2):
+                            q.mvp[k] = 0
+                            q.spel_min[k], q.spel_max[k] = smin[k], smax[k]
+                            q.lim_min[k], q.lim_max[k] = (smin[k] >> 2) + 6, (smax[k] >> 2) - 6
+                        q.n_mvc = 0
+                        reqs.append(q)
+                args_ = (reqs, fenc_l.data_ptr(), mw, [planes[k].data_ptr() + org for k in range(4)], pw, integ.data_ptr() + org * 2, ph * pw, cmv.data_ptr() + 2 * centre)
+                ctx.me_search_batch(*args_)
+                t0 = time.perf_counter()
+                ctx.me_search_batch(*args_)
+                out["me_full_%s_16x16_searches_per_s" % name] = round(len(reqs) / (time.perf_counter() - t0))
+            del planes, integ, fenc_l, ref_l
+        except Exception as e:  # pragma: no cover
+            out["me_full_error"] = repr(e)
         luma = torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda", generator=g)
         torch.cuda.synchronize()
         ctx.frame_put(0, None, device_ptr=luma.data_ptr(), stride=W); ctx.synchronize()

@@ -161,6 +161,28 @@ struct Mef
     int bmx, bmy, bcost;
 };
 
+// Cooperation policy of the exhaustive branches (ESA / TESA).  CoopNone: one thread runs the whole search -- the host check and the
+// scalar device reference.  CoopWave (device, below): the 64 lanes of a wave run the search of ONE request in lock step with
+// identical state; in the exhaustive scans lane l costs candidate l of every chunk of 64, the chunk's winner is the smallest cost
+// and among equal costs the earliest candidate -- exactly what scanning the chunk in order with strict '<' keeps.
+struct CoopNone
+{
+    static constexpr int W = 1;
+    int16_t xs_[MF_TESA_WIDTH_MAX + 64];
+    BM_HD int lane() const { return 0; }
+    BM_HD void argmin( int &, int & ) const {}
+    BM_HD unsigned long long ballot( bool p ) const { return p ? 1ull : 0ull; }
+    BM_HD int bcast( int v, int ) const { return v; }
+    BM_HD void sync() const {}
+    BM_HD int16_t *xs() { return xs_; }
+};
+BM_HD int mf_popc64( unsigned long long v )
+{
+    int n = 0;
+    for( ; v; v &= v - 1 ) n++;
+    return n;
+}
+
 template <typename T>
 BM_HD int mef_fpelcmp( const Mef<T> *s, const T *b, int sb )
 {
@@ -344,8 +366,8 @@ BM_HD void mef_refine_subpel( Mef<T> *s, int mv[2], int *cost, int *cost_mv, int
     *cost_mv = mef_bits_q( s, bmx, bmy );
 }
 
-template <typename T>
-BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_mvc, int out[4] )
+template <typename T, class Coop = CoopNone>
+BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_mvc, int out[4], Coop coop = Coop() )
 {
     const uint8_t mef_size[7][2] = { {16,16}, {16,8}, {8,16}, {8,8}, {8,4}, {4,8}, {4,4} };
     const uint8_t mef_subpel_iterations[12][4] = /* me.c:38-50 */
@@ -538,8 +560,14 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
                 {
                     if( s->bcost <= p->cost_mv[4*my - p->mvp[1]] )
                         continue;
-                    for( int mx = min_x; mx < min_x + width; mx++ )
-                        mef_try_f( s, mx, my );
+                    for( int base = 0; base < width; base += Coop::W )
+                    {
+                        int idx = base + coop.lane(), c = MF_COST_MAX;
+                        if( idx < width )
+                            c = mef_cost_f( s, min_x + idx, my );
+                        coop.argmin( c, idx );
+                        if( c < s->bcost ) { s->bcost = c; s->bmx = min_x + idx; s->bmy = my; }
+                    }
                 }
                 break;
             }
@@ -570,7 +598,7 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
                 enc_dc[1] = enc_dc[2];
             // candidate list of the SAD stage: in the request's scratch area (MF_TESA_ROWS_MAX x MF_TESA_WIDTH_MAX entries)
             mef_mvsad *mvsads = (mef_mvsad *)p->scratch;
-            int16_t xs[MF_TESA_WIDTH_MAX + 64];
+            int16_t *xs = coop.xs();
             uint16_t cost_fpel_mvx[MF_TESA_WIDTH_MAX + 4];
             for( int x = 0; x < width; x++ )
                 cost_fpel_mvx[x] = p->cost_mv[4*( min_x + x ) - p->mvp[0]];
@@ -583,19 +611,53 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
                 if( bsad <= ycost )
                     continue;
                 bsad -= ycost;
-                int xn = mf_ads( ads_n, enc_dc, sums_base + min_x + (long)my * p->stride, delta, cost_fpel_mvx, xs, width, bsad * 17 >> 4 );
-                for( int i = 0; i < xn; i++ )
+                /* ads stage (pixel.c:756-803): the candidates of the row below the threshold, kept in scan order -- with several
+                 * lanes through a ballot and the count of kept candidates in front of each */
+                int xn = 0;
                 {
-                    int mx = min_x + xs[i];
-                    /* the reference indexes its x-cost table with the offset from min_x here (me.c:671,688: cost_fpel_mvx[xs[i]],
-                     * not cost_fpel_mvx[min_x + xs[i]] as in the ads call), so the SAD stage charges the cost of column xs[i] */
-                    int sad = mf_sad( p->fenc, p->fenc_stride, p->ref[0] + (long)my * p->stride + mx, p->stride, s->bw, s->bh ) +
-                              p->cost_mv[4 * xs[i] - p->mvp[0]];
-                    if( sad < bsad * sad_thresh >> 3 )
+                    const uint16_t *sums = sums_base + min_x + (long)my * p->stride;
+                    const int thresh = bsad * 17 >> 4;
+                    coop.sync();
+                    for( int base = 0; base < width; base += Coop::W )
                     {
-                        if( sad < bsad ) bsad = sad;
-                        mvsads[nmvsad].sad = sad + ycost; mvsads[nmvsad].mx = mx; mvsads[nmvsad].my = my;
-                        nmvsad++;
+                        const int i = base + coop.lane();
+                        bool keep = false;
+                        if( i < width )
+                        {
+                            int a = enc_dc[0] - sums[i], ads = mf_abs( a ) + cost_fpel_mvx[i];
+                            if( ads_n == 2 ) ads += mf_abs( enc_dc[1] - sums[i + delta] );
+                            else if( ads_n == 4 ) ads += mf_abs( enc_dc[1] - sums[i + 8] ) + mf_abs( enc_dc[2] - sums[i + delta] ) + mf_abs( enc_dc[3] - sums[i + delta + 8] );
+                            keep = ads < thresh;
+                        }
+                        const unsigned long long m = coop.ballot( keep );
+                        if( keep )
+                            xs[xn + mf_popc64( m & ( ( 1ull << coop.lane() ) - 1 ) )] = (int16_t)i;
+                        xn += mf_popc64( m );
+                    }
+                    coop.sync();
+                }
+                /* SAD stage: the SADs of a chunk of survivors side by side, the running thresholds applied to them in scan order */
+                for( int base = 0; base < xn; base += Coop::W )
+                {
+                    const int i = base + coop.lane();
+                    int sad_mine = MF_COST_MAX;
+                    if( i < xn )
+                    {
+                        /* the reference indexes its x-cost table with the offset from min_x here (me.c:671,688: cost_fpel_mvx[xs[i]],
+                         * not cost_fpel_mvx[min_x + xs[i]] as in the ads call), so the SAD stage charges the cost of column xs[i] */
+                        sad_mine = mf_sad( p->fenc, p->fenc_stride, p->ref[0] + (long)my * p->stride + min_x + xs[i], p->stride, s->bw, s->bh ) +
+                                   p->cost_mv[4 * xs[i] - p->mvp[0]];
+                    }
+                    const int n_chunk = xn - base < Coop::W ? xn - base : Coop::W;
+                    for( int k = 0; k < n_chunk; k++ )
+                    {
+                        const int sad = coop.bcast( sad_mine, k );
+                        if( sad < bsad * sad_thresh >> 3 )
+                        {
+                            if( sad < bsad ) bsad = sad;
+                            mvsads[nmvsad].sad = sad + ycost; mvsads[nmvsad].mx = min_x + xs[base + k]; mvsads[nmvsad].my = my;
+                            nmvsad++;
+                        }
                     }
                 }
                 bsad += ycost;
@@ -658,6 +720,60 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
 #ifdef __HIPCC__
 // request table in device memory; candidates per request in mvc[i][MF_MVC_MAX][2]
 #define MF_MVC_MAX 10
+struct CoopWave
+{
+    static constexpr int W = 64;
+    int16_t *xs_; // in LDS: the ads survivors of the current row, shared by the wave
+    __device__ __forceinline__ int lane() const { return threadIdx.x & 63; }
+    __device__ __forceinline__ void argmin( int &cost, int &idx ) const
+    {
+        unsigned long long key = ( (unsigned long long)(unsigned)cost << 32 ) | (unsigned)idx; // costs are non-negative and below 2^28
+#pragma unroll
+        for( int m = 1; m < 64; m <<= 1 )
+        {
+            const unsigned long long o = __shfl_xor( key, m, 64 );
+            key = o < key ? o : key;
+        }
+        cost = (int)( key >> 32 ); idx = (int)(unsigned)key;
+    }
+    __device__ __forceinline__ unsigned long long ballot( bool p ) const { return __builtin_amdgcn_ballot_w64( p ); }
+    __device__ __forceinline__ int bcast( int v, int l ) const { return __shfl( v, l, 64 ); }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ int16_t *xs() { return xs_; }
+};
+
+// The exhaustive methods (ESA, TESA): one wave per request.  The 64 lanes run the whole search in lock step (the predictor stage
+// and the sub-pel refinement redundantly, their loads are broadcasts) and share the exhaustive scan: 64 candidates per step,
+// ordered compaction of the ads survivors, first-in-scan-order ties -- bit-exact with the one-thread form below, which remains
+// the device reference and serves DIA / HEX / UMH requests.
+template <typename T>
+__global__ __launch_bounds__( 64 ) void me_full_coop_kernel( const MfReq<T> *reqs, const int16_t *mvc, const int *n_mvc, const int *index, int n, int *out )
+{
+    __shared__ int16_t xs_lds[MF_TESA_WIDTH_MAX + 64];
+    if( (int)blockIdx.x >= n )
+        return;
+    const int i = index[blockIdx.x];
+    CoopWave coop;
+    coop.xs_ = xs_lds;
+    int res[4];
+    mefull::mf_me_search_full<T, CoopWave>( &reqs[i], (const int16_t( * )[2])( mvc + (long)i * MF_MVC_MAX * 2 ), n_mvc[i], res, coop );
+    if( ( threadIdx.x & 63 ) == 0 )
+        for( int k = 0; k < 4; k++ )
+            out[4 * i + k] = res[k];
+}
+// one thread per request, for the listed requests (index == nullptr: all)
+template <typename T>
+__global__ __launch_bounds__( 64 ) void me_full_list_kernel( const MfReq<T> *reqs, const int16_t *mvc, const int *n_mvc, const int *index, int n, int *out )
+{
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if( k >= n )
+        return;
+    const int i = index[k];
+    int res[4];
+    mefull::mf_me_search_full<T>( &reqs[i], (const int16_t( * )[2])( mvc + (long)i * MF_MVC_MAX * 2 ), n_mvc[i], res );
+    for( int j = 0; j < 4; j++ )
+        out[4 * i + j] = res[j];
+}
 template <typename T>
 __global__ __launch_bounds__( 64 ) void me_full_kernel( const MfReq<T> *reqs, const int16_t *mvc, const int *n_mvc, int n, int *out )
 {

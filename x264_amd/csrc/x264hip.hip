@@ -1510,7 +1510,7 @@ static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request 
     char *scratch = nullptr;
     MfReq<T> *table_dev = nullptr;
     int16_t *mvc_dev = nullptr;
-    int *n_mvc_dev = nullptr, *out_dev = nullptr;
+    int *n_mvc_dev = nullptr, *out_dev = nullptr, *index_dev = nullptr;
     int rc = X264HIP_OK;
 #define MECK( call ) do { if( ( call ) != hipSuccess ) { rc = X264HIP_ENOMEM; goto done; } } while( 0 )
     if( scratch_total ) MECK( hipMalloc( &scratch, scratch_total ) );
@@ -1544,7 +1544,24 @@ static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request 
     MECK( hipMemcpyAsync( table_dev, table.data(), sizeof( MfReq<T> ) * n, hipMemcpyHostToDevice, ctx->stream ) );
     MECK( hipMemcpyAsync( mvc_dev, mvc.data(), mvc.size() * sizeof( int16_t ), hipMemcpyHostToDevice, ctx->stream ) );
     MECK( hipMemcpyAsync( n_mvc_dev, n_mvc.data(), sizeof( int ) * n, hipMemcpyHostToDevice, ctx->stream ) );
-    me_full_kernel<T><<<( n + 63 ) / 64, 64, 0, ctx->stream>>>( table_dev, mvc_dev, n_mvc_dev, n, out_dev );
+    {
+        // exhaustive requests (ESA, TESA): a wave each; pattern searches (DIA, HEX, UMH): a thread each.  X264HIP_ME_FULL_SCALAR=1
+        // sends everything through the one-thread form (the device reference the cooperative form is checked against)
+        static const bool all_scalar = getenv( "X264HIP_ME_FULL_SCALAR" ) != nullptr;
+        std::vector<int> coop_idx, scalar_idx;
+        for( int i = 0; i < n; i++ )
+            ( reqs[i].me_method >= 3 && !all_scalar ? coop_idx : scalar_idx ).push_back( i );
+        MECK( hipMalloc( &index_dev, sizeof( int ) * n ) );
+        if( !coop_idx.empty() )
+            MECK( hipMemcpyAsync( index_dev, coop_idx.data(), sizeof( int ) * coop_idx.size(), hipMemcpyHostToDevice, ctx->stream ) );
+        if( !scalar_idx.empty() )
+            MECK( hipMemcpyAsync( index_dev + coop_idx.size(), scalar_idx.data(), sizeof( int ) * scalar_idx.size(), hipMemcpyHostToDevice, ctx->stream ) );
+        if( !coop_idx.empty() )
+            me_full_coop_kernel<T><<<(int)coop_idx.size(), 64, 0, ctx->stream>>>( table_dev, mvc_dev, n_mvc_dev, index_dev, (int)coop_idx.size(), out_dev );
+        if( !scalar_idx.empty() )
+            me_full_list_kernel<T><<<( (int)scalar_idx.size() + 63 ) / 64, 64, 0, ctx->stream>>>( table_dev, mvc_dev, n_mvc_dev, index_dev + coop_idx.size(),
+                                                                                                 (int)scalar_idx.size(), out_dev );
+    }
     MECK( hipGetLastError() );
     MECK( hipMemcpyAsync( out, out_dev, sizeof( int ) * 4 * n, hipMemcpyDeviceToHost, ctx->stream ) );
     if( hipStreamSynchronize( ctx->stream ) != hipSuccess ) rc = X264HIP_EDEVICE;
@@ -1555,6 +1572,7 @@ done:
     if( mvc_dev ) (void)hipFree( mvc_dev );
     if( n_mvc_dev ) (void)hipFree( n_mvc_dev );
     if( out_dev ) (void)hipFree( out_dev );
+    if( index_dev ) (void)hipFree( index_dev );
     return rc;
 }
 
