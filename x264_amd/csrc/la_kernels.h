@@ -120,7 +120,7 @@ __device__ __forceinline__ unsigned wave_sum_u32( unsigned v )
 }
 
 template <typename T>
-__global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc single, int width, int height, int mb_w,
+__global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc single, int width, int height, int mb_w, int mb_h,
                                                    float strength, float log2_bias, const AqLuts *luts, int aq_mode, float depth_corr, int chroma_format )
 {
     const PutDesc D = descs ? descs[blockIdx.z] : single;
@@ -129,7 +129,14 @@ __global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc
     uint16_t *inv_qscale = D.inv_qscale;
     uint2 *mb_sums = D.mb_sums;
     float *qp_offset_aq = D.qp_aq, *qp_offset = D.qp;
-    const int mx = blockIdx.x, my = blockIdx.y, lane = lane_id();
+    // XCD-aware placement: workgroup b runs on XCD b % 8 (observed dispatch order, used for locality only), so the macroblocks are
+    // dealt to the XCDs in eight contiguous runs -- the 128-byte lines that horizontally adjacent macroblocks share are then fetched
+    // into ONE L2 instead of eight (the launch is 1-D, a multiple of 8 workgroups per frame)
+    const int lane = lane_id();
+    const int logical = (int)( blockIdx.x & 7 ) * (int)( gridDim.x >> 3 ) + (int)( blockIdx.x >> 3 );
+    if( logical >= mb_w * mb_h )
+        return;
+    const int mx = logical % mb_w, my = logical / mb_w;
     const int ly = lane >> 2, lx = ( lane & 3 ) * 4;
     unsigned s = 0, q = 0;
     {
@@ -367,7 +374,11 @@ __global__ __launch_bounds__( 64 ) void intra_kernel( LaP P, const PutDesc *desc
     uint16_t *intra_cost = D.intra_cost;
     __shared__ IntraEdges E;
     const int lane = lane_id();
-    const int bx = blockIdx.x, by = blockIdx.y;
+    // XCD-aware placement as in aq_kernel: each XCD gets a contiguous run of blocks
+    const int logical = (int)( blockIdx.x & 7 ) * (int)( gridDim.x >> 3 ) + (int)( blockIdx.x >> 3 );
+    if( logical >= P.mb_w * P.mb_h )
+        return;
+    const int bx = logical % P.mb_w, by = logical / P.mb_w;
     const T *src = fenc0 + 8 * ( by * P.stride + bx );
     if( lane < 17 )
         E.top[lane] = src[-P.stride + lane - 1];
