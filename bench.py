@@ -203,7 +203,7 @@ def cpu_baseline(cfg, frames, preset, opts, lookahead_threads=None):
     return dict(value=round(n / dt, 2), unit="frames/s", cores=1, kind="port", sample="%d frames %dx%d, oracle restatement, 1 thread" % (n, cfg["width"], cfg["height"]))
 
 
-def make_clip_device(torch, W, H, F, seed, bit_depth=8, scene_cuts=(), pan=(5, 3), noise=3, texture=0.18):
+def make_clip_device(torch, W, H, F, seed, bit_depth=8, scene_cuts=(), pan=(5, 3), noise=3, texture=0.18, fade=None):
     """The synthetic recipe of x264_amd/synth.py (smooth random field, per-frame pan, +-noise, inversion at scene cuts) generated
     on the device with torch: used for the 4K workload, where the numpy generator would take longer than the benchmark."""
     g = torch.Generator(device="cuda").manual_seed(seed)
@@ -223,6 +223,9 @@ def make_clip_device(torch, W, H, F, seed, bit_depth=8, scene_cuts=(), pan=(5, 3
         img = field[dy:dy + H, dx:dx + W]
         if sum(1 for c in cuts if c <= i) & 1:
             img = 255.0 - img
+        if fade is not None:  # (start, length, gain_end, offset_end): linear fade, held afterwards (exercises weighted prediction)
+            t = min(max((i - fade[0] + 1) / float(fade[1]), 0.0), 1.0)
+            img = img * (1.0 + (fade[2] - 1.0) * t) + fade[3] * t
         img = img + torch.randint(-noise, noise + 1, img.shape, generator=g, device="cuda")
         out[i] = torch.clamp(torch.round(img * scale), 0, maxv).to(out.dtype)
     return out
@@ -314,7 +317,7 @@ def main():
                     help="x264 --threads of the mirrored configuration: > 1 turns on the reference's automatic lookahead bands "
                          "(i_lookahead_threads, encoder.c:1273-1300); 1 = the --threads 1 parity configuration")
     ap.add_argument("--paced", action="store_true", help="encoder-paced put/get instead of the deep-prefetch batch")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=8,
                     help="independent GOP segments in flight per GPU (one host thread + one context each): the decisions of one "
                          "segment overlap the device work of the other")
     ap.add_argument("--shard", default="segments", choices=("segments", "window"),
@@ -364,8 +367,9 @@ def main():
     # every (rank, segment) gets its own part of the synthetic sequence (different seed = different content)
     seg_frames, seg_dev = [], []
     for sgi in range(S):
-        if args.device_clip:
-            dv = make_clip_device(torch, W, H, F, 100 + rank * S + sgi, args.bit_depth, scene_cuts=(F // 3, F // 3 + 47))
+        if args.device_clip or sgi > 0:
+            # only the first segment is generated on the host (the CPU baseline runs on it); the others come from the same recipe on the device
+            dv = make_clip_device(torch, W, H, F, 100 + rank * S + sgi, args.bit_depth, scene_cuts=(F // 3, F // 3 + 47), fade=(2 * F // 3, 10, 0.6, 12))
             fr = None
         else:
             fr = make_clip(W, H, F, seed=100 + rank * S + sgi, bit_depth=args.bit_depth, scene_cuts=(F // 3, F // 3 + 47), fade=(2 * F // 3, 10, 0.6, 12),

@@ -1118,7 +1118,10 @@ struct MbtOpDev
     const unsigned long long *mvq0, *mvq1;
     const float *qp_aq;
     float *qp;
+    int lds_b, lds_p0, lds_p1, pad_; // mbtree_lds_kernel: accumulator slots in LDS
 };
+#define MBT_LDS_LOAD 5   // mbtree_lds_kernel only: global accumulator prop_b -> LDS slot lds_b
+#define MBT_LDS_STORE 6  // LDS slot lds_b -> global accumulator prop_b
 
 __device__ __forceinline__ int prop_read( const int *p )
 {
@@ -1135,7 +1138,7 @@ __device__ __forceinline__ float lut_log2_diff( const AqLuts *luts, unsigned a, 
 }
 
 // one macroblock of a PROPAGATE step: mbtree_propagate_cost + both mbtree_propagate_list scatters
-__device__ __forceinline__ void mbt_propagate_mb( const MbtOpDev &o, int W, int H, int i, int ic, int lc, int inv, int in_cost,
+__device__ __forceinline__ void mbt_propagate_mb( const MbtOpDev &o, int *ref0, int *ref1, int W, int H, int i, int ic, int lc, int inv, int in_cost,
                                                   unsigned w0, unsigned w1 )
 {
     const int mx = i % W, my = i / W;
@@ -1152,7 +1155,7 @@ __device__ __forceinline__ void mbt_propagate_mb( const MbtOpDev &o, int W, int 
     {
         if( list && !o.b_bidir ) break;
         if( !( lists_used & ( 1 << list ) ) ) continue;
-        int *ref = list ? o.prop_p1 : o.prop_p0;
+        int *ref = list ? ref1 : ref0;
         int la = amount;
         if( lists_used == 3 )
             la = ( la * ( list ? 64 - o.bipred_weight : o.bipred_weight ) + 32 ) >> 6;
@@ -1182,7 +1185,7 @@ __device__ __forceinline__ void mbt_propagate_mb( const MbtOpDev &o, int W, int 
 }
 
 #define MBT_UNROLL 4
-#define MBT_WGS 16
+#define MBT_WGS 8
 // All MBT_WGS workgroups walk the same step list; where a step reads what earlier steps accumulated they meet at a
 // counter barrier (monotonic counter, relaxed agent-scope polling, bounded spin).  Everything exchanged between
 // steps lives in the propagate accumulators, which are only touched with agent-scope atomics, so no fences are
@@ -1259,7 +1262,7 @@ __global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *
                 {
                     const int i = base + u * nthreads;
                     if( i < n_mb )
-                        mbt_propagate_mb( o, W, H, i, ic[u], lc[u], inv[u], in_cost[u], w0[u], w1[u] );
+                        mbt_propagate_mb( o, o.prop_p0, o.prop_p1, W, H, i, ic[u], lc[u], inv[u], in_cost[u], w0[u], w1[u] );
                 }
             }
         }
@@ -1283,6 +1286,81 @@ __global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *
     {
         __hip_atomic_store( &bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
         __hip_atomic_store( &bar[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    }
+}
+
+// The same step list walked by ONE workgroup with the accumulators of the frames in play held in LDS (pictures up to ~12 800
+// macroblocks: 1080p and below).  A macroblock_tree() call is a chain of ~25 dependent phases (every mini-GOP: its B-frames, then the
+// anchor that closes it); across 16 workgroups each phase boundary costs a device-wide barrier plus the drain of the L2 atomics
+// (~10 us), several times the work between two boundaries.  Inside one workgroup a boundary is a __syncthreads(), the adds are LDS
+// atomics and the in_cost reads are LDS reads; the inputs (costs, vectors) still stream from memory, eight macroblocks per thread in
+// flight.  The host maps the accumulators of the call onto the LDS slots (least-recently-used; MBT_LDS_LOAD / MBT_LDS_STORE steps
+// move an accumulator in and out) and writes every touched accumulator back at the end, so the global buffers hold what the
+// multi-workgroup kernel would have left there.
+#define MBT_LDS_UNROLL 8
+__global__ __launch_bounds__( 1024 ) void mbtree_lds_kernel( LaP P, const MbtOpDev *ops, int n_ops, const AqLuts *luts )
+{
+    extern __shared__ __attribute__( ( aligned( 16 ) ) ) int mbt_acc[];
+    const int W = P.mb_w, H = P.mb_h, n_mb = W * H;
+    const int tid = threadIdx.x, NT = blockDim.x;
+    for( int k = 0; k < n_ops; k++ )
+    {
+        const MbtOpDev o = ops[k];
+        int *A_b = mbt_acc + o.lds_b * n_mb, *A_p0 = mbt_acc + o.lds_p0 * n_mb, *A_p1 = mbt_acc + o.lds_p1 * n_mb;
+        if( o.type == 0 )
+            for( int i = tid; i < n_mb; i += NT ) A_b[i] = 0;
+        else if( o.type == MBT_LDS_LOAD )
+            for( int i = tid; i < n_mb; i += NT ) A_b[i] = o.prop_b[i];
+        else if( o.type == MBT_LDS_STORE )
+            for( int i = tid; i < n_mb; i += NT ) o.prop_b[i] = A_b[i];
+        else if( o.type == 1 )
+        {
+            for( int base = tid; base < n_mb; base += NT * MBT_LDS_UNROLL )
+            {
+                int ic[MBT_LDS_UNROLL], lc[MBT_LDS_UNROLL], inv[MBT_LDS_UNROLL];
+                unsigned w0[MBT_LDS_UNROLL], w1[MBT_LDS_UNROLL];
+#pragma unroll
+                for( int u = 0; u < MBT_LDS_UNROLL; u++ )
+                {
+                    const int i = base + u * NT;
+                    const int ii = i < n_mb ? i : 0;
+                    ic[u] = o.intra_cost[ii]; lc[u] = o.lowres_costs[ii]; inv[u] = o.inv_qscale[ii];
+                    w0[u] = (unsigned)o.mvq0[ii];
+                    w1[u] = o.b_bidir ? (unsigned)o.mvq1[ii] : 0u;
+                }
+#pragma unroll
+                for( int u = 0; u < MBT_LDS_UNROLL; u++ )
+                {
+                    const int i = base + u * NT;
+                    if( i < n_mb )
+                    {
+                        int in_cost = 0;
+                        if( o.referenced )
+                        {
+                            in_cost = A_b[i];
+                            in_cost = in_cost < 32767 ? in_cost : 32767;
+                        }
+                        mbt_propagate_mb( o, A_p0, A_p1, W, H, i, ic[u], lc[u], inv[u], in_cost, w0[u], w1[u] );
+                    }
+                }
+            }
+        }
+        else
+        {
+            for( int i = tid; i < n_mb; i += NT )
+            {
+                const int ic = ( (int)o.intra_cost[i] * (int)o.inv_qscale[i] + 128 ) >> 8;
+                if( ic )
+                {
+                    int pr = A_b[i];
+                    pr = pr < 32767 ? pr : 32767;
+                    const int pc = ( pr * o.fps_factor_i + 128 ) >> 8;
+                    const float ratio = lut_log2_diff( luts, (unsigned)( ic + pc ), (unsigned)ic, o.weightdelta );
+                    o.qp[i] = __fsub_rn( o.qp_aq[i], __fmul_rn( o.strength, ratio ) );
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 

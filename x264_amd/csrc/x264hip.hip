@@ -1146,20 +1146,103 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
     // inputs come from the main stream (cells, clamp kernels): order the MB-tree stream behind it
     HIPCK( hipEventRecord( ctx->ev_cross, ctx->stream ) );
     HIPCK( hipStreamWaitEvent( ctx->stream2, ctx->ev_cross, 0 ) );
-    (void)n_host;
-    if( n > 0 )
+    // One workgroup with the accumulators in LDS when at least three of them fit (three are in play in a mini-GOP with a
+    // B-reference: the two anchors and the middle frame); larger pictures use the multi-workgroup kernel below
+    static const bool no_lds = getenv( "X264HIP_MBT_LDS" ) == nullptr; // measured slower than the multi-workgroup kernel: opt-in for experiments
+    const int lds_slots = std::min( 6, (int)( ( 156 * 1024 ) / ( (size_t)ctx->n_mb * sizeof( int ) ) ) );
+    bool done_in_lds = false;
+    if( n > 0 && !no_lds && lds_slots >= 3 )
+    {
+        // steps in the caller's order; accumulators (identified by their global buffer) mapped onto LDS slots, least recently used out
+        std::vector<MbtOpDev> L;
+        std::vector<int *> held( lds_slots, nullptr );
+        std::vector<int> stamp( lds_slots, 0 );
+        int clock = 0;
+        auto find = [&]( int *acc ) { for( int k = 0; k < lds_slots; k++ ) if( held[k] == acc ) return k; return -1; };
+        auto move_op = [&]( int type, int *acc, int slot ) {
+            MbtOpDev d;
+            memset( &d, 0, sizeof( d ) );
+            d.type = type; d.prop_b = acc; d.lds_b = slot;
+            L.push_back( d );
+        };
+        // make acc resident (pinned = slots that must stay); load = its current global contents matter
+        auto hold = [&]( int *acc, bool load, int pin0, int pin1 ) {
+            int k = find( acc );
+            if( k < 0 )
+            {
+                // a free slot if there is one, else the slot used longest ago; never one this step still needs
+                for( int c = 0; c < lds_slots && k < 0; c++ )
+                    if( !held[c] && c != pin0 && c != pin1 ) k = c;
+                for( int c = 0; c < lds_slots && !( k >= 0 && !held[k] ); c++ )
+                    if( held[c] && c != pin0 && c != pin1 && ( k < 0 || stamp[c] < stamp[k] ) ) k = c;
+                if( held[k] ) move_op( MBT_LDS_STORE, held[k], k );
+                held[k] = acc;
+                if( load ) move_op( MBT_LDS_LOAD, acc, k );
+            }
+            stamp[k] = ++clock;
+            return k;
+        };
+        for( int q = 0; q < n_host; q++ )
+        {
+            const x264hip_mbtree_op &o = ops[q];
+            if( o.type != X264HIP_MBT_ZERO && o.type != X264HIP_MBT_PROPAGATE && o.type != X264HIP_MBT_FINISH ) continue;
+            FrameSlot &b = ctx->slots[o.slot_b];
+            MbtOpDev d;
+            memset( &d, 0, sizeof( d ) );
+            d.type = o.type; d.referenced = o.referenced; d.bipred_weight = o.bipred_weight; d.fps_factor_i = o.fps_factor_i;
+            d.fps_factor = o.fps_factor; d.weightdelta = o.weightdelta; d.strength = o.strength;
+            d.b_bidir = o.dist_p1 > 0;
+            d.prop_b = res_b[q]; d.prop_p0 = res_p0[q]; d.prop_p1 = res_p1[q];
+            d.intra_cost = b.lowres_costs; d.inv_qscale = b.inv_qscale;
+            d.lowres_costs = b.lowres_costs + (size_t)( o.dist_p0 * nstride + o.dist_p1 ) * ctx->n_mb;
+            d.qp_aq = b.qp_aq; d.qp = b.qp;
+            if( o.type == X264HIP_MBT_ZERO )
+                d.lds_b = hold( res_b[q], false, -1, -1 );
+            else if( o.type == X264HIP_MBT_FINISH )
+                d.lds_b = hold( res_b[q], true, -1, -1 );
+            else
+            {
+                d.mvq0 = b.mvq[0][o.dist_p0 - 1];
+                d.mvq1 = o.dist_p1 > 0 ? b.mvq[1][o.dist_p1 - 1] : nullptr;
+                int kb = -1;
+                if( o.referenced ) kb = hold( res_b[q], true, -1, -1 ); // its own total is read; an unreferenced B-frame has none
+                const int k0 = hold( res_p0[q], true, kb, -1 );
+                const int k1 = d.b_bidir ? hold( res_p1[q], true, kb, k0 ) : k0;
+                d.lds_b = kb < 0 ? 0 : kb; d.lds_p0 = k0; d.lds_p1 = k1;
+            }
+            L.push_back( d );
+        }
+        for( int k = 0; k < lds_slots; k++ )
+            if( held[k] ) move_op( MBT_LDS_STORE, held[k], k );
+        if( (int)L.size() <= x264hip_ctx::MBT_CAP )
+        {
+            memcpy( dh, L.data(), L.size() * sizeof( MbtOpDev ) );
+            static bool attr_set = false;
+            if( !attr_set )
+            {
+                HIPCK( hipFuncSetAttribute( (const void *)mbtree_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 ) );
+                attr_set = true;
+            }
+            HIPCK( hipMemcpyAsync( ctx->mbt_dev[r], dh, L.size() * sizeof( MbtOpDev ), hipMemcpyHostToDevice, ctx->stream2 ) );
+            mbtree_lds_kernel<<<1, 1024, (size_t)lds_slots * ctx->n_mb * sizeof( int ), ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], (int)L.size(), ctx->luts_dev );
+            HIPCK( hipGetLastError() );
+            done_in_lds = true;
+        }
+    }
+    if( n > 0 && !done_in_lds )
     {
     const size_t table_bytes = (size_t)n * sizeof( MbtOpDev );
     // Measured (two segments in flight, 1080p): copying the step list to the device in front of the call gives 8500 frames/s,
     // letting every workgroup pull it from pinned host memory into LDS 8070 -- sixteen PCIe read bursts per call cost more
     // than one small copy.  The staging path stays available for experiments.
     static const bool stage_lds = getenv( "X264HIP_MBT_STAGE_LDS" ) != nullptr;
+    static const int mbt_wgs = getenv( "X264HIP_MBT_WGS" ) ? std::max( 1, std::min( 64, atoi( getenv( "X264HIP_MBT_WGS" ) ) ) ) : MBT_WGS;
     if( table_bytes <= 48 * 1024 && stage_lds )
-        mbtree_kernel<<<MBT_WGS, 1024, table_bytes, ctx->stream2>>>( ctx->P, dh, n, 1, ctx->luts_dev, ctx->mbt_bar + 4 * r );
+        mbtree_kernel<<<mbt_wgs, 1024, table_bytes, ctx->stream2>>>( ctx->P, dh, n, 1, ctx->luts_dev, ctx->mbt_bar + 4 * r );
     else
     {
         HIPCK( hipMemcpyAsync( ctx->mbt_dev[r], dh, table_bytes, hipMemcpyHostToDevice, ctx->stream2 ) );
-        mbtree_kernel<<<MBT_WGS, 1024, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], n, 0, ctx->luts_dev, ctx->mbt_bar + 4 * r );
+        mbtree_kernel<<<mbt_wgs, 1024, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], n, 0, ctx->luts_dev, ctx->mbt_bar + 4 * r );
     }
     HIPCK( hipGetLastError() );
     }
