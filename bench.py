@@ -412,6 +412,16 @@ def main():
     # ---- what was timed is what the reference would decide: one untimed pass of every segment in the other batching mode
     # (encoder-paced when the timed passes were deep-prefetch batches and vice versa) must give the same frame types and the
     # same cost cells, frame for frame; its wall time is the figure of the other mode.
+    # the search kernel alone: one context, nothing else in flight (what the rocprofv3 counter passes in profiles/ measure as well);
+    # in the timed region several contexts launch concurrently, which stretches every launch
+    solo = None
+    if S > 1 and not args.no_check:
+        lib.search_profile(las[0].L, las[0].ctx_handle(), 1)
+        las[0].reset()
+        las[0].run(device_ptrs=wl.seg_ptrs[0], stride=W, paced=args.paced)
+        ms_, nl_, ns_ = lib.search_profile(las[0].L, las[0].ctx_handle(), 0)
+        if ms_ > 0 and ns_:
+            solo = (ms_, nl_, ns_)
     other_paced = not args.paced
     other_fps = None
     if not args.no_check:
@@ -474,10 +484,15 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "me_rows_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
                          "launches": prof_launches, "searches": prof_searches, "avg_launch_ms": round(prof_ms / max(prof_launches, 1), 4),
-                         "us_per_search": round(prof_ms * 1e3 / max(prof_searches, 1), 3),
+                         "us_per_search": round(prof_ms * 1e3 / max(prof_searches, 1), 3), "contexts_launching_concurrently": S,
+                         "solo": None if solo is None else {
+                             "what": "one untimed pass of one segment alone on the GPU (no concurrent launches), HIP events on the library's stream",
+                             "launches": solo[1], "searches": solo[2], "avg_launch_ms": round(solo[0] / solo[1], 4), "us_per_search": round(solo[0] * 1e3 / solo[2], 3),
+                             "achieved": round(solo[2] * bytes_per_search / 1e9 / (solo[0] / 1e3), 2),
+                             "frac": round(solo[2] * bytes_per_search / 1e9 / (solo[0] / 1e3) / HBM_PEAK_GBS, 5)},
                          "algorithmic_bytes_per_search": bytes_per_search,
-                         "note": "not a streaming kernel (dependent candidate rounds per block): HBM traffic is below the algorithmic bytes; the "
-                                 "ceiling that binds and its counters are in profiles/ (DESIGN.md section 3)"},
+                         "note": "not a streaming kernel: bound by the latency of the dependent candidate rounds of a block search (DESIGN.md section 3); "
+                                 "the counters are in profiles/r02_search_pmc.json"},
             "lookahead_stats": {"frame_cost_calls": int(la_stats[0]), "evaluations": int(la_stats[1]),
                                 "weights_analysed": int(la_stats[2]), "weights_kept": int(la_stats[3]),
                                 "device": {"searches": int(dev_counters[0]), "cell_requests": int(dev_counters[1]), "cell_hits": int(dev_counters[4]),
@@ -489,7 +504,8 @@ def main():
         ipath = os.path.join(ROOT, "profiles", "search_issue.json")
         if os.path.exists(ipath):
             try:
-                res["roofline_issue"] = issue_roofline(json.load(open(ipath)), prof_ms, prof_searches, cfg)
+                pm, ps = (solo[0], solo[2]) if solo is not None else (prof_ms, prof_searches)
+                res["roofline_issue"] = issue_roofline(json.load(open(ipath)), pm, ps, cfg)
             except Exception as e:  # pragma: no cover
                 res["roofline_issue"] = {"error": str(e)}
         if window is not None:
@@ -595,7 +611,10 @@ def issue_roofline(prof, prof_ms, prof_searches, cfg):
     achieved = prof_searches * blocks * valu / (prof_ms / 1e3) if prof_ms > 0 else 0.0
     peak = 1024 * 2.4e9 / 2
     return {"bound": "valu-issue", "kernel": "me_rows_kernel", "achieved": round(achieved / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-instr/s",
-            "frac": round(achieved / peak, 4), "valu_per_block": valu, "source": prof.get("source")}
+            "frac": round(achieved / peak, 4), "valu_per_block": valu, "source": prof.get("source"),
+            "note": "second ceiling: vector issue slots.  Neither this nor HBM binds: the kernel is bound by the latency of its dependent candidate rounds "
+                    "(waves parked on s_waitcnt %.0f %% of their lifetime, profiles/r02_search_pmc.json; cycles per step in profiles/r02_search_cycle_breakdown.txt)"
+                    % (100 * prof.get("wait_any_share_of_wave_cycles", 0))}
 
 
 if __name__ == "__main__":
