@@ -120,6 +120,7 @@ __device__ __forceinline__ unsigned wave_sum_u32( unsigned v )
 }
 
 template <typename T>
+#define AQ_MBS_PER_WG 8
 __global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc single, int width, int height, int mb_w, int mb_h,
                                                    float strength, float log2_bias, const AqLuts *luts, int aq_mode, float depth_corr, int chroma_format )
 {
@@ -132,12 +133,16 @@ __global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc
     // XCD-aware placement: workgroup b runs on XCD b % 8 (observed dispatch order, used for locality only), so the macroblocks are
     // dealt to the XCDs in eight contiguous runs -- the 128-byte lines that horizontally adjacent macroblocks share are then fetched
     // into ONE L2 instead of eight (the launch is 1-D, a multiple of 8 workgroups per frame)
+    // one-wave workgroups, AQ_MBS_PER_WG macroblocks one after the other (a workgroup per macroblock is dispatch-bound)
     const int lane = lane_id();
-    const int logical = (int)( blockIdx.x & 7 ) * (int)( gridDim.x >> 3 ) + (int)( blockIdx.x >> 3 );
-    if( logical >= mb_w * mb_h )
-        return;
-    const int mx = logical % mb_w, my = logical / mb_w;
+    const int wg = (int)( blockIdx.x & 7 ) * (int)( gridDim.x >> 3 ) + (int)( blockIdx.x >> 3 );
     const int ly = lane >> 2, lx = ( lane & 3 ) * 4;
+    for( int it = 0; it < AQ_MBS_PER_WG; it++ )
+    {
+    const int logical = wg * AQ_MBS_PER_WG + it;
+    if( logical >= mb_w * mb_h )
+        return; // wave-uniform
+    const int mx = logical % mb_w, my = logical / mb_w;
     unsigned s = 0, q = 0;
     {
         const T *row = luma + (size_t)imin2( 16 * my + ly, height - 1 ) * stride;
@@ -187,7 +192,7 @@ __global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc
             qp_offset_aq[my * mb_w + mx] = r4;
             qp_offset[my * mb_w + mx] = sqrtf( r4 ); // sqrtf: correctly rounded (the __fsqrt_rn intrinsic is the 1-ulp native one)
             inv_qscale[my * mb_w + mx] = 256;
-            return;
+            continue;
         }
         if( aq_on )
         {
@@ -202,6 +207,7 @@ __global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc
         inv_qscale[my * mb_w + mx] = (uint16_t)out;
         qp_offset_aq[my * mb_w + mx] = qp_adj; // f_qp_offset_aq = f_qp_offset = qp_adj (ratecontrol.c:392-396)
         qp_offset[my * mb_w + mx] = qp_adj;
+    }
     }
 }
 
@@ -366,6 +372,11 @@ __device__ __forceinline__ int intra_pred_px( const IntraEdges &E, int mode, int
 #undef LL
 }
 
+// One-wave workgroups, every wave walks INTRA_BLOCKS_PER_WG consecutive blocks (a workgroup per block made the launch
+// dispatch-bound: 1.3 M workgroups for 160 frames of 1080p -- 28 -> 13 us per frame alone).  The workgroups stay one wave wide on
+// purpose: beside the search kernel, whose waves fill the register files, a single free wave slot is all such a workgroup needs
+// (four-wave workgroups measured 5 % slower end to end with eight contexts in flight).
+#define INTRA_BLOCKS_PER_WG 8
 template <typename T>
 __global__ __launch_bounds__( 64 ) void intra_kernel( LaP P, const PutDesc *descs, PutDesc single )
 {
@@ -374,55 +385,61 @@ __global__ __launch_bounds__( 64 ) void intra_kernel( LaP P, const PutDesc *desc
     uint16_t *intra_cost = D.intra_cost;
     __shared__ IntraEdges E;
     const int lane = lane_id();
-    // XCD-aware placement as in aq_kernel: each XCD gets a contiguous run of blocks
-    const int logical = (int)( blockIdx.x & 7 ) * (int)( gridDim.x >> 3 ) + (int)( blockIdx.x >> 3 );
-    if( logical >= P.mb_w * P.mb_h )
-        return;
-    const int bx = logical % P.mb_w, by = logical / P.mb_w;
-    const T *src = fenc0 + 8 * ( by * P.stride + bx );
-    if( lane < 17 )
-        E.top[lane] = src[-P.stride + lane - 1];
-    else if( lane >= 32 && lane < 40 )
-        E.left[lane - 32] = src[( lane - 32 ) * P.stride - 1];
-    __syncthreads();
-    if( lane < 17 )
-    {
-        // ft[lane] = p'[lane-1,-1]: corner, t0..t15 (predict.c:632-675 with all neighbours available)
-        int i = lane - 1, v;
-        if( i < 0 ) v = f3( E.top[1], E.top[0], E.left[0] );
-        else if( i == 15 ) v = ( E.top[15] + 3 * E.top[16] + 2 ) >> 2;
-        else v = f3( E.top[i], E.top[i + 1], E.top[i + 2] );
-        E.ft[lane] = v;
-    }
-    else if( lane >= 32 && lane < 40 )
-    {
-        int y = lane - 32, v;
-        if( y == 7 ) v = ( E.left[6] + 3 * E.left[7] + 2 ) >> 2;
-        else v = f3( y == 0 ? E.top[0] : E.left[y - 1], E.left[y], E.left[y + 1] );
-        E.fl[y] = v;
-    }
-    __syncthreads();
+    // XCD-aware placement as in aq_kernel: each XCD gets a contiguous run of workgroups (INTRA_BLOCKS_PER_WG consecutive blocks each)
+    const int n_blocks = P.mb_w * P.mb_h;
+    const int wg = (int)( blockIdx.x & 7 ) * (int)( gridDim.x >> 3 ) + (int)( blockIdx.x >> 3 );
     const int g = lane >> 4, l = lane & 15, q = l >> 2;
     const int tx = ( q & 1 ) * 4, row = ( q >> 1 ) * 4 + ( l & 3 );
-    const Px4 f = load_px4( src + row * P.stride + tx );
-    int best = COST_MAX_I;
     const int n_modes = P.subme > 1 ? 10 : 3;
-    for( int m0 = 0; m0 < n_modes; m0 += 4 )
+    for( int it = 0; it < INTRA_BLOCKS_PER_WG; it++ )
     {
-        const int mode = imin2( m0 + g, 9 );
-        int pr[4];
+        const int logical = wg * INTRA_BLOCKS_PER_WG + it;
+        const bool live = logical < n_blocks;
+        const int lg = live ? logical : n_blocks - 1; // dead trips redo the last block and write nothing
+        const int bx = lg % P.mb_w, by = lg / P.mb_w;
+        const T *src = fenc0 + 8 * ( by * P.stride + bx );
+        if( lane < 17 )
+            E.top[lane] = src[-P.stride + lane - 1];
+        else if( lane >= 32 && lane < 40 )
+            E.left[lane - 32] = src[( lane - 32 ) * P.stride - 1];
+        __syncthreads();
+        if( lane < 17 )
+        {
+            // ft[lane] = p'[lane-1,-1]: corner, t0..t15 (predict.c:632-675 with all neighbours available)
+            int i = lane - 1, v;
+            if( i < 0 ) v = f3( E.top[1], E.top[0], E.left[0] );
+            else if( i == 15 ) v = ( E.top[15] + 3 * E.top[16] + 2 ) >> 2;
+            else v = f3( E.top[i], E.top[i + 1], E.top[i + 2] );
+            E.ft[lane] = v;
+        }
+        else if( lane >= 32 && lane < 40 )
+        {
+            int y = lane - 32, v;
+            if( y == 7 ) v = ( E.left[6] + 3 * E.left[7] + 2 ) >> 2;
+            else v = f3( y == 0 ? E.top[0] : E.left[y - 1], E.left[y], E.left[y + 1] );
+            E.fl[y] = v;
+        }
+        __syncthreads();
+        const Px4 f = load_px4( src + row * P.stride + tx );
+        int best = COST_MAX_I;
+        for( int m0 = 0; m0 < n_modes; m0 += 4 )
+        {
+            const int mode = imin2( m0 + g, 9 );
+            int pr[4];
 #pragma unroll
-        for( int i = 0; i < 4; i++ )
-            pr[i] = intra_pred_px( E, mode, tx + i, row, P.pixel_max );
-        const Px4 r = px4_from_ints( pr, false );
-        int v = P.mbcmp_satd ? reduce16( satd_partial_px4( f, r ) ) >> 1 : reduce16( sad_partial16( f, r ) );
+            for( int i = 0; i < 4; i++ )
+                pr[i] = intra_pred_px( E, mode, tx + i, row, P.pixel_max );
+            const Px4 r = px4_from_ints( pr, false );
+            int v = P.mbcmp_satd ? reduce16( satd_partial_px4( f, r ) ) >> 1 : reduce16( sad_partial16( f, r ) );
 #pragma unroll
-        for( int k = 0; k < 4; k++ )
-            if( m0 + k < n_modes )
-                best = imin2( best, __builtin_amdgcn_readlane( v, 16 * k ) );
+            for( int k = 0; k < 4; k++ )
+                if( m0 + k < n_modes )
+                    best = imin2( best, __builtin_amdgcn_readlane( v, 16 * k ) );
+        }
+        if( lane == 0 && live )
+            intra_cost[by * P.mb_w + bx] = (uint16_t)( ( ( best + 5 * P.lambda ) >> P.depth_shift ) + 4 );
+        __syncthreads(); // the edges are rewritten by the next trip
     }
-    if( lane == 0 )
-        intra_cost[by * P.mb_w + bx] = (uint16_t)( ( ( best + 5 * P.lambda ) >> P.depth_shift ) + 4 );
 }
 
 // ---- explicit weights: weighted copy of padded plane 0 (slicetype.c:490-500, mc.c:117-160) -------------

@@ -464,13 +464,14 @@ static int launch_ingest_t( x264hip_ctx *ctx, const PutDesc *descs_dev, const Pu
     const float bias = 14.427f + 2 * ( p.bit_depth - 8 );
     dim3 grd( ( ( ctx->lw + 2 * LA_PAD ) / 4 + 255 ) / 256, ctx->lh + 2 * LA_PAD, n );
     lowres_kernel<T><<<grd, 256, 0, ctx->stream>>>( descs_dev, single, p.width, p.height, P.plane_elems, P.stride, ctx->lw, ctx->lh );
-    const int wg_per_frame = ( ctx->n_mb + 7 ) / 8 * 8; // a multiple of 8: the kernels deal contiguous runs of macroblocks to the 8 XCDs
+    const int wg_per_frame = ( ( ctx->n_mb + AQ_MBS_PER_WG - 1 ) / AQ_MBS_PER_WG + 7 ) / 8 * 8; // a multiple of 8: contiguous runs of macroblocks per XCD
     aq_kernel<T><<<dim3( wg_per_frame, 1, n ), 64, 0, ctx->stream>>>( descs_dev, single, p.width, p.height, P.mb_w, P.mb_h, strength, bias, ctx->luts_dev,
                                                                        p.aq_mode, 1.f / ( 1 << ( 2 * ( p.bit_depth - 8 ) ) ), p.chroma_format );
     if( p.aq_mode >= 2 && p.aq_strength != 0.f )
         aq_auto_kernel<<<n, 1024, 0, ctx->stream>>>( descs_dev, single, ctx->n_mb, p.aq_mode, p.aq_strength, ctx->luts_dev );
     aq_reduce_kernel<<<n, 1024, 0, ctx->stream>>>( descs_dev, single, ctx->n_mb );
-    intra_kernel<T><<<dim3( wg_per_frame, 1, n ), 64, 0, ctx->stream>>>( P, descs_dev, single );
+    const int intra_wgs = ( ( ctx->n_mb + INTRA_BLOCKS_PER_WG - 1 ) / INTRA_BLOCKS_PER_WG + 7 ) / 8 * 8;
+    intra_kernel<T><<<dim3( intra_wgs, 1, n ), 64, 0, ctx->stream>>>( P, descs_dev, single );
     HIPCK( hipGetLastError() );
     HIPCK( hipEventRecord( ctx->ev_ingest, ctx->stream ) );
     return X264HIP_OK;
