@@ -863,7 +863,7 @@ static int launch_cells_t( x264hip_ctx *ctx, const std::vector<SpecCell> &cells 
             cell_p_kernel<<<dim3( ( ctx->n_mb + 255 ) / 256, n_p ), 256, 0, ctx->stream>>>( P, dd, none );
         if( n_b )
             cell_b_kernel<T><<<dim3( ( P.mb_w + CELLB_BPW - 1 ) / CELLB_BPW, P.mb_h, n_b ), 64, 0, ctx->stream>>>( P, dd + n_p, none );
-        cell_reduce_kernel<<<n, 1024, 0, ctx->stream>>>( P, dd, none ); // sums go straight to pinned host memory
+        cell_reduce_kernel<<<n, 1024, 0, ctx->stream>>>( P, dd, none ); // sums go straight to pinned host memory (256 ... 1024 threads: no difference end to end)
         HIPCK( hipGetLastError() );
         if( ring_commit( ctx->cell_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
     }
