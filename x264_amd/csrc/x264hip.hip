@@ -19,6 +19,7 @@
 #include "x264hip.h"
 #include "device_common.h"
 #include "me_search.h"
+#include "me_search_wg.h"
 #include "la_kernels.h"
 #include "block_metrics.h"
 #include "dct_quant_block.h"
@@ -121,6 +122,7 @@ struct x264hip_ctx
     int mbt_next = 0, mbt_pending = 0;
     unsigned *mbt_bar = nullptr;      // device [MBT_RING][4]: barrier arrivals, error, exits, unused
     int desc_cap = 0;
+    int me_wg = 1;                   // searches on unweighted 8-bit planes run the shared-window workgroup kernel (X264HIP_ME_WG=0: never)
     // weight costs: WCAP job entries, each with device counters [2][2] and a pinned result pair; entry 0 serves the
     // on-demand call, the others hold speculative pairs (x264hip_prefetch_weight_costs) until their frames go away
     static const int WCAP = 1024;
@@ -329,8 +331,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         OPENCK( hipMalloc( &ctx->luts_dev, sizeof( AqLuts ) ) );
         OPENCK( hipMemcpy( ctx->luts_dev, &l, sizeof( l ), hipMemcpyHostToDevice ) );
     }
-    OPENCK( hipMalloc( &ctx->sync_words, ME_QUEUES * ME_QUEUE_STRIDE * sizeof( unsigned ) ) ); // row tickets of the search kernel
-    OPENCK( hipMemset( ctx->sync_words, 0, ME_QUEUES * ME_QUEUE_STRIDE * sizeof( unsigned ) ) );
+    OPENCK( hipMalloc( &ctx->sync_words, 2 * ME_QUEUES * ME_QUEUE_STRIDE * sizeof( unsigned ) ) ); // row tickets of the two search kernels
+    OPENCK( hipMemset( ctx->sync_words, 0, 2 * ME_QUEUES * ME_QUEUE_STRIDE * sizeof( unsigned ) ) );
 #ifdef ME_PROFILE
     OPENCK( hipMalloc( &ctx->me_prof, 8 * sizeof( unsigned long long ) ) );
     OPENCK( hipMemset( ctx->me_prof, 0, 8 * sizeof( unsigned long long ) ) );
@@ -364,7 +366,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( ring_alloc( ctx->wjob_ring, (size_t)x264hip_ctx::WCAP * sizeof( WeightJob ) ) );
     ctx->wcache.assign( x264hip_ctx::WCAP, x264hip_ctx::WEntry() );
     ctx->desc_cap = 2 * ( p.bframes + 1 ) * p.max_frames + 16;
-    OPENCK( ring_alloc( ctx->search_ring, (size_t)ctx->desc_cap * sizeof( SearchDesc<uint8_t> ) ) );
+    if( const char *e = getenv( "X264HIP_ME_WG" ) ) ctx->me_wg = atoi( e ) != 0;
+    OPENCK( ring_alloc( ctx->search_ring, (size_t)ctx->desc_cap * ( sizeof( SearchDesc<uint8_t> ) + sizeof( RefGroup ) ) ) );
     ctx->staging_bytes = (size_t)p.width * p.height * ctx->psz;
     OPENCK( hipHostMalloc( &ctx->staging, ctx->staging_bytes ) );
 
@@ -710,9 +713,23 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
     int rc = 0, ri = 0;
     if( ring_acquire( ctx->search_ring, &ri ) ) return X264HIP_EDEVICE;
     SearchDesc<T> *dh = (SearchDesc<T> *)ctx->search_ring.host[ri], *dd = (SearchDesc<T> *)ctx->search_ring.dev[ri];
+    RefGroup *gh = (RefGroup *)( dh + ctx->desc_cap ), *gd = (RefGroup *)( dd + ctx->desc_cap );
+    // 8-bit searches on the unweighted planes go to the workgroup kernel (me_search_wg.h), grouped by the frame they read; the
+    // table holds them first, in request (= frame) order, and the weighted / high-bit-depth ones after them
+    std::vector<int> order( n );
+    int n_wg = 0;
+    if( sizeof( T ) == 1 && ctx->me_wg )
+    {
+        for( int i = 0; i < n; i++ )
+            if( !reqs[i].wt.on ) order[n_wg++] = i;
+        for( int i = 0, k = n_wg; i < n; i++ )
+            if( reqs[i].wt.on ) order[k++] = i;
+    }
+    else
+        for( int i = 0; i < n; i++ ) order[i] = i;
     for( int i = 0; i < n; i++ )
     {
-        const SearchReq &r = reqs[i];
+        const SearchReq &r = reqs[order[i]];
         FrameSlot &b = ctx->slots[r.slot_b], &rf = ctx->slots[r.slot_ref];
         SearchDesc<T> d;
         d.fenc0 = plane_origin<T>( ctx, b, 0 );
@@ -735,8 +752,31 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         d.pad = 0;
         dh[i] = d;
     }
+    // reference groups: the searches of one frame, MEW_WAVES at a time, in the order the frames first appear as a reference
+    int n_groups = 0;
+    if( n_wg )
+    {
+        std::vector<char> taken( n_wg, 0 );
+        for( int i = 0; i < n_wg; i++ )
+        {
+            if( taken[i] ) continue;
+            const int ref = reqs[order[i]].slot_ref;
+            RefGroup g; g.n = 0;
+            for( int k = i; k < n_wg; k++ )
+                if( !taken[k] && reqs[order[k]].slot_ref == ref )
+                {
+                    if( g.n == MEW_WAVES ) { gh[n_groups++] = g; g.n = 0; }
+                    g.search[g.n++] = k;
+                    taken[k] = 1;
+                }
+            for( int k = g.n; k < MEW_WAVES; k++ ) g.search[k] = g.search[0];
+            gh[n_groups++] = g;
+        }
+    }
     HIPCK( hipMemcpyAsync( dd, dh, (size_t)n * sizeof( SearchDesc<T> ), hipMemcpyHostToDevice, ctx->stream ) );
-    HIPCK( hipMemsetAsync( ctx->sync_words, 0, ME_QUEUES * ME_QUEUE_STRIDE * sizeof( unsigned ), ctx->stream ) ); // row tickets
+    if( n_groups )
+        HIPCK( hipMemcpyAsync( gd, gh, (size_t)n_groups * sizeof( RefGroup ), hipMemcpyHostToDevice, ctx->stream ) );
+    HIPCK( hipMemsetAsync( ctx->sync_words, 0, 2 * ME_QUEUES * ME_QUEUE_STRIDE * sizeof( unsigned ), ctx->stream ) ); // row tickets
     hipEvent_t e0 = ctx->ev_start, e1 = ctx->ev_stop;
     if( ctx->prof_on )
     {
@@ -750,27 +790,52 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         ctx->prof_used += 2;
     }
     HIPCK( hipEventRecord( e0, ctx->stream ) );
-    MeQueues Q;
-    for( int q = 0; q <= ME_QUEUES; q++ )
-        Q.base[q] = (int)( (long long)n * q / ME_QUEUES ); // contiguous groups: the request list is in frame order
     {
-        // one wave per (search, group of ME_ROWS block rows); the kernel is specialised on the search pattern and the sub-pel depth
-        const int n_waves = n * ( ( P.mb_h + ME_ROWS - 1 ) / ME_ROWS );
+        const int n_rowgroups = ( P.mb_h + ME_ROWS - 1 ) / ME_ROWS;
         const bool hex = P.me_method == X264HIP_ME_HEX, r4 = P.subpel_refine >= 3;
         const int mode = !r4 && !P.mbcmp_satd && !P.fpelcmp_satd ? 0 : r4 && P.mbcmp_satd ? ( P.fpelcmp_satd ? 2 : 1 ) : 3;
-#define ME_LAUNCH( HEXV, MODEV ) me_rows_kernel<T, HEXV, MODEV><<<n_waves, 64, 0, ctx->stream>>>( P, dd, Q, ctx->sync_words, ctx->err_host, 1u << 22, ctx->me_prof )
-        switch( 4 * hex + mode )
+        const int n_rest = n - n_wg;
+        static const int dyn_lds = getenv( "X264HIP_ME_DYN_LDS" ) ? atoi( getenv( "X264HIP_ME_DYN_LDS" ) ) : 0; // EXPERIMENT
+        MeQueues Q;
+        if( n_groups )
         {
-            case 0: ME_LAUNCH( 0, 0 ); break;
-            case 1: ME_LAUNCH( 0, 1 ); break;
-            case 2: ME_LAUNCH( 0, 2 ); break;
-            case 3: ME_LAUNCH( 0, 3 ); break;
-            case 4: ME_LAUNCH( 1, 0 ); break;
-            case 5: ME_LAUNCH( 1, 1 ); break;
-            case 6: ME_LAUNCH( 1, 2 ); break;
-            default: ME_LAUNCH( 1, 3 ); break;
-        }
+            // one workgroup per (reference group, group of ME_ROWS block rows)
+            for( int q = 0; q <= ME_QUEUES; q++ )
+                Q.base[q] = (int)( (long long)n_groups * q / ME_QUEUES );
+#define ME_LAUNCH( HEXV, MODEV ) me_rows_wg_kernel<HEXV, MODEV><<<n_groups * n_rowgroups, 64 * MEW_WAVES, dyn_lds, ctx->stream>>>( \
+            P, (const SearchDesc<uint8_t> *)dd, gd, Q, ctx->sync_words + ME_QUEUES * ME_QUEUE_STRIDE, ctx->err_host, 1u << 22, ctx->me_prof )
+            switch( 4 * hex + mode )
+            {
+                case 0: ME_LAUNCH( 0, 0 ); break;
+                case 1: ME_LAUNCH( 0, 1 ); break;
+                case 2: ME_LAUNCH( 0, 2 ); break;
+                case 3: ME_LAUNCH( 0, 3 ); break;
+                case 4: ME_LAUNCH( 1, 0 ); break;
+                case 5: ME_LAUNCH( 1, 1 ); break;
+                case 6: ME_LAUNCH( 1, 2 ); break;
+                default: ME_LAUNCH( 1, 3 ); break;
+            }
 #undef ME_LAUNCH
+        }
+        if( n_rest )
+        {
+            // one wave per (search, group of ME_ROWS block rows); the kernel is specialised on the search pattern and the sub-pel depth
+            for( int q = 0; q <= ME_QUEUES; q++ )
+                Q.base[q] = (int)( (long long)n_rest * q / ME_QUEUES ); // contiguous groups: the request list is in frame order
+#define ME_LAUNCH( HEXV, MODEV ) me_rows_kernel<T, HEXV, MODEV><<<n_rest * n_rowgroups, 64, dyn_lds, ctx->stream>>>( P, dd + n_wg, Q, ctx->sync_words, ctx->err_host, 1u << 22, ctx->me_prof )
+            switch( 4 * hex + mode )
+            {
+                case 0: ME_LAUNCH( 0, 0 ); break;
+                case 1: ME_LAUNCH( 0, 1 ); break;
+                case 2: ME_LAUNCH( 0, 2 ); break;
+                case 3: ME_LAUNCH( 0, 3 ); break;
+                case 4: ME_LAUNCH( 1, 0 ); break;
+                case 5: ME_LAUNCH( 1, 1 ); break;
+                case 6: ME_LAUNCH( 1, 2 ); break;
+                default: ME_LAUNCH( 1, 3 ); break;
+            }
+#undef ME_LAUNCH
+        }
     }
     HIPCK( hipEventRecord( e1, ctx->stream ) );
     if( ring_commit( ctx->search_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
