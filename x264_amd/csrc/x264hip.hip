@@ -122,7 +122,7 @@ struct x264hip_ctx
     int mbt_next = 0, mbt_pending = 0;
     unsigned *mbt_bar = nullptr;      // device [MBT_RING][4]: barrier arrivals, error, exits, unused
     int desc_cap = 0;
-    int me_wg = 1;                   // searches on unweighted 8-bit planes run the shared-window workgroup kernel (X264HIP_ME_WG=0: never)
+    int me_wg = 0;                   // searches on unweighted 8-bit planes run the shared-window workgroup kernel (X264HIP_ME_WG=0: never)
     // weight costs: WCAP job entries, each with device counters [2][2] and a pinned result pair; entry 0 serves the
     // on-demand call, the others hold speculative pairs (x264hip_prefetch_weight_costs) until their frames go away
     static const int WCAP = 1024;
