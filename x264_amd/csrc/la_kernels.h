@@ -83,6 +83,24 @@ __global__ __launch_bounds__( 256 ) void lowres_kernel( const PutDesc *descs, Pu
     __builtin_memcpy( planes + plane_elems + o, oh, 4 * sizeof( T ) );
     __builtin_memcpy( planes + 2 * (size_t)plane_elems + o, ov, 4 * sizeof( T ) );
     __builtin_memcpy( planes + 3 * (size_t)plane_elems + o, oc, 4 * sizeof( T ) );
+    // the strip copy read by the search (me_search8.h): strip k of a plane = columns 8k .. 8k+15 of every row, 16 samples per
+    // row; the four planes' strips follow the row-major planes, each twice the size of its plane
+    T *strips = planes + 4 * (size_t)plane_elems;
+    const size_t strip_elems = (size_t)( lh + 2 * LA_PAD ) * 16, strip_plane = 2 * (size_t)plane_elems;
+    const int c = X4 * 4, k = c >> 3;
+    const size_t so = k * strip_elems + (size_t)Y * 16 + ( c & 7 );
+    __builtin_memcpy( strips + so, o0, 4 * sizeof( T ) );
+    __builtin_memcpy( strips + strip_plane + so, oh, 4 * sizeof( T ) );
+    __builtin_memcpy( strips + 2 * strip_plane + so, ov, 4 * sizeof( T ) );
+    __builtin_memcpy( strips + 3 * strip_plane + so, oc, 4 * sizeof( T ) );
+    if( k )
+    {
+        const size_t sp = so - strip_elems + 8; // the same columns as the right half of the strip before
+        __builtin_memcpy( strips + sp, o0, 4 * sizeof( T ) );
+        __builtin_memcpy( strips + strip_plane + sp, oh, 4 * sizeof( T ) );
+        __builtin_memcpy( strips + 2 * strip_plane + sp, ov, 4 * sizeof( T ) );
+        __builtin_memcpy( strips + 3 * strip_plane + sp, oc, 4 * sizeof( T ) );
+    }
 }
 
 // plain x264_mc_functions_t.frame_init_lowres_core signature (mc.h:326-327): no borders, caller's layout
@@ -449,6 +467,22 @@ __global__ __launch_bounds__( 256 ) void weight_plane_kernel( const T *__restric
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if( i < n )
         dst[i] = (T)weight_px( src[i], w, pixel_max );
+}
+
+// the same into the strip layout of me_search8.h (plane 0 only)
+template <typename T>
+__global__ __launch_bounds__( 256 ) void weight_strips_kernel( const T *__restrict__ src, T *__restrict__ strips, int n, int stride, WtD w, int pixel_max )
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if( i >= n )
+        return;
+    const int Y = i / stride, c = i - Y * stride, k = c >> 3;
+    const size_t strip_elems = (size_t)( n / stride ) * 16;
+    const size_t so = k * strip_elems + (size_t)Y * 16 + ( c & 7 );
+    const T v = (T)weight_px( src[i], w, pixel_max );
+    strips[so] = v;
+    if( k )
+        strips[so - strip_elems + 8] = v;
 }
 
 // weight_cost_luma (slicetype.c:191-222): sum over blocks of min( mbcmp, intra_cost ).  256-thread workgroups, four

@@ -103,6 +103,10 @@ ME_HD int neighbour_list( int bx, int W, bool has_below, int right, int below, i
     return n;
 }
 
+#ifndef ME_MARK
+#define ME_MARK( ev, k ) // profiling builds of the device kernel time the phases of a search
+#endif
+
 template <class E>
 ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, int n_mvc, const int mvcx[4], const int mvcy[4],
                    int &out_mvx, int &out_mvy, int &out_cost )
@@ -110,6 +114,7 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
     int bmx, bmy, bcost;
     int bpred_cost = ME_COST_MAX, bpred_mx = 0, bpred_my = 0;
     int pmvx, pmvy;
+    ME_MARK( ev, 0 );
 
     if( C.refine4 )
     {
@@ -208,6 +213,7 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
         }
     }
 
+    ME_MARK( ev, 1 );
     if( !C.hex )
     {
         // radius-1 diamond: up, down, left, right (me.c:322-342)
@@ -292,6 +298,7 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
         }
     }
 
+    ME_MARK( ev, 2 );
     // back to quarter-pel units (me.c:774-789)
     int mvx, mvy, cost;
     if( !C.refine4 )
@@ -343,6 +350,7 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
                 mvy += 2 * dia_dy( best );
             }
         }
+        ME_MARK( ev, 3 );
         if( C.refine4 )
         {
             // quarter-pel diamond, one iteration, costs with mbcmp (me.c:935-976)
@@ -374,6 +382,7 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
         else if( C.mbcmp_satd != C.fpelcmp_satd )
             cost = ev.qpel( mvx, mvy, C.mbcmp_satd ) + ev.bits( mvx, mvy );
     }
+    ME_MARK( ev, 4 );
     out_mvx = mvx; out_mvy = mvy; out_cost = cost;
 }
 

@@ -18,6 +18,9 @@
 #pragma once
 #include "device_common.h"
 #define ME_HD __device__ __forceinline__
+#ifdef ME_PROFILE
+#define ME_MARK( ev, k ) ( ev ).mark( k )
+#endif
 #include "me_logic.h"
 
 #define ME_ROWS 4
@@ -33,6 +36,8 @@ struct SearchDesc
     int *costs;                 // [n_mb]
     unsigned tag;               // non-zero, unique per use of mvq
     int pad;
+    const T *ref_strips;        // strip copy of the reference's four planes (me_search8.h), start of the allocation
+    const T *refw_strips;       // strip copy of the weighted plane 0 or nullptr
 };
 
 // The searches of a launch are split into ME_QUEUES contiguous groups (neighbouring frames), one ticket counter
@@ -93,6 +98,16 @@ struct GroupEval
         return block_cost8x8<T>( f, r, use_satd );
     }
     __device__ __forceinline__ bool any( bool c ) const { return __builtin_amdgcn_ballot_w64( c ) != 0ull; }
+#ifdef ME_PROFILE
+    unsigned long long pf_last;
+    unsigned pf_phase[5]; // [k] = cycles between mark k-1 and mark k: 1 start candidates, 2 pattern, 3 half-pel, 4 quarter-pel
+    __device__ __forceinline__ void mark( int k )
+    {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        if( k ) pf_phase[k] += (unsigned)( now - pf_last );
+        pf_last = now;
+    }
+#endif
 };
 
 // value of the same lane position one group (16 lanes) further down; group 0 gets its own value back
@@ -117,6 +132,7 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
     const int lane = lane_id();
 #ifdef ME_PROFILE
     unsigned long long pf_wait = 0, pf_pre = 0, pf_search = 0, pf_store = 0, pf_spins = 0, pf_steps = 0;
+    unsigned long long pf_ph[5] = { 0, 0, 0, 0, 0 };
     const unsigned long long pf_begin = __builtin_amdgcn_s_memtime();
 #define PF_NOW() __builtin_amdgcn_s_memtime()
 #endif
@@ -167,6 +183,9 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
     C.mbcmp_satd = MODE == 3 ? P.mbcmp_satd : MODE >= 1;
     C.fpelcmp_satd = MODE == 3 ? P.fpelcmp_satd : MODE == 2;
     GroupEval<T, 0> ev;
+#ifdef ME_PROFILE
+    for( int k = 0; k < 5; k++ ) ev.pf_phase[k] = 0;
+#endif
     ev.lds_tab = tab_window;
     const int border = LA_PAD * P.stride + LA_PAD;
     const T *fbase = D.fenc0 - border;
@@ -296,7 +315,13 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
                         evl.stride = ev.stride; evl.pixel_max = ev.pixel_max; evl.fpelcmp_satd = ev.fpelcmp_satd; evl.wt = ev.wt;
                         evl.lane_off = ev.lane_off; evl.f = ev.f;
                         evl.tab_x = ME_TAB_HALF - mvpx; evl.tab_y = ME_TAB_HALF - mvpy;
+#ifdef ME_PROFILE
+                        for( int k = 0; k < 5; k++ ) evl.pf_phase[k] = 0;
+#endif
                         melogic::search( C, L, evl, mvpx, mvpy, n, mvcx, mvcy, mvx, mvy, cost );
+#ifdef ME_PROFILE
+                        for( int k = 1; k < 5; k++ ) pf_ph[k] += evl.pf_phase[k];
+#endif
                     }
                     else
                     melogic::search( C, L, ev, mvpx, mvpy, n, mvcx, mvcy, mvx, mvy, cost );
@@ -335,6 +360,7 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
     {
         atomicAdd( prof + 0, PF_NOW() - pf_begin ); atomicAdd( prof + 1, pf_wait ); atomicAdd( prof + 2, pf_pre ); atomicAdd( prof + 3, pf_search );
         atomicAdd( prof + 4, pf_store ); atomicAdd( prof + 5, pf_spins ); atomicAdd( prof + 6, pf_steps ); atomicAdd( prof + 7, 1ull );
+        for( int k = 1; k < 5; k++ ) atomicAdd( prof + 7 + k, pf_ph[k] ); // lane 0's view: group 0 of the wave
     }
 #endif
 }

@@ -50,6 +50,9 @@ struct WinEval
     int tab_x, tab_y;
     Px4 f;
 
+#ifdef ME_PROFILE
+    __device__ __forceinline__ void mark( int ) {}
+#endif
     __device__ __forceinline__ bool any( bool c ) const { return __builtin_amdgcn_ballot_w64( c ) != 0ull; }
     __device__ __forceinline__ int bits( int qx, int qy ) const
     {

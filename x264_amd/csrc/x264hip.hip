@@ -19,7 +19,7 @@
 #include "x264hip.h"
 #include "device_common.h"
 #include "me_search.h"
-#include "me_search_wg.h"
+#include "me_search8.h"
 #include "la_kernels.h"
 #include "block_metrics.h"
 #include "dct_quant_block.h"
@@ -122,7 +122,7 @@ struct x264hip_ctx
     int mbt_next = 0, mbt_pending = 0;
     unsigned *mbt_bar = nullptr;      // device [MBT_RING][4]: barrier arrivals, error, exits, unused
     int desc_cap = 0;
-    int me_wg = 0;                   // searches on unweighted 8-bit planes run the shared-window workgroup kernel (X264HIP_ME_WG=0: never)
+    int me_rows = 8;                 // block rows per wave of the search kernel: 8 (me_search8.h) or 4 (me_search.h, X264HIP_ME_ROWS=4)
     // weight costs: WCAP job entries, each with device counters [2][2] and a pinned result pair; entry 0 serves the
     // on-demand call, the others hold speculative pairs (x264hip_prefetch_weight_costs) until their frames go away
     static const int WCAP = 1024;
@@ -251,12 +251,15 @@ extern "C" void x264hip_close( x264hip_ctx *ctx )
 #ifdef ME_PROFILE
     if( ctx->me_prof )
     {
-        unsigned long long v[8] = { 0 };
+        unsigned long long v[12] = { 0 };
         (void)hipStreamSynchronize( ctx->stream );
         (void)hipMemcpy( v, ctx->me_prof, sizeof( v ), hipMemcpyDeviceToHost );
         if( v[7] )
             fprintf( stderr, "ME_PROFILE waves %llu steps/wave %.1f cycles/wave %.0f | per step: wait-below %.0f pre %.0f search %.0f store+rest %.0f | spins/step %.3f\n", v[7],
                      (double)v[6] / v[7], (double)v[0] / v[7], (double)v[1] / v[6], (double)v[2] / v[6], (double)v[3] / v[6], (double)v[4] / v[6], (double)v[5] / v[6] );
+        if( v[7] )
+            fprintf( stderr, "ME_PROFILE search phases per step (group 0): start candidates %.0f pattern %.0f half-pel %.0f quarter-pel %.0f\n",
+                     (double)v[8] / v[6], (double)v[9] / v[6], (double)v[10] / v[6], (double)v[11] / v[6] );
         (void)hipFree( ctx->me_prof );
     }
 #endif
@@ -334,8 +337,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( hipMalloc( &ctx->sync_words, 2 * ME_QUEUES * ME_QUEUE_STRIDE * sizeof( unsigned ) ) ); // row tickets of the two search kernels
     OPENCK( hipMemset( ctx->sync_words, 0, 2 * ME_QUEUES * ME_QUEUE_STRIDE * sizeof( unsigned ) ) );
 #ifdef ME_PROFILE
-    OPENCK( hipMalloc( &ctx->me_prof, 8 * sizeof( unsigned long long ) ) );
-    OPENCK( hipMemset( ctx->me_prof, 0, 8 * sizeof( unsigned long long ) ) );
+    OPENCK( hipMalloc( &ctx->me_prof, 12 * sizeof( unsigned long long ) ) );
+    OPENCK( hipMemset( ctx->me_prof, 0, 12 * sizeof( unsigned long long ) ) );
 #endif
     ctx->n_cells = ( p.bframes + 2 ) * ( p.bframes + 2 );
     OPENCK( hipHostMalloc( &ctx->cell_acc_host, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
@@ -366,8 +369,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( ring_alloc( ctx->wjob_ring, (size_t)x264hip_ctx::WCAP * sizeof( WeightJob ) ) );
     ctx->wcache.assign( x264hip_ctx::WCAP, x264hip_ctx::WEntry() );
     ctx->desc_cap = 2 * ( p.bframes + 1 ) * p.max_frames + 16;
-    if( const char *e = getenv( "X264HIP_ME_WG" ) ) ctx->me_wg = atoi( e ) != 0;
-    OPENCK( ring_alloc( ctx->search_ring, (size_t)ctx->desc_cap * ( sizeof( SearchDesc<uint8_t> ) + sizeof( RefGroup ) ) ) );
+    if( const char *e = getenv( "X264HIP_ME_ROWS" ) ) ctx->me_rows = atoi( e ) == 4 ? 4 : 8;
+    OPENCK( ring_alloc( ctx->search_ring, (size_t)ctx->desc_cap * sizeof( SearchDesc<uint8_t> ) ) );
     ctx->staging_bytes = (size_t)p.width * p.height * ctx->psz;
     OPENCK( hipHostMalloc( &ctx->staging, ctx->staging_bytes ) );
 
@@ -376,7 +379,7 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     for( auto &s : ctx->slots )
     {
         size_t off = 0;
-        const size_t o_planes = off; off += align_up( 4 * ctx->plane_bytes, 256 );
+        const size_t o_planes = off; off += align_up( 12 * ctx->plane_bytes, 256 ); // four row-major planes, then their strip copies (twice the size)
         const size_t o_luma = off; off += align_up( ctx->staging_bytes, 256 );
         const size_t o_inv = off; off += align_up( ctx->n_mb * sizeof( uint16_t ), 256 );
         const size_t o_sums = off; off += 256;
@@ -636,7 +639,7 @@ static int acquire_wplane( x264hip_ctx *ctx, int owner_slot )
     for( size_t i = 0; i < ctx->wplanes.size(); i++ )
         if( ctx->wplane_owner[i] < 0 ) { ctx->wplane_owner[i] = owner_slot; return (int)i; }
     char *pl = nullptr;
-    if( hipMalloc( &pl, ctx->plane_bytes ) != hipSuccess ) return -1;
+    if( hipMalloc( &pl, 2 * ctx->plane_bytes ) != hipSuccess ) return -1; // row-major, or strips (me_search8.h)
     ctx->wplanes.push_back( pl );
     ctx->wplane_owner.push_back( owner_slot );
     return (int)ctx->wplanes.size() - 1;
@@ -713,16 +716,15 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
     int rc = 0, ri = 0;
     if( ring_acquire( ctx->search_ring, &ri ) ) return X264HIP_EDEVICE;
     SearchDesc<T> *dh = (SearchDesc<T> *)ctx->search_ring.host[ri], *dd = (SearchDesc<T> *)ctx->search_ring.dev[ri];
-    RefGroup *gh = (RefGroup *)( dh + ctx->desc_cap ), *gd = (RefGroup *)( dd + ctx->desc_cap );
-    // 8-bit searches on the unweighted planes go to the workgroup kernel (me_search_wg.h), grouped by the frame they read; the
-    // table holds them first, in request (= frame) order, and the weighted / high-bit-depth ones after them
+    // the table holds the searches on unweighted planes first, in request (= frame) order, then the weighted ones: the row
+    // kernel is compiled once without and once with the weighting code (me_search8.h)
     std::vector<int> order( n );
-    int n_wg = 0;
-    if( sizeof( T ) == 1 && ctx->me_wg )
+    int n_plain = 0;
+    if( ctx->me_rows == 8 )
     {
         for( int i = 0; i < n; i++ )
-            if( !reqs[i].wt.on ) order[n_wg++] = i;
-        for( int i = 0, k = n_wg; i < n; i++ )
+            if( !reqs[i].wt.on ) order[n_plain++] = i;
+        for( int i = 0, k = n_plain; i < n; i++ )
             if( reqs[i].wt.on ) order[k++] = i;
     }
     else
@@ -735,14 +737,20 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         d.fenc0 = plane_origin<T>( ctx, b, 0 );
         d.ref0 = plane_origin<T>( ctx, rf, 0 );
         d.refw = nullptr;
+        d.ref_strips = (const T *)( rf.planes + 4 * ctx->plane_bytes );
+        d.refw_strips = nullptr;
         d.wt = r.wt;
         if( r.wt.on )
         {
             if( b.wplane_idx < 0 ) b.wplane_idx = acquire_wplane( ctx, r.slot_b );
             if( b.wplane_idx < 0 ) return X264HIP_ENOMEM;
             T *wp = (T *)ctx->wplanes[b.wplane_idx];
-            weight_plane_kernel<T><<<( P.plane_elems + 255 ) / 256, 256, 0, ctx->stream>>>( (const T *)rf.planes, wp, P.plane_elems, r.wt, P.pixel_max );
+            if( ctx->me_rows == 8 )
+                weight_strips_kernel<T><<<( P.plane_elems + 255 ) / 256, 256, 0, ctx->stream>>>( (const T *)rf.planes, wp, P.plane_elems, P.stride, r.wt, P.pixel_max );
+            else
+                weight_plane_kernel<T><<<( P.plane_elems + 255 ) / 256, 256, 0, ctx->stream>>>( (const T *)rf.planes, wp, P.plane_elems, r.wt, P.pixel_max );
             d.refw = wp + LA_PAD * P.stride + LA_PAD;
+            d.refw_strips = wp;
         }
         d.mvq = b.mvq[r.list][r.dist_m1];
         d.costs = b.mvcost[r.list][r.dist_m1];
@@ -752,30 +760,7 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         d.pad = 0;
         dh[i] = d;
     }
-    // reference groups: the searches of one frame, MEW_WAVES at a time, in the order the frames first appear as a reference
-    int n_groups = 0;
-    if( n_wg )
-    {
-        std::vector<char> taken( n_wg, 0 );
-        for( int i = 0; i < n_wg; i++ )
-        {
-            if( taken[i] ) continue;
-            const int ref = reqs[order[i]].slot_ref;
-            RefGroup g; g.n = 0;
-            for( int k = i; k < n_wg; k++ )
-                if( !taken[k] && reqs[order[k]].slot_ref == ref )
-                {
-                    if( g.n == MEW_WAVES ) { gh[n_groups++] = g; g.n = 0; }
-                    g.search[g.n++] = k;
-                    taken[k] = 1;
-                }
-            for( int k = g.n; k < MEW_WAVES; k++ ) g.search[k] = g.search[0];
-            gh[n_groups++] = g;
-        }
-    }
     HIPCK( hipMemcpyAsync( dd, dh, (size_t)n * sizeof( SearchDesc<T> ), hipMemcpyHostToDevice, ctx->stream ) );
-    if( n_groups )
-        HIPCK( hipMemcpyAsync( gd, gh, (size_t)n_groups * sizeof( RefGroup ), hipMemcpyHostToDevice, ctx->stream ) );
     HIPCK( hipMemsetAsync( ctx->sync_words, 0, 2 * ME_QUEUES * ME_QUEUE_STRIDE * sizeof( unsigned ), ctx->stream ) ); // row tickets
     hipEvent_t e0 = ctx->ev_start, e1 = ctx->ev_stop;
     if( ctx->prof_on )
@@ -791,38 +776,44 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
     }
     HIPCK( hipEventRecord( e0, ctx->stream ) );
     {
-        const int n_rowgroups = ( P.mb_h + ME_ROWS - 1 ) / ME_ROWS;
         const bool hex = P.me_method == X264HIP_ME_HEX, r4 = P.subpel_refine >= 3;
         const int mode = !r4 && !P.mbcmp_satd && !P.fpelcmp_satd ? 0 : r4 && P.mbcmp_satd ? ( P.fpelcmp_satd ? 2 : 1 ) : 3;
-        const int n_rest = n - n_wg;
-        static const int dyn_lds = getenv( "X264HIP_ME_DYN_LDS" ) ? atoi( getenv( "X264HIP_ME_DYN_LDS" ) ) : 0; // EXPERIMENT
         MeQueues Q;
-        if( n_groups )
+        if( ctx->me_rows == 8 )
         {
-            // one workgroup per (reference group, group of ME_ROWS block rows)
-            for( int q = 0; q <= ME_QUEUES; q++ )
-                Q.base[q] = (int)( (long long)n_groups * q / ME_QUEUES );
-#define ME_LAUNCH( HEXV, MODEV ) me_rows_wg_kernel<HEXV, MODEV><<<n_groups * n_rowgroups, 64 * MEW_WAVES, dyn_lds, ctx->stream>>>( \
-            P, (const SearchDesc<uint8_t> *)dd, gd, Q, ctx->sync_words + ME_QUEUES * ME_QUEUE_STRIDE, ctx->err_host, 1u << 22, ctx->me_prof )
-            switch( 4 * hex + mode )
+            // one wave per (search, group of ME8_ROWS block rows); the kernel is specialised on the search pattern, the sub-pel
+            // depth and on whether its searches read weighted references
+            const int n_rowgroups = ( P.mb_h + ME8_ROWS - 1 ) / ME8_ROWS;
+            for( int part = 0; part < 2; part++ )
             {
-                case 0: ME_LAUNCH( 0, 0 ); break;
-                case 1: ME_LAUNCH( 0, 1 ); break;
-                case 2: ME_LAUNCH( 0, 2 ); break;
-                case 3: ME_LAUNCH( 0, 3 ); break;
-                case 4: ME_LAUNCH( 1, 0 ); break;
-                case 5: ME_LAUNCH( 1, 1 ); break;
-                case 6: ME_LAUNCH( 1, 2 ); break;
-                default: ME_LAUNCH( 1, 3 ); break;
-            }
+                const int first = part ? n_plain : 0, count = part ? n - n_plain : n_plain;
+                if( !count ) continue;
+                for( int q = 0; q <= ME_QUEUES; q++ )
+                    Q.base[q] = (int)( (long long)count * q / ME_QUEUES ); // contiguous groups: the request list is in frame order
+                unsigned *tickets = ctx->sync_words + part * ME_QUEUES * ME_QUEUE_STRIDE;
+#define ME_LAUNCH( HEXV, MODEV ) do { if( part ) me_rows8_kernel<T, HEXV, MODEV, 1><<<count * n_rowgroups, 64, 0, ctx->stream>>>( P, dd + first, Q, tickets, ctx->err_host, 1u << 22 ); \
+                                      else me_rows8_kernel<T, HEXV, MODEV, 0><<<count * n_rowgroups, 64, 0, ctx->stream>>>( P, dd + first, Q, tickets, ctx->err_host, 1u << 22 ); } while( 0 )
+                switch( 4 * hex + mode )
+                {
+                    case 0: ME_LAUNCH( 0, 0 ); break;
+                    case 1: ME_LAUNCH( 0, 1 ); break;
+                    case 2: ME_LAUNCH( 0, 2 ); break;
+                    case 3: ME_LAUNCH( 0, 3 ); break;
+                    case 4: ME_LAUNCH( 1, 0 ); break;
+                    case 5: ME_LAUNCH( 1, 1 ); break;
+                    case 6: ME_LAUNCH( 1, 2 ); break;
+                    default: ME_LAUNCH( 1, 3 ); break;
+                }
 #undef ME_LAUNCH
+            }
         }
-        if( n_rest )
+        else
         {
-            // one wave per (search, group of ME_ROWS block rows); the kernel is specialised on the search pattern and the sub-pel depth
+            // the four-rows-per-wave kernel of me_search.h (X264HIP_ME_ROWS=4)
+            const int n_rowgroups = ( P.mb_h + ME_ROWS - 1 ) / ME_ROWS;
             for( int q = 0; q <= ME_QUEUES; q++ )
-                Q.base[q] = (int)( (long long)n_rest * q / ME_QUEUES ); // contiguous groups: the request list is in frame order
-#define ME_LAUNCH( HEXV, MODEV ) me_rows_kernel<T, HEXV, MODEV><<<n_rest * n_rowgroups, 64, dyn_lds, ctx->stream>>>( P, dd + n_wg, Q, ctx->sync_words, ctx->err_host, 1u << 22, ctx->me_prof )
+                Q.base[q] = (int)( (long long)n * q / ME_QUEUES );
+#define ME_LAUNCH( HEXV, MODEV ) me_rows_kernel<T, HEXV, MODEV><<<n * n_rowgroups, 64, 0, ctx->stream>>>( P, dd, Q, ctx->sync_words, ctx->err_host, 1u << 22, ctx->me_prof )
             switch( 4 * hex + mode )
             {
                 case 0: ME_LAUNCH( 0, 0 ); break;
