@@ -1,7 +1,7 @@
 """Reduce the counter passes of scripts/pmc_search.sh to profiles/<tag>_search_pmc.json: counter sums of the search kernel over
 its launches, the number of block searches they covered (from the bench line of the same run), per-block figures and the
 derivation of what bounds the kernel.
-usage: python scripts/summarize_search_pmc.py <tag> [kernel substring] [note]"""
+usage: python scripts/summarize_search_pmc.py <tag> [kernel substring] [note] [issue]     ("issue": also refresh profiles/search_issue.json)"""
 import collections
 import csv
 import glob
@@ -64,11 +64,21 @@ if blocks:
         if "SQ_BUSY_CYCLES" in c and "SQ_WAVES" in c:
             d["avg_wave_quad_cycles"] = round(wc / c["SQ_WAVES"], 1)
     if "SQ_INSTS_VALU" in c and ns:
-        # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles; 1024 SIMDs; clock from GRBM_GUI_ACTIVE / wall when collected
-        # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs
+        # cycles a wave64 VALU instruction occupies its SIMD: 2 for the plain VOP2 kinds, 4 for the rest (experiments/gen_valu_rate.py);
+        # the kernel's mix comes from scripts/valu_mix.py.  1024 SIMDs; clock from GRBM_GUI_ACTIVE / wall when collected
+        # (GRBM_GUI_ACTIVE comes back summed over the 8 XCDs)
         clk = c.get("GRBM_GUI_ACTIVE", 0) / 8 / (dur_ns[0] if dur_ns else ns) if c.get("GRBM_GUI_ACTIVE") else 2.4
         d["effective_clock_GHz"] = round(clk, 3)
-        d["valu_issue_utilisation"] = round(c["SQ_INSTS_VALU"] * 2 / (1024 * ns * clk), 4)
+        try:
+            cpv = json.load(open(os.path.join(ROOT, "profiles", "search_valu_mix.json")))["cycles_per_valu"]
+        except Exception:
+            cpv = 4.0
+        d["cycles_per_valu_instruction"] = cpv
+        d["valu_issue_utilisation"] = round(c["SQ_INSTS_VALU"] * cpv / (1024 * ns * clk), 4)
+        if "SQ_WAVE_CYCLES" in c:
+            # resident waves averaged over the launch, of 4096 slots at 4 waves/SIMD (SQ_WAVE_CYCLES counts quad-cycles)
+            d["avg_resident_waves"] = round(c["SQ_WAVE_CYCLES"] * 4 / (ns * clk), 1)
+            d["valu_issue_utilisation_while_resident"] = round(d["valu_issue_utilisation"] / max(d["avg_resident_waves"] / 4096, 1e-9), 4)
         if "SQ_INSTS_SALU" in c:
             # one scalar issue per CU-cycle at best (256 CUs)
             d["salu_issue_utilisation_1_per_cu_cycle"] = round(c["SQ_INSTS_SALU"] / (256 * ns * clk), 4)
@@ -76,6 +86,9 @@ if blocks:
         d["l2_hit_rate"] = round(c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c.get("TCC_MISS_sum", 0), 1), 4)
     if "TCP_TOTAL_CACHE_ACCESSES_sum" in c and "TCP_TCC_READ_REQ_sum" in c:
         d["l1_miss_share"] = round(c["TCP_TCC_READ_REQ_sum"] / max(c["TCP_TOTAL_CACHE_ACCESSES_sum"], 1), 4)
+        d["l1_line_accesses_per_block"] = round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / blocks, 2)
+        # one tag lookup (64-byte line) per cycle and CU
+        d["l1_pipe_utilisation"] = round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256 * ns * d.get("effective_clock_GHz", 2.4)), 4)
     if "FETCH_SIZE" in c:
         d["fetch_bytes_per_search_raw"] = round(c["FETCH_SIZE"] * 1024 / searches)
     if "WRITE_SIZE" in c:
@@ -88,3 +101,13 @@ path = os.path.join(ROOT, "profiles", "%s_search_pmc.json" % tag)
 json.dump(out, open(path, "w"), indent=1)
 print(path)
 print(json.dumps(out.get("derived"), indent=1))
+if len(sys.argv) > 4 and sys.argv[4] == "issue" and out.get("derived"):
+    # the figures bench.py's issue roofline is computed from
+    d = out["derived"]
+    json.dump({"source": "profiles/%s_search_pmc.json (SQ_INSTS_VALU pass of scripts/pmc_search.sh: wave-level VALU instructions of %s / block searches "
+                         "of the same run) and profiles/search_valu_mix.json (scripts/valu_mix.py)" % (tag, sub),
+               "valu_per_block": d.get("insts_valu_per_block"), "salu_per_block": d.get("insts_salu_per_block"), "vmem_rd_per_block": d.get("insts_vmem_rd_per_block"),
+               "lds_per_block": d.get("insts_lds_per_block"), "cycles_per_valu": d.get("cycles_per_valu_instruction"),
+               "l1_line_accesses_per_block": d.get("l1_line_accesses_per_block"), "wait_any_share_of_wave_cycles": d.get("wait_any_share_of_wave_cycles"),
+               "valu_issue_utilisation_while_resident": d.get("valu_issue_utilisation_while_resident"), "effective_clock_GHz": d.get("effective_clock_GHz")},
+              open(os.path.join(ROOT, "profiles", "search_issue.json"), "w"), indent=1)

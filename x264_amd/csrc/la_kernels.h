@@ -83,7 +83,7 @@ __global__ __launch_bounds__( 256 ) void lowres_kernel( const PutDesc *descs, Pu
     __builtin_memcpy( planes + plane_elems + o, oh, 4 * sizeof( T ) );
     __builtin_memcpy( planes + 2 * (size_t)plane_elems + o, ov, 4 * sizeof( T ) );
     __builtin_memcpy( planes + 3 * (size_t)plane_elems + o, oc, 4 * sizeof( T ) );
-    // the strip copy read by the search (me_search8.h): strip k of a plane = columns 8k .. 8k+15 of every row, 16 samples per
+    // the strip copy read by the search (me_search.h): strip k of a plane = columns 8k .. 8k+15 of every row, 16 samples per
     // row; the four planes' strips follow the row-major planes, each twice the size of its plane
     T *strips = planes + 4 * (size_t)plane_elems;
     const size_t strip_elems = (size_t)( lh + 2 * LA_PAD ) * 16, strip_plane = 2 * (size_t)plane_elems;
@@ -460,16 +460,7 @@ __global__ __launch_bounds__( 64 ) void intra_kernel( LaP P, const PutDesc *desc
     }
 }
 
-// ---- explicit weights: weighted copy of padded plane 0 (slicetype.c:490-500, mc.c:117-160) -------------
-template <typename T>
-__global__ __launch_bounds__( 256 ) void weight_plane_kernel( const T *__restrict__ src, T *__restrict__ dst, int n, WtD w, int pixel_max )
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if( i < n )
-        dst[i] = (T)weight_px( src[i], w, pixel_max );
-}
-
-// the same into the strip layout of me_search8.h (plane 0 only)
+// ---- explicit weights: weighted copy of padded plane 0 (slicetype.c:490-500, mc.c:117-160), in the strip layout of me_search.h
 template <typename T>
 __global__ __launch_bounds__( 256 ) void weight_strips_kernel( const T *__restrict__ src, T *__restrict__ strips, int n, int stride, WtD w, int pixel_max )
 {

@@ -19,7 +19,6 @@
 #include "x264hip.h"
 #include "device_common.h"
 #include "me_search.h"
-#include "me_search8.h"
 #include "la_kernels.h"
 #include "block_metrics.h"
 #include "dct_quant_block.h"
@@ -122,7 +121,6 @@ struct x264hip_ctx
     int mbt_next = 0, mbt_pending = 0;
     unsigned *mbt_bar = nullptr;      // device [MBT_RING][4]: barrier arrivals, error, exits, unused
     int desc_cap = 0;
-    int me_rows = 8;                 // block rows per wave of the search kernel: 8 (me_search8.h) or 4 (me_search.h, X264HIP_ME_ROWS=4)
     // weight costs: WCAP job entries, each with device counters [2][2] and a pinned result pair; entry 0 serves the
     // on-demand call, the others hold speculative pairs (x264hip_prefetch_weight_costs) until their frames go away
     static const int WCAP = 1024;
@@ -369,7 +367,6 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( ring_alloc( ctx->wjob_ring, (size_t)x264hip_ctx::WCAP * sizeof( WeightJob ) ) );
     ctx->wcache.assign( x264hip_ctx::WCAP, x264hip_ctx::WEntry() );
     ctx->desc_cap = 2 * ( p.bframes + 1 ) * p.max_frames + 16;
-    if( const char *e = getenv( "X264HIP_ME_ROWS" ) ) ctx->me_rows = atoi( e ) == 4 ? 4 : 8;
     OPENCK( ring_alloc( ctx->search_ring, (size_t)ctx->desc_cap * sizeof( SearchDesc<uint8_t> ) ) );
     ctx->staging_bytes = (size_t)p.width * p.height * ctx->psz;
     OPENCK( hipHostMalloc( &ctx->staging, ctx->staging_bytes ) );
@@ -639,7 +636,7 @@ static int acquire_wplane( x264hip_ctx *ctx, int owner_slot )
     for( size_t i = 0; i < ctx->wplanes.size(); i++ )
         if( ctx->wplane_owner[i] < 0 ) { ctx->wplane_owner[i] = owner_slot; return (int)i; }
     char *pl = nullptr;
-    if( hipMalloc( &pl, 2 * ctx->plane_bytes ) != hipSuccess ) return -1; // row-major, or strips (me_search8.h)
+    if( hipMalloc( &pl, 2 * ctx->plane_bytes ) != hipSuccess ) return -1; // plane 0 in the strip layout of me_search.h
     ctx->wplanes.push_back( pl );
     ctx->wplane_owner.push_back( owner_slot );
     return (int)ctx->wplanes.size() - 1;
@@ -717,26 +714,19 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
     if( ring_acquire( ctx->search_ring, &ri ) ) return X264HIP_EDEVICE;
     SearchDesc<T> *dh = (SearchDesc<T> *)ctx->search_ring.host[ri], *dd = (SearchDesc<T> *)ctx->search_ring.dev[ri];
     // the table holds the searches on unweighted planes first, in request (= frame) order, then the weighted ones: the row
-    // kernel is compiled once without and once with the weighting code (me_search8.h)
+    // kernel is compiled once without and once with the weighting code (me_search.h)
     std::vector<int> order( n );
     int n_plain = 0;
-    if( ctx->me_rows == 8 )
-    {
-        for( int i = 0; i < n; i++ )
-            if( !reqs[i].wt.on ) order[n_plain++] = i;
-        for( int i = 0, k = n_plain; i < n; i++ )
-            if( reqs[i].wt.on ) order[k++] = i;
-    }
-    else
-        for( int i = 0; i < n; i++ ) order[i] = i;
+    for( int i = 0; i < n; i++ )
+        if( !reqs[i].wt.on ) order[n_plain++] = i;
+    for( int i = 0, k = n_plain; i < n; i++ )
+        if( reqs[i].wt.on ) order[k++] = i;
     for( int i = 0; i < n; i++ )
     {
         const SearchReq &r = reqs[order[i]];
         FrameSlot &b = ctx->slots[r.slot_b], &rf = ctx->slots[r.slot_ref];
         SearchDesc<T> d;
         d.fenc0 = plane_origin<T>( ctx, b, 0 );
-        d.ref0 = plane_origin<T>( ctx, rf, 0 );
-        d.refw = nullptr;
         d.ref_strips = (const T *)( rf.planes + 4 * ctx->plane_bytes );
         d.refw_strips = nullptr;
         d.wt = r.wt;
@@ -745,11 +735,7 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
             if( b.wplane_idx < 0 ) b.wplane_idx = acquire_wplane( ctx, r.slot_b );
             if( b.wplane_idx < 0 ) return X264HIP_ENOMEM;
             T *wp = (T *)ctx->wplanes[b.wplane_idx];
-            if( ctx->me_rows == 8 )
-                weight_strips_kernel<T><<<( P.plane_elems + 255 ) / 256, 256, 0, ctx->stream>>>( (const T *)rf.planes, wp, P.plane_elems, P.stride, r.wt, P.pixel_max );
-            else
-                weight_plane_kernel<T><<<( P.plane_elems + 255 ) / 256, 256, 0, ctx->stream>>>( (const T *)rf.planes, wp, P.plane_elems, r.wt, P.pixel_max );
-            d.refw = wp + LA_PAD * P.stride + LA_PAD;
+            weight_strips_kernel<T><<<( P.plane_elems + 255 ) / 256, 256, 0, ctx->stream>>>( (const T *)rf.planes, wp, P.plane_elems, P.stride, r.wt, P.pixel_max );
             d.refw_strips = wp;
         }
         d.mvq = b.mvq[r.list][r.dist_m1];
@@ -779,41 +765,18 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         const bool hex = P.me_method == X264HIP_ME_HEX, r4 = P.subpel_refine >= 3;
         const int mode = !r4 && !P.mbcmp_satd && !P.fpelcmp_satd ? 0 : r4 && P.mbcmp_satd ? ( P.fpelcmp_satd ? 2 : 1 ) : 3;
         MeQueues Q;
-        if( ctx->me_rows == 8 )
+        // one wave per (search, group of ME_ROWS block rows); the kernel is specialised on the search pattern, the sub-pel
+        // depth and on whether its searches read weighted references
+        const int n_rowgroups = ( P.mb_h + ME_ROWS - 1 ) / ME_ROWS;
+        for( int part = 0; part < 2; part++ )
         {
-            // one wave per (search, group of ME8_ROWS block rows); the kernel is specialised on the search pattern, the sub-pel
-            // depth and on whether its searches read weighted references
-            const int n_rowgroups = ( P.mb_h + ME8_ROWS - 1 ) / ME8_ROWS;
-            for( int part = 0; part < 2; part++ )
-            {
-                const int first = part ? n_plain : 0, count = part ? n - n_plain : n_plain;
-                if( !count ) continue;
-                for( int q = 0; q <= ME_QUEUES; q++ )
-                    Q.base[q] = (int)( (long long)count * q / ME_QUEUES ); // contiguous groups: the request list is in frame order
-                unsigned *tickets = ctx->sync_words + part * ME_QUEUES * ME_QUEUE_STRIDE;
-#define ME_LAUNCH( HEXV, MODEV ) do { if( part ) me_rows8_kernel<T, HEXV, MODEV, 1><<<count * n_rowgroups, 64, 0, ctx->stream>>>( P, dd + first, Q, tickets, ctx->err_host, 1u << 22 ); \
-                                      else me_rows8_kernel<T, HEXV, MODEV, 0><<<count * n_rowgroups, 64, 0, ctx->stream>>>( P, dd + first, Q, tickets, ctx->err_host, 1u << 22 ); } while( 0 )
-                switch( 4 * hex + mode )
-                {
-                    case 0: ME_LAUNCH( 0, 0 ); break;
-                    case 1: ME_LAUNCH( 0, 1 ); break;
-                    case 2: ME_LAUNCH( 0, 2 ); break;
-                    case 3: ME_LAUNCH( 0, 3 ); break;
-                    case 4: ME_LAUNCH( 1, 0 ); break;
-                    case 5: ME_LAUNCH( 1, 1 ); break;
-                    case 6: ME_LAUNCH( 1, 2 ); break;
-                    default: ME_LAUNCH( 1, 3 ); break;
-                }
-#undef ME_LAUNCH
-            }
-        }
-        else
-        {
-            // the four-rows-per-wave kernel of me_search.h (X264HIP_ME_ROWS=4)
-            const int n_rowgroups = ( P.mb_h + ME_ROWS - 1 ) / ME_ROWS;
+            const int first = part ? n_plain : 0, count = part ? n - n_plain : n_plain;
+            if( !count ) continue;
             for( int q = 0; q <= ME_QUEUES; q++ )
-                Q.base[q] = (int)( (long long)n * q / ME_QUEUES );
-#define ME_LAUNCH( HEXV, MODEV ) me_rows_kernel<T, HEXV, MODEV><<<n * n_rowgroups, 64, 0, ctx->stream>>>( P, dd, Q, ctx->sync_words, ctx->err_host, 1u << 22, ctx->me_prof )
+                Q.base[q] = (int)( (long long)count * q / ME_QUEUES ); // contiguous groups: the request list is in frame order
+            unsigned *tickets = ctx->sync_words + part * ME_QUEUES * ME_QUEUE_STRIDE;
+#define ME_LAUNCH( HEXV, MODEV ) do { if( part ) me_rows_kernel<T, HEXV, MODEV, 1><<<count * n_rowgroups, 64, 0, ctx->stream>>>( P, dd + first, Q, tickets, ctx->err_host, 1u << 22, ctx->me_prof ); \
+                                  else me_rows_kernel<T, HEXV, MODEV, 0><<<count * n_rowgroups, 64, 0, ctx->stream>>>( P, dd + first, Q, tickets, ctx->err_host, 1u << 22, ctx->me_prof ); } while( 0 )
             switch( 4 * hex + mode )
             {
                 case 0: ME_LAUNCH( 0, 0 ); break;
