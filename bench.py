@@ -491,8 +491,8 @@ def main():
                              "achieved": round(solo[2] * bytes_per_search / 1e9 / (solo[0] / 1e3), 2),
                              "frac": round(solo[2] * bytes_per_search / 1e9 / (solo[0] / 1e3) / HBM_PEAK_GBS, 5)},
                          "algorithmic_bytes_per_search": bytes_per_search,
-                         "note": "not a streaming kernel: bound by the latency of the dependent candidate rounds of a block search (DESIGN.md section 3); "
-                                 "the counters are in profiles/r02_search_pmc.json"},
+                         "note": "not a streaming kernel: bound by vector-ALU issue (roofline_issue) and the L1 pipe while the CU is full, by the dependency "
+                                 "chain of the launch otherwise (DESIGN.md section 3); the counters are in profiles/r02_search_pmc.json"},
             "lookahead_stats": {"frame_cost_calls": int(la_stats[0]), "evaluations": int(la_stats[1]),
                                 "weights_analysed": int(la_stats[2]), "weights_kept": int(la_stats[3]),
                                 "device": {"searches": int(dev_counters[0]), "cell_requests": int(dev_counters[1]), "cell_hits": int(dev_counters[4]),
@@ -505,7 +505,8 @@ def main():
         if os.path.exists(ipath):
             try:
                 pm, ps = (solo[0], solo[2]) if solo is not None else (prof_ms, prof_searches)
-                res["roofline_issue"] = issue_roofline(json.load(open(ipath)), pm, ps, cfg)
+                res["roofline_issue"] = issue_roofline(json.load(open(ipath)), pm, ps, cfg, wall_s=dt, all_searches=prof_searches)
+                res["roofline_issue"]["what"] = ("one untimed pass of one segment alone: " if solo is not None else "") + res["roofline_issue"]["what"]
             except Exception as e:  # pragma: no cover
                 res["roofline_issue"] = {"error": str(e)}
         if window is not None:
@@ -602,19 +603,28 @@ def window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend,
     return res
 
 
-def issue_roofline(prof, prof_ms, prof_searches, cfg):
-    """Second roofline of the search kernel, against the ceiling that binds it: vector-ALU issue slots.  profiles/search_issue.json
-    holds wave-level VALU instructions per block search from the SQ_INSTS_VALU pass of this command; a wave64 VALU instruction
-    occupies its SIMD for 2 cycles (MI355X_MICROARCH.md: SIMD-32), 1024 SIMDs at 2.4 GHz."""
+def issue_roofline(prof, prof_ms, prof_searches, cfg, wall_s=None, all_searches=None):
+    """Second roofline of the search kernel, against the ceiling that binds it while the CU is full: vector-ALU issue cycles.
+    profiles/search_issue.json holds wave-level VALU instructions per block search (SQ_INSTS_VALU pass of this command) and the
+    cycles one of them occupies its SIMD on average (2 for the plain VOP2 kinds, 4 for the rest, measured with
+    experiments/gen_valu_rate.py; the kernel's mix from scripts/valu_mix.py); 1024 SIMDs at 2.4 GHz."""
     blocks = ((cfg["width"] + 15) // 16) * ((cfg["height"] + 15) // 16)
     valu = prof["valu_per_block"]
+    cpv = prof.get("cycles_per_valu", 4.0)
+    peak = 1024 * 2.4e9 / cpv
     achieved = prof_searches * blocks * valu / (prof_ms / 1e3) if prof_ms > 0 else 0.0
-    peak = 1024 * 2.4e9 / 2
-    return {"bound": "valu-issue", "kernel": "me_rows_kernel", "achieved": round(achieved / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-instr/s",
-            "frac": round(achieved / peak, 4), "valu_per_block": valu, "source": prof.get("source"),
-            "note": "second ceiling: vector issue slots.  Neither this nor HBM binds: the kernel is bound by the latency of its dependent candidate rounds "
-                    "(waves parked on s_waitcnt %.0f %% of their lifetime, profiles/r02_search_pmc.json; cycles per step in profiles/r02_search_cycle_breakdown.txt)"
-                    % (100 * prof.get("wait_any_share_of_wave_cycles", 0))}
+    out = {"bound": "valu-issue", "kernel": "me_rows_kernel", "achieved": round(achieved / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-instr/s",
+           "frac": round(achieved / peak, 4), "valu_per_block": valu, "cycles_per_valu_instruction": cpv, "source": prof.get("source"),
+           "what": "achieved = VALU instructions of the launches / summed launch time (launches of several contexts overlap, each is stretched)",
+           "note": "the ceiling that binds while the CU is full (%.0f %% of the issue cycles of the resident waves in the counter passes, the L1 pipe "
+                   "next to it); a launch alone is bound by its dependency chain instead (DESIGN.md section 3, profiles/r02_search_pmc.json)"
+                   % (100 * prof.get("valu_issue_utilisation_while_resident", 0))}
+    if wall_s and all_searches:
+        # whole timed region: every search of every context against the wall clock
+        agg = all_searches * blocks * valu / wall_s
+        out["aggregate"] = {"achieved": round(agg / 1e9, 2), "frac": round(agg / peak, 4),
+                            "what": "VALU instructions of all searches of the timed steps / wall time of the timed steps (the GPU also runs every other kernel of the path)"}
+    return out
 
 
 if __name__ == "__main__":
