@@ -35,12 +35,16 @@ for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, [0, 0.0]), write.get(k, [0, 0.0])
     out["kernels"][k] = {"launches": f[0] or w[0], "fetch_bytes_per_launch": f[1] * 1024 / max(f[0], 1), "write_bytes_per_launch": w[1] * 1024 / max(w[0], 1)}
 # calibration on a kernel with known traffic (the guide: FETCH_SIZE under-reports wide coalesced reads; WRITE_SIZE is exact here):
-# lowres_kernel reads the 1920x1080 luma of every frame once and writes 4 padded planes of 608 x 1024
+# lowres_kernel reads the 1920x1080 luma of every frame once and writes 4 padded planes of 608 x 1024 plus the strip copies
 lw = out["kernels"].get("lowres_kernel")
 if lw:
+    # (the strip copies, twice that, are written by strips_kernel)
     known_r, known_w = 1920 * 1080 * frames, 4 * 608 * 1024 * frames
     cal_r, cal_w = known_r / lw["fetch_bytes_per_launch"], known_w / lw["write_bytes_per_launch"]
     out["calibration"] = {"kernel": "lowres_kernel", "known_read_bytes": known_r, "known_write_bytes": known_w, "read_factor": cal_r, "write_factor": cal_w}
+    st = out["kernels"].get("strips_kernel")
+    if st:
+        st["write_over_strip_bytes"] = st["write_bytes_per_launch"] / (8 * 608 * 1024 * frames)
     pic = 1920 * 1080
     for k in ("aq_kernel", "intra_kernel", "lowres_kernel"):
         if k in out["kernels"]:
@@ -54,7 +58,9 @@ if lw:
         out["me_rows_kernel"] = {"searches_per_launch": n, "calibrated_hbm_bytes_per_search": per_search,
                                  "fetch_bytes_per_search_calibrated": me["fetch_bytes_per_launch"] * cal_r / n,
                                  "write_bytes_per_search_calibrated": me["write_bytes_per_launch"] * cal_w / n,
-                                 "algorithmic_bytes_per_search": 5 * 960 * 544 + 8 * 120 * 68}
+                                 "algorithmic_bytes_per_search": 5 * 960 * 544 + 8 * 120 * 68,
+                                 "result_bytes_per_search": 12 * 120 * 68,
+                                 "write_amplification": me["write_bytes_per_launch"] * cal_w / n / ( 12 * 120 * 68 )}
         json.dump({"source": "profiles/%s_traffic.json" % tag, "workload": "1920x1080 slow+dia", "me_rows_kernel_hbm_bytes_per_search": per_search},
                   open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(ROOT, "profiles", "%s_traffic.json" % tag), "w"), indent=1)

@@ -83,24 +83,33 @@ __global__ __launch_bounds__( 256 ) void lowres_kernel( const PutDesc *descs, Pu
     __builtin_memcpy( planes + plane_elems + o, oh, 4 * sizeof( T ) );
     __builtin_memcpy( planes + 2 * (size_t)plane_elems + o, ov, 4 * sizeof( T ) );
     __builtin_memcpy( planes + 3 * (size_t)plane_elems + o, oc, 4 * sizeof( T ) );
-    // the strip copy read by the search (me_search.h): strip k of a plane = columns 8k .. 8k+15 of every row, 16 samples per
-    // row; the four planes' strips follow the row-major planes, each twice the size of its plane
-    T *strips = planes + 4 * (size_t)plane_elems;
-    const size_t strip_elems = (size_t)( lh + 2 * LA_PAD ) * 16, strip_plane = 2 * (size_t)plane_elems;
-    const int c = X4 * 4, k = c >> 3;
-    const size_t so = k * strip_elems + (size_t)Y * 16 + ( c & 7 );
-    __builtin_memcpy( strips + so, o0, 4 * sizeof( T ) );
-    __builtin_memcpy( strips + strip_plane + so, oh, 4 * sizeof( T ) );
-    __builtin_memcpy( strips + 2 * strip_plane + so, ov, 4 * sizeof( T ) );
-    __builtin_memcpy( strips + 3 * strip_plane + so, oc, 4 * sizeof( T ) );
-    if( k )
-    {
-        const size_t sp = so - strip_elems + 8; // the same columns as the right half of the strip before
-        __builtin_memcpy( strips + sp, o0, 4 * sizeof( T ) );
-        __builtin_memcpy( strips + strip_plane + sp, oh, 4 * sizeof( T ) );
-        __builtin_memcpy( strips + 2 * strip_plane + sp, ov, 4 * sizeof( T ) );
-        __builtin_memcpy( strips + 3 * strip_plane + sp, oc, 4 * sizeof( T ) );
-    }
+}
+
+// The strip copy of the four planes read by the search (me_search.h): strip k of a plane = columns 8k .. 8k+15 of every row, 16
+// samples per row, rows one after the other; the strips of plane p start 4 + 2p planes behind the row-major planes.  A wave copies 64
+// consecutive rows of one strip: the lanes read the 16 samples of their row out of the row-major plane lowres_kernel has just written
+// (L2 hits) and the wave's store is one contiguous kilobyte.  (Writing the strips from lowres_kernel itself, in the 4-sample pieces
+// its threads own, reached memory as 13 MB per 1080p frame for 7.5 MB of planes: profiles/r02_traffic.json.)
+template <typename T>
+__global__ __launch_bounds__( 256 ) void strips_kernel( const PutDesc *descs, PutDesc single, int plane_elems, int stride, int rows )
+{
+    const PutDesc D = descs ? descs[blockIdx.z] : single;
+    const T *__restrict__ planes = (const T *)D.planes;
+    T *__restrict__ strips = (T *)D.planes + 4 * (size_t)plane_elems;
+    const int n_strips = stride >> 3;
+    const int sidx = blockIdx.y * 4 + ( threadIdx.x >> 6 ), p = sidx / n_strips, k = sidx - p * n_strips;
+    const int Y = blockIdx.x * 64 + ( threadIdx.x & 63 );
+    if( p >= 4 || Y >= rows )
+        return;
+    const T *src = planes + (size_t)p * plane_elems + (size_t)Y * stride + 8 * k;
+    T v[16];
+    __builtin_memcpy( v, src, 8 * sizeof( T ) );
+    if( k + 1 < n_strips )
+        __builtin_memcpy( v + 8, src + 8, 8 * sizeof( T ) );
+    else
+        for( int i = 8; i < 16; i++ ) v[i] = 0; // beyond the plane: never part of a block a search may read
+    T *dst = strips + 2 * (size_t)p * plane_elems + ( (size_t)k * rows + Y ) * 16;
+    __builtin_memcpy( dst, v, 16 * sizeof( T ) );
 }
 
 // plain x264_mc_functions_t.frame_init_lowres_core signature (mc.h:326-327): no borders, caller's layout

@@ -285,6 +285,7 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
     const int zero_bits = P.cost_mv[0];
 
     int r1 = 0, r2 = 0, r3 = 0; // packed vectors this group found in the last three steps
+    int keep_mv = 0, keep_cost = 0; // lanes 0..3 of a group: the result of the block with x % 4 == lane, until the four leave together
     const int n_steps = W + 2 * ( ME_ROWS - 1 );
     for( int t = 0; t < n_steps; t++ )
     {
@@ -411,14 +412,24 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
             pf_t3 = PF_NOW();
 #endif
             // blocks slicetype_slice_cost never visits (slicetype.c:823-833) keep zero vectors (frame.c:283-285)
-            if( ( lane & 7 ) == 0 )
+            // Results leave four blocks at a time: lane j (< 4) of the group keeps the block with x % 4 == j, and when the group
+            // reaches x % 4 == 0 the four lanes store four neighbouring granules (one 32-byte sector) and four costs.  One 8-byte
+            // and one 4-byte store per block dirtied a sector each, and with a step every ~10 us the L2 had usually written a
+            // sector back before its next store arrived (0.58 MB written per search for 98 KB of results).  The top row of the
+            // wave is the exception: the wave above is waiting for its vectors, so they go out at once (sc1), only its costs wait.
+            const int packed = ( mvx & 0xFFFF ) | ( mvy << 16 );
+            const int j = lane & 7;
+            if( j == ( bx & 3 ) )
             {
-                const unsigned long long gv = ( (unsigned long long)D.tag << 32 ) | (unsigned)( ( mvx & 0xFFFF ) | ( mvy << 16 ) );
-                if( g == ME_ROWS - 1 )
-                    __hip_atomic_store( D.mvq + xy, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ); // read by the wave above
-                else
-                    D.mvq[xy] = gv;
-                D.costs[xy] = cost;
+                keep_mv = packed; keep_cost = cost;
+            }
+            if( g == ME_ROWS - 1 && j == 0 )
+                __hip_atomic_store( D.mvq + xy, ( (unsigned long long)D.tag << 32 ) | (unsigned)packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+            if( !( bx & 3 ) && j < 4 && bx + j < W )
+            {
+                if( g != ME_ROWS - 1 )
+                    D.mvq[xy + j] = ( (unsigned long long)D.tag << 32 ) | (unsigned)keep_mv;
+                D.costs[xy + j] = keep_cost;
             }
         }
         r3 = r2; r2 = r1;

@@ -467,6 +467,10 @@ static int launch_ingest_t( x264hip_ctx *ctx, const PutDesc *descs_dev, const Pu
     const float bias = 14.427f + 2 * ( p.bit_depth - 8 );
     dim3 grd( ( ( ctx->lw + 2 * LA_PAD ) / 4 + 255 ) / 256, ctx->lh + 2 * LA_PAD, n );
     lowres_kernel<T><<<grd, 256, 0, ctx->stream>>>( descs_dev, single, p.width, p.height, P.plane_elems, P.stride, ctx->lw, ctx->lh );
+    {
+        const int rows = ctx->lh + 2 * LA_PAD;
+        strips_kernel<T><<<dim3( ( rows + 63 ) / 64, ( 4 * ( P.stride / 8 ) + 3 ) / 4, n ), 256, 0, ctx->stream>>>( descs_dev, single, P.plane_elems, P.stride, rows );
+    }
     const int wg_per_frame = ( ( ctx->n_mb + AQ_MBS_PER_WG - 1 ) / AQ_MBS_PER_WG + 7 ) / 8 * 8; // a multiple of 8: contiguous runs of macroblocks per XCD
     aq_kernel<T><<<dim3( wg_per_frame, 1, n ), 64, 0, ctx->stream>>>( descs_dev, single, p.width, p.height, P.mb_w, P.mb_h, strength, bias, ctx->luts_dev,
                                                                        p.aq_mode, 1.f / ( 1 << ( 2 * ( p.bit_depth - 8 ) ) ), p.chroma_format );
