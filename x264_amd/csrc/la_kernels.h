@@ -569,7 +569,7 @@ struct CellArgs
     int *row_satds, *row_satds_intra;
     int *acc;                     // [5]: cost_est, cost_est_aq, intra_mbs, intra_cost_est, intra_cost_est_aq
     int *blk;                     // [n_mb] scratch: final block cost | b_intra << 30, input of cell_reduce_kernel
-    const void *fenc0, *ref0_0, *ref1_0; // plane-0 origins (B cells)
+    const void *fenc0, *ref0_0, *ref1_0; // B cells: plane-0 origin of the source frame, strip copies (me_search.h) of the two references
     int sums_only;                // reduce only: intra sums of a frame, no maps written (speculative [0][0] sums)
     int pad_;
 };
@@ -724,11 +724,51 @@ __global__ __launch_bounds__( 256 ) void cell_p_kernel( LaP P, const CellArgs *d
     cell_finish( P, A, xy, bcost, list_used );
 }
 
-// B cells: a wave walks CELLB_BPW consecutive blocks of a row; groups 0..2 evaluate the three bidirectional
-// candidates of a block in parallel.  The per-block words (vectors, list costs) are fetched once by lanes
-// 0..CELLB_BPW-1 and read back with v_readlane, the results leave through the same lanes in one store, and the
-// block loop is unrolled so that the pixel loads of neighbouring blocks are in flight together.
+// B cells: a wave walks CELLB_BPW consecutive blocks of a row, two at a time.  Geometry of the search (me_search.h): a block is 8 lanes,
+// a lane one 8-pixel row, reference samples from the strip copies; the eight lane groups are 2 blocks x 4 candidate slots (direct-style
+// vectors, zero vectors, searched vectors twice -- three of the four are used).  The per-block words (vectors, list costs) are fetched
+// once by lanes 0..CELLB_BPW-1 and read back with v_readlane, the candidate vectors are computed as scalars for both blocks and
+// handed to the lanes by one select per component, the results leave through the same lanes in one store.
 #define CELLB_BPW 8
+struct CellBVec
+{
+    int d0x, d0y, d1x, d1y, m0x, m0y, m1x, m1y;
+    bool dmv_nz, mv_nz;
+};
+// candidate vectors of block bx (wave uniform): slicetype.c:560-600
+__device__ __forceinline__ CellBVec cellb_vectors( const LaP &P, const CellArgs &A, int bx, int smin_y, int smax_y, int range, int wr, int w0, int w1 )
+{
+    CellBVec v;
+    const int smin_x = imax2( 4 * ( -8 * bx - 12 ), -range ), smax_x = imin2( 4 * ( 8 * ( P.mb_w - bx - 1 ) + 12 ), range - 1 );
+    v.d0x = v.d0y = v.d1x = v.d1y = 0;
+    if( A.ref1_l0_valid )
+    {
+        const int rx = (int)(short)( wr & 0xFFFF ), ry = wr >> 16;
+        v.d0x = ( rx * A.dist_scale_factor + 128 ) >> 8;
+        v.d0y = ( ry * A.dist_scale_factor + 128 ) >> 8;
+        v.d1x = v.d0x - rx; v.d1y = v.d0y - ry;
+        v.d0x = iclip3( v.d0x, smin_x, smax_x ); v.d0y = iclip3( v.d0y, smin_y, smax_y );
+        v.d1x = iclip3( v.d1x, smin_x, smax_x ); v.d1y = iclip3( v.d1y, smin_y, smax_y );
+        if( P.subme <= 1 ) { v.d0x &= ~1; v.d0y &= ~1; v.d1x &= ~1; v.d1y &= ~1; }
+    }
+    v.m0x = (int)(short)( w0 & 0xFFFF ); v.m0y = w0 >> 16; v.m1x = (int)(short)( w1 & 0xFFFF ); v.m1y = w1 >> 16;
+    v.dmv_nz = ( v.d0x | v.d0y | v.d1x | v.d1y ) != 0; v.mv_nz = ( v.m0x | v.m0y | v.m1x | v.m1y ) != 0;
+    return v;
+}
+// the decision for one block out of its three candidate costs and the two list costs (slicetype.c:601-652)
+__device__ __forceinline__ void cellb_decide( const LaP &P, const CellBVec &v, int c_dmv, int c_zero, int c_mv, int c0, int c1, int &bcost, int &list_used )
+{
+    bcost = COST_MAX_I; list_used = 0;
+    if( c_dmv < bcost ) { bcost = c_dmv; list_used = 3; }                // the scaled vectors of the list-1 reference (zero without them)
+    if( v.dmv_nz && c_zero < bcost ) { bcost = c_zero; list_used = 3; }  // zero vectors, if those were not zero
+    if( c0 < bcost ) { bcost = c0; list_used = 1; }
+    if( c1 < bcost ) { bcost = c1; list_used = 2; }
+    if( v.mv_nz )
+    {
+        const int c = 5 * P.lambda + c_mv;
+        if( c < bcost ) { bcost = c; list_used = 3; }
+    }
+}
 template <typename T>
 __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *descs, CellArgs single )
 {
@@ -736,10 +776,12 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
     const int lane = lane_id();
     const int by = blockIdx.y, bx0 = blockIdx.x * CELLB_BPW;
     const int nb = imin2( CELLB_BPW, P.mb_w - bx0 );
-    const int g = lane >> 4, l = lane & 15, q = l >> 2;
+    const int half = lane >> 5, slot = ( lane >> 3 ) & 3, l = lane & 7; // block of the pair, candidate slot, row of the block
     const int border = LA_PAD * P.stride + LA_PAD;
-    const T *fbase = (const T *)A.fenc0 - border, *r0base = (const T *)A.ref0_0 - border, *r1base = (const T *)A.ref1_0 - border;
-    const int row_off = border + 8 * by * P.stride + ( ( q >> 1 ) * 4 + ( l & 3 ) ) * P.stride + ( q & 1 ) * 4;
+    const T *fbase = (const T *)A.fenc0 - border, *s0base = (const T *)A.ref0_0, *s1base = (const T *)A.ref1_0; // strips of the two references
+    const int strip_elems = ( P.plane_elems / P.stride ) * 16;
+    const int row16 = ( 8 * by + l + LA_PAD ) << 4;
+    const int frow = border + ( 8 * by + l ) * P.stride;
     const int bipred_weight = P.weighted_bipred ? 64 - ( A.dist_scale_factor >> 2 ) : 32;
     const int range = 2 * P.mv_range;
     const int smin_y = imax2( 4 * ( -8 * by - 12 ), -range ), smax_y = imin2( 4 * ( 8 * ( P.mb_h - by - 1 ) + 12 ), range - 1 );
@@ -753,69 +795,50 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
         c0v = A.costs0[xy_mine]; c1v = A.costs1[xy_mine];
     }
     int my_cost = 0, my_list = 0;
-#pragma unroll 2
-    for( int k = 0; k < nb; k++ )
+    for( int k = 0; k < nb; k += 2 )
     {
-        const int bx = bx0 + k;
-        const int smin_x = imax2( 4 * ( -8 * bx - 12 ), -range ), smax_x = imin2( 4 * ( 8 * ( P.mb_w - bx - 1 ) + 12 ), range - 1 );
-        // candidate vectors (wave uniform)
-        int d0x = 0, d0y = 0, d1x = 0, d1y = 0;
-        if( A.ref1_l0_valid )
-        {
-            const int w = __builtin_amdgcn_readlane( wrv, k );
-            const int rx = (int)(short)( w & 0xFFFF ), ry = w >> 16;
-            d0x = ( rx * A.dist_scale_factor + 128 ) >> 8;
-            d0y = ( ry * A.dist_scale_factor + 128 ) >> 8;
-            d1x = d0x - rx; d1y = d0y - ry;
-            d0x = iclip3( d0x, smin_x, smax_x ); d0y = iclip3( d0y, smin_y, smax_y );
-            d1x = iclip3( d1x, smin_x, smax_x ); d1y = iclip3( d1y, smin_y, smax_y );
-            if( P.subme <= 1 ) { d0x &= ~1; d0y &= ~1; d1x &= ~1; d1y &= ~1; }
-        }
-        const int w0 = __builtin_amdgcn_readlane( w0v, k ), w1 = __builtin_amdgcn_readlane( w1v, k );
-        const int m0x = (int)(short)( w0 & 0xFFFF ), m0y = w0 >> 16, m1x = (int)(short)( w1 & 0xFFFF ), m1y = w1 >> 16;
-        const bool dmv_nz = ( d0x | d0y | d1x | d1y ) != 0, mv_nz = ( m0x | m0y | m1x | m1y ) != 0;
-        // group g's pair: 0 -> direct-style (dmv), 1 -> zero, 2/3 -> searched vectors
-        int ax = sel4( g, d0x, 0, m0x, m0x ), ay = sel4( g, d0y, 0, m0y, m0y );
-        int cx = sel4( g, d1x, 0, m1x, m1x ), cy = sel4( g, d1y, 0, m1y, m1y );
+        const int k1 = imin2( k + 1, nb - 1 ); // an odd row end costs its last block twice
+        const CellBVec va = cellb_vectors( P, A, bx0 + k, smin_y, smax_y, range, __builtin_amdgcn_readlane( wrv, k ), __builtin_amdgcn_readlane( w0v, k ),
+                                           __builtin_amdgcn_readlane( w1v, k ) );
+        const CellBVec vb = cellb_vectors( P, A, bx0 + k1, smin_y, smax_y, range, __builtin_amdgcn_readlane( wrv, k1 ), __builtin_amdgcn_readlane( w0v, k1 ),
+                                           __builtin_amdgcn_readlane( w1v, k1 ) );
+        // this lane's pair: slot 0 -> direct-style (dmv), 1 -> zero, 2/3 -> searched vectors, of block `half`
+        int ax = sel4( slot, half ? vb.d0x : va.d0x, 0, half ? vb.m0x : va.m0x, half ? vb.m0x : va.m0x );
+        int ay = sel4( slot, half ? vb.d0y : va.d0y, 0, half ? vb.m0y : va.m0y, half ? vb.m0y : va.m0y );
+        int cx = sel4( slot, half ? vb.d1x : va.d1x, 0, half ? vb.m1x : va.m1x, half ? vb.m1x : va.m1x );
+        int cy = sel4( slot, half ? vb.d1y : va.d1y, 0, half ? vb.m1y : va.m1y, half ? vb.m1y : va.m1y );
         if( P.subme <= 1 ) { ax &= ~1; ay &= ~1; cx &= ~1; cy &= ~1; } // half-pel plane pick (slicetype.c:582-589)
-        const int lane_off = row_off + 8 * bx;
-        const Px4 f = load_px4_at( fbase, lane_off );
-        const Px4 ra = qpel_px4_at( r0base, P.plane_elems, P.stride, lane_off, ax, ay );
-        const Px4 rb = qpel_px4_at( r1base, P.plane_elems, P.stride, lane_off, cx, cy );
-        Px4 pred;
+        const int bx = bx0 + ( half ? k1 : k );
+        const int cx0 = 8 * bx + LA_PAD;
+        const Px8 f = load_px8_at( fbase, frow + 8 * bx );
+        const Px8 ra = qpel_px8_strips( s0base, P.plane_elems, strip_elems, cx0, row16, ax, ay );
+        const Px8 rb = qpel_px8_strips( s1base, P.plane_elems, strip_elems, cx0, row16, cx, cy );
+        Px8 pred;
         if( bipred_weight == 32 )
-            pred = avg_px4( ra, rb, (const T *)nullptr );
+        {
+            pred.lo = avg_px4( ra.lo, rb.lo, (const T *)nullptr ); pred.hi = avg_px4( ra.hi, rb.hi, (const T *)nullptr );
+        }
         else
         {
-            int va[4], vb[4];
-            px4_to_ints( ra, va ); px4_to_ints( rb, vb );
 #pragma unroll
-            for( int i = 0; i < 4; i++ )
-                va[i] = iclip3( ( va[i] * bipred_weight + vb[i] * ( 64 - bipred_weight ) + 32 ) >> 6, 0, P.pixel_max );
-            pred = px4_from_ints( va, sizeof( T ) == 1 );
+            for( int h = 0; h < 2; h++ )
+            {
+                int pa[4], pb[4];
+                px4_to_ints( h ? ra.hi : ra.lo, pa ); px4_to_ints( h ? rb.hi : rb.lo, pb );
+#pragma unroll
+                for( int i = 0; i < 4; i++ )
+                    pa[i] = iclip3( ( pa[i] * bipred_weight + pb[i] * ( 64 - bipred_weight ) + 32 ) >> 6, 0, P.pixel_max );
+                ( h ? pred.hi : pred.lo ) = px4_from_ints( pa, sizeof( T ) == 1 );
+            }
         }
-        const int v = block_cost8x8<T>( f, pred, P.mbcmp_satd );
-        int bcost = COST_MAX_I, list_used = 0;
-        {
-            int c = __builtin_amdgcn_readlane( v, 0 );
-            if( c < bcost ) { bcost = c; list_used = 3; }
-        }
-        if( dmv_nz )
-        {
-            int c = __builtin_amdgcn_readlane( v, 16 );
-            if( c < bcost ) { bcost = c; list_used = 3; }
-        }
-        {
-            int c0 = __builtin_amdgcn_readlane( c0v, k ), c1 = __builtin_amdgcn_readlane( c1v, k );
-            if( c0 < bcost ) { bcost = c0; list_used = 1; }
-            if( c1 < bcost ) { bcost = c1; list_used = 2; }
-        }
-        if( mv_nz )
-        {
-            int c = 5 * P.lambda + __builtin_amdgcn_readlane( v, 32 );
-            if( c < bcost ) { bcost = c; list_used = 3; }
-        }
+        const int v = block_cost8<T>( f, pred, P.mbcmp_satd );
+        int bcost, list_used;
+        cellb_decide( P, va, __builtin_amdgcn_readlane( v, 0 ), __builtin_amdgcn_readlane( v, 8 ), __builtin_amdgcn_readlane( v, 16 ),
+                      __builtin_amdgcn_readlane( c0v, k ), __builtin_amdgcn_readlane( c1v, k ), bcost, list_used );
         if( lane == k ) { my_cost = bcost; my_list = list_used; }
+        cellb_decide( P, vb, __builtin_amdgcn_readlane( v, 32 ), __builtin_amdgcn_readlane( v, 40 ), __builtin_amdgcn_readlane( v, 48 ),
+                      __builtin_amdgcn_readlane( c0v, k1 ), __builtin_amdgcn_readlane( c1v, k1 ), bcost, list_used );
+        if( lane == k1 ) { my_cost = bcost; my_list = list_used; }
     }
     if( lane < nb )
         cell_finish( P, A, xy_mine, my_cost, my_list );

@@ -832,7 +832,7 @@ static CellArgs make_cell( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_
         {
             A.mvq1 = b.mvq[1][d1 - 1]; A.costs1 = b.mvcost[1][d1 - 1];
             A.ref1_l0 = A.ref1_l0_valid ? f1.mvq[0][d0 + d1 - 1] : nullptr;
-            A.fenc0 = plane_origin<T>( ctx, b, 0 ); A.ref0_0 = plane_origin<T>( ctx, f0, 0 ); A.ref1_0 = plane_origin<T>( ctx, f1, 0 );
+            A.fenc0 = plane_origin<T>( ctx, b, 0 ); A.ref0_0 = f0.planes + 4 * ctx->plane_bytes; A.ref1_0 = f1.planes + 4 * ctx->plane_bytes;
         }
     }
     A.intra_cost = b.lowres_costs; // cell [0][0] (frame.c:283)
