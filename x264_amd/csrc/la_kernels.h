@@ -160,28 +160,42 @@ __global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc
     // XCD-aware placement: workgroup b runs on XCD b % 8 (observed dispatch order, used for locality only), so the macroblocks are
     // dealt to the XCDs in eight contiguous runs -- the 128-byte lines that horizontally adjacent macroblocks share are then fetched
     // into ONE L2 instead of eight (the launch is 1-D, a multiple of 8 workgroups per frame)
-    // one-wave workgroups, AQ_MBS_PER_WG macroblocks one after the other (a workgroup per macroblock is dispatch-bound)
+    // one-wave workgroups, AQ_MBS_PER_WG macroblocks each, in three phases so that nothing waits for memory one macroblock at a
+    // time: (1) the pixel loads of all macroblocks, (2) their wave sums, (3) the per-macroblock finish with one LANE per
+    // macroblock (table look-ups and stores of the eight macroblocks in parallel instead of eight times on lane 0)
     const int lane = lane_id();
     const int wg = (int)( blockIdx.x & 7 ) * (int)( gridDim.x >> 3 ) + (int)( blockIdx.x >> 3 );
     const int ly = lane >> 2, lx = ( lane & 3 ) * 4;
+    const int first = wg * AQ_MBS_PER_WG, n_here = imin2( AQ_MBS_PER_WG, mb_w * mb_h - first );
+    if( n_here <= 0 )
+        return; // wave-uniform
+    __shared__ unsigned sh_s[AQ_MBS_PER_WG], sh_q[AQ_MBS_PER_WG], sh_e[AQ_MBS_PER_WG];
+    unsigned ps[AQ_MBS_PER_WG], pq[AQ_MBS_PER_WG];
+#pragma unroll
     for( int it = 0; it < AQ_MBS_PER_WG; it++ )
     {
-    const int logical = wg * AQ_MBS_PER_WG + it;
-    if( logical >= mb_w * mb_h )
-        return; // wave-uniform
-    const int mx = logical % mb_w, my = logical / mb_w;
-    unsigned s = 0, q = 0;
-    {
+        const int logical = first + imin2( it, n_here - 1 );
+        const int mx = logical % mb_w, my = logical / mb_w;
         const T *row = luma + (size_t)imin2( 16 * my + ly, height - 1 ) * stride;
+        unsigned s = 0, q = 0;
 #pragma unroll
         for( int i = 0; i < 4; i++ )
         {
             unsigned v = row[imin2( 16 * mx + lx + i, width - 1 )];
             s += v; q += v * v;
         }
+        ps[it] = s; pq[it] = q;
     }
-    s = wave_sum_u32( s ); q = wave_sum_u32( q );
-    unsigned energy = q - (unsigned)( ( (unsigned long long)s * s ) >> 8 );
+#pragma unroll
+    for( int it = 0; it < AQ_MBS_PER_WG; it++ )
+    {
+        const unsigned s = wave_sum_u32( ps[it] ), q = wave_sum_u32( pq[it] );
+        if( lane == 0 )
+        {
+            sh_s[it] = s; sh_q[it] = q;
+            sh_e[it] = q - (unsigned)( ( (unsigned long long)s * s ) >> 8 );
+        }
+    }
     if( cb )
     {
         // chroma part of ac_energy_mb (ratecontrol.c:238-296): per plane an 8x8 block with shift 6 (4:2:0), 8x16 with shift 7
@@ -189,21 +203,29 @@ __global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc
         const int c444 = chroma_format == 3, c420 = chroma_format < 2;
         const int cw = c444 ? width : ( width + 1 ) >> 1, ch = c420 ? ( height + 1 ) >> 1 : height;
         const int lbw = c444 ? 4 : 3, bw = 1 << lbw, bh = c420 ? 8 : 16, n = ( bw * bh ) >> 6, shift = c444 ? 8 : c420 ? 6 : 7;
-        unsigned sb = 0, qb = 0, sr = 0, qr = 0;
-        for( int k = 0; k < n; k++ )
+        for( int it = 0; it < n_here; it++ )
         {
-            const int idx = lane + 64 * k;
-            const int cy = imin2( bh * my + ( idx >> lbw ), ch - 1 ), cx = imin2( bw * mx + ( idx & ( bw - 1 ) ), cw - 1 );
-            const unsigned vb = cb[(size_t)cy * cstride + cx], vr = cr[(size_t)cy * cstride + cx];
-            sb += vb; qb += vb * vb; sr += vr; qr += vr * vr;
+            const int logical = first + it;
+            const int mx = logical % mb_w, my = logical / mb_w;
+            unsigned sb = 0, qb = 0, sr = 0, qr = 0;
+            for( int k = 0; k < n; k++ )
+            {
+                const int idx = lane + 64 * k;
+                const int cy = imin2( bh * my + ( idx >> lbw ), ch - 1 ), cx = imin2( bw * mx + ( idx & ( bw - 1 ) ), cw - 1 );
+                const unsigned vb = cb[(size_t)cy * cstride + cx], vr = cr[(size_t)cy * cstride + cx];
+                sb += vb; qb += vb * vb; sr += vr; qr += vr * vr;
+            }
+            sb = wave_sum_u32( sb ); qb = wave_sum_u32( qb ); sr = wave_sum_u32( sr ); qr = wave_sum_u32( qr );
+            if( lane == 0 )
+                sh_e[it] += qb - (unsigned)( ( (unsigned long long)sb * sb ) >> shift ) + qr - (unsigned)( ( (unsigned long long)sr * sr ) >> shift );
         }
-        sb = wave_sum_u32( sb ); qb = wave_sum_u32( qb ); sr = wave_sum_u32( sr ); qr = wave_sum_u32( qr );
-        energy += qb - (unsigned)( ( (unsigned long long)sb * sb ) >> shift );
-        energy += qr - (unsigned)( ( (unsigned long long)sr * sr ) >> shift );
     }
-    if( lane == 0 )
+    __syncthreads(); // one wave: orders the LDS words
+    if( lane < n_here )
     {
-        mb_sums[my * mb_w + mx] = make_uint2( s, q );
+        const int xy = first + lane; // raster index = my * mb_w + mx
+        const unsigned energy = sh_e[lane];
+        mb_sums[xy] = make_uint2( sh_s[lane], sh_q[lane] );
         int out = 256;
         float qp_adj = 0.f;
         if( aq_on && aq_mode >= 2 )
@@ -216,10 +238,10 @@ __global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc
                 x = __fmul_rn( x, depth_corr );
             x = __fadd_rn( x, 1.f );
             const float r4 = sqrtf( sqrtf( x ) );
-            qp_offset_aq[my * mb_w + mx] = r4;
-            qp_offset[my * mb_w + mx] = sqrtf( r4 ); // sqrtf: correctly rounded (the __fsqrt_rn intrinsic is the 1-ulp native one)
-            inv_qscale[my * mb_w + mx] = 256;
-            continue;
+            qp_offset_aq[xy] = r4;
+            qp_offset[xy] = sqrtf( r4 ); // sqrtf: correctly rounded (the __fsqrt_rn intrinsic is the 1-ulp native one)
+            inv_qscale[xy] = 256;
+            return;
         }
         if( aq_on )
         {
@@ -231,10 +253,9 @@ __global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc
             int i = (int)__fadd_rn( __fmul_rn( qp_adj, -64.f / 6.f ), 512.5f );
             out = i < 0 ? 0 : i > 1023 ? 0xffff : ( ( luts->exp2_lut[i & 63] + 256 ) << ( i >> 6 ) >> 8 );
         }
-        inv_qscale[my * mb_w + mx] = (uint16_t)out;
-        qp_offset_aq[my * mb_w + mx] = qp_adj; // f_qp_offset_aq = f_qp_offset = qp_adj (ratecontrol.c:392-396)
-        qp_offset[my * mb_w + mx] = qp_adj;
-    }
+        inv_qscale[xy] = (uint16_t)out;
+        qp_offset_aq[xy] = qp_adj; // f_qp_offset_aq = f_qp_offset = qp_adj (ratecontrol.c:392-396)
+        qp_offset[xy] = qp_adj;
     }
 }
 
@@ -418,17 +439,36 @@ __global__ __launch_bounds__( 64 ) void intra_kernel( LaP P, const PutDesc *desc
     const int g = lane >> 4, l = lane & 15, q = l >> 2;
     const int tx = ( q & 1 ) * 4, row = ( q >> 1 ) * 4 + ( l & 3 );
     const int n_modes = P.subme > 1 ? 10 : 3;
+    // the neighbour sample and the four pixels this lane contributes, requested one block ahead: a trip works out of registers
+    // and LDS while the next block's loads are in flight
+    T edge_next = 0;
+    Px4 f_next;
+    auto request = [&]( int it, T &edge, Px4 &f )
+    {
+        const int lg = imin2( wg * INTRA_BLOCKS_PER_WG + it, n_blocks - 1 );
+        const T *src = fenc0 + 8 * ( ( lg / P.mb_w ) * P.stride + lg % P.mb_w );
+        edge = 0;
+        if( lane < 17 )
+            edge = src[-P.stride + lane - 1];
+        else if( lane >= 32 && lane < 40 )
+            edge = src[( lane - 32 ) * P.stride - 1];
+        f = load_px4( src + row * P.stride + tx );
+    };
+    request( 0, edge_next, f_next );
     for( int it = 0; it < INTRA_BLOCKS_PER_WG; it++ )
     {
         const int logical = wg * INTRA_BLOCKS_PER_WG + it;
         const bool live = logical < n_blocks;
         const int lg = live ? logical : n_blocks - 1; // dead trips redo the last block and write nothing
         const int bx = lg % P.mb_w, by = lg / P.mb_w;
-        const T *src = fenc0 + 8 * ( by * P.stride + bx );
+        const T edge = edge_next;
+        const Px4 f = f_next;
+        if( it + 1 < INTRA_BLOCKS_PER_WG )
+            request( it + 1, edge_next, f_next );
         if( lane < 17 )
-            E.top[lane] = src[-P.stride + lane - 1];
+            E.top[lane] = edge;
         else if( lane >= 32 && lane < 40 )
-            E.left[lane - 32] = src[( lane - 32 ) * P.stride - 1];
+            E.left[lane - 32] = edge;
         __syncthreads();
         if( lane < 17 )
         {
@@ -447,7 +487,6 @@ __global__ __launch_bounds__( 64 ) void intra_kernel( LaP P, const PutDesc *desc
             E.fl[y] = v;
         }
         __syncthreads();
-        const Px4 f = load_px4( src + row * P.stride + tx );
         int best = COST_MAX_I;
         for( int m0 = 0; m0 < n_modes; m0 += 4 )
         {
