@@ -1,4 +1,4 @@
-"""The block-search logic the device search kernel runs per 16-lane group (x264_amd/csrc/me_logic.h: x264_me_search_ref DIA / HEX +
+"""The block-search logic the device search kernel runs per 8-lane group (x264_amd/csrc/me_logic.h: x264_me_search_ref DIA / HEX +
 refine_subpel as slicetype_mb_cost drives them, candidates costed one after the other and applied in the reference's order)
 compiled for the host with a scalar evaluator (tests/tools/me_logic_host.cpp) and compared, vector for vector and cost for cost,
 with the oracle's whole-field search, which is pinned against the reference.  Covers the neighbour/predictor list, the limits,
