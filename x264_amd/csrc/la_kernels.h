@@ -1299,6 +1299,7 @@ __device__ __forceinline__ void mbt_propagate_mb( const MbtOpDev &o, int *ref0, 
 
 #define MBT_UNROLL 4
 #define MBT_WGS 8
+#define MBT_THREADS 1024
 // All MBT_WGS workgroups walk the same step list; where a step reads what earlier steps accumulated they meet at a
 // counter barrier (monotonic counter, relaxed agent-scope polling, bounded spin).  Everything exchanged between
 // steps lives in the propagate accumulators, which are only touched with agent-scope atomics, so no fences are

@@ -152,6 +152,8 @@ struct x264hip_ctx
     // no longer speculated (a later request is still served, on demand).
     uint32_t field_req[2][X264HIP_BFRAME_MAX + 1] = { { 0 } };
     uint32_t cell_req[( X264HIP_BFRAME_MAX + 2 ) * ( X264HIP_BFRAME_MAX + 2 )] = { 0 };
+    uint32_t field_spec[2][X264HIP_BFRAME_MAX + 1] = { { 0 } };  // speculative searches / cells per class (X264HIP_TRACE_CLASSES prints them next to the requests)
+    uint32_t cell_spec[( X264HIP_BFRAME_MAX + 2 ) * ( X264HIP_BFRAME_MAX + 2 )] = { 0 };
     uint32_t n_requests = 0;
     static const uint32_t LEARN_REQUESTS = 400;
 };
@@ -246,6 +248,19 @@ extern "C" void x264hip_close( x264hip_ctx *ctx )
 {
     if( !ctx ) return;
     x264hip_mc_unbind( ctx );
+    if( getenv( "X264HIP_TRACE_CLASSES" ) )
+    {
+        const int bf = ctx->p.bframes, ns = bf + 2;
+        fprintf( stderr, "x264hip classes (requested / speculated): fields" );
+        for( int l = 0; l < 2; l++ )
+            for( int d = 0; d <= bf; d++ )
+                fprintf( stderr, " L%d d%d %u/%u", l, d + 1, ctx->field_req[l][d], ctx->field_spec[l][d] );
+        fprintf( stderr, " | cells" );
+        for( int d0 = 0; d0 <= bf + 1; d0++ )
+            for( int d1 = 0; d0 + d1 <= bf + 1; d1++ )
+                fprintf( stderr, " (%d,%d) %u/%u", d0, d1, ctx->cell_req[d0 * ns + d1], ctx->cell_spec[d0 * ns + d1] );
+        fprintf( stderr, "\n" );
+    }
 #ifdef ME_PROFILE
     if( ctx->me_prof )
     {
@@ -923,6 +938,7 @@ extern "C" int x264hip_prefetch_ex( x264hip_ctx *ctx, const int *slots, const in
             if( learned && !ctx->field_req[list][dm1] ) continue; // a class this caller never asks for
             if( flags & X264HIP_PREFETCH_CELLS_ONLY ) continue;     // the fields come from elsewhere (x264hip_import_field)
             b.field_prefetched[list][dm1] = 1;
+            ctx->field_spec[list][dm1]++;
             reqs.push_back( SearchReq{ slots[i], slots[j], list, dm1, none } );
         }
     }
@@ -973,6 +989,7 @@ extern "C" int x264hip_prefetch_ex( x264hip_ctx *ctx, const int *slots, const in
                 }
                 e.valid = 1; e.batch = ctx->batch_serial + 1; e.variant = (unsigned char)variant;
                 e.tag0 = b.field_tag[0][d0 - 1]; e.tag1 = t1; e.tagr = tr;
+                ctx->cell_spec[d0 * nstride + d1]++;
                 cells.push_back( SpecCell{ slots[j0], slots[d1 ? j1 : i], slots[i], d0, d1, 0, variant } );
             }
         }
@@ -1260,13 +1277,14 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
     // letting every workgroup pull it from pinned host memory into LDS 8070 -- sixteen PCIe read bursts per call cost more
     // than one small copy.  The staging path stays available for experiments.
     static const bool stage_lds = getenv( "X264HIP_MBT_STAGE_LDS" ) != nullptr;
+    static const int mbt_threads = getenv( "X264HIP_MBT_THREADS" ) ? std::max( 64, std::min( 1024, atoi( getenv( "X264HIP_MBT_THREADS" ) ) & ~63 ) ) : MBT_THREADS;
     static const int mbt_wgs = getenv( "X264HIP_MBT_WGS" ) ? std::max( 1, std::min( 64, atoi( getenv( "X264HIP_MBT_WGS" ) ) ) ) : MBT_WGS;
     if( table_bytes <= 48 * 1024 && stage_lds )
-        mbtree_kernel<<<mbt_wgs, 1024, table_bytes, ctx->stream2>>>( ctx->P, dh, n, 1, ctx->luts_dev, ctx->mbt_bar + 4 * r );
+        mbtree_kernel<<<mbt_wgs, mbt_threads, table_bytes, ctx->stream2>>>( ctx->P, dh, n, 1, ctx->luts_dev, ctx->mbt_bar + 4 * r );
     else
     {
         HIPCK( hipMemcpyAsync( ctx->mbt_dev[r], dh, table_bytes, hipMemcpyHostToDevice, ctx->stream2 ) );
-        mbtree_kernel<<<mbt_wgs, 1024, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], n, 0, ctx->luts_dev, ctx->mbt_bar + 4 * r );
+        mbtree_kernel<<<mbt_wgs, mbt_threads, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], n, 0, ctx->luts_dev, ctx->mbt_bar + 4 * r );
     }
     HIPCK( hipGetLastError() );
     }
