@@ -341,9 +341,8 @@ __global__ __launch_bounds__( 1024 ) void aq_reduce_kernel( const PutDesc *descs
 }
 
 // ---- lowres intra cost (encoder/slicetype.c:714-757; predictors common/predict.c:221-308,632-884) ----
-// One wave per 8x8 block, 4 prediction modes per pass (one per 16-lane group).  The 17+8 neighbours
-// and their low-pass filtered versions sit in LDS; every lane derives its 4 predicted pixels directly
-// from the H.264 per-pixel formulas.
+// Four 8x8 blocks per wave (one per 16-lane group), one prediction mode per pass.  The 17+8 neighbours of a block and their
+// low-pass filtered versions sit in LDS; every lane derives its 4 predicted pixels directly from the H.264 per-pixel formulas.
 struct IntraEdges
 {
     int top[18];  // top[i+1] = p[i,-1], i = -1..15 (top[0] is the corner); top[17] pad
@@ -420,10 +419,13 @@ __device__ __forceinline__ int intra_pred_px( const IntraEdges &E, int mode, int
 #undef LL
 }
 
-// One-wave workgroups, every wave walks INTRA_BLOCKS_PER_WG consecutive blocks (a workgroup per block made the launch
-// dispatch-bound: 1.3 M workgroups for 160 frames of 1080p -- 28 -> 13 us per frame alone).  The workgroups stay one wave wide on
-// purpose: beside the search kernel, whose waves fill the register files, a single free wave slot is all such a workgroup needs
-// (four-wave workgroups measured 5 % slower end to end with eight contexts in flight).
+// One-wave workgroups, every wave walks INTRA_BLOCKS_PER_WG consecutive blocks, FOUR AT A TIME: a 16-lane group owns one block (the
+// Px4 geometry: a lane holds 4 pixels of a row) and all four groups evaluate the SAME prediction mode in a pass, so the mode switch
+// is uniform across the wave.  (One block per wave with four modes side by side ran the four case bodies of a pass one after the
+// other at a quarter of the lanes each: ten serial case bodies per block, against ten per FOUR blocks here.)  The workgroups stay
+// one wave wide on purpose: beside the search kernel, whose waves fill the register files, a single free wave slot is all such a
+// workgroup needs (four-wave workgroups measured 5 % slower end to end with eight contexts in flight).  A workgroup per block made
+// the launch dispatch-bound (1.3 M workgroups for 160 frames of 1080p).
 #define INTRA_BLOCKS_PER_WG 8
 template <typename T>
 __global__ __launch_bounds__( 64 ) void intra_kernel( LaP P, const PutDesc *descs, PutDesc single )
@@ -431,7 +433,7 @@ __global__ __launch_bounds__( 64 ) void intra_kernel( LaP P, const PutDesc *desc
     const PutDesc D = descs ? descs[blockIdx.z] : single;
     const T *__restrict__ fenc0 = (const T *)D.planes + LA_PAD * P.stride + LA_PAD;
     uint16_t *intra_cost = D.intra_cost;
-    __shared__ IntraEdges E;
+    __shared__ IntraEdges E4[4];
     const int lane = lane_id();
     // XCD-aware placement as in aq_kernel: each XCD gets a contiguous run of workgroups (INTRA_BLOCKS_PER_WG consecutive blocks each)
     const int n_blocks = P.mb_w * P.mb_h;
@@ -439,70 +441,44 @@ __global__ __launch_bounds__( 64 ) void intra_kernel( LaP P, const PutDesc *desc
     const int g = lane >> 4, l = lane & 15, q = l >> 2;
     const int tx = ( q & 1 ) * 4, row = ( q >> 1 ) * 4 + ( l & 3 );
     const int n_modes = P.subme > 1 ? 10 : 3;
-    // the neighbour sample and the four pixels this lane contributes, requested one block ahead: a trip works out of registers
-    // and LDS while the next block's loads are in flight
-    T edge_next = 0;
-    Px4 f_next;
-    auto request = [&]( int it, T &edge, Px4 &f )
+    IntraEdges &E = E4[g];
+    for( int it = 0; it < INTRA_BLOCKS_PER_WG; it += 4 )
     {
-        const int lg = imin2( wg * INTRA_BLOCKS_PER_WG + it, n_blocks - 1 );
-        const T *src = fenc0 + 8 * ( ( lg / P.mb_w ) * P.stride + lg % P.mb_w );
-        edge = 0;
-        if( lane < 17 )
-            edge = src[-P.stride + lane - 1];
-        else if( lane >= 32 && lane < 40 )
-            edge = src[( lane - 32 ) * P.stride - 1];
-        f = load_px4( src + row * P.stride + tx );
-    };
-    request( 0, edge_next, f_next );
-    for( int it = 0; it < INTRA_BLOCKS_PER_WG; it++ )
-    {
-        const int logical = wg * INTRA_BLOCKS_PER_WG + it;
+        const int logical = wg * INTRA_BLOCKS_PER_WG + it + g;
         const bool live = logical < n_blocks;
-        const int lg = live ? logical : n_blocks - 1; // dead trips redo the last block and write nothing
+        const int lg = live ? logical : n_blocks - 1; // dead groups redo the last block and write nothing
         const int bx = lg % P.mb_w, by = lg / P.mb_w;
-        const T edge = edge_next;
-        const Px4 f = f_next;
-        if( it + 1 < INTRA_BLOCKS_PER_WG )
-            request( it + 1, edge_next, f_next );
-        if( lane < 17 )
-            E.top[lane] = edge;
-        else if( lane >= 32 && lane < 40 )
-            E.left[lane - 32] = edge;
+        const T *src = fenc0 + 8 * ( by * P.stride + bx );
+        // the 17 + 8 neighbours of the group's block: lane l fetches top[l] and, lanes 0..8, top[16] / left[0..7]
+        E.top[l] = src[-P.stride + l - 1];
+        if( l == 8 )
+            E.top[16] = src[-P.stride + 15];
+        else if( l < 8 )
+            E.left[l] = src[l * P.stride - 1];
+        const Px4 f = load_px4( src + row * P.stride + tx );
         __syncthreads();
-        if( lane < 17 )
         {
-            // ft[lane] = p'[lane-1,-1]: corner, t0..t15 (predict.c:632-675 with all neighbours available)
-            int i = lane - 1, v;
-            if( i < 0 ) v = f3( E.top[1], E.top[0], E.left[0] );
-            else if( i == 15 ) v = ( E.top[15] + 3 * E.top[16] + 2 ) >> 2;
-            else v = f3( E.top[i], E.top[i + 1], E.top[i + 2] );
-            E.ft[lane] = v;
-        }
-        else if( lane >= 32 && lane < 40 )
-        {
-            int y = lane - 32, v;
-            if( y == 7 ) v = ( E.left[6] + 3 * E.left[7] + 2 ) >> 2;
-            else v = f3( y == 0 ? E.top[0] : E.left[y - 1], E.left[y], E.left[y + 1] );
-            E.fl[y] = v;
+            // ft[l] = p'[l-1,-1]: corner, t0..t15 (predict.c:632-675 with all neighbours available); lanes 0..8 also ft[16] / fl[0..7]
+            const int i = l - 1;
+            E.ft[l] = i < 0 ? f3( E.top[1], E.top[0], E.left[0] ) : f3( E.top[i], E.top[i + 1], E.top[i + 2] );
+            if( l == 8 )
+                E.ft[16] = ( E.top[15] + 3 * E.top[16] + 2 ) >> 2;
+            else if( l < 8 )
+                E.fl[l] = l == 7 ? ( E.left[6] + 3 * E.left[7] + 2 ) >> 2 : f3( l == 0 ? E.top[0] : E.left[l - 1], E.left[l], E.left[l + 1] );
         }
         __syncthreads();
         int best = COST_MAX_I;
-        for( int m0 = 0; m0 < n_modes; m0 += 4 )
+        for( int mode = 0; mode < n_modes; mode++ )
         {
-            const int mode = imin2( m0 + g, 9 );
             int pr[4];
 #pragma unroll
             for( int i = 0; i < 4; i++ )
                 pr[i] = intra_pred_px( E, mode, tx + i, row, P.pixel_max );
             const Px4 r = px4_from_ints( pr, false );
-            int v = P.mbcmp_satd ? reduce16( satd_partial_px4( f, r ) ) >> 1 : reduce16( sad_partial16( f, r ) );
-#pragma unroll
-            for( int k = 0; k < 4; k++ )
-                if( m0 + k < n_modes )
-                    best = imin2( best, __builtin_amdgcn_readlane( v, 16 * k ) );
+            const int v = P.mbcmp_satd ? reduce16( satd_partial_px4( f, r ) ) >> 1 : reduce16( sad_partial16( f, r ) );
+            best = imin2( best, v );
         }
-        if( lane == 0 && live )
+        if( l == 0 && live )
             intra_cost[by * P.mb_w + bx] = (uint16_t)( ( ( best + 5 * P.lambda ) >> P.depth_shift ) + 4 );
         __syncthreads(); // the edges are rewritten by the next trip
     }
