@@ -741,49 +741,13 @@ __global__ __launch_bounds__( 256 ) void cell_p_kernel( LaP P, const CellArgs *d
 
 // B cells: a wave walks CELLB_BPW consecutive blocks of a row, two at a time.  Geometry of the search (me_search.h): a block is 8 lanes,
 // a lane one 8-pixel row, reference samples from the strip copies; the eight lane groups are 2 blocks x 4 candidate slots (direct-style
-// vectors, zero vectors, searched vectors twice -- three of the four are used).  The per-block words (vectors, list costs) are fetched
-// once by lanes 0..CELLB_BPW-1 and read back with v_readlane, the candidate vectors are computed as scalars for both blocks and
-// handed to the lanes by one select per component, the results leave through the same lanes in one store.
+// vectors, zero vectors, searched vectors twice -- three of the four are used).  Everything per block that is not pixel work is
+// vector code on lane k for block bx0 + k, done once for the eight blocks of the wave: fetching the vectors and list costs,
+// deriving the candidate vectors (slicetype.c:560-600), and the final choice (:601-652); the pixel lanes pick their block's vectors
+// up with ds_bpermute and hand the three candidate costs back the same way.  (As scalar code per block -- v_readlane, SALU clips
+// and compares -- the kernel issued more scalar than vector instructions.)
 #define CELLB_BPW 8
-struct CellBVec
-{
-    int d0x, d0y, d1x, d1y, m0x, m0y, m1x, m1y;
-    bool dmv_nz, mv_nz;
-};
-// candidate vectors of block bx (wave uniform): slicetype.c:560-600
-__device__ __forceinline__ CellBVec cellb_vectors( const LaP &P, const CellArgs &A, int bx, int smin_y, int smax_y, int range, int wr, int w0, int w1 )
-{
-    CellBVec v;
-    const int smin_x = imax2( 4 * ( -8 * bx - 12 ), -range ), smax_x = imin2( 4 * ( 8 * ( P.mb_w - bx - 1 ) + 12 ), range - 1 );
-    v.d0x = v.d0y = v.d1x = v.d1y = 0;
-    if( A.ref1_l0_valid )
-    {
-        const int rx = (int)(short)( wr & 0xFFFF ), ry = wr >> 16;
-        v.d0x = ( rx * A.dist_scale_factor + 128 ) >> 8;
-        v.d0y = ( ry * A.dist_scale_factor + 128 ) >> 8;
-        v.d1x = v.d0x - rx; v.d1y = v.d0y - ry;
-        v.d0x = iclip3( v.d0x, smin_x, smax_x ); v.d0y = iclip3( v.d0y, smin_y, smax_y );
-        v.d1x = iclip3( v.d1x, smin_x, smax_x ); v.d1y = iclip3( v.d1y, smin_y, smax_y );
-        if( P.subme <= 1 ) { v.d0x &= ~1; v.d0y &= ~1; v.d1x &= ~1; v.d1y &= ~1; }
-    }
-    v.m0x = (int)(short)( w0 & 0xFFFF ); v.m0y = w0 >> 16; v.m1x = (int)(short)( w1 & 0xFFFF ); v.m1y = w1 >> 16;
-    v.dmv_nz = ( v.d0x | v.d0y | v.d1x | v.d1y ) != 0; v.mv_nz = ( v.m0x | v.m0y | v.m1x | v.m1y ) != 0;
-    return v;
-}
-// the decision for one block out of its three candidate costs and the two list costs (slicetype.c:601-652)
-__device__ __forceinline__ void cellb_decide( const LaP &P, const CellBVec &v, int c_dmv, int c_zero, int c_mv, int c0, int c1, int &bcost, int &list_used )
-{
-    bcost = COST_MAX_I; list_used = 0;
-    if( c_dmv < bcost ) { bcost = c_dmv; list_used = 3; }                // the scaled vectors of the list-1 reference (zero without them)
-    if( v.dmv_nz && c_zero < bcost ) { bcost = c_zero; list_used = 3; }  // zero vectors, if those were not zero
-    if( c0 < bcost ) { bcost = c0; list_used = 1; }
-    if( c1 < bcost ) { bcost = c1; list_used = 2; }
-    if( v.mv_nz )
-    {
-        const int c = 5 * P.lambda + c_mv;
-        if( c < bcost ) { bcost = c; list_used = 3; }
-    }
-}
+__device__ __forceinline__ int pack_mv( int x, int y ) { return ( x & 0xFFFF ) | ( y << 16 ); }
 template <typename T>
 __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *descs, CellArgs single )
 {
@@ -800,30 +764,38 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
     const int bipred_weight = P.weighted_bipred ? 64 - ( A.dist_scale_factor >> 2 ) : 32;
     const int range = 2 * P.mv_range;
     const int smin_y = imax2( 4 * ( -8 * by - 12 ), -range ), smax_y = imin2( 4 * ( 8 * ( P.mb_h - by - 1 ) + 12 ), range - 1 );
-    // lane k holds the words of block bx0 + k
-    int w0v = 0, w1v = 0, wrv = 0, c0v = 0, c1v = 0;
-    const int xy_mine = by * P.mb_w + bx0 + imin2( lane, nb - 1 );
+    // lane k: the words and the candidate vectors of block bx0 + k
+    const int bx_mine = bx0 + imin2( lane, nb - 1 ), xy_mine = by * P.mb_w + bx_mine;
+    int pm0 = 0, pm1 = 0, pd0 = 0, pd1 = 0, c0v = 0, c1v = 0;
     if( lane < nb )
     {
-        w0v = (int)(unsigned)A.mvq0[xy_mine]; w1v = (int)(unsigned)A.mvq1[xy_mine];
-        if( A.ref1_l0_valid ) wrv = (int)(unsigned)A.ref1_l0[xy_mine];
+        pm0 = (int)(unsigned)A.mvq0[xy_mine]; pm1 = (int)(unsigned)A.mvq1[xy_mine];
         c0v = A.costs0[xy_mine]; c1v = A.costs1[xy_mine];
+        if( A.ref1_l0_valid )
+        {
+            const int wr = (int)(unsigned)A.ref1_l0[xy_mine];
+            const int smin_x = imax2( 4 * ( -8 * bx_mine - 12 ), -range ), smax_x = imin2( 4 * ( 8 * ( P.mb_w - bx_mine - 1 ) + 12 ), range - 1 );
+            const int rx = (int)(short)( wr & 0xFFFF ), ry = wr >> 16;
+            int d0x = ( rx * A.dist_scale_factor + 128 ) >> 8, d0y = ( ry * A.dist_scale_factor + 128 ) >> 8;
+            int d1x = d0x - rx, d1y = d0y - ry;
+            d0x = iclip3( d0x, smin_x, smax_x ); d0y = iclip3( d0y, smin_y, smax_y );
+            d1x = iclip3( d1x, smin_x, smax_x ); d1y = iclip3( d1y, smin_y, smax_y );
+            if( P.subme <= 1 ) { d0x &= ~1; d0y &= ~1; d1x &= ~1; d1y &= ~1; }
+            pd0 = pack_mv( d0x, d0y ); pd1 = pack_mv( d1x, d1y );
+        }
     }
+    const bool dmv_nz = ( pd0 | pd1 ) != 0, mv_nz = ( pm0 | pm1 ) != 0;
     int my_cost = 0, my_list = 0;
     for( int k = 0; k < nb; k += 2 )
     {
         const int k1 = imin2( k + 1, nb - 1 ); // an odd row end costs its last block twice
-        const CellBVec va = cellb_vectors( P, A, bx0 + k, smin_y, smax_y, range, __builtin_amdgcn_readlane( wrv, k ), __builtin_amdgcn_readlane( w0v, k ),
-                                           __builtin_amdgcn_readlane( w1v, k ) );
-        const CellBVec vb = cellb_vectors( P, A, bx0 + k1, smin_y, smax_y, range, __builtin_amdgcn_readlane( wrv, k1 ), __builtin_amdgcn_readlane( w0v, k1 ),
-                                           __builtin_amdgcn_readlane( w1v, k1 ) );
-        // this lane's pair: slot 0 -> direct-style (dmv), 1 -> zero, 2/3 -> searched vectors, of block `half`
-        int ax = sel4( slot, half ? vb.d0x : va.d0x, 0, half ? vb.m0x : va.m0x, half ? vb.m0x : va.m0x );
-        int ay = sel4( slot, half ? vb.d0y : va.d0y, 0, half ? vb.m0y : va.m0y, half ? vb.m0y : va.m0y );
-        int cx = sel4( slot, half ? vb.d1x : va.d1x, 0, half ? vb.m1x : va.m1x, half ? vb.m1x : va.m1x );
-        int cy = sel4( slot, half ? vb.d1y : va.d1y, 0, half ? vb.m1y : va.m1y, half ? vb.m1y : va.m1y );
+        const int kk = half ? k1 : k;
+        // this lane's pair: slot 0 -> direct-style (dmv), 1 -> zero, 2/3 -> searched vectors, of block kk
+        const int qd0 = __shfl( pd0, kk ), qd1 = __shfl( pd1, kk ), qm0 = __shfl( pm0, kk ), qm1 = __shfl( pm1, kk );
+        const int pa = slot == 0 ? qd0 : slot == 1 ? 0 : qm0, pc = slot == 0 ? qd1 : slot == 1 ? 0 : qm1;
+        int ax = (int)(short)( pa & 0xFFFF ), ay = pa >> 16, cx = (int)(short)( pc & 0xFFFF ), cy = pc >> 16;
         if( P.subme <= 1 ) { ax &= ~1; ay &= ~1; cx &= ~1; cy &= ~1; } // half-pel plane pick (slicetype.c:582-589)
-        const int bx = bx0 + ( half ? k1 : k );
+        const int bx = bx0 + kk;
         const int cx0 = 8 * bx + LA_PAD;
         const Px8 f = load_px8_at( fbase, frow + 8 * bx );
         const Px8 ra = qpel_px8_strips( s0base, P.plane_elems, strip_elems, cx0, row16, ax, ay );
@@ -838,22 +810,29 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
 #pragma unroll
             for( int h = 0; h < 2; h++ )
             {
-                int pa[4], pb[4];
-                px4_to_ints( h ? ra.hi : ra.lo, pa ); px4_to_ints( h ? rb.hi : rb.lo, pb );
+                int va[4], vb[4];
+                px4_to_ints( h ? ra.hi : ra.lo, va ); px4_to_ints( h ? rb.hi : rb.lo, vb );
 #pragma unroll
                 for( int i = 0; i < 4; i++ )
-                    pa[i] = iclip3( ( pa[i] * bipred_weight + pb[i] * ( 64 - bipred_weight ) + 32 ) >> 6, 0, P.pixel_max );
-                ( h ? pred.hi : pred.lo ) = px4_from_ints( pa, sizeof( T ) == 1 );
+                    va[i] = iclip3( ( va[i] * bipred_weight + vb[i] * ( 64 - bipred_weight ) + 32 ) >> 6, 0, P.pixel_max );
+                ( h ? pred.hi : pred.lo ) = px4_from_ints( va, sizeof( T ) == 1 );
             }
         }
         const int v = block_cost8<T>( f, pred, P.mbcmp_satd );
-        int bcost, list_used;
-        cellb_decide( P, va, __builtin_amdgcn_readlane( v, 0 ), __builtin_amdgcn_readlane( v, 8 ), __builtin_amdgcn_readlane( v, 16 ),
-                      __builtin_amdgcn_readlane( c0v, k ), __builtin_amdgcn_readlane( c1v, k ), bcost, list_used );
-        if( lane == k ) { my_cost = bcost; my_list = list_used; }
-        cellb_decide( P, vb, __builtin_amdgcn_readlane( v, 32 ), __builtin_amdgcn_readlane( v, 40 ), __builtin_amdgcn_readlane( v, 48 ),
-                      __builtin_amdgcn_readlane( c0v, k1 ), __builtin_amdgcn_readlane( c1v, k1 ), bcost, list_used );
-        if( lane == k1 ) { my_cost = bcost; my_list = list_used; }
+        // lanes k and k1 collect the three candidate costs of their block (lane groups 0..2 of half 0 / half 1) and choose
+        const int base = ( lane == k1 && k1 != k ) ? 32 : 0;
+        const int c_dmv = __shfl( v, base ), c_zero = __shfl( v, base + 8 ), c_mv = __shfl( v, base + 16 );
+        int bcost = COST_MAX_I, list_used = 0;
+        if( c_dmv < bcost ) { bcost = c_dmv; list_used = 3; }              // the scaled vectors of the list-1 reference (zero without them)
+        if( dmv_nz && c_zero < bcost ) { bcost = c_zero; list_used = 3; }  // zero vectors, if those were not zero
+        if( c0v < bcost ) { bcost = c0v; list_used = 1; }
+        if( c1v < bcost ) { bcost = c1v; list_used = 2; }
+        if( mv_nz )
+        {
+            const int c = 5 * P.lambda + c_mv;
+            if( c < bcost ) { bcost = c; list_used = 3; }
+        }
+        if( lane == k || lane == k1 ) { my_cost = bcost; my_list = list_used; }
     }
     if( lane < nb )
         cell_finish( P, A, xy_mine, my_cost, my_list );
