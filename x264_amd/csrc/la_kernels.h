@@ -138,12 +138,11 @@ struct AqLuts
     unsigned char exp2_lut[64];
 };
 
+// sum over the wave, the same (wave-uniform) value in every lane: DPP within the 16-lane rows, then the four row totals as scalars
 __device__ __forceinline__ unsigned wave_sum_u32( unsigned v )
 {
-#pragma unroll
-    for( int o = 32; o > 0; o >>= 1 )
-        v += __shfl_xor( v, o );
-    return v;
+    const int r = reduce16( (int)v );
+    return (unsigned)( __builtin_amdgcn_readlane( r, 0 ) + __builtin_amdgcn_readlane( r, 16 ) + __builtin_amdgcn_readlane( r, 32 ) + __builtin_amdgcn_readlane( r, 48 ) );
 }
 
 template <typename T>
@@ -178,10 +177,19 @@ __global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc
         const int mx = logical % mb_w, my = logical / mb_w;
         const T *row = luma + (size_t)imin2( 16 * my + ly, height - 1 ) * stride;
         unsigned s = 0, q = 0;
+        T px[4];
+        if( 16 * mx + 15 < width ) // wave-uniform: the macroblock lies inside the picture, one 4-sample load per lane
+            __builtin_memcpy( px, row + 16 * mx + lx, 4 * sizeof( T ) );
+        else
+        {
+#pragma unroll
+            for( int i = 0; i < 4; i++ )
+                px[i] = row[imin2( 16 * mx + lx + i, width - 1 )];
+        }
 #pragma unroll
         for( int i = 0; i < 4; i++ )
         {
-            unsigned v = row[imin2( 16 * mx + lx + i, width - 1 )];
+            const unsigned v = px[i];
             s += v; q += v * v;
         }
         ps[it] = s; pq[it] = q;
