@@ -659,12 +659,7 @@ __global__ __launch_bounds__( 1024 ) void cell_reduce_kernel( LaP P, const CellA
                 if( scored ) { t[0] += bcost; t[1] += bcost_aq; }
             }
         }
-#pragma unroll
-        for( int o = 32; o > 0; o >>= 1 )
-        {
-            row += __shfl_xor( row, o );
-            row_i += __shfl_xor( row_i, o );
-        }
+        row = (int)wave_sum_u32( (unsigned)row ); row_i = (int)wave_sum_u32( (unsigned)row_i );
         if( lane == 0 )
         {
             if( !A.is_intra_only && !A.sums_only ) A.row_satds[by] = row;
@@ -674,9 +669,7 @@ __global__ __launch_bounds__( 1024 ) void cell_reduce_kernel( LaP P, const CellA
 #pragma unroll
     for( int k = 0; k < 5; k++ )
     {
-#pragma unroll
-        for( int o = 32; o > 0; o >>= 1 )
-            t[k] += __shfl_xor( t[k], o );
+        t[k] = (int)wave_sum_u32( (unsigned)t[k] );
         if( lane == 0 ) sh[k][wave] = t[k];
     }
     __syncthreads();
