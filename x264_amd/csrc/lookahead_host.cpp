@@ -25,6 +25,7 @@ static inline bool auto_or_b( int t ) { return t == T_AUTO || is_b( t ); }
 
 const int BMAX = X264HIP_BFRAME_MAX;
 const int LOOKAHEAD_MAX = 250; // X264_LOOKAHEAD_MAX, common/base.h:140
+const int LA_PREFETCH_CHUNK = 64; // frames of read-ahead per speculative submission (X264HIP_LA_CHUNK overrides it for experiments)
 const uint64_t COST_MAX64 = 1ULL << 60;
 
 // adds the wall time of its scope to a statistics slot (x264hip_lookahead_stats)
@@ -970,7 +971,7 @@ struct Lookahead
     {
         pending_prefetch.clear();
         if( !be.prefetch ) return;
-        const int chunk = 64;
+        static const int chunk = getenv( "X264HIP_LA_CHUNK" ) ? ( atoi( getenv( "X264HIP_LA_CHUNK" ) ) > 2 ? atoi( getenv( "X264HIP_LA_CHUNK" ) ) : 2 ) : LA_PREFETCH_CHUNK;
         const int reach = (int)next.size() < i_delay + 2 ? (int)next.size() : i_delay + 2;
         int submitted = 0;
         while( submitted < (int)next.size() && next[submitted]->prefetch_submitted ) submitted++;
