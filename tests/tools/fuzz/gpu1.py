@@ -1,4 +1,4 @@
-"""Device fuzz: tests/tools/fuzz/gpu1.py <seed> <n>   (needs a GPU and oracle/_ref).
+"""Device fuzz: tests/tools/fuzz/gpu1.py <seed> <n> [big]   (needs a GPU and oracle/_ref; "big": 540p ... 1080p pictures).
 Random picture sizes (odd widths, non-mod-16, tiny), bit depths, presets and lookahead options; the whole lookahead on the device
 (lib.Lookahead, paced or batched) against the real reference build (refharness.Ref.lookahead_run): slice types, every cost cell that
 was evaluated, f_qp_offset.  Exercises the search, cell, intra, AQ, weight and MB-tree kernels over geometries the fixed tests do
@@ -17,6 +17,8 @@ from x264_amd.synth import make_clip
 rng = np.random.default_rng(int(sys.argv[1]))
 bad = 0
 SIZES = [(96, 80), (100, 70), (48, 32), (176, 144), (64, 48), (128, 272), (200, 120), (352, 288), (416, 240), (330, 190), (640, 360), (34, 34)]
+if len(sys.argv) > 3 and sys.argv[3] == "big":
+    SIZES = [(960, 540), (1280, 720), (1000, 562), (1920, 1080), (1366, 768), (720, 1280)]
 for t in range(int(sys.argv[2])):
     W, H = SIZES[int(rng.integers(0, len(SIZES)))]
     depth = int(rng.choice([8, 8, 10]))
