@@ -2,7 +2,9 @@
 refine_subpel as slicetype_mb_cost drives them, candidates costed one after the other and applied in the reference's order)
 compiled for the host with a scalar evaluator (tests/tools/me_logic_host.cpp) and compared, vector for vector and cost for cost,
 with the oracle's whole-field search, which is pinned against the reference.  Covers the neighbour/predictor list, the limits,
-weights, lookahead bands and the unvisited edge ring; the device evaluator itself is covered by the -m gpu parity tests."""
+weights, lookahead bands and the unvisited edge ring; the device evaluator itself is covered by the -m gpu parity tests.
+Every case also runs with an evaluator that reads the reference out of the STRIP copy of the planes through
+x264_amd/csrc/strip_layout.h, the index arithmetic the kernels share: the layout is checked here as well."""
 import ctypes as C
 import os
 import subprocess
@@ -21,10 +23,11 @@ OUT = os.path.join(HERE, "tools", "_build", "libme_logic_host.so")
 
 def _lib():
     hdr = os.path.join(ROOT, "x264_amd", "csrc", "me_logic.h")
+    hdr2 = os.path.join(ROOT, "x264_amd", "csrc", "strip_layout.h")
     from oracle import oraclelib
     oraclelib.build()
     olib = os.path.join(ROOT, "oracle", "liboracle.so")
-    if not os.path.exists(OUT) or max(os.path.getmtime(SRC), os.path.getmtime(hdr), os.path.getmtime(olib)) > os.path.getmtime(OUT):
+    if not os.path.exists(OUT) or max(os.path.getmtime(SRC), os.path.getmtime(hdr), os.path.getmtime(hdr2), os.path.getmtime(olib)) > os.path.getmtime(OUT):
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "x264_amd", "csrc"), "-I" + os.path.join(ROOT, "oracle"),
                                "-o", OUT, SRC, olib, "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
@@ -44,12 +47,12 @@ CONFIGS = {
 }
 
 
-def _field(L, o, cfg, fenc, ref, wt=None, wplane=None):
+def _field(L, o, cfg, fenc, ref, wt=None, wplane=None, strips=False):
     n = cfg.mb_w * cfg.mb_h
     mvs = np.zeros((n, 2), np.int16)
     costs = np.zeros(n, np.int32)
     evals = np.zeros(2, np.int64)
-    fn = getattr(L, "mel%d_search_field" % o.d)
+    fn = getattr(L, "mel%d_search_field%s" % (o.d, "_strips" if strips else ""))  # _strips: reference samples out of the strip copy
     fn.restype = None
     fn(C.byref(cfg), C.c_void_p(o.origin(fenc[0])), o._plane_ptrs(ref), C.c_void_p(o.origin(wplane)) if wplane is not None else None,
        C.byref(wt) if wt is not None else None, mvs.ctypes.data_as(C.c_void_p), costs.ctypes.data_as(C.c_void_p), evals.ctypes.data_as(C.c_void_p))
@@ -68,11 +71,12 @@ def test_logic_matches_oracle_field(cfgname, clipname):
                      mbcmp_satd=mbcmp, fpelcmp_satd=fpelcmp)
     pl = [o.lowres_init(cfg, f) for f in frames]
     for (b, r) in ((1, 0), (2, 0), (0, 2)):
-        m, c, ev = _field(L, o, cfg, pl[b], pl[r])
         wm, wc = o.search_field(cfg, pl[b], pl[r])
-        assert np.array_equal(m, wm), (b, r, int((m != wm).any(1).sum()))
-        assert np.array_equal(c, wc), (b, r)
-        assert ev.sum() > 0 or clipname == "static"
+        for strips in (False, True):
+            m, c, ev = _field(L, o, cfg, pl[b], pl[r], strips=strips)
+            assert np.array_equal(m, wm), (b, r, strips, int((m != wm).any(1).sum()))
+            assert np.array_equal(c, wc), (b, r, strips)
+            assert ev.sum() > 0 or clipname == "static"
 
 
 @pytest.mark.parametrize("cfgname", ["hex_r4", "dia_r2_sad", "hex_10bit"])
@@ -86,9 +90,10 @@ def test_logic_with_weights(cfgname):
     for wt in ((1, 55, 6, 3), (1, 100, 7, -4), (1, 3, 0, -2)):
         w = Weight(*wt)
         wp = o.weight_plane(cfg, pl[0][0], w)
-        m, c, _ = _field(L, o, cfg, pl[2], pl[0], w, wp)
         wm, wc = o.search_field(cfg, pl[2], pl[0], w, wp)
-        assert np.array_equal(m, wm) and np.array_equal(c, wc), wt
+        for strips in (False, True):
+            m, c, _ = _field(L, o, cfg, pl[2], pl[0], w, wp, strips=strips)
+            assert np.array_equal(m, wm) and np.array_equal(c, wc), (wt, strips)
 
 
 @pytest.mark.parametrize("n_slices,do_edges", [(3, 1), (1, 0), (4, 0), (16, 1)])
@@ -100,6 +105,7 @@ def test_logic_bands_and_edge_ring(n_slices, do_edges):
         cfg = o.make_cfg((W + 15) // 16, (H + 15) // 16, me_method=1, subpel_refine=4, me_range=16, mv_range=128, subme=7, mbcmp_satd=1, fpelcmp_satd=0,
                          n_slices=n_slices, do_edges=do_edges)
         pl = [o.lowres_init(cfg, f) for f in frames]
-        m, c, _ = _field(L, o, cfg, pl[1], pl[0])
         wm, wc = o.search_field(cfg, pl[1], pl[0])
-        assert np.array_equal(m, wm) and np.array_equal(c, wc), (W, H)
+        for strips in (False, True):
+            m, c, _ = _field(L, o, cfg, pl[1], pl[0], strips=strips)
+            assert np.array_equal(m, wm) and np.array_equal(c, wc), (W, H, strips)

@@ -108,7 +108,7 @@ __global__ __launch_bounds__( 256 ) void strips_kernel( const PutDesc *descs, Pu
         __builtin_memcpy( v + 8, src + 8, 8 * sizeof( T ) );
     else
         for( int i = 8; i < 16; i++ ) v[i] = 0; // beyond the plane: never part of a block a search may read
-    T *dst = strips + 2 * (size_t)p * plane_elems + ( (size_t)k * rows + Y ) * 16;
+    T *dst = strips + 2 * (size_t)p * plane_elems + strip_layout::row_off( k, Y, rows );
     __builtin_memcpy( dst, v, 16 * sizeof( T ) );
 }
 
@@ -499,13 +499,11 @@ __global__ __launch_bounds__( 256 ) void weight_strips_kernel( const T *__restri
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if( i >= n )
         return;
-    const int Y = i / stride, c = i - Y * stride, k = c >> 3;
-    const size_t strip_elems = (size_t)( n / stride ) * 16;
-    const size_t so = k * strip_elems + (size_t)Y * 16 + ( c & 7 );
+    const int Y = i / stride, c = i - Y * stride, k = c >> 3, rows = n / stride;
     const T v = (T)weight_px( src[i], w, pixel_max );
-    strips[so] = v;
+    strips[strip_layout::row_off( k, Y, rows ) + ( c & 7 )] = v;         // left half of strip k ...
     if( k )
-        strips[so - strip_elems + 8] = v;
+        strips[strip_layout::row_off( k - 1, Y, rows ) + 8 + ( c & 7 )] = v; // ... and right half of strip k - 1
 }
 
 // weight_cost_luma (slicetype.c:191-222): sum over blocks of min( mbcmp, intra_cost ).  256-thread workgroups, four

@@ -39,6 +39,7 @@
 #define ME_MARK( ev, k ) ( ev ).mark( k )
 #endif
 #include "me_logic.h"
+#include "strip_layout.h"
 
 #define ME_ROWS 8
 #define DPP_ROW_HALF_MIRROR 0x141 // lane i of every 8 reads lane 7 - i
@@ -99,22 +100,18 @@ __device__ __forceinline__ Px8 load_px8_at( const uint16_t *ubase, int elem_off 
     return r;
 }
 // element offset inside a plane's strips of the 8 samples starting at padded column c of the row whose strip-row offset is row16
+// (strip_layout.h, with the 24-bit multiply of the device)
 __device__ __forceinline__ int strip_off( int c, int row16, int strip_elems )
 {
     return mad24( c >> 3, strip_elems, ( c & 7 ) + row16 );
 }
 // the quarter-pel samples of device_common.h's qpel_px4_at, eight per lane, out of the strip copy: sbase = strips of plane 0,
-// cx0 / row16 = padded column of the block and strip-row offset of this lane's row at zero displacement
+// cx0 / row16 = padded column of the block and strip-row offset of this lane's row at zero displacement (taps: strip_layout.h)
 template <typename T>
 __device__ __forceinline__ Px8 qpel_px8_strips( const T *sbase, int plane_elems, int strip_elems, int cx0, int row16, int mvx, int mvy )
 {
-    const int fx = mvx & 3, fy = mvy & 3;
-    const int sh = 2 * ( fx | ( fy << 2 ) );
-    const unsigned pa = ( 0x54FE5454u >> sh ) & 3u, pb = ( 0xBABABA10u >> sh ) & 3u; // plane pair of the phase (device_common.h)
-    const int o = strip_off( cx0 + ( mvx >> 2 ), row16 + ( ( mvy >> 2 ) << 4 ), strip_elems );
-    // a plane's strips take twice the plane; the partner column is in the same strip (offsets 0..8 + 8 samples <= 16)
-    const int oa = ( (int)__umul24( pa, (unsigned)plane_elems ) << 1 ) + o + ( fy == 3 ? 16 : 0 );
-    const int ob = ( (int)__umul24( pb, (unsigned)plane_elems ) << 1 ) + o + ( fx == 3 );
+    int oa, ob;
+    strip_layout::qpel_taps( plane_elems, strip_off( cx0 + ( mvx >> 2 ), row16 + ( ( mvy >> 2 ) << 4 ), strip_elems ), mvx, mvy, oa, ob );
     const Px8 a = load_px8_at( sbase, oa ), b = load_px8_at( sbase, ob );
     Px8 r;
     r.lo = avg_px4( a.lo, b.lo, (const T *)nullptr ); r.hi = avg_px4( a.hi, b.hi, (const T *)nullptr );
