@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE: compiles x264_amd/csrc/me_logic.h (the block-search logic the device kernel runs per 16-lane group) for
+// TEST INFRASTRUCTURE: compiles x264_amd/csrc/me_logic.h (the block-search logic the device kernel runs per 8-lane group) for
 // the host with a scalar evaluator, so that its candidate order, tie-breaking and early exits can be checked against the oracle's
 // whole-field search (or{8,10}_search_field) without a GPU.  Pixel costs come from the oracle's own metrics (liboracle.so): only
 // the logic is under test here; the device evaluator (loads, DPP reductions) is covered by the -m gpu parity tests.

@@ -5,9 +5,9 @@
 // costed one after the other by an evaluator E and applied in the reference's order with strict '<' -- what its packed
 // (cost << k) + index comparisons implement (me.c:330-333,370-375,912-915).
 //
-// On the device (me_search.h) the "thread" that runs this code is a group of 16 lanes holding one block: E's cost functions
-// reduce over the group with DPP and return the same value in its 16 lanes, so control flow is uniform inside a group and may
-// differ between the four groups of a wave (four block rows searched in lock step).  The costs of one pattern are requested back
+// On the device (me_search.h) the "thread" that runs this code is a group of 8 lanes holding one block: E's cost functions
+// reduce over the group with DPP and return the same value in its 8 lanes, so control flow is uniform inside a group and may
+// differ between the eight groups of a wave (eight block rows searched in lock step).  The costs of one pattern are requested back
 // to back, before any of them is consumed: their loads are in flight together.  On the host (tests/tools/me_logic_host.cpp) E is
 // a plain scalar evaluator, which is how this logic is checked against the oracle without a GPU.
 //
