@@ -14,52 +14,62 @@ from tests.test_golden import check_lookahead_outputs
 from x264_amd import lib
 from x264_amd.synth import make_clip
 
-rng = np.random.default_rng(int(sys.argv[1]))
-bad = 0
 SIZES = [(96, 80), (100, 70), (48, 32), (176, 144), (64, 48), (128, 272), (200, 120), (352, 288), (416, 240), (330, 190), (640, 360), (34, 34)]
-if len(sys.argv) > 3 and sys.argv[3] == "big":
-    SIZES = [(960, 540), (1280, 720), (1000, 562), (1920, 1080), (1366, 768), (720, 1280)]
-for t in range(int(sys.argv[2])):
-    W, H = SIZES[int(rng.integers(0, len(SIZES)))]
-    depth = int(rng.choice([8, 8, 10]))
-    bframes = int(rng.choice([0, 1, 2, 3, 5, 8])); b_adapt = int(rng.integers(0, 3)); pyr = int(rng.integers(0, 3))
-    keyint = int(rng.choice([8, 24, 60, 250])); sc = int(rng.choice([0, 40, 80])); la = int(rng.choice([5, 20, 40, 60]))
-    wp = int(rng.integers(0, 3)); og = int(rng.integers(0, 2)); aqm = int(rng.integers(0, 4)); mbt = int(rng.integers(0, 3) > 0)
-    me = str(rng.choice(["dia", "hex", "umh", "tesa"])); subme = int(rng.choice([0, 1, 2, 4, 7, 9]))
-    preset = str(rng.choice(["medium", "fast", "faster", "veryfast", "slow", "slower"]))
-    if sc == 0 and b_adapt == 0 and mbt:
-        sc = 40  # the reference reads uninitialised intra costs there (known divergences)
-    nf = int(rng.integers(12, 40))
-    opts = "bframes=%d,b-adapt=%d,b-pyramid=%s,keyint=%d,scenecut=%d,rc-lookahead=%d,weightp=%d,open-gop=%d,aq-mode=%d,mbtree=%d,me=%s,subme=%d" % (
-        bframes, b_adapt, ["none", "strict", "normal"][pyr], keyint, sc, la, wp, og, aqm, mbt, me, subme)
-    over = dict(bframes=bframes, b_adapt=b_adapt, b_pyramid=pyr, keyint_max=keyint, scenecut=sc, rc_lookahead=la, weightp=wp, open_gop=og, aq_mode=aqm,
-                mb_tree=mbt, me=me, subme=subme)
-    ckw = dict(seed=int(rng.integers(0, 1000)), scene_cuts=tuple(sorted(int(x) for x in rng.integers(3, nf, size=int(rng.integers(0, 3))))),
-               pan=(int(rng.integers(0, 6)), int(rng.integers(0, 4))))
-    if rng.integers(0, 2):
-        ckw["fade"] = (int(rng.integers(2, max(3, nf - 12))), 10, float(rng.choice([0.6, 1.5])), int(rng.integers(-20, 20)))
-    paced = bool(rng.integers(0, 2))
-    print("TRY", preset, W, H, depth, opts, nf, ckw, "paced" if paced else "batched", flush=True)
-    try:
-        frames = make_clip(W, H, nf, bit_depth=depth, **ckw)
-        r = refharness.Ref(W, H, preset, opts=opts, bit_depth=depth)
+BIG = [(960, 540), (1280, 720), (1000, 562), (1920, 1080), (1366, 768), (720, 1280)]
+
+
+def run(seed, n, big=False, verbose=True):
+    """n random configurations; returns the number that differ from the reference build"""
+    rng = np.random.default_rng(int(seed))
+    bad = 0
+    sizes = BIG if big else SIZES
+    say = print if verbose else (lambda *a, **k: None)
+    for t in range(int(n)):
+        W, H = sizes[int(rng.integers(0, len(sizes)))]
+        depth = int(rng.choice([8, 8, 10]))
+        bframes = int(rng.choice([0, 1, 2, 3, 5, 8])); b_adapt = int(rng.integers(0, 3)); pyr = int(rng.integers(0, 3))
+        keyint = int(rng.choice([8, 24, 60, 250])); sc = int(rng.choice([0, 40, 80])); la = int(rng.choice([5, 20, 40, 60]))
+        wp = int(rng.integers(0, 3)); og = int(rng.integers(0, 2)); aqm = int(rng.integers(0, 4)); mbt = int(rng.integers(0, 3) > 0)
+        me = str(rng.choice(["dia", "hex", "umh", "tesa"])); subme = int(rng.choice([0, 1, 2, 4, 7, 9]))
+        preset = str(rng.choice(["medium", "fast", "faster", "veryfast", "slow", "slower"]))
+        if sc == 0 and b_adapt == 0 and mbt:
+            sc = 40  # the reference reads uninitialised intra costs there (DESIGN.md, known divergences)
+        nf = int(rng.integers(12, 40))
+        opts = "bframes=%d,b-adapt=%d,b-pyramid=%s,keyint=%d,scenecut=%d,rc-lookahead=%d,weightp=%d,open-gop=%d,aq-mode=%d,mbtree=%d,me=%s,subme=%d" % (
+            bframes, b_adapt, ["none", "strict", "normal"][pyr], keyint, sc, la, wp, og, aqm, mbt, me, subme)
+        over = dict(bframes=bframes, b_adapt=b_adapt, b_pyramid=pyr, keyint_max=keyint, scenecut=sc, rc_lookahead=la, weightp=wp, open_gop=og, aq_mode=aqm,
+                    mb_tree=mbt, me=me, subme=subme)
+        ckw = dict(seed=int(rng.integers(0, 1000)), scene_cuts=tuple(sorted(int(x) for x in rng.integers(3, nf, size=int(rng.integers(0, 3))))),
+                   pan=(int(rng.integers(0, 6)), int(rng.integers(0, 4))))
+        if rng.integers(0, 2):
+            ckw["fade"] = (int(rng.integers(2, max(3, nf - 12))), 10, float(rng.choice([0.6, 1.5])), int(rng.integers(-20, 20)))
+        paced = bool(rng.integers(0, 2))
+        desc = (preset, W, H, depth, opts, nf, ckw, "paced" if paced else "batched")
+        say("TRY", *desc, flush=True)
         try:
-            ref = r.lookahead_run(frames, with_qp_offsets=True)
-        finally:
-            r.close()
-        cfg = lib.la_config(W, H, preset, bit_depth=depth, **over)
-        dev = lib.Lookahead(cfg, max_frames=0 if paced else nf + 4)
-        try:
-            outs = dev.run(frames, paced=paced, qp_offsets=True)
-        finally:
-            dev.close()
-        nb = cfg["bframes"] + 2
-        z = dict(idx=ref["idx"], type=ref["type"], cost=ref["cost"][:, :nb, :nb], cost_aq=ref["cost_aq"][:, :nb, :nb], qp_offset=ref["qp_offset"])
-        check_lookahead_outputs(outs, z, nb)
-        ok = True
-    except Exception as e:  # noqa: BLE001
-        print("EXC", repr(e)[:400])
-        ok = False
-    print("OK" if ok else "BAD", flush=True)
-    bad += not ok
-print("bad", bad)
+            frames = make_clip(W, H, nf, bit_depth=depth, **ckw)
+            r = refharness.Ref(W, H, preset, opts=opts, bit_depth=depth)
+            try:
+                ref = r.lookahead_run(frames, with_qp_offsets=True)
+            finally:
+                r.close()
+            cfg = lib.la_config(W, H, preset, bit_depth=depth, **over)
+            dev = lib.Lookahead(cfg, max_frames=0 if paced else nf + 4)
+            try:
+                outs = dev.run(frames, paced=paced, qp_offsets=True)
+            finally:
+                dev.close()
+            nb = cfg["bframes"] + 2
+            z = dict(idx=ref["idx"], type=ref["type"], cost=ref["cost"][:, :nb, :nb], cost_aq=ref["cost_aq"][:, :nb, :nb], qp_offset=ref["qp_offset"])
+            check_lookahead_outputs(outs, z, nb)
+            ok = True
+        except Exception as e:  # noqa: BLE001
+            print("EXC", repr(e)[:400], "in", *desc)
+            ok = False
+        say("OK" if ok else "BAD", flush=True)
+        bad += not ok
+    return bad
+
+
+if __name__ == "__main__":
+    print("bad", run(sys.argv[1], sys.argv[2], big=len(sys.argv) > 3 and sys.argv[3] == "big"))
