@@ -394,7 +394,6 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         const size_t o_planes = off; off += align_up( 12 * ctx->plane_bytes, 256 ); // four row-major planes, then their strip copies (twice the size)
         const size_t o_luma = off; off += align_up( ctx->staging_bytes, 256 );
         const size_t o_inv = off; off += align_up( ctx->n_mb * sizeof( uint16_t ), 256 );
-        const size_t o_sums = off; off += 256;
         const size_t o_mbs = off; off += align_up( ctx->n_mb * sizeof( uint2 ), 256 );
         const size_t o_mvq = off; off += align_up( (size_t)2 * nd * ctx->n_mb * sizeof( unsigned long long ), 256 );
         const size_t o_mvc = off; off += align_up( (size_t)2 * nd * ctx->n_mb * sizeof( int ), 256 );
