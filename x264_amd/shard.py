@@ -117,20 +117,20 @@ class WindowShard:
         width = max(len(x) for x in by_owner)
         if self.world == 1 or width == 0:
             return
-        # one gather of equally sized buffers: [width, n_mb, 2] int32 per rank, padded
+        # one collective of equally sized buffers: [width, n_mb, 2] int32 per rank, padded.  all_gather rather than gather: rank 0 is
+        # the only consumer, but its ingress is the bottleneck either way and all_gather is a collective every
+        # backend implements natively (RCCL ring over xGMI; gloo in the tests)
         buf = torch.zeros((width, self.a.n_mb, 2), dtype=torch.int32, device=self.device if self.device is not None else "cpu")
         if mine:
             buf[:len(mine)] = self.a.export([(r[0], r[2], r[3]) for r in mine])
+        out = [torch.empty_like(buf) for _ in range(self.world)]
+        self.dist.all_gather(out, buf)
         if self.rank == 0:
-            out = [torch.empty_like(buf) for _ in range(self.world)]
-            self.dist.gather(buf, gather_list=out, dst=0)
             for r in range(1, self.world):
                 if by_owner[r]:
                     self.a.import_([(q[0], q[2], q[3]) for q in by_owner[r]], out[r][:len(by_owner[r])])
                     self.stats["fields_imported"] += len(by_owner[r])
             self.stats["bytes_gathered"] += (self.world - 1) * buf.numel() * 4
-        else:
-            self.dist.gather(buf, dst=0)
 
     # ---- rank 0 ----
     def on_prefetch(self, slots, numbers):
