@@ -30,7 +30,7 @@ template <> struct Ops<uint16_t>
 };
 
 template <typename T>
-struct HostEval
+struct HostEval : melogic::ScalarSets<HostEval<T>>
 {
     const or_la_cfg *c;
     const T *fenc;          // block origin in the source plane
@@ -56,7 +56,7 @@ struct HostEval
 // exactly as a lane of the device evaluator does (me_search.h: GroupEval::fpel / qpel)
 #define LA_PAD_HOST 32
 template <typename T>
-struct StripEval
+struct StripEval : melogic::ScalarSets<StripEval<T>>
 {
     const or_la_cfg *c;
     const T *fenc;          // block origin in the source plane (row-major, as on the device)

@@ -886,56 +886,77 @@ __device__ __forceinline__ void load_row8<uint16_t>( const uint16_t *p, Px4 f[2]
 // All seven partition sizes of x264_pixel_function_t.sad / .satd (common/pixel.h:37-59): BW x BH in {16,8,4} x {16,8,4} with
 // 16x4 / 4x16 excluded.  A 16-lane group holds a 16x16 region of the planes, lane = row, four Px4 per lane; a region contains
 // (16/BW) x (16/BH) blocks.  Every block of the field has its own full-pel displacement (mv[block], raster order of blocks).
-template <typename T, int BW, int BH, bool SATD>
+// RR = region rows per lane: a lane walks RR vertically adjacent 16x16 regions with all their loads requested before the first
+// cost is computed (the displacement of a block is itself a load the reference address depends on: with one region per lane the
+// kernel had two dependent memory round trips and 32 bytes in flight per lane; RR = 4 keeps 128).
+template <typename T, int BW, int BH, bool SATD, int RR>
 __global__ __launch_bounds__( 256 ) void pixel_cmp_batch_kernel( const T *__restrict__ fenc, const T *__restrict__ ref, int stride,
-                                                                 int regions_w, const int16_t *__restrict__ mv, int *__restrict__ out )
+                                                                 int regions_w, int regions_h, const int16_t *__restrict__ mv, int *__restrict__ out )
 {
     const int lane = lane_id();
     const int rx0 = ( blockIdx.x * 4 + ( threadIdx.x >> 6 ) ) * 4;
     if( rx0 >= regions_w )
         return; // wave-uniform
-    const int rx = rx0 + ( lane >> 4 ), ry = blockIdx.y, row = lane & 15;
+    const int rx = rx0 + ( lane >> 4 ), row = lane & 15;
     const bool live = rx < regions_w;
     const int rxc = live ? rx : regions_w - 1; // keep every lane in the DPP exchanges
     constexpr int NX = 16 / BW, NY = 16 / BH;  // blocks of a region per row of blocks / per column
     const int bw = regions_w * NX;             // blocks per row of the field
-    const int by = ry * NY + row / BH;
-    const size_t o = (size_t)( ry * 16 + row ) * stride + rxc * 16;
-    Px4 f[4], r[4];
-    load_row16<T>( fenc + o, f );
+    int m[RR][NX];
 #pragma unroll
-    for( int k = 0; k < NX; k++ )
+    for( int q = 0; q < RR; q++ )
     {
-        int m;
-        __builtin_memcpy( &m, mv + 2 * ( by * bw + rxc * NX + k ), 4 );
-        const T *rp = ref + (long)o + ( m >> 16 ) * stride + (int16_t)m + k * BW;
-        if( BW == 16 )
-            load_row16<T>( rp, r );
-        else if( BW == 8 )
-            load_row8<T>( rp, r + 2 * k );
-        else
-            r[k] = load_px4( rp );
+        const int ry = imin2( blockIdx.y * RR + q, regions_h - 1 );
+        const int by = ry * NY + row / BH;
+#pragma unroll
+        for( int k = 0; k < NX; k++ )
+            __builtin_memcpy( &m[q][k], mv + 2 * ( by * bw + rxc * NX + k ), 4 );
     }
-    int part[4];
+    Px4 f[RR][4], r[RR][4];
 #pragma unroll
-    for( int t = 0; t < 4; t++ )
-        part[t] = SATD ? satd_partial_px4( f[t], r[t] ) : sad_partial_px4( f[t], r[t], (const T *)nullptr );
-    // per block of this row of blocks: the 4-sample columns it spans, then the BH rows (quad, half row, row of 16 lanes)
-    int mine = 0;
-#pragma unroll
-    for( int k = 0; k < NX; k++ )
+    for( int q = 0; q < RR; q++ )
     {
-        int v = 0;
+        const int ry = imin2( blockIdx.y * RR + q, regions_h - 1 );
+        const size_t o = (size_t)( ry * 16 + row ) * stride + rxc * 16;
+        load_row16<T>( fenc + o, f[q] );
 #pragma unroll
-        for( int t = 0; t < BW / 4; t++ )
-            v += part[k * ( BW / 4 ) + t];
-        v = reduce_quad( v );
-        if( BH >= 8 ) v += dpp_mov<DPP_ROW_HALF_MIRROR>( v );
-        if( BH == 16 ) v += dpp_mov<DPP_ROW_MIRROR>( v );
-        if( ( row % BH ) == k ) mine = v; // lane k of the block's rows writes block k (NX <= 4 <= BH)
+        for( int k = 0; k < NX; k++ )
+        {
+            const T *rp = ref + (long)o + ( m[q][k] >> 16 ) * stride + (int16_t)m[q][k] + k * BW;
+            if( BW == 16 )
+                load_row16<T>( rp, r[q] );
+            else if( BW == 8 )
+                load_row8<T>( rp, r[q] + 2 * k );
+            else
+                r[q][k] = load_px4( rp );
+        }
     }
-    if( live && ( row % BH ) < NX )
-        out[by * bw + rxc * NX + ( row % BH )] = SATD ? mine >> 1 : mine;
+#pragma unroll
+    for( int q = 0; q < RR; q++ )
+    {
+        const int ry = blockIdx.y * RR + q;
+        const int by = ry * NY + row / BH;
+        int part[4];
+#pragma unroll
+        for( int t = 0; t < 4; t++ )
+            part[t] = SATD ? satd_partial_px4( f[q][t], r[q][t] ) : sad_partial_px4( f[q][t], r[q][t], (const T *)nullptr );
+        // per block of this row of blocks: the 4-sample columns it spans, then the BH rows (quad, half row, row of 16 lanes)
+        int mine = 0;
+#pragma unroll
+        for( int k = 0; k < NX; k++ )
+        {
+            int v = 0;
+#pragma unroll
+            for( int t = 0; t < BW / 4; t++ )
+                v += part[k * ( BW / 4 ) + t];
+            v = reduce_quad( v );
+            if( BH >= 8 ) v += dpp_mov<DPP_ROW_HALF_MIRROR>( v );
+            if( BH == 16 ) v += dpp_mov<DPP_ROW_MIRROR>( v );
+            if( ( row % BH ) == k ) mine = v; // lane k of the block's rows writes block k (NX <= 4 <= BH)
+        }
+        if( live && ry < regions_h && ( row % BH ) < NX )
+            out[by * bw + rxc * NX + ( row % BH )] = SATD ? mine >> 1 : mine;
+    }
 }
 
 // ---- hpel_filter (common/mc.c:172-196; x264_mc_functions_t.hpel_filter, mc.h:306-307) -------------------------
@@ -985,11 +1006,18 @@ __global__ __launch_bounds__( 256 ) void hpel_filter_kernel( T *__restrict__ dst
     const int x0 = blockIdx.x * HPEL_TW, y0 = blockIdx.y * HPEL_TH;
     const int t = threadIdx.x;
     // source tile: columns x0-2 .. x0+TW+2, rows y0-2 .. y0+TH+2, never beyond what the reference itself reads
-    for( int i = t; i < ( HPEL_TH + 5 ) * HPEL_LW; i += 256 )
+    // (four samples per load where all four lie inside what the reference reads; the tile edge sample by sample)
+    for( int i = t; i < ( HPEL_TH + 5 ) * ( HPEL_LW / 4 ); i += 256 )
     {
-        const int r = i / HPEL_LW, c = i - r * HPEL_LW;
-        const int x = imin2( x0 - 2 + c, width + 2 ), y = imin2( y0 - 2 + r, height + 2 );
-        s_src[r][c] = src[(long)y * stride + x];
+        const int r = i / ( HPEL_LW / 4 ), c = 4 * ( i - r * ( HPEL_LW / 4 ) );
+        const int x = x0 - 2 + c, y = imin2( y0 - 2 + r, height + 2 );
+        const T *row = src + (long)y * stride;
+        if( x + 3 <= width + 2 )
+            __builtin_memcpy( &s_src[r][c], row + x, 4 * sizeof( T ) );
+        else
+#pragma unroll
+            for( int k = 0; k < 4; k++ )
+                s_src[r][c + k] = row[imin2( x + k, width + 2 )];
     }
     __syncthreads();
     // unrounded vertical six-tap sums, four columns per thread
@@ -1053,11 +1081,34 @@ __global__ __launch_bounds__( 256 ) void hpel_filter_kernel( T *__restrict__ dst
 }
 
 // Plain device copy, 16 bytes per lane: the measured HBM rate the SAD/SATD figures are quoted against
-// (vendor peak and the build's own copy kernel).
-__global__ __launch_bounds__( 256 ) void copy16_kernel( const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16 )
+// (vendor peak and the build's own copy kernel).  A workgroup moves contiguous chunks of 256 x U x 16 bytes: its U loads
+// per lane are requested back to back before the first store; NT = non-temporal loads and stores (the data is touched once).
+typedef unsigned copy_v4u __attribute__( ( ext_vector_type( 4 ) ) );
+template <int U, bool NT>
+__global__ __launch_bounds__( 256 ) void copy16_kernel( const copy_v4u *__restrict__ src, copy_v4u *__restrict__ dst, size_t n16 )
 {
-    for( size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x )
-        dst[i] = src[i];
+    const size_t chunk = (size_t)256 * U;
+    for( size_t base = (size_t)blockIdx.x * chunk; base < n16; base += (size_t)gridDim.x * chunk )
+    {
+        copy_v4u v[U];
+#pragma unroll
+        for( int u = 0; u < U; u++ )
+        {
+            const size_t i = base + (size_t)u * 256 + threadIdx.x;
+            if( i < n16 )
+                v[u] = NT ? __builtin_nontemporal_load( src + i ) : src[i];
+        }
+#pragma unroll
+        for( int u = 0; u < U; u++ )
+        {
+            const size_t i = base + (size_t)u * 256 + threadIdx.x;
+            if( i < n16 )
+            {
+                if( NT ) __builtin_nontemporal_store( v[u], dst + i );
+                else dst[i] = v[u];
+            }
+        }
+    }
 }
 
 // ---- D1/Q1 as batched primitives (common/dct.c:157-205,332-386, common/quant.c:50-104) -----------------

@@ -11,10 +11,21 @@
 // to back, before any of them is consumed: their loads are in flight together.  On the host (tests/tools/me_logic_host.cpp) E is
 // a plain scalar evaluator, which is how this logic is checked against the oracle without a GPU.
 //
-// E provides:   int  fpel( int x, int y )                 pixel cost (fpelcmp) of the full-pel candidate, read from the weighted plane
-//               int  qpel( int qx, int qy, int use_satd ) pixel cost of the quarter-pel candidate (get_ref semantics, mc.c:218-249)
-//               int  bits( int qx, int qy )               p_cost_mvx[qx] + p_cost_mvy[qy]
+// Candidates are handed to the evaluator in SETS (the four points of a diamond, the six of a hexagon, the start candidates ...): a
+// set is described by a generator gen( k, x, y, ok, with_bits ) giving candidate k's position, whether it takes part, and whether its
+// vector costs bits.  The evaluator returns the cheapest participating candidate as  ( cost << 3 ) | k  -- the lowest k among equal
+// costs -- which is what applying the candidates in order with strict '<' gives (ME_PACK_MAX when none takes part).  On the device a
+// set is costed ACROSS the lanes of the group: lane k derives candidate k's address and mv bits, the addresses are handed round, the
+// per-lane partial costs of all candidates are reduced together (transposed butterfly) and the arg-min is a packed minimum.  A
+// candidate that does not take part must still have a readable position (callers give the set's centre).
+//
+// E provides:   template <int N, class G> int fpel_set( G gen )                        N <= 8 full-pel candidates: fpelcmp + bits( 4x, 4y )
+//               template <int N, class G> int qpel_set( int use_satd, G gen, int &c0 ) N <= 8 quarter-pel candidates (get_ref semantics,
+//                                                                                       mc.c:218-249) + bits( qx, qy ); c0 = cost of candidate 0
+//               int  bits( int qx, int qy )               p_cost_mvx[qx] + p_cost_mvy[qy] of a vector every thread of the group agrees on
 //               bool any( bool c )                        true if c holds for any thread that shares this instruction stream
+// melogic::ScalarSets<E> implements the two set functions over E's scalar fpel( x, y ) / qpel( qx, qy, use_satd ) / bits( qx, qy ): the
+// host evaluators of the tests use it (candidates one after the other).
 #pragma once
 
 #ifndef ME_HD
@@ -48,8 +59,12 @@ ME_HD int hex_dy( int k ) { return (int)( ( 0x002442u >> ( 4 * k ) ) & 15 ) - 2;
 ME_HD int mod6( int v ) { return v < 0 ? v + 6 : v >= 6 ? v - 6 : v; }
 
 // the four neighbours of a diamond in the reference's order: up, down, left, right
-ME_HD int dia_dx( int k ) { return k == 2 ? -1 : k == 3 ? 1 : 0; }
-ME_HD int dia_dy( int k ) { return k == 0 ? -1 : k == 1 ? 1 : 0; }
+// (also the first four of the eight points of the square refinement, me.c:411-420: then (-1,-1) (-1,1) (1,-1) (1,1); offset + 1 in
+// two bits per index, so that an index that differs from lane to lane costs a shift and a mask)
+ME_HD int square_dx( int k ) { return (int)( ( 0xA085u >> ( 2 * k ) ) & 3 ) - 1; }
+ME_HD int square_dy( int k ) { return (int)( ( 0x8858u >> ( 2 * k ) ) & 3 ) - 1; }
+ME_HD int dia_dx( int k ) { return square_dx( k ); }
+ME_HD int dia_dy( int k ) { return square_dy( k ); }
 
 // motion vector limits of block (bx, by) of a W x H block picture (slicetype.c:518-531 with the lowres 8x8 geometry): the block may
 // leave the picture by 12 samples (the padded border is 32), and never by more than the level's vertical / horizontal range
@@ -107,6 +122,55 @@ ME_HD int neighbour_list( int bx, int W, bool has_below, int right, int below, i
 #define ME_MARK( ev, k ) // profiling builds of the device kernel time the phases of a search
 #endif
 
+// ---- candidate sets -----------------------------------------------------------------------------------------------------------
+#define ME_PACK_MAX 0x7FFFFFFF
+ME_HD int pk_cost( int p ) { return p >> 3; }
+ME_HD int pk_idx( int p ) { return p & 7; }
+// entry i (0..3) of a four-entry list as a chain of selects: i may differ from lane to lane on the device
+ME_HD int pick4( int i, const int v[4] ) { return i == 0 ? v[0] : i == 1 ? v[1] : i == 2 ? v[2] : v[3]; }
+
+// The set functions over a scalar evaluator (candidates one after the other): D provides fpel( x, y ), qpel( qx, qy, use_satd ),
+// bits( qx, qy ).  Used by the host evaluators of the tests.
+template <class D>
+struct ScalarSets
+{
+    template <int N, class G>
+    int fpel_set( G gen )
+    {
+        D &d = *static_cast<D *>( this );
+        int best = ME_PACK_MAX;
+        for( int k = 0; k < N; k++ )
+        {
+            int x = 0, y = 0;
+            bool ok = false, wb = true;
+            gen( k, x, y, ok, wb );
+            if( !ok ) continue;
+            const int p = ( ( d.fpel( x, y ) + ( wb ? d.bits( 4 * x, 4 * y ) : 0 ) ) << 3 ) | k;
+            if( p < best ) best = p;
+        }
+        return best;
+    }
+    template <int N, class G>
+    int qpel_set( int use_satd, G gen, int &cost0 )
+    {
+        D &d = *static_cast<D *>( this );
+        int best = ME_PACK_MAX;
+        cost0 = ME_COST_MAX;
+        for( int k = 0; k < N; k++ )
+        {
+            int x = 0, y = 0;
+            bool ok = false, wb = true;
+            gen( k, x, y, ok, wb );
+            if( !ok ) continue;
+            const int c = d.qpel( x, y, use_satd ) + ( wb ? d.bits( x, y ) : 0 );
+            if( k == 0 ) cost0 = c;
+            const int p = ( c << 3 ) | k;
+            if( p < best ) best = p;
+        }
+        return best;
+    }
+};
+
 template <class E>
 ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, int n_mvc, const int mvcx[4], const int mvcy[4],
                    int &out_mvx, int &out_mvy, int &out_cost )
@@ -114,54 +178,49 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
     int bmx, bmy, bcost;
     int bpred_cost = ME_COST_MAX, bpred_mx = 0, bpred_my = 0;
     int pmvx, pmvy;
+    int unused_c0 = 0;
     ME_MARK( ev, 0 );
 
     if( C.refine4 )
     {
-        // predictor and neighbour candidates at quarter-pel precision (me.c:216-275)
-        bpred_mx = clip3( mvpx, 4 * L.fmin_x, 4 * L.fmax_x );
-        bpred_my = clip3( mvpy, 4 * L.fmin_y, 4 * L.fmax_y );
-        pmvx = bpred_mx; pmvy = bpred_my;
-        // x264_predictor_clip (common/common.h:774-805): candidates equal to zero or to the predictor are dropped, the rest clipped
-        bool ok[4];
-        int cx[4], cy[4];
-#pragma unroll
-        for( int i = 0; i < 4; i++ )
+        // predictor and neighbour candidates at quarter-pel precision (me.c:216-275): one set, the clipped predictor first, then the
+        // neighbours x264_predictor_clip keeps (common/common.h:774-805: not zero, not the predictor), clipped
+        pmvx = clip3( mvpx, 4 * L.fmin_x, 4 * L.fmax_x );
+        pmvy = clip3( mvpy, 4 * L.fmin_y, 4 * L.fmax_y );
+        int pmv_cost = ME_COST_MAX;
+        const int p = ev.template qpel_set<5>( C.fpelcmp_satd, [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
+            const int i = k - 1;
+            const int vx = pick4( i, mvcx ), vy = pick4( i, mvcy );
+            const bool keep = k > 0 && i < n_mvc && ( vx | vy ) && !( vx == pmvx && vy == pmvy );
+            x = keep ? clip3( vx, 4 * L.fmin_x, 4 * L.fmax_x ) : pmvx;
+            y = keep ? clip3( vy, 4 * L.fmin_y, 4 * L.fmax_y ) : pmvy;
+            ok = k == 0 || keep; wb = true;
+        }, pmv_cost );
+        bpred_cost = pk_cost( p );
+        bpred_mx = pmvx; bpred_my = pmvy;
+        if( pk_idx( p ) )
         {
-            const int mx = mvcx[i], my = mvcy[i];
-            ok[i] = i < n_mvc && ( mx | my ) && !( mx == pmvx && my == pmvy );
-            cx[i] = ok[i] ? clip3( mx, 4 * L.fmin_x, 4 * L.fmax_x ) : pmvx;
-            cy[i] = ok[i] ? clip3( my, 4 * L.fmin_y, 4 * L.fmax_y ) : pmvy;
+            bpred_mx = clip3( pick4( pk_idx( p ) - 1, mvcx ), 4 * L.fmin_x, 4 * L.fmax_x );
+            bpred_my = clip3( pick4( pk_idx( p ) - 1, mvcy ), 4 * L.fmin_y, 4 * L.fmax_y );
         }
-        int pmv_cost;
-        if( ev.any( ok[0] | ok[1] | ok[2] | ok[3] ) )
-        {
-            // a dropped candidate is costed at the predictor's position (no new memory traffic) and never applied
-            const int v = ev.qpel( pmvx, pmvy, C.fpelcmp_satd ) + ev.bits( pmvx, pmvy );
-            int c[4];
-#pragma unroll
-            for( int i = 0; i < 4; i++ )
-                c[i] = ev.qpel( cx[i], cy[i], C.fpelcmp_satd ) + ev.bits( cx[i], cy[i] );
-            bpred_cost = pmv_cost = v;
-#pragma unroll
-            for( int i = 0; i < 4; i++ )
-                if( ok[i] && c[i] < bpred_cost ) { bpred_cost = c[i]; bpred_mx = cx[i]; bpred_my = cy[i]; }
-        }
-        else
-            bpred_cost = pmv_cost = ev.qpel( pmvx, pmvy, C.fpelcmp_satd ) + ev.bits( pmvx, pmvy );
         bmx = ( bpred_mx + 2 ) >> 2;
         bmy = ( bpred_my + 2 ) >> 2;
-        // the rounded best predictor, then the zero vector, in that order (me.c:258-275)
+        // the rounded best predictor, then the zero vector, in that order (me.c:258-275): the rounded one replaces the cost whatever
+        // it is, the zero vector only if it is cheaper
         const bool need_round = ( ( bpred_mx | bpred_my ) & 3 ) != 0;
         const bool need_zero = ( pmvx | pmvy ) && ( bmx | bmy );
         bcost = need_round ? ME_COST_MAX : bpred_cost;
         if( ev.any( need_round || need_zero ) )
         {
-            const int rx = need_round ? bmx : 0, ry = need_round ? bmy : 0;
-            const int vr = ev.fpel( rx, ry ) + ev.bits( 4 * rx, 4 * ry );
-            const int vz = ev.fpel( 0, 0 ) + ev.bits( 0, 0 );
-            if( need_round ) bcost = vr;
-            if( need_zero && vz < bcost ) { bcost = vz; bmx = 0; bmy = 0; }
+            const int p2 = ev.template fpel_set<2>( [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
+                x = k == 0 ? bmx : 0; y = k == 0 ? bmy : 0;
+                ok = k == 0 ? need_round : need_zero; wb = true;
+            } );
+            if( need_round || ( need_zero && pk_cost( p2 ) < bcost ) )
+            {
+                bcost = pk_cost( p2 );
+                if( pk_idx( p2 ) == 1 ) { bmx = 0; bmy = 0; }
+            }
         }
         if( !( pmvx | pmvy ) && pmv_cost < bcost )
         {
@@ -170,46 +229,28 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
     }
     else
     {
-        // predictor rounded to full-pel; it carries no mv bits here (me.c:276-318)
+        // predictor rounded to full-pel (it carries no mv bits here), the neighbours x264_predictor_roundclip keeps
+        // (common/common.h:789-805), the zero vector (me.c:276-318)
         bmx = clip3( ( mvpx + 2 ) >> 2, L.fmin_x, L.fmax_x );
         bmy = clip3( ( mvpy + 2 ) >> 2, L.fmin_y, L.fmax_y );
         pmvx = bmx; pmvy = bmy;
-        bool ok[4];
-        int cx[4], cy[4];
-#pragma unroll
-        for( int i = 0; i < 4; i++ )
-        {
-            // x264_predictor_roundclip (common/common.h:789-805)
-            const int mx = ( mvcx[i] + 2 ) >> 2, my = ( mvcy[i] + 2 ) >> 2;
-            ok[i] = i < n_mvc && ( mx | my ) && !( mx == pmvx && my == pmvy );
-            cx[i] = ok[i] ? clip3( mx, L.fmin_x, L.fmax_x ) : pmvx;
-            cy[i] = ok[i] ? clip3( my, L.fmin_y, L.fmax_y ) : pmvy;
-        }
         const bool need_zero = ( pmvx | pmvy ) != 0;
-        if( ev.any( ok[0] | ok[1] | ok[2] | ok[3] ) )
+        const int p = ev.template fpel_set<6>( [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
+            const int i = k - 1;
+            const int mx = ( pick4( i, mvcx ) + 2 ) >> 2, my = ( pick4( i, mvcy ) + 2 ) >> 2;
+            const bool keep = k > 0 && k < 5 && i < n_mvc && ( mx | my ) && !( mx == pmvx && my == pmvy );
+            x = keep ? clip3( mx, L.fmin_x, L.fmax_x ) : k == 5 ? 0 : pmvx;
+            y = keep ? clip3( my, L.fmin_y, L.fmax_y ) : k == 5 ? 0 : pmvy;
+            ok = k == 0 || keep || ( k == 5 && need_zero );
+            wb = k != 0;
+        } );
+        bcost = pk_cost( p );
+        const int kb = pk_idx( p );
+        if( kb == 5 ) { bmx = 0; bmy = 0; }
+        else if( kb )
         {
-            const int v = ev.fpel( pmvx, pmvy );
-            int c[4];
-#pragma unroll
-            for( int i = 0; i < 4; i++ )
-                c[i] = ev.fpel( cx[i], cy[i] ) + ev.bits( 4 * cx[i], 4 * cy[i] );
-            const int vz = ev.fpel( 0, 0 ) + ev.bits( 0, 0 );
-            bcost = v;
-            const int px = pmvx, py = pmvy;
-#pragma unroll
-            for( int i = 0; i < 4; i++ )
-                if( ok[i] && c[i] < bcost ) { bcost = c[i]; bmx = cx[i]; bmy = cy[i]; }
-            (void)px; (void)py;
-            if( need_zero && vz < bcost ) { bcost = vz; bmx = 0; bmy = 0; }
-        }
-        else
-        {
-            bcost = ev.fpel( pmvx, pmvy );
-            if( ev.any( need_zero ) )
-            {
-                const int vz = ev.fpel( 0, 0 ) + ev.bits( 0, 0 );
-                if( need_zero && vz < bcost ) { bcost = vz; bmx = 0; bmy = 0; }
-            }
+            bmx = clip3( ( pick4( kb - 1, mvcx ) + 2 ) >> 2, L.fmin_x, L.fmax_x );
+            bmy = clip3( ( pick4( kb - 1, mvcy ) + 2 ) >> 2, L.fmin_y, L.fmax_y );
         }
     }
 
@@ -220,21 +261,14 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
         int iters = C.me_range;
         do
         {
-            int c[4];
-#pragma unroll
-            for( int k = 0; k < 4; k++ )
-            {
-                const int x = bmx + dia_dx( k ), y = bmy + dia_dy( k );
-                c[k] = ev.fpel( x, y ) + ev.bits( 4 * x, 4 * y );
-            }
-            int best = -1;
-#pragma unroll
-            for( int k = 0; k < 4; k++ )
-                if( c[k] < bcost ) { bcost = c[k]; best = k; }
-            if( best < 0 )
+            const int p = ev.template fpel_set<4>( [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
+                x = bmx + dia_dx( k ); y = bmy + dia_dy( k ); ok = true; wb = true;
+            } );
+            if( pk_cost( p ) >= bcost )
                 break;
-            bmx += dia_dx( best );
-            bmy += dia_dy( best );
+            bcost = pk_cost( p );
+            bmx += dia_dx( pk_idx( p ) );
+            bmy += dia_dy( pk_idx( p ) );
         } while( --iters && in_fpel_range( L, bmx, bmy ) );
     }
     else
@@ -242,16 +276,10 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
         // hexagon (me.c:344-420)
         int dir = -1;
         {
-            int c[6];
-#pragma unroll
-            for( int k = 0; k < 6; k++ )
-            {
-                const int x = bmx + hex_dx( k ), y = bmy + hex_dy( k );
-                c[k] = ev.fpel( x, y ) + ev.bits( 4 * x, 4 * y );
-            }
-#pragma unroll
-            for( int k = 0; k < 6; k++ )
-                if( c[k] < bcost ) { bcost = c[k]; dir = k; }
+            const int p = ev.template fpel_set<6>( [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
+                x = bmx + hex_dx( k ); y = bmy + hex_dy( k ); ok = true; wb = true;
+            } );
+            if( pk_cost( p ) < bcost ) { bcost = pk_cost( p ); dir = pk_idx( p ); }
         }
         if( dir >= 0 )
         {
@@ -259,41 +287,27 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
             // half hexagons: the three new points in the direction of the last move
             for( int i = ( C.me_range >> 1 ) - 1; i > 0 && in_fpel_range( L, bmx, bmy ); i-- )
             {
-                int c[3];
-#pragma unroll
-                for( int k = 0; k < 3; k++ )
-                {
+                const int p = ev.template fpel_set<3>( [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
                     const int kd = mod6( dir + k - 1 );
-                    const int x = bmx + hex_dx( kd ), y = bmy + hex_dy( kd );
-                    c[k] = ev.fpel( x, y ) + ev.bits( 4 * x, 4 * y );
-                }
-                int best = -2;
-#pragma unroll
-                for( int k = 0; k < 3; k++ )
-                    if( c[k] < bcost ) { bcost = c[k]; best = k - 1; }
-                if( best == -2 )
+                    x = bmx + hex_dx( kd ); y = bmy + hex_dy( kd ); ok = true; wb = true;
+                } );
+                if( pk_cost( p ) >= bcost )
                     break;
-                dir = mod6( dir + best );
+                bcost = pk_cost( p );
+                dir = mod6( dir + pk_idx( p ) - 1 );
                 bmx += hex_dx( dir ); bmy += hex_dy( dir );
             }
         }
         // square refine: (0,-1) (0,1) (-1,0) (1,0) then (-1,-1) (-1,1) (1,-1) (1,1)
         {
-            int c[8];
-#pragma unroll
-            for( int k = 0; k < 8; k++ )
+            const int p = ev.template fpel_set<8>( [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
+                x = bmx + square_dx( k ); y = bmy + square_dy( k ); ok = true; wb = true;
+            } );
+            if( pk_cost( p ) < bcost )
             {
-                const int dx = k < 4 ? dia_dx( k ) : ( k < 6 ? -1 : 1 ), dy = k < 4 ? dia_dy( k ) : ( ( k & 1 ) ? 1 : -1 );
-                c[k] = ev.fpel( bmx + dx, bmy + dy ) + ev.bits( 4 * ( bmx + dx ), 4 * ( bmy + dy ) );
-            }
-            int best = -1;
-#pragma unroll
-            for( int k = 0; k < 8; k++ )
-                if( c[k] < bcost ) { bcost = c[k]; best = k; }
-            if( best >= 0 )
-            {
-                bmx += best < 4 ? dia_dx( best ) : ( best < 6 ? -1 : 1 );
-                bmy += best < 4 ? dia_dy( best ) : ( ( best & 1 ) ? 1 : -1 );
+                bcost = pk_cost( p );
+                bmx += square_dx( pk_idx( p ) );
+                bmy += square_dy( pk_idx( p ) );
             }
         }
     }
@@ -305,7 +319,7 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
     {
         cost = bcost;
         if( bmx == pmvx && bmy == pmvy )
-            cost += ev.bits( 4 * bmx, 4 * bmy );
+            cost += ev.bits( 4 * bmx, 4 * bmy ); // the predictor was costed without its bits (me.c:781-782)
         mvx = 4 * bmx; mvy = 4 * bmy;
     }
     else if( bpred_cost < bcost )
@@ -327,60 +341,63 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
             const bool differs = mx != mvx || my != mvy;
             if( ev.any( differs ) )
             {
-                const int c = ev.qpel( mx, my, C.fpelcmp_satd ) + ev.bits( mx, my );
-                if( differs && c < cost ) { cost = c; mvx = mx; mvy = my; }
+                const int p = ev.template qpel_set<1>( C.fpelcmp_satd, [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
+                    x = mx; y = my; ok = differs; wb = true;
+                }, unused_c0 );
+                if( differs && pk_cost( p ) < cost ) { cost = pk_cost( p ); mvx = mx; mvy = my; }
             }
         }
         {
             // half-pel diamond, one iteration: up, down, left, right
-            int c[4];
-#pragma unroll
-            for( int k = 0; k < 4; k++ )
+            const int p = ev.template qpel_set<4>( C.fpelcmp_satd, [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
+                x = mvx + 2 * dia_dx( k ); y = mvy + 2 * dia_dy( k ); ok = true; wb = true;
+            }, unused_c0 );
+            if( pk_cost( p ) < cost )
             {
-                const int x = mvx + 2 * dia_dx( k ), y = mvy + 2 * dia_dy( k );
-                c[k] = ev.qpel( x, y, C.fpelcmp_satd ) + ev.bits( x, y );
-            }
-            int best = -1;
-#pragma unroll
-            for( int k = 0; k < 4; k++ )
-                if( c[k] < cost ) { cost = c[k]; best = k; }
-            if( best >= 0 )
-            {
-                mvx += 2 * dia_dx( best );
-                mvy += 2 * dia_dy( best );
+                cost = pk_cost( p );
+                mvx += 2 * dia_dx( pk_idx( p ) );
+                mvy += 2 * dia_dy( pk_idx( p ) );
             }
         }
         ME_MARK( ev, 3 );
         if( C.refine4 )
         {
-            // quarter-pel diamond, one iteration, costs with mbcmp (me.c:935-976)
+            // quarter-pel diamond, one iteration, costs with mbcmp (me.c:935-976); when mbcmp is not the metric the cost so far was
+            // measured with, the current vector is re-costed first (me.c:925-929): it joins the set as candidate 0
             const bool inside = !( mvy <= L.smin_y || mvy >= L.smax_y || mvx <= L.smin_x || mvx >= L.smax_x );
-            int c[4];
-            int base = cost;
             if( C.mbcmp_satd != C.fpelcmp_satd )
-                base = ev.qpel( mvx, mvy, C.mbcmp_satd ) + ev.bits( mvx, mvy );
-            if( ev.any( inside ) )
             {
-#pragma unroll
-                for( int k = 0; k < 4; k++ )
+                const int p = ev.template qpel_set<5>( C.mbcmp_satd, [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
+                    const bool moved = k > 0 && inside;
+                    x = moved ? mvx + dia_dx( k - 1 ) : mvx; y = moved ? mvy + dia_dy( k - 1 ) : mvy;
+                    ok = k == 0 || inside; wb = true;
+                }, unused_c0 );
+                cost = pk_cost( p );
+                if( pk_idx( p ) )
                 {
-                    const int x = inside ? mvx + dia_dx( k ) : mvx, y = inside ? mvy + dia_dy( k ) : mvy;
-                    c[k] = ev.qpel( x, y, C.mbcmp_satd ) + ev.bits( x, y );
-                }
-                cost = base;
-                if( inside )
-                {
-                    const int omx = mvx, omy = mvy;
-#pragma unroll
-                    for( int k = 0; k < 4; k++ )
-                        if( c[k] < cost ) { cost = c[k]; mvx = omx + dia_dx( k ); mvy = omy + dia_dy( k ); }
+                    const int kb = pk_idx( p ) - 1;
+                    mvx += dia_dx( kb ); mvy += dia_dy( kb );
                 }
             }
-            else
-                cost = base;
+            else if( ev.any( inside ) )
+            {
+                const int p = ev.template qpel_set<4>( C.mbcmp_satd, [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
+                    x = inside ? mvx + dia_dx( k ) : mvx; y = inside ? mvy + dia_dy( k ) : mvy; ok = inside; wb = true;
+                }, unused_c0 );
+                if( inside && pk_cost( p ) < cost )
+                {
+                    cost = pk_cost( p );
+                    mvx += dia_dx( pk_idx( p ) ); mvy += dia_dy( pk_idx( p ) );
+                }
+            }
         }
         else if( C.mbcmp_satd != C.fpelcmp_satd )
-            cost = ev.qpel( mvx, mvy, C.mbcmp_satd ) + ev.bits( mvx, mvy );
+        {
+            const int p = ev.template qpel_set<1>( C.mbcmp_satd, [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
+                x = mvx; y = mvy; ok = true; wb = true;
+            }, unused_c0 );
+            cost = pk_cost( p );
+        }
     }
     ME_MARK( ev, 4 );
     out_mvx = mvx; out_mvy = mvy; out_cost = cost;

@@ -141,7 +141,90 @@ __device__ __forceinline__ int block_cost8( const Px8 &f, const Px8 &r, int use_
     return reduce8( sad_partial_px8( f, r, (const T *)nullptr ) );
 }
 
-// the evaluator of me_logic.h on the 8-lane geometry
+// ---- candidate sets across the lanes of a group (the evaluator of me_logic.h on the 8-lane geometry) ---------------------------------
+// Lane l (0..7) of a group owns candidate slot SLOT(l) = l for l < 4 and 11 - l for l >= 4 (7, 6, 5, 4): with p, q, r the three bits
+// of l, SLOT = P | Q << 1 | r << 2 where P = p ^ r and Q = q ^ r.  The two lanes a half-row mirror pairs (l and 7 - l) agree in P and
+// Q, so a set of at most four candidates is held twice (once per quad) and one mirror step completes its sums.
+#define DPP_QUAD_XOR1_ 0xB1
+#define DPP_QUAD_XOR2_ 0x4E
+struct LaneSlots
+{
+    bool P, Q, R;   // this lane's slot bits
+    int slot;       // 0..7
+    int bp0;        // ds_bpermute byte address of lane 0 of this lane's group
+    int row16;      // ( lane & 7 ) << 4: this lane's row of the block in strip-row units
+};
+__device__ __forceinline__ LaneSlots make_lane_slots( int lane )
+{
+    LaneSlots S;
+    const int l = lane & 7, r = l >> 2;
+    S.R = r != 0;
+    S.P = ( ( l ^ r ) & 1 ) != 0;
+    S.Q = ( ( ( l >> 1 ) ^ r ) & 1 ) != 0;
+    S.slot = r ? 11 - l : l;
+    S.bp0 = ( lane & ~7 ) << 2;
+    S.row16 = l << 4;
+    return S;
+}
+// value held by the lane that owns candidate slot J (a compile-time constant) of this lane's group
+template <int J>
+__device__ __forceinline__ int from_slot( const LaneSlots &S, int v )
+{
+    return __builtin_amdgcn_ds_bpermute( S.bp0 + 4 * ( J < 4 ? J : 11 - J ), v );
+}
+// Sums over the 8 lanes of a group of N per-lane partial costs c[0..N-1] at once: every lane ends up with the total of the candidate
+// in ITS slot (slot & 3 for N <= 4).  Each butterfly step halves the number of live values: a lane keeps the half its slot bit selects
+// and receives the partner's partial of that half (6 selects + 4 DPP adds for four candidates, 14 + 7 for eight, against 3 DPP adds
+// per candidate one at a time).
+template <int N>
+__device__ __forceinline__ int reduce_slots( const LaneSlots &S, const int *c )
+{
+    int s[4];
+#pragma unroll
+    for( int m = 0; m < 4; m++ )
+    {
+        const int lo = 2 * m < N ? c[2 * m] : 0, hi = 2 * m + 1 < N ? c[2 * m + 1] : 0;
+        if( 2 * m + 1 < N )
+            s[m] = ( S.P ? hi : lo ) + dpp_mov<DPP_QUAD_XOR1_>( S.P ? lo : hi );
+        else if( 2 * m < N )
+            s[m] = ( S.P ? 0 : lo ) + dpp_mov<DPP_QUAD_XOR1_>( S.P ? lo : 0 );
+        else
+            s[m] = 0;
+    }
+    int u[2];
+#pragma unroll
+    for( int m = 0; m < 2; m++ )
+    {
+        if( 4 * m + 2 < N )
+            u[m] = ( S.Q ? s[2 * m + 1] : s[2 * m] ) + dpp_mov<DPP_QUAD_XOR2_>( S.Q ? s[2 * m] : s[2 * m + 1] );
+        else if( 4 * m < N )
+            u[m] = ( S.Q ? 0 : s[2 * m] ) + dpp_mov<DPP_QUAD_XOR2_>( S.Q ? s[2 * m] : 0 );
+        else
+            u[m] = 0;
+    }
+    if( N <= 4 )
+        return u[0] + dpp_mov<DPP_ROW_HALF_MIRROR>( u[0] );
+    return ( S.R ? u[1] : u[0] ) + dpp_mov<DPP_ROW_HALF_MIRROR>( S.R ? u[0] : u[1] );
+}
+// minimum over the lanes of a group (over a quad for N <= 4: both quads hold the same four slots)
+template <int N>
+__device__ __forceinline__ int min_slots( int v )
+{
+    v = imin2( v, dpp_mov<DPP_QUAD_XOR1_>( v ) );
+    v = imin2( v, dpp_mov<DPP_QUAD_XOR2_>( v ) );
+    if( N > 4 )
+        v = imin2( v, dpp_mov<DPP_ROW_HALF_MIRROR>( v ) );
+    return v;
+}
+// per-lane partial cost of the block this group holds against the 8 reference samples r of this lane's row
+template <typename T>
+__device__ __forceinline__ int block_partial8( const Px8 &f, const Px8 &r, int use_satd )
+{
+    if( use_satd )
+        return satd_partial_px4( f.lo, r.lo ) + satd_partial_px4( f.hi, r.hi );
+    return sad_partial_px8( f, r, (const T *)nullptr );
+}
+
 template <typename T, int LDS_TAB, int WEIGHTED>
 struct GroupEval
 {
@@ -152,9 +235,10 @@ struct GroupEval
     int plane_elems, strip_elems, pixel_max;
     int fpelcmp_satd;
     WtD wt;
-    int cx0, row16;          // padded column of the block, strip-row offset of this lane's row, both at zero displacement
+    int cx0, row16;          // padded column of the block, strip-row offset of the block's row 0, both at zero displacement
     int tab_x, tab_y;
     Px8 f;                   // this lane's 8 source pixels
+    LaneSlots S;
 
     __device__ __forceinline__ int bits( int qx, int qy ) const
     {
@@ -162,19 +246,79 @@ struct GroupEval
             return lds_tab[qx + tab_x] + lds_tab[qy + tab_y];
         return gload_u16( tab, 2u * (unsigned)( qx + tab_x ) ) + gload_u16( tab, 2u * (unsigned)( qy + tab_y ) );
     }
-    __device__ __forceinline__ int fpel( int x, int y ) const
+    // the total cost of the candidate in this lane's slot -> the cheapest of the set, packed with its index
+    template <int N>
+    __device__ __forceinline__ int pack_min( int total, bool ok ) const
     {
-        const Px8 r = load_px8_at( WEIGHTED ? wsbase : sbase, strip_off( cx0 + x, row16 + ( y << 4 ), strip_elems ) );
-        return block_cost8<T>( f, r, fpelcmp_satd );
+        const int k = N <= 4 ? ( S.slot & 3 ) : S.slot;
+        return min_slots<N>( ok && k < N ? ( total << 3 ) | k : ME_PACK_MAX );
     }
-    __device__ __forceinline__ int qpel( int qx, int qy, int use_satd ) const
+    template <int N, class G>
+    __device__ __forceinline__ int fpel_set( G gen ) const
     {
-        Px8 r = qpel_px8_strips( sbase, plane_elems, strip_elems, cx0, row16, qx, qy );
-        if( WEIGHTED )
+        // this lane's own candidate: position, offset of its row 0 in the strips, mv bits
+        const int slot = N <= 4 ? ( S.slot & 3 ) : S.slot, k = imin2( slot, N - 1 );
+        int x = 0, y = 0;
+        bool ok = false, wb = true;
+        gen( k, x, y, ok, wb );
+        const int off = strip_off( cx0 + x, row16 + ( y << 4 ), strip_elems );
+        const int b = wb ? bits( 4 * x, 4 * y ) : 0;
+        // every candidate's row for this lane: the owner's offset plus this lane's row
+        const T *base = WEIGHTED ? wsbase : sbase;
+        Px8 r[N];
+        r[0] = load_px8_at( base, from_slot<0>( S, off ) + S.row16 );
+        if constexpr( N > 1 ) r[1] = load_px8_at( base, from_slot<1>( S, off ) + S.row16 );
+        if constexpr( N > 2 ) r[2] = load_px8_at( base, from_slot<2>( S, off ) + S.row16 );
+        if constexpr( N > 3 ) r[3] = load_px8_at( base, from_slot<3>( S, off ) + S.row16 );
+        if constexpr( N > 4 ) r[4] = load_px8_at( base, from_slot<4>( S, off ) + S.row16 );
+        if constexpr( N > 5 ) r[5] = load_px8_at( base, from_slot<5>( S, off ) + S.row16 );
+        if constexpr( N > 6 ) r[6] = load_px8_at( base, from_slot<6>( S, off ) + S.row16 );
+        if constexpr( N > 7 ) r[7] = load_px8_at( base, from_slot<7>( S, off ) + S.row16 );
+        int c[N];
+#pragma unroll
+        for( int j = 0; j < N; j++ )
+            c[j] = block_partial8<T>( f, r[j], fpelcmp_satd );
+        int total = reduce_slots<N>( S, c );
+        if( fpelcmp_satd ) total >>= 1;
+        return pack_min<N>( total + b, ok );
+    }
+    template <int N, class G>
+    __device__ __forceinline__ int qpel_set( int use_satd, G gen, int &cost0 ) const
+    {
+        const int slot = N <= 4 ? ( S.slot & 3 ) : S.slot, k = imin2( slot, N - 1 );
+        int x = 0, y = 0;
+        bool ok = false, wb = true;
+        gen( k, x, y, ok, wb );
+        int oa, ob;
+        strip_layout::qpel_taps( plane_elems, strip_off( cx0 + ( x >> 2 ), row16 + ( ( y >> 2 ) << 4 ), strip_elems ), x, y, oa, ob );
+        const int b = wb ? bits( x, y ) : 0;
+        int ta[N], tb[N];
+        ta[0] = from_slot<0>( S, oa ); tb[0] = from_slot<0>( S, ob );
+        if constexpr( N > 1 ) { ta[1] = from_slot<1>( S, oa ); tb[1] = from_slot<1>( S, ob ); }
+        if constexpr( N > 2 ) { ta[2] = from_slot<2>( S, oa ); tb[2] = from_slot<2>( S, ob ); }
+        if constexpr( N > 3 ) { ta[3] = from_slot<3>( S, oa ); tb[3] = from_slot<3>( S, ob ); }
+        if constexpr( N > 4 ) { ta[4] = from_slot<4>( S, oa ); tb[4] = from_slot<4>( S, ob ); }
+        if constexpr( N > 5 ) { ta[5] = from_slot<5>( S, oa ); tb[5] = from_slot<5>( S, ob ); }
+        if constexpr( N > 6 ) { ta[6] = from_slot<6>( S, oa ); tb[6] = from_slot<6>( S, ob ); }
+        if constexpr( N > 7 ) { ta[7] = from_slot<7>( S, oa ); tb[7] = from_slot<7>( S, ob ); }
+        int c[N];
+#pragma unroll
+        for( int j = 0; j < N; j++ )
         {
-            r.lo = weight_px4<T>( r.lo, wt, pixel_max ); r.hi = weight_px4<T>( r.hi, wt, pixel_max );
+            const Px8 a = load_px8_at( sbase, ta[j] + S.row16 ), bb = load_px8_at( sbase, tb[j] + S.row16 );
+            Px8 r;
+            r.lo = avg_px4( a.lo, bb.lo, (const T *)nullptr ); r.hi = avg_px4( a.hi, bb.hi, (const T *)nullptr );
+            if( WEIGHTED )
+            {
+                r.lo = weight_px4<T>( r.lo, wt, pixel_max ); r.hi = weight_px4<T>( r.hi, wt, pixel_max );
+            }
+            c[j] = block_partial8<T>( f, r, use_satd );
         }
-        return block_cost8<T>( f, r, use_satd );
+        int total = reduce_slots<N>( S, c );
+        if( use_satd ) total >>= 1;
+        total += b;
+        cost0 = from_slot<0>( S, total );
+        return pack_min<N>( total, ok );
     }
     __device__ __forceinline__ bool any( bool c ) const { return __builtin_amdgcn_ballot_w64( c ) != 0ull; }
 #ifdef ME_PROFILE
@@ -220,6 +364,17 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
     const int n_rowgroups = ( H + ME_ROWS - 1 ) / ME_ROWS;
     // the ticket is wave-uniform: fetched on lane 0 and broadcast through an SGPR, so that the row group, the descriptor and
     // everything derived from them stay scalar
+    // Every wave reports its exit on a second counter; the last one out clears the tickets for the next launch on this stream
+    // (all ticket requests of a wave have returned before it exits, so nothing can arrive after the clear).  Saves the memset
+    // dispatch in front of every search launch.
+    auto leave = [&]() {
+        if( lane == 0 && atomicAdd( &tickets[1], 1u ) == gridDim.x - 1 )
+        {
+            for( int q = 0; q < ME_QUEUES; q++ )
+                atomicExch( &tickets[q * ME_QUEUE_STRIDE], 0u );
+            atomicExch( &tickets[1], 0u );
+        }
+    };
     const int home = xcc_id();
     int j = 0, s = -1;
     for( int k = 0; k < ME_QUEUES && s < 0; k++ )
@@ -239,7 +394,10 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
         }
     }
     if( s < 0 )
+    {
+        leave();
         return;
+    }
     const SearchDesc<T> D = descs[s];
     const int g = lane >> 3;
     const int by0 = H - 1 - ME_ROWS * j; // row of group 0 (scalar)
@@ -281,6 +439,7 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
     const bool below_is_remote = (bool)__builtin_amdgcn_readfirstlane( (int)has_below );
     const int zero_bits = P.cost_mv[0];
 
+    const LaneSlots LS = make_lane_slots( lane );
     int r1 = 0, r2 = 0, r3 = 0; // packed vectors this group found in the last three steps
     int keep_mv = 0, keep_cost = 0; // lanes 0..3 of a group: the result of the block with x % 4 == lane, until the four leave together
     const int n_steps = W + 2 * ( ME_ROWS - 1 );
@@ -315,6 +474,7 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
                     {
                         if( lane == 0 )
                             __hip_atomic_store( err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+                        leave();
                         return;
                     }
                     __builtin_amdgcn_s_sleep( 4 );
@@ -349,13 +509,13 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
                     mvpy = melogic::median3( mvcy[0], mvcy[1], mvcy[2] );
                 }
                 const int lane_off = border + 8 * ( by * P.stride + bx ) + row_off;
-                const int cx0 = 8 * bx + LA_PAD, row16 = ( 8 * by + ( lane & 7 ) + LA_PAD ) << 4;
+                const int cx0 = 8 * bx + LA_PAD, row16 = ( 8 * by + LA_PAD ) << 4; // the block's row 0; this lane's row is LS.row16 further
                 const Px8 f = load_px8_at( fbase, lane_off );
                 bool done = false;
                 if( !( mvpx | mvpy ) )
                 {
                     // near-zero residual shortcut on the unweighted plane (slicetype.c:684-692)
-                    const Px8 r = load_px8_at( sbase, strip_off( cx0, row16, strip_elems ) );
+                    const Px8 r = load_px8_at( sbase, strip_off( cx0, row16 + LS.row16, strip_elems ) );
                     cost = block_cost8<T>( f, r, C.mbcmp_satd );
                     done = cost < 64;
                 }
@@ -378,7 +538,7 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
                         GroupEval<T, 1, WEIGHTED> ev;
                         ev.lds_tab = tab_window; ev.sbase = sbase; ev.wsbase = wsbase; ev.tab = nullptr; ev.plane_elems = P.plane_elems;
                         ev.strip_elems = strip_elems; ev.pixel_max = P.pixel_max; ev.fpelcmp_satd = C.fpelcmp_satd; ev.wt = D.wt;
-                        ev.cx0 = cx0; ev.row16 = row16; ev.f = f;
+                        ev.cx0 = cx0; ev.row16 = row16; ev.f = f; ev.S = LS;
                         ev.tab_x = ME_TAB_HALF - mvpx; ev.tab_y = ME_TAB_HALF - mvpy;
 #ifdef ME_PROFILE
                         for( int k = 0; k < 5; k++ ) ev.pf_phase[k] = 0;
@@ -393,7 +553,7 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
                         GroupEval<T, 0, WEIGHTED> ev;
                         ev.lds_tab = nullptr; ev.sbase = sbase; ev.wsbase = wsbase; ev.tab = P.cost_mv - tab_centre; ev.plane_elems = P.plane_elems;
                         ev.strip_elems = strip_elems; ev.pixel_max = P.pixel_max; ev.fpelcmp_satd = C.fpelcmp_satd; ev.wt = D.wt;
-                        ev.cx0 = cx0; ev.row16 = row16; ev.f = f;
+                        ev.cx0 = cx0; ev.row16 = row16; ev.f = f; ev.S = LS;
                         ev.tab_x = tab_centre - mvpx; ev.tab_y = tab_centre - mvpy;
 #ifdef ME_PROFILE
                         for( int k = 0; k < 5; k++ ) ev.pf_phase[k] = 0;
@@ -440,6 +600,7 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
         }
 #endif
     }
+    leave();
 #ifdef ME_PROFILE
     if( lane == 0 && prof )
     {

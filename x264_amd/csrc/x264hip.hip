@@ -765,7 +765,7 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         dh[i] = d;
     }
     HIPCK( hipMemcpyAsync( dd, dh, (size_t)n * sizeof( SearchDesc<T> ), hipMemcpyHostToDevice, ctx->stream ) );
-    HIPCK( hipMemsetAsync( ctx->sync_words, 0, 2 * ME_QUEUES * ME_QUEUE_STRIDE * sizeof( unsigned ), ctx->stream ) ); // row tickets
+    // (the row tickets in sync_words are cleared by the last wave of the previous launch: me_search.h)
     hipEvent_t e0 = ctx->ev_start, e1 = ctx->ev_stop;
     if( ctx->prof_on )
     {
@@ -1590,9 +1590,18 @@ extern "C" int x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     const int rw = blocks_w * bwid / 16, rh = blocks_h * bhgt / 16;
-    const dim3 grd( ( rw + 15 ) / 16, rh );
+    // region rows per lane (loads in flight per lane): 4 unless the field is too small to fill the chip with a quarter of the
+    // workgroups (X264HIP_CMP_ROWS = 1 / 2 / 4 overrides it: A/B aid)
+    static const int rows_env = getenv( "X264HIP_CMP_ROWS" ) ? atoi( getenv( "X264HIP_CMP_ROWS" ) ) : 0;
+    const int wgs1 = ( ( rw + 15 ) / 16 ) * rh;
+    const int rr = rows_env == 1 || rows_env == 2 || rows_env == 4 ? rows_env : wgs1 >= 16 * ctx->n_cu ? 4 : wgs1 >= 8 * ctx->n_cu ? 2 : 1;
+    const dim3 grd( ( rw + 15 ) / 16, ( rh + rr - 1 ) / rr );
 #define CMP_LAUNCH( T, BW, BH, D ) \
-    pixel_cmp_batch_kernel<T, BW, BH, D><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, mv_dev, out_dev )
+    do { \
+        if( rr == 4 ) pixel_cmp_batch_kernel<T, BW, BH, D, 4><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev ); \
+        else if( rr == 2 ) pixel_cmp_batch_kernel<T, BW, BH, D, 2><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev ); \
+        else pixel_cmp_batch_kernel<T, BW, BH, D, 1><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev ); \
+    } while( 0 )
 #define CMP_METRIC( T, BW, BH ) do { if( satd ) CMP_LAUNCH( T, BW, BH, true ); else CMP_LAUNCH( T, BW, BH, false ); } while( 0 )
 #define CMP_SIZE( T ) \
     do { \
@@ -1895,9 +1904,32 @@ extern "C" int x264hip_device_copy( x264hip_ctx *ctx, void *dst_dev, const void 
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     const size_t n16 = bytes / 16;
-    const int grid = (int)std::min<size_t>( ( n16 + 255 ) / 256, (size_t)ctx->n_cu * 32 );
-    if( grid )
-        copy16_kernel<<<grid, 256, 0, ctx->stream>>>( (const uint4 *)src_dev, (uint4 *)dst_dev, n16 );
+    // X264HIP_COPY = "<unroll><n|t>[,<workgroups per CU>]" picks another form of the kernel (A/B aid); default: 4 loads per lane in flight,
+    // non-temporal, 8 workgroups of 256 per CU (a full complement of waves)
+    static const char *cv = getenv( "X264HIP_COPY" );
+    int unroll = 4, nt = 1, per_cu = 8;
+    if( cv && cv[0] )
+    {
+        unroll = cv[0] - '0'; nt = cv[1] == 't';
+        if( cv[1] && cv[2] == ',' ) per_cu = std::max( 1, atoi( cv + 3 ) );
+    }
+    if( n16 )
+    {
+        const size_t chunk = (size_t)256 * unroll;
+        const int grid = (int)std::min<size_t>( ( n16 + chunk - 1 ) / chunk, (size_t)ctx->n_cu * per_cu );
+        const copy_v4u *sp = (const copy_v4u *)src_dev; copy_v4u *dp = (copy_v4u *)dst_dev;
+        switch( unroll * 2 + nt )
+        {
+            case 2: copy16_kernel<1, false><<<grid, 256, 0, ctx->stream>>>( sp, dp, n16 ); break;
+            case 3: copy16_kernel<1, true><<<grid, 256, 0, ctx->stream>>>( sp, dp, n16 ); break;
+            case 4: copy16_kernel<2, false><<<grid, 256, 0, ctx->stream>>>( sp, dp, n16 ); break;
+            case 5: copy16_kernel<2, true><<<grid, 256, 0, ctx->stream>>>( sp, dp, n16 ); break;
+            case 8: copy16_kernel<4, false><<<grid, 256, 0, ctx->stream>>>( sp, dp, n16 ); break;
+            case 16: copy16_kernel<8, false><<<grid, 256, 0, ctx->stream>>>( sp, dp, n16 ); break;
+            case 17: copy16_kernel<8, true><<<grid, 256, 0, ctx->stream>>>( sp, dp, n16 ); break;
+            default: copy16_kernel<4, true><<<grid, 256, 0, ctx->stream>>>( sp, dp, n16 ); break;
+        }
+    }
     HIPCK( hipGetLastError() );
     return X264HIP_OK;
 }
