@@ -353,7 +353,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))  # RCCL over xGMI
+            import datetime
+            # (a collective that never completes ends the run after ten minutes instead of hanging it)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=datetime.timedelta(minutes=10))  # RCCL over xGMI
         else:
             dist.init_process_group(backend)
 
@@ -511,6 +513,8 @@ def main():
                 res["roofline_issue"] = {"error": str(e)}
         if window is not None:
             res["window_shard"] = window
+            if "error" in window and "value" not in window:
+                res["window_shard_error"] = window["error"]
             if args.shard == "window" and "value" in window:
                 # the one-stream figure as the primary value (strong scaling); the segment figure stays in the line
                 res["segments_value"] = res["value"]
@@ -563,44 +567,75 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if window is not None and "error" in window and "value" not in window and "MISMATCH" in str(window.get("error")):
+        raise SystemExit(3)  # a sharded run whose results differ from the single-rank run is a failure, not a figure
 
 
 def window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend, steps=2, frames=250):
-    """BASELINE configs[3]: 3840x2160, one 250-frame GOP, --rc-lookahead 60 --bframes 8, ONE stream over all ranks: rank b % N searches
-    frame b, the fields are gathered to rank 0 (RCCL over xGMI), which decides.  Strong scaling: the same 250 frames at every N.
-    Returns the result object on rank 0 (None elsewhere).  The N > 1 result is checked against a single-rank pass of rank 0."""
+    """BASELINE configs[3]: 3840x2160, one 250-frame GOP, --rc-lookahead 60 --bframes 8, ONE stream over all ranks: rank b % N runs frame
+    b's searches and cost cells, the list-0 fields of list-1 references are exchanged, cell summaries are gathered to rank 0 (RCCL over
+    xGMI), which decides, runs MB-tree and fetches the per-block maps MB-tree reads.  The one input copy lives on rank 0 and is
+    broadcast inside the timed region.  Strong scaling: the same 250 frames at every N.  Returns the result object on rank 0 (None
+    elsewhere).  The N > 1 result is checked against a single-rank pass of rank 0: a mismatch is an error (no value is reported)."""
     W, H = 3840, 2160
     cfg = lib.la_config(W, H, "medium", bit_depth=8, bframes=8, rc_lookahead=60, keyint_max=250)
-    clip = make_clip_device(torch, W, H, frames, 4242, 8, scene_cuts=(frames // 3,))  # the same seed on every rank: the same pictures
+    if rank == 0:
+        clip = make_clip_device(torch, W, H, frames, 4242, 8, scene_cuts=(frames // 3,))
+    else:
+        clip = torch.empty((frames, H, W), dtype=torch.uint8, device="cuda")  # filled by the broadcast of every pass
     nb = cfg["bframes"] + 2
     on_dev = backend == "nccl"
     best = None
     outs = None
     for k in range(steps + 1):  # one warm-up pass
-        outs, dt, stats = shard.run_window_shard(torch, lib, dist if world > 1 else None, rank, world, dev_index, cfg, clip, on_dev)
+        if rank and world > 1:
+            clip.zero_()  # every pass really receives its input
+        outs, dt, stats = shard.run_window_shard(torch, lib, dist if world > 1 else None, rank, world, dev_index, cfg, clip, on_dev, broadcast_input=world > 1)
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         if k > 0:
             best = float(t.item()) if best is None else min(best, float(t.item()))
     res = None
+    ok = torch.ones(1, dtype=torch.int32, device="cuda")
     if rank == 0:
-        checked = None
+        res = {"workload": "3840x2160 8-bit, one %d-frame GOP, --rc-lookahead 60 --bframes 8 (BASELINE configs[3]); ONE stream: frame b's searches and cost "
+                           "cells on rank b %% N, cell summaries gathered to rank 0, which decides" % frames,
+               "unit": "frames/s", "n_gpus": world, "rccl_ranks": world if on_dev else 0, "exchange": "RCCL on the contexts' streams" if on_dev else backend,
+               "scaling": "strong", "seconds": round(best, 4)}
         if world > 1:
-            # (reported, not raised: the other ranks are waiting at the barrier below)
-            ref, _, _ = shard.run_window_shard(torch, lib, None, 0, 1, dev_index, cfg, clip, on_dev)
+            t1 = None
+            ref, t1, st1 = shard.run_window_shard(torch, lib, None, 0, 1, dev_index, cfg, clip, on_dev)
             same = outputs_signature(outs, nb) == outputs_signature(ref, nb)
-            checked = "types + every cost cell == single-rank run of the same stream" if same else "MISMATCH: decisions or cost cells differ from the single-rank run"
-        res = {"workload": "3840x2160 8-bit, one %d-frame GOP, --rc-lookahead 60 --bframes 8 (BASELINE configs[3]); ONE stream, frame b searched on rank "
-                           "b %% N, fields gathered to rank 0" % frames,
-               "value": round(frames / best, 2), "unit": "frames/s", "n_gpus": world, "scaling": "strong", "seconds": round(best, 4),
-               "fields_searched_rank0": stats["fields_searched"], "fields_imported_rank0": stats["fields_imported"],
-               "bytes_gathered": stats["bytes_gathered"], "checked": checked}
-    elif world > 1:
-        pass
+            if not same:
+                ok[0] = 0
+                res["error"] = "MISMATCH: decisions or cost cells differ from the single-rank run of the same stream"
+            else:
+                res["checked"] = "types + every cost cell == single-rank run of the same stream"
+                res["value"] = round(frames / best, 2)
+            moved = {k: stats.get(k, 0) for k in ("bytes_input_broadcast", "bytes_l0_exchange", "bytes_summaries", "bytes_maps")}
+            res["bytes_moved"] = dict(moved, total_without_input=moved["bytes_l0_exchange"] + moved["bytes_summaries"] + moved["bytes_maps"],
+                                      all_fields_to_rank0_would_be=8 * ((W + 15) // 16) * ((H + 15) // 16) * (st1["fields_searched"]))
+            # rank 0's residual: what it still evaluates itself, against the single-rank run's totals (searches and cells are the two
+            # kernels that scale; decisions and MB-tree stay on rank 0)
+            own = dict(searches=stats.get("searches_here", 0) + stats.get("remote_fields_searched_here", 0), cells=stats.get("cells_here", 0) + stats.get("cells_on_demand", 0))
+            one = dict(searches=st1.get("searches_here", 0), cells=st1.get("cells_here", 0) + st1.get("cells_on_demand", 0))
+            frac = (own["searches"] + own["cells"]) / max(one["searches"] + one["cells"], 1)
+            res["rank0_share"] = {"searches": own["searches"], "cells": own["cells"], "of_single_rank": one, "fraction_of_search_and_cell_evaluations": round(frac, 4),
+                                  "maps_fetched": stats.get("maps_fetched", 0), "maps_recomputed_on_rank0": stats.get("remote_maps_recomputed_here", 0),
+                                  "fetch_commands": stats.get("fetch_commands", 0), "chunks": stats.get("chunks", 0)}
+            res["single_rank_seconds"] = round(t1, 4)
+            res["speedup_vs_single_rank_pass"] = round(t1 / best, 3)
+            res["amdahl"] = {"serial_fraction_measured": round(max(0.0, (best - t1 / world) / (t1 * (1 - 1.0 / world))), 4) if world > 1 else None,
+                             "what": "the fraction s of the single-rank pass that did not scale, from T(N) = T(1) (s + (1 - s) / N) with both passes measured here"}
+        else:
+            res["value"] = round(frames / best, 2)
+            res["cells_and_searches"] = {"searches": stats.get("searches_here", 0), "cells": stats.get("cells_here", 0), "cells_on_demand": stats.get("cells_on_demand", 0)}
     if world > 1:
-        dist.barrier()  # rank 0's verification pass
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank learns the verdict (rank 0's verification pass ends here)
     del clip
+    if int(ok.item()) == 0 and rank == 0:
+        print("window shard: " + res["error"], file=sys.stderr)
     return res
 
 

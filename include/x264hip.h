@@ -176,17 +176,41 @@ int  x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *frame_numb
 int  x264hip_prefetch_ex( x264hip_ctx *ctx, const int *slots, const int *frame_numbers, int n, int flags );
 
 /* ---- one lookahead window over several GPUs (x264_amd/shard.py) -----------------------------------------------------
- * The frames of a window are dealt round-robin to the ranks of a node; a rank runs the unweighted searches of the frames it owns
- * (x264hip_search_fields: like the search half of x264hip_prefetch, for an explicit list of (frame, reference, list, distance)),
- * packs each finished field as n_mb x { mvx | mvy << 16, mv cost } int32 pairs (x264hip_export_field, device buffer) for the
- * collective that carries it to the deciding rank, which takes it in with x264hip_import_field: the field then counts as
- * speculatively computed there, exactly as if that context had searched it (a field the context already has is left alone).
- * x264hip_field_classes: which (list, distance) classes this context would speculate (bit d of mask_l = distance d + 1), so that
- * the deciding rank can tell the others. */
+ * The frames of a window are dealt round-robin to the ranks of a node.  The rank that owns frame b runs b's unweighted searches
+ * (x264hip_search_fields) AND b's speculative cost cells (x264hip_spec_cells); what a B cell reads from another rank's frame -- the
+ * list-1 reference's own list-0 vectors, encoder/slicetype.c:629-642 -- travels as a packed field (x264hip_export_field /
+ * x264hip_import_field, n_mb x { mvx | mvy << 16, mv cost } int32 pairs).  Only per-cell SUMMARIES reach the deciding rank
+ * (x264hip_export_cells -> x264hip_import_cells): the five sums of slicetype_frame_cost (slicetype.c:946-991) and the row sums,
+ * X264HIP_CELL_SUMMARY_INTS( mb_h ) ints per cell.  There the fields count as searched elsewhere (x264hip_fields_remote) and the
+ * cells answer x264hip_frame_cost exactly like cells speculated locally; the per-block maps stay with the owner until somebody needs
+ * them: MB-tree propagation reads lowres_costs and the vectors of the cells finally chosen -- x264hip_cells_missing tells which of
+ * them are not local, x264hip_export_cell_map / x264hip_import_cell_map move one ([3][n_mb] int32: lowres_costs, list-0 vectors,
+ * list-1 vectors).  Anything else that needs absent data (a cell evaluated on demand, a getter, a cell MB-tree uses that was not
+ * fetched) recomputes it locally: results are identical by construction (a search is a pure function of its two frames).
+ * x264hip_field_classes / x264hip_cell_classes: which (list, distance) / (d0, d1) classes the deciding context would speculate, so
+ * that it can tell the others (cell class: 0 = none, 1 = without, 2 = with the list-1 reference's vectors). */
 int  x264hip_search_fields( x264hip_ctx *ctx, int n, const int *slot_b, const int *slot_ref, const int *list, const int *dist_minus1 );
 int  x264hip_export_field( x264hip_ctx *ctx, int slot, int list, int dist_minus1, void *dst_dev );
 int  x264hip_import_field( x264hip_ctx *ctx, int slot, int list, int dist_minus1, const void *src_dev );
 int  x264hip_field_classes( x264hip_ctx *ctx, unsigned *mask_l0, unsigned *mask_l1 );
+int  x264hip_cell_classes( x264hip_ctx *ctx, unsigned char *cell_class /* [(bframes+2) * (bframes+2)], index d0 * (bframes+2) + d1 */ );
+typedef struct x264hip_cell_ref
+{
+    int slot_b, slot_p0, slot_p1;   /* frame handles; dist_p0 == dist_p1 == 0: the frame's intra sums */
+    int dist_p0, dist_p1;
+    int with_ref1_l0;               /* B cells: evaluated with the list-1 reference's own list-0 vectors */
+} x264hip_cell_ref;
+#define X264HIP_CELL_SUMMARY_INTS( mb_h ) ( 8 + 2 * ( mb_h ) ) /* cost_est, cost_est_aq, intra_mbs, intra_cost_est, intra_cost_est_aq, 3 spare, row sums, intra row sums */
+int  x264hip_spec_cells( x264hip_ctx *ctx, int n, const x264hip_cell_ref *cells );
+int  x264hip_export_cells( x264hip_ctx *ctx, int n, const x264hip_cell_ref *cells, void *dst_dev );
+int  x264hip_import_cells( x264hip_ctx *ctx, int n, const x264hip_cell_ref *cells, const void *src_dev );
+int  x264hip_fields_remote( x264hip_ctx *ctx, int n, const int *slot, const int *frame_number, const int *list, const int *dist_minus1 );
+int  x264hip_cells_missing( x264hip_ctx *ctx, int n, const x264hip_cell_ref *cells, unsigned char *missing );
+int  x264hip_export_cell_map( x264hip_ctx *ctx, const x264hip_cell_ref *cell, void *dst_dev );
+int  x264hip_import_cell_map( x264hip_ctx *ctx, const x264hip_cell_ref *cell, const void *src_dev );
+/* the HIP stream the context enqueues its searches and cells on (hipStream_t): lets a caller order its own device work -- the
+ * collectives of x264_amd/shard.py -- against them without a host synchronisation */
+int  x264hip_stream_handle( x264hip_ctx *ctx, void **hip_stream );
 
 /* MB-tree: replaces mbtree_propagate_cost / mbtree_propagate_list of x264_mc_functions_t (common/mc.h:333-338,
  * common/mc.c:511-598) and macroblock_tree_finish (encoder/slicetype.c:1029-1049) for a whole list of steps at once.
@@ -458,6 +482,10 @@ int  x264hip_lookahead_open( x264hip_lookahead **out, int device, const x264hip_
  * finishes with x264hip_import_field + x264hip_prefetch_ex( CELLS_ONLY ).  Never changes results. */
 typedef int (*x264hip_prefetch_hook)( void *user, const int *slots, const int *frame_numbers, int n );
 int  x264hip_lookahead_open_hooked( x264hip_lookahead **out, int device, const x264hip_la_params *params, x264hip_prefetch_hook hook, void *user );
+/* Called with the step list right before the host logic hands it to x264hip_mbtree: the window shard fetches the maps of the cells
+ * the propagation is about to read (x264hip_cells_missing / x264hip_import_cell_map).  NULL = none. */
+typedef int (*x264hip_mbtree_hook)( void *user, const x264hip_mbtree_op *ops, int n );
+int  x264hip_lookahead_set_mbtree_hook( x264hip_lookahead *la, x264hip_mbtree_hook hook, void *user );
 /* Same host logic over a caller-supplied backend (plugin / test hook). */
 int  x264hip_lookahead_open_backend( x264hip_lookahead **out, const x264hip_la_params *params, const x264hip_backend *backend );
 void x264hip_lookahead_close( x264hip_lookahead *la );

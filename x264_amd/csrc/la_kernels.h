@@ -593,6 +593,7 @@ struct CellArgs
     const void *fenc0, *ref0_0, *ref1_0; // B cells: plane-0 origin of the source frame, strip copies (me_search.h) of the two references
     int sums_only;                // reduce only: intra sums of a frame, no maps written (speculative [0][0] sums)
     int pad_;
+    int *acc_dev;                 // device copy of acc[0..4] (what x264hip_export_cells packs for another rank)
 };
 
 __device__ __forceinline__ void cell_finish( const LaP &P, const CellArgs &A, int xy, int bcost, int list_used )
@@ -676,6 +677,7 @@ __global__ __launch_bounds__( 1024 ) void cell_reduce_kernel( LaP P, const CellA
         int v = 0;
         for( int i = 0; i < n_waves; i++ ) v += sh[threadIdx.x][i];
         A.acc[threadIdx.x] = v;
+        A.acc_dev[threadIdx.x] = v;
     }
 }
 

@@ -101,6 +101,14 @@ struct Lookahead
     int err = 0;
     x264hip_prefetch_hook prefetch_hook = nullptr; // x264hip_lookahead_open_hooked
     void *prefetch_hook_user = nullptr;
+    x264hip_mbtree_hook mbtree_hook = nullptr;     // x264hip_lookahead_set_mbtree_hook
+    void *mbtree_hook_user = nullptr;
+
+    int run_mbtree( std::vector<x264hip_mbtree_op> &ops )
+    {
+        if( mbtree_hook && need( mbtree_hook( mbtree_hook_user, ops.data(), (int)ops.size() ) ) ) return err;
+        return need( be.mbtree( be.user, ops.data(), (int)ops.size() ) );
+    }
 
     // ---- frame bookkeeping -------------------------------------------------------------------------
     void release( LaFrame *f )
@@ -506,7 +514,7 @@ struct Lookahead
             {
                 mbt_zero( ops, w[0] );
                 mbt_simple( ops, X264HIP_MBT_RESET_QP, w[0], w[0] );
-                if( be.mbtree && !err ) need( be.mbtree( be.user, ops.data(), (int)ops.size() ) );
+                if( be.mbtree && !err ) run_mbtree( ops );
                 return;
             }
             mbt_simple( ops, X264HIP_MBT_SWAP, w[far], w[0] );
@@ -565,7 +573,7 @@ struct Lookahead
         if( be.mbtree && !ops.empty() && !err )
         {
             ScopeNs tm( stats[6] );
-            need( be.mbtree( be.user, ops.data(), (int)ops.size() ) );
+            run_mbtree( ops );
         }
     }
 
@@ -1144,6 +1152,14 @@ extern "C" int x264hip_lookahead_open_hooked( x264hip_lookahead **out, int devic
     if( rc ) return rc;
     ( *out )->L.prefetch_hook = hook;
     ( *out )->L.prefetch_hook_user = user;
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_lookahead_set_mbtree_hook( x264hip_lookahead *la, x264hip_mbtree_hook hook, void *user )
+{
+    if( !la ) return X264HIP_EINVAL;
+    la->L.mbtree_hook = hook;
+    la->L.mbtree_hook_user = user;
     return X264HIP_OK;
 }
 

@@ -37,6 +37,15 @@
         }                                                                                                    \
     } while( 0 )
 
+// one cell summary travelling between ranks (x264hip_export_cells / x264hip_import_cells): where its parts live on this side
+struct CellXfer
+{
+    int *acc_host;            // import: pinned record x264hip_frame_cost reads; export: unused
+    int *acc_dev;             // the five sums on the device
+    int *rows, *rows_intra;   // [mb_h] each
+    int skip, pad_;           // import: this context already has the cell
+};
+
 struct CellEntry
 {
     unsigned char valid = 0;      // a speculative result for this cell sits in cell_acc
@@ -44,6 +53,10 @@ struct CellEntry
     unsigned char variant = 1;    // B cells: evaluated with (1) or without (0) the list-1 reference's own L0 vectors
     unsigned tag0 = 0, tag1 = 0, tagr = 0; // tags of the fields the speculative evaluation consumed
     unsigned batch = 0;
+    // window shard (include/x264hip.h "one lookahead window over several GPUs"): the sums came from the rank that owns the frame,
+    // the per-block map (lowres_costs) is not in this context; the frames the cell refers to, for a local re-evaluation
+    unsigned char map_remote = 0;
+    int slot_p0 = -1, slot_p1 = -1;
 };
 
 struct FrameSlot
@@ -67,6 +80,10 @@ struct FrameSlot
     // host-side state of the device fields
     unsigned char field_ready[2][X264HIP_BFRAME_MAX + 1]; // searched (any variant) and complete on the stream
     unsigned char field_prefetched[2][X264HIP_BFRAME_MAX + 1]; // unweighted field computed speculatively, not yet claimed
+    // window shard: the field was searched on the rank that owns this frame -- 1: nothing of it is here (the tag stands for it),
+    // 2: its vectors are here (x264hip_import_cell_map), its costs are not.  0: an ordinary local field
+    unsigned char field_remote[2][X264HIP_BFRAME_MAX + 1];
+    int *cell_sums = nullptr;         // [(bf+2)*(bf+2)][8] device copy of the cell sums (x264hip_export_cells)
     int wplane_idx = -1;          // weighted-plane pool entry in use by this slot's current weighted search
     uint64_t sum = 0, ssd = 0;
     int stats_valid = 0;
@@ -103,7 +120,8 @@ struct x264hip_ctx
     unsigned long long *me_prof = nullptr; // ME_PROFILE builds: 8 cycle accumulators of the search kernel (device), else unused
     int n_cells = 0;                 // (bframes+2)^2
     int *cell_acc_host = nullptr;    // pinned [slots][n_cells][8]: sums of every cell evaluation, written by the device directly
-    DescRing cell_ring, put_ring, search_ring;
+    DescRing cell_ring, put_ring, search_ring, xfer_ring;
+    int xfer_cap = 2048;
     unsigned *err_host = nullptr;    // pinned: sticky in-kernel timeout flag, written by the device directly
     int put_desc_cap = 256;
     int cell_desc_cap = 0;
@@ -143,7 +161,7 @@ struct x264hip_ctx
     std::vector<int> prof_n;
     int prof_on = 0, prof_used = 0;
     double prof_ms = 0; uint64_t prof_launches = 0, prof_searches = 0;
-    uint64_t counters[8] = { 0 };
+    uint64_t counters[16] = { 0 }; // [8] remote fields searched here after all [9] remote cell maps recomputed here [10] maps imported [11] cells imported [12] fields registered as remote
     // how often callers asked for each B cell class with / without a searched L0 field of the list-1 reference
     // (slicetype.c:629-642): speculation evaluates the variant asked for more often so far
     uint32_t variant_req[( X264HIP_BFRAME_MAX + 2 ) * ( X264HIP_BFRAME_MAX + 2 )][2] = { { 0 } };
@@ -216,7 +234,7 @@ static void free_all( x264hip_ctx *ctx )
     }
     for( auto w : ctx->wplanes ) (void)hipFree( w );
     (void)hipFree( ctx->cost_mv_dev ); (void)hipFree( ctx->luts_dev ); (void)hipFree( ctx->sync_words );
-    ring_free( ctx->cell_ring ); ring_free( ctx->put_ring ); ring_free( ctx->search_ring ); ring_free( ctx->wjob_ring );
+    ring_free( ctx->cell_ring ); ring_free( ctx->put_ring ); ring_free( ctx->search_ring ); ring_free( ctx->wjob_ring ); ring_free( ctx->xfer_ring );
     (void)hipHostFree( ctx->err_host );
     (void)hipHostFree( ctx->stats_host );
     if( ctx->stream2 ) (void)hipStreamSynchronize( ctx->stream2 );
@@ -380,6 +398,7 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( hipMemset( ctx->wcost_dev, 0, (size_t)x264hip_ctx::WCAP * 4 * sizeof( unsigned ) ) );
     OPENCK( hipHostMalloc( &ctx->wcost_host, (size_t)x264hip_ctx::WCAP * 2 * sizeof( unsigned ) ) );
     OPENCK( ring_alloc( ctx->wjob_ring, (size_t)x264hip_ctx::WCAP * sizeof( WeightJob ) ) );
+    OPENCK( ring_alloc( ctx->xfer_ring, (size_t)ctx->xfer_cap * sizeof( CellXfer ) ) );
     ctx->wcache.assign( x264hip_ctx::WCAP, x264hip_ctx::WEntry() );
     ctx->desc_cap = 2 * ( p.bframes + 1 ) * p.max_frames + 16;
     OPENCK( ring_alloc( ctx->search_ring, (size_t)ctx->desc_cap * sizeof( SearchDesc<uint8_t> ) ) );
@@ -403,6 +422,7 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         const size_t o_prop = off; off += align_up( (size_t)ctx->n_mb * sizeof( int ), 256 );
         const size_t o_qpa = off; off += align_up( (size_t)ctx->n_mb * sizeof( float ), 256 );
         const size_t o_qp = off; off += align_up( (size_t)ctx->n_mb * sizeof( float ), 256 );
+        const size_t o_sums = off; off += align_up( (size_t)nc * 8 * sizeof( int ), 256 );
         char *base = nullptr;
         OPENCK( hipMalloc( &base, off ) );
         OPENCK( hipMemset( base, 0, off ) );
@@ -419,10 +439,12 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         s.row_satds = (int *)( base + o_rows );
         s.blk = (int *)( base + o_blk );
         s.prop = (int *)( base + o_prop ); s.qp_aq = (float *)( base + o_qpa ); s.qp = (float *)( base + o_qp );
+        s.cell_sums = (int *)( base + o_sums );
         s.cells.assign( nc, CellEntry() );
         memset( s.field_tag, 0, sizeof( s.field_tag ) );
         memset( s.field_ready, 0, sizeof( s.field_ready ) );
         memset( s.field_prefetched, 0, sizeof( s.field_prefetched ) );
+        memset( s.field_remote, 0, sizeof( s.field_remote ) );
     }
 #undef OPENCK
     *out = ctx;
@@ -506,6 +528,7 @@ static void slot_reset( x264hip_ctx *ctx, FrameSlot &s )
     memset( s.field_ready, 0, sizeof( s.field_ready ) );
     memset( s.field_prefetched, 0, sizeof( s.field_prefetched ) );
     memset( s.field_tag, 0, sizeof( s.field_tag ) );
+    memset( s.field_remote, 0, sizeof( s.field_remote ) );
     s.cells.assign( ctx->n_cells, CellEntry() );
     if( s.wplane_idx >= 0 ) { ctx->wplane_owner[s.wplane_idx] = -1; s.wplane_idx = -1; }
     ctx->counters[3]++;
@@ -684,6 +707,7 @@ struct SearchReq
 {
     int slot_b, slot_ref, list, dist_m1;
     WtD wt;
+    unsigned keep_tag = 0; // non-zero: search under this tag (a field that so far existed on another rank only keeps its identity)
 };
 
 // wait for the stream, latch in-kernel timeouts (the flag lives in pinned host memory); every completed batch is now readable
@@ -758,9 +782,15 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         }
         d.mvq = b.mvq[r.list][r.dist_m1];
         d.costs = b.mvcost[r.list][r.dist_m1];
-        d.tag = ctx->tag_serial++;
-        if( !ctx->tag_serial ) ctx->tag_serial = 1;
+        if( r.keep_tag )
+            d.tag = r.keep_tag;
+        else
+        {
+            d.tag = ctx->tag_serial++;
+            if( !ctx->tag_serial ) ctx->tag_serial = 1;
+        }
         b.field_tag[r.list][r.dist_m1] = d.tag;
+        b.field_remote[r.list][r.dist_m1] = 0;
         d.pad = 0;
         dh[i] = d;
     }
@@ -856,6 +886,7 @@ static CellArgs make_cell( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_
     A.row_satds_intra = b.row_satds;
     A.blk = b.blk + (size_t)idx * ctx->n_mb;
     A.acc = ctx->cell_acc_host + ( (size_t)slot_b * ctx->n_cells + idx ) * 8; // pinned, device-visible
+    A.acc_dev = b.cell_sums + (size_t)idx * 8;
     return A;
 }
 
@@ -954,7 +985,7 @@ extern "C" int x264hip_prefetch_ex( x264hip_ctx *ctx, const int *slots, const in
     if( getenv( "X264HIP_NO_SPEC_CELLS" ) ) return X264HIP_OK; // debugging aid: searches only
     std::vector<int> by_number; // frame number -> index in the lists (small window: linear scans are fine)
     auto find = [&]( int number ) { for( int k = 0; k < n; k++ ) if( frame_numbers[k] == number ) return k; return -1; };
-    auto has_field = [&]( FrameSlot &f, int list, int dm1 ) { return f.field_ready[list][dm1] || f.field_prefetched[list][dm1]; };
+    auto has_field = [&]( FrameSlot &f, int list, int dm1 ) { return ( f.field_ready[list][dm1] || f.field_prefetched[list][dm1] ) && !f.field_remote[list][dm1]; };
     for( int i = 0; i < n; i++ )
     {
         FrameSlot &b = ctx->slots[slots[i]];
@@ -1003,6 +1034,82 @@ extern "C" int x264hip_prefetch_ex( x264hip_ctx *ctx, const int *slots, const in
         ctx->counters[5] += cells.size();
     }
     return X264HIP_OK;
+}
+
+// ---- window shard: data that lives on the owner rank until somebody here needs it ----------------------------------------------
+// The fields a cell (p0, p1, b) reads, searched locally if this context only knows them by tag (x264hip_fields_remote).  The result is
+// what the owner computed: a search is a pure function of its two frames.
+static int ensure_fields_local( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b, int d0, int d1, int with_ref1_l0 )
+{
+    std::vector<SearchReq> reqs;
+    const WtD none = { 0, 1, 0, 0 };
+    auto need = [&]( int slot_f, int slot_ref, int list, int dm1 ) {
+        FrameSlot &f = ctx->slots[slot_f];
+        if( f.field_remote[list][dm1] )
+        {
+            reqs.push_back( SearchReq{ slot_f, slot_ref, list, dm1, none, f.field_tag[list][dm1] } );
+            ctx->counters[8]++;
+        }
+    };
+    if( d0 > 0 ) need( slot_b, slot_p0, 0, d0 - 1 );
+    if( d1 > 0 )
+    {
+        need( slot_b, slot_p1, 1, d1 - 1 );
+        if( with_ref1_l0 ) need( slot_p1, slot_p0, 0, d0 + d1 - 1 );
+    }
+    if( reqs.empty() ) return X264HIP_OK;
+    const uint64_t n_before = ctx->counters[0];
+    int r = launch_searches( ctx, reqs );
+    ctx->counters[0] = n_before; // counted under [8]
+    return r;
+}
+
+template <typename T>
+static CellArgs make_cell( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b, int d0, int d1, int with_intra, int ref1_l0_valid, int sums_only );
+
+// The per-block map of a cell whose sums came from its owner rank, evaluated here after all (MB-tree reads it, so do
+// x264hip_frame_cost_recalculate and the getters): fields first, then the cell kernel; the sums are known already.
+template <typename T>
+static int ensure_cell_local_t( x264hip_ctx *ctx, int slot_b, int d0, int d1 )
+{
+    FrameSlot &b = ctx->slots[slot_b];
+    CellEntry &e = b.cells[d0 * ( ctx->p.bframes + 2 ) + d1];
+    if( !e.map_remote ) return X264HIP_OK;
+    if( !slot_ok( ctx, e.slot_p0 ) || !slot_ok( ctx, e.slot_p1 ) || !ctx->slots[e.slot_p0].in_use || !ctx->slots[e.slot_p1].in_use ) return X264HIP_ESTATE;
+    const int with_l0 = d1 > 0 && e.variant;
+    int r = ensure_fields_local( ctx, e.slot_p0, e.slot_p1, slot_b, d0, d1, with_l0 );
+    if( r ) return r;
+    const CellArgs A = make_cell<T>( ctx, e.slot_p0, e.slot_p1, slot_b, d0, d1, 0, with_l0, 0 );
+    if( d1 > 0 )
+        cell_b_kernel<T><<<dim3( ( ctx->P.mb_w + CELLB_BPW - 1 ) / CELLB_BPW, ctx->P.mb_h, 1 ), 64, 0, ctx->stream>>>( ctx->P, nullptr, A );
+    else
+        cell_p_kernel<<<dim3( ( ctx->n_mb + 255 ) / 256, 1 ), 256, 0, ctx->stream>>>( ctx->P, nullptr, A );
+    HIPCK( hipGetLastError() );
+    e.map_remote = 0;
+    ctx->counters[9]++;
+    return X264HIP_OK;
+}
+static int ensure_cell_local( x264hip_ctx *ctx, int slot_b, int d0, int d1 )
+{
+    return ctx->p.bit_depth == 8 ? ensure_cell_local_t<uint8_t>( ctx, slot_b, d0, d1 ) : ensure_cell_local_t<uint16_t>( ctx, slot_b, d0, d1 );
+}
+// a field this context only knows by tag, for a getter: the reference frame is found by its number
+static int ensure_field_local_by_number( x264hip_ctx *ctx, int slot, int list, int dm1 )
+{
+    FrameSlot &f = ctx->slots[slot];
+    if( !f.field_remote[list][dm1] ) return X264HIP_OK;
+    const int want = f.frame_no + ( list ? dm1 + 1 : -( dm1 + 1 ) );
+    for( int i = 0; i < (int)ctx->slots.size(); i++ )
+        if( ctx->slots[i].in_use && ctx->slots[i].frame_no == want )
+        {
+            std::vector<SearchReq> reqs( 1, SearchReq{ slot, i, list, dm1, WtD{ 0, 1, 0, 0 }, f.field_tag[list][dm1] } );
+            const uint64_t n_before = ctx->counters[0];
+            int r = launch_searches( ctx, reqs );
+            ctx->counters[0] = n_before;
+            ctx->counters[8]++;
+            return r;
+        }
+    return X264HIP_ESTATE;
 }
 
 // ---- evaluation -------------------------------------------------------------------------------------
@@ -1084,6 +1191,13 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
     else
     {
         ctx->counters[7]++;
+        if( !intra_only )
+        {
+            // inputs that so far exist on another rank only (window shard) are searched here now, under the tag they are known by
+            int r = ensure_fields_local( ctx, slot_p0, slot_p1, slot_b, d0, d1, ref1_l0_valid );
+            if( r ) return r;
+        }
+        e.map_remote = 0;
         static const bool trace_miss = getenv( "X264HIP_TRACE_MISS" ) != nullptr;
         if( trace_miss )
             fprintf( stderr, "miss b=%d d0=%d d1=%d valid=%d tags have %u/%u/%u want %u/%u/%u ref1_ok=%d wi=%d search=%d,%d w=%d\n", b.frame_no, d0, d1, was_valid,
@@ -1133,6 +1247,14 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
             if( o.dist_p0 < 0 || o.dist_p1 < 0 || o.dist_p0 + o.dist_p1 > ctx->p.bframes + 1 || ( o.type == X264HIP_MBT_PROPAGATE && o.dist_p0 < 1 ) )
                 return X264HIP_EINVAL;
     }
+    // window shard: a propagation reads the cell's map and vectors; whatever the caller did not fetch from the owner rank
+    // (x264hip_import_cell_map) is evaluated here
+    for( int i = 0; i < n; i++ )
+        if( ops[i].type == X264HIP_MBT_PROPAGATE )
+        {
+            int rc = ensure_cell_local( ctx, ops[i].slot_b, ops[i].dist_p0, ops[i].dist_p1 );
+            if( rc ) return rc;
+        }
     const int r = ctx->mbt_next;
     ctx->mbt_next = ( r + 1 ) % x264hip_ctx::MBT_RING;
     if( ctx->mbt_pending >= x264hip_ctx::MBT_RING )
@@ -1323,6 +1445,10 @@ extern "C" int x264hip_frame_cost_recalculate( x264hip_ctx *ctx, int slot_b, int
     FrameSlot &b = ctx->slots[slot_b];
     if( !b.in_use ) return X264HIP_ESTATE;
     const int idx = dist_p0 * ( ctx->p.bframes + 2 ) + dist_p1;
+    {
+        int rc0 = ensure_cell_local( ctx, slot_b, dist_p0, dist_p1 ); // (window shard: the map may still be with the owner rank)
+        if( rc0 ) return rc0;
+    }
     // f_qp_offset is written by the MB-tree stream: order this stream behind it
     if( ctx->mbt_pending )
         HIPCK( hipStreamWaitEvent( ctx->stream, ctx->ev_mbt_last, 0 ) );
@@ -1491,6 +1617,10 @@ extern "C" int x264hip_get_mvs( x264hip_ctx *ctx, int slot, int list, int dist_m
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     FrameSlot &s = ctx->slots[slot];
+    {
+        int rc0 = ensure_field_local_by_number( ctx, slot, list, dist_minus1 );
+        if( rc0 ) return rc0;
+    }
     std::vector<unsigned long long> g( ctx->n_mb );
     HIPCK( hipMemcpyAsync( g.data(), s.mvq[list][dist_minus1], ctx->n_mb * sizeof( unsigned long long ), hipMemcpyDeviceToHost, ctx->stream ) );
     if( mv_costs )
@@ -1513,6 +1643,11 @@ extern "C" int x264hip_get_lowres_costs( x264hip_ctx *ctx, int slot, int dist_p0
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     FrameSlot &s = ctx->slots[slot];
     const int idx = dist_p0 * ( ctx->p.bframes + 2 ) + dist_p1;
+    if( costs && dist_p0 + dist_p1 <= ctx->p.bframes + 1 )
+    {
+        int rc0 = ensure_cell_local( ctx, slot, dist_p0, dist_p1 );
+        if( rc0 ) return rc0;
+    }
     if( costs )
         HIPCK( hipMemcpyAsync( costs, s.lowres_costs + (size_t)idx * ctx->n_mb, ctx->n_mb * sizeof( uint16_t ), hipMemcpyDeviceToHost, ctx->stream ) );
     if( row_satds )
@@ -1574,7 +1709,7 @@ extern "C" int x264hip_search_profile( x264hip_ctx *ctx, int enable, double *tot
 extern "C" int x264hip_counters( x264hip_ctx *ctx, uint64_t *out, int n )
 {
     if( !ctx || !out ) return X264HIP_EINVAL;
-    for( int i = 0; i < n && i < 8; i++ ) out[i] = ctx->counters[i];
+    for( int i = 0; i < n && i < 16; i++ ) out[i] = ctx->counters[i];
     return X264HIP_OK;
 }
 
@@ -1594,7 +1729,7 @@ extern "C" int x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx
     // workgroups (X264HIP_CMP_ROWS = 1 / 2 / 4 overrides it: A/B aid)
     static const int rows_env = getenv( "X264HIP_CMP_ROWS" ) ? atoi( getenv( "X264HIP_CMP_ROWS" ) ) : 0;
     const int wgs1 = ( ( rw + 15 ) / 16 ) * rh;
-    const int rr = rows_env == 1 || rows_env == 2 || rows_env == 4 ? rows_env : wgs1 >= 16 * ctx->n_cu ? 4 : wgs1 >= 8 * ctx->n_cu ? 2 : 1;
+    const int rr = rows_env == 1 || rows_env == 2 || rows_env == 4 ? rows_env : wgs1 >= 32 * ctx->n_cu ? 4 : wgs1 >= 4 * ctx->n_cu ? 2 : 1;
     const dim3 grd( ( rw + 15 ) / 16, ( rh + rr - 1 ) / rr );
 #define CMP_LAUNCH( T, BW, BH, D ) \
     do { \
@@ -1904,10 +2039,11 @@ extern "C" int x264hip_device_copy( x264hip_ctx *ctx, void *dst_dev, const void 
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     const size_t n16 = bytes / 16;
-    // X264HIP_COPY = "<unroll><n|t>[,<workgroups per CU>]" picks another form of the kernel (A/B aid); default: 4 loads per lane in flight,
-    // non-temporal, 8 workgroups of 256 per CU (a full complement of waves)
+    // X264HIP_COPY = "<unroll><n|t>[,<workgroups per CU>]" picks another form of the kernel (A/B aid); default: 2 loads per lane in flight,
+    // non-temporal, 16 workgroups of 256 per CU (measured on MI355X over 512 MB: 6.27 TB/s; one load per lane, 32 workgroups per CU,
+    // the round-2 form: 5.35; four or eight loads per lane in 4 ... 8 workgroups per CU: 5.0 ... 5.9)
     static const char *cv = getenv( "X264HIP_COPY" );
-    int unroll = 4, nt = 1, per_cu = 8;
+    int unroll = 2, nt = 1, per_cu = 16;
     if( cv && cv[0] )
     {
         unroll = cv[0] - '0'; nt = cv[1] == 't';
@@ -1923,11 +2059,11 @@ extern "C" int x264hip_device_copy( x264hip_ctx *ctx, void *dst_dev, const void 
             case 2: copy16_kernel<1, false><<<grid, 256, 0, ctx->stream>>>( sp, dp, n16 ); break;
             case 3: copy16_kernel<1, true><<<grid, 256, 0, ctx->stream>>>( sp, dp, n16 ); break;
             case 4: copy16_kernel<2, false><<<grid, 256, 0, ctx->stream>>>( sp, dp, n16 ); break;
-            case 5: copy16_kernel<2, true><<<grid, 256, 0, ctx->stream>>>( sp, dp, n16 ); break;
             case 8: copy16_kernel<4, false><<<grid, 256, 0, ctx->stream>>>( sp, dp, n16 ); break;
             case 16: copy16_kernel<8, false><<<grid, 256, 0, ctx->stream>>>( sp, dp, n16 ); break;
             case 17: copy16_kernel<8, true><<<grid, 256, 0, ctx->stream>>>( sp, dp, n16 ); break;
-            default: copy16_kernel<4, true><<<grid, 256, 0, ctx->stream>>>( sp, dp, n16 ); break;
+            case 9: copy16_kernel<4, true><<<grid, 256, 0, ctx->stream>>>( sp, dp, n16 ); break;
+            default: copy16_kernel<2, true><<<grid, 256, 0, ctx->stream>>>( sp, dp, n16 ); break;
         }
     }
     HIPCK( hipGetLastError() );
@@ -2314,7 +2450,7 @@ extern "C" int x264hip_export_field( x264hip_ctx *ctx, int slot, int list, int d
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     FrameSlot &s = ctx->slots[slot];
-    if( !s.field_ready[list][dist_minus1] && !s.field_prefetched[list][dist_minus1] ) return X264HIP_ESTATE;
+    if( ( !s.field_ready[list][dist_minus1] && !s.field_prefetched[list][dist_minus1] ) || s.field_remote[list][dist_minus1] ) return X264HIP_ESTATE;
     export_field_kernel<<<( ctx->n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( s.mvq[list][dist_minus1], s.mvcost[list][dist_minus1], (int2 *)dst_dev, ctx->n_mb );
     HIPCK( hipGetLastError() );
     return X264HIP_OK;
@@ -2327,14 +2463,295 @@ extern "C" int x264hip_import_field( x264hip_ctx *ctx, int slot, int list, int d
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     FrameSlot &s = ctx->slots[slot];
     if( !s.in_use ) return X264HIP_ESTATE;
-    if( s.field_ready[list][dist_minus1] || s.field_prefetched[list][dist_minus1] )
+    unsigned tag;
+    if( s.field_remote[list][dist_minus1] )
+        tag = s.field_tag[list][dist_minus1]; // known by tag so far (x264hip_fields_remote): the data arrives, the identity stays
+    else if( s.field_ready[list][dist_minus1] || s.field_prefetched[list][dist_minus1] )
         return X264HIP_OK; // this context already has the field (searched here on demand): identical by construction, keep it
-    const unsigned tag = ctx->tag_serial++;
-    if( !ctx->tag_serial ) ctx->tag_serial = 1;
+    else
+    {
+        tag = ctx->tag_serial++;
+        if( !ctx->tag_serial ) ctx->tag_serial = 1;
+    }
+    s.field_remote[list][dist_minus1] = 0;
     import_field_kernel<<<( ctx->n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( s.mvq[list][dist_minus1], s.mvcost[list][dist_minus1], (const int2 *)src_dev, tag, ctx->n_mb );
     HIPCK( hipGetLastError() );
     s.field_tag[list][dist_minus1] = tag;
     s.field_prefetched[list][dist_minus1] = 1;
+    return X264HIP_OK;
+}
+
+// ---- cells on the owner rank, summaries to the deciding rank (include/x264hip.h, "one lookahead window over several GPUs") -------------
+extern "C" int x264hip_stream_handle( x264hip_ctx *ctx, void **hip_stream )
+{
+    if( !ctx || !hip_stream ) return X264HIP_EINVAL;
+    *hip_stream = (void *)ctx->stream;
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_cell_classes( x264hip_ctx *ctx, unsigned char *cell_class )
+{
+    if( !ctx || !cell_class ) return X264HIP_EINVAL;
+    static const bool no_learn = getenv( "X264HIP_NO_CLASS_LEARNING" ) != nullptr;
+    const bool learned = !no_learn && ctx->n_requests >= x264hip_ctx::LEARN_REQUESTS;
+    const int bf = ctx->p.bframes, ns = bf + 2;
+    memset( cell_class, 0, (size_t)ns * ns );
+    for( int d0 = 1; d0 <= bf + 1; d0++ )
+        for( int d1 = 0; d0 + d1 <= bf + 1; d1++ )
+        {
+            const int idx = d0 * ns + d1;
+            if( learned && !ctx->cell_req[idx] ) continue;
+            const uint32_t *rq = ctx->variant_req[idx];
+            cell_class[idx] = d1 && rq[0] <= rq[1] ? 2 : 1; // the same choice x264hip_prefetch makes
+        }
+    return X264HIP_OK;
+}
+
+static bool cell_ref_ok( x264hip_ctx *ctx, const x264hip_cell_ref &c )
+{
+    return slot_ok( ctx, c.slot_b ) && slot_ok( ctx, c.slot_p0 ) && slot_ok( ctx, c.slot_p1 ) && c.dist_p0 >= 0 && c.dist_p1 >= 0 &&
+           c.dist_p0 + c.dist_p1 <= ctx->p.bframes + 1 && !( c.dist_p0 == 0 && c.dist_p1 != 0 );
+}
+
+extern "C" int x264hip_spec_cells( x264hip_ctx *ctx, int n, const x264hip_cell_ref *cells )
+{
+    if( !ctx || n < 0 || ( n && !cells ) ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    const int ns = ctx->p.bframes + 2;
+    std::vector<SpecCell> list;
+    auto local = [&]( FrameSlot &f, int l, int dm1 ) { return ( f.field_ready[l][dm1] || f.field_prefetched[l][dm1] ) && !f.field_remote[l][dm1]; };
+    for( int i = 0; i < n; i++ )
+    {
+        const x264hip_cell_ref &c = cells[i];
+        if( !cell_ref_ok( ctx, c ) ) return X264HIP_EINVAL;
+        FrameSlot &b = ctx->slots[c.slot_b], &f1 = ctx->slots[c.slot_p1];
+        if( !b.in_use || !ctx->slots[c.slot_p0].in_use || !f1.in_use ) return X264HIP_ESTATE;
+        const int d0 = c.dist_p0, d1 = c.dist_p1;
+        CellEntry &e = b.cells[d0 * ns + d1];
+        if( e.valid || e.requested ) continue;
+        unsigned t0 = 0, t1 = 0, tr = 0;
+        const int variant = d1 && c.with_ref1_l0;
+        if( d0 )
+        {
+            // every field the cell reads has to be in this context (searched here, or imported)
+            if( !local( b, 0, d0 - 1 ) || ( d1 && ( !local( b, 1, d1 - 1 ) || ( variant && !local( f1, 0, d0 + d1 - 1 ) ) ) ) ) return X264HIP_ESTATE;
+            t0 = b.field_tag[0][d0 - 1];
+            if( d1 ) { t1 = b.field_tag[1][d1 - 1]; tr = variant ? f1.field_tag[0][d0 + d1 - 1] : 0; }
+            ctx->cell_spec[d0 * ns + d1]++;
+        }
+        e.valid = 1; e.batch = ctx->batch_serial + 1; e.variant = (unsigned char)( d1 ? variant : 1 );
+        e.tag0 = t0; e.tag1 = t1; e.tagr = tr; e.map_remote = 0;
+        list.push_back( SpecCell{ c.slot_p0, c.slot_p1, c.slot_b, d0, d1, d0 == 0, variant } );
+    }
+    if( list.empty() ) return X264HIP_OK;
+    int r = ctx->p.bit_depth == 8 ? launch_cells_t<uint8_t>( ctx, list ) : launch_cells_t<uint16_t>( ctx, list );
+    if( r ) return r;
+    ctx->counters[5] += list.size();
+    return batch_close( ctx );
+}
+
+__global__ __launch_bounds__( 64 ) void export_cells_kernel( const CellXfer *__restrict__ x, int mb_h, int *__restrict__ dst )
+{
+    const CellXfer X = x[blockIdx.x];
+    int *d = dst + (size_t)blockIdx.x * X264HIP_CELL_SUMMARY_INTS( mb_h );
+    if( threadIdx.x < 8 ) d[threadIdx.x] = threadIdx.x < 5 ? X.acc_dev[threadIdx.x] : 0;
+    for( int i = threadIdx.x; i < mb_h; i += 64 )
+    {
+        d[8 + i] = X.rows[i];
+        d[8 + mb_h + i] = X.rows_intra[i];
+    }
+}
+__global__ __launch_bounds__( 64 ) void import_cells_kernel( const CellXfer *__restrict__ x, int mb_h, const int *__restrict__ src )
+{
+    const CellXfer X = x[blockIdx.x];
+    if( X.skip ) return;
+    const int *s = src + (size_t)blockIdx.x * X264HIP_CELL_SUMMARY_INTS( mb_h );
+    if( threadIdx.x < 5 )
+    {
+        const int v = s[threadIdx.x];
+        X.acc_dev[threadIdx.x] = v;
+        __hip_atomic_store( X.acc_host + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM ); // pinned host record
+    }
+    for( int i = threadIdx.x; i < mb_h; i += 64 )
+    {
+        X.rows[i] = s[8 + i];
+        X.rows_intra[i] = s[8 + mb_h + i];
+    }
+}
+
+static CellXfer make_xfer( x264hip_ctx *ctx, const x264hip_cell_ref &c )
+{
+    FrameSlot &b = ctx->slots[c.slot_b];
+    const int idx = c.dist_p0 * ( ctx->p.bframes + 2 ) + c.dist_p1;
+    CellXfer X;
+    X.acc_host = ctx->cell_acc_host + ( (size_t)c.slot_b * ctx->n_cells + idx ) * 8;
+    X.acc_dev = b.cell_sums + (size_t)idx * 8;
+    X.rows = b.row_satds + (size_t)idx * ctx->P.mb_h;
+    X.rows_intra = b.row_satds;
+    X.skip = 0; X.pad_ = 0;
+    return X;
+}
+
+extern "C" int x264hip_export_cells( x264hip_ctx *ctx, int n, const x264hip_cell_ref *cells, void *dst_dev )
+{
+    if( !ctx || n < 0 || ( n && ( !cells || !dst_dev ) ) ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    const size_t per = X264HIP_CELL_SUMMARY_INTS( ctx->P.mb_h );
+    for( int o = 0; o < n; o += ctx->xfer_cap )
+    {
+        const int m = std::min( n - o, ctx->xfer_cap );
+        int ri = 0;
+        if( ring_acquire( ctx->xfer_ring, &ri ) ) return X264HIP_EDEVICE;
+        CellXfer *xh = (CellXfer *)ctx->xfer_ring.host[ri], *xd = (CellXfer *)ctx->xfer_ring.dev[ri];
+        for( int i = 0; i < m; i++ )
+        {
+            if( !cell_ref_ok( ctx, cells[o + i] ) ) return X264HIP_EINVAL;
+            xh[i] = make_xfer( ctx, cells[o + i] );
+        }
+        HIPCK( hipMemcpyAsync( xd, xh, (size_t)m * sizeof( CellXfer ), hipMemcpyHostToDevice, ctx->stream ) );
+        export_cells_kernel<<<m, 64, 0, ctx->stream>>>( xd, ctx->P.mb_h, (int *)dst_dev + (size_t)o * per );
+        HIPCK( hipGetLastError() );
+        if( ring_commit( ctx->xfer_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
+    }
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_import_cells( x264hip_ctx *ctx, int n, const x264hip_cell_ref *cells, const void *src_dev )
+{
+    if( !ctx || n < 0 || ( n && ( !cells || !src_dev ) ) ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    const size_t per = X264HIP_CELL_SUMMARY_INTS( ctx->P.mb_h );
+    const int ns = ctx->p.bframes + 2;
+    int taken = 0;
+    for( int o = 0; o < n; o += ctx->xfer_cap )
+    {
+        const int m = std::min( n - o, ctx->xfer_cap );
+        int ri = 0;
+        if( ring_acquire( ctx->xfer_ring, &ri ) ) return X264HIP_EDEVICE;
+        CellXfer *xh = (CellXfer *)ctx->xfer_ring.host[ri], *xd = (CellXfer *)ctx->xfer_ring.dev[ri];
+        for( int i = 0; i < m; i++ )
+        {
+            const x264hip_cell_ref &c = cells[o + i];
+            if( !cell_ref_ok( ctx, c ) || !c.dist_p0 ) return X264HIP_EINVAL; // (the intra sums of a frame are computed where they are needed)
+            FrameSlot &b = ctx->slots[c.slot_b], &f1 = ctx->slots[c.slot_p1];
+            if( !b.in_use ) return X264HIP_ESTATE;
+            const int d0 = c.dist_p0, d1 = c.dist_p1;
+            CellEntry &e = b.cells[d0 * ns + d1];
+            xh[i] = make_xfer( ctx, c );
+            // the cell stands for the fields as this context knows them now (registered with x264hip_fields_remote, or local)
+            auto known = [&]( FrameSlot &f, int l, int dm1 ) { return f.field_ready[l][dm1] || f.field_prefetched[l][dm1]; };
+            const int variant = d1 && c.with_ref1_l0;
+            const bool inputs = known( b, 0, d0 - 1 ) && ( !d1 || ( known( b, 1, d1 - 1 ) && ( !variant || known( f1, 0, d0 + d1 - 1 ) ) ) );
+            if( e.valid || e.requested || !inputs ) { xh[i].skip = 1; continue; }
+            e.valid = 1; e.batch = ctx->batch_serial + 1; e.variant = (unsigned char)( d1 ? variant : 1 );
+            e.tag0 = b.field_tag[0][d0 - 1];
+            e.tag1 = d1 ? b.field_tag[1][d1 - 1] : 0;
+            e.tagr = variant ? f1.field_tag[0][d0 + d1 - 1] : 0;
+            e.map_remote = 1; e.slot_p0 = c.slot_p0; e.slot_p1 = c.slot_p1;
+            taken++;
+        }
+        HIPCK( hipMemcpyAsync( xd, xh, (size_t)m * sizeof( CellXfer ), hipMemcpyHostToDevice, ctx->stream ) );
+        import_cells_kernel<<<m, 64, 0, ctx->stream>>>( xd, ctx->P.mb_h, (const int *)src_dev + (size_t)o * per );
+        HIPCK( hipGetLastError() );
+        if( ring_commit( ctx->xfer_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
+    }
+    ctx->counters[11] += taken;
+    return n ? batch_close( ctx ) : X264HIP_OK;
+}
+
+extern "C" int x264hip_fields_remote( x264hip_ctx *ctx, int n, const int *slot, const int *frame_number, const int *list, const int *dist_minus1 )
+{
+    if( !ctx || n < 0 || ( n && ( !slot || !frame_number || !list || !dist_minus1 ) ) ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    for( int i = 0; i < n; i++ )
+    {
+        if( !slot_ok( ctx, slot[i] ) || list[i] < 0 || list[i] > 1 || dist_minus1[i] < 0 || dist_minus1[i] > ctx->p.bframes ) return X264HIP_EINVAL;
+        FrameSlot &f = ctx->slots[slot[i]];
+        if( !f.in_use ) return X264HIP_ESTATE;
+        f.frame_no = frame_number[i];
+        if( f.field_ready[list[i]][dist_minus1[i]] || f.field_prefetched[list[i]][dist_minus1[i]] ) continue; // this context has it
+        f.field_prefetched[list[i]][dist_minus1[i]] = 1;
+        f.field_remote[list[i]][dist_minus1[i]] = 1;
+        f.field_tag[list[i]][dist_minus1[i]] = ctx->tag_serial++;
+        if( !ctx->tag_serial ) ctx->tag_serial = 1;
+        ctx->counters[12]++;
+    }
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_cells_missing( x264hip_ctx *ctx, int n, const x264hip_cell_ref *cells, unsigned char *missing )
+{
+    if( !ctx || n < 0 || ( n && ( !cells || !missing ) ) ) return X264HIP_EINVAL;
+    const int ns = ctx->p.bframes + 2;
+    for( int i = 0; i < n; i++ )
+    {
+        if( !cell_ref_ok( ctx, cells[i] ) ) return X264HIP_EINVAL;
+        missing[i] = ctx->slots[cells[i].slot_b].cells[cells[i].dist_p0 * ns + cells[i].dist_p1].map_remote;
+    }
+    return X264HIP_OK;
+}
+
+__global__ __launch_bounds__( 256 ) void export_map_kernel( const uint16_t *__restrict__ costs, const unsigned long long *__restrict__ mvq0, const unsigned long long *__restrict__ mvq1,
+                                                            int *__restrict__ dst, int n )
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if( i < n )
+    {
+        dst[i] = costs[i];
+        dst[n + i] = (int)(unsigned)mvq0[i];
+        dst[2 * n + i] = mvq1 ? (int)(unsigned)mvq1[i] : 0;
+    }
+}
+__global__ __launch_bounds__( 256 ) void import_map_kernel( uint16_t *__restrict__ costs, unsigned long long *__restrict__ mvq0, unsigned tag0, unsigned long long *__restrict__ mvq1,
+                                                            unsigned tag1, const int *__restrict__ src, int n )
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if( i < n )
+    {
+        costs[i] = (uint16_t)src[i];
+        if( mvq0 ) mvq0[i] = ( (unsigned long long)tag0 << 32 ) | (unsigned)src[n + i];
+        if( mvq1 ) mvq1[i] = ( (unsigned long long)tag1 << 32 ) | (unsigned)src[2 * n + i];
+    }
+}
+
+extern "C" int x264hip_export_cell_map( x264hip_ctx *ctx, const x264hip_cell_ref *cell, void *dst_dev )
+{
+    if( !ctx || !cell || !dst_dev || !cell_ref_ok( ctx, *cell ) || !cell->dist_p0 ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    FrameSlot &b = ctx->slots[cell->slot_b];
+    const int d0 = cell->dist_p0, d1 = cell->dist_p1, idx = d0 * ( ctx->p.bframes + 2 ) + d1;
+    const CellEntry &e = b.cells[idx];
+    if( !b.in_use || e.map_remote || ( !e.valid && !e.requested ) ) return X264HIP_ESTATE; // the map has to have been evaluated HERE
+    export_map_kernel<<<( ctx->n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( b.lowres_costs + (size_t)idx * ctx->n_mb, b.mvq[0][d0 - 1], d1 ? b.mvq[1][d1 - 1] : nullptr,
+                                                                          (int *)dst_dev, ctx->n_mb );
+    HIPCK( hipGetLastError() );
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_import_cell_map( x264hip_ctx *ctx, const x264hip_cell_ref *cell, const void *src_dev )
+{
+    if( !ctx || !cell || !src_dev || !cell_ref_ok( ctx, *cell ) || !cell->dist_p0 ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    FrameSlot &b = ctx->slots[cell->slot_b];
+    const int d0 = cell->dist_p0, d1 = cell->dist_p1, idx = d0 * ( ctx->p.bframes + 2 ) + d1;
+    CellEntry &e = b.cells[idx];
+    if( !b.in_use ) return X264HIP_ESTATE;
+    if( !e.map_remote ) return X264HIP_OK; // evaluated here in the meantime: identical by construction
+    // vectors of fields this context only knows by tag arrive with the map (their costs stay with the owner); local fields are left alone
+    unsigned long long *q0 = b.field_remote[0][d0 - 1] ? b.mvq[0][d0 - 1] : nullptr;
+    unsigned long long *q1 = d1 && b.field_remote[1][d1 - 1] ? b.mvq[1][d1 - 1] : nullptr;
+    import_map_kernel<<<( ctx->n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( b.lowres_costs + (size_t)idx * ctx->n_mb, q0, b.field_tag[0][d0 - 1], q1,
+                                                                          d1 ? b.field_tag[1][d1 - 1] : 0u, (const int *)src_dev, ctx->n_mb );
+    HIPCK( hipGetLastError() );
+    if( q0 ) b.field_remote[0][d0 - 1] = 2;
+    if( q1 ) b.field_remote[1][d1 - 1] = 2;
+    e.map_remote = 0;
+    ctx->counters[10]++;
     return X264HIP_OK;
 }
 

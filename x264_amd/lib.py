@@ -50,6 +50,11 @@ class MbtreeOp(C.Structure):
                 ("fps_factor_i", C.c_int), ("weightdelta", C.c_float), ("strength", C.c_float)]
 
 
+class CellRef(C.Structure):
+    """x264hip_cell_ref"""
+    _fields_ = [("slot_b", C.c_int), ("slot_p0", C.c_int), ("slot_p1", C.c_int), ("dist_p0", C.c_int), ("dist_p1", C.c_int), ("with_ref1_l0", C.c_int)]
+
+
 _lib = None
 
 
@@ -377,6 +382,7 @@ WEIGHT_COST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(We
 FRAME_COST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                             C.POINTER(Weight), C.c_int, C.c_int, C.POINTER(Cost))
 PREFETCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int)
+MBTREE_HOOK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(MbtreeOp), C.c_int)
 MBTREE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(MbtreeOp), C.c_int)
 QP_OFFSETS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float))
 PUT_BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_int)
@@ -630,9 +636,11 @@ def make_la_params(cfg, cost_mv=None, max_frames=0):
 class Lookahead:
     """x264hip_lookahead: put frames in display order, get frames back in coded order with their types."""
 
-    def __init__(self, cfg, device=0, backend=None, cost_mv=None, max_frames=0, prefetch_hook=None):
+    def __init__(self, cfg, device=0, backend=None, cost_mv=None, max_frames=0, prefetch_hook=None, mbtree_hook=None):
         """prefetch_hook( slots, frame_numbers ): device lookahead whose speculative submissions go through the caller
-        (x264hip_lookahead_open_hooked; x264_amd/shard.py spreads them over several GPUs)."""
+        (x264hip_lookahead_open_hooked; x264_amd/shard.py spreads them over several GPUs).
+        mbtree_hook( cells ): called with the (slot_b, slot_p0, slot_p1, d0, d1) of the PROPAGATE steps right before every MB-tree call
+        (x264hip_lookahead_set_mbtree_hook: the window shard fetches the per-block maps those steps read)."""
         L = load()
         self.L = L
         self.cfg = cfg
@@ -659,6 +667,19 @@ class Lookahead:
             L.x264hip_lookahead_open_backend.argtypes = [C.POINTER(C.c_void_p), C.POINTER(LaParams), C.POINTER(Backend)]
             _ck(L.x264hip_lookahead_open_backend(C.byref(self.h), C.byref(self.params), C.byref(backend)),
                 "x264hip_lookahead_open_backend")
+        if mbtree_hook is not None:
+            def _mhook(user, ops, n):
+                try:
+                    mbtree_hook([(ops[i].slot_b, ops[i].slot_p0, ops[i].slot_p1, ops[i].dist_p0, ops[i].dist_p1) for i in range(n) if ops[i].type == 1])
+                    return 0
+                except Exception as e:  # never let an exception cross the C ABI
+                    import traceback
+                    traceback.print_exc()
+                    self._hook_error = e
+                    return -4
+            self._mhook = MBTREE_HOOK_FN(_mhook)
+            L.x264hip_lookahead_set_mbtree_hook.argtypes = [C.c_void_p, MBTREE_HOOK_FN, C.c_void_p]
+            _ck(L.x264hip_lookahead_set_mbtree_hook(self.h, self._mhook, None), "x264hip_lookahead_set_mbtree_hook")
         self.dtype = np.uint8 if cfg["bit_depth"] == 8 else np.uint16
         L.x264hip_lookahead_ctx.restype = C.c_void_p
         self.delay = L.x264hip_lookahead_delay(self.h)

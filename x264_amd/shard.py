@@ -2,9 +2,10 @@
 gloo on CPU for the tests).  Two forms:
 
 * WindowShard -- ONE stream, one lookahead window, the frames of the window dealt round-robin to the ranks (BASELINE
-  configs[3]): rank b % world runs the motion searches of frame b, the finished fields (mv + mv cost per block) are gathered to
-  rank 0, which takes the decisions, evaluates the cost cells and runs MB-tree exactly as a single-GPU run would.  Slice types and
-  every cost cell are those of the single-stream run (no IDR is forced anywhere).
+  configs[3]): rank b % world runs frame b's motion searches AND its cost cells; the only fields that cross ranks are the list-0
+  fields B cells read from their list-1 reference (encoder/slicetype.c:629-642), and rank 0 -- which takes the decisions and runs
+  MB-tree -- receives per-cell SUMMARIES (the sums of slicetype.c:946-991 + row sums) plus, on request, the per-block maps of the
+  cells MB-tree propagation reads.  Slice types and every cost cell are those of the single-stream run (no IDR is forced anywhere).
 * GOP segments (segment_bounds / summarize / gather_summaries) -- independent closed-GOP segments per rank, the only exchange an
   all-gather of per-frame summaries: the zero-communication form, used for throughput scaling over independent streams."""
 import numpy as np
@@ -57,34 +58,55 @@ def gather_summaries(summary, dist, device=None):
 # ---------------------------------------------------------------------------------------------------------------------------
 # One window over several ranks
 # ---------------------------------------------------------------------------------------------------------------------------
-CMD_STOP, CMD_CHUNK = 0, 1
+CMD_STOP, CMD_CHUNK, CMD_FETCH = 0, 1, 2
 
 
 class WindowShard:
     """Protocol shared by all ranks.  Rank 0 runs the host lookahead; whenever it would submit speculative work for a chunk of
-    frames (the host logic's prefetch call: every resident frame the next decisions can reach) it broadcasts the chunk, every rank
-    searches the fields of the frames it owns, and a gather brings them to rank 0.  The other ranks sit in serve().
+    frames (the host logic's prefetch call: every resident frame the next decisions can reach) it broadcasts the chunk.  Every rank
+    derives the same plan from it -- field (b, list, d) and cell (b, d0, d1) belong to rank b % world -- and then, per chunk:
+      1. searches the fields of its frames;
+      2. takes part in ONE exchange of the list-0 fields some other rank's B cells read from their list-1 reference;
+      3. evaluates the cost cells of its frames;
+      4. contributes their summaries to a gather on rank 0, which registers the other ranks' fields as searched elsewhere and takes
+         the summaries in as speculative cells.
+    The per-block maps stay with their owners; when MB-tree on rank 0 is about to read some (before_mbtree), rank 0 names them in a
+    FETCH command and a gather brings exactly those.  The other ranks sit in serve().  With exchange on the device every step is
+    enqueued on the contexts' own streams (collectives included): rank 0's host thread never waits for a chunk, it only waits -- per
+    batch, inside x264hip_frame_cost -- for a result it actually needs.
 
     adapter (duck-typed; HipAdapter below, an oracle-backed one in the tests):
-        n_mb, bframes                                 geometry
-        ingest(slot, frame_number)                    make the frame resident in `slot` (no-op if it already is)
-        classes() -> (mask_l0, mask_l1)               rank 0: the (list, distance) classes worth speculating
-        search(reqs)                                  reqs: list of (slot_b, slot_ref, list, dist_m1): unweighted searches, asynchronous
-        export(keys) -> tensor [len(keys), n_mb, 2]   int32 {mv, cost} of the fields (slot, list, dist_m1), on the exchange device
-        import_(keys, tensor)                         rank 0: take fields searched elsewhere
-        finish(slots, numbers)                        rank 0: speculative cost cells over the fields now present
+        n_mb, mb_h, bframes                              geometry
+        ingest(slot, frame_number)                       make the frame resident in `slot` (no-op if it already is)
+        classes() -> (mask_l0, mask_l1, cell_class)      rank 0: the (list, distance) and (d0, d1) classes worth speculating
+        search(reqs)                                     reqs: list of (slot_b, slot_ref, list, dist_m1): unweighted searches, asynchronous
+        export_fields(keys, out)                         {mv, cost} of the fields (slot, list, dist_m1) into out[:len] ([., n_mb, 2] int32)
+        import_fields(keys, tensor, rows)                field k from tensor[rows[k]]
+        spec_cells(cells)                                cells: list of (slot_b, slot_p0, slot_p1, d0, d1, with_ref1_l0); d0 == 0: intra sums
+        export_cells(cells, out)                         summaries into out[:len] ([., 8 + 2 mb_h] int32)
+        import_cells(cells, tensor)                      rank 0
+        fields_remote(keys)                              rank 0: keys (slot, frame_number, list, dist_m1) searched on other ranks
+        cells_missing(cells) -> [bool]                   rank 0: whose per-block map is not local
+        export_map(cell, out) ; import_map(cell, tensor) the per-block map of one cell ([3, n_mb] int32: lowres_costs, list-0 vectors, list-1 vectors)
+        exchange                                         Exchange (below): zeros / all_gather / gather
     """
 
-    def __init__(self, adapter, dist, rank, world, device=None):
-        self.a, self.dist, self.rank, self.world, self.device = adapter, dist, rank, world, device
-        self.done = set()       # (frame_number, list, dist_m1) fields already planned in an earlier chunk (same on every rank)
-        self.resident = {}      # slot -> frame number, as announced by rank 0
-        self.stats = dict(chunks=0, fields_searched=0, fields_imported=0, bytes_gathered=0)
+    def __init__(self, adapter, dist, rank, world, device=None, cmd_group=None):
+        self.a, self.dist, self.rank, self.world, self.device, self.cmd_group = adapter, dist, rank, world, device, cmd_group
+        self.done = set()        # (frame_number, list, dist_m1) fields planned in this or an earlier chunk (same on every rank)
+        self.cells_done = set()  # (frame_number, d0, d1)
+        self.sums_done = set()   # rank 0: frames whose intra sums have been queued
+        self.l0_sent = set()     # (receiving rank, frame_number, dist_m1): list-0 fields already shipped (same on every rank)
+        self.slot_of = {}        # frame number -> slot, as announced by rank 0
+        self.number_in = {}      # slot -> frame number
+        self.stats = dict(chunks=0, fields_searched=0, cells_evaluated=0, l0_fields_exchanged=0, cells_imported=0, maps_fetched=0,
+                          bytes_l0_exchange=0, bytes_summaries=0, bytes_maps=0, fetch_commands=0)
 
     # ---- the plan of a chunk: identical on every rank ----
-    def plan(self, slots, numbers, masks):
-        by_owner = [[] for _ in range(self.world)]
-        bf = self.a.bframes
+    def plan(self, slots, numbers, masks, cell_class):
+        bf, ns = self.a.bframes, self.a.bframes + 2
+        owner = lambda n: n % self.world  # noqa: E731
+        fields = [[] for _ in range(self.world)]
         for i, ni in enumerate(numbers):
             for j, nj in enumerate(numbers):
                 d = nj - ni
@@ -94,93 +116,281 @@ class WindowShard:
                 if not (masks[lst] >> dm1) & 1 or (ni, lst, dm1) in self.done:
                     continue
                 self.done.add((ni, lst, dm1))
-                by_owner[ni % self.world].append((slots[i], slots[j], lst, dm1))
-        return by_owner
+                fields[owner(ni)].append((slots[i], slots[j], lst, dm1, ni))
+        cells = [[] for _ in range(self.world)]
+        l0_wanted = [set() for _ in range(self.world)]  # per receiving rank: (frame_number, dist_m1) list-0 fields of other ranks' frames
+        here = dict(zip(numbers, slots))  # a chunk names every resident frame the decisions can reach: only those are safe to refer to
+        for i, ni in enumerate(numbers):
+            for d0 in range(1, bf + 2):
+                p0 = ni - d0
+                if p0 not in here or (ni, 0, d0 - 1) not in self.done:
+                    continue
+                for d1 in range(0, bf + 2 - d0):
+                    c = cell_class[d0 * ns + d1]
+                    if not c or (ni, d0, d1) in self.cells_done:
+                        continue
+                    p1, with_l0 = ni, 0
+                    if d1:
+                        p1, with_l0 = ni + d1, int(c == 2)
+                        if p1 not in here or (ni, 1, d1 - 1) not in self.done:
+                            continue
+                        if with_l0 and (p1, 0, d0 + d1 - 1) not in self.done:
+                            continue
+                        if with_l0 and owner(p1) != owner(ni):
+                            l0_wanted[owner(ni)].add((p1, d0 + d1 - 1))
+                    self.cells_done.add((ni, d0, d1))
+                    cells[owner(ni)].append((slots[i], here[p0], here[p1], d0, d1, with_l0, ni))
+        return fields, cells, l0_wanted
 
-    def _bcast(self, t):
-        import torch
+    def _bcast_cmd(self, t):
+        """small int64 command tensors: over the side group (gloo) when there is one, so that no rank touches the GPU for them"""
+        if self.cmd_group is not None:
+            self.dist.broadcast(t, src=0, group=self.cmd_group)
+            return t
         t = t.to(self.device) if self.device is not None else t
         self.dist.broadcast(t, src=0)
         return t.cpu()
 
-    def _run_chunk(self, slots, numbers, masks):
+    def _send(self, cmd):
         import torch
+        if self.world > 1:
+            t = torch.tensor(cmd, dtype=torch.int64)
+            self._bcast_cmd(torch.tensor([t.numel()], dtype=torch.int64))
+            self._bcast_cmd(t)
+
+    def _run_chunk(self, slots, numbers, masks, cell_class):
+        import torch
+        a, X = self.a, self.a.exchange
         for s, n in zip(slots, numbers):
-            if self.resident.get(s) != n:
-                self.resident[s] = n  # (a frame number never comes back in another slot within a stream)
-                self.a.ingest(s, n)
-        by_owner = self.plan(slots, numbers, masks)
-        mine = by_owner[self.rank]
-        self.a.search(mine)
+            if self.number_in.get(s) != n:
+                self.slot_of.pop(self.number_in.get(s), None)
+                self.number_in[s] = n
+                self.slot_of[n] = s   # (a frame number never comes back in another slot within a stream)
+                a.ingest(s, n)
+        fields, cells, l0_wanted = self.plan(slots, numbers, masks, cell_class)
+        mine = fields[self.rank]
+        a.search([f[:4] for f in mine])
         self.stats["chunks"] += 1
         self.stats["fields_searched"] += len(mine)
-        width = max(len(x) for x in by_owner)
-        if self.world == 1 or width == 0:
-            return
-        # one collective of equally sized buffers: [width, n_mb, 2] int32 per rank, padded.  all_gather rather than gather: rank 0 is
-        # the only consumer, but its ingress is the bottleneck either way and all_gather is a collective every
-        # backend implements natively (RCCL ring over xGMI; gloo in the tests)
-        buf = torch.zeros((width, self.a.n_mb, 2), dtype=torch.int32, device=self.device if self.device is not None else "cpu")
-        if mine:
-            buf[:len(mine)] = self.a.export([(r[0], r[2], r[3]) for r in mine])
-        out = [torch.empty_like(buf) for _ in range(self.world)]
-        self.dist.all_gather(out, buf)
+        # ---- list-0 fields that B cells on OTHER ranks read from their list-1 reference: one all_gather of what each rank owns of them
+        if self.world > 1:
+            for r in range(self.world):
+                l0_wanted[r] = {k for k in l0_wanted[r] if (r,) + k not in self.l0_sent}
+                self.l0_sent.update((r,) + k for k in l0_wanted[r])
+            give = [sorted({k for r in range(self.world) if r != o for k in l0_wanted[r] if k[0] % self.world == o}) for o in range(self.world)]
+            width = max(len(g) for g in give)
+            if width:
+                buf = X.zeros((width, a.n_mb, 2))
+                if give[self.rank]:
+                    a.export_fields([(self.slot_of[n], 0, dm1) for n, dm1 in give[self.rank]], buf)
+                out = X.all_gather(buf)
+                for o in range(self.world):
+                    take = [k for k, key in enumerate(give[o]) if key in l0_wanted[self.rank]] if o != self.rank else []
+                    if take:
+                        a.import_fields([(self.slot_of[give[o][k][0]], 0, give[o][k][1]) for k in take], out[o], take)
+                        self.stats["l0_fields_exchanged"] += len(take)
+                self.stats["bytes_l0_exchange"] += (self.world - 1) * width * a.n_mb * 8
+        # ---- the cells of the frames this rank owns; rank 0 also queues the intra sums of every frame (it has all of them resident)
+        my_cells = [c[:6] for c in cells[self.rank]]
+        sums = []
         if self.rank == 0:
-            for r in range(1, self.world):
-                if by_owner[r]:
-                    self.a.import_([(q[0], q[2], q[3]) for q in by_owner[r]], out[r][:len(by_owner[r])])
-                    self.stats["fields_imported"] += len(by_owner[r])
-            self.stats["bytes_gathered"] += (self.world - 1) * buf.numel() * 4
+            sums = [(s, s, s, 0, 0, 0) for s, n in zip(slots, numbers) if n not in self.sums_done]
+            self.sums_done.update(numbers)
+        a.spec_cells(sums + my_cells)
+        self.stats["cells_evaluated"] += len(my_cells)
+        if self.world == 1:
+            return
+        # ---- summaries to rank 0
+        width = max(len(c) for c in cells[1:])
+        if width:
+            per = 8 + 2 * a.mb_h
+            buf = X.zeros((width, per))
+            if my_cells and self.rank:
+                a.export_cells(my_cells, buf)
+            out = X.gather(buf)
+            if self.rank == 0:
+                remote = [(f[0], f[4], f[2], f[3]) for r in range(1, self.world) for f in fields[r]]
+                a.fields_remote(remote)
+                for r in range(1, self.world):
+                    if cells[r]:
+                        a.import_cells([c[:6] for c in cells[r]], out[r][:len(cells[r])])
+                        self.stats["cells_imported"] += len(cells[r])
+                self.stats["bytes_summaries"] += (self.world - 1) * width * per * 4
+        elif self.rank == 0:
+            a.fields_remote([(f[0], f[4], f[2], f[3]) for r in range(1, self.world) for f in fields[r]])
 
     # ---- rank 0 ----
     def on_prefetch(self, slots, numbers):
         """the host logic's speculative submission on rank 0 (x264hip_prefetch_hook / the backend's prefetch entry)"""
-        import torch
-        m0, m1 = self.a.classes()
+        m0, m1, cc = self.a.classes()
         n = len(slots)
-        cmd = torch.tensor([CMD_CHUNK, n, m0, m1] + list(slots) + list(numbers), dtype=torch.int64)
-        if self.world > 1:
-            self._bcast(torch.tensor([cmd.numel()], dtype=torch.int64))
-            self._bcast(cmd)
-        self._run_chunk(list(slots), list(numbers), (m0, m1))
-        self.a.finish(list(slots), list(numbers))
+        self._send([CMD_CHUNK, n, m0, m1] + list(slots) + list(numbers) + [int(v) for v in cc])
+        self._run_chunk(list(slots), list(numbers), (m0, m1), cc)
+
+    def before_mbtree(self, cells):
+        """cells: (slot_b, slot_p0, slot_p1, d0, d1) of the PROPAGATE steps MB-tree is about to run on rank 0: the per-block maps that
+        are still with their owners are fetched (one FETCH command + one gather)"""
+        if self.world == 1 or not cells:
+            return
+        cells = [tuple(c) for c in dict.fromkeys(cells)]
+        miss = [c for c, m in zip(cells, self.a.cells_missing([c + (0,) for c in cells])) if m]
+        if not miss:
+            return
+        payload = [CMD_FETCH, len(miss)]
+        for c in miss:
+            payload += list(c) + [self.number_in[c[0]]]
+        self._send(payload)
+        self._fetch(miss, [self.number_in[c[0]] for c in miss])
+
+    def _fetch(self, cells, numbers):
+        a, X = self.a, self.a.exchange
+        by_owner = [[c for c, n in zip(cells, numbers) if n % self.world == r] for r in range(self.world)]
+        width = max(len(x) for x in by_owner[1:]) if self.world > 1 else 0
+        if not width:
+            return
+        buf = X.zeros((width, 3, a.n_mb))
+        if self.rank:
+            for k, c in enumerate(by_owner[self.rank]):
+                a.export_map(c + (0,), buf[k])
+        out = X.gather(buf)
+        if self.rank == 0:
+            for r in range(1, self.world):
+                for k, c in enumerate(by_owner[r]):
+                    a.import_map(c + (0,), out[r][k])
+                    self.stats["maps_fetched"] += 1
+            self.stats["bytes_maps"] += (self.world - 1) * width * 3 * a.n_mb * 4
+            self.stats["fetch_commands"] += 1
 
     def stop(self):
-        import torch
-        if self.world > 1:
-            self._bcast(torch.tensor([1], dtype=torch.int64))
-            self._bcast(torch.tensor([CMD_STOP], dtype=torch.int64))
+        self._send([CMD_STOP])
 
     # ---- ranks 1 .. world-1 ----
     def serve(self):
         import torch
+        ns2 = (self.a.bframes + 2) ** 2
         while True:
-            ln = int(self._bcast(torch.zeros(1, dtype=torch.int64))[0])
-            cmd = self._bcast(torch.zeros(ln, dtype=torch.int64)).tolist()
+            ln = int(self._bcast_cmd(torch.zeros(1, dtype=torch.int64))[0])
+            cmd = self._bcast_cmd(torch.zeros(ln, dtype=torch.int64)).tolist()
             if cmd[0] == CMD_STOP:
                 return
+            if cmd[0] == CMD_FETCH:
+                n = cmd[1]
+                rec = [cmd[2 + 6 * k: 8 + 6 * k] for k in range(n)]
+                self._fetch([tuple(r[:5]) for r in rec], [r[5] for r in rec])
+                continue
             n = cmd[1]
-            self._run_chunk(cmd[4:4 + n], cmd[4 + n:4 + 2 * n], (cmd[2], cmd[3]))
+            self._run_chunk(cmd[4:4 + n], cmd[4 + n:4 + 2 * n], (cmd[2], cmd[3]), cmd[4 + 2 * n:4 + 2 * n + ns2])
+
+
+class Exchange:
+    """The collectives of WindowShard over torch.distributed.  on_device: tensors live on this rank's GPU and every collective is
+    issued under the context's own HIP stream (backend nccl = RCCL over xGMI), so exports, collectives and imports are ordered on
+    the device and no host thread waits.  Otherwise (gloo: the CPU tests, and two ranks sharing one GPU) tensors are staged through
+    host memory: `before` runs ahead of a collective (wait for the exports), `after` behind it (wait for the upload)."""
+
+    def __init__(self, dist, rank, world, torch_device=None, stream=None, before=None, after=None):
+        self.dist, self.rank, self.world, self.dev, self.stream, self.before, self.after = dist, rank, world, torch_device, stream, before, after
+        self.on_device = stream is not None
+
+    def _ctx(self):
+        import contextlib
+        import torch
+        return torch.cuda.stream(self.stream) if self.on_device else contextlib.nullcontext()
+
+    def zeros(self, shape):
+        import torch
+        with self._ctx():
+            return torch.zeros(shape, dtype=torch.int32, device=self.dev if self.dev is not None else "cpu")
+
+    def _host(self, t):
+        if self.on_device or self.dev is None:
+            return t
+        if self.before:
+            self.before()
+        return t.cpu()
+
+    def _back(self, ts):
+        if self.on_device or self.dev is None:
+            return ts
+        ts = [t.to(self.dev) for t in ts]
+        if self.after:
+            self.after()
+        return ts
+
+    def all_gather(self, buf):
+        import torch
+        with self._ctx():
+            h = self._host(buf)
+            out = [torch.empty_like(h) for _ in range(self.world)]
+            self.dist.all_gather(out, h)
+            return self._back(out)
+
+    def gather(self, buf):
+        import torch
+        with self._ctx():
+            h = self._host(buf)
+            out = [torch.empty_like(h) for _ in range(self.world)] if self.rank == 0 else None
+            self.dist.gather(h, out, dst=0)
+            return self._back(out) if out is not None else None
 
 
 class HipAdapter:
     """WindowShard over a device context (x264hip_ctx) of this rank's GPU.  frames: callable frame_number -> (device pointer, stride)
-    of the full-resolution luma on THIS device (every rank needs the reference frames of the searches it runs: in the benchmark
-    the clip is resident on every GPU; a caller with one input copy would all-gather the lowres planes instead)."""
+    of the full-resolution luma on THIS device (a rank reads the references of its frames' searches: with 2 (bframes + 1) + 1 >= world
+    that is every frame of the window, so the input is broadcast once -- run_window_shard -- and every rank makes its own planes)."""
 
-    def __init__(self, L, ctx_handle, cfg, frames, torch_device):
+    def __init__(self, L, ctx_handle, cfg, frames, torch_device, dist=None, rank=0, world=1, exchange_on_device=True):
         import ctypes as C
         self.C, self.L, self.h, self.cfg, self.frames, self.dev = C, L, ctx_handle, cfg, frames, torch_device
-        mb_w, mb_h = (cfg["width"] + 15) // 16, (cfg["height"] + 15) // 16
-        self.n_mb, self.bframes = mb_w * mb_h, cfg["bframes"]
+        mb_w, self.mb_h = (cfg["width"] + 15) // 16, (cfg["height"] + 15) // 16
+        self.n_mb, self.bframes = mb_w * self.mb_h, cfg["bframes"]
         self.own_ingest = False  # rank 0's frames are ingested by its host lookahead (put_frame)
+        self.dist, self.rank, self.world, self.exchange_on_device = dist, rank, world, exchange_on_device
+        self.exchange = None
+        self._keep = []
         L.x264hip_frame_put.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.x264hip_export_field.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.x264hip_import_field.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        for f in ("x264hip_spec_cells", "x264hip_export_cells", "x264hip_import_cells"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_int, C.c_void_p] + ([C.c_void_p] if f != "x264hip_spec_cells" else [])
+        L.x264hip_fields_remote.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.x264hip_cells_missing.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.x264hip_export_cell_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.x264hip_import_cell_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.x264hip_cell_classes.argtypes = [C.c_void_p, C.c_void_p]
+        L.x264hip_stream_handle.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+
+    def attach(self, ctx_handle):
+        """the context exists now: bind the exchange to its stream"""
+        import torch
+        self.h = ctx_handle
+        stream = None
+        if self.exchange_on_device and self.world > 1:
+            sp = self.C.c_void_p()
+            self._ck(self.L.x264hip_stream_handle(self.h, self.C.byref(sp)), "stream_handle")
+            stream = torch.cuda.ExternalStream(sp.value, device=self.dev)
+        self.stream = stream
+        self.exchange = Exchange(self.dist, self.rank, self.world, self.dev, stream,
+                                 before=lambda: self._ck(self.L.x264hip_synchronize(self.h), "synchronize"),
+                                 after=lambda: torch.cuda.synchronize(self.dev))
 
     def _ck(self, rc, what):
         from . import lib
         lib._ck(rc, what)
+
+    def _refs(self, cells):
+        from . import lib
+        arr = (lib.CellRef * len(cells))()
+        for i, c in enumerate(cells):
+            arr[i] = lib.CellRef(*[int(v) for v in c])
+        return arr
+
+    def _hold(self, t):
+        """tensors the context's stream still reads: kept for a few calls (every consumer is stream-ordered behind its producer)"""
+        self._keep.append(t)
+        if len(self._keep) > 64:
+            del self._keep[:32]
+        return t
 
     def ingest(self, slot, number):
         if not self.own_ingest:
@@ -191,7 +401,9 @@ class HipAdapter:
     def classes(self):
         a, b = self.C.c_uint(), self.C.c_uint()
         self._ck(self.L.x264hip_field_classes(self.h, self.C.byref(a), self.C.byref(b)), "field_classes")
-        return a.value, b.value
+        cc = (self.C.c_ubyte * ((self.bframes + 2) ** 2))()
+        self._ck(self.L.x264hip_cell_classes(self.h, cc), "cell_classes")
+        return a.value, b.value, list(cc)
 
     def search(self, reqs):
         if not reqs:
@@ -200,55 +412,102 @@ class HipAdapter:
         arr = lambda k: (self.C.c_int * n)(*[r[k] for r in reqs])  # noqa: E731
         self._ck(self.L.x264hip_search_fields(self.h, n, arr(0), arr(1), arr(2), arr(3)), "search_fields")
 
-    def export(self, keys):
-        import torch
-        out = torch.empty((len(keys), self.n_mb, 2), dtype=torch.int32, device=self.dev)
+    def export_fields(self, keys, out):
+        self._hold(out)
         for i, (slot, lst, dm1) in enumerate(keys):
             self._ck(self.L.x264hip_export_field(self.h, slot, lst, dm1, self.C.c_void_p(out[i].data_ptr())), "export_field")
-        self._ck(self.L.x264hip_synchronize(self.h), "synchronize")  # the collective runs on torch's stream
-        return out
 
-    def import_(self, keys, t):
-        import torch
-        t = t.to(self.dev).contiguous()  # (a CPU tensor when the exchange ran over gloo)
-        torch.cuda.synchronize()  # the gathered data was produced on torch's stream; the context reads it on its own
-        for i, (slot, lst, dm1) in enumerate(keys):
+    def import_fields(self, keys, t, rows):
+        assert t.is_contiguous()
+        self._hold(t)
+        for (slot, lst, dm1), i in zip(keys, rows):
             self._ck(self.L.x264hip_import_field(self.h, slot, lst, dm1, self.C.c_void_p(t[i].data_ptr())), "import_field")
-        self._keep = t  # until the context's stream has consumed it
 
-    def finish(self, slots, numbers):
-        n = len(slots)
-        self.L.x264hip_prefetch_ex.argtypes = [self.C.c_void_p, self.C.c_void_p, self.C.c_void_p, self.C.c_int, self.C.c_int]
-        self._ck(self.L.x264hip_prefetch_ex(self.h, (self.C.c_int * n)(*slots), (self.C.c_int * n)(*numbers), n, 1), "prefetch_ex")
+    def spec_cells(self, cells):
+        if cells:
+            self._ck(self.L.x264hip_spec_cells(self.h, len(cells), self._refs(cells)), "spec_cells")
+
+    def export_cells(self, cells, out):
+        self._hold(out)
+        self._ck(self.L.x264hip_export_cells(self.h, len(cells), self._refs(cells), self.C.c_void_p(out.data_ptr())), "export_cells")
+
+    def import_cells(self, cells, t):
+        assert t.is_contiguous()
+        self._hold(t)
+        self._ck(self.L.x264hip_import_cells(self.h, len(cells), self._refs(cells), self.C.c_void_p(t.data_ptr())), "import_cells")
+
+    def fields_remote(self, keys):
+        if not keys:
+            return
+        n = len(keys)
+        arr = lambda k: (self.C.c_int * n)(*[int(r[k]) for r in keys])  # noqa: E731
+        self._ck(self.L.x264hip_fields_remote(self.h, n, arr(0), arr(1), arr(2), arr(3)), "fields_remote")
+
+    def cells_missing(self, cells):
+        out = (self.C.c_ubyte * len(cells))()
+        self._ck(self.L.x264hip_cells_missing(self.h, len(cells), self._refs(cells), out), "cells_missing")
+        return [bool(v) for v in out]
+
+    def export_map(self, cell, out):
+        self._hold(out)
+        self._ck(self.L.x264hip_export_cell_map(self.h, self._refs([cell]), self.C.c_void_p(out.data_ptr())), "export_cell_map")
+
+    def import_map(self, cell, t):
+        assert t.is_contiguous()
+        self._hold(t)
+        self._ck(self.L.x264hip_import_cell_map(self.h, self._refs([cell]), self.C.c_void_p(t.data_ptr())), "import_cell_map")
 
 
-def run_window_shard(torch, lib, dist, rank, world, dev_index, cfg, dev_clip, exchange_on_device, qp_offsets=False):
+def run_window_shard(torch, lib, dist, rank, world, dev_index, cfg, dev_clip, exchange_on_device, qp_offsets=False, broadcast_input=False):
     """One pass of ONE stream over `world` ranks: returns (outputs on rank 0 | None, seconds, WindowShard.stats).
-    dev_clip: [F, H, W] tensor of the whole clip resident on this rank's GPU (the same content on every rank)."""
+    dev_clip: [F, H, W] tensor of the whole clip resident on this rank's GPU (the same content on every rank), or, with
+    broadcast_input, the clip on rank 0 and an uninitialised tensor of the same shape elsewhere: the one input copy is then broadcast
+    inside the timed region (W x H bytes per frame over xGMI) before the ranks make their own lowres planes."""
     import time
     F, W = dev_clip.shape[0], cfg["width"]
     ptrs = [dev_clip[i].data_ptr() for i in range(F)]
     L = lib.load()
-    adapter = HipAdapter(L, None, cfg, lambda n: (ptrs[n], W), torch.device("cuda", dev_index))
-    ws = WindowShard(adapter, dist, rank, world, device=torch.device("cuda", dev_index) if exchange_on_device else None)
+    dev = torch.device("cuda", dev_index)
+    adapter = HipAdapter(L, None, cfg, lambda n: (ptrs[n], W), dev, dist, rank, world, exchange_on_device)
+    cmd_group = None
+    if world > 1 and exchange_on_device and dist.get_backend() == "nccl":
+        cmd_group = dist.new_group(backend="gloo")  # commands are a few int64 words: keep them off the GPU
+    ws = WindowShard(adapter, dist, rank, world, device=dev if (exchange_on_device and cmd_group is None) else None, cmd_group=cmd_group)
     # every rank opens the same context geometry; only rank 0 drives its lookahead
-    la = lib.Lookahead(cfg, device=dev_index, max_frames=F + 4, prefetch_hook=ws.on_prefetch if rank == 0 else None)
-    adapter.h = la.ctx_handle()
+    la = lib.Lookahead(cfg, device=dev_index, max_frames=F + 4, prefetch_hook=ws.on_prefetch if rank == 0 else None,
+                       mbtree_hook=ws.before_mbtree if rank == 0 and world > 1 else None)
+    adapter.attach(la.ctx_handle())
     adapter.own_ingest = rank != 0
     try:
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
+        if broadcast_input and world > 1:
+            dist.broadcast(dev_clip, src=0)
+            torch.cuda.synchronize()  # (the collective ran on torch's stream; the contexts read the pictures on their own)
         outs = None
         if rank == 0:
-            outs = la.run(device_ptrs=ptrs, stride=W, paced=False, qp_offsets=qp_offsets)
-            ws.stop()
+            try:
+                outs = la.run(device_ptrs=ptrs, stride=W, paced=False, qp_offsets=qp_offsets)
+            finally:
+                if world > 1:
+                    ws.stop()  # also on failure: the other ranks are waiting for a command
         else:
             ws.serve()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        return outs, time.perf_counter() - t0, ws.stats
+        dt = time.perf_counter() - t0
+        counters = np.zeros(16, np.uint64)
+        import ctypes as C
+        lib._ck(L.x264hip_counters(la.ctx_handle(), counters.ctypes.data_as(C.c_void_p), 16), "counters")
+        ws.stats.update(searches_here=int(counters[0]), cells_here=int(counters[5]), cells_on_demand=int(counters[7]), remote_fields_searched_here=int(counters[8]),
+                        remote_maps_recomputed_here=int(counters[9]), maps_imported=int(counters[10]), cells_imported_ctx=int(counters[11]))
+        if broadcast_input and world > 1:
+            ws.stats["bytes_input_broadcast"] = int(dev_clip.numel() * dev_clip.element_size())
+        return outs, dt, ws.stats
     finally:
         la.close()
+        if cmd_group is not None:
+            dist.destroy_process_group(cmd_group)
