@@ -394,10 +394,10 @@ def main():
     outs = outs_all[0]
     prof_ms = prof_launches = prof_searches = 0
     la_stats = np.zeros(8, np.uint64)
-    dev_counters = np.zeros(8, np.uint64)
+    dev_counters = np.zeros(16, np.uint64)
     for la in las:
-        cbuf = np.zeros(8, np.uint64)
-        lib._ck(la.L.x264hip_counters(la.ctx_handle(), cbuf.ctypes.data_as(ctypes.c_void_p), 8), "counters")
+        cbuf = np.zeros(16, np.uint64)
+        lib._ck(la.L.x264hip_counters(la.ctx_handle(), cbuf.ctypes.data_as(ctypes.c_void_p), 16), "counters")
         dev_counters += cbuf
         ms_, nl_, ns_ = lib.search_profile(la.L, la.ctx_handle(), 0)
         prof_ms += ms_; prof_launches += nl_; prof_searches += ns_
@@ -499,7 +499,10 @@ def main():
                                 "weights_analysed": int(la_stats[2]), "weights_kept": int(la_stats[3]),
                                 "device": {"searches": int(dev_counters[0]), "cell_requests": int(dev_counters[1]), "cell_hits": int(dev_counters[4]),
                                            "cells_on_demand": int(dev_counters[7]), "cells_speculated": int(dev_counters[5]),
-                                           "fields_claimed": int(dev_counters[2]), "weight_sums_from_cache": int(dev_counters[6])},
+                                           "fields_claimed": int(dev_counters[2]), "searches_on_demand": int(dev_counters[13]), "weight_sums_from_cache": int(dev_counters[6]),
+                                           "unclaimed_field_share": round(1.0 - float(dev_counters[2]) / max(float(dev_counters[0]) - float(dev_counters[13]), 1.0), 4),
+                                           "unused_cell_share": round(1.0 - float(dev_counters[4]) / max(float(dev_counters[5]), 1.0), 4),
+                                           "note": "counters since the contexts were opened (warm-up, timed steps)"},
                                 "host_ms": {"frame_cost": round(la_stats[4] / 1e6, 2), "weights_analyse": round(la_stats[5] / 1e6, 2),
                                             "prefetch_mbtree": round(la_stats[6] / 1e6, 2), "api_total": round(la_stats[7] / 1e6, 2)}},
         }

@@ -170,6 +170,14 @@ int  x264hip_geometry( x264hip_ctx *ctx, int *mb_w, int *mb_h, int *lowres_strid
  * calls pick the finished fields up instead of searching.  Never changes results. */
 int  x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *frame_numbers, int n );
 
+/* What the caller's decisions looked like lately, as a hint for the speculation above: frames anchor_frame + k * period are expected to
+ * be coded as P (anchors), the period - 1 frames between two of them as B-frames (period 0 = no expectation).  Which fields and cells
+ * the decision flow asks for depends on a frame's position between its anchors; the context keeps, per ( period, position ), how many
+ * frames asked for each (list, distance) field class and each (d0, d1) cell class, and -- once enough frames of a position have come
+ * and gone -- speculates for a frame at that position only the classes such frames did ask for.  A request for anything that was not
+ * speculated is served on demand as always.  Never changes results. */
+int  x264hip_gop_hint( x264hip_ctx *ctx, int anchor_frame, int period );
+
 /* The two halves of x264hip_prefetch separately: flags = X264HIP_PREFETCH_CELLS_ONLY skips the searches (the fields are expected
  * to arrive through x264hip_import_field) and only enqueues the speculative cost cells over the fields that exist. */
 #define X264HIP_PREFETCH_CELLS_ONLY 1
@@ -362,15 +370,21 @@ int  x264hip_ads_batch( x264hip_ctx *ctx, int n, const x264hip_ads_call *calls, 
  *    right after x264_mc_init and copies the five pointers into h->mc.  The pointers the encoder passes are host pointers: every
  *    call stages its operands through device memory, so these members are drop-in correct, not fast; the fast forms are the
  *    x264hip_* entries above that take device pointers (x264hip_hpel_filter, x264hip_frame_init_lowres_core, x264hip_mbtree, ...).
- *    The functions have no context argument (neither have the reference's), so one context per process is bound by the last
- *    x264hip_mc_fill call; they return void, a device failure latches the context like x264_opencl_t.b_fatal_error.
+ *    The functions have no context argument (neither have the reference's), so the library keeps a process-wide registry: one bound
+ *    context per bit depth (the last x264hip_*_fill call of that depth), plus contexts registered for an encoder handle
+ *    (x264hip_mc_bind_handle: mbtree_propagate_list receives the x264_t * and reads the picture geometry of the context registered for
+ *    it).  The members may be called from any thread: calls are serialised by the registry lock and a bound context cannot be closed
+ *    under a running call.  They return like the originals; a device failure latches the context like x264_opencl_t.b_fatal_error.
  *  - x264_pixel_function_t / x264_dct_function_t / x264_quant_function_t: every member is a per-block call (an 8x8 SAD reads 128
- *    bytes and returns an int); behind a host function pointer each call would cost a PCIe round trip (~10 us) for ~10 ns of work,
- *    and the reference calls them millions of times per frame from a serial loop.  They are therefore exported in BATCH form only
- *    -- x264hip_pixel_cmp_batch (sad / satd, all 7 sizes), x264hip_pixel_metric_batch (ssd, sa8d, var, hadamard_ac, vsad, asd8),
+ *    bytes and returns an int); behind a host function pointer each call costs a PCIe round trip (~50 us) for ~10 ns of work, and
+ *    the reference calls them millions of times per frame from a serial loop.  The FAST forms are therefore the batch entries --
+ *    x264hip_pixel_cmp_batch (sad / satd, all 7 sizes), x264hip_pixel_metric_batch (ssd, sa8d, var, hadamard_ac, vsad, asd8),
  *    x264hip_var2_batch, x264hip_ads_batch, x264hip_dct_batch (all 9 dctf entries), x264hip_quant_batch (all 5 quantf entries) --
  *    and the hot callers of those tables on this path (slicetype_mb_cost, x264_me_search_ref) run on the device as a whole behind
- *    the coarse hook (x264hip_frame_cost), which is where the reference's own accelerator boundary is (slicetype.c:878-897). */
+ *    the coarse hook (x264hip_frame_cost), which is where the reference's own accelerator boundary is (slicetype.c:878-897).
+ *    For completeness of the table-shaped boundary x264hip_pixel_fill / x264hip_dct_fill / x264hip_quant_fill hand out members with
+ *    the reference's exact signatures as well (same member names; `pixel` / `dctcoef` / `udctcoef` by the context's bit depth): each
+ *    call stages its one block through the batch entry -- drop-in correct, three orders of magnitude slower than the C version. */
 typedef struct x264hip_mc_functions
 {
     void (*plane_copy)( void *dst, intptr_t i_dst, void *src, intptr_t i_src, int w, int h );
@@ -381,7 +395,45 @@ typedef struct x264hip_mc_functions
                                    int len, int list );
 } x264hip_mc_functions;
 int  x264hip_mc_fill( x264hip_ctx *ctx, x264hip_mc_functions *pf );
-void x264hip_mc_unbind( x264hip_ctx *ctx ); /* done by x264hip_close as well */
+/* x264_dct_function_t (common/dct.h:29-59): the forward transforms */
+typedef struct x264hip_dct_functions
+{
+    void (*sub4x4_dct)( void *dct /* dctcoef[16] */, void *pix1, void *pix2 );
+    void (*sub8x8_dct)( void *dct /* dctcoef[4][16] */, void *pix1, void *pix2 );
+    void (*sub8x8_dct_dc)( void *dct /* dctcoef[4] */, void *pix1, void *pix2 );
+    void (*sub8x16_dct_dc)( void *dct /* dctcoef[8] */, void *pix1, void *pix2 );
+    void (*sub16x16_dct)( void *dct /* dctcoef[16][16] */, void *pix1, void *pix2 );
+    void (*sub8x8_dct8)( void *dct /* dctcoef[64] */, void *pix1, void *pix2 );
+    void (*sub16x16_dct8)( void *dct /* dctcoef[4][64] */, void *pix1, void *pix2 );
+    void (*dct4x4dc)( void *d /* dctcoef[16] */ );
+    void (*dct2x4dc)( void *dct /* dctcoef[8] */, void *dct4x4 /* dctcoef[8][16] */ );
+} x264hip_dct_functions;
+int  x264hip_dct_fill( x264hip_ctx *ctx, x264hip_dct_functions *pf );
+/* x264_quant_function_t (common/quant.h:30-45): the quantisers */
+typedef struct x264hip_quant_functions
+{
+    int (*quant_8x8)( void *dct /* dctcoef[64] */, void *mf /* udctcoef[64] */, void *bias );
+    int (*quant_4x4)( void *dct, void *mf, void *bias );
+    int (*quant_4x4x4)( void *dct /* dctcoef[4][16] */, void *mf, void *bias );
+    int (*quant_4x4_dc)( void *dct, int mf, int bias );
+    int (*quant_2x2_dc)( void *dct /* dctcoef[4] */, int mf, int bias );
+} x264hip_quant_functions;
+int  x264hip_quant_fill( x264hip_ctx *ctx, x264hip_quant_functions *pf );
+/* x264_pixel_function_t (common/pixel.h:78-100): sad / ssd / satd over the sizes PIXEL_16x16 .. PIXEL_4x4, sa8d[PIXEL_16x16], sa8d[PIXEL_8x8],
+ * var[PIXEL_16x16 / PIXEL_8x16 / PIXEL_8x8], hadamard_ac[PIXEL_16x16 .. PIXEL_8x8]; entries the reference leaves empty are NULL */
+typedef struct x264hip_pixel_functions
+{
+    int (*sad[8])( void *pix1, intptr_t i_stride1, void *pix2, intptr_t i_stride2 );
+    int (*ssd[8])( void *pix1, intptr_t i_stride1, void *pix2, intptr_t i_stride2 );
+    int (*satd[8])( void *pix1, intptr_t i_stride1, void *pix2, intptr_t i_stride2 );
+    int (*sa8d[4])( void *pix1, intptr_t i_stride1, void *pix2, intptr_t i_stride2 );
+    uint64_t (*var[4])( void *pix, intptr_t stride );
+    uint64_t (*hadamard_ac[4])( void *pix, intptr_t stride );
+} x264hip_pixel_functions;
+int  x264hip_pixel_fill( x264hip_ctx *ctx, x264hip_pixel_functions *pf );
+/* registers the context for an encoder handle: mbtree_propagate_list( h, ... ) then works on THAT context's picture geometry */
+int  x264hip_mc_bind_handle( x264hip_ctx *ctx, const void *encoder_handle );
+void x264hip_mc_unbind( x264hip_ctx *ctx ); /* every binding of the context; done by x264hip_close as well */
 
 /* timing of the most recent search launch in ms (HIP events on the context's stream) and counters */
 int  x264hip_last_search_ms( x264hip_ctx *ctx, float *ms, int *n_searches, int *n_blocks );
@@ -461,6 +513,7 @@ typedef struct x264hip_backend
     int (*add_quant_offsets)( void *user, int slot, const float *quant_offsets );
     int (*frame_put_batch_yuv)( void *user, int n, const int *slots, const void *const *luma_dev, int stride, const void *const *cb_dev,
                                 const void *const *cr_dev, int cstride ); /* may be NULL: the pictures go in one by one */
+    int (*gop_hint)( void *user, int anchor_frame, int period ); /* contract of x264hip_gop_hint, called in front of prefetch; may be NULL */
 } x264hip_backend;
 
 typedef struct x264hip_la_frame
@@ -486,6 +539,9 @@ int  x264hip_lookahead_open_hooked( x264hip_lookahead **out, int device, const x
  * the propagation is about to read (x264hip_cells_missing / x264hip_import_cell_map).  NULL = none. */
 typedef int (*x264hip_mbtree_hook)( void *user, const x264hip_mbtree_op *ops, int n );
 int  x264hip_lookahead_set_mbtree_hook( x264hip_lookahead *la, x264hip_mbtree_hook hook, void *user );
+/* How many frames beyond the reach of the next decision one speculative submission covers when more than that are queued (batch
+ * ingest); 0 = the default (256; 64 for a hooked lookahead, whose chunks are rounds of collectives).  Never changes results. */
+int  x264hip_lookahead_set_chunk( x264hip_lookahead *la, int frames );
 /* Same host logic over a caller-supplied backend (plugin / test hook). */
 int  x264hip_lookahead_open_backend( x264hip_lookahead **out, const x264hip_la_params *params, const x264hip_backend *backend );
 void x264hip_lookahead_close( x264hip_lookahead *la );

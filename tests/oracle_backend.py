@@ -34,13 +34,19 @@ class OracleBackend:
         self.on_mbtree = None
         self.cells_from_owner = self.cells_here = self.remote_fields_searched_here = self.maps_recomputed_here = 0
         self.variant_req = {}
+        self.gop_hints = []
         self.verify_imported = False
         self.struct = lib.Backend(None, lib.FRAME_PUT_FN(self._put), lib.FRAME_STATS_FN(self._stats),
                                   lib.WEIGHT_COST_FN(self._wcost), lib.FRAME_COST_FN(self._cost),
                                   lib.PREFETCH_FN(self._prefetch) if speculative else lib.PREFETCH_FN(0),
                                   lib.MBTREE_FN(self._mbtree), lib.QP_OFFSETS_FN(self._qp), lib.PUT_BATCH_FN(0),
                                   lib.PREFETCH_WEIGHTS_FN(self._prefetch_weights) if speculative else lib.PREFETCH_WEIGHTS_FN(0),
-                                  lib.RECALC_FN(self._recalc), lib.ROW_SATDS_FN(self._rows), lib.FRAME_PUT_YUV_FN(self._put_yuv), lib.ADD_QOFFS_FN(self._add_qoffs), lib.PUT_BATCH_YUV_FN(0))
+                                  lib.RECALC_FN(self._recalc), lib.ROW_SATDS_FN(self._rows), lib.FRAME_PUT_YUV_FN(self._put_yuv), lib.ADD_QOFFS_FN(self._add_qoffs), lib.PUT_BATCH_YUV_FN(0),
+                                  lib.GOP_HINT_FN(self._gop_hint) if speculative else lib.GOP_HINT_FN(0))
+
+    def _gop_hint(self, user, anchor, period):
+        self.gop_hints.append((anchor, period))
+        return 0
 
     def _prefetch(self, user, slots, numbers, n):
         if self.on_prefetch is not None:  # window sharding (x264_amd/shard.py): the speculative searches of this chunk, spread over ranks

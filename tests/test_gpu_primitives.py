@@ -348,3 +348,116 @@ def test_mc_fill_exact_signature_members(depth):
         assert np.array_equal(have[0], want[0]) and np.array_equal(have[1], want[1])
     finally:
         ctx.close()
+
+
+_CMP = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t)
+_ONE = C.CFUNCTYPE(C.c_uint64, C.c_void_p, C.c_ssize_t)
+
+
+class PixelFunctions(C.Structure):
+    """x264hip_pixel_functions (member names and signatures of x264_pixel_function_t, common/pixel.h:78-100)"""
+    _fields_ = [("sad", _CMP * 8), ("ssd", _CMP * 8), ("satd", _CMP * 8), ("sa8d", _CMP * 4), ("var", _ONE * 4), ("hadamard_ac", _ONE * 4)]
+
+
+_SUB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p)
+
+
+class DctFunctions(C.Structure):
+    """x264hip_dct_functions (x264_dct_function_t, common/dct.h:29-59)"""
+    _fields_ = [("sub4x4_dct", _SUB), ("sub8x8_dct", _SUB), ("sub8x8_dct_dc", _SUB), ("sub8x16_dct_dc", _SUB), ("sub16x16_dct", _SUB), ("sub8x8_dct8", _SUB),
+                ("sub16x16_dct8", _SUB), ("dct4x4dc", C.CFUNCTYPE(None, C.c_void_p)), ("dct2x4dc", C.CFUNCTYPE(None, C.c_void_p, C.c_void_p))]
+
+
+_Q = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+_QDC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
+
+
+class QuantFunctions(C.Structure):
+    """x264hip_quant_functions (x264_quant_function_t, common/quant.h:30-45)"""
+    _fields_ = [("quant_8x8", _Q), ("quant_4x4", _Q), ("quant_4x4x4", _Q), ("quant_4x4_dc", _QDC), ("quant_2x2_dc", _QDC)]
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_table_fillers_exact_signature_members(depth):
+    """x264hip_pixel_fill / x264hip_dct_fill / x264hip_quant_fill: members with the reference's exact signatures, called the way the
+    encoder calls h->pixf.* / h->dctf.* / h->quantf.* -- host pointers INTO macroblock buffers (fenc stride 16, fdec stride 32, any block
+    offset), one block per call -- against the oracle.  Also: two contexts of different bit depth stay bound side by side, and the
+    members can be called from several threads at once."""
+    from tests.test_vtable_blocks_host import DCT_COEFS
+    o = Oracle(depth)
+    maxv = (1 << depth) - 1
+    rng = np.random.default_rng(17 + depth)
+    ctx = lib.Context(64, 64, bit_depth=depth, max_frames=2, mv_range=32)
+    other = lib.Context(64, 64, bit_depth=18 - depth, max_frames=2, mv_range=32)  # the other bit depth: its binding must not disturb ours
+    try:
+        L = ctx.L
+        pf, df, qf, opf = PixelFunctions(), DctFunctions(), QuantFunctions(), PixelFunctions()
+        for name, st in (("pixel", pf), ("dct", df), ("quant", qf)):
+            fn = getattr(L, "x264hip_%s_fill" % name)
+            fn.argtypes = [C.c_void_p, C.c_void_p]
+            assert fn(ctx.h, C.byref(st)) == 0
+        assert L.x264hip_pixel_fill(other.h, C.byref(opf)) == 0
+        sizes = [(16, 16), (16, 8), (8, 16), (8, 8), (8, 4), (4, 8), (4, 4)]
+        # the encoder's macroblock buffers: 48 rows of FENC_STRIDE, 54 rows of FDEC_STRIDE (common/common.h), blocks at interior offsets
+        fenc = rng.integers(0, maxv + 1, size=(48, 16)).astype(o.dtype)
+        fdec = rng.integers(0, maxv + 1, size=(54, 32)).astype(o.dtype)
+        fenc[:4, :4] = maxv; fdec[:4, :4] = 0
+        isz = fenc.itemsize
+        for idx, (w, h) in enumerate(sizes):
+            for (ye, xe, yd, xd) in ((0, 0, 0, 0), (16 - h, 16 - w, 2 + 16 - h, 16 - w), (4 * (h < 16), 4 * (w < 16), 7, 13)):
+                a, b = _ptr(fenc, ye * 16 + xe), _ptr(fdec, yd * 32 + xd)
+                for name, fo in (("sad", "sad"), ("satd", "satd"), ("ssd", "ssd")):
+                    want = o.f(fo, C.c_int)(a, 16, b, 32, w, h)
+                    assert getattr(pf, name)[idx](a, 16, b, 32) == want, (name, w, h, ye, xe)
+            if (w, h) in ((16, 16), (8, 8)):
+                assert pf.sa8d[idx](_ptr(fenc), 16, _ptr(fdec, 64), 32) == o.f("sa8d", C.c_int)(_ptr(fenc), 16, _ptr(fdec, 64), 32, w)
+            if (w, h) in ((16, 16), (8, 16), (8, 8)):
+                assert pf.var[idx](_ptr(fdec, 37), 32) == o.f("var", C.c_uint64)(_ptr(fdec, 37), 32, w, h), ("var", w, h)
+            if idx < 4:
+                assert pf.hadamard_ac[idx](_ptr(fdec, 70), 32) == o.f("hadamard_ac", C.c_uint64)(_ptr(fdec, 70), 32, w, h), ("hadamard_ac", w, h)
+        assert not pf.sa8d[1] and not pf.var[1] and not pf.sad[7]  # entries the reference leaves empty stay NULL
+        # dct members: (kind of x264hip_dct_batch, member)
+        for kind, name in ((0, "sub4x4_dct"), (1, "sub8x8_dct"), (2, "sub16x16_dct"), (3, "sub8x8_dct8"), (4, "sub16x16_dct8"), (5, "sub8x8_dct_dc"), (6, "sub8x16_dct_dc")):
+            bs = 16 if "16x16" in name else 8 if "8x" in name else 4
+            ye = xe = 0 if bs == 16 else 8 if bs == 8 else 12
+            a, b = _ptr(fenc, ye * 16 + xe), _ptr(fdec, (2 + ye) * 32 + xe)
+            want = np.zeros(DCT_COEFS[kind], o.coef_dtype); got = np.full(DCT_COEFS[kind], 7, o.coef_dtype)
+            o.f("dct")(kind, _ptr(want), a, b)
+            getattr(df, name)(_ptr(got), a, b)
+            assert np.array_equal(got, want), name
+        co = rng.integers(-4000, 4000, size=16).astype(o.coef_dtype); want = co.copy()
+        o.f("dct")(7, _ptr(want), None, None); df.dct4x4dc(_ptr(co))
+        assert np.array_equal(co, want)
+        blk = rng.integers(-4000, 4000, size=(8, 16)).astype(o.coef_dtype)
+        want = np.ascontiguousarray(blk[:, 0]); o.f("dct")(8, _ptr(want), None, None)
+        got = np.zeros(8, o.coef_dtype); keep = blk.copy()
+        df.dct2x4dc(_ptr(got), _ptr(blk))
+        assert np.array_equal(got, want) and (blk[:, 0] == 0).all() and np.array_equal(blk[:, 1:], keep[:, 1:])
+        # quant members
+        lim = 30000 if depth == 8 else 1 << 20
+        for kind, name, nc in ((1, "quant_8x8", 64), (0, "quant_4x4", 16), (2, "quant_4x4x4", 64)):
+            nt = 64 if kind == 1 else 16
+            mf = rng.integers(1, 30000 if depth == 8 else 1 << 18, size=nt).astype(o.ucoef_dtype)
+            bias = rng.integers(0, 30000, size=nt).astype(o.ucoef_dtype)
+            co = rng.integers(-lim, lim + 1, size=nc).astype(o.coef_dtype); want = co.copy()
+            r = o.f("quant", C.c_int)(kind, _ptr(want), _ptr(mf), _ptr(bias), 0, 0)
+            assert getattr(qf, name)(_ptr(co), _ptr(mf), _ptr(bias)) == r and np.array_equal(co, want), name
+        for kind, name, nc in ((3, "quant_4x4_dc", 16), (4, "quant_2x2_dc", 4)):
+            co = rng.integers(-lim, lim + 1, size=nc).astype(o.coef_dtype); want = co.copy()
+            r = o.f("quant", C.c_int)(kind, _ptr(want), None, None, 11000, 20000)
+            assert getattr(qf, name)(_ptr(co), 11000, 20000) == r and np.array_equal(co, want), name
+        # re-entrancy: the same members from four threads at once (the reference calls table members from its frame threads)
+        import threading
+        errs = []
+
+        def hammer(seed):
+            r2 = np.random.default_rng(seed)
+            fe = r2.integers(0, maxv + 1, size=(16, 16)).astype(o.dtype); fd = r2.integers(0, maxv + 1, size=(16, 32)).astype(o.dtype)
+            for _ in range(40):
+                if pf.satd[3](_ptr(fe), 16, _ptr(fd), 32) != o.f("satd", C.c_int)(_ptr(fe), 16, _ptr(fd), 32, 8, 8):
+                    errs.append(seed)
+        th = [threading.Thread(target=hammer, args=(s,)) for s in range(4)]
+        [t.start() for t in th]; [t.join() for t in th]
+        assert not errs
+    finally:
+        ctx.close(); other.close()

@@ -176,6 +176,7 @@ def test_chunked_submission_of_a_long_queue():
     spy_fn = lib.PREFETCH_FN(spy)  # keep the callback object alive for the lifetime of the lookahead
     be.struct.prefetch = spy_fn
     la = lib.Lookahead(cfg, backend=be.struct, max_frames=nf + 4)
+    la.set_chunk(64)
     try:
         outs = _run_unpaced(la, frames)
     finally:

@@ -590,7 +590,7 @@ struct CellArgs
     int *row_satds, *row_satds_intra;
     int *acc;                     // [5]: cost_est, cost_est_aq, intra_mbs, intra_cost_est, intra_cost_est_aq
     int *blk;                     // [n_mb] scratch: final block cost | b_intra << 30, input of cell_reduce_kernel
-    const void *fenc0, *ref0_0, *ref1_0; // B cells: plane-0 origin of the source frame, strip copies (me_search.h) of the two references
+    const void *fenc0, *ref0_0, *ref1_0; // B cells: strip copies (me_search.h) of the source frame's plane 0 and of the two references' planes
     int sums_only;                // reduce only: intra sums of a frame, no maps written (speculative [0][0] sums)
     int pad_;
     int *acc_dev;                 // device copy of acc[0..4] (what x264hip_export_cells packs for another rank)
@@ -757,11 +757,9 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
     const int by = blockIdx.y, bx0 = blockIdx.x * CELLB_BPW;
     const int nb = imin2( CELLB_BPW, P.mb_w - bx0 );
     const int half = lane >> 5, slot = ( lane >> 3 ) & 3, l = lane & 7; // block of the pair, candidate slot, row of the block
-    const int border = LA_PAD * P.stride + LA_PAD;
-    const T *fbase = (const T *)A.fenc0 - border, *s0base = (const T *)A.ref0_0, *s1base = (const T *)A.ref1_0; // strips of the two references
+    const T *fbase = (const T *)A.fenc0, *s0base = (const T *)A.ref0_0, *s1base = (const T *)A.ref1_0; // strips of the source frame's plane 0 and of the two references
     const int strip_elems = ( P.plane_elems / P.stride ) * 16;
     const int row16 = ( 8 * by + l + LA_PAD ) << 4;
-    const int frow = border + ( 8 * by + l ) * P.stride;
     const int bipred_weight = P.weighted_bipred ? 64 - ( A.dist_scale_factor >> 2 ) : 32;
     const int range = 2 * P.mv_range;
     const int smin_y = imax2( 4 * ( -8 * by - 12 ), -range ), smax_y = imin2( 4 * ( 8 * ( P.mb_h - by - 1 ) + 12 ), range - 1 );
@@ -798,7 +796,7 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
         if( P.subme <= 1 ) { ax &= ~1; ay &= ~1; cx &= ~1; cy &= ~1; } // half-pel plane pick (slicetype.c:582-589)
         const int bx = bx0 + kk;
         const int cx0 = 8 * bx + LA_PAD;
-        const Px8 f = load_px8_at( fbase, frow + 8 * bx );
+        const Px8 f = load_px8_at( fbase, strip_off( cx0, row16, strip_elems ) );
         const Px8 ra = qpel_px8_strips( s0base, P.plane_elems, strip_elems, cx0, row16, ax, ay );
         const Px8 rb = qpel_px8_strips( s1base, P.plane_elems, strip_elems, cx0, row16, cx, cy );
         Px8 pred;
@@ -1546,4 +1544,14 @@ __global__ __launch_bounds__( 256 ) void narrow_clip15_kernel( uint16_t *__restr
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if( i < n ) dst[i] = (uint16_t)( src[i] < 32767 ? src[i] : 32767 );
+}
+// only the entries a row's scatter added to are saturated (MC_CLIP_ADD, common/mc.c:527-598); the others keep the caller's 16 bits
+__global__ __launch_bounds__( 256 ) void narrow_changed_kernel( uint16_t *__restrict__ dst, const int *__restrict__ sum32, const uint16_t *__restrict__ before, int n )
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if( i < n )
+    {
+        const int v = sum32[i], o = before[i];
+        dst[i] = (uint16_t)( v != o ? ( v < 32767 ? v : 32767 ) : o );
+    }
 }

@@ -25,7 +25,7 @@ static inline bool auto_or_b( int t ) { return t == T_AUTO || is_b( t ); }
 
 const int BMAX = X264HIP_BFRAME_MAX;
 const int LOOKAHEAD_MAX = 250; // X264_LOOKAHEAD_MAX, common/base.h:140
-const int LA_PREFETCH_CHUNK = 64; // frames of read-ahead per speculative submission (X264HIP_LA_CHUNK overrides it for experiments)
+const int LA_PREFETCH_CHUNK = 256; // frames of read-ahead per speculative submission (X264HIP_LA_CHUNK overrides it for experiments)
 const uint64_t COST_MAX64 = 1ULL << 60;
 
 // adds the wall time of its scope to a statistics slot (x264hip_lookahead_stats)
@@ -102,6 +102,8 @@ struct Lookahead
     x264hip_prefetch_hook prefetch_hook = nullptr; // x264hip_lookahead_open_hooked
     void *prefetch_hook_user = nullptr;
     x264hip_mbtree_hook mbtree_hook = nullptr;     // x264hip_lookahead_set_mbtree_hook
+    int chunk_frames = 0;                          // x264hip_lookahead_set_chunk (0 = default)
+    int gop_len[3] = { 0, 0, 0 };                  // frames of the last three mini-GOPs decided (newest first): the speculation hint
     void *mbtree_hook_user = nullptr;
 
     int run_mbtree( std::vector<x264hip_mbtree_op> &ops )
@@ -898,6 +900,8 @@ struct Lookahead
         while( !settle_type( n_b, n_b, n_bref ) )
             n_b++;
         next[n_b]->i_bframes = n_b;
+        gop_len[2] = gop_len[1]; gop_len[1] = gop_len[0];
+        gop_len[0] = is_i( next[n_b]->i_type ) ? 0 : n_b + 1; // (a mini-GOP closed by an I frame says nothing about the ones behind it)
         if( p.b_pyramid && n_b > 1 && !n_bref )
         {
             next[( n_b - 1 ) / 2]->i_type = T_BREF; // the middle B-frame of the run becomes a reference
@@ -979,7 +983,10 @@ struct Lookahead
     {
         pending_prefetch.clear();
         if( !be.prefetch ) return;
-        static const int chunk = getenv( "X264HIP_LA_CHUNK" ) ? ( atoi( getenv( "X264HIP_LA_CHUNK" ) ) > 2 ? atoi( getenv( "X264HIP_LA_CHUNK" ) ) : 2 ) : LA_PREFETCH_CHUNK;
+        // (a hooked lookahead -- the window shard -- works in smaller chunks: a chunk is one round of collectives, and the other ranks
+        // should be busy with the next one while rank 0 decides on this one)
+        static const int chunk_env = getenv( "X264HIP_LA_CHUNK" ) ? ( atoi( getenv( "X264HIP_LA_CHUNK" ) ) > 2 ? atoi( getenv( "X264HIP_LA_CHUNK" ) ) : 2 ) : 0;
+        const int chunk = chunk_frames ? chunk_frames : chunk_env ? chunk_env : prefetch_hook ? 64 : LA_PREFETCH_CHUNK;
         const int reach = (int)next.size() < i_delay + 2 ? (int)next.size() : i_delay + 2;
         int submitted = 0;
         while( submitted < (int)next.size() && next[submitted]->prefetch_submitted ) submitted++;
@@ -997,6 +1004,12 @@ struct Lookahead
             next[i]->prefetch_submitted = true;
         }
         ScopeNs tm( stats[6] );
+        if( be.gop_hint && !err )
+        {
+            // three mini-GOPs of one length in a row: expect the frames ahead to fall the same way (the backend speculates by position)
+            const int period = last_nonb && gop_len[0] > 0 && gop_len[0] == gop_len[1] && gop_len[1] == gop_len[2] ? gop_len[0] : 0;
+            need( be.gop_hint( be.user, last_nonb ? last_nonb->i_frame : 0, period ) );
+        }
         if( prefetch_hook )
             need( prefetch_hook( prefetch_hook_user, slots.data(), nums.data(), (int)slots.size() ) );
         else
@@ -1058,6 +1071,7 @@ static int dev_put_batch( void *u, int n, const int *slots, const void *const *l
 {
     return x264hip_frame_put_batch( (x264hip_ctx *)u, n, slots, luma, stride );
 }
+static int dev_gop_hint( void *u, int anchor, int period ) { return x264hip_gop_hint( (x264hip_ctx *)u, anchor, period ); }
 static int dev_prefetch_weights( void *u, int n, const int *sf, const int *sr, const x264hip_weight *w )
 {
     return x264hip_prefetch_weight_costs( (x264hip_ctx *)u, n, sf, sr, w );
@@ -1139,7 +1153,7 @@ extern "C" int x264hip_lookahead_open( x264hip_lookahead **out, int device, cons
     x264hip_ctx *ctx = nullptr;
     int rc = x264hip_open( &ctx, device, &p.dev );
     if( rc ) return rc;
-    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch, dev_mbtree, dev_qp_offsets, dev_put_batch, dev_prefetch_weights, dev_recalc, dev_row_satds, dev_frame_put_yuv, dev_add_quant_offsets, dev_put_batch_yuv };
+    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch, dev_mbtree, dev_qp_offsets, dev_put_batch, dev_prefetch_weights, dev_recalc, dev_row_satds, dev_frame_put_yuv, dev_add_quant_offsets, dev_put_batch_yuv, dev_gop_hint };
     rc = x264hip_lookahead_open_backend( out, &p, &be );
     if( rc ) { x264hip_close( ctx ); return rc; }
     ( *out )->L.ctx = ctx;
@@ -1152,6 +1166,13 @@ extern "C" int x264hip_lookahead_open_hooked( x264hip_lookahead **out, int devic
     if( rc ) return rc;
     ( *out )->L.prefetch_hook = hook;
     ( *out )->L.prefetch_hook_user = user;
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_lookahead_set_chunk( x264hip_lookahead *la, int frames )
+{
+    if( !la || frames < 0 ) return X264HIP_EINVAL;
+    la->L.chunk_frames = frames == 0 ? 0 : frames < 2 ? 2 : frames;
     return X264HIP_OK;
 }
 
@@ -1185,6 +1206,7 @@ extern "C" int x264hip_lookahead_reset( x264hip_lookahead *la )
         if( f != L.last_nonb ) { L.free_slots.push_back( f->slot ); delete f; }
     if( L.last_nonb ) { L.free_slots.push_back( L.last_nonb->slot ); delete L.last_nonb; }
     L.next.clear(); L.current.clear(); L.last_nonb = nullptr; L.pending_prefetch.clear();
+    // (gop_len stays: the next sequence on this context is expected to be decided like the last one until it shows otherwise)
     L.i_input = 0;
     L.i_last_keyframe = -L.p.keyint_max;
     L.i_prev_duration = L.i_prev_duration0;

@@ -47,7 +47,8 @@
 template <typename T>
 struct SearchDesc
 {
-    const T *fenc0;             // source frame: origin of the row-major plane 0
+    const T *fenc0;             // source frame: strip copy of its plane 0 (a block's eight rows are 128 consecutive samples: one or two cache lines
+                                // where the row-major plane costs eight -- the kernel is bound by L1 line accesses once the chip is full)
     const T *ref_strips;        // reference frame: strip copy of its four planes, start of the allocation
     const T *refw_strips;       // strip copy of the weighted plane 0 or nullptr
     WtD wt;
@@ -305,7 +306,11 @@ struct GroupEval
 #pragma unroll
         for( int j = 0; j < N; j++ )
         {
-            const Px8 a = load_px8_at( sbase, ta[j] + S.row16 ), bb = load_px8_at( sbase, tb[j] + S.row16 );
+            // both taps of a full- or half-pel position are the same sample: one load (the branch is uniform inside the group)
+            const Px8 a = load_px8_at( sbase, ta[j] + S.row16 );
+            Px8 bb = a;
+            if( tb[j] != ta[j] )
+                bb = load_px8_at( sbase, tb[j] + S.row16 );
             Px8 r;
             r.lo = avg_px4( a.lo, bb.lo, (const T *)nullptr ); r.hi = avg_px4( a.hi, bb.hi, (const T *)nullptr );
             if( WEIGHTED )
@@ -419,13 +424,11 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
     C.refine4 = MODE == 3 ? P.subpel_refine >= 3 : MODE >= 1;
     C.mbcmp_satd = MODE == 3 ? P.mbcmp_satd : MODE >= 1;
     C.fpelcmp_satd = MODE == 3 ? P.fpelcmp_satd : MODE == 2;
-    const int border = LA_PAD * P.stride + LA_PAD;
-    const T *fbase = D.fenc0 - border;
+    const T *fbase = D.fenc0;
     const T *sbase = D.ref_strips;
     const T *wsbase = WEIGHTED ? D.refw_strips : sbase;
     const int strip_elems = ( P.plane_elems / P.stride ) * 16; // rows of the padded plane x 16 samples
     const int tab_centre = 2 * 4 * P.mv_range;
-    const int row_off = ( lane & 7 ) * P.stride; // this lane's row inside an 8x8 block
     // end row of the band this row belongs to (slicetype.c:917-918): rows of one band do not see the vectors of the band below
     int band_end = H;
     for( int sl = P.n_slices - 1; sl >= 1; sl-- )
@@ -508,9 +511,8 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
                     mvpx = melogic::median3( mvcx[0], mvcx[1], mvcx[2] );
                     mvpy = melogic::median3( mvcy[0], mvcy[1], mvcy[2] );
                 }
-                const int lane_off = border + 8 * ( by * P.stride + bx ) + row_off;
                 const int cx0 = 8 * bx + LA_PAD, row16 = ( 8 * by + LA_PAD ) << 4; // the block's row 0; this lane's row is LS.row16 further
-                const Px8 f = load_px8_at( fbase, lane_off );
+                const Px8 f = load_px8_at( fbase, strip_off( cx0, row16 + LS.row16, strip_elems ) );
                 bool done = false;
                 if( !( mvpx | mvpy ) )
                 {

@@ -84,6 +84,10 @@ struct FrameSlot
     // 2: its vectors are here (x264hip_import_cell_map), its costs are not.  0: an ordinary local field
     unsigned char field_remote[2][X264HIP_BFRAME_MAX + 1];
     int *cell_sums = nullptr;         // [(bf+2)*(bf+2)][8] device copy of the cell sums (x264hip_export_cells)
+    // speculation by position (x264hip_gop_hint): the ( period, position ) this frame was speculated under, and what it was asked for
+    int pos_key = 0;                  // period * 32 + position, 0 = no expectation
+    unsigned req_fields[2] = { 0, 0 };// bit d: (list, distance d + 1) requested
+    std::vector<unsigned char> req_cells; // [(bf+2)*(bf+2)]
     int wplane_idx = -1;          // weighted-plane pool entry in use by this slot's current weighted search
     uint64_t sum = 0, ssd = 0;
     int stats_valid = 0;
@@ -152,6 +156,8 @@ struct x264hip_ctx
     char *chroma_staging = nullptr, *chroma_dev = nullptr; // host-buffer ingest with chroma: pinned + device copies of Cb and Cr (allocated on first use)
     size_t staging_bytes = 0;
     std::vector<char *> wplanes;     // weighted plane pool
+    char *vt_pool = nullptr;         // staging memory of the function-table members (x264hip_mc_fill & co.), grow-only
+    size_t vt_pool_bytes = 0;
     std::vector<int> wplane_owner;
     unsigned tag_serial = 1;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -161,7 +167,7 @@ struct x264hip_ctx
     std::vector<int> prof_n;
     int prof_on = 0, prof_used = 0;
     double prof_ms = 0; uint64_t prof_launches = 0, prof_searches = 0;
-    uint64_t counters[16] = { 0 }; // [8] remote fields searched here after all [9] remote cell maps recomputed here [10] maps imported [11] cells imported [12] fields registered as remote
+    uint64_t counters[16] = { 0 }; // [8] remote fields searched here after all [9] remote cell maps recomputed here [10] maps imported [11] cells imported [12] fields registered as remote [13] searches on demand (x264hip_frame_cost)
     // how often callers asked for each B cell class with / without a searched L0 field of the list-1 reference
     // (slicetype.c:629-642): speculation evaluates the variant asked for more often so far
     uint32_t variant_req[( X264HIP_BFRAME_MAX + 2 ) * ( X264HIP_BFRAME_MAX + 2 )][2] = { { 0 } };
@@ -174,6 +180,13 @@ struct x264hip_ctx
     uint32_t cell_spec[( X264HIP_BFRAME_MAX + 2 ) * ( X264HIP_BFRAME_MAX + 2 )] = { 0 };
     uint32_t n_requests = 0;
     static const uint32_t LEARN_REQUESTS = 400;
+    // speculation by position: hint of the caller, and per ( period, position ) key the number of frames that have come and gone and
+    // how many of them asked for each field / cell class
+    int hint_anchor = 0, hint_period = 0;
+    static const int POS_KEYS = 32 * ( X264HIP_BFRAME_MAX + 2 ), POS_LEARN_FRAMES = 24;
+    std::vector<uint32_t> pos_frames;             // [POS_KEYS]
+    std::vector<uint32_t> pos_field_req;          // [POS_KEYS][2][BFRAME_MAX + 1]
+    std::vector<uint32_t> pos_cell_req;           // [POS_KEYS][n_cells]
 };
 
 static const char *const g_errstr[] = { "ok", "no usable HIP device", "invalid argument", "out of memory", "device failure",
@@ -233,6 +246,7 @@ static void free_all( x264hip_ctx *ctx )
         (void)hipFree( s.planes ); // one allocation per slot holds everything
     }
     for( auto w : ctx->wplanes ) (void)hipFree( w );
+    if( ctx->vt_pool ) (void)hipFree( ctx->vt_pool );
     (void)hipFree( ctx->cost_mv_dev ); (void)hipFree( ctx->luts_dev ); (void)hipFree( ctx->sync_words );
     ring_free( ctx->cell_ring ); ring_free( ctx->put_ring ); ring_free( ctx->search_ring ); ring_free( ctx->wjob_ring ); ring_free( ctx->xfer_ring );
     (void)hipHostFree( ctx->err_host );
@@ -372,6 +386,9 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( hipMemset( ctx->me_prof, 0, 12 * sizeof( unsigned long long ) ) );
 #endif
     ctx->n_cells = ( p.bframes + 2 ) * ( p.bframes + 2 );
+    ctx->pos_frames.assign( x264hip_ctx::POS_KEYS, 0 );
+    ctx->pos_field_req.assign( (size_t)x264hip_ctx::POS_KEYS * 2 * ( X264HIP_BFRAME_MAX + 1 ), 0 );
+    ctx->pos_cell_req.assign( (size_t)x264hip_ctx::POS_KEYS * ctx->n_cells, 0 );
     OPENCK( hipHostMalloc( &ctx->cell_acc_host, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
     memset( ctx->cell_acc_host, 0, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) );
     OPENCK( hipHostMalloc( &ctx->err_host, sizeof( unsigned ) ) );
@@ -441,6 +458,7 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         s.prop = (int *)( base + o_prop ); s.qp_aq = (float *)( base + o_qpa ); s.qp = (float *)( base + o_qp );
         s.cell_sums = (int *)( base + o_sums );
         s.cells.assign( nc, CellEntry() );
+        s.req_cells.assign( nc, 0 );
         memset( s.field_tag, 0, sizeof( s.field_tag ) );
         memset( s.field_ready, 0, sizeof( s.field_ready ) );
         memset( s.field_prefetched, 0, sizeof( s.field_prefetched ) );
@@ -522,6 +540,21 @@ static int launch_ingest_t( x264hip_ctx *ctx, const PutDesc *descs_dev, const Pu
 
 static void slot_reset( x264hip_ctx *ctx, FrameSlot &s )
 {
+    if( s.in_use && s.pos_key )
+    {
+        // the frame that leaves this slot has been asked for everything it will ever be asked for: count it under its position
+        const int k = s.pos_key;
+        ctx->pos_frames[k]++;
+        for( int l = 0; l < 2; l++ )
+            for( int d = 0; d <= X264HIP_BFRAME_MAX; d++ )
+                if( s.req_fields[l] >> d & 1 )
+                    ctx->pos_field_req[( (size_t)k * 2 + l ) * ( X264HIP_BFRAME_MAX + 1 ) + d]++;
+        for( int c = 0; c < ctx->n_cells; c++ )
+            if( s.req_cells[c] )
+                ctx->pos_cell_req[(size_t)k * ctx->n_cells + c]++;
+    }
+    s.pos_key = 0; s.req_fields[0] = s.req_fields[1] = 0;
+    std::fill( s.req_cells.begin(), s.req_cells.end(), 0 );
     s.in_use = 1;
     s.gen++;
     s.stats_valid = 0;
@@ -768,7 +801,7 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         const SearchReq &r = reqs[order[i]];
         FrameSlot &b = ctx->slots[r.slot_b], &rf = ctx->slots[r.slot_ref];
         SearchDesc<T> d;
-        d.fenc0 = plane_origin<T>( ctx, b, 0 );
+        d.fenc0 = (const T *)( b.planes + 4 * ctx->plane_bytes );
         d.ref_strips = (const T *)( rf.planes + 4 * ctx->plane_bytes );
         d.refw_strips = nullptr;
         d.wt = r.wt;
@@ -876,7 +909,7 @@ static CellArgs make_cell( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_
         {
             A.mvq1 = b.mvq[1][d1 - 1]; A.costs1 = b.mvcost[1][d1 - 1];
             A.ref1_l0 = A.ref1_l0_valid ? f1.mvq[0][d0 + d1 - 1] : nullptr;
-            A.fenc0 = plane_origin<T>( ctx, b, 0 ); A.ref0_0 = f0.planes + 4 * ctx->plane_bytes; A.ref1_0 = f1.planes + 4 * ctx->plane_bytes;
+            A.fenc0 = b.planes + 4 * ctx->plane_bytes; A.ref0_0 = f0.planes + 4 * ctx->plane_bytes; A.ref1_0 = f1.planes + 4 * ctx->plane_bytes;
         }
     }
     A.intra_cost = b.lowres_costs; // cell [0][0] (frame.c:283)
@@ -938,6 +971,14 @@ static int launch_cells_t( x264hip_ctx *ctx, const std::vector<SpecCell> &cells 
     return X264HIP_OK;
 }
 
+extern "C" int x264hip_gop_hint( x264hip_ctx *ctx, int anchor_frame, int period )
+{
+    if( !ctx || period < 0 ) return X264HIP_EINVAL;
+    ctx->hint_anchor = anchor_frame;
+    ctx->hint_period = period <= X264HIP_BFRAME_MAX + 1 ? period : 0;
+    return X264HIP_OK;
+}
+
 extern "C" int x264hip_prefetch( x264hip_ctx *ctx, const int *slots, const int *frame_numbers, int n )
 {
     return x264hip_prefetch_ex( ctx, slots, frame_numbers, n, 0 );
@@ -953,10 +994,32 @@ extern "C" int x264hip_prefetch_ex( x264hip_ctx *ctx, const int *slots, const in
     const int bf = ctx->p.bframes, nstride = bf + 2;
     static const bool no_learn = getenv( "X264HIP_NO_CLASS_LEARNING" ) != nullptr; // debugging aid: speculate everything
     const bool learned = !no_learn && ctx->n_requests >= x264hip_ctx::LEARN_REQUESTS;
+    static const bool no_pos = getenv( "X264HIP_NO_POSITION_CLASSES" ) != nullptr; // debugging aid: ignore x264hip_gop_hint
+    // a class is worth speculating for a frame at a known position if at least one in ten of the frames seen there asked for it
+    auto pos_wants_field = [&]( const FrameSlot &f, int list, int dm1 ) {
+        const int k = f.pos_key;
+        if( !k || ctx->pos_frames[k] < (uint32_t)x264hip_ctx::POS_LEARN_FRAMES ) return true;
+        return ctx->pos_field_req[( (size_t)k * 2 + list ) * ( X264HIP_BFRAME_MAX + 1 ) + dm1] * 10 >= ctx->pos_frames[k];
+    };
+    auto pos_wants_cell = [&]( const FrameSlot &f, int idx ) {
+        const int k = f.pos_key;
+        if( !k || ctx->pos_frames[k] < (uint32_t)x264hip_ctx::POS_LEARN_FRAMES ) return true;
+        return ctx->pos_cell_req[(size_t)k * ctx->n_cells + idx] * 10 >= ctx->pos_frames[k];
+    };
     for( int i = 0; i < n; i++ )
     {
         if( !slot_ok( ctx, slots[i] ) || !ctx->slots[slots[i]].in_use ) return X264HIP_ESTATE;
         ctx->slots[slots[i]].frame_no = frame_numbers[i];
+        {
+            // the position this frame is expected to take between two anchors (0 = an anchor itself), under the caller's current hint
+            FrameSlot &f = ctx->slots[slots[i]];
+            const int per = no_pos ? 0 : ctx->hint_period;
+            int key = 0;
+            if( per > 0 && per <= X264HIP_BFRAME_MAX + 1 && frame_numbers[i] > ctx->hint_anchor )
+                key = per * 32 + ( frame_numbers[i] - ctx->hint_anchor ) % per + 1;
+            // a frame keeps the key it was first speculated under unless that was "no expectation": its requests are counted there
+            if( !f.pos_key ) f.pos_key = key;
+        }
         for( int j = 0; j < n; j++ )
         {
             const int d = frame_numbers[j] - frame_numbers[i]; // reference j relative to source i
@@ -966,6 +1029,7 @@ extern "C" int x264hip_prefetch_ex( x264hip_ctx *ctx, const int *slots, const in
             FrameSlot &b = ctx->slots[slots[i]];
             if( b.field_ready[list][dm1] || b.field_prefetched[list][dm1] ) continue;
             if( learned && !ctx->field_req[list][dm1] ) continue; // a class this caller never asks for
+            if( !pos_wants_field( b, list, dm1 ) ) continue;       // ... or hardly ever for a frame at this position
             if( flags & X264HIP_PREFETCH_CELLS_ONLY ) continue;     // the fields come from elsewhere (x264hip_import_field)
             b.field_prefetched[list][dm1] = 1;
             ctx->field_spec[list][dm1]++;
@@ -1004,6 +1068,7 @@ extern "C" int x264hip_prefetch_ex( x264hip_ctx *ctx, const int *slots, const in
                 CellEntry &e = b.cells[d0 * nstride + d1];
                 if( e.valid || e.requested ) continue;
                 if( learned && !ctx->cell_req[d0 * nstride + d1] ) continue;
+                if( !pos_wants_cell( b, d0 * nstride + d1 ) ) continue;
                 int j1 = j0, variant = 1;
                 unsigned t1 = 0, tr = 0;
                 if( d1 )
@@ -1125,11 +1190,12 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
     std::vector<SearchReq> reqs;
     ctx->n_requests++;
     ctx->cell_req[idx]++;
+    b.req_cells[idx] = 1;
     if( !intra_only )
     {
         const WtD wt = make_wt( ctx, w );
-        if( do_search[0] ) ctx->field_req[0][d0 - 1]++;
-        if( b_bidir && do_search[1] ) ctx->field_req[1][d1 - 1]++;
+        if( do_search[0] ) { ctx->field_req[0][d0 - 1]++; b.req_fields[0] |= 1u << ( d0 - 1 ); }
+        if( b_bidir && do_search[1] ) { ctx->field_req[1][d1 - 1]++; b.req_fields[1] |= 1u << ( d1 - 1 ); }
         if( do_search[0] )
         {
             if( b.field_prefetched[0][d0 - 1] && !wt.on )
@@ -1157,6 +1223,7 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
             if( ref1_l0_valid && !f1.field_ready[0][d0 + d1 - 1] )
                 return X264HIP_ESTATE;
         }
+        ctx->counters[13] += reqs.size(); // searches on demand
         int r = launch_searches( ctx, reqs );
         if( r ) return r;
     }
@@ -2250,38 +2317,75 @@ extern "C" int x264hip_ads_batch( x264hip_ctx *ctx, int n, const x264hip_ads_cal
     return X264HIP_OK;
 }
 
-// ---- x264_mc_functions_t members with the reference's exact signatures (common/mc.h:292,306-307,326-327,333-337) -----------------------
-// The vtable functions of the reference carry no context argument, so the filler binds them to one context per process; the
-// pointers are HOST pointers like the ones the encoder passes, staged through device memory on every call (correct and
-// signature-compatible; a caller that cares about speed keeps its planes on the device and uses the x264hip_* entries that take
-// device pointers).  The functions return void like the originals: a device failure latches the context (x264hip_synchronize and
-// every other call then return X264HIP_EDEVICE), which is how slicetype-cl.c:44-56 reports errors as well.
+// ---- function-table members with the reference's exact signatures (common/mc.h:292,306-307,326-327,333-337; common/pixel.h:78-100;
+// common/dct.h:29-59; common/quant.h:30-45) ---------------------------------------------------------------------------------------------
+// The table functions of the reference carry no context argument.  The filler therefore binds them through a process-wide registry:
+// one context per bit depth (the reference's tables are bit-depth templated too: x264_8_*, x264_10_*), plus, for the one member that
+// receives the encoder handle (mbtree_propagate_list), contexts registered per handle (x264hip_mc_bind_handle) so that two encoders
+// with different picture sizes can coexist.  The members may be called from any thread (the reference calls hpel_filter from its frame
+// threads, common/mc.c:704-784): every call takes the registry lock, so calls are serialised, the bound context cannot be closed under a
+// running call, and all of them share the context's staging buffer.  The pointers are HOST pointers like the ones the encoder passes,
+// staged through device memory on every call (correct and signature-compatible; a caller that cares about speed keeps its planes on the
+// device and uses the x264hip_* entries that take device pointers).  The functions return like the originals: a device failure latches
+// the context (x264hip_synchronize and every other call then return X264HIP_EDEVICE), which is how slicetype-cl.c:44-56 reports errors.
+#include <mutex>
+#include <map>
 namespace {
-x264hip_ctx *g_vt_ctx = nullptr;
+std::mutex g_vt_mutex;
+x264hip_ctx *g_vt_ctx[2] = { nullptr, nullptr };          // [bit depth 8 / 10]
+std::map<const void *, x264hip_ctx *> g_vt_by_handle;     // x264_t * -> context
 
 struct VtFail {};
 #define VTCK( call ) do { if( ( call ) != hipSuccess ) throw VtFail(); } while( 0 )
 #define VTRC( call ) do { if( ( call ) != X264HIP_OK ) throw VtFail(); } while( 0 )
 
-template <typename F>
-void vt_guard( F body )
+// staging memory of a table call: carved out of the context's grow-only pool (calls are serialised by the registry lock and every call
+// drains the stream before it returns, so one pool serves them all)
+struct VtStage
 {
-    x264hip_ctx *ctx = g_vt_ctx;
+    x264hip_ctx *ctx;
+    std::vector<size_t> off;
+    size_t total = 0;
+    explicit VtStage( x264hip_ctx *c ) : ctx( c ) {}
+    size_t add( size_t bytes ) { off.push_back( total ); total += align_up( bytes ? bytes : 1, 256 ); return off.size() - 1; }
+    void commit()
+    {
+        if( total > ctx->vt_pool_bytes )
+        {
+            if( ctx->vt_pool ) VTCK( hipFree( ctx->vt_pool ) );
+            ctx->vt_pool = nullptr; ctx->vt_pool_bytes = 0;
+            VTCK( hipMalloc( &ctx->vt_pool, total + ( total >> 1 ) ) );
+            ctx->vt_pool_bytes = total + ( total >> 1 );
+        }
+    }
+    char *at( size_t i ) const { return ctx->vt_pool + off[i]; }
+};
+
+template <typename F>
+void vt_guard_ctx( x264hip_ctx *ctx, F body )
+{
     if( !ctx || ctx->broken ) return;
     if( hipSetDevice( ctx->device ) != hipSuccess ) { ctx->broken = 1; return; }
     try { body( ctx ); }
     catch( const VtFail & ) { ctx->broken = 1; }
     catch( ... ) { ctx->broken = 1; }
 }
+template <int D, typename F>
+void vt_guard( F body )
+{
+    std::lock_guard<std::mutex> lock( g_vt_mutex );
+    vt_guard_ctx( g_vt_ctx[D], body );
+}
 
+template <int D>
 void vt_plane_copy( void *dst, intptr_t i_dst, void *src, intptr_t i_src, int w, int h )
 {
-    vt_guard( [&]( x264hip_ctx *ctx ) {
+    vt_guard<D>( [&]( x264hip_ctx *ctx ) {
         if( w <= 0 || h <= 0 ) return;
         const size_t row = (size_t)w * ctx->psz, pitch = align_up( row, 16 );
-        Staged st;
+        VtStage st( ctx );
         const size_t a = st.add( pitch * h ), b = st.add( pitch * h );
-        VTCK( hipMalloc( &st.dev, st.total ) );
+        st.commit();
         VTCK( hipMemcpy2D( st.at( a ), pitch, src, (size_t)i_src * ctx->psz, row, h, hipMemcpyHostToDevice ) );
         VTRC( x264hip_device_copy( ctx, st.at( b ), st.at( a ), pitch * h ) );
         VTCK( hipStreamSynchronize( ctx->stream ) );
@@ -2289,17 +2393,18 @@ void vt_plane_copy( void *dst, intptr_t i_dst, void *src, intptr_t i_src, int w,
     } );
 }
 
+template <int D>
 void vt_hpel_filter( void *dsth, void *dstv, void *dstc, void *src, intptr_t stride, int width, int height, int16_t *buf )
 {
     (void)buf; // the C version's scratch row; the kernel keeps its intermediate sums in LDS
-    vt_guard( [&]( x264hip_ctx *ctx ) {
+    vt_guard<D>( [&]( x264hip_ctx *ctx ) {
         if( width <= 0 || height <= 0 ) return;
         const int psz = ctx->psz;
         // the four planes get the caller's geometry on the device: rows -2 .. height+2 of `stride` samples, 8 samples of slack in front
         const size_t rows = height + 5, plane_b = ( rows * stride + 16 ) * psz;
-        Staged st;
+        VtStage st( ctx );
         const size_t i_s = st.add( plane_b ), i_h = st.add( plane_b ), i_v = st.add( plane_b ), i_c = st.add( plane_b );
-        VTCK( hipMalloc( &st.dev, st.total ) );
+        st.commit();
         auto org = [&]( size_t i ) { return st.at( i ) + ( (size_t)2 * stride + 8 ) * psz; }; // sample (0,0)
         // what the C version reads: columns -2 .. width+2 of rows -2 .. height+2 (mc.c:172-196)
         VTCK( hipMemcpy2D( org( i_s ) - ( 2 * stride + 2 ) * psz, (size_t)stride * psz, (const char *)src - ( 2 * stride + 2 ) * psz, (size_t)stride * psz,
@@ -2313,18 +2418,19 @@ void vt_hpel_filter( void *dsth, void *dstv, void *dstc, void *src, intptr_t str
     } );
 }
 
+template <int D>
 void vt_frame_init_lowres_core( void *src0, void *dst0, void *dsth, void *dstv, void *dstc, intptr_t src_stride, intptr_t dst_stride, int width, int height )
 {
-    vt_guard( [&]( x264hip_ctx *ctx ) {
+    vt_guard<D>( [&]( x264hip_ctx *ctx ) {
         if( width <= 0 || height <= 0 ) return;
         const int psz = ctx->psz;
         // reads rows 0 .. 2*height and columns 0 .. 2*width of the source (mc.c:484-507)
         const size_t s_rows = 2 * (size_t)height + 1, s_row_b = ( 2 * (size_t)width + 1 ) * psz, s_pitch = align_up( s_row_b, 16 );
         const size_t d_row_b = (size_t)width * psz, d_pitch = align_up( d_row_b, 16 );
-        Staged st;
+        VtStage st( ctx );
         const size_t i_s = st.add( s_pitch * s_rows ), i0 = st.add( d_pitch * height ), i1 = st.add( d_pitch * height ), i2 = st.add( d_pitch * height ),
                      i3 = st.add( d_pitch * height );
-        VTCK( hipMalloc( &st.dev, st.total ) );
+        st.commit();
         VTCK( hipMemcpy2D( st.at( i_s ), s_pitch, src0, (size_t)src_stride * psz, s_row_b, s_rows, hipMemcpyHostToDevice ) );
         VTRC( x264hip_frame_init_lowres_core( ctx, st.at( i_s ), st.at( i0 ), st.at( i1 ), st.at( i2 ), st.at( i3 ), (intptr_t)( s_pitch / psz ), (intptr_t)( d_pitch / psz ),
                                               width, height ) );
@@ -2336,14 +2442,15 @@ void vt_frame_init_lowres_core( void *src0, void *dst0, void *dsth, void *dstv, 
     } );
 }
 
+template <int D>
 void vt_mbtree_propagate_cost( int16_t *dst, uint16_t *propagate_in, uint16_t *intra_costs, uint16_t *inter_costs, uint16_t *inv_qscales, float *fps_factor, int len )
 {
-    vt_guard( [&]( x264hip_ctx *ctx ) {
+    vt_guard<D>( [&]( x264hip_ctx *ctx ) {
         if( len <= 0 ) return;
         const size_t b = (size_t)len * 2;
-        Staged st;
+        VtStage st( ctx );
         const size_t i_d = st.add( b ), i_p = st.add( b ), i_i = st.add( b ), i_e = st.add( b ), i_q = st.add( b );
-        VTCK( hipMalloc( &st.dev, st.total ) );
+        st.commit();
         VTCK( hipMemcpy( st.at( i_p ), propagate_in, b, hipMemcpyHostToDevice ) );
         VTCK( hipMemcpy( st.at( i_i ), intra_costs, b, hipMemcpyHostToDevice ) );
         VTCK( hipMemcpy( st.at( i_e ), inter_costs, b, hipMemcpyHostToDevice ) );
@@ -2356,17 +2463,21 @@ void vt_mbtree_propagate_cost( int16_t *dst, uint16_t *propagate_in, uint16_t *i
     } );
 }
 
+template <int D>
 void vt_mbtree_propagate_list( void *h, uint16_t *ref_costs, int16_t ( *mvs )[2], int16_t *propagate_amount, uint16_t *lowres_costs, int bipred_weight, int mb_y, int len,
                                int list )
 {
-    (void)h; // x264_t *: the C version reads the macroblock geometry from it; here that is the bound context's
-    vt_guard( [&]( x264hip_ctx *ctx ) {
+    // x264_t *: the C version reads the macroblock geometry from it; here that is the context registered for this handle
+    // (x264hip_mc_bind_handle), or the one bound for the bit depth
+    std::lock_guard<std::mutex> lock( g_vt_mutex );
+    auto it = g_vt_by_handle.find( h );
+    vt_guard_ctx( it != g_vt_by_handle.end() ? it->second : g_vt_ctx[D], [&]( x264hip_ctx *ctx ) {
         const int W = ctx->P.mb_w, H = ctx->P.mb_h, n_mb = W * H;
         if( len <= 0 || len > W || mb_y < 0 || mb_y >= H ) throw VtFail();
-        Staged st;
+        VtStage st( ctx );
         const size_t i_r16 = st.add( (size_t)n_mb * 2 ), i_r32 = st.add( (size_t)n_mb * 4 ), i_mv = st.add( (size_t)len * 4 ), i_pa = st.add( (size_t)len * 2 ),
-                     i_lc = st.add( (size_t)len * 2 );
-        VTCK( hipMalloc( &st.dev, st.total ) );
+                     i_lc = st.add( (size_t)len * 2 ), i_o16 = st.add( (size_t)n_mb * 2 );
+        st.commit();
         VTCK( hipMemcpy( st.at( i_r16 ), ref_costs, (size_t)n_mb * 2, hipMemcpyHostToDevice ) );
         VTCK( hipMemcpy( st.at( i_mv ), mvs, (size_t)len * 4, hipMemcpyHostToDevice ) );
         VTCK( hipMemcpy( st.at( i_pa ), propagate_amount, (size_t)len * 2, hipMemcpyHostToDevice ) );
@@ -2374,29 +2485,189 @@ void vt_mbtree_propagate_list( void *h, uint16_t *ref_costs, int16_t ( *mvs )[2]
         widen_u16_kernel<<<( n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( (int *)st.at( i_r32 ), (const uint16_t *)st.at( i_r16 ), n_mb );
         mbt_list_row_kernel<<<( len + 255 ) / 256, 256, 0, ctx->stream>>>( (int *)st.at( i_r32 ), (const int16_t *)st.at( i_mv ), (const int16_t *)st.at( i_pa ),
                                                                          (const uint16_t *)st.at( i_lc ), bipred_weight, mb_y, len, list, W, H );
-        narrow_clip15_kernel<<<( n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( (uint16_t *)st.at( i_r16 ), (const int *)st.at( i_r32 ), n_mb );
+        // only the entries this row added to are saturated (MC_CLIP_ADD, mc.c:527-598): everything else keeps the caller's value
+        narrow_changed_kernel<<<( n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( (uint16_t *)st.at( i_o16 ), (const int *)st.at( i_r32 ), (const uint16_t *)st.at( i_r16 ), n_mb );
         VTCK( hipGetLastError() );
         VTCK( hipStreamSynchronize( ctx->stream ) );
-        VTCK( hipMemcpy( ref_costs, st.at( i_r16 ), (size_t)n_mb * 2, hipMemcpyDeviceToHost ) );
+        VTCK( hipMemcpy( ref_costs, st.at( i_o16 ), (size_t)n_mb * 2, hipMemcpyDeviceToHost ) );
     } );
+}
+
+// ---- x264_dct_function_t / x264_quant_function_t / x264_pixel_function_t members: ONE call staged through the batch entries above.  The
+// encoder's pointers point into its macroblock buffers (fenc stride 16, fdec stride 32): exactly the rows a member reads are copied.
+template <int D, int KIND, int BW, int BH>
+void vt_sub_dct( void *dct, void *pix1, void *pix2 )
+{
+    vt_guard<D>( [&]( x264hip_ctx *ctx ) {
+        const int psz = ctx->psz;
+        std::vector<char> fe( (size_t)16 * VT_FENC_STRIDE * psz, 0 ), fd( (size_t)16 * VT_FDEC_STRIDE * psz, 0 );
+        for( int y = 0; y < BH; y++ )
+        {
+            memcpy( &fe[(size_t)y * VT_FENC_STRIDE * psz], (const char *)pix1 + (size_t)y * VT_FENC_STRIDE * psz, (size_t)BW * psz );
+            memcpy( &fd[(size_t)y * VT_FDEC_STRIDE * psz], (const char *)pix2 + (size_t)y * VT_FDEC_STRIDE * psz, (size_t)BW * psz );
+        }
+        VTRC( x264hip_dct_batch( ctx, KIND, 1, fe.data(), fd.data(), dct ) );
+    } );
+}
+template <int D>
+void vt_dct4x4dc( void *d )
+{
+    vt_guard<D>( [&]( x264hip_ctx *ctx ) { VTRC( x264hip_dct_batch( ctx, 7, 1, nullptr, nullptr, d ) ); } );
+}
+template <int D, typename C>
+void vt_dct2x4dc( void *dct, void *dct4x4 )
+{
+    vt_guard<D>( [&]( x264hip_ctx *ctx ) {
+        C *out = (C *)dct, ( *blk )[16] = (C( * )[16])dct4x4;
+        for( int i = 0; i < 8; i++ ) out[i] = blk[i][0];
+        VTRC( x264hip_dct_batch( ctx, 8, 1, nullptr, nullptr, out ) );
+        for( int i = 0; i < 8; i++ ) blk[i][0] = 0; // the DC terms move to dct[] (dct.c:109-143)
+    } );
+}
+template <int D, int KIND>
+int vt_quant( void *dct, void *mf, void *bias )
+{
+    int nz = 0;
+    vt_guard<D>( [&]( x264hip_ctx *ctx ) { VTRC( x264hip_quant_batch( ctx, KIND, 1, dct, mf, bias, 0, 0, &nz ) ); } );
+    return nz;
+}
+template <int D, int KIND>
+int vt_quant_dc( void *dct, int mf, int bias )
+{
+    int nz = 0;
+    vt_guard<D>( [&]( x264hip_ctx *ctx ) { VTRC( x264hip_quant_batch( ctx, KIND, 1, dct, nullptr, nullptr, mf, bias, &nz ) ); } );
+    return nz;
+}
+
+static const int vt_size_w[7] = { 16, 16, 8, 8, 8, 4, 4 }, vt_size_h[7] = { 16, 8, 16, 8, 4, 8, 4 }; // PIXEL_16x16 .. PIXEL_4x4 (common/pixel.h:37-59)
+// one block pair on the device: both blocks in the top-left corner of a 16x16 plane pair (what the batch entries index)
+template <int D>
+uint64_t vt_block_metric( int metric /* -1 sad, -2 satd, else X264HIP_METRIC_* */, int size_idx, void *pix1, intptr_t s1, void *pix2, intptr_t s2 )
+{
+    uint64_t result = 0;
+    vt_guard<D>( [&]( x264hip_ctx *ctx ) {
+        const int psz = ctx->psz, w = vt_size_w[size_idx], h = vt_size_h[size_idx];
+        VtStage st( ctx );
+        const size_t i_a = st.add( (size_t)16 * 16 * psz ), i_b = st.add( (size_t)16 * 16 * psz ), i_mv = st.add( 256 * 4 ), i_out = st.add( 256 * 8 );
+        st.commit();
+        VTCK( hipMemsetAsync( st.at( i_a ), 0, st.total, ctx->stream ) );
+        VTCK( hipMemcpy2DAsync( st.at( i_a ), (size_t)16 * psz, pix1, (size_t)s1 * psz, (size_t)w * psz, h, hipMemcpyHostToDevice, ctx->stream ) );
+        if( pix2 )
+            VTCK( hipMemcpy2DAsync( st.at( i_b ), (size_t)16 * psz, pix2, (size_t)s2 * psz, (size_t)w * psz, h, hipMemcpyHostToDevice, ctx->stream ) );
+        if( metric < 0 )
+        {
+            VTRC( x264hip_pixel_cmp_batch( ctx, metric == -2, size_idx, st.at( i_a ), st.at( i_b ), 16, 16 / w, 16 / h, (const int16_t *)st.at( i_mv ), (int *)st.at( i_out ) ) );
+            int v = 0;
+            VTCK( hipMemcpyAsync( &v, st.at( i_out ), 4, hipMemcpyDeviceToHost, ctx->stream ) );
+            VTCK( hipStreamSynchronize( ctx->stream ) );
+            result = (uint64_t)(unsigned)v;
+        }
+        else
+        {
+            VTRC( x264hip_pixel_metric_batch( ctx, metric, size_idx, st.at( i_a ), pix2 ? st.at( i_b ) : nullptr, 16, 1, 1, (uint64_t *)st.at( i_out ) ) );
+            VTCK( hipMemcpyAsync( &result, st.at( i_out ), 8, hipMemcpyDeviceToHost, ctx->stream ) );
+            VTCK( hipStreamSynchronize( ctx->stream ) );
+        }
+    } );
+    return result;
+}
+template <int D, int METRIC, int SIZE>
+int vt_cmp( void *pix1, intptr_t s1, void *pix2, intptr_t s2 ) { return (int)vt_block_metric<D>( METRIC, SIZE, pix1, s1, pix2, s2 ); }
+template <int D, int METRIC, int SIZE>
+uint64_t vt_one( void *pix, intptr_t stride ) { return vt_block_metric<D>( METRIC, SIZE, pix, stride, nullptr, 0 ); }
+
+template <int D>
+void fill_mc( x264hip_mc_functions *pf )
+{
+    pf->plane_copy = vt_plane_copy<D>;
+    pf->hpel_filter = vt_hpel_filter<D>;
+    pf->frame_init_lowres_core = vt_frame_init_lowres_core<D>;
+    pf->mbtree_propagate_cost = vt_mbtree_propagate_cost<D>;
+    pf->mbtree_propagate_list = vt_mbtree_propagate_list<D>;
+}
+template <int D, typename C>
+void fill_dct( x264hip_dct_functions *pf )
+{
+    pf->sub4x4_dct = vt_sub_dct<D, 0, 4, 4>;       pf->sub8x8_dct = vt_sub_dct<D, 1, 8, 8>;       pf->sub16x16_dct = vt_sub_dct<D, 2, 16, 16>;
+    pf->sub8x8_dct8 = vt_sub_dct<D, 3, 8, 8>;      pf->sub16x16_dct8 = vt_sub_dct<D, 4, 16, 16>;
+    pf->sub8x8_dct_dc = vt_sub_dct<D, 5, 8, 8>;    pf->sub8x16_dct_dc = vt_sub_dct<D, 6, 8, 16>;
+    pf->dct4x4dc = vt_dct4x4dc<D>;                 pf->dct2x4dc = vt_dct2x4dc<D, C>;
+}
+template <int D>
+void fill_quant( x264hip_quant_functions *pf )
+{
+    pf->quant_8x8 = vt_quant<D, 1>; pf->quant_4x4 = vt_quant<D, 0>; pf->quant_4x4x4 = vt_quant<D, 2>;
+    pf->quant_4x4_dc = vt_quant_dc<D, 3>; pf->quant_2x2_dc = vt_quant_dc<D, 4>;
+}
+template <int D>
+void fill_pixel( x264hip_pixel_functions *pf )
+{
+    memset( pf, 0, sizeof( *pf ) );
+#define VT_SIZE( S ) pf->sad[S] = vt_cmp<D, -1, S>; pf->satd[S] = vt_cmp<D, -2, S>; pf->ssd[S] = vt_cmp<D, X264HIP_METRIC_SSD, S>;
+    VT_SIZE( 0 ) VT_SIZE( 1 ) VT_SIZE( 2 ) VT_SIZE( 3 ) VT_SIZE( 4 ) VT_SIZE( 5 ) VT_SIZE( 6 )
+#undef VT_SIZE
+    pf->sa8d[0] = vt_cmp<D, X264HIP_METRIC_SA8D, 0>; pf->sa8d[3] = vt_cmp<D, X264HIP_METRIC_SA8D, 3>;
+    pf->var[0] = vt_one<D, X264HIP_METRIC_VAR, 0>; pf->var[2] = vt_one<D, X264HIP_METRIC_VAR, 2>; pf->var[3] = vt_one<D, X264HIP_METRIC_VAR, 3>;
+    pf->hadamard_ac[0] = vt_one<D, X264HIP_METRIC_HADAMARD_AC, 0>; pf->hadamard_ac[1] = vt_one<D, X264HIP_METRIC_HADAMARD_AC, 1>;
+    pf->hadamard_ac[2] = vt_one<D, X264HIP_METRIC_HADAMARD_AC, 2>; pf->hadamard_ac[3] = vt_one<D, X264HIP_METRIC_HADAMARD_AC, 3>;
+}
+int vt_bind( x264hip_ctx *ctx )
+{
+    if( !ctx ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    std::lock_guard<std::mutex> lock( g_vt_mutex );
+    g_vt_ctx[ctx->p.bit_depth == 8 ? 0 : 1] = ctx;
+    return X264HIP_OK;
 }
 } // namespace
 
 extern "C" int x264hip_mc_fill( x264hip_ctx *ctx, x264hip_mc_functions *pf )
 {
-    if( !ctx || !pf ) return X264HIP_EINVAL;
-    if( ctx->broken ) return X264HIP_EDEVICE;
-    g_vt_ctx = ctx;
-    pf->plane_copy = vt_plane_copy;
-    pf->hpel_filter = vt_hpel_filter;
-    pf->frame_init_lowres_core = vt_frame_init_lowres_core;
-    pf->mbtree_propagate_cost = vt_mbtree_propagate_cost;
-    pf->mbtree_propagate_list = vt_mbtree_propagate_list;
+    if( !pf ) return X264HIP_EINVAL;
+    int rc = vt_bind( ctx );
+    if( rc ) return rc;
+    if( ctx->p.bit_depth == 8 ) fill_mc<0>( pf ); else fill_mc<1>( pf );
+    return X264HIP_OK;
+}
+extern "C" int x264hip_dct_fill( x264hip_ctx *ctx, x264hip_dct_functions *pf )
+{
+    if( !pf ) return X264HIP_EINVAL;
+    int rc = vt_bind( ctx );
+    if( rc ) return rc;
+    if( ctx->p.bit_depth == 8 ) fill_dct<0, int16_t>( pf ); else fill_dct<1, int32_t>( pf );
+    return X264HIP_OK;
+}
+extern "C" int x264hip_quant_fill( x264hip_ctx *ctx, x264hip_quant_functions *pf )
+{
+    if( !pf ) return X264HIP_EINVAL;
+    int rc = vt_bind( ctx );
+    if( rc ) return rc;
+    if( ctx->p.bit_depth == 8 ) fill_quant<0>( pf ); else fill_quant<1>( pf );
+    return X264HIP_OK;
+}
+extern "C" int x264hip_pixel_fill( x264hip_ctx *ctx, x264hip_pixel_functions *pf )
+{
+    if( !pf ) return X264HIP_EINVAL;
+    int rc = vt_bind( ctx );
+    if( rc ) return rc;
+    if( ctx->p.bit_depth == 8 ) fill_pixel<0>( pf ); else fill_pixel<1>( pf );
+    return X264HIP_OK;
+}
+extern "C" int x264hip_mc_bind_handle( x264hip_ctx *ctx, const void *encoder_handle )
+{
+    if( !ctx || !encoder_handle ) return X264HIP_EINVAL;
+    std::lock_guard<std::mutex> lock( g_vt_mutex );
+    g_vt_by_handle[encoder_handle] = ctx;
     return X264HIP_OK;
 }
 extern "C" void x264hip_mc_unbind( x264hip_ctx *ctx )
 {
-    if( g_vt_ctx == ctx ) g_vt_ctx = nullptr;
+    // (waits for a table call that is running on this context: they hold the lock)
+    std::lock_guard<std::mutex> lock( g_vt_mutex );
+    for( int d = 0; d < 2; d++ )
+        if( g_vt_ctx[d] == ctx ) g_vt_ctx[d] = nullptr;
+    for( auto it = g_vt_by_handle.begin(); it != g_vt_by_handle.end(); )
+        it = it->second == ctx ? g_vt_by_handle.erase( it ) : std::next( it );
 }
 
 // ---- one lookahead window sharded over several GPUs: the unweighted motion searches of a frame run on the rank that

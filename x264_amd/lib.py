@@ -399,13 +399,16 @@ PUT_BATCH_YUV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int),
 FRAME_PUT_YUV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
 
 
+GOP_HINT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
+
+
 class Backend(C.Structure):
     _fields_ = [("user", C.c_void_p), ("frame_put", FRAME_PUT_FN), ("frame_stats", FRAME_STATS_FN),
                 ("weight_cost", WEIGHT_COST_FN), ("frame_cost", FRAME_COST_FN), ("prefetch", PREFETCH_FN),
                 ("mbtree", MBTREE_FN), ("get_qp_offsets", QP_OFFSETS_FN), ("frame_put_batch", PUT_BATCH_FN),
                 ("prefetch_weight_costs", PREFETCH_WEIGHTS_FN), ("frame_cost_recalculate", RECALC_FN),
                 ("get_row_satds", ROW_SATDS_FN), ("frame_put_yuv", FRAME_PUT_YUV_FN),
-                ("add_quant_offsets", ADD_QOFFS_FN), ("frame_put_batch_yuv", PUT_BATCH_YUV_FN)]
+                ("add_quant_offsets", ADD_QOFFS_FN), ("frame_put_batch_yuv", PUT_BATCH_YUV_FN), ("gop_hint", GOP_HINT_FN)]
 
 
 class Picture(C.Structure):
@@ -689,6 +692,9 @@ class Lookahead:
         if self.h:
             self.L.x264hip_lookahead_close(self.h)
             self.h = None
+
+    def set_chunk(self, frames):
+        _ck(self.L.x264hip_lookahead_set_chunk(self.h, int(frames)), "lookahead_set_chunk")
 
     def reset(self):
         _ck(self.L.x264hip_lookahead_reset(self.h), "lookahead_reset")

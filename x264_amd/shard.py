@@ -300,7 +300,10 @@ class Exchange:
     def zeros(self, shape):
         import torch
         with self._ctx():
-            return torch.zeros(shape, dtype=torch.int32, device=self.dev if self.dev is not None else "cpu")
+            t = torch.zeros(shape, dtype=torch.int32, device=self.dev if self.dev is not None else "cpu")
+        if not self.on_device and self.dev is not None:
+            torch.cuda.synchronize(self.dev)  # the fill ran on torch's stream; the context's export kernels write on theirs
+        return t
 
     def _host(self, t):
         if self.on_device or self.dev is None:
