@@ -524,28 +524,39 @@ def main():
                 res.update(value=window["value"], scaling="strong", ms_per_step=round(window["seconds"] * 1e3, 3))
                 res["config"] = {"workload": window["workload"], "parallelism": "window x%d" % world}
         if world == 1 and not args.no_extra and (W, H) == (1920, 1080):
-            # BASELINE configs[2]: 3840x2160, --preset slower --me umh --merange 32 (the lookahead searches with HEX, range 32, b-adapt 2,
-            # rc-lookahead 60), clips generated on the device; same check (batched == paced) as above
-            try:
-                F4 = 64
-                cfg4 = lib.la_config(3840, 2160, "slower", bit_depth=8, me="umh", me_range=32)
-                dev4 = [make_clip_device(torch, 3840, 2160, F4, 300 + sgi, 8, scene_cuts=(F4 // 3,)) for sgi in range(S)]
-                wl4 = Workload(torch, lib, shard, cfg4, dev_index, 0, S, F4, dev4, False)
+            # the other single-GPU forms of the BASELINE configurations, clips generated on the device, each with the same check as
+            # the headline (the batched passes that were timed == one encoder-paced pass: frame types and every cost cell)
+            def other_config(key, what, cfg_x, Fx, Sx, steps_x, depth_x=8, cuts=None):
                 try:
-                    dt4, o4 = wl4.timed(2, 1)
-                    dtp4, op4 = wl4.timed(1, 0, paced=True)
-                    nb4 = cfg4["bframes"] + 2
-                    for sgi in range(S):
-                        assert outputs_signature(o4[sgi], nb4) == outputs_signature(op4[sgi], nb4), "4K: batched and paced passes disagree"
-                finally:
-                    wl4.close()
-                del dev4
-                res["configs2_4k"] = {"workload": "3840x2160 8-bit, --preset slower --me umh --merange 32 (BASELINE configs[2]), %d segment(s) of %d frames "
-                                                  "in flight, clips generated on the device" % (S, F4),
-                                      "value": round(S * F4 * 2 / dt4, 2), "unit": "frames/s", "paced_fps": round(S * F4 / dtp4, 2),
-                                      "checked": "batched == paced (types + cost cells)"}
+                    devx = [make_clip_device(torch, cfg_x["width"], cfg_x["height"], Fx, 300 + sgi, depth_x, scene_cuts=cuts if cuts is not None else (Fx // 3,)) for sgi in range(Sx)]
+                    wlx = Workload(torch, lib, shard, cfg_x, dev_index, 0, Sx, Fx, devx, False)
+                    try:
+                        dtx, ox = wlx.timed(steps_x, 1)
+                        dtp, opx = wlx.timed(1, 0, paced=True)
+                        nbx = cfg_x["bframes"] + 2
+                        for sgi in range(Sx):
+                            assert outputs_signature(ox[sgi], nbx) == outputs_signature(opx[sgi], nbx), "%s: batched and paced passes disagree" % key
+                    finally:
+                        wlx.close()
+                    del devx
+                    res[key] = {"workload": what + ", %d segment(s) of %d frames in flight, clips generated on the device" % (Sx, Fx),
+                                "value": round(Sx * Fx * steps_x / dtx, 2), "unit": "frames/s", "paced_fps": round(Sx * Fx / dtp, 2),
+                                "checked": "batched == paced (types + cost cells)"}
+                except Exception as e:  # pragma: no cover
+                    res[key] = {"error": str(e)}
+            # BASELINE configs[2]: 3840x2160, --preset slower --me umh --merange 32 (the lookahead searches with HEX, range 32, b-adapt 2, rc-lookahead 60)
+            other_config("configs2_4k", "3840x2160 8-bit, --preset slower --me umh --merange 32 (BASELINE configs[2])",
+                         lib.la_config(3840, 2160, "slower", bit_depth=8, me="umh", me_range=32), 64, S, 2)
+            # BASELINE configs[4] on one GPU: 7680x4320 10-bit, --preset veryslow --me tesa (HEX with SATD full-pel costs, bframes 8, b-adapt 2,
+            # rc-lookahead 60); a dozen frames per segment: the window never fills, every frame is decided at the flush
+            other_config("configs4_8k_1gpu", "7680x4320 10-bit, --preset veryslow --me tesa (BASELINE configs[4], one GPU)",
+                         lib.la_config(7680, 4320, "veryslow", bit_depth=10, me="tesa"), 12, 4, 2, depth_x=10, cuts=(7,))
+            # BASELINE configs[3] on one GPU: one 250-frame 4K GOP, --bframes 8 --rc-lookahead 60, ONE stream (the N = 1 point of the window shard)
+            try:
+                w1 = window_shard_bench(torch, lib, shard, None, 0, 1, dev_index, backend, steps=2, paced_check=True)
+                res["configs3_4k_1gpu"] = w1
             except Exception as e:  # pragma: no cover
-                res["configs2_4k"] = {"error": str(e)}
+                res["configs3_4k_1gpu"] = {"error": str(e)}
         if not args.no_primitives:
             try:
                 res["primitives"] = primitives_bench(torch, lib, dict(cfg, width=3840, height=2160))
@@ -574,7 +585,7 @@ def main():
         raise SystemExit(3)  # a sharded run whose results differ from the single-rank run is a failure, not a figure
 
 
-def window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend, steps=2, frames=250):
+def window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend, steps=2, frames=250, paced_check=False):
     """BASELINE configs[3]: 3840x2160, one 250-frame GOP, --rc-lookahead 60 --bframes 8, ONE stream over all ranks: rank b % N runs frame
     b's searches and cost cells, the list-0 fields of list-1 references are exchanged, cell summaries are gathered to rank 0 (RCCL over
     xGMI), which decides, runs MB-tree and fetches the per-block maps MB-tree reads.  The one input copy lives on rank 0 and is
@@ -634,6 +645,22 @@ def window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend,
         else:
             res["value"] = round(frames / best, 2)
             res["cells_and_searches"] = {"searches": stats.get("searches_here", 0), "cells": stats.get("cells_here", 0), "cells_on_demand": stats.get("cells_on_demand", 0)}
+            if paced_check:
+                # the same stream through the encoder-paced put / get interface: same types, same cost cells
+                la = lib.Lookahead(cfg, device=dev_index, max_frames=0)
+                try:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    paced = la.run(device_ptrs=[clip[i].data_ptr() for i in range(frames)], stride=W, paced=True)
+                    dtp = time.perf_counter() - t0
+                finally:
+                    la.close()
+                if outputs_signature(outs, nb) != outputs_signature(paced, nb):
+                    res.pop("value")
+                    res["error"] = "MISMATCH: the batched and the encoder-paced pass of the stream disagree"
+                else:
+                    res["paced_fps"] = round(frames / dtp, 2)
+                    res["checked"] = "batched == paced (types + cost cells)"
     if world > 1:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank learns the verdict (rank 0's verification pass ends here)
     del clip

@@ -58,6 +58,11 @@ LOOKAHEAD_CASES_R2 = {
     # whole 4:2:0 pictures: the chroma planes (x264_amd.synth.make_chroma, same seed as the luma clip) enter adaptive quantisation
     "chroma_aq": ("medium", "", dict(_chroma=1), 8, 352, 288, dict(seed=23, scene_cuts=(19,), pan=(4, 1)), 40),
     "bands_auto_720p": ("veryslow", "threads=24,sync-lookahead=0,lookahead-threads=auto", dict(threads=24), 8, 1280, 720, dict(seed=20, pan=(9, 4)), 20),
+    # lookahead-less MB-tree (rc-lookahead 0 is only kept with infinite keyint or intra refresh, encoder.c:1128-1133): the propagation of
+    # one call carries over to the next through an exchange of accumulators (X264HIP_MBT_SWAP / RESET_QP, slicetype.c:1112-1124,1173-1178)
+    "la0_keyint_inf": ("medium", "keyint=infinite,rc-lookahead=0", dict(keyint_max=1 << 30, rc_lookahead=0), 8, 176, 144, dict(seed=31, scene_cuts=(21,), pan=(3, 1)), 40),
+    "la0_intra_refresh": ("medium", "intra-refresh=1,rc-lookahead=0,keyint=30", dict(intra_refresh=1, rc_lookahead=0, keyint_max=30), 8, 176, 144,
+                          dict(seed=32, scene_cuts=(17,), pan=(2, 2), fade=(25, 8, 0.7, 6)), 44),
 }
 
 EVAL_CONFIGS = [("medium", "", 8), ("slow", "me=dia", 8), ("medium", "subme=1", 8), ("veryslow", "me=tesa", 10)]

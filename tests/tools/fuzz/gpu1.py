@@ -34,9 +34,13 @@ def run(seed, n, big=False, verbose=True):
         preset = str(rng.choice(["medium", "fast", "faster", "veryfast", "slow", "slower"]))
         if sc == 0 and b_adapt == 0 and mbt:
             sc = 40  # the reference reads uninitialised intra costs there (known divergences)
+        if int(rng.integers(0, 8)) == 0:
+            # lookahead-less MB-tree: rc-lookahead 0 survives validation only with an infinite key interval (encoder.c:1128-1133); the
+            # propagation then carries over from call to call (X264HIP_MBT_SWAP / RESET_QP)
+            la, keyint = 0, 1 << 30
         nf = int(rng.integers(12, 40))
-        opts = "bframes=%d,b-adapt=%d,b-pyramid=%s,keyint=%d,scenecut=%d,rc-lookahead=%d,weightp=%d,open-gop=%d,aq-mode=%d,mbtree=%d,me=%s,subme=%d" % (
-            bframes, b_adapt, ["none", "strict", "normal"][pyr], keyint, sc, la, wp, og, aqm, mbt, me, subme)
+        opts = "bframes=%d,b-adapt=%d,b-pyramid=%s,keyint=%s,scenecut=%d,rc-lookahead=%d,weightp=%d,open-gop=%d,aq-mode=%d,mbtree=%d,me=%s,subme=%d" % (
+            bframes, b_adapt, ["none", "strict", "normal"][pyr], "infinite" if keyint == 1 << 30 else str(keyint), sc, la, wp, og, aqm, mbt, me, subme)
         over = dict(bframes=bframes, b_adapt=b_adapt, b_pyramid=pyr, keyint_max=keyint, scenecut=sc, rc_lookahead=la, weightp=wp, open_gop=og, aq_mode=aqm,
                     mb_tree=mbt, me=me, subme=subme)
         ckw = dict(seed=int(rng.integers(0, 1000)), scene_cuts=tuple(sorted(int(x) for x in rng.integers(3, nf, size=int(rng.integers(0, 3))))),

@@ -104,6 +104,7 @@ struct Lookahead
     x264hip_mbtree_hook mbtree_hook = nullptr;     // x264hip_lookahead_set_mbtree_hook
     int chunk_frames = 0;                          // x264hip_lookahead_set_chunk (0 = default)
     int gop_len[3] = { 0, 0, 0 };                  // frames of the last three mini-GOPs decided (newest first): the speculation hint
+    int chain_anchor = -1, chain_period = 0;       // the B placement of the latest analysis: its last anchor and the usual anchor spacing
     void *mbtree_hook_user = nullptr;
 
     int run_mbtree( std::vector<x264hip_mbtree_op> &ops )
@@ -813,6 +814,27 @@ struct Lookahead
                     w[j]->i_type = T_P;
             first_to_reset = !window_starts_intra + 1;
         }
+        // what the placement looks like right now, for the backend's speculation (x264hip_gop_hint): the last anchor in front of the
+        // window's closing frame (which is an anchor only because the window ends there) and the spacing most anchors have; frames
+        // that enter the window later are expected to continue the pattern from there
+        if( be.gop_hint && p.dev.bframes )
+        {
+            int gaps[8], n_gaps = 0, last = -1;
+            for( int j = n - 1; j >= 0 && n_gaps < 8; j-- )
+                if( j == 0 || !is_b( w[j]->i_type ) )
+                {
+                    if( last >= 0 ) gaps[n_gaps++] = last - j;
+                    else chain_anchor = w[j]->i_frame;
+                    last = j;
+                }
+            chain_period = 0;
+            for( int a = 0; a < n_gaps && !chain_period; a++ )
+            {
+                int same = 0;
+                for( int b = 0; b < n_gaps; b++ ) same += gaps[b] == gaps[a];
+                if( n_gaps >= 3 && same * 5 >= n_gaps * 3 ) chain_period = gaps[a];
+            }
+        }
         // pass 5: MB-tree over the types as they stand
         if( p.mb_tree )
             macroblock_tree( w, n < p.keyint_max ? n : p.keyint_max, window_starts_intra );
@@ -1006,9 +1028,15 @@ struct Lookahead
         ScopeNs tm( stats[6] );
         if( be.gop_hint && !err )
         {
-            // three mini-GOPs of one length in a row: expect the frames ahead to fall the same way (the backend speculates by position)
-            const int period = last_nonb && gop_len[0] > 0 && gop_len[0] == gop_len[1] && gop_len[1] == gop_len[2] ? gop_len[0] : 0;
-            need( be.gop_hint( be.user, last_nonb ? last_nonb->i_frame : 0, period ) );
+            // the placement of the latest analysis if there is one (the frames about to be submitted continue it); else three decided
+            // mini-GOPs of one length in a row, counted from the last anchor coded
+            if( chain_anchor >= 0 && last_nonb && chain_anchor >= last_nonb->i_frame )
+                need( be.gop_hint( be.user, chain_anchor, chain_period ) );
+            else
+            {
+                const int period = gop_len[0] > 0 && gop_len[0] == gop_len[1] && gop_len[1] == gop_len[2] ? gop_len[0] : 0;
+                need( be.gop_hint( be.user, last_nonb ? last_nonb->i_frame : 0, period ) );
+            }
         }
         if( prefetch_hook )
             need( prefetch_hook( prefetch_hook_user, slots.data(), nums.data(), (int)slots.size() ) );
@@ -1206,6 +1234,7 @@ extern "C" int x264hip_lookahead_reset( x264hip_lookahead *la )
         if( f != L.last_nonb ) { L.free_slots.push_back( f->slot ); delete f; }
     if( L.last_nonb ) { L.free_slots.push_back( L.last_nonb->slot ); delete L.last_nonb; }
     L.next.clear(); L.current.clear(); L.last_nonb = nullptr; L.pending_prefetch.clear();
+    L.chain_anchor = -1; L.chain_period = 0;
     // (gop_len stays: the next sequence on this context is expected to be decided like the last one until it shows otherwise)
     L.i_input = 0;
     L.i_last_keyframe = -L.p.keyint_max;

@@ -48,6 +48,22 @@ namespace mefull {
 template <typename T>
 BM_HD int mf_sad( const T *a, int sa, const T *b, int sb, int w, int h )
 {
+#if defined( __HIP_DEVICE_COMPILE__ )
+    if( sizeof( T ) == 1 )
+    {
+        // four samples per load and per v_sad_u8 (every partition width is a multiple of four)
+        unsigned acc = 0;
+        for( int y = 0; y < h; y++ )
+            for( int x = 0; x < w; x += 4 )
+            {
+                uint32_t wa, wb;
+                __builtin_memcpy( &wa, a + y*sa + x, 4 );
+                __builtin_memcpy( &wb, b + y*sb + x, 4 );
+                acc = __builtin_amdgcn_sad_u8( wa, wb, acc );
+            }
+        return (int)acc;
+    }
+#endif
     int s = 0;
     for( int y = 0; y < h; y++ )
         for( int x = 0; x < w; x++ )
@@ -153,12 +169,19 @@ BM_HD void mf_mc_luma( T *dst, int ds, const T *const planes[4], int stride, int
 }
 
 
-template <typename T>
+// C: the search is run by a whole wave in lock step (device only, me_full_coop_kernel): block costs are then computed ACROSS the wave --
+// lane l owns four horizontally adjacent samples of the block (quad q = l >> 2 is a 4x4 tile, l & 3 its row, so the vertical Hadamard
+// of a SATD is a quad exchange) and the totals come back wave-uniform -- instead of by every lane over the whole block.
+template <typename T, bool C = false>
 struct Mef
 {
     const MfReq<T> *p;
     int bw, bh;
     int bmx, bmy, bcost;
+#ifdef __HIPCC__
+    int l_active, l_row, l_col; // this lane's four samples: ( l_col .. l_col + 3, l_row ), taking part if l_active
+    Px4 l_f;                    // ... of the source block
+#endif
 };
 
 // Cooperation policy of the exhaustive branches (ESA / TESA).  CoopNone: one thread runs the whole search -- the host check and the
@@ -183,52 +206,96 @@ BM_HD int mf_popc64( unsigned long long v )
     return n;
 }
 
-template <typename T>
-BM_HD int mef_fpelcmp( const Mef<T> *s, const T *b, int sb )
+#if defined( __HIP_DEVICE_COMPILE__ )
+// cost of the candidate block at b (row-major, stride sb) against the source block, over the wave: every lane gets the total
+template <typename T, bool C>
+__device__ __forceinline__ int mef_wave_cmp( const Mef<T, C> *s, const T *b, int sb, int use_satd )
 {
+    const Px4 r = load_px4( b + (long)s->l_row * sb + s->l_col );
+    int v = use_satd ? satd_partial_px4( s->l_f, r ) : sad_partial_px4( s->l_f, r, (const T *)nullptr );
+    v = (int)wave_sum_u32( (unsigned)( s->l_active ? v : 0 ) );
+    return use_satd ? v >> 1 : v; // every 4x4 sum of absolute Hadamard coefficients is even: halving the total == PIXEL_SATD_C's halves
+}
+// the same for the quarter-pel position ( qx, qy ) (get_ref semantics: one plane tap or the rounded average of two, mc.c:218-249)
+template <typename T, bool C>
+__device__ __forceinline__ int mef_wave_qpel( const Mef<T, C> *s, int qx, int qy, int use_satd )
+{
+    const MfReq<T> *p = s->p;
+    const int fx = qx & 3, fy = qy & 3;
+    const long o = (long)( s->l_row + ( qy >> 2 ) ) * p->stride + s->l_col + ( qx >> 2 );
+    const int pa = ( fx ? 1 : 0 ) + ( fy == 2 ? 2 : 0 ), pb = ( fx == 2 ? 1 : 0 ) + ( fy ? 2 : 0 );
+    Px4 r = load_px4( p->ref[pa] + o + ( fy == 3 ? p->stride : 0 ) );
+    if( ( fx | fy ) & 1 )
+        r = avg_px4( r, load_px4( p->ref[pb] + o + ( fx == 3 ) ), (const T *)nullptr );
+    int v = use_satd ? satd_partial_px4( s->l_f, r ) : sad_partial_px4( s->l_f, r, (const T *)nullptr );
+    v = (int)wave_sum_u32( (unsigned)( s->l_active ? v : 0 ) );
+    return use_satd ? v >> 1 : v;
+}
+#endif
+
+template <typename T, bool C>
+BM_HD int mef_fpelcmp( const Mef<T, C> *s, const T *b, int sb )
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+    if( C ) return mef_wave_cmp( s, b, sb, s->p->fpelcmp_satd );
+#endif
     return s->p->fpelcmp_satd ? mf_satd( s->p->fenc, s->p->fenc_stride, b, sb, s->bw, s->bh ) : mf_sad( s->p->fenc, s->p->fenc_stride, b, sb, s->bw, s->bh );
 }
-template <typename T>
-BM_HD int mef_mbcmp( const Mef<T> *s, const T *b, int sb )
+template <typename T, bool C>
+BM_HD int mef_mbcmp( const Mef<T, C> *s, const T *b, int sb )
 {
+#if defined( __HIP_DEVICE_COMPILE__ )
+    if( C ) return mef_wave_cmp( s, b, sb, s->p->mbcmp_satd );
+#endif
     return s->p->mbcmp_satd ? mf_satd( s->p->fenc, s->p->fenc_stride, b, sb, s->bw, s->bh ) : mf_sad( s->p->fenc, s->p->fenc_stride, b, sb, s->bw, s->bh );
 }
-template <typename T>
-BM_HD int mef_bits_q( const Mef<T> *s, int qx, int qy ) { return s->p->cost_mv[qx - s->p->mvp[0]] + s->p->cost_mv[qy - s->p->mvp[1]]; }
-template <typename T>
-BM_HD int mef_bits_f( const Mef<T> *s, int fx, int fy ) { return mef_bits_q( s, 4*fx, 4*fy ); } /* BITS_MVD */
-template <typename T>
-BM_HD int mef_cost_f( const Mef<T> *s, int fx, int fy ) /* the cost COST_MV computes */
+template <typename T, bool C>
+BM_HD int mef_bits_q( const Mef<T, C> *s, int qx, int qy ) { return s->p->cost_mv[qx - s->p->mvp[0]] + s->p->cost_mv[qy - s->p->mvp[1]]; }
+template <typename T, bool C>
+BM_HD int mef_bits_f( const Mef<T, C> *s, int fx, int fy ) { return mef_bits_q( s, 4*fx, 4*fy ); } /* BITS_MVD */
+template <typename T, bool C>
+BM_HD int mef_cost_f( const Mef<T, C> *s, int fx, int fy ) /* the cost COST_MV computes */
 {
     return mef_fpelcmp( s, s->p->ref[0] + (long)fy * s->p->stride + fx, s->p->stride ) + mef_bits_f( s, fx, fy );
 }
-template <typename T>
-BM_HD void mef_try_f( Mef<T> *s, int fx, int fy ) /* COST_MV */
+// the same cost computed by THIS lane alone whatever C is: the exhaustive scans hand every lane of a wave its own candidate
+template <typename T, bool C>
+BM_HD int mef_cost_f_lane( const Mef<T, C> *s, int fx, int fy )
+{
+    const T *b = s->p->ref[0] + (long)fy * s->p->stride + fx;
+    return ( s->p->fpelcmp_satd ? mf_satd( s->p->fenc, s->p->fenc_stride, b, s->p->stride, s->bw, s->bh )
+                                : mf_sad( s->p->fenc, s->p->fenc_stride, b, s->p->stride, s->bw, s->bh ) ) + mef_bits_f( s, fx, fy );
+}
+template <typename T, bool C>
+BM_HD void mef_try_f( Mef<T, C> *s, int fx, int fy ) /* COST_MV */
 {
     int c = mef_cost_f( s, fx, fy );
     if( c < s->bcost ) { s->bcost = c; s->bmx = fx; s->bmy = fy; }
 }
-template <typename T>
-BM_HD int mef_cost_q( const Mef<T> *s, int qx, int qy, int use_mbcmp ) /* COST_MV_HPEL / COST_MV_SAD / COST_MV_SATD */
+template <typename T, bool C>
+BM_HD int mef_cost_q( const Mef<T, C> *s, int qx, int qy, int use_mbcmp ) /* COST_MV_HPEL / COST_MV_SAD / COST_MV_SATD */
 {
+#if defined( __HIP_DEVICE_COMPILE__ )
+    if( C ) return mef_wave_qpel( s, qx, qy, use_mbcmp ? s->p->mbcmp_satd : s->p->fpelcmp_satd ) + mef_bits_q( s, qx, qy );
+#endif
     T pix[16*16];
     mf_mc_luma( pix, 16, s->p->ref, s->p->stride, qx, qy, s->bw, s->bh, NULL );
     return ( use_mbcmp ? mef_mbcmp( s, pix, 16 ) : mef_fpelcmp( s, pix, 16 ) ) + mef_bits_q( s, qx, qy );
 }
-template <typename T>
-BM_HD int mef_in_range( const Mef<T> *s, int fx, int fy ) /* CHECK_MVRANGE */
+template <typename T, bool C>
+BM_HD int mef_in_range( const Mef<T, C> *s, int fx, int fy ) /* CHECK_MVRANGE */
 {
     return fx >= s->p->lim_min[0] && fx <= s->p->lim_max[0] && fy >= s->p->lim_min[1] && fy <= s->p->lim_max[1];
 }
 /* COST_MV_X4 relative to (omx, omy), candidates applied in order */
-template <typename T>
-BM_HD void mef_x4( Mef<T> *s, int omx, int omy, const int d[4][2] )
+template <typename T, bool C>
+BM_HD void mef_x4( Mef<T, C> *s, int omx, int omy, const int d[4][2] )
 {
     for( int k = 0; k < 4; k++ )
         mef_try_f( s, omx + d[k][0], omy + d[k][1] );
 }
-template <typename T>
-BM_HD void mef_cross( Mef<T> *s, int omx, int omy, int start, int x_max, int y_max ) /* CROSS, me.c:139-166 */
+template <typename T, bool C>
+BM_HD void mef_cross( Mef<T, C> *s, int omx, int omy, int start, int x_max, int y_max ) /* CROSS, me.c:139-166 */
 {
     const MfReq<T> *p = s->p;
     int i = start;
@@ -257,8 +324,8 @@ BM_HD void mef_cross( Mef<T> *s, int omx, int omy, int start, int x_max, int y_m
     }
 }
 
-template <typename T>
-BM_HD void mef_hex2( Mef<T> *s, int me_range ) /* the HEX branch incl. the square refine, me.c:344-420 */
+template <typename T, bool C>
+BM_HD void mef_hex2( Mef<T, C> *s, int me_range ) /* the HEX branch incl. the square refine, me.c:344-420 */
 {
     const int8_t hex2[8][2] = { {-1,-2}, {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2}, {-2,0} };
     const uint8_t mod6m1[8] = { 5,0,1,2,3,4,5,0 };
@@ -300,8 +367,8 @@ BM_HD void mef_hex2( Mef<T> *s, int me_range ) /* the HEX branch incl. the squar
 
 typedef struct { int sad; int mx, my; } mef_mvsad;
 
-template <typename T>
-BM_HD void mef_refine_subpel( Mef<T> *s, int mv[2], int *cost, int *cost_mv, int hpel_iters, int qpel_iters )
+template <typename T, bool C>
+BM_HD void mef_refine_subpel( Mef<T, C> *s, int mv[2], int *cost, int *cost_mv, int hpel_iters, int qpel_iters )
 {
     const MfReq<T> *p = s->p;
     int bmx = mv[0], bmy = mv[1], bcost = *cost;
@@ -372,8 +439,19 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
     const uint8_t mef_size[7][2] = { {16,16}, {16,8}, {8,16}, {8,8}, {8,4}, {4,8}, {4,4} };
     const uint8_t mef_subpel_iterations[12][4] = /* me.c:38-50 */
         { {0,0,0,0}, {1,1,0,0}, {0,1,1,0}, {0,2,1,0}, {0,2,1,1}, {0,2,1,2}, {0,0,2,2}, {0,0,2,2}, {0,0,4,10}, {0,0,4,10}, {0,0,4,10}, {0,0,4,10} };
-    Mef<T> S, *s = &S;
+    Mef<T, ( Coop::W > 1 )> S, *s = &S;
     s->p = p; s->bw = mef_size[p->i_pixel][0]; s->bh = mef_size[p->i_pixel][1];
+#if defined( __HIP_DEVICE_COMPILE__ )
+    if( Coop::W > 1 )
+    {
+        const int l = coop.lane(), tiles_per_row = s->bw >> 2, q = l >> 2;
+        const int ty = q / tiles_per_row, tx = q - ty * tiles_per_row;
+        s->l_active = 4 * ty < s->bh;
+        s->l_row = s->l_active ? 4 * ty + ( l & 3 ) : ( l & 3 ); // (lanes beyond the block read its first tile: always addressable)
+        s->l_col = s->l_active ? 4 * tx : 0;
+        s->l_f = load_px4( p->fenc + (long)s->l_row * p->fenc_stride + s->l_col );
+    }
+#endif
     const int mv_x_min = p->lim_min[0], mv_y_min = p->lim_min[1], mv_x_max = p->lim_max[0], mv_y_max = p->lim_max[1];
     int me_range = p->me_range;
     int bpred_cost = MF_COST_MAX, bpred_mx = 0, bpred_my = 0, pmx, pmy, pmv_nonzero;
@@ -564,7 +642,7 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
                     {
                         int idx = base + coop.lane(), c = MF_COST_MAX;
                         if( idx < width )
-                            c = mef_cost_f( s, min_x + idx, my );
+                            c = mef_cost_f_lane( s, min_x + idx, my );
                         coop.argmin( c, idx );
                         if( c < s->bcost ) { s->bcost = c; s->bmx = min_x + idx; s->bmy = my; }
                     }

@@ -1796,11 +1796,12 @@ extern "C" int x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx
     // workgroups (X264HIP_CMP_ROWS = 1 / 2 / 4 overrides it: A/B aid)
     static const int rows_env = getenv( "X264HIP_CMP_ROWS" ) ? atoi( getenv( "X264HIP_CMP_ROWS" ) ) : 0;
     const int wgs1 = ( ( rw + 15 ) / 16 ) * rh;
-    const int rr = rows_env == 1 || rows_env == 2 || rows_env == 4 ? rows_env : wgs1 >= 32 * ctx->n_cu ? 4 : wgs1 >= 4 * ctx->n_cu ? 2 : 1;
+    const int rr = rows_env == 1 || rows_env == 2 || rows_env == 4 || rows_env == 8 ? rows_env : wgs1 >= 32 * ctx->n_cu ? 4 : wgs1 >= 4 * ctx->n_cu ? 2 : 1;
     const dim3 grd( ( rw + 15 ) / 16, ( rh + rr - 1 ) / rr );
 #define CMP_LAUNCH( T, BW, BH, D ) \
     do { \
-        if( rr == 4 ) pixel_cmp_batch_kernel<T, BW, BH, D, 4><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev ); \
+        if( rr == 8 ) pixel_cmp_batch_kernel<T, BW, BH, D, 8><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev ); \
+        else if( rr == 4 ) pixel_cmp_batch_kernel<T, BW, BH, D, 4><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev ); \
         else if( rr == 2 ) pixel_cmp_batch_kernel<T, BW, BH, D, 2><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev ); \
         else pixel_cmp_batch_kernel<T, BW, BH, D, 1><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev ); \
     } while( 0 )
@@ -1881,12 +1882,13 @@ static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request 
     MECK( hipMemcpyAsync( mvc_dev, mvc.data(), mvc.size() * sizeof( int16_t ), hipMemcpyHostToDevice, ctx->stream ) );
     MECK( hipMemcpyAsync( n_mvc_dev, n_mvc.data(), sizeof( int ) * n, hipMemcpyHostToDevice, ctx->stream ) );
     {
-        // exhaustive requests (ESA, TESA): a wave each; pattern searches (DIA, HEX, UMH): a thread each.  X264HIP_ME_FULL_SCALAR=1
-        // sends everything through the one-thread form (the device reference the cooperative form is checked against)
+        // a wave per request: its 64 lanes run the search in lock step, block costs are computed across the wave (four samples per
+        // lane) and the exhaustive scans (ESA, TESA) cost 64 candidates per step.  X264HIP_ME_FULL_SCALAR=1 sends everything through
+        // the one-thread form instead (the device reference the cooperative form is checked against)
         static const bool all_scalar = getenv( "X264HIP_ME_FULL_SCALAR" ) != nullptr;
         std::vector<int> coop_idx, scalar_idx;
         for( int i = 0; i < n; i++ )
-            ( reqs[i].me_method >= 3 && !all_scalar ? coop_idx : scalar_idx ).push_back( i );
+            ( !all_scalar ? coop_idx : scalar_idx ).push_back( i );
         MECK( hipMalloc( &index_dev, sizeof( int ) * n ) );
         if( !coop_idx.empty() )
             MECK( hipMemcpyAsync( index_dev, coop_idx.data(), sizeof( int ) * coop_idx.size(), hipMemcpyHostToDevice, ctx->stream ) );
