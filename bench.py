@@ -106,7 +106,7 @@ def primitives_bench(torch, libmod, cfg, iters=30):
         out["device_copy_GBps"] = round(2 * a.numel() * 10 / (time.perf_counter() - t0) / 1e9, 1)
         del a, b
         # main-encode motion search: every 16x16 macroblock of a 1920x1072 frame pair searched in one batch, searches/s.
-        # esa / tesa: one wave per request (cooperative exhaustive scan, me_range 16); umh: one thread per request
+        # a wave per request for every method: block costs across the wave, 64 candidates per step in the exhaustive scans (me_range 16)
         try:
             mw, mh, padh, padv, mvr = 1920, 1072, 32, 32, 64
             pw, ph = mw + 2 * padh, mh + 2 * padv
@@ -140,6 +140,7 @@ def primitives_bench(torch, libmod, cfg, iters=30):
                             q.lim_min[k], q.lim_max[k] = (smin[k] >> 2) + 6, (smax[k] >> 2) - 6
                         q.n_mvc = 0
                         reqs.append(q)
+                reqs = reqs * 4  # every macroblock four times in one batch (32 160 requests): the fixed cost of a call (table upload, launch, read-back) is amortised
                 args_ = (reqs, fenc_l.data_ptr(), mw, [planes[k].data_ptr() + org for k in range(4)], pw, integ.data_ptr() + org * 2, ph * pw, cmv.data_ptr() + 2 * centre)
                 ctx.me_search_batch(*args_)
                 t0 = time.perf_counter()
@@ -499,7 +500,8 @@ def main():
                                 "weights_analysed": int(la_stats[2]), "weights_kept": int(la_stats[3]),
                                 "device": {"searches": int(dev_counters[0]), "cell_requests": int(dev_counters[1]), "cell_hits": int(dev_counters[4]),
                                            "cells_on_demand": int(dev_counters[7]), "cells_speculated": int(dev_counters[5]),
-                                           "fields_claimed": int(dev_counters[2]), "searches_on_demand": int(dev_counters[13]), "weight_sums_from_cache": int(dev_counters[6]),
+                                           "fields_claimed": int(dev_counters[2]), "searches_on_demand": int(dev_counters[13]),
+                                           "second_variants_speculated": int(dev_counters[14]), "second_variants_used": int(dev_counters[15]), "weight_sums_from_cache": int(dev_counters[6]),
                                            "unclaimed_field_share": round(1.0 - float(dev_counters[2]) / max(float(dev_counters[0]) - float(dev_counters[13]), 1.0), 4),
                                            "unused_cell_share": round(1.0 - float(dev_counters[4]) / max(float(dev_counters[5]), 1.0), 4),
                                            "note": "counters since the contexts were opened (warm-up, timed steps)"},

@@ -433,7 +433,78 @@ BM_HD void mef_refine_subpel( Mef<T, C> *s, int mv[2], int *cost, int *cost_mv, 
     *cost_mv = mef_bits_q( s, bmx, bmy );
 }
 
-template <typename T, class Coop = CoopNone>
+#if defined( __HIP_DEVICE_COMPILE__ )
+// smallest value over the wave, wave-uniform (DPP inside the 16-lane rows, the four row results as scalars)
+__device__ __forceinline__ unsigned mef_wave_min_u32( unsigned v )
+{
+    auto mn = []( unsigned a, unsigned b ) { return a < b ? a : b; };
+    v = mn( v, (unsigned)dpp_mov<DPP_QUAD_XOR1>( (int)v ) );
+    v = mn( v, (unsigned)dpp_mov<DPP_QUAD_XOR2>( (int)v ) );
+    v = mn( v, (unsigned)dpp_mov<0x141>( (int)v ) ); // row_half_mirror
+    v = mn( v, (unsigned)dpp_mov<0x140>( (int)v ) ); // row_mirror
+    return mn( mn( (unsigned)__builtin_amdgcn_readlane( (int)v, 0 ), (unsigned)__builtin_amdgcn_readlane( (int)v, 16 ) ),
+               mn( (unsigned)__builtin_amdgcn_readlane( (int)v, 32 ), (unsigned)__builtin_amdgcn_readlane( (int)v, 48 ) ) );
+}
+// The exhaustive scan of ESA (me.c:620-660) by a whole wave: the candidates of the window in scan order, 64 per step -- whatever row
+// they are in --, every lane the full SAD of its own candidate with the source block held in registers (the candidates of a step are
+// neighbours: their loads share cache lines), then one packed minimum ( cost << 6 | lane: the earliest of equal costs ).  Skipping
+// rows whose vertical mv cost alone reaches the best cost, as the reference does, cannot change the result (every cost of such a row
+// is at least that) and is left out.
+template <typename T, int BW, int BH>
+__device__ __forceinline__ void mef_esa_scan_wave( Mef<T, true> *s, int min_x, int min_y, int max_y, int width )
+{
+    const MfReq<T> *p = s->p;
+    const int lane = threadIdx.x & 63;
+    Px4 fe[BH][BW / 4];
+#pragma unroll
+    for( int y = 0; y < BH; y++ )
+#pragma unroll
+        for( int k = 0; k < BW / 4; k++ )
+            fe[y][k] = load_px4( p->fenc + (long)y * p->fenc_stride + 4 * k );
+    const int total = ( max_y - min_y + 1 ) * width;
+    for( int base = 0; base < total; base += 64 )
+    {
+        const int t = base + lane < total ? base + lane : total - 1;
+        const int row = t / width, col = t - row * width;
+        const T *b = p->ref[0] + (long)( min_y + row ) * p->stride + min_x + col;
+        int acc = 0;
+#pragma unroll
+        for( int y = 0; y < BH; y++ )
+#pragma unroll
+            for( int k = 0; k < BW / 4; k++ )
+                acc += sad_partial_px4( fe[y][k], load_px4( b + (long)y * p->stride + 4 * k ), (const T *)nullptr );
+        const int c = acc + p->cost_mv[4 * ( min_x + col ) - p->mvp[0]] + p->cost_mv[4 * ( min_y + row ) - p->mvp[1]];
+        const unsigned key = mef_wave_min_u32( base + lane < total ? ( (unsigned)c << 6 ) | (unsigned)lane : 0xFFFFFFFFu );
+        const int cmin = (int)( key >> 6 );
+        if( cmin < s->bcost )
+        {
+            const int tt = base + (int)( key & 63 ), r2 = tt / width;
+            s->bcost = cmin; s->bmx = min_x + tt - r2 * width; s->bmy = min_y + r2;
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void mef_esa_scan_dispatch( Mef<T, true> *s, int min_x, int min_y, int max_y, int width )
+{
+    switch( s->p->i_pixel )
+    {
+        case 0: mef_esa_scan_wave<T, 16, 16>( s, min_x, min_y, max_y, width ); break;
+        case 1: mef_esa_scan_wave<T, 16, 8>( s, min_x, min_y, max_y, width ); break;
+        case 2: mef_esa_scan_wave<T, 8, 16>( s, min_x, min_y, max_y, width ); break;
+        case 3: mef_esa_scan_wave<T, 8, 8>( s, min_x, min_y, max_y, width ); break;
+        case 4: mef_esa_scan_wave<T, 8, 4>( s, min_x, min_y, max_y, width ); break;
+        case 5: mef_esa_scan_wave<T, 4, 8>( s, min_x, min_y, max_y, width ); break;
+        default: mef_esa_scan_wave<T, 4, 4>( s, min_x, min_y, max_y, width ); break;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void mef_esa_scan_dispatch( Mef<T, false> *, int, int, int, int ) {}
+#endif
+
+// METHODS: which branches are compiled in -- bit 0 the pattern searches (DIA, HEX, UMH), bit 1 the exhaustive ones (ESA, TESA).  The
+// device builds one kernel per class: the exhaustive scan keeps the source block in registers, which would cost the pattern searches
+// half their occupancy.
+template <typename T, class Coop = CoopNone, int METHODS = 3>
 BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_mvc, int out[4], Coop coop = Coop() )
 {
     const uint8_t mef_size[7][2] = { {16,16}, {16,8}, {8,16}, {8,8}, {8,4}, {4,8}, {4,4} };
@@ -507,6 +578,9 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
             mef_try_f( s, 0, 0 );
     }
 
+    // (a build for one class of methods never sees a request of the other: tells the compiler to drop those branches)
+    if( ( !( METHODS & 2 ) && p->me_method >= 3 ) || ( !( METHODS & 1 ) && p->me_method < 3 ) )
+        __builtin_unreachable();
     switch( p->me_method )
     {
         case 0: /* DIA, me.c:322-342 */
@@ -626,9 +700,18 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
         }
         default: /* ESA (3) / TESA (4), me.c:620-772 */
         {
+            if( !( METHODS & 2 ) )
+                break; // (compiled out of the pattern-search build)
             const int min_x = imax( s->bmx - me_range, mv_x_min ), min_y = imax( s->bmy - me_range, mv_y_min );
             const int max_x = imin( s->bmx + me_range, mv_x_max ), max_y = imin( s->bmy + me_range, mv_y_max );
             const int width = ( max_x - min_x + 3 ) & ~3;
+#if defined( __HIP_DEVICE_COMPILE__ )
+            if( p->me_method == 3 && Coop::W > 1 && !p->fpelcmp_satd )
+            {
+                mef_esa_scan_dispatch( s, min_x, min_y, max_y, width );
+                break;
+            }
+#endif
             if( p->me_method == 3 )
             {
                 /* successive elimination only discards candidates that cannot beat the current best (sum|d| >= |sum d|),
@@ -824,17 +907,17 @@ struct CoopWave
 // and the sub-pel refinement redundantly, their loads are broadcasts) and share the exhaustive scan: 64 candidates per step,
 // ordered compaction of the ads survivors, first-in-scan-order ties -- bit-exact with the one-thread form below, which remains
 // the device reference and serves DIA / HEX / UMH requests.
-template <typename T>
+template <typename T, int METHODS>
 __global__ __launch_bounds__( 64 ) void me_full_coop_kernel( const MfReq<T> *reqs, const int16_t *mvc, const int *n_mvc, const int *index, int n, int *out )
 {
-    __shared__ int16_t xs_lds[MF_TESA_WIDTH_MAX + 64];
+    __shared__ int16_t xs_lds[( METHODS & 2 ) ? MF_TESA_WIDTH_MAX + 64 : 2];
     if( (int)blockIdx.x >= n )
         return;
     const int i = index[blockIdx.x];
     CoopWave coop;
     coop.xs_ = xs_lds;
     int res[4];
-    mefull::mf_me_search_full<T, CoopWave>( &reqs[i], (const int16_t( * )[2])( mvc + (long)i * MF_MVC_MAX * 2 ), n_mvc[i], res, coop );
+    mefull::mf_me_search_full<T, CoopWave, METHODS>( &reqs[i], (const int16_t( * )[2])( mvc + (long)i * MF_MVC_MAX * 2 ), n_mvc[i], res, coop );
     if( ( threadIdx.x & 63 ) == 0 )
         for( int k = 0; k < 4; k++ )
             out[4 * i + k] = res[k];

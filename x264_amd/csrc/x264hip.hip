@@ -77,6 +77,11 @@ struct FrameSlot
     float *qp_aq = nullptr, *qp = nullptr; // [n_mb] f_qp_offset_aq, f_qp_offset
     unsigned field_tag[2][X264HIP_BFRAME_MAX + 1]; // serial of the search that last wrote the field
     std::vector<CellEntry> cells;
+    // Callers ask for some B cell classes now with, now without the list-1 reference's own vectors (slicetype.c:629: it depends on
+    // whether that frame has been searched as a P frame by then).  When both happen often the minority variant is speculated as well,
+    // into the slot's one spare cell; a request for it copies map and sums over (no evaluation, no wait for an on-demand launch).
+    CellEntry alt;
+    int alt_idx = -1;                 // the (d0, d1) class the spare holds, -1: free
     // host-side state of the device fields
     unsigned char field_ready[2][X264HIP_BFRAME_MAX + 1]; // searched (any variant) and complete on the stream
     unsigned char field_prefetched[2][X264HIP_BFRAME_MAX + 1]; // unweighted field computed speculatively, not yet claimed
@@ -124,6 +129,7 @@ struct x264hip_ctx
     unsigned long long *me_prof = nullptr; // ME_PROFILE builds: 8 cycle accumulators of the search kernel (device), else unused
     int n_cells = 0;                 // (bframes+2)^2
     int *cell_acc_host = nullptr;    // pinned [slots][n_cells][8]: sums of every cell evaluation, written by the device directly
+    int *cell_alt_host = nullptr;    // pinned [slots][8]: sums of a slot's spare cell (FrameSlot alt)
     DescRing cell_ring, put_ring, search_ring, xfer_ring;
     int xfer_cap = 2048;
     unsigned *err_host = nullptr;    // pinned: sticky in-kernel timeout flag, written by the device directly
@@ -156,6 +162,8 @@ struct x264hip_ctx
     char *chroma_staging = nullptr, *chroma_dev = nullptr; // host-buffer ingest with chroma: pinned + device copies of Cb and Cr (allocated on first use)
     size_t staging_bytes = 0;
     std::vector<char *> wplanes;     // weighted plane pool
+    char *me_pool = nullptr;         // device memory of x264hip_me_search_batch calls (request table, results, TESA lists), grow-only
+    size_t me_pool_bytes = 0;
     char *vt_pool = nullptr;         // staging memory of the function-table members (x264hip_mc_fill & co.), grow-only
     size_t vt_pool_bytes = 0;
     std::vector<int> wplane_owner;
@@ -167,7 +175,7 @@ struct x264hip_ctx
     std::vector<int> prof_n;
     int prof_on = 0, prof_used = 0;
     double prof_ms = 0; uint64_t prof_launches = 0, prof_searches = 0;
-    uint64_t counters[16] = { 0 }; // [8] remote fields searched here after all [9] remote cell maps recomputed here [10] maps imported [11] cells imported [12] fields registered as remote [13] searches on demand (x264hip_frame_cost)
+    uint64_t counters[16] = { 0 }; // [8] remote fields searched here after all [9] remote cell maps recomputed here [10] maps imported [11] cells imported [12] fields registered as remote [13] searches on demand (x264hip_frame_cost) [14] second variants of B cells speculated [15] ... and used
     // how often callers asked for each B cell class with / without a searched L0 field of the list-1 reference
     // (slicetype.c:629-642): speculation evaluates the variant asked for more often so far
     uint32_t variant_req[( X264HIP_BFRAME_MAX + 2 ) * ( X264HIP_BFRAME_MAX + 2 )][2] = { { 0 } };
@@ -247,6 +255,7 @@ static void free_all( x264hip_ctx *ctx )
     }
     for( auto w : ctx->wplanes ) (void)hipFree( w );
     if( ctx->vt_pool ) (void)hipFree( ctx->vt_pool );
+    if( ctx->me_pool ) (void)hipFree( ctx->me_pool );
     (void)hipFree( ctx->cost_mv_dev ); (void)hipFree( ctx->luts_dev ); (void)hipFree( ctx->sync_words );
     ring_free( ctx->cell_ring ); ring_free( ctx->put_ring ); ring_free( ctx->search_ring ); ring_free( ctx->wjob_ring ); ring_free( ctx->xfer_ring );
     (void)hipHostFree( ctx->err_host );
@@ -265,6 +274,7 @@ static void free_all( x264hip_ctx *ctx )
         if( ctx->batch_ev[i] ) (void)hipEventDestroy( ctx->batch_ev[i] );
     if( ctx->stream2 ) (void)hipStreamDestroy( ctx->stream2 );
     (void)hipHostFree( ctx->cell_acc_host );
+    (void)hipHostFree( ctx->cell_alt_host );
     (void)hipFree( ctx->wcost_dev );
     (void)hipHostFree( ctx->wcost_host ); (void)hipHostFree( ctx->staging );
     if( ctx->chroma_staging ) (void)hipHostFree( ctx->chroma_staging );
@@ -390,6 +400,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     ctx->pos_field_req.assign( (size_t)x264hip_ctx::POS_KEYS * 2 * ( X264HIP_BFRAME_MAX + 1 ), 0 );
     ctx->pos_cell_req.assign( (size_t)x264hip_ctx::POS_KEYS * ctx->n_cells, 0 );
     OPENCK( hipHostMalloc( &ctx->cell_acc_host, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
+    OPENCK( hipHostMalloc( &ctx->cell_alt_host, (size_t)p.max_frames * 8 * sizeof( int ) ) );
+    memset( ctx->cell_alt_host, 0, (size_t)p.max_frames * 8 * sizeof( int ) );
     memset( ctx->cell_acc_host, 0, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) );
     OPENCK( hipHostMalloc( &ctx->err_host, sizeof( unsigned ) ) );
     *ctx->err_host = 0;
@@ -433,13 +445,14 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         const size_t o_mbs = off; off += align_up( ctx->n_mb * sizeof( uint2 ), 256 );
         const size_t o_mvq = off; off += align_up( (size_t)2 * nd * ctx->n_mb * sizeof( unsigned long long ), 256 );
         const size_t o_mvc = off; off += align_up( (size_t)2 * nd * ctx->n_mb * sizeof( int ), 256 );
-        const size_t o_lc = off; off += align_up( (size_t)nc * ctx->n_mb * sizeof( uint16_t ), 256 );
-        const size_t o_rows = off; off += align_up( (size_t)nc * mb_h * sizeof( int ), 256 );
-        const size_t o_blk = off; off += align_up( (size_t)nc * ctx->n_mb * sizeof( int ), 256 );
+        // (one cell more than the reference has: the spare holds the speculative SECOND variant of a B cell class, see CellEntry alt)
+        const size_t o_lc = off; off += align_up( (size_t)( nc + 1 ) * ctx->n_mb * sizeof( uint16_t ), 256 );
+        const size_t o_rows = off; off += align_up( (size_t)( nc + 1 ) * mb_h * sizeof( int ), 256 );
+        const size_t o_blk = off; off += align_up( (size_t)( nc + 1 ) * ctx->n_mb * sizeof( int ), 256 );
         const size_t o_prop = off; off += align_up( (size_t)ctx->n_mb * sizeof( int ), 256 );
         const size_t o_qpa = off; off += align_up( (size_t)ctx->n_mb * sizeof( float ), 256 );
         const size_t o_qp = off; off += align_up( (size_t)ctx->n_mb * sizeof( float ), 256 );
-        const size_t o_sums = off; off += align_up( (size_t)nc * 8 * sizeof( int ), 256 );
+        const size_t o_sums = off; off += align_up( (size_t)( nc + 1 ) * 8 * sizeof( int ), 256 );
         char *base = nullptr;
         OPENCK( hipMalloc( &base, off ) );
         OPENCK( hipMemset( base, 0, off ) );
@@ -563,6 +576,7 @@ static void slot_reset( x264hip_ctx *ctx, FrameSlot &s )
     memset( s.field_tag, 0, sizeof( s.field_tag ) );
     memset( s.field_remote, 0, sizeof( s.field_remote ) );
     s.cells.assign( ctx->n_cells, CellEntry() );
+    s.alt = CellEntry(); s.alt_idx = -1;
     if( s.wplane_idx >= 0 ) { ctx->wplane_owner[s.wplane_idx] = -1; s.wplane_idx = -1; }
     ctx->counters[3]++;
 }
@@ -891,7 +905,7 @@ static int launch_searches( x264hip_ctx *ctx, const std::vector<SearchReq> &reqs
 // Descriptor of the cell (slot_b, d0, d1) with the fields as they stand now.  kind: 0 intra sums only, 1 real cell.
 template <typename T>
 static CellArgs make_cell( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b, int d0, int d1, int with_intra, int ref1_l0_valid,
-                           int sums_only )
+                           int sums_only, int to_spare = 0 )
 {
     const LaP &P = ctx->P;
     FrameSlot &b = ctx->slots[slot_b], &f0 = ctx->slots[slot_p0], &f1 = ctx->slots[slot_p1];
@@ -920,12 +934,23 @@ static CellArgs make_cell( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_
     A.blk = b.blk + (size_t)idx * ctx->n_mb;
     A.acc = ctx->cell_acc_host + ( (size_t)slot_b * ctx->n_cells + idx ) * 8; // pinned, device-visible
     A.acc_dev = b.cell_sums + (size_t)idx * 8;
+    if( to_spare )
+    {
+        // the slot's spare cell: its own map, block words, row sums and sums; the intra row sums are the frame's (same values)
+        const int sp = ctx->n_cells;
+        A.lowres_costs = b.lowres_costs + (size_t)sp * ctx->n_mb;
+        A.row_satds = b.row_satds + (size_t)sp * P.mb_h;
+        A.blk = b.blk + (size_t)sp * ctx->n_mb;
+        A.acc = ctx->cell_alt_host + (size_t)slot_b * 8;
+        A.acc_dev = b.cell_sums + (size_t)sp * 8;
+    }
     return A;
 }
 
 struct SpecCell
 {
     int slot_p0, slot_p1, slot_b, d0, d1, sums_only, ref1_valid;
+    int to_spare = 0;
 };
 
 // one batch: all P cells, all B cells, then one reduction launch (a workgroup per cell)
@@ -955,7 +980,7 @@ static int launch_cells_t( x264hip_ctx *ctx, const std::vector<SpecCell> &cells 
         for( int i = 0; i < n; i++ )
         {
             const SpecCell &c = *ord[i];
-            dh[i] = make_cell<T>( ctx, c.slot_p0, c.slot_p1, c.slot_b, c.d0, c.d1, 1, c.ref1_valid, c.sums_only );
+            dh[i] = make_cell<T>( ctx, c.slot_p0, c.slot_p1, c.slot_b, c.d0, c.d1, 1, c.ref1_valid, c.sums_only, c.to_spare );
         }
         HIPCK( hipMemcpyAsync( dd, dh, (size_t)n * sizeof( CellArgs ), hipMemcpyHostToDevice, ctx->stream ) );
         CellArgs none;
@@ -995,6 +1020,12 @@ extern "C" int x264hip_prefetch_ex( x264hip_ctx *ctx, const int *slots, const in
     static const bool no_learn = getenv( "X264HIP_NO_CLASS_LEARNING" ) != nullptr; // debugging aid: speculate everything
     const bool learned = !no_learn && ctx->n_requests >= x264hip_ctx::LEARN_REQUESTS;
     static const bool no_pos = getenv( "X264HIP_NO_POSITION_CLASSES" ) != nullptr; // debugging aid: ignore x264hip_gop_hint
+    // A class is speculated when at least this share of the frames seen so far asked for it (percent; 0 = any request at all, the
+    // default for fields: a field that is missing costs a whole search launch -- a dependency chain of W + 2 H steps -- on demand,
+    // a missing cell only a cell launch).  X264HIP_FIELD_RATE / X264HIP_CELL_RATE override them (experiments).
+    static const unsigned field_rate = getenv( "X264HIP_FIELD_RATE" ) ? (unsigned)atoi( getenv( "X264HIP_FIELD_RATE" ) ) : 0;
+    static const unsigned cell_rate = getenv( "X264HIP_CELL_RATE" ) ? (unsigned)atoi( getenv( "X264HIP_CELL_RATE" ) ) : 0;
+    const uint64_t frames_seen = ctx->counters[3];
     // a class is worth speculating for a frame at a known position if at least one in ten of the frames seen there asked for it
     auto pos_wants_field = [&]( const FrameSlot &f, int list, int dm1 ) {
         const int k = f.pos_key;
@@ -1029,6 +1060,7 @@ extern "C" int x264hip_prefetch_ex( x264hip_ctx *ctx, const int *slots, const in
             FrameSlot &b = ctx->slots[slots[i]];
             if( b.field_ready[list][dm1] || b.field_prefetched[list][dm1] ) continue;
             if( learned && !ctx->field_req[list][dm1] ) continue; // a class this caller never asks for
+            if( learned && field_rate && (uint64_t)ctx->field_req[list][dm1] * 100 < field_rate * frames_seen ) continue; // ... or too rarely
             if( !pos_wants_field( b, list, dm1 ) ) continue;       // ... or hardly ever for a frame at this position
             if( flags & X264HIP_PREFETCH_CELLS_ONLY ) continue;     // the fields come from elsewhere (x264hip_import_field)
             b.field_prefetched[list][dm1] = 1;
@@ -1068,6 +1100,7 @@ extern "C" int x264hip_prefetch_ex( x264hip_ctx *ctx, const int *slots, const in
                 CellEntry &e = b.cells[d0 * nstride + d1];
                 if( e.valid || e.requested ) continue;
                 if( learned && !ctx->cell_req[d0 * nstride + d1] ) continue;
+                if( learned && cell_rate && (uint64_t)ctx->cell_req[d0 * nstride + d1] * 100 < cell_rate * frames_seen ) continue;
                 if( !pos_wants_cell( b, d0 * nstride + d1 ) ) continue;
                 int j1 = j0, variant = 1;
                 unsigned t1 = 0, tr = 0;
@@ -1086,6 +1119,26 @@ extern "C" int x264hip_prefetch_ex( x264hip_ctx *ctx, const int *slots, const in
                 e.tag0 = b.field_tag[0][d0 - 1]; e.tag1 = t1; e.tagr = tr;
                 ctx->cell_spec[d0 * nstride + d1]++;
                 cells.push_back( SpecCell{ slots[j0], slots[d1 ? j1 : i], slots[i], d0, d1, 0, variant } );
+                if( d1 && b.alt_idx < 0 )
+                {
+                    // both variants of this class are asked for often (each at least a quarter of the requests): the other one goes
+                    // into the slot's spare cell
+                    const uint32_t *rq = ctx->variant_req[d0 * nstride + d1];
+                    const uint32_t all = rq[0] + rq[1];
+                    FrameSlot &f1 = ctx->slots[slots[j1]];
+                    const int other = !variant;
+                    if( all >= 8 && 4 * rq[0] >= all && 4 * rq[1] >= all && ( !other || has_field( f1, 0, d0 + d1 - 1 ) ) )
+                    {
+                        b.alt_idx = d0 * nstride + d1;
+                        b.alt = CellEntry();
+                        b.alt.valid = 1; b.alt.batch = ctx->batch_serial + 1; b.alt.variant = (unsigned char)other;
+                        b.alt.tag0 = e.tag0; b.alt.tag1 = t1; b.alt.tagr = other ? f1.field_tag[0][d0 + d1 - 1] : 0;
+                        SpecCell sc{ slots[j0], slots[j1], slots[i], d0, d1, 0, other };
+                        sc.to_spare = 1;
+                        cells.push_back( sc );
+                        ctx->counters[14]++;
+                    }
+                }
             }
         }
     }
@@ -1130,7 +1183,7 @@ static int ensure_fields_local( x264hip_ctx *ctx, int slot_p0, int slot_p1, int 
 }
 
 template <typename T>
-static CellArgs make_cell( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b, int d0, int d1, int with_intra, int ref1_l0_valid, int sums_only );
+static CellArgs make_cell( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b, int d0, int d1, int with_intra, int ref1_l0_valid, int sums_only, int to_spare );
 
 // The per-block map of a cell whose sums came from its owner rank, evaluated here after all (MB-tree reads it, so do
 // x264hip_frame_cost_recalculate and the getters): fields first, then the cell kernel; the sums are known already.
@@ -1235,6 +1288,27 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
     const bool hit = e.valid && e.tag0 == t0 && e.tag1 == t1 && e.tagr == tr && ( !b_bidir || e.variant == ( ref1_l0_valid ? 1 : 0 ) );
     if( b_bidir )
         ctx->variant_req[idx][ref1_l0_valid ? 1 : 0]++;
+    if( !hit && b_bidir && b.alt_idx == idx && b.alt.valid && b.alt.tag0 == t0 && b.alt.tag1 == t1 && b.alt.tagr == tr &&
+        b.alt.variant == ( ref1_l0_valid ? 1 : 0 ) )
+    {
+        // the other variant was speculated into the spare cell: move it to the cell's own place (stream-ordered, nothing to wait for
+        // beyond the batch that evaluated it) and answer from its sums
+        int r = batch_wait( ctx, b.alt.batch );
+        if( r ) return r;
+        const int sp = ctx->n_cells;
+        cell_move_kernel<<<( ctx->n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( b.lowres_costs + (size_t)idx * ctx->n_mb, b.lowres_costs + (size_t)sp * ctx->n_mb,
+                                                                            b.blk + (size_t)idx * ctx->n_mb, b.blk + (size_t)sp * ctx->n_mb,
+                                                                            b.row_satds + (size_t)idx * P.mb_h, b.row_satds + (size_t)sp * P.mb_h,
+                                                                            b.cell_sums + (size_t)idx * 8, b.cell_sums + (size_t)sp * 8, ctx->n_mb, P.mb_h );
+        HIPCK( hipGetLastError() );
+        const int *ra = ctx->cell_alt_host + (size_t)slot_b * 8;
+        out->cost_est = ra[0]; out->cost_est_aq = ra[1]; out->intra_mbs = ra[2];
+        out->intra_cost_est = ra[3]; out->intra_cost_est_aq = ra[4];
+        b.alt.valid = 0; b.alt_idx = -1;
+        e.requested = 1; e.valid = 0; e.map_remote = 0;
+        ctx->counters[4]++; ctx->counters[15]++; ctx->counters[1]++;
+        return X264HIP_OK;
+    }
     const int was_valid = e.valid;
     e.requested = 1;
     e.valid = 0;
@@ -1844,13 +1918,24 @@ static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request 
     size_t scratch_total = 0;
     for( int i = 0; i < n; i++ )
         if( reqs[i].me_method == 4 ) scratch_total += tesa_bytes( reqs[i].me_range );
-    char *scratch = nullptr;
-    MfReq<T> *table_dev = nullptr;
-    int16_t *mvc_dev = nullptr;
-    int *n_mvc_dev = nullptr, *out_dev = nullptr, *index_dev = nullptr;
+    // one device allocation for the call, kept by the context and grown when a call needs more (an allocation per call cost more than the
+    // searches of a 1080p frame)
+    const size_t b_scratch = align_up( scratch_total, 256 ), b_table = align_up( sizeof( MfReq<T> ) * n, 256 ), b_mvc = align_up( mvc.size() * sizeof( int16_t ), 256 ),
+                 b_nmvc = align_up( sizeof( int ) * n, 256 ), b_out = align_up( sizeof( int ) * 4 * n, 256 ), b_index = align_up( sizeof( int ) * n, 256 );
+    const size_t need = b_scratch + b_table + b_mvc + b_nmvc + b_out + b_index;
+    if( need > ctx->me_pool_bytes )
+    {
+        if( ctx->me_pool ) (void)hipFree( ctx->me_pool );
+        ctx->me_pool = nullptr; ctx->me_pool_bytes = 0;
+        if( hipMalloc( &ctx->me_pool, need + ( need >> 2 ) ) != hipSuccess ) return X264HIP_ENOMEM;
+        ctx->me_pool_bytes = need + ( need >> 2 );
+    }
+    char *scratch = ctx->me_pool;
+    MfReq<T> *table_dev = (MfReq<T> *)( scratch + b_scratch );
+    int16_t *mvc_dev = (int16_t *)( (char *)table_dev + b_table );
+    int *n_mvc_dev = (int *)( (char *)mvc_dev + b_mvc ), *out_dev = (int *)( (char *)n_mvc_dev + b_nmvc ), *index_dev = (int *)( (char *)out_dev + b_out );
     int rc = X264HIP_OK;
-#define MECK( call ) do { if( ( call ) != hipSuccess ) { rc = X264HIP_ENOMEM; goto done; } } while( 0 )
-    if( scratch_total ) MECK( hipMalloc( &scratch, scratch_total ) );
+#define MECK( call ) do { if( ( call ) != hipSuccess ) { ctx->broken = 1; return X264HIP_EDEVICE; } } while( 0 )
     for( size_t i = 0, t = 0; i < (size_t)n; i++ )
     {
         const x264hip_me_request &q = reqs[i];
@@ -1874,10 +1959,6 @@ static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request 
         n_mvc[i] = q.n_mvc;
         memcpy( &mvc[(size_t)i * MF_MVC_MAX * 2], q.mvc, sizeof( q.mvc ) );
     }
-    MECK( hipMalloc( &table_dev, sizeof( MfReq<T> ) * n ) );
-    MECK( hipMalloc( &mvc_dev, mvc.size() * sizeof( int16_t ) ) );
-    MECK( hipMalloc( &n_mvc_dev, sizeof( int ) * n ) );
-    MECK( hipMalloc( &out_dev, sizeof( int ) * 4 * n ) );
     MECK( hipMemcpyAsync( table_dev, table.data(), sizeof( MfReq<T> ) * n, hipMemcpyHostToDevice, ctx->stream ) );
     MECK( hipMemcpyAsync( mvc_dev, mvc.data(), mvc.size() * sizeof( int16_t ), hipMemcpyHostToDevice, ctx->stream ) );
     MECK( hipMemcpyAsync( n_mvc_dev, n_mvc.data(), sizeof( int ) * n, hipMemcpyHostToDevice, ctx->stream ) );
@@ -1886,31 +1967,27 @@ static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request 
         // lane) and the exhaustive scans (ESA, TESA) cost 64 candidates per step.  X264HIP_ME_FULL_SCALAR=1 sends everything through
         // the one-thread form instead (the device reference the cooperative form is checked against)
         static const bool all_scalar = getenv( "X264HIP_ME_FULL_SCALAR" ) != nullptr;
-        std::vector<int> coop_idx, scalar_idx;
-        for( int i = 0; i < n; i++ )
-            ( !all_scalar ? coop_idx : scalar_idx ).push_back( i );
-        MECK( hipMalloc( &index_dev, sizeof( int ) * n ) );
-        if( !coop_idx.empty() )
-            MECK( hipMemcpyAsync( index_dev, coop_idx.data(), sizeof( int ) * coop_idx.size(), hipMemcpyHostToDevice, ctx->stream ) );
-        if( !scalar_idx.empty() )
-            MECK( hipMemcpyAsync( index_dev + coop_idx.size(), scalar_idx.data(), sizeof( int ) * scalar_idx.size(), hipMemcpyHostToDevice, ctx->stream ) );
-        if( !coop_idx.empty() )
-            me_full_coop_kernel<T><<<(int)coop_idx.size(), 64, 0, ctx->stream>>>( table_dev, mvc_dev, n_mvc_dev, index_dev, (int)coop_idx.size(), out_dev );
-        if( !scalar_idx.empty() )
-            me_full_list_kernel<T><<<( (int)scalar_idx.size() + 63 ) / 64, 64, 0, ctx->stream>>>( table_dev, mvc_dev, n_mvc_dev, index_dev + coop_idx.size(),
-                                                                                                 (int)scalar_idx.size(), out_dev );
+        // one launch per class of methods: the pattern searches (DIA, HEX, UMH) and the exhaustive ones (ESA, TESA) are separate builds
+        std::vector<int> idx;
+        idx.reserve( n );
+        for( int i = 0; i < n; i++ ) if( reqs[i].me_method < 3 ) idx.push_back( i );
+        const int n_pat = (int)idx.size();
+        for( int i = 0; i < n; i++ ) if( reqs[i].me_method >= 3 ) idx.push_back( i );
+        MECK( hipMemcpyAsync( index_dev, idx.data(), sizeof( int ) * n, hipMemcpyHostToDevice, ctx->stream ) );
+        if( all_scalar )
+            me_full_list_kernel<T><<<( n + 63 ) / 64, 64, 0, ctx->stream>>>( table_dev, mvc_dev, n_mvc_dev, index_dev, n, out_dev );
+        else
+        {
+            if( n_pat )
+                me_full_coop_kernel<T, 1><<<n_pat, 64, 0, ctx->stream>>>( table_dev, mvc_dev, n_mvc_dev, index_dev, n_pat, out_dev );
+            if( n - n_pat )
+                me_full_coop_kernel<T, 2><<<n - n_pat, 64, 0, ctx->stream>>>( table_dev, mvc_dev, n_mvc_dev, index_dev + n_pat, n - n_pat, out_dev );
+        }
     }
     MECK( hipGetLastError() );
     MECK( hipMemcpyAsync( out, out_dev, sizeof( int ) * 4 * n, hipMemcpyDeviceToHost, ctx->stream ) );
-    if( hipStreamSynchronize( ctx->stream ) != hipSuccess ) rc = X264HIP_EDEVICE;
-done:
+    MECK( hipStreamSynchronize( ctx->stream ) ); // (the host vectors above stay alive until here)
 #undef MECK
-    if( scratch ) (void)hipFree( scratch );
-    if( table_dev ) (void)hipFree( table_dev );
-    if( mvc_dev ) (void)hipFree( mvc_dev );
-    if( n_mvc_dev ) (void)hipFree( n_mvc_dev );
-    if( out_dev ) (void)hipFree( out_dev );
-    if( index_dev ) (void)hipFree( index_dev );
     return rc;
 }
 
