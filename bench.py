@@ -494,8 +494,9 @@ def main():
                              "achieved": round(solo[2] * bytes_per_search / 1e9 / (solo[0] / 1e3), 2),
                              "frac": round(solo[2] * bytes_per_search / 1e9 / (solo[0] / 1e3) / HBM_PEAK_GBS, 5)},
                          "algorithmic_bytes_per_search": bytes_per_search,
-                         "note": "not a streaming kernel: bound by vector-ALU issue (roofline_issue) and the L1 pipe while the CU is full, by the dependency "
-                                 "chain of the launch otherwise (DESIGN.md section 3); the counters are in profiles/r02_search_pmc.json"},
+                         "note": "not a streaming kernel: once the chip is full it is bound by the L1 (texture cache) line rate -- roofline_l1 --, with vector-ALU "
+                                 "issue (roofline_issue) second; a launch that does not fill the chip is bound by its dependency chain (DESIGN.md section 3); the "
+                                 "counters are in profiles/r03_search_pmc.json"},
             "lookahead_stats": {"frame_cost_calls": int(la_stats[0]), "evaluations": int(la_stats[1]),
                                 "weights_analysed": int(la_stats[2]), "weights_kept": int(la_stats[3]),
                                 "device": {"searches": int(dev_counters[0]), "cell_requests": int(dev_counters[1]), "cell_hits": int(dev_counters[4]),
@@ -516,6 +517,11 @@ def main():
                 res["roofline_issue"]["what"] = ("one untimed pass of one segment alone: " if solo is not None else "") + res["roofline_issue"]["what"]
             except Exception as e:  # pragma: no cover
                 res["roofline_issue"] = {"error": str(e)}
+        if os.path.exists(ipath):
+            try:
+                res["roofline_l1"] = l1_roofline(json.load(open(ipath)), solo if solo is not None else (prof_ms, prof_launches, prof_searches), cfg)
+            except Exception as e:  # pragma: no cover
+                res["roofline_l1"] = {"error": str(e)}
         if window is not None:
             res["window_shard"] = window
             if "error" in window and "value" not in window:
@@ -671,6 +677,25 @@ def window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend,
     return res
 
 
+def l1_roofline(prof, timing, cfg):
+    """Third roofline of the search kernel, the one that binds it once the chip is full: cache-line accesses of the per-CU L1 (TCP).  Every
+    reference row a lane group loads is a 128-byte line access (148 per block search in the TCP_TOTAL_CACHE_ACCESSES pass, profiles/
+    r03_search_pmc.json); a CU's L1 serves 64 bytes per clock, i.e. one line every two clocks: 256 CUs x clock / 2 lines per second.
+    timing: (ms, launches, searches) of launches that ran alone."""
+    ms, launches, searches = timing
+    blocks = ((cfg["width"] + 15) // 16) * ((cfg["height"] + 15) // 16)
+    lines = prof["l1_line_accesses_per_block"]
+    clock = prof.get("effective_clock_GHz", 2.3) * 1e9
+    peak = 256 * clock / 2.0
+    achieved = searches * blocks * lines / (ms / 1e3) if ms > 0 else 0.0
+    return {"bound": "l1-lines", "kernel": "me_rows_kernel", "achieved": round(achieved / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G line accesses/s",
+            "frac": round(achieved / peak, 4), "l1_line_accesses_per_block": lines, "bytes_per_s_equivalent_TBps": round(achieved * 128 / 1e12, 2),
+            "searches_per_launch": round(searches / max(launches, 1)), "source": prof.get("source"),
+            "what": "line accesses of the launches that ran alone / their time, against 256 CUs x one 128-byte line per two clocks at the clock of the counter pass",
+            "note": "the same launches with 19 % fewer vector instructions per block (round 3 rewrite) take the same time once the chip is full: the L1 line "
+                    "rate, not instruction issue, is what is left (DESIGN.md section 3)"}
+
+
 def issue_roofline(prof, prof_ms, prof_searches, cfg, wall_s=None, all_searches=None):
     """Second roofline of the search kernel, against the ceiling that binds it while the CU is full: vector-ALU issue cycles.
     profiles/search_issue.json holds wave-level VALU instructions per block search (SQ_INSTS_VALU pass of this command) and the
@@ -685,7 +710,7 @@ def issue_roofline(prof, prof_ms, prof_searches, cfg, wall_s=None, all_searches=
            "frac": round(achieved / peak, 4), "valu_per_block": valu, "cycles_per_valu_instruction": cpv, "source": prof.get("source"),
            "what": "achieved = VALU instructions of the launches / summed launch time (launches of several contexts overlap, each is stretched)",
            "note": "the ceiling that binds while the CU is full (%.0f %% of the issue cycles of the resident waves in the counter passes, the L1 pipe "
-                   "next to it); a launch alone is bound by its dependency chain instead (DESIGN.md section 3, profiles/r02_search_pmc.json)"
+                   "next to it); a launch alone is bound by its dependency chain instead (DESIGN.md section 3, profiles/r03_search_pmc.json)"
                    % (100 * prof.get("valu_issue_utilisation_while_resident", 0))}
     if wall_s and all_searches:
         # whole timed region: every search of every context against the wall clock
