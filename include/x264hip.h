@@ -245,7 +245,7 @@ int  x264hip_frame_cost_recalculate( x264hip_ctx *ctx, int slot_b, int dist_p0, 
  * of 16 samples in both directions.  Planes are device pointers.  Used for parity and for the SAD/SATD GB/s metric. */
 int  x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx, const void *fenc_plane, const void *ref_plane,
                               int stride, int blocks_w, int blocks_h, const int16_t *mv_dev, int *out_dev );
-/* ---- main-encode motion search, functional baseline --------------------------------------------------
+/* ---- main-encode motion search ----------------------------------------------------------------------
  * x264_me_search_ref (encoder/me.c:182-798: DIA, HEX, UMH, ESA, TESA) + refine_subpel (:865-992) for a batch of independent
  * requests -- what analyse.c hands to x264_me_search_ref for one partition (x264_me_t, common/me.h:33-56, plus the limits of
  * h->mb.mv_limit_fpel / mv_min_spel / mv_max_spel): luma only, one reference per request, no weights.  Planes are device
@@ -253,7 +253,7 @@ int  x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx, const vo
  * padded far enough for the limits given.  integral_dev: element (0,0) of the 8x8-sum plane with the reference stride,
  * integral_lower elements from there to the 4x4-sum plane (frame.c:240-256); only read by TESA requests.  cost_mv_dev: the centred
  * cost table of the request's qp (h->cost_mv[qp], analyse.c:151-157) on the device.  out[i] = { mv x, mv y (quarter-pel), cost,
- * cost_mv } as x264_me_search_ref leaves them in x264_me_t.  One thread per request: bit-exact, not tuned. */
+ * cost_mv } as x264_me_search_ref leaves them in x264_me_t.  A wave per request (block costs across its lanes). */
 /* The integral planes x264_frame_filter keeps for the exhaustive searches (common/mc.c:424-456, :757-783; frame.c:240-256): for the
  * padded luma plane starting at plane_dev (width x height samples, device memory), sum8[y*stride + x] = the sum of the 8x8 box
  * whose top-left sample is (x, y), modulo 2^16, and sum4 the same for 4x4 boxes.  Entries whose box would leave the plane are not

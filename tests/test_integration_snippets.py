@@ -36,6 +36,8 @@ def test_integration_snippets_compile_against_reference_headers(depth, tmp_path)
     hook = _pick(blocks, "#if HAVE_HIPLOOKAHEAD")
     hpel = _pick(blocks, "h->hip.hpel_filter( ctx")
     tables = _pick(blocks, "h->hip.mc_fill( h->hip.ctx, &f )")
+    bind = _pick(blocks, "h->hip.mc_bind_handle( h->hip.ctx, h );")
+    fillers = _pick(blocks, "x264hip_pixel_fill( ctx, &pf )")
     redirect = lambda s: s.replace("h->hip.", "g_hip.")  # noqa: E731
     src = """
 #include "common/common.h"
@@ -69,8 +71,14 @@ void snippet_hpel( x264_t *h, x264_frame_t *frame, int p, int offs, intptr_t str
 void snippet_tables( x264_t *h )
 {
 %s
+%s
 }
-""" % (struct, redirect(upload), redirect(hook), redirect(hpel), redirect(tables))
+
+void snippet_fillers( x264_t *h, x264hip_ctx *ctx )
+{
+%s
+}
+""" % (struct, redirect(upload), redirect(hook), redirect(hpel), redirect(tables), redirect(bind), fillers.replace("/* ... the other eight */", "").replace("/* ... the other four  */", ""))
     tu = tmp_path / "integration_snippets.c"
     tu.write_text(src)
     cmd = ["gcc", "-std=gnu99", "-fsyntax-only", "-Wall", "-Werror=implicit-function-declaration", "-Werror=incompatible-pointer-types",
