@@ -1231,6 +1231,21 @@ __global__ __launch_bounds__( 256 ) void frame_dct_quant4x4_kernel( const T *__r
     nz_out[(size_t)by * blocks_w + bx] = nz != 0;
 }
 
+// ---- descriptor tables: pinned host memory -> device memory ---------------------------------------------------------------------
+// Every launch that takes a table of descriptors (ingest, search, cells, MB-tree steps, weight jobs) gets it through this kernel
+// instead of hipMemcpyAsync.  Measured (rocprofv3 --hip-runtime-trace, eight contexts): a host-to-device hipMemcpyAsync on a stream
+// that has an unresolved hipStreamWaitEvent in front of it does not return until the other stream gets there -- 12-41 ms per call,
+// ~28 ms per 160-frame pass of a context -- whereas a kernel launch is queued behind the wait and returns at once.  The pinned
+// tables are mapped into the device's address space (hipHostMalloc), so the copy is a read over the host link by the kernel itself.
+__global__ __launch_bounds__( 256 ) void upload_kernel( uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, unsigned n_words )
+{
+    const unsigned n16 = n_words >> 2;
+    for( unsigned i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256 )
+        ( (uint4 *)dst )[i] = ( (const uint4 *)src )[i];
+    if( blockIdx.x == 0 && threadIdx.x < ( n_words & 3 ) )
+        dst[4 * n16 + threadIdx.x] = src[4 * n16 + threadIdx.x];
+}
+
 // ---- MB-tree: common/mc.c:511-598, encoder/slicetype.c:1029-1089 -------------------------
 // The host hands over the ordered step list of one macroblock_tree() call; ONE workgroup walks it (steps depend on
 // each other through the propagate buffers, a frame at a time), 1024 threads over the macroblocks of a step.  It
@@ -1313,30 +1328,31 @@ __device__ __forceinline__ void mbt_propagate_mb( const MbtOpDev &o, int *ref0, 
 }
 
 #define MBT_UNROLL 4
-#define MBT_WGS 8
+#define MBT_WGS 4   // workgroups per list at most (x264hip.hip: mbt_wgs_per_list)
 #define MBT_THREADS 1024
-// All MBT_WGS workgroups walk the same step list; where a step reads what earlier steps accumulated they meet at a
+#define MBT_MAX_GROUPS 16
+// The step lists of up to MBT_MAX_GROUPS macroblock_tree() calls, one after the other in the table; list g is steps [beg[g], beg[g+1])
+struct MbtGroups
+{
+    int n, beg[MBT_MAX_GROUPS + 1];
+};
+// A launch runs the lists of G.n macroblock_tree() calls side by side, list g on workgroups [g * wgs, (g+1) * wgs).  The calls of a
+// stream follow each other as a chain of ~25 dependent phases each, and nothing but the accumulators ties one call to the next (every
+// call clears the accumulators it uses before it adds to them, slicetype.c:1108-1135): the host gives each list of a launch its own
+// accumulator bank, so the chains overlap instead of queueing (x264hip.hip, mbt_flush).
+// The wgs workgroups of a list walk its steps together; where a step reads what earlier steps accumulated they meet at a
 // counter barrier (monotonic counter, relaxed agent-scope polling, bounded spin).  Everything exchanged between
 // steps lives in the propagate accumulators, which are only touched with agent-scope atomics, so no fences are
 // needed beyond draining this wave's outstanding operations before it arrives.
-__global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *ops_in, int n_ops, int stage_in_lds, const AqLuts *luts,
-                                                         unsigned *bar /* [0] arrivals, [1] error, [2] exits */ )
+__global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *ops_in, MbtGroups G, int wgs, const AqLuts *luts,
+                                                         unsigned *bar_all /* per list: [0] arrivals, [2] exits */, unsigned *err )
 {
-    extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char mbt_lds[];
     const int W = P.mb_w, H = P.mb_h, n_mb = W * H;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
-    const MbtOpDev *ops = ops_in;
-    if( stage_in_lds )
-    {
-        // the step list sits in pinned host memory: every workgroup pulls it into LDS with one parallel burst of reads
-        // instead of a separate copy kernel in front of every call
-        const uint32_t *src = (const uint32_t *)ops_in;
-        uint32_t *dst = (uint32_t *)mbt_lds;
-        for( int i = threadIdx.x; i < n_ops * (int)( sizeof( MbtOpDev ) / 4 ); i += blockDim.x )
-            dst[i] = __hip_atomic_load( src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
-        __syncthreads();
-        ops = (const MbtOpDev *)mbt_lds;
-    }
+    const int g = blockIdx.x / wgs;
+    const int tid = ( blockIdx.x - g * wgs ) * blockDim.x + threadIdx.x, nthreads = wgs * blockDim.x;
+    const MbtOpDev *ops = ops_in + G.beg[g];
+    const int n_ops = G.beg[g + 1] - G.beg[g];
+    unsigned *bar = bar_all + 4 * g;
     unsigned n_bar = 0;
     for( int k = 0; k < n_ops; k++ )
     {
@@ -1350,12 +1366,12 @@ __global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *
             {
                 __hip_atomic_fetch_add( &bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
                 unsigned spins = 0;
-                while( __hip_atomic_load( &bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) < n_bar * gridDim.x )
+                while( __hip_atomic_load( &bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) < n_bar * wgs )
                 {
                     __builtin_amdgcn_s_sleep( 2 );
                     if( ++spins > ( 1u << 24 ) )
                     {
-                        __hip_atomic_store( &bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+                        __hip_atomic_store( err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
                         break;
                     }
                 }
@@ -1409,9 +1425,9 @@ __global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *
             }
         }
     }
-    // the last workgroup to leave re-arms the barrier counters for the next call that uses this ring entry
+    // the last workgroup of the list to leave re-arms its barrier counters for the next launch that uses this ring entry
     __syncthreads();
-    if( threadIdx.x == 0 && __hip_atomic_fetch_add( &bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) == gridDim.x - 1 )
+    if( threadIdx.x == 0 && __hip_atomic_fetch_add( &bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) == (unsigned)wgs - 1 )
     {
         __hip_atomic_store( &bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
         __hip_atomic_store( &bar[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );

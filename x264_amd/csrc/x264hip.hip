@@ -74,6 +74,7 @@ struct FrameSlot
     int *row_satds = nullptr;         // [(bf+2)*(bf+2)][mb_h]
     int *blk = nullptr;               // [(bf+2)*(bf+2)][n_mb] unclamped block cost | b_intra << 30 per cell
     int *prop = nullptr;              // [n_mb] MB-tree i_propagate_cost accumulator
+    int *prop_view = nullptr;         // where the accumulator's current contents are: prop, or this slot's array in one of the context's banks
     float *qp_aq = nullptr, *qp = nullptr; // [n_mb] f_qp_offset_aq, f_qp_offset
     unsigned field_tag[2][X264HIP_BFRAME_MAX + 1]; // serial of the search that last wrote the field
     std::vector<CellEntry> cells;
@@ -141,13 +142,20 @@ struct x264hip_ctx
     unsigned long long *stats_host = nullptr; // pinned [slots][2]
     // MB-tree: own stream, ring of pinned/device step tables
     hipStream_t stream2 = nullptr;
-    static const int MBT_RING = 64, MBT_CAP = 1024;
-    MbtOpDev *mbt_host[64] = { nullptr }, *mbt_dev[64] = { nullptr };
-    hipEvent_t mbt_done[64] = { nullptr };
+    static const int MBT_RING = 32, MBT_CAP = 2048;
+    MbtOpDev *mbt_host[32] = { nullptr }, *mbt_dev[32] = { nullptr };
+    hipEvent_t mbt_done[32] = { nullptr };
     hipEvent_t ev_cross = nullptr, ev_mbt_last = nullptr;
     hipEvent_t ev_ingest = nullptr;  // behind the most recent ingest kernels: frame totals are readable after it
     int mbt_next = 0, mbt_pending = 0;
-    unsigned *mbt_bar = nullptr;      // device [MBT_RING][4]: barrier arrivals, error, exits, unused
+    unsigned *mbt_bar = nullptr;      // device [MBT_RING][MBT_MAX_GROUPS][4]: barrier arrivals, unused, exits, unused; then one error word
+    // step lists waiting for their launch (x264hip_mbtree queues, mbt_flush launches): list g of the queue is steps
+    // [mbt_q.beg[g], mbt_q.beg[g+1]) of ring entry mbt_q_ring and adds into accumulator bank g
+    MbtGroups mbt_q = { 0, { 0 } };
+    int mbt_q_ring = -1;
+    bool counted_open = false;
+    std::vector<int> mbt_q_finished;  // slots some queued list writes quantiser offsets of
+    int *prop_bank[MBT_MAX_GROUPS] = { nullptr }; // bank g > 0: [max_frames][n_mb] accumulators of list g of a launch (bank 0 = the slots' own)
     int desc_cap = 0;
     // weight costs: WCAP job entries, each with device counters [2][2] and a pinned result pair; entry 0 serves the
     // on-demand call, the others hold speculative pairs (x264hip_prefetch_weight_costs) until their frames go away
@@ -211,6 +219,16 @@ static inline T *plane_origin( x264hip_ctx *ctx, FrameSlot &s, int p )
     return (T *)( s.planes + (size_t)p * ctx->plane_bytes ) + LA_PAD * ctx->P.stride + LA_PAD;
 }
 
+// table in pinned host memory (16-byte aligned, a multiple of 4 bytes) -> device, as a kernel (la_kernels.h: upload_kernel)
+static hipError_t upload_async( void *dst_dev, const void *src_pinned, size_t bytes, hipStream_t s )
+{
+    if( !bytes ) return hipSuccess;
+    const unsigned n_words = (unsigned)( ( bytes + 3 ) / 4 );
+    const unsigned wgs = std::max( 1u, std::min( 64u, ( n_words / 4 + 255 ) / 256 ) );
+    upload_kernel<<<wgs, 256, 0, s>>>( (uint32_t *)dst_dev, (const uint32_t *)src_pinned, n_words );
+    return hipGetLastError();
+}
+
 static void ring_free( DescRing &r )
 {
     for( int i = 0; i < DescRing::K; i++ )
@@ -246,8 +264,13 @@ static int ring_commit( DescRing &r, int i, hipStream_t s )
     return hipEventRecord( r.ev[i], s ) == hipSuccess ? 0 : -1;
 }
 
+// contexts open on each device: the MB-tree launches size themselves so that the lists of every context fit the chip together
+#include <atomic>
+static std::atomic<int> g_open_contexts[64];
+
 static void free_all( x264hip_ctx *ctx )
 {
+    if( ctx->counted_open ) { g_open_contexts[ctx->device & 63]--; ctx->counted_open = false; }
     if( ctx->stream ) (void)hipStreamSynchronize( ctx->stream );
     for( auto &s : ctx->slots )
     {
@@ -267,6 +290,7 @@ static void free_all( x264hip_ctx *ctx )
         if( ctx->mbt_done[i] ) (void)hipEventDestroy( ctx->mbt_done[i] );
     }
     (void)hipFree( ctx->mbt_bar );
+    for( int g = 1; g < MBT_MAX_GROUPS; g++ ) (void)hipFree( ctx->prop_bank[g] );
     if( ctx->ev_cross ) (void)hipEventDestroy( ctx->ev_cross );
     if( ctx->ev_mbt_last ) (void)hipEventDestroy( ctx->ev_mbt_last );
     if( ctx->ev_ingest ) (void)hipEventDestroy( ctx->ev_ingest );
@@ -412,8 +436,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( hipEventCreateWithFlags( &ctx->ev_ingest, hipEventDisableTiming ) );
     for( int i = 0; i < x264hip_ctx::BATCH_EVS; i++ )
         OPENCK( hipEventCreateWithFlags( &ctx->batch_ev[i], hipEventDisableTiming ) );
-    OPENCK( hipMalloc( &ctx->mbt_bar, x264hip_ctx::MBT_RING * 4 * sizeof( unsigned ) ) );
-    OPENCK( hipMemset( ctx->mbt_bar, 0, x264hip_ctx::MBT_RING * 4 * sizeof( unsigned ) ) );
+    OPENCK( hipMalloc( &ctx->mbt_bar, ( x264hip_ctx::MBT_RING * MBT_MAX_GROUPS * 4 + 4 ) * sizeof( unsigned ) ) );
+    OPENCK( hipMemset( ctx->mbt_bar, 0, ( x264hip_ctx::MBT_RING * MBT_MAX_GROUPS * 4 + 4 ) * sizeof( unsigned ) ) );
     for( int i = 0; i < x264hip_ctx::MBT_RING; i++ )
     {
         OPENCK( hipHostMalloc( &ctx->mbt_host[i], x264hip_ctx::MBT_CAP * sizeof( MbtOpDev ) ) );
@@ -468,7 +492,7 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         s.lowres_costs = (uint16_t *)( base + o_lc );
         s.row_satds = (int *)( base + o_rows );
         s.blk = (int *)( base + o_blk );
-        s.prop = (int *)( base + o_prop ); s.qp_aq = (float *)( base + o_qpa ); s.qp = (float *)( base + o_qp );
+        s.prop = s.prop_view = (int *)( base + o_prop ); s.qp_aq = (float *)( base + o_qpa ); s.qp = (float *)( base + o_qp );
         s.cell_sums = (int *)( base + o_sums );
         s.cells.assign( nc, CellEntry() );
         s.req_cells.assign( nc, 0 );
@@ -478,6 +502,7 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         memset( s.field_remote, 0, sizeof( s.field_remote ) );
     }
 #undef OPENCK
+    g_open_contexts[ctx->device & 63]++; ctx->counted_open = true;
     *out = ctx;
     return X264HIP_OK;
 }
@@ -491,11 +516,16 @@ extern "C" int x264hip_device_name( x264hip_ctx *ctx, char *buf, size_t cap )
     return X264HIP_OK;
 }
 
+static int mbt_flush( x264hip_ctx *ctx );
 extern "C" int x264hip_synchronize( x264hip_ctx *ctx )
 {
     if( !ctx ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    {
+        int rc = mbt_flush( ctx ); // queued MB-tree lists are work the caller has handed over
+        if( rc ) return rc;
+    }
     HIPCK( hipStreamSynchronize( ctx->stream ) );
     return X264HIP_OK;
 }
@@ -589,6 +619,10 @@ extern "C" int x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, 
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     FrameSlot &s = ctx->slots[slot];
+    {
+        int rc = mbt_flush( ctx );
+        if( rc ) return rc;
+    }
     if( ctx->mbt_pending )
         HIPCK( hipStreamWaitEvent( ctx->stream, ctx->ev_mbt_last, 0 ) ); // MB-tree steps may still read this slot's maps
     slot_reset( ctx, s );
@@ -649,6 +683,10 @@ extern "C" int x264hip_frame_put_batch_yuv( x264hip_ctx *ctx, int n, const int *
         return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    {
+        int rc = mbt_flush( ctx );
+        if( rc ) return rc;
+    }
     if( ctx->mbt_pending )
         HIPCK( hipStreamWaitEvent( ctx->stream, ctx->ev_mbt_last, 0 ) );
     const x264hip_params &p = ctx->p;
@@ -666,7 +704,7 @@ extern "C" int x264hip_frame_put_batch_yuv( x264hip_ctx *ctx, int n, const int *
             slot_reset( ctx, s );
             dh[i] = make_put_desc( ctx, s, luma_dev[o + i], stride, cb_dev ? cb_dev[o + i] : nullptr, cb_dev ? cr_dev[o + i] : nullptr, cstride, aq_on );
         }
-        HIPCK( hipMemcpyAsync( dd, dh, (size_t)m * sizeof( PutDesc ), hipMemcpyHostToDevice, ctx->stream ) );
+        HIPCK( upload_async( dd, dh, (size_t)m * sizeof( PutDesc ), ctx->stream ) );
         PutDesc none;
         memset( &none, 0, sizeof( none ) );
         int rc = p.bit_depth == 8 ? launch_ingest_t<uint8_t>( ctx, dd, none, m ) : launch_ingest_t<uint16_t>( ctx, dd, none, m );
@@ -841,7 +879,7 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         d.pad = 0;
         dh[i] = d;
     }
-    HIPCK( hipMemcpyAsync( dd, dh, (size_t)n * sizeof( SearchDesc<T> ), hipMemcpyHostToDevice, ctx->stream ) );
+    HIPCK( upload_async( dd, dh, (size_t)n * sizeof( SearchDesc<T> ), ctx->stream ) );
     // (the row tickets in sync_words are cleared by the last wave of the previous launch: me_search.h)
     hipEvent_t e0 = ctx->ev_start, e1 = ctx->ev_stop;
     if( ctx->prof_on )
@@ -982,7 +1020,7 @@ static int launch_cells_t( x264hip_ctx *ctx, const std::vector<SpecCell> &cells 
             const SpecCell &c = *ord[i];
             dh[i] = make_cell<T>( ctx, c.slot_p0, c.slot_p1, c.slot_b, c.d0, c.d1, 1, c.ref1_valid, c.sums_only, c.to_spare );
         }
-        HIPCK( hipMemcpyAsync( dd, dh, (size_t)n * sizeof( CellArgs ), hipMemcpyHostToDevice, ctx->stream ) );
+        HIPCK( upload_async( dd, dh, (size_t)n * sizeof( CellArgs ), ctx->stream ) );
         CellArgs none;
         memset( &none, 0, sizeof( none ) );
         if( n_p )
@@ -1324,7 +1362,10 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
         if( r ) return r;
         if( intra_only )
         {
-            // the sums are known; the map still has to take the reference's 14-bit clamp (aliases the intra costs)
+            // the sums are known; the map still has to take the reference's 14-bit clamp (aliases the intra costs, which queued
+            // MB-tree lists read as they were when they were handed over)
+            int rf = mbt_flush( ctx );
+            if( rf ) return rf;
             cell_p_kernel<<<dim3( ( ctx->n_mb + 255 ) / 256, 1 ), 256, 0, ctx->stream>>>( P, nullptr, A );
             HIPCK( hipGetLastError() );
         }
@@ -1372,6 +1413,63 @@ extern "C" int x264hip_frame_cost( x264hip_ctx *ctx, int slot_p0, int slot_p1, i
 }
 
 // ---- MB-tree ----------------------------------------------------------------------------------------------
+// The ring entry the next launch's step table is written to (its previous launch has consumed it)
+static int mbt_ring_acquire( x264hip_ctx *ctx, int *r_out )
+{
+    const int ring = ctx->mbt_next;
+    ctx->mbt_next = ( ring + 1 ) % x264hip_ctx::MBT_RING;
+    if( ctx->mbt_pending >= x264hip_ctx::MBT_RING )
+        HIPCK( hipEventSynchronize( ctx->mbt_done[ring] ) );
+    *r_out = ring;
+    return X264HIP_OK;
+}
+
+// Workgroups per list.  The workgroups of a list wait for each other at its barriers, so all of them have to be resident together:
+// with 1024 threads and 80 registers a CU holds one, and MBT_MAX_GROUPS lists of every open context must fit the chip at once
+// (otherwise workgroups that spin at a barrier could keep the ones they wait for off the CUs).  Measured, 1080p, lists of ~80 steps:
+// one context 14 750 frames/s with 4 workgroups per list, 13 100 with 2, 10 200 with 1; eight contexts 21 900 / 21 800 / 20 800.
+static int mbt_wgs_per_list( x264hip_ctx *ctx )
+{
+    static const int forced = getenv( "X264HIP_MBT_WGS" ) ? std::max( 1, std::min( 64, atoi( getenv( "X264HIP_MBT_WGS" ) ) ) ) : 0;
+    if( forced ) return forced;
+    const int contexts = std::max( 1, g_open_contexts[ctx->device & 63].load() );
+    return std::max( 1, std::min( MBT_WGS, ctx->n_cu / ( MBT_MAX_GROUPS * contexts ) ) );
+}
+
+// Launch the queued step lists: one kernel, every list on its own workgroups and accumulator bank.  Everything that reads what the
+// lists write (quantiser offsets, accumulators), rewrites what they read (slot reuse, the intra clamp) or must see them finished
+// (synchronize) calls this first, so that a caller cannot tell the queue from a launch per call.
+static int mbt_flush( x264hip_ctx *ctx )
+{
+    if( ctx->mbt_q.n == 0 ) return X264HIP_OK;
+    const int r = ctx->mbt_q_ring;
+    const MbtGroups G = ctx->mbt_q;
+    ctx->mbt_q.n = 0; ctx->mbt_q.beg[0] = 0; ctx->mbt_q_ring = -1;
+    ctx->mbt_q_finished.clear();
+    static const int mbt_threads = getenv( "X264HIP_MBT_THREADS" ) ? std::max( 64, std::min( 1024, atoi( getenv( "X264HIP_MBT_THREADS" ) ) & ~63 ) ) : MBT_THREADS;
+    const int mbt_wgs = mbt_wgs_per_list( ctx );
+    // inputs come from the main stream (cells, clamp kernels): order the MB-tree stream behind it
+    HIPCK( hipEventRecord( ctx->ev_cross, ctx->stream ) );
+    HIPCK( hipStreamWaitEvent( ctx->stream2, ctx->ev_cross, 0 ) );
+    // Measured (two segments in flight, 1080p): copying the step list to the device in front of the launch gives 8500 frames/s,
+    // letting every workgroup pull it from pinned host memory into LDS 8070
+    HIPCK( upload_async( ctx->mbt_dev[r], ctx->mbt_host[r], (size_t)G.beg[G.n] * sizeof( MbtOpDev ), ctx->stream2 ) );
+    mbtree_kernel<<<G.n * mbt_wgs, mbt_threads, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], G, mbt_wgs, ctx->luts_dev,
+                                                                    ctx->mbt_bar + (size_t)r * MBT_MAX_GROUPS * 4,
+                                                                    ctx->mbt_bar + (size_t)x264hip_ctx::MBT_RING * MBT_MAX_GROUPS * 4 );
+    HIPCK( hipGetLastError() );
+    HIPCK( hipEventRecord( ctx->mbt_done[r], ctx->stream2 ) );
+    HIPCK( hipEventRecord( ctx->ev_mbt_last, ctx->stream2 ) );
+    ctx->mbt_pending++;
+    return X264HIP_OK;
+}
+
+// the accumulator of (bank, slot)
+static int *mbt_bank_acc( x264hip_ctx *ctx, int bank, int slot )
+{
+    return bank == 0 ? ctx->slots[slot].prop : ctx->prop_bank[bank] + (size_t)slot * ctx->n_mb;
+}
+
 extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, int n )
 {
     if( !ctx || !ops || n <= 0 || n > x264hip_ctx::MBT_CAP ) return X264HIP_EINVAL;
@@ -1396,10 +1494,112 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
             int rc = ensure_cell_local( ctx, ops[i].slot_b, ops[i].dist_p0, ops[i].dist_p1 );
             if( rc ) return rc;
         }
-    const int r = ctx->mbt_next;
-    ctx->mbt_next = ( r + 1 ) % x264hip_ctx::MBT_RING;
-    if( ctx->mbt_pending >= x264hip_ctx::MBT_RING )
-        HIPCK( hipEventSynchronize( ctx->mbt_done[r] ) ); // the table we are about to rewrite has been consumed
+    // A list that clears every accumulator it reads before it adds to it (every list of a lookahead with frames in it,
+    // slicetype.c:1108-1135) depends on the lists before it through nothing but the buffers: it is queued, gets an accumulator bank
+    // of its own and runs beside the other lists of the launch.  Lists that carry state across calls (the lookahead-less form swaps
+    // accumulators and resets offsets, slicetype.c:1096-1121) run at once on the slots' own accumulators, as before.
+    static const bool no_lds = getenv( "X264HIP_MBT_LDS" ) == nullptr; // measured slower than the multi-workgroup kernel (DESIGN.md): opt-in for experiments
+    static const int max_groups = getenv( "X264HIP_MBT_GROUPS" ) ? std::max( 0, std::min( MBT_MAX_GROUPS, atoi( getenv( "X264HIP_MBT_GROUPS" ) ) ) ) : MBT_MAX_GROUPS;
+    bool queued_form = no_lds && max_groups > 0;
+    {
+        std::vector<char> cleared( ctx->slots.size(), 0 );
+        for( int i = 0; i < n && queued_form; i++ )
+        {
+            const x264hip_mbtree_op &o = ops[i];
+            if( o.type == X264HIP_MBT_ZERO ) cleared[o.slot_b] = 1;
+            else if( o.type == X264HIP_MBT_SWAP || o.type == X264HIP_MBT_RESET_QP ) queued_form = false;
+        }
+        for( int i = 0; i < n && queued_form; i++ )
+        {
+            const x264hip_mbtree_op &o = ops[i];
+            if( o.type == X264HIP_MBT_FINISH ) queued_form = cleared[o.slot_b];
+            else if( o.type == X264HIP_MBT_PROPAGATE )
+                queued_form = ( !o.referenced || cleared[o.slot_b] ) && cleared[o.slot_p0] && ( o.dist_p1 == 0 || cleared[o.slot_p1] );
+        }
+    }
+    if( queued_form )
+    {
+        // two lists of a launch must not write the offsets of the same frame (the later one has to win)
+        for( int i = 0; i < n; i++ )
+            if( ops[i].type == X264HIP_MBT_FINISH && std::find( ctx->mbt_q_finished.begin(), ctx->mbt_q_finished.end(), ops[i].slot_b ) != ctx->mbt_q_finished.end() )
+            {
+                int rc = mbt_flush( ctx );
+                if( rc ) return rc;
+                break;
+            }
+        if( ctx->mbt_q.n >= max_groups || ctx->mbt_q.beg[ctx->mbt_q.n] + n > x264hip_ctx::MBT_CAP )
+        {
+            int rc = mbt_flush( ctx );
+            if( rc ) return rc;
+        }
+        const int bank = ctx->mbt_q.n;
+        if( bank > 0 && !ctx->prop_bank[bank] )
+            HIPCK( hipMalloc( &ctx->prop_bank[bank], ctx->slots.size() * (size_t)ctx->n_mb * sizeof( int ) ) );
+        if( ctx->mbt_q_ring < 0 )
+        {
+            int rc = mbt_ring_acquire( ctx, &ctx->mbt_q_ring );
+            if( rc ) return rc;
+        }
+        MbtOpDev *dh = ctx->mbt_host[ctx->mbt_q_ring] + ctx->mbt_q.beg[bank];
+        // Step order on the device: every ZERO first (a buffer is always cleared before anything is added to it in the
+        // reference's order too), then the rest in order.  A barrier is only needed where a step reads what earlier
+        // steps accumulated: referenced PROPAGATEs and FINISH; runs of B-frame propagations overlap freely.
+        int k = 0;
+        for( int pass = 0; pass < 2; pass++ )
+            for( int i = 0; i < n; i++ )
+            {
+                const x264hip_mbtree_op &o = ops[i];
+                if( ( o.type == X264HIP_MBT_ZERO ) != ( pass == 0 ) ) continue;
+                FrameSlot &b = ctx->slots[o.slot_b];
+                MbtOpDev d;
+                memset( &d, 0, sizeof( d ) );
+                d.type = o.type; d.referenced = o.referenced; d.bipred_weight = o.bipred_weight; d.fps_factor_i = o.fps_factor_i;
+                d.fps_factor = o.fps_factor; d.weightdelta = o.weightdelta; d.strength = o.strength;
+                d.b_bidir = o.dist_p1 > 0;
+                d.prop_b = mbt_bank_acc( ctx, bank, o.slot_b ); d.prop_p0 = mbt_bank_acc( ctx, bank, o.slot_p0 ); d.prop_p1 = mbt_bank_acc( ctx, bank, o.slot_p1 );
+                d.intra_cost = b.lowres_costs; d.inv_qscale = b.inv_qscale;
+                d.qp_aq = b.qp_aq; d.qp = b.qp;
+                d.lowres_costs = b.lowres_costs;
+                if( o.type == X264HIP_MBT_ZERO )
+                    b.prop_view = d.prop_b; // the frame's accumulator is what this list leaves in its bank
+                else
+                {
+                    d.barrier_before = k == 0 || dh[k - 1].type == X264HIP_MBT_ZERO || ( o.type == X264HIP_MBT_PROPAGATE && o.referenced ) || o.type == X264HIP_MBT_FINISH;
+                    d.lowres_costs = b.lowres_costs + (size_t)( o.dist_p0 * nstride + o.dist_p1 ) * ctx->n_mb;
+                    if( o.type == X264HIP_MBT_PROPAGATE )
+                    {
+                        d.mvq0 = b.mvq[0][o.dist_p0 - 1];
+                        d.mvq1 = o.dist_p1 > 0 ? b.mvq[1][o.dist_p1 - 1] : nullptr;
+                    }
+                    else
+                        ctx->mbt_q_finished.push_back( o.slot_b );
+                }
+                dh[k++] = d;
+            }
+        ctx->mbt_q.beg[bank + 1] = ctx->mbt_q.beg[bank] + k;
+        ctx->mbt_q.n = bank + 1;
+        return X264HIP_OK;
+    }
+    // the immediate form: behind everything queued, on the slots' own accumulators -- contents that live in a bank move home first
+    {
+        int rc = mbt_flush( ctx );
+        if( rc ) return rc;
+        for( int i = 0; i < n; i++ )
+            for( int slot : { ops[i].slot_b, ops[i].slot_p0, ops[i].slot_p1 } )
+            {
+                FrameSlot &f = ctx->slots[slot];
+                if( f.prop_view != f.prop )
+                {
+                    HIPCK( hipMemcpyAsync( f.prop, f.prop_view, ctx->n_mb * sizeof( int ), hipMemcpyDeviceToDevice, ctx->stream2 ) );
+                    f.prop_view = f.prop;
+                }
+            }
+    }
+    int r = 0;
+    {
+        int rc = mbt_ring_acquire( ctx, &r );
+        if( rc ) return rc;
+    }
     MbtOpDev *dh = ctx->mbt_host[r];
     // The lookahead-less form exchanges the accumulators of two frames (X264HIP_MBT_SWAP): that is a swap of the two slots' buffer
     // pointers, applied here in the caller's order, so that every step below addresses the buffer the reference would.  RESET_QP
@@ -1410,14 +1610,15 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
     {
         const x264hip_mbtree_op &o = ops[i];
         if( o.type == X264HIP_MBT_SWAP )
+        {
             std::swap( ctx->slots[o.slot_b].prop, ctx->slots[o.slot_p0].prop );
+            ctx->slots[o.slot_b].prop_view = ctx->slots[o.slot_b].prop; ctx->slots[o.slot_p0].prop_view = ctx->slots[o.slot_p0].prop;
+        }
         else if( o.type == X264HIP_MBT_RESET_QP )
             resets.push_back( o.slot_b );
         res_b[i] = ctx->slots[o.slot_b].prop; res_p0[i] = ctx->slots[o.slot_p0].prop; res_p1[i] = ctx->slots[o.slot_p1].prop;
     }
-    // Step order on the device: every ZERO first (a buffer is always cleared before anything is added to it in the
-    // reference's order too), then the rest in order.  A barrier is only needed where a step reads what earlier
-    // steps accumulated: referenced PROPAGATEs and FINISH; runs of B-frame propagations overlap freely.
+    // step order and barriers as in the queued form
     std::vector<int> order;
     for( int i = 0; i < n; i++ ) if( ops[i].type == X264HIP_MBT_ZERO ) order.push_back( i );
     const int n_zero = (int)order.size();
@@ -1451,7 +1652,6 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
     HIPCK( hipStreamWaitEvent( ctx->stream2, ctx->ev_cross, 0 ) );
     // One workgroup with the accumulators in LDS when at least three of them fit (three are in play in a mini-GOP with a
     // B-reference: the two anchors and the middle frame); larger pictures use the multi-workgroup kernel below
-    static const bool no_lds = getenv( "X264HIP_MBT_LDS" ) == nullptr; // measured slower than the multi-workgroup kernel (DESIGN.md): opt-in for experiments
     const int lds_slots = std::min( 6, (int)( ( 156 * 1024 ) / ( (size_t)ctx->n_mb * sizeof( int ) ) ) );
     bool done_in_lds = false;
     if( n > 0 && !no_lds && lds_slots >= 3 )
@@ -1526,7 +1726,7 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
                 HIPCK( hipFuncSetAttribute( (const void *)mbtree_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 ) );
                 attr_set = true;
             }
-            HIPCK( hipMemcpyAsync( ctx->mbt_dev[r], dh, L.size() * sizeof( MbtOpDev ), hipMemcpyHostToDevice, ctx->stream2 ) );
+            HIPCK( upload_async( ctx->mbt_dev[r], dh, L.size() * sizeof( MbtOpDev ), ctx->stream2 ) );
             mbtree_lds_kernel<<<1, 1024, (size_t)lds_slots * ctx->n_mb * sizeof( int ), ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], (int)L.size(), ctx->luts_dev );
             HIPCK( hipGetLastError() );
             done_in_lds = true;
@@ -1534,20 +1734,14 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
     }
     if( n > 0 && !done_in_lds )
     {
-    const size_t table_bytes = (size_t)n * sizeof( MbtOpDev );
-    // Measured (two segments in flight, 1080p): copying the step list to the device in front of the call gives 8500 frames/s,
-    // letting every workgroup pull it from pinned host memory into LDS 8070 -- sixteen PCIe read bursts per call cost more
-    // than one small copy.  The staging path stays available for experiments.
-    static const bool stage_lds = getenv( "X264HIP_MBT_STAGE_LDS" ) != nullptr;
     static const int mbt_threads = getenv( "X264HIP_MBT_THREADS" ) ? std::max( 64, std::min( 1024, atoi( getenv( "X264HIP_MBT_THREADS" ) ) & ~63 ) ) : MBT_THREADS;
-    static const int mbt_wgs = getenv( "X264HIP_MBT_WGS" ) ? std::max( 1, std::min( 64, atoi( getenv( "X264HIP_MBT_WGS" ) ) ) ) : MBT_WGS;
-    if( table_bytes <= 48 * 1024 && stage_lds )
-        mbtree_kernel<<<mbt_wgs, mbt_threads, table_bytes, ctx->stream2>>>( ctx->P, dh, n, 1, ctx->luts_dev, ctx->mbt_bar + 4 * r );
-    else
-    {
-        HIPCK( hipMemcpyAsync( ctx->mbt_dev[r], dh, table_bytes, hipMemcpyHostToDevice, ctx->stream2 ) );
-        mbtree_kernel<<<mbt_wgs, mbt_threads, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], n, 0, ctx->luts_dev, ctx->mbt_bar + 4 * r );
-    }
+    const int mbt_wgs = mbt_wgs_per_list( ctx );
+    MbtGroups G;
+    memset( &G, 0, sizeof( G ) );
+    G.n = 1; G.beg[1] = n;
+    HIPCK( upload_async( ctx->mbt_dev[r], dh, (size_t)n * sizeof( MbtOpDev ), ctx->stream2 ) );
+    mbtree_kernel<<<mbt_wgs, mbt_threads, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], G, mbt_wgs, ctx->luts_dev, ctx->mbt_bar + (size_t)r * MBT_MAX_GROUPS * 4,
+                                                            ctx->mbt_bar + (size_t)x264hip_ctx::MBT_RING * MBT_MAX_GROUPS * 4 );
     HIPCK( hipGetLastError() );
     }
     for( int slot : resets )
@@ -1563,18 +1757,21 @@ extern "C" int x264hip_get_qp_offsets( x264hip_ctx *ctx, int slot, float *qp_off
     if( !ctx || !slot_ok( ctx, slot ) || !qp_offset ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    {
+        int rc = mbt_flush( ctx );
+        if( rc ) return rc;
+    }
     HIPCK( hipEventSynchronize( ctx->ev_ingest ) ); // f_qp_offset starts as the AQ offsets written at ingest (main stream)
     HIPCK( hipMemcpyAsync( qp_offset, ctx->slots[slot].qp, ctx->n_mb * sizeof( float ), hipMemcpyDeviceToHost, ctx->stream2 ) );
-    std::vector<unsigned> bar( x264hip_ctx::MBT_RING * 4 );
-    HIPCK( hipMemcpyAsync( bar.data(), ctx->mbt_bar, bar.size() * sizeof( unsigned ), hipMemcpyDeviceToHost, ctx->stream2 ) );
+    unsigned err = 0;
+    HIPCK( hipMemcpyAsync( &err, ctx->mbt_bar + (size_t)x264hip_ctx::MBT_RING * MBT_MAX_GROUPS * 4, sizeof( unsigned ), hipMemcpyDeviceToHost, ctx->stream2 ) );
     HIPCK( hipStreamSynchronize( ctx->stream2 ) );
     ctx->mbt_pending = 0;
-    for( int i = 0; i < x264hip_ctx::MBT_RING; i++ )
-        if( bar[4 * i + 1] )
-        {
-            ctx->broken = 1;
-            return X264HIP_ETIMEOUT;
-        }
+    if( err ) // a barrier of the step walk gave up
+    {
+        ctx->broken = 1;
+        return X264HIP_ETIMEOUT;
+    }
     return X264HIP_OK;
 }
 
@@ -1591,6 +1788,10 @@ extern "C" int x264hip_frame_cost_recalculate( x264hip_ctx *ctx, int slot_b, int
         if( rc0 ) return rc0;
     }
     // f_qp_offset is written by the MB-tree stream: order this stream behind it
+    {
+        int rc1 = mbt_flush( ctx );
+        if( rc1 ) return rc1;
+    }
     if( ctx->mbt_pending )
         HIPCK( hipStreamWaitEvent( ctx->stream, ctx->ev_mbt_last, 0 ) );
     int *res = ctx->cell_acc_host + ( (size_t)slot_b * ctx->n_cells + idx ) * 8 + 7; // a spare word of the cell's pinned result record
@@ -1609,6 +1810,10 @@ extern "C" int x264hip_frame_add_quant_offsets( x264hip_ctx *ctx, int slot, cons
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     if( !ctx->p.aq_mode ) return X264HIP_OK; // the reference has no offset maps without AQ (frame.c:217-226)
+    {
+        int rc = mbt_flush( ctx );
+        if( rc ) return rc;
+    }
     FrameSlot &s = ctx->slots[slot];
     const int n = ctx->n_mb;
     std::vector<float> qp( n );
@@ -1636,8 +1841,12 @@ extern "C" int x264hip_get_propagate_cost( x264hip_ctx *ctx, int slot, uint16_t 
     if( !ctx || !slot_ok( ctx, slot ) || !propagate ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    {
+        int rc = mbt_flush( ctx );
+        if( rc ) return rc;
+    }
     std::vector<int> tmp( ctx->n_mb );
-    HIPCK( hipMemcpyAsync( tmp.data(), ctx->slots[slot].prop, ctx->n_mb * sizeof( int ), hipMemcpyDeviceToHost, ctx->stream2 ) );
+    HIPCK( hipMemcpyAsync( tmp.data(), ctx->slots[slot].prop_view, ctx->n_mb * sizeof( int ), hipMemcpyDeviceToHost, ctx->stream2 ) );
     HIPCK( hipStreamSynchronize( ctx->stream2 ) );
     for( int i = 0; i < ctx->n_mb; i++ )
         propagate[i] = (uint16_t)( tmp[i] < 32767 ? tmp[i] : 32767 );
@@ -1692,7 +1901,7 @@ extern "C" int x264hip_prefetch_weight_costs( x264hip_ctx *ctx, int n, const int
         jh[m++] = make_wjob( ctx, e, f, r, make_wt( ctx, &w[i] ) );
     }
     if( !m ) return X264HIP_OK;
-    HIPCK( hipMemcpyAsync( jd, jh, (size_t)m * sizeof( WeightJob ), hipMemcpyHostToDevice, ctx->stream ) );
+    HIPCK( upload_async( jd, jh, (size_t)m * sizeof( WeightJob ), ctx->stream ) );
     const dim3 grid( ( ctx->n_mb + WCOST_BLOCKS_PER_WG - 1 ) / WCOST_BLOCKS_PER_WG, m, 1 );
     WeightJob none;
     memset( &none, 0, sizeof( none ) );
@@ -2960,7 +3169,7 @@ extern "C" int x264hip_export_cells( x264hip_ctx *ctx, int n, const x264hip_cell
             if( !cell_ref_ok( ctx, cells[o + i] ) ) return X264HIP_EINVAL;
             xh[i] = make_xfer( ctx, cells[o + i] );
         }
-        HIPCK( hipMemcpyAsync( xd, xh, (size_t)m * sizeof( CellXfer ), hipMemcpyHostToDevice, ctx->stream ) );
+        HIPCK( upload_async( xd, xh, (size_t)m * sizeof( CellXfer ), ctx->stream ) );
         export_cells_kernel<<<m, 64, 0, ctx->stream>>>( xd, ctx->P.mb_h, (int *)dst_dev + (size_t)o * per );
         HIPCK( hipGetLastError() );
         if( ring_commit( ctx->xfer_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
@@ -3003,7 +3212,7 @@ extern "C" int x264hip_import_cells( x264hip_ctx *ctx, int n, const x264hip_cell
             e.map_remote = 1; e.slot_p0 = c.slot_p0; e.slot_p1 = c.slot_p1;
             taken++;
         }
-        HIPCK( hipMemcpyAsync( xd, xh, (size_t)m * sizeof( CellXfer ), hipMemcpyHostToDevice, ctx->stream ) );
+        HIPCK( upload_async( xd, xh, (size_t)m * sizeof( CellXfer ), ctx->stream ) );
         import_cells_kernel<<<m, 64, 0, ctx->stream>>>( xd, ctx->P.mb_h, (const int *)src_dev + (size_t)o * per );
         HIPCK( hipGetLastError() );
         if( ring_commit( ctx->xfer_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
