@@ -172,6 +172,8 @@ struct x264hip_ctx
     std::vector<char *> wplanes;     // weighted plane pool
     char *me_pool = nullptr;         // device memory of x264hip_me_search_batch calls (request table, results, TESA lists), grow-only
     size_t me_pool_bytes = 0;
+    char *me_host = nullptr;         // ... and the pinned host block its tables are written to and its results come back to
+    size_t me_host_bytes = 0;
     char *vt_pool = nullptr;         // staging memory of the function-table members (x264hip_mc_fill & co.), grow-only
     size_t vt_pool_bytes = 0;
     std::vector<int> wplane_owner;
@@ -279,6 +281,7 @@ static void free_all( x264hip_ctx *ctx )
     for( auto w : ctx->wplanes ) (void)hipFree( w );
     if( ctx->vt_pool ) (void)hipFree( ctx->vt_pool );
     if( ctx->me_pool ) (void)hipFree( ctx->me_pool );
+    if( ctx->me_host ) (void)hipHostFree( ctx->me_host );
     (void)hipFree( ctx->cost_mv_dev ); (void)hipFree( ctx->luts_dev ); (void)hipFree( ctx->sync_words );
     ring_free( ctx->cell_ring ); ring_free( ctx->put_ring ); ring_free( ctx->search_ring ); ring_free( ctx->wjob_ring ); ring_free( ctx->xfer_ring );
     (void)hipHostFree( ctx->err_host );
@@ -2118,20 +2121,19 @@ static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request 
                               const void *const ref_planes[4], intptr_t ref_stride, const uint16_t *integral, intptr_t integral_lower,
                               const uint16_t *cost_mv, int *out )
 {
-    std::vector<MfReq<T>> table( n );
-    std::vector<int16_t> mvc( (size_t)n * MF_MVC_MAX * 2, 0 );
-    std::vector<int> n_mvc( n );
     // TESA keeps the candidates that pass its SAD threshold: at most ( width + 4 ) * ( rows + 1 ) of them, 12 bytes each, with
     // width <= 2 * me_range + 4 and rows <= 2 * me_range + 1 (me.c:651-655)
     auto tesa_bytes = []( int me_range ) { return (size_t)( 2 * me_range + 8 ) * ( 2 * me_range + 2 ) * 12; };
     size_t scratch_total = 0;
     for( int i = 0; i < n; i++ )
         if( reqs[i].me_method == 4 ) scratch_total += tesa_bytes( reqs[i].me_range );
-    // one device allocation for the call, kept by the context and grown when a call needs more (an allocation per call cost more than the
-    // searches of a 1080p frame)
-    const size_t b_scratch = align_up( scratch_total, 256 ), b_table = align_up( sizeof( MfReq<T> ) * n, 256 ), b_mvc = align_up( mvc.size() * sizeof( int16_t ), 256 ),
+    // One device allocation and one pinned host allocation for the call, kept by the context and grown when a call needs more (an
+    // allocation per call cost more than the searches of a 1080p frame).  The tables are written straight into the pinned block and
+    // go to the device in one upload; the results come back into it.
+    const size_t b_scratch = align_up( scratch_total, 256 ), b_table = align_up( sizeof( MfReq<T> ) * n, 256 ), b_mvc = align_up( (size_t)n * MF_MVC_MAX * 2 * sizeof( int16_t ), 256 ),
                  b_nmvc = align_up( sizeof( int ) * n, 256 ), b_out = align_up( sizeof( int ) * 4 * n, 256 ), b_index = align_up( sizeof( int ) * n, 256 );
-    const size_t need = b_scratch + b_table + b_mvc + b_nmvc + b_out + b_index;
+    const size_t b_tables = b_table + b_mvc + b_nmvc + b_index; // what the host writes: contiguous
+    const size_t need = b_scratch + b_tables + b_out;
     if( need > ctx->me_pool_bytes )
     {
         if( ctx->me_pool ) (void)hipFree( ctx->me_pool );
@@ -2139,10 +2141,22 @@ static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request 
         if( hipMalloc( &ctx->me_pool, need + ( need >> 2 ) ) != hipSuccess ) return X264HIP_ENOMEM;
         ctx->me_pool_bytes = need + ( need >> 2 );
     }
+    if( b_tables + b_out > ctx->me_host_bytes )
+    {
+        if( ctx->me_host ) (void)hipHostFree( ctx->me_host );
+        ctx->me_host = nullptr; ctx->me_host_bytes = 0;
+        const size_t want = b_tables + b_out + ( ( b_tables + b_out ) >> 2 );
+        if( hipHostMalloc( &ctx->me_host, want ) != hipSuccess ) return X264HIP_ENOMEM;
+        ctx->me_host_bytes = want;
+    }
     char *scratch = ctx->me_pool;
     MfReq<T> *table_dev = (MfReq<T> *)( scratch + b_scratch );
     int16_t *mvc_dev = (int16_t *)( (char *)table_dev + b_table );
-    int *n_mvc_dev = (int *)( (char *)mvc_dev + b_mvc ), *out_dev = (int *)( (char *)n_mvc_dev + b_nmvc ), *index_dev = (int *)( (char *)out_dev + b_out );
+    int *n_mvc_dev = (int *)( (char *)mvc_dev + b_mvc ), *index_dev = (int *)( (char *)n_mvc_dev + b_nmvc ), *out_dev = (int *)( (char *)index_dev + b_index );
+    MfReq<T> *table = (MfReq<T> *)ctx->me_host;
+    int16_t *mvc = (int16_t *)( ctx->me_host + b_table );
+    int *n_mvc = (int *)( ctx->me_host + b_table + b_mvc ), *idx = (int *)( ctx->me_host + b_table + b_mvc + b_nmvc );
+    int *out_host = (int *)( ctx->me_host + b_tables );
     int rc = X264HIP_OK;
 #define MECK( call ) do { if( ( call ) != hipSuccess ) { ctx->broken = 1; return X264HIP_EDEVICE; } } while( 0 )
     for( size_t i = 0, t = 0; i < (size_t)n; i++ )
@@ -2168,21 +2182,17 @@ static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request 
         n_mvc[i] = q.n_mvc;
         memcpy( &mvc[(size_t)i * MF_MVC_MAX * 2], q.mvc, sizeof( q.mvc ) );
     }
-    MECK( hipMemcpyAsync( table_dev, table.data(), sizeof( MfReq<T> ) * n, hipMemcpyHostToDevice, ctx->stream ) );
-    MECK( hipMemcpyAsync( mvc_dev, mvc.data(), mvc.size() * sizeof( int16_t ), hipMemcpyHostToDevice, ctx->stream ) );
-    MECK( hipMemcpyAsync( n_mvc_dev, n_mvc.data(), sizeof( int ) * n, hipMemcpyHostToDevice, ctx->stream ) );
+    // one launch per class of methods: the pattern searches (DIA, HEX, UMH) and the exhaustive ones (ESA, TESA) are separate builds
+    int n_pat = 0;
+    for( int i = 0; i < n; i++ ) if( reqs[i].me_method < 3 ) idx[n_pat++] = i;
+    for( int i = 0, k = n_pat; i < n; i++ ) if( reqs[i].me_method >= 3 ) idx[k++] = i;
+    MECK( upload_async( table_dev, table, b_tables, ctx->stream ) );
+    MECK( hipEventRecord( ctx->ev_start, ctx->stream ) );
     {
         // a wave per request: its 64 lanes run the search in lock step, block costs are computed across the wave (four samples per
         // lane) and the exhaustive scans (ESA, TESA) cost 64 candidates per step.  X264HIP_ME_FULL_SCALAR=1 sends everything through
         // the one-thread form instead (the device reference the cooperative form is checked against)
         static const bool all_scalar = getenv( "X264HIP_ME_FULL_SCALAR" ) != nullptr;
-        // one launch per class of methods: the pattern searches (DIA, HEX, UMH) and the exhaustive ones (ESA, TESA) are separate builds
-        std::vector<int> idx;
-        idx.reserve( n );
-        for( int i = 0; i < n; i++ ) if( reqs[i].me_method < 3 ) idx.push_back( i );
-        const int n_pat = (int)idx.size();
-        for( int i = 0; i < n; i++ ) if( reqs[i].me_method >= 3 ) idx.push_back( i );
-        MECK( hipMemcpyAsync( index_dev, idx.data(), sizeof( int ) * n, hipMemcpyHostToDevice, ctx->stream ) );
         if( all_scalar )
             me_full_list_kernel<T><<<( n + 63 ) / 64, 64, 0, ctx->stream>>>( table_dev, mvc_dev, n_mvc_dev, index_dev, n, out_dev );
         else
@@ -2194,8 +2204,12 @@ static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request 
         }
     }
     MECK( hipGetLastError() );
-    MECK( hipMemcpyAsync( out, out_dev, sizeof( int ) * 4 * n, hipMemcpyDeviceToHost, ctx->stream ) );
-    MECK( hipStreamSynchronize( ctx->stream ) ); // (the host vectors above stay alive until here)
+    // (x264hip_last_search_ms reports the device time of the batch's kernels: n searches of one block each)
+    MECK( hipEventRecord( ctx->ev_stop, ctx->stream ) );
+    ctx->ev_valid = 1; ctx->last_n_search = n; ctx->last_n_blocks = n;
+    MECK( hipMemcpyAsync( out_host, out_dev, sizeof( int ) * 4 * n, hipMemcpyDeviceToHost, ctx->stream ) );
+    MECK( hipStreamSynchronize( ctx->stream ) );
+    memcpy( out, out_host, sizeof( int ) * 4 * n );
 #undef MECK
     return rc;
 }

@@ -236,10 +236,16 @@ class Context:
         _ck(self.L.x264hip_pixel_cmp_batch(self.h, int(satd), int(size_idx), C.c_void_p(fenc_ptr), C.c_void_p(ref_ptr), int(stride),
                                            int(blocks_w), int(blocks_h), C.c_void_p(mv_ptr), C.c_void_p(out_ptr)), "pixel_cmp_batch")
 
+    @staticmethod
+    def me_requests(reqs):
+        """the request table of x264hip_me_search_batch as the C array the call takes"""
+        return (MeRequest * len(reqs))(*reqs)
+
     def me_search_batch(self, reqs, fenc_ptr, fenc_stride, ref_ptrs, ref_stride, integral_ptr, integral_lower, cost_mv_ptr):
-        """reqs: list of MeRequest; pointers are device addresses of pixel / element (0,0).  Returns int32 [n, 4]."""
+        """reqs: list of MeRequest, or the array me_requests() makes of one (a caller that repeats a batch builds it once);
+        pointers are device addresses of pixel / element (0,0).  Returns int32 [n, 4]."""
         n = len(reqs)
-        arr = (MeRequest * n)(*reqs)
+        arr = reqs if isinstance(reqs, C.Array) else (MeRequest * n)(*reqs)
         refs = (C.c_void_p * 4)(*ref_ptrs)
         out = np.zeros((n, 4), np.int32)
         self.L.x264hip_me_search_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t,
