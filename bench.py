@@ -78,6 +78,22 @@ def primitives_bench(torch, libmod, cfg, iters=30):
         ctx.synchronize()
         out["hpel_filter_GBps"] = round(4 * W * H * iters / (time.perf_counter() - t0) / 1e9, 1)
         del src, dst
+        # the same over an 8K plane: a 4K plane is ~15 us of work, of which ~8 us are the launch and the first loads / last stores of a wave
+        W8, H8 = 2 * W, 2 * H
+        hs = W8 + 64
+        src = torch.randint(0, 256, (H8 + 16, hs), dtype=torch.uint8, device="cuda", generator=g)
+        dst = torch.empty((3, H8 + 16, hs), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ho = 8 * hs + 32
+        def run_hpel8():
+            ctx.hpel_filter(dst[0].data_ptr() + ho, dst[1].data_ptr() + ho, dst[2].data_ptr() + ho, src.data_ptr() + ho, hs, W8, H8)
+        run_hpel8(); ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            run_hpel8()
+        ctx.synchronize()
+        out["hpel_filter_8k_GBps"] = round(4 * W8 * H8 * iters / (time.perf_counter() - t0) / 1e9, 1)
+        del src, dst
         # frame-level sub4x4_dct + quant_4x4 (first piece): 2*W*H read, 2*W*H (int16 coefficients) + W*H/16 written
         fe = torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda", generator=g)
         fp = torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda", generator=g)

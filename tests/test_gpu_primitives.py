@@ -136,7 +136,8 @@ def test_hpel_filter(depth):
     f.argtypes = [C.c_void_p] * 4 + [C.c_long, C.c_int, C.c_int, C.c_void_p]
     ctx = lib.Context(64, 64, bit_depth=depth, max_frames=2, mv_range=32)
     try:
-        for w, h, kind in [(64, 16, "r"), (100, 9, "r"), (37, 5, "x"), (1920, 1080, "r"), (130, 33, "x")]:
+        for w, h, kind in [(64, 16, "r"), (100, 9, "r"), (37, 5, "x"), (1920, 1080, "r"), (130, 33, "x"), (248, 8, "r"), (251, 10, "x"),
+                           (499, 20, "r"), (745, 3, "r")]:  # (the 8-bit kernel works in strips of 248 columns x 8 rows)
             stride = w + 32
             src = rng.integers(0, maxv + 1, size=(h + 8, stride)).astype(o.dtype)
             if kind == "x":

@@ -1090,6 +1090,128 @@ __global__ __launch_bounds__( 256 ) void hpel_filter_kernel( T *__restrict__ dst
     }
 }
 
+// 8-bit planes: the same three planes by one wave per strip, no LDS and no barrier.  The tiled kernel above spends ~24 scalar integer
+// operations per output sample and is bound by them (607 M lane-operations over a 4K plane = 15 us of the 18 us it takes); here a lane
+// holds four neighbouring columns as packed 16-bit pairs: the vertical six-tap sums are v_pk_* arithmetic (two columns per operation, the
+// sums fit 16 bits), the two horizontal filters are v_dot2_i32_i16 on pairs of neighbouring columns (exact 32-bit accumulation: the
+// nested-shift 16-bit form of the reference's assembly wraps for extreme inputs), and the columns a lane needs from its neighbours
+// come through wave_shr / wave_shl DPP moves.  A wave walks HPS_R output rows down a strip of 64 x 4 columns (the outer two lanes only
+// feed their neighbours) with every row load of the strip in flight before the first is used.
+// Measured on a 4K plane: 4 rows per wave 17.2 us, 8 rows 18.1, 2 rows 17.7, 16 rows 23.1 (the tiled kernel 19.8).
+#ifndef HPS_R
+#define HPS_R 4
+#endif
+#define HPS_W 248
+typedef short hp_s2 __attribute__( ( ext_vector_type( 2 ) ) );
+__device__ __forceinline__ hp_s2 hp_as_s2( unsigned v ) { return __builtin_bit_cast( hp_s2, v ); }
+__device__ __forceinline__ unsigned hp_as_u( hp_s2 v ) { return __builtin_bit_cast( unsigned, v ); }
+__device__ __forceinline__ unsigned hp_prev( unsigned v ) { return (unsigned)__builtin_amdgcn_mov_dpp( (int)v, 0x138, 0xf, 0xf, true ); } // lane - 1 (wave_shr:1)
+__device__ __forceinline__ unsigned hp_next( unsigned v ) { return (unsigned)__builtin_amdgcn_mov_dpp( (int)v, 0x130, 0xf, 0xf, true ); } // lane + 1 (wave_shl:1)
+// ( low half of a, low half of b ), ( high, high ), ( high of a, low of b ), ( low of a, high of b ) as one register each
+__device__ __forceinline__ unsigned hp_lo_lo( unsigned a, unsigned b ) { return __builtin_amdgcn_perm( b, a, 0x05040100 ); }
+__device__ __forceinline__ unsigned hp_hi_hi( unsigned a, unsigned b ) { return __builtin_amdgcn_perm( b, a, 0x07060302 ); }
+__device__ __forceinline__ unsigned hp_hi_lo( unsigned a, unsigned b ) { return __builtin_amdgcn_perm( b, a, 0x05040302 ); }
+__device__ __forceinline__ unsigned hp_lo_hi( unsigned a, unsigned b ) { return __builtin_amdgcn_perm( b, a, 0x07060100 ); }
+// ( t + rnd ) >> sh clipped to 8 bits, both halves
+__device__ __forceinline__ hp_s2 hp_round_clip( hp_s2 t, short rnd, int sh )
+{
+    const hp_s2 r = { rnd, rnd }, zero = { 0, 0 }, top = { 255, 255 };
+    return __builtin_elementwise_min( __builtin_elementwise_max( ( t + r ) >> (short)sh, zero ), top );
+}
+// the six-tap filter over columns x-2 .. x+3 given as three pairs of neighbouring columns, + 512 >> 10, clipped to 8 bits
+__device__ __forceinline__ unsigned hp_tap6( unsigned p0, unsigned p1, unsigned p2 )
+{
+    int acc = __builtin_amdgcn_sdot2( hp_as_s2( p0 ), hp_as_s2( 0xFFFB0001u ), 512, false ); //  1 -5
+    acc = __builtin_amdgcn_sdot2( hp_as_s2( p1 ), hp_as_s2( 0x00140014u ), acc, false );     // 20 20
+    acc = __builtin_amdgcn_sdot2( hp_as_s2( p2 ), hp_as_s2( 0x0001FFFBu ), acc, false );     // -5  1
+    return (unsigned)iclip3( acc >> 10, 0, 255 );
+}
+__global__ __launch_bounds__( 64 ) void hpel_stream_kernel( uint8_t *__restrict__ dsth, uint8_t *__restrict__ dstv, uint8_t *__restrict__ dstc, const uint8_t *__restrict__ src,
+                                                            int stride, int width, int height )
+{
+    const int lane = threadIdx.x;
+    const int x = blockIdx.x * HPS_W + 4 * ( lane - 1 ), y0 = blockIdx.y * HPS_R;
+    const bool last_tile = blockIdx.x == gridDim.x - 1;
+    // The strip's rows y0-2 .. y0+R+2, never beyond what the reference itself reads (columns -2 .. width+2, rows .. height+2), each
+    // split once into its ( c0, c2 ) and ( c1, c3 ) pairs of 16-bit values.  Offsets are relative to sample (-2, -2): never negative.
+    const uint8_t *s0 = src - 2 * (long)stride - 2;
+    hp_s2 e[HPS_R + 5], o[HPS_R + 5];
+    const bool whole = x >= -2 && x + 3 <= width + 2;
+#pragma unroll
+    for( int r = 0; r < HPS_R + 5; r++ )
+    {
+        const unsigned row = (unsigned)( imin2( y0 + r, height + 4 ) * stride );
+        unsigned w = 0;
+        if( whole )
+            __builtin_memcpy( &w, s0 + ( row + (unsigned)( x + 2 ) ), 4 );
+        else
+#pragma unroll
+            for( int k = 0; k < 4; k++ )
+                w |= (unsigned)s0[row + (unsigned)imin2( imax2( x + k + 2, 0 ), width + 4 )] << ( 8 * k );
+        e[r] = hp_as_s2( w & 0x00FF00FFu ); o[r] = hp_as_s2( ( w >> 8 ) & 0x00FF00FFu );
+    }
+    const hp_s2 m5 = { -5, -5 }, m20 = { 20, 20 };
+#pragma unroll
+    for( int r = 0; r < HPS_R; r++ )
+    {
+        const int y = y0 + r;
+        // vertical sums of rows y-2 .. y+3
+        const hp_s2 ve = ( e[r] + e[r + 5] ) + ( e[r + 1] + e[r + 4] ) * m5 + ( e[r + 2] + e[r + 3] ) * m20;
+        const hp_s2 vo = ( o[r] + o[r + 5] ) + ( o[r + 1] + o[r + 4] ) * m5 + ( o[r + 2] + o[r + 3] ) * m20;
+        const unsigned ov = hp_as_u( hp_round_clip( ve, 16, 5 ) ) | hp_as_u( hp_round_clip( vo, 16, 5 ) ) << 8;
+        // centre plane: the filter across the sums (32-bit accumulation: v_dot2 on pairs of neighbouring columns)
+        unsigned oc;
+        {
+            const unsigned E = hp_as_u( ve ), O = hp_as_u( vo ), pe = hp_prev( E ), po = hp_prev( O ), ne = hp_next( E ), no = hp_next( O );
+            const unsigned Pm = hp_hi_hi( pe, po ), P0 = hp_lo_lo( E, O ), P1 = hp_hi_hi( E, O ), P2 = hp_lo_lo( ne, no ); // ( c-2, c-1 ) ( c0, c1 ) ( c2, c3 ) ( c4, c5 )
+            const unsigned Qm = hp_hi_lo( po, E ), Q0 = hp_lo_hi( O, E ), Q1 = hp_hi_lo( O, ne ), Q2 = hp_lo_hi( no, ne ); // ( c-1, c0 ) ( c1, c2 ) ( c3, c4 ) ( c5, c6 )
+            // (bytes 0 and 1 are not joined directly: ROCm 7.2's compiler turns "clip( a >> s ) | clip( b >> s ) << 8" into v_ashr_pk_u8_i32,
+            // which writes only the low half of its destination, and then uses the stale upper half as if it were zero)
+            const unsigned even = hp_tap6( Pm, P0, P1 ) | hp_tap6( P0, P1, P2 ) << 16;
+            const unsigned odd = hp_tap6( Qm, Q0, Q1 ) | hp_tap6( Q0, Q1, Q2 ) << 16;
+            oc = even | odd << 8;
+        }
+        // horizontal plane: the filter across the samples of row y, whose sums fit 16 bits: two outputs per packed operation
+        unsigned oh;
+        {
+            const hp_s2 E = e[r + 2], O = o[r + 2];
+            const unsigned uE = hp_as_u( E ), uO = hp_as_u( O ), pe = hp_prev( uE ), po = hp_prev( uO ), ne = hp_next( uE ), no = hp_next( uO );
+            const hp_s2 A = hp_as_s2( hp_hi_lo( pe, uE ) ), B = hp_as_s2( hp_hi_lo( po, uO ) );  // ( c-2, c0 ) ( c-1, c1 )
+            const hp_s2 G = hp_as_s2( hp_hi_lo( uE, ne ) ), F = hp_as_s2( hp_hi_lo( uO, no ) );  // ( c2, c4 ) ( c3, c5 )
+            const hp_s2 he = ( A + F ) + ( B + G ) * m5 + ( E + O ) * m20;                       // outputs x, x+2
+            const hp_s2 ho = ( B + hp_as_s2( ne ) ) + ( E + F ) * m5 + ( O + G ) * m20;          // outputs x+1, x+3
+            oh = hp_as_u( hp_round_clip( he, 16, 5 ) ) | hp_as_u( hp_round_clip( ho, 16, 5 ) ) << 8;
+        }
+        if( y < height )
+        {
+            const unsigned at = (unsigned)( y * stride + x );
+            if( lane >= 1 && lane <= 62 && x < width )
+            {
+                if( x + 4 <= width )
+                {
+                    __builtin_memcpy( dstv + at, &ov, 4 ); __builtin_memcpy( dstc + at, &oc, 4 ); __builtin_memcpy( dsth + at, &oh, 4 );
+                }
+                else
+                    for( int k = 0; x + k < width; k++ )
+                    {
+                        dstv[at + k] = (uint8_t)( ov >> ( 8 * k ) ); dstc[at + k] = (uint8_t)( oc >> ( 8 * k ) ); dsth[at + k] = (uint8_t)( oh >> ( 8 * k ) );
+                    }
+            }
+            // the reference's five extra dstv columns (-2, -1, width .. width+2)
+            if( blockIdx.x == 0 && lane == 0 )
+            {
+                uint8_t *q = dstv + (long)y * stride;
+                q[-2] = (uint8_t)( ov >> 16 ); q[-1] = (uint8_t)( ov >> 24 );
+            }
+            if( last_tile && lane >= 1 )
+#pragma unroll
+                for( int k = 0; k < 4; k++ )
+                    if( x + k >= width && x + k <= width + 2 )
+                        dstv[at + k] = (uint8_t)( ov >> ( 8 * k ) );
+        }
+    }
+}
+
 // Plain device copy, 16 bytes per lane: the measured HBM rate the SAD/SATD figures are quoted against
 // (vendor peak and the build's own copy kernel).  A workgroup moves contiguous chunks of 256 x U x 16 bytes: its U loads
 // per lane are requested back to back before the first store; NT = non-temporal loads and stores (the data is touched once).
