@@ -154,6 +154,11 @@ struct x264hip_ctx
     MbtGroups mbt_q = { 0, { 0 } };
     int mbt_q_ring = -1;
     bool counted_open = false;
+    // descriptor tables go to the device through a stream of their own (upload_async)
+    hipStream_t stream_up = nullptr;
+    static const int UP_EVS = 64;
+    hipEvent_t up_ev[64] = { nullptr };
+    int up_next = 0;
     std::vector<int> mbt_q_finished;  // slots some queued list writes quantiser offsets of
     int *prop_bank[MBT_MAX_GROUPS] = { nullptr }; // bank g > 0: [max_frames][n_mb] accumulators of list g of a launch (bank 0 = the slots' own)
     int desc_cap = 0;
@@ -221,14 +226,37 @@ static inline T *plane_origin( x264hip_ctx *ctx, FrameSlot &s, int p )
     return (T *)( s.planes + (size_t)p * ctx->plane_bytes ) + LA_PAD * ctx->P.stride + LA_PAD;
 }
 
-// table in pinned host memory (16-byte aligned, a multiple of 4 bytes) -> device, as a kernel (la_kernels.h: upload_kernel)
-static hipError_t upload_async( void *dst_dev, const void *src_pinned, size_t bytes, hipStream_t s )
+// Table in pinned host memory (16-byte aligned, a multiple of 4 bytes) -> device memory, in front of the launch on stream s that reads
+// it: a kernel on s (la_kernels.h: upload_kernel).  Measured (rocprofv3 --hip-runtime-trace, eight contexts, 1080p): hipMemcpyAsync on s
+// does not return while s has an unresolved hipStreamWaitEvent in front of it -- 12-41 ms per call, ~28 ms per 160-frame pass of a
+// context, 20 700 frames/s; the kernel 21 400-21 900; hipMemcpyAsync on a stream of its own that never waits, s waiting for the copy's
+// event (X264HIP_UPLOAD=stream), 18 300; the kernel on a high-priority stream of its own (X264HIP_UPLOAD=prio) 21 700, but 15 700 against 21 400
+// with four contexts.
+static hipError_t upload_async( x264hip_ctx *ctx, void *dst_dev, const void *src_pinned, size_t bytes, hipStream_t s )
 {
     if( !bytes ) return hipSuccess;
+    static const int mode = !getenv( "X264HIP_UPLOAD" ) ? 0 : !strcmp( getenv( "X264HIP_UPLOAD" ), "stream" ) ? 1 : !strcmp( getenv( "X264HIP_UPLOAD" ), "prio" ) ? 2 : 0;
     const unsigned n_words = (unsigned)( ( bytes + 3 ) / 4 );
     const unsigned wgs = std::max( 1u, std::min( 64u, ( n_words / 4 + 255 ) / 256 ) );
-    upload_kernel<<<wgs, 256, 0, s>>>( (uint32_t *)dst_dev, (const uint32_t *)src_pinned, n_words );
-    return hipGetLastError();
+    if( mode == 0 )
+    {
+        upload_kernel<<<wgs, 256, 0, s>>>( (uint32_t *)dst_dev, (const uint32_t *)src_pinned, n_words );
+        return hipGetLastError();
+    }
+    // (the previous reader of the destination is done: ring_acquire / mbt_ring_acquire)
+    hipEvent_t ev = ctx->up_ev[ctx->up_next];
+    ctx->up_next = ( ctx->up_next + 1 ) % x264hip_ctx::UP_EVS;
+    hipError_t e = hipSuccess;
+    if( mode == 1 )
+        e = hipMemcpyAsync( dst_dev, src_pinned, bytes, hipMemcpyHostToDevice, ctx->stream_up );
+    else
+    {
+        upload_kernel<<<wgs, 256, 0, ctx->stream_up>>>( (uint32_t *)dst_dev, (const uint32_t *)src_pinned, n_words );
+        e = hipGetLastError();
+    }
+    if( e == hipSuccess ) e = hipEventRecord( ev, ctx->stream_up );
+    if( e == hipSuccess ) e = hipStreamWaitEvent( s, ev, 0 );
+    return e;
 }
 
 static void ring_free( DescRing &r )
@@ -286,6 +314,7 @@ static void free_all( x264hip_ctx *ctx )
     ring_free( ctx->cell_ring ); ring_free( ctx->put_ring ); ring_free( ctx->search_ring ); ring_free( ctx->wjob_ring ); ring_free( ctx->xfer_ring );
     (void)hipHostFree( ctx->err_host );
     (void)hipHostFree( ctx->stats_host );
+    if( ctx->stream_up ) (void)hipStreamSynchronize( ctx->stream_up );
     if( ctx->stream2 ) (void)hipStreamSynchronize( ctx->stream2 );
     for( int i = 0; i < x264hip_ctx::MBT_RING; i++ )
     {
@@ -300,6 +329,9 @@ static void free_all( x264hip_ctx *ctx )
     for( int i = 0; i < x264hip_ctx::BATCH_EVS; i++ )
         if( ctx->batch_ev[i] ) (void)hipEventDestroy( ctx->batch_ev[i] );
     if( ctx->stream2 ) (void)hipStreamDestroy( ctx->stream2 );
+    for( int i = 0; i < x264hip_ctx::UP_EVS; i++ )
+        if( ctx->up_ev[i] ) (void)hipEventDestroy( ctx->up_ev[i] );
+    if( ctx->stream_up ) (void)hipStreamDestroy( ctx->stream_up );
     (void)hipHostFree( ctx->cell_acc_host );
     (void)hipHostFree( ctx->cell_alt_host );
     (void)hipFree( ctx->wcost_dev );
@@ -433,7 +465,15 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( hipHostMalloc( &ctx->err_host, sizeof( unsigned ) ) );
     *ctx->err_host = 0;
     OPENCK( hipHostMalloc( &ctx->stats_host, (size_t)p.max_frames * 2 * sizeof( unsigned long long ) ) );
+    // (MB-tree launches on the main stream instead, no cross-stream waits at all: 20 700 frames/s against 21 400, eight contexts)
     OPENCK( hipStreamCreateWithFlags( &ctx->stream2, hipStreamNonBlocking ) );
+    {
+        int prio_low = 0, prio_high = 0;
+        OPENCK( hipDeviceGetStreamPriorityRange( &prio_low, &prio_high ) );
+        OPENCK( hipStreamCreateWithPriority( &ctx->stream_up, hipStreamNonBlocking, prio_high ) );
+    }
+    for( int i = 0; i < x264hip_ctx::UP_EVS; i++ )
+        OPENCK( hipEventCreateWithFlags( &ctx->up_ev[i], hipEventDisableTiming ) );
     OPENCK( hipEventCreateWithFlags( &ctx->ev_cross, hipEventDisableTiming ) );
     OPENCK( hipEventCreateWithFlags( &ctx->ev_mbt_last, hipEventDisableTiming ) );
     OPENCK( hipEventCreateWithFlags( &ctx->ev_ingest, hipEventDisableTiming ) );
@@ -707,7 +747,7 @@ extern "C" int x264hip_frame_put_batch_yuv( x264hip_ctx *ctx, int n, const int *
             slot_reset( ctx, s );
             dh[i] = make_put_desc( ctx, s, luma_dev[o + i], stride, cb_dev ? cb_dev[o + i] : nullptr, cb_dev ? cr_dev[o + i] : nullptr, cstride, aq_on );
         }
-        HIPCK( upload_async( dd, dh, (size_t)m * sizeof( PutDesc ), ctx->stream ) );
+        HIPCK( upload_async( ctx, dd, dh, (size_t)m * sizeof( PutDesc ), ctx->stream ) );
         PutDesc none;
         memset( &none, 0, sizeof( none ) );
         int rc = p.bit_depth == 8 ? launch_ingest_t<uint8_t>( ctx, dd, none, m ) : launch_ingest_t<uint16_t>( ctx, dd, none, m );
@@ -882,7 +922,7 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         d.pad = 0;
         dh[i] = d;
     }
-    HIPCK( upload_async( dd, dh, (size_t)n * sizeof( SearchDesc<T> ), ctx->stream ) );
+    HIPCK( upload_async( ctx, dd, dh, (size_t)n * sizeof( SearchDesc<T> ), ctx->stream ) );
     // (the row tickets in sync_words are cleared by the last wave of the previous launch: me_search.h)
     hipEvent_t e0 = ctx->ev_start, e1 = ctx->ev_stop;
     if( ctx->prof_on )
@@ -1023,7 +1063,7 @@ static int launch_cells_t( x264hip_ctx *ctx, const std::vector<SpecCell> &cells 
             const SpecCell &c = *ord[i];
             dh[i] = make_cell<T>( ctx, c.slot_p0, c.slot_p1, c.slot_b, c.d0, c.d1, 1, c.ref1_valid, c.sums_only, c.to_spare );
         }
-        HIPCK( upload_async( dd, dh, (size_t)n * sizeof( CellArgs ), ctx->stream ) );
+        HIPCK( upload_async( ctx, dd, dh, (size_t)n * sizeof( CellArgs ), ctx->stream ) );
         CellArgs none;
         memset( &none, 0, sizeof( none ) );
         if( n_p )
@@ -1456,7 +1496,7 @@ static int mbt_flush( x264hip_ctx *ctx )
     HIPCK( hipStreamWaitEvent( ctx->stream2, ctx->ev_cross, 0 ) );
     // Measured (two segments in flight, 1080p): copying the step list to the device in front of the launch gives 8500 frames/s,
     // letting every workgroup pull it from pinned host memory into LDS 8070
-    HIPCK( upload_async( ctx->mbt_dev[r], ctx->mbt_host[r], (size_t)G.beg[G.n] * sizeof( MbtOpDev ), ctx->stream2 ) );
+    HIPCK( upload_async( ctx, ctx->mbt_dev[r], ctx->mbt_host[r], (size_t)G.beg[G.n] * sizeof( MbtOpDev ), ctx->stream2 ) );
     mbtree_kernel<<<G.n * mbt_wgs, mbt_threads, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], G, mbt_wgs, ctx->luts_dev,
                                                                     ctx->mbt_bar + (size_t)r * MBT_MAX_GROUPS * 4,
                                                                     ctx->mbt_bar + (size_t)x264hip_ctx::MBT_RING * MBT_MAX_GROUPS * 4 );
@@ -1729,7 +1769,7 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
                 HIPCK( hipFuncSetAttribute( (const void *)mbtree_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 ) );
                 attr_set = true;
             }
-            HIPCK( upload_async( ctx->mbt_dev[r], dh, L.size() * sizeof( MbtOpDev ), ctx->stream2 ) );
+            HIPCK( upload_async( ctx, ctx->mbt_dev[r], dh, L.size() * sizeof( MbtOpDev ), ctx->stream2 ) );
             mbtree_lds_kernel<<<1, 1024, (size_t)lds_slots * ctx->n_mb * sizeof( int ), ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], (int)L.size(), ctx->luts_dev );
             HIPCK( hipGetLastError() );
             done_in_lds = true;
@@ -1742,7 +1782,7 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
     MbtGroups G;
     memset( &G, 0, sizeof( G ) );
     G.n = 1; G.beg[1] = n;
-    HIPCK( upload_async( ctx->mbt_dev[r], dh, (size_t)n * sizeof( MbtOpDev ), ctx->stream2 ) );
+    HIPCK( upload_async( ctx, ctx->mbt_dev[r], dh, (size_t)n * sizeof( MbtOpDev ), ctx->stream2 ) );
     mbtree_kernel<<<mbt_wgs, mbt_threads, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], G, mbt_wgs, ctx->luts_dev, ctx->mbt_bar + (size_t)r * MBT_MAX_GROUPS * 4,
                                                             ctx->mbt_bar + (size_t)x264hip_ctx::MBT_RING * MBT_MAX_GROUPS * 4 );
     HIPCK( hipGetLastError() );
@@ -1904,7 +1944,7 @@ extern "C" int x264hip_prefetch_weight_costs( x264hip_ctx *ctx, int n, const int
         jh[m++] = make_wjob( ctx, e, f, r, make_wt( ctx, &w[i] ) );
     }
     if( !m ) return X264HIP_OK;
-    HIPCK( upload_async( jd, jh, (size_t)m * sizeof( WeightJob ), ctx->stream ) );
+    HIPCK( upload_async( ctx, jd, jh, (size_t)m * sizeof( WeightJob ), ctx->stream ) );
     const dim3 grid( ( ctx->n_mb + WCOST_BLOCKS_PER_WG - 1 ) / WCOST_BLOCKS_PER_WG, m, 1 );
     WeightJob none;
     memset( &none, 0, sizeof( none ) );
@@ -2186,7 +2226,7 @@ static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request 
     int n_pat = 0;
     for( int i = 0; i < n; i++ ) if( reqs[i].me_method < 3 ) idx[n_pat++] = i;
     for( int i = 0, k = n_pat; i < n; i++ ) if( reqs[i].me_method >= 3 ) idx[k++] = i;
-    MECK( upload_async( table_dev, table, b_tables, ctx->stream ) );
+    MECK( upload_async( ctx, table_dev, table, b_tables, ctx->stream ) );
     MECK( hipEventRecord( ctx->ev_start, ctx->stream ) );
     {
         // a wave per request: its 64 lanes run the search in lock step, block costs are computed across the wave (four samples per
@@ -3191,7 +3231,7 @@ extern "C" int x264hip_export_cells( x264hip_ctx *ctx, int n, const x264hip_cell
             if( !cell_ref_ok( ctx, cells[o + i] ) ) return X264HIP_EINVAL;
             xh[i] = make_xfer( ctx, cells[o + i] );
         }
-        HIPCK( upload_async( xd, xh, (size_t)m * sizeof( CellXfer ), ctx->stream ) );
+        HIPCK( upload_async( ctx, xd, xh, (size_t)m * sizeof( CellXfer ), ctx->stream ) );
         export_cells_kernel<<<m, 64, 0, ctx->stream>>>( xd, ctx->P.mb_h, (int *)dst_dev + (size_t)o * per );
         HIPCK( hipGetLastError() );
         if( ring_commit( ctx->xfer_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
@@ -3234,7 +3274,7 @@ extern "C" int x264hip_import_cells( x264hip_ctx *ctx, int n, const x264hip_cell
             e.map_remote = 1; e.slot_p0 = c.slot_p0; e.slot_p1 = c.slot_p1;
             taken++;
         }
-        HIPCK( upload_async( xd, xh, (size_t)m * sizeof( CellXfer ), ctx->stream ) );
+        HIPCK( upload_async( ctx, xd, xh, (size_t)m * sizeof( CellXfer ), ctx->stream ) );
         import_cells_kernel<<<m, 64, 0, ctx->stream>>>( xd, ctx->P.mb_h, (const int *)src_dev + (size_t)o * per );
         HIPCK( hipGetLastError() );
         if( ring_commit( ctx->xfer_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
