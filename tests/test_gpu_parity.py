@@ -231,6 +231,73 @@ def test_mbtree_steps_match_oracle():
         ctx.close()
 
 
+def test_mbtree_queued_and_immediate_lists_interleave():
+    """x264hip_mbtree queues step lists that clear every accumulator they read and runs them side by side on accumulator banks of
+    their own; lists that continue from what an earlier list left run at once on the frames' own accumulators.  A caller must not be
+    able to tell: two queued lists (the second lands in bank 1), then a list that adds to the accumulators without clearing them,
+    every accumulator and offset map against the oracle applied in the caller's order."""
+    import ctypes as C
+    frames = clip("fastpan", 176, 144, 3)
+    o, cfg, ctx = _mk(*CONFIGS["hex_r4"], 176, 144)
+    try:
+        n = cfg.mb_w * cfg.mb_h
+        planes, inv, intra, qp_aq = [], [], [], []
+        for i in range(3):
+            ctx.frame_put(i, frames[i])
+            planes.append(o.lowres_init(cfg, frames[i]))
+            iq, qp, _, _ = o.aq_frame(frames[i], cfg.mb_w, cfg.mb_h, 1, 1.0)
+            inv.append(iq); qp_aq.append(qp); intra.append(o.intra_costs(cfg, planes[i]))
+        ctx.frame_cost(0, 2, 2, 2, 0, (1, 0), None, True, False)
+        ctx.frame_cost(0, 2, 1, 1, 1, (1, 1), None, True, True)
+        f20 = o.search_field(cfg, planes[2], planes[0])
+        f10 = o.search_field(cfg, planes[1], planes[0]); f11 = o.search_field(cfg, planes[1], planes[2])
+        lcP = o.cell(cfg, planes[2], planes[0], None, 128, f20[0], f20[1], None, None, None, intra[2], inv[2], True)[0]
+        lcB = o.cell(cfg, planes[1], planes[0], planes[2], 128, f10[0], f10[1], f11[0], f11[1], f20[0], intra[1], inv[1], True)[0]
+        L = o.lib
+        L.or_mbtree_propagate.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_float]
+        L.or_mbtree_finish.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_float, C.c_float]
+        prop = [np.zeros(n, np.uint16) for _ in range(3)]
+        qp_now = [q.copy() for q in qp_aq]
+
+        def oracle_b(fps):
+            L.or_mbtree_propagate(cfg.mb_w, cfg.mb_h, intra[1].ctypes.data, lcB.ctypes.data, inv[1].ctypes.data, None,
+                                  f10[0].ctypes.data, f11[0].ctypes.data, prop[0].ctypes.data, prop[2].ctypes.data, 32, fps)
+
+        def oracle_p(fps):
+            pin = prop[2].copy()
+            L.or_mbtree_propagate(cfg.mb_w, cfg.mb_h, intra[2].ctypes.data, lcP.ctypes.data, inv[2].ctypes.data, pin.ctypes.data,
+                                  f20[0].ctypes.data, None, prop[0].ctypes.data, None, 32, fps)
+
+        def oracle_finish(i, strength):
+            L.or_mbtree_finish(n, intra[i].ctypes.data, inv[i].ctypes.data, prop[i].ctypes.data, qp_aq[i].ctypes.data, qp_now[i].ctypes.data, 512, 0.0, strength)
+
+        def zero(i): return lib.MbtreeOp(0, i, i, i, 0, 0, 0, 0, 0.0, 0, 0.0, 0.0)
+        def prop_b(fps): return lib.MbtreeOp(1, 1, 0, 2, 1, 1, 0, 32, fps, 0, 0.0, 0.0)
+        def prop_p(fps): return lib.MbtreeOp(1, 2, 0, 2, 2, 0, 1, 32, fps, 0, 0.0, 0.0)
+        def finish(i, strength): return lib.MbtreeOp(2, i, i, i, 0, 0, 0, 0, 0.0, 512, 0.0, strength)
+        fps1 = np.float32(0.04 / (0.04 * 256.0) * 0.5); fps2 = np.float32(fps1 * 0.5)
+        # list 1 (queued, bank 0): finishes frame 0
+        ctx.mbtree([zero(2), zero(0), prop_b(fps1), prop_p(fps1), finish(0, 2.0)])
+        prop[0][:] = 0; prop[2][:] = 0; oracle_b(fps1); oracle_p(fps1); oracle_finish(0, 2.0)
+        # list 2 (queued beside it, bank 1): other factors, finishes frame 2
+        ctx.mbtree([zero(2), zero(0), prop_b(fps2), prop_p(fps2), finish(2, 1.5)])
+        prop[0][:] = 0; prop[2][:] = 0; oracle_b(fps2); oracle_p(fps2); oracle_finish(2, 1.5)
+        # list 3 continues from there (clears nothing): runs at once, behind the queue, on what list 2 left
+        ctx.mbtree([prop_p(fps1), finish(0, 1.0)])
+        oracle_p(fps1); oracle_finish(0, 1.0)
+        for i in (0, 2):
+            assert np.array_equal(ctx.propagate_cost(i), prop[i]), ("i_propagate_cost", i)
+            assert np.array_equal(ctx.qp_offsets(i), qp_now[i]), ("f_qp_offset", i)
+        # and a queued list after the immediate one: the accumulators it clears are the frames' own again
+        ctx.mbtree([zero(2), zero(0), prop_b(fps2), prop_p(fps1), finish(0, 2.0)])
+        prop[0][:] = 0; prop[2][:] = 0; oracle_b(fps2); oracle_p(fps1); oracle_finish(0, 2.0)
+        for i in (0, 2):
+            assert np.array_equal(ctx.propagate_cost(i), prop[i]), ("i_propagate_cost after the last list", i)
+        assert np.array_equal(ctx.qp_offsets(0), qp_now[0])
+    finally:
+        ctx.close()
+
+
 def test_frame_cost_recalculate():
     """x264hip_frame_cost_recalculate (slicetype_frame_cost_recalculate, slicetype.c:999-1024) against the oracle on the
     device's own maps: a P cell under f_qp_offset, a B cell under f_qp_offset_aq, and the I cell after an MB-tree finish."""
