@@ -281,7 +281,7 @@ class Workload:
         summaries, outs = [], None
         for k in range(n_steps):
             la.reset()
-            outs = la.run(device_ptrs=self.seg_ptrs[sgi], stride=self.W, paced=paced)
+            outs = la.run_frames(self.seg_ptrs[sgi], stride=self.W, paced=paced)  # one C call per pass (x264hip_lookahead_run_frames)
             assert len(outs) == self.F
             summaries.append(self.shard.summarize(outs, (self.rank * self.S + sgi) * self.F))
         return outs, summaries

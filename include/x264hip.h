@@ -554,6 +554,11 @@ int  x264hip_lookahead_delay( x264hip_lookahead *la );       /* h->frames.i_dela
 int  x264hip_lookahead_put_frame( x264hip_lookahead *la, const void *luma, int stride, int is_device, int forced_type );
 /* n device-resident frames at once (display order, all X264_TYPE_AUTO): batched ingest when the backend supports it */
 int  x264hip_lookahead_put_frames( x264hip_lookahead *la, int n, const void *const *luma_dev, int stride );
+/* a whole clip of device-resident frames in one call: n frames put and every decided frame taken (out[n], coded order; *n_out of them),
+ * paced != 0: one put and one get per frame like x264_encoder_encode (encoder/encoder.c:3300-3440), then the flush; else all frames
+ * put first.  Equivalent to the put_frame(s) / get_frame calls it makes. */
+int  x264hip_lookahead_run_frames( x264hip_lookahead *la, int n, const void *const *luma_dev, int stride, int paced, x264hip_la_frame *out,
+                                   int *n_out );
 /* batch form of x264hip_lookahead_put_picture for device-resident 4:2:0 pictures: cb_dev / cr_dev NULL = luma only; types (forced
  * picture types) and pts may be NULL (AUTO / the frame numbers) */
 int  x264hip_lookahead_put_pictures( x264hip_lookahead *la, int n, const void *const *luma_dev, int stride, const void *const *cb_dev,

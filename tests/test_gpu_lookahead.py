@@ -141,6 +141,29 @@ def test_batch_ingest_device_pointers():
         assert np.array_equal(a.qp_offset, b.qp_offset)
 
 
+@pytest.mark.parametrize("paced", [False, True])
+def test_run_frames_is_the_put_get_sequence(paced):
+    """x264hip_lookahead_run_frames (a whole clip of device-resident frames in one call) against the put / get calls it stands for."""
+    import torch
+    W, H, nf = 352, 288, 40
+    frames = make_clip(W, H, nf, seed=5, scene_cuts=(21,))
+    cfg = lib.la_config(W, H, "medium")
+    dev = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    ptrs = [dev[i].data_ptr() for i in range(nf)]
+    res = []
+    for one_call in (False, True):
+        la = lib.Lookahead(cfg, max_frames=nf + 4)
+        try:
+            res.append(la.run_frames(ptrs, stride=W, paced=paced) if one_call else la.run(device_ptrs=ptrs, stride=W, paced=paced))
+        finally:
+            la.close()
+    assert len(res[1]) == nf and _types(res[0]) == _types(res[1])
+    nb = cfg["bframes"] + 2
+    for a, b in zip(_mats(res[0], nb), _mats(res[1], nb)):
+        assert np.array_equal(a, b)
+
+
 def _shard_worker(rank, world, port, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

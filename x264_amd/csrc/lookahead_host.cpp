@@ -1276,6 +1276,41 @@ extern "C" int x264hip_lookahead_put_frames( x264hip_lookahead *la, int n, const
     return x264hip_lookahead_put_pictures( la, n, luma_dev, stride, nullptr, nullptr, 0, nullptr, nullptr );
 }
 
+// A whole clip of device-resident frames through the lookahead in one call: every frame put, every decided frame taken, in the order
+// x264_encoder_encode would (paced: one put, one get per frame, then the flush; otherwise all frames put first -- deep read-ahead).
+// The same sequence of x264hip_lookahead_put_frame(s) / x264hip_lookahead_get_frame calls a caller would make, without a trip through
+// the caller's language per frame.
+extern "C" int x264hip_lookahead_run_frames( x264hip_lookahead *la, int n, const void *const *luma_dev, int stride, int paced, x264hip_la_frame *out,
+                                             int *n_out )
+{
+    if( !la || n <= 0 || !luma_dev || !out || !n_out ) return X264HIP_EINVAL;
+    int got = 0, m = 0, rc = X264HIP_OK;
+    *n_out = 0;
+    if( !paced )
+    {
+        rc = x264hip_lookahead_put_frames( la, n, luma_dev, stride );
+        if( rc ) return rc;
+    }
+    else
+        for( int i = 0; i < n; i++ )
+        {
+            rc = x264hip_lookahead_put_frame( la, luma_dev[i], stride, 1, 0 );
+            if( rc ) return rc;
+            rc = x264hip_lookahead_get_frame_ex( la, 0, out + m, &got, nullptr );
+            if( rc ) return rc;
+            m += got;
+        }
+    while( m < n )
+    {
+        rc = x264hip_lookahead_get_frame_ex( la, 1, out + m, &got, nullptr );
+        if( rc ) return rc;
+        if( !got ) break;
+        m++;
+    }
+    *n_out = m;
+    return X264HIP_OK;
+}
+
 extern "C" int x264hip_lookahead_put_pictures( x264hip_lookahead *la, int n, const void *const *luma_dev, int stride, const void *const *cb_dev,
                                                const void *const *cr_dev, int cstride, const int *types, const int64_t *pts )
 {

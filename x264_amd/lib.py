@@ -802,6 +802,15 @@ class Lookahead:
         _ck(self.L.x264hip_lookahead_stats(self.h, _p(out), 8), "lookahead_stats")
         return out
 
+    def run_frames(self, device_ptrs, stride=None, paced=True):
+        """run() for device-resident luma frames with nothing but types and costs asked for, as ONE call (x264hip_lookahead_run_frames)"""
+        n = len(device_ptrs)
+        arr = (C.c_void_p * n)(*device_ptrs)
+        outs = (LaFrameOut * n)()
+        got = C.c_int(0)
+        _ck(self.L.x264hip_lookahead_run_frames(self.h, n, arr, stride or self.cfg["width"], int(paced), outs, C.byref(got)), "lookahead_run_frames")
+        return [outs[i] for i in range(got.value)]
+
     def run(self, frames=None, device_ptrs=None, stride=None, paced=True, qp_offsets=False, forced_types=None, vbv=False, pts=None, chroma=None, quant_offsets=None):
         """Feed a whole clip.  paced=True interleaves put/get exactly like x264_encoder_encode; paced=False puts
         every frame first (deep prefetch) -- results are identical, only the batching differs."""
