@@ -110,6 +110,11 @@ void x264hip_close( x264hip_ctx *ctx );
 const char *x264hip_strerror( int code );
 int  x264hip_device_name( x264hip_ctx *ctx, char *buf, size_t cap );
 int  x264hip_synchronize( x264hip_ctx *ctx );  /* x264_opencl_flush (encoder/slicetype-cl.c:58-80) */
+/* Hands everything the context has queued on the host to the device without waiting for it: x264hip_mbtree keeps the step lists of
+ * consecutive macroblock_tree() calls back so that one launch runs several of them side by side; every call that reads what they
+ * write flushes them itself, this entry is for a caller that will not make such a call (end of a stream whose quantiser offsets
+ * nobody fetches). */
+int  x264hip_flush( x264hip_ctx *ctx );
 
 /* ---- frame ingest ----------------------------------------------------------------------------
  * Replaces, per input frame: x264_adaptive_quant_frame (encoder/ratecontrol.c:304-415, aq-mode 0/1),
@@ -514,6 +519,9 @@ typedef struct x264hip_backend
     int (*frame_put_batch_yuv)( void *user, int n, const int *slots, const void *const *luma_dev, int stride, const void *const *cb_dev,
                                 const void *const *cr_dev, int cstride ); /* may be NULL: the pictures go in one by one */
     int (*gop_hint)( void *user, int anchor_frame, int period ); /* contract of x264hip_gop_hint, called in front of prefetch; may be NULL */
+    /* contract of x264hip_flush: called when the last delayed frame of a flush has been handed out, so that no work the lookahead
+     * asked for stays queued in the backend behind the end of the stream; may be NULL */
+    int (*flush)( void *user );
 } x264hip_backend;
 
 typedef struct x264hip_la_frame

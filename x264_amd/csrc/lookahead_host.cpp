@@ -1100,6 +1100,7 @@ static int dev_put_batch( void *u, int n, const int *slots, const void *const *l
     return x264hip_frame_put_batch( (x264hip_ctx *)u, n, slots, luma, stride );
 }
 static int dev_gop_hint( void *u, int anchor, int period ) { return x264hip_gop_hint( (x264hip_ctx *)u, anchor, period ); }
+static int dev_flush( void *u ) { return x264hip_flush( (x264hip_ctx *)u ); }
 static int dev_prefetch_weights( void *u, int n, const int *sf, const int *sr, const x264hip_weight *w )
 {
     return x264hip_prefetch_weight_costs( (x264hip_ctx *)u, n, sf, sr, w );
@@ -1181,7 +1182,7 @@ extern "C" int x264hip_lookahead_open( x264hip_lookahead **out, int device, cons
     x264hip_ctx *ctx = nullptr;
     int rc = x264hip_open( &ctx, device, &p.dev );
     if( rc ) return rc;
-    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch, dev_mbtree, dev_qp_offsets, dev_put_batch, dev_prefetch_weights, dev_recalc, dev_row_satds, dev_frame_put_yuv, dev_add_quant_offsets, dev_put_batch_yuv, dev_gop_hint };
+    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch, dev_mbtree, dev_qp_offsets, dev_put_batch, dev_prefetch_weights, dev_recalc, dev_row_satds, dev_frame_put_yuv, dev_add_quant_offsets, dev_put_batch_yuv, dev_gop_hint, dev_flush };
     rc = x264hip_lookahead_open_backend( out, &p, &be );
     if( rc ) { x264hip_close( ctx ); return rc; }
     ( *out )->L.ctx = ctx;
@@ -1452,6 +1453,9 @@ extern "C" int x264hip_lookahead_get_frame_vbv( x264hip_lookahead *la, int flush
         out->intra_mbs[i] = f->intra_mbs[i];
     }
     *got = 1;
+    // the last delayed frame of a flush: nothing the analysis asked the backend for may stay queued behind the end of the stream
+    if( flush && L.current.empty() && L.next.empty() && L.be.flush && L.need( L.be.flush( L.be.user ) ) )
+        return L.err;
     if( qp_offset && L.be.get_qp_offsets && ( L.p.mb_tree || L.p.dev.aq_mode ) ) // the arrays exist with AQ on (frame.c:217-226)
         if( L.need( L.be.get_qp_offsets( L.be.user, f->slot, qp_offset ) ) )
             return L.err;

@@ -573,6 +573,14 @@ extern "C" int x264hip_synchronize( x264hip_ctx *ctx )
     return X264HIP_OK;
 }
 
+extern "C" int x264hip_flush( x264hip_ctx *ctx )
+{
+    if( !ctx ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    return mbt_flush( ctx );
+}
+
 extern "C" int x264hip_geometry( x264hip_ctx *ctx, int *mb_w, int *mb_h, int *lowres_stride )
 {
     if( !ctx ) return X264HIP_EINVAL;

@@ -406,6 +406,7 @@ FRAME_PUT_YUV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int
 
 
 GOP_HINT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
+FLUSH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
 
 class Backend(C.Structure):
@@ -414,7 +415,7 @@ class Backend(C.Structure):
                 ("mbtree", MBTREE_FN), ("get_qp_offsets", QP_OFFSETS_FN), ("frame_put_batch", PUT_BATCH_FN),
                 ("prefetch_weight_costs", PREFETCH_WEIGHTS_FN), ("frame_cost_recalculate", RECALC_FN),
                 ("get_row_satds", ROW_SATDS_FN), ("frame_put_yuv", FRAME_PUT_YUV_FN),
-                ("add_quant_offsets", ADD_QOFFS_FN), ("frame_put_batch_yuv", PUT_BATCH_YUV_FN), ("gop_hint", GOP_HINT_FN)]
+                ("add_quant_offsets", ADD_QOFFS_FN), ("frame_put_batch_yuv", PUT_BATCH_YUV_FN), ("gop_hint", GOP_HINT_FN), ("flush", FLUSH_FN)]
 
 
 class Picture(C.Structure):
