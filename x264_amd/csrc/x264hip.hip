@@ -1476,15 +1476,19 @@ static int mbt_ring_acquire( x264hip_ctx *ctx, int *r_out )
 }
 
 // Workgroups per list.  The workgroups of a list wait for each other at its barriers, so all of them have to be resident together:
-// with 1024 threads and 80 registers a CU holds one, and MBT_MAX_GROUPS lists of every open context must fit the chip at once
-// (otherwise workgroups that spin at a barrier could keep the ones they wait for off the CUs).  Measured, 1080p, lists of ~80 steps:
-// one context 14 750 frames/s with 4 workgroups per list, 13 100 with 2, 10 200 with 1; eight contexts 21 900 / 21 800 / 20 800.
-static int mbt_wgs_per_list( x264hip_ctx *ctx )
+// with 1024 threads and 80 registers a CU holds one, and the lists of a launch of every open context must fit the chip at once
+// (otherwise workgroups that spin at a barrier could keep the ones they wait for off the CUs): a context's share of the CUs, divided
+// among the lists of the launch, and no more than leaves a thread four macroblocks per step (at least four workgroups).  Measured, 1080p, 16 lists of ~80 steps
+// per launch: one context 14 750 frames/s with 4 workgroups per list, 13 100 with 2, 10 200 with 1; eight contexts 21 900 / 21 800 /
+// 20 800.  Few lists of large pictures (BASELINE configs[4]: 8K, 12 frames per segment, one to three lists per launch) get up to 16.
+static int mbt_wgs_per_list( x264hip_ctx *ctx, int n_lists )
 {
     static const int forced = getenv( "X264HIP_MBT_WGS" ) ? std::max( 1, std::min( 64, atoi( getenv( "X264HIP_MBT_WGS" ) ) ) ) : 0;
     if( forced ) return forced;
     const int contexts = std::max( 1, g_open_contexts[ctx->device & 63].load() );
-    return std::max( 1, std::min( MBT_WGS, ctx->n_cu / ( MBT_MAX_GROUPS * contexts ) ) );
+    const int share = std::max( 1, ctx->n_cu / contexts );
+    const int by_work = std::max( 4, ( ctx->n_mb + 4095 ) / 4096 ); // 1080p 4, 4K 8, 8K 16
+    return std::max( 1, std::min( std::min( share / std::max( 1, n_lists ), by_work ), 16 ) );
 }
 
 // Launch the queued step lists: one kernel, every list on its own workgroups and accumulator bank.  Everything that reads what the
@@ -1498,7 +1502,7 @@ static int mbt_flush( x264hip_ctx *ctx )
     ctx->mbt_q.n = 0; ctx->mbt_q.beg[0] = 0; ctx->mbt_q_ring = -1;
     ctx->mbt_q_finished.clear();
     static const int mbt_threads = getenv( "X264HIP_MBT_THREADS" ) ? std::max( 64, std::min( 1024, atoi( getenv( "X264HIP_MBT_THREADS" ) ) & ~63 ) ) : MBT_THREADS;
-    const int mbt_wgs = mbt_wgs_per_list( ctx );
+    const int mbt_wgs = mbt_wgs_per_list( ctx, G.n );
     // inputs come from the main stream (cells, clamp kernels): order the MB-tree stream behind it
     HIPCK( hipEventRecord( ctx->ev_cross, ctx->stream ) );
     HIPCK( hipStreamWaitEvent( ctx->stream2, ctx->ev_cross, 0 ) );
@@ -1786,7 +1790,7 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
     if( n > 0 && !done_in_lds )
     {
     static const int mbt_threads = getenv( "X264HIP_MBT_THREADS" ) ? std::max( 64, std::min( 1024, atoi( getenv( "X264HIP_MBT_THREADS" ) ) & ~63 ) ) : MBT_THREADS;
-    const int mbt_wgs = mbt_wgs_per_list( ctx );
+    const int mbt_wgs = mbt_wgs_per_list( ctx, 1 );
     MbtGroups G;
     memset( &G, 0, sizeof( G ) );
     G.n = 1; G.beg[1] = n;
