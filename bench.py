@@ -575,11 +575,11 @@ def main():
                     res[key] = {"error": str(e)}
             # BASELINE configs[2]: 3840x2160, --preset slower --me umh --merange 32 (the lookahead searches with HEX, range 32, b-adapt 2, rc-lookahead 60)
             other_config("configs2_4k", "3840x2160 8-bit, --preset slower --me umh --merange 32 (BASELINE configs[2])",
-                         lib.la_config(3840, 2160, "slower", bit_depth=8, me="umh", me_range=32), 64, S, 2)
+                         lib.la_config(3840, 2160, "slower", bit_depth=8, me="umh", me_range=32), 64, S, 4)
             # BASELINE configs[4] on one GPU: 7680x4320 10-bit, --preset veryslow --me tesa (HEX with SATD full-pel costs, bframes 8, b-adapt 2,
             # rc-lookahead 60); a dozen frames per segment: the window never fills, every frame is decided at the flush
             other_config("configs4_8k_1gpu", "7680x4320 10-bit, --preset veryslow --me tesa (BASELINE configs[4], one GPU)",
-                         lib.la_config(7680, 4320, "veryslow", bit_depth=10, me="tesa"), 12, 4, 2, depth_x=10, cuts=(7,))
+                         lib.la_config(7680, 4320, "veryslow", bit_depth=10, me="tesa"), 12, 4, 6, depth_x=10, cuts=(7,))
             # BASELINE configs[3] on one GPU: one 250-frame 4K GOP, --bframes 8 --rc-lookahead 60, ONE stream (the N = 1 point of the window shard)
             try:
                 w1 = window_shard_bench(torch, lib, shard, None, 0, 1, dev_index, backend, steps=2, paced_check=True)
