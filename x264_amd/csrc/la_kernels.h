@@ -357,6 +357,9 @@ struct IntraEdges
     int left[8];  // p[-1,y]
     int ft[18];   // filtered: ft[i+1] = p'[i,-1], ft[0] = p'[-1,-1]
     int fl[8];    // filtered left p'[-1,y]
+    int e[28];    // the filtered edge as ONE line, bottom of the left column -> corner -> top row: e[7-i] = p'[-1,i], e[8] = p'[-1,-1],
+                  // e[9+i] = p'[i,-1] (i = 0..15).  A directional predictor is then three neighbouring entries whatever side of the
+                  // diagonal the pixel is on (the per-pixel case distinctions of predict.c:700-884 become index arithmetic)
 };
 
 __device__ __forceinline__ int f3( int a, int b, int c ) { return ( a + 2 * b + c + 2 ) >> 2; }
@@ -388,39 +391,33 @@ __device__ __forceinline__ int intra_pred_px( const IntraEdges &E, int mode, int
             int a = 16 * ( E.left[7] + E.top[8] ), b = ( 17 * H + 16 ) >> 5, c = ( 17 * V + 16 ) >> 5;
             return iclip3( ( a + b * ( x - 3 ) + c * ( y - 3 ) + 16 ) >> 5, 0, pixel_max );
         }
-        case 4: // diagonal down-left
-            return ( x == 7 && y == 7 ) ? ( TT( 14 ) + 3 * TT( 15 ) + 2 ) >> 2 : f3( TT( x + y ), TT( x + y + 1 ), TT( x + y + 2 ) );
+        case 4: // diagonal down-left: the last pixel's third tap repeats p'[15,-1], which is the reference's ( t14 + 3 t15 + 2 ) >> 2
+            return f3( E.e[9 + x + y], E.e[10 + x + y], E.e[9 + imin2( x + y + 2, 15 )] );
         case 5: // diagonal down-right
-            if( x > y ) return f3( TT( x - y - 2 ), TT( x - y - 1 ), TT( x - y ) );
-            if( x < y ) return f3( LL( y - x - 2 ), LL( y - x - 1 ), LL( y - x ) );
-            return f3( TT( 0 ), TT( -1 ), LL( 0 ) );
+            return f3( E.e[7 + x - y], E.e[8 + x - y], E.e[9 + x - y] );
         case 6: // vertical right
         {
-            int z = 2 * x - y, k = x - ( y >> 1 );
-            if( z >= 0 && !( z & 1 ) ) return f2( TT( k - 1 ), TT( k ) );
-            if( z >= 0 ) return f3( TT( k - 2 ), TT( k - 1 ), TT( k ) );
-            if( z == -1 ) return f3( LL( 0 ), TT( -1 ), TT( 0 ) );
-            return f3( LL( y - 2 * x - 1 ), LL( y - 2 * x - 2 ), LL( y - 2 * x - 3 ) );
+            const int z = 2 * x - y, base = z >= -1 ? 7 + x - ( y >> 1 ) : 8 + z;
+            const int e0 = E.e[base], e1 = E.e[base + 1], e2 = E.e[base + 2];
+            return ( z >= 0 && !( z & 1 ) ) ? f2( e1, e2 ) : f3( e0, e1, e2 );
         }
         case 7: // horizontal down
         {
-            int z = 2 * y - x, k = y - ( x >> 1 );
-            if( z >= 0 && !( z & 1 ) ) return f2( LL( k - 1 ), LL( k ) );
-            if( z >= 0 ) return f3( LL( k - 2 ), LL( k - 1 ), LL( k ) );
-            if( z == -1 ) return f3( LL( 0 ), TT( -1 ), TT( 0 ) );
-            return f3( TT( x - 2 * y - 1 ), TT( x - 2 * y - 2 ), TT( x - 2 * y - 3 ) );
+            const int z = 2 * y - x, base = z >= -1 ? 7 - y + ( x >> 1 ) : 6 - z;
+            const int e0 = E.e[base], e1 = E.e[base + 1], e2 = E.e[base + 2];
+            return ( z >= 0 && !( z & 1 ) ) ? f2( e0, e1 ) : f3( e0, e1, e2 );
         }
         case 8: // vertical left
         {
-            int k = x + ( y >> 1 );
-            return ( y & 1 ) ? f3( TT( k ), TT( k + 1 ), TT( k + 2 ) ) : f2( TT( k ), TT( k + 1 ) );
+            const int k = 9 + x + ( y >> 1 );
+            const int e0 = E.e[k], e1 = E.e[k + 1], e2 = E.e[k + 2];
+            return ( y & 1 ) ? f3( e0, e1, e2 ) : f2( e0, e1 );
         }
-        default: // 9: horizontal up
+        default: // 9: horizontal up: beyond the last left sample the edge repeats it (the reference's special cases for z >= 13)
         {
-            int z = x + 2 * y, k = y + ( x >> 1 );
-            if( z > 13 ) return E.fl[7];
-            if( z == 13 ) return ( E.fl[6] + 3 * E.fl[7] + 2 ) >> 2;
-            return ( z & 1 ) ? f3( E.fl[k], E.fl[k + 1], E.fl[k + 2] ) : f2( E.fl[k], E.fl[k + 1] );
+            const int k = y + ( x >> 1 );
+            const int e0 = E.e[7 - imin2( k, 7 )], e1 = E.e[7 - imin2( k + 1, 7 )], e2 = E.e[7 - imin2( k + 2, 7 )];
+            return ( ( x + 2 * y ) & 1 ) ? f3( e0, e1, e2 ) : f2( e0, e1 );
         }
     }
 #undef TT
@@ -468,11 +465,18 @@ __global__ __launch_bounds__( 64 ) void intra_kernel( LaP P, const PutDesc *desc
         {
             // ft[l] = p'[l-1,-1]: corner, t0..t15 (predict.c:632-675 with all neighbours available); lanes 0..8 also ft[16] / fl[0..7]
             const int i = l - 1;
-            E.ft[l] = i < 0 ? f3( E.top[1], E.top[0], E.left[0] ) : f3( E.top[i], E.top[i + 1], E.top[i + 2] );
+            const int ftl = i < 0 ? f3( E.top[1], E.top[0], E.left[0] ) : f3( E.top[i], E.top[i + 1], E.top[i + 2] );
+            E.ft[l] = ftl; E.e[8 + l] = ftl;
             if( l == 8 )
-                E.ft[16] = ( E.top[15] + 3 * E.top[16] + 2 ) >> 2;
+            {
+                const int v = ( E.top[15] + 3 * E.top[16] + 2 ) >> 2;
+                E.ft[16] = v; E.e[24] = v;
+            }
             else if( l < 8 )
-                E.fl[l] = l == 7 ? ( E.left[6] + 3 * E.left[7] + 2 ) >> 2 : f3( l == 0 ? E.top[0] : E.left[l - 1], E.left[l], E.left[l + 1] );
+            {
+                const int v = l == 7 ? ( E.left[6] + 3 * E.left[7] + 2 ) >> 2 : f3( l == 0 ? E.top[0] : E.left[l - 1], E.left[l], E.left[l + 1] );
+                E.fl[l] = v; E.e[7 - l] = v;
+            }
         }
         __syncthreads();
         int best = COST_MAX_I;
