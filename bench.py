@@ -405,6 +405,17 @@ def main():
     wl = Workload(torch, lib, shard, cfg, dev_index, rank, S, F, seg_dev, args.paced, dist, backend, world)
     las = wl.las
 
+    # bring the clocks up before anything is timed: a fresh process starts on an idle device and W may be small (half a second of
+    # device copies; no lookahead work, and outside the timed region like the warm-up steps themselves)
+    if not os.environ.get("X264HIP_BENCH_NO_PREHEAT"):
+        pa = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+        pb = torch.empty_like(pa)
+        t_end = time.perf_counter() + 0.5
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                pb.copy_(pa)
+            torch.cuda.synchronize()
+        del pa, pb
     wl.run_steps(args.warmup)
     wl.barrier()
     for la in las:
