@@ -1,0 +1,646 @@
+// me_team.h -- the lookahead motion search of whole frames on gfx950, searched out of LDS: a wave64 is a TEAM of up to eight searches
+// that read the SAME reference frame, one 8x8 block per 8-lane group, one block row (8 samples) per lane; the wave walks ONE block row
+// of the picture from right to left and keeps the reference window of that row -- the four half-pel planes, +-8 samples around the
+// block -- in wave-private LDS, filled one 8-column strip ahead by LDS-DMA (global_load_lds_dwordx4), so that the dependent rounds of a
+// block search (me_logic.h: load -> reduce -> choose, ~8 per block) are LDS round trips instead of L1 / L2 round trips.
+//
+// Behaviour follows the reference's slicetype_mb_cost search part (encoder/slicetype.c:654-709) over x264_me_search_ref
+// (encoder/me.c:182-420,774-798, DIA and HEX) + refine_subpel (me.c:865-992); the decision logic is me_logic.h, the candidate-set
+// evaluation across the lanes of a group is me_search.h's (LaneSlots, reduce_slots, min_slots).
+//
+// Work decomposition.  A search (source frame, reference frame, list, distance) is a W x H field of 8x8 blocks scanned from the
+// bottom right; block (x, y) takes its predictors from (x+1, y) and (x-1..x+1, y+1).  The searches of a launch are sorted by
+// reference frame and cut into teams of at most eight; wave (team, y) runs block row y of the team's searches in lock step: in step
+// t every group searches block x = W-1-t of ITS search, so the block position, the vector limits and the window are wave-uniform
+// (scalar) and one window serves eight searches.  Rows are claimed bottom-up through ticket counters; row y takes the vectors of row
+// y+1 from memory (self-validating 8-byte granules { mv, tag }, sc1 stores / L1-bypassing loads, one new granule per step and search,
+// requested a step ahead), so it trails the row below by two blocks plus one hand-off; the wave a row depends on always holds an
+// earlier ticket and is running or done: the waits cannot deadlock whatever the dispatch order.  W steps per wave.
+//
+// The window (WIN_*).  The reference's strip copy (strip_layout.h: strip k = columns 8k .. 8k+15 of every row, 16 samples per row)
+// is mirrored piece by piece: an LDS slot holds one strip column of the window -- rows Y0-8 .. Y0+16 of the NP planes, 16 samples
+// each, plane after plane -- and the window is the slots of strips k-1, k, k+1 (k = the block's own strip) in a ring of four indexed
+// by the strip number modulo 4; the fourth slot receives strip k-2 while block k is searched.  A slot is contiguous in the order the
+// DMA lanes write it (lane i -> byte 16 i), the lanes pick their source rows.  8 samples starting at ANY column of the window (and
+// the quarter-pel partner one column / one row further) lie inside one 16-sample row piece: a tap is read as the three (8-bit) / five
+// (16-bit) aligned dwords that cover it and shifted into place with v_alignbyte (unaligned wide DS reads are replayed at 64 cycles).
+// Candidates outside the window (|mv| > 8 full samples in x or y) take the whole set through the global strip copy instead
+// (compact loop, same arithmetic): results do not depend on the window.
+#pragma once
+#include "me_search.h"
+
+#define TEAM_MAX 8
+#define WIN_R 8
+#define WIN_ROWS ( 8 + 2 * WIN_R + 1 ) // block rows + reach above and below + the quarter-pel partner row
+#define WIN_RING 4
+#define TEAM_TAB_HALF 512
+
+struct TeamDesc
+{
+    int first, n; // searches [first, first + n) of the launch's descriptor table read one reference
+};
+
+template <typename T, int NP>
+struct WinGeo
+{
+    static constexpr int E = (int)sizeof( T );
+    static constexpr int ROWB = 16 * E;                      // bytes of one row piece
+    static constexpr int SLOTB = NP * WIN_ROWS * ROWB;       // bytes of one strip column of the window
+    static constexpr int BYTES = WIN_RING * SLOTB;
+    static constexpr int NCH = NP * WIN_ROWS * E;            // 16-byte chunks per slot
+    static constexpr int NI = ( NCH + 63 ) / 64;             // DMA instructions per slot
+};
+
+// one LDS-DMA instruction: lane i of the wave copies 16 bytes from sbase + voff (per lane) to LDS byte lds_dst + 16 i (M0 is the
+// destination base; it is compiler-reserved, so it is set and restored inside the statement).  hipcc does not count this load:
+// me_dma_drain() before the window is read.
+__device__ __forceinline__ void me_dma16( const void *sbase, unsigned voff, unsigned lds_dst )
+{
+    unsigned keep;
+    asm volatile( "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                  : "=&s"( keep )
+                  : "v"( voff ), "s"( sbase ), "s"( lds_dst )
+                  : "memory" );
+}
+// wait for every outstanding vector-memory operation, the DMA included
+__device__ __forceinline__ void me_dma_drain()
+{
+    asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+}
+
+// a pointer every lane agrees on, moved into scalar registers (the compiler cannot prove it for values loaded through a table)
+template <typename P>
+__device__ __forceinline__ P *uniform_ptr( P *p )
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane( (unsigned)v ), hi = __builtin_amdgcn_readfirstlane( (unsigned)( v >> 32 ) );
+    return (P *)( ( (unsigned long long)hi << 32 ) | lo );
+}
+__device__ __forceinline__ uint4 gload_u128( const void *ubase, unsigned byte_off )
+{
+    uint4 w;
+    __builtin_memcpy( &w, (const AS_GLOBAL char *)ubase + byte_off, 16 );
+    return w;
+}
+typedef __attribute__( ( address_space( 3 ) ) ) unsigned char lds_byte;
+__device__ __forceinline__ uint32_t lds_u32( const unsigned char *lds, int byte_off, int imm )
+{
+    return *(const uint32_t *)( lds + byte_off + imm );
+}
+// 8 samples starting at LDS byte address v (any alignment, inside one row piece) + rowb (a multiple of 16)
+__device__ __forceinline__ Px8 win_px8( const unsigned char *lds, int v, int rowb, const uint8_t * )
+{
+    const int a = ( v & ~3 ) + rowb;
+    const uint32_t w0 = lds_u32( lds, a, 0 ), w1 = lds_u32( lds, a, 4 ), w2 = lds_u32( lds, a, 8 );
+    const unsigned t = (unsigned)v & 3u;
+    Px8 r;
+    r.lo = px4_from_raw( __builtin_amdgcn_alignbyte( w1, w0, t ) );
+    r.hi = px4_from_raw( __builtin_amdgcn_alignbyte( w2, w1, t ) );
+    return r;
+}
+__device__ __forceinline__ Px8 win_px8( const unsigned char *lds, int v, int rowb, const uint16_t * )
+{
+    const int a = ( v & ~3 ) + rowb;
+    const uint32_t w0 = lds_u32( lds, a, 0 ), w1 = lds_u32( lds, a, 4 ), w2 = lds_u32( lds, a, 8 ), w3 = lds_u32( lds, a, 12 ), w4 = lds_u32( lds, a, 16 );
+    const unsigned t = (unsigned)v & 3u; // 0 or 2
+    Px8 r;
+    r.lo.a = __builtin_amdgcn_alignbyte( w1, w0, t ); r.lo.b = __builtin_amdgcn_alignbyte( w2, w1, t ); r.lo.raw = 0;
+    r.hi.a = __builtin_amdgcn_alignbyte( w3, w2, t ); r.hi.b = __builtin_amdgcn_alignbyte( w4, w3, t ); r.hi.raw = 0;
+    return r;
+}
+
+#define TEAM_BAD ( (int)0x80000000 )
+
+// The evaluator of me_logic.h on the team geometry: candidate sets across the 8 lanes of a group (me_search.h), samples out of the window.
+template <typename T, int LDS_TAB, int WEIGHTED>
+struct TeamEval
+{
+    static constexpr int NP = WEIGHTED ? 5 : 4;
+    typedef WinGeo<T, NP> G;
+    const unsigned char *win;  // the wave's window ring
+    const uint16_t *lds_tab;   // the wave's window of the mv cost table: entry TEAM_TAB_HALF + d is the cost of difference d
+    const T *sbase;            // wave-uniform: strips of the reference frame's four planes (unweighted)
+    const T *wsbase;           // group-uniform: strips read by full-pel candidates (weighted copy of plane 0, or sbase)
+    const uint16_t *tab;       // wave-uniform: first entry of the cost_mv table in memory
+    int plane_elems, strip_elems, pixel_max;
+    int fpelcmp_satd;
+    WtD wt;
+    int cx0, row16;            // wave-uniform: padded column of the block, strip-row offset of the block's row 0, at zero displacement
+    int tab_x, tab_y;
+    Px8 f;                     // this lane's 8 source pixels
+    LaneSlots S;
+    int rowb;                  // this lane's row of the block in window bytes
+
+    __device__ __forceinline__ int bits( int qx, int qy ) const
+    {
+        if( LDS_TAB )
+            return lds_tab[qx + tab_x] + lds_tab[qy + tab_y];
+        return gload_u16( tab, 2u * (unsigned)( qx + tab_x ) ) + gload_u16( tab, 2u * (unsigned)( qy + tab_y ) );
+    }
+    // LDS byte address of the sample of plane p at full-sample displacement (x, y) from the block's top left sample (row 0 of the block)
+    __device__ __forceinline__ int win_addr( int p, int x, int y ) const
+    {
+        const int c = cx0 + x;
+        return mad24( ( c >> 3 ) & ( WIN_RING - 1 ), G::SLOTB, mad24( mad24( p, WIN_ROWS, y + WIN_R ), G::ROWB, ( c & 7 ) * G::E ) );
+    }
+    static __device__ __forceinline__ bool in_window( int x, int y )
+    {
+        return (unsigned)( x + WIN_R ) <= 2u * WIN_R && (unsigned)( y + WIN_R ) <= 2u * WIN_R;
+    }
+    template <int N>
+    __device__ __forceinline__ int pack_min( int total, bool ok ) const
+    {
+        const int k = N <= 4 ? ( S.slot & 3 ) : S.slot;
+        return min_slots<N>( ok && k < N ? ( total << 3 ) | k : ME_PACK_MAX );
+    }
+    // total of the candidate in this lane's slot, candidates one after the other (the path of sets that leave the window; also the
+    // reference form of the unrolled paths): v = this lane's own candidate's offset(s) into the global strips
+    template <int N, int QPEL>
+    __device__ __forceinline__ int slow_totals( int oa, int ob, int use_satd ) const
+    {
+        const int myslot = N <= 4 ? ( S.slot & 3 ) : S.slot;
+        int total = 0;
+#pragma nounroll
+        for( int j = 0; j < N; j++ )
+        {
+            const int src = S.bp0 + 4 * ( j < 4 ? j : 11 - j );
+            const int ta = __builtin_amdgcn_ds_bpermute( src, oa );
+            Px8 r;
+            if( QPEL )
+            {
+                const int tb = __builtin_amdgcn_ds_bpermute( src, ob );
+                const Px8 a = load_px8_at( sbase, ta + S.row16 ), b = load_px8_at( sbase, tb + S.row16 );
+                r.lo = avg_px4( a.lo, b.lo, (const T *)nullptr ); r.hi = avg_px4( a.hi, b.hi, (const T *)nullptr );
+                if( WEIGHTED )
+                {
+                    r.lo = weight_px4<T>( r.lo, wt, pixel_max ); r.hi = weight_px4<T>( r.hi, wt, pixel_max );
+                }
+            }
+            else
+                r = load_px8_at( WEIGHTED ? wsbase : sbase, ta + S.row16 );
+            const int c = reduce8( block_partial8<T>( f, r, use_satd ) );
+            if( myslot == j )
+                total = c;
+        }
+        return total;
+    }
+    template <int N, class GEN>
+    __device__ __forceinline__ int fpel_set( GEN gen ) const
+    {
+        const int slot = N <= 4 ? ( S.slot & 3 ) : S.slot, k = imin2( slot, N - 1 );
+        int x = 0, y = 0;
+        bool ok = false, wb = true;
+        gen( k, x, y, ok, wb );
+        const int b = wb ? bits( 4 * x, 4 * y ) : 0;
+        const int v = in_window( x, y ) ? win_addr( WEIGHTED ? 4 : 0, x, y ) : TEAM_BAD;
+        int total;
+        int t[N];
+        t[0] = from_slot<0>( S, v );
+        if constexpr( N > 1 ) t[1] = from_slot<1>( S, v );
+        if constexpr( N > 2 ) t[2] = from_slot<2>( S, v );
+        if constexpr( N > 3 ) t[3] = from_slot<3>( S, v );
+        if constexpr( N > 4 ) t[4] = from_slot<4>( S, v );
+        if constexpr( N > 5 ) t[5] = from_slot<5>( S, v );
+        if constexpr( N > 6 ) t[6] = from_slot<6>( S, v );
+        if constexpr( N > 7 ) t[7] = from_slot<7>( S, v );
+        int any_bad = t[0];
+#pragma unroll
+        for( int j = 1; j < N; j++ )
+            any_bad |= t[j];
+        if( __builtin_amdgcn_ballot_w64( any_bad < 0 ) == 0ull )
+        {
+            Px8 r[N];
+#pragma unroll
+            for( int j = 0; j < N; j++ )
+                r[j] = win_px8( win, t[j], rowb, (const T *)nullptr );
+            int c[N];
+#pragma unroll
+            for( int j = 0; j < N; j++ )
+                c[j] = block_partial8<T>( f, r[j], fpelcmp_satd );
+            total = reduce_slots<N>( S, c );
+        }
+        else
+            total = slow_totals<N, 0>( strip_off( cx0 + x, row16 + ( y << 4 ), strip_elems ), 0, fpelcmp_satd );
+        if( fpelcmp_satd ) total >>= 1;
+        return pack_min<N>( total + b, ok );
+    }
+    template <int N, class GEN>
+    __device__ __forceinline__ int qpel_set( int use_satd, GEN gen, int &cost0 ) const
+    {
+        const int slot = N <= 4 ? ( S.slot & 3 ) : S.slot, k = imin2( slot, N - 1 );
+        int x = 0, y = 0;
+        bool ok = false, wb = true;
+        gen( k, x, y, ok, wb );
+        const int b = wb ? bits( x, y ) : 0;
+        // the two taps (strip_layout.h qpel_taps): plane pa at ( fx, fy + (fy == 3) ), plane pb at ( fx + (fx == 3), fy )
+        const int fx = x & 3, fy = y & 3, ix = x >> 2, iy = y >> 2;
+        const int sh = 2 * ( fx | ( fy << 2 ) );
+        const int pa = (int)( ( 0x54FE5454u >> sh ) & 3u ), pb = (int)( ( 0xBABABA10u >> sh ) & 3u );
+        const bool inw = in_window( ix, iy );
+        const int va = inw ? win_addr( pa, ix, iy + ( fy == 3 ) ) : TEAM_BAD;
+        const int vb = inw ? win_addr( pb, ix + ( fx == 3 ), iy ) : TEAM_BAD;
+        int ta[N], tb[N];
+        ta[0] = from_slot<0>( S, va ); tb[0] = from_slot<0>( S, vb );
+        if constexpr( N > 1 ) { ta[1] = from_slot<1>( S, va ); tb[1] = from_slot<1>( S, vb ); }
+        if constexpr( N > 2 ) { ta[2] = from_slot<2>( S, va ); tb[2] = from_slot<2>( S, vb ); }
+        if constexpr( N > 3 ) { ta[3] = from_slot<3>( S, va ); tb[3] = from_slot<3>( S, vb ); }
+        if constexpr( N > 4 ) { ta[4] = from_slot<4>( S, va ); tb[4] = from_slot<4>( S, vb ); }
+        if constexpr( N > 5 ) { ta[5] = from_slot<5>( S, va ); tb[5] = from_slot<5>( S, vb ); }
+        if constexpr( N > 6 ) { ta[6] = from_slot<6>( S, va ); tb[6] = from_slot<6>( S, vb ); }
+        if constexpr( N > 7 ) { ta[7] = from_slot<7>( S, va ); tb[7] = from_slot<7>( S, vb ); }
+        int any_bad = ta[0];
+#pragma unroll
+        for( int j = 1; j < N; j++ )
+            any_bad |= ta[j];
+        int total;
+        if( __builtin_amdgcn_ballot_w64( any_bad < 0 ) == 0ull )
+        {
+            int c[N];
+#pragma unroll
+            for( int j = 0; j < N; j++ )
+            {
+                // both taps of a full- or half-pel position are the same sample: one read (the branch is uniform inside the group)
+                const Px8 a = win_px8( win, ta[j], rowb, (const T *)nullptr );
+                Px8 bb = a;
+                if( tb[j] != ta[j] )
+                    bb = win_px8( win, tb[j], rowb, (const T *)nullptr );
+                Px8 r;
+                r.lo = avg_px4( a.lo, bb.lo, (const T *)nullptr ); r.hi = avg_px4( a.hi, bb.hi, (const T *)nullptr );
+                if( WEIGHTED )
+                {
+                    r.lo = weight_px4<T>( r.lo, wt, pixel_max ); r.hi = weight_px4<T>( r.hi, wt, pixel_max );
+                }
+                c[j] = block_partial8<T>( f, r, use_satd );
+            }
+            total = reduce_slots<N>( S, c );
+        }
+        else
+        {
+            int oa, ob;
+            strip_layout::qpel_taps( plane_elems, strip_off( cx0 + ix, row16 + ( iy << 4 ), strip_elems ), x, y, oa, ob );
+            total = slow_totals<N, 1>( oa, ob, use_satd );
+        }
+        if( use_satd ) total >>= 1;
+        total += b;
+        cost0 = from_slot<0>( S, total );
+        return pack_min<N>( total, ok );
+    }
+    __device__ __forceinline__ bool any( bool c ) const { return __builtin_amdgcn_ballot_w64( c ) != 0ull; }
+#ifdef ME_PROFILE
+    unsigned long long pf_last;
+    unsigned pf_phase[5];
+    __device__ __forceinline__ void mark( int k )
+    {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        if( k ) pf_phase[k] += (unsigned)( now - pf_last );
+        pf_last = now;
+    }
+#endif
+};
+
+// MODE / WEIGHTED as in me_rows_kernel (me_search.h).  Q.base[] counts TEAMS.
+template <typename T, int HEX, int MODE, int WEIGHTED>
+__global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_team_kernel( LaP P, const SearchDesc<T> *descs, const TeamDesc *teams, MeQueues Q,
+                                                                       unsigned *tickets /* [ME_QUEUES * ME_QUEUE_STRIDE] */, unsigned *err_host /* pinned sticky timeout flag */,
+                                                                       unsigned spin_limit, unsigned long long *prof /* ME_PROFILE builds: cycle accumulators, else unused */ )
+{
+    constexpr int NP = WEIGHTED ? 5 : 4;
+    typedef WinGeo<T, NP> G;
+    const int lane = lane_id();
+#ifdef ME_PROFILE
+    unsigned long long pf_wait = 0, pf_pre = 0, pf_search = 0, pf_store = 0, pf_spins = 0, pf_steps = 0;
+    unsigned long long pf_ph[5] = { 0, 0, 0, 0, 0 };
+    const unsigned long long pf_begin = __builtin_amdgcn_s_memtime();
+#define PF_NOW() __builtin_amdgcn_s_memtime()
+#endif
+    const int W = P.mb_w, H = P.mb_h;
+    // Every wave reports its exit on a second counter; the last one out clears the tickets for the next launch on this stream.
+    auto leave = [&]() {
+        if( lane == 0 && atomicAdd( &tickets[1], 1u ) == gridDim.x - 1 )
+        {
+            for( int q = 0; q < ME_QUEUES; q++ )
+                atomicExch( &tickets[q * ME_QUEUE_STRIDE], 0u );
+            atomicExch( &tickets[1], 0u );
+        }
+    };
+    const int home = xcc_id();
+    int j = 0, tm = -1;
+    for( int k = 0; k < ME_QUEUES && tm < 0; k++ )
+    {
+        const int q = ( home + k ) & ( ME_QUEUES - 1 );
+        const int n_q = Q.base[q + 1] - Q.base[q];
+        if( !n_q )
+            continue;
+        unsigned t0 = 0;
+        if( lane == 0 )
+            t0 = atomicAdd( &tickets[q * ME_QUEUE_STRIDE], 1u );
+        const unsigned t = __builtin_amdgcn_readfirstlane( t0 );
+        if( t < (unsigned)( n_q * H ) )
+        {
+            j = t / n_q;
+            tm = Q.base[q] + ( t - j * n_q );
+        }
+    }
+    if( tm < 0 )
+    {
+        leave();
+        return;
+    }
+    TeamDesc TD = teams[tm];
+    TD.first = __builtin_amdgcn_readfirstlane( TD.first ); TD.n = __builtin_amdgcn_readfirstlane( TD.n );
+    const int by = H - 1 - j; // this wave's block row (scalar)
+    const int g = lane >> 3;
+    const bool live = g < TD.n;
+    const SearchDesc<T> *dp = descs + TD.first + ( live ? g : 0 );
+    // per group: the search's own buffers; wave-uniform: the reference
+    const T *fbase = dp->fenc0;
+    AS_GLOBAL unsigned long long *mvq = (AS_GLOBAL unsigned long long *)dp->mvq;
+    AS_GLOBAL int *costs = (AS_GLOBAL int *)dp->costs;
+    const unsigned tag = dp->tag;
+    const WtD wt = descs[TD.first].wt;          // a team shares reference AND weight (x264hip.hip launch_searches_t)
+    const T *sbase = uniform_ptr( descs[TD.first].ref_strips );
+    const T *wsbase = WEIGHTED ? uniform_ptr( descs[TD.first].refw_strips ) : sbase;
+
+    __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char win[G::BYTES];
+    __shared__ uint16_t tab_window[2 * TEAM_TAB_HALF];
+    {
+        const int centre = 2 * 4 * P.mv_range; // P.cost_mv is centred: valid differences are -centre .. +centre
+        for( int i = lane; i < 2 * TEAM_TAB_HALF; i += 64 )
+        {
+            const int d = i - TEAM_TAB_HALF;
+            tab_window[i] = d >= -centre && d <= centre ? P.cost_mv[d] : (uint16_t)0;
+        }
+    }
+    MeCfg C;
+    C.hex = HEX; C.me_range = P.me_range;
+    C.refine4 = MODE == 3 ? P.subpel_refine >= 3 : MODE >= 1;
+    C.mbcmp_satd = MODE == 3 ? P.mbcmp_satd : MODE >= 1;
+    C.fpelcmp_satd = MODE == 3 ? P.fpelcmp_satd : MODE == 2;
+    const int strip_elems = ( P.plane_elems / P.stride ) * 16; // rows of the padded plane x 16 samples
+    const int tab_centre = 2 * 4 * P.mv_range;
+    // end row of the band this row belongs to (slicetype.c:917-918): rows of one band do not see the vectors of the band below
+    int band_end = H;
+    for( int sl = P.n_slices - 1; sl >= 1; sl-- )
+    {
+        const int start = ( H * sl + P.n_slices / 2 ) / P.n_slices;
+        if( by < start )
+            band_end = start;
+    }
+    const bool has_below = by < band_end - 1; // scalar
+    const int zero_bits = P.cost_mv[0];
+    const LaneSlots LS = make_lane_slots( lane );
+    const int rowb = ( lane & 7 ) * G::ROWB;
+
+    // ---- the window: DMA source offsets of this lane's chunks of a slot, relative to the strip's first row (bytes) ----
+    // chunk q = lane + 64 i of a slot: piece q / E (plane piece / WIN_ROWS, window row piece % WIN_ROWS), 16-byte half q % E
+    const unsigned win_lds = (unsigned)(size_t)(const lds_byte *)win;
+    unsigned goff[G::NI];
+    const int Yw0 = 8 * by + LA_PAD - WIN_R; // first padded row of the window
+#pragma unroll
+    for( int i = 0; i < G::NI; i++ )
+    {
+        const int q = lane + 64 * i, piece = q / G::E, half = q % G::E;
+        const int p = piece / WIN_ROWS, r = piece - p * WIN_ROWS;
+        // plane 4 (weighted builds) = the weighted copy of plane 0, which is a separate allocation: its offset is taken against wsbase
+        const long elem = ( p < 4 ? (long)p * 2 * P.plane_elems : 0 ) + (long)( Yw0 + r ) * 16 + half * 8;
+        goff[i] = (unsigned)( elem * G::E );
+    }
+    auto fill_slot = [&]( int ks ) { // strip ks of every plane -> slot ks & 3
+        const unsigned strip_byte = (unsigned)ks * (unsigned)strip_elems * G::E;
+        const unsigned dst = __builtin_amdgcn_readfirstlane( win_lds + ( ks & ( WIN_RING - 1 ) ) * G::SLOTB );
+#pragma unroll
+        for( int i = 0; i < G::NI; i++ )
+        {
+            const int q = lane + 64 * i;
+            if( q < G::NCH )
+            {
+                if( WEIGHTED && q >= 4 * WIN_ROWS * G::E )
+                    me_dma16( wsbase, goff[i] + strip_byte, dst + 1024 * i );
+                else
+                    me_dma16( sbase, goff[i] + strip_byte, dst + 1024 * i );
+            }
+        }
+    };
+    const int k_first = W - 1 + ( LA_PAD >> 3 );
+    fill_slot( k_first + 1 ); fill_slot( k_first ); fill_slot( k_first - 1 );
+
+    // ---- hand-off state: the vectors of the row below at x+1, x, x-1 (lane 8g of each group holds its search's) ----
+    const AS_GLOBAL unsigned long long *below_row = mvq + ( by + 1 ) * W;
+    auto granule = [&]( int x ) -> unsigned long long { // lane 8g: granule of block (x, by+1) of this group's search, L1-bypassing
+        unsigned long long gq = 0;
+        if( has_below && ( lane & 7 ) == 0 )
+            gq = __hip_atomic_load( below_row + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+        return gq;
+    };
+    auto granule_ok = [&]( unsigned long long gq ) -> bool { return ( lane & 7 ) != 0 || !live || (unsigned)( gq >> 32 ) == tag; };
+    bool timed_out = false;
+    // The granule requested a step ahead normally carries the tag already (the row below is two blocks ahead): the check is then
+    // the only cost.  Otherwise spin, reloading, until every live group's granule carries its tag.
+    auto granule_spin = [&]( int x ) -> unsigned long long {
+        unsigned spins = 0;
+        unsigned long long gq;
+        do
+        {
+            if( ++spins > spin_limit )
+            {
+                timed_out = true;
+                return 0ull;
+            }
+            __builtin_amdgcn_s_sleep( 4 );
+#ifdef ME_PROFILE
+            pf_spins++;
+#endif
+            gq = granule( x );
+        } while( !__all( granule_ok( gq ) ) );
+        return gq;
+    };
+    // every lane of the group gets lane 8g's vector
+    auto granule_mv = [&]( unsigned long long gq ) -> int { return __builtin_amdgcn_ds_bpermute( ( lane & ~7 ) << 2, (int)(unsigned)gq ); };
+    int below_right = 0, below = 0, below_left = 0;
+    unsigned long long g_next = 0;
+    if( has_below )
+    {
+        unsigned long long gq = granule( W - 1 );
+        if( !__all( granule_ok( gq ) ) )
+            gq = granule_spin( W - 1 );
+        below = granule_mv( gq );
+        g_next = granule( imax2( W - 2, 0 ) );
+    }
+    if( timed_out )
+    {
+        if( lane == 0 )
+            __hip_atomic_store( err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+        me_dma_drain();
+        leave();
+        return;
+    }
+    // this lane's source row of block x (strip copy of the source frame: 8 rows of a block are 128 consecutive samples)
+    const int frow16 = ( 8 * by + LA_PAD ) << 4;
+    // (requested a block ahead and kept as loaded: unpacking it would wait for the load)
+    auto source_raw = [&]( int x ) -> uint4 {
+        const int o = strip_off( 8 * x + LA_PAD, frow16 + LS.row16, strip_elems );
+        uint4 w = { 0, 0, 0, 0 };
+        if( sizeof( T ) == 1 ) { const uint2 h = gload_u64( fbase, (unsigned)o ); w.x = h.x; w.y = h.y; }
+        else w = gload_u128( fbase, 2u * (unsigned)o );
+        return w;
+    };
+    auto source_px8 = [&]( const uint4 &w ) -> Px8 {
+        Px8 r;
+        if( sizeof( T ) == 1 ) { r.lo = px4_from_raw( w.x ); r.hi = px4_from_raw( w.y ); }
+        else { r.lo.a = w.x; r.lo.b = w.y; r.lo.raw = 0; r.hi.a = w.z; r.hi.b = w.w; r.hi.raw = 0; }
+        return r;
+    };
+    uint4 f_next = source_raw( W - 1 );
+    __syncthreads(); // one wave per workgroup: orders the cost table writes before the first block's reads
+
+    int r1 = 0;                     // packed vector of the block to the right (this group's previous result)
+    int keep_cost = 0;              // lanes 0..3 of a group: the cost of the block with x % 4 == lane, until the four leave together
+    for( int bx = W - 1; bx >= 0; bx-- )
+    {
+#ifdef ME_PROFILE
+        const unsigned long long pf_t0 = PF_NOW();
+#endif
+        // Everything the last step requested has landed (the strip of the window, the source block, the granule) and everything it
+        // stored is acknowledged: all of it went out at the START of that step, a whole block search ago.
+        me_dma_drain();
+        const int k = bx + ( LA_PAD >> 3 );
+        // What this step consumes of the last step's requests first.  hipcc does not see the DMA instructions, so every s_waitcnt vmcnt(n)
+        // it places after them is two operations too strict and would wait for the window: the values are pinned here (the empty asm
+        // statements make them "used"), before the new requests go out, and the DMA goes out last.
+        Px8 f = source_px8( f_next );
+        asm volatile( "" : "+v"( f.lo.raw ), "+v"( f.hi.raw ), "+v"( f.lo.a ), "+v"( f.lo.b ), "+v"( f.hi.a ), "+v"( f.hi.b ) );
+        if( has_below && bx > 0 )
+        {
+            unsigned long long gq = g_next;
+            if( !__all( granule_ok( gq ) ) )
+                gq = granule_spin( bx - 1 );
+            below_left = granule_mv( gq );
+            asm volatile( "" : "+v"( below_left ) );
+        }
+        if( timed_out )
+            break;
+        // Then everything this step sends to memory, in one go: the vector of the block just searched (sc1: the row above is waiting for
+        // it), the costs of the four blocks to the right when they are complete (lane j < 4 of the group keeps the block with
+        // x % 4 == j; four neighbouring costs are one 16-byte store), and the requests for the next step: the source block, the granule,
+        // the strip the window moves onto.  Nothing else touches memory until the next step's wait, which therefore never waits for
+        // anything younger than a block search.
+        if( bx + 1 < W && live && ( lane & 7 ) == 0 )
+            __hip_atomic_store( mvq + by * W + bx + 1, ( (unsigned long long)tag << 32 ) | (unsigned)r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+        if( !( ( bx + 1 ) & 3 ) && bx + 1 < W && live && ( lane & 7 ) < 4 && bx + 1 + ( lane & 7 ) < W )
+            costs[by * W + bx + 1 + ( lane & 7 )] = keep_cost;
+        f_next = source_raw( imax2( bx - 1, 0 ) );
+        g_next = granule( imax2( bx - 2, 0 ) );
+        if( bx > 0 )
+            fill_slot( k - 2 );
+#ifdef ME_PROFILE
+        const unsigned long long pf_t1 = PF_NOW();
+        unsigned long long pf_t2 = pf_t1, pf_t3 = pf_t1;
+#endif
+        int mvx = 0, mvy = 0, cost = 0;
+        if( live && la_visited( P, bx, by ) )
+        {
+            MeLim L;
+            melogic::block_limits( L, bx, by, W, H, P.mv_range );
+            int mvcx[4], mvcy[4];
+            const int n = melogic::neighbour_list( bx, W, has_below, r1, below, below_left, below_right, mvcx, mvcy );
+            int mvpx, mvpy;
+            if( n <= 1 ) { mvpx = mvcx[0]; mvpy = mvcy[0]; }
+            else
+            {
+                mvpx = melogic::median3( mvcx[0], mvcx[1], mvcx[2] );
+                mvpy = melogic::median3( mvcy[0], mvcy[1], mvcy[2] );
+            }
+            const int cx0 = 8 * bx + LA_PAD, row16 = frow16;
+            bool done = false;
+            if( !( mvpx | mvpy ) )
+            {
+                // near-zero residual shortcut on the unweighted plane (slicetype.c:684-692): plane 0 at zero displacement
+                const int v0 = mad24( k & ( WIN_RING - 1 ), G::SLOTB, WIN_R * G::ROWB );
+                const Px8 r = win_px8( win, v0, rowb, (const T *)nullptr );
+                cost = block_cost8<T>( f, r, C.mbcmp_satd );
+                done = cost < 64;
+            }
+#ifdef ME_PROFILE
+            pf_t2 = PF_NOW();
+#endif
+            if( !done )
+            {
+                // how far from the predictor can a candidate of this block be?  (the cost table window)
+                int reach = imax2( iabs( mvpx ), iabs( mvpy ) );
+#pragma unroll
+                for( int i = 0; i < 4; i++ )
+                    if( i < n )
+                        reach = imax2( reach, imax2( iabs( mvcx[i] - mvpx ), iabs( mvcy[i] - mvpy ) ) );
+                reach = imax2( reach, imax2( iabs( iclip3( mvpx, 4 * L.fmin_x, 4 * L.fmax_x ) - mvpx ), iabs( iclip3( mvpy, 4 * L.fmin_y, 4 * L.fmax_y ) - mvpy ) ) );
+                reach = imax2( reach, imax2( iabs( iclip3( mvpx, L.smin_x + 2, L.smax_x - 2 ) - mvpx ), iabs( iclip3( mvpy, L.smin_y + 2, L.smax_y - 2 ) - mvpy ) ) );
+                const bool far = reach + 4 * ( P.me_range + 4 ) >= TEAM_TAB_HALF;
+                if( __builtin_amdgcn_ballot_w64( far ) == 0ull )
+                {
+                    TeamEval<T, 1, WEIGHTED> ev;
+                    ev.win = win; ev.lds_tab = tab_window; ev.sbase = sbase; ev.wsbase = wsbase; ev.tab = nullptr; ev.plane_elems = P.plane_elems;
+                    ev.strip_elems = strip_elems; ev.pixel_max = P.pixel_max; ev.fpelcmp_satd = C.fpelcmp_satd; ev.wt = wt;
+                    ev.cx0 = cx0; ev.row16 = row16; ev.f = f; ev.S = LS; ev.rowb = rowb;
+                    ev.tab_x = TEAM_TAB_HALF - mvpx; ev.tab_y = TEAM_TAB_HALF - mvpy;
+#ifdef ME_PROFILE
+                    for( int i = 0; i < 5; i++ ) ev.pf_phase[i] = 0;
+#endif
+                    melogic::search( C, L, ev, mvpx, mvpy, n, mvcx, mvcy, mvx, mvy, cost );
+#ifdef ME_PROFILE
+                    for( int i = 1; i < 5; i++ ) pf_ph[i] += ev.pf_phase[i];
+#endif
+                }
+                else
+                {
+                    TeamEval<T, 0, WEIGHTED> ev;
+                    ev.win = win; ev.lds_tab = nullptr; ev.sbase = sbase; ev.wsbase = wsbase; ev.tab = P.cost_mv - tab_centre; ev.plane_elems = P.plane_elems;
+                    ev.strip_elems = strip_elems; ev.pixel_max = P.pixel_max; ev.fpelcmp_satd = C.fpelcmp_satd; ev.wt = wt;
+                    ev.cx0 = cx0; ev.row16 = row16; ev.f = f; ev.S = LS; ev.rowb = rowb;
+                    ev.tab_x = tab_centre - mvpx; ev.tab_y = tab_centre - mvpy;
+#ifdef ME_PROFILE
+                    for( int i = 0; i < 5; i++ ) ev.pf_phase[i] = 0;
+#endif
+                    melogic::search( C, L, ev, mvpx, mvpy, n, mvcx, mvcy, mvx, mvy, cost );
+                }
+                cost -= zero_bits;
+                if( mvx | mvy )
+                    cost += 5 * P.lambda;
+            }
+        }
+#ifdef ME_PROFILE
+        pf_t3 = PF_NOW();
+#endif
+        // blocks slicetype_slice_cost never visits (slicetype.c:823-833) keep zero vectors (frame.c:283-285); the vector leaves at the
+        // start of the next step
+        const int packed = ( mvx & 0xFFFF ) | ( mvy << 16 );
+        if( ( lane & 7 ) == ( bx & 3 ) )
+            keep_cost = cost;
+        r1 = packed;
+        below_right = below; below = below_left;
+#ifdef ME_PROFILE
+        {
+            const unsigned long long pf_t4 = PF_NOW();
+            const unsigned long long a2 = __builtin_amdgcn_readfirstlane( (unsigned)( pf_t2 - pf_t1 ) ), a3 = __builtin_amdgcn_readfirstlane( (unsigned)( pf_t3 - pf_t2 ) );
+            pf_wait += pf_t1 - pf_t0; pf_pre += a2; pf_search += a3; pf_store += pf_t4 - pf_t1 - a2 - a3; pf_steps++;
+        }
+#endif
+    }
+    if( timed_out && lane == 0 )
+        __hip_atomic_store( err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+    if( !timed_out && live )
+    {
+        if( ( lane & 7 ) == 0 )
+            __hip_atomic_store( mvq + by * W, ( (unsigned long long)tag << 32 ) | (unsigned)r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+        if( ( lane & 7 ) < 4 && ( lane & 7 ) < W )
+            costs[by * W + ( lane & 7 )] = keep_cost;
+    }
+    me_dma_drain();
+    leave();
+#ifdef ME_PROFILE
+    if( lane == 0 && prof )
+    {
+        atomicAdd( prof + 0, PF_NOW() - pf_begin ); atomicAdd( prof + 1, pf_wait ); atomicAdd( prof + 2, pf_pre ); atomicAdd( prof + 3, pf_search );
+        atomicAdd( prof + 4, pf_store ); atomicAdd( prof + 5, pf_spins ); atomicAdd( prof + 6, pf_steps ); atomicAdd( prof + 7, 1ull );
+        for( int i = 1; i < 5; i++ ) atomicAdd( prof + 7 + i, pf_ph[i] );
+    }
+#endif
+}

@@ -15,10 +15,12 @@
 #include <string.h>
 #include <math.h>
 #include <vector>
+#include <algorithm>
 
 #include "x264hip.h"
 #include "device_common.h"
 #include "me_search.h"
+#include "me_team.h"
 #include "la_kernels.h"
 #include "block_metrics.h"
 #include "dct_quant_block.h"
@@ -497,7 +499,7 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( ring_alloc( ctx->xfer_ring, (size_t)ctx->xfer_cap * sizeof( CellXfer ) ) );
     ctx->wcache.assign( x264hip_ctx::WCAP, x264hip_ctx::WEntry() );
     ctx->desc_cap = 2 * ( p.bframes + 1 ) * p.max_frames + 16;
-    OPENCK( ring_alloc( ctx->search_ring, (size_t)ctx->desc_cap * sizeof( SearchDesc<uint8_t> ) ) );
+    OPENCK( ring_alloc( ctx->search_ring, (size_t)ctx->desc_cap * ( sizeof( SearchDesc<uint8_t> ) + sizeof( TeamDesc ) ) ) ); // descriptors, then the team table
     ctx->staging_bytes = (size_t)p.width * p.height * ctx->psz;
     OPENCK( hipHostMalloc( &ctx->staging, ctx->staging_bytes ) );
 
@@ -891,14 +893,24 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
     int rc = 0, ri = 0;
     if( ring_acquire( ctx->search_ring, &ri ) ) return X264HIP_EDEVICE;
     SearchDesc<T> *dh = (SearchDesc<T> *)ctx->search_ring.host[ri], *dd = (SearchDesc<T> *)ctx->search_ring.dev[ri];
-    // the table holds the searches on unweighted planes first, in request (= frame) order, then the weighted ones: the row
-    // kernel is compiled once without and once with the weighting code (me_search.h)
+    // The table holds the searches on unweighted planes first, sorted by reference frame (stable: request = frame order inside a
+    // reference), then the weighted ones: the kernels are compiled once without and once with the weighting code.  Searches that read
+    // one reference form TEAMS of up to TEAM_MAX (me_team.h: a wave = one block row of a team, one LDS window of the reference);
+    // a weighted search reads its own weighted copy and is a team of its own.
+    static const bool use_rows = getenv( "X264HIP_SEARCH" ) && !strcmp( getenv( "X264HIP_SEARCH" ), "rows" ); // A/B runs: the round-3 kernel
     std::vector<int> order( n );
     int n_plain = 0;
     for( int i = 0; i < n; i++ )
         if( !reqs[i].wt.on ) order[n_plain++] = i;
+    if( !use_rows )
+        std::stable_sort( order.begin(), order.begin() + n_plain, [&]( int a, int b ) {
+            const FrameSlot &ra = ctx->slots[reqs[a].slot_ref], &rb = ctx->slots[reqs[b].slot_ref];
+            return ra.frame_no != rb.frame_no ? ra.frame_no < rb.frame_no : reqs[a].slot_ref < reqs[b].slot_ref;
+        } );
     for( int i = 0, k = n_plain; i < n; i++ )
         if( reqs[i].wt.on ) order[k++] = i;
+    TeamDesc *th = (TeamDesc *)( dh + ctx->desc_cap ), *td = (TeamDesc *)( dd + ctx->desc_cap );
+    int n_teams[2] = { 0, 0 }; // unweighted teams first, then the weighted ones
     for( int i = 0; i < n; i++ )
     {
         const SearchReq &r = reqs[order[i]];
@@ -929,8 +941,24 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         b.field_remote[r.list][r.dist_m1] = 0;
         d.pad = 0;
         dh[i] = d;
+        const int part = i >= n_plain, nt = n_teams[0] + n_teams[1];
+        bool joined = false;
+        if( !part && nt )
+        {
+            TeamDesc &l = th[nt - 1];
+            joined = l.n < TEAM_MAX && dh[l.first].ref_strips == d.ref_strips;
+            if( joined ) l.n++;
+        }
+        if( !joined )
+        {
+            th[nt].first = part ? i - n_plain : i; // relative to the part's first descriptor
+            th[nt].n = 1;
+            n_teams[part]++;
+        }
     }
     HIPCK( upload_async( ctx, dd, dh, (size_t)n * sizeof( SearchDesc<T> ), ctx->stream ) );
+    if( !use_rows )
+        HIPCK( upload_async( ctx, td, th, (size_t)( n_teams[0] + n_teams[1] ) * sizeof( TeamDesc ), ctx->stream ) );
     // (the row tickets in sync_words are cleared by the last wave of the previous launch: me_search.h)
     hipEvent_t e0 = ctx->ev_start, e1 = ctx->ev_stop;
     if( ctx->prof_on )
@@ -949,18 +977,26 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         const bool hex = P.me_method == X264HIP_ME_HEX, r4 = P.subpel_refine >= 3;
         const int mode = !r4 && !P.mbcmp_satd && !P.fpelcmp_satd ? 0 : r4 && P.mbcmp_satd ? ( P.fpelcmp_satd ? 2 : 1 ) : 3;
         MeQueues Q;
-        // one wave per (search, group of ME_ROWS block rows); the kernel is specialised on the search pattern, the sub-pel
-        // depth and on whether its searches read weighted references
+        // team kernel: one wave per (team, block row); rows kernel: one wave per (search, group of ME_ROWS block rows).  Both are
+        // specialised on the search pattern, the sub-pel depth and on whether their searches read weighted references
         const int n_rowgroups = ( P.mb_h + ME_ROWS - 1 ) / ME_ROWS;
         for( int part = 0; part < 2; part++ )
         {
             const int first = part ? n_plain : 0, count = part ? n - n_plain : n_plain;
             if( !count ) continue;
+            const int units = use_rows ? count : n_teams[part]; // what the ticket queues hand out
             for( int q = 0; q <= ME_QUEUES; q++ )
-                Q.base[q] = (int)( (long long)count * q / ME_QUEUES ); // contiguous groups: the request list is in frame order
+                Q.base[q] = (int)( (long long)units * q / ME_QUEUES ); // contiguous groups: the table is in frame order
             unsigned *tickets = ctx->sync_words + part * ME_QUEUES * ME_QUEUE_STRIDE;
-#define ME_LAUNCH( HEXV, MODEV ) do { if( part ) me_rows_kernel<T, HEXV, MODEV, 1><<<count * n_rowgroups, 64, 0, ctx->stream>>>( P, dd + first, Q, tickets, ctx->err_host, 1u << 22, ctx->me_prof ); \
-                                  else me_rows_kernel<T, HEXV, MODEV, 0><<<count * n_rowgroups, 64, 0, ctx->stream>>>( P, dd + first, Q, tickets, ctx->err_host, 1u << 22, ctx->me_prof ); } while( 0 )
+            const TeamDesc *tp = td + ( part ? n_teams[0] : 0 );
+#define ME_LAUNCH( HEXV, MODEV ) do { \
+                if( use_rows ) { \
+                    if( part ) me_rows_kernel<T, HEXV, MODEV, 1><<<count * n_rowgroups, 64, 0, ctx->stream>>>( P, dd + first, Q, tickets, ctx->err_host, 1u << 22, ctx->me_prof ); \
+                    else me_rows_kernel<T, HEXV, MODEV, 0><<<count * n_rowgroups, 64, 0, ctx->stream>>>( P, dd + first, Q, tickets, ctx->err_host, 1u << 22, ctx->me_prof ); \
+                } else { \
+                    if( part ) me_team_kernel<T, HEXV, MODEV, 1><<<units * P.mb_h, 64, 0, ctx->stream>>>( P, dd + first, tp, Q, tickets, ctx->err_host, 1u << 22, ctx->me_prof ); \
+                    else me_team_kernel<T, HEXV, MODEV, 0><<<units * P.mb_h, 64, 0, ctx->stream>>>( P, dd + first, tp, Q, tickets, ctx->err_host, 1u << 22, ctx->me_prof ); \
+                } } while( 0 )
             switch( 4 * hex + mode )
             {
                 case 0: ME_LAUNCH( 0, 0 ); break;
