@@ -35,8 +35,17 @@ ab)
       line "$E $B" $out/ab_$i.log
     done
   done ;;
+lat)
+  i=0
+  for E in "X264HIP_LAT_WAVES=2048" "X264HIP_LAT_WAVES=8192" "X264HIP_LAT_WAVES=16384"; do
+    for B in "--inflight 8 --paced" "--inflight 1 --paced" "--inflight 8"; do
+      i=$((i+1))
+      env $E timeout 300 python bench.py $short $B > $out/lat_$i.log 2>&1
+      line "$E $B" $out/lat_$i.log
+    done
+  done ;;
 prof)
-  for E in "A=0" "X264HIP_SEARCH=rows"; do
+  for E in "A=0" "X264HIP_SEARCH=rows" "X264HIP_SEARCH=team"; do
     for B in "--inflight 1" "--inflight 1 --paced"; do
       env $E X264HIP_LIB=$GRAFT_REPO_ROOT/x264_amd/libx264hip_prof.so timeout 300 python bench.py $short $B > $out/prof.log 2>&1
       echo "== $E $B" | tee -a $out/summary.txt; grep -h "ME_PROFILE" $out/prof.log | tail -4 | tee -a $out/summary.txt

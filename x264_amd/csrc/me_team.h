@@ -27,6 +27,7 @@
 // Candidates outside the window (|mv| > 8 full samples in x or y) take the whole set through the global strip copy instead
 // (compact loop, same arithmetic): results do not depend on the window.
 #pragma once
+#include <type_traits>
 #include "me_search.h"
 
 #define TEAM_MAX 8
@@ -298,8 +299,133 @@ struct TeamEval
 #endif
 };
 
-// MODE / WEIGHTED as in me_rows_kernel (me_search.h).  Q.base[] counts TEAMS.
-template <typename T, int HEX, int MODE, int WEIGHTED>
+// ---- one search per wave: the candidates of a set across the eight lane groups ---------------------------------------------------------
+// The latency form of the same search (me_team_kernel<.., LAT = 1>): the wave holds ONE block, group g (lanes 8g .. 8g+7) costs
+// candidate g of a set -- lane = one row of the candidate, a group sum is three DPP steps, the cheapest candidate a packed minimum over
+// the groups (two row broadcasts) moved to a scalar register -- so a set of up to eight candidates is ONE pass of ~45 instructions
+// whatever its size, and everything between two sets (the decision logic of me_logic.h) is wave-uniform and runs on the scalar unit.
+// A block search is then ~400 instructions instead of ~1 900 for eight blocks side by side: a fifth of the latency per block at
+// five times the instructions per block.  Used for launches that cannot fill the chip anyway (x264hip.hip launch_searches_t): there
+// the length of the dependency chain W + 2 (H - 1) blocks is what the caller waits for.
+#define DPP_ROW_ROR8_ 0x128
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+__device__ __forceinline__ int wave_min_groups( int v ) // minimum over the eight groups (every lane of a group holds the group's value) -> scalar
+{
+    v = imin2( v, dpp_mov<DPP_ROW_ROR8_>( v ) );
+    v = imin2( v, __builtin_amdgcn_update_dpp( v, v, DPP_ROW_BCAST15, 0xA, 0xF, false ) );
+    v = imin2( v, __builtin_amdgcn_update_dpp( v, v, DPP_ROW_BCAST31, 0xC, 0xF, false ) );
+    return __builtin_amdgcn_readlane( v, 63 );
+}
+template <typename T, int LDS_TAB, int WEIGHTED>
+struct WaveEval
+{
+    static constexpr int NP = WEIGHTED ? 5 : 4;
+    typedef WinGeo<T, NP> G;
+    const unsigned char *win;
+    const uint16_t *lds_tab;
+    const T *sbase, *wsbase;
+    const uint16_t *tab;
+    int plane_elems, strip_elems, pixel_max;
+    int fpelcmp_satd;
+    WtD wt;
+    int cx0, row16;
+    int tab_x, tab_y;
+    Px8 f;
+    LaneSlots S;   // only row16 (this lane's row in strip-row units) is used
+    int rowb;
+    int grp;       // lane >> 3: the candidate this lane works on
+
+    __device__ __forceinline__ int bits( int qx, int qy ) const
+    {
+        if( LDS_TAB )
+            return lds_tab[qx + tab_x] + lds_tab[qy + tab_y];
+        return gload_u16( tab, 2u * (unsigned)( qx + tab_x ) ) + gload_u16( tab, 2u * (unsigned)( qy + tab_y ) );
+    }
+    __device__ __forceinline__ int win_addr( int p, int x, int y ) const
+    {
+        const int c = cx0 + x;
+        return mad24( ( c >> 3 ) & ( WIN_RING - 1 ), G::SLOTB, mad24( mad24( p, WIN_ROWS, y + WIN_R ), G::ROWB, ( c & 7 ) * G::E ) );
+    }
+    static __device__ __forceinline__ bool in_window( int x, int y )
+    {
+        return (unsigned)( x + WIN_R ) <= 2u * WIN_R && (unsigned)( y + WIN_R ) <= 2u * WIN_R;
+    }
+    template <int N, class GEN>
+    __device__ __forceinline__ int fpel_set( GEN gen ) const
+    {
+        const int k = imin2( grp, N - 1 );
+        int x = 0, y = 0;
+        bool ok = false, wb = true;
+        gen( k, x, y, ok, wb );
+        const int b = wb ? bits( 4 * x, 4 * y ) : 0;
+        Px8 r;
+        if( __builtin_amdgcn_ballot_w64( !in_window( x, y ) ) == 0ull )
+            r = win_px8( win, win_addr( WEIGHTED ? 4 : 0, x, y ), rowb, (const T *)nullptr );
+        else
+            r = load_px8_at( WEIGHTED ? wsbase : sbase, strip_off( cx0 + x, row16 + ( y << 4 ), strip_elems ) + S.row16 );
+        int total = reduce8( block_partial8<T>( f, r, fpelcmp_satd ) );
+        if( fpelcmp_satd ) total >>= 1;
+        return wave_min_groups( ok && grp < N ? ( ( total + b ) << 3 ) | k : ME_PACK_MAX );
+    }
+    template <int N, class GEN>
+    __device__ __forceinline__ int qpel_set( int use_satd, GEN gen, int &cost0 ) const
+    {
+        const int k = imin2( grp, N - 1 );
+        int x = 0, y = 0;
+        bool ok = false, wb = true;
+        gen( k, x, y, ok, wb );
+        const int b = wb ? bits( x, y ) : 0;
+        const int fx = x & 3, fy = y & 3, ix = x >> 2, iy = y >> 2;
+        Px8 a, bb;
+        if( __builtin_amdgcn_ballot_w64( !in_window( ix, iy ) ) == 0ull )
+        {
+            const int sh = 2 * ( fx | ( fy << 2 ) );
+            const int pa = (int)( ( 0x54FE5454u >> sh ) & 3u ), pb = (int)( ( 0xBABABA10u >> sh ) & 3u );
+            const int va = win_addr( pa, ix, iy + ( fy == 3 ) ), vb = win_addr( pb, ix + ( fx == 3 ), iy );
+            a = win_px8( win, va, rowb, (const T *)nullptr );
+            bb = a;
+            if( vb != va ) // both taps of a full- or half-pel position are the same sample (uniform inside the group)
+                bb = win_px8( win, vb, rowb, (const T *)nullptr );
+        }
+        else
+        {
+            int oa, ob;
+            strip_layout::qpel_taps( plane_elems, strip_off( cx0 + ix, row16 + ( iy << 4 ), strip_elems ), x, y, oa, ob );
+            a = load_px8_at( sbase, oa + S.row16 );
+            bb = load_px8_at( sbase, ob + S.row16 );
+        }
+        Px8 r;
+        r.lo = avg_px4( a.lo, bb.lo, (const T *)nullptr ); r.hi = avg_px4( a.hi, bb.hi, (const T *)nullptr );
+        if( WEIGHTED )
+        {
+            r.lo = weight_px4<T>( r.lo, wt, pixel_max ); r.hi = weight_px4<T>( r.hi, wt, pixel_max );
+        }
+        int total = reduce8( block_partial8<T>( f, r, use_satd ) );
+        if( use_satd ) total >>= 1;
+        total += b;
+        cost0 = __builtin_amdgcn_readlane( total, 0 );
+        return wave_min_groups( ok && grp < N ? ( total << 3 ) | k : ME_PACK_MAX );
+    }
+    __device__ __forceinline__ bool any( bool c ) const { return c; } // uniform
+#ifdef ME_PROFILE
+    unsigned long long pf_last;
+    unsigned pf_phase[5];
+    __device__ __forceinline__ void mark( int k )
+    {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        if( k ) pf_phase[k] += (unsigned)( now - pf_last );
+        pf_last = now;
+    }
+#endif
+};
+
+template <typename T, int A, int B> __device__ __forceinline__ void set_grp( WaveEval<T, A, B> &ev, int g ) { ev.grp = g; }
+template <typename T, int A, int B> __device__ __forceinline__ void set_grp( TeamEval<T, A, B> &, int ) {}
+
+// MODE / WEIGHTED as in me_rows_kernel (me_search.h).  Q.base[] counts TEAMS.  LAT: one search per wave, the candidates of a set across the
+// groups (WaveEval); the team table then holds one team per search.
+template <typename T, int HEX, int MODE, int WEIGHTED, int LAT>
 __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_team_kernel( LaP P, const SearchDesc<T> *descs, const TeamDesc *teams, MeQueues Q,
                                                                        unsigned *tickets /* [ME_QUEUES * ME_QUEUE_STRIDE] */, unsigned *err_host /* pinned sticky timeout flag */,
                                                                        unsigned spin_limit, unsigned long long *prof /* ME_PROFILE builds: cycle accumulators, else unused */ )
@@ -350,8 +476,11 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_team_kernel( LaP P, con
     TD.first = __builtin_amdgcn_readfirstlane( TD.first ); TD.n = __builtin_amdgcn_readfirstlane( TD.n );
     const int by = H - 1 - j; // this wave's block row (scalar)
     const int g = lane >> 3;
-    const bool live = g < TD.n;
-    const SearchDesc<T> *dp = descs + TD.first + ( live ? g : 0 );
+    const bool live = LAT || g < TD.n;
+    const SearchDesc<T> *dp = descs + TD.first + ( !LAT && live ? g : 0 );
+    // the lane that talks to memory for its block / the lanes that keep its costs
+    const bool leader = LAT ? lane == 0 : ( lane & 7 ) == 0;
+    const int cost_lane = LAT ? lane : ( lane & 7 );
     // per group: the search's own buffers; wave-uniform: the reference
     const T *fbase = dp->fenc0;
     AS_GLOBAL unsigned long long *mvq = (AS_GLOBAL unsigned long long *)dp->mvq;
@@ -428,11 +557,11 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_team_kernel( LaP P, con
     const AS_GLOBAL unsigned long long *below_row = mvq + ( by + 1 ) * W;
     auto granule = [&]( int x ) -> unsigned long long { // lane 8g: granule of block (x, by+1) of this group's search, L1-bypassing
         unsigned long long gq = 0;
-        if( has_below && ( lane & 7 ) == 0 )
+        if( has_below && leader )
             gq = __hip_atomic_load( below_row + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
         return gq;
     };
-    auto granule_ok = [&]( unsigned long long gq ) -> bool { return ( lane & 7 ) != 0 || !live || (unsigned)( gq >> 32 ) == tag; };
+    auto granule_ok = [&]( unsigned long long gq ) -> bool { return !leader || !live || (unsigned)( gq >> 32 ) == tag; };
     bool timed_out = false;
     // The granule requested a step ahead normally carries the tag already (the row below is two blocks ahead): the check is then
     // the only cost.  Otherwise spin, reloading, until every live group's granule carries its tag.
@@ -455,7 +584,11 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_team_kernel( LaP P, con
         return gq;
     };
     // every lane of the group gets lane 8g's vector
-    auto granule_mv = [&]( unsigned long long gq ) -> int { return __builtin_amdgcn_ds_bpermute( ( lane & ~7 ) << 2, (int)(unsigned)gq ); };
+    auto granule_mv = [&]( unsigned long long gq ) -> int {
+        if( LAT )
+            return __builtin_amdgcn_readfirstlane( (int)(unsigned)gq );
+        return __builtin_amdgcn_ds_bpermute( ( lane & ~7 ) << 2, (int)(unsigned)gq );
+    };
     int below_right = 0, below = 0, below_left = 0;
     unsigned long long g_next = 0;
     if( has_below )
@@ -524,10 +657,10 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_team_kernel( LaP P, con
         // x % 4 == j; four neighbouring costs are one 16-byte store), and the requests for the next step: the source block, the granule,
         // the strip the window moves onto.  Nothing else touches memory until the next step's wait, which therefore never waits for
         // anything younger than a block search.
-        if( bx + 1 < W && live && ( lane & 7 ) == 0 )
+        if( bx + 1 < W && live && leader )
             __hip_atomic_store( mvq + by * W + bx + 1, ( (unsigned long long)tag << 32 ) | (unsigned)r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-        if( !( ( bx + 1 ) & 3 ) && bx + 1 < W && live && ( lane & 7 ) < 4 && bx + 1 + ( lane & 7 ) < W )
-            costs[by * W + bx + 1 + ( lane & 7 )] = keep_cost;
+        if( !( ( bx + 1 ) & 3 ) && bx + 1 < W && live && cost_lane < 4 && bx + 1 + cost_lane < W )
+            costs[by * W + bx + 1 + cost_lane] = keep_cost;
         f_next = source_raw( imax2( bx - 1, 0 ) );
         g_next = granule( imax2( bx - 2, 0 ) );
         if( bx > 0 )
@@ -558,6 +691,8 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_team_kernel( LaP P, con
                 const int v0 = mad24( k & ( WIN_RING - 1 ), G::SLOTB, WIN_R * G::ROWB );
                 const Px8 r = win_px8( win, v0, rowb, (const T *)nullptr );
                 cost = block_cost8<T>( f, r, C.mbcmp_satd );
+                if( LAT )
+                    cost = __builtin_amdgcn_readfirstlane( cost );
                 done = cost < 64;
             }
 #ifdef ME_PROFILE
@@ -576,7 +711,8 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_team_kernel( LaP P, con
                 const bool far = reach + 4 * ( P.me_range + 4 ) >= TEAM_TAB_HALF;
                 if( __builtin_amdgcn_ballot_w64( far ) == 0ull )
                 {
-                    TeamEval<T, 1, WEIGHTED> ev;
+                    typename std::conditional<LAT != 0, WaveEval<T, 1, WEIGHTED>, TeamEval<T, 1, WEIGHTED>>::type ev;
+                    set_grp( ev, g );
                     ev.win = win; ev.lds_tab = tab_window; ev.sbase = sbase; ev.wsbase = wsbase; ev.tab = nullptr; ev.plane_elems = P.plane_elems;
                     ev.strip_elems = strip_elems; ev.pixel_max = P.pixel_max; ev.fpelcmp_satd = C.fpelcmp_satd; ev.wt = wt;
                     ev.cx0 = cx0; ev.row16 = row16; ev.f = f; ev.S = LS; ev.rowb = rowb;
@@ -591,7 +727,8 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_team_kernel( LaP P, con
                 }
                 else
                 {
-                    TeamEval<T, 0, WEIGHTED> ev;
+                    typename std::conditional<LAT != 0, WaveEval<T, 0, WEIGHTED>, TeamEval<T, 0, WEIGHTED>>::type ev;
+                    set_grp( ev, g );
                     ev.win = win; ev.lds_tab = nullptr; ev.sbase = sbase; ev.wsbase = wsbase; ev.tab = P.cost_mv - tab_centre; ev.plane_elems = P.plane_elems;
                     ev.strip_elems = strip_elems; ev.pixel_max = P.pixel_max; ev.fpelcmp_satd = C.fpelcmp_satd; ev.wt = wt;
                     ev.cx0 = cx0; ev.row16 = row16; ev.f = f; ev.S = LS; ev.rowb = rowb;
@@ -612,7 +749,7 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_team_kernel( LaP P, con
         // blocks slicetype_slice_cost never visits (slicetype.c:823-833) keep zero vectors (frame.c:283-285); the vector leaves at the
         // start of the next step
         const int packed = ( mvx & 0xFFFF ) | ( mvy << 16 );
-        if( ( lane & 7 ) == ( bx & 3 ) )
+        if( cost_lane == ( bx & 3 ) )
             keep_cost = cost;
         r1 = packed;
         below_right = below; below = below_left;
@@ -628,10 +765,10 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_team_kernel( LaP P, con
         __hip_atomic_store( err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
     if( !timed_out && live )
     {
-        if( ( lane & 7 ) == 0 )
+        if( leader )
             __hip_atomic_store( mvq + by * W, ( (unsigned long long)tag << 32 ) | (unsigned)r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-        if( ( lane & 7 ) < 4 && ( lane & 7 ) < W )
-            costs[by * W + ( lane & 7 )] = keep_cost;
+        if( cost_lane < 4 && cost_lane < W )
+            costs[by * W + cost_lane] = keep_cost;
     }
     me_dma_drain();
     leave();

@@ -897,12 +897,13 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
     // reference), then the weighted ones: the kernels are compiled once without and once with the weighting code.  Searches that read
     // one reference form TEAMS of up to TEAM_MAX (me_team.h: a wave = one block row of a team, one LDS window of the reference);
     // a weighted search reads its own weighted copy and is a team of its own.
-    static const bool use_rows = getenv( "X264HIP_SEARCH" ) && !strcmp( getenv( "X264HIP_SEARCH" ), "rows" ); // A/B runs: the round-3 kernel
+    static const bool use_rows = getenv( "X264HIP_SEARCH" ) && !strcmp( getenv( "X264HIP_SEARCH" ), "rows" ); // A/B runs: the rows kernel for every launch
+    static const bool use_team = getenv( "X264HIP_SEARCH" ) && !strcmp( getenv( "X264HIP_SEARCH" ), "team" ); // A/B runs: the team form for large launches
     std::vector<int> order( n );
     int n_plain = 0;
     for( int i = 0; i < n; i++ )
         if( !reqs[i].wt.on ) order[n_plain++] = i;
-    if( !use_rows )
+    if( use_team )
         std::stable_sort( order.begin(), order.begin() + n_plain, [&]( int a, int b ) {
             const FrameSlot &ra = ctx->slots[reqs[a].slot_ref], &rb = ctx->slots[reqs[b].slot_ref];
             return ra.frame_no != rb.frame_no ? ra.frame_no < rb.frame_no : reqs[a].slot_ref < reqs[b].slot_ref;
@@ -911,6 +912,13 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         if( reqs[i].wt.on ) order[k++] = i;
     TeamDesc *th = (TeamDesc *)( dh + ctx->desc_cap ), *td = (TeamDesc *)( dd + ctx->desc_cap );
     int n_teams[2] = { 0, 0 }; // unweighted teams first, then the weighted ones
+    // Which kernel ("two search kernels"): a launch that cannot fill the chip is as long as its dependency chain
+    // -- W + 2 (H - 1) block searches one after the other -- whatever its width, so it goes to the LATENCY form of the search out of LDS
+    // (me_team_kernel<.., LAT = 1>: a wave per search and block row, ~5 x shorter per block, ~3 x more instructions per block);
+    // everything larger goes to the throughput kernel (me_rows_kernel; X264HIP_SEARCH=team: the team form of the LDS kernel).
+    static const int lat_waves = getenv( "X264HIP_LAT_WAVES" ) ? atoi( getenv( "X264HIP_LAT_WAVES" ) ) : 4096;
+    const bool lat[2] = { (long long)n_plain * P.mb_h <= lat_waves, (long long)( n - n_plain ) * P.mb_h <= lat_waves };
+    const bool rows[2] = { use_rows || ( !lat[0] && !use_team ), use_rows || ( !lat[1] && !use_team ) };
     for( int i = 0; i < n; i++ )
     {
         const SearchReq &r = reqs[order[i]];
@@ -943,7 +951,7 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         dh[i] = d;
         const int part = i >= n_plain, nt = n_teams[0] + n_teams[1];
         bool joined = false;
-        if( !part && nt )
+        if( !part && nt && !lat[0] )
         {
             TeamDesc &l = th[nt - 1];
             joined = l.n < TEAM_MAX && dh[l.first].ref_strips == d.ref_strips;
@@ -957,7 +965,7 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         }
     }
     HIPCK( upload_async( ctx, dd, dh, (size_t)n * sizeof( SearchDesc<T> ), ctx->stream ) );
-    if( !use_rows )
+    if( !rows[0] || !rows[1] )
         HIPCK( upload_async( ctx, td, th, (size_t)( n_teams[0] + n_teams[1] ) * sizeof( TeamDesc ), ctx->stream ) );
     // (the row tickets in sync_words are cleared by the last wave of the previous launch: me_search.h)
     hipEvent_t e0 = ctx->ev_start, e1 = ctx->ev_stop;
@@ -984,18 +992,24 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         {
             const int first = part ? n_plain : 0, count = part ? n - n_plain : n_plain;
             if( !count ) continue;
-            const int units = use_rows ? count : n_teams[part]; // what the ticket queues hand out
+            const int units = rows[part] ? count : n_teams[part]; // what the ticket queues hand out
             for( int q = 0; q <= ME_QUEUES; q++ )
                 Q.base[q] = (int)( (long long)units * q / ME_QUEUES ); // contiguous groups: the table is in frame order
             unsigned *tickets = ctx->sync_words + part * ME_QUEUES * ME_QUEUE_STRIDE;
             const TeamDesc *tp = td + ( part ? n_teams[0] : 0 );
+            const int grid_rows = count * n_rowgroups, grid_team = units * P.mb_h;
+#define ME_ARGS_ROWS P, dd + first, Q, tickets, ctx->err_host, 1u << 22, ctx->me_prof
+#define ME_ARGS_TEAM P, dd + first, tp, Q, tickets, ctx->err_host, 1u << 22, ctx->me_prof
 #define ME_LAUNCH( HEXV, MODEV ) do { \
-                if( use_rows ) { \
-                    if( part ) me_rows_kernel<T, HEXV, MODEV, 1><<<count * n_rowgroups, 64, 0, ctx->stream>>>( P, dd + first, Q, tickets, ctx->err_host, 1u << 22, ctx->me_prof ); \
-                    else me_rows_kernel<T, HEXV, MODEV, 0><<<count * n_rowgroups, 64, 0, ctx->stream>>>( P, dd + first, Q, tickets, ctx->err_host, 1u << 22, ctx->me_prof ); \
+                if( rows[part] ) { \
+                    if( part ) me_rows_kernel<T, HEXV, MODEV, 1><<<grid_rows, 64, 0, ctx->stream>>>( ME_ARGS_ROWS ); \
+                    else me_rows_kernel<T, HEXV, MODEV, 0><<<grid_rows, 64, 0, ctx->stream>>>( ME_ARGS_ROWS ); \
+                } else if( lat[part] ) { \
+                    if( part ) me_team_kernel<T, HEXV, MODEV, 1, 1><<<grid_team, 64, 0, ctx->stream>>>( ME_ARGS_TEAM ); \
+                    else me_team_kernel<T, HEXV, MODEV, 0, 1><<<grid_team, 64, 0, ctx->stream>>>( ME_ARGS_TEAM ); \
                 } else { \
-                    if( part ) me_team_kernel<T, HEXV, MODEV, 1><<<units * P.mb_h, 64, 0, ctx->stream>>>( P, dd + first, tp, Q, tickets, ctx->err_host, 1u << 22, ctx->me_prof ); \
-                    else me_team_kernel<T, HEXV, MODEV, 0><<<units * P.mb_h, 64, 0, ctx->stream>>>( P, dd + first, tp, Q, tickets, ctx->err_host, 1u << 22, ctx->me_prof ); \
+                    if( part ) me_team_kernel<T, HEXV, MODEV, 1, 0><<<grid_team, 64, 0, ctx->stream>>>( ME_ARGS_TEAM ); \
+                    else me_team_kernel<T, HEXV, MODEV, 0, 0><<<grid_team, 64, 0, ctx->stream>>>( ME_ARGS_TEAM ); \
                 } } while( 0 )
             switch( 4 * hex + mode )
             {
@@ -1009,6 +1023,8 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
                 default: ME_LAUNCH( 1, 3 ); break;
             }
 #undef ME_LAUNCH
+#undef ME_ARGS_ROWS
+#undef ME_ARGS_TEAM
         }
     }
     HIPCK( hipEventRecord( e1, ctx->stream ) );
