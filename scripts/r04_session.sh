@@ -58,6 +58,13 @@ stats)
   cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
   mkdir -p ${out}_stats
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d ${out}_stats -o run -- python bench.py $short > ${out}_stats/bench.log 2>&1; echo "stats rc=$?" | tee -a $out/summary.txt ;;
+window)
+  cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+  timeout 600 python scripts/window_profile.py $WINDOW_ARGS > $out/window.log 2>&1; grep -h '^{' $out/window.log | cut -c1-420 | tee -a $out/summary.txt
+  mkdir -p ${out}_wstats ${out}_wapi
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d ${out}_wstats -o run -- python scripts/window_profile.py $WINDOW_ARGS --modes plain --passes 1 > ${out}_wstats/log.txt 2>&1; echo "wstats rc=$?" | tee -a $out/summary.txt
+  timeout 600 rocprofv3 --hip-runtime-trace --stats --output-format csv -d ${out}_wapi -o run -- python scripts/window_profile.py $WINDOW_ARGS --modes plain --passes 1 > ${out}_wapi/log.txt 2>&1; echo "wapi rc=$?" | tee -a $out/summary.txt
+  find ${out}_wstats ${out}_wapi -name "*_trace.csv" -size +8M -delete ;;
 pmc)
   bash scripts/pmc_search.sh ${tag} 2>&1 | tee -a $out/summary.txt ;;
 esac

@@ -176,9 +176,10 @@ def _shard_worker(rank, world, port, q):
     frames = make_clip(W, H, nf, seed=12, scene_cuts=(23,), fade=(40, 8, 0.7, 6), pan=(4, 2))
     cfg = L2.la_config(W, H, "medium", bframes=8, rc_lookahead=60)
     dev = torch.from_numpy(frames).cuda()
-    outs, dt, stats = shard.run_window_shard(torch, L2, dist, rank, world, 0, cfg, dev, exchange_on_device=False, qp_offsets=True)
+    outs, dt, stats = shard.run_window_shard(torch, L2, dist, rank, world, 0, cfg, dev, exchange_on_device=False, qp_offsets=True, vbv=True)
     if rank == 0:
-        q.put(dict(sig=[(o.frame, o.type, [o.cost_est[i][j] for i in range(10) for j in range(10)], o.qp_offset.tobytes()) for o in outs], stats=stats))
+        q.put(dict(sig=[(o.frame, o.type, [o.cost_est[i][j] for i in range(10) for j in range(10)], o.qp_offset.tobytes()) for o in outs],
+                   rows=[(o.row_satds.tobytes(), o.row_satds_intra.tobytes()) for o in outs], stats=stats))
     else:
         q.put(dict(stats=stats))
     dist.barrier()
@@ -197,10 +198,11 @@ def test_window_shard_two_ranks_on_one_gpu():
     cfg = lib.la_config(W, H, "medium", bframes=8, rc_lookahead=60)
     la = lib.Lookahead(cfg, max_frames=nf + 4)
     try:
-        ref = la.run(frames, paced=False, qp_offsets=True)
+        ref = la.run(frames, paced=False, qp_offsets=True, vbv=True)
     finally:
         la.close()
     want = [(o.frame, o.type, [o.cost_est[i][j] for i in range(10) for j in range(10)], o.qp_offset.tobytes()) for o in ref]
+    want_rows = [(o.row_satds.tobytes(), o.row_satds_intra.tobytes()) for o in ref]
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -214,10 +216,15 @@ def test_window_shard_two_ranks_on_one_gpu():
     r0 = next(g for g in got if "sig" in g)
     r1 = next(g for g in got if "sig" not in g)
     assert r0["sig"] == want
+    # what VBV rate control reads per frame -- the row sums of the cell the frame is coded with AND its intra row sums -- for the frames
+    # another rank owns as well (an imported cell summary must not touch the intra rows rank 0 computed itself)
+    assert r0["rows"] == want_rows
     s0, s1 = r0["stats"], r1["stats"]
     print("window shard on one GPU:", s0)
     assert s1["fields_searched"] > 100 and s1["cells_evaluated"] > 100 and s0["cells_imported"] == s1["cells_evaluated"]
-    assert s0["maps_fetched"] > 0 and s0["remote_maps_recomputed_here"] == 0
+    # (the row sums asked for above come through the getter that also serves the per-block map: a cell whose map was never fetched is
+    # evaluated locally for it -- a handful at most)
+    assert s0["maps_fetched"] > 0 and s0["remote_maps_recomputed_here"] <= 2
     # what rank 0 searched of the other rank's frames (cells evaluated on demand after all) stays a small part of that rank's searches
     assert s0["remote_fields_searched_here"] <= 0.2 * s1["fields_searched"], (s0["remote_fields_searched_here"], s1["fields_searched"])
     # rank 0's own share of the two big kernels: about half of the fields and cells (two ranks), not all of them

@@ -598,9 +598,15 @@ struct CellArgs
     int sums_only;                // reduce only: intra sums of a frame, no maps written (speculative [0][0] sums)
     int pad_;
     int *acc_dev;                 // device copy of acc[0..4] (what x264hip_export_cells packs for another rank)
+    int *work;                    // [8] zero between launches: partial sums [0..4] and the arrival counter [5] of cell_reduce_kernel's workgroups
+    // B cells evaluated BOTH ways in one pass (dual != 0, ref1_l0_valid set): the outcome without the list-1 reference's own vectors goes here
+    // (the cell's spare storage); its sums are reduced through a descriptor of its own
+    uint16_t *lowres_costs2;
+    int *blk2;
+    int dual, pad2_;
 };
 
-__device__ __forceinline__ void cell_finish( const LaP &P, const CellArgs &A, int xy, int bcost, int list_used )
+__device__ __forceinline__ void cell_finish( const LaP &P, const CellArgs &A, int xy, int bcost, int list_used, bool second = false )
 {
     // executed by ONE lane per block: final cost of the block, its map entry, and the word the reduction reads
     const int icost = A.intra_cost[xy];
@@ -611,20 +617,25 @@ __device__ __forceinline__ void cell_finish( const LaP &P, const CellArgs &A, in
         b_intra = icost < bcost;
         if( b_intra ) { bcost = icost; list_used = 0; }
     }
-    A.blk[xy] = bcost | ( b_intra << 30 );
-    A.lowres_costs[xy] = (uint16_t)( imin2( bcost, 0x3FFF ) + ( list_used << 14 ) );
+    ( second ? A.blk2 : A.blk )[xy] = bcost | ( b_intra << 30 );
+    ( second ? A.lowres_costs2 : A.lowres_costs )[xy] = (uint16_t)( imin2( bcost, 0x3FFF ) + ( list_used << 14 ) );
 }
 
-// Row and frame sums of one evaluation (slicetype.c:746-757,778-788,946-985): ONE workgroup, each wave owns
-// whole block rows, no atomics, no pre-zeroing; writes row_satds[], row_satds_intra[] and acc[0..4].
-__global__ __launch_bounds__( 1024 ) void cell_reduce_kernel( LaP P, const CellArgs *descs, CellArgs single )
+// Row and frame sums of one evaluation (slicetype.c:746-757,778-788,946-985): gridDim.y workgroups per cell, each owning a contiguous
+// band of block rows (a wave owns whole rows: the row sums need no atomics); the five frame sums are integer sums, so the order of the
+// workgroups' contributions does not matter: each adds its part to the cell's work words, and the last one to arrive publishes the totals
+// (pinned host record + device copy) and leaves the work words zero for the next use.  (One workgroup per cell -- the round 1-3 form --
+// took 80 us for a 4K cell whatever else the chip was doing: a cell evaluated on demand waited for it.)
+__global__ __launch_bounds__( 256 ) void cell_reduce_kernel( LaP P, const CellArgs *descs, CellArgs single )
 {
-    __shared__ int sh[5][16];
+    __shared__ int sh[5][4];
+    __shared__ int last;
     const CellArgs A = descs ? descs[blockIdx.x] : single;
     const int W = P.mb_w, H = P.mb_h;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
+    const int row_begin = (int)( (long long)H * blockIdx.y / gridDim.y ), row_end = (int)( (long long)H * ( blockIdx.y + 1 ) / gridDim.y );
     int t[5] = { 0, 0, 0, 0, 0 };
-    for( int by = wave; by < H; by += n_waves )
+    for( int by = row_begin + wave; by < row_end; by += n_waves )
     {
         int row = 0, row_i = 0;
         for( int bx = lane; bx < W; bx += 64 )
@@ -680,8 +691,29 @@ __global__ __launch_bounds__( 1024 ) void cell_reduce_kernel( LaP P, const CellA
     {
         int v = 0;
         for( int i = 0; i < n_waves; i++ ) v += sh[threadIdx.x][i];
+        if( gridDim.y == 1 )
+        {
+            A.acc[threadIdx.x] = v;
+            A.acc_dev[threadIdx.x] = v;
+        }
+        else if( v )
+            atomicAdd( &A.work[threadIdx.x], v );
+    }
+    if( gridDim.y == 1 )
+        return;
+    __threadfence();
+    __syncthreads();
+    if( threadIdx.x == 0 )
+        last = atomicAdd( &A.work[5], 1 ) == (int)gridDim.y - 1;
+    __syncthreads();
+    if( last && threadIdx.x < 5 )
+    {
+        __threadfence();
+        const int v = atomicExch( &A.work[threadIdx.x], 0 );
         A.acc[threadIdx.x] = v;
         A.acc_dev[threadIdx.x] = v;
+        if( threadIdx.x == 0 )
+            atomicExch( &A.work[5], 0 );
     }
 }
 
@@ -798,7 +830,7 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
         }
     }
     const bool dmv_nz = ( pd0 | pd1 ) != 0, mv_nz = ( pm0 | pm1 ) != 0;
-    int my_cost = 0, my_list = 0;
+    int my_cost = 0, my_list = 0, my_cost2 = 0, my_list2 = 0;
     for( int k = 0; k < nb; k += 2 )
     {
         const int k1 = imin2( k + 1, nb - 1 ); // an odd row end costs its last block twice
@@ -846,9 +878,28 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
             if( c < bcost ) { bcost = c; list_used = 3; }
         }
         if( lane == k || lane == k1 ) { my_cost = bcost; my_list = list_used; }
+        if( A.dual )
+        {
+            // the same block WITHOUT the list-1 reference's vectors (slicetype.c:629 false): the zero vectors take the first place, the
+            // rest of the order is unchanged -- all three candidate costs are the ones above
+            int b2 = COST_MAX_I, l2 = 0;
+            if( c_zero < b2 ) { b2 = c_zero; l2 = 3; }
+            if( c0v < b2 ) { b2 = c0v; l2 = 1; }
+            if( c1v < b2 ) { b2 = c1v; l2 = 2; }
+            if( mv_nz )
+            {
+                const int c = 5 * P.lambda + c_mv;
+                if( c < b2 ) { b2 = c; l2 = 3; }
+            }
+            if( lane == k || lane == k1 ) { my_cost2 = b2; my_list2 = l2; }
+        }
     }
     if( lane < nb )
+    {
         cell_finish( P, A, xy_mine, my_cost, my_list );
+        if( A.dual )
+            cell_finish( P, A, xy_mine, my_cost2, my_list2, true );
+    }
 }
 
 // ---- batched vtable primitives: SAD / SATD of every block of a plane against a displaced reference ----

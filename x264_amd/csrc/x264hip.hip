@@ -83,15 +83,15 @@ struct FrameSlot
     // Callers ask for some B cell classes now with, now without the list-1 reference's own vectors (slicetype.c:629: it depends on
     // whether that frame has been searched as a P frame by then).  When both happen often the minority variant is speculated as well,
     // into the slot's one spare cell; a request for it copies map and sums over (no evaluation, no wait for an on-demand launch).
-    CellEntry alt;
-    int alt_idx = -1;                 // the (d0, d1) class the spare holds, -1: free
+    std::vector<CellEntry> alts;      // [n_cells]: the speculative OTHER variant of B cell idx, evaluated into spare cell n_cells + idx
     // host-side state of the device fields
     unsigned char field_ready[2][X264HIP_BFRAME_MAX + 1]; // searched (any variant) and complete on the stream
     unsigned char field_prefetched[2][X264HIP_BFRAME_MAX + 1]; // unweighted field computed speculatively, not yet claimed
     // window shard: the field was searched on the rank that owns this frame -- 1: nothing of it is here (the tag stands for it),
     // 2: its vectors are here (x264hip_import_cell_map), its costs are not.  0: an ordinary local field
     unsigned char field_remote[2][X264HIP_BFRAME_MAX + 1];
-    int *cell_sums = nullptr;         // [(bf+2)*(bf+2)][8] device copy of the cell sums (x264hip_export_cells)
+    int *cell_sums = nullptr;         // [2 (bf+2)*(bf+2)][8] device copy of the cell sums (x264hip_export_cells)
+    int *cell_work = nullptr;         // [2 (bf+2)*(bf+2)][8] work words of cell_reduce_kernel
     // speculation by position (x264hip_gop_hint): the ( period, position ) this frame was speculated under, and what it was asked for
     int pos_key = 0;                  // period * 32 + position, 0 = no expectation
     unsigned req_fields[2] = { 0, 0 };// bit d: (list, distance d + 1) requested
@@ -132,7 +132,7 @@ struct x264hip_ctx
     unsigned long long *me_prof = nullptr; // ME_PROFILE builds: 8 cycle accumulators of the search kernel (device), else unused
     int n_cells = 0;                 // (bframes+2)^2
     int *cell_acc_host = nullptr;    // pinned [slots][n_cells][8]: sums of every cell evaluation, written by the device directly
-    int *cell_alt_host = nullptr;    // pinned [slots][8]: sums of a slot's spare cell (FrameSlot alt)
+    int *cell_alt_host = nullptr;    // pinned [slots][n_cells][8]: sums of the spare cells (FrameSlot alts)
     DescRing cell_ring, put_ring, search_ring, xfer_ring;
     int xfer_cap = 2048;
     unsigned *err_host = nullptr;    // pinned: sticky in-kernel timeout flag, written by the device directly
@@ -461,8 +461,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     ctx->pos_field_req.assign( (size_t)x264hip_ctx::POS_KEYS * 2 * ( X264HIP_BFRAME_MAX + 1 ), 0 );
     ctx->pos_cell_req.assign( (size_t)x264hip_ctx::POS_KEYS * ctx->n_cells, 0 );
     OPENCK( hipHostMalloc( &ctx->cell_acc_host, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
-    OPENCK( hipHostMalloc( &ctx->cell_alt_host, (size_t)p.max_frames * 8 * sizeof( int ) ) );
-    memset( ctx->cell_alt_host, 0, (size_t)p.max_frames * 8 * sizeof( int ) );
+    OPENCK( hipHostMalloc( &ctx->cell_alt_host, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
+    memset( ctx->cell_alt_host, 0, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) );
     memset( ctx->cell_acc_host, 0, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) );
     OPENCK( hipHostMalloc( &ctx->err_host, sizeof( unsigned ) ) );
     *ctx->err_host = 0;
@@ -514,14 +514,15 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         const size_t o_mbs = off; off += align_up( ctx->n_mb * sizeof( uint2 ), 256 );
         const size_t o_mvq = off; off += align_up( (size_t)2 * nd * ctx->n_mb * sizeof( unsigned long long ), 256 );
         const size_t o_mvc = off; off += align_up( (size_t)2 * nd * ctx->n_mb * sizeof( int ), 256 );
-        // (one cell more than the reference has: the spare holds the speculative SECOND variant of a B cell class, see CellEntry alt)
-        const size_t o_lc = off; off += align_up( (size_t)( nc + 1 ) * ctx->n_mb * sizeof( uint16_t ), 256 );
-        const size_t o_rows = off; off += align_up( (size_t)( nc + 1 ) * mb_h * sizeof( int ), 256 );
-        const size_t o_blk = off; off += align_up( (size_t)( nc + 1 ) * ctx->n_mb * sizeof( int ), 256 );
+        // (twice the cells the reference has: spare nc + idx holds the speculative SECOND variant of B cell idx, see FrameSlot alts)
+        const size_t o_lc = off; off += align_up( (size_t)( 2 * nc ) * ctx->n_mb * sizeof( uint16_t ), 256 );
+        const size_t o_rows = off; off += align_up( (size_t)( 2 * nc ) * mb_h * sizeof( int ), 256 );
+        const size_t o_blk = off; off += align_up( (size_t)( 2 * nc ) * ctx->n_mb * sizeof( int ), 256 );
         const size_t o_prop = off; off += align_up( (size_t)ctx->n_mb * sizeof( int ), 256 );
         const size_t o_qpa = off; off += align_up( (size_t)ctx->n_mb * sizeof( float ), 256 );
         const size_t o_qp = off; off += align_up( (size_t)ctx->n_mb * sizeof( float ), 256 );
-        const size_t o_sums = off; off += align_up( (size_t)( nc + 1 ) * 8 * sizeof( int ), 256 );
+        const size_t o_sums = off; off += align_up( (size_t)( 2 * nc ) * 8 * sizeof( int ), 256 );
+        const size_t o_work = off; off += align_up( (size_t)( 2 * nc ) * 8 * sizeof( int ), 256 ); // cell_reduce_kernel's work words (zero between launches)
         char *base = nullptr;
         OPENCK( hipMalloc( &base, off ) );
         OPENCK( hipMemset( base, 0, off ) );
@@ -539,7 +540,9 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         s.blk = (int *)( base + o_blk );
         s.prop = s.prop_view = (int *)( base + o_prop ); s.qp_aq = (float *)( base + o_qpa ); s.qp = (float *)( base + o_qp );
         s.cell_sums = (int *)( base + o_sums );
+        s.cell_work = (int *)( base + o_work );
         s.cells.assign( nc, CellEntry() );
+        s.alts.assign( nc, CellEntry() );
         s.req_cells.assign( nc, 0 );
         memset( s.field_tag, 0, sizeof( s.field_tag ) );
         memset( s.field_ready, 0, sizeof( s.field_ready ) );
@@ -659,7 +662,7 @@ static void slot_reset( x264hip_ctx *ctx, FrameSlot &s )
     memset( s.field_tag, 0, sizeof( s.field_tag ) );
     memset( s.field_remote, 0, sizeof( s.field_remote ) );
     s.cells.assign( ctx->n_cells, CellEntry() );
-    s.alt = CellEntry(); s.alt_idx = -1;
+    s.alts.assign( ctx->n_cells, CellEntry() );
     if( s.wplane_idx >= 0 ) { ctx->wplane_owner[s.wplane_idx] = -1; s.wplane_idx = -1; }
     ctx->counters[3]++;
 }
@@ -1075,23 +1078,33 @@ static CellArgs make_cell( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_
     A.blk = b.blk + (size_t)idx * ctx->n_mb;
     A.acc = ctx->cell_acc_host + ( (size_t)slot_b * ctx->n_cells + idx ) * 8; // pinned, device-visible
     A.acc_dev = b.cell_sums + (size_t)idx * 8;
+    A.work = b.cell_work + (size_t)idx * 8;
     if( to_spare )
     {
-        // the slot's spare cell: its own map, block words, row sums and sums; the intra row sums are the frame's (same values)
-        const int sp = ctx->n_cells;
+        // the cell's spare: its own map, block words, row sums and sums; the intra row sums are the frame's (same values)
+        const int sp = ctx->n_cells + idx;
         A.lowres_costs = b.lowres_costs + (size_t)sp * ctx->n_mb;
         A.row_satds = b.row_satds + (size_t)sp * P.mb_h;
         A.blk = b.blk + (size_t)sp * ctx->n_mb;
-        A.acc = ctx->cell_alt_host + (size_t)slot_b * 8;
+        A.acc = ctx->cell_alt_host + ( (size_t)slot_b * ctx->n_cells + idx ) * 8;
         A.acc_dev = b.cell_sums + (size_t)sp * 8;
+        A.work = b.cell_work + (size_t)sp * 8;
     }
     return A;
+}
+
+// workgroups per cell of cell_reduce_kernel: enough of them over the whole launch to spread it over the chip, each with at least 4 rows
+static int reduce_bands( const LaP &P, int n_cells_in_launch )
+{
+    const int by_rows = std::max( 1, P.mb_h / 4 ), by_chip = std::max( 1, 512 / std::max( 1, n_cells_in_launch ) );
+    return std::min( std::min( by_rows, by_chip ), 32 );
 }
 
 struct SpecCell
 {
     int slot_p0, slot_p1, slot_b, d0, d1, sums_only, ref1_valid;
     int to_spare = 0;
+    int dual = 0; // B cell with the list-1 reference's vectors: the outcome WITHOUT them is produced in the same pass, into the cell's spare
 };
 
 // one batch: all P cells, all B cells, then one reduction launch (a workgroup per cell)
@@ -1099,9 +1112,10 @@ template <typename T>
 static int launch_cells_t( x264hip_ctx *ctx, const std::vector<SpecCell> &cells )
 {
     const LaP &P = ctx->P;
-    for( size_t o = 0; o < cells.size(); o += ctx->cell_desc_cap )
+    const size_t per_launch = (size_t)ctx->cell_desc_cap / 2; // a cell evaluated both ways takes a second descriptor (its spare half's sums)
+    for( size_t o = 0; o < cells.size(); o += per_launch )
     {
-        const int n = (int)std::min( cells.size() - o, (size_t)ctx->cell_desc_cap );
+        const int n = (int)std::min( cells.size() - o, per_launch );
         int ri = 0;
         if( ring_acquire( ctx->cell_ring, &ri ) ) return X264HIP_EDEVICE;
         CellArgs *dh = (CellArgs *)ctx->cell_ring.host[ri], *dd = (CellArgs *)ctx->cell_ring.dev[ri];
@@ -1118,19 +1132,26 @@ static int launch_cells_t( x264hip_ctx *ctx, const std::vector<SpecCell> &cells 
                 if( pass == 0 ) n_p++;
                 if( pass == 1 ) n_b++;
             }
+        int n_red = n; // descriptors the reduction walks: every cell, then the spare halves of the cells evaluated both ways
         for( int i = 0; i < n; i++ )
         {
             const SpecCell &c = *ord[i];
             dh[i] = make_cell<T>( ctx, c.slot_p0, c.slot_p1, c.slot_b, c.d0, c.d1, 1, c.ref1_valid, c.sums_only, c.to_spare );
+            if( c.dual )
+            {
+                const CellArgs S = make_cell<T>( ctx, c.slot_p0, c.slot_p1, c.slot_b, c.d0, c.d1, 1, 0, 0, 1 );
+                dh[i].dual = 1; dh[i].lowres_costs2 = S.lowres_costs; dh[i].blk2 = S.blk;
+                dh[n_red++] = S;
+            }
         }
-        HIPCK( upload_async( ctx, dd, dh, (size_t)n * sizeof( CellArgs ), ctx->stream ) );
+        HIPCK( upload_async( ctx, dd, dh, (size_t)n_red * sizeof( CellArgs ), ctx->stream ) );
         CellArgs none;
         memset( &none, 0, sizeof( none ) );
         if( n_p )
             cell_p_kernel<<<dim3( ( ctx->n_mb + 255 ) / 256, n_p ), 256, 0, ctx->stream>>>( P, dd, none );
         if( n_b )
             cell_b_kernel<T><<<dim3( ( P.mb_w + CELLB_BPW - 1 ) / CELLB_BPW, P.mb_h, n_b ), 64, 0, ctx->stream>>>( P, dd + n_p, none );
-        cell_reduce_kernel<<<n, 1024, 0, ctx->stream>>>( P, dd, none ); // sums go straight to pinned host memory (256 ... 1024 threads: no difference end to end)
+        cell_reduce_kernel<<<dim3( n_red, reduce_bands( P, n_red ) ), 256, 0, ctx->stream>>>( P, dd, none ); // sums go straight to pinned host memory
         HIPCK( hipGetLastError() );
         if( ring_commit( ctx->cell_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
     }
@@ -1220,6 +1241,7 @@ extern "C" int x264hip_prefetch_ex( x264hip_ctx *ctx, const int *slots, const in
     // (unweighted speculative or already claimed fields).  Entries remember the field tags they consumed.
     std::vector<SpecCell> cells;
     if( getenv( "X264HIP_NO_SPEC_CELLS" ) ) return X264HIP_OK; // debugging aid: searches only
+    static const bool no_dual = getenv( "X264HIP_NO_DUAL" ) != nullptr; // A/B runs: one variant per B cell, chosen by the requests so far
     std::vector<int> by_number; // frame number -> index in the lists (small window: linear scans are fine)
     auto find = [&]( int number ) { for( int k = 0; k < n; k++ ) if( frame_numbers[k] == number ) return k; return -1; };
     auto has_field = [&]( FrameSlot &f, int list, int dm1 ) { return ( f.field_ready[list][dm1] || f.field_prefetched[list][dm1] ) && !f.field_remote[list][dm1]; };
@@ -1243,42 +1265,44 @@ extern "C" int x264hip_prefetch_ex( x264hip_ctx *ctx, const int *slots, const in
                 if( learned && !ctx->cell_req[d0 * nstride + d1] ) continue;
                 if( learned && cell_rate && (uint64_t)ctx->cell_req[d0 * nstride + d1] * 100 < cell_rate * frames_seen ) continue;
                 if( !pos_wants_cell( b, d0 * nstride + d1 ) ) continue;
-                int j1 = j0, variant = 1;
+                int j1 = j0, variant = 1, dual = 0;
                 unsigned t1 = 0, tr = 0;
                 if( d1 )
                 {
                     j1 = find( frame_numbers[i] + d1 );
                     if( j1 < 0 || !has_field( b, 1, d1 - 1 ) ) continue;
                     FrameSlot &f1 = ctx->slots[slots[j1]];
-                    const uint32_t *rq = ctx->variant_req[d0 * nstride + d1];
-                    variant = rq[0] > rq[1] ? 0 : 1;
-                    if( variant && !has_field( f1, 0, d0 + d1 - 1 ) ) continue;
+                    // Which way the caller will ask for a B cell -- with or without the list-1 reference's own list-0 vectors
+                    // (slicetype.c:629) -- depends on the order of its requests.  The two outcomes share their three candidate costs, so
+                    // one pass of the cell kernel produces both: with the vectors into the cell's own place, without them into its spare
+                    // (FrameSlot alts); if the reference's field does not exist only the second is possible.  (Rounds 2-3 speculated the
+                    // variant asked for more often so far and the other one into ONE spare per frame: a fresh context -- every pass of a
+                    // single stream -- knew nothing, and 766 of the 2 281 requests of a 250-frame 4K pass were evaluated on demand.)
+                    const bool with_r = has_field( f1, 0, d0 + d1 - 1 );
+                    variant = with_r ? 1 : 0;
+                    dual = with_r && !no_dual;
+                    if( no_dual )
+                    {
+                        const uint32_t *rq = ctx->variant_req[d0 * nstride + d1];
+                        variant = rq[0] > rq[1] ? 0 : 1;
+                        if( variant && !with_r ) continue;
+                    }
                     t1 = b.field_tag[1][d1 - 1];
                     tr = variant ? f1.field_tag[0][d0 + d1 - 1] : 0;
                 }
                 e.valid = 1; e.batch = ctx->batch_serial + 1; e.variant = (unsigned char)variant;
                 e.tag0 = b.field_tag[0][d0 - 1]; e.tag1 = t1; e.tagr = tr;
                 ctx->cell_spec[d0 * nstride + d1]++;
-                cells.push_back( SpecCell{ slots[j0], slots[d1 ? j1 : i], slots[i], d0, d1, 0, variant } );
-                if( d1 && b.alt_idx < 0 )
+                SpecCell sc{ slots[j0], slots[d1 ? j1 : i], slots[i], d0, d1, 0, variant };
+                sc.dual = dual;
+                cells.push_back( sc );
+                if( dual )
                 {
-                    // both variants of this class are asked for often (each at least a quarter of the requests): the other one goes
-                    // into the slot's spare cell
-                    const uint32_t *rq = ctx->variant_req[d0 * nstride + d1];
-                    const uint32_t all = rq[0] + rq[1];
-                    FrameSlot &f1 = ctx->slots[slots[j1]];
-                    const int other = !variant;
-                    if( all >= 8 && 4 * rq[0] >= all && 4 * rq[1] >= all && ( !other || has_field( f1, 0, d0 + d1 - 1 ) ) )
-                    {
-                        b.alt_idx = d0 * nstride + d1;
-                        b.alt = CellEntry();
-                        b.alt.valid = 1; b.alt.batch = ctx->batch_serial + 1; b.alt.variant = (unsigned char)other;
-                        b.alt.tag0 = e.tag0; b.alt.tag1 = t1; b.alt.tagr = other ? f1.field_tag[0][d0 + d1 - 1] : 0;
-                        SpecCell sc{ slots[j0], slots[j1], slots[i], d0, d1, 0, other };
-                        sc.to_spare = 1;
-                        cells.push_back( sc );
-                        ctx->counters[14]++;
-                    }
+                    CellEntry &a = b.alts[d0 * nstride + d1];
+                    a = CellEntry();
+                    a.valid = 1; a.batch = ctx->batch_serial + 1; a.variant = 0;
+                    a.tag0 = e.tag0; a.tag1 = t1; a.tagr = 0;
+                    ctx->counters[14]++;
                 }
             }
         }
@@ -1429,23 +1453,29 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
     const bool hit = e.valid && e.tag0 == t0 && e.tag1 == t1 && e.tagr == tr && ( !b_bidir || e.variant == ( ref1_l0_valid ? 1 : 0 ) );
     if( b_bidir )
         ctx->variant_req[idx][ref1_l0_valid ? 1 : 0]++;
-    if( !hit && b_bidir && b.alt_idx == idx && b.alt.valid && b.alt.tag0 == t0 && b.alt.tag1 == t1 && b.alt.tagr == tr &&
-        b.alt.variant == ( ref1_l0_valid ? 1 : 0 ) )
+    if( !hit && b_bidir && b.alts[idx].valid && b.alts[idx].tag0 == t0 && b.alts[idx].tag1 == t1 && b.alts[idx].tagr == tr &&
+        b.alts[idx].variant == ( ref1_l0_valid ? 1 : 0 ) )
     {
-        // the other variant was speculated into the spare cell: move it to the cell's own place (stream-ordered, nothing to wait for
+        // the other variant was speculated into the cell's spare: move it to the cell's own place (stream-ordered, nothing to wait for
         // beyond the batch that evaluated it) and answer from its sums
-        int r = batch_wait( ctx, b.alt.batch );
+        CellEntry &a = b.alts[idx];
+        int r = batch_wait( ctx, a.batch );
         if( r ) return r;
-        const int sp = ctx->n_cells;
+        if( e.requested ) // a cell the caller asks for again may be one a queued MB-tree list reads (x264hip.h: x264hip_mbtree)
+        {
+            r = mbt_flush( ctx );
+            if( r ) return r;
+        }
+        const int sp = ctx->n_cells + idx;
         cell_move_kernel<<<( ctx->n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( b.lowres_costs + (size_t)idx * ctx->n_mb, b.lowres_costs + (size_t)sp * ctx->n_mb,
                                                                             b.blk + (size_t)idx * ctx->n_mb, b.blk + (size_t)sp * ctx->n_mb,
                                                                             b.row_satds + (size_t)idx * P.mb_h, b.row_satds + (size_t)sp * P.mb_h,
                                                                             b.cell_sums + (size_t)idx * 8, b.cell_sums + (size_t)sp * 8, ctx->n_mb, P.mb_h );
         HIPCK( hipGetLastError() );
-        const int *ra = ctx->cell_alt_host + (size_t)slot_b * 8;
+        const int *ra = ctx->cell_alt_host + ( (size_t)slot_b * ctx->n_cells + idx ) * 8;
         out->cost_est = ra[0]; out->cost_est_aq = ra[1]; out->intra_mbs = ra[2];
         out->intra_cost_est = ra[3]; out->intra_cost_est_aq = ra[4];
-        b.alt.valid = 0; b.alt_idx = -1;
+        a.valid = 0;
         e.requested = 1; e.valid = 0; e.map_remote = 0;
         ctx->counters[4]++; ctx->counters[15]++; ctx->counters[1]++;
         return X264HIP_OK;
@@ -1491,7 +1521,7 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
             cell_b_kernel<T><<<dim3( ( P.mb_w + CELLB_BPW - 1 ) / CELLB_BPW, P.mb_h, 1 ), 64, 0, ctx->stream>>>( P, nullptr, A );
         else
             cell_p_kernel<<<dim3( ( ctx->n_mb + 255 ) / 256, 1 ), 256, 0, ctx->stream>>>( P, nullptr, A );
-        cell_reduce_kernel<<<1, 256, 0, ctx->stream>>>( P, nullptr, A );
+        cell_reduce_kernel<<<dim3( 1, reduce_bands( P, 1 ) ), 256, 0, ctx->stream>>>( P, nullptr, A );
         HIPCK( hipGetLastError() );
         int r = sync_stream( ctx );
         if( r ) return r;
@@ -3258,11 +3288,10 @@ __global__ __launch_bounds__( 64 ) void import_cells_kernel( const CellXfer *__r
         X.acc_dev[threadIdx.x] = v;
         __hip_atomic_store( X.acc_host + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM ); // pinned host record
     }
+    // (the intra row sums of the summary are NOT taken over: the rank that decides evaluates the intra sums of every frame itself --
+    // x264hip_spec_cells with a d0 == 0 entry -- and an owner that never did would overwrite them with zeros)
     for( int i = threadIdx.x; i < mb_h; i += 64 )
-    {
         X.rows[i] = s[8 + i];
-        X.rows_intra[i] = s[8 + mb_h + i];
-    }
 }
 
 static CellXfer make_xfer( x264hip_ctx *ctx, const x264hip_cell_ref &c )

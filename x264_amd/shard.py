@@ -461,7 +461,7 @@ class HipAdapter:
         self._ck(self.L.x264hip_import_cell_map(self.h, self._refs([cell]), self.C.c_void_p(t.data_ptr())), "import_cell_map")
 
 
-def run_window_shard(torch, lib, dist, rank, world, dev_index, cfg, dev_clip, exchange_on_device, qp_offsets=False, broadcast_input=False):
+def run_window_shard(torch, lib, dist, rank, world, dev_index, cfg, dev_clip, exchange_on_device, qp_offsets=False, broadcast_input=False, vbv=False):
     """One pass of ONE stream over `world` ranks: returns (outputs on rank 0 | None, seconds, WindowShard.stats).
     dev_clip: [F, H, W] tensor of the whole clip resident on this rank's GPU (the same content on every rank), or, with
     broadcast_input, the clip on rank 0 and an uninitialised tensor of the same shape elsewhere: the one input copy is then broadcast
@@ -492,7 +492,7 @@ def run_window_shard(torch, lib, dist, rank, world, dev_index, cfg, dev_clip, ex
         outs = None
         if rank == 0:
             try:
-                outs = la.run(device_ptrs=ptrs, stride=W, paced=False, qp_offsets=qp_offsets)
+                outs = la.run(device_ptrs=ptrs, stride=W, paced=False, qp_offsets=qp_offsets, vbv=vbv)
             finally:
                 if world > 1:
                     ws.stop()  # also on failure: the other ranks are waiting for a command
