@@ -365,6 +365,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # --gpus N is a claim about the launch (python -m torch.distributed.run --nproc-per-node N ...): a line that says n_gpus = N must
+        # come from N ranks
+        print("bench.py: --gpus %d but WORLD_SIZE is %d (launch with python -m torch.distributed.run --nnodes=1 --nproc-per-node %d ...)" %
+              (args.gpus, world, args.gpus), file=sys.stderr)
+        raise SystemExit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the lookahead path has no CPU fallback")
     # one process per GPU; the modulo only matters for the single-GPU test rig (X264HIP_BENCH_BACKEND=gloo)
@@ -380,6 +386,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=datetime.timedelta(minutes=10))  # RCCL over xGMI
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            print("bench.py: the process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus), file=sys.stderr)
+            raise SystemExit(2)
 
     W, H, F = args.width, args.height, args.frames
     over = dict(me=args.me, threads=args.threads)
@@ -497,6 +506,7 @@ def main():
             "value": round(world * S * F * args.steps / dt, 2),
             "unit": "frames/s",
             "n_gpus": world,
+            "rccl_ranks": world if (world == 1 or backend == "nccl") else 0,  # ranks of the RCCL process group the summaries were gathered over
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -591,6 +601,16 @@ def main():
             # rc-lookahead 60); a dozen frames per segment: the window never fills, every frame is decided at the flush
             other_config("configs4_8k_1gpu", "7680x4320 10-bit, --preset veryslow --me tesa (BASELINE configs[4], one GPU)",
                          lib.la_config(7680, 4320, "veryslow", bit_depth=10, me="tesa"), 12, 4, 6, depth_x=10, cuts=(7,))
+            # ONE stream alone on the GPU (one context, one host thread: what a single encoder instance sees), batched and
+            # encoder-paced, for configs[1] and configs[2]; same check as above
+            res["single_stream"] = {}
+            for key_s, what_s, cfg_s, F_s in (("configs1", "1920x1080 8-bit, --preset slow --me dia (BASELINE configs[1])", cfg, F),
+                                              ("configs2", "3840x2160 8-bit, --preset slower --me umh --merange 32 (BASELINE configs[2])",
+                                               lib.la_config(3840, 2160, "slower", bit_depth=8, me="umh", me_range=32), 64)):
+                other_config("_single", what_s, cfg_s, F_s, 1, 4)
+                one = res.pop("_single")
+                res["single_stream"][key_s] = one if "error" in one else {"workload": one["workload"], "batched_fps": one["value"], "paced_fps": one["paced_fps"],
+                                                                          "unit": "frames/s", "checked": one["checked"]}
             # BASELINE configs[3] on one GPU: one 250-frame 4K GOP, --bframes 8 --rc-lookahead 60, ONE stream (the N = 1 point of the window shard)
             try:
                 w1 = window_shard_bench(torch, lib, shard, None, 0, 1, dev_index, backend, steps=2, paced_check=True)
@@ -650,6 +670,7 @@ def window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend,
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         if k > 0:
             best = float(t.item()) if best is None else min(best, float(t.item()))
+        dt_last = float(t.item())
     res = None
     ok = torch.ones(1, dtype=torch.int32, device="cuda")
     if rank == 0:
@@ -685,6 +706,20 @@ def window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend,
         else:
             res["value"] = round(frames / best, 2)
             res["cells_and_searches"] = {"searches": stats.get("searches_here", 0), "cells": stats.get("cells_here", 0), "cells_on_demand": stats.get("cells_on_demand", 0)}
+            # What a window shard can reach from here: the searches and the cost cells are what moves to the owner ranks (frame b on rank
+            # b % N); everything else of this pass -- ingest, intra, decisions, MB-tree, waiting for the last batch -- stays on rank 0.
+            # Both parts measured in THIS pass: HIP events around every search and cell launch on the context's stream, wall time around
+            # the pass.  The prediction leaves the exchange out (summaries of 8 + 2 mb_h ints per cell, list-0 fields of the list-1
+            # references); the measured N > 1 line carries its own serial_fraction_measured.
+            par = (stats.get("device_ms_searches", 0.0) + stats.get("device_ms_cells", 0.0)) / 1e3
+            if 0 < par < dt_last:
+                ser = dt_last - par
+                res["amdahl"] = {"pass_seconds": round(dt_last, 4), "shardable_seconds": round(par, 4), "serial_seconds": round(ser, 4),
+                                 "device_ms": {"searches": stats.get("device_ms_searches"), "cells": stats.get("device_ms_cells"),
+                                               "search_launches": stats.get("search_launches"), "cell_launches": stats.get("cell_launches")},
+                                 "predicted_speedup": {str(n): round(dt_last / (ser + par / n), 2) for n in (2, 4, 8)},
+                                 "what": "T(N) = serial + shardable / N with both terms measured in the last N = 1 pass (searches + cost cells by HIP events on the "
+                                         "context's stream; serial = wall time of the pass minus that); exchange not included"}
             if paced_check:
                 # the same stream through the encoder-paced put / get interface: same types, same cost cells
                 la = lib.Lookahead(cfg, device=dev_index, max_frames=0)

@@ -446,6 +446,9 @@ int  x264hip_counters( x264hip_ctx *ctx, uint64_t *out, int n );
 /* Per-launch HIP-event timing of the search kernel on the context's stream.  Returns the totals gathered
  * since profiling was last (re)enabled; enable = 1/0 switches it and clears the totals, -1 only reads. */
 int  x264hip_search_profile( x264hip_ctx *ctx, int enable, double *total_ms, uint64_t *launches, uint64_t *searches ); /* [0] searches [1] cells [2] cache hits [3] frames */
+/* The same window's totals for the cost cell launches (cell kernels + their sums): together with the searches, the device work a
+ * window shard spreads over ranks (bench.py: window_shard.amdahl). */
+int  x264hip_cell_profile( x264hip_ctx *ctx, double *total_ms, uint64_t *launches, uint64_t *cells );
 
 
 /* ==================================================================================================

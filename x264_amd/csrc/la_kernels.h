@@ -717,16 +717,6 @@ __global__ __launch_bounds__( 256 ) void cell_reduce_kernel( LaP P, const CellAr
     }
 }
 
-// a speculative cell evaluated into a slot's spare storage takes the place of the cell proper (x264hip.hip, FrameSlot::alt)
-__global__ __launch_bounds__( 256 ) void cell_move_kernel( uint16_t *__restrict__ costs, const uint16_t *__restrict__ costs_s, int *__restrict__ blk, const int *__restrict__ blk_s,
-                                                           int *__restrict__ rows, const int *__restrict__ rows_s, int *__restrict__ sums, const int *__restrict__ sums_s, int n_mb, int mb_h )
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if( i < n_mb ) { costs[i] = costs_s[i]; blk[i] = blk_s[i]; }
-    if( i < mb_h ) rows[i] = rows_s[i];
-    if( i < 8 ) sums[i] = sums_s[i];
-}
-
 // slicetype_frame_cost_recalculate (slicetype.c:999-1024): the cost of an evaluated cell under the frame's current quantiser
 // offsets (f_qp_offset after MB-tree, or f_qp_offset_aq for B frames): cost14 * exp2fix8( qp_offset ), new row sums, and
 // the frame sum over the interior blocks.  One workgroup, a wave per block row (like cell_reduce_kernel); exp2fix8 is the

@@ -1008,7 +1008,14 @@ struct Lookahead
         // (a hooked lookahead -- the window shard -- works in smaller chunks: a chunk is one round of collectives, and the other ranks
         // should be busy with the next one while rank 0 decides on this one)
         static const int chunk_env = getenv( "X264HIP_LA_CHUNK" ) ? ( atoi( getenv( "X264HIP_LA_CHUNK" ) ) > 2 ? atoi( getenv( "X264HIP_LA_CHUNK" ) ) : 2 ) : 0;
-        const int chunk = chunk_frames ? chunk_frames : chunk_env ? chunk_env : prefetch_hook ? 64 : LA_PREFETCH_CHUNK;
+        // read-ahead per submission: 256 frames of 1080p, fewer of larger pictures -- the same amount of device work per submission.  A 4K
+        // stream submitted 256 frames at a time spends its first 60 ms in ONE search launch while the host waits, and speculates every
+        // class for all of them before the first request has told the context which classes this caller asks for (0.136 s per 250-frame
+        // pass against 0.112 s in chunks of 64; 1080p: 22.7 k frames/s at 256 against 21.2 k at 64, profiles/r04_chunk_sweep.txt)
+        const long mbs = (long)( ( p.dev.width + 15 ) / 16 ) * ( ( p.dev.height + 15 ) / 16 );
+        const int by_area = (int)( (long)LA_PREFETCH_CHUNK * 8160 / ( mbs > 0 ? mbs : 1 ) );
+        const int chunk_default = by_area > LA_PREFETCH_CHUNK ? LA_PREFETCH_CHUNK : by_area < 16 ? 16 : by_area;
+        const int chunk = chunk_frames ? chunk_frames : chunk_env ? chunk_env : prefetch_hook ? ( chunk_default < 64 ? chunk_default : 64 ) : chunk_default;
         const int reach = (int)next.size() < i_delay + 2 ? (int)next.size() : i_delay + 2;
         int submitted = 0;
         while( submitted < (int)next.size() && next[submitted]->prefetch_submitted ) submitted++;

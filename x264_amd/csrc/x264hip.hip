@@ -84,6 +84,7 @@ struct FrameSlot
     // whether that frame has been searched as a P frame by then).  When both happen often the minority variant is speculated as well,
     // into the slot's one spare cell; a request for it copies map and sums over (no evaluation, no wait for an on-demand launch).
     std::vector<CellEntry> alts;      // [n_cells]: the speculative OTHER variant of B cell idx, evaluated into spare cell n_cells + idx
+    std::vector<int> cell_at;         // [n_cells]: where the data of cell idx lives -- idx, or n_cells + idx once the caller asked for the variant in the spare
     // host-side state of the device fields
     unsigned char field_ready[2][X264HIP_BFRAME_MAX + 1]; // searched (any variant) and complete on the stream
     unsigned char field_prefetched[2][X264HIP_BFRAME_MAX + 1]; // unweighted field computed speculatively, not yet claimed
@@ -192,6 +193,7 @@ struct x264hip_ctx
     std::vector<int> prof_n;
     int prof_on = 0, prof_used = 0;
     double prof_ms = 0; uint64_t prof_launches = 0, prof_searches = 0;
+    double prof_cell_ms = 0; uint64_t prof_cell_launches = 0, prof_cells = 0; // the same for the cost cell launches (prof_n entries < 0)
     uint64_t counters[16] = { 0 }; // [8] remote fields searched here after all [9] remote cell maps recomputed here [10] maps imported [11] cells imported [12] fields registered as remote [13] searches on demand (x264hip_frame_cost) [14] second variants of B cells speculated [15] ... and used
     // how often callers asked for each B cell class with / without a searched L0 field of the list-1 reference
     // (slicetype.c:629-642): speculation evaluates the variant asked for more often so far
@@ -543,6 +545,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         s.cell_work = (int *)( base + o_work );
         s.cells.assign( nc, CellEntry() );
         s.alts.assign( nc, CellEntry() );
+        s.cell_at.resize( nc );
+        for( int c = 0; c < nc; c++ ) s.cell_at[c] = c;
         s.req_cells.assign( nc, 0 );
         memset( s.field_tag, 0, sizeof( s.field_tag ) );
         memset( s.field_ready, 0, sizeof( s.field_ready ) );
@@ -663,6 +667,7 @@ static void slot_reset( x264hip_ctx *ctx, FrameSlot &s )
     memset( s.field_remote, 0, sizeof( s.field_remote ) );
     s.cells.assign( ctx->n_cells, CellEntry() );
     s.alts.assign( ctx->n_cells, CellEntry() );
+    for( int c = 0; c < ctx->n_cells; c++ ) s.cell_at[c] = c;
     if( s.wplane_idx >= 0 ) { ctx->wplane_owner[s.wplane_idx] = -1; s.wplane_idx = -1; }
     ctx->counters[3]++;
 }
@@ -834,9 +839,9 @@ static int prof_drain( x264hip_ctx *ctx )
         {
             float ms = 0;
             HIPCK( hipEventElapsedTime( &ms, ctx->prof_ev[i], ctx->prof_ev[i + 1] ) );
-            ctx->prof_ms += ms;
-            ctx->prof_launches++;
-            ctx->prof_searches += ctx->prof_n[i / 2];
+            const int k = ctx->prof_n[i / 2];
+            if( k < 0 ) { ctx->prof_cell_ms += ms; ctx->prof_cell_launches++; ctx->prof_cells += (uint64_t)-k; }
+            else { ctx->prof_ms += ms; ctx->prof_launches++; ctx->prof_searches += k; }
         }
     }
     ctx->prof_used = 0;
@@ -1079,6 +1084,8 @@ static CellArgs make_cell( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_
     A.acc = ctx->cell_acc_host + ( (size_t)slot_b * ctx->n_cells + idx ) * 8; // pinned, device-visible
     A.acc_dev = b.cell_sums + (size_t)idx * 8;
     A.work = b.cell_work + (size_t)idx * 8;
+    if( !to_spare )
+        b.cell_at[idx] = idx; // an evaluation into the cell's own place is what the cell is from now on
     if( to_spare )
     {
         // the cell's spare: its own map, block words, row sums and sums; the intra row sums are the frame's (same values)
@@ -1147,11 +1154,26 @@ static int launch_cells_t( x264hip_ctx *ctx, const std::vector<SpecCell> &cells 
         HIPCK( upload_async( ctx, dd, dh, (size_t)n_red * sizeof( CellArgs ), ctx->stream ) );
         CellArgs none;
         memset( &none, 0, sizeof( none ) );
+        hipEvent_t pe1 = nullptr;
+        if( ctx->prof_on )
+        {
+            if( ctx->prof_used + 2 > (int)ctx->prof_ev.size() )
+            {
+                int rc = prof_drain( ctx );
+                if( rc ) return rc;
+            }
+            HIPCK( hipEventRecord( ctx->prof_ev[ctx->prof_used], ctx->stream ) );
+            pe1 = ctx->prof_ev[ctx->prof_used + 1];
+            ctx->prof_n.push_back( -n );
+            ctx->prof_used += 2;
+        }
         if( n_p )
             cell_p_kernel<<<dim3( ( ctx->n_mb + 255 ) / 256, n_p ), 256, 0, ctx->stream>>>( P, dd, none );
         if( n_b )
             cell_b_kernel<T><<<dim3( ( P.mb_w + CELLB_BPW - 1 ) / CELLB_BPW, P.mb_h, n_b ), 64, 0, ctx->stream>>>( P, dd + n_p, none );
         cell_reduce_kernel<<<dim3( n_red, reduce_bands( P, n_red ) ), 256, 0, ctx->stream>>>( P, dd, none ); // sums go straight to pinned host memory
+        if( pe1 )
+            HIPCK( hipEventRecord( pe1, ctx->stream ) );
         HIPCK( hipGetLastError() );
         if( ring_commit( ctx->cell_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
     }
@@ -1456,22 +1478,12 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
     if( !hit && b_bidir && b.alts[idx].valid && b.alts[idx].tag0 == t0 && b.alts[idx].tag1 == t1 && b.alts[idx].tagr == tr &&
         b.alts[idx].variant == ( ref1_l0_valid ? 1 : 0 ) )
     {
-        // the other variant was speculated into the cell's spare: move it to the cell's own place (stream-ordered, nothing to wait for
-        // beyond the batch that evaluated it) and answer from its sums
+        // the other variant was evaluated into the cell's spare: the spare becomes the cell (nothing to wait for beyond the batch that
+        // evaluated it) and the answer comes from its sums
         CellEntry &a = b.alts[idx];
         int r = batch_wait( ctx, a.batch );
         if( r ) return r;
-        if( e.requested ) // a cell the caller asks for again may be one a queued MB-tree list reads (x264hip.h: x264hip_mbtree)
-        {
-            r = mbt_flush( ctx );
-            if( r ) return r;
-        }
-        const int sp = ctx->n_cells + idx;
-        cell_move_kernel<<<( ctx->n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( b.lowres_costs + (size_t)idx * ctx->n_mb, b.lowres_costs + (size_t)sp * ctx->n_mb,
-                                                                            b.blk + (size_t)idx * ctx->n_mb, b.blk + (size_t)sp * ctx->n_mb,
-                                                                            b.row_satds + (size_t)idx * P.mb_h, b.row_satds + (size_t)sp * P.mb_h,
-                                                                            b.cell_sums + (size_t)idx * 8, b.cell_sums + (size_t)sp * 8, ctx->n_mb, P.mb_h );
-        HIPCK( hipGetLastError() );
+        b.cell_at[idx] = ctx->n_cells + idx; // the spare IS the cell from now on: every reader goes through cell_at (no copy, no launch)
         const int *ra = ctx->cell_alt_host + ( (size_t)slot_b * ctx->n_cells + idx ) * 8;
         out->cost_est = ra[0]; out->cost_est_aq = ra[1]; out->intra_mbs = ra[2];
         out->intra_cost_est = ra[3]; out->intra_cost_est_aq = ra[4];
@@ -1480,7 +1492,7 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
         ctx->counters[4]++; ctx->counters[15]++; ctx->counters[1]++;
         return X264HIP_OK;
     }
-    const int was_valid = e.valid;
+    const int was_valid = e.valid, was_requested = e.requested;
     e.requested = 1;
     e.valid = 0;
     const int *res = ctx->cell_acc_host + ( (size_t)slot_b * ctx->n_cells + idx ) * 8;
@@ -1506,6 +1518,13 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
     else
     {
         ctx->counters[7]++;
+        if( was_requested )
+        {
+            // a cell the caller asks for AGAIN may be one a queued MB-tree list reads (x264hip_mbtree queues lists and reads their inputs
+            // when they are launched): the lists go first, then the map is rewritten
+            int rf = mbt_flush( ctx );
+            if( rf ) return rf;
+        }
         if( !intra_only )
         {
             // inputs that so far exist on another rank only (window shard) are searched here now, under the tag they are known by
@@ -1702,7 +1721,7 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
                 else
                 {
                     d.barrier_before = k == 0 || dh[k - 1].type == X264HIP_MBT_ZERO || ( o.type == X264HIP_MBT_PROPAGATE && o.referenced ) || o.type == X264HIP_MBT_FINISH;
-                    d.lowres_costs = b.lowres_costs + (size_t)( o.dist_p0 * nstride + o.dist_p1 ) * ctx->n_mb;
+                    d.lowres_costs = b.lowres_costs + (size_t)b.cell_at[o.dist_p0 * nstride + o.dist_p1] * ctx->n_mb;
                     if( o.type == X264HIP_MBT_PROPAGATE )
                     {
                         d.mvq0 = b.mvq[0][o.dist_p0 - 1];
@@ -1775,7 +1794,7 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
         d.barrier_before = k == n_zero || ( o.type == X264HIP_MBT_PROPAGATE && o.referenced ) || o.type == X264HIP_MBT_FINISH;
         d.prop_b = res_b[order[k]]; d.prop_p0 = res_p0[order[k]]; d.prop_p1 = res_p1[order[k]];
         d.intra_cost = b.lowres_costs; d.inv_qscale = b.inv_qscale;
-        d.lowres_costs = b.lowres_costs + (size_t)( o.dist_p0 * nstride + o.dist_p1 ) * ctx->n_mb;
+        d.lowres_costs = b.lowres_costs + (size_t)b.cell_at[o.dist_p0 * nstride + o.dist_p1] * ctx->n_mb;
         if( o.type == X264HIP_MBT_PROPAGATE )
         {
             d.mvq0 = b.mvq[0][o.dist_p0 - 1];
@@ -1834,7 +1853,7 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
             d.b_bidir = o.dist_p1 > 0;
             d.prop_b = res_b[q]; d.prop_p0 = res_p0[q]; d.prop_p1 = res_p1[q];
             d.intra_cost = b.lowres_costs; d.inv_qscale = b.inv_qscale;
-            d.lowres_costs = b.lowres_costs + (size_t)( o.dist_p0 * nstride + o.dist_p1 ) * ctx->n_mb;
+            d.lowres_costs = b.lowres_costs + (size_t)b.cell_at[o.dist_p0 * nstride + o.dist_p1] * ctx->n_mb;
             d.qp_aq = b.qp_aq; d.qp = b.qp;
             if( o.type == X264HIP_MBT_ZERO )
                 d.lds_b = hold( res_b[q], false, -1, -1 );
@@ -1932,8 +1951,8 @@ extern "C" int x264hip_frame_cost_recalculate( x264hip_ctx *ctx, int slot_b, int
     if( ctx->mbt_pending )
         HIPCK( hipStreamWaitEvent( ctx->stream, ctx->ev_mbt_last, 0 ) );
     int *res = ctx->cell_acc_host + ( (size_t)slot_b * ctx->n_cells + idx ) * 8 + 7; // a spare word of the cell's pinned result record
-    recalc_kernel<<<1, 256, 0, ctx->stream>>>( ctx->P, b.lowres_costs + (size_t)idx * ctx->n_mb, use_aq_offsets ? b.qp_aq : b.qp, ctx->luts_dev,
-                                               b.row_satds + (size_t)idx * ctx->P.mb_h, res );
+    recalc_kernel<<<1, 256, 0, ctx->stream>>>( ctx->P, b.lowres_costs + (size_t)b.cell_at[idx] * ctx->n_mb, use_aq_offsets ? b.qp_aq : b.qp, ctx->luts_dev,
+                                               b.row_satds + (size_t)b.cell_at[idx] * ctx->P.mb_h, res );
     HIPCK( hipGetLastError() );
     int rc = sync_stream( ctx );
     if( rc ) return rc;
@@ -2136,9 +2155,9 @@ extern "C" int x264hip_get_lowres_costs( x264hip_ctx *ctx, int slot, int dist_p0
         if( rc0 ) return rc0;
     }
     if( costs )
-        HIPCK( hipMemcpyAsync( costs, s.lowres_costs + (size_t)idx * ctx->n_mb, ctx->n_mb * sizeof( uint16_t ), hipMemcpyDeviceToHost, ctx->stream ) );
+        HIPCK( hipMemcpyAsync( costs, s.lowres_costs + (size_t)s.cell_at[idx] * ctx->n_mb, ctx->n_mb * sizeof( uint16_t ), hipMemcpyDeviceToHost, ctx->stream ) );
     if( row_satds )
-        HIPCK( hipMemcpyAsync( row_satds, s.row_satds + (size_t)idx * ctx->P.mb_h, ctx->P.mb_h * sizeof( int ), hipMemcpyDeviceToHost, ctx->stream ) );
+        HIPCK( hipMemcpyAsync( row_satds, s.row_satds + (size_t)s.cell_at[idx] * ctx->P.mb_h, ctx->P.mb_h * sizeof( int ), hipMemcpyDeviceToHost, ctx->stream ) );
     HIPCK( hipStreamSynchronize( ctx->stream ) );
     return X264HIP_OK;
 }
@@ -2182,6 +2201,7 @@ extern "C" int x264hip_search_profile( x264hip_ctx *ctx, int enable, double *tot
     if( enable >= 0 )
     {
         ctx->prof_ms = 0; ctx->prof_launches = 0; ctx->prof_searches = 0;
+        ctx->prof_cell_ms = 0; ctx->prof_cell_launches = 0; ctx->prof_cells = 0;
         ctx->prof_on = enable;
         if( enable && ctx->prof_ev.empty() )
         {
@@ -2190,6 +2210,19 @@ extern "C" int x264hip_search_profile( x264hip_ctx *ctx, int enable, double *tot
                 HIPCK( hipEventCreate( &e ) );
         }
     }
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_cell_profile( x264hip_ctx *ctx, double *total_ms, uint64_t *launches, uint64_t *cells )
+{
+    if( !ctx ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    int rc = prof_drain( ctx );
+    if( rc ) return rc;
+    if( total_ms ) *total_ms = ctx->prof_cell_ms;
+    if( launches ) *launches = ctx->prof_cell_launches;
+    if( cells ) *cells = ctx->prof_cells;
     return X264HIP_OK;
 }
 
@@ -3294,14 +3327,17 @@ __global__ __launch_bounds__( 64 ) void import_cells_kernel( const CellXfer *__r
         X.rows[i] = s[8 + i];
 }
 
-static CellXfer make_xfer( x264hip_ctx *ctx, const x264hip_cell_ref &c )
+static CellXfer make_xfer( x264hip_ctx *ctx, const x264hip_cell_ref &c, bool importing )
 {
     FrameSlot &b = ctx->slots[c.slot_b];
     const int idx = c.dist_p0 * ( ctx->p.bframes + 2 ) + c.dist_p1;
+    if( importing )
+        b.cell_at[idx] = idx; // a summary from the owner rank goes to the cell's own place
+    const int at = b.cell_at[idx];
     CellXfer X;
     X.acc_host = ctx->cell_acc_host + ( (size_t)c.slot_b * ctx->n_cells + idx ) * 8;
-    X.acc_dev = b.cell_sums + (size_t)idx * 8;
-    X.rows = b.row_satds + (size_t)idx * ctx->P.mb_h;
+    X.acc_dev = b.cell_sums + (size_t)at * 8;
+    X.rows = b.row_satds + (size_t)at * ctx->P.mb_h;
     X.rows_intra = b.row_satds;
     X.skip = 0; X.pad_ = 0;
     return X;
@@ -3322,7 +3358,7 @@ extern "C" int x264hip_export_cells( x264hip_ctx *ctx, int n, const x264hip_cell
         for( int i = 0; i < m; i++ )
         {
             if( !cell_ref_ok( ctx, cells[o + i] ) ) return X264HIP_EINVAL;
-            xh[i] = make_xfer( ctx, cells[o + i] );
+            xh[i] = make_xfer( ctx, cells[o + i], false );
         }
         HIPCK( upload_async( ctx, xd, xh, (size_t)m * sizeof( CellXfer ), ctx->stream ) );
         export_cells_kernel<<<m, 64, 0, ctx->stream>>>( xd, ctx->P.mb_h, (int *)dst_dev + (size_t)o * per );
@@ -3354,7 +3390,7 @@ extern "C" int x264hip_import_cells( x264hip_ctx *ctx, int n, const x264hip_cell
             if( !b.in_use ) return X264HIP_ESTATE;
             const int d0 = c.dist_p0, d1 = c.dist_p1;
             CellEntry &e = b.cells[d0 * ns + d1];
-            xh[i] = make_xfer( ctx, c );
+            xh[i] = make_xfer( ctx, c, true );
             // the cell stands for the fields as this context knows them now (registered with x264hip_fields_remote, or local)
             auto known = [&]( FrameSlot &f, int l, int dm1 ) { return f.field_ready[l][dm1] || f.field_prefetched[l][dm1]; };
             const int variant = d1 && c.with_ref1_l0;
@@ -3440,7 +3476,7 @@ extern "C" int x264hip_export_cell_map( x264hip_ctx *ctx, const x264hip_cell_ref
     const int d0 = cell->dist_p0, d1 = cell->dist_p1, idx = d0 * ( ctx->p.bframes + 2 ) + d1;
     const CellEntry &e = b.cells[idx];
     if( !b.in_use || e.map_remote || ( !e.valid && !e.requested ) ) return X264HIP_ESTATE; // the map has to have been evaluated HERE
-    export_map_kernel<<<( ctx->n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( b.lowres_costs + (size_t)idx * ctx->n_mb, b.mvq[0][d0 - 1], d1 ? b.mvq[1][d1 - 1] : nullptr,
+    export_map_kernel<<<( ctx->n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( b.lowres_costs + (size_t)b.cell_at[idx] * ctx->n_mb, b.mvq[0][d0 - 1], d1 ? b.mvq[1][d1 - 1] : nullptr,
                                                                           (int *)dst_dev, ctx->n_mb );
     HIPCK( hipGetLastError() );
     return X264HIP_OK;

@@ -106,6 +106,13 @@ def search_profile(L, ctx_handle, enable=-1):
     return ms.value, int(nl.value), int(ns.value)
 
 
+def cell_profile(L, ctx_handle):
+    """(total_ms, launches, cells) of the cost cell launches in the window x264hip_search_profile opened."""
+    ms, nl, ns = C.c_double(), C.c_uint64(), C.c_uint64()
+    _ck(L.x264hip_cell_profile(ctx_handle, C.byref(ms), C.byref(nl), C.byref(ns)), "cell_profile")
+    return ms.value, int(nl.value), int(ns.value)
+
+
 class Context:
     """Thin object view of x264hip_ctx."""
 

@@ -477,7 +477,9 @@ def run_window_shard(torch, lib, dist, rank, world, dev_index, cfg, dev_clip, ex
         cmd_group = dist.new_group(backend="gloo")  # commands are a few int64 words: keep them off the GPU
     ws = WindowShard(adapter, dist, rank, world, device=dev if (exchange_on_device and cmd_group is None) else None, cmd_group=cmd_group)
     # every rank opens the same context geometry; only rank 0 drives its lookahead
-    la = lib.Lookahead(cfg, device=dev_index, max_frames=F + 4, prefetch_hook=ws.on_prefetch if rank == 0 else None,
+    # (one rank: nothing to spread -- the context's own speculative submission does the same work in fewer, larger launches and
+    # evaluates every B cell both ways in one pass, x264hip_prefetch)
+    la = lib.Lookahead(cfg, device=dev_index, max_frames=F + 4, prefetch_hook=ws.on_prefetch if rank == 0 and world > 1 else None,
                        mbtree_hook=ws.before_mbtree if rank == 0 and world > 1 else None)
     adapter.attach(la.ctx_handle())
     adapter.own_ingest = rank != 0
@@ -485,6 +487,7 @@ def run_window_shard(torch, lib, dist, rank, world, dev_index, cfg, dev_clip, ex
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
+        lib.search_profile(L, la.ctx_handle(), 1)  # HIP events around the search and cell launches of this pass (the work the shard spreads)
         t0 = time.perf_counter()
         if broadcast_input and world > 1:
             dist.broadcast(dev_clip, src=0)
@@ -502,6 +505,9 @@ def run_window_shard(torch, lib, dist, rank, world, dev_index, cfg, dev_clip, ex
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
+        ms_s, nl_s, n_s = lib.search_profile(L, la.ctx_handle(), -1)
+        ms_c, nl_c, n_c = lib.cell_profile(L, la.ctx_handle())
+        ws.stats.update(device_ms_searches=round(ms_s, 3), search_launches=nl_s, device_ms_cells=round(ms_c, 3), cell_launches=nl_c, cells_in_launches=n_c)
         counters = np.zeros(16, np.uint64)
         import ctypes as C
         lib._ck(L.x264hip_counters(la.ctx_handle(), counters.ctypes.data_as(C.c_void_p), 16), "counters")
