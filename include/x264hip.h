@@ -424,8 +424,9 @@ typedef struct x264hip_quant_functions
     int (*quant_2x2_dc)( void *dct /* dctcoef[4] */, int mf, int bias );
 } x264hip_quant_functions;
 int  x264hip_quant_fill( x264hip_ctx *ctx, x264hip_quant_functions *pf );
-/* x264_pixel_function_t (common/pixel.h:78-100): sad / ssd / satd over the sizes PIXEL_16x16 .. PIXEL_4x4, sa8d[PIXEL_16x16], sa8d[PIXEL_8x8],
- * var[PIXEL_16x16 / PIXEL_8x16 / PIXEL_8x8], hadamard_ac[PIXEL_16x16 .. PIXEL_8x8]; entries the reference leaves empty are NULL */
+/* x264_pixel_function_t (common/pixel.h:78-146): sad / ssd / satd over the sizes PIXEL_16x16 .. PIXEL_4x4, sa8d[PIXEL_16x16], sa8d[PIXEL_8x8],
+ * var[PIXEL_16x16 / PIXEL_8x16 / PIXEL_8x8], hadamard_ac[PIXEL_16x16 .. PIXEL_8x8], the x3 / x4 forms, vsad, asd8, var2, ads and the
+ * mbcmp / fpelcmp aliases; entries the reference leaves empty are NULL */
 typedef struct x264hip_pixel_functions
 {
     int (*sad[8])( void *pix1, intptr_t i_stride1, void *pix2, intptr_t i_stride2 );
@@ -434,6 +435,25 @@ typedef struct x264hip_pixel_functions
     int (*sa8d[4])( void *pix1, intptr_t i_stride1, void *pix2, intptr_t i_stride2 );
     uint64_t (*var[4])( void *pix, intptr_t stride );
     uint64_t (*hadamard_ac[4])( void *pix, intptr_t stride );
+    /* several candidates against one source block (common/pixel.h:107-110, pixel.c:441-516): fenc has FENC_STRIDE (16), the candidates share i_stride */
+    void (*sad_x3[7])( void *fenc, void *pix0, void *pix1, void *pix2, intptr_t i_stride, int scores[3] );
+    void (*sad_x4[7])( void *fenc, void *pix0, void *pix1, void *pix2, void *pix3, intptr_t i_stride, int scores[4] );
+    void (*satd_x3[7])( void *fenc, void *pix0, void *pix1, void *pix2, intptr_t i_stride, int scores[3] );
+    void (*satd_x4[7])( void *fenc, void *pix0, void *pix1, void *pix2, void *pix3, intptr_t i_stride, int scores[4] );
+    int (*vsad)( void *pix, intptr_t stride, int height );                                         /* pixel.c:716-723, height 8 or 16 */
+    int (*asd8)( void *pix1, intptr_t stride1, void *pix2, intptr_t stride2, int height );           /* pixel.c:747-754, height 8 or 16 */
+    int (*var2[4])( void *fenc, void *fdec, int ssd[2] );                                          /* [PIXEL_8x16], [PIXEL_8x8] (pixel.c:206-231) */
+    int (*ads[7])( int enc_dc[4], uint16_t *sums, int delta, uint16_t *cost_mvx, int16_t *mvs, int width, int thresh ); /* [PIXEL_16x16] ads4, [PIXEL_16x8] ads2, [PIXEL_8x8] ads1 */
+    /* what mbcmp_init (encoder/encoder.c:1409-1427) copies: satd or sad by the context's subme (> 1) and, for the full-pel tables, --me tesa */
+    int (*mbcmp[8])( void *pix1, intptr_t i_stride1, void *pix2, intptr_t i_stride2 );
+    int (*mbcmp_unaligned[8])( void *pix1, intptr_t i_stride1, void *pix2, intptr_t i_stride2 );
+    int (*fpelcmp[8])( void *pix1, intptr_t i_stride1, void *pix2, intptr_t i_stride2 );
+    void (*fpelcmp_x3[7])( void *fenc, void *pix0, void *pix1, void *pix2, intptr_t i_stride, int scores[3] );
+    void (*fpelcmp_x4[7])( void *fenc, void *pix0, void *pix1, void *pix2, void *pix3, intptr_t i_stride, int scores[4] );
+    int (*sad_aligned[8])( void *pix1, intptr_t i_stride1, void *pix2, intptr_t i_stride2 );
+    /* NOT handed out, deliberately: intra_*_x3_* / intra_*_x9_* (they write their predictions into the encoder's fdec buffer: intra analysis
+     * of the main encode, SURVEY 2 out of scope; the lookahead's own intra costs are intra_kernel behind x264hip_frame_put), ssim[] /
+     * ssim_4x4x2_core / ssim_end4 / ssd_nv12_core (quality statistics, not on the hot path), sa8d_satd (assembly-only pairing). */
 } x264hip_pixel_functions;
 int  x264hip_pixel_fill( x264hip_ctx *ctx, x264hip_pixel_functions *pf );
 /* registers the context for an encoder handle: mbtree_propagate_list( h, ... ) then works on THAT context's picture geometry */

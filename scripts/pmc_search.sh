@@ -22,6 +22,6 @@ for C in "${PASSES[@]}"; do
   if [ -n "$ONLY_PASSES" ] && [[ " $ONLY_PASSES " != *" $i "* ]]; then continue; fi   # ONLY_PASSES="6 7": just the traffic passes
   mkdir -p gpurun_out/${tag}_p$i
   timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/${tag}_p$i -o run -- \
-     python bench.py --no-cpu-baseline --no-primitives --no-extra --no-check --steps 1 --warmup 0 --frames 64 --inflight 1 "$@" > gpurun_out/${tag}_p$i/bench.log 2>&1
+     python bench.py --no-cpu-baseline --no-primitives --no-extra --no-check --steps 1 --warmup 0 --frames ${PMC_FRAMES:-160} --inflight 1 "$@" > gpurun_out/${tag}_p$i/bench.log 2>&1
   echo "pass $i rc=$? ($C)"
 done

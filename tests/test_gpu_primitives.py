@@ -355,9 +355,20 @@ _CMP = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t)
 _ONE = C.CFUNCTYPE(C.c_uint64, C.c_void_p, C.c_ssize_t)
 
 
+_X3 = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p)
+_X4 = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p)
+
+
 class PixelFunctions(C.Structure):
-    """x264hip_pixel_functions (member names and signatures of x264_pixel_function_t, common/pixel.h:78-100)"""
-    _fields_ = [("sad", _CMP * 8), ("ssd", _CMP * 8), ("satd", _CMP * 8), ("sa8d", _CMP * 4), ("var", _ONE * 4), ("hadamard_ac", _ONE * 4)]
+    """x264hip_pixel_functions (member names and signatures of x264_pixel_function_t, common/pixel.h:78-146)"""
+    _fields_ = [("sad", _CMP * 8), ("ssd", _CMP * 8), ("satd", _CMP * 8), ("sa8d", _CMP * 4), ("var", _ONE * 4), ("hadamard_ac", _ONE * 4),
+                ("sad_x3", _X3 * 7), ("sad_x4", _X4 * 7), ("satd_x3", _X3 * 7), ("satd_x4", _X4 * 7),
+                ("vsad", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_ssize_t, C.c_int)),
+                ("asd8", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int)),
+                ("var2", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p) * 4),
+                ("ads", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int) * 7),
+                ("mbcmp", _CMP * 8), ("mbcmp_unaligned", _CMP * 8), ("fpelcmp", _CMP * 8), ("fpelcmp_x3", _X3 * 7), ("fpelcmp_x4", _X4 * 7),
+                ("sad_aligned", _CMP * 8)]
 
 
 _SUB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p)
@@ -417,6 +428,44 @@ def test_table_fillers_exact_signature_members(depth):
             if idx < 4:
                 assert pf.hadamard_ac[idx](_ptr(fdec, 70), 32) == o.f("hadamard_ac", C.c_uint64)(_ptr(fdec, 70), 32, w, h), ("hadamard_ac", w, h)
         assert not pf.sa8d[1] and not pf.var[1] and not pf.sad[7]  # entries the reference leaves empty stay NULL
+        # sad_x3 / sad_x4 / satd_x3 / satd_x4 (common/pixel.c:441-516): one source block (FENC_STRIDE) against three / four candidates of a
+        # reference plane with its own stride, every size
+        plane = rng.integers(0, maxv + 1, size=(40, 72)).astype(o.dtype)
+        for idx, (w, h) in enumerate(sizes):
+            a = _ptr(fenc, 16 * (16 - h) + (16 - w))
+            offs = [5 * 72 + 9, 6 * 72 + 10, 4 * 72 + 8, 5 * 72 + 11]
+            for name, fo in (("sad", "sad"), ("satd", "satd")):
+                want = [o.f(fo, C.c_int)(a, 16, _ptr(plane, off), 72, w, h) for off in offs]
+                s3, s4 = np.full(3, -1, np.int32), np.full(4, -1, np.int32)
+                getattr(pf, name + "_x3")[idx](a, *[_ptr(plane, off) for off in offs[:3]], 72, _ptr(s3))
+                getattr(pf, name + "_x4")[idx](a, *[_ptr(plane, off) for off in offs], 72, _ptr(s4))
+                assert s3.tolist() == want[:3] and s4.tolist() == want, (name, w, h)
+        # vsad / asd8 (pixel.c:716-754)
+        for hgt in (16, 8):
+            assert pf.vsad(_ptr(fdec, 3 * 32 + 5), 32, hgt) == o.f("vsad", C.c_int)(_ptr(fdec, 3 * 32 + 5), 32, hgt)
+            assert pf.asd8(_ptr(fenc, 4), 16, _ptr(fdec, 2 * 32 + 7), 32, hgt) == o.f("asd8", C.c_int)(_ptr(fenc, 4), 16, _ptr(fdec, 2 * 32 + 7), 32, hgt)
+        # var2[PIXEL_8x16] / [PIXEL_8x8] (pixel.c:206-231): the chroma halves of the encoder's fenc / fdec buffers
+        cfe = rng.integers(0, maxv + 1, size=(16, 16)).astype(o.dtype); cfd = rng.integers(0, maxv + 1, size=(16, 32)).astype(o.dtype)
+        for slot, hgt in ((2, 16), (3, 8)):
+            ws, gs = np.zeros(2, np.int32), np.zeros(2, np.int32)
+            want = o.f("var2", C.c_int)(_ptr(cfe), _ptr(cfd), hgt, _ptr(ws))
+            assert pf.var2[slot](_ptr(cfe), _ptr(cfd), _ptr(gs)) == want and np.array_equal(gs, ws), ("var2", hgt)
+        assert not pf.var2[0] and not pf.ads[2]
+        # ads[PIXEL_16x16] = ads4, [PIXEL_16x8] = ads2, [PIXEL_8x8] = ads1 (pixel.c:756-803)
+        sums = rng.integers(0, 1 << 16, size=400).astype(np.uint16); cost = rng.integers(0, 200, size=200).astype(np.uint16)
+        for slot, ndc in ((0, 4), (1, 2), (3, 1)):
+            for width, thresh in ((37, 60000), (150, 90000), (8, 0)):
+                dc = rng.integers(0, 1 << 16, size=4).astype(np.int32)
+                want = np.zeros(width, np.int16); got = np.full(width, -7, np.int16)
+                r = o.f("ads", C.c_int)(ndc, _ptr(dc), _ptr(sums), 32, _ptr(cost), _ptr(want), width, thresh)
+                assert pf.ads[slot](_ptr(dc), _ptr(sums), 32, _ptr(cost), _ptr(got), width, thresh) == r and np.array_equal(got[:r], want[:r]), ("ads", ndc, width)
+        # mbcmp / fpelcmp (mbcmp_init, encoder/encoder.c:1409-1427): this context has subme 7 and me dia -> mbcmp = satd, fpelcmp = sad
+        a, b = _ptr(fenc), _ptr(fdec, 64)
+        assert pf.mbcmp[0](a, 16, b, 32) == pf.satd[0](a, 16, b, 32) == pf.mbcmp_unaligned[0](a, 16, b, 32)
+        assert pf.fpelcmp[3](a, 16, b, 32) == pf.sad[3](a, 16, b, 32) == pf.sad_aligned[3](a, 16, b, 32)
+        s3a, s3b = np.zeros(3, np.int32), np.zeros(3, np.int32)
+        pf.fpelcmp_x3[0](a, _ptr(plane, 80), _ptr(plane, 81), _ptr(plane, 152), 72, _ptr(s3a)); pf.sad_x3[0](a, _ptr(plane, 80), _ptr(plane, 81), _ptr(plane, 152), 72, _ptr(s3b))
+        assert np.array_equal(s3a, s3b)
         # dct members: (kind of x264hip_dct_batch, member)
         for kind, name in ((0, "sub4x4_dct"), (1, "sub8x8_dct"), (2, "sub16x16_dct"), (3, "sub8x8_dct8"), (4, "sub16x16_dct8"), (5, "sub8x8_dct_dc"), (6, "sub8x16_dct_dc")):
             bs = 16 if "16x16" in name else 8 if "8x" in name else 4

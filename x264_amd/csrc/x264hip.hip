@@ -3053,6 +3053,68 @@ int vt_cmp( void *pix1, intptr_t s1, void *pix2, intptr_t s2 ) { return (int)vt_
 template <int D, int METRIC, int SIZE>
 uint64_t vt_one( void *pix, intptr_t stride ) { return vt_block_metric<D>( METRIC, SIZE, pix, stride, nullptr, 0 ); }
 
+// several candidates against one source block: one staged call per candidate (fenc has FENC_STRIDE)
+template <int D, int METRIC, int SIZE>
+void vt_x3( void *fenc, void *p0, void *p1, void *p2, intptr_t stride, int scores[3] )
+{
+    void *p[3] = { p0, p1, p2 };
+    for( int k = 0; k < 3; k++ )
+        scores[k] = (int)vt_block_metric<D>( METRIC, SIZE, fenc, VT_FENC_STRIDE, p[k], stride );
+}
+template <int D, int METRIC, int SIZE>
+void vt_x4( void *fenc, void *p0, void *p1, void *p2, void *p3, intptr_t stride, int scores[4] )
+{
+    void *p[4] = { p0, p1, p2, p3 };
+    for( int k = 0; k < 4; k++ )
+        scores[k] = (int)vt_block_metric<D>( METRIC, SIZE, fenc, VT_FENC_STRIDE, p[k], stride );
+}
+template <int D>
+int vt_vsad( void *pix, intptr_t stride, int height )
+{
+    if( height != 16 && height != 8 ) return 0; // the reference calls it with the rows of a macroblock (pair) only
+    return (int)vt_block_metric<D>( X264HIP_METRIC_VSAD, height == 16 ? 0 : 1, pix, stride, nullptr, 0 );
+}
+template <int D>
+int vt_asd8( void *pix1, intptr_t s1, void *pix2, intptr_t s2, int height )
+{
+    if( height != 16 && height != 8 ) return 0;
+    return (int)vt_block_metric<D>( X264HIP_METRIC_ASD8, height == 16 ? 2 : 3, pix1, s1, pix2, s2 );
+}
+template <int D, int H>
+int vt_var2( void *fenc, void *fdec, int ssd[2] )
+{
+    int var = 0;
+    vt_guard<D>( [&]( x264hip_ctx *ctx ) {
+        const int psz = ctx->psz;
+        std::vector<char> fe( (size_t)16 * VT_FENC_STRIDE * psz, 0 ), fd( (size_t)16 * VT_FDEC_STRIDE * psz, 0 );
+        for( int y = 0; y < H; y++ )
+        {
+            // U at column 0, V at column stride / 2 of the encoder's chroma buffers (common/macroblock.c: p_fenc[1] / p_fenc[2])
+            memcpy( &fe[(size_t)y * VT_FENC_STRIDE * psz], (const char *)fenc + (size_t)y * VT_FENC_STRIDE * psz, (size_t)VT_FENC_STRIDE * psz );
+            memcpy( &fd[(size_t)y * VT_FDEC_STRIDE * psz], (const char *)fdec + (size_t)y * VT_FDEC_STRIDE * psz, (size_t)( VT_FDEC_STRIDE / 2 + 8 ) * psz );
+        }
+        VTRC( x264hip_var2_batch( ctx, H, 1, fe.data(), fd.data(), &var, ssd ) );
+    } );
+    return var;
+}
+template <int D, int NDC>
+int vt_ads( int enc_dc[4], uint16_t *sums, int delta, uint16_t *cost_mvx, int16_t *mvs, int width, int thresh )
+{
+    int count = 0;
+    vt_guard<D>( [&]( x264hip_ctx *ctx ) {
+        if( width <= 0 ) return;
+        x264hip_ads_call c;
+        memset( &c, 0, sizeof( c ) );
+        c.n_dc = NDC; c.delta = delta; c.width = width; c.thresh = thresh;
+        for( int k = 0; k < NDC; k++ ) c.enc_dc[k] = enc_dc[k];
+        const size_t n_sums = (size_t)( NDC == 4 ? delta + 8 : NDC == 2 ? delta : 0 ) + width;
+        std::vector<int16_t> out( (size_t)width );
+        VTRC( x264hip_ads_batch( ctx, 1, &c, sums, n_sums, cost_mvx, (size_t)width, out.data(), (size_t)width, &count ) );
+        memcpy( mvs, out.data(), (size_t)count * sizeof( int16_t ) ); // the reference writes the surviving candidates only
+    } );
+    return count;
+}
+
 template <int D>
 void fill_mc( x264hip_mc_functions *pf )
 {
@@ -3077,7 +3139,7 @@ void fill_quant( x264hip_quant_functions *pf )
     pf->quant_4x4_dc = vt_quant_dc<D, 3>; pf->quant_2x2_dc = vt_quant_dc<D, 4>;
 }
 template <int D>
-void fill_pixel( x264hip_pixel_functions *pf )
+void fill_pixel( x264hip_pixel_functions *pf, bool satd, bool satd_fpel )
 {
     memset( pf, 0, sizeof( *pf ) );
 #define VT_SIZE( S ) pf->sad[S] = vt_cmp<D, -1, S>; pf->satd[S] = vt_cmp<D, -2, S>; pf->ssd[S] = vt_cmp<D, X264HIP_METRIC_SSD, S>;
@@ -3087,6 +3149,26 @@ void fill_pixel( x264hip_pixel_functions *pf )
     pf->var[0] = vt_one<D, X264HIP_METRIC_VAR, 0>; pf->var[2] = vt_one<D, X264HIP_METRIC_VAR, 2>; pf->var[3] = vt_one<D, X264HIP_METRIC_VAR, 3>;
     pf->hadamard_ac[0] = vt_one<D, X264HIP_METRIC_HADAMARD_AC, 0>; pf->hadamard_ac[1] = vt_one<D, X264HIP_METRIC_HADAMARD_AC, 1>;
     pf->hadamard_ac[2] = vt_one<D, X264HIP_METRIC_HADAMARD_AC, 2>; pf->hadamard_ac[3] = vt_one<D, X264HIP_METRIC_HADAMARD_AC, 3>;
+#define VT_MULTI( S ) pf->sad_x3[S] = vt_x3<D, -1, S>; pf->sad_x4[S] = vt_x4<D, -1, S>; pf->satd_x3[S] = vt_x3<D, -2, S>; pf->satd_x4[S] = vt_x4<D, -2, S>;
+    VT_MULTI( 0 ) VT_MULTI( 1 ) VT_MULTI( 2 ) VT_MULTI( 3 ) VT_MULTI( 4 ) VT_MULTI( 5 ) VT_MULTI( 6 )
+#undef VT_MULTI
+    pf->vsad = vt_vsad<D>; pf->asd8 = vt_asd8<D>;
+    pf->var2[2] = vt_var2<D, 16>; pf->var2[3] = vt_var2<D, 8>;                       // PIXEL_8x16, PIXEL_8x8 (pixel.c:880-881)
+    pf->ads[0] = vt_ads<D, 4>; pf->ads[1] = vt_ads<D, 2>; pf->ads[3] = vt_ads<D, 1>; // PIXEL_16x16, PIXEL_16x8, PIXEL_8x8 (pixel.c:883-885)
+    // mbcmp_init (encoder/encoder.c:1409-1427): satd for sub-pel refinement and mode decision from subme 2 on, for the full-pel search with
+    // --me tesa on top of that
+    for( int i = 0; i < 8; i++ )
+    {
+        pf->sad_aligned[i] = pf->sad[i];
+        pf->mbcmp[i] = satd ? pf->satd[i] : pf->sad_aligned[i];
+        pf->mbcmp_unaligned[i] = satd ? pf->satd[i] : pf->sad[i];
+        pf->fpelcmp[i] = satd_fpel ? pf->satd[i] : pf->sad[i];
+    }
+    for( int i = 0; i < 7; i++ )
+    {
+        pf->fpelcmp_x3[i] = satd_fpel ? pf->satd_x3[i] : pf->sad_x3[i];
+        pf->fpelcmp_x4[i] = satd_fpel ? pf->satd_x4[i] : pf->sad_x4[i];
+    }
 }
 int vt_bind( x264hip_ctx *ctx )
 {
@@ -3127,7 +3209,8 @@ extern "C" int x264hip_pixel_fill( x264hip_ctx *ctx, x264hip_pixel_functions *pf
     if( !pf ) return X264HIP_EINVAL;
     int rc = vt_bind( ctx );
     if( rc ) return rc;
-    if( ctx->p.bit_depth == 8 ) fill_pixel<0>( pf ); else fill_pixel<1>( pf );
+    // (the context's parameters say which metric the tables select: x264hip_params mbcmp_satd / fpelcmp_satd)
+    if( ctx->p.bit_depth == 8 ) fill_pixel<0>( pf, ctx->p.mbcmp_satd != 0, ctx->p.fpelcmp_satd != 0 ); else fill_pixel<1>( pf, ctx->p.mbcmp_satd != 0, ctx->p.fpelcmp_satd != 0 );
     return X264HIP_OK;
 }
 extern "C" int x264hip_mc_bind_handle( x264hip_ctx *ctx, const void *encoder_handle )
