@@ -111,6 +111,7 @@ __device__ __forceinline__ Px8 win_px8( const unsigned char *lds, int v, int row
 }
 
 #define TEAM_BAD ( (int)0x80000000 )
+#define TEAM_NONE ( (int)0x80000000 ) // no packed vector looks like this (mvy = -32768)
 
 // The evaluator of me_logic.h on the team geometry: candidate sets across the 8 lanes of a group (me_search.h), samples out of the window.
 template <typename T, int LDS_TAB, int WEIGHTED>
@@ -425,8 +426,16 @@ template <typename T, int A, int B> __device__ __forceinline__ void set_grp( Tea
 
 // MODE / WEIGHTED as in me_rows_kernel (me_search.h).  Q.base[] counts TEAMS.  LAT: one search per wave, the candidates of a set across the
 // groups (WaveEval); the team table then holds one team per search.
-template <typename T, int HEX, int MODE, int WEIGHTED, int LAT>
-__global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_team_kernel( LaP P, const SearchDesc<T> *descs, const TeamDesc *teams, MeQueues Q,
+// Block rows (waves) per workgroup of the latency form.  RW > 1 hands vectors from row to row through LDS inside a workgroup; measured with
+// RW = 4 (round 4, 1080p, launches of 24 searches): launch 1.024 ms against 1.019 ms, wait for the row below 2 660 against 2 380 cycles per
+// step -- what a row waits for is the block below-left being SEARCHED (the spread of the step times along the dependency chain), not the
+// trip of its vector through memory.  So the default stays one row per workgroup; -DME_LAT_ROWS=4 builds the other form.
+#ifndef ME_LAT_ROWS
+#define ME_LAT_ROWS 1
+#endif
+#define TEAM_HAND_W 512 // widest row (blocks) handed over through LDS inside a workgroup (8K pictures: 480)
+template <typename T, int HEX, int MODE, int WEIGHTED, int LAT, int RW>
+__global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_team_kernel( LaP P, const SearchDesc<T> *descs, const TeamDesc *teams, MeQueues Q,
                                                                        unsigned *tickets /* [ME_QUEUES * ME_QUEUE_STRIDE] */, unsigned *err_host /* pinned sticky timeout flag */,
                                                                        unsigned spin_limit, unsigned long long *prof /* ME_PROFILE builds: cycle accumulators, else unused */ )
 {
@@ -440,32 +449,46 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_team_kernel( LaP P, con
 #define PF_NOW() __builtin_amdgcn_s_memtime()
 #endif
     const int W = P.mb_w, H = P.mb_h;
+    // RW > 1: a workgroup is RW waves on RW consecutive block rows of one team (wave w on the row w above wave 0's): row to row hand-offs
+    // inside the workgroup go through LDS (a few hundred cycles instead of a round trip to memory), only wave 0 waits for another workgroup
+    const int wv = RW > 1 ? __builtin_amdgcn_readfirstlane( (int)( threadIdx.x >> 6 ) ) : 0;
     // Every wave reports its exit on a second counter; the last one out clears the tickets for the next launch on this stream.
     auto leave = [&]() {
-        if( lane == 0 && atomicAdd( &tickets[1], 1u ) == gridDim.x - 1 )
+        if( lane == 0 && atomicAdd( &tickets[1], 1u ) == gridDim.x * RW - 1 )
         {
             for( int q = 0; q < ME_QUEUES; q++ )
                 atomicExch( &tickets[q * ME_QUEUE_STRIDE], 0u );
             atomicExch( &tickets[1], 0u );
         }
     };
-    const int home = xcc_id();
+    const int n_bands = ( H + RW - 1 ) / RW; // tickets per team: one per workgroup
+    __shared__ int ticket_sh[2];
     int j = 0, tm = -1;
-    for( int k = 0; k < ME_QUEUES && tm < 0; k++ )
+    if( wv == 0 )
     {
-        const int q = ( home + k ) & ( ME_QUEUES - 1 );
-        const int n_q = Q.base[q + 1] - Q.base[q];
-        if( !n_q )
-            continue;
-        unsigned t0 = 0;
-        if( lane == 0 )
-            t0 = atomicAdd( &tickets[q * ME_QUEUE_STRIDE], 1u );
-        const unsigned t = __builtin_amdgcn_readfirstlane( t0 );
-        if( t < (unsigned)( n_q * H ) )
+        const int home = xcc_id();
+        for( int k = 0; k < ME_QUEUES && tm < 0; k++ )
         {
-            j = t / n_q;
-            tm = Q.base[q] + ( t - j * n_q );
+            const int q = ( home + k ) & ( ME_QUEUES - 1 );
+            const int n_q = Q.base[q + 1] - Q.base[q];
+            if( !n_q )
+                continue;
+            unsigned t0 = 0;
+            if( lane == 0 )
+                t0 = atomicAdd( &tickets[q * ME_QUEUE_STRIDE], 1u );
+            const unsigned t = __builtin_amdgcn_readfirstlane( t0 );
+            if( t < (unsigned)( n_q * n_bands ) )
+            {
+                j = t / n_q;
+                tm = Q.base[q] + ( t - j * n_q );
+            }
         }
+        if( RW > 1 && lane == 0 ) { ticket_sh[0] = j; ticket_sh[1] = tm; }
+    }
+    if( RW > 1 )
+    {
+        __syncthreads();
+        j = __builtin_amdgcn_readfirstlane( ticket_sh[0] ); tm = __builtin_amdgcn_readfirstlane( ticket_sh[1] );
     }
     if( tm < 0 )
     {
@@ -474,7 +497,8 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_team_kernel( LaP P, con
     }
     TeamDesc TD = teams[tm];
     TD.first = __builtin_amdgcn_readfirstlane( TD.first ); TD.n = __builtin_amdgcn_readfirstlane( TD.n );
-    const int by = H - 1 - j; // this wave's block row (scalar)
+    const int by = H - 1 - ( RW * j + wv ); // this wave's block row (scalar); above the picture: nothing to do for this wave
+    const bool idle = by < 0;
     const int g = lane >> 3;
     const bool live = LAT || g < TD.n;
     const SearchDesc<T> *dp = descs + TD.first + ( !LAT && live ? g : 0 );
@@ -490,15 +514,27 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_team_kernel( LaP P, con
     const T *sbase = uniform_ptr( descs[TD.first].ref_strips );
     const T *wsbase = WEIGHTED ? uniform_ptr( descs[TD.first].refw_strips ) : sbase;
 
-    __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char win[G::BYTES];
+    __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char win_all[RW * G::BYTES];
     __shared__ uint16_t tab_window[2 * TEAM_TAB_HALF];
+    __shared__ int hand[RW > 1 ? RW : 1][RW > 1 ? TEAM_HAND_W : 1]; // hand[w][x]: the vector wave w found for block x of its row (TEAM_NONE: not yet)
+    unsigned char *win = win_all + wv * G::BYTES;
+    const bool lds_hand = RW > 1 && W <= TEAM_HAND_W;
     {
         const int centre = 2 * 4 * P.mv_range; // P.cost_mv is centred: valid differences are -centre .. +centre
-        for( int i = lane; i < 2 * TEAM_TAB_HALF; i += 64 )
+        for( int i = threadIdx.x; i < 2 * TEAM_TAB_HALF; i += 64 * RW )
         {
             const int d = i - TEAM_TAB_HALF;
             tab_window[i] = d >= -centre && d <= centre ? P.cost_mv[d] : (uint16_t)0;
         }
+        if( RW > 1 )
+            for( int i = threadIdx.x; i < RW * TEAM_HAND_W; i += 64 * RW )
+                hand[i / TEAM_HAND_W][i % TEAM_HAND_W] = TEAM_NONE;
+    }
+    __syncthreads(); // orders the cost table (and the hand-off words) before the first block's reads; the last barrier of the kernel
+    if( idle )
+    {
+        leave();
+        return;
     }
     MeCfg C;
     C.hex = HEX; C.me_range = P.me_range;
@@ -555,10 +591,19 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_team_kernel( LaP P, con
 
     // ---- hand-off state: the vectors of the row below at x+1, x, x-1 (lane 8g of each group holds its search's) ----
     const AS_GLOBAL unsigned long long *below_row = mvq + ( by + 1 ) * W;
+    const bool below_in_lds = lds_hand && wv > 0; // the row below is wave wv - 1 of this workgroup
     auto granule = [&]( int x ) -> unsigned long long { // lane 8g: granule of block (x, by+1) of this group's search, L1-bypassing
         unsigned long long gq = 0;
         if( has_below && leader )
-            gq = __hip_atomic_load( below_row + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+        {
+            if( below_in_lds )
+            {
+                const int v = __hip_atomic_load( &hand[RW > 1 ? wv - 1 : 0][x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+                gq = v == TEAM_NONE ? 0ull : ( (unsigned long long)tag << 32 ) | (unsigned)v;
+            }
+            else
+                gq = __hip_atomic_load( below_row + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+        }
         return gq;
     };
     auto granule_ok = [&]( unsigned long long gq ) -> bool { return !leader || !live || (unsigned)( gq >> 32 ) == tag; };
@@ -575,7 +620,7 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_team_kernel( LaP P, con
                 timed_out = true;
                 return 0ull;
             }
-            __builtin_amdgcn_s_sleep( 4 );
+            if( below_in_lds ) __builtin_amdgcn_s_sleep( 1 ); else __builtin_amdgcn_s_sleep( 4 );
 #ifdef ME_PROFILE
             pf_spins++;
 #endif
@@ -624,7 +669,6 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_team_kernel( LaP P, con
         return r;
     };
     uint4 f_next = source_raw( W - 1 );
-    __syncthreads(); // one wave per workgroup: orders the cost table writes before the first block's reads
 
     int r1 = 0;                     // packed vector of the block to the right (this group's previous result)
     int keep_cost = 0;              // lanes 0..3 of a group: the cost of the block with x % 4 == lane, until the four leave together
@@ -749,6 +793,8 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_team_kernel( LaP P, con
         // blocks slicetype_slice_cost never visits (slicetype.c:823-833) keep zero vectors (frame.c:283-285); the vector leaves at the
         // start of the next step
         const int packed = ( mvx & 0xFFFF ) | ( mvy << 16 );
+        if( lds_hand && leader && live )
+            __hip_atomic_store( &hand[wv][bx], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ); // the wave above polls this word
         if( cost_lane == ( bx & 3 ) )
             keep_cost = cost;
         r1 = packed;

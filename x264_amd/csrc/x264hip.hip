@@ -1005,7 +1005,7 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
                 Q.base[q] = (int)( (long long)units * q / ME_QUEUES ); // contiguous groups: the table is in frame order
             unsigned *tickets = ctx->sync_words + part * ME_QUEUES * ME_QUEUE_STRIDE;
             const TeamDesc *tp = td + ( part ? n_teams[0] : 0 );
-            const int grid_rows = count * n_rowgroups, grid_team = units * P.mb_h;
+            const int grid_rows = count * n_rowgroups, grid_team = units * P.mb_h, grid_lat = units * ( ( P.mb_h + ME_LAT_ROWS - 1 ) / ME_LAT_ROWS );
 #define ME_ARGS_ROWS P, dd + first, Q, tickets, ctx->err_host, 1u << 22, ctx->me_prof
 #define ME_ARGS_TEAM P, dd + first, tp, Q, tickets, ctx->err_host, 1u << 22, ctx->me_prof
 #define ME_LAUNCH( HEXV, MODEV ) do { \
@@ -1013,11 +1013,11 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
                     if( part ) me_rows_kernel<T, HEXV, MODEV, 1><<<grid_rows, 64, 0, ctx->stream>>>( ME_ARGS_ROWS ); \
                     else me_rows_kernel<T, HEXV, MODEV, 0><<<grid_rows, 64, 0, ctx->stream>>>( ME_ARGS_ROWS ); \
                 } else if( lat[part] ) { \
-                    if( part ) me_team_kernel<T, HEXV, MODEV, 1, 1><<<grid_team, 64, 0, ctx->stream>>>( ME_ARGS_TEAM ); \
-                    else me_team_kernel<T, HEXV, MODEV, 0, 1><<<grid_team, 64, 0, ctx->stream>>>( ME_ARGS_TEAM ); \
+                    if( part ) me_team_kernel<T, HEXV, MODEV, 1, 1, ME_LAT_ROWS><<<grid_lat, 64 * ME_LAT_ROWS, 0, ctx->stream>>>( ME_ARGS_TEAM ); \
+                    else me_team_kernel<T, HEXV, MODEV, 0, 1, ME_LAT_ROWS><<<grid_lat, 64 * ME_LAT_ROWS, 0, ctx->stream>>>( ME_ARGS_TEAM ); \
                 } else { \
-                    if( part ) me_team_kernel<T, HEXV, MODEV, 1, 0><<<grid_team, 64, 0, ctx->stream>>>( ME_ARGS_TEAM ); \
-                    else me_team_kernel<T, HEXV, MODEV, 0, 0><<<grid_team, 64, 0, ctx->stream>>>( ME_ARGS_TEAM ); \
+                    if( part ) me_team_kernel<T, HEXV, MODEV, 1, 0, 1><<<grid_team, 64, 0, ctx->stream>>>( ME_ARGS_TEAM ); \
+                    else me_team_kernel<T, HEXV, MODEV, 0, 0, 1><<<grid_team, 64, 0, ctx->stream>>>( ME_ARGS_TEAM ); \
                 } } while( 0 )
             switch( 4 * hex + mode )
             {
