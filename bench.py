@@ -385,7 +385,8 @@ def main():
             # (a collective that never completes ends the run after ten minutes instead of hanging it)
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=datetime.timedelta(minutes=10))  # RCCL over xGMI
         else:
-            dist.init_process_group(backend)
+            import datetime
+            dist.init_process_group(backend, timeout=datetime.timedelta(minutes=10))
         if dist.get_world_size() != args.gpus:
             print("bench.py: the process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus), file=sys.stderr)
             raise SystemExit(2)

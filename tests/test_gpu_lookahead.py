@@ -176,7 +176,10 @@ def _shard_worker(rank, world, port, q):
     frames = make_clip(W, H, nf, seed=12, scene_cuts=(23,), fade=(40, 8, 0.7, 6), pan=(4, 2))
     cfg = L2.la_config(W, H, "medium", bframes=8, rc_lookahead=60)
     dev = torch.from_numpy(frames).cuda()
-    outs, dt, stats = shard.run_window_shard(torch, L2, dist, rank, world, 0, cfg, dev, exchange_on_device=False, qp_offsets=True, vbv=True)
+    if rank:
+        dev.zero_()  # the pictures arrive chunk by chunk from rank 0 (broadcast_input)
+    outs, dt, stats = shard.run_window_shard(torch, L2, dist, rank, world, 0, cfg, dev, exchange_on_device=False, qp_offsets=True, vbv=True,
+                                             broadcast_input=True)
     if rank == 0:
         q.put(dict(sig=[(o.frame, o.type, [o.cost_est[i][j] for i in range(10) for j in range(10)], o.qp_offset.tobytes()) for o in outs],
                    rows=[(o.row_satds.tobytes(), o.row_satds_intra.tobytes()) for o in outs], stats=stats))
@@ -184,6 +187,54 @@ def _shard_worker(rank, world, port, q):
         q.put(dict(stats=stats))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _loopback_worker(port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    import torch
+    import torch.distributed as dist
+    from x264_amd import lib as L2, shard
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))  # RCCL, one rank: the collectives loop back
+    W, H, nf = 704, 576, 70
+    frames = make_clip(W, H, nf, seed=12, scene_cuts=(23,), fade=(40, 8, 0.7, 6), pan=(4, 2))
+    cfg = L2.la_config(W, H, "medium", bframes=8, rc_lookahead=60)
+    dev = torch.from_numpy(frames).cuda()
+    outs, dt, stats = shard.run_window_shard(torch, L2, dist, 0, 1, 0, cfg, dev, exchange_on_device=True, qp_offsets=True, loopback=True)
+    q.put(dict(sig=[(o.frame, o.type, [o.cost_est[i][j] for i in range(10) for j in range(10)], o.qp_offset.tobytes()) for o in outs], stats=stats))
+    dist.destroy_process_group()
+
+
+def test_window_shard_loopback_on_device():
+    """The exchange code path of the window shard as the 8-GPU run will execute it -- Exchange(on_device=True): export kernels, RCCL
+    collectives (broadcast, all_to_all_single, gather) issued under the context's own HIP stream as a torch ExternalStream, imports --
+    on ONE GPU: a one-rank RCCL process group loops every collective back to the sender.  Results must equal the plain run, and every
+    buffer that came back must equal what the export kernels wrote (the collectives really ran behind them on the stream)."""
+    import socket
+    import torch.multiprocessing as mp
+    W, H, nf = 704, 576, 70
+    frames = make_clip(W, H, nf, seed=12, scene_cuts=(23,), fade=(40, 8, 0.7, 6), pan=(4, 2))
+    cfg = lib.la_config(W, H, "medium", bframes=8, rc_lookahead=60)
+    la = lib.Lookahead(cfg, max_frames=nf + 4)
+    try:
+        ref = la.run(frames, paced=False, qp_offsets=True)
+    finally:
+        la.close()
+    want = [(o.frame, o.type, [o.cost_est[i][j] for i in range(10) for j in range(10)], o.qp_offset.tobytes()) for o in ref]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_loopback_worker, args=(port, q))
+    p.start()
+    got = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert got["sig"] == want
+    st = got["stats"]
+    print("window shard loop-back:", st)
+    assert st["chunks"] >= 1 and st["loopback_checks"] >= 2 and st["l0_fields_exchanged"] > 0 and st["cells_imported"] > 0 and st["bytes_l0_sent"] > 0
 
 
 def test_window_shard_two_ranks_on_one_gpu():

@@ -91,8 +91,11 @@ class WindowShard:
         exchange                                         Exchange (below): zeros / all_gather / gather
     """
 
-    def __init__(self, adapter, dist, rank, world, device=None, cmd_group=None):
+    def __init__(self, adapter, dist, rank, world, device=None, cmd_group=None, loopback=False):
         self.a, self.dist, self.rank, self.world, self.device, self.cmd_group = adapter, dist, rank, world, device, cmd_group
+        # loopback (world == 1 only): every exchange step runs anyway, over the one-rank process group, with this rank as its own peer --
+        # the export kernels, the collectives on the context's stream and the imports execute once on a single GPU (run_window_shard)
+        self.loop = bool(loopback) and world == 1
         self.done = set()        # (frame_number, list, dist_m1) fields planned in this or an earlier chunk (same on every rank)
         self.cells_done = set()  # (frame_number, d0, d1)
         self.sums_done = set()   # rank 0: frames whose intra sums have been queued
@@ -100,7 +103,9 @@ class WindowShard:
         self.slot_of = {}        # frame number -> slot, as announced by rank 0
         self.number_in = {}      # slot -> frame number
         self.stats = dict(chunks=0, fields_searched=0, cells_evaluated=0, l0_fields_exchanged=0, cells_imported=0, maps_fetched=0,
-                          bytes_l0_exchange=0, bytes_summaries=0, bytes_maps=0, fetch_commands=0)
+                          bytes_l0_exchange=0, bytes_l0_sent=0, bytes_l0_received=0, bytes_summaries=0, bytes_maps=0, bytes_input_broadcast=0,
+                          fetch_commands=0, loopback_checks=0)
+        self.ingested = set()    # frame numbers whose picture is on this rank (broadcast per chunk)
 
     # ---- the plan of a chunk: identical on every rank ----
     def plan(self, slots, numbers, masks, cell_class):
@@ -136,7 +141,7 @@ class WindowShard:
                             continue
                         if with_l0 and (p1, 0, d0 + d1 - 1) not in self.done:
                             continue
-                        if with_l0 and owner(p1) != owner(ni):
+                        if with_l0 and (owner(p1) != owner(ni) or self.loop):
                             l0_wanted[owner(ni)].add((p1, d0 + d1 - 1))
                     self.cells_done.add((ni, d0, d1))
                     cells[owner(ni)].append((slots[i], here[p0], here[p1], d0, d1, with_l0, ni))
@@ -161,6 +166,18 @@ class WindowShard:
     def _run_chunk(self, slots, numbers, masks, cell_class):
         import torch
         a, X = self.a, self.a.exchange
+        # ---- the pictures of the chunk's new frames: ONE broadcast per run of consecutive frame numbers, on the context's stream (the ingest
+        # kernels of this rank are ordered behind it there; nothing waits on the host)
+        if getattr(a, "bcast_clip", None) is not None and (self.world > 1 or self.loop):
+            new = sorted(n for n in numbers if n not in self.ingested)
+            self.ingested.update(new)
+            lo = 0
+            while lo < len(new):
+                hi = lo
+                while hi + 1 < len(new) and new[hi + 1] == new[hi] + 1:
+                    hi += 1
+                self.stats["bytes_input_broadcast"] += a.broadcast_frames(new[lo], new[hi] + 1)
+                lo = hi + 1
         for s, n in zip(slots, numbers):
             if self.number_in.get(s) != n:
                 self.slot_of.pop(self.number_in.get(s), None)
@@ -172,24 +189,33 @@ class WindowShard:
         a.search([f[:4] for f in mine])
         self.stats["chunks"] += 1
         self.stats["fields_searched"] += len(mine)
-        # ---- list-0 fields that B cells on OTHER ranks read from their list-1 reference: one all_gather of what each rank owns of them
-        if self.world > 1:
+        # ---- list-0 fields that B cells on OTHER ranks read from their list-1 reference: every rank sends each peer exactly the fields
+        # that peer asked for (the plan is the same on every rank, so both sides know the counts), one exchange per chunk
+        if self.world > 1 or self.loop:
             for r in range(self.world):
                 l0_wanted[r] = {k for k in l0_wanted[r] if (r,) + k not in self.l0_sent}
                 self.l0_sent.update((r,) + k for k in l0_wanted[r])
-            give = [sorted({k for r in range(self.world) if r != o for k in l0_wanted[r] if k[0] % self.world == o}) for o in range(self.world)]
-            width = max(len(g) for g in give)
-            if width:
-                buf = X.zeros((width, a.n_mb, 2))
-                if give[self.rank]:
-                    a.export_fields([(self.slot_of[n], 0, dm1) for n, dm1 in give[self.rank]], buf)
-                out = X.all_gather(buf)
+            give = [[sorted(k for k in l0_wanted[r] if k[0] % self.world == o) for r in range(self.world)] for o in range(self.world)]  # [owner][receiver]
+            n_send = [len(g) for g in give[self.rank]]
+            n_recv = [len(give[o][self.rank]) for o in range(self.world)]
+            if sum(len(g) for row in give for g in row):
+                sbuf = X.zeros((max(sum(n_send), 1), a.n_mb, 2))
+                keys = [k for g in give[self.rank] for k in g]
+                if keys:
+                    a.export_fields([(self.slot_of[n], 0, dm1) for n, dm1 in keys], sbuf)
+                rbuf = X.send_recv(sbuf, n_send, n_recv)
+                row = 0
                 for o in range(self.world):
-                    take = [k for k, key in enumerate(give[o]) if key in l0_wanted[self.rank]] if o != self.rank else []
-                    if take:
-                        a.import_fields([(self.slot_of[give[o][k][0]], 0, give[o][k][1]) for k in take], out[o], take)
-                        self.stats["l0_fields_exchanged"] += len(take)
-                self.stats["bytes_l0_exchange"] += (self.world - 1) * width * a.n_mb * 8
+                    got = give[o][self.rank]
+                    if got:
+                        a.import_fields([(self.slot_of[n], 0, dm1) for n, dm1 in got], rbuf, list(range(row, row + len(got))))
+                        self.stats["l0_fields_exchanged"] += len(got)
+                    row += len(got)
+                self.stats["bytes_l0_sent"] += sum(n_send) * a.n_mb * 8
+                self.stats["bytes_l0_received"] += sum(n_recv) * a.n_mb * 8
+                self.stats["bytes_l0_exchange"] += sum(n_recv) * a.n_mb * 8
+                if self.loop and keys:
+                    self._loop_checks = getattr(self, "_loop_checks", []) + [(sbuf[:len(keys)], rbuf[:len(keys)])]
         # ---- the cells of the frames this rank owns; rank 0 also queues the intra sums of every frame (it has all of them resident)
         my_cells = [c[:6] for c in cells[self.rank]]
         sums = []
@@ -198,26 +224,37 @@ class WindowShard:
             self.sums_done.update(numbers)
         a.spec_cells(sums + my_cells)
         self.stats["cells_evaluated"] += len(my_cells)
-        if self.world == 1:
+        if self.world == 1 and not self.loop:
             return
         # ---- summaries to rank 0
-        width = max(len(c) for c in cells[1:])
+        width = max([len(c) for c in cells[1:]] + ([len(cells[0])] if self.loop else [0]))
         if width:
             per = 8 + 2 * a.mb_h
             buf = X.zeros((width, per))
-            if my_cells and self.rank:
+            if my_cells and (self.rank or self.loop):
                 a.export_cells(my_cells, buf)
             out = X.gather(buf)
             if self.rank == 0:
                 remote = [(f[0], f[4], f[2], f[3]) for r in range(1, self.world) for f in fields[r]]
                 a.fields_remote(remote)
-                for r in range(1, self.world):
+                for r in range(0 if self.loop else 1, self.world):
                     if cells[r]:
-                        a.import_cells([c[:6] for c in cells[r]], out[r][:len(cells[r])])
+                        a.import_cells([c[:6] for c in cells[r]], out[r][:len(cells[r])])   # (loopback: every entry is skipped -- the cells are here)
                         self.stats["cells_imported"] += len(cells[r])
                 self.stats["bytes_summaries"] += (self.world - 1) * width * per * 4
+                if self.loop and my_cells:
+                    self._loop_checks = getattr(self, "_loop_checks", []) + [(buf[:len(my_cells)], out[0][:len(my_cells)])]
         elif self.rank == 0:
             a.fields_remote([(f[0], f[4], f[2], f[3]) for r in range(1, self.world) for f in fields[r]])
+
+    def loopback_verify(self, sync):
+        """loopback: what came back from every exchange equals what the export kernels wrote (the collectives ran behind them on the stream)"""
+        import torch
+        sync()
+        for sent, got in getattr(self, "_loop_checks", []):
+            assert torch.equal(sent.cpu(), got.cpu()), "loop-back exchange returned different data"
+            self.stats["loopback_checks"] += 1
+        self._loop_checks = []
 
     # ---- rank 0 ----
     def on_prefetch(self, slots, numbers):
@@ -328,6 +365,49 @@ class Exchange:
             self.dist.all_gather(out, h)
             return self._back(out)
 
+    def send_recv(self, sbuf, n_send, n_recv):
+        """sbuf: rows for peer 0, then for peer 1, ... (n_send[r] rows each, first dimension); returns the rows received, peer after peer
+        (n_recv[r] from rank r).  On the device (RCCL): ONE all_to_all_single with those split sizes on the context's stream.  Staged
+        through the host (gloo has no all-to-all): one isend / irecv per peer with something to move."""
+        import torch
+        rows = max(sum(n_recv), 1)
+        with self._ctx():
+            if self.on_device:
+                out = torch.empty((rows,) + tuple(sbuf.shape[1:]), dtype=sbuf.dtype, device=sbuf.device)
+                self.dist.all_to_all_single(out[:sum(n_recv)], sbuf[:sum(n_send)], output_split_sizes=list(n_recv), input_split_sizes=list(n_send))
+                return out
+            h = self._host(sbuf)
+            out = torch.zeros((rows,) + tuple(h.shape[1:]), dtype=h.dtype)
+            ops, so, ro = [], 0, 0
+            for r in range(self.world):
+                if r == self.rank:
+                    out[ro:ro + n_recv[r]] = h[so:so + n_send[r]]  # (loopback: a rank is its own peer)
+                else:
+                    if n_send[r]:
+                        ops.append(self.dist.P2POp(self.dist.isend, h[so:so + n_send[r]].contiguous(), r))
+                    if n_recv[r]:
+                        ops.append(self.dist.P2POp(self.dist.irecv, out[ro:ro + n_recv[r]], r))
+                so += n_send[r]; ro += n_recv[r]
+            if ops:
+                for w in self.dist.batch_isend_irecv(ops):
+                    w.wait()
+            return self._back([out])[0]
+
+    def broadcast(self, t):
+        """t from rank 0 to everybody, in place"""
+        with self._ctx():
+            if self.on_device or self.dev is None:
+                self.dist.broadcast(t, src=0)
+                return
+            if self.before:
+                self.before()
+            h = t.cpu()
+            self.dist.broadcast(h, src=0)
+            if self.rank:
+                t.copy_(h)
+            if self.after:
+                self.after()
+
     def gather(self, buf):
         import torch
         with self._ctx():
@@ -363,15 +443,14 @@ class HipAdapter:
         L.x264hip_cell_classes.argtypes = [C.c_void_p, C.c_void_p]
         L.x264hip_stream_handle.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
 
-    def attach(self, ctx_handle):
+    def attach(self, ctx_handle, loopback=False):
         """the context exists now: bind the exchange to its stream"""
         import torch
         self.h = ctx_handle
-        stream = None
-        if self.exchange_on_device and self.world > 1:
-            sp = self.C.c_void_p()
-            self._ck(self.L.x264hip_stream_handle(self.h, self.C.byref(sp)), "stream_handle")
-            stream = torch.cuda.ExternalStream(sp.value, device=self.dev)
+        sp = self.C.c_void_p()
+        self._ck(self.L.x264hip_stream_handle(self.h, self.C.byref(sp)), "stream_handle")
+        self.ext = torch.cuda.ExternalStream(sp.value, device=self.dev)  # the context's stream as torch sees it (events, collectives)
+        stream = self.ext if self.exchange_on_device and (self.world > 1 or loopback) else None
         self.stream = stream
         self.exchange = Exchange(self.dist, self.rank, self.world, self.dev, stream,
                                  before=lambda: self._ck(self.L.x264hip_synchronize(self.h), "synchronize"),
@@ -389,11 +468,21 @@ class HipAdapter:
         return arr
 
     def _hold(self, t):
-        """tensors the context's stream still reads: kept for a few calls (every consumer is stream-ordered behind its producer)"""
-        self._keep.append(t)
-        if len(self._keep) > 64:
-            del self._keep[:32]
+        """a tensor the context's stream reads or writes in kernels that have just been enqueued: kept until an event recorded on that
+        stream behind them has completed (not for a number of calls: a slow stream must not lose its buffers)"""
+        import torch
+        ev = torch.cuda.Event()
+        ev.record(self.ext)
+        self._keep.append((ev, t))
+        while self._keep and self._keep[0][0].query():
+            self._keep.pop(0)
         return t
+
+    def broadcast_frames(self, lo, hi):
+        """the pictures of frames lo .. hi-1 from rank 0 to every rank (in place in the clip tensor); returns the bytes a rank receives"""
+        part = self.bcast_clip[lo:hi]
+        self.exchange.broadcast(part)
+        return int(part.numel() * part.element_size()) if self.world > 1 else 0
 
     def ingest(self, slot, number):
         if not self.own_ingest:
@@ -416,28 +505,28 @@ class HipAdapter:
         self._ck(self.L.x264hip_search_fields(self.h, n, arr(0), arr(1), arr(2), arr(3)), "search_fields")
 
     def export_fields(self, keys, out):
-        self._hold(out)
         for i, (slot, lst, dm1) in enumerate(keys):
             self._ck(self.L.x264hip_export_field(self.h, slot, lst, dm1, self.C.c_void_p(out[i].data_ptr())), "export_field")
+        self._hold(out)
 
     def import_fields(self, keys, t, rows):
         assert t.is_contiguous()
-        self._hold(t)
         for (slot, lst, dm1), i in zip(keys, rows):
             self._ck(self.L.x264hip_import_field(self.h, slot, lst, dm1, self.C.c_void_p(t[i].data_ptr())), "import_field")
+        self._hold(t)
 
     def spec_cells(self, cells):
         if cells:
             self._ck(self.L.x264hip_spec_cells(self.h, len(cells), self._refs(cells)), "spec_cells")
 
     def export_cells(self, cells, out):
-        self._hold(out)
         self._ck(self.L.x264hip_export_cells(self.h, len(cells), self._refs(cells), self.C.c_void_p(out.data_ptr())), "export_cells")
+        self._hold(out)
 
     def import_cells(self, cells, t):
         assert t.is_contiguous()
-        self._hold(t)
         self._ck(self.L.x264hip_import_cells(self.h, len(cells), self._refs(cells), self.C.c_void_p(t.data_ptr())), "import_cells")
+        self._hold(t)
 
     def fields_remote(self, keys):
         if not keys:
@@ -452,36 +541,46 @@ class HipAdapter:
         return [bool(v) for v in out]
 
     def export_map(self, cell, out):
-        self._hold(out)
         self._ck(self.L.x264hip_export_cell_map(self.h, self._refs([cell]), self.C.c_void_p(out.data_ptr())), "export_cell_map")
+        self._hold(out)
 
     def import_map(self, cell, t):
         assert t.is_contiguous()
-        self._hold(t)
         self._ck(self.L.x264hip_import_cell_map(self.h, self._refs([cell]), self.C.c_void_p(t.data_ptr())), "import_cell_map")
+        self._hold(t)
 
 
-def run_window_shard(torch, lib, dist, rank, world, dev_index, cfg, dev_clip, exchange_on_device, qp_offsets=False, broadcast_input=False, vbv=False):
+def run_window_shard(torch, lib, dist, rank, world, dev_index, cfg, dev_clip, exchange_on_device, qp_offsets=False, broadcast_input=False, vbv=False,
+                     loopback=False):
     """One pass of ONE stream over `world` ranks: returns (outputs on rank 0 | None, seconds, WindowShard.stats).
     dev_clip: [F, H, W] tensor of the whole clip resident on this rank's GPU (the same content on every rank), or, with
-    broadcast_input, the clip on rank 0 and an uninitialised tensor of the same shape elsewhere: the one input copy is then broadcast
-    inside the timed region (W x H bytes per frame over xGMI) before the ranks make their own lowres planes."""
+    broadcast_input, the clip on rank 0 and an uninitialised tensor of the same shape elsewhere: the pictures are then broadcast inside the
+    timed region, chunk by chunk as the stream advances (W x H bytes per frame over xGMI, on the contexts' streams), before the ranks make
+    their own lowres planes.
+    loopback (world == 1, a one-rank process group): the whole exchange machinery runs with this rank as its own peer -- input broadcast,
+    export kernels, the collectives on the context's stream, imports -- and what comes back is compared with what was sent."""
     import time
     F, W = dev_clip.shape[0], cfg["width"]
     ptrs = [dev_clip[i].data_ptr() for i in range(F)]
     L = lib.load()
     dev = torch.device("cuda", dev_index)
+    loopback = bool(loopback) and world == 1 and dist is not None
     adapter = HipAdapter(L, None, cfg, lambda n: (ptrs[n], W), dev, dist, rank, world, exchange_on_device)
+    adapter.bcast_clip = dev_clip if (broadcast_input and world > 1) or loopback else None
     cmd_group = None
     if world > 1 and exchange_on_device and dist.get_backend() == "nccl":
-        cmd_group = dist.new_group(backend="gloo")  # commands are a few int64 words: keep them off the GPU
-    ws = WindowShard(adapter, dist, rank, world, device=dev if (exchange_on_device and cmd_group is None) else None, cmd_group=cmd_group)
+        import datetime
+        # commands are a few int64 words: keep them off the GPU.  (A rank that fails leaves the protocol; the others then sit in a collective
+        # until this timeout -- ten minutes, like the RCCL group's in bench.py -- instead of for ever.)
+        cmd_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=10))
+    ws = WindowShard(adapter, dist, rank, world, device=dev if (exchange_on_device and cmd_group is None) else None, cmd_group=cmd_group, loopback=loopback)
     # every rank opens the same context geometry; only rank 0 drives its lookahead
-    # (one rank: nothing to spread -- the context's own speculative submission does the same work in fewer, larger launches and
-    # evaluates every B cell both ways in one pass, x264hip_prefetch)
-    la = lib.Lookahead(cfg, device=dev_index, max_frames=F + 4, prefetch_hook=ws.on_prefetch if rank == 0 and world > 1 else None,
+    # (one rank without loopback: nothing to spread -- the context's own speculative submission does the same work in fewer, larger launches
+    # and evaluates every B cell both ways in one pass, x264hip_prefetch)
+    hooked = world > 1 or loopback
+    la = lib.Lookahead(cfg, device=dev_index, max_frames=F + 4, prefetch_hook=ws.on_prefetch if rank == 0 and hooked else None,
                        mbtree_hook=ws.before_mbtree if rank == 0 and world > 1 else None)
-    adapter.attach(la.ctx_handle())
+    adapter.attach(la.ctx_handle(), loopback=loopback)
     adapter.own_ingest = rank != 0
     try:
         torch.cuda.synchronize()
@@ -489,9 +588,6 @@ def run_window_shard(torch, lib, dist, rank, world, dev_index, cfg, dev_clip, ex
             dist.barrier()
         lib.search_profile(L, la.ctx_handle(), 1)  # HIP events around the search and cell launches of this pass (the work the shard spreads)
         t0 = time.perf_counter()
-        if broadcast_input and world > 1:
-            dist.broadcast(dev_clip, src=0)
-            torch.cuda.synchronize()  # (the collective ran on torch's stream; the contexts read the pictures on their own)
         outs = None
         if rank == 0:
             try:
@@ -505,6 +601,8 @@ def run_window_shard(torch, lib, dist, rank, world, dev_index, cfg, dev_clip, ex
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
+        if loopback:
+            ws.loopback_verify(lambda: torch.cuda.synchronize())
         ms_s, nl_s, n_s = lib.search_profile(L, la.ctx_handle(), -1)
         ms_c, nl_c, n_c = lib.cell_profile(L, la.ctx_handle())
         ws.stats.update(device_ms_searches=round(ms_s, 3), search_launches=nl_s, device_ms_cells=round(ms_c, 3), cell_launches=nl_c, cells_in_launches=n_c)
@@ -513,8 +611,6 @@ def run_window_shard(torch, lib, dist, rank, world, dev_index, cfg, dev_clip, ex
         lib._ck(L.x264hip_counters(la.ctx_handle(), counters.ctypes.data_as(C.c_void_p), 16), "counters")
         ws.stats.update(searches_here=int(counters[0]), cells_here=int(counters[5]), cells_on_demand=int(counters[7]), remote_fields_searched_here=int(counters[8]),
                         remote_maps_recomputed_here=int(counters[9]), maps_imported=int(counters[10]), cells_imported_ctx=int(counters[11]))
-        if broadcast_input and world > 1:
-            ws.stats["bytes_input_broadcast"] = int(dev_clip.numel() * dev_clip.element_size())
         return outs, dt, ws.stats
     finally:
         la.close()
