@@ -201,7 +201,8 @@ int  x264hip_prefetch_ex( x264hip_ctx *ctx, const int *slots, const int *frame_n
  * list-1 vectors).  Anything else that needs absent data (a cell evaluated on demand, a getter, a cell MB-tree uses that was not
  * fetched) recomputes it locally: results are identical by construction (a search is a pure function of its two frames).
  * x264hip_field_classes / x264hip_cell_classes: which (list, distance) / (d0, d1) classes the deciding context would speculate, so
- * that it can tell the others (cell class: 0 = none, 1 = without, 2 = with the list-1 reference's vectors). */
+ * that it can tell the others (cell class: 0 = none, 1 = without, 2 = with the list-1 reference's vectors, 3 = both ways where that reference's
+ * field exists).  x264hip_cells_missing: 0 = the map is here, 1 = with its owner, 2 = the map of the cell's SPARE half is with its owner. */
 int  x264hip_search_fields( x264hip_ctx *ctx, int n, const int *slot_b, const int *slot_ref, const int *list, const int *dist_minus1 );
 int  x264hip_export_field( x264hip_ctx *ctx, int slot, int list, int dist_minus1, void *dst_dev );
 int  x264hip_import_field( x264hip_ctx *ctx, int slot, int list, int dist_minus1, const void *src_dev );
@@ -211,8 +212,12 @@ typedef struct x264hip_cell_ref
 {
     int slot_b, slot_p0, slot_p1;   /* frame handles; dist_p0 == dist_p1 == 0: the frame's intra sums */
     int dist_p0, dist_p1;
-    int with_ref1_l0;               /* B cells: evaluated with the list-1 reference's own list-0 vectors */
+    int with_ref1_l0;               /* B cells: X264HIP_CELL_* flags below (0 / 1 as before: without / with the list-1 reference's vectors) */
 } x264hip_cell_ref;
+#define X264HIP_CELL_WITH_L0 1      /* evaluated with the list-1 reference's own list-0 vectors (slicetype.c:629) */
+#define X264HIP_CELL_BOTH 2         /* x264hip_spec_cells: evaluate the cell BOTH ways in one pass -- with the vectors into the cell's own place, without them
+                                     * into its spare half (the caller's later request decides which one the cell is) */
+#define X264HIP_CELL_SPARE 4        /* x264hip_export_cells / _import_cells / _export_cell_map: the entry refers to the spare half (the evaluation WITHOUT the vectors) */
 #define X264HIP_CELL_SUMMARY_INTS( mb_h ) ( 8 + 2 * ( mb_h ) ) /* cost_est, cost_est_aq, intra_mbs, intra_cost_est, intra_cost_est_aq, 3 spare, row sums, intra row sums */
 int  x264hip_spec_cells( x264hip_ctx *ctx, int n, const x264hip_cell_ref *cells );
 int  x264hip_export_cells( x264hip_ctx *ctx, int n, const x264hip_cell_ref *cells, void *dst_dev );

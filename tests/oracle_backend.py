@@ -80,7 +80,7 @@ class OracleBackend:
         inv, qp, s, ssd = self.o.aq_frame(img, self.ocfg.mb_w, self.ocfg.mb_h, c["aq_mode"], c["aq_strength"], cb, cr,
                                             chroma_format=c.get("chroma_format", 1))
         n = self.ocfg.mb_w * self.ocfg.mb_h
-        self.slots[slot] = dict(planes=pl, inv=inv, sum=s, ssd=ssd, intra=self.o.intra_costs(self.ocfg, pl), fields={}, spec={}, maps={}, rows={}, remote=set(), ident={}, sums={}, map_remote={},
+        self.slots[slot] = dict(planes=pl, inv=inv, sum=s, ssd=ssd, intra=self.o.intra_costs(self.ocfg, pl), fields={}, spec={}, maps={}, rows={}, remote=set(), ident={}, sums={}, sums_spare={}, map_remote={},
                                 prop=np.zeros(n, np.uint16), qp_aq=qp.copy(), qp=qp.copy(), img=img, cb=cb, cr=cr)
         return 0
 
@@ -144,6 +144,8 @@ class OracleBackend:
             imp = B["sums"].get((d0, d1))
             ids = (B["ident"].get((0, d0 - 1)), B["ident"].get((1, d1 - 1)) if d1 else None,
                    F1["ident"].get((0, d0 + d1 - 1)) if d1 and ref1_valid else None)
+            if d1 and not (imp is not None and imp["ids"] == ids and imp["with_l0"] == bool(ref1_valid)):
+                imp = B["sums_spare"].get((d0, d1))  # the owner evaluated the cell both ways: the other half (without the list-1 reference's vectors)
             if imp is not None and imp["ids"] == ids and (not d1 or imp["with_l0"] == bool(ref1_valid)):
                 # the owner rank's evaluation of this cell: sums and row sums only, the per-block map stays there
                 self.cells_from_owner += 1
@@ -165,7 +167,7 @@ class OracleBackend:
                     B["fields"], F1["fields"] = fb, f1
                     same = (chk[3].cost_est, chk[3].cost_est_aq, chk[3].intra_mbs) == (co.cost_est, co.cost_est_aq, co.intra_mbs) and np.array_equal(chk[1], rows)
                     assert same, ("imported cell differs", sb, d0, d1, ref1_valid, chk[3].cost_est, co.cost_est, chk[3].intra_mbs, co.intra_mbs)
-                B["map_remote"][(d0, d1)] = dict(s0=s0, s1=s1, with_l0=imp["with_l0"])
+                B["map_remote"][(d0, d1)] = dict(s0=s0, s1=s1, with_l0=imp["with_l0"], spare=imp.get("spare", False))
                 B["maps"].pop((d0, d1), None)
                 lc = None
             else:
@@ -299,10 +301,12 @@ class OracleShardAdapter:
         self.n_mb, self.mb_h, self.bframes = be.ocfg.mb_w * be.ocfg.mb_h, be.ocfg.mb_h, be.cfg["bframes"]
         self.exchange = Exchange(dist, rank, world)
         self.owned = {}
+        self.owned_spare = {}
 
     def ingest(self, slot, number):
-        for k in [k for k in self.owned if k[0] == slot]:
-            del self.owned[k]  # the slot holds another frame now
+        for d in (self.owned, self.owned_spare):
+            for k in [k for k in d if k[0] == slot]:
+                del d[k]  # the slot holds another frame now
         if self.own_ingest:
             self.be.put_array(slot, self.clip[number])
 
@@ -312,7 +316,7 @@ class OracleShardAdapter:
         for d0 in range(1, ns):
             for d1 in range(0, ns - d0):
                 rq = self.be.variant_req.get((d0, d1), [0, 0])
-                cc[d0 * ns + d1] = 2 if d1 and rq[0] <= rq[1] else 1
+                cc[d0 * ns + d1] = 3 if d1 else 1  # B cells: both ways in one pass (x264hip_cell_classes)
         return (1 << (self.bframes + 1)) - 1, (1 << (self.bframes + 1)) - 1, cc
 
     def search(self, reqs):
@@ -356,12 +360,14 @@ class OracleShardAdapter:
     def spec_cells(self, cells):
         for c in cells:
             if c[3] and (c[0], c[3], c[4]) not in self.owned and not self.be.on_prefetch:  # (rank 0 evaluates its own cells on demand)
-                self.owned[(c[0], c[3], c[4])] = self._cell(c)
+                self.owned[(c[0], c[3], c[4])] = self._cell(tuple(c[:5]) + (c[5] & 1,))
+                if c[5] & 2:  # both ways: the spare half is the evaluation without the list-1 reference's vectors
+                    self.owned_spare[(c[0], c[3], c[4])] = self._cell(tuple(c[:5]) + (0,))
 
     def export_cells(self, cells, out):
         import torch
         for i, c in enumerate(cells):
-            lc, rows, rows_i, co = self.owned[(c[0], c[3], c[4])]
+            lc, rows, rows_i, co = (self.owned_spare if c[5] & 4 else self.owned)[(c[0], c[3], c[4])]
             row = np.zeros(8 + 2 * self.mb_h, np.int32)
             row[:5] = (co.cost_est, co.cost_est_aq, co.intra_mbs, co.intra_cost_est, co.intra_cost_est_aq)
             row[8:8 + self.mb_h], row[8 + self.mb_h:] = rows, rows_i
@@ -370,12 +376,14 @@ class OracleShardAdapter:
     def import_cells(self, cells, t):
         from oracle.oraclelib import CellOut
         a = t.numpy()
-        for i, (sb, s0, s1, d0, d1, with_l0) in enumerate(cells):
+        for i, (sb, s0, s1, d0, d1, flags) in enumerate(cells):
             B, F1 = self.be.slots[sb], self.be.slots[s1]
+            spare, with_l0 = bool(flags & 4), bool(flags & 1) and not flags & 4
             co = CellOut()
             co.cost_est, co.cost_est_aq, co.intra_mbs, co.intra_cost_est, co.intra_cost_est_aq = (int(v) for v in a[i, :5])
             ids = (B["ident"].get((0, d0 - 1)), B["ident"].get((1, d1 - 1)) if d1 else None, F1["ident"].get((0, d0 + d1 - 1)) if d1 and with_l0 else None)
-            B["sums"][(d0, d1)] = dict(co=co, rows=a[i, 8:8 + self.mb_h].copy(), rows_i=a[i, 8 + self.mb_h:].copy(), with_l0=bool(with_l0), ids=ids)
+            B["sums_spare" if spare else "sums"][(d0, d1)] = dict(co=co, rows=a[i, 8:8 + self.mb_h].copy(), rows_i=a[i, 8 + self.mb_h:].copy(), with_l0=with_l0, ids=ids,
+                                                                   spare=spare)
 
     def fields_remote(self, keys):
         for slot, number, lst, dm1 in keys:
@@ -386,13 +394,14 @@ class OracleShardAdapter:
             B["ident"][(lst, dm1)] = "unweighted"
 
     def cells_missing(self, cells):
-        return [(c[3], c[4]) in self.be.slots[c[0]]["map_remote"] for c in cells]
+        info = lambda c: self.be.slots[c[0]]["map_remote"].get((c[3], c[4]))  # noqa: E731
+        return [0 if info(c) is None else 2 if info(c).get("spare") else 1 for c in cells]
 
     def export_map(self, cell, out):
         import torch
         sb, s0, s1, d0, d1 = cell[:5]
         B = self.be.slots[sb]
-        lc = self.owned[(sb, d0, d1)][0]
+        lc = (self.owned_spare if len(cell) > 5 and cell[5] & 4 else self.owned)[(sb, d0, d1)][0]
         m = np.zeros((3, self.n_mb), np.int32)
         m[0] = lc
         m[1] = _pack_mv(self._have(B, (0, d0 - 1))[0])

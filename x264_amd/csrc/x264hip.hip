@@ -1487,8 +1487,10 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
         const int *ra = ctx->cell_alt_host + ( (size_t)slot_b * ctx->n_cells + idx ) * 8;
         out->cost_est = ra[0]; out->cost_est_aq = ra[1]; out->intra_mbs = ra[2];
         out->intra_cost_est = ra[3]; out->intra_cost_est_aq = ra[4];
+        e.requested = 1; e.valid = 0;
+        e.variant = a.variant;
+        e.map_remote = a.map_remote; e.slot_p0 = a.slot_p0; e.slot_p1 = a.slot_p1; // (window shard: the spare's map may still be with its owner)
         a.valid = 0;
-        e.requested = 1; e.valid = 0; e.map_remote = 0;
         ctx->counters[4]++; ctx->counters[15]++; ctx->counters[1]++;
         return X264HIP_OK;
     }
@@ -3333,7 +3335,10 @@ extern "C" int x264hip_cell_classes( x264hip_ctx *ctx, unsigned char *cell_class
             const int idx = d0 * ns + d1;
             if( learned && !ctx->cell_req[idx] ) continue;
             const uint32_t *rq = ctx->variant_req[idx];
-            cell_class[idx] = d1 && rq[0] <= rq[1] ? 2 : 1; // the same choice x264hip_prefetch makes
+            // B cells: 3 = both ways in one pass wherever the list-1 reference's field exists (what x264hip_prefetch does); X264HIP_NO_DUAL:
+            // the variant asked for more often so far
+            static const bool no_dual = getenv( "X264HIP_NO_DUAL" ) != nullptr;
+            cell_class[idx] = !d1 ? 1 : !no_dual ? 3 : rq[0] <= rq[1] ? 2 : 1;
         }
     return X264HIP_OK;
 }
@@ -3362,7 +3367,7 @@ extern "C" int x264hip_spec_cells( x264hip_ctx *ctx, int n, const x264hip_cell_r
         CellEntry &e = b.cells[d0 * ns + d1];
         if( e.valid || e.requested ) continue;
         unsigned t0 = 0, t1 = 0, tr = 0;
-        const int variant = d1 && c.with_ref1_l0;
+        const int variant = d1 && ( c.with_ref1_l0 & X264HIP_CELL_WITH_L0 ), dual = variant && ( c.with_ref1_l0 & X264HIP_CELL_BOTH );
         if( d0 )
         {
             // every field the cell reads has to be in this context (searched here, or imported)
@@ -3373,7 +3378,17 @@ extern "C" int x264hip_spec_cells( x264hip_ctx *ctx, int n, const x264hip_cell_r
         }
         e.valid = 1; e.batch = ctx->batch_serial + 1; e.variant = (unsigned char)( d1 ? variant : 1 );
         e.tag0 = t0; e.tag1 = t1; e.tagr = tr; e.map_remote = 0;
-        list.push_back( SpecCell{ c.slot_p0, c.slot_p1, c.slot_b, d0, d1, d0 == 0, variant } );
+        SpecCell sc{ c.slot_p0, c.slot_p1, c.slot_b, d0, d1, d0 == 0, variant };
+        sc.dual = dual;
+        list.push_back( sc );
+        if( dual )
+        {
+            CellEntry &a = b.alts[d0 * ns + d1];
+            a = CellEntry();
+            a.valid = 1; a.batch = ctx->batch_serial + 1; a.variant = 0;
+            a.tag0 = t0; a.tag1 = t1; a.tagr = 0;
+            ctx->counters[14]++;
+        }
     }
     if( list.empty() ) return X264HIP_OK;
     int r = ctx->p.bit_depth == 8 ? launch_cells_t<uint8_t>( ctx, list ) : launch_cells_t<uint16_t>( ctx, list );
@@ -3414,11 +3429,12 @@ static CellXfer make_xfer( x264hip_ctx *ctx, const x264hip_cell_ref &c, bool imp
 {
     FrameSlot &b = ctx->slots[c.slot_b];
     const int idx = c.dist_p0 * ( ctx->p.bframes + 2 ) + c.dist_p1;
-    if( importing )
+    const bool spare = ( c.with_ref1_l0 & X264HIP_CELL_SPARE ) != 0;
+    if( importing && !spare )
         b.cell_at[idx] = idx; // a summary from the owner rank goes to the cell's own place
-    const int at = b.cell_at[idx];
+    const int at = spare ? ctx->n_cells + idx : b.cell_at[idx];
     CellXfer X;
-    X.acc_host = ctx->cell_acc_host + ( (size_t)c.slot_b * ctx->n_cells + idx ) * 8;
+    X.acc_host = ( spare ? ctx->cell_alt_host : ctx->cell_acc_host ) + ( (size_t)c.slot_b * ctx->n_cells + idx ) * 8;
     X.acc_dev = b.cell_sums + (size_t)at * 8;
     X.rows = b.row_satds + (size_t)at * ctx->P.mb_h;
     X.rows_intra = b.row_satds;
@@ -3472,13 +3488,14 @@ extern "C" int x264hip_import_cells( x264hip_ctx *ctx, int n, const x264hip_cell
             FrameSlot &b = ctx->slots[c.slot_b], &f1 = ctx->slots[c.slot_p1];
             if( !b.in_use ) return X264HIP_ESTATE;
             const int d0 = c.dist_p0, d1 = c.dist_p1;
-            CellEntry &e = b.cells[d0 * ns + d1];
+            const bool spare = d1 && ( c.with_ref1_l0 & X264HIP_CELL_SPARE );
+            CellEntry &e = spare ? b.alts[d0 * ns + d1] : b.cells[d0 * ns + d1];
             xh[i] = make_xfer( ctx, c, true );
             // the cell stands for the fields as this context knows them now (registered with x264hip_fields_remote, or local)
             auto known = [&]( FrameSlot &f, int l, int dm1 ) { return f.field_ready[l][dm1] || f.field_prefetched[l][dm1]; };
-            const int variant = d1 && c.with_ref1_l0;
+            const int variant = d1 && !spare && ( c.with_ref1_l0 & X264HIP_CELL_WITH_L0 );
             const bool inputs = known( b, 0, d0 - 1 ) && ( !d1 || ( known( b, 1, d1 - 1 ) && ( !variant || known( f1, 0, d0 + d1 - 1 ) ) ) );
-            if( e.valid || e.requested || !inputs ) { xh[i].skip = 1; continue; }
+            if( e.valid || e.requested || b.cells[d0 * ns + d1].requested || !inputs ) { xh[i].skip = 1; continue; }
             e.valid = 1; e.batch = ctx->batch_serial + 1; e.variant = (unsigned char)( d1 ? variant : 1 );
             e.tag0 = b.field_tag[0][d0 - 1];
             e.tag1 = d1 ? b.field_tag[1][d1 - 1] : 0;
@@ -3522,7 +3539,10 @@ extern "C" int x264hip_cells_missing( x264hip_ctx *ctx, int n, const x264hip_cel
     for( int i = 0; i < n; i++ )
     {
         if( !cell_ref_ok( ctx, cells[i] ) ) return X264HIP_EINVAL;
-        missing[i] = ctx->slots[cells[i].slot_b].cells[cells[i].dist_p0 * ns + cells[i].dist_p1].map_remote;
+        const FrameSlot &b = ctx->slots[cells[i].slot_b];
+        const int idx = cells[i].dist_p0 * ns + cells[i].dist_p1;
+        // 1: the map of the cell's own evaluation is with its owner, 2: the map of its spare half (the caller asked for that variant)
+        missing[i] = b.cells[idx].map_remote ? ( b.cell_at[idx] != idx ? 2 : 1 ) : 0;
     }
     return X264HIP_OK;
 }
@@ -3557,9 +3577,11 @@ extern "C" int x264hip_export_cell_map( x264hip_ctx *ctx, const x264hip_cell_ref
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     FrameSlot &b = ctx->slots[cell->slot_b];
     const int d0 = cell->dist_p0, d1 = cell->dist_p1, idx = d0 * ( ctx->p.bframes + 2 ) + d1;
-    const CellEntry &e = b.cells[idx];
+    const bool spare = d1 && ( cell->with_ref1_l0 & X264HIP_CELL_SPARE );
+    const CellEntry &e = spare ? b.alts[idx] : b.cells[idx];
     if( !b.in_use || e.map_remote || ( !e.valid && !e.requested ) ) return X264HIP_ESTATE; // the map has to have been evaluated HERE
-    export_map_kernel<<<( ctx->n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( b.lowres_costs + (size_t)b.cell_at[idx] * ctx->n_mb, b.mvq[0][d0 - 1], d1 ? b.mvq[1][d1 - 1] : nullptr,
+    const int at = spare ? ctx->n_cells + idx : b.cell_at[idx];
+    export_map_kernel<<<( ctx->n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( b.lowres_costs + (size_t)at * ctx->n_mb, b.mvq[0][d0 - 1], d1 ? b.mvq[1][d1 - 1] : nullptr,
                                                                           (int *)dst_dev, ctx->n_mb );
     HIPCK( hipGetLastError() );
     return X264HIP_OK;
@@ -3578,7 +3600,7 @@ extern "C" int x264hip_import_cell_map( x264hip_ctx *ctx, const x264hip_cell_ref
     // vectors of fields this context only knows by tag arrive with the map (their costs stay with the owner); local fields are left alone
     unsigned long long *q0 = b.field_remote[0][d0 - 1] ? b.mvq[0][d0 - 1] : nullptr;
     unsigned long long *q1 = d1 && b.field_remote[1][d1 - 1] ? b.mvq[1][d1 - 1] : nullptr;
-    import_map_kernel<<<( ctx->n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( b.lowres_costs + (size_t)idx * ctx->n_mb, q0, b.field_tag[0][d0 - 1], q1,
+    import_map_kernel<<<( ctx->n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( b.lowres_costs + (size_t)b.cell_at[idx] * ctx->n_mb, q0, b.field_tag[0][d0 - 1], q1,
                                                                           d1 ? b.field_tag[1][d1 - 1] : 0u, (const int *)src_dev, ctx->n_mb );
     HIPCK( hipGetLastError() );
     if( q0 ) b.field_remote[0][d0 - 1] = 2;

@@ -82,11 +82,12 @@ class WindowShard:
         search(reqs)                                     reqs: list of (slot_b, slot_ref, list, dist_m1): unweighted searches, asynchronous
         export_fields(keys, out)                         {mv, cost} of the fields (slot, list, dist_m1) into out[:len] ([., n_mb, 2] int32)
         import_fields(keys, tensor, rows)                field k from tensor[rows[k]]
-        spec_cells(cells)                                cells: list of (slot_b, slot_p0, slot_p1, d0, d1, with_ref1_l0); d0 == 0: intra sums
+        spec_cells(cells)                                cells: list of (slot_b, slot_p0, slot_p1, d0, d1, flags); d0 == 0: intra sums; flags: 1 with the list-1
+                                                         reference's vectors, 2 both ways in one pass (own place + spare half), 4 (export / import) the spare half
         export_cells(cells, out)                         summaries into out[:len] ([., 8 + 2 mb_h] int32)
         import_cells(cells, tensor)                      rank 0
         fields_remote(keys)                              rank 0: keys (slot, frame_number, list, dist_m1) searched on other ranks
-        cells_missing(cells) -> [bool]                   rank 0: whose per-block map is not local
+        cells_missing(cells) -> [0 | 1 | 2]              rank 0: whose per-block map is not local (2: the map of the cell's spare half)
         export_map(cell, out) ; import_map(cell, tensor) the per-block map of one cell ([3, n_mb] int32: lowres_costs, list-0 vectors, list-1 vectors)
         exchange                                         Exchange (below): zeros / all_gather / gather
     """
@@ -139,6 +140,8 @@ class WindowShard:
                         p1, with_l0 = ni + d1, int(c == 2)
                         if p1 not in here or (ni, 1, d1 - 1) not in self.done:
                             continue
+                        if c == 3:  # both ways in one pass where the list-1 reference's field exists (flags 1 | 2), else without it
+                            with_l0 = 3 if (p1, 0, d0 + d1 - 1) in self.done else 0
                         if with_l0 and (p1, 0, d0 + d1 - 1) not in self.done:
                             continue
                         if with_l0 and (owner(p1) != owner(ni) or self.loop):
@@ -218,6 +221,8 @@ class WindowShard:
                     self._loop_checks = getattr(self, "_loop_checks", []) + [(sbuf[:len(keys)], rbuf[:len(keys)])]
         # ---- the cells of the frames this rank owns; rank 0 also queues the intra sums of every frame (it has all of them resident)
         my_cells = [c[:6] for c in cells[self.rank]]
+        # summaries: a cell evaluated both ways travels as two entries, its own (flag 1) and its spare half (flag 4)
+        halves = lambda cs: [h for c in cs for h in ([c[:5] + (1,), c[:5] + (4,)] if c[5] & 2 else [c[:6]])]  # noqa: E731
         sums = []
         if self.rank == 0:
             sums = [(s, s, s, 0, 0, 0) for s, n in zip(slots, numbers) if n not in self.sums_done]
@@ -227,23 +232,24 @@ class WindowShard:
         if self.world == 1 and not self.loop:
             return
         # ---- summaries to rank 0
-        width = max([len(c) for c in cells[1:]] + ([len(cells[0])] if self.loop else [0]))
+        sent = [halves(cs) for cs in cells]
+        width = max([len(c) for c in sent[1:]] + ([len(sent[0])] if self.loop else [0]))
         if width:
             per = 8 + 2 * a.mb_h
             buf = X.zeros((width, per))
-            if my_cells and (self.rank or self.loop):
-                a.export_cells(my_cells, buf)
+            if sent[self.rank] and (self.rank or self.loop):
+                a.export_cells(sent[self.rank], buf)
             out = X.gather(buf)
             if self.rank == 0:
                 remote = [(f[0], f[4], f[2], f[3]) for r in range(1, self.world) for f in fields[r]]
                 a.fields_remote(remote)
                 for r in range(0 if self.loop else 1, self.world):
-                    if cells[r]:
-                        a.import_cells([c[:6] for c in cells[r]], out[r][:len(cells[r])])   # (loopback: every entry is skipped -- the cells are here)
+                    if sent[r]:
+                        a.import_cells(sent[r], out[r][:len(sent[r])])   # (loopback: every entry is skipped -- the cells are here)
                         self.stats["cells_imported"] += len(cells[r])
                 self.stats["bytes_summaries"] += (self.world - 1) * width * per * 4
-                if self.loop and my_cells:
-                    self._loop_checks = getattr(self, "_loop_checks", []) + [(buf[:len(my_cells)], out[0][:len(my_cells)])]
+                if self.loop and sent[0]:
+                    self._loop_checks = getattr(self, "_loop_checks", []) + [(buf[:len(sent[0])], out[0][:len(sent[0])])]
         elif self.rank == 0:
             a.fields_remote([(f[0], f[4], f[2], f[3]) for r in range(1, self.world) for f in fields[r]])
 
@@ -270,7 +276,7 @@ class WindowShard:
         if self.world == 1 or not cells:
             return
         cells = [tuple(c) for c in dict.fromkeys(cells)]
-        miss = [c for c, m in zip(cells, self.a.cells_missing([c + (0,) for c in cells])) if m]
+        miss = [c + (4 if m == 2 else 0,) for c, m in zip(cells, self.a.cells_missing([c + (0,) for c in cells])) if m]  # (.., half of the cell that is wanted)
         if not miss:
             return
         payload = [CMD_FETCH, len(miss)]
@@ -288,12 +294,12 @@ class WindowShard:
         buf = X.zeros((width, 3, a.n_mb))
         if self.rank:
             for k, c in enumerate(by_owner[self.rank]):
-                a.export_map(c + (0,), buf[k])
+                a.export_map(c, buf[k])
         out = X.gather(buf)
         if self.rank == 0:
             for r in range(1, self.world):
                 for k, c in enumerate(by_owner[r]):
-                    a.import_map(c + (0,), out[r][k])
+                    a.import_map(c[:5] + (0,), out[r][k])
                     self.stats["maps_fetched"] += 1
             self.stats["bytes_maps"] += (self.world - 1) * width * 3 * a.n_mb * 4
             self.stats["fetch_commands"] += 1
@@ -312,8 +318,8 @@ class WindowShard:
                 return
             if cmd[0] == CMD_FETCH:
                 n = cmd[1]
-                rec = [cmd[2 + 6 * k: 8 + 6 * k] for k in range(n)]
-                self._fetch([tuple(r[:5]) for r in rec], [r[5] for r in rec])
+                rec = [cmd[2 + 7 * k: 9 + 7 * k] for k in range(n)]
+                self._fetch([tuple(r[:6]) for r in rec], [r[6] for r in rec])
                 continue
             n = cmd[1]
             self._run_chunk(cmd[4:4 + n], cmd[4 + n:4 + 2 * n], (cmd[2], cmd[3]), cmd[4 + 2 * n:4 + 2 * n + ns2])
@@ -538,7 +544,7 @@ class HipAdapter:
     def cells_missing(self, cells):
         out = (self.C.c_ubyte * len(cells))()
         self._ck(self.L.x264hip_cells_missing(self.h, len(cells), self._refs(cells), out), "cells_missing")
-        return [bool(v) for v in out]
+        return [int(v) for v in out]  # 0 here, 1 with its owner, 2 the spare half is with its owner
 
     def export_map(self, cell, out):
         self._ck(self.L.x264hip_export_cell_map(self.h, self._refs([cell]), self.C.c_void_p(out.data_ptr())), "export_cell_map")
