@@ -842,16 +842,16 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
         }
         else
         {
-#pragma unroll
-            for( int h = 0; h < 2; h++ )
-            {
-                int va[4], vb[4];
-                px4_to_ints( h ? ra.hi : ra.lo, va ); px4_to_ints( h ? rb.hi : rb.lo, vb );
-#pragma unroll
-                for( int i = 0; i < 4; i++ )
-                    va[i] = iclip3( ( va[i] * bipred_weight + vb[i] * ( 64 - bipred_weight ) + 32 ) >> 6, 0, P.pixel_max );
-                ( h ? pred.hi : pred.lo ) = px4_from_ints( va, sizeof( T ) == 1 );
-            }
+            // ( a w + b ( 64 - w ) + 32 ) >> 6 on packed 16-bit pairs: w = 64 - ( dist_scale_factor >> 2 ) lies in 4 .. 61, so the sum stays below
+            // 2^16 for 10-bit samples too and the result never leaves 0 .. pixel_max (mc.c:61-87 pixel_avg_weight_wxh without its clip doing anything)
+            const u16x2 wa = { (unsigned short)bipred_weight, (unsigned short)bipred_weight };
+            const u16x2 wb = { (unsigned short)( 64 - bipred_weight ), (unsigned short)( 64 - bipred_weight ) };
+            const u16x2 rnd = { 32, 32 }, six = { 6, 6 };
+            auto mix = [&]( uint32_t x, uint32_t y ) { return as_u32( (u16x2)( ( as_u2( x ) * wa + as_u2( y ) * wb + rnd ) >> six ) ); };
+            pred.lo.a = mix( ra.lo.a, rb.lo.a ); pred.lo.b = mix( ra.lo.b, rb.lo.b );
+            pred.hi.a = mix( ra.hi.a, rb.hi.a ); pred.hi.b = mix( ra.hi.b, rb.hi.b );
+            pred.lo.raw = sizeof( T ) == 1 ? __builtin_amdgcn_perm( pred.lo.b, pred.lo.a, 0x06040200u ) : 0;
+            pred.hi.raw = sizeof( T ) == 1 ? __builtin_amdgcn_perm( pred.hi.b, pred.hi.a, 0x06040200u ) : 0;
         }
         const int v = block_cost8<T>( f, pred, P.mbcmp_satd );
         // lanes k and k1 collect the three candidate costs of their block (lane groups 0..2 of half 0 / half 1) and choose

@@ -195,6 +195,7 @@ struct CoopNone
     BM_HD int lane() const { return 0; }
     BM_HD void argmin( int &, int & ) const {}
     BM_HD unsigned long long ballot( bool p ) const { return p ? 1ull : 0ull; }
+    BM_HD unsigned long long max64( unsigned long long v ) const { return v; }
     BM_HD int bcast( int v, int ) const { return v; }
     BM_HD void sync() const {}
     BM_HD int16_t *xs() { return xs_; }
@@ -204,6 +205,58 @@ BM_HD int mf_popc64( unsigned long long v )
     int n = 0;
     for( ; v; v &= v - 1 ) n++;
     return n;
+}
+
+// TESA, between the SAD stage and the full costs (behaviour: encoder/me.c:704-752): a list of (SAD, position) survivors in scan order, the
+// best SAD among them, a bar (the SAD stage's last threshold) and a quota.  While more than twice the quota remain and the bar is above
+// the best SAD, the bar moves half way down towards it and every entry above it leaves -- the rest keep their order; then the most expensive
+// entry leaves (the first one among equals), its place taken by the LAST entry of the list, until the quota is met.  Written for a group
+// of Coop::W cooperating lanes that all hold the same scalars: a pass over the list is ceil( count / W ) chunks, the entries that stay are
+// placed by a ballot and the number of staying lanes below each (ordered compaction), the most expensive one is a maximum over packed
+// ( SAD, first-index-wins ) keys.  With W = 1 the same code is the scalar form the host tests run.
+template <class Coop, class Entry>
+BM_HD int mf_thin_survivors( Coop &coop, Entry *list, int count, int best, int bar, int quota )
+{
+    const unsigned long long below = coop.lane() ? ( 1ull << coop.lane() ) - 1 : 0ull; // the lanes in front of this one
+    while( count > 2 * quota && bar > best )
+    {
+        bar = ( bar + best ) >> 1;
+        int kept = 0;
+        for( int base = 0; base < count; base += Coop::W )
+        {
+            const int i = base + coop.lane();
+            Entry e = list[i < count ? i : base];
+            const bool stays = i < count && e.sad <= bar;
+            const unsigned long long who = coop.ballot( stays );
+            coop.sync(); // the whole chunk has been read: its entries may be overwritten now (a kept entry never moves up the list)
+            if( stays )
+                list[kept + mf_popc64( who & below )] = e;
+            kept += mf_popc64( who );
+        }
+        coop.sync();
+        count = kept;
+    }
+    while( count > quota )
+    {
+        unsigned long long top = 0; // ( SAD << 32 ) | ( 0x7FFFFFFF - index ): the largest key is the largest SAD at the smallest index
+        for( int base = 0; base < count; base += Coop::W )
+        {
+            const int i = base + coop.lane();
+            if( i < count )
+            {
+                const unsigned long long key = ( (unsigned long long)(unsigned)list[i].sad << 32 ) | (unsigned)( 0x7FFFFFFF - i );
+                top = key > top ? key : top;
+            }
+        }
+        top = coop.max64( top );
+        const int out = 0x7FFFFFFF - (int)(unsigned)top;
+        count--;
+        coop.sync();
+        if( coop.lane() == 0 )
+            list[out] = list[count];
+        coop.sync();
+    }
+    return count;
 }
 
 #if defined( __HIP_DEVICE_COMPILE__ )
@@ -763,7 +816,7 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
             uint16_t cost_fpel_mvx[MF_TESA_WIDTH_MAX + 4];
             for( int x = 0; x < width; x++ )
                 cost_fpel_mvx[x] = p->cost_mv[4*( min_x + x ) - p->mvp[0]];
-            int nmvsad = 0, limit;
+            int nmvsad = 0;
             int sad_thresh = me_range <= 16 ? 10 : me_range <= 24 ? 11 : 12;
             int bsad = mf_sad( p->fenc, p->fenc_stride, p->ref[0] + (long)s->bmy * p->stride + s->bmx, p->stride, s->bw, s->bh ) + mef_bits_f( s, s->bmx, s->bmy );
             for( int my = min_y; my <= max_y; my++ )
@@ -823,31 +876,8 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
                 }
                 bsad += ycost;
             }
-            limit = me_range >> 1;
-            sad_thresh = bsad * sad_thresh >> 3;
-            while( nmvsad > limit*2 && sad_thresh > bsad )
-            {
-                int i = 0;
-                sad_thresh = ( sad_thresh + bsad ) >> 1;
-                while( i < nmvsad && mvsads[i].sad <= sad_thresh )
-                    i++;
-                for( int j = i; j < nmvsad; j++ )
-                {
-                    mvsads[i] = mvsads[j];
-                    if( mvsads[j].sad <= sad_thresh ) /* i += (sad - (sad_thresh+1)) >> 31 with the sign trick */
-                        i++;
-                }
-                nmvsad = i;
-            }
-            while( nmvsad > limit )
-            {
-                int bi = 0;
-                for( int i = 1; i < nmvsad; i++ )
-                    if( mvsads[i].sad > mvsads[bi].sad )
-                        bi = i;
-                nmvsad--;
-                mvsads[bi] = mvsads[nmvsad];
-            }
+            // the survivors are thinned to half the range's worth before their full costs are taken (me.c:704-752)
+            nmvsad = mf_thin_survivors( coop, mvsads, nmvsad, bsad, bsad * sad_thresh >> 3, me_range >> 1 );
             for( int i = 0; i < nmvsad; i++ )
                 mef_try_f( s, mvsads[i].mx, mvsads[i].my );
             break;
@@ -898,6 +928,16 @@ struct CoopWave
         cost = (int)( key >> 32 ); idx = (int)(unsigned)key;
     }
     __device__ __forceinline__ unsigned long long ballot( bool p ) const { return __builtin_amdgcn_ballot_w64( p ); }
+    __device__ __forceinline__ unsigned long long max64( unsigned long long v ) const
+    {
+#pragma unroll
+        for( int m = 1; m < 64; m <<= 1 )
+        {
+            const unsigned long long o = __shfl_xor( v, m, 64 );
+            v = o > v ? o : v;
+        }
+        return v;
+    }
     __device__ __forceinline__ int bcast( int v, int l ) const { return __shfl( v, l, 64 ); }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ int16_t *xs() { return xs_; }
