@@ -537,9 +537,9 @@ def main():
                              "achieved": round(solo[2] * bytes_per_search / 1e9 / (solo[0] / 1e3), 2),
                              "frac": round(solo[2] * bytes_per_search / 1e9 / (solo[0] / 1e3) / HBM_PEAK_GBS, 5)},
                          "algorithmic_bytes_per_search": bytes_per_search,
-                         "note": "not a streaming kernel: once the chip is full it is bound by the L1 (texture cache) line rate -- roofline_l1 --, with vector-ALU "
-                                 "issue (roofline_issue) second; a launch that does not fill the chip is bound by its dependency chain (DESIGN.md section 3); the "
-                                 "counters are in profiles/r03_search_pmc.json"},
+                         "note": "not a streaming kernel: it is bound by vector instruction issue (roofline_issue: 147 VALU + 36 SALU instructions per block search, "
+                                 "profiles/r04_search_pmc.json); HBM is the roofline the metric names.  A launch that does not fill the chip is bound by its "
+                                 "dependency chain and runs on the latency form of the search out of LDS (me_team.h; DESIGN.md section 3.1)"},
             "lookahead_stats": {"frame_cost_calls": int(la_stats[0]), "evaluations": int(la_stats[1]),
                                 "weights_analysed": int(la_stats[2]), "weights_kept": int(la_stats[3]),
                                 "device": {"searches": int(dev_counters[0]), "cell_requests": int(dev_counters[1]), "cell_hits": int(dev_counters[4]),
@@ -746,22 +746,24 @@ def window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend,
 
 
 def l1_roofline(prof, timing, cfg):
-    """Third roofline of the search kernel, the one that binds it once the chip is full: cache-line accesses of the per-CU L1 (TCP).  Every
-    reference row a lane group loads is a 128-byte line access (148 per block search in the TCP_TOTAL_CACHE_ACCESSES pass, profiles/
-    r03_search_pmc.json); a CU's L1 serves 64 bytes per clock, i.e. one line every two clocks: 256 CUs x clock / 2 lines per second.
-    timing: (ms, launches, searches) of launches that ran alone."""
+    """Cache-line accesses of the per-CU L1 (TCP) by the search kernel: TCP_TOTAL_CACHE_ACCESSES per block search (profiles/r04_search_pmc.json)
+    x block searches / time, against ONE tag lookup per clock and CU -- the same denominator as scripts/summarize_search_pmc.py's
+    l1_pipe_utilisation (an assumed rate: no L1 microbenchmark backs it; round 3 quoted one line per two clocks here and 0.90).  Reported for
+    completeness: round 4 showed the kernel is bound by instruction issue, not by this pipe (an LDS window that removes these accesses does
+    not shorten a block search).  timing: (ms, launches, searches) of launches that ran alone."""
     ms, launches, searches = timing
     blocks = ((cfg["width"] + 15) // 16) * ((cfg["height"] + 15) // 16)
     lines = prof["l1_line_accesses_per_block"]
     clock = prof.get("effective_clock_GHz", 2.3) * 1e9
-    peak = 256 * clock / 2.0
+    peak = 256 * clock
     achieved = searches * blocks * lines / (ms / 1e3) if ms > 0 else 0.0
-    return {"bound": "l1-lines", "kernel": "me_rows_kernel", "achieved": round(achieved / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G line accesses/s",
-            "frac": round(achieved / peak, 4), "l1_line_accesses_per_block": lines, "bytes_per_s_equivalent_TBps": round(achieved * 128 / 1e12, 2),
+    return {"bound": "l1-tag-lookups", "kernel": "me_rows_kernel", "achieved": round(achieved / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G line accesses/s",
+            "frac": round(achieved / peak, 4), "l1_line_accesses_per_block": lines,
             "searches_per_launch": round(searches / max(launches, 1)), "source": prof.get("source"),
-            "what": "line accesses of the launches that ran alone / their time, against 256 CUs x one 128-byte line per two clocks at the clock of the counter pass",
-            "note": "the same launches with 19 % fewer vector instructions per block (round 3 rewrite) take the same time once the chip is full: the L1 line "
-                    "rate, not instruction issue, is what is left (DESIGN.md section 3)"}
+            "what": "line accesses of the launches that ran alone / their time, against 256 CUs x one tag lookup per clock at the clock of the counter pass "
+                    "(assumed rate, same denominator as profiles/r04_search_pmc.json l1_pipe_utilisation)",
+            "note": "not the ceiling of this kernel: the search out of an LDS window (me_team.h) removes these accesses and a block search takes as long "
+                    "(DESIGN.md section 3.1)"}
 
 
 def issue_roofline(prof, prof_ms, prof_searches, cfg, wall_s=None, all_searches=None):
@@ -777,8 +779,9 @@ def issue_roofline(prof, prof_ms, prof_searches, cfg, wall_s=None, all_searches=
     out = {"bound": "valu-issue", "kernel": "me_rows_kernel", "achieved": round(achieved / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-instr/s",
            "frac": round(achieved / peak, 4), "valu_per_block": valu, "cycles_per_valu_instruction": cpv, "source": prof.get("source"),
            "what": "achieved = VALU instructions of the launches / summed launch time (launches of several contexts overlap, each is stretched)",
-           "note": "the ceiling that binds while the CU is full (%.0f %% of the issue cycles of the resident waves in the counter passes, the L1 pipe "
-                   "next to it); a launch alone is bound by its dependency chain instead (DESIGN.md section 3, profiles/r03_search_pmc.json)"
+           "note": "the ceiling that binds: %.0f %% of the issue cycles of the resident waves in the counter passes (four waves per SIMD taking turns; a lone "
+                   "wave spends 2/3 of a step issuing); a launch that cannot fill the chip is as long as its dependency chain and goes to the latency "
+                   "form of the search (DESIGN.md section 3.1, profiles/r04_search_pmc.json, r04lat_search_pmc.json)"
                    % (100 * prof.get("valu_issue_utilisation_while_resident", 0))}
     if wall_s and all_searches:
         # whole timed region: every search of every context against the wall clock
