@@ -776,13 +776,14 @@ __global__ __launch_bounds__( 256 ) void cell_p_kernel( LaP P, const CellArgs *d
     cell_finish( P, A, xy, bcost, list_used );
 }
 
-// B cells: a wave walks CELLB_BPW consecutive blocks of a row, two at a time.  Geometry of the search (me_search.h): a block is 8 lanes,
-// a lane one 8-pixel row, reference samples from the strip copies; the eight lane groups are 2 blocks x 4 candidate slots (direct-style
-// vectors, zero vectors, searched vectors twice -- three of the four are used).  Everything per block that is not pixel work is
-// vector code on lane k for block bx0 + k, done once for the eight blocks of the wave: fetching the vectors and list costs,
-// deriving the candidate vectors (slicetype.c:560-600), and the final choice (:601-652); the pixel lanes pick their block's vectors
-// up with ds_bpermute and hand the three candidate costs back the same way.  (As scalar code per block -- v_readlane, SALU clips
-// and compares -- the kernel issued more scalar than vector instructions.)
+// B cells: a wave evaluates CELLB_BPW = 8 consecutive blocks of a row AT ONCE on the geometry of the search (me_search.h): a block is 8 lanes,
+// a lane one 8-pixel row, reference samples from the strip copies; the three bidirectional candidates of a block (direct-style vectors,
+// zero vectors, searched vectors) follow each other in the same lanes, so one instruction stream serves eight blocks and every lane
+// works all the time.  (Rounds 2-3 walked the blocks two at a time with the candidates side by side in four lane-group slots, one of them
+// idle: four passes of the whole instruction stream per eight blocks -- 7.1 us per 4K cell in a batch against 4.1 now.)  Everything per block
+// that is not pixel work is vector code on lane k for block bx0 + k: fetching the vectors and list costs, deriving the candidate vectors
+// (slicetype.c:560-600) and the final choice (:601-652); the pixel lanes of group k pick block k's vectors up with ds_bpermute and hand
+// the three candidate costs back the same way.
 #define CELLB_BPW 8
 __device__ __forceinline__ int pack_mv( int x, int y ) { return ( x & 0xFFFF ) | ( y << 16 ); }
 template <typename T>
@@ -792,7 +793,7 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
     const int lane = lane_id();
     const int by = blockIdx.y, bx0 = blockIdx.x * CELLB_BPW;
     const int nb = imin2( CELLB_BPW, P.mb_w - bx0 );
-    const int half = lane >> 5, slot = ( lane >> 3 ) & 3, l = lane & 7; // block of the pair, candidate slot, row of the block
+    const int g = lane >> 3, l = lane & 7; // block of the wave, row of the block
     const T *fbase = (const T *)A.fenc0, *s0base = (const T *)A.ref0_0, *s1base = (const T *)A.ref1_0; // strips of the source frame's plane 0 and of the two references
     const int strip_elems = ( P.plane_elems / P.stride ) * 16;
     const int row16 = ( 8 * by + l + LA_PAD ) << 4;
@@ -820,21 +821,14 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
         }
     }
     const bool dmv_nz = ( pd0 | pd1 ) != 0, mv_nz = ( pm0 | pm1 ) != 0;
-    int my_cost = 0, my_list = 0, my_cost2 = 0, my_list2 = 0;
-    for( int k = 0; k < nb; k += 2 )
-    {
-        const int k1 = imin2( k + 1, nb - 1 ); // an odd row end costs its last block twice
-        const int kk = half ? k1 : k;
-        // this lane's pair: slot 0 -> direct-style (dmv), 1 -> zero, 2/3 -> searched vectors, of block kk
-        const int qd0 = __shfl( pd0, kk ), qd1 = __shfl( pd1, kk ), qm0 = __shfl( pm0, kk ), qm1 = __shfl( pm1, kk );
-        const int pa = slot == 0 ? qd0 : slot == 1 ? 0 : qm0, pc = slot == 0 ? qd1 : slot == 1 ? 0 : qm1;
-        int ax = (int)(short)( pa & 0xFFFF ), ay = pa >> 16, cx = (int)(short)( pc & 0xFFFF ), cy = pc >> 16;
-        if( P.subme <= 1 ) { ax &= ~1; ay &= ~1; cx &= ~1; cy &= ~1; } // half-pel plane pick (slicetype.c:582-589)
-        const int bx = bx0 + kk;
-        const int cx0 = 8 * bx + LA_PAD;
-        const Px8 f = load_px8_at( fbase, strip_off( cx0, row16, strip_elems ) );
-        const Px8 ra = qpel_px8_strips( s0base, P.plane_elems, strip_elems, cx0, row16, ax, ay );
-        const Px8 rb = qpel_px8_strips( s1base, P.plane_elems, strip_elems, cx0, row16, cx, cy );
+    // the pixel lanes of group g work on block min( g, nb - 1 ) (a short row end costs its last block again)
+    const int gb = imin2( g, nb - 1 ), from = gb << 2; // ds_bpermute address of lane gb
+    const int qd0 = __builtin_amdgcn_ds_bpermute( from, pd0 ), qd1 = __builtin_amdgcn_ds_bpermute( from, pd1 );
+    const int qm0 = __builtin_amdgcn_ds_bpermute( from, pm0 ), qm1 = __builtin_amdgcn_ds_bpermute( from, pm1 );
+    const int cx0 = 8 * ( bx0 + gb ) + LA_PAD;
+    const int o0 = strip_off( cx0, row16, strip_elems );
+    const Px8 f = load_px8_at( fbase, o0 );
+    auto mix = [&]( const Px8 &ra, const Px8 &rb ) -> Px8 {
         Px8 pred;
         if( bipred_weight == 32 )
         {
@@ -847,16 +841,30 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
             const u16x2 wa = { (unsigned short)bipred_weight, (unsigned short)bipred_weight };
             const u16x2 wb = { (unsigned short)( 64 - bipred_weight ), (unsigned short)( 64 - bipred_weight ) };
             const u16x2 rnd = { 32, 32 }, six = { 6, 6 };
-            auto mix = [&]( uint32_t x, uint32_t y ) { return as_u32( (u16x2)( ( as_u2( x ) * wa + as_u2( y ) * wb + rnd ) >> six ) ); };
-            pred.lo.a = mix( ra.lo.a, rb.lo.a ); pred.lo.b = mix( ra.lo.b, rb.lo.b );
-            pred.hi.a = mix( ra.hi.a, rb.hi.a ); pred.hi.b = mix( ra.hi.b, rb.hi.b );
+            auto one = [&]( uint32_t x, uint32_t y ) { return as_u32( (u16x2)( ( as_u2( x ) * wa + as_u2( y ) * wb + rnd ) >> six ) ); };
+            pred.lo.a = one( ra.lo.a, rb.lo.a ); pred.lo.b = one( ra.lo.b, rb.lo.b );
+            pred.hi.a = one( ra.hi.a, rb.hi.a ); pred.hi.b = one( ra.hi.b, rb.hi.b );
             pred.lo.raw = sizeof( T ) == 1 ? __builtin_amdgcn_perm( pred.lo.b, pred.lo.a, 0x06040200u ) : 0;
             pred.hi.raw = sizeof( T ) == 1 ? __builtin_amdgcn_perm( pred.hi.b, pred.hi.a, 0x06040200u ) : 0;
         }
-        const int v = block_cost8<T>( f, pred, P.mbcmp_satd );
-        // lanes k and k1 collect the three candidate costs of their block (lane groups 0..2 of half 0 / half 1) and choose
-        const int base = ( lane == k1 && k1 != k ) ? 32 : 0;
-        const int c_dmv = __shfl( v, base ), c_zero = __shfl( v, base + 8 ), c_mv = __shfl( v, base + 16 );
+        return pred;
+    };
+    auto candidate = [&]( int pa, int pc ) -> int {
+        int ax = (int)(short)( pa & 0xFFFF ), ay = pa >> 16, cx = (int)(short)( pc & 0xFFFF ), cy = pc >> 16;
+        if( P.subme <= 1 ) { ax &= ~1; ay &= ~1; cx &= ~1; cy &= ~1; } // half-pel plane pick (slicetype.c:582-589)
+        const Px8 ra = qpel_px8_strips( s0base, P.plane_elems, strip_elems, cx0, row16, ax, ay );
+        const Px8 rb = qpel_px8_strips( s1base, P.plane_elems, strip_elems, cx0, row16, cx, cy );
+        return block_cost8<T>( f, mix( ra, rb ), P.mbcmp_satd );
+    };
+    // the three candidates, one after the other; the zero vectors are plane 0 of both references at the block itself: one tap each
+    const int v_dmv = candidate( qd0, qd1 );
+    const int v_zero = block_cost8<T>( f, mix( load_px8_at( s0base, o0 ), load_px8_at( s1base, o0 ) ), P.mbcmp_satd );
+    const int v_mv = candidate( qm0, qm1 );
+    // lane k collects the costs of block k (any lane of group k holds them) and chooses
+    const int back = ( imin2( lane, 7 ) << 3 ) << 2; // ds_bpermute address of lane 8 k
+    const int c_dmv = __builtin_amdgcn_ds_bpermute( back, v_dmv ), c_zero = __builtin_amdgcn_ds_bpermute( back, v_zero ), c_mv = __builtin_amdgcn_ds_bpermute( back, v_mv );
+    if( lane < nb )
+    {
         int bcost = COST_MAX_I, list_used = 0;
         if( c_dmv < bcost ) { bcost = c_dmv; list_used = 3; }              // the scaled vectors of the list-1 reference (zero without them)
         if( dmv_nz && c_zero < bcost ) { bcost = c_zero; list_used = 3; }  // zero vectors, if those were not zero
@@ -867,7 +875,7 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
             const int c = 5 * P.lambda + c_mv;
             if( c < bcost ) { bcost = c; list_used = 3; }
         }
-        if( lane == k || lane == k1 ) { my_cost = bcost; my_list = list_used; }
+        cell_finish( P, A, xy_mine, bcost, list_used );
         if( A.dual )
         {
             // the same block WITHOUT the list-1 reference's vectors (slicetype.c:629 false): the zero vectors take the first place, the
@@ -881,14 +889,8 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
                 const int c = 5 * P.lambda + c_mv;
                 if( c < b2 ) { b2 = c; l2 = 3; }
             }
-            if( lane == k || lane == k1 ) { my_cost2 = b2; my_list2 = l2; }
+            cell_finish( P, A, xy_mine, b2, l2, true );
         }
-    }
-    if( lane < nb )
-    {
-        cell_finish( P, A, xy_mine, my_cost, my_list );
-        if( A.dual )
-            cell_finish( P, A, xy_mine, my_cost2, my_list2, true );
     }
 }
 
