@@ -165,8 +165,13 @@ def primitives_bench(torch, libmod, cfg, iters=30):
                 t_call = time.perf_counter() - t0
                 # device rate: the batch's kernels between HIP events on the context's stream, requests and planes resident (like `value`);
                 # call rate: the whole C call -- request table translated and uploaded, kernels, results read back
-                out["me_full_%s_16x16_searches_per_s" % name] = round(n_req / (ctx.last_search_ms()[0] * 1e-3))
-                out["me_full_%s_16x16_call_searches_per_s" % name] = round(n_req / t_call)
+                # (key names: `_searches_per_s` has been the rate of the whole call since round 2 -- in round 3 it briefly named the device
+                # rate --, the device rate has its own key)
+                out["me_full_%s_16x16_device_searches_per_s" % name] = round(n_req / (ctx.last_search_ms()[0] * 1e-3))
+                out["me_full_%s_16x16_searches_per_s" % name] = round(n_req / t_call)
+            out["me_full_note"] = ("me_full_*_searches_per_s = the whole x264hip_me_search_batch call (request table translated and uploaded, kernels, read-back), "
+                                   "32 160 requests; me_full_*_device_searches_per_s = its kernels between HIP events.  In round 3's line the unsuffixed key was the "
+                                   "device rate and *_call_searches_per_s the call rate")
             del planes, integ, fenc_l, ref_l
         except Exception as e:  # pragma: no cover
             out["me_full_error"] = repr(e)

@@ -189,6 +189,41 @@ def _shard_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _kernel_form_worker(env, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(env)
+    from x264_amd import lib as L2
+    W, H, nf = 704, 576, 48
+    frames = make_clip(W, H, nf, seed=21, scene_cuts=(19,), fade=(30, 6, 0.7, 5), pan=(7, 3))
+    cfg = L2.la_config(W, H, "slow", me="dia")
+    la = L2.Lookahead(cfg, max_frames=nf + 4)
+    try:
+        outs = la.run(frames, paced=False, qp_offsets=True)
+    finally:
+        la.close()
+    q.put([(o.frame, o.type, [o.cost_est[i][j] for i in range(5) for j in range(5)], o.qp_offset.tobytes()) for o in outs])
+
+
+def test_every_form_of_the_search_kernel_gives_the_same_lookahead():
+    """The three forms of the whole-frame motion search -- me_rows_kernel (strips through the L1), the team form and the latency form of the
+    search out of LDS (me_team.h) -- behind the same lookahead: types, cost cells and f_qp_offset must not depend on which of them a launch
+    was sent to.  The switches are read once per process, so every form runs in a process of its own."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    got = {}
+    for name, env in (("default", {}), ("rows", {"X264HIP_SEARCH": "rows"}), ("team", {"X264HIP_SEARCH": "team", "X264HIP_LAT_WAVES": "0"}),
+                      ("latency", {"X264HIP_LAT_WAVES": "1000000"})):
+        q = ctx.Queue()
+        p = ctx.Process(target=_kernel_form_worker, args=(env, q))
+        p.start()
+        got[name] = q.get(timeout=600)
+        p.join(timeout=120)
+        assert p.exitcode == 0, name
+    for name in ("rows", "team", "latency"):
+        assert got[name] == got["default"], name
+
+
 def _loopback_worker(port, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

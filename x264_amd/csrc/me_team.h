@@ -692,7 +692,10 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_team_kernel( LaP P
             if( !__all( granule_ok( gq ) ) )
                 gq = granule_spin( bx - 1 );
             below_left = granule_mv( gq );
-            asm volatile( "" : "+v"( below_left ) );
+            // (the latency form keeps the vector in a scalar register: an asm result in a VGPR counts as divergent, and everything derived
+            // from it -- predictor, candidates, the whole decision logic -- would be vector code again)
+            if( LAT ) asm volatile( "" : "+s"( below_left ) );
+            else asm volatile( "" : "+v"( below_left ) );
         }
         if( timed_out )
             break;

@@ -164,6 +164,7 @@ struct x264hip_ctx
     int up_next = 0;
     std::vector<int> mbt_q_finished;  // slots some queued list writes quantiser offsets of
     int *prop_bank[MBT_MAX_GROUPS] = { nullptr }; // bank g > 0: [max_frames][n_mb] accumulators of list g of a launch (bank 0 = the slots' own)
+    int mbt_bank_limit = MBT_MAX_GROUPS;          // lists per launch this context has memory for (lowered when a bank cannot be allocated)
     int desc_cap = 0;
     // weight costs: WCAP job entries, each with device counters [2][2] and a pinned result pair; entry 0 serves the
     // on-demand call, the others hold speculative pairs (x264hip_prefetch_weight_costs) until their frames go away
@@ -1690,9 +1691,24 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
             int rc = mbt_flush( ctx );
             if( rc ) return rc;
         }
-        const int bank = ctx->mbt_q.n;
-        if( bank > 0 && !ctx->prop_bank[bank] )
-            HIPCK( hipMalloc( &ctx->prop_bank[bank], ctx->slots.size() * (size_t)ctx->n_mb * sizeof( int ) ) );
+        // the list's accumulator bank: bank 0 is the slots' own accumulators, the others are allocated when first used.  A context that cannot
+        // get another bank (max_frames x n_mb x 4 bytes each: 130 MB for a 250-frame window at 8K) is not broken by that: it runs with the
+        // banks it has -- fewer lists side by side -- from then on
+        if( ctx->mbt_q.n >= ctx->mbt_bank_limit )
+        {
+            int rc = mbt_flush( ctx );
+            if( rc ) return rc;
+        }
+        int bank = ctx->mbt_q.n;
+        if( bank > 0 && !ctx->prop_bank[bank] && hipMalloc( &ctx->prop_bank[bank], ctx->slots.size() * (size_t)ctx->n_mb * sizeof( int ) ) != hipSuccess )
+        {
+            (void)hipGetLastError();
+            ctx->prop_bank[bank] = nullptr;
+            ctx->mbt_bank_limit = bank;
+            int rc = mbt_flush( ctx );
+            if( rc ) return rc;
+            bank = 0;
+        }
         if( ctx->mbt_q_ring < 0 )
         {
             int rc = mbt_ring_acquire( ctx, &ctx->mbt_q_ring );
