@@ -94,6 +94,28 @@ def primitives_bench(torch, libmod, cfg, iters=30):
         ctx.synchronize()
         out["hpel_filter_8k_GBps"] = round(4 * W8 * H8 * iters / (time.perf_counter() - t0) / 1e9, 1)
         del src, dst
+        # a 4K plane of 10-bit samples (2 bytes each): the high-bit-depth streaming kernel
+        try:
+            ctx10 = libmod.Context(W, H, bit_depth=10, max_frames=2, mv_range=cfg["mv_range"])
+            try:
+                hs = W + 64
+                src = torch.randint(0, 1024, (H + 16, hs), dtype=torch.int16, device="cuda", generator=g)
+                dst = torch.empty((3, H + 16, hs), dtype=torch.int16, device="cuda")
+                torch.cuda.synchronize()
+                ho = (8 * hs + 32) * 2
+                def run_hpel10():
+                    ctx10.hpel_filter(dst[0].data_ptr() + ho, dst[1].data_ptr() + ho, dst[2].data_ptr() + ho, src.data_ptr() + ho, hs, W, H)
+                run_hpel10(); ctx10.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    run_hpel10()
+                ctx10.synchronize()
+                out["hpel_filter_10bit_GBps"] = round(2 * 4 * W * H * iters / (time.perf_counter() - t0) / 1e9, 1)
+                del src, dst
+            finally:
+                ctx10.close()
+        except Exception as e:  # pragma: no cover
+            out["hpel_filter_10bit_error"] = repr(e)
         # frame-level sub4x4_dct + quant_4x4 (first piece): 2*W*H read, 2*W*H (int16 coefficients) + W*H/16 written
         fe = torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda", generator=g)
         fp = torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda", generator=g)

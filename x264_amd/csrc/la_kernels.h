@@ -1259,6 +1259,124 @@ __global__ __launch_bounds__( 64 ) void hpel_stream_kernel( uint8_t *__restrict_
     }
 }
 
+// High-bit-depth planes (uint16 samples, up to 14 bits): the same strip walk as hpel_stream_kernel -- one wave per strip of 62 x 4 columns and
+// HPS_R rows, no LDS, no barrier, every row load in flight before the first is used -- with 32-bit sums: a vertical six-tap sum of 10-bit
+// samples reaches 42 966 and does not fit the packed 16-bit lanes the 8-bit kernel lives on.  A lane loads its four columns of a row as
+// two registers of neighbouring sample pairs ( c0, c1 ) ( c2, c3 ); the symmetric row pairs are added as packed pairs first (two columns per
+// add, no overflow below 15 bits), then each column's sum is a - 5 b + 20 c in 32 bits.  The centre plane filters those sums across the
+// lanes (neighbours through wave_shr / wave_shl DPP moves); the horizontal plane is v_dot2_i32_i16 on neighbouring sample pairs, the odd
+// pairs through v_alignbyte.  (10-bit planes took the LDS-tiled kernel until round 4: ~24 scalar operations per output sample, 1.7 TB/s.)
+__device__ __forceinline__ int hp16_lo( unsigned v ) { return (int)( v & 0xFFFFu ); }
+__device__ __forceinline__ int hp16_hi( unsigned v ) { return (int)( v >> 16 ); }
+__device__ __forceinline__ int hp_prev_i( int v ) { return __builtin_amdgcn_mov_dpp( v, 0x138, 0xf, 0xf, true ); } // lane - 1
+__device__ __forceinline__ int hp_next_i( int v ) { return __builtin_amdgcn_mov_dpp( v, 0x130, 0xf, 0xf, true ); } // lane + 1
+__device__ __forceinline__ int hp16_tap6( unsigned p0, unsigned p1, unsigned p2, int rnd )
+{
+    int acc = __builtin_amdgcn_sdot2( hp_as_s2( p0 ), hp_as_s2( 0xFFFB0001u ), rnd, false ); //  1 -5
+    acc = __builtin_amdgcn_sdot2( hp_as_s2( p1 ), hp_as_s2( 0x00140014u ), acc, false );     // 20 20
+    return __builtin_amdgcn_sdot2( hp_as_s2( p2 ), hp_as_s2( 0x0001FFFBu ), acc, false );    // -5  1
+}
+__device__ __forceinline__ unsigned hp16_pack( int a, int b ) { return (unsigned)a | ( (unsigned)b << 16 ); }
+__global__ __launch_bounds__( 64 ) void hpel_stream16_kernel( uint16_t *__restrict__ dsth, uint16_t *__restrict__ dstv, uint16_t *__restrict__ dstc,
+                                                              const uint16_t *__restrict__ src, int stride, int width, int height, int pixel_max )
+{
+    const int lane = threadIdx.x;
+    const int x = blockIdx.x * HPS_W + 4 * ( lane - 1 ), y0 = blockIdx.y * HPS_R;
+    const bool last_tile = blockIdx.x == gridDim.x - 1;
+    // rows y0-2 .. y0+R+2 of the strip, never beyond what the reference itself reads (columns -2 .. width+2, rows .. height+2); offsets
+    // are relative to sample (-2, -2): never negative
+    const uint16_t *s0 = src - 2 * (long)stride - 2;
+    unsigned d0[HPS_R + 5], d1[HPS_R + 5]; // ( c0, c1 ), ( c2, c3 ) of every row
+    const bool whole = x >= -2 && x + 3 <= width + 2;
+#pragma unroll
+    for( int r = 0; r < HPS_R + 5; r++ )
+    {
+        const unsigned row = (unsigned)( imin2( y0 + r, height + 4 ) * stride );
+        if( whole )
+        {
+            uint2 w;
+            __builtin_memcpy( &w, s0 + ( row + (unsigned)( x + 2 ) ), 8 );
+            d0[r] = w.x; d1[r] = w.y;
+        }
+        else
+        {
+            unsigned c[4];
+#pragma unroll
+            for( int k = 0; k < 4; k++ )
+                c[k] = s0[row + (unsigned)imin2( imax2( x + k + 2, 0 ), width + 4 )];
+            d0[r] = c[0] | c[1] << 16; d1[r] = c[2] | c[3] << 16;
+        }
+    }
+#pragma unroll
+    for( int r = 0; r < HPS_R; r++ )
+    {
+        const int y = y0 + r;
+        // vertical sums of rows y-2 .. y+3, four columns: the symmetric pairs as packed adds, then a - 5 b + 20 c per column in 32 bits
+        int v[4];
+        {
+            const u16x2 a0 = as_u2( d0[r] ) + as_u2( d0[r + 5] ), b0 = as_u2( d0[r + 1] ) + as_u2( d0[r + 4] ), c0 = as_u2( d0[r + 2] ) + as_u2( d0[r + 3] );
+            const u16x2 a1 = as_u2( d1[r] ) + as_u2( d1[r + 5] ), b1 = as_u2( d1[r + 1] ) + as_u2( d1[r + 4] ), c1 = as_u2( d1[r + 2] ) + as_u2( d1[r + 3] );
+            const unsigned A0 = as_u32( a0 ), B0 = as_u32( b0 ), C0 = as_u32( c0 ), A1 = as_u32( a1 ), B1 = as_u32( b1 ), C1 = as_u32( c1 );
+            v[0] = hp16_lo( A0 ) - 5 * hp16_lo( B0 ) + 20 * hp16_lo( C0 ); v[1] = hp16_hi( A0 ) - 5 * hp16_hi( B0 ) + 20 * hp16_hi( C0 );
+            v[2] = hp16_lo( A1 ) - 5 * hp16_lo( B1 ) + 20 * hp16_lo( C1 ); v[3] = hp16_hi( A1 ) - 5 * hp16_hi( B1 ) + 20 * hp16_hi( C1 );
+        }
+        int ov[4], oc[4], oh[4];
+#pragma unroll
+        for( int k = 0; k < 4; k++ )
+            ov[k] = iclip3( ( v[k] + 16 ) >> 5, 0, pixel_max );
+        // centre plane: the six-tap filter across the sums, columns x-2 .. x+6 (the neighbours' through DPP)
+        {
+            const int m2 = hp_prev_i( v[2] ), m1 = hp_prev_i( v[3] ), p4 = hp_next_i( v[0] ), p5 = hp_next_i( v[1] ), p6 = hp_next_i( v[2] );
+            const int c[9] = { m2, m1, v[0], v[1], v[2], v[3], p4, p5, p6 };
+#pragma unroll
+            for( int k = 0; k < 4; k++ )
+                oc[k] = iclip3( ( ( c[k] + c[k + 5] ) - 5 * ( c[k + 1] + c[k + 4] ) + 20 * ( c[k + 2] + c[k + 3] ) + 512 ) >> 10, 0, pixel_max );
+        }
+        // horizontal plane: the filter across the samples of row y, neighbouring pairs into v_dot2
+        {
+            const unsigned P0 = d0[r + 2], P1 = d1[r + 2];                                                        // ( c0, c1 ) ( c2, c3 )
+            const unsigned Pm = (unsigned)hp_prev_i( (int)P1 ), P2 = (unsigned)hp_next_i( (int)P0 ), P3 = (unsigned)hp_next_i( (int)P1 ); // ( c-2, c-1 ) ( c4, c5 ) ( c6, c7 )
+            const unsigned Qm = __builtin_amdgcn_alignbyte( P0, Pm, 2 ), Q0 = __builtin_amdgcn_alignbyte( P1, P0, 2 );   // ( c-1, c0 ) ( c1, c2 )
+            const unsigned Q1 = __builtin_amdgcn_alignbyte( P2, P1, 2 ), Q2 = __builtin_amdgcn_alignbyte( P3, P2, 2 );   // ( c3, c4 ) ( c5, c6 )
+            oh[0] = iclip3( hp16_tap6( Pm, P0, P1, 16 ) >> 5, 0, pixel_max );
+            oh[1] = iclip3( hp16_tap6( Qm, Q0, Q1, 16 ) >> 5, 0, pixel_max );
+            oh[2] = iclip3( hp16_tap6( P0, P1, P2, 16 ) >> 5, 0, pixel_max );
+            oh[3] = iclip3( hp16_tap6( Q0, Q1, Q2, 16 ) >> 5, 0, pixel_max );
+        }
+        if( y < height )
+        {
+            const unsigned at = (unsigned)( y * stride + x );
+            if( lane >= 1 && lane <= 62 && x < width )
+            {
+                if( x + 4 <= width )
+                {
+                    const uint2 wv = { hp16_pack( ov[0], ov[1] ), hp16_pack( ov[2], ov[3] ) }, wc = { hp16_pack( oc[0], oc[1] ), hp16_pack( oc[2], oc[3] ) },
+                                wh = { hp16_pack( oh[0], oh[1] ), hp16_pack( oh[2], oh[3] ) };
+                    __builtin_memcpy( dstv + at, &wv, 8 ); __builtin_memcpy( dstc + at, &wc, 8 ); __builtin_memcpy( dsth + at, &wh, 8 );
+                }
+                else
+#pragma unroll
+                    for( int k = 0; k < 4; k++ )
+                        if( x + k < width )
+                        {
+                            dstv[at + k] = (uint16_t)ov[k]; dstc[at + k] = (uint16_t)oc[k]; dsth[at + k] = (uint16_t)oh[k];
+                        }
+            }
+            // the reference's five extra dstv columns (-2, -1, width .. width+2)
+            if( blockIdx.x == 0 && lane == 0 )
+            {
+                uint16_t *q = dstv + (long)y * stride;
+                q[-2] = (uint16_t)ov[2]; q[-1] = (uint16_t)ov[3];
+            }
+            if( last_tile && lane >= 1 )
+#pragma unroll
+                for( int k = 0; k < 4; k++ )
+                    if( x + k >= width && x + k <= width + 2 )
+                        dstv[at + k] = (uint16_t)ov[k];
+        }
+    }
+}
+
 // Plain device copy, 16 bytes per lane: the measured HBM rate the SAD/SATD figures are quoted against
 // (vendor peak and the build's own copy kernel).  A workgroup moves contiguous chunks of 256 x U x 16 bytes: its U loads
 // per lane are requested back to back before the first store; NT = non-temporal loads and stores (the data is touched once).

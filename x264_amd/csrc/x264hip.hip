@@ -2532,13 +2532,16 @@ extern "C" int x264hip_hpel_filter( x264hip_ctx *ctx, void *dsth, void *dstv, vo
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     const dim3 grd( ( width + HPEL_TW - 1 ) / HPEL_TW, ( height + HPEL_TH - 1 ) / HPEL_TH );
-    static const bool tiled8 = getenv( "X264HIP_HPEL_TILED" ) != nullptr; // the LDS-tiled kernel for 8-bit planes too (A/B runs)
+    static const bool tiled8 = getenv( "X264HIP_HPEL_TILED" ) != nullptr; // the LDS-tiled kernel instead of the streaming ones (A/B runs)
     if( ctx->p.bit_depth == 8 && !tiled8 )
         hpel_stream_kernel<<<dim3( ( width + HPS_W - 1 ) / HPS_W, ( height + HPS_R - 1 ) / HPS_R ), 64, 0, ctx->stream>>>(
             (uint8_t *)dsth, (uint8_t *)dstv, (uint8_t *)dstc, (const uint8_t *)src, (int)stride, width, height );
     else if( ctx->p.bit_depth == 8 )
         hpel_filter_kernel<uint8_t><<<grd, 256, 0, ctx->stream>>>( (uint8_t *)dsth, (uint8_t *)dstv, (uint8_t *)dstc, (const uint8_t *)src, (long)stride, width, height,
                                                                    ctx->P.pixel_max );
+    else if( !tiled8 )
+        hpel_stream16_kernel<<<dim3( ( width + HPS_W - 1 ) / HPS_W, ( height + HPS_R - 1 ) / HPS_R ), 64, 0, ctx->stream>>>(
+            (uint16_t *)dsth, (uint16_t *)dstv, (uint16_t *)dstc, (const uint16_t *)src, (int)stride, width, height, ctx->P.pixel_max );
     else
         hpel_filter_kernel<uint16_t><<<grd, 256, 0, ctx->stream>>>( (uint16_t *)dsth, (uint16_t *)dstv, (uint16_t *)dstc, (const uint16_t *)src, (long)stride, width,
                                                                     height, ctx->P.pixel_max );
@@ -2564,8 +2567,8 @@ static int frame_filter_t( x264hip_ctx *ctx, const T *luma, intptr_t luma_stride
         hpel_stream_kernel<<<dim3( ( width + 16 + HPS_W - 1 ) / HPS_W, ( height + 16 + HPS_R - 1 ) / HPS_R ), 64, 0, ctx->stream>>>(
             planes[1] + offs, planes[2] + offs, planes[3] + offs, planes[0] + offs, (int)stride, width + 16, height + 16 );
     else
-        hpel_filter_kernel<T><<<dim3( ( width + 16 + HPEL_TW - 1 ) / HPEL_TW, ( height + 16 + HPEL_TH - 1 ) / HPEL_TH ), 256, 0, ctx->stream>>>(
-            planes[1] + offs, planes[2] + offs, planes[3] + offs, planes[0] + offs, (long)stride, width + 16, height + 16, ctx->P.pixel_max );
+        hpel_stream16_kernel<<<dim3( ( width + 16 + HPS_W - 1 ) / HPS_W, ( height + 16 + HPS_R - 1 ) / HPS_R ), 64, 0, ctx->stream>>>(
+            planes[1] + offs, planes[2] + offs, planes[3] + offs, planes[0] + offs, (int)stride, width + 16, height + 16, ctx->P.pixel_max );
     // 3. their borders from the last trustworthy filtered samples: 4 columns / 8 rows outside the picture (frame.c:599-623)
     for( int k = 1; k < 4; k++ )
         expand_border_kernel<T><<<grd, 256, 0, ctx->stream>>>( planes[k], (long)stride, planes[k], (long)stride, 1, -4, width + 3, -8, height + 7, -padh, width + padh - 1, -padv );
