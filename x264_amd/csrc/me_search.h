@@ -42,6 +42,9 @@
 #include "strip_layout.h"
 
 #define ME_ROWS 8
+#ifndef ME_TAPS
+#define ME_TAPS 2
+#endif
 #define DPP_ROW_HALF_MIRROR 0x141 // lane i of every 8 reads lane 7 - i
 
 template <typename T>
@@ -138,7 +141,7 @@ template <typename T>
 __device__ __forceinline__ int block_cost8( const Px8 &f, const Px8 &r, int use_satd )
 {
     if( use_satd )
-        return reduce8( satd_partial_px4( f.lo, r.lo ) + satd_partial_px4( f.hi, r.hi ) ) >> 1;
+        return reduce8( satd_partial_px4( f.hi, r.hi, (unsigned)satd_partial_px4( f.lo, r.lo ) ) ) >> 1;
     return reduce8( sad_partial_px8( f, r, (const T *)nullptr ) );
 }
 
@@ -222,7 +225,7 @@ template <typename T>
 __device__ __forceinline__ int block_partial8( const Px8 &f, const Px8 &r, int use_satd )
 {
     if( use_satd )
-        return satd_partial_px4( f.lo, r.lo ) + satd_partial_px4( f.hi, r.hi );
+        return satd_partial_px4( f.hi, r.hi, (unsigned)satd_partial_px4( f.lo, r.lo ) );
     return sad_partial_px8( f, r, (const T *)nullptr );
 }
 
@@ -302,15 +305,30 @@ struct GroupEval
         if constexpr( N > 5 ) { ta[5] = from_slot<5>( S, oa ); tb[5] = from_slot<5>( S, ob ); }
         if constexpr( N > 6 ) { ta[6] = from_slot<6>( S, oa ); tb[6] = from_slot<6>( S, ob ); }
         if constexpr( N > 7 ) { ta[7] = from_slot<7>( S, oa ); tb[7] = from_slot<7>( S, ob ); }
+        // Both taps of every candidate are requested before anything waits (ME_TAPS: 2).  A full- or half-pel position has the same
+        // sample twice and the second request hits the line the first one brought; skipping it (ME_TAPS: 1) needs a copy of the
+        // first tap's registers, which makes every candidate wait for its own load before the next one is issued.
         int c[N];
+#if ME_TAPS == 2
+        Px8 pa[N], pb[N];
+#pragma unroll
+        for( int j = 0; j < N; j++ )
+            pa[j] = load_px8_at( sbase, ta[j] + S.row16 );
+#pragma unroll
+        for( int j = 0; j < N; j++ )
+            pb[j] = load_px8_at( sbase, tb[j] + S.row16 );
+#endif
 #pragma unroll
         for( int j = 0; j < N; j++ )
         {
-            // both taps of a full- or half-pel position are the same sample: one load (the branch is uniform inside the group)
+#if ME_TAPS == 2
+            const Px8 a = pa[j], bb = pb[j];
+#else
             const Px8 a = load_px8_at( sbase, ta[j] + S.row16 );
             Px8 bb = a;
             if( tb[j] != ta[j] )
                 bb = load_px8_at( sbase, tb[j] + S.row16 );
+#endif
             Px8 r;
             r.lo = avg_px4( a.lo, bb.lo, (const T *)nullptr ); r.hi = avg_px4( a.hi, bb.hi, (const T *)nullptr );
             if( WEIGHTED )
@@ -424,9 +442,14 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
     C.refine4 = MODE == 3 ? P.subpel_refine >= 3 : MODE >= 1;
     C.mbcmp_satd = MODE == 3 ? P.mbcmp_satd : MODE >= 1;
     C.fpelcmp_satd = MODE == 3 ? P.fpelcmp_satd : MODE == 2;
-    const T *fbase = D.fenc0;
-    const T *sbase = D.ref_strips;
-    const T *wsbase = WEIGHTED ? D.refw_strips : sbase;
+    // the descriptor arrives through vector loads (the table is written by other launches, so no scalar load): without these every
+    // load below would move its base address into scalar registers again (two v_readfirstlane per load, ~10 % of the vector instructions)
+    const T *fbase = uniform_ptr( D.fenc0 );
+    const T *sbase = uniform_ptr( D.ref_strips );
+    const T *wsbase = WEIGHTED ? uniform_ptr( D.refw_strips ) : sbase;
+    unsigned long long *const mvq = uniform_ptr( D.mvq );
+    int *const costs_out = uniform_ptr( D.costs );
+    const unsigned tag = __builtin_amdgcn_readfirstlane( D.tag );
     const int strip_elems = ( P.plane_elems / P.stride ) * 16; // rows of the padded plane x 16 samples
     const int tab_centre = 2 * 4 * P.mv_range;
     // end row of the band this row belongs to (slicetype.c:917-918): rows of one band do not see the vectors of the band below
@@ -461,7 +484,7 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
             {
                 unsigned long long gq = 0;
                 const int nb = lane == 1 ? ( bx0 > 0 ? -1 : 0 ) : lane == 2 ? ( bx0 < W - 1 ? 1 : 0 ) : 0;
-                const unsigned long long *gp = D.mvq + ( ( by0 + 1 ) * W + bx0 + nb );
+                const unsigned long long *gp = mvq + ( ( by0 + 1 ) * W + bx0 + nb );
                 unsigned spins = 0;
                 while( 1 )
                 {
@@ -469,7 +492,7 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
                     if( lane < 3 )
                     {
                         gq = __hip_atomic_load( gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-                        ok = (unsigned)( gq >> 32 ) == D.tag;
+                        ok = (unsigned)( gq >> 32 ) == tag;
                     }
                     if( __all( ok ) )
                         break;
@@ -583,12 +606,12 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
                 keep_mv = packed; keep_cost = cost;
             }
             if( g == ME_ROWS - 1 && j == 0 )
-                __hip_atomic_store( D.mvq + xy, ( (unsigned long long)D.tag << 32 ) | (unsigned)packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+                __hip_atomic_store( mvq + xy, ( (unsigned long long)tag << 32 ) | (unsigned)packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
             if( !( bx & 3 ) && j < 4 && bx + j < W )
             {
                 if( g != ME_ROWS - 1 )
-                    D.mvq[xy + j] = ( (unsigned long long)D.tag << 32 ) | (unsigned)keep_mv;
-                D.costs[xy + j] = keep_cost;
+                    mvq[xy + j] = ( (unsigned long long)tag << 32 ) | (unsigned)keep_mv;
+                costs_out[xy + j] = keep_cost;
             }
         }
         r3 = r2; r2 = r1;

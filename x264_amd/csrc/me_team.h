@@ -69,14 +69,6 @@ __device__ __forceinline__ void me_dma_drain()
     asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
 }
 
-// a pointer every lane agrees on, moved into scalar registers (the compiler cannot prove it for values loaded through a table)
-template <typename P>
-__device__ __forceinline__ P *uniform_ptr( P *p )
-{
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane( (unsigned)v ), hi = __builtin_amdgcn_readfirstlane( (unsigned)( v >> 32 ) );
-    return (P *)( ( (unsigned long long)hi << 32 ) | lo );
-}
 __device__ __forceinline__ uint4 gload_u128( const void *ubase, unsigned byte_off )
 {
     uint4 w;
