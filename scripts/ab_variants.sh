@@ -1,14 +1,15 @@
+#!/bin/bash
+# usage (through gpurun): bash scripts/ab_variants.sh <variant tag>...   -- short bench runs of x264_amd/libx264hip_<tag>.so builds
+# (python -m x264_amd.build --variant <tag> DEF=..) against the default build: 8 segments in flight twice, one segment batched and paced
 short="--no-cpu-baseline --no-primitives --no-extra --no-check"
 r() { python bench.py $short $2 | python -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', '$2', j['value'], j['roofline']['us_per_search'])"; }
 for rep in 1 2; do
-for v in "" taps1 w5; do
+for v in "" "$@"; do
   if [ -n "$v" ]; then export X264HIP_LIB=$GRAFT_REPO_ROOT/x264_amd/libx264hip_$v.so; else unset X264HIP_LIB; fi
   r "lib=$v" "--inflight 8"
 done; done
-for v in "" taps1 w5; do
+for v in "" "$@"; do
   if [ -n "$v" ]; then export X264HIP_LIB=$GRAFT_REPO_ROOT/x264_amd/libx264hip_$v.so; else unset X264HIP_LIB; fi
   r "lib=$v" "--inflight 1"
   r "lib=$v" "--inflight 1 --paced"
 done
-unset X264HIP_LIB
-python -m pytest tests/test_gpu_parity.py -q -m gpu -x 2>&1 | tail -1

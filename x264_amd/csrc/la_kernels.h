@@ -112,6 +112,131 @@ __global__ __launch_bounds__( 256 ) void strips_kernel( const PutDesc *descs, Pu
     __builtin_memcpy( dst, v, 16 * sizeof( T ) );
 }
 
+// lowres_kernel + strips_kernel in one pass (the default ingest): a workgroup produces a tile of LT_ROWS x (LT_COLS + 8) padded samples of the four
+// planes in LDS (the 8 extra columns are the right half of the tile's last strip) and writes it out twice, both times in whole
+// contiguous runs -- the row-major planes 16 samples per thread (a row of the tile = one or two full cache lines), the strips 16
+// samples per thread with consecutive lanes on consecutive rows (LT_ROWS x 16 samples of a strip = one contiguous run).  The planes
+// are not read back, so a frame costs W*H read + 4*S + 8*S written and nothing else (the two-kernel form read the 4*S again, from
+// HBM once a batch of frames exceeds the caches).  Columns at and beyond the padded width (< stride) are zero in the strips and
+// untouched in the planes; no candidate reads them.
+#define LT_ROWS 32
+#define LT_COLS 128
+#define LT_PITCH 144 // samples per tile row in LDS: LT_COLS + 8, rounded up to keep every row 16-byte aligned
+template <typename T>
+__device__ __forceinline__ void lowres_px4( const T *__restrict__ src, int src_stride, int width, int height, int lw, int lh, int xb, int Y,
+                                            T o0[4], T oh[4], T ov[4], T oc[4] )
+{
+    const int y = iclip3( Y - LA_PAD, 0, lh - 1 );
+    const T *r0 = src + (size_t)imin2( 2 * y, height - 1 ) * src_stride;
+    const T *r1 = src + (size_t)imin2( 2 * y + 1, height - 1 ) * src_stride;
+    const T *r2 = src + (size_t)imin2( 2 * y + 2, height - 1 ) * src_stride;
+    if( xb >= 0 && 2 * ( xb + 3 ) + 2 < width )
+    {
+        int a[9], b[9], c[9];
+        T va[8], vb[8], vc[8];
+        __builtin_memcpy( va, r0 + 2 * xb, 8 * sizeof( T ) );
+        __builtin_memcpy( vb, r1 + 2 * xb, 8 * sizeof( T ) );
+        __builtin_memcpy( vc, r2 + 2 * xb, 8 * sizeof( T ) );
+#pragma unroll
+        for( int i = 0; i < 8; i++ ) { a[i] = va[i]; b[i] = vb[i]; c[i] = vc[i]; }
+        a[8] = r0[2 * xb + 8]; b[8] = r1[2 * xb + 8]; c[8] = r2[2 * xb + 8];
+        int t[9], u[9];
+#pragma unroll
+        for( int i = 0; i < 9; i++ ) { t[i] = ( a[i] + b[i] + 1 ) >> 1; u[i] = ( b[i] + c[i] + 1 ) >> 1; }
+#pragma unroll
+        for( int i = 0; i < 4; i++ )
+        {
+            o0[i] = (T)( ( t[2 * i] + t[2 * i + 1] + 1 ) >> 1 );
+            oh[i] = (T)( ( t[2 * i + 1] + t[2 * i + 2] + 1 ) >> 1 );
+            ov[i] = (T)( ( u[2 * i] + u[2 * i + 1] + 1 ) >> 1 );
+            oc[i] = (T)( ( u[2 * i + 1] + u[2 * i + 2] + 1 ) >> 1 );
+        }
+    }
+    else
+    {
+#pragma unroll
+        for( int i = 0; i < 4; i++ )
+        {
+            const int x = iclip3( xb + i, 0, lw - 1 );
+            const int x0 = imin2( 2 * x, width - 1 ), x1 = imin2( 2 * x + 1, width - 1 ), x2 = imin2( 2 * x + 2, width - 1 );
+            int t0 = ( r0[x0] + r1[x0] + 1 ) >> 1, t1 = ( r0[x1] + r1[x1] + 1 ) >> 1, t2 = ( r0[x2] + r1[x2] + 1 ) >> 1;
+            int u0 = ( r1[x0] + r2[x0] + 1 ) >> 1, u1 = ( r1[x1] + r2[x1] + 1 ) >> 1, u2 = ( r1[x2] + r2[x2] + 1 ) >> 1;
+            o0[i] = (T)( ( t0 + t1 + 1 ) >> 1 ); oh[i] = (T)( ( t1 + t2 + 1 ) >> 1 );
+            ov[i] = (T)( ( u0 + u1 + 1 ) >> 1 ); oc[i] = (T)( ( u1 + u2 + 1 ) >> 1 );
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__( 256 ) void lowres_tiles_kernel( const PutDesc *descs, PutDesc single, int width, int height,
+                                                              int plane_elems, int stride, int lw, int lh )
+{
+    const PutDesc D = descs ? descs[blockIdx.z] : single;
+    const T *__restrict__ src = (const T *)D.src;
+    T *__restrict__ planes = (T *)D.planes;
+    T *__restrict__ strips = planes + 4 * (size_t)plane_elems;
+    const int pw = lw + 2 * LA_PAD, rows = lh + 2 * LA_PAD, n_strips = stride >> 3;
+    const int X0 = blockIdx.x * LT_COLS, Y0 = blockIdx.y * LT_ROWS;
+    __shared__ __attribute__( ( aligned( 16 ) ) ) T tile[4][LT_ROWS][LT_PITCH];
+    const int tid = threadIdx.x;
+    constexpr int Q = ( LT_COLS + 8 ) / 4; // 4-sample pieces per tile row
+    for( int item = tid; item < LT_ROWS * Q; item += 256 )
+    {
+        const int r = item / Q, q = item - r * Q;
+        const int Y = Y0 + r, X = X0 + 4 * q;
+        T o[4][4];
+        if( Y < rows && X < pw )
+            lowres_px4<T>( src, D.src_stride, width, height, lw, lh, X - LA_PAD, Y, o[0], o[1], o[2], o[3] );
+        else
+#pragma unroll
+            for( int p = 0; p < 4; p++ )
+#pragma unroll
+                for( int i = 0; i < 4; i++ ) o[p][i] = 0;
+#pragma unroll
+        for( int p = 0; p < 4; p++ )
+            __builtin_memcpy( &tile[p][r][4 * q], o[p], 4 * sizeof( T ) );
+    }
+    __syncthreads();
+    {
+        // row-major planes: LT_ROWS rows x 8 pieces of 16 samples
+        const int r = tid >> 3, c = ( tid & 7 ) * 16;
+        const int Y = Y0 + r, X = X0 + c;
+        if( Y < rows )
+        {
+            const size_t o = (size_t)Y * stride + X;
+#pragma unroll
+            for( int p = 0; p < 4; p++ )
+            {
+                T v[16];
+                __builtin_memcpy( v, &tile[p][r][c], 16 * sizeof( T ) );
+                if( X + 16 <= pw )
+                    __builtin_memcpy( planes + (size_t)p * plane_elems + o, v, 16 * sizeof( T ) );
+                else if( X + 8 <= pw ) // the padded width is a multiple of 8, not of 16
+                    __builtin_memcpy( planes + (size_t)p * plane_elems + o, v, 8 * sizeof( T ) );
+            }
+        }
+    }
+    // strips X0 / 8 .. X0 / 8 + 15: a lane per row, 16 samples each
+#pragma unroll
+    for( int pass = 0; pass < LT_COLS / 8 * LT_ROWS / 256; pass++ )
+    {
+        const int s = pass * ( 256 / LT_ROWS ) + tid / LT_ROWS, r = tid % LT_ROWS;
+        const int k = ( X0 >> 3 ) + s, Y = Y0 + r;
+        if( k < n_strips && Y < rows )
+        {
+#pragma unroll
+            for( int p = 0; p < 4; p++ )
+            {
+                T v[16];
+                __builtin_memcpy( v, &tile[p][r][8 * s], 16 * sizeof( T ) );
+                if( k + 1 >= n_strips )
+#pragma unroll
+                    for( int i = 8; i < 16; i++ ) v[i] = 0; // beyond the plane
+                __builtin_memcpy( strips + 2 * (size_t)p * plane_elems + strip_layout::row_off( k, Y, rows ), v, 16 * sizeof( T ) );
+            }
+        }
+    }
+}
+
 // plain x264_mc_functions_t.frame_init_lowres_core signature (mc.h:326-327): no borders, caller's layout
 template <typename T>
 __global__ __launch_bounds__( 256 ) void lowres_core_kernel( const T *__restrict__ src, T *d0, T *dh, T *dv, T *dc,

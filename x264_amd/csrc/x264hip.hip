@@ -623,10 +623,16 @@ static int launch_ingest_t( x264hip_ctx *ctx, const PutDesc *descs_dev, const Pu
     const LaP &P = ctx->P;
     const float strength = p.aq_strength * 1.0397f;
     const float bias = 14.427f + 2 * ( p.bit_depth - 8 );
-    dim3 grd( ( ( ctx->lw + 2 * LA_PAD ) / 4 + 255 ) / 256, ctx->lh + 2 * LA_PAD, n );
-    lowres_kernel<T><<<grd, 256, 0, ctx->stream>>>( descs_dev, single, p.width, p.height, P.plane_elems, P.stride, ctx->lw, ctx->lh );
+    static const bool split_ingest = getenv( "X264HIP_INGEST" ) && !strcmp( getenv( "X264HIP_INGEST" ), "split" );
+    const int rows = ctx->lh + 2 * LA_PAD;
+    if( !split_ingest )
+        lowres_tiles_kernel<T><<<dim3( ( P.stride + LT_COLS - 1 ) / LT_COLS, ( rows + LT_ROWS - 1 ) / LT_ROWS, n ), 256, 0, ctx->stream>>>(
+            descs_dev, single, p.width, p.height, P.plane_elems, P.stride, ctx->lw, ctx->lh );
+    else
     {
-        const int rows = ctx->lh + 2 * LA_PAD;
+        // the two-kernel form (planes, then their strip copy read back from the planes): kept for comparison
+        dim3 grd( ( ( ctx->lw + 2 * LA_PAD ) / 4 + 255 ) / 256, rows, n );
+        lowres_kernel<T><<<grd, 256, 0, ctx->stream>>>( descs_dev, single, p.width, p.height, P.plane_elems, P.stride, ctx->lw, ctx->lh );
         strips_kernel<T><<<dim3( ( rows + 63 ) / 64, ( 4 * ( P.stride / 8 ) + 3 ) / 4, n ), 256, 0, ctx->stream>>>( descs_dev, single, P.plane_elems, P.stride, rows );
     }
     const int wg_per_frame = ( ( ctx->n_mb + AQ_MBS_PER_WG - 1 ) / AQ_MBS_PER_WG + 7 ) / 8 * 8; // a multiple of 8: contiguous runs of macroblocks per XCD
