@@ -20,7 +20,7 @@ rows.sort()
 ours = [r for r in rows if any(k in r[2] for k in ("me_rows", "cell_", "mbtree", "lowres", "strips", "intra", "aq_", "weight", "copyBuffer", "fillBuffer", "recalc"))]
 # the timed steps: every context starts a step with one lowres launch (batch ingest of its segment); the default run is one warm-up step
 # and three timed ones, so the timed region begins with the launch that opens the second quarter of them
-lw = sorted(r[0] for r in ours if "lowres_kernel" in r[2])
+lw = sorted(r[0] for r in ours if "lowres" in r[2])
 t_last = max(r[1] for r in ours)
 t0 = lw[len(lw) // 4] if len(lw) >= 4 else ours[0][0]
 win = [r for r in ours if r[1] > t0]

@@ -24,6 +24,9 @@
 //                                                                                       mc.c:218-249) + bits( qx, qy ); c0 = cost of candidate 0
 //               int  bits( int qx, int qy )               p_cost_mvx[qx] + p_cost_mvy[qy] of a vector every thread of the group agrees on
 //               bool any( bool c )                        true if c holds for any thread that shares this instruction stream
+//               template <int N, class G> bool more_than_first( G gen )   false only if NO thread that shares this instruction stream has a
+//                                                         candidate k >= 1 of the set gen describes (may answer true when in doubt): lets the
+//                                                         caller evaluate candidate 0 alone
 // melogic::ScalarSets<E> implements the two set functions over E's scalar fpel( x, y ) / qpel( qx, qy, use_satd ) / bits( qx, qy ): the
 // host evaluators of the tests use it (candidates one after the other).
 #pragma once
@@ -127,7 +130,11 @@ ME_HD int neighbour_list( int bx, int W, bool has_below, int right, int below, i
 ME_HD int pk_cost( int p ) { return p >> 3; }
 ME_HD int pk_idx( int p ) { return p & 7; }
 // entry i (0..3) of a four-entry list as a chain of selects: i may differ from lane to lane on the device
-ME_HD int pick4( int i, const int v[4] ) { return i == 0 ? v[0] : i == 1 ? v[1] : i == 2 ? v[2] : v[3]; }
+// (the list is passed by value: with the entries behind a pointer the compiler may turn the selects into an indexed load, which on the
+// device puts the list into scratch memory)
+struct Mv4 { int v0, v1, v2, v3; };
+ME_HD Mv4 mv4_of( const int v[4] ) { Mv4 r; r.v0 = v[0]; r.v1 = v[1]; r.v2 = v[2]; r.v3 = v[3]; return r; }
+ME_HD int pick4( int i, const Mv4 v ) { return i == 0 ? v.v0 : i == 1 ? v.v1 : i == 2 ? v.v2 : v.v3; }
 
 // The set functions over a scalar evaluator (candidates one after the other): D provides fpel( x, y ), qpel( qx, qy, use_satd ),
 // bits( qx, qy ).  Used by the host evaluators of the tests.
@@ -149,6 +156,18 @@ struct ScalarSets
             if( p < best ) best = p;
         }
         return best;
+    }
+    template <int N, class G>
+    bool more_than_first( G gen )
+    {
+        for( int k = 1; k < N; k++ )
+        {
+            int x = 0, y = 0;
+            bool ok = false, wb = true;
+            gen( k, x, y, ok, wb );
+            if( ok ) return true;
+        }
+        return false;
     }
     template <int N, class G>
     int qpel_set( int use_satd, G gen, int &cost0 )
@@ -179,6 +198,7 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
     int bpred_cost = ME_COST_MAX, bpred_mx = 0, bpred_my = 0;
     int pmvx, pmvy;
     int unused_c0 = 0;
+    const Mv4 cand_x = mv4_of( mvcx ), cand_y = mv4_of( mvcy );
     ME_MARK( ev, 0 );
 
     if( C.refine4 )
@@ -188,20 +208,38 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
         pmvx = clip3( mvpx, 4 * L.fmin_x, 4 * L.fmax_x );
         pmvy = clip3( mvpy, 4 * L.fmin_y, 4 * L.fmax_y );
         int pmv_cost = ME_COST_MAX;
-        const int p = ev.template qpel_set<5>( C.fpelcmp_satd, [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
+        auto start_set = [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
             const int i = k - 1;
-            const int vx = pick4( i, mvcx ), vy = pick4( i, mvcy );
+            const int vx = pick4( i, cand_x ), vy = pick4( i, cand_y );
             const bool keep = k > 0 && i < n_mvc && ( vx | vy ) && !( vx == pmvx && vy == pmvy );
             x = keep ? clip3( vx, 4 * L.fmin_x, 4 * L.fmax_x ) : pmvx;
             y = keep ? clip3( vy, 4 * L.fmin_y, 4 * L.fmax_y ) : pmvy;
             ok = k == 0 || keep; wb = true;
-        }, pmv_cost );
+        };
+        // where motion is uniform every neighbour repeats the predictor and x264_predictor_clip drops them all: the predictor alone then
+        const int p = ev.template more_than_first<5>( start_set ) ? ev.template qpel_set<5>( C.fpelcmp_satd, start_set, pmv_cost )
+                                                                  : ev.template qpel_set<1>( C.fpelcmp_satd, start_set, pmv_cost );
+#ifdef ME_PROFILE
+        {
+            int kept = 0, single = ( ( pmvx | pmvy ) & 1 ) == 0, total = 1;
+            for( int i = 0; i < 4; i++ )
+            {
+                const int vx = pick4( i, cand_x ), vy = pick4( i, cand_y );
+                if( i < n_mvc && ( vx | vy ) && !( vx == pmvx && vy == pmvy ) )
+                {
+                    kept++; total++;
+                    single += ( ( clip3( vx, 4 * L.fmin_x, 4 * L.fmax_x ) | clip3( vy, 4 * L.fmin_y, 4 * L.fmax_y ) ) & 1 ) == 0;
+                }
+            }
+            ev.pf_kept = kept; ev.pf_single_start = single; ev.pf_total_start = total;
+        }
+#endif
         bpred_cost = pk_cost( p );
         bpred_mx = pmvx; bpred_my = pmvy;
         if( pk_idx( p ) )
         {
-            bpred_mx = clip3( pick4( pk_idx( p ) - 1, mvcx ), 4 * L.fmin_x, 4 * L.fmax_x );
-            bpred_my = clip3( pick4( pk_idx( p ) - 1, mvcy ), 4 * L.fmin_y, 4 * L.fmax_y );
+            bpred_mx = clip3( pick4( pk_idx( p ) - 1, cand_x ), 4 * L.fmin_x, 4 * L.fmax_x );
+            bpred_my = clip3( pick4( pk_idx( p ) - 1, cand_y ), 4 * L.fmin_y, 4 * L.fmax_y );
         }
         bmx = ( bpred_mx + 2 ) >> 2;
         bmy = ( bpred_my + 2 ) >> 2;
@@ -237,7 +275,7 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
         const bool need_zero = ( pmvx | pmvy ) != 0;
         const int p = ev.template fpel_set<6>( [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
             const int i = k - 1;
-            const int mx = ( pick4( i, mvcx ) + 2 ) >> 2, my = ( pick4( i, mvcy ) + 2 ) >> 2;
+            const int mx = ( pick4( i, cand_x ) + 2 ) >> 2, my = ( pick4( i, cand_y ) + 2 ) >> 2;
             const bool keep = k > 0 && k < 5 && i < n_mvc && ( mx | my ) && !( mx == pmvx && my == pmvy );
             x = keep ? clip3( mx, L.fmin_x, L.fmax_x ) : k == 5 ? 0 : pmvx;
             y = keep ? clip3( my, L.fmin_y, L.fmax_y ) : k == 5 ? 0 : pmvy;
@@ -249,8 +287,8 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
         if( kb == 5 ) { bmx = 0; bmy = 0; }
         else if( kb )
         {
-            bmx = clip3( ( pick4( kb - 1, mvcx ) + 2 ) >> 2, L.fmin_x, L.fmax_x );
-            bmy = clip3( ( pick4( kb - 1, mvcy ) + 2 ) >> 2, L.fmin_y, L.fmax_y );
+            bmx = clip3( ( pick4( kb - 1, cand_x ) + 2 ) >> 2, L.fmin_x, L.fmax_x );
+            bmy = clip3( ( pick4( kb - 1, cand_y ) + 2 ) >> 2, L.fmin_y, L.fmax_y );
         }
     }
 
@@ -347,6 +385,9 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
                 if( differs && pk_cost( p ) < cost ) { cost = pk_cost( p ); mvx = mx; mvy = my; }
             }
         }
+#ifdef ME_PROFILE
+        ev.pf_single_hpel = ( ( mvx | mvy ) & 1 ) == 0;
+#endif
         {
             // half-pel diamond, one iteration: up, down, left, right
             const int p = ev.template qpel_set<4>( C.fpelcmp_satd, [&]( int k, int &x, int &y, bool &ok, bool &wb ) {

@@ -287,6 +287,15 @@ struct GroupEval
         return pack_min<N>( total + b, ok );
     }
     template <int N, class G>
+    __device__ __forceinline__ bool more_than_first( G gen ) const
+    {
+        const int slot = N <= 4 ? ( S.slot & 3 ) : S.slot;
+        int x = 0, y = 0;
+        bool ok = false, wb = true;
+        gen( imin2( slot, N - 1 ), x, y, ok, wb );
+        return any( ok && slot >= 1 && slot < N );
+    }
+    template <int N, class G>
     __device__ __forceinline__ int qpel_set( int use_satd, G gen, int &cost0 ) const
     {
         const int slot = N <= 4 ? ( S.slot & 3 ) : S.slot, k = imin2( slot, N - 1 );
@@ -296,6 +305,9 @@ struct GroupEval
         int oa, ob;
         strip_layout::qpel_taps( plane_elems, strip_off( cx0 + ( x >> 2 ), row16 + ( ( y >> 2 ) << 4 ), strip_elems ), x, y, oa, ob );
         const int b = wb ? bits( x, y ) : 0;
+        // does any candidate of any block of the wave average two different samples?  (after a full-pel search the half-pel diamond
+        // never does: 98 % of its candidates on the bench clip; a wave-uniform answer, so the branch below costs no masking)
+        const bool two_taps = any( oa != ob );
         int ta[N], tb[N];
         ta[0] = from_slot<0>( S, oa ); tb[0] = from_slot<0>( S, ob );
         if constexpr( N > 1 ) { ta[1] = from_slot<1>( S, oa ); tb[1] = from_slot<1>( S, ob ); }
@@ -314,9 +326,18 @@ struct GroupEval
 #pragma unroll
         for( int j = 0; j < N; j++ )
             pa[j] = load_px8_at( sbase, ta[j] + S.row16 );
+        if( two_taps )
+        {
 #pragma unroll
-        for( int j = 0; j < N; j++ )
-            pb[j] = load_px8_at( sbase, tb[j] + S.row16 );
+            for( int j = 0; j < N; j++ )
+                pb[j] = load_px8_at( sbase, tb[j] + S.row16 );
+        }
+        else
+        {
+#pragma unroll
+            for( int j = 0; j < N; j++ )
+                pb[j] = pa[j]; // the copies wait for the loads, but every load of the set has been issued by now
+        }
 #endif
 #pragma unroll
         for( int j = 0; j < N; j++ )
@@ -346,6 +367,7 @@ struct GroupEval
     __device__ __forceinline__ bool any( bool c ) const { return __builtin_amdgcn_ballot_w64( c ) != 0ull; }
 #ifdef ME_PROFILE
     unsigned long long pf_last;
+    int pf_kept, pf_single_start, pf_total_start, pf_single_hpel;
     unsigned pf_phase[5]; // [k] = cycles between mark k-1 and mark k: 1 start candidates, 2 pattern, 3 half-pel, 4 quarter-pel
     __device__ __forceinline__ void mark( int k )
     {
@@ -571,6 +593,20 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
                         melogic::search( C, L, ev, mvpx, mvpy, n, mvcx, mvcy, mvx, mvy, cost );
 #ifdef ME_PROFILE
                         for( int k = 1; k < 5; k++ ) pf_ph[k] += ev.pf_phase[k];
+                        if( prof )
+                        {
+                            if( ( lane & 7 ) == 0 )
+                            {
+                                atomicAdd( prof + 12 + ev.pf_kept, 1ull );
+                                atomicAdd( prof + 22, (unsigned long long)( ev.pf_single_hpel ? 4 : 0 ) ); atomicAdd( prof + 23, 4ull );
+                                atomicAdd( prof + 24, (unsigned long long)ev.pf_single_start ); atomicAdd( prof + 25, (unsigned long long)ev.pf_total_start );
+                            }
+                            int wmax = 0;
+                            for( int v = 4; v > 0 && !wmax; v-- )
+                                if( __builtin_amdgcn_ballot_w64( ev.pf_kept == v ) ) wmax = v;
+                            if( lane == __builtin_ctzll( __builtin_amdgcn_ballot_w64( true ) ) )
+                                atomicAdd( prof + 17 + wmax, 1ull );
+                        }
 #endif
                     }
                     else

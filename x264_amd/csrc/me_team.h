@@ -219,6 +219,8 @@ struct TeamEval
         return pack_min<N>( total + b, ok );
     }
     template <int N, class GEN>
+    __device__ __forceinline__ bool more_than_first( GEN ) const { return true; } // a set across the lanes costs the same whatever its size
+    template <int N, class GEN>
     __device__ __forceinline__ int qpel_set( int use_satd, GEN gen, int &cost0 ) const
     {
         const int slot = N <= 4 ? ( S.slot & 3 ) : S.slot, k = imin2( slot, N - 1 );
@@ -283,6 +285,7 @@ struct TeamEval
 #ifdef ME_PROFILE
     unsigned long long pf_last;
     unsigned pf_phase[5];
+    int pf_kept, pf_single_start, pf_total_start, pf_single_hpel;
     __device__ __forceinline__ void mark( int k )
     {
         const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -362,6 +365,8 @@ struct WaveEval
         return wave_min_groups( ok && grp < N ? ( ( total + b ) << 3 ) | k : ME_PACK_MAX );
     }
     template <int N, class GEN>
+    __device__ __forceinline__ bool more_than_first( GEN ) const { return true; } // the candidates of a set are evaluated side by side
+    template <int N, class GEN>
     __device__ __forceinline__ int qpel_set( int use_satd, GEN gen, int &cost0 ) const
     {
         const int k = imin2( grp, N - 1 );
@@ -404,6 +409,7 @@ struct WaveEval
 #ifdef ME_PROFILE
     unsigned long long pf_last;
     unsigned pf_phase[5];
+    int pf_kept, pf_single_start, pf_total_start, pf_single_hpel;
     __device__ __forceinline__ void mark( int k )
     {
         const unsigned long long now = __builtin_amdgcn_s_memtime();

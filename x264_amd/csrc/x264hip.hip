@@ -370,7 +370,7 @@ extern "C" void x264hip_close( x264hip_ctx *ctx )
 #ifdef ME_PROFILE
     if( ctx->me_prof )
     {
-        unsigned long long v[12] = { 0 };
+        unsigned long long v[32] = { 0 };
         (void)hipStreamSynchronize( ctx->stream );
         (void)hipMemcpy( v, ctx->me_prof, sizeof( v ), hipMemcpyDeviceToHost );
         if( v[7] )
@@ -379,6 +379,15 @@ extern "C" void x264hip_close( x264hip_ctx *ctx )
         if( v[7] )
             fprintf( stderr, "ME_PROFILE search phases per step (group 0): start candidates %.0f pattern %.0f half-pel %.0f quarter-pel %.0f\n",
                      (double)v[8] / v[6], (double)v[9] / v[6], (double)v[10] / v[6], (double)v[11] / v[6] );
+        if( v[7] )
+        {
+            fprintf( stderr, "ME_PROFILE neighbour candidates kept per block, share of blocks (0..4):" );
+            unsigned long long tb = v[12] + v[13] + v[14] + v[15] + v[16], tw = v[17] + v[18] + v[19] + v[20] + v[21];
+            for( int i = 0; i < 5; i++ ) fprintf( stderr, " %.3f", (double)v[12 + i] / ( tb ? tb : 1 ) );
+            fprintf( stderr, " | largest of a wave's eight blocks:" );
+            for( int i = 0; i < 5; i++ ) fprintf( stderr, " %.3f", (double)v[17 + i] / ( tw ? tw : 1 ) );
+            fprintf( stderr, " | single-tap share of the half-pel set's candidates %.3f, of the start set's %.3f\n", (double)v[22] / ( v[23] ? v[23] : 1 ), (double)v[24] / ( v[25] ? v[25] : 1 ) );
+        }
         (void)hipFree( ctx->me_prof );
     }
 #endif
@@ -456,8 +465,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( hipMalloc( &ctx->sync_words, 2 * ME_QUEUES * ME_QUEUE_STRIDE * sizeof( unsigned ) ) ); // row tickets of the two search kernels
     OPENCK( hipMemset( ctx->sync_words, 0, 2 * ME_QUEUES * ME_QUEUE_STRIDE * sizeof( unsigned ) ) );
 #ifdef ME_PROFILE
-    OPENCK( hipMalloc( &ctx->me_prof, 12 * sizeof( unsigned long long ) ) );
-    OPENCK( hipMemset( ctx->me_prof, 0, 12 * sizeof( unsigned long long ) ) );
+    OPENCK( hipMalloc( &ctx->me_prof, 32 * sizeof( unsigned long long ) ) );
+    OPENCK( hipMemset( ctx->me_prof, 0, 32 * sizeof( unsigned long long ) ) );
 #endif
     ctx->n_cells = ( p.bframes + 2 ) * ( p.bframes + 2 );
     ctx->pos_frames.assign( x264hip_ctx::POS_KEYS, 0 );
