@@ -252,14 +252,17 @@ struct TeamEval
         if( __builtin_amdgcn_ballot_w64( any_bad < 0 ) == 0ull )
         {
             int c[N];
+            Px8 pa[N], pb[N]; // every read of the set is issued before anything waits (see GroupEval::qpel_set)
+#pragma unroll
+            for( int j = 0; j < N; j++ )
+                pa[j] = win_px8( win, ta[j], rowb, (const T *)nullptr );
+#pragma unroll
+            for( int j = 0; j < N; j++ )
+                pb[j] = win_px8( win, tb[j], rowb, (const T *)nullptr );
 #pragma unroll
             for( int j = 0; j < N; j++ )
             {
-                // both taps of a full- or half-pel position are the same sample: one read (the branch is uniform inside the group)
-                const Px8 a = win_px8( win, ta[j], rowb, (const T *)nullptr );
-                Px8 bb = a;
-                if( tb[j] != ta[j] )
-                    bb = win_px8( win, tb[j], rowb, (const T *)nullptr );
+                const Px8 a = pa[j], bb = pb[j];
                 Px8 r;
                 r.lo = avg_px4( a.lo, bb.lo, (const T *)nullptr ); r.hi = avg_px4( a.hi, bb.hi, (const T *)nullptr );
                 if( WEIGHTED )
@@ -381,10 +384,10 @@ struct WaveEval
             const int sh = 2 * ( fx | ( fy << 2 ) );
             const int pa = (int)( ( 0x54FE5454u >> sh ) & 3u ), pb = (int)( ( 0xBABABA10u >> sh ) & 3u );
             const int va = win_addr( pa, ix, iy + ( fy == 3 ) ), vb = win_addr( pb, ix + ( fx == 3 ), iy );
+            // both taps are read even where they are the same sample (full- and half-pel positions): skipping the second read needs a
+            // copy of the first one's registers, i.e. a wait for it, and this kernel is about the latency of a block
             a = win_px8( win, va, rowb, (const T *)nullptr );
-            bb = a;
-            if( vb != va ) // both taps of a full- or half-pel position are the same sample (uniform inside the group)
-                bb = win_px8( win, vb, rowb, (const T *)nullptr );
+            bb = win_px8( win, vb, rowb, (const T *)nullptr );
         }
         else
         {
