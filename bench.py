@@ -564,9 +564,10 @@ def main():
                              "achieved": round(solo[2] * bytes_per_search / 1e9 / (solo[0] / 1e3), 2),
                              "frac": round(solo[2] * bytes_per_search / 1e9 / (solo[0] / 1e3) / HBM_PEAK_GBS, 5)},
                          "algorithmic_bytes_per_search": bytes_per_search,
-                         "note": "not a streaming kernel: it is bound by vector instruction issue (roofline_issue: 147 VALU + 36 SALU instructions per block search, "
-                                 "profiles/r04_search_pmc.json); HBM is the roofline the metric names.  A launch that does not fill the chip is bound by its "
-                                 "dependency chain and runs on the latency form of the search out of LDS (me_team.h; DESIGN.md section 3.1)"},
+                         "note": "not a streaming kernel: with the chip full it is bound by vector instruction issue and the L1 tag rate together (roofline_issue, "
+                                 "roofline_l1; instructions and line accesses per block search in profiles/search_issue.json); HBM is the roofline the metric names.  "
+                                 "A launch that does not fill the chip is bound by its dependency chain and runs on the latency form of the search out of LDS "
+                                 "(me_team.h; DESIGN.md section 3.1)"},
             "lookahead_stats": {"frame_cost_calls": int(la_stats[0]), "evaluations": int(la_stats[1]),
                                 "weights_analysed": int(la_stats[2]), "weights_kept": int(la_stats[3]),
                                 "device": {"searches": int(dev_counters[0]), "cell_requests": int(dev_counters[1]), "cell_hits": int(dev_counters[4]),
@@ -773,11 +774,11 @@ def window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend,
 
 
 def l1_roofline(prof, timing, cfg):
-    """Cache-line accesses of the per-CU L1 (TCP) by the search kernel: TCP_TOTAL_CACHE_ACCESSES per block search (profiles/r04_search_pmc.json)
-    x block searches / time, against ONE tag lookup per clock and CU -- the same denominator as scripts/summarize_search_pmc.py's
-    l1_pipe_utilisation (an assumed rate: no L1 microbenchmark backs it; round 3 quoted one line per two clocks here and 0.90).  Reported for
-    completeness: round 4 showed the kernel is bound by instruction issue, not by this pipe (an LDS window that removes these accesses does
-    not shorten a block search).  timing: (ms, launches, searches) of launches that ran alone."""
+    """Cache-line accesses of the per-CU L1 (TCP) by the search kernel: TCP_TOTAL_CACHE_ACCESSES per block search (profiles/search_issue.json, from
+    the counter passes of scripts/pmc_search.sh) x block searches / time, against ONE tag lookup per clock and CU -- the same denominator as
+    scripts/summarize_search_pmc.py's l1_pipe_utilisation (an assumed rate: no L1 microbenchmark backs it).  The second of the two ceilings the
+    kernel runs against once the chip is full (removing a fifth of these accesses shortened a search by 4.5 %).
+    timing: (ms, launches, searches) of launches that ran alone."""
     ms, launches, searches = timing
     blocks = ((cfg["width"] + 15) // 16) * ((cfg["height"] + 15) // 16)
     lines = prof["l1_line_accesses_per_block"]
@@ -788,9 +789,9 @@ def l1_roofline(prof, timing, cfg):
             "frac": round(achieved / peak, 4), "l1_line_accesses_per_block": lines,
             "searches_per_launch": round(searches / max(launches, 1)), "source": prof.get("source"),
             "what": "line accesses of the launches that ran alone / their time, against 256 CUs x one tag lookup per clock at the clock of the counter pass "
-                    "(assumed rate, same denominator as profiles/r04_search_pmc.json l1_pipe_utilisation)",
-            "note": "not the ceiling of this kernel: the search out of an LDS window (me_team.h) removes these accesses and a block search takes as long "
-                    "(DESIGN.md section 3.1)"}
+                    "(assumed rate, same denominator as l1_pipe_utilisation in the profiles/*_search_pmc.json summaries)",
+            "note": "co-limiter with vector issue: each wave-wide 8-byte load of a block candidate's rows (8 rows x 16 B apart) is ~28 lookups; the search "
+                    "out of an LDS window (me_team.h) removes them and pays for it in instructions (DESIGN.md section 3.1)"}
 
 
 def issue_roofline(prof, prof_ms, prof_searches, cfg, wall_s=None, all_searches=None):
@@ -808,7 +809,7 @@ def issue_roofline(prof, prof_ms, prof_searches, cfg, wall_s=None, all_searches=
            "what": "achieved = VALU instructions of the launches / summed launch time (launches of several contexts overlap, each is stretched)",
            "note": "the ceiling that binds: %.0f %% of the issue cycles of the resident waves in the counter passes (four waves per SIMD taking turns; a lone "
                    "wave spends 2/3 of a step issuing); a launch that cannot fill the chip is as long as its dependency chain and goes to the latency "
-                   "form of the search (DESIGN.md section 3.1, profiles/r04_search_pmc.json, r04lat_search_pmc.json)"
+                   "form of the search (DESIGN.md section 3.1, profiles/r04f_search_pmc.json, r04lat_search_pmc.json)"
                    % (100 * prof.get("valu_issue_utilisation_while_resident", 0))}
     if wall_s and all_searches:
         # whole timed region: every search of every context against the wall clock
