@@ -611,7 +611,8 @@ def main():
                     wlx = Workload(torch, lib, shard, cfg_x, dev_index, 0, Sx, Fx, devx, False)
                     try:
                         dtx, ox = wlx.timed(steps_x, 1)
-                        dtp, opx = wlx.timed(1, 0, paced=True)
+                        dtp, opx = wlx.timed(2, 1, paced=True)  # one untimed pass first: a form of the search kernel this context has not launched yet loads its code
+                        dtp /= 2
                         nbx = cfg_x["bframes"] + 2
                         for sgi in range(Sx):
                             assert outputs_signature(ox[sgi], nbx) == outputs_signature(opx[sgi], nbx), "%s: batched and paced passes disagree" % key

@@ -213,14 +213,14 @@ def test_every_form_of_the_search_kernel_gives_the_same_lookahead():
     ctx = mp.get_context("spawn")
     got = {}
     for name, env in (("default", {}), ("rows", {"X264HIP_SEARCH": "rows"}), ("team", {"X264HIP_SEARCH": "team", "X264HIP_LAT_WAVES": "0"}),
-                      ("latency", {"X264HIP_LAT_WAVES": "1000000"})):
+                      ("latency", {"X264HIP_LAT_WAVES": "1000000"}), ("split ingest", {"X264HIP_INGEST": "split"})):
         q = ctx.Queue()
         p = ctx.Process(target=_kernel_form_worker, args=(env, q))
         p.start()
         got[name] = q.get(timeout=600)
         p.join(timeout=120)
         assert p.exitcode == 0, name
-    for name in ("rows", "team", "latency"):
+    for name in ("rows", "team", "latency", "split ingest"):  # the last: planes + strip copy from two kernels instead of lowres_tiles_kernel
         assert got[name] == got["default"], name
 
 

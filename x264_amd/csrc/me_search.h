@@ -593,6 +593,7 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
                         melogic::search( C, L, ev, mvpx, mvpy, n, mvcx, mvcy, mvx, mvy, cost );
 #ifdef ME_PROFILE
                         for( int k = 1; k < 5; k++ ) pf_ph[k] += ev.pf_phase[k];
+#ifdef ME_PROFILE_HIST // (-DME_PROFILE_HIST: the atomics distort the cycle counters above)
                         if( prof )
                         {
                             if( ( lane & 7 ) == 0 )
@@ -607,6 +608,7 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
                             if( lane == __builtin_ctzll( __builtin_amdgcn_ballot_w64( true ) ) )
                                 atomicAdd( prof + 17 + wmax, 1ull );
                         }
+#endif
 #endif
                     }
                     else

@@ -379,7 +379,7 @@ extern "C" void x264hip_close( x264hip_ctx *ctx )
         if( v[7] )
             fprintf( stderr, "ME_PROFILE search phases per step (group 0): start candidates %.0f pattern %.0f half-pel %.0f quarter-pel %.0f\n",
                      (double)v[8] / v[6], (double)v[9] / v[6], (double)v[10] / v[6], (double)v[11] / v[6] );
-        if( v[7] )
+        if( v[7] && v[23] )
         {
             fprintf( stderr, "ME_PROFILE neighbour candidates kept per block, share of blocks (0..4):" );
             unsigned long long tb = v[12] + v[13] + v[14] + v[15] + v[16], tw = v[17] + v[18] + v[19] + v[20] + v[21];
