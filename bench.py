@@ -55,11 +55,14 @@ def primitives_bench(torch, libmod, cfg, iters=30):
                     def run():
                         ctx.pixel_cmp_batch(satd, size_idx, fenc.data_ptr() + org, ref.data_ptr() + org, stride, bw, bh, mv.data_ptr(), res.data_ptr())
                     run(); ctx.synchronize()
-                    t0 = time.perf_counter()
-                    for _ in range(iters):
-                        run()
-                    ctx.synchronize()
-                    dt = (time.perf_counter() - t0) / iters
+                    dt = None
+                    for _ in range(3):  # best of three timed loops: a one-off stall (clock ramp, another process on the box) would otherwise be the figure
+                        t0 = time.perf_counter()
+                        for _ in range(iters):
+                            run()
+                        ctx.synchronize()
+                        d = (time.perf_counter() - t0) / iters
+                        dt = d if dt is None else min(dt, d)
                     nbytes = bw * bh * (2 * size * size + 4)  # SURVEY 8(d) per-block form: both blocks + the result
                     out["%s_%dx%d%s_GBps" % ("satd" if satd else "sad", size, size, tag)] = round(nbytes / dt / 1e9, 1)
             del fenc, ref
@@ -182,14 +185,19 @@ def primitives_bench(torch, libmod, cfg, iters=30):
                 n_req = len(reqs)
                 args_ = (ctx.me_requests(reqs), fenc_l.data_ptr(), mw, [planes[k].data_ptr() + org for k in range(4)], pw, integ.data_ptr() + org * 2, ph * pw, cmv.data_ptr() + 2 * centre)
                 ctx.me_search_batch(*args_)
-                t0 = time.perf_counter()
-                ctx.me_search_batch(*args_)
-                t_call = time.perf_counter() - t0
+                t_call = dev_ms = None
+                for _ in range(3):  # best of three calls, call time and device time each
+                    t0 = time.perf_counter()
+                    ctx.me_search_batch(*args_)
+                    d = time.perf_counter() - t0
+                    t_call = d if t_call is None else min(t_call, d)
+                    m = ctx.last_search_ms()[0]
+                    dev_ms = m if dev_ms is None else min(dev_ms, m)
                 # device rate: the batch's kernels between HIP events on the context's stream, requests and planes resident (like `value`);
                 # call rate: the whole C call -- request table translated and uploaded, kernels, results read back
                 # (key names: `_searches_per_s` has been the rate of the whole call since round 2 -- in round 3 it briefly named the device
                 # rate --, the device rate has its own key)
-                out["me_full_%s_16x16_device_searches_per_s" % name] = round(n_req / (ctx.last_search_ms()[0] * 1e-3))
+                out["me_full_%s_16x16_device_searches_per_s" % name] = round(n_req / (dev_ms * 1e-3))
                 out["me_full_%s_16x16_searches_per_s" % name] = round(n_req / t_call)
             out["me_full_note"] = ("me_full_*_searches_per_s = the whole x264hip_me_search_batch call (request table translated and uploaded, kernels, read-back), "
                                    "32 160 requests; me_full_*_device_searches_per_s = its kernels between HIP events.  In round 3's line the unsuffixed key was the "
