@@ -135,6 +135,17 @@ __device__ __forceinline__ Px4 load_px4( const uint16_t *p )
 // Loads through a wave-uniform base pointer plus an unsigned 32-bit byte offset: the backend emits the
 // `global_load_* v, v_off, s[base:base+1]` form (no 64-bit VALU address arithmetic, no flat aperture check).
 #define AS_GLOBAL __attribute__( ( address_space( 1 ) ) )
+// A descriptor every lane of the wave reads from the same address (a table entry picked by blockIdx): fetched through the scalar cache, so
+// its fields -- the pointers above all -- land in SGPRs: one s_load instead of a round of per-lane loads, and every load through one of
+// those pointers is a plain global load with a scalar base (no flat aperture check, no v_readfirstlane pair in front of it).  The table
+// was written by an earlier launch on the same stream; the scalar cache is invalidated at the start of every dispatch.
+template <typename D>
+__device__ __forceinline__ D load_uniform( const D *p )
+{
+    D r;
+    __builtin_memcpy( &r, (const __attribute__( ( address_space( 4 ) ) ) D *)p, sizeof( D ) );
+    return r;
+}
 // a pointer every lane agrees on, moved into scalar registers (the compiler cannot prove it for values loaded through a table)
 template <typename P>
 __device__ __forceinline__ P *uniform_ptr( P *p )

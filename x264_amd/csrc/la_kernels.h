@@ -27,7 +27,7 @@ template <typename T>
 __global__ __launch_bounds__( 256 ) void lowres_kernel( const PutDesc *descs, PutDesc single, int width, int height,
                                                         int plane_elems, int stride, int lw, int lh )
 {
-    const PutDesc D = descs ? descs[blockIdx.z] : single;
+    const PutDesc D = descs ? load_uniform( descs + blockIdx.z ) : single;
     const T *__restrict__ src = (const T *)D.src;
     T *__restrict__ planes = (T *)D.planes;
     const int src_stride = D.src_stride;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__( 256 ) void lowres_kernel( const PutDesc *descs, Pu
 template <typename T>
 __global__ __launch_bounds__( 256 ) void strips_kernel( const PutDesc *descs, PutDesc single, int plane_elems, int stride, int rows )
 {
-    const PutDesc D = descs ? descs[blockIdx.z] : single;
+    const PutDesc D = descs ? load_uniform( descs + blockIdx.z ) : single;
     const T *__restrict__ planes = (const T *)D.planes;
     T *__restrict__ strips = (T *)D.planes + 4 * (size_t)plane_elems;
     const int n_strips = stride >> 3;
@@ -170,7 +170,7 @@ template <typename T>
 __global__ __launch_bounds__( 256 ) void lowres_tiles_kernel( const PutDesc *descs, PutDesc single, int width, int height,
                                                               int plane_elems, int stride, int lw, int lh )
 {
-    const PutDesc D = descs ? descs[blockIdx.z] : single;
+    const PutDesc D = descs ? load_uniform( descs + blockIdx.z ) : single;
     const T *__restrict__ src = (const T *)D.src;
     T *__restrict__ planes = (T *)D.planes;
     T *__restrict__ strips = planes + 4 * (size_t)plane_elems;
@@ -275,7 +275,7 @@ template <typename T>
 __global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc single, int width, int height, int mb_w, int mb_h,
                                                    float strength, float log2_bias, const AqLuts *luts, int aq_mode, float depth_corr, int chroma_format )
 {
-    const PutDesc D = descs ? descs[blockIdx.z] : single;
+    const PutDesc D = descs ? load_uniform( descs + blockIdx.z ) : single;
     const T *__restrict__ luma = (const T *)D.src, *__restrict__ cb = (const T *)D.cb, *__restrict__ cr = (const T *)D.cr;
     const int stride = D.src_stride, cstride = D.cstride, aq_on = D.aq_on;
     uint16_t *inv_qscale = D.inv_qscale;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__( 64 ) void aq_kernel( const PutDesc *descs, PutDesc
 __global__ __launch_bounds__( 1024 ) void aq_auto_kernel( const PutDesc *descs, PutDesc single, int n_mb, int aq_mode, float aq_strength,
                                                           const AqLuts *luts )
 {
-    const PutDesc D = descs ? descs[blockIdx.x] : single;
+    const PutDesc D = descs ? load_uniform( descs + blockIdx.x ) : single;
     if( !D.aq_on )
         return;
     __shared__ float t4[AQ_AUTO_TILE], t8[AQ_AUTO_TILE];
@@ -447,7 +447,7 @@ __global__ __launch_bounds__( 1024 ) void aq_auto_kernel( const PutDesc *descs, 
 // frame totals of the per-MB sums: one workgroup, no atomics
 __global__ __launch_bounds__( 1024 ) void aq_reduce_kernel( const PutDesc *descs, PutDesc single, int n )
 {
-    const PutDesc D = descs ? descs[blockIdx.x] : single;
+    const PutDesc D = descs ? load_uniform( descs + blockIdx.x ) : single;
     const uint2 *__restrict__ mb_sums = D.mb_sums;
     unsigned long long *frame_sums = D.frame_sums;
     __shared__ unsigned long long sh[2][16];
@@ -560,7 +560,7 @@ __device__ __forceinline__ int intra_pred_px( const IntraEdges &E, int mode, int
 template <typename T>
 __global__ __launch_bounds__( 64 ) void intra_kernel( LaP P, const PutDesc *descs, PutDesc single )
 {
-    const PutDesc D = descs ? descs[blockIdx.z] : single;
+    const PutDesc D = descs ? load_uniform( descs + blockIdx.z ) : single;
     const T *__restrict__ fenc0 = (const T *)D.planes + LA_PAD * P.stride + LA_PAD;
     uint16_t *intra_cost = D.intra_cost;
     __shared__ IntraEdges E4[4];
@@ -653,7 +653,7 @@ template <typename T>
 __global__ __launch_bounds__( 256 ) void weight_cost_kernel( LaP P, const WeightJob *jobs, WeightJob single, int mode /* 0 unweighted, 1 weighted, 2 both */ )
 {
     __shared__ unsigned part[2][4];
-    const WeightJob J = jobs ? jobs[blockIdx.y] : single;
+    const WeightJob J = jobs ? load_uniform( jobs + blockIdx.y ) : single;
     const T *__restrict__ fenc0 = (const T *)J.fenc0, *__restrict__ ref0 = (const T *)J.ref0;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int g = lane >> 4, l = lane & 15, q = l >> 2;
@@ -755,7 +755,7 @@ __global__ __launch_bounds__( 256 ) void cell_reduce_kernel( LaP P, const CellAr
 {
     __shared__ int sh[5][4];
     __shared__ int last;
-    const CellArgs A = descs ? descs[blockIdx.x] : single;
+    const CellArgs A = descs ? load_uniform( descs + blockIdx.x ) : single;
     const int W = P.mb_w, H = P.mb_h;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
     const int row_begin = (int)( (long long)H * blockIdx.y / gridDim.y ), row_end = (int)( (long long)H * ( blockIdx.y + 1 ) / gridDim.y );
@@ -888,7 +888,7 @@ __global__ __launch_bounds__( 256 ) void recalc_kernel( LaP P, const uint16_t *_
 // P and intra-only cells: no pixel work, one thread per block
 __global__ __launch_bounds__( 256 ) void cell_p_kernel( LaP P, const CellArgs *descs, CellArgs single )
 {
-    const CellArgs A = descs ? descs[blockIdx.y] : single;
+    const CellArgs A = descs ? load_uniform( descs + blockIdx.y ) : single;
     const int xy = blockIdx.x * blockDim.x + threadIdx.x;
     if( xy >= P.mb_w * P.mb_h )
         return;
@@ -911,10 +911,16 @@ __global__ __launch_bounds__( 256 ) void cell_p_kernel( LaP P, const CellArgs *d
 // the three candidate costs back the same way.
 #define CELLB_BPW 8
 __device__ __forceinline__ int pack_mv( int x, int y ) { return ( x & 0xFFFF ) | ( y << 16 ); }
+// The wave's life is a chain of memory round trips around ~500 instructions, so the order of the requests is the design: the descriptor
+// comes through the scalar cache (load_uniform), then ONE round for everything whose address needs no vector -- the per-block words, the
+// source rows, both taps of the zero candidate --, then ONE round for the eight taps of the two candidates with vectors; nothing is read
+// at the end (a B cell never looks at the intra cost: slicetype.c:735 applies to P cells only).  Rounds 2-4 first half: nine dependent
+// round trips (descriptor, pointer fields, words, the list-1 vector behind its pointer, three candidates one after the other, intra cost
+// twice).
 template <typename T>
 __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *descs, CellArgs single )
 {
-    const CellArgs A = descs ? descs[blockIdx.z] : single;
+    const CellArgs A = descs ? load_uniform( descs + blockIdx.z ) : single;
     const int lane = lane_id();
     const int by = blockIdx.y, bx0 = blockIdx.x * CELLB_BPW;
     const int nb = imin2( CELLB_BPW, P.mb_w - bx0 );
@@ -927,32 +933,35 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
     const int smin_y = imax2( 4 * ( -8 * by - 12 ), -range ), smax_y = imin2( 4 * ( 8 * ( P.mb_h - by - 1 ) + 12 ), range - 1 );
     // lane k: the words and the candidate vectors of block bx0 + k
     const int bx_mine = bx0 + imin2( lane, nb - 1 ), xy_mine = by * P.mb_w + bx_mine;
-    int pm0 = 0, pm1 = 0, pd0 = 0, pd1 = 0, c0v = 0, c1v = 0;
+    int pm0 = 0, pm1 = 0, pd0 = 0, pd1 = 0, c0v = 0, c1v = 0, wr = 0;
     if( lane < nb )
     {
         pm0 = (int)(unsigned)A.mvq0[xy_mine]; pm1 = (int)(unsigned)A.mvq1[xy_mine];
         c0v = A.costs0[xy_mine]; c1v = A.costs1[xy_mine];
         if( A.ref1_l0_valid )
-        {
-            const int wr = (int)(unsigned)A.ref1_l0[xy_mine];
-            const int smin_x = imax2( 4 * ( -8 * bx_mine - 12 ), -range ), smax_x = imin2( 4 * ( 8 * ( P.mb_w - bx_mine - 1 ) + 12 ), range - 1 );
-            const int rx = (int)(short)( wr & 0xFFFF ), ry = wr >> 16;
-            int d0x = ( rx * A.dist_scale_factor + 128 ) >> 8, d0y = ( ry * A.dist_scale_factor + 128 ) >> 8;
-            int d1x = d0x - rx, d1y = d0y - ry;
-            d0x = iclip3( d0x, smin_x, smax_x ); d0y = iclip3( d0y, smin_y, smax_y );
-            d1x = iclip3( d1x, smin_x, smax_x ); d1y = iclip3( d1y, smin_y, smax_y );
-            if( P.subme <= 1 ) { d0x &= ~1; d0y &= ~1; d1x &= ~1; d1y &= ~1; }
-            pd0 = pack_mv( d0x, d0y ); pd1 = pack_mv( d1x, d1y );
-        }
+            wr = (int)(unsigned)A.ref1_l0[xy_mine];
     }
-    const bool dmv_nz = ( pd0 | pd1 ) != 0, mv_nz = ( pm0 | pm1 ) != 0;
-    // the pixel lanes of group g work on block min( g, nb - 1 ) (a short row end costs its last block again)
+    // the pixel lanes of group g work on block min( g, nb - 1 ) (a short row end costs its last block again); the source rows and the zero
+    // candidate (plane 0 of both references at the block itself, one tap each) need no vector: requested together with the words
     const int gb = imin2( g, nb - 1 ), from = gb << 2; // ds_bpermute address of lane gb
-    const int qd0 = __builtin_amdgcn_ds_bpermute( from, pd0 ), qd1 = __builtin_amdgcn_ds_bpermute( from, pd1 );
-    const int qm0 = __builtin_amdgcn_ds_bpermute( from, pm0 ), qm1 = __builtin_amdgcn_ds_bpermute( from, pm1 );
     const int cx0 = 8 * ( bx0 + gb ) + LA_PAD;
     const int o0 = strip_off( cx0, row16, strip_elems );
     const Px8 f = load_px8_at( fbase, o0 );
+    const Px8 z0 = load_px8_at( s0base, o0 ), z1 = load_px8_at( s1base, o0 );
+    if( lane < nb && A.ref1_l0_valid )
+    {
+        const int smin_x = imax2( 4 * ( -8 * bx_mine - 12 ), -range ), smax_x = imin2( 4 * ( 8 * ( P.mb_w - bx_mine - 1 ) + 12 ), range - 1 );
+        const int rx = (int)(short)( wr & 0xFFFF ), ry = wr >> 16;
+        int d0x = ( rx * A.dist_scale_factor + 128 ) >> 8, d0y = ( ry * A.dist_scale_factor + 128 ) >> 8;
+        int d1x = d0x - rx, d1y = d0y - ry;
+        d0x = iclip3( d0x, smin_x, smax_x ); d0y = iclip3( d0y, smin_y, smax_y );
+        d1x = iclip3( d1x, smin_x, smax_x ); d1y = iclip3( d1y, smin_y, smax_y );
+        if( P.subme <= 1 ) { d0x &= ~1; d0y &= ~1; d1x &= ~1; d1y &= ~1; }
+        pd0 = pack_mv( d0x, d0y ); pd1 = pack_mv( d1x, d1y );
+    }
+    const bool dmv_nz = ( pd0 | pd1 ) != 0, mv_nz = ( pm0 | pm1 ) != 0;
+    const int qd0 = __builtin_amdgcn_ds_bpermute( from, pd0 ), qd1 = __builtin_amdgcn_ds_bpermute( from, pd1 );
+    const int qm0 = __builtin_amdgcn_ds_bpermute( from, pm0 ), qm1 = __builtin_amdgcn_ds_bpermute( from, pm1 );
     auto mix = [&]( const Px8 &ra, const Px8 &rb ) -> Px8 {
         Px8 pred;
         if( bipred_weight == 32 )
@@ -974,22 +983,36 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
         }
         return pred;
     };
-    auto candidate = [&]( int pa, int pc ) -> int {
+    // tap offsets of a candidate pair (list-0 vector pa into reference 0, list-1 vector pc into reference 1): o[0], o[1] / o[2], o[3]
+    auto taps = [&]( int pa, int pc, int o[4] ) {
         int ax = (int)(short)( pa & 0xFFFF ), ay = pa >> 16, cx = (int)(short)( pc & 0xFFFF ), cy = pc >> 16;
         if( P.subme <= 1 ) { ax &= ~1; ay &= ~1; cx &= ~1; cy &= ~1; } // half-pel plane pick (slicetype.c:582-589)
-        const Px8 ra = qpel_px8_strips( s0base, P.plane_elems, strip_elems, cx0, row16, ax, ay );
-        const Px8 rb = qpel_px8_strips( s1base, P.plane_elems, strip_elems, cx0, row16, cx, cy );
-        return block_cost8<T>( f, mix( ra, rb ), P.mbcmp_satd );
+        strip_layout::qpel_taps( P.plane_elems, strip_off( cx0 + ( ax >> 2 ), row16 + ( ( ay >> 2 ) << 4 ), strip_elems ), ax, ay, o[0], o[1] );
+        strip_layout::qpel_taps( P.plane_elems, strip_off( cx0 + ( cx >> 2 ), row16 + ( ( cy >> 2 ) << 4 ), strip_elems ), cx, cy, o[2], o[3] );
     };
-    // the three candidates, one after the other; the zero vectors are plane 0 of both references at the block itself: one tap each
-    const int v_dmv = candidate( qd0, qd1 );
-    const int v_zero = block_cost8<T>( f, mix( load_px8_at( s0base, o0 ), load_px8_at( s1base, o0 ) ), P.mbcmp_satd );
-    const int v_mv = candidate( qm0, qm1 );
+    int od[4], om[4];
+    taps( qd0, qd1, od ); taps( qm0, qm1, om );
+    const Px8 d0a = load_px8_at( s0base, od[0] ), d0b = load_px8_at( s0base, od[1] ), d1a = load_px8_at( s1base, od[2] ), d1b = load_px8_at( s1base, od[3] );
+    const Px8 m0a = load_px8_at( s0base, om[0] ), m0b = load_px8_at( s0base, om[1] ), m1a = load_px8_at( s1base, om[2] ), m1b = load_px8_at( s1base, om[3] );
+    auto avg8 = [&]( const Px8 &a, const Px8 &b ) -> Px8 {
+        Px8 r;
+        r.lo = avg_px4( a.lo, b.lo, (const T *)nullptr ); r.hi = avg_px4( a.hi, b.hi, (const T *)nullptr );
+        return r;
+    };
+    const int v_zero = block_cost8<T>( f, mix( z0, z1 ), P.mbcmp_satd );
+    const int v_dmv = block_cost8<T>( f, mix( avg8( d0a, d0b ), avg8( d1a, d1b ) ), P.mbcmp_satd );
+    const int v_mv = block_cost8<T>( f, mix( avg8( m0a, m0b ), avg8( m1a, m1b ) ), P.mbcmp_satd );
     // lane k collects the costs of block k (any lane of group k holds them) and chooses
     const int back = ( imin2( lane, 7 ) << 3 ) << 2; // ds_bpermute address of lane 8 k
     const int c_dmv = __builtin_amdgcn_ds_bpermute( back, v_dmv ), c_zero = __builtin_amdgcn_ds_bpermute( back, v_zero ), c_mv = __builtin_amdgcn_ds_bpermute( back, v_mv );
     if( lane < nb )
     {
+        // the block's word and map entry (cell_finish without its intra comparison, which a bidirectional cell does not make)
+        auto finish = [&]( int bcost, int list_used, int *blk, uint16_t *map ) {
+            bcost = ( bcost >> P.depth_shift ) + 4;
+            blk[xy_mine] = bcost;
+            map[xy_mine] = (uint16_t)( imin2( bcost, 0x3FFF ) + ( list_used << 14 ) );
+        };
         int bcost = COST_MAX_I, list_used = 0;
         if( c_dmv < bcost ) { bcost = c_dmv; list_used = 3; }              // the scaled vectors of the list-1 reference (zero without them)
         if( dmv_nz && c_zero < bcost ) { bcost = c_zero; list_used = 3; }  // zero vectors, if those were not zero
@@ -1000,7 +1023,7 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
             const int c = 5 * P.lambda + c_mv;
             if( c < bcost ) { bcost = c; list_used = 3; }
         }
-        cell_finish( P, A, xy_mine, bcost, list_used );
+        finish( bcost, list_used, A.blk, A.lowres_costs );
         if( A.dual )
         {
             // the same block WITHOUT the list-1 reference's vectors (slicetype.c:629 false): the zero vectors take the first place, the
@@ -1014,7 +1037,7 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
                 const int c = 5 * P.lambda + c_mv;
                 if( c < b2 ) { b2 = c; l2 = 3; }
             }
-            cell_finish( P, A, xy_mine, b2, l2, true );
+            finish( b2, l2, A.blk2, A.lowres_costs2 );
         }
     }
 }

@@ -443,7 +443,7 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
         leave();
         return;
     }
-    const SearchDesc<T> D = descs[s];
+    const SearchDesc<T> D = load_uniform( descs + s ); // s is wave-uniform (the ticket went through an SGPR)
     const int g = lane >> 3;
     const int by0 = H - 1 - ME_ROWS * j; // row of group 0 (scalar)
     const int by = by0 - g;               // this group's row
