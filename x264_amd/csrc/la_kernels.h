@@ -1096,10 +1096,24 @@ __device__ __forceinline__ void load_row8<uint16_t>( const uint16_t *p, Px4 f[2]
 // kernel had two dependent memory round trips and 32 bytes in flight per lane; RR = 4 keeps 128).
 template <typename T, int BW, int BH, bool SATD, int RR>
 __global__ __launch_bounds__( 256 ) void pixel_cmp_batch_kernel( const T *__restrict__ fenc, const T *__restrict__ ref, int stride,
-                                                                 int regions_w, int regions_h, const int16_t *__restrict__ mv, int *__restrict__ out )
+                                                                 int regions_w, int regions_h, const int16_t *__restrict__ mv, int *__restrict__ out, int xcd_bands )
 {
     const int lane = lane_id();
-    const int rx0 = ( blockIdx.x * 4 + ( threadIdx.x >> 6 ) ) * 4;
+    // workgroups go to the 8 XCDs round robin by their linear index: XCD k takes the k-th horizontal band of the field, so that the reference
+    // rows two vertically neighbouring workgroups both read (vectors move a block up to the search range) are fetched into ONE L2
+    int wg_x = blockIdx.x, wg_y = blockIdx.y;
+    if( xcd_bands )
+    {
+        // a bijection of the linear workgroup index: the indices XCD k receives (k, k + 8, ...) become one contiguous run of the row-major order
+        const int G = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x, xcd = id & 7;
+        int start = 0;
+        for( int j = 0; j < xcd; j++ )
+            start += ( G - j + 7 ) >> 3;
+        const int id2 = start + ( id >> 3 );
+        wg_y = id2 / (int)gridDim.x;
+        wg_x = id2 - wg_y * (int)gridDim.x;
+    }
+    const int rx0 = ( wg_x * 4 + ( threadIdx.x >> 6 ) ) * 4;
     if( rx0 >= regions_w )
         return; // wave-uniform
     const int rx = rx0 + ( lane >> 4 ), row = lane & 15;
@@ -1111,7 +1125,7 @@ __global__ __launch_bounds__( 256 ) void pixel_cmp_batch_kernel( const T *__rest
 #pragma unroll
     for( int q = 0; q < RR; q++ )
     {
-        const int ry = imin2( blockIdx.y * RR + q, regions_h - 1 );
+        const int ry = imin2( wg_y * RR + q, regions_h - 1 );
         const int by = ry * NY + row / BH;
 #pragma unroll
         for( int k = 0; k < NX; k++ )
@@ -1121,7 +1135,7 @@ __global__ __launch_bounds__( 256 ) void pixel_cmp_batch_kernel( const T *__rest
 #pragma unroll
     for( int q = 0; q < RR; q++ )
     {
-        const int ry = imin2( blockIdx.y * RR + q, regions_h - 1 );
+        const int ry = imin2( wg_y * RR + q, regions_h - 1 );
         const size_t o = (size_t)( ry * 16 + row ) * stride + rxc * 16;
         load_row16<T>( fenc + o, f[q] );
 #pragma unroll
@@ -1139,7 +1153,7 @@ __global__ __launch_bounds__( 256 ) void pixel_cmp_batch_kernel( const T *__rest
 #pragma unroll
     for( int q = 0; q < RR; q++ )
     {
-        const int ry = blockIdx.y * RR + q;
+        const int ry = wg_y * RR + q;
         const int by = ry * NY + row / BH;
         int part[4];
 #pragma unroll

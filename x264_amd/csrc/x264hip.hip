@@ -2284,12 +2284,13 @@ extern "C" int x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx
     const int wgs1 = ( ( rw + 15 ) / 16 ) * rh;
     const int rr = rows_env == 1 || rows_env == 2 || rows_env == 4 || rows_env == 8 ? rows_env : wgs1 >= 32 * ctx->n_cu ? 4 : wgs1 >= 4 * ctx->n_cu ? 2 : 1;
     const dim3 grd( ( rw + 15 ) / 16, ( rh + rr - 1 ) / rr );
+    static const int xcd_bands = !( getenv( "X264HIP_CMP_BANDS" ) && atoi( getenv( "X264HIP_CMP_BANDS" ) ) == 0 ); // 0: workgroups in launch order (A/B aid)
 #define CMP_LAUNCH( T, BW, BH, D ) \
     do { \
-        if( rr == 8 ) pixel_cmp_batch_kernel<T, BW, BH, D, 8><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev ); \
-        else if( rr == 4 ) pixel_cmp_batch_kernel<T, BW, BH, D, 4><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev ); \
-        else if( rr == 2 ) pixel_cmp_batch_kernel<T, BW, BH, D, 2><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev ); \
-        else pixel_cmp_batch_kernel<T, BW, BH, D, 1><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev ); \
+        if( rr == 8 ) pixel_cmp_batch_kernel<T, BW, BH, D, 8><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev, xcd_bands ); \
+        else if( rr == 4 ) pixel_cmp_batch_kernel<T, BW, BH, D, 4><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev, xcd_bands ); \
+        else if( rr == 2 ) pixel_cmp_batch_kernel<T, BW, BH, D, 2><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev, xcd_bands ); \
+        else pixel_cmp_batch_kernel<T, BW, BH, D, 1><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev, xcd_bands ); \
     } while( 0 )
 #define CMP_METRIC( T, BW, BH ) do { if( satd ) CMP_LAUNCH( T, BW, BH, true ); else CMP_LAUNCH( T, BW, BH, false ); } while( 0 )
 #define CMP_SIZE( T ) \
