@@ -135,6 +135,20 @@ __device__ __forceinline__ Px4 load_px4( const uint16_t *p )
 // Loads through a wave-uniform base pointer plus an unsigned 32-bit byte offset: the backend emits the
 // `global_load_* v, v_off, s[base:base+1]` form (no 64-bit VALU address arithmetic, no flat aperture check).
 #define AS_GLOBAL __attribute__( ( address_space( 1 ) ) )
+// Workgroups of a 2-D grid reach the 8 XCDs round robin by their linear index, so vertical neighbours -- which share the rows a filter's
+// taps or a displaced block reach into -- sit behind different L2s and each fetches those rows from memory.  This bijection of the linear
+// index hands XCD k (indices k, k + 8, ...) ONE contiguous run of the row-major order, i.e. a horizontal band of the field: shared rows are
+// fetched once per band border instead of once per workgroup row.  (bx, by) replace blockIdx.x / blockIdx.y; scalar arithmetic only.
+__device__ __forceinline__ void xcd_band_block( int &bx, int &by )
+{
+    const int G = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x, xcd = id & 7;
+    int start = 0;
+    for( int j = 0; j < xcd; j++ )
+        start += ( G - j + 7 ) >> 3;
+    const int id2 = start + ( id >> 3 );
+    by = id2 / (int)gridDim.x;
+    bx = id2 - by * (int)gridDim.x;
+}
 // A descriptor every lane of the wave reads from the same address (a table entry picked by blockIdx): fetched through the scalar cache, so
 // its fields -- the pointers above all -- land in SGPRs: one s_load instead of a round of per-lane loads, and every load through one of
 // those pointers is a plain global load with a scalar base (no flat aperture check, no v_readfirstlane pair in front of it).  The table

@@ -1099,20 +1099,11 @@ __global__ __launch_bounds__( 256 ) void pixel_cmp_batch_kernel( const T *__rest
                                                                  int regions_w, int regions_h, const int16_t *__restrict__ mv, int *__restrict__ out, int xcd_bands )
 {
     const int lane = lane_id();
-    // workgroups go to the 8 XCDs round robin by their linear index: XCD k takes the k-th horizontal band of the field, so that the reference
-    // rows two vertically neighbouring workgroups both read (vectors move a block up to the search range) are fetched into ONE L2
+    // XCD k takes the k-th horizontal band of the field (device_common.h xcd_band_block): the reference rows two vertically neighbouring
+    // workgroups both read (vectors move a block up to the search range) are fetched into ONE L2 -- 4.1 -> 5.1 TB/s on the 265 MB mosaic
     int wg_x = blockIdx.x, wg_y = blockIdx.y;
     if( xcd_bands )
-    {
-        // a bijection of the linear workgroup index: the indices XCD k receives (k, k + 8, ...) become one contiguous run of the row-major order
-        const int G = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x, xcd = id & 7;
-        int start = 0;
-        for( int j = 0; j < xcd; j++ )
-            start += ( G - j + 7 ) >> 3;
-        const int id2 = start + ( id >> 3 );
-        wg_y = id2 / (int)gridDim.x;
-        wg_x = id2 - wg_y * (int)gridDim.x;
-    }
+        xcd_band_block( wg_x, wg_y );
     const int rx0 = ( wg_x * 4 + ( threadIdx.x >> 6 ) ) * 4;
     if( rx0 >= regions_w )
         return; // wave-uniform
@@ -1339,8 +1330,10 @@ __global__ __launch_bounds__( 64 ) void hpel_stream_kernel( uint8_t *__restrict_
                                                             int stride, int width, int height )
 {
     const int lane = threadIdx.x;
-    const int x = blockIdx.x * HPS_W + 4 * ( lane - 1 ), y0 = blockIdx.y * HPS_R;
-    const bool last_tile = blockIdx.x == gridDim.x - 1;
+    int wg_x, wg_y;
+    xcd_band_block( wg_x, wg_y ); // the five extra rows of a strip are its vertical neighbours' rows: one L2 per band of strips
+    const int x = wg_x * HPS_W + 4 * ( lane - 1 ), y0 = wg_y * HPS_R;
+    const bool last_tile = wg_x == (int)gridDim.x - 1;
     // The strip's rows y0-2 .. y0+R+2, never beyond what the reference itself reads (columns -2 .. width+2, rows .. height+2), each
     // split once into its ( c0, c2 ) and ( c1, c3 ) pairs of 16-bit values.  Offsets are relative to sample (-2, -2): never negative.
     const uint8_t *s0 = src - 2 * (long)stride - 2;
@@ -1407,7 +1400,7 @@ __global__ __launch_bounds__( 64 ) void hpel_stream_kernel( uint8_t *__restrict_
                     }
             }
             // the reference's five extra dstv columns (-2, -1, width .. width+2)
-            if( blockIdx.x == 0 && lane == 0 )
+            if( wg_x == 0 && lane == 0 )
             {
                 uint8_t *q = dstv + (long)y * stride;
                 q[-2] = (uint8_t)( ov >> 16 ); q[-1] = (uint8_t)( ov >> 24 );
@@ -1443,8 +1436,10 @@ __global__ __launch_bounds__( 64 ) void hpel_stream16_kernel( uint16_t *__restri
                                                               const uint16_t *__restrict__ src, int stride, int width, int height, int pixel_max )
 {
     const int lane = threadIdx.x;
-    const int x = blockIdx.x * HPS_W + 4 * ( lane - 1 ), y0 = blockIdx.y * HPS_R;
-    const bool last_tile = blockIdx.x == gridDim.x - 1;
+    int wg_x, wg_y;
+    xcd_band_block( wg_x, wg_y ); // the five extra rows of a strip are its vertical neighbours' rows: one L2 per band of strips
+    const int x = wg_x * HPS_W + 4 * ( lane - 1 ), y0 = wg_y * HPS_R;
+    const bool last_tile = wg_x == (int)gridDim.x - 1;
     // rows y0-2 .. y0+R+2 of the strip, never beyond what the reference itself reads (columns -2 .. width+2, rows .. height+2); offsets
     // are relative to sample (-2, -2): never negative
     const uint16_t *s0 = src - 2 * (long)stride - 2;
@@ -1525,7 +1520,7 @@ __global__ __launch_bounds__( 64 ) void hpel_stream16_kernel( uint16_t *__restri
                         }
             }
             // the reference's five extra dstv columns (-2, -1, width .. width+2)
-            if( blockIdx.x == 0 && lane == 0 )
+            if( wg_x == 0 && lane == 0 )
             {
                 uint16_t *q = dstv + (long)y * stride;
                 q[-2] = (uint16_t)ov[2]; q[-1] = (uint16_t)ov[3];
