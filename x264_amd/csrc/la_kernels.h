@@ -1800,7 +1800,7 @@ __global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *
     unsigned n_bar = 0;
     for( int k = 0; k < n_ops; k++ )
     {
-        const MbtOpDev o = ops[k];
+        const MbtOpDev o = load_uniform( ops + k ); // the same entry for every thread: through the scalar cache (the table was uploaded by an earlier launch)
         if( o.barrier_before )
         {
             __builtin_amdgcn_s_waitcnt( 0 );
