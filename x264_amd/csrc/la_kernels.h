@@ -119,7 +119,9 @@ __global__ __launch_bounds__( 256 ) void strips_kernel( const PutDesc *descs, Pu
 // are not read back, so a frame costs W*H read + 4*S + 8*S written and nothing else (the two-kernel form read the 4*S again, from
 // HBM once a batch of frames exceeds the caches).  Columns at and beyond the padded width (< stride) are zero in the strips and
 // untouched in the planes; no candidate reads them.
+#ifndef LT_ROWS
 #define LT_ROWS 32
+#endif
 #define LT_COLS 128
 #define LT_PITCH 144 // samples per tile row in LDS: LT_COLS + 8, rounded up to keep every row 16-byte aligned
 template <typename T>
@@ -196,9 +198,11 @@ __global__ __launch_bounds__( 256 ) void lowres_tiles_kernel( const PutDesc *des
             __builtin_memcpy( &tile[p][r][4 * q], o[p], 4 * sizeof( T ) );
     }
     __syncthreads();
+#pragma unroll
+    for( int rp = 0; rp < LT_ROWS / 32; rp++ )
     {
         // row-major planes: LT_ROWS rows x 8 pieces of 16 samples
-        const int r = tid >> 3, c = ( tid & 7 ) * 16;
+        const int r = rp * 32 + ( tid >> 3 ), c = ( tid & 7 ) * 16;
         const int Y = Y0 + r, X = X0 + c;
         if( Y < rows )
         {
