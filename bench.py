@@ -637,7 +637,7 @@ def main():
                          lib.la_config(3840, 2160, "slower", bit_depth=8, me="umh", me_range=32), 64, S, 4)
             # BASELINE configs[4] on one GPU: 7680x4320 10-bit, --preset veryslow --me tesa (HEX with SATD full-pel costs, bframes 8, b-adapt 2,
             # rc-lookahead 60); a dozen frames per segment: the window never fills, every frame is decided at the flush
-            other_config("configs4_8k_1gpu", "7680x4320 10-bit, --preset veryslow --me tesa (BASELINE configs[4], one GPU)",
+            other_config("configs4_8k_1gpu", "7680x4320 10-bit, --preset veryslow --me tesa (BASELINE configs[4], one GPU; a dozen frames per segment never fill the 60-frame window: every frame is decided at the flush)",
                          lib.la_config(7680, 4320, "veryslow", bit_depth=10, me="tesa"), 12, 4, 6, depth_x=10, cuts=(7,))
             # ONE stream alone on the GPU (one context, one host thread: what a single encoder instance sees), batched and
             # encoder-paced, for configs[1] and configs[2]; same check as above
