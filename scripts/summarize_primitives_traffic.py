@@ -31,7 +31,7 @@ def load(counter):
 
 fetch, dur_f = load("FETCH_SIZE")
 write, dur_w = load("WRITE_SIZE")
-keep = ("pixel_cmp_batch_kernel", "hpel_stream", "hpel_filter_kernel", "frame_dct_quant", "copy16_kernel", "lowres_kernel", "strips_kernel", "me_full")
+keep = ("pixel_cmp_batch_kernel", "hpel_stream", "hpel_filter_kernel", "frame_dct_quant", "copy16_kernel", "lowres_tiles_kernel", "lowres_kernel", "strips_kernel", "me_full")
 out = {"command": "scripts/pmc_primitives.sh %s (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python scripts/prim_bench.py)" % tag,
        "note": "bytes = counter x 1024, uncorrected.  Calibration inside this very run: copy16_kernel moves 512 MiB each way -- WRITE_SIZE is exact, FETCH_SIZE reports half "
                "(16 B / lane streaming reads: the guide's gfx950 correction, x2).  Narrower reads are tallied differently (lowres_kernel: x1.2-1.3, DESIGN.md section 5), so for the other "

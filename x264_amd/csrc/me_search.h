@@ -26,7 +26,7 @@
 //   DPP steps.  SATD is the sum of four 4x4 transforms: the two column halves of a lane go through the quad-wide transform of
 //   device_common.h one after the other.  (Round 2 started with 16 lanes x 4 pixels and four rows per wave: 249 VALU
 //   instructions per block against 171 now.)
-// * Reference samples come from the STRIP copy of the planes (written next to the row-major planes by lowres_kernel): strip k
+// * Reference samples come from the STRIP copy of the planes (written next to the row-major planes by lowres_tiles_kernel): strip k
 //   of a plane holds columns 8k .. 8k+15 of every row, 16 samples per row, rows one after the other.  The eight rows of a
 //   block candidate are then 128 consecutive bytes (2-3 cache lines) instead of one line per row (~9 per block and candidate
 //   in row-major planes: the eight-row kernel on row-major planes was SLOWER than the four-row one, 11.6 against 8.7 us per
