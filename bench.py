@@ -430,6 +430,9 @@ def main():
     over = dict(me=args.me, threads=args.threads)
     if args.me_range:
         over["me_range"] = args.me_range
+    for kv in filter(None, os.environ.get("X264HIP_BENCH_CFG", "").split(",")):  # experiments only, e.g. mb_tree=0: the line is then NOT the BASELINE workload
+        k, v = kv.split("=")
+        over[k] = int(v)
     cfg = lib.la_config(W, H, args.preset, bit_depth=args.bit_depth, **over)
     nb = cfg["bframes"] + 2
     S = max(1, args.inflight)

@@ -137,6 +137,11 @@ def check_lookahead_outputs(outs, z, nb, check_qp=True):
         for k, o in enumerate(outs):
             assert np.array_equal(o.qp_offset, z["qp_offset"][k]), ("f_qp_offset", k, o.frame, o.type,
                                                                    float(np.abs(o.qp_offset - z["qp_offset"][k]).max()))
+    if check_qp and "qp_crc" in z and hasattr(outs[0], "qp_offset"):
+        # full-size fixtures hold a CRC-32 of every frame's f_qp_offset instead of the map
+        import zlib
+        for k, o in enumerate(outs):
+            assert zlib.crc32(np.ascontiguousarray(o.qp_offset, np.float32).tobytes()) == int(z["qp_crc"][k]), ("f_qp_offset crc", k, o.frame, o.type)
     if "planned_type" in z and hasattr(outs[0], "planned"):
         # VBV outputs (slicetype.c:1224-1286, :1916-1934): plans of the non-B frames, row sums of the cell each frame is coded with
         for k, o in enumerate(outs):

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import refharness
-from tests.golden.make_golden import LOOKAHEAD_CASES
+from tests.golden.make_golden import FULL_SIZE_CASES, LOOKAHEAD_CASES
 from tests.test_golden import GOLD, check_lookahead_outputs
 from x264_amd import lib
 from x264_amd.synth import make_clip
@@ -65,6 +65,31 @@ def test_full_size_vs_reference(W, H, depth, preset, opts, over, nf):
     z = dict(idx=ref["idx"], type=ref["type"], cost=ref["cost"][:, :nb, :nb], cost_aq=ref["cost_aq"][:, :nb, :nb],
              qp_offset=ref["qp_offset"])
     check_lookahead_outputs(outs, z, nb)
+
+
+@pytest.mark.parametrize("name", list(FULL_SIZE_CASES))
+def test_baseline_configs_as_written(name):
+    """BASELINE configs[3] (3840x2160, ONE 250-frame GOP, --rc-lookahead 60 --bframes 8) and configs[4] (7680x4320 10-bit, --preset
+    veryslow --me tesa, 72 frames: the 60-frame window fills and slides, b-adapt 2 trellis over a full window) at their full size against
+    fixtures the real reference produced in the build container (tests/golden/make_golden.py --full-size): coded order, slice types,
+    every cost cell, and a CRC of every frame's f_qp_offset -- encoder-paced and with every frame queued before the first decision."""
+    import zlib
+    from x264_amd.synth import upscaled_clip
+    preset, opts, over, depth, W, H, ckw, nf = FULL_SIZE_CASES[name]
+    z = np.load(os.path.join(GOLD, "fullsize_%s.npz" % name))
+    frames = upscaled_clip(W, H, nf, depth, **ckw)
+    for k in (0, nf // 2, nf - 1):  # the clip is the one the reference saw
+        assert zlib.crc32(frames[k].tobytes()) == int(z["frame_crc"][k]), "clip differs from the fixture's (numpy version?)"
+    cfg = lib.la_config(W, H, preset, bit_depth=depth, **over)
+    gold_cfg = {str(k): int(v) for k, v in zip(z["cfg_keys"], z["cfg"])}
+    assert (cfg["bframes"], cfg["b_adapt"], cfg["rc_lookahead"]) == (gold_cfg["bframes"], gold_cfg["b_adapt"], gold_cfg["rc_lookahead"])
+    for paced in (True, False):
+        la = lib.Lookahead(cfg, max_frames=0 if paced else nf + 4)
+        try:
+            outs = la.run(frames, paced=paced, qp_offsets=True)
+        finally:
+            la.close()
+        check_lookahead_outputs(outs, z, cfg["bframes"] + 2)
 
 
 @pytest.mark.parametrize("W,H,preset,over,nf", [(1920, 1080, "slow", dict(me="dia"), 70), (3840, 2160, "medium", dict(bframes=8, rc_lookahead=60), 30)])

@@ -330,19 +330,7 @@ def test_frame_cost_recalculate():
         ctx.close()
 
 
-def upscaled_clip(W, H, n, depth, factor=4, **kw):
-    """A picture sequence of BASELINE configs[4] size without minutes of numpy filtering: a (W/factor x H/factor) synthetic clip
-    enlarged by sample repetition plus a little per-sample noise (so that neighbouring blocks differ and sub-pel positions matter)."""
-    from x264_amd.synth import make_clip
-    small = make_clip(W // factor, H // factor, n, bit_depth=depth, **kw)
-    rng = np.random.default_rng(kw.get("seed", 1))
-    out = np.empty((n, H, W), small.dtype)
-    hi = (1 << depth) - 1
-    for i in range(n):
-        big = np.repeat(np.repeat(small[i], factor, axis=0), factor, axis=1).astype(np.int32)
-        big += rng.integers(-6, 7, big.shape, dtype=np.int32)
-        out[i] = np.clip(big, 0, hi).astype(small.dtype)
-    return out
+from x264_amd.synth import upscaled_clip  # noqa: E402,F401  (imported from here by other test modules)
 
 
 def test_8k_10bit_search_matches_oracle():

@@ -69,6 +69,8 @@ __device__ __forceinline__ int reduce16( int v )
 __device__ __forceinline__ int iabs( int v ) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int imin2( int a, int b ) { return a < b ? a : b; }
 __device__ __forceinline__ int imax2( int a, int b ) { return a > b ? a : b; }
+__device__ __forceinline__ int imax3( int a, int b, int c ) { return imax2( imax2( a, b ), c ); } // v_max3_i32
+__device__ __forceinline__ int imin3( int a, int b, int c ) { return imin2( imin2( a, b ), c ); } // v_min3_i32
 __device__ __forceinline__ int iclip3( int v, int lo, int hi ) { return v < lo ? lo : v > hi ? hi : v; }
 __device__ __forceinline__ int median3i( int a, int b, int c )
 {
@@ -179,6 +181,12 @@ __device__ __forceinline__ uint2 gload_u64( const void *ubase, unsigned byte_off
     uint2 w;
     __builtin_memcpy( &w, (const AS_GLOBAL char *)ubase + byte_off, 8 );
     return w;
+}
+typedef unsigned u32x3 __attribute__( ( ext_vector_type( 3 ) ) );
+__device__ __forceinline__ u32x3 gload_u96( const void *ubase, unsigned byte_off ) // byte_off a multiple of 4
+{
+    typedef u32x3 u32x3_a4 __attribute__( ( aligned( 4 ) ) );
+    return *(const AS_GLOBAL u32x3_a4 *)( (const AS_GLOBAL char *)ubase + byte_off );
 }
 __device__ __forceinline__ int gload_u16( const void *ubase, unsigned byte_off )
 {

@@ -36,6 +36,9 @@
 #endif
 
 #define ME_COST_MAX ( 1 << 28 )
+#ifndef ME_QSTAR
+#define ME_QSTAR 1 // 0: the quarter-pel diamond always as a general set (A/B builds)
+#endif
 
 struct MeCfg
 {
@@ -168,6 +171,16 @@ struct ScalarSets
             if( ok ) return true;
         }
         return false;
+    }
+    // the quarter-pel diamond around ( mvx, mvy ) with the centre as candidate 0 (see search()): here simply the set it stands for
+    int qpel_star5( int use_satd, int mvx, int mvy, bool inside )
+    {
+        int c0;
+        return qpel_set<5>( use_satd, [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
+            const bool moved = k > 0 && inside;
+            x = moved ? mvx + dia_dx( k - 1 ) : mvx; y = moved ? mvy + dia_dy( k - 1 ) : mvy;
+            ok = k == 0 || inside; wb = true;
+        }, c0 );
     }
     template <int N, class G>
     int qpel_set( int use_satd, G gen, int &cost0 )
@@ -408,7 +421,9 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
             const bool inside = !( mvy <= L.smin_y || mvy >= L.smax_y || mvx <= L.smin_x || mvx >= L.smax_x );
             if( C.mbcmp_satd != C.fpelcmp_satd )
             {
-                const int p = ev.template qpel_set<5>( C.mbcmp_satd, [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
+                // (at a half-pel position the evaluator may know a cheaper way to the same five costs: E::qpel_star5)
+                const int p = ME_QSTAR && !ev.any( ( ( mvx | mvy ) & 1 ) != 0 ) ? ev.qpel_star5( C.mbcmp_satd, mvx, mvy, inside ) :
+                              ev.template qpel_set<5>( C.mbcmp_satd, [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
                     const bool moved = k > 0 && inside;
                     x = moved ? mvx + dia_dx( k - 1 ) : mvx; y = moved ? mvy + dia_dy( k - 1 ) : mvy;
                     ok = k == 0 || inside; wb = true;

@@ -90,11 +90,26 @@ struct Px8
     Px4 lo, hi; // samples 0..3 and 4..7 of this lane's row
 };
 
+// A wave-wide load whose lanes are not dword-aligned is split by the L1's address unit: 30 CU-cycles per instruction for the 8 bytes of a
+// candidate row at its own byte offset against 17.3 for ANY dword-aligned 4 / 8 / 12 / 16 bytes per lane -- the rate of a fully coalesced
+// load (experiments/mem_rates, profiles/r05_mem_rates.json).  ME_ALIGN=1 reads a tap as the three aligned dwords that cover it (they
+// never leave the 16-sample strip row: the offset inside the row is at most 8) and shifts it into place with two v_alignbyte.  Measured
+// (profiles/r05_search_ab.txt): 3.31 against 3.28 us per 1080p search -- the four extra vector instructions per load cost what the L1
+// time saves, the kernel is not bound by the L1's address unit -- so the plain unaligned load stays the default.
+#ifndef ME_ALIGN
+#define ME_ALIGN 0
+#endif
 __device__ __forceinline__ Px8 load_px8_at( const uint8_t *ubase, int elem_off )
 {
-    const uint2 w = gload_u64( ubase, (unsigned)elem_off ); // one global_load_dwordx2 at any byte alignment
     Px8 r;
+#if ME_ALIGN
+    const u32x3 w = gload_u96( ubase, (unsigned)elem_off & ~3u );
+    const unsigned t = (unsigned)elem_off & 3u;
+    r.lo = px4_from_raw( __builtin_amdgcn_alignbyte( w.y, w.x, t ) ); r.hi = px4_from_raw( __builtin_amdgcn_alignbyte( w.z, w.y, t ) );
+#else
+    const uint2 w = gload_u64( ubase, (unsigned)elem_off ); // one global_load_dwordx2 at any byte alignment
     r.lo = px4_from_raw( w.x ); r.hi = px4_from_raw( w.y );
+#endif
     return r;
 }
 __device__ __forceinline__ Px8 load_px8_at( const uint16_t *ubase, int elem_off )
@@ -364,6 +379,41 @@ struct GroupEval
         cost0 = from_slot<0>( S, total );
         return pack_min<N>( total, ok );
     }
+    // The quarter-pel diamond around a vector at a half-pel position (both components even), its centre re-costed as candidate 0
+    // (me_logic.h): each of the four neighbours is the rounded average of the centre's sample run and of the run at the half-pel
+    // position two quarter-pels further on (get_ref, mc.c:218-249 with the tables of tables.c:183-184: one tap of an odd position is
+    // the even position next to it in each direction) -- five single-tap runs instead of ten taps, one address each.
+    __device__ __forceinline__ int qpel_star5( int use_satd, int mvx, int mvy, bool inside ) const
+    {
+        const int k = imin2( S.slot, 4 );
+        const int dx = k && inside ? melogic::dia_dx( k - 1 ) : 0, dy = k && inside ? melogic::dia_dy( k - 1 ) : 0;
+        const int px = mvx + 2 * dx, py = mvy + 2 * dy; // the half-pel point this lane addresses
+        int oa, ob;
+        strip_layout::qpel_taps( plane_elems, strip_off( cx0 + ( px >> 2 ), row16 + ( ( py >> 2 ) << 4 ), strip_elems ), px, py, oa, ob );
+        const int b = bits( mvx + dx, mvy + dy );
+        const int t0 = from_slot<0>( S, oa ), t1 = from_slot<1>( S, oa ), t2 = from_slot<2>( S, oa ), t3 = from_slot<3>( S, oa ), t4 = from_slot<4>( S, oa );
+        const Px8 p0 = load_px8_at( sbase, t0 + S.row16 ), p1 = load_px8_at( sbase, t1 + S.row16 ), p2 = load_px8_at( sbase, t2 + S.row16 ),
+                  p3 = load_px8_at( sbase, t3 + S.row16 ), p4 = load_px8_at( sbase, t4 + S.row16 );
+        const Px8 *const p[5] = { &p0, &p1, &p2, &p3, &p4 };
+        int c[5];
+#pragma unroll
+        for( int j = 0; j < 5; j++ )
+        {
+            Px8 r = p0;
+            if( j )
+            {
+                r.lo = avg_px4( p0.lo, p[j]->lo, (const T *)nullptr ); r.hi = avg_px4( p0.hi, p[j]->hi, (const T *)nullptr );
+            }
+            if( WEIGHTED )
+            {
+                r.lo = weight_px4<T>( r.lo, wt, pixel_max ); r.hi = weight_px4<T>( r.hi, wt, pixel_max );
+            }
+            c[j] = block_partial8<T>( f, r, use_satd );
+        }
+        int total = reduce_slots<5>( S, c );
+        if( use_satd ) total >>= 1;
+        return pack_min<5>( total + b, k == 0 || inside );
+    }
     __device__ __forceinline__ bool any( bool c ) const { return __builtin_amdgcn_ballot_w64( c ) != 0ull; }
 #ifdef ME_PROFILE
     unsigned long long pf_last;
@@ -571,14 +621,14 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
 #endif
                 if( !done )
                 {
-                    // how far from the predictor can a candidate of this block be?  (me_search.h)
-                    int reach = imax2( iabs( mvpx ), iabs( mvpy ) );
-#pragma unroll
-                    for( int i = 0; i < 4; i++ )
-                        if( i < n )
-                            reach = imax2( reach, imax2( iabs( mvcx[i] - mvpx ), iabs( mvcy[i] - mvpy ) ) );
-                    reach = imax2( reach, imax2( iabs( iclip3( mvpx, 4 * L.fmin_x, 4 * L.fmax_x ) - mvpx ), iabs( iclip3( mvpy, 4 * L.fmin_y, 4 * L.fmax_y ) - mvpy ) ) );
-                    reach = imax2( reach, imax2( iabs( iclip3( mvpx, L.smin_x + 2, L.smax_x - 2 ) - mvpx ), iabs( iclip3( mvpy, L.smin_y + 2, L.smax_y - 2 ) - mvpy ) ) );
+                    // How far from the predictor can a candidate of this block be?  Every start candidate is the predictor, a neighbour's
+                    // vector, one of them clipped (towards zero: the limits include the zero vector) or the zero vector, and the predictor
+                    // is a neighbour's vector or a median of them: with m the largest component of the neighbours (absent ones are zero),
+                    // no difference to the predictor exceeds 2 m.  (The exact maximum took 59 vector instructions per step for a test that
+                    // fails only for vectors beyond a hundred samples; min / max of the eight components take 8.)
+                    const int hi = imax2( imax3( mvcx[0], mvcx[1], mvcx[2] ), imax3( mvcx[3], mvcy[0], imax3( mvcy[1], mvcy[2], mvcy[3] ) ) );
+                    const int lo = imin2( imin3( mvcx[0], mvcx[1], mvcx[2] ), imin3( mvcx[3], mvcy[0], imin3( mvcy[1], mvcy[2], mvcy[3] ) ) );
+                    const int reach = 2 * imax2( hi, -lo );
                     const bool far = reach + 4 * ( P.me_range + 4 ) >= ME_TAB_HALF;
                     if( __builtin_amdgcn_ballot_w64( far ) == 0ull )
                     {

@@ -284,6 +284,16 @@ struct TeamEval
         cost0 = from_slot<0>( S, total );
         return pack_min<N>( total, ok );
     }
+    // me_logic.h's shortcut for the quarter-pel diamond at a half-pel position: the window serves the ten taps as they are
+    __device__ __forceinline__ int qpel_star5( int use_satd, int mvx, int mvy, bool inside ) const
+    {
+        int c0;
+        return qpel_set<5>( use_satd, [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
+            const bool moved = k > 0 && inside;
+            x = moved ? mvx + melogic::dia_dx( k - 1 ) : mvx; y = moved ? mvy + melogic::dia_dy( k - 1 ) : mvy;
+            ok = k == 0 || inside; wb = true;
+        }, c0 );
+    }
     __device__ __forceinline__ bool any( bool c ) const { return __builtin_amdgcn_ballot_w64( c ) != 0ull; }
 #ifdef ME_PROFILE
     unsigned long long pf_last;
@@ -407,6 +417,16 @@ struct WaveEval
         total += b;
         cost0 = __builtin_amdgcn_readlane( total, 0 );
         return wave_min_groups( ok && grp < N ? ( total << 3 ) | k : ME_PACK_MAX );
+    }
+    // me_logic.h's shortcut for the quarter-pel diamond at a half-pel position: the window serves the ten taps as they are
+    __device__ __forceinline__ int qpel_star5( int use_satd, int mvx, int mvy, bool inside ) const
+    {
+        int c0;
+        return qpel_set<5>( use_satd, [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
+            const bool moved = k > 0 && inside;
+            x = moved ? mvx + melogic::dia_dx( k - 1 ) : mvx; y = moved ? mvy + melogic::dia_dy( k - 1 ) : mvy;
+            ok = k == 0 || inside; wb = true;
+        }, c0 );
     }
     __device__ __forceinline__ bool any( bool c ) const { return c; } // uniform
 #ifdef ME_PROFILE

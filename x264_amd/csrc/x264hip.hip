@@ -1628,6 +1628,8 @@ static int mbt_flush( x264hip_ctx *ctx )
     // Measured (two segments in flight, 1080p): copying the step list to the device in front of the launch gives 8500 frames/s,
     // letting every workgroup pull it from pinned host memory into LDS 8070
     HIPCK( upload_async( ctx, ctx->mbt_dev[r], ctx->mbt_host[r], (size_t)G.beg[G.n] * sizeof( MbtOpDev ), ctx->stream2 ) );
+    static const bool skip_kernel = getenv( "X264HIP_MBT_SKIP" ) != nullptr; // timing experiments only: what the stream costs the others (offsets are then wrong)
+    if( !skip_kernel )
     mbtree_kernel<<<G.n * mbt_wgs, mbt_threads, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], G, mbt_wgs, ctx->luts_dev,
                                                                     ctx->mbt_bar + (size_t)r * MBT_MAX_GROUPS * 4,
                                                                     ctx->mbt_bar + (size_t)x264hip_ctx::MBT_RING * MBT_MAX_GROUPS * 4 );

@@ -68,3 +68,19 @@ def make_chroma(width, height, n_frames, seed=0, bit_depth=8):
     cb = np.stack([np.clip(np.roll(smooth, i, axis=1) + rng.integers(-9, 10, size=(ch, cw)), 0, maxv) for i in range(n_frames)])
     cr = np.stack([np.clip(np.roll(base, 2 * i, axis=0) // 2 + maxv // 4 + rng.integers(-30, 31, size=(ch, cw)), 0, maxv) for i in range(n_frames)])
     return cb.astype(dt), cr.astype(dt)
+
+
+def upscaled_clip(W, H, n, depth, factor=4, **kw):
+    """A picture sequence of BASELINE configs[3] / configs[4] size without minutes of numpy filtering: a (W/factor x H/factor)
+    synthetic clip enlarged by sample repetition plus a little per-sample noise (so that neighbouring blocks differ and sub-pel
+    positions matter).  Deterministic in its arguments: the full-size goldens (tests/golden/make_golden.py) are regenerated from
+    the same call on the GPU box."""
+    small = make_clip(W // factor, H // factor, n, bit_depth=depth, **kw)
+    rng = np.random.default_rng(kw.get("seed", 1))
+    out = np.empty((n, H, W), small.dtype)
+    hi = (1 << depth) - 1
+    for i in range(n):
+        big = np.repeat(np.repeat(small[i], factor, axis=0), factor, axis=1).astype(np.int32)
+        big += rng.integers(-6, 7, big.shape, dtype=np.int32)
+        out[i] = np.clip(big, 0, hi).astype(small.dtype)
+    return out
