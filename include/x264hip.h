@@ -652,6 +652,62 @@ int  x264hip_lookahead_get_frame_vbv( x264hip_lookahead *la, int flush, x264hip_
  * wall time in ns spent in [4] backend frame_cost, [5] weights_analyse, [6] backend prefetch + mbtree, [7] the put/get calls in total */
 int  x264hip_lookahead_stats( x264hip_lookahead *la, uint64_t *out, int n );
 
+/* ---- one lookahead window over the GPUs of a node, from C (x264_amd/csrc/shard_host.cpp; SURVEY 8e, BASELINE configs[3]) ----------------
+ * The host side of the entries above, inside the library: what encoder/slicetype-cl.h:29-42 is to one OpenCL device, for N GPUs.  One
+ * process (or thread) per GPU opens a shard with the same parameters and a transport of `world` ranks.  Rank 0 then drives the ordinary
+ * lookahead calls on x264hip_shard_lookahead() -- pictures enter through x264hip_shard_put_frames, which also remembers where they
+ * are so that they can be broadcast -- while every other rank sits in x264hip_shard_serve() until rank 0 closes its shard.  Frame b's
+ * searches and cost cells run on rank b % world; only cell summaries (and, before an MB-tree call, the per-block maps that call reads)
+ * reach rank 0, which decides.  Slice types, cost cells and f_qp_offset are those of the single stream.
+ * Errors: after every command a status word is max-reduced over the ranks; a rank whose device calls fail keeps issuing the command's
+ * collectives (the plan tells every rank the counts) and reports through that word, so the NEXT call fails on every rank -- with its own
+ * error where it failed, X264HIP_EPEER elsewhere -- instead of leaving the others inside a collective.
+ * The transport: four operations on DEVICE buffers, each enqueued on the given HIP stream (the context's own: searches, exports,
+ * collectives and imports are ordered on the device, no host thread waits for a chunk).  x264hip_shard_transport_rccl fills one in over
+ * RCCL (xGMI inside a node); librccl.so is opened at run time, X264HIP_ENODEV if it is absent.  A one-rank transport with .loopback set
+ * runs every exchange step with the rank as its own peer (tests: the whole path on one GPU; x264hip_shard_loopback_verify). */
+#define X264HIP_EPEER    -7   /* window shard: another rank failed (its own error is reported there) */
+typedef struct x264hip_shard x264hip_shard;
+typedef struct x264hip_shard_transport
+{
+    void *user;
+    int rank, world;
+    int loopback;             /* world == 1 only: run the exchange anyway, this rank being its own peer */
+    /* buf: `bytes` bytes, from rank `root` to every rank, in place */
+    int (*broadcast)( void *user, void *buf, size_t bytes, int root, void *hip_stream );
+    /* sbuf: send_bytes[0] bytes for rank 0, then send_bytes[1] for rank 1, ...; rbuf receives recv_bytes[r] bytes from rank r in rank order */
+    int (*send_recv)( void *user, const void *sbuf, const size_t *send_bytes, void *rbuf, const size_t *recv_bytes, void *hip_stream );
+    /* every rank's `bytes` bytes to rank `root`: rbuf (root only) = world x bytes in rank order */
+    int (*gather)( void *user, const void *sbuf, void *rbuf, size_t bytes, int root, void *hip_stream );
+    int (*allreduce_max_i32)( void *user, int *buf, int n, void *hip_stream );
+    void (*destroy)( void *user ); /* may be NULL; called by x264hip_shard_close */
+} x264hip_shard_transport;
+int  x264hip_rccl_unique_id( void *id128 /* 128 bytes: ncclUniqueId, from rank 0 to the others by the caller's own means */ );
+int  x264hip_shard_transport_rccl( x264hip_shard_transport *t, const void *nccl_unique_id, int rank, int world, int device );
+int  x264hip_shard_open( x264hip_shard **out, int device, const x264hip_la_params *params, const x264hip_shard_transport *transport );
+x264hip_lookahead *x264hip_shard_lookahead( x264hip_shard *s ); /* rank 0: put / get as usual (pictures through the call below) */
+x264hip_ctx *x264hip_shard_ctx( x264hip_shard *s );
+/* rank 0: n device-resident pictures, frame numbers first_number .. first_number + n - 1 (display order, counted from 0 like the
+ * lookahead counts them), put into the lookahead; the pointers must stay valid until those frames have been returned by get_frame */
+int  x264hip_shard_put_frames( x264hip_shard *s, int first_number, int n, const void *const *luma_dev, int stride );
+int  x264hip_shard_serve( x264hip_shard *s );                   /* ranks 1 .. world-1: returns when rank 0 closes; X264HIP_OK or the first error */
+#define X264HIP_SHARD_CHUNKS 0
+#define X264HIP_SHARD_FIELDS_SEARCHED 1
+#define X264HIP_SHARD_CELLS_EVALUATED 2
+#define X264HIP_SHARD_L0_FIELDS 3      /* list-0 fields received from their owners */
+#define X264HIP_SHARD_CELLS_IMPORTED 4
+#define X264HIP_SHARD_MAPS_FETCHED 5
+#define X264HIP_SHARD_FETCH_COMMANDS 6
+#define X264HIP_SHARD_BYTES_INPUT 7    /* bytes this rank received / rank 0 sent per peer: pictures, fields, summaries, maps */
+#define X264HIP_SHARD_BYTES_L0 8
+#define X264HIP_SHARD_BYTES_SUMMARIES 9
+#define X264HIP_SHARD_BYTES_MAPS 10
+#define X264HIP_SHARD_STATS 12
+int  x264hip_shard_status( x264hip_shard *s );                   /* waits for everything enqueued; X264HIP_OK, this rank's first error, or X264HIP_EPEER */
+int  x264hip_shard_stats( x264hip_shard *s, uint64_t *out, int n );
+int  x264hip_shard_loopback_verify( x264hip_shard *s, int *n_checked ); /* loopback: every buffer that came back equals what was sent */
+void x264hip_shard_close( x264hip_shard *s );                   /* rank 0: also tells the other ranks to leave x264hip_shard_serve */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,156 @@
+"""The window shard through the library's C entry points (x264_amd/csrc/shard_host.cpp: x264hip_shard_open / _put_frames / _serve /
+_status / _close over an x264hip_shard_transport): one lookahead window over several ranks, driven the way a C host would drive it.
+* one rank, RCCL transport in loop-back mode: every exchange step (picture broadcast, peer-to-peer fields, summaries gather, status
+  all-reduce) runs on ONE GPU over librccl opened by the library itself; results equal the plain run, every buffer that came back
+  equals what was sent;
+* two ranks sharing the GPU over a host-staged transport (gloo): decisions, cost cells and f_qp_offset equal the single stream's;
+* a rank that fails: the other ranks do not hang, the failure reaches every rank (X264HIP_EPEER on the healthy one);
+* tests/tools/shard_driver.c: the same calls from plain C with dlopen (what INTEGRATION.md section 7 shows)."""
+import os
+import socket
+import subprocess
+
+import numpy as np
+import pytest
+
+from x264_amd import lib
+from x264_amd.synth import make_clip
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+W, H, NF = 704, 576, 70
+CLIP = dict(seed=12, scene_cuts=(23,), fade=(40, 8, 0.7, 6), pan=(4, 2))
+OVER = dict(bframes=8, rc_lookahead=60)  # BASELINE configs[3] options
+
+
+def _sig(outs):
+    return [(o.frame, o.type, [o.cost_est[i][j] for i in range(10) for j in range(10)], o.qp_offset.tobytes()) for o in outs]
+
+
+def _plain():
+    frames = make_clip(W, H, NF, **CLIP)
+    cfg = lib.la_config(W, H, "medium", **OVER)
+    la = lib.Lookahead(cfg, max_frames=NF + 4)
+    try:
+        return _sig(la.run(frames, paced=False, qp_offsets=True))
+    finally:
+        la.close()
+
+
+def _loopback_worker(q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch
+    from x264_amd import lib as L2, shard
+    torch.cuda.set_device(0)
+    L = L2.load()
+    cfg = L2.la_config(W, H, "medium", **OVER)
+    dev = torch.from_numpy(make_clip(W, H, NF, **CLIP)).cuda()
+    t = shard.rccl_transport(L, shard.rccl_unique_id(L), 0, 1, 0, loopback=True)
+    outs, dt, st, rc = shard.run_c_window_shard(torch, L2, 0, 1, 0, cfg, dev, t, qp_offsets=True)
+    q.put(dict(sig=_sig(outs), stats=st))
+
+
+def test_c_shard_loopback_over_rccl():
+    import torch.multiprocessing as mp
+    want = _plain()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_loopback_worker, args=(q,))
+    p.start()
+    got = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert got["sig"] == want
+    st = got["stats"]
+    print("C window shard, RCCL loop-back:", st)
+    assert st["chunks"] >= 1 and st["loopback_checks"] >= 2 and st["l0_fields_exchanged"] > 0 and st["cells_imported"] > 0
+
+
+def _two_rank_worker(rank, port, q, env):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2")
+    os.environ.update(env)
+    import datetime
+    import torch
+    import torch.distributed as dist
+    from x264_amd import lib as L2, shard
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=2, timeout=datetime.timedelta(seconds=120))
+    cfg = L2.la_config(W, H, "medium", **OVER)
+    cfg["_frames"] = NF
+    dev = torch.from_numpy(make_clip(W, H, NF, **CLIP)).cuda() if rank == 0 else None
+    t = shard.HostStagedTransport(dist, rank, 2)
+    try:
+        outs, dt, st, rc = shard.run_c_window_shard(torch, L2, rank, 2, 0, cfg, dev, t, qp_offsets=True)
+        q.put(dict(rank=rank, sig=_sig(outs) if outs is not None else None, stats=st, rc=rc, calls=t.calls))
+    except L2.X264HipError as e:
+        q.put(dict(rank=rank, error=e.code, calls=t.calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_two(env):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, port, q, env)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    return {g["rank"]: g for g in got}
+
+
+def test_c_shard_two_ranks_on_one_gpu():
+    want = _plain()
+    got = _run_two({})
+    assert got[0]["sig"] == want
+    assert got[1]["rc"] == 0
+    s0, s1 = got[0]["stats"], got[1]["stats"]
+    print("C window shard, two ranks:", s0, s1)
+    assert s1["fields_searched"] > 0 and s1["cells_evaluated"] > 0 and s0["cells_imported"] > 0 and s0["maps_fetched"] > 0
+    assert s1["bytes_input_broadcast"] == NF * W * H  # every picture reached rank 1 exactly once
+
+
+def test_c_shard_failing_rank_fails_everybody():
+    """rank 1 fails at its first chunk: it keeps the collectives going, the status word carries the failure, rank 0's calls fail with
+    X264HIP_EPEER (-7) -- nobody is left inside a collective (the test would time out)"""
+    got = _run_two({"X264HIP_SHARD_TEST_FAIL": "1:0"})
+    assert got[1].get("rc", got[1].get("error")) == -4      # its own error: X264HIP_EDEVICE
+    assert got[0].get("error") in (-7, -4), got[0]           # X264HIP_EPEER through the status word (or the hook's own failure code)
+
+
+def test_c_shard_from_plain_c():
+    """tests/tools/shard_driver.c: dlopen + the C entry points only (HIP runtime calls through dlsym as well), world = 1 over RCCL in
+    loop-back mode; the program prints one line per frame, compared with the plain run"""
+    src, exe = os.path.join(HERE, "tools", "shard_driver.c"), os.path.join(HERE, "tools", "_build", "shard_driver")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", exe, src, "-ldl"])
+    Wc, Hc, nf = 352, 288, 40
+    frames = make_clip(Wc, Hc, nf, seed=3, scene_cuts=(17,))
+    cfg = lib.la_config(Wc, Hc, "medium")
+    la = lib.Lookahead(cfg, max_frames=nf + 4)
+    try:
+        ref = la.run(frames, paced=False)
+    finally:
+        la.close()
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        frames.tofile(os.path.join(d, "frames.bin"))
+        params = lib.make_la_params(cfg, None, nf + 4)
+        import ctypes as C
+        open(os.path.join(d, "params.bin"), "wb").write(bytes(C.string_at(C.addressof(params), C.sizeof(params))))
+        # (the cost_mv pointer inside the blob is meaningless in another process: the driver points it at its own copy of the table)
+        cm, centre = lib.cost_mv_table(cfg["mv_range"], cfg["lam"])
+        np.ascontiguousarray(cm, np.uint16).tofile(os.path.join(d, "cost_mv.bin"))
+        out = subprocess.check_output([exe, os.path.join(ROOT, "x264_amd", "libx264hip.so"), d, str(Wc), str(Hc), str(nf), str(C.sizeof(params))],
+                                      timeout=300).decode()
+    rows = [tuple(int(v) for v in ln.split()[1:]) for ln in out.splitlines() if ln.startswith("frame ")]
+    assert rows == [(o.frame, o.type, o.cost_est[0][0]) for o in ref], out[-2000:]
+    assert "loopback checks" in out

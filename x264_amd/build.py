@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", "x264hip.hip"), os.path.join(HERE, "csrc", "lookahead_host.cpp")]
+SRC = [os.path.join(HERE, "csrc", "x264hip.hip"), os.path.join(HERE, "csrc", "lookahead_host.cpp"), os.path.join(HERE, "csrc", "shard_host.cpp")]
 import glob
 HDR = sorted(glob.glob(os.path.join(HERE, "csrc", "*.h"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
 OUT = os.path.join(HERE, "libx264hip.so")
@@ -25,7 +25,7 @@ def build_profile(verbose=False):
     out = os.path.join(HERE, "libx264hip_prof.so")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DME_PROFILE", "-I" + os.path.join(ROOT, "include"),
-           "-I" + os.path.join(HERE, "csrc"), "-o", out] + SRC
+           "-I" + os.path.join(HERE, "csrc"), "-o", out] + SRC + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -37,25 +37,48 @@ def build_variant(tag, defines, verbose=False):
     out = os.path.join(HERE, "libx264hip_%s.so" % tag)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"] + ["-D" + d for d in defines] + \
-          ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"), "-o", out] + SRC
+          ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"), "-o", out] + SRC + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return out
 
 
+OBJDIR = os.path.join(HERE, "_obj")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+
+
+def _deps(src):
+    """what an object is rebuilt for: its source, the public header, and -- for the device translation unit -- every kernel header"""
+    pub = sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
+    return [src] + pub + (sorted(glob.glob(os.path.join(HERE, "csrc", "*.h"))) if src.endswith(".hip") else [])
+
+
 def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return OUT
+    """One object per source under x264_amd/_obj (the device translation unit takes minutes, the host ones seconds: only what changed is
+    compiled again), linked into x264_amd/libx264hip.so."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    srcs = [s for s in SRC if os.path.exists(s)]
+    os.makedirs(OBJDIR, exist_ok=True)
     # -ffp-contract=off: the few FP32 expressions on this path (AQ, MB-tree) must round like the reference's
     # separate multiply/add instructions; hipcc's default would fuse them into FMAs (1-ulp differences)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
-           "-I" + os.path.join(HERE, "csrc"), "-o", OUT] + srcs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc")]
+    objs, jobs = [], []
+    for src in SRC:
+        obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src)):
+            cmd = [hipcc] + FLAGS + inc + ["-x", "hip", "-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in jobs:
+        if p.wait():
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    if jobs or not os.path.exists(OUT) or any(os.path.getmtime(o) > os.path.getmtime(OUT) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", OUT] + objs + ["-ldl"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return OUT
 
 

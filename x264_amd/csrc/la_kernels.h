@@ -1882,6 +1882,66 @@ __global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *
     }
 }
 
+// The same lists level by level: level L of a list is what lies between its L-th and (L+1)-th barrier, and the steps of one level --
+// of every list of the launch -- depend on nothing but earlier levels.  One launch per level, grid.y = the steps of that level (order[]:
+// step indices sorted by level), grid.x = blocks of 256 x MBT_UNROLL macroblocks; the kernel boundary is the barrier.  Against the
+// barrier kernel above: no workgroup ever waits, so nothing holds a CU while it does no work (a list of the barrier kernel keeps its
+// workgroups resident for ~25 phases of ~10 us each, most of it in the counter barrier and the drain of the atomics; with eight
+// contexts three or four such launches were resident at any time, profiles/r04_trace_concurrency.json), and the launch fills the chip
+// for the few microseconds a level takes instead of 2 x 16 CUs for a millisecond.
+__global__ __launch_bounds__( 256 ) void mbtree_level_kernel( LaP P, const MbtOpDev *ops, const int *order, const AqLuts *luts )
+{
+    const int W = P.mb_w, H = P.mb_h, n_mb = W * H;
+    const int k = load_uniform( order + blockIdx.y );
+    const MbtOpDev o = load_uniform( ops + k );
+    const int first = blockIdx.x * ( 256 * MBT_UNROLL ) + threadIdx.x;
+    if( o.type == 0 )
+    {
+#pragma unroll
+        for( int u = 0; u < MBT_UNROLL; u++ )
+            if( first + u * 256 < n_mb )
+                o.prop_b[first + u * 256] = 0;
+    }
+    else if( o.type == 1 )
+    {
+        int ic[MBT_UNROLL], lc[MBT_UNROLL], inv[MBT_UNROLL], in_cost[MBT_UNROLL];
+        unsigned w0[MBT_UNROLL], w1[MBT_UNROLL];
+#pragma unroll
+        for( int u = 0; u < MBT_UNROLL; u++ )
+        {
+            const int i = first + u * 256;
+            const int ii = i < n_mb ? i : 0;
+            ic[u] = o.intra_cost[ii]; lc[u] = o.lowres_costs[ii]; inv[u] = o.inv_qscale[ii];
+            in_cost[u] = o.referenced ? prop_read( &o.prop_b[ii] ) : 0;
+            w0[u] = (unsigned)o.mvq0[ii];
+            w1[u] = o.b_bidir ? (unsigned)o.mvq1[ii] : 0u;
+        }
+#pragma unroll
+        for( int u = 0; u < MBT_UNROLL; u++ )
+        {
+            const int i = first + u * 256;
+            if( i < n_mb )
+                mbt_propagate_mb( o, o.prop_p0, o.prop_p1, W, H, i, ic[u], lc[u], inv[u], in_cost[u], w0[u], w1[u] );
+        }
+    }
+    else
+    {
+#pragma unroll
+        for( int u = 0; u < MBT_UNROLL; u++ )
+        {
+            const int i = first + u * 256;
+            if( i >= n_mb ) continue;
+            const int ic = ( (int)o.intra_cost[i] * (int)o.inv_qscale[i] + 128 ) >> 8;
+            if( ic )
+            {
+                const int pc = ( prop_read( &o.prop_b[i] ) * o.fps_factor_i + 128 ) >> 8;
+                const float ratio = lut_log2_diff( luts, (unsigned)( ic + pc ), (unsigned)ic, o.weightdelta );
+                o.qp[i] = __fsub_rn( o.qp_aq[i], __fmul_rn( o.strength, ratio ) );
+            }
+        }
+    }
+}
+
 // The same step list walked by ONE workgroup with the accumulators of the frames in play held in LDS (pictures up to ~12 800
 // macroblocks: 1080p and below).  A macroblock_tree() call is a chain of ~25 dependent phases (every mini-GOP: its B-frames, then the
 // anchor that closes it); across 16 workgroups each phase boundary costs a device-wide barrier plus the drain of the L2 atomics

@@ -218,11 +218,11 @@ struct x264hip_ctx
 };
 
 static const char *const g_errstr[] = { "ok", "no usable HIP device", "invalid argument", "out of memory", "device failure",
-                                        "in-kernel wait timed out", "bad call sequence" };
+                                        "in-kernel wait timed out", "bad call sequence", "another rank of the window shard failed" };
 extern "C" const char *x264hip_strerror( int code )
 {
     int i = -code;
-    return i >= 0 && i < 7 ? g_errstr[i] : "unknown";
+    return i >= 0 && i < 8 ? g_errstr[i] : "unknown";
 }
 
 template <typename T>
@@ -497,8 +497,9 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( hipMemset( ctx->mbt_bar, 0, ( x264hip_ctx::MBT_RING * MBT_MAX_GROUPS * 4 + 4 ) * sizeof( unsigned ) ) );
     for( int i = 0; i < x264hip_ctx::MBT_RING; i++ )
     {
-        OPENCK( hipHostMalloc( &ctx->mbt_host[i], x264hip_ctx::MBT_CAP * sizeof( MbtOpDev ) ) );
-        OPENCK( hipMalloc( &ctx->mbt_dev[i], x264hip_ctx::MBT_CAP * sizeof( MbtOpDev ) ) );
+        // (the step table, then the steps' indices sorted by level: mbt_flush)
+        OPENCK( hipHostMalloc( &ctx->mbt_host[i], x264hip_ctx::MBT_CAP * ( sizeof( MbtOpDev ) + sizeof( int ) ) ) );
+        OPENCK( hipMalloc( &ctx->mbt_dev[i], x264hip_ctx::MBT_CAP * ( sizeof( MbtOpDev ) + sizeof( int ) ) ) );
         OPENCK( hipEventCreateWithFlags( &ctx->mbt_done[i], hipEventDisableTiming ) );
     }
     OPENCK( ring_alloc( ctx->put_ring, (size_t)ctx->put_desc_cap * sizeof( PutDesc ) ) );
@@ -1629,10 +1630,49 @@ static int mbt_flush( x264hip_ctx *ctx )
     // letting every workgroup pull it from pinned host memory into LDS 8070
     HIPCK( upload_async( ctx, ctx->mbt_dev[r], ctx->mbt_host[r], (size_t)G.beg[G.n] * sizeof( MbtOpDev ), ctx->stream2 ) );
     static const bool skip_kernel = getenv( "X264HIP_MBT_SKIP" ) != nullptr; // timing experiments only: what the stream costs the others (offsets are then wrong)
-    if( !skip_kernel )
-    mbtree_kernel<<<G.n * mbt_wgs, mbt_threads, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], G, mbt_wgs, ctx->luts_dev,
-                                                                    ctx->mbt_bar + (size_t)r * MBT_MAX_GROUPS * 4,
-                                                                    ctx->mbt_bar + (size_t)x264hip_ctx::MBT_RING * MBT_MAX_GROUPS * 4 );
+    // One launch with counter barriers (default) or one launch per level (X264HIP_MBT=levels).  Measured, 1080p slow+dia, eight contexts
+    // (profiles/r05_mbtree_forms.txt): 31 600 - 32 200 frames/s against 22 700 - 23 200 -- a level is a small launch that has to find free
+    // wave slots on a chip full of search waves that live for a millisecond, thirty times per flush, where the barrier form takes its
+    // CUs once; one context alone: 19 900 either way.  (No MB-tree at all: 36 100 / 27 800 -- the propagation is a tenth of the device work.)
+    static const bool spin_form = !( getenv( "X264HIP_MBT" ) && !strcmp( getenv( "X264HIP_MBT" ), "levels" ) );
+    if( skip_kernel )
+        ;
+    else if( spin_form )
+        mbtree_kernel<<<G.n * mbt_wgs, mbt_threads, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], G, mbt_wgs, ctx->luts_dev,
+                                                                        ctx->mbt_bar + (size_t)r * MBT_MAX_GROUPS * 4,
+                                                                        ctx->mbt_bar + (size_t)x264hip_ctx::MBT_RING * MBT_MAX_GROUPS * 4 );
+    else
+    {
+        // one launch per level (la_kernels.h, mbtree_level_kernel): the steps sorted by the number of barriers in front of them in their list
+        const MbtOpDev *dh = ctx->mbt_host[r];
+        const int n_ops = G.beg[G.n];
+        std::vector<int> level( n_ops );
+        int n_levels = 0;
+        for( int g = 0; g < G.n; g++ )
+        {
+            int lv = 0;
+            for( int k = G.beg[g]; k < G.beg[g + 1]; k++ )
+            {
+                lv += dh[k].barrier_before;
+                level[k] = lv;
+            }
+            n_levels = std::max( n_levels, lv + 1 );
+        }
+        std::vector<int> first( n_levels + 1, 0 );
+        for( int k = 0; k < n_ops; k++ ) first[level[k] + 1]++;
+        for( int l = 0; l < n_levels; l++ ) first[l + 1] += first[l];
+        int *order_host = (int *)( ctx->mbt_host[r] + x264hip_ctx::MBT_CAP );
+        {
+            std::vector<int> at( first.begin(), first.end() - 1 );
+            for( int k = 0; k < n_ops; k++ ) order_host[at[level[k]]++] = k;
+        }
+        int *order_dev = (int *)( ctx->mbt_dev[r] + x264hip_ctx::MBT_CAP );
+        HIPCK( upload_async( ctx, order_dev, order_host, (size_t)n_ops * sizeof( int ), ctx->stream2 ) );
+        const unsigned gx = (unsigned)( ( ctx->n_mb + 256 * MBT_UNROLL - 1 ) / ( 256 * MBT_UNROLL ) );
+        for( int l = 0; l < n_levels; l++ )
+            if( first[l + 1] > first[l] )
+                mbtree_level_kernel<<<dim3( gx, (unsigned)( first[l + 1] - first[l] ) ), 256, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], order_dev + first[l], ctx->luts_dev );
+    }
     HIPCK( hipGetLastError() );
     HIPCK( hipEventRecord( ctx->mbt_done[r], ctx->stream2 ) );
     HIPCK( hipEventRecord( ctx->ev_mbt_last, ctx->stream2 ) );

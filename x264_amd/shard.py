@@ -622,3 +622,232 @@ def run_window_shard(torch, lib, dist, rank, world, dev_index, cfg, dev_clip, ex
         la.close()
         if cmd_group is not None:
             dist.destroy_process_group(cmd_group)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The same window shard through the library's C entry points (x264_amd/csrc/shard_host.cpp: x264hip_shard_open / _put_frames / _serve /
+# _close over an x264hip_shard_transport).  Everything above orchestrates from Python and is what the CPU tests run over the oracle
+# backend (no device there); on a device the C path is the product -- a C host calls exactly these entries --
+# and the code below only binds it for the tests and bench.py.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _ctypes_defs():
+    import ctypes as C
+    BCAST = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+    SENDRECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p)
+    GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+    ALLRED = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+    DESTROY = C.CFUNCTYPE(None, C.c_void_p)
+
+    class Transport(C.Structure):
+        """x264hip_shard_transport of include/x264hip.h"""
+        _fields_ = [("user", C.c_void_p), ("rank", C.c_int), ("world", C.c_int), ("loopback", C.c_int), ("broadcast", BCAST), ("send_recv", SENDRECV),
+                    ("gather", GATHER), ("allreduce_max_i32", ALLRED), ("destroy", DESTROY)]
+    return C, Transport, (BCAST, SENDRECV, GATHER, ALLRED, DESTROY)
+
+
+def rccl_unique_id(L):
+    """128 bytes from x264hip_rccl_unique_id (rank 0); the caller hands them to the other ranks"""
+    import ctypes as C
+    from . import lib
+    buf = (C.c_char * 128)()
+    lib._ck(L.x264hip_rccl_unique_id(buf), "rccl_unique_id")
+    return bytes(buf)
+
+
+def rccl_transport(L, unique_id, rank, world, device, loopback=False):
+    C, Transport, _ = _ctypes_defs()
+    from . import lib
+    t = Transport()
+    L.x264hip_shard_transport_rccl.argtypes = [C.POINTER(Transport), C.c_char_p, C.c_int, C.c_int, C.c_int]
+    lib._ck(L.x264hip_shard_transport_rccl(C.byref(t), unique_id, rank, world, device), "shard_transport_rccl")
+    t.loopback = int(bool(loopback) and world == 1)
+    return t
+
+
+class HostStagedTransport:
+    """An x264hip_shard_transport whose four operations go through host memory and torch.distributed (gloo): what lets two ranks share
+    ONE GPU in the tests (RCCL refuses two ranks on a device).  Every operation waits for the stream, moves the bytes over gloo and
+    copies the result back before it returns -- the semantics of the device transport without its asynchrony."""
+
+    def __init__(self, dist, rank, world):
+        import ctypes as C
+        self.C, self.dist, self.rank, self.world = C, dist, rank, world
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        _, Transport, (BCAST, SENDRECV, GATHER, ALLRED, DESTROY) = _ctypes_defs()
+        self._fns = (BCAST(self._broadcast), SENDRECV(self._send_recv), GATHER(self._gather), ALLRED(self._allreduce))
+        self.struct = Transport(None, rank, world, 0, self._fns[0], self._fns[1], self._fns[2], self._fns[3], DESTROY())
+        self.calls = dict(broadcast=0, send_recv=0, gather=0, allreduce=0)
+
+    def _down(self, ptr, n, stream):
+        import torch
+        assert self.hip.hipStreamSynchronize(stream) == 0
+        t = torch.empty(max(n, 1), dtype=torch.uint8)
+        if n:
+            assert self.hip.hipMemcpy(t.data_ptr(), ptr, n, 2) == 0  # hipMemcpyDeviceToHost
+        return t
+
+    def _up(self, ptr, t, n):
+        if n:
+            assert self.hip.hipMemcpy(ptr, t.data_ptr(), n, 1) == 0  # hipMemcpyHostToDevice
+
+    def _guard(self, f, *a):
+        try:
+            f(*a)
+            return 0
+        except Exception:  # never let an exception cross the C ABI
+            import traceback
+            traceback.print_exc()
+            return -1
+
+    def _broadcast(self, user, buf, n, root, stream):
+        def go():
+            self.calls["broadcast"] += 1
+            t = self._down(buf, n, stream)
+            self.dist.broadcast(t, src=root)
+            if self.rank != root:
+                self._up(buf, t, n)
+        return self._guard(go)
+
+    def _send_recv(self, user, sbuf, sb, rbuf, rb, stream):
+        def go():
+            import torch
+            self.calls["send_recv"] += 1
+            sb_, rb_ = [sb[r] for r in range(self.world)], [rb[r] for r in range(self.world)]
+            h = self._down(sbuf, sum(sb_), stream)
+            out = torch.zeros(max(sum(rb_), 1), dtype=torch.uint8)
+            ops, so, ro = [], 0, 0
+            for r in range(self.world):
+                if r == self.rank:
+                    out[ro:ro + rb_[r]] = h[so:so + sb_[r]]
+                else:
+                    if sb_[r]:
+                        ops.append(self.dist.P2POp(self.dist.isend, h[so:so + sb_[r]].contiguous(), r))
+                    if rb_[r]:
+                        ops.append(self.dist.P2POp(self.dist.irecv, out[ro:ro + rb_[r]], r))
+                so += sb_[r]; ro += rb_[r]
+            if ops:
+                for w in self.dist.batch_isend_irecv(ops):
+                    w.wait()
+            self._up(rbuf, out, sum(rb_))
+        return self._guard(go)
+
+    def _gather(self, user, sbuf, rbuf, n, root, stream):
+        def go():
+            import torch
+            self.calls["gather"] += 1
+            h = self._down(sbuf, n, stream)
+            out = [torch.empty_like(h) for _ in range(self.world)] if self.rank == root else None
+            self.dist.gather(h, out, dst=root)
+            if self.rank == root:
+                self._up(rbuf, torch.cat(out), n * self.world)
+        return self._guard(go)
+
+    def _allreduce(self, user, buf, n, stream):
+        def go():
+            import torch
+            self.calls["allreduce"] += 1
+            t = self._down(buf, 4 * n, stream).view(torch.int32)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            self._up(buf, t.view(torch.uint8), 4 * n)
+        return self._guard(go)
+
+
+SHARD_STAT_NAMES = ("chunks", "fields_searched", "cells_evaluated", "l0_fields_exchanged", "cells_imported", "maps_fetched", "fetch_commands",
+                    "bytes_input_broadcast", "bytes_l0_received", "bytes_summaries", "bytes_maps", "reserved")
+
+
+class CShard:
+    """x264hip_shard of one rank.  Rank 0: put_frames(), then frames come out of .lookahead.get(); other ranks: serve()."""
+
+    def __init__(self, L, cfg, transport, device=0, max_frames=0):
+        import ctypes as C
+        from . import lib
+        self.C, self.L, self.cfg, self._t = C, L, cfg, transport
+        self.params = lib.make_la_params(cfg, None, max_frames)
+        self.h = C.c_void_p()
+        tstruct = transport.struct if hasattr(transport, "struct") else transport
+        L.x264hip_shard_open.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(lib.LaParams), C.c_void_p]
+        lib._ck(L.x264hip_shard_open(C.byref(self.h), device, C.byref(self.params), C.byref(tstruct)), "shard_open")
+        L.x264hip_shard_lookahead.restype = C.c_void_p
+        L.x264hip_shard_lookahead.argtypes = [C.c_void_p]
+        L.x264hip_shard_ctx.restype = C.c_void_p
+        L.x264hip_shard_ctx.argtypes = [C.c_void_p]
+        la = lib.Lookahead.__new__(lib.Lookahead)  # a view of the shard's own lookahead: get() / stats() as usual, never closed from here
+        la.L, la.cfg, la.params, la.h = L, cfg, self.params, C.c_void_p(L.x264hip_shard_lookahead(self.h))
+        la.dtype = np.uint8 if cfg["bit_depth"] == 8 else np.uint16
+        la._n_put = 0
+        self.lookahead = la
+        self._n = 0
+
+    def ctx_handle(self):
+        return self.C.c_void_p(self.L.x264hip_shard_ctx(self.h))
+
+    def put_frames(self, device_ptrs, stride=None):
+        from . import lib
+        n = len(device_ptrs)
+        arr = (self.C.c_void_p * n)(*device_ptrs)
+        self.L.x264hip_shard_put_frames.argtypes = [self.C.c_void_p, self.C.c_int, self.C.c_int, self.C.c_void_p, self.C.c_int]
+        lib._ck(self.L.x264hip_shard_put_frames(self.h, self._n, n, arr, stride or self.cfg["width"]), "shard_put_frames")
+        self._n += n
+
+    def status(self):
+        self.L.x264hip_shard_status.argtypes = [self.C.c_void_p]
+        return self.L.x264hip_shard_status(self.h)
+
+    def serve(self):
+        self.L.x264hip_shard_serve.argtypes = [self.C.c_void_p]
+        return self.L.x264hip_shard_serve(self.h)
+
+    def stats(self):
+        out = np.zeros(12, np.uint64)
+        self.L.x264hip_shard_stats.argtypes = [self.C.c_void_p, self.C.c_void_p, self.C.c_int]
+        self.L.x264hip_shard_stats(self.h, out.ctypes.data_as(self.C.c_void_p), 12)
+        return {k: int(v) for k, v in zip(SHARD_STAT_NAMES, out)}
+
+    def loopback_verify(self):
+        from . import lib
+        n = self.C.c_int(0)
+        self.L.x264hip_shard_loopback_verify.argtypes = [self.C.c_void_p, self.C.POINTER(self.C.c_int)]
+        lib._ck(self.L.x264hip_shard_loopback_verify(self.h, self.C.byref(n)), "shard_loopback_verify")
+        return n.value
+
+    def close(self):
+        if self.h:
+            self.L.x264hip_shard_close.argtypes = [self.C.c_void_p]
+            self.L.x264hip_shard_close(self.h)
+            self.h = None
+            self.lookahead.h = None
+
+
+def run_c_window_shard(torch, lib, rank, world, dev_index, cfg, dev_clip, transport, qp_offsets=False, vbv=False):
+    """One pass of ONE stream over `world` ranks through the C entry points: (outputs on rank 0 | None, seconds, stats, rc of serve()).
+    dev_clip: the clip on rank 0's GPU ([F, H, W]); the other ranks receive the pictures chunk by chunk inside the timed region."""
+    import time
+    L = lib.load()
+    F = dev_clip.shape[0] if dev_clip is not None else 0
+    sh = CShard(L, cfg, transport, device=dev_index, max_frames=(F or cfg.get("_frames", 0)) + 4)
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs, rc = None, 0
+        if rank == 0:
+            sh.put_frames([dev_clip[i].data_ptr() for i in range(F)], cfg["width"])
+            outs = []
+            while True:
+                o = sh.lookahead.get(True, qp_offsets, vbv)
+                if o is None:
+                    break
+                outs.append(o)
+            lib._ck(L.x264hip_synchronize(sh.ctx_handle()), "synchronize")
+            lib._ck(sh.status(), "shard_status")  # a rank that failed anywhere fails the pass here at the latest
+        else:
+            rc = sh.serve()
+        dt = time.perf_counter() - t0
+        checks = sh.loopback_verify() if getattr(transport, "loopback", 0) else 0
+        st = sh.stats()
+        st["loopback_checks"] = checks
+        return outs, dt, st, rc
+    finally:
+        sh.close()
