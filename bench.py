@@ -694,18 +694,33 @@ def window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend,
     elsewhere).  The N > 1 result is checked against a single-rank pass of rank 0: a mismatch is an error (no value is reported)."""
     W, H = 3840, 2160
     cfg = lib.la_config(W, H, "medium", bit_depth=8, bframes=8, rc_lookahead=60, keyint_max=250)
-    if rank == 0:
-        clip = make_clip_device(torch, W, H, frames, 4242, 8, scene_cuts=(frames // 3,))
-    else:
-        clip = torch.empty((frames, H, W), dtype=torch.uint8, device="cuda")  # filled by the broadcast of every pass
+    clip = make_clip_device(torch, W, H, frames, 4242, 8, scene_cuts=(frames // 3,)) if rank == 0 else None  # the other ranks receive the pictures inside every pass
     nb = cfg["bframes"] + 2
     on_dev = backend == "nccl"
     best = None
     outs = None
+    tr = destroy = None
+    if world > 1:
+        # N > 1 goes through the library's own C entry points (x264hip_shard_*: what a C host calls, INTEGRATION.md section 7): one RCCL
+        # communicator per rank made by the library from an id rank 0 hands round; torch.distributed only carries that id and the timings
+        L = lib.load()
+        cfg["_frames"] = frames
+        if on_dev:
+            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(shard.rccl_unique_id(L)), dtype=torch.uint8))
+            dist.broadcast(idt, src=0)
+            tr = shard.rccl_transport(L, bytes(idt.cpu().numpy().tobytes()), rank, world, dev_index)
+            destroy, tr.destroy = tr.destroy, type(tr.destroy)()  # the communicator outlives the shards of the passes below
+        else:
+            tr = shard.HostStagedTransport(dist, rank, world)  # test rig: two ranks sharing one GPU over gloo
     for k in range(steps + 1):  # one warm-up pass
-        if rank and world > 1:
-            clip.zero_()  # every pass really receives its input
-        outs, dt, stats = shard.run_window_shard(torch, lib, dist if world > 1 else None, rank, world, dev_index, cfg, clip, on_dev, broadcast_input=world > 1)
+        if world > 1:
+            outs, dt, stats, rc = shard.run_c_window_shard(torch, lib, rank, world, dev_index, cfg, clip, tr)
+            if rc:
+                raise SystemExit("window shard: rank %d left x264hip_shard_serve with %d" % (rank, rc))
+        else:
+            outs, dt, stats = shard.run_window_shard(torch, lib, None, rank, world, dev_index, cfg, clip, on_dev)
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -717,7 +732,8 @@ def window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend,
     if rank == 0:
         res = {"workload": "3840x2160 8-bit, one %d-frame GOP, --rc-lookahead 60 --bframes 8 (BASELINE configs[3]); ONE stream: frame b's searches and cost "
                            "cells on rank b %% N, cell summaries gathered to rank 0, which decides" % frames,
-               "unit": "frames/s", "n_gpus": world, "rccl_ranks": world if on_dev else 0, "exchange": "RCCL on the contexts' streams" if on_dev else backend,
+               "unit": "frames/s", "n_gpus": world, "rccl_ranks": world if on_dev else 0,
+               "exchange": "x264hip_shard_* (C entry points of libx264hip.so), RCCL on the contexts' streams" if on_dev and world > 1 else "RCCL on the contexts' streams" if on_dev else backend,
                "scaling": "strong", "seconds": round(best, 4)}
         if world > 1:
             t1 = None
@@ -779,6 +795,8 @@ def window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend,
                     res["checked"] = "batched == paced (types + cost cells)"
     if world > 1:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank learns the verdict (rank 0's verification pass ends here)
+    if destroy is not None and tr is not None:
+        destroy(tr.user)
     del clip
     if int(ok.item()) == 0 and rank == 0:
         print("window shard: " + res["error"], file=sys.stderr)

@@ -848,6 +848,12 @@ def run_c_window_shard(torch, lib, rank, world, dev_index, cfg, dev_clip, transp
         checks = sh.loopback_verify() if getattr(transport, "loopback", 0) else 0
         st = sh.stats()
         st["loopback_checks"] = checks
+        st["bytes_l0_exchange"] = st["bytes_l0_received"]
+        counters = np.zeros(16, np.uint64)
+        import ctypes as C
+        lib._ck(L.x264hip_counters(sh.ctx_handle(), counters.ctypes.data_as(C.c_void_p), 16), "counters")
+        st.update(searches_here=int(counters[0]), cells_here=int(counters[5]), cells_on_demand=int(counters[7]), remote_fields_searched_here=int(counters[8]),
+                  remote_maps_recomputed_here=int(counters[9]), maps_imported=int(counters[10]), cells_imported_ctx=int(counters[11]))
         return outs, dt, st, rc
     finally:
         sh.close()
