@@ -498,10 +498,13 @@ def main():
     # the search kernel alone: one context, nothing else in flight (what the rocprofv3 counter passes in profiles/ measure as well);
     # in the timed region several contexts launch concurrently, which stretches every launch
     solo = None
-    if S > 1 and not args.no_check:
-        lib.search_profile(las[0].L, las[0].ctx_handle(), 1)
+    kernel_times = None
+    if not args.no_check:
+        lib.search_profile(las[0].L, las[0].ctx_handle(), 3)  # | 2: an event pair around every ingest and cell kernel as well
         las[0].reset()
         las[0].run(device_ptrs=wl.seg_ptrs[0], stride=W, paced=args.paced)
+        kernel_times = lib.kernel_profile(las[0].L, las[0].ctx_handle())
+        cms_, cnl_, ncell_ = lib.cell_profile(las[0].L, las[0].ctx_handle())
         ms_, nl_, ns_ = lib.search_profile(las[0].L, las[0].ctx_handle(), 0)
         if ms_ > 0 and ns_:
             solo = (ms_, nl_, ns_)
@@ -565,15 +568,28 @@ def main():
                        "parallelism": "gop-segments x%d" % world, "slice_types": types[:64]},
             "checked": None if args.no_check else "types + every cost cell of the timed passes == one untimed %s pass of the same segments" % ("encoder-paced" if other_paced else "batched"),
             ("paced_fps" if other_paced else "batched_fps"): other_fps,
-            "roofline": {"bound": "hbm", "kernel": "me_rows_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
-                         "launches": prof_launches, "searches": prof_searches, "avg_launch_ms": round(prof_ms / max(prof_launches, 1), 4),
-                         "us_per_search": round(prof_ms * 1e3 / max(prof_searches, 1), 3), "contexts_launching_concurrently": S,
-                         "solo": None if solo is None else {
-                             "what": "one untimed pass of one segment alone on the GPU (no concurrent launches), HIP events on the library's stream",
-                             "launches": solo[1], "searches": solo[2], "avg_launch_ms": round(solo[0] / solo[1], 4), "us_per_search": round(solo[0] * 1e3 / solo[2], 3),
-                             "achieved": round(solo[2] * bytes_per_search / 1e9 / (solo[0] / 1e3), 2),
-                             "frac": round(solo[2] * bytes_per_search / 1e9 / (solo[0] / 1e3) / HBM_PEAK_GBS, 5)},
+            # The kernel's own duration is what the launches of ONE context take with nothing else in flight (`solo`; the counter passes in
+            # profiles/ measure the same thing).  In the timed region S contexts launch concurrently: their launches overlap, each is
+            # stretched, and the sum of the launch durations exceeds the step time -- kept below as `concurrent`, it is a figure of the
+            # contention, not of the kernel.
+            "roofline": dict(
+                {"bound": "hbm", "kernel": "me_rows_kernel", "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+                **({"achieved": round(solo[2] * bytes_per_search / 1e9 / (solo[0] / 1e3), 2),
+                    "frac": round(solo[2] * bytes_per_search / 1e9 / (solo[0] / 1e3) / HBM_PEAK_GBS, 5),
+                    "what": "one untimed pass of one segment alone on the GPU (no concurrent launches), HIP events on the library's stream",
+                    "launches": solo[1], "searches": solo[2], "avg_launch_ms": round(solo[0] / solo[1], 4), "us_per_search": round(solo[0] * 1e3 / solo[2], 3),
+                    "traffic": None if traffic is None else round(traffic * (solo[2] / max(solo[1], 1)) / max(prof_searches / max(prof_launches, 1), 1))}
+                   if solo is not None else
+                   {"achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5), "what": "launches of the timed region (no solo pass: --no-check)",
+                    "launches": prof_launches, "searches": prof_searches, "avg_launch_ms": round(prof_ms / max(prof_launches, 1), 4),
+                    "us_per_search": round(prof_ms * 1e3 / max(prof_searches, 1), 3), "traffic": traffic}),
+                **{"traffic_source": tsrc,
+                   "concurrent": {"what": "the launches of the timed region: %d contexts launching at once, every launch stretched by the others (sum of launch "
+                                          "durations / step time = %.2f)" % (S, prof_ms / max(dt * 1e3, 1e-9)),
+                                  "launches": prof_launches, "searches": prof_searches, "avg_launch_ms": round(prof_ms / max(prof_launches, 1), 4),
+                                  "us_per_search": round(prof_ms * 1e3 / max(prof_searches, 1), 3), "achieved": round(achieved, 2),
+                                  "frac": round(achieved / HBM_PEAK_GBS, 5)}}),
+            "roofline_extra_": {
                          "algorithmic_bytes_per_search": bytes_per_search,
                          "note": "not a streaming kernel: with the chip full it is bound by vector instruction issue and the L1 tag rate together (roofline_issue, "
                                  "roofline_l1; instructions and line accesses per block search in profiles/search_issue.json); HBM is the roofline the metric names.  "
@@ -591,6 +607,9 @@ def main():
                                 "host_ms": {"frame_cost": round(la_stats[4] / 1e6, 2), "weights_analyse": round(la_stats[5] / 1e6, 2),
                                             "prefetch_mbtree": round(la_stats[6] / 1e6, 2), "api_total": round(la_stats[7] / 1e6, 2)}},
         }
+        res["roofline"].update(res.pop("roofline_extra_"))
+        if kernel_times is not None:
+            res["roofline_kernels"] = kernel_rooflines(kernel_times, cfg, W, H, args.bit_depth, solo)
         ipath = os.path.join(ROOT, "profiles", "search_issue.json")
         if os.path.exists(ipath):
             try:
@@ -803,25 +822,59 @@ def window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend,
     return res
 
 
+def kernel_rooflines(kt, cfg, W, H, depth, solo):
+    """The kernels of the path beside the search, each against HBM: algorithmic bytes per unit (SURVEY 8d's formulas: what the kernel has
+    to read and write once, whatever it re-reads) x units / device time between HIP events around its launches, one segment alone on the
+    GPU (x264hip_kernel_profile).  `share_of_device_time`: of the summed device time of the pass's kernels on the main stream."""
+    px = 1 if depth == 8 else 2
+    mb_w, mb_h = (W + 15) // 16, (H + 15) // 16
+    B = mb_w * mb_h
+    S = 8 * mb_w * 8 * mb_h * px               # one unpadded lowres plane
+    full = 16 * mb_w * 16 * mb_h * px          # the picture at its mod-16 size (frame.c:640-666)
+    per_unit = {
+        "lowres_tiles_kernel": (full + 4 * S, "per frame: the picture read once + four half-pel planes written (SURVEY 8d); the kernel also writes their strip copy, 8 S more"),
+        "aq_kernel": (W * H * px + B * 16, "per frame: the picture read once + AQ factor, two offset maps and the sums of every macroblock written"),
+        "intra_kernel": (S + 2 * B, "per frame: plane 0 read once + one cost per 8x8 block"),
+        "cell_p_kernel": (10 * B, "per cell: mv cost, intra cost and AQ factor of every block read, lowres_cost written"),
+        "cell_b_kernel": (3 * S + 22 * B, "per cell: source and one plane's worth of each reference read once, two vector granules + costs per block, lowres_cost written"),
+        "cell_reduce_kernel": (6 * B, "per cell: the per-block costs summed"),
+    }
+    names = list(per_unit)
+    total = sum(kt[k][0] for k in range(len(names))) + (solo[0] if solo else 0.0)
+    out = {}
+    for k, name in enumerate(names):
+        ms, launches, units = kt[k]
+        if not launches or ms <= 0:
+            continue
+        bytes_, what = per_unit[name]
+        ach = units * bytes_ / 1e9 / (ms / 1e3)
+        out[name] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "ms": round(ms, 4),
+                     "launches": int(launches), "units": int(units), "algorithmic_bytes_per_unit": int(bytes_), "what": what,
+                     "share_of_device_time": round(ms / total, 4) if total > 0 else None}
+    if solo:
+        out["me_rows_kernel"] = {"ms": round(solo[0], 4), "share_of_device_time": round(solo[0] / total, 4) if total > 0 else None, "see": "roofline"}
+    return out
+
+
 def l1_roofline(prof, timing, cfg):
-    """Cache-line accesses of the per-CU L1 (TCP) by the search kernel: TCP_TOTAL_CACHE_ACCESSES per block search (profiles/search_issue.json, from
-    the counter passes of scripts/pmc_search.sh) x block searches / time, against ONE tag lookup per clock and CU -- the same denominator as
-    scripts/summarize_search_pmc.py's l1_pipe_utilisation (an assumed rate: no L1 microbenchmark backs it).  The second of the two ceilings the
-    kernel runs against once the chip is full (removing a fifth of these accesses shortened a search by 4.5 %).
-    timing: (ms, launches, searches) of launches that ran alone."""
+    """Wave-wide vector loads of the search kernel against the MEASURED rate of a CU's L1 address unit for exactly this load shape
+    (experiments/mem_rates, profiles/r05_mem_rates.json: 8 bytes per lane at the candidate's byte offset, lane = row of the strip, sixteen
+    waves per CU reading an L1-resident region: 29.9 CU-cycles per instruction; any dword-aligned shape costs 17.3).  Loads per block
+    search: SQ_INSTS_VMEM_RD of the counter passes (profiles/search_issue.json).  timing: (ms, launches, searches) of launches that ran alone.
+    (Rounds 2-4 priced TCP_TOTAL_CACHE_ACCESSES against an assumed lookup per clock; both say about 0.6.  What the measurement added: the
+    unit is NOT what bounds the kernel -- reading every tap as aligned dwords halves this figure and changes nothing, profiles/r05_search_ab.txt.)"""
     ms, launches, searches = timing
     blocks = ((cfg["width"] + 15) // 16) * ((cfg["height"] + 15) // 16)
-    lines = prof["l1_line_accesses_per_block"]
-    clock = prof.get("effective_clock_GHz", 2.3) * 1e9
-    peak = 256 * clock
-    achieved = searches * blocks * lines / (ms / 1e3) if ms > 0 else 0.0
-    return {"bound": "l1-tag-lookups", "kernel": "me_rows_kernel", "achieved": round(achieved / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G line accesses/s",
-            "frac": round(achieved / peak, 4), "l1_line_accesses_per_block": lines,
-            "searches_per_launch": round(searches / max(launches, 1)), "source": prof.get("source"),
-            "what": "line accesses of the launches that ran alone / their time, against 256 CUs x one tag lookup per clock at the clock of the counter pass "
-                    "(assumed rate, same denominator as l1_pipe_utilisation in the profiles/*_search_pmc.json summaries)",
-            "note": "co-limiter with vector issue: each wave-wide 8-byte load of a block candidate's rows (8 rows x 16 B apart) is ~28 lookups; the search "
-                    "out of an LDS window (me_team.h) removes them and pays for it in instructions (DESIGN.md section 3.1)"}
+    rates = json.load(open(os.path.join(ROOT, "profiles", "r05_mem_rates.json")))
+    shape = rates["l1"][0]
+    cycles, clock, cus = shape["cu_cycles"], rates["clock_GHz"] * 1e9, rates["cus"]
+    loads = prof["vmem_rd_per_block"]
+    peak = cus * clock / cycles
+    achieved = searches * blocks * loads / (ms / 1e3) if ms > 0 else 0.0
+    return {"bound": "l1-address-unit", "kernel": "me_rows_kernel", "achieved": round(achieved / 1e9, 3), "peak": round(peak / 1e9, 3), "unit": "G wave-loads/s",
+            "frac": round(achieved / peak, 4), "wave_loads_per_block": loads, "cu_cycles_per_wave_load_measured": cycles, "load_shape": shape["pattern"],
+            "searches_per_launch": round(searches / max(launches, 1)), "source": "profiles/r05_mem_rates.json (experiments/mem_rates) + " + str(prof.get("source")),
+            "what": "vector loads of the launches that ran alone / their time, against %d CUs x the measured instruction rate of this load shape" % cus}
 
 
 def issue_roofline(prof, prof_ms, prof_searches, cfg, wall_s=None, all_searches=None):

@@ -474,6 +474,17 @@ int  x264hip_search_profile( x264hip_ctx *ctx, int enable, double *total_ms, uin
 /* The same window's totals for the cost cell launches (cell kernels + their sums): together with the searches, the device work a
  * window shard spreads over ranks (bench.py: window_shard.amdahl). */
 int  x264hip_cell_profile( x264hip_ctx *ctx, double *total_ms, uint64_t *launches, uint64_t *cells );
+/* x264hip_search_profile( enable | 2 ) also puts an event pair around every kernel of the ingest and cost-cell launches; per class:
+ * summed device time, launches, and the frames (ingest classes) / cells (cell classes) they worked on -- what bench.py prices the
+ * kernels beside the search against their rooflines with.  Arrays of X264HIP_KPROF_CLASSES entries. */
+#define X264HIP_KPROF_LOWRES 0      /* lowres_tiles_kernel: planes + strip copy (frame_init_lowres_core + border) */
+#define X264HIP_KPROF_AQ 1          /* aq_kernel (adaptive_quant_frame: var_16x16 / 8x8 per macroblock) */
+#define X264HIP_KPROF_INTRA 2       /* intra_kernel: the ten intra modes of an 8x8 lowres block */
+#define X264HIP_KPROF_CELL_P 3      /* cell_p_kernel */
+#define X264HIP_KPROF_CELL_B 4      /* cell_b_kernel: the three bidirectional candidates of every block */
+#define X264HIP_KPROF_CELL_REDUCE 5 /* cell_reduce_kernel */
+#define X264HIP_KPROF_CLASSES 6
+int  x264hip_kernel_profile( x264hip_ctx *ctx, double *total_ms, uint64_t *launches, uint64_t *units );
 
 
 /* ==================================================================================================

@@ -657,96 +657,102 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
         case 1:
             mef_hex2( s, me_range );
             break;
-        case 2: /* UMH, me.c:422-618 */
+        case 2:
         {
-            const uint8_t pixel_size_shift[7] = { 0, 1, 1, 2, 3, 3, 4 };
-            const int dia1[4][2] = { {0,-1}, {0,1}, {-1,0}, {1,0} };
-            int ucost1, ucost2, cross_start = 1, omx, omy;
-            ucost1 = s->bcost;
-            mef_x4( s, pmx, pmy, dia1 );
+            // Uneven multi-hexagon search (behaviour of me.c:422-618) as a programme over probe sets.  The search keeps a best vector and
+            // its cost; every stage probes a fixed set of offsets around an origin (probes apply in order, strict '<').  Three cost
+            // marks decide the exits: `entry` (before anything of this method ran), `settled` (after the small diamonds around the
+            // predictor, zero and -- if that moved the best -- the new best).  "Nothing better since a mark" is the test bcost == mark.
+            // Thresholds are stated for a 16x16 block and scale down with the partition's area class.
+            static const int8_t kDiamond[4][2] = { {0,-1}, {0,1}, {-1,0}, {1,0} };
+            // the eight points at city-block distance 2, the eight knight moves, the four diagonal corners at distance 2 (two sets of four each)
+            static const int8_t kProbe[5][4][2] = { { {0,-2}, {-1,-1}, {1,-1}, {-2,0} }, { {2,0}, {-1,1}, {1,1}, {0,2} },
+                                                    { {-1,-2}, {1,-2}, {-2,-1}, {2,-1} }, { {-2,1}, {2,1}, {-1,2}, {1,2} },
+                                                    { {-2,-2}, {-2,2}, {2,-2}, {2,2} } };
+            auto probe = [&]( int cx, int cy, const int8_t ( *set )[2] ) {
+                for( int k = 0; k < 4; k++ )
+                    mef_try_f( s, cx + set[k][0], cy + set[k][1] );
+            };
+            const int area_class = (int)( ( 0x4332110u >> ( 4 * p->i_pixel ) ) & 15 ); // 16x16 0, 16x8 / 8x16 1, 8x8 2, 8x4 / 4x8 3, 4x4 4
+            auto good_match = [&]( int limit16 ) { return s->bcost < ( limit16 >> area_class ); };
+            const int entry = s->bcost;
+            probe( pmx, pmy, kDiamond );
             if( pmx | pmy )
-                mef_x4( s, 0, 0, dia1 );
-            omx = ( pmx | pmy ) ? 0 : pmx; omy = ( pmx | pmy ) ? 0 : pmy; /* what DIA1_ITER left in omx/omy */
-            if( p->i_pixel == 6 ) /* PIXEL_4x4 */
+                probe( 0, 0, kDiamond );
+            if( p->i_pixel == 6 ) // 4x4 partitions go straight to the hexagon
             {
                 mef_hex2( s, me_range );
                 break;
             }
-            ucost2 = s->bcost;
-            if( ( s->bmx | s->bmy ) && ( ( s->bmx - pmx ) | ( s->bmy - pmy ) ) )
+            const int settled = s->bcost;
+            if( ( s->bmx | s->bmy ) && ( s->bmx != pmx || s->bmy != pmy ) )
+                probe( s->bmx, s->bmy, kDiamond );
+            int cross_first = s->bcost == settled ? 3 : 1; // the cross skips what the diamond around the origin has just covered
+            const int ox = s->bmx, oy = s->bmy;            // origin of every stage up to the hexagon rings
+            bool finished = false;
+            if( s->bcost == settled && good_match( 2000 ) )
             {
-                omx = s->bmx; omy = s->bmy;
-                mef_x4( s, omx, omy, dia1 );
-            }
-            if( s->bcost == ucost2 )
-                cross_start = 3;
-            omx = s->bmx; omy = s->bmy;
-#define MEF_SAD_THRESH( v ) ( s->bcost < ( (v) >> pixel_size_shift[p->i_pixel] ) )
-            int done = 0;
-            if( s->bcost == ucost2 && MEF_SAD_THRESH( 2000 ) )
-            {
-                const int o1[4][2] = { {0,-2}, {-1,-1}, {1,-1}, {-2,0} }, o2[4][2] = { {2,0}, {-1,1}, {1,1}, {0,2} };
-                mef_x4( s, omx, omy, o1 );
-                mef_x4( s, omx, omy, o2 );
-                if( s->bcost == ucost1 && MEF_SAD_THRESH( 500 ) )
-                    done = 1;
-                else if( s->bcost == ucost2 )
+                // the start is already a good match and its diamond found nothing: look a little further before paying for the full programme
+                probe( ox, oy, kProbe[0] );
+                probe( ox, oy, kProbe[1] );
+                if( s->bcost == entry && good_match( 500 ) )
+                    finished = true;
+                else if( s->bcost == settled )
                 {
-                    int range = ( me_range >> 1 ) | 1;
-                    const int o3[4][2] = { {-1,-2}, {1,-2}, {-2,-1}, {2,-1} }, o4[4][2] = { {-2,1}, {2,1}, {-1,2}, {1,2} };
-                    mef_cross( s, omx, omy, 3, range, range );
-                    mef_x4( s, omx, omy, o3 );
-                    mef_x4( s, omx, omy, o4 );
-                    if( s->bcost == ucost2 )
-                        done = 1;
+                    const int reach = ( me_range >> 1 ) | 1;
+                    mef_cross( s, ox, oy, 3, reach, reach );
+                    probe( ox, oy, kProbe[2] );
+                    probe( ox, oy, kProbe[3] );
+                    if( s->bcost == settled )
+                        finished = true;
                     else
-                        cross_start = range + 2;
+                        cross_first = reach + 2;
                 }
             }
-            if( done )
+            if( finished )
                 break;
             if( n_mvc )
             {
-                const uint8_t range_mul[4][4] = { {3,3,4,4}, {3,4,4,4}, {4,4,4,5}, {4,4,5,6} };
-                int mvd, denom = 1;
+                // the range adapts to how well the predictors agree (spread per predictor pair, 4 classes) and to how good the match
+                // is (4 classes): quarters of the configured range, one nibble per (agreement, match) pair
+                int spread, pairs = 1;
+                const int to_mvp = mf_abs( p->mvp[0] - mvc[0][0] ) + mf_abs( p->mvp[1] - mvc[0][1] );
                 if( n_mvc == 1 )
-                    mvd = p->i_pixel == 0 ? 25 : mf_abs( p->mvp[0] - mvc[0][0] ) + mf_abs( p->mvp[1] - mvc[0][1] );
+                    spread = p->i_pixel == 0 ? 25 : to_mvp;
                 else
                 {
-                    denom = n_mvc - 1;
-                    mvd = 0;
-                    if( p->i_pixel != 0 )
-                    {
-                        mvd = mf_abs( p->mvp[0] - mvc[0][0] ) + mf_abs( p->mvp[1] - mvc[0][1] );
-                        denom++;
-                    }
-                    for( int i = 0; i < n_mvc - 1; i++ ) /* x264_predictor_difference */
-                        mvd += mf_abs( mvc[i][0] - mvc[i+1][0] ) + mf_abs( mvc[i][1] - mvc[i+1][1] );
+                    pairs = n_mvc - 1 + ( p->i_pixel != 0 );
+                    spread = p->i_pixel != 0 ? to_mvp : 0;
+                    for( int i = 0; i + 1 < n_mvc; i++ )
+                        spread += mf_abs( mvc[i][0] - mvc[i + 1][0] ) + mf_abs( mvc[i][1] - mvc[i + 1][1] );
                 }
-                int sad_ctx = MEF_SAD_THRESH( 1000 ) ? 0 : MEF_SAD_THRESH( 2000 ) ? 1 : MEF_SAD_THRESH( 4000 ) ? 2 : 3;
-                int mvd_ctx = mvd < 10*denom ? 0 : mvd < 20*denom ? 1 : mvd < 40*denom ? 2 : 3;
-                me_range = me_range * range_mul[mvd_ctx][sad_ctx] >> 2;
+                const int match = good_match( 1000 ) ? 0 : good_match( 2000 ) ? 1 : good_match( 4000 ) ? 2 : 3;
+                const int agree = spread < 10 * pairs ? 0 : spread < 20 * pairs ? 1 : spread < 40 * pairs ? 2 : 3;
+                static const uint16_t kQuarters[4] = { 0x4433, 0x4443, 0x5444, 0x6544 }; // [agree], nibble `match`
+                me_range = me_range * (int)( ( kQuarters[agree] >> ( 4 * match ) ) & 15 ) >> 2;
             }
-#undef MEF_SAD_THRESH
-            mef_cross( s, omx, omy, cross_start, me_range, me_range >> 1 );
+            mef_cross( s, ox, oy, cross_first, me_range, me_range >> 1 );
+            probe( ox, oy, kProbe[4] );
+            // sixteen-point hexagon rings of growing radius around the best so far: (0, -4) and (0, 4), then the pairs (-x, y), (x, y)
+            // for y = -3 .. 3 with x = 2 on the two outer rows and 4 between them, all scaled by the ring number
             {
-                const int o5[4][2] = { {-2,-2}, {-2,2}, {2,-2}, {2,2} };
-                mef_x4( s, omx, omy, o5 );
-            }
-            omx = s->bmx; omy = s->bmy;
-            int i = 1;
-            do
-            {
-                const int8_t hex4[16][2] = { {0,-4}, {0,4}, {-2,-3}, {2,-3}, {-4,-2}, {4,-2}, {-4,-1}, {4,-1},
-                                                    {-4,0}, {4,0}, {-4,1}, {4,1}, {-4,2}, {4,2}, {-2,3}, {2,3} };
-                const int near_edge = 4*i > imin( imin( mv_x_max - omx, omx - mv_x_min ), imin( mv_y_max - omy, omy - mv_y_min ) );
-                for( int j = 0; j < 16; j++ )
+                const int rx = s->bmx, ry = s->bmy;
+                int ring = 1;
+                do // (at least one ring, also where the adapted range is below four)
                 {
-                    int mx = omx + hex4[j][0]*i, my = omy + hex4[j][1]*i;
-                    if( !near_edge || mef_in_range( s, mx, my ) )
-                        mef_try_f( s, mx, my );
-                }
-            } while( ++i <= me_range >> 2 );
+                    const int room = imin( imin( mv_x_max - rx, rx - mv_x_min ), imin( mv_y_max - ry, ry - mv_y_min ) );
+                    const bool clipped = 4 * ring > room;
+                    for( int j = 0; j < 16; j++ )
+                    {
+                        const int row = ( j - 2 ) >> 1;
+                        const int dy = j < 2 ? ( j ? 4 : -4 ) : row - 3;
+                        const int ax = j < 2 ? 0 : ( row == 0 || row == 6 ) ? 2 : 4;
+                        const int mx = rx + ( ( j & 1 ) ? ax : -ax ) * ring, my = ry + dy * ring;
+                        if( !clipped || mef_in_range( s, mx, my ) )
+                            mef_try_f( s, mx, my );
+                    }
+                } while( ++ring <= me_range >> 2 );
+            }
             if( s->bmy <= mv_y_max && s->bmy >= mv_y_min && s->bmx <= mv_x_max && s->bmx >= mv_x_min )
                 mef_hex2( s, me_range );
             break;

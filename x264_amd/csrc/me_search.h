@@ -514,8 +514,10 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
     C.refine4 = MODE == 3 ? P.subpel_refine >= 3 : MODE >= 1;
     C.mbcmp_satd = MODE == 3 ? P.mbcmp_satd : MODE >= 1;
     C.fpelcmp_satd = MODE == 3 ? P.fpelcmp_satd : MODE == 2;
-    // the descriptor arrives through vector loads (the table is written by other launches, so no scalar load): without these every
-    // load below would move its base address into scalar registers again (two v_readfirstlane per load, ~10 % of the vector instructions)
+    // the descriptor came through the scalar cache (load_uniform: the table was written by an upload kernel of an EARLIER dispatch on this
+    // stream, and the scalar cache is invalidated at the start of every dispatch -- device_common.h); the compiler still cannot prove
+    // the pointers uniform, and without these every load below would move its base address into scalar registers again (two
+    // v_readfirstlane per load, ~10 % of the vector instructions)
     const T *fbase = uniform_ptr( D.fenc0 );
     const T *sbase = uniform_ptr( D.ref_strips );
     const T *wsbase = WEIGHTED ? uniform_ptr( D.refw_strips ) : sbase;

@@ -195,6 +195,9 @@ struct x264hip_ctx
     int prof_on = 0, prof_used = 0;
     double prof_ms = 0; uint64_t prof_launches = 0, prof_searches = 0;
     double prof_cell_ms = 0; uint64_t prof_cell_launches = 0, prof_cells = 0; // the same for the cost cell launches (prof_n entries < 0)
+    // prof_on & 2: an event pair around every kernel of the ingest and cell launches as well (x264hip_kernel_profile; class = X264HIP_KPROF_*)
+    std::vector<int> prof_kind;       // parallel to prof_n: -1 = a search / cell launch as above, else the kernel class
+    double kprof_ms[X264HIP_KPROF_CLASSES] = { 0 }; uint64_t kprof_launches[X264HIP_KPROF_CLASSES] = { 0 }, kprof_units[X264HIP_KPROF_CLASSES] = { 0 };
     uint64_t counters[16] = { 0 }; // [8] remote fields searched here after all [9] remote cell maps recomputed here [10] maps imported [11] cells imported [12] fields registered as remote [13] searches on demand (x264hip_frame_cost) [14] second variants of B cells speculated [15] ... and used
     // how often callers asked for each B cell class with / without a searched L0 field of the list-1 reference
     // (slicetype.c:629-642): speculation evaluates the variant asked for more often so far
@@ -611,6 +614,32 @@ extern "C" int x264hip_geometry( x264hip_ctx *ctx, int *mb_w, int *mb_h, int *lo
 }
 
 static int sync_stream( x264hip_ctx *ctx );
+static int prof_drain( x264hip_ctx *ctx );
+// x264hip_kernel_profile: the first event of a pair in front of one kernel of class `kind` (units: frames / cells it works on); the
+// second one is recorded by kprof_end.  Both are no-ops unless bit 1 of the profile switch is set.
+static int kprof_begin( x264hip_ctx *ctx, int kind, int units, hipEvent_t *end_ev )
+{
+    *end_ev = nullptr;
+    if( !( ctx->prof_on & 2 ) ) return X264HIP_OK;
+    if( ctx->prof_used + 2 > (int)ctx->prof_ev.size() )
+    {
+        int rc = prof_drain( ctx );
+        if( rc ) return rc;
+    }
+    HIPCK( hipEventRecord( ctx->prof_ev[ctx->prof_used], ctx->stream ) );
+    *end_ev = ctx->prof_ev[ctx->prof_used + 1];
+    while( ctx->prof_kind.size() < ctx->prof_n.size() ) ctx->prof_kind.push_back( -1 );
+    ctx->prof_n.push_back( units ); ctx->prof_kind.push_back( kind );
+    ctx->prof_used += 2;
+    return X264HIP_OK;
+}
+static int kprof_end( x264hip_ctx *ctx, hipEvent_t end_ev )
+{
+    if( end_ev ) HIPCK( hipEventRecord( end_ev, ctx->stream ) );
+    return X264HIP_OK;
+}
+#define KPROF( kind, units, launch ) do { hipEvent_t kp_; { int rc_ = kprof_begin( ctx, kind, units, &kp_ ); if( rc_ ) return rc_; } launch; { int rc_ = kprof_end( ctx, kp_ ); if( rc_ ) return rc_; } } while( 0 )
+
 static inline bool slot_ok( x264hip_ctx *ctx, int s ) { return s >= 0 && s < (int)ctx->slots.size(); }
 
 // ---- frame ingest ------------------------------------------------------------------------------------
@@ -636,8 +665,8 @@ static int launch_ingest_t( x264hip_ctx *ctx, const PutDesc *descs_dev, const Pu
     static const bool split_ingest = getenv( "X264HIP_INGEST" ) && !strcmp( getenv( "X264HIP_INGEST" ), "split" );
     const int rows = ctx->lh + 2 * LA_PAD;
     if( !split_ingest )
-        lowres_tiles_kernel<T><<<dim3( ( P.stride + LT_COLS - 1 ) / LT_COLS, ( rows + LT_ROWS - 1 ) / LT_ROWS, n ), 256, 0, ctx->stream>>>(
-            descs_dev, single, p.width, p.height, P.plane_elems, P.stride, ctx->lw, ctx->lh );
+        KPROF( X264HIP_KPROF_LOWRES, n, ( lowres_tiles_kernel<T><<<dim3( ( P.stride + LT_COLS - 1 ) / LT_COLS, ( rows + LT_ROWS - 1 ) / LT_ROWS, n ), 256, 0, ctx->stream>>>(
+            descs_dev, single, p.width, p.height, P.plane_elems, P.stride, ctx->lw, ctx->lh ) ) );
     else
     {
         // the two-kernel form (planes, then their strip copy read back from the planes): kept for comparison
@@ -646,13 +675,13 @@ static int launch_ingest_t( x264hip_ctx *ctx, const PutDesc *descs_dev, const Pu
         strips_kernel<T><<<dim3( ( rows + 63 ) / 64, ( 4 * ( P.stride / 8 ) + 3 ) / 4, n ), 256, 0, ctx->stream>>>( descs_dev, single, P.plane_elems, P.stride, rows );
     }
     const int wg_per_frame = ( ( ctx->n_mb + AQ_MBS_PER_WG - 1 ) / AQ_MBS_PER_WG + 7 ) / 8 * 8; // a multiple of 8: contiguous runs of macroblocks per XCD
-    aq_kernel<T><<<dim3( wg_per_frame, 1, n ), 64, 0, ctx->stream>>>( descs_dev, single, p.width, p.height, P.mb_w, P.mb_h, strength, bias, ctx->luts_dev,
-                                                                       p.aq_mode, 1.f / ( 1 << ( 2 * ( p.bit_depth - 8 ) ) ), p.chroma_format );
+    KPROF( X264HIP_KPROF_AQ, n, ( aq_kernel<T><<<dim3( wg_per_frame, 1, n ), 64, 0, ctx->stream>>>( descs_dev, single, p.width, p.height, P.mb_w, P.mb_h, strength, bias, ctx->luts_dev,
+                                                                       p.aq_mode, 1.f / ( 1 << ( 2 * ( p.bit_depth - 8 ) ) ), p.chroma_format ) ) );
     if( p.aq_mode >= 2 && p.aq_strength != 0.f )
         aq_auto_kernel<<<n, 1024, 0, ctx->stream>>>( descs_dev, single, ctx->n_mb, p.aq_mode, p.aq_strength, ctx->luts_dev );
     aq_reduce_kernel<<<n, 1024, 0, ctx->stream>>>( descs_dev, single, ctx->n_mb );
     const int intra_wgs = ( ( ctx->n_mb + INTRA_BLOCKS_PER_WG - 1 ) / INTRA_BLOCKS_PER_WG + 7 ) / 8 * 8;
-    intra_kernel<T><<<dim3( intra_wgs, 1, n ), 64, 0, ctx->stream>>>( P, descs_dev, single );
+    KPROF( X264HIP_KPROF_INTRA, n, ( intra_kernel<T><<<dim3( intra_wgs, 1, n ), 64, 0, ctx->stream>>>( P, descs_dev, single ) ) );
     HIPCK( hipGetLastError() );
     HIPCK( hipEventRecord( ctx->ev_ingest, ctx->stream ) );
     return X264HIP_OK;
@@ -857,12 +886,15 @@ static int prof_drain( x264hip_ctx *ctx )
             float ms = 0;
             HIPCK( hipEventElapsedTime( &ms, ctx->prof_ev[i], ctx->prof_ev[i + 1] ) );
             const int k = ctx->prof_n[i / 2];
-            if( k < 0 ) { ctx->prof_cell_ms += ms; ctx->prof_cell_launches++; ctx->prof_cells += (uint64_t)-k; }
+            const int kind = i / 2 < (int)ctx->prof_kind.size() ? ctx->prof_kind[i / 2] : -1;
+            if( kind >= 0 ) { ctx->kprof_ms[kind] += ms; ctx->kprof_launches[kind]++; ctx->kprof_units[kind] += (uint64_t)k; }
+            else if( k < 0 ) { ctx->prof_cell_ms += ms; ctx->prof_cell_launches++; ctx->prof_cells += (uint64_t)-k; }
             else { ctx->prof_ms += ms; ctx->prof_launches++; ctx->prof_searches += k; }
         }
     }
     ctx->prof_used = 0;
     ctx->prof_n.clear();
+    ctx->prof_kind.clear();
     return X264HIP_OK;
 }
 
@@ -1002,7 +1034,8 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
             if( rc ) return rc;
         }
         e0 = ctx->prof_ev[ctx->prof_used]; e1 = ctx->prof_ev[ctx->prof_used + 1];
-        ctx->prof_n.push_back( n );
+        while( ctx->prof_kind.size() < ctx->prof_n.size() ) ctx->prof_kind.push_back( -1 );
+        ctx->prof_n.push_back( n ); ctx->prof_kind.push_back( -1 );
         ctx->prof_used += 2;
     }
     HIPCK( hipEventRecord( e0, ctx->stream ) );
@@ -1181,14 +1214,15 @@ static int launch_cells_t( x264hip_ctx *ctx, const std::vector<SpecCell> &cells 
             }
             HIPCK( hipEventRecord( ctx->prof_ev[ctx->prof_used], ctx->stream ) );
             pe1 = ctx->prof_ev[ctx->prof_used + 1];
-            ctx->prof_n.push_back( -n );
+            while( ctx->prof_kind.size() < ctx->prof_n.size() ) ctx->prof_kind.push_back( -1 );
+            ctx->prof_n.push_back( -n ); ctx->prof_kind.push_back( -1 );
             ctx->prof_used += 2;
         }
         if( n_p )
-            cell_p_kernel<<<dim3( ( ctx->n_mb + 255 ) / 256, n_p ), 256, 0, ctx->stream>>>( P, dd, none );
+            KPROF( X264HIP_KPROF_CELL_P, n_p, ( cell_p_kernel<<<dim3( ( ctx->n_mb + 255 ) / 256, n_p ), 256, 0, ctx->stream>>>( P, dd, none ) ) );
         if( n_b )
-            cell_b_kernel<T><<<dim3( ( P.mb_w + CELLB_BPW - 1 ) / CELLB_BPW, P.mb_h, n_b ), 64, 0, ctx->stream>>>( P, dd + n_p, none );
-        cell_reduce_kernel<<<dim3( n_red, reduce_bands( P, n_red ) ), 256, 0, ctx->stream>>>( P, dd, none ); // sums go straight to pinned host memory
+            KPROF( X264HIP_KPROF_CELL_B, n_b, ( cell_b_kernel<T><<<dim3( ( P.mb_w + CELLB_BPW - 1 ) / CELLB_BPW, P.mb_h, n_b ), 64, 0, ctx->stream>>>( P, dd + n_p, none ) ) );
+        KPROF( X264HIP_KPROF_CELL_REDUCE, n_red, ( cell_reduce_kernel<<<dim3( n_red, reduce_bands( P, n_red ) ), 256, 0, ctx->stream>>>( P, dd, none ) ) ); // sums go straight to pinned host memory
         if( pe1 )
             HIPCK( hipEventRecord( pe1, ctx->stream ) );
         HIPCK( hipGetLastError() );
@@ -2277,6 +2311,7 @@ extern "C" int x264hip_search_profile( x264hip_ctx *ctx, int enable, double *tot
     {
         ctx->prof_ms = 0; ctx->prof_launches = 0; ctx->prof_searches = 0;
         ctx->prof_cell_ms = 0; ctx->prof_cell_launches = 0; ctx->prof_cells = 0;
+        for( int k = 0; k < X264HIP_KPROF_CLASSES; k++ ) { ctx->kprof_ms[k] = 0; ctx->kprof_launches[k] = 0; ctx->kprof_units[k] = 0; }
         ctx->prof_on = enable;
         if( enable && ctx->prof_ev.empty() )
         {
@@ -2298,6 +2333,22 @@ extern "C" int x264hip_cell_profile( x264hip_ctx *ctx, double *total_ms, uint64_
     if( total_ms ) *total_ms = ctx->prof_cell_ms;
     if( launches ) *launches = ctx->prof_cell_launches;
     if( cells ) *cells = ctx->prof_cells;
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_kernel_profile( x264hip_ctx *ctx, double *total_ms, uint64_t *launches, uint64_t *units )
+{
+    if( !ctx ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    int rc = prof_drain( ctx );
+    if( rc ) return rc;
+    for( int k = 0; k < X264HIP_KPROF_CLASSES; k++ )
+    {
+        if( total_ms ) total_ms[k] = ctx->kprof_ms[k];
+        if( launches ) launches[k] = ctx->kprof_launches[k];
+        if( units ) units[k] = ctx->kprof_units[k];
+    }
     return X264HIP_OK;
 }
 
@@ -3507,9 +3558,9 @@ static CellXfer make_xfer( x264hip_ctx *ctx, const x264hip_cell_ref &c, bool imp
     FrameSlot &b = ctx->slots[c.slot_b];
     const int idx = c.dist_p0 * ( ctx->p.bframes + 2 ) + c.dist_p1;
     const bool spare = ( c.with_ref1_l0 & X264HIP_CELL_SPARE ) != 0;
-    if( importing && !spare )
-        b.cell_at[idx] = idx; // a summary from the owner rank goes to the cell's own place
-    const int at = spare ? ctx->n_cells + idx : b.cell_at[idx];
+    // a summary from the owner rank goes to the cell's own place (the caller re-points cell_at there once it has decided to take
+    // the entry: an entry that is skipped -- the cell was already answered here, possibly from its spare half -- must not move it)
+    const int at = spare ? ctx->n_cells + idx : importing ? idx : b.cell_at[idx];
     CellXfer X;
     X.acc_host = ( spare ? ctx->cell_alt_host : ctx->cell_acc_host ) + ( (size_t)c.slot_b * ctx->n_cells + idx ) * 8;
     X.acc_dev = b.cell_sums + (size_t)at * 8;
@@ -3573,6 +3624,7 @@ extern "C" int x264hip_import_cells( x264hip_ctx *ctx, int n, const x264hip_cell
             const int variant = d1 && !spare && ( c.with_ref1_l0 & X264HIP_CELL_WITH_L0 );
             const bool inputs = known( b, 0, d0 - 1 ) && ( !d1 || ( known( b, 1, d1 - 1 ) && ( !variant || known( f1, 0, d0 + d1 - 1 ) ) ) );
             if( e.valid || e.requested || b.cells[d0 * ns + d1].requested || !inputs ) { xh[i].skip = 1; continue; }
+            if( !spare ) b.cell_at[d0 * ns + d1] = d0 * ns + d1;
             e.valid = 1; e.batch = ctx->batch_serial + 1; e.variant = (unsigned char)( d1 ? variant : 1 );
             e.tag0 = b.field_tag[0][d0 - 1];
             e.tag1 = d1 ? b.field_tag[1][d1 - 1] : 0;

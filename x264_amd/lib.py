@@ -106,6 +106,14 @@ def search_profile(L, ctx_handle, enable=-1):
     return ms.value, int(nl.value), int(ns.value)
 
 
+def kernel_profile(L, ctx_handle):
+    """[(total_ms, launches, units)] per X264HIP_KPROF_* class (x264hip_kernel_profile; filled while x264hip_search_profile was on with bit 1 set)"""
+    ms, nl, nu = (C.c_double * 6)(), (C.c_uint64 * 6)(), (C.c_uint64 * 6)()
+    L.x264hip_kernel_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _ck(L.x264hip_kernel_profile(ctx_handle, ms, nl, nu), "kernel_profile")
+    return [(ms[k], nl[k], nu[k]) for k in range(6)]
+
+
 def cell_profile(L, ctx_handle):
     """(total_ms, launches, cells) of the cost cell launches in the window x264hip_search_profile opened."""
     ms, nl, ns = C.c_double(), C.c_uint64(), C.c_uint64()
