@@ -66,6 +66,34 @@ def primitives_bench(torch, libmod, cfg, iters=30):
                     nbytes = bw * bh * (2 * size * size + 4)  # SURVEY 8(d) per-block form: both blocks + the result
                     out["%s_%dx%d%s_GBps" % ("satd" if satd else "sad", size, size, tag)] = round(nbytes / dt / 1e9, 1)
             del fenc, ref
+        # The same blocks as SIXTEEN separate frame pairs in one launch of the public multi-pair entry (x264hip_pixel_cmp_batch_multi: pair =
+        # blockIdx.z): what a caller with a window of frames has -- the single 4K pair above is a launch of a few microseconds
+        NP = 16
+        Wp, Hp = (W // 16) * 16, (H // 16) * 16
+        stride = Wp + 64
+        org = 32 * stride + 32
+        fencs = [torch.randint(0, 256, (Hp + 64, stride), dtype=torch.uint8, device="cuda", generator=g) for _ in range(NP)]
+        refs = [torch.randint(0, 256, (Hp + 64, stride), dtype=torch.uint8, device="cuda", generator=g) for _ in range(NP)]
+        for size_idx, size in ((0, 16), (3, 8), (6, 4)):
+            bw, bh = Wp // size, Hp // size
+            mvs = [torch.randint(-16, 17, (bw * bh, 2), dtype=torch.int16, device="cuda", generator=g) for _ in range(NP)]
+            ress = [torch.zeros(bw * bh, dtype=torch.int32, device="cuda") for _ in range(NP)]
+            torch.cuda.synchronize()
+            fp_, rp_, mp_, op_ = ([t.data_ptr() + o_ for t in lst] for lst, o_ in ((fencs, org), (refs, org), (mvs, 0), (ress, 0)))
+            for satd in (0, 1):
+                def run():
+                    ctx.pixel_cmp_batch_multi(satd, size_idx, fp_, rp_, stride, bw, bh, mp_, op_)
+                run(); ctx.synchronize()
+                dt = None
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    for _ in range(iters):
+                        run()
+                    ctx.synchronize()
+                    d = (time.perf_counter() - t0) / iters
+                    dt = d if dt is None else min(dt, d)
+                out["%s_%dx%d_16pairs_GBps" % ("satd" if satd else "sad", size, size)] = round(NP * bw * bh * (2 * size * size + 4) / dt / 1e9, 1)
+        del fencs, refs, mvs, ress
         # hpel_filter (first piece) over a 4K plane: W*H read + 3*W*H written
         hs = W + 64
         src = torch.randint(0, 256, (H + 16, hs), dtype=torch.uint8, device="cuda", generator=g)
@@ -80,7 +108,20 @@ def primitives_bench(torch, libmod, cfg, iters=30):
             run_hpel()
         ctx.synchronize()
         out["hpel_filter_GBps"] = round(4 * W * H * iters / (time.perf_counter() - t0) / 1e9, 1)
-        del src, dst
+        # eight such planes in one launch (x264hip_hpel_filter_multi)
+        srcs = [src] + [torch.randint(0, 256, (H + 16, hs), dtype=torch.uint8, device="cuda", generator=g) for _ in range(7)]
+        dsts = [dst] + [torch.empty((3, H + 16, hs), dtype=torch.uint8, device="cuda") for _ in range(7)]
+        torch.cuda.synchronize()
+        hp_ = [[d_[k].data_ptr() + ho for d_ in dsts] for k in range(3)] + [[s_.data_ptr() + ho for s_ in srcs]]
+        def run_hpel_multi():
+            ctx.hpel_filter_multi(hp_[0], hp_[1], hp_[2], hp_[3], hs, W, H)
+        run_hpel_multi(); ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            run_hpel_multi()
+        ctx.synchronize()
+        out["hpel_filter_8planes_GBps"] = round(8 * 4 * W * H * iters / (time.perf_counter() - t0) / 1e9, 1)
+        del src, dst, srcs, dsts
         # the same over an 8K plane: a 4K plane is ~15 us of work, of which ~8 us are the launch and the first loads / last stores of a wave
         W8, H8 = 2 * W, 2 * H
         hs = W8 + 64
@@ -134,7 +175,22 @@ def primitives_bench(torch, libmod, cfg, iters=30):
             run_dq()
         ctx.synchronize()
         out["frame_dct_quant4x4_GBps"] = round((4 * W * H + W * H // 16) * iters / (time.perf_counter() - t0) / 1e9, 1)
-        del fe, fp, co, nzb
+        # eight plane pairs in one launch (x264hip_frame_dct_quant4x4_multi)
+        fes = [fe] + [torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda", generator=g) for _ in range(7)]
+        fps = [fp] + [torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda", generator=g) for _ in range(7)]
+        cos = [co] + [torch.empty((H // 4, W // 4, 16), dtype=torch.int16, device="cuda") for _ in range(7)]
+        nzs = [nzb] + [torch.empty((H // 4, W // 4), dtype=torch.uint8, device="cuda") for _ in range(7)]
+        torch.cuda.synchronize()
+        dq_ = [[t.data_ptr() for t in lst] for lst in (fes, fps, cos, nzs)]
+        def run_dq_multi():
+            ctx.frame_dct_quant4x4_multi(dq_[0], W, dq_[1], W, W, H, mfq, bq, dq_[2], dq_[3])
+        run_dq_multi(); ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            run_dq_multi()
+        ctx.synchronize()
+        out["frame_dct_quant4x4_8planes_GBps"] = round(8 * (4 * W * H + W * H // 16) * iters / (time.perf_counter() - t0) / 1e9, 1)
+        del fe, fp, co, nzb, fes, fps, cos, nzs
         # the build's own copy kernel over 512 MB (read + write counted): the measured HBM rate next to the 8 TB/s vendor peak
         a = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
         b = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
@@ -199,8 +255,22 @@ def primitives_bench(torch, libmod, cfg, iters=30):
                 # rate --, the device rate has its own key)
                 out["me_full_%s_16x16_device_searches_per_s" % name] = round(n_req / (dev_ms * 1e-3))
                 out["me_full_%s_16x16_searches_per_s" % name] = round(n_req / t_call)
+                # the same table resident on the device (x264hip_me_search_batch_dev): the call enqueues, the wait is x264hip_synchronize
+                import ctypes as _C
+                raw = np.frombuffer(bytes(_C.string_at(_C.addressof(args_[0]), _C.sizeof(args_[0]))), dtype=np.uint8)
+                rq_dev = torch.from_numpy(raw.copy()).cuda()
+                res_dev = torch.zeros((n_req, 4), dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()
+                t_dev = None
+                for _ in range(4):
+                    t0 = time.perf_counter()
+                    ctx.me_search_batch_dev(n_req, rq_dev.data_ptr(), *args_[1:], method, 16, res_dev.data_ptr())
+                    ctx.synchronize()
+                    d = time.perf_counter() - t0
+                    t_dev = d if t_dev is None else min(t_dev, d)
+                out["me_full_%s_16x16_resident_call_searches_per_s" % name] = round(n_req / t_dev)
             out["me_full_note"] = ("me_full_*_searches_per_s = the whole x264hip_me_search_batch call (request table translated and uploaded, kernels, read-back), "
-                                   "32 160 requests; me_full_*_device_searches_per_s = its kernels between HIP events.  In round 3's line the unsuffixed key was the "
+                                   "32 160 requests (116 bytes each over PCIe); me_full_*_resident_call_searches_per_s = x264hip_me_search_batch_dev + x264hip_synchronize, table and results on the device; me_full_*_device_searches_per_s = the kernels between HIP events.  In round 3's line the unsuffixed key was the "
                                    "device rate and *_call_searches_per_s the call rate")
             del planes, integ, fenc_l, ref_l
         except Exception as e:  # pragma: no cover

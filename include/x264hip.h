@@ -295,6 +295,12 @@ typedef struct x264hip_me_request
 int  x264hip_me_search_batch( x264hip_ctx *ctx, int n, const x264hip_me_request *reqs, const void *fenc_plane_dev, intptr_t fenc_stride,
                               const void *const ref_planes_dev[4], intptr_t ref_stride, const uint16_t *integral_dev, intptr_t integral_lower,
                               const uint16_t *cost_mv_dev, int *out );
+/* The same for a request table and a result array that live ON the device (requests generated there): enqueued on the context's stream
+ * (x264hip_synchronize to wait), nothing crosses the host link.  Every request is searched with me_method; me_range_max bounds their
+ * me_range.  The call above moves 116 bytes per request over PCIe, which is what its rate is bound by. */
+int  x264hip_me_search_batch_dev( x264hip_ctx *ctx, int n, const x264hip_me_request *reqs_dev, const void *fenc_plane_dev, intptr_t fenc_stride,
+                                  const void *const ref_planes_dev[4], intptr_t ref_stride, const uint16_t *integral_dev, intptr_t integral_lower,
+                                  const uint16_t *cost_mv_dev, int me_method, int me_range_max, int *out_dev );
 
 /* The block metrics of x264_pixel_function_t that only the main encode calls, over a raster of blocks_w x blocks_h blocks of size_idx
  * (PIXEL_16x16 = 0 .. PIXEL_4x4 = 6, common/pixel.h:37-59) of device-resident planes sharing one stride; block (x, y) starts at
@@ -328,6 +334,17 @@ int  x264hip_frame_dct_quant8x8( x264hip_ctx *ctx, const void *fenc, intptr_t fe
  * half-pel planes of `src` (device pointers, element stride).  Like the reference it reads src columns -2..width+2
  * and rows -2..height+2 and also writes dstv columns -2,-1 and width..width+2.  First piece of SURVEY 8(f) rank 3. */
 int  x264hip_hpel_filter( x264hip_ctx *ctx, void *dsth, void *dstv, void *dstc, const void *src, intptr_t stride, int width, int height );
+/* The three streaming primitives above for up to X264HIP_MULTI_MAX independent planes / plane pairs of ONE geometry in one launch (the
+ * arrays hold one device pointer per plane set; strides, sizes and quantiser tables are shared).  The input BASELINE defines for the
+ * primitive metric -- the blocks of ONE 4K frame pair -- is a launch of a few microseconds, half of it launch and ramp; the pairs of a
+ * lookahead window in one launch run at the rate of one large field.  Same results as n single calls. */
+#define X264HIP_MULTI_MAX 16
+int  x264hip_pixel_cmp_batch_multi( x264hip_ctx *ctx, int satd, int size_idx, int n_pairs, const void *const *fenc_planes, const void *const *ref_planes, int stride,
+                                    int blocks_w, int blocks_h, const int16_t *const *mv_dev, int *const *out_dev );
+int  x264hip_hpel_filter_multi( x264hip_ctx *ctx, int n, void *const *dsth, void *const *dstv, void *const *dstc, const void *const *src, intptr_t stride,
+                                int width, int height );
+int  x264hip_frame_dct_quant4x4_multi( x264hip_ctx *ctx, int n, const void *const *fenc, intptr_t fenc_stride, const void *const *fdec, intptr_t fdec_stride,
+                                       int width, int height, const void *mf, const void *bias, void *const *coefs_dev, uint8_t *const *nz_dev );
 /* plain device-to-device copy on the context's stream (16-byte aligned): the build's own copy kernel, whose measured
  * GB/s is the second denominator of the SAD/SATD figures next to the vendor peak */
 int  x264hip_device_copy( x264hip_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes );

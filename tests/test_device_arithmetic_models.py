@@ -61,22 +61,25 @@ def test_biased_satd_tail_equals_the_hadamard_sum_at_the_extremes(maxdiff):
         assert _satd4x4_device_model(d).sum() == _satd4x4_plain(d), d
 
 
-def _xcd_band_block(gx, gy, bx, by):
+def _xcd_band_block(gx, gy, bx, by, bz=0):
     G, idx = gx * gy, by * gx + bx
-    xcd = idx & 7
-    start = sum((G - j + 7) >> 3 for j in range(xcd))
-    id2 = start + (idx >> 3)
+    shift = (bz * G) & 7
+    xcd = (idx + shift) & 7
+    start = sum((G - ((j - shift) & 7) + 7) >> 3 for j in range(xcd))
+    id2 = start + ((idx - ((xcd - shift) & 7)) >> 3)
     return id2 % gx, id2 // gx
 
 
 @pytest.mark.parametrize("gx,gy", [(1, 1), (1, 7), (3, 5), (8, 8), (60, 135), (16, 271), (7, 9), (5, 1), (31, 2), (2, 1000)])
-def test_xcd_band_renumbering_is_a_bijection_and_keeps_an_xcd_in_one_run(gx, gy):
+@pytest.mark.parametrize("bz", [0, 1, 2, 5, 13])
+def test_xcd_band_renumbering_is_a_bijection_and_keeps_an_xcd_in_one_run(gx, gy, bz):
+    """bz: the slice of a 3-D grid (multi-plane launches): the hardware deals workgroups to XCDs by their index over all three dimensions"""
     seen = {}
     for by in range(gy):
         for bx in range(gx):
-            x, y = _xcd_band_block(gx, gy, bx, by)
+            x, y = _xcd_band_block(gx, gy, bx, by, bz)
             assert 0 <= x < gx and 0 <= y < gy
-            seen[(x, y)] = (by * gx + bx) & 7
+            seen[(x, y)] = (bz * gx * gy + by * gx + bx) & 7   # the XCD this workgroup really runs on
     assert len(seen) == gx * gy
     # row-major order of the new positions: the XCD index never decreases (one contiguous run per XCD)
     order = [seen[(x, y)] for y in range(gy) for x in range(gx)]

@@ -263,11 +263,25 @@ def test_me_search_batch(depth):
     try:
         got = ctx.me_search_batch(reqs, frame.data_ptr(), frame.shape[1], [p.data_ptr() + org0 * isz for p in planes], pw,
                                   integral.data_ptr() + org0 * 2, ph * pw, cmv.data_ptr() + 2 * centre)
+        # the same requests resident on the device, one method per table (x264hip_me_search_batch_dev): nothing crosses the host link
+        import ctypes as C
+        got_dev = np.zeros_like(got)
+        for me, mid in ME_METHODS.items():
+            sel = [k for k, q in enumerate(reqs) if q.me_method == mid]
+            arr = ctx.me_requests([reqs[k] for k in sel])
+            raw = torch.from_numpy(np.frombuffer(bytes(C.string_at(C.addressof(arr), C.sizeof(arr))), dtype=np.uint8).copy()).cuda()
+            res = torch.full((len(sel), 4), -7, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            ctx.me_search_batch_dev(len(sel), raw.data_ptr(), frame.data_ptr(), frame.shape[1], [p.data_ptr() + org0 * isz for p in planes], pw,
+                                    integral.data_ptr() + org0 * 2, ph * pw, cmv.data_ptr() + 2 * centre, mid, max(reqs[k].me_range for k in sel), res.data_ptr())
+            ctx.synchronize()
+            got_dev[sel] = res.cpu().numpy()
     finally:
         ctx.close()
     for k in range(len(reqs)):
         n = 4 if subs[k] >= 2 else 3
         assert np.array_equal(got[k][:n], want[k][:n]), (k, got[k].tolist(), [int(v) for v in want[k]])
+        assert np.array_equal(got_dev[k][:n], want[k][:n]), ("device-resident table", k, got_dev[k].tolist(), [int(v) for v in want[k]])
     assert len(reqs) >= 500
 
 

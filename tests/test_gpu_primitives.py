@@ -511,3 +511,72 @@ def test_table_fillers_exact_signature_members(depth):
         assert not errs
     finally:
         ctx.close(); other.close()
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_multi_plane_forms_equal_single_calls(depth):
+    """x264hip_pixel_cmp_batch_multi / _hpel_filter_multi / _frame_dct_quant4x4_multi: several independent planes / plane pairs in ONE launch
+    (blockIdx.z picks the set) give exactly what one call per set gives (the single forms are checked against the oracle above)."""
+    import torch
+    o = Oracle(depth)
+    maxv = (1 << depth) - 1
+    rng = np.random.default_rng(77 + depth)
+    vdt = np.uint8 if depth == 8 else np.int16
+    N, PAD = 5, 32
+    ctx = lib.Context(64, 64, bit_depth=depth, max_frames=2, mv_range=32)
+    try:
+        # --- SAD / SATD of displaced blocks, all seven sizes
+        W, H = 208, 112
+        stride = W + 2 * PAD + 3
+        planes = [torch.from_numpy(rng.integers(0, maxv + 1, size=(2, H + 2 * PAD, stride)).astype(o.dtype).view(vdt)).cuda() for _ in range(N)]
+        org = (PAD * stride + PAD) * (1 if depth == 8 else 2)
+        for size_idx, (sw, sh) in enumerate(((16, 16), (16, 8), (8, 16), (8, 8), (8, 4), (4, 8), (4, 4))):
+            bw, bh = W // sw, H // sh
+            mvs = [torch.from_numpy(rng.integers(-PAD, PAD - 15, size=(bw * bh, 2)).astype(np.int16)).cuda() for _ in range(N)]
+            for satd in (0, 1):
+                one = [torch.full((bw * bh,), -1, dtype=torch.int32, device="cuda") for _ in range(N)]
+                many = [torch.full((bw * bh,), -2, dtype=torch.int32, device="cuda") for _ in range(N)]
+                torch.cuda.synchronize()
+                for k in range(N):
+                    ctx.pixel_cmp_batch(satd, size_idx, planes[k][0].data_ptr() + org, planes[k][1].data_ptr() + org, stride, bw, bh, mvs[k].data_ptr(), one[k].data_ptr())
+                ctx.pixel_cmp_batch_multi(satd, size_idx, [p[0].data_ptr() + org for p in planes], [p[1].data_ptr() + org for p in planes], stride, bw, bh,
+                                          [m.data_ptr() for m in mvs], [t.data_ptr() for t in many])
+                ctx.synchronize()
+                for k in range(N):
+                    assert torch.equal(one[k], many[k]) and int(one[k].min()) >= 0, (size_idx, satd, k)
+        # --- hpel_filter
+        w, h = 499, 37
+        st = w + 32
+        off = (3 * st + 8) * (1 if depth == 8 else 2)
+        srcs = [torch.from_numpy(rng.integers(0, maxv + 1, size=(h + 8, st)).astype(o.dtype).view(vdt)).cuda() for _ in range(N)]
+        one = [torch.full((3, h + 8, st), 7, dtype=srcs[0].dtype, device="cuda") for _ in range(N)]
+        many = [torch.full((3, h + 8, st), 7, dtype=srcs[0].dtype, device="cuda") for _ in range(N)]
+        torch.cuda.synchronize()
+        for k in range(N):
+            ctx.hpel_filter(one[k][0].data_ptr() + off, one[k][1].data_ptr() + off, one[k][2].data_ptr() + off, srcs[k].data_ptr() + off, st, w, h)
+        ctx.hpel_filter_multi([m[0].data_ptr() + off for m in many], [m[1].data_ptr() + off for m in many], [m[2].data_ptr() + off for m in many],
+                              [s_.data_ptr() + off for s_ in srcs], st, w, h)
+        ctx.synchronize()
+        for k in range(N):
+            assert torch.equal(one[k], many[k]), k
+        assert not torch.equal(one[0], one[1])
+        # --- sub4x4_dct + quant_4x4 of whole planes
+        W2, H2 = 1036, 68
+        fs, ds = W2 + 12, W2 + 40
+        mf = rng.integers(500, 14000, size=16).astype(o.ucoef_dtype)
+        bias = rng.integers(0, 30000, size=16).astype(o.ucoef_dtype)
+        fe = [torch.from_numpy(rng.integers(0, maxv + 1, size=(H2, fs)).astype(o.dtype).view(vdt)).cuda() for _ in range(N)]
+        fd = [torch.from_numpy(rng.integers(0, maxv + 1, size=(H2, ds)).astype(o.dtype).view(vdt)).cuda() for _ in range(N)]
+        cdt = torch.int16 if depth == 8 else torch.int32
+        mk = lambda fill: ([torch.full((H2 // 4, W2 // 4, 16), fill, dtype=cdt, device="cuda") for _ in range(N)],  # noqa: E731
+                           [torch.full((H2 // 4, W2 // 4), 9, dtype=torch.uint8, device="cuda") for _ in range(N)])
+        (c1, z1), (c2, z2) = mk(77), mk(55)
+        torch.cuda.synchronize()
+        for k in range(N):
+            ctx.frame_dct_quant4x4(fe[k].data_ptr(), fs, fd[k].data_ptr(), ds, W2, H2, mf, bias, c1[k].data_ptr(), z1[k].data_ptr())
+        ctx.frame_dct_quant4x4_multi([t.data_ptr() for t in fe], fs, [t.data_ptr() for t in fd], ds, W2, H2, mf, bias, [t.data_ptr() for t in c2], [t.data_ptr() for t in z2])
+        ctx.synchronize()
+        for k in range(N):
+            assert torch.equal(c1[k], c2[k]) and torch.equal(z1[k], z2[k]), k
+    finally:
+        ctx.close()

@@ -141,16 +141,30 @@ __device__ __forceinline__ Px4 load_px4( const uint16_t *p )
 // taps or a displaced block reach into -- sit behind different L2s and each fetches those rows from memory.  This bijection of the linear
 // index hands XCD k (indices k, k + 8, ...) ONE contiguous run of the row-major order, i.e. a horizontal band of the field: shared rows are
 // fetched once per band border instead of once per workgroup row.  (bx, by) replace blockIdx.x / blockIdx.y; scalar arithmetic only.
+// (A 3-D grid -- the multi-plane launches, plane = blockIdx.z -- is dealt to the XCDs by the index over all three dimensions: slice z
+// starts at XCD ( z G ) mod 8, so the classes are rotated by that much inside the slice.)
 __device__ __forceinline__ void xcd_band_block( int &bx, int &by )
 {
-    const int G = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x, xcd = id & 7;
+    const int G = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int shift = (int)( ( blockIdx.z * (unsigned)G ) & 7u ), xcd = ( id + shift ) & 7;
     int start = 0;
     for( int j = 0; j < xcd; j++ )
-        start += ( G - j + 7 ) >> 3;
-    const int id2 = start + ( id >> 3 );
+        start += ( G - ( ( j - shift ) & 7 ) + 7 ) >> 3;   // workgroups of this slice on XCD j: indices ( j - shift ) mod 8, + 8, ...
+    const int id2 = start + ( ( id - ( ( xcd - shift ) & 7 ) ) >> 3 );
     by = id2 / (int)gridDim.x;
     bx = id2 - by * (int)gridDim.x;
 }
+// The streaming primitives in their multi-plane form (x264hip_*_multi): up to 16 independent planes / plane pairs per launch, blockIdx.z
+// picks the set; the pointers travel by value in the kernel arguments (scalar loads).  n == 0: the pointers given as plain arguments.
+// A launch over one 4K plane pair lasts 5 us and is half launch and ramp; sixteen of them in one launch run at the rate of a large field.
+#define MULTI_PLANES_MAX 16
+struct MultiPtrs
+{
+    int n, pad_;
+    void *p[4][MULTI_PLANES_MAX]; // four pointer roles of the kernel at hand, one entry per plane set
+};
+#define MULTI_PICK( M, role, T, plain ) ( ( M ).n ? (T)( M ).p[role][blockIdx.z] : ( plain ) )
+
 // A descriptor every lane of the wave reads from the same address (a table entry picked by blockIdx): fetched through the scalar cache, so
 // its fields -- the pointers above all -- land in SGPRs: one s_load instead of a round of per-lane loads, and every load through one of
 // those pointers is a plain global load with a scalar base (no flat aperture check, no v_readfirstlane pair in front of it).  The table

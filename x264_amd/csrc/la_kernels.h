@@ -1099,9 +1099,13 @@ __device__ __forceinline__ void load_row8<uint16_t>( const uint16_t *p, Px4 f[2]
 // cost is computed (the displacement of a block is itself a load the reference address depends on: with one region per lane the
 // kernel had two dependent memory round trips and 32 bytes in flight per lane; RR = 4 keeps 128).
 template <typename T, int BW, int BH, bool SATD, int RR>
-__global__ __launch_bounds__( 256 ) void pixel_cmp_batch_kernel( const T *__restrict__ fenc, const T *__restrict__ ref, int stride,
-                                                                 int regions_w, int regions_h, const int16_t *__restrict__ mv, int *__restrict__ out, int xcd_bands )
+__global__ __launch_bounds__( 256 ) void pixel_cmp_batch_kernel( const T *__restrict__ fenc_, const T *__restrict__ ref_, int stride,
+                                                                 int regions_w, int regions_h, const int16_t *__restrict__ mv_, int *__restrict__ out_, int xcd_bands, MultiPtrs M )
 {
+    const T *__restrict__ fenc = MULTI_PICK( M, 0, const T *, fenc_ );
+    const T *__restrict__ ref = MULTI_PICK( M, 1, const T *, ref_ );
+    const int16_t *__restrict__ mv = MULTI_PICK( M, 2, const int16_t *, mv_ );
+    int *__restrict__ out = MULTI_PICK( M, 3, int *, out_ );
     const int lane = lane_id();
     // XCD k takes the k-th horizontal band of the field (device_common.h xcd_band_block): the reference rows two vertically neighbouring
     // workgroups both read (vectors move a block up to the search range) are fetched into ONE L2 -- 4.1 -> 5.1 TB/s on the 265 MB mosaic
@@ -1330,9 +1334,11 @@ __device__ __forceinline__ unsigned hp_tap6( unsigned p0, unsigned p1, unsigned 
     acc = __builtin_amdgcn_sdot2( hp_as_s2( p2 ), hp_as_s2( 0x0001FFFBu ), acc, false );     // -5  1
     return (unsigned)iclip3( acc >> 10, 0, 255 );
 }
-__global__ __launch_bounds__( 64 ) void hpel_stream_kernel( uint8_t *__restrict__ dsth, uint8_t *__restrict__ dstv, uint8_t *__restrict__ dstc, const uint8_t *__restrict__ src,
-                                                            int stride, int width, int height )
+__global__ __launch_bounds__( 64 ) void hpel_stream_kernel( uint8_t *__restrict__ dsth_, uint8_t *__restrict__ dstv_, uint8_t *__restrict__ dstc_, const uint8_t *__restrict__ src_,
+                                                            int stride, int width, int height, MultiPtrs M )
 {
+    uint8_t *__restrict__ dsth = MULTI_PICK( M, 0, uint8_t *, dsth_ ), *__restrict__ dstv = MULTI_PICK( M, 1, uint8_t *, dstv_ ), *__restrict__ dstc = MULTI_PICK( M, 2, uint8_t *, dstc_ );
+    const uint8_t *__restrict__ src = MULTI_PICK( M, 3, const uint8_t *, src_ );
     const int lane = threadIdx.x;
     int wg_x, wg_y;
     xcd_band_block( wg_x, wg_y ); // the five extra rows of a strip are its vertical neighbours' rows: one L2 per band of strips
@@ -1436,9 +1442,11 @@ __device__ __forceinline__ int hp16_tap6( unsigned p0, unsigned p1, unsigned p2,
     return __builtin_amdgcn_sdot2( hp_as_s2( p2 ), hp_as_s2( 0x0001FFFBu ), acc, false );    // -5  1
 }
 __device__ __forceinline__ unsigned hp16_pack( int a, int b ) { return (unsigned)a | ( (unsigned)b << 16 ); }
-__global__ __launch_bounds__( 64 ) void hpel_stream16_kernel( uint16_t *__restrict__ dsth, uint16_t *__restrict__ dstv, uint16_t *__restrict__ dstc,
-                                                              const uint16_t *__restrict__ src, int stride, int width, int height, int pixel_max )
+__global__ __launch_bounds__( 64 ) void hpel_stream16_kernel( uint16_t *__restrict__ dsth_, uint16_t *__restrict__ dstv_, uint16_t *__restrict__ dstc_,
+                                                              const uint16_t *__restrict__ src_, int stride, int width, int height, int pixel_max, MultiPtrs M )
 {
+    uint16_t *__restrict__ dsth = MULTI_PICK( M, 0, uint16_t *, dsth_ ), *__restrict__ dstv = MULTI_PICK( M, 1, uint16_t *, dstv_ ), *__restrict__ dstc = MULTI_PICK( M, 2, uint16_t *, dstc_ );
+    const uint16_t *__restrict__ src = MULTI_PICK( M, 3, const uint16_t *, src_ );
     const int lane = threadIdx.x;
     int wg_x, wg_y;
     xcd_band_block( wg_x, wg_y ); // the five extra rows of a strip are its vertical neighbours' rows: one L2 per band of strips
@@ -1638,9 +1646,12 @@ struct QuantTab
 };
 
 template <typename T, typename C>
-__global__ __launch_bounds__( 256 ) void frame_dct_quant4x4_kernel( const T *__restrict__ fenc, long fenc_stride, const T *__restrict__ fdec, long fdec_stride,
-                                                                    int blocks_w, int blocks_h, QuantTab q, C *__restrict__ coefs, uint8_t *__restrict__ nz_out )
+__global__ __launch_bounds__( 256 ) void frame_dct_quant4x4_kernel( const T *__restrict__ fenc_, long fenc_stride, const T *__restrict__ fdec_, long fdec_stride,
+                                                                    int blocks_w, int blocks_h, QuantTab q, C *__restrict__ coefs_, uint8_t *__restrict__ nz_out_, MultiPtrs M )
 {
+    const T *__restrict__ fenc = MULTI_PICK( M, 0, const T *, fenc_ ), *__restrict__ fdec = MULTI_PICK( M, 1, const T *, fdec_ );
+    C *__restrict__ coefs = MULTI_PICK( M, 2, C *, coefs_ );
+    uint8_t *__restrict__ nz_out = MULTI_PICK( M, 3, uint8_t *, nz_out_ );
     const int bx = blockIdx.x * 256 + threadIdx.x, by = blockIdx.y;
     if( bx >= blocks_w )
         return;

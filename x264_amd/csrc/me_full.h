@@ -968,6 +968,57 @@ __global__ __launch_bounds__( 64 ) void me_full_coop_kernel( const MfReq<T> *req
         for( int k = 0; k < 4; k++ )
             out[4 * i + k] = res[k];
 }
+// The request table of the public entry (x264hip_me_request, include/x264hip.h) turned into the kernels' own records ON the device: a thread
+// per request.  The records carry eight pointers each; built on the host they were 200 bytes per request written into pinned memory and
+// read back over the host link, twice the size of what the caller handed over.  scratch_off: per-request byte offset of a TESA
+// request's candidate list (nullptr: request i takes slot i of `uniform_scratch` bytes); force_method >= 0: every request is searched
+// with that method (device-resident tables are declared to hold one class of methods).
+struct MeTranslate
+{
+    const void *fenc_plane, *ref[4];
+    long fenc_stride, ref_stride, integral_lower;
+    const uint16_t *integral, *cost_mv;
+    char *scratch;
+    const unsigned *scratch_off;
+    unsigned long long uniform_scratch;
+    int force_method, n;
+};
+template <typename T>
+__global__ __launch_bounds__( 256 ) void me_translate_kernel( const x264hip_me_request *q_all, MeTranslate A, MfReq<T> *table, int16_t *mvc, int *n_mvc, int *index )
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if( i >= A.n )
+        return;
+    const x264hip_me_request q = q_all[i];
+    MfReq<T> r;
+    r.i_pixel = q.i_pixel; r.me_method = A.force_method >= 0 ? A.force_method : q.me_method; r.subpel_refine = q.subpel_refine; r.me_range = q.me_range;
+    r.mbcmp_satd = q.mbcmp_satd; r.fpelcmp_satd = q.fpelcmp_satd;
+    r.fenc = (const T *)A.fenc_plane + (long)q.y * A.fenc_stride + q.x; r.fenc_stride = (int)A.fenc_stride;
+#pragma unroll
+    for( int k = 0; k < 4; k++ )
+        r.ref[k] = (const T *)A.ref[k] + (long)q.y * A.ref_stride + q.x;
+    r.stride = (int)A.ref_stride;
+    r.integral = A.integral ? A.integral + (long)q.y * A.ref_stride + q.x : nullptr;
+    r.integral_lower = A.integral_lower;
+#pragma unroll
+    for( int k = 0; k < 2; k++ )
+    {
+        r.mvp[k] = q.mvp[k]; r.lim_min[k] = q.lim_min[k]; r.lim_max[k] = q.lim_max[k];
+        r.spel_min[k] = q.spel_min[k]; r.spel_max[k] = q.spel_max[k];
+    }
+    r.cost_mv = A.cost_mv;
+    r.scratch = r.me_method == 4 ? A.scratch + ( A.scratch_off ? (unsigned long long)A.scratch_off[i] : (unsigned long long)i * A.uniform_scratch ) : nullptr;
+    table[i] = r;
+    n_mvc[i] = q.n_mvc < 0 ? 0 : q.n_mvc > X264HIP_ME_MVC_MAX ? X264HIP_ME_MVC_MAX : q.n_mvc;
+#pragma unroll
+    for( int k = 0; k < X264HIP_ME_MVC_MAX; k++ )
+    {
+        mvc[( (long)i * MF_MVC_MAX + k ) * 2] = q.mvc[k][0];
+        mvc[( (long)i * MF_MVC_MAX + k ) * 2 + 1] = q.mvc[k][1];
+    }
+    if( index )
+        index[i] = i;
+}
 // one thread per request, for the listed requests (index == nullptr: all)
 template <typename T>
 __global__ __launch_bounds__( 64 ) void me_full_list_kernel( const MfReq<T> *reqs, const int16_t *mvc, const int *n_mvc, const int *index, int n, int *out )

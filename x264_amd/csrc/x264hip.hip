@@ -2360,8 +2360,40 @@ extern "C" int x264hip_counters( x264hip_ctx *ctx, uint64_t *out, int n )
 }
 
 // ---- batched primitives ------------------------------------------------------------------------------
+static int fill_multi( MultiPtrs &M, int n, const void *const *a, const void *const *b, const void *const *c, const void *const *d )
+{
+    memset( &M, 0, sizeof( M ) );
+    if( n < 1 || n > MULTI_PLANES_MAX || !a || !b || !c || !d ) return X264HIP_EINVAL;
+    for( int i = 0; i < n; i++ )
+    {
+        if( !a[i] || !b[i] || !c[i] || !d[i] ) return X264HIP_EINVAL;
+        M.p[0][i] = (void *)a[i]; M.p[1][i] = (void *)b[i]; M.p[2][i] = (void *)c[i]; M.p[3][i] = (void *)d[i];
+    }
+    M.n = n;
+    return X264HIP_OK;
+}
+
+static int pixel_cmp_launch( x264hip_ctx *ctx, int satd, int size_idx, const void *fenc_plane, const void *ref_plane, int stride,
+                             int blocks_w, int blocks_h, const int16_t *mv_dev, int *out_dev, const MultiPtrs &M );
 extern "C" int x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx, const void *fenc_plane, const void *ref_plane, int stride,
                                         int blocks_w, int blocks_h, const int16_t *mv_dev, int *out_dev )
+{
+    MultiPtrs none;
+    memset( &none, 0, sizeof( none ) );
+    return pixel_cmp_launch( ctx, satd, size_idx, fenc_plane, ref_plane, stride, blocks_w, blocks_h, mv_dev, out_dev, none );
+}
+// n_pairs independent frame pairs of one geometry in ONE launch (pair = blockIdx.z): the BASELINE-defined primitive input -- all blocks of one
+// 4K frame pair -- is a 5 us launch, half of it launch and ramp; a window's worth of pairs runs at the rate of a large field
+extern "C" int x264hip_pixel_cmp_batch_multi( x264hip_ctx *ctx, int satd, int size_idx, int n_pairs, const void *const *fenc_planes, const void *const *ref_planes, int stride,
+                                              int blocks_w, int blocks_h, const int16_t *const *mv_dev, int *const *out_dev )
+{
+    MultiPtrs M;
+    int rc = fill_multi( M, n_pairs, fenc_planes, ref_planes, (const void *const *)mv_dev, (const void *const *)out_dev );
+    if( rc ) return rc;
+    return pixel_cmp_launch( ctx, satd, size_idx, fenc_planes[0], ref_planes[0], stride, blocks_w, blocks_h, mv_dev[0], out_dev[0], M );
+}
+static int pixel_cmp_launch( x264hip_ctx *ctx, int satd, int size_idx, const void *fenc_plane, const void *ref_plane, int stride,
+                             int blocks_w, int blocks_h, const int16_t *mv_dev, int *out_dev, const MultiPtrs &M )
 {
     if( !ctx || !fenc_plane || !ref_plane || !mv_dev || !out_dev ) return X264HIP_EINVAL;
     static const int sz_w[7] = { 16, 16, 8, 8, 8, 4, 4 }, sz_h[7] = { 16, 8, 16, 8, 4, 8, 4 }; // common/pixel.h:37-59, PIXEL_16x16 .. PIXEL_4x4
@@ -2374,16 +2406,16 @@ extern "C" int x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx
     // region rows per lane (loads in flight per lane): 4 unless the field is too small to fill the chip with a quarter of the
     // workgroups (X264HIP_CMP_ROWS = 1 / 2 / 4 overrides it: A/B aid)
     static const int rows_env = getenv( "X264HIP_CMP_ROWS" ) ? atoi( getenv( "X264HIP_CMP_ROWS" ) ) : 0;
-    const int wgs1 = ( ( rw + 15 ) / 16 ) * rh;
+    const int wgs1 = ( ( rw + 15 ) / 16 ) * rh * ( M.n ? M.n : 1 );
     const int rr = rows_env == 1 || rows_env == 2 || rows_env == 4 || rows_env == 8 ? rows_env : wgs1 >= 32 * ctx->n_cu ? 4 : wgs1 >= 4 * ctx->n_cu ? 2 : 1;
-    const dim3 grd( ( rw + 15 ) / 16, ( rh + rr - 1 ) / rr );
+    const dim3 grd( ( rw + 15 ) / 16, ( rh + rr - 1 ) / rr, M.n ? M.n : 1 );
     static const int xcd_bands = !( getenv( "X264HIP_CMP_BANDS" ) && atoi( getenv( "X264HIP_CMP_BANDS" ) ) == 0 ); // 0: workgroups in launch order (A/B aid)
 #define CMP_LAUNCH( T, BW, BH, D ) \
     do { \
-        if( rr == 8 ) pixel_cmp_batch_kernel<T, BW, BH, D, 8><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev, xcd_bands ); \
-        else if( rr == 4 ) pixel_cmp_batch_kernel<T, BW, BH, D, 4><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev, xcd_bands ); \
-        else if( rr == 2 ) pixel_cmp_batch_kernel<T, BW, BH, D, 2><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev, xcd_bands ); \
-        else pixel_cmp_batch_kernel<T, BW, BH, D, 1><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev, xcd_bands ); \
+        if( rr == 8 ) pixel_cmp_batch_kernel<T, BW, BH, D, 8><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev, xcd_bands, M ); \
+        else if( rr == 4 ) pixel_cmp_batch_kernel<T, BW, BH, D, 4><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev, xcd_bands, M ); \
+        else if( rr == 2 ) pixel_cmp_batch_kernel<T, BW, BH, D, 2><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev, xcd_bands, M ); \
+        else pixel_cmp_batch_kernel<T, BW, BH, D, 1><<<grd, 256, 0, ctx->stream>>>( (const T *)fenc_plane, (const T *)ref_plane, stride, rw, rh, mv_dev, out_dev, xcd_bands, M ); \
     } while( 0 )
 #define CMP_METRIC( T, BW, BH ) do { if( satd ) CMP_LAUNCH( T, BW, BH, true ); else CMP_LAUNCH( T, BW, BH, false ); } while( 0 )
 #define CMP_SIZE( T ) \
@@ -2410,77 +2442,85 @@ extern "C" int x264hip_pixel_cmp_batch( x264hip_ctx *ctx, int satd, int size_idx
     return X264HIP_OK;
 }
 
+// reqs_host / out_host: the caller's table and result array in host memory (x264hip_me_search_batch: synchronous), or
+// reqs_dev / out_dev: both on the device (x264hip_me_search_batch_dev: enqueued; one class of methods, declared by the caller).
 template <typename T>
-static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request *reqs, const void *fenc_plane, intptr_t fenc_stride,
+static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request *reqs_host, const x264hip_me_request *reqs_dev, int dev_method, int dev_range,
+                              const void *fenc_plane, intptr_t fenc_stride,
                               const void *const ref_planes[4], intptr_t ref_stride, const uint16_t *integral, intptr_t integral_lower,
-                              const uint16_t *cost_mv, int *out )
+                              const uint16_t *cost_mv, int *out_host_user, int *out_dev_user )
 {
     // TESA keeps the candidates that pass its SAD threshold: at most ( width + 4 ) * ( rows + 1 ) of them, 12 bytes each, with
     // width <= 2 * me_range + 4 and rows <= 2 * me_range + 1 (me.c:651-655)
     auto tesa_bytes = []( int me_range ) { return (size_t)( 2 * me_range + 8 ) * ( 2 * me_range + 2 ) * 12; };
+    const bool on_dev = reqs_dev != nullptr;
     size_t scratch_total = 0;
-    for( int i = 0; i < n; i++ )
-        if( reqs[i].me_method == 4 ) scratch_total += tesa_bytes( reqs[i].me_range );
+    if( on_dev )
+        scratch_total = dev_method == 4 ? tesa_bytes( dev_range ) * (size_t)n : 0;
+    else
+        for( int i = 0; i < n; i++ )
+            if( reqs_host[i].me_method == 4 ) scratch_total += tesa_bytes( reqs_host[i].me_range );
     // One device allocation and one pinned host allocation for the call, kept by the context and grown when a call needs more (an
-    // allocation per call cost more than the searches of a 1080p frame).  The tables are written straight into the pinned block and
-    // go to the device in one upload; the results come back into it.
+    // allocation per call cost more than the searches of a 1080p frame).  What crosses the host link is the caller's table as it is
+    // (116 bytes per request), two ints per request and the results; the kernels' own records are made from it on the device
+    // (me_translate_kernel).
     const size_t b_scratch = align_up( scratch_total, 256 ), b_table = align_up( sizeof( MfReq<T> ) * n, 256 ), b_mvc = align_up( (size_t)n * MF_MVC_MAX * 2 * sizeof( int16_t ), 256 ),
-                 b_nmvc = align_up( sizeof( int ) * n, 256 ), b_out = align_up( sizeof( int ) * 4 * n, 256 ), b_index = align_up( sizeof( int ) * n, 256 );
-    const size_t b_tables = b_table + b_mvc + b_nmvc + b_index; // what the host writes: contiguous
-    const size_t need = b_scratch + b_tables + b_out;
+                 b_nmvc = align_up( sizeof( int ) * n, 256 ), b_out = align_up( sizeof( int ) * 4 * n, 256 ), b_index = align_up( sizeof( int ) * n, 256 ),
+                 b_raw = on_dev ? 0 : align_up( sizeof( x264hip_me_request ) * (size_t)n, 256 ), b_off = on_dev ? 0 : align_up( sizeof( unsigned ) * n, 256 );
+    const size_t b_host = b_raw + b_off + b_index; // what the host writes: contiguous
+    const size_t need = b_scratch + b_table + b_mvc + b_nmvc + b_host + b_out;
     if( need > ctx->me_pool_bytes )
     {
+        HIPCK( hipStreamSynchronize( ctx->stream ) ); // (an enqueued batch may still be using the block)
         if( ctx->me_pool ) (void)hipFree( ctx->me_pool );
         ctx->me_pool = nullptr; ctx->me_pool_bytes = 0;
         if( hipMalloc( &ctx->me_pool, need + ( need >> 2 ) ) != hipSuccess ) return X264HIP_ENOMEM;
         ctx->me_pool_bytes = need + ( need >> 2 );
     }
-    if( b_tables + b_out > ctx->me_host_bytes )
+    if( !on_dev && b_host + b_out > ctx->me_host_bytes )
     {
         if( ctx->me_host ) (void)hipHostFree( ctx->me_host );
         ctx->me_host = nullptr; ctx->me_host_bytes = 0;
-        const size_t want = b_tables + b_out + ( ( b_tables + b_out ) >> 2 );
+        const size_t want = b_host + b_out + ( ( b_host + b_out ) >> 2 );
         if( hipHostMalloc( &ctx->me_host, want ) != hipSuccess ) return X264HIP_ENOMEM;
         ctx->me_host_bytes = want;
     }
     char *scratch = ctx->me_pool;
     MfReq<T> *table_dev = (MfReq<T> *)( scratch + b_scratch );
     int16_t *mvc_dev = (int16_t *)( (char *)table_dev + b_table );
-    int *n_mvc_dev = (int *)( (char *)mvc_dev + b_mvc ), *index_dev = (int *)( (char *)n_mvc_dev + b_nmvc ), *out_dev = (int *)( (char *)index_dev + b_index );
-    MfReq<T> *table = (MfReq<T> *)ctx->me_host;
-    int16_t *mvc = (int16_t *)( ctx->me_host + b_table );
-    int *n_mvc = (int *)( ctx->me_host + b_table + b_mvc ), *idx = (int *)( ctx->me_host + b_table + b_mvc + b_nmvc );
-    int *out_host = (int *)( ctx->me_host + b_tables );
+    int *n_mvc_dev = (int *)( (char *)mvc_dev + b_mvc );
+    char *host_dev = (char *)n_mvc_dev + b_nmvc; // the device copy of the host-written block: raw requests, TESA offsets, index
+    const x264hip_me_request *raw_dev = on_dev ? reqs_dev : (const x264hip_me_request *)host_dev;
+    unsigned *off_dev = (unsigned *)( host_dev + b_raw );
+    int *index_dev = (int *)( host_dev + b_raw + b_off ), *out_dev = on_dev ? out_dev_user : (int *)( host_dev + b_host );
     int rc = X264HIP_OK;
 #define MECK( call ) do { if( ( call ) != hipSuccess ) { ctx->broken = 1; return X264HIP_EDEVICE; } } while( 0 )
-    for( size_t i = 0, t = 0; i < (size_t)n; i++ )
+    int n_pat = on_dev ? ( dev_method < 3 ? n : 0 ) : 0;
+    if( !on_dev )
     {
-        const x264hip_me_request &q = reqs[i];
-        MfReq<T> &r = table[i];
-        r.i_pixel = q.i_pixel; r.me_method = q.me_method; r.subpel_refine = q.subpel_refine; r.me_range = q.me_range;
-        r.mbcmp_satd = q.mbcmp_satd; r.fpelcmp_satd = q.fpelcmp_satd;
-        r.fenc = (const T *)fenc_plane + (long)q.y * fenc_stride + q.x; r.fenc_stride = (int)fenc_stride;
-        for( int k = 0; k < 4; k++ )
-            r.ref[k] = (const T *)ref_planes[k] + (long)q.y * ref_stride + q.x;
-        r.stride = (int)ref_stride;
-        r.integral = integral ? integral + (long)q.y * ref_stride + q.x : nullptr;
-        r.integral_lower = (long)integral_lower;
-        for( int k = 0; k < 2; k++ )
+        x264hip_me_request *raw = (x264hip_me_request *)ctx->me_host;
+        unsigned *off = (unsigned *)( ctx->me_host + b_raw );
+        int *idx = (int *)( ctx->me_host + b_raw + b_off );
+        memcpy( raw, reqs_host, sizeof( x264hip_me_request ) * (size_t)n );
+        size_t t = 0;
+        for( int i = 0; i < n; i++ )
         {
-            r.mvp[k] = q.mvp[k]; r.lim_min[k] = q.lim_min[k]; r.lim_max[k] = q.lim_max[k];
-            r.spel_min[k] = q.spel_min[k]; r.spel_max[k] = q.spel_max[k];
+            off[i] = (unsigned)t;
+            if( reqs_host[i].me_method == 4 ) t += tesa_bytes( reqs_host[i].me_range );
         }
-        r.cost_mv = cost_mv;
-        r.scratch = q.me_method == 4 ? scratch + t : nullptr;
-        if( q.me_method == 4 ) t += tesa_bytes( q.me_range );
-        n_mvc[i] = q.n_mvc;
-        memcpy( &mvc[(size_t)i * MF_MVC_MAX * 2], q.mvc, sizeof( q.mvc ) );
+        // one launch per class of methods: the pattern searches (DIA, HEX, UMH) and the exhaustive ones (ESA, TESA) are separate builds
+        for( int i = 0; i < n; i++ ) if( reqs_host[i].me_method < 3 ) idx[n_pat++] = i;
+        for( int i = 0, k = n_pat; i < n; i++ ) if( reqs_host[i].me_method >= 3 ) idx[k++] = i;
+        MECK( upload_async( ctx, host_dev, ctx->me_host, b_host, ctx->stream ) );
     }
-    // one launch per class of methods: the pattern searches (DIA, HEX, UMH) and the exhaustive ones (ESA, TESA) are separate builds
-    int n_pat = 0;
-    for( int i = 0; i < n; i++ ) if( reqs[i].me_method < 3 ) idx[n_pat++] = i;
-    for( int i = 0, k = n_pat; i < n; i++ ) if( reqs[i].me_method >= 3 ) idx[k++] = i;
-    MECK( upload_async( ctx, table_dev, table, b_tables, ctx->stream ) );
+    MeTranslate A;
+    memset( &A, 0, sizeof( A ) );
+    A.fenc_plane = fenc_plane; A.fenc_stride = (long)fenc_stride; A.ref_stride = (long)ref_stride; A.integral_lower = (long)integral_lower;
+    for( int k = 0; k < 4; k++ ) A.ref[k] = ref_planes[k];
+    A.integral = integral; A.cost_mv = cost_mv; A.scratch = scratch;
+    A.scratch_off = on_dev ? nullptr : off_dev; A.uniform_scratch = on_dev ? tesa_bytes( dev_range ) : 0;
+    A.force_method = on_dev ? dev_method : -1; A.n = n;
+    me_translate_kernel<T><<<( n + 255 ) / 256, 256, 0, ctx->stream>>>( raw_dev, A, table_dev, mvc_dev, n_mvc_dev, on_dev ? index_dev : nullptr );
     MECK( hipEventRecord( ctx->ev_start, ctx->stream ) );
     {
         // a wave per request: its 64 lanes run the search in lock step, block costs are computed across the wave (four samples per
@@ -2501,9 +2541,13 @@ static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request 
     // (x264hip_last_search_ms reports the device time of the batch's kernels: n searches of one block each)
     MECK( hipEventRecord( ctx->ev_stop, ctx->stream ) );
     ctx->ev_valid = 1; ctx->last_n_search = n; ctx->last_n_blocks = n;
-    MECK( hipMemcpyAsync( out_host, out_dev, sizeof( int ) * 4 * n, hipMemcpyDeviceToHost, ctx->stream ) );
-    MECK( hipStreamSynchronize( ctx->stream ) );
-    memcpy( out, out_host, sizeof( int ) * 4 * n );
+    if( !on_dev )
+    {
+        int *out_pinned = (int *)( ctx->me_host + b_host );
+        MECK( hipMemcpyAsync( out_pinned, out_dev, sizeof( int ) * 4 * n, hipMemcpyDeviceToHost, ctx->stream ) );
+        MECK( hipStreamSynchronize( ctx->stream ) );
+        memcpy( out_host_user, out_pinned, sizeof( int ) * 4 * n );
+    }
 #undef MECK
     return rc;
 }
@@ -2525,8 +2569,29 @@ extern "C" int x264hip_me_search_batch( x264hip_ctx *ctx, int n, const x264hip_m
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     return ctx->p.bit_depth == 8
-           ? me_search_batch_t<uint8_t>( ctx, n, reqs, fenc_plane_dev, fenc_stride, ref_planes_dev, ref_stride, integral_dev, integral_lower, cost_mv_dev, out )
-           : me_search_batch_t<uint16_t>( ctx, n, reqs, fenc_plane_dev, fenc_stride, ref_planes_dev, ref_stride, integral_dev, integral_lower, cost_mv_dev, out );
+           ? me_search_batch_t<uint8_t>( ctx, n, reqs, nullptr, 0, 0, fenc_plane_dev, fenc_stride, ref_planes_dev, ref_stride, integral_dev, integral_lower, cost_mv_dev, out, nullptr )
+           : me_search_batch_t<uint16_t>( ctx, n, reqs, nullptr, 0, 0, fenc_plane_dev, fenc_stride, ref_planes_dev, ref_stride, integral_dev, integral_lower, cost_mv_dev, out, nullptr );
+}
+
+// the same with the request table and the results ON the device (a front end that generates its requests there): enqueued on the
+// context's stream, nothing crosses the host link.  The table holds one method (me_method: every request is searched with it) and
+// me_range_max bounds the requests' me_range (it sizes the TESA candidate lists).  The fields of the requests are not validated.
+extern "C" int x264hip_me_search_batch_dev( x264hip_ctx *ctx, int n, const x264hip_me_request *reqs_dev, const void *fenc_plane_dev, intptr_t fenc_stride,
+                                            const void *const ref_planes_dev[4], intptr_t ref_stride, const uint16_t *integral_dev, intptr_t integral_lower,
+                                            const uint16_t *cost_mv_dev, int me_method, int me_range_max, int *out_dev )
+{
+    if( !ctx || n <= 0 || !reqs_dev || !fenc_plane_dev || !ref_planes_dev || !cost_mv_dev || !out_dev || me_method < 0 || me_method > 4 || me_range_max < 1 ||
+        ( me_method == 4 && ( !integral_dev || me_range_max > 64 ) ) )
+        return X264HIP_EINVAL;
+    for( int k = 0; k < 4; k++ )
+        if( !ref_planes_dev[k] ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    return ctx->p.bit_depth == 8
+           ? me_search_batch_t<uint8_t>( ctx, n, nullptr, reqs_dev, me_method, me_range_max, fenc_plane_dev, fenc_stride, ref_planes_dev, ref_stride, integral_dev, integral_lower,
+                                         cost_mv_dev, nullptr, out_dev )
+           : me_search_batch_t<uint16_t>( ctx, n, nullptr, reqs_dev, me_method, me_range_max, fenc_plane_dev, fenc_stride, ref_planes_dev, ref_stride, integral_dev, integral_lower,
+                                          cost_mv_dev, nullptr, out_dev );
 }
 
 extern "C" int x264hip_integral_init( x264hip_ctx *ctx, const void *plane_dev, intptr_t stride, int width, int height, uint16_t *sum8_dev, uint16_t *sum4_dev )
@@ -2583,8 +2648,26 @@ extern "C" int x264hip_pixel_metric_batch( x264hip_ctx *ctx, int metric, int siz
     return X264HIP_OK;
 }
 
+static int dct_quant4x4_launch( x264hip_ctx *ctx, const void *fenc, intptr_t fenc_stride, const void *fdec, intptr_t fdec_stride, int width, int height,
+                                const void *mf, const void *bias, void *coefs_dev, uint8_t *nz_dev, const MultiPtrs &M );
 extern "C" int x264hip_frame_dct_quant4x4( x264hip_ctx *ctx, const void *fenc, intptr_t fenc_stride, const void *fdec, intptr_t fdec_stride, int width, int height,
                                            const void *mf, const void *bias, void *coefs_dev, uint8_t *nz_dev )
+{
+    MultiPtrs none;
+    memset( &none, 0, sizeof( none ) );
+    return dct_quant4x4_launch( ctx, fenc, fenc_stride, fdec, fdec_stride, width, height, mf, bias, coefs_dev, nz_dev, none );
+}
+extern "C" int x264hip_frame_dct_quant4x4_multi( x264hip_ctx *ctx, int n, const void *const *fenc, intptr_t fenc_stride, const void *const *fdec, intptr_t fdec_stride,
+                                                 int width, int height, const void *mf, const void *bias, void *const *coefs_dev, uint8_t *const *nz_dev )
+{
+    MultiPtrs M;
+    int rc = fill_multi( M, n, fenc, fdec, (const void *const *)coefs_dev, (const void *const *)nz_dev );
+    if( rc ) return rc;
+    for( int i = 0; i < n; i++ ) if( (uintptr_t)coefs_dev[i] & 15 ) return X264HIP_EINVAL;
+    return dct_quant4x4_launch( ctx, fenc[0], fenc_stride, fdec[0], fdec_stride, width, height, mf, bias, coefs_dev[0], nz_dev[0], M );
+}
+static int dct_quant4x4_launch( x264hip_ctx *ctx, const void *fenc, intptr_t fenc_stride, const void *fdec, intptr_t fdec_stride, int width, int height,
+                                const void *mf, const void *bias, void *coefs_dev, uint8_t *nz_dev, const MultiPtrs &M )
 {
     if( !ctx || !fenc || !fdec || !mf || !bias || !coefs_dev || !nz_dev || width <= 0 || height <= 0 || ( width & 3 ) || ( height & 3 ) ||
         fenc_stride < width || fdec_stride < width || ( (uintptr_t)coefs_dev & 15 ) )
@@ -2598,13 +2681,13 @@ extern "C" int x264hip_frame_dct_quant4x4( x264hip_ctx *ctx, const void *fenc, i
         q.bias[i] = ctx->p.bit_depth == 8 ? ( (const uint16_t *)bias )[i] : ( (const uint32_t *)bias )[i];
     }
     const int bw = width / 4, bh = height / 4;
-    const dim3 grd( ( bw + 255 ) / 256, bh );
+    const dim3 grd( ( bw + 255 ) / 256, bh, M.n ? M.n : 1 );
     if( ctx->p.bit_depth == 8 )
         frame_dct_quant4x4_kernel<uint8_t, int16_t><<<grd, 256, 0, ctx->stream>>>( (const uint8_t *)fenc, (long)fenc_stride, (const uint8_t *)fdec, (long)fdec_stride, bw, bh, q,
-                                                                                   (int16_t *)coefs_dev, nz_dev );
+                                                                                   (int16_t *)coefs_dev, nz_dev, M );
     else
         frame_dct_quant4x4_kernel<uint16_t, int32_t><<<grd, 256, 0, ctx->stream>>>( (const uint16_t *)fenc, (long)fenc_stride, (const uint16_t *)fdec, (long)fdec_stride, bw, bh,
-                                                                                    q, (int32_t *)coefs_dev, nz_dev );
+                                                                                    q, (int32_t *)coefs_dev, nz_dev, M );
     HIPCK( hipGetLastError() );
     return X264HIP_OK;
 }
@@ -2635,22 +2718,40 @@ extern "C" int x264hip_frame_dct_quant8x8( x264hip_ctx *ctx, const void *fenc, i
     return X264HIP_OK;
 }
 
+static int hpel_filter_launch( x264hip_ctx *ctx, void *dsth, void *dstv, void *dstc, const void *src, intptr_t stride, int width, int height, const MultiPtrs &M );
 extern "C" int x264hip_hpel_filter( x264hip_ctx *ctx, void *dsth, void *dstv, void *dstc, const void *src, intptr_t stride, int width, int height )
+{
+    MultiPtrs none;
+    memset( &none, 0, sizeof( none ) );
+    return hpel_filter_launch( ctx, dsth, dstv, dstc, src, stride, width, height, none );
+}
+// the three half-pel planes of n planes of one geometry in one launch (plane = blockIdx.z)
+extern "C" int x264hip_hpel_filter_multi( x264hip_ctx *ctx, int n, void *const *dsth, void *const *dstv, void *const *dstc, const void *const *src, intptr_t stride,
+                                          int width, int height )
+{
+    MultiPtrs M;
+    int rc = fill_multi( M, n, (const void *const *)dsth, (const void *const *)dstv, (const void *const *)dstc, src );
+    if( rc ) return rc;
+    return hpel_filter_launch( ctx, dsth[0], dstv[0], dstc[0], src[0], stride, width, height, M );
+}
+static int hpel_filter_launch( x264hip_ctx *ctx, void *dsth, void *dstv, void *dstc, const void *src, intptr_t stride, int width, int height, const MultiPtrs &M )
 {
     if( !ctx || !dsth || !dstv || !dstc || !src || width <= 0 || height <= 0 || stride < width ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     const dim3 grd( ( width + HPEL_TW - 1 ) / HPEL_TW, ( height + HPEL_TH - 1 ) / HPEL_TH );
     static const bool tiled8 = getenv( "X264HIP_HPEL_TILED" ) != nullptr; // the LDS-tiled kernel instead of the streaming ones (A/B runs)
+    if( tiled8 && M.n ) return X264HIP_EINVAL; // (the comparison kernel has no multi-plane form)
+    const unsigned nz = M.n ? M.n : 1;
     if( ctx->p.bit_depth == 8 && !tiled8 )
-        hpel_stream_kernel<<<dim3( ( width + HPS_W - 1 ) / HPS_W, ( height + HPS_R - 1 ) / HPS_R ), 64, 0, ctx->stream>>>(
-            (uint8_t *)dsth, (uint8_t *)dstv, (uint8_t *)dstc, (const uint8_t *)src, (int)stride, width, height );
+        hpel_stream_kernel<<<dim3( ( width + HPS_W - 1 ) / HPS_W, ( height + HPS_R - 1 ) / HPS_R, nz ), 64, 0, ctx->stream>>>(
+            (uint8_t *)dsth, (uint8_t *)dstv, (uint8_t *)dstc, (const uint8_t *)src, (int)stride, width, height, M );
     else if( ctx->p.bit_depth == 8 )
         hpel_filter_kernel<uint8_t><<<grd, 256, 0, ctx->stream>>>( (uint8_t *)dsth, (uint8_t *)dstv, (uint8_t *)dstc, (const uint8_t *)src, (long)stride, width, height,
                                                                    ctx->P.pixel_max );
     else if( !tiled8 )
-        hpel_stream16_kernel<<<dim3( ( width + HPS_W - 1 ) / HPS_W, ( height + HPS_R - 1 ) / HPS_R ), 64, 0, ctx->stream>>>(
-            (uint16_t *)dsth, (uint16_t *)dstv, (uint16_t *)dstc, (const uint16_t *)src, (int)stride, width, height, ctx->P.pixel_max );
+        hpel_stream16_kernel<<<dim3( ( width + HPS_W - 1 ) / HPS_W, ( height + HPS_R - 1 ) / HPS_R, nz ), 64, 0, ctx->stream>>>(
+            (uint16_t *)dsth, (uint16_t *)dstv, (uint16_t *)dstc, (const uint16_t *)src, (int)stride, width, height, ctx->P.pixel_max, M );
     else
         hpel_filter_kernel<uint16_t><<<grd, 256, 0, ctx->stream>>>( (uint16_t *)dsth, (uint16_t *)dstv, (uint16_t *)dstc, (const uint16_t *)src, (long)stride, width,
                                                                     height, ctx->P.pixel_max );
@@ -2672,12 +2773,14 @@ static int frame_filter_t( x264hip_ctx *ctx, const T *luma, intptr_t luma_stride
     expand_border_kernel<T><<<grd, 256, 0, ctx->stream>>>( planes[0], (long)stride, luma, (long)luma_stride, 0, 0, width - 1, 0, height - 1, -padh, width + padh - 1, -padv );
     // 2. the three half-pel planes over the picture plus 8 samples all round (mc.c:706-726)
     const long offs = -8 * (long)stride - 8;
+    MultiPtrs one_plane;
+    memset( &one_plane, 0, sizeof( one_plane ) );
     if constexpr( sizeof( T ) == 1 )
         hpel_stream_kernel<<<dim3( ( width + 16 + HPS_W - 1 ) / HPS_W, ( height + 16 + HPS_R - 1 ) / HPS_R ), 64, 0, ctx->stream>>>(
-            planes[1] + offs, planes[2] + offs, planes[3] + offs, planes[0] + offs, (int)stride, width + 16, height + 16 );
+            planes[1] + offs, planes[2] + offs, planes[3] + offs, planes[0] + offs, (int)stride, width + 16, height + 16, one_plane );
     else
         hpel_stream16_kernel<<<dim3( ( width + 16 + HPS_W - 1 ) / HPS_W, ( height + 16 + HPS_R - 1 ) / HPS_R ), 64, 0, ctx->stream>>>(
-            planes[1] + offs, planes[2] + offs, planes[3] + offs, planes[0] + offs, (int)stride, width + 16, height + 16, ctx->P.pixel_max );
+            planes[1] + offs, planes[2] + offs, planes[3] + offs, planes[0] + offs, (int)stride, width + 16, height + 16, ctx->P.pixel_max, one_plane );
     // 3. their borders from the last trustworthy filtered samples: 4 columns / 8 rows outside the picture (frame.c:599-623)
     for( int k = 1; k < 4; k++ )
         expand_border_kernel<T><<<grd, 256, 0, ctx->stream>>>( planes[k], (long)stride, planes[k], (long)stride, 1, -4, width + 3, -8, height + 7, -padh, width + padh - 1, -padv );

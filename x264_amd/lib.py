@@ -269,6 +269,14 @@ class Context:
                                            cost_mv_ptr, _p(out)), "me_search_batch")
         return out
 
+    def me_search_batch_dev(self, n, reqs_ptr, fenc_ptr, fenc_stride, ref_ptrs, ref_stride, integral_ptr, integral_lower, cost_mv_ptr, me_method, me_range_max, out_ptr):
+        """x264hip_me_search_batch_dev: request table ([n] MeRequest) and results ([n, 4] int32) on the device; enqueued, not waited for"""
+        refs = (C.c_void_p * 4)(*ref_ptrs)
+        self.L.x264hip_me_search_batch_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t,
+                                                       C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _ck(self.L.x264hip_me_search_batch_dev(self.h, int(n), reqs_ptr, fenc_ptr, fenc_stride, refs, ref_stride, integral_ptr, integral_lower, cost_mv_ptr,
+                                               int(me_method), int(me_range_max), out_ptr), "me_search_batch_dev")
+
     def frame_filter(self, luma_ptr, luma_stride, width, height, plane_ptrs, stride, padh, padv, sum8_ptr=None, sum4_ptr=None):
         self.L.x264hip_frame_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int,
                                                 C.c_void_p, C.c_void_p]
@@ -297,6 +305,24 @@ class Context:
     def hpel_filter(self, dsth_ptr, dstv_ptr, dstc_ptr, src_ptr, stride, width, height):
         _ck(self.L.x264hip_hpel_filter(self.h, C.c_void_p(dsth_ptr), C.c_void_p(dstv_ptr), C.c_void_p(dstc_ptr), C.c_void_p(src_ptr),
                                        C.c_ssize_t(stride), int(width), int(height)), "hpel_filter")
+
+    # ---- multi-plane forms: lists of device addresses, one per plane set (x264hip_*_multi) ----
+    @staticmethod
+    def _ptrs(lst):
+        return (C.c_void_p * len(lst))(*[int(v) for v in lst])
+
+    def pixel_cmp_batch_multi(self, satd, size_idx, fenc_ptrs, ref_ptrs, stride, blocks_w, blocks_h, mv_ptrs, out_ptrs):
+        _ck(self.L.x264hip_pixel_cmp_batch_multi(self.h, int(satd), int(size_idx), len(fenc_ptrs), self._ptrs(fenc_ptrs), self._ptrs(ref_ptrs), int(stride),
+                                                 int(blocks_w), int(blocks_h), self._ptrs(mv_ptrs), self._ptrs(out_ptrs)), "pixel_cmp_batch_multi")
+
+    def hpel_filter_multi(self, dsth_ptrs, dstv_ptrs, dstc_ptrs, src_ptrs, stride, width, height):
+        _ck(self.L.x264hip_hpel_filter_multi(self.h, len(src_ptrs), self._ptrs(dsth_ptrs), self._ptrs(dstv_ptrs), self._ptrs(dstc_ptrs), self._ptrs(src_ptrs),
+                                             C.c_ssize_t(stride), int(width), int(height)), "hpel_filter_multi")
+
+    def frame_dct_quant4x4_multi(self, fenc_ptrs, fenc_stride, fdec_ptrs, fdec_stride, width, height, mf, bias, coefs_ptrs, nz_ptrs):
+        mf = np.ascontiguousarray(mf); bias = np.ascontiguousarray(bias)
+        _ck(self.L.x264hip_frame_dct_quant4x4_multi(self.h, len(fenc_ptrs), self._ptrs(fenc_ptrs), C.c_ssize_t(fenc_stride), self._ptrs(fdec_ptrs), C.c_ssize_t(fdec_stride),
+                                                    int(width), int(height), _p(mf), _p(bias), self._ptrs(coefs_ptrs), self._ptrs(nz_ptrs)), "frame_dct_quant4x4_multi")
 
     def device_copy(self, dst_ptr, src_ptr, nbytes):
         _ck(self.L.x264hip_device_copy(self.h, C.c_void_p(dst_ptr), C.c_void_p(src_ptr), C.c_size_t(nbytes)), "device_copy")
