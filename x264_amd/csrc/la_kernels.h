@@ -757,19 +757,24 @@ __device__ __forceinline__ void cell_finish( const LaP &P, const CellArgs &A, in
 // took 80 us for a 4K cell whatever else the chip was doing: a cell evaluated on demand waited for it.)
 __global__ __launch_bounds__( 256 ) void cell_reduce_kernel( LaP P, const CellArgs *descs, CellArgs single )
 {
-    __shared__ int sh[5][4];
+    // (a sixth sum beside the five of the reference: how many intra costs of the frame exceed the 14 bits a map entry holds -- zero for
+    // nearly every frame, and then the clamp an intra-only evaluation applies to the map, slicetype.c:790, is the identity and the host
+    // neither launches it nor orders the queued MB-tree lists in front of it: x264hip.hip, frame_cost_t)
+    __shared__ int sh[6][4];
     __shared__ int last;
     const CellArgs A = descs ? load_uniform( descs + blockIdx.x ) : single;
     const int W = P.mb_w, H = P.mb_h;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
     const int row_begin = (int)( (long long)H * blockIdx.y / gridDim.y ), row_end = (int)( (long long)H * ( blockIdx.y + 1 ) / gridDim.y );
-    int t[5] = { 0, 0, 0, 0, 0 };
+    int t[6] = { 0, 0, 0, 0, 0, 0 };
     for( int by = row_begin + wave; by < row_end; by += n_waves )
     {
         int row = 0, row_i = 0;
         for( int bx = lane; bx < W; bx += 64 )
         {
             const int xy = by * W + bx;
+            if( A.sums_only )
+                t[5] += A.intra_cost[xy] > 0x3FFF;
             if( !la_visited( P, bx, by ) )
                 continue; // contributes to no sum (slicetype.c:825-833)
             const bool scored = ( bx > 0 && bx < W - 1 && by > 0 && by < H - 1 ) || W <= 2 || H <= 2;
@@ -810,13 +815,14 @@ __global__ __launch_bounds__( 256 ) void cell_reduce_kernel( LaP P, const CellAr
         }
     }
 #pragma unroll
-    for( int k = 0; k < 5; k++ )
+    for( int k = 0; k < 6; k++ )
     {
         t[k] = (int)wave_sum_u32( (unsigned)t[k] );
         if( lane == 0 ) sh[k][wave] = t[k];
     }
     __syncthreads();
-    if( threadIdx.x < 5 )
+    const int slot = threadIdx.x < 5 ? threadIdx.x : 6; // work[5] is the arrival counter: the sixth sum gathers in work[6]
+    if( threadIdx.x < 6 )
     {
         int v = 0;
         for( int i = 0; i < n_waves; i++ ) v += sh[threadIdx.x][i];
@@ -826,7 +832,7 @@ __global__ __launch_bounds__( 256 ) void cell_reduce_kernel( LaP P, const CellAr
             A.acc_dev[threadIdx.x] = v;
         }
         else if( v )
-            atomicAdd( &A.work[threadIdx.x], v );
+            atomicAdd( &A.work[slot], v );
     }
     if( gridDim.y == 1 )
         return;
@@ -835,10 +841,10 @@ __global__ __launch_bounds__( 256 ) void cell_reduce_kernel( LaP P, const CellAr
     if( threadIdx.x == 0 )
         last = atomicAdd( &A.work[5], 1 ) == (int)gridDim.y - 1;
     __syncthreads();
-    if( last && threadIdx.x < 5 )
+    if( last && threadIdx.x < 6 )
     {
         __threadfence();
-        const int v = atomicExch( &A.work[threadIdx.x], 0 );
+        const int v = atomicExch( &A.work[slot], 0 );
         A.acc[threadIdx.x] = v;
         A.acc_dev[threadIdx.x] = v;
         if( threadIdx.x == 0 )
@@ -1724,6 +1730,7 @@ struct MbtOpDev
 };
 #define MBT_LDS_LOAD 5   // mbtree_lds_kernel only: global accumulator prop_b -> LDS slot lds_b
 #define MBT_LDS_STORE 6  // LDS slot lds_b -> global accumulator prop_b
+#define MBT_NOP 7        // a queued FINISH whose frame a later list of the same launch finishes again (the later one wins): skipped
 
 __device__ __forceinline__ int prop_read( const int *p )
 {
@@ -1789,7 +1796,7 @@ __device__ __forceinline__ void mbt_propagate_mb( const MbtOpDev &o, int *ref0, 
 #define MBT_UNROLL 4
 #define MBT_WGS 4   // workgroups per list at most (x264hip.hip: mbt_wgs_per_list)
 #define MBT_THREADS 1024
-#define MBT_MAX_GROUPS 16
+#define MBT_MAX_GROUPS 48
 // The step lists of up to MBT_MAX_GROUPS macroblock_tree() calls, one after the other in the table; list g is steps [beg[g], beg[g+1])
 struct MbtGroups
 {
@@ -1870,7 +1877,7 @@ __global__ __launch_bounds__( 1024 ) void mbtree_kernel( LaP P, const MbtOpDev *
                 }
             }
         }
-        else
+        else if( o.type == 2 ) // (MBT_NOP: a FINISH a later list of the same launch overrides -- nothing to do)
         {
             for( int i = tid; i < n_mb; i += nthreads )
             {
@@ -1935,7 +1942,7 @@ __global__ __launch_bounds__( 256 ) void mbtree_level_kernel( LaP P, const MbtOp
                 mbt_propagate_mb( o, o.prop_p0, o.prop_p1, W, H, i, ic[u], lc[u], inv[u], in_cost[u], w0[u], w1[u] );
         }
     }
-    else
+    else if( o.type == 2 )
     {
 #pragma unroll
         for( int u = 0; u < MBT_UNROLL; u++ )

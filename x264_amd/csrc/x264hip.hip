@@ -16,6 +16,7 @@
 #include <math.h>
 #include <vector>
 #include <algorithm>
+#include <map>
 
 #include "x264hip.h"
 #include "device_common.h"
@@ -145,7 +146,7 @@ struct x264hip_ctx
     unsigned long long *stats_host = nullptr; // pinned [slots][2]
     // MB-tree: own stream, ring of pinned/device step tables
     hipStream_t stream2 = nullptr;
-    static const int MBT_RING = 32, MBT_CAP = 2048;
+    static const int MBT_RING = 16, MBT_CAP = 6144;
     MbtOpDev *mbt_host[32] = { nullptr }, *mbt_dev[32] = { nullptr };
     hipEvent_t mbt_done[32] = { nullptr };
     hipEvent_t ev_cross = nullptr, ev_mbt_last = nullptr;
@@ -162,7 +163,8 @@ struct x264hip_ctx
     static const int UP_EVS = 64;
     hipEvent_t up_ev[64] = { nullptr };
     int up_next = 0;
-    std::vector<int> mbt_q_finished;  // slots some queued list writes quantiser offsets of
+    std::vector<std::pair<int, int>> mbt_q_finished;  // (slot, step index in the ring entry) of the FINISH steps of the queued lists
+    std::map<int, std::pair<uint64_t, uint64_t>> flush_sites; // source line of an mbt_flush_at call -> (flushes of a non-empty queue, lists launched)
     int *prop_bank[MBT_MAX_GROUPS] = { nullptr }; // bank g > 0: [max_frames][n_mb] accumulators of list g of a launch (bank 0 = the slots' own)
     int mbt_bank_limit = MBT_MAX_GROUPS;          // lists per launch this context has memory for (lowered when a bank cannot be allocated)
     int desc_cap = 0;
@@ -368,6 +370,10 @@ extern "C" void x264hip_close( x264hip_ctx *ctx )
         for( int d0 = 0; d0 <= bf + 1; d0++ )
             for( int d1 = 0; d0 + d1 <= bf + 1; d1++ )
                 fprintf( stderr, " (%d,%d) %u/%u", d0, d1, ctx->cell_req[d0 * ns + d1], ctx->cell_spec[d0 * ns + d1] );
+        fprintf( stderr, "\n" );
+        fprintf( stderr, "x264hip MB-tree queue flushed at (source line: flushes, lists launched):" );
+        for( auto &kv : ctx->flush_sites )
+            fprintf( stderr, " %d: %llu, %llu;", kv.first, (unsigned long long)kv.second.first, (unsigned long long)kv.second.second );
         fprintf( stderr, "\n" );
     }
 #ifdef ME_PROFILE
@@ -583,13 +589,14 @@ extern "C" int x264hip_device_name( x264hip_ctx *ctx, char *buf, size_t cap )
 }
 
 static int mbt_flush( x264hip_ctx *ctx );
+static int mbt_flush_at( x264hip_ctx *ctx, int line );
 extern "C" int x264hip_synchronize( x264hip_ctx *ctx )
 {
     if( !ctx ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     {
-        int rc = mbt_flush( ctx ); // queued MB-tree lists are work the caller has handed over
+        int rc = mbt_flush_at( ctx, __LINE__ ); // queued MB-tree lists are work the caller has handed over
         if( rc ) return rc;
     }
     HIPCK( hipStreamSynchronize( ctx->stream ) );
@@ -601,7 +608,7 @@ extern "C" int x264hip_flush( x264hip_ctx *ctx )
     if( !ctx ) return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
-    return mbt_flush( ctx );
+    return mbt_flush_at( ctx, __LINE__ );
 }
 
 extern "C" int x264hip_geometry( x264hip_ctx *ctx, int *mb_w, int *mb_h, int *lowres_stride )
@@ -727,7 +734,7 @@ extern "C" int x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, 
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     FrameSlot &s = ctx->slots[slot];
     {
-        int rc = mbt_flush( ctx );
+        int rc = mbt_flush_at( ctx, __LINE__ );
         if( rc ) return rc;
     }
     if( ctx->mbt_pending )
@@ -791,7 +798,7 @@ extern "C" int x264hip_frame_put_batch_yuv( x264hip_ctx *ctx, int n, const int *
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     {
-        int rc = mbt_flush( ctx );
+        int rc = mbt_flush_at( ctx, __LINE__ );
         if( rc ) return rc;
     }
     if( ctx->mbt_pending )
@@ -1558,11 +1565,14 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
             fprintf( stderr, "hit b=%d d0=%d d1=%d ref1_ok=%d\n", b.frame_no, d0, d1, ref1_l0_valid );
         int r = batch_wait( ctx, e.batch );
         if( r ) return r;
-        if( intra_only )
+        if( intra_only && res[5] )
         {
             // the sums are known; the map still has to take the reference's 14-bit clamp (aliases the intra costs, which queued
-            // MB-tree lists read as they were when they were handed over)
-            int rf = mbt_flush( ctx );
+            // MB-tree lists read as they were when they were handed over).  res[5] = the frame's intra costs above 14 bits, counted with
+            // the sums (cell_reduce_kernel): none -- nearly every frame -- and the clamp is the identity: no launch, and above all no
+            // flush of the MB-tree queue, which this request used to cut into launches of one to six lists (one intra-only request per
+            // mini-GOP: a flush and a clamp launch per MB-tree call, profiles/r04_bench_kernel_stats.csv)
+            int rf = mbt_flush_at( ctx, __LINE__ );
             if( rf ) return rf;
             cell_p_kernel<<<dim3( ( ctx->n_mb + 255 ) / 256, 1 ), 256, 0, ctx->stream>>>( P, nullptr, A );
             HIPCK( hipGetLastError() );
@@ -1575,7 +1585,7 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
         {
             // a cell the caller asks for AGAIN may be one a queued MB-tree list reads (x264hip_mbtree queues lists and reads their inputs
             // when they are launched): the lists go first, then the map is rewritten
-            int rf = mbt_flush( ctx );
+            int rf = mbt_flush_at( ctx, __LINE__ );
             if( rf ) return rf;
         }
         if( !intra_only )
@@ -1713,6 +1723,16 @@ static int mbt_flush( x264hip_ctx *ctx )
     ctx->mbt_pending++;
     return X264HIP_OK;
 }
+// (X264HIP_TRACE_CLASSES: which call sites cut the MB-tree queue into launches, printed when the context closes)
+static int mbt_flush_at( x264hip_ctx *ctx, int line )
+{
+    if( ctx->mbt_q.n )
+    {
+        ctx->flush_sites[line].first++;
+        ctx->flush_sites[line].second += ctx->mbt_q.n;
+    }
+    return mbt_flush( ctx );
+}
 
 // the accumulator of (bank, slot)
 static int *mbt_bank_acc( x264hip_ctx *ctx, int bank, int slot )
@@ -1769,17 +1789,22 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
     }
     if( queued_form )
     {
-        // two lists of a launch must not write the offsets of the same frame (the later one has to win)
-        for( int i = 0; i < n; i++ )
-            if( ops[i].type == X264HIP_MBT_FINISH && std::find( ctx->mbt_q_finished.begin(), ctx->mbt_q_finished.end(), ops[i].slot_b ) != ctx->mbt_q_finished.end() )
-            {
-                int rc = mbt_flush( ctx );
-                if( rc ) return rc;
-                break;
-            }
+        // Two lists of a launch must not write the offsets of the same frame: the later one has to win.  Nothing can have read the
+        // earlier list's offsets in between (every reader launches the queue first), so its FINISH step is dead: it becomes a no-op.
+        // (Until round 5 the queue was launched instead -- 120 times per 1 900 frames of the bench clip, 5.5 lists per launch on
+        // average where 16 fit; profiles/r05_mbtree_forms.txt.)
+        if( ctx->mbt_q_ring >= 0 )
+            for( int i = 0; i < n; i++ )
+                if( ops[i].type == X264HIP_MBT_FINISH )
+                    for( auto &f : ctx->mbt_q_finished )
+                        if( f.first == ops[i].slot_b && f.second >= 0 )
+                        {
+                            ctx->mbt_host[ctx->mbt_q_ring][f.second].type = MBT_NOP;
+                            f.second = -1;
+                        }
         if( ctx->mbt_q.n >= max_groups || ctx->mbt_q.beg[ctx->mbt_q.n] + n > x264hip_ctx::MBT_CAP )
         {
-            int rc = mbt_flush( ctx );
+            int rc = mbt_flush_at( ctx, __LINE__ );
             if( rc ) return rc;
         }
         // the list's accumulator bank: bank 0 is the slots' own accumulators, the others are allocated when first used.  A context that cannot
@@ -1787,7 +1812,7 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
         // banks it has -- fewer lists side by side -- from then on
         if( ctx->mbt_q.n >= ctx->mbt_bank_limit )
         {
-            int rc = mbt_flush( ctx );
+            int rc = mbt_flush_at( ctx, __LINE__ );
             if( rc ) return rc;
         }
         int bank = ctx->mbt_q.n;
@@ -1796,7 +1821,7 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
             (void)hipGetLastError();
             ctx->prop_bank[bank] = nullptr;
             ctx->mbt_bank_limit = bank;
-            int rc = mbt_flush( ctx );
+            int rc = mbt_flush_at( ctx, __LINE__ );
             if( rc ) return rc;
             bank = 0;
         }
@@ -1837,7 +1862,7 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
                         d.mvq1 = o.dist_p1 > 0 ? b.mvq[1][o.dist_p1 - 1] : nullptr;
                     }
                     else
-                        ctx->mbt_q_finished.push_back( o.slot_b );
+                        ctx->mbt_q_finished.push_back( std::make_pair( o.slot_b, ctx->mbt_q.beg[bank] + k ) );
                 }
                 dh[k++] = d;
             }
@@ -1847,7 +1872,7 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
     }
     // the immediate form: behind everything queued, on the slots' own accumulators -- contents that live in a bank move home first
     {
-        int rc = mbt_flush( ctx );
+        int rc = mbt_flush_at( ctx, __LINE__ );
         if( rc ) return rc;
         for( int i = 0; i < n; i++ )
             for( int slot : { ops[i].slot_b, ops[i].slot_p0, ops[i].slot_p1 } )
@@ -2023,7 +2048,7 @@ extern "C" int x264hip_get_qp_offsets( x264hip_ctx *ctx, int slot, float *qp_off
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     {
-        int rc = mbt_flush( ctx );
+        int rc = mbt_flush_at( ctx, __LINE__ );
         if( rc ) return rc;
     }
     HIPCK( hipEventSynchronize( ctx->ev_ingest ) ); // f_qp_offset starts as the AQ offsets written at ingest (main stream)
@@ -2054,7 +2079,7 @@ extern "C" int x264hip_frame_cost_recalculate( x264hip_ctx *ctx, int slot_b, int
     }
     // f_qp_offset is written by the MB-tree stream: order this stream behind it
     {
-        int rc1 = mbt_flush( ctx );
+        int rc1 = mbt_flush_at( ctx, __LINE__ );
         if( rc1 ) return rc1;
     }
     if( ctx->mbt_pending )
@@ -2076,7 +2101,7 @@ extern "C" int x264hip_frame_add_quant_offsets( x264hip_ctx *ctx, int slot, cons
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     if( !ctx->p.aq_mode ) return X264HIP_OK; // the reference has no offset maps without AQ (frame.c:217-226)
     {
-        int rc = mbt_flush( ctx );
+        int rc = mbt_flush_at( ctx, __LINE__ );
         if( rc ) return rc;
     }
     FrameSlot &s = ctx->slots[slot];
@@ -2107,7 +2132,7 @@ extern "C" int x264hip_get_propagate_cost( x264hip_ctx *ctx, int slot, uint16_t 
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     {
-        int rc = mbt_flush( ctx );
+        int rc = mbt_flush_at( ctx, __LINE__ );
         if( rc ) return rc;
     }
     std::vector<int> tmp( ctx->n_mb );
