@@ -1650,7 +1650,10 @@ static int mbt_wgs_per_list( x264hip_ctx *ctx, int n_lists )
     static const int forced = getenv( "X264HIP_MBT_WGS" ) ? std::max( 1, std::min( 64, atoi( getenv( "X264HIP_MBT_WGS" ) ) ) ) : 0;
     if( forced ) return forced;
     const int contexts = std::max( 1, g_open_contexts[ctx->device & 63].load() );
-    const int share = std::max( 1, ctx->n_cu / contexts );
+    // never more than a quarter of the chip for the workgroups of one launch that wait for each other (with up to 48 lists per launch
+    // since round 5, four workgroups per list would hold 192 CUs at their barriers: a latency-form search launch beside them, whose
+    // waves also wait for each other, then cannot become resident -- seen once as an in-kernel timeout)
+    const int share = std::max( 1, std::min( ctx->n_cu / contexts, ctx->n_cu / 4 ) );
     const int by_work = std::max( 4, ( ctx->n_mb + 4095 ) / 4096 ); // 1080p 4, 4K 8, 8K 16
     return std::max( 1, std::min( std::min( share / std::max( 1, n_lists ), by_work ), 16 ) );
 }
