@@ -132,7 +132,13 @@ __device__ __forceinline__ void lowres_px4( const T *__restrict__ src, int src_s
     const T *r0 = src + (size_t)imin2( 2 * y, height - 1 ) * src_stride;
     const T *r1 = src + (size_t)imin2( 2 * y + 1, height - 1 ) * src_stride;
     const T *r2 = src + (size_t)imin2( 2 * y + 2, height - 1 ) * src_stride;
-    if( xb >= 0 && 2 * ( xb + 3 ) + 2 < width )
+    // A piece of four samples never straddles the picture's edge (the border is 32 wide, the picture a multiple of 8): a piece of the
+    // left / right border repeats sample 0 of the first / sample 3 of the last piece of its row (plane_expand_border, frame.c:535-554).
+    // (Until round 5 border pieces recomputed every sample from clamped source columns, 18 single-sample loads per piece, and a tile
+    // that touches the border -- a third of them at 1080p -- ran that path for the whole wave.)
+    const int xb_req = xb;
+    xb = iclip3( xb, 0, lw - 4 );
+    if( 2 * xb + 7 < width )
     {
         int a[9], b[9], c[9];
         T va[8], vb[8], vc[8];
@@ -141,7 +147,8 @@ __device__ __forceinline__ void lowres_px4( const T *__restrict__ src, int src_s
         __builtin_memcpy( vc, r2 + 2 * xb, 8 * sizeof( T ) );
 #pragma unroll
         for( int i = 0; i < 8; i++ ) { a[i] = va[i]; b[i] = vb[i]; c[i] = vc[i]; }
-        a[8] = r0[2 * xb + 8]; b[8] = r1[2 * xb + 8]; c[8] = r2[2 * xb + 8];
+        const int x8 = imin2( 2 * xb + 8, width - 1 ); // the column right of the picture is its last column again (mc.c:466-468)
+        a[8] = r0[x8]; b[8] = r1[x8]; c[8] = r2[x8];
         int t[9], u[9];
 #pragma unroll
         for( int i = 0; i < 9; i++ ) { t[i] = ( a[i] + b[i] + 1 ) >> 1; u[i] = ( b[i] + c[i] + 1 ) >> 1; }
@@ -166,6 +173,13 @@ __device__ __forceinline__ void lowres_px4( const T *__restrict__ src, int src_s
             o0[i] = (T)( ( t0 + t1 + 1 ) >> 1 ); oh[i] = (T)( ( t1 + t2 + 1 ) >> 1 );
             ov[i] = (T)( ( u0 + u1 + 1 ) >> 1 ); oc[i] = (T)( ( u1 + u2 + 1 ) >> 1 );
         }
+    }
+    if( xb_req != xb )
+    {
+        const int k = xb_req < 0 ? 0 : 3;
+        const T e0 = o0[k], eh = oh[k], ev = ov[k], ec = oc[k];
+#pragma unroll
+        for( int i = 0; i < 4; i++ ) { o0[i] = e0; oh[i] = eh; ov[i] = ev; oc[i] = ec; }
     }
 }
 template <typename T>
