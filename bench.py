@@ -590,14 +590,7 @@ def main():
     wl.close()
 
     window = None
-    if ( world > 1 and not args.no_extra ) or args.shard == "window":
-        try:
-            window = window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend)
-        except Exception as e:  # pragma: no cover
-            if args.shard == "window":
-                raise
-            window = {"error": repr(e)} if rank == 0 else None
-
+    res = None
     if rank == 0:
         bytes_per_search = algorithmic_bytes_per_search(cfg)
         achieved = (prof_searches * bytes_per_search / 1e9) / (prof_ms / 1e3) if prof_ms > 0 else 0.0
@@ -693,6 +686,35 @@ def main():
                 res["roofline_l1"] = l1_roofline(json.load(open(ipath)), solo if solo is not None else (prof_ms, prof_launches, prof_searches), cfg)
             except Exception as e:  # pragma: no cover
                 res["roofline_l1"] = {"error": str(e)}
+    # ---- N > 1: ONE stream over the ranks (BASELINE configs[3]) beside the GOP-segment figure.  The segment line above is complete at this
+    # point; the window shard runs a collective protocol over a communicator of its own, and a rank that dies or a transport that wedges
+    # would leave the others inside a collective.  A watchdog therefore bounds it: when it expires rank 0 prints the line it has (with
+    # the reason) and every rank leaves -- the driver gets its line whatever happens to the extra measurement.
+    if ( world > 1 and not args.no_extra ) or args.shard == "window":
+        import threading
+        finished = threading.Event()
+        limit = float(os.environ.get("X264HIP_BENCH_WINDOW_TIMEOUT", "300"))
+
+        def bail():
+            if finished.is_set():
+                return
+            if rank == 0:
+                res["window_shard_error"] = "the window-shard measurement did not finish within %.0f s (watchdog); the line is the GOP-segment measurement" % limit
+                print(json.dumps(res), flush=True)
+            os._exit(0 if args.shard != "window" else 4)
+        timer = threading.Timer(limit, bail)
+        timer.daemon = True
+        timer.start()
+        try:
+            window = window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend)
+        except Exception as e:  # pragma: no cover
+            if args.shard == "window":
+                raise
+            window = {"error": repr(e)} if rank == 0 else None
+        finished.set()
+        timer.cancel()
+
+    if rank == 0:
         if window is not None:
             res["window_shard"] = window
             if "error" in window and "value" not in window:
