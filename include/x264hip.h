@@ -208,6 +208,16 @@ int  x264hip_export_field( x264hip_ctx *ctx, int slot, int list, int dist_minus1
 int  x264hip_import_field( x264hip_ctx *ctx, int slot, int list, int dist_minus1, const void *src_dev );
 int  x264hip_field_classes( x264hip_ctx *ctx, unsigned *mask_l0, unsigned *mask_l1 );
 int  x264hip_cell_classes( x264hip_ctx *ctx, unsigned char *cell_class /* [(bframes+2) * (bframes+2)], index d0 * (bframes+2) + d1 */ );
+/* What the caller can say ahead of time about its decision flow: which cell classes (cell_allowed[d0 * (bframes + 2) + d1] != 0;
+ * NULL = all) and which field classes (bit d - 1 of mask_l0 / mask_l1 = distance d in list 0 / 1) it can ever ask for.  Classes
+ * outside are never speculated (x264hip_prefetch*, x264hip_spec_cells, x264hip_cell_classes, x264hip_field_classes); a request for
+ * one is still served, on demand, so a wrong statement costs time and never changes a result.  x264hip_lookahead_open states the
+ * classes of its own flow (slicetype.c:1062-1095 with B-pyramid: the middle frame of a run splits it into two halves, so a B-frame
+ * never sees two references further apart than half the longest run except as that middle frame). */
+int  x264hip_spec_classes( x264hip_ctx *ctx, const unsigned char *cell_allowed, unsigned mask_l0, unsigned mask_l1 );
+/* the requests per class so far -- field_req[list * (bframes + 1) + d - 1], cell_req[d0 * (bframes + 2) + d1] -- and the statement in force
+ * (any pointer may be NULL): what the tests hold x264hip_lookahead_open's statement against */
+int  x264hip_class_requests( x264hip_ctx *ctx, uint32_t *field_req, uint32_t *cell_req, unsigned char *cell_allowed, unsigned *field_allowed );
 typedef struct x264hip_cell_ref
 {
     int slot_b, slot_p0, slot_p1;   /* frame handles; dist_p0 == dist_p1 == 0: the frame's intra sums */

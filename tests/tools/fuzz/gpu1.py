@@ -61,6 +61,12 @@ def run(seed, n, big=False, verbose=True):
             dev = lib.Lookahead(cfg, max_frames=0 if paced else nf + 4)
             try:
                 outs = dev.run(frames, paced=paced, qp_offsets=True)
+                # what x264hip_lookahead_open said about its flow (x264hip_spec_classes) must hold: no request for a class it ruled out
+                fr, cr, ca, fa = dev.class_requests()
+                bf = cfg["bframes"]  # (validation may have lowered it, e.g. under a short key interval)
+                ruled_out = [(d0, d1) for d0 in range(bf + 2) for d1 in range(bf + 2) if cr[d0, d1] and not ca[d0, d1]]
+                ruled_out += [("L%d" % l, d + 1) for l in range(2) for d in range(bf + 1) if fr[l, d] and not (int(fa[l]) >> d) & 1]
+                assert not ruled_out, "requests for classes the lookahead ruled out: %s" % ruled_out
             finally:
                 dev.close()
             nb = cfg["bframes"] + 2

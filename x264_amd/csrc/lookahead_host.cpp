@@ -1193,6 +1193,26 @@ extern "C" int x264hip_lookahead_open( x264hip_lookahead **out, int device, cons
     rc = x264hip_lookahead_open_backend( out, &p, &be );
     if( rc ) { x264hip_close( ctx ); return rc; }
     ( *out )->L.ctx = ctx;
+    if( p.b_pyramid && p.dev.bframes > 1 )
+    {
+        // The cells this flow can ask for (add_bframe_costs, mbtree_ops and the costs ahead of time all split a run of B-frames at the
+        // same middle frame): between anchors `len` apart the middle frame sees ( len / 2, len - len / 2 ) and every other B-frame
+        // two references inside one half.  Everything else -- most of the triangle for long runs -- need never be speculated.
+        const int bf = p.dev.bframes, ns = bf + 2;
+        std::vector<unsigned char> ok( (size_t)ns * ns, 0 );
+        unsigned l1 = 0;
+        auto allow = [&]( int d0, int d1 ) { ok[d0 * ns + d1] = 1; if( d1 ) l1 |= 1u << ( d1 - 1 ); };
+        allow( 0, 0 );
+        for( int d = 1; d <= bf + 1; d++ ) allow( d, 0 );
+        for( int len = 2; len <= bf + 1; len++ )
+        {
+            const int h0 = len > 2 ? len / 2 : len, h1 = len > 2 ? len - len / 2 : len;
+            if( len > 2 ) allow( h0, h1 );
+            for( int k = 1; k < h0; k++ ) allow( k, h0 - k );
+            for( int k = 1; k < h1; k++ ) allow( k, h1 - k );
+        }
+        x264hip_spec_classes( ctx, ok.data(), ~0u, l1 );
+    }
     return X264HIP_OK;
 }
 

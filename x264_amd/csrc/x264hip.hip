@@ -213,6 +213,10 @@ struct x264hip_ctx
     uint32_t cell_spec[( X264HIP_BFRAME_MAX + 2 ) * ( X264HIP_BFRAME_MAX + 2 )] = { 0 };
     uint32_t n_requests = 0;
     static const uint32_t LEARN_REQUESTS = 400;
+    // ... and what the caller can say ahead of time about its flow (x264hip_spec_classes): classes outside these are never speculated
+    uint8_t cell_allowed[( X264HIP_BFRAME_MAX + 2 ) * ( X264HIP_BFRAME_MAX + 2 )];
+    x264hip_ctx() { memset( cell_allowed, 1, sizeof( cell_allowed ) ); }
+    uint32_t field_allowed[2] = { ~0u, ~0u };
     // speculation by position: hint of the caller, and per ( period, position ) key the number of frames that have come and gone and
     // how many of them asked for each field / cell class
     int hint_anchor = 0, hint_period = 0;
@@ -1301,6 +1305,7 @@ extern "C" int x264hip_prefetch_ex( x264hip_ctx *ctx, const int *slots, const in
             if( list && !bf ) continue;
             FrameSlot &b = ctx->slots[slots[i]];
             if( b.field_ready[list][dm1] || b.field_prefetched[list][dm1] ) continue;
+            if( !( ctx->field_allowed[list] >> dm1 & 1 ) ) continue;  // a class the caller has ruled out (x264hip_spec_classes)
             if( learned && !ctx->field_req[list][dm1] ) continue; // a class this caller never asks for
             if( learned && field_rate && (uint64_t)ctx->field_req[list][dm1] * 100 < field_rate * frames_seen ) continue; // ... or too rarely
             if( !pos_wants_field( b, list, dm1 ) ) continue;       // ... or hardly ever for a frame at this position
@@ -1342,6 +1347,7 @@ extern "C" int x264hip_prefetch_ex( x264hip_ctx *ctx, const int *slots, const in
             {
                 CellEntry &e = b.cells[d0 * nstride + d1];
                 if( e.valid || e.requested ) continue;
+                if( !ctx->cell_allowed[d0 * nstride + d1] ) continue;
                 if( learned && !ctx->cell_req[d0 * nstride + d1] ) continue;
                 if( learned && cell_rate && (uint64_t)ctx->cell_req[d0 * nstride + d1] * 100 < cell_rate * frames_seen ) continue;
                 if( !pos_wants_cell( b, d0 * nstride + d1 ) ) continue;
@@ -3592,7 +3598,7 @@ extern "C" int x264hip_cell_classes( x264hip_ctx *ctx, unsigned char *cell_class
         for( int d1 = 0; d0 + d1 <= bf + 1; d1++ )
         {
             const int idx = d0 * ns + d1;
-            if( learned && !ctx->cell_req[idx] ) continue;
+            if( !ctx->cell_allowed[idx] || ( learned && !ctx->cell_req[idx] ) ) continue;
             const uint32_t *rq = ctx->variant_req[idx];
             // B cells: 3 = both ways in one pass wherever the list-1 reference's field exists (what x264hip_prefetch does); X264HIP_NO_DUAL:
             // the variant asked for more often so far
@@ -3870,6 +3876,32 @@ extern "C" int x264hip_import_cell_map( x264hip_ctx *ctx, const x264hip_cell_ref
     return X264HIP_OK;
 }
 
+extern "C" int x264hip_spec_classes( x264hip_ctx *ctx, const unsigned char *cell_allowed, unsigned mask_l0, unsigned mask_l1 )
+{
+    if( !ctx ) return X264HIP_EINVAL;
+    static const bool off = getenv( "X264HIP_NO_STATIC_CLASSES" ) != nullptr; // A/B runs: learn everything from the requests
+    if( off ) return X264HIP_OK;
+    const int ns = ctx->p.bframes + 2;
+    if( cell_allowed ) memcpy( ctx->cell_allowed, cell_allowed, (size_t)ns * ns );
+    else memset( ctx->cell_allowed, 1, sizeof( ctx->cell_allowed ) );
+    ctx->field_allowed[0] = mask_l0; ctx->field_allowed[1] = mask_l1;
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_class_requests( x264hip_ctx *ctx, uint32_t *field_req, uint32_t *cell_req, unsigned char *cell_allowed, unsigned *field_allowed )
+{
+    if( !ctx ) return X264HIP_EINVAL;
+    const int ns = ctx->p.bframes + 2;
+    if( field_req )
+        for( int l = 0; l < 2; l++ )
+            for( int d = 0; d <= ctx->p.bframes; d++ )
+                field_req[l * ( ctx->p.bframes + 1 ) + d] = ctx->field_req[l][d];
+    if( cell_req ) memcpy( cell_req, ctx->cell_req, sizeof( uint32_t ) * ns * ns );
+    if( cell_allowed ) memcpy( cell_allowed, ctx->cell_allowed, (size_t)ns * ns );
+    if( field_allowed ) { field_allowed[0] = ctx->field_allowed[0]; field_allowed[1] = ctx->field_allowed[1]; }
+    return X264HIP_OK;
+}
+
 extern "C" int x264hip_field_classes( x264hip_ctx *ctx, unsigned *mask_l0, unsigned *mask_l1 )
 {
     if( !ctx || !mask_l0 || !mask_l1 ) return X264HIP_EINVAL;
@@ -3878,7 +3910,7 @@ extern "C" int x264hip_field_classes( x264hip_ctx *ctx, unsigned *mask_l0, unsig
     unsigned m[2] = { 0, 0 };
     for( int l = 0; l < 2; l++ )
         for( int d = 0; d <= ctx->p.bframes; d++ )
-            if( !learned || ctx->field_req[l][d] )
+            if( ( ctx->field_allowed[l] >> d & 1 ) && ( !learned || ctx->field_req[l][d] ) )
                 m[l] |= 1u << d;
     *mask_l0 = m[0]; *mask_l1 = m[1];
     return X264HIP_OK;

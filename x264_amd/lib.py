@@ -844,6 +844,16 @@ class Lookahead:
         _ck(self.L.x264hip_lookahead_stats(self.h, _p(out), 8), "lookahead_stats")
         return out
 
+    def class_requests(self):
+        """(field_req[2][bframes+1], cell_req[ns][ns], cell_allowed[ns][ns], field_allowed[2]) of the lookahead's device context
+        (x264hip_class_requests): the requests per class so far next to the statement x264hip_lookahead_open made about its flow"""
+        bf = self.cfg["bframes"]
+        ns = bf + 2
+        fr, cr = np.zeros((2, bf + 1), np.uint32), np.zeros((ns, ns), np.uint32)
+        ca, fa = np.zeros((ns, ns), np.uint8), np.zeros(2, np.uint32)
+        _ck(self.L.x264hip_class_requests(self.ctx_handle(), _p(fr), _p(cr), _p(ca), _p(fa)), "class_requests")
+        return fr, cr, ca, fa
+
     def run_frames(self, device_ptrs, stride=None, paced=True):
         """run() for device-resident luma frames with nothing but types and costs asked for, as ONE call (x264hip_lookahead_run_frames)"""
         n = len(device_ptrs)
