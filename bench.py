@@ -657,7 +657,7 @@ def main():
                          "note": "not a streaming kernel: with the chip full it is bound by vector instruction issue and the L1 tag rate together (roofline_issue, "
                                  "roofline_l1; instructions and line accesses per block search in profiles/search_issue.json); HBM is the roofline the metric names.  "
                                  "A launch that does not fill the chip is bound by its dependency chain and runs on the latency form of the search out of LDS "
-                                 "(me_team.h; DESIGN.md section 3.1)"},
+                                 "(me_latency.h; DESIGN.md section 3.1)"},
             "lookahead_stats": {"frame_cost_calls": int(la_stats[0]), "evaluations": int(la_stats[1]),
                                 "weights_analysed": int(la_stats[2]), "weights_kept": int(la_stats[3]),
                                 "device": {"searches": int(dev_counters[0]), "cell_requests": int(dev_counters[1]), "cell_hits": int(dev_counters[4]),

@@ -492,6 +492,18 @@ int  x264hip_pixel_fill( x264hip_ctx *ctx, x264hip_pixel_functions *pf );
 int  x264hip_mc_bind_handle( x264hip_ctx *ctx, const void *encoder_handle );
 void x264hip_mc_unbind( x264hip_ctx *ctx ); /* every binding of the context; done by x264hip_close as well */
 
+/* Test entry for x264_mc_functions_t.mc_luma / get_ref (common/mc.c:198-249) on the lowres planes: out[i] = the 8x8 block (64 pixels of
+ * the context's bit depth, row-major) of frame `slot` at lowres position (x, y) displaced by (mvx, mvy) quarter-pels, weighted by *w if
+ * w != NULL -- produced by the tap arithmetic every candidate of the search and cell kernels goes through (strip copy of the four
+ * half-pel planes).  tools/checkasm.c:1226-1290 sweeps the reference's mc_luma the same way; tests/test_gpu_parity.py does it here over
+ * all 16 phases, the picture's corners and the furthest displacements the padding allows.  EINVAL for a block that leaves the padded
+ * planes.  Host pointers; synchronous. */
+typedef struct x264hip_mc_probe
+{
+    int x, y, mvx, mvy;
+} x264hip_mc_probe;
+int  x264hip_mc_luma_probe( x264hip_ctx *ctx, int slot, int n, const x264hip_mc_probe *req, const x264hip_weight *w, void *out );
+
 /* timing of the most recent search launch in ms (HIP events on the context's stream) and counters */
 int  x264hip_last_search_ms( x264hip_ctx *ctx, float *ms, int *n_searches, int *n_blocks );
 int  x264hip_counters( x264hip_ctx *ctx, uint64_t *out, int n );

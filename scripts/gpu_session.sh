@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (through gpurun, from the repo root): bash scripts/gpu_session.sh <tag> <stage...>
-# stages: parity (search + lookahead parity tests), suite (whole GPU suite), ab (short bench runs: team kernel vs X264HIP_SEARCH=rows,
+# stages: parity (search + lookahead parity tests), suite (whole GPU suite), ab (short bench runs: default dispatch vs X264HIP_SEARCH=rows,
 # 8 / 1 contexts, batched and paced), prof (cycle breakdown of the search kernel from the -DME_PROFILE build), bench (default bench line),
 # stats (rocprofv3 kernel stats of the bench command), pmc (counter passes of the search kernel)
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -45,7 +45,7 @@ lat)
     done
   done ;;
 prof)
-  for E in "A=0" "X264HIP_SEARCH=rows" "X264HIP_SEARCH=team"; do
+  for E in "A=0" "X264HIP_SEARCH=rows"; do
     for B in "--inflight 1" "--inflight 1 --paced"; do
       env $E X264HIP_LIB=$GRAFT_REPO_ROOT/x264_amd/libx264hip_prof.so timeout 300 python bench.py $short $B > $out/prof.log 2>&1
       echo "== $E $B" | tee -a $out/summary.txt; grep -h "ME_PROFILE" $out/prof.log | tail -4 | tee -a $out/summary.txt

@@ -231,13 +231,12 @@ def _kernel_form_worker(env, q):
 
 
 def test_every_form_of_the_search_kernel_gives_the_same_lookahead():
-    """The three forms of the whole-frame motion search -- me_rows_kernel (strips through the L1), the team form and the latency form of the
-    search out of LDS (me_team.h) -- behind the same lookahead: types, cost cells and f_qp_offset must not depend on which of them a launch
-    was sent to.  The switches are read once per process, so every form runs in a process of its own."""
+    """The two forms of the whole-frame motion search -- me_rows_kernel (strips through the L1) and the latency form out of LDS
+    (me_latency.h) -- behind the same lookahead: types, cost cells and f_qp_offset must not depend on which of them a launch was sent to.  The switches are read once per process, so every form runs in a process of its own."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     got = {}
-    for name, env in (("default", {}), ("rows", {"X264HIP_SEARCH": "rows"}), ("team", {"X264HIP_SEARCH": "team", "X264HIP_LAT_WAVES": "0"}),
+    for name, env in (("default", {}), ("rows", {"X264HIP_SEARCH": "rows"}),
                       ("latency", {"X264HIP_LAT_WAVES": "1000000"}), ("split ingest", {"X264HIP_INGEST": "split"})):
         q = ctx.Queue()
         p = ctx.Process(target=_kernel_form_worker, args=(env, q))
@@ -245,7 +244,7 @@ def test_every_form_of_the_search_kernel_gives_the_same_lookahead():
         got[name] = q.get(timeout=600)
         p.join(timeout=120)
         assert p.exitcode == 0, name
-    for name in ("rows", "team", "latency", "split ingest"):  # the last: planes + strip copy from two kernels instead of lowres_tiles_kernel
+    for name in ("rows", "latency", "split ingest"):  # the last: planes + strip copy from two kernels instead of lowres_tiles_kernel
         assert got[name] == got["default"], name
 
 

@@ -132,6 +132,53 @@ def test_weighted_search(cfgname):
         ctx.close()
 
 
+@pytest.mark.parametrize("depth", [8, 10])
+def test_mc_luma_all_phases_and_edges(depth):
+    """x264_mc_functions_t.mc_luma / get_ref on the lowres planes (common/mc.c:198-249), swept the way tools/checkasm.c:1226-1290 sweeps
+    the reference's: all 16 quarter-pel phases x full-pel displacements up to the furthest the 32-sample padding allows, for blocks in
+    the picture's corners, on its edges and inside, unweighted and under four weights (denominator 0, rounding, negative offset, clip at
+    both ends) -- the device's tap arithmetic over the strip copy (what every candidate of the search and cell kernels reads) against
+    the oracle's mc_luma over the oracle's own planes."""
+    import ctypes as C
+    W, H = 208, 112  # lowres 104 x 56 -> 13 x 7 blocks: the strip copy's last strips and the bottom rows are reached
+    frames = clip("fastpan", W, H, 2, depth)
+    cfgname = "hex_10bit" if depth == 10 else "hex_r4"
+    o, cfg, ctx = _mk(*CONFIGS[cfgname], W, H)
+    try:
+        ctx.frame_put(0, frames[1])
+        pl = o.lowres_init(cfg, frames[1])
+        W8, H8 = 8 * cfg.mb_w, 8 * cfg.mb_h
+        reqs = []
+        for (x, y) in ((0, 0), (W8 - 8, 0), (0, H8 - 8), (W8 - 8, H8 - 8), (W8 // 2 - 3, H8 // 2 + 1), (8, H8 - 8), (W8 - 8, 16), (5, 3)):
+            # full-pel displacements: none, one either way, the reference's own limit (12 samples outside, slicetype.c:585-588) and the
+            # last position inside the padding (the quarter-pel partner reads one sample / one row further)
+            xs = sorted({0, -1, 1, -x - 12, W8 - 8 - x + 12, -x - PAD, W8 + PAD - 9 - x})
+            ys = sorted({0, -1, 1, -y - 12, H8 - 8 - y + 12, -y - PAD, H8 + PAD - 9 - y})
+            for fy in ys:
+                for fx in xs:
+                    for ph in range(16):
+                        reqs.append((x, y, 4 * fx + (ph & 3), 4 * fy + (ph >> 2)))
+        reqs = np.array(reqs, np.int32)
+        pp = o._plane_ptrs(pl)
+        mc = o.f("mc_luma")
+        for wt in (None, (1, 55, 6, 3), (1, 100, 5, -20), (1, 3, 0, -1), (1, 127, 7, 127)):
+            got = ctx.mc_luma_probe(0, reqs, wt)
+            w = Weight(*wt) if wt else None
+            want = np.zeros_like(got)
+            blk = np.zeros((8, 8), o.dtype)
+            for i, (x, y, mvx, mvy) in enumerate(reqs):
+                org = (C.c_void_p * 4)(*[pp[k] + (int(y) * cfg.stride + int(x)) * o.isz for k in range(4)])
+                mc(C.c_void_p(blk.ctypes.data), 8, org, cfg.stride, int(mvx), int(mvy), 8, 8, C.byref(w) if w else None)
+                want[i] = blk
+            bad = np.nonzero((got != want).reshape(len(reqs), -1).any(axis=1))[0]
+            assert not len(bad), (wt, len(bad), reqs[bad[:4]].tolist())
+        # a block that leaves the padded planes is refused
+        with pytest.raises(Exception):
+            ctx.mc_luma_probe(0, np.array([[0, 0, 4 * (-PAD - 1), 0]], np.int32))
+    finally:
+        ctx.close()
+
+
 def test_prefetch_does_not_change_results():
     frames = clip("fastpan", 176, 144, 4)
     o, cfg, ctx = _mk(*CONFIGS["hex_r4"], 176, 144)

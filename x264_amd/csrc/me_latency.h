@@ -1,21 +1,21 @@
-// me_team.h -- the lookahead motion search of whole frames on gfx950, searched out of LDS: a wave64 is a TEAM of up to eight searches
-// that read the SAME reference frame, one 8x8 block per 8-lane group, one block row (8 samples) per lane; the wave walks ONE block row
+// me_latency.h -- the LATENCY form of the lookahead motion search on gfx950, searched out of LDS: a wave64 holds ONE 8x8 block of ONE
+// search, lane group g (lanes 8g .. 8g+7) costs candidate g of a set, one block row (8 samples) per lane; the wave walks ONE block row
 // of the picture from right to left and keeps the reference window of that row -- the four half-pel planes, +-8 samples around the
 // block -- in wave-private LDS, filled one 8-column strip ahead by LDS-DMA (global_load_lds_dwordx4), so that the dependent rounds of a
-// block search (me_logic.h: load -> reduce -> choose, ~8 per block) are LDS round trips instead of L1 / L2 round trips.
+// block search (me_logic.h: load -> reduce -> choose, ~8 per block) are LDS round trips instead of L1 / L2 round trips.  It serves the
+// launches that cannot fill the chip (x264hip.hip launch_searches_t): those are as long as their dependency chain of W + 2 (H - 1)
+// block searches whatever their width; everything larger goes to me_rows_kernel (me_search.h).
 //
 // Behaviour follows the reference's slicetype_mb_cost search part (encoder/slicetype.c:654-709) over x264_me_search_ref
-// (encoder/me.c:182-420,774-798, DIA and HEX) + refine_subpel (me.c:865-992); the decision logic is me_logic.h, the candidate-set
-// evaluation across the lanes of a group is me_search.h's (LaneSlots, reduce_slots, min_slots).
+// (encoder/me.c:182-420,774-798, DIA and HEX) + refine_subpel (me.c:865-992); the decision logic is me_logic.h.
 //
 // Work decomposition.  A search (source frame, reference frame, list, distance) is a W x H field of 8x8 blocks scanned from the
-// bottom right; block (x, y) takes its predictors from (x+1, y) and (x-1..x+1, y+1).  The searches of a launch are sorted by
-// reference frame and cut into teams of at most eight; wave (team, y) runs block row y of the team's searches in lock step: in step
-// t every group searches block x = W-1-t of ITS search, so the block position, the vector limits and the window are wave-uniform
-// (scalar) and one window serves eight searches.  Rows are claimed bottom-up through ticket counters; row y takes the vectors of row
-// y+1 from memory (self-validating 8-byte granules { mv, tag }, sc1 stores / L1-bypassing loads, one new granule per step and search,
-// requested a step ahead), so it trails the row below by two blocks plus one hand-off; the wave a row depends on always holds an
-// earlier ticket and is running or done: the waits cannot deadlock whatever the dispatch order.  W steps per wave.
+// bottom right; block (x, y) takes its predictors from (x+1, y) and (x-1..x+1, y+1).  Wave (search, y) runs block row y: in step t it
+// searches block x = W-1-t, so the block position, the vector limits, the window AND the decisions between two candidate sets are
+// wave-uniform (scalar).  Rows are claimed bottom-up through ticket counters; row y takes the vectors of row y+1 from memory
+// (self-validating 8-byte granules { mv, tag }, sc1 stores / L1-bypassing loads, one new granule per step, requested a step ahead), so
+// it trails the row below by two blocks plus one hand-off; the wave a row depends on always holds an earlier ticket and is running or
+// done: the waits cannot deadlock whatever the dispatch order.  W steps per wave.
 //
 // The window (WIN_*).  The reference's strip copy (strip_layout.h: strip k = columns 8k .. 8k+15 of every row, 16 samples per row)
 // is mirrored piece by piece: an LDS slot holds one strip column of the window -- rows Y0-8 .. Y0+16 of the NP planes, 16 samples
@@ -24,22 +24,18 @@
 // DMA lanes write it (lane i -> byte 16 i), the lanes pick their source rows.  8 samples starting at ANY column of the window (and
 // the quarter-pel partner one column / one row further) lie inside one 16-sample row piece: a tap is read as the three (8-bit) / five
 // (16-bit) aligned dwords that cover it and shifted into place with v_alignbyte (unaligned wide DS reads are replayed at 64 cycles).
-// Candidates outside the window (|mv| > 8 full samples in x or y) take the whole set through the global strip copy instead
-// (compact loop, same arithmetic): results do not depend on the window.
+// Candidates outside the window (|mv| > 8 full samples in x or y) are read from the global strip copy instead (same arithmetic):
+// results do not depend on the window.
+//
+// (Round 4 also had a throughput form on this window -- eight searches of one reference per wave -- measured slower than
+// me_rows_kernel at every launch size, experiments/README.md; it was removed in round 5.)
 #pragma once
-#include <type_traits>
 #include "me_search.h"
 
-#define TEAM_MAX 8
 #define WIN_R 8
 #define WIN_ROWS ( 8 + 2 * WIN_R + 1 ) // block rows + reach above and below + the quarter-pel partner row
 #define WIN_RING 4
-#define TEAM_TAB_HALF 512
-
-struct TeamDesc
-{
-    int first, n; // searches [first, first + n) of the launch's descriptor table read one reference
-};
+#define WIN_TAB_HALF 512
 
 template <typename T, int NP>
 struct WinGeo
@@ -102,220 +98,14 @@ __device__ __forceinline__ Px8 win_px8( const unsigned char *lds, int v, int row
     return r;
 }
 
-#define TEAM_BAD ( (int)0x80000000 )
-#define TEAM_NONE ( (int)0x80000000 ) // no packed vector looks like this (mvy = -32768)
-
-// The evaluator of me_logic.h on the team geometry: candidate sets across the 8 lanes of a group (me_search.h), samples out of the window.
-template <typename T, int LDS_TAB, int WEIGHTED>
-struct TeamEval
-{
-    static constexpr int NP = WEIGHTED ? 5 : 4;
-    typedef WinGeo<T, NP> G;
-    const unsigned char *win;  // the wave's window ring
-    const uint16_t *lds_tab;   // the wave's window of the mv cost table: entry TEAM_TAB_HALF + d is the cost of difference d
-    const T *sbase;            // wave-uniform: strips of the reference frame's four planes (unweighted)
-    const T *wsbase;           // group-uniform: strips read by full-pel candidates (weighted copy of plane 0, or sbase)
-    const uint16_t *tab;       // wave-uniform: first entry of the cost_mv table in memory
-    int plane_elems, strip_elems, pixel_max;
-    int fpelcmp_satd;
-    WtD wt;
-    int cx0, row16;            // wave-uniform: padded column of the block, strip-row offset of the block's row 0, at zero displacement
-    int tab_x, tab_y;
-    Px8 f;                     // this lane's 8 source pixels
-    LaneSlots S;
-    int rowb;                  // this lane's row of the block in window bytes
-
-    __device__ __forceinline__ int bits( int qx, int qy ) const
-    {
-        if( LDS_TAB )
-            return lds_tab[qx + tab_x] + lds_tab[qy + tab_y];
-        return gload_u16( tab, 2u * (unsigned)( qx + tab_x ) ) + gload_u16( tab, 2u * (unsigned)( qy + tab_y ) );
-    }
-    // LDS byte address of the sample of plane p at full-sample displacement (x, y) from the block's top left sample (row 0 of the block)
-    __device__ __forceinline__ int win_addr( int p, int x, int y ) const
-    {
-        const int c = cx0 + x;
-        return mad24( ( c >> 3 ) & ( WIN_RING - 1 ), G::SLOTB, mad24( mad24( p, WIN_ROWS, y + WIN_R ), G::ROWB, ( c & 7 ) * G::E ) );
-    }
-    static __device__ __forceinline__ bool in_window( int x, int y )
-    {
-        return (unsigned)( x + WIN_R ) <= 2u * WIN_R && (unsigned)( y + WIN_R ) <= 2u * WIN_R;
-    }
-    template <int N>
-    __device__ __forceinline__ int pack_min( int total, bool ok ) const
-    {
-        const int k = N <= 4 ? ( S.slot & 3 ) : S.slot;
-        return min_slots<N>( ok && k < N ? ( total << 3 ) | k : ME_PACK_MAX );
-    }
-    // total of the candidate in this lane's slot, candidates one after the other (the path of sets that leave the window; also the
-    // reference form of the unrolled paths): v = this lane's own candidate's offset(s) into the global strips
-    template <int N, int QPEL>
-    __device__ __forceinline__ int slow_totals( int oa, int ob, int use_satd ) const
-    {
-        const int myslot = N <= 4 ? ( S.slot & 3 ) : S.slot;
-        int total = 0;
-#pragma nounroll
-        for( int j = 0; j < N; j++ )
-        {
-            const int src = S.bp0 + 4 * ( j < 4 ? j : 11 - j );
-            const int ta = __builtin_amdgcn_ds_bpermute( src, oa );
-            Px8 r;
-            if( QPEL )
-            {
-                const int tb = __builtin_amdgcn_ds_bpermute( src, ob );
-                const Px8 a = load_px8_at( sbase, ta + S.row16 ), b = load_px8_at( sbase, tb + S.row16 );
-                r.lo = avg_px4( a.lo, b.lo, (const T *)nullptr ); r.hi = avg_px4( a.hi, b.hi, (const T *)nullptr );
-                if( WEIGHTED )
-                {
-                    r.lo = weight_px4<T>( r.lo, wt, pixel_max ); r.hi = weight_px4<T>( r.hi, wt, pixel_max );
-                }
-            }
-            else
-                r = load_px8_at( WEIGHTED ? wsbase : sbase, ta + S.row16 );
-            const int c = reduce8( block_partial8<T>( f, r, use_satd ) );
-            if( myslot == j )
-                total = c;
-        }
-        return total;
-    }
-    template <int N, class GEN>
-    __device__ __forceinline__ int fpel_set( GEN gen ) const
-    {
-        const int slot = N <= 4 ? ( S.slot & 3 ) : S.slot, k = imin2( slot, N - 1 );
-        int x = 0, y = 0;
-        bool ok = false, wb = true;
-        gen( k, x, y, ok, wb );
-        const int b = wb ? bits( 4 * x, 4 * y ) : 0;
-        const int v = in_window( x, y ) ? win_addr( WEIGHTED ? 4 : 0, x, y ) : TEAM_BAD;
-        int total;
-        int t[N];
-        t[0] = from_slot<0>( S, v );
-        if constexpr( N > 1 ) t[1] = from_slot<1>( S, v );
-        if constexpr( N > 2 ) t[2] = from_slot<2>( S, v );
-        if constexpr( N > 3 ) t[3] = from_slot<3>( S, v );
-        if constexpr( N > 4 ) t[4] = from_slot<4>( S, v );
-        if constexpr( N > 5 ) t[5] = from_slot<5>( S, v );
-        if constexpr( N > 6 ) t[6] = from_slot<6>( S, v );
-        if constexpr( N > 7 ) t[7] = from_slot<7>( S, v );
-        int any_bad = t[0];
-#pragma unroll
-        for( int j = 1; j < N; j++ )
-            any_bad |= t[j];
-        if( __builtin_amdgcn_ballot_w64( any_bad < 0 ) == 0ull )
-        {
-            Px8 r[N];
-#pragma unroll
-            for( int j = 0; j < N; j++ )
-                r[j] = win_px8( win, t[j], rowb, (const T *)nullptr );
-            int c[N];
-#pragma unroll
-            for( int j = 0; j < N; j++ )
-                c[j] = block_partial8<T>( f, r[j], fpelcmp_satd );
-            total = reduce_slots<N>( S, c );
-        }
-        else
-            total = slow_totals<N, 0>( strip_off( cx0 + x, row16 + ( y << 4 ), strip_elems ), 0, fpelcmp_satd );
-        if( fpelcmp_satd ) total >>= 1;
-        return pack_min<N>( total + b, ok );
-    }
-    template <int N, class GEN>
-    __device__ __forceinline__ bool more_than_first( GEN ) const { return true; } // a set across the lanes costs the same whatever its size
-    template <int N, class GEN>
-    __device__ __forceinline__ int qpel_set( int use_satd, GEN gen, int &cost0 ) const
-    {
-        const int slot = N <= 4 ? ( S.slot & 3 ) : S.slot, k = imin2( slot, N - 1 );
-        int x = 0, y = 0;
-        bool ok = false, wb = true;
-        gen( k, x, y, ok, wb );
-        const int b = wb ? bits( x, y ) : 0;
-        // the two taps (strip_layout.h qpel_taps): plane pa at ( fx, fy + (fy == 3) ), plane pb at ( fx + (fx == 3), fy )
-        const int fx = x & 3, fy = y & 3, ix = x >> 2, iy = y >> 2;
-        const int sh = 2 * ( fx | ( fy << 2 ) );
-        const int pa = (int)( ( 0x54FE5454u >> sh ) & 3u ), pb = (int)( ( 0xBABABA10u >> sh ) & 3u );
-        const bool inw = in_window( ix, iy );
-        const int va = inw ? win_addr( pa, ix, iy + ( fy == 3 ) ) : TEAM_BAD;
-        const int vb = inw ? win_addr( pb, ix + ( fx == 3 ), iy ) : TEAM_BAD;
-        int ta[N], tb[N];
-        ta[0] = from_slot<0>( S, va ); tb[0] = from_slot<0>( S, vb );
-        if constexpr( N > 1 ) { ta[1] = from_slot<1>( S, va ); tb[1] = from_slot<1>( S, vb ); }
-        if constexpr( N > 2 ) { ta[2] = from_slot<2>( S, va ); tb[2] = from_slot<2>( S, vb ); }
-        if constexpr( N > 3 ) { ta[3] = from_slot<3>( S, va ); tb[3] = from_slot<3>( S, vb ); }
-        if constexpr( N > 4 ) { ta[4] = from_slot<4>( S, va ); tb[4] = from_slot<4>( S, vb ); }
-        if constexpr( N > 5 ) { ta[5] = from_slot<5>( S, va ); tb[5] = from_slot<5>( S, vb ); }
-        if constexpr( N > 6 ) { ta[6] = from_slot<6>( S, va ); tb[6] = from_slot<6>( S, vb ); }
-        if constexpr( N > 7 ) { ta[7] = from_slot<7>( S, va ); tb[7] = from_slot<7>( S, vb ); }
-        int any_bad = ta[0];
-#pragma unroll
-        for( int j = 1; j < N; j++ )
-            any_bad |= ta[j];
-        int total;
-        if( __builtin_amdgcn_ballot_w64( any_bad < 0 ) == 0ull )
-        {
-            int c[N];
-            Px8 pa[N], pb[N]; // every read of the set is issued before anything waits (see GroupEval::qpel_set)
-#pragma unroll
-            for( int j = 0; j < N; j++ )
-                pa[j] = win_px8( win, ta[j], rowb, (const T *)nullptr );
-#pragma unroll
-            for( int j = 0; j < N; j++ )
-                pb[j] = win_px8( win, tb[j], rowb, (const T *)nullptr );
-#pragma unroll
-            for( int j = 0; j < N; j++ )
-            {
-                const Px8 a = pa[j], bb = pb[j];
-                Px8 r;
-                r.lo = avg_px4( a.lo, bb.lo, (const T *)nullptr ); r.hi = avg_px4( a.hi, bb.hi, (const T *)nullptr );
-                if( WEIGHTED )
-                {
-                    r.lo = weight_px4<T>( r.lo, wt, pixel_max ); r.hi = weight_px4<T>( r.hi, wt, pixel_max );
-                }
-                c[j] = block_partial8<T>( f, r, use_satd );
-            }
-            total = reduce_slots<N>( S, c );
-        }
-        else
-        {
-            int oa, ob;
-            strip_layout::qpel_taps( plane_elems, strip_off( cx0 + ix, row16 + ( iy << 4 ), strip_elems ), x, y, oa, ob );
-            total = slow_totals<N, 1>( oa, ob, use_satd );
-        }
-        if( use_satd ) total >>= 1;
-        total += b;
-        cost0 = from_slot<0>( S, total );
-        return pack_min<N>( total, ok );
-    }
-    // me_logic.h's shortcut for the quarter-pel diamond at a half-pel position: the window serves the ten taps as they are
-    __device__ __forceinline__ int qpel_star5( int use_satd, int mvx, int mvy, bool inside ) const
-    {
-        int c0;
-        return qpel_set<5>( use_satd, [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
-            const bool moved = k > 0 && inside;
-            x = moved ? mvx + melogic::dia_dx( k - 1 ) : mvx; y = moved ? mvy + melogic::dia_dy( k - 1 ) : mvy;
-            ok = k == 0 || inside; wb = true;
-        }, c0 );
-    }
-    __device__ __forceinline__ bool any( bool c ) const { return __builtin_amdgcn_ballot_w64( c ) != 0ull; }
-#ifdef ME_PROFILE
-    unsigned long long pf_last;
-    unsigned pf_phase[5];
-    int pf_kept, pf_single_start, pf_total_start, pf_single_hpel;
-    __device__ __forceinline__ void mark( int k )
-    {
-        const unsigned long long now = __builtin_amdgcn_s_memtime();
-        if( k ) pf_phase[k] += (unsigned)( now - pf_last );
-        pf_last = now;
-    }
-#endif
-};
+#define WIN_NONE ( (int)0x80000000 ) // no packed vector looks like this (mvy = -32768)
 
 // ---- one search per wave: the candidates of a set across the eight lane groups ---------------------------------------------------------
-// The latency form of the same search (me_team_kernel<.., LAT = 1>): the wave holds ONE block, group g (lanes 8g .. 8g+7) costs
-// candidate g of a set -- lane = one row of the candidate, a group sum is three DPP steps, the cheapest candidate a packed minimum over
-// the groups (two row broadcasts) moved to a scalar register -- so a set of up to eight candidates is ONE pass of ~45 instructions
-// whatever its size, and everything between two sets (the decision logic of me_logic.h) is wave-uniform and runs on the scalar unit.
-// A block search is then ~400 instructions instead of ~1 900 for eight blocks side by side: a fifth of the latency per block at
-// five times the instructions per block.  Used for launches that cannot fill the chip anyway (x264hip.hip launch_searches_t): there
-// the length of the dependency chain W + 2 (H - 1) blocks is what the caller waits for.
+// The evaluator of me_logic.h on this geometry: lane = one row of candidate (lane >> 3), a group sum is three DPP steps, the cheapest
+// candidate a packed minimum over the groups (two row broadcasts) moved to a scalar register -- so a set of up to eight candidates is
+// ONE pass of ~45 instructions whatever its size, and everything between two sets (the decision logic of me_logic.h) is wave-uniform
+// and runs on the scalar unit.  A block search is then ~400 instructions instead of ~1 900 for eight blocks side by side
+// (me_rows_kernel): a fifth of the latency per block at five times the instructions per block.
 #define DPP_ROW_ROR8_ 0x128
 #define DPP_ROW_BCAST15 0x142
 #define DPP_ROW_BCAST31 0x143
@@ -442,11 +232,7 @@ struct WaveEval
 #endif
 };
 
-template <typename T, int A, int B> __device__ __forceinline__ void set_grp( WaveEval<T, A, B> &ev, int g ) { ev.grp = g; }
-template <typename T, int A, int B> __device__ __forceinline__ void set_grp( TeamEval<T, A, B> &, int ) {}
-
-// MODE / WEIGHTED as in me_rows_kernel (me_search.h).  Q.base[] counts TEAMS.  LAT: one search per wave, the candidates of a set across the
-// groups (WaveEval); the team table then holds one team per search.
+// MODE / WEIGHTED as in me_rows_kernel (me_search.h).  Q.base[] counts searches.
 // Block rows (waves) per workgroup of the latency form.  RW > 1 hands vectors from row to row through LDS inside a workgroup; measured with
 // RW = 4 (round 4, 1080p, launches of 24 searches): launch 1.024 ms against 1.019 ms, wait for the row below 2 660 against 2 380 cycles per
 // step -- what a row waits for is the block below-left being SEARCHED (the spread of the step times along the dependency chain), not the
@@ -454,10 +240,10 @@ template <typename T, int A, int B> __device__ __forceinline__ void set_grp( Tea
 #ifndef ME_LAT_ROWS
 #define ME_LAT_ROWS 1
 #endif
-#define TEAM_HAND_W 512 // widest row (blocks) handed over through LDS inside a workgroup (8K pictures: 480)
-template <typename T, int HEX, int MODE, int WEIGHTED, int LAT, int RW>
-__global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_team_kernel( LaP P, const SearchDesc<T> *descs, const TeamDesc *teams, MeQueues Q,
-                                                                       unsigned *tickets /* [ME_QUEUES * ME_QUEUE_STRIDE] */, unsigned *err_host /* pinned sticky timeout flag */,
+#define WIN_HAND_W 512 // widest row (blocks) handed over through LDS inside a workgroup (8K pictures: 480)
+template <typename T, int HEX, int MODE, int WEIGHTED, int RW>
+__global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_latency_kernel( LaP P, const SearchDesc<T> *descs, MeQueues Q,
+                                                                          unsigned *tickets /* [ME_QUEUES * ME_QUEUE_STRIDE] */, unsigned *err_host /* pinned sticky timeout flag */,
                                                                        unsigned spin_limit, unsigned long long *prof /* ME_PROFILE builds: cycle accumulators, else unused */ )
 {
     constexpr int NP = WEIGHTED ? 5 : 4;
@@ -470,7 +256,7 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_team_kernel( LaP P
 #define PF_NOW() __builtin_amdgcn_s_memtime()
 #endif
     const int W = P.mb_w, H = P.mb_h;
-    // RW > 1: a workgroup is RW waves on RW consecutive block rows of one team (wave w on the row w above wave 0's): row to row hand-offs
+    // RW > 1: a workgroup is RW waves on RW consecutive block rows of one search (wave w on the row w above wave 0's): row to row hand-offs
     // inside the workgroup go through LDS (a few hundred cycles instead of a round trip to memory), only wave 0 waits for another workgroup
     const int wv = RW > 1 ? __builtin_amdgcn_readfirstlane( (int)( threadIdx.x >> 6 ) ) : 0;
     // Every wave reports its exit on a second counter; the last one out clears the tickets for the next launch on this stream.
@@ -482,13 +268,13 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_team_kernel( LaP P
             atomicExch( &tickets[1], 0u );
         }
     };
-    const int n_bands = ( H + RW - 1 ) / RW; // tickets per team: one per workgroup
+    const int n_bands = ( H + RW - 1 ) / RW; // tickets per search: one per workgroup
     __shared__ int ticket_sh[2];
-    int j = 0, tm = -1;
+    int j = 0, si = -1;
     if( wv == 0 )
     {
         const int home = xcc_id();
-        for( int k = 0; k < ME_QUEUES && tm < 0; k++ )
+        for( int k = 0; k < ME_QUEUES && si < 0; k++ )
         {
             const int q = ( home + k ) & ( ME_QUEUES - 1 );
             const int n_q = Q.base[q + 1] - Q.base[q];
@@ -501,55 +287,49 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_team_kernel( LaP P
             if( t < (unsigned)( n_q * n_bands ) )
             {
                 j = t / n_q;
-                tm = Q.base[q] + ( t - j * n_q );
+                si = Q.base[q] + ( t - j * n_q );
             }
         }
-        if( RW > 1 && lane == 0 ) { ticket_sh[0] = j; ticket_sh[1] = tm; }
+        if( RW > 1 && lane == 0 ) { ticket_sh[0] = j; ticket_sh[1] = si; }
     }
     if( RW > 1 )
     {
         __syncthreads();
-        j = __builtin_amdgcn_readfirstlane( ticket_sh[0] ); tm = __builtin_amdgcn_readfirstlane( ticket_sh[1] );
+        j = __builtin_amdgcn_readfirstlane( ticket_sh[0] ); si = __builtin_amdgcn_readfirstlane( ticket_sh[1] );
     }
-    if( tm < 0 )
+    if( si < 0 )
     {
         leave();
         return;
     }
-    TeamDesc TD = teams[tm];
-    TD.first = __builtin_amdgcn_readfirstlane( TD.first ); TD.n = __builtin_amdgcn_readfirstlane( TD.n );
     const int by = H - 1 - ( RW * j + wv ); // this wave's block row (scalar); above the picture: nothing to do for this wave
     const bool idle = by < 0;
     const int g = lane >> 3;
-    const bool live = LAT || g < TD.n;
-    const SearchDesc<T> *dp = descs + TD.first + ( !LAT && live ? g : 0 );
-    // the lane that talks to memory for its block / the lanes that keep its costs
-    const bool leader = LAT ? lane == 0 : ( lane & 7 ) == 0;
-    const int cost_lane = LAT ? lane : ( lane & 7 );
-    // per group: the search's own buffers; wave-uniform: the reference
+    const SearchDesc<T> *dp = descs + si;
+    const bool leader = lane == 0; // the lane that talks to memory for the block; lanes 0..3 keep its costs
     const T *fbase = dp->fenc0;
     AS_GLOBAL unsigned long long *mvq = (AS_GLOBAL unsigned long long *)dp->mvq;
     AS_GLOBAL int *costs = (AS_GLOBAL int *)dp->costs;
     const unsigned tag = dp->tag;
-    const WtD wt = descs[TD.first].wt;          // a team shares reference AND weight (x264hip.hip launch_searches_t)
-    const T *sbase = uniform_ptr( descs[TD.first].ref_strips );
-    const T *wsbase = WEIGHTED ? uniform_ptr( descs[TD.first].refw_strips ) : sbase;
+    const WtD wt = dp->wt;
+    const T *sbase = uniform_ptr( dp->ref_strips );
+    const T *wsbase = WEIGHTED ? uniform_ptr( dp->refw_strips ) : sbase;
 
     __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char win_all[RW * G::BYTES];
-    __shared__ uint16_t tab_window[2 * TEAM_TAB_HALF];
-    __shared__ int hand[RW > 1 ? RW : 1][RW > 1 ? TEAM_HAND_W : 1]; // hand[w][x]: the vector wave w found for block x of its row (TEAM_NONE: not yet)
+    __shared__ uint16_t tab_window[2 * WIN_TAB_HALF];
+    __shared__ int hand[RW > 1 ? RW : 1][RW > 1 ? WIN_HAND_W : 1]; // hand[w][x]: the vector wave w found for block x of its row (WIN_NONE: not yet)
     unsigned char *win = win_all + wv * G::BYTES;
-    const bool lds_hand = RW > 1 && W <= TEAM_HAND_W;
+    const bool lds_hand = RW > 1 && W <= WIN_HAND_W;
     {
         const int centre = 2 * 4 * P.mv_range; // P.cost_mv is centred: valid differences are -centre .. +centre
-        for( int i = threadIdx.x; i < 2 * TEAM_TAB_HALF; i += 64 * RW )
+        for( int i = threadIdx.x; i < 2 * WIN_TAB_HALF; i += 64 * RW )
         {
-            const int d = i - TEAM_TAB_HALF;
+            const int d = i - WIN_TAB_HALF;
             tab_window[i] = d >= -centre && d <= centre ? P.cost_mv[d] : (uint16_t)0;
         }
         if( RW > 1 )
-            for( int i = threadIdx.x; i < RW * TEAM_HAND_W; i += 64 * RW )
-                hand[i / TEAM_HAND_W][i % TEAM_HAND_W] = TEAM_NONE;
+            for( int i = threadIdx.x; i < RW * WIN_HAND_W; i += 64 * RW )
+                hand[i / WIN_HAND_W][i % WIN_HAND_W] = WIN_NONE;
     }
     __syncthreads(); // orders the cost table (and the hand-off words) before the first block's reads; the last barrier of the kernel
     if( idle )
@@ -610,27 +390,27 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_team_kernel( LaP P
     const int k_first = W - 1 + ( LA_PAD >> 3 );
     fill_slot( k_first + 1 ); fill_slot( k_first ); fill_slot( k_first - 1 );
 
-    // ---- hand-off state: the vectors of the row below at x+1, x, x-1 (lane 8g of each group holds its search's) ----
+    // ---- hand-off state: the vectors of the row below at x+1, x, x-1 (scalars) ----
     const AS_GLOBAL unsigned long long *below_row = mvq + ( by + 1 ) * W;
     const bool below_in_lds = lds_hand && wv > 0; // the row below is wave wv - 1 of this workgroup
-    auto granule = [&]( int x ) -> unsigned long long { // lane 8g: granule of block (x, by+1) of this group's search, L1-bypassing
+    auto granule = [&]( int x ) -> unsigned long long { // lane 0: granule of block (x, by+1), L1-bypassing
         unsigned long long gq = 0;
         if( has_below && leader )
         {
             if( below_in_lds )
             {
                 const int v = __hip_atomic_load( &hand[RW > 1 ? wv - 1 : 0][x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
-                gq = v == TEAM_NONE ? 0ull : ( (unsigned long long)tag << 32 ) | (unsigned)v;
+                gq = v == WIN_NONE ? 0ull : ( (unsigned long long)tag << 32 ) | (unsigned)v;
             }
             else
                 gq = __hip_atomic_load( below_row + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
         }
         return gq;
     };
-    auto granule_ok = [&]( unsigned long long gq ) -> bool { return !leader || !live || (unsigned)( gq >> 32 ) == tag; };
+    auto granule_ok = [&]( unsigned long long gq ) -> bool { return !leader || (unsigned)( gq >> 32 ) == tag; };
     bool timed_out = false;
     // The granule requested a step ahead normally carries the tag already (the row below is two blocks ahead): the check is then
-    // the only cost.  Otherwise spin, reloading, until every live group's granule carries its tag.
+    // the only cost.  Otherwise spin, reloading, until the granule carries the tag.
     auto granule_spin = [&]( int x ) -> unsigned long long {
         unsigned spins = 0;
         unsigned long long gq;
@@ -649,12 +429,8 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_team_kernel( LaP P
         } while( !__all( granule_ok( gq ) ) );
         return gq;
     };
-    // every lane of the group gets lane 8g's vector
-    auto granule_mv = [&]( unsigned long long gq ) -> int {
-        if( LAT )
-            return __builtin_amdgcn_readfirstlane( (int)(unsigned)gq );
-        return __builtin_amdgcn_ds_bpermute( ( lane & ~7 ) << 2, (int)(unsigned)gq );
-    };
+    // lane 0's vector, as a scalar
+    auto granule_mv = [&]( unsigned long long gq ) -> int { return __builtin_amdgcn_readfirstlane( (int)(unsigned)gq ); };
     int below_right = 0, below = 0, below_left = 0;
     unsigned long long g_next = 0;
     if( has_below )
@@ -691,8 +467,8 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_team_kernel( LaP P
     };
     uint4 f_next = source_raw( W - 1 );
 
-    int r1 = 0;                     // packed vector of the block to the right (this group's previous result)
-    int keep_cost = 0;              // lanes 0..3 of a group: the cost of the block with x % 4 == lane, until the four leave together
+    int r1 = 0;                     // packed vector of the block to the right (the previous result)
+    int keep_cost = 0;              // lanes 0..3: the cost of the block with x % 4 == lane, until the four leave together
     for( int bx = W - 1; bx >= 0; bx-- )
     {
 #ifdef ME_PROFILE
@@ -713,22 +489,21 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_team_kernel( LaP P
             if( !__all( granule_ok( gq ) ) )
                 gq = granule_spin( bx - 1 );
             below_left = granule_mv( gq );
-            // (the latency form keeps the vector in a scalar register: an asm result in a VGPR counts as divergent, and everything derived
-            // from it -- predictor, candidates, the whole decision logic -- would be vector code again)
-            if( LAT ) asm volatile( "" : "+s"( below_left ) );
-            else asm volatile( "" : "+v"( below_left ) );
+            // (kept in a scalar register: an asm result in a VGPR counts as divergent, and everything derived from it -- predictor,
+            // candidates, the whole decision logic -- would be vector code again)
+            asm volatile( "" : "+s"( below_left ) );
         }
         if( timed_out )
             break;
         // Then everything this step sends to memory, in one go: the vector of the block just searched (sc1: the row above is waiting for
-        // it), the costs of the four blocks to the right when they are complete (lane j < 4 of the group keeps the block with
+        // it), the costs of the four blocks to the right when they are complete (lane j < 4 keeps the block with
         // x % 4 == j; four neighbouring costs are one 16-byte store), and the requests for the next step: the source block, the granule,
         // the strip the window moves onto.  Nothing else touches memory until the next step's wait, which therefore never waits for
         // anything younger than a block search.
-        if( bx + 1 < W && live && leader )
+        if( bx + 1 < W && leader )
             __hip_atomic_store( mvq + by * W + bx + 1, ( (unsigned long long)tag << 32 ) | (unsigned)r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-        if( !( ( bx + 1 ) & 3 ) && bx + 1 < W && live && cost_lane < 4 && bx + 1 + cost_lane < W )
-            costs[by * W + bx + 1 + cost_lane] = keep_cost;
+        if( !( ( bx + 1 ) & 3 ) && bx + 1 < W && lane < 4 && bx + 1 + lane < W )
+            costs[by * W + bx + 1 + lane] = keep_cost;
         f_next = source_raw( imax2( bx - 1, 0 ) );
         g_next = granule( imax2( bx - 2, 0 ) );
         if( bx > 0 )
@@ -738,7 +513,7 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_team_kernel( LaP P
         unsigned long long pf_t2 = pf_t1, pf_t3 = pf_t1;
 #endif
         int mvx = 0, mvy = 0, cost = 0;
-        if( live && la_visited( P, bx, by ) )
+        if( la_visited( P, bx, by ) )
         {
             MeLim L;
             melogic::block_limits( L, bx, by, W, H, P.mv_range );
@@ -759,8 +534,7 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_team_kernel( LaP P
                 const int v0 = mad24( k & ( WIN_RING - 1 ), G::SLOTB, WIN_R * G::ROWB );
                 const Px8 r = win_px8( win, v0, rowb, (const T *)nullptr );
                 cost = block_cost8<T>( f, r, C.mbcmp_satd );
-                if( LAT )
-                    cost = __builtin_amdgcn_readfirstlane( cost );
+                cost = __builtin_amdgcn_readfirstlane( cost );
                 done = cost < 64;
             }
 #ifdef ME_PROFILE
@@ -776,15 +550,15 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_team_kernel( LaP P
                         reach = imax2( reach, imax2( iabs( mvcx[i] - mvpx ), iabs( mvcy[i] - mvpy ) ) );
                 reach = imax2( reach, imax2( iabs( iclip3( mvpx, 4 * L.fmin_x, 4 * L.fmax_x ) - mvpx ), iabs( iclip3( mvpy, 4 * L.fmin_y, 4 * L.fmax_y ) - mvpy ) ) );
                 reach = imax2( reach, imax2( iabs( iclip3( mvpx, L.smin_x + 2, L.smax_x - 2 ) - mvpx ), iabs( iclip3( mvpy, L.smin_y + 2, L.smax_y - 2 ) - mvpy ) ) );
-                const bool far = reach + 4 * ( P.me_range + 4 ) >= TEAM_TAB_HALF;
+                const bool far = reach + 4 * ( P.me_range + 4 ) >= WIN_TAB_HALF;
                 if( __builtin_amdgcn_ballot_w64( far ) == 0ull )
                 {
-                    typename std::conditional<LAT != 0, WaveEval<T, 1, WEIGHTED>, TeamEval<T, 1, WEIGHTED>>::type ev;
-                    set_grp( ev, g );
+                    WaveEval<T, 1, WEIGHTED> ev;
+                    ev.grp = g;
                     ev.win = win; ev.lds_tab = tab_window; ev.sbase = sbase; ev.wsbase = wsbase; ev.tab = nullptr; ev.plane_elems = P.plane_elems;
                     ev.strip_elems = strip_elems; ev.pixel_max = P.pixel_max; ev.fpelcmp_satd = C.fpelcmp_satd; ev.wt = wt;
                     ev.cx0 = cx0; ev.row16 = row16; ev.f = f; ev.S = LS; ev.rowb = rowb;
-                    ev.tab_x = TEAM_TAB_HALF - mvpx; ev.tab_y = TEAM_TAB_HALF - mvpy;
+                    ev.tab_x = WIN_TAB_HALF - mvpx; ev.tab_y = WIN_TAB_HALF - mvpy;
 #ifdef ME_PROFILE
                     for( int i = 0; i < 5; i++ ) ev.pf_phase[i] = 0;
 #endif
@@ -795,8 +569,8 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_team_kernel( LaP P
                 }
                 else
                 {
-                    typename std::conditional<LAT != 0, WaveEval<T, 0, WEIGHTED>, TeamEval<T, 0, WEIGHTED>>::type ev;
-                    set_grp( ev, g );
+                    WaveEval<T, 0, WEIGHTED> ev;
+                    ev.grp = g;
                     ev.win = win; ev.lds_tab = nullptr; ev.sbase = sbase; ev.wsbase = wsbase; ev.tab = P.cost_mv - tab_centre; ev.plane_elems = P.plane_elems;
                     ev.strip_elems = strip_elems; ev.pixel_max = P.pixel_max; ev.fpelcmp_satd = C.fpelcmp_satd; ev.wt = wt;
                     ev.cx0 = cx0; ev.row16 = row16; ev.f = f; ev.S = LS; ev.rowb = rowb;
@@ -817,9 +591,9 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_team_kernel( LaP P
         // blocks slicetype_slice_cost never visits (slicetype.c:823-833) keep zero vectors (frame.c:283-285); the vector leaves at the
         // start of the next step
         const int packed = ( mvx & 0xFFFF ) | ( mvy << 16 );
-        if( lds_hand && leader && live )
+        if( lds_hand && leader )
             __hip_atomic_store( &hand[wv][bx], packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ); // the wave above polls this word
-        if( cost_lane == ( bx & 3 ) )
+        if( lane == ( bx & 3 ) )
             keep_cost = cost;
         r1 = packed;
         below_right = below; below = below_left;
@@ -833,12 +607,12 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_team_kernel( LaP P
     }
     if( timed_out && lane == 0 )
         __hip_atomic_store( err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
-    if( !timed_out && live )
+    if( !timed_out )
     {
         if( leader )
             __hip_atomic_store( mvq + by * W, ( (unsigned long long)tag << 32 ) | (unsigned)r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-        if( cost_lane < 4 && cost_lane < W )
-            costs[by * W + cost_lane] = keep_cost;
+        if( lane < 4 && lane < W )
+            costs[by * W + lane] = keep_cost;
     }
     me_dma_drain();
     leave();

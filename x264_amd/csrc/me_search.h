@@ -725,3 +725,31 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
     }
 #endif
 }
+
+// ---- the prediction the searches and cost cells read, block by block (test entry x264hip_mc_luma_probe) ---------------------------------
+// out[i] = the 8x8 block at lowres position (x, y) displaced by (mvx, mvy) quarter-pels, through qpel_px8_strips -- the tap arithmetic of
+// every candidate of me_rows_kernel, me_latency_kernel (outside its window) and cell_b_kernel -- then weighted like mc_luma does
+// (common/mc.c:198-218: average first, weight afterwards).  A request per 8-lane group, a row per lane.
+struct McProbe
+{
+    int x, y, mvx, mvy;
+};
+template <typename T>
+__global__ __launch_bounds__( 64 ) void mc_probe_kernel( LaP P, const T *strips, const McProbe *req, int n, WtD wt, T *out )
+{
+    const int i = blockIdx.x * 8 + ( threadIdx.x >> 3 ), r = threadIdx.x & 7;
+    if( i >= n )
+        return;
+    const McProbe q = req[i];
+    const int strip_elems = ( P.plane_elems / P.stride ) * 16;
+    Px8 p = qpel_px8_strips<T>( strips, P.plane_elems, strip_elems, q.x + LA_PAD, ( q.y + LA_PAD + r ) << 4, q.mvx, q.mvy );
+    if( wt.on )
+    {
+        p.lo = weight_px4<T>( p.lo, wt, P.pixel_max ); p.hi = weight_px4<T>( p.hi, wt, P.pixel_max );
+    }
+    int v[8];
+    px4_to_ints( p.lo, v ); px4_to_ints( p.hi, v + 4 );
+#pragma unroll
+    for( int k = 0; k < 8; k++ )
+        out[(size_t)i * 64 + r * 8 + k] = (T)v[k];
+}

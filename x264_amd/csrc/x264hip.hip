@@ -21,7 +21,7 @@
 #include "x264hip.h"
 #include "device_common.h"
 #include "me_search.h"
-#include "me_team.h"
+#include "me_latency.h"
 #include "la_kernels.h"
 #include "block_metrics.h"
 #include "dct_quant_block.h"
@@ -84,16 +84,16 @@ struct FrameSlot
     // Callers ask for some B cell classes now with, now without the list-1 reference's own vectors (slicetype.c:629: it depends on
     // whether that frame has been searched as a P frame by then).  When both happen often the minority variant is speculated as well,
     // into the slot's one spare cell; a request for it copies map and sums over (no evaluation, no wait for an on-demand launch).
-    std::vector<CellEntry> alts;      // [n_cells]: the speculative OTHER variant of B cell idx, evaluated into spare cell n_cells + idx
-    std::vector<int> cell_at;         // [n_cells]: where the data of cell idx lives -- idx, or n_cells + idx once the caller asked for the variant in the spare
+    std::vector<CellEntry> alts;      // [n_cells]: the speculative OTHER variant of B cell idx, evaluated into spare cell ctx->spare_at[idx]
+    std::vector<int> cell_at;         // [n_cells]: where the data of cell idx lives -- idx, or spare_at[idx] once the caller asked for the variant in the spare
     // host-side state of the device fields
     unsigned char field_ready[2][X264HIP_BFRAME_MAX + 1]; // searched (any variant) and complete on the stream
     unsigned char field_prefetched[2][X264HIP_BFRAME_MAX + 1]; // unweighted field computed speculatively, not yet claimed
     // window shard: the field was searched on the rank that owns this frame -- 1: nothing of it is here (the tag stands for it),
     // 2: its vectors are here (x264hip_import_cell_map), its costs are not.  0: an ordinary local field
     unsigned char field_remote[2][X264HIP_BFRAME_MAX + 1];
-    int *cell_sums = nullptr;         // [2 (bf+2)*(bf+2)][8] device copy of the cell sums (x264hip_export_cells)
-    int *cell_work = nullptr;         // [2 (bf+2)*(bf+2)][8] work words of cell_reduce_kernel
+    int *cell_sums = nullptr;         // [n_store][8] device copy of the cell sums (x264hip_export_cells)
+    int *cell_work = nullptr;         // [n_store][8] work words of cell_reduce_kernel
     // speculation by position (x264hip_gop_hint): the ( period, position ) this frame was speculated under, and what it was asked for
     int pos_key = 0;                  // period * 32 + position, 0 = no expectation
     unsigned req_fields[2] = { 0, 0 };// bit d: (list, distance d + 1) requested
@@ -133,6 +133,8 @@ struct x264hip_ctx
     unsigned *sync_words = nullptr;  // device: row-ticket counters of the search kernel
     unsigned long long *me_prof = nullptr; // ME_PROFILE builds: 8 cycle accumulators of the search kernel (device), else unused
     int n_cells = 0;                 // (bframes+2)^2
+    std::vector<int> spare_at;       // [n_cells]: storage index of the spare of B cell idx (n_cells + its rank among the B classes; only they have one)
+    int n_store = 0;                 // cell maps per slot: n_cells own places + one spare per B class + one nobody reads (spare_at of the other classes)
     int *cell_acc_host = nullptr;    // pinned [slots][n_cells][8]: sums of every cell evaluation, written by the device directly
     int *cell_alt_host = nullptr;    // pinned [slots][n_cells][8]: sums of the spare cells (FrameSlot alts)
     DescRing cell_ring, put_ring, search_ring, xfer_ring;
@@ -482,6 +484,18 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( hipMemset( ctx->me_prof, 0, 32 * sizeof( unsigned long long ) ) );
 #endif
     ctx->n_cells = ( p.bframes + 2 ) * ( p.bframes + 2 );
+    {
+        const int ns = p.bframes + 2;
+        int n_b = 0;
+        for( int d0 = 1; d0 <= p.bframes + 1; d0++ )
+            for( int d1 = 1; d0 + d1 <= p.bframes + 1; d1++ )
+                n_b++;
+        ctx->spare_at.assign( ctx->n_cells, ctx->n_cells + n_b );
+        for( int d0 = 1, k = 0; d0 <= p.bframes + 1; d0++ )
+            for( int d1 = 1; d0 + d1 <= p.bframes + 1; d1++ )
+                ctx->spare_at[d0 * ns + d1] = ctx->n_cells + k++;
+        ctx->n_store = ctx->n_cells + n_b + 1;
+    }
     ctx->pos_frames.assign( x264hip_ctx::POS_KEYS, 0 );
     ctx->pos_field_req.assign( (size_t)x264hip_ctx::POS_KEYS * 2 * ( X264HIP_BFRAME_MAX + 1 ), 0 );
     ctx->pos_cell_req.assign( (size_t)x264hip_ctx::POS_KEYS * ctx->n_cells, 0 );
@@ -525,7 +539,7 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( ring_alloc( ctx->xfer_ring, (size_t)ctx->xfer_cap * sizeof( CellXfer ) ) );
     ctx->wcache.assign( x264hip_ctx::WCAP, x264hip_ctx::WEntry() );
     ctx->desc_cap = 2 * ( p.bframes + 1 ) * p.max_frames + 16;
-    OPENCK( ring_alloc( ctx->search_ring, (size_t)ctx->desc_cap * ( sizeof( SearchDesc<uint8_t> ) + sizeof( TeamDesc ) ) ) ); // descriptors, then the team table
+    OPENCK( ring_alloc( ctx->search_ring, (size_t)ctx->desc_cap * sizeof( SearchDesc<uint8_t> ) ) );
     ctx->staging_bytes = (size_t)p.width * p.height * ctx->psz;
     OPENCK( hipHostMalloc( &ctx->staging, ctx->staging_bytes ) );
 
@@ -540,15 +554,16 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         const size_t o_mbs = off; off += align_up( ctx->n_mb * sizeof( uint2 ), 256 );
         const size_t o_mvq = off; off += align_up( (size_t)2 * nd * ctx->n_mb * sizeof( unsigned long long ), 256 );
         const size_t o_mvc = off; off += align_up( (size_t)2 * nd * ctx->n_mb * sizeof( int ), 256 );
-        // (twice the cells the reference has: spare nc + idx holds the speculative SECOND variant of B cell idx, see FrameSlot alts)
-        const size_t o_lc = off; off += align_up( (size_t)( 2 * nc ) * ctx->n_mb * sizeof( uint16_t ), 256 );
-        const size_t o_rows = off; off += align_up( (size_t)( 2 * nc ) * mb_h * sizeof( int ), 256 );
-        const size_t o_blk = off; off += align_up( (size_t)( 2 * nc ) * ctx->n_mb * sizeof( int ), 256 );
+        // (more cells than the reference has: spare_at[idx] holds the speculative SECOND variant of B cell idx, see FrameSlot alts)
+        const int nst = ctx->n_store;
+        const size_t o_lc = off; off += align_up( (size_t)nst * ctx->n_mb * sizeof( uint16_t ), 256 );
+        const size_t o_rows = off; off += align_up( (size_t)nst * mb_h * sizeof( int ), 256 );
+        const size_t o_blk = off; off += align_up( (size_t)nst * ctx->n_mb * sizeof( int ), 256 );
         const size_t o_prop = off; off += align_up( (size_t)ctx->n_mb * sizeof( int ), 256 );
         const size_t o_qpa = off; off += align_up( (size_t)ctx->n_mb * sizeof( float ), 256 );
         const size_t o_qp = off; off += align_up( (size_t)ctx->n_mb * sizeof( float ), 256 );
-        const size_t o_sums = off; off += align_up( (size_t)( 2 * nc ) * 8 * sizeof( int ), 256 );
-        const size_t o_work = off; off += align_up( (size_t)( 2 * nc ) * 8 * sizeof( int ), 256 ); // cell_reduce_kernel's work words (zero between launches)
+        const size_t o_sums = off; off += align_up( (size_t)nst * 8 * sizeof( int ), 256 );
+        const size_t o_work = off; off += align_up( (size_t)nst * 8 * sizeof( int ), 256 ); // cell_reduce_kernel's work words (zero between launches)
         char *base = nullptr;
         OPENCK( hipMalloc( &base, off ) );
         OPENCK( hipMemset( base, 0, off ) );
@@ -961,32 +976,22 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
     int rc = 0, ri = 0;
     if( ring_acquire( ctx->search_ring, &ri ) ) return X264HIP_EDEVICE;
     SearchDesc<T> *dh = (SearchDesc<T> *)ctx->search_ring.host[ri], *dd = (SearchDesc<T> *)ctx->search_ring.dev[ri];
-    // The table holds the searches on unweighted planes first, sorted by reference frame (stable: request = frame order inside a
-    // reference), then the weighted ones: the kernels are compiled once without and once with the weighting code.  Searches that read
-    // one reference form TEAMS of up to TEAM_MAX (me_team.h: a wave = one block row of a team, one LDS window of the reference);
-    // a weighted search reads its own weighted copy and is a team of its own.
+    // The table holds the searches on unweighted planes first (in request = frame order), then the weighted ones: the kernels are
+    // compiled once without and once with the weighting code.
     static const bool use_rows = getenv( "X264HIP_SEARCH" ) && !strcmp( getenv( "X264HIP_SEARCH" ), "rows" ); // A/B runs: the rows kernel for every launch
-    static const bool use_team = getenv( "X264HIP_SEARCH" ) && !strcmp( getenv( "X264HIP_SEARCH" ), "team" ); // A/B runs: the team form for large launches
     std::vector<int> order( n );
     int n_plain = 0;
     for( int i = 0; i < n; i++ )
         if( !reqs[i].wt.on ) order[n_plain++] = i;
-    if( use_team )
-        std::stable_sort( order.begin(), order.begin() + n_plain, [&]( int a, int b ) {
-            const FrameSlot &ra = ctx->slots[reqs[a].slot_ref], &rb = ctx->slots[reqs[b].slot_ref];
-            return ra.frame_no != rb.frame_no ? ra.frame_no < rb.frame_no : reqs[a].slot_ref < reqs[b].slot_ref;
-        } );
     for( int i = 0, k = n_plain; i < n; i++ )
         if( reqs[i].wt.on ) order[k++] = i;
-    TeamDesc *th = (TeamDesc *)( dh + ctx->desc_cap ), *td = (TeamDesc *)( dd + ctx->desc_cap );
-    int n_teams[2] = { 0, 0 }; // unweighted teams first, then the weighted ones
     // Which kernel ("two search kernels"): a launch that cannot fill the chip is as long as its dependency chain
     // -- W + 2 (H - 1) block searches one after the other -- whatever its width, so it goes to the LATENCY form of the search out of LDS
-    // (me_team_kernel<.., LAT = 1>: a wave per search and block row, ~5 x shorter per block, ~3 x more instructions per block);
-    // everything larger goes to the throughput kernel (me_rows_kernel; X264HIP_SEARCH=team: the team form of the LDS kernel).
+    // (me_latency_kernel: a wave per search and block row, ~5 x shorter per block, ~3 x more instructions per block);
+    // everything larger goes to the throughput kernel (me_rows_kernel).
     static const int lat_waves = getenv( "X264HIP_LAT_WAVES" ) ? atoi( getenv( "X264HIP_LAT_WAVES" ) ) : 4096;
     const bool lat[2] = { (long long)n_plain * P.mb_h <= lat_waves, (long long)( n - n_plain ) * P.mb_h <= lat_waves };
-    const bool rows[2] = { use_rows || ( !lat[0] && !use_team ), use_rows || ( !lat[1] && !use_team ) };
+    const bool rows[2] = { use_rows || !lat[0], use_rows || !lat[1] };
     for( int i = 0; i < n; i++ )
     {
         const SearchReq &r = reqs[order[i]];
@@ -1017,24 +1022,8 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         b.field_remote[r.list][r.dist_m1] = 0;
         d.pad = 0;
         dh[i] = d;
-        const int part = i >= n_plain, nt = n_teams[0] + n_teams[1];
-        bool joined = false;
-        if( !part && nt && !lat[0] )
-        {
-            TeamDesc &l = th[nt - 1];
-            joined = l.n < TEAM_MAX && dh[l.first].ref_strips == d.ref_strips;
-            if( joined ) l.n++;
-        }
-        if( !joined )
-        {
-            th[nt].first = part ? i - n_plain : i; // relative to the part's first descriptor
-            th[nt].n = 1;
-            n_teams[part]++;
-        }
     }
     HIPCK( upload_async( ctx, dd, dh, (size_t)n * sizeof( SearchDesc<T> ), ctx->stream ) );
-    if( !rows[0] || !rows[1] )
-        HIPCK( upload_async( ctx, td, th, (size_t)( n_teams[0] + n_teams[1] ) * sizeof( TeamDesc ), ctx->stream ) );
     // (the row tickets in sync_words are cleared by the last wave of the previous launch: me_search.h)
     hipEvent_t e0 = ctx->ev_start, e1 = ctx->ev_stop;
     if( ctx->prof_on )
@@ -1054,31 +1043,25 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         const bool hex = P.me_method == X264HIP_ME_HEX, r4 = P.subpel_refine >= 3;
         const int mode = !r4 && !P.mbcmp_satd && !P.fpelcmp_satd ? 0 : r4 && P.mbcmp_satd ? ( P.fpelcmp_satd ? 2 : 1 ) : 3;
         MeQueues Q;
-        // team kernel: one wave per (team, block row); rows kernel: one wave per (search, group of ME_ROWS block rows).  Both are
+        // latency kernel: one wave per (search, block row); rows kernel: one wave per (search, group of ME_ROWS block rows).  Both are
         // specialised on the search pattern, the sub-pel depth and on whether their searches read weighted references
         const int n_rowgroups = ( P.mb_h + ME_ROWS - 1 ) / ME_ROWS;
         for( int part = 0; part < 2; part++ )
         {
             const int first = part ? n_plain : 0, count = part ? n - n_plain : n_plain;
             if( !count ) continue;
-            const int units = rows[part] ? count : n_teams[part]; // what the ticket queues hand out
             for( int q = 0; q <= ME_QUEUES; q++ )
-                Q.base[q] = (int)( (long long)units * q / ME_QUEUES ); // contiguous groups: the table is in frame order
+                Q.base[q] = (int)( (long long)count * q / ME_QUEUES ); // the ticket queues hand out searches; contiguous groups: the table is in frame order
             unsigned *tickets = ctx->sync_words + part * ME_QUEUES * ME_QUEUE_STRIDE;
-            const TeamDesc *tp = td + ( part ? n_teams[0] : 0 );
-            const int grid_rows = count * n_rowgroups, grid_team = units * P.mb_h, grid_lat = units * ( ( P.mb_h + ME_LAT_ROWS - 1 ) / ME_LAT_ROWS );
+            const int grid_rows = count * n_rowgroups, grid_lat = count * ( ( P.mb_h + ME_LAT_ROWS - 1 ) / ME_LAT_ROWS );
 #define ME_ARGS_ROWS P, dd + first, Q, tickets, ctx->err_host, 1u << 22, ctx->me_prof
-#define ME_ARGS_TEAM P, dd + first, tp, Q, tickets, ctx->err_host, 1u << 22, ctx->me_prof
 #define ME_LAUNCH( HEXV, MODEV ) do { \
                 if( rows[part] ) { \
                     if( part ) me_rows_kernel<T, HEXV, MODEV, 1><<<grid_rows, 64, 0, ctx->stream>>>( ME_ARGS_ROWS ); \
                     else me_rows_kernel<T, HEXV, MODEV, 0><<<grid_rows, 64, 0, ctx->stream>>>( ME_ARGS_ROWS ); \
-                } else if( lat[part] ) { \
-                    if( part ) me_team_kernel<T, HEXV, MODEV, 1, 1, ME_LAT_ROWS><<<grid_lat, 64 * ME_LAT_ROWS, 0, ctx->stream>>>( ME_ARGS_TEAM ); \
-                    else me_team_kernel<T, HEXV, MODEV, 0, 1, ME_LAT_ROWS><<<grid_lat, 64 * ME_LAT_ROWS, 0, ctx->stream>>>( ME_ARGS_TEAM ); \
                 } else { \
-                    if( part ) me_team_kernel<T, HEXV, MODEV, 1, 0, 1><<<grid_team, 64, 0, ctx->stream>>>( ME_ARGS_TEAM ); \
-                    else me_team_kernel<T, HEXV, MODEV, 0, 0, 1><<<grid_team, 64, 0, ctx->stream>>>( ME_ARGS_TEAM ); \
+                    if( part ) me_latency_kernel<T, HEXV, MODEV, 1, ME_LAT_ROWS><<<grid_lat, 64 * ME_LAT_ROWS, 0, ctx->stream>>>( ME_ARGS_ROWS ); \
+                    else me_latency_kernel<T, HEXV, MODEV, 0, ME_LAT_ROWS><<<grid_lat, 64 * ME_LAT_ROWS, 0, ctx->stream>>>( ME_ARGS_ROWS ); \
                 } } while( 0 )
             switch( 4 * hex + mode )
             {
@@ -1093,7 +1076,6 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
             }
 #undef ME_LAUNCH
 #undef ME_ARGS_ROWS
-#undef ME_ARGS_TEAM
         }
     }
     HIPCK( hipEventRecord( e1, ctx->stream ) );
@@ -1150,7 +1132,7 @@ static CellArgs make_cell( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_
     if( to_spare )
     {
         // the cell's spare: its own map, block words, row sums and sums; the intra row sums are the frame's (same values)
-        const int sp = ctx->n_cells + idx;
+        const int sp = ctx->spare_at[idx];
         A.lowres_costs = b.lowres_costs + (size_t)sp * ctx->n_mb;
         A.row_satds = b.row_satds + (size_t)sp * P.mb_h;
         A.blk = b.blk + (size_t)sp * ctx->n_mb;
@@ -1547,7 +1529,7 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
         CellEntry &a = b.alts[idx];
         int r = batch_wait( ctx, a.batch );
         if( r ) return r;
-        b.cell_at[idx] = ctx->n_cells + idx; // the spare IS the cell from now on: every reader goes through cell_at (no copy, no launch)
+        b.cell_at[idx] = ctx->spare_at[idx]; // the spare IS the cell from now on: every reader goes through cell_at (no copy, no launch)
         const int *ra = ctx->cell_alt_host + ( (size_t)slot_b * ctx->n_cells + idx ) * 8;
         out->cost_est = ra[0]; out->cost_est_aq = ra[1]; out->intra_mbs = ra[2];
         out->intra_cost_est = ra[3]; out->intra_cost_est_aq = ra[4];
@@ -3697,7 +3679,7 @@ static CellXfer make_xfer( x264hip_ctx *ctx, const x264hip_cell_ref &c, bool imp
     const bool spare = ( c.with_ref1_l0 & X264HIP_CELL_SPARE ) != 0;
     // a summary from the owner rank goes to the cell's own place (the caller re-points cell_at there once it has decided to take
     // the entry: an entry that is skipped -- the cell was already answered here, possibly from its spare half -- must not move it)
-    const int at = spare ? ctx->n_cells + idx : importing ? idx : b.cell_at[idx];
+    const int at = spare ? ctx->spare_at[idx] : importing ? idx : b.cell_at[idx];
     CellXfer X;
     X.acc_host = ( spare ? ctx->cell_alt_host : ctx->cell_acc_host ) + ( (size_t)c.slot_b * ctx->n_cells + idx ) * 8;
     X.acc_dev = b.cell_sums + (size_t)at * 8;
@@ -3846,7 +3828,7 @@ extern "C" int x264hip_export_cell_map( x264hip_ctx *ctx, const x264hip_cell_ref
     const bool spare = d1 && ( cell->with_ref1_l0 & X264HIP_CELL_SPARE );
     const CellEntry &e = spare ? b.alts[idx] : b.cells[idx];
     if( !b.in_use || e.map_remote || ( !e.valid && !e.requested ) ) return X264HIP_ESTATE; // the map has to have been evaluated HERE
-    const int at = spare ? ctx->n_cells + idx : b.cell_at[idx];
+    const int at = spare ? ctx->spare_at[idx] : b.cell_at[idx];
     export_map_kernel<<<( ctx->n_mb + 255 ) / 256, 256, 0, ctx->stream>>>( b.lowres_costs + (size_t)at * ctx->n_mb, b.mvq[0][d0 - 1], d1 ? b.mvq[1][d1 - 1] : nullptr,
                                                                           (int *)dst_dev, ctx->n_mb );
     HIPCK( hipGetLastError() );
@@ -3874,6 +3856,51 @@ extern "C" int x264hip_import_cell_map( x264hip_ctx *ctx, const x264hip_cell_ref
     e.map_remote = 0;
     ctx->counters[10]++;
     return X264HIP_OK;
+}
+
+template <typename T>
+static int mc_luma_probe_t( x264hip_ctx *ctx, int slot, int n, const x264hip_mc_probe *req, const x264hip_weight *w, void *out )
+{
+    FrameSlot &f = ctx->slots[slot];
+    McProbe *rd = nullptr;
+    T *od = nullptr;
+    int rc = X264HIP_OK;
+    if( hipMalloc( &rd, (size_t)n * sizeof( McProbe ) ) != hipSuccess || hipMalloc( &od, (size_t)n * 64 * sizeof( T ) ) != hipSuccess )
+        rc = X264HIP_ENOMEM;
+    else
+    {
+        static_assert( sizeof( McProbe ) == sizeof( x264hip_mc_probe ), "the request record is the public one" );
+        const WtD wt = w ? make_wt( ctx, w ) : WtD{ 0, 1, 0, 0 };
+        if( hipMemcpyAsync( rd, req, (size_t)n * sizeof( McProbe ), hipMemcpyHostToDevice, ctx->stream ) != hipSuccess )
+            rc = X264HIP_EDEVICE;
+        else
+        {
+            mc_probe_kernel<T><<<( n + 7 ) / 8, 64, 0, ctx->stream>>>( ctx->P, (const T *)( f.planes + 4 * ctx->plane_bytes ), rd, n, wt, od );
+            if( hipMemcpyAsync( out, od, (size_t)n * 64 * sizeof( T ), hipMemcpyDeviceToHost, ctx->stream ) != hipSuccess ||
+                hipStreamSynchronize( ctx->stream ) != hipSuccess || hipGetLastError() != hipSuccess )
+                rc = X264HIP_EDEVICE;
+        }
+    }
+    if( rd ) (void)hipFree( rd );
+    if( od ) (void)hipFree( od );
+    return rc;
+}
+
+extern "C" int x264hip_mc_luma_probe( x264hip_ctx *ctx, int slot, int n, const x264hip_mc_probe *req, const x264hip_weight *w, void *out )
+{
+    if( !ctx || !req || !out || n < 0 ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( !slot_ok( ctx, slot ) || !ctx->slots[slot].in_use ) return X264HIP_ESTATE;
+    if( !n ) return X264HIP_OK;
+    // what a legal candidate can reach: the picture plus the 8-sample block inside the padding, one sample spare for the quarter-pel partner
+    const int W8 = 8 * ctx->P.mb_w, H8 = 8 * ctx->P.mb_h;
+    for( int i = 0; i < n; i++ )
+    {
+        const int x0 = req[i].x + ( req[i].mvx >> 2 ), y0 = req[i].y + ( req[i].mvy >> 2 );
+        if( x0 < -LA_PAD || x0 + 9 > W8 + LA_PAD || y0 < -LA_PAD || y0 + 9 > H8 + LA_PAD ) return X264HIP_EINVAL;
+    }
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE;
+    return ctx->p.bit_depth == 8 ? mc_luma_probe_t<uint8_t>( ctx, slot, n, req, w, out ) : mc_luma_probe_t<uint16_t>( ctx, slot, n, req, w, out );
 }
 
 extern "C" int x264hip_spec_classes( x264hip_ctx *ctx, const unsigned char *cell_allowed, unsigned mask_l0, unsigned mask_l1 )

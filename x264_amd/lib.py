@@ -207,6 +207,14 @@ class Context:
         _ck(self.L.x264hip_get_lowres(self.h, slot, plane, _p(out), out.shape[1]), "get_lowres")
         return out
 
+    def mc_luma_probe(self, slot, reqs, weight=None):
+        """x264hip_mc_luma_probe: reqs = (n, 4) int32 rows (x, y, mvx, mvy) -> (n, 8, 8) predicted blocks"""
+        reqs = np.ascontiguousarray(reqs, np.int32).reshape(-1, 4)
+        out = np.zeros((len(reqs), 8, 8), self.dtype)
+        w = Weight(*weight) if weight is not None else None
+        _ck(self.L.x264hip_mc_luma_probe(self.h, slot, len(reqs), _p(reqs), C.byref(w) if w else None, _p(out)), "mc_luma_probe")
+        return out
+
     def mvs(self, slot, lst, dist_m1):
         mv = np.zeros((self.n_mb, 2), np.int16)
         cost = np.zeros(self.n_mb, np.int32)
