@@ -876,9 +876,11 @@ def window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend,
             res["cells_and_searches"] = {"searches": stats.get("searches_here", 0), "cells": stats.get("cells_here", 0), "cells_on_demand": stats.get("cells_on_demand", 0)}
             # What a window shard can reach from here: the searches and the cost cells are what moves to the owner ranks (frame b on rank
             # b % N); everything else of this pass -- ingest, intra, decisions, MB-tree, waiting for the last batch -- stays on rank 0.
-            # Both parts measured in THIS pass: HIP events around every search and cell launch on the context's stream, wall time around
-            # the pass.  The prediction leaves the exchange out (summaries of 8 + 2 mb_h ints per cell, list-0 fields of the list-1
-            # references); the measured N > 1 line carries its own serial_fraction_measured.
+            # Both parts measured in ONE more, untimed pass: HIP events around every search and cell launch on the context's stream (the
+            # events perturb a pass, so `value` comes from the passes above, without them), wall time around that pass.  The prediction
+            # leaves the exchange out (summaries of 8 + 2 mb_h ints per cell, list-0 fields of the list-1 references); the measured N > 1
+            # line carries its own serial_fraction_measured.
+            _, dt_last, stats = shard.run_window_shard(torch, lib, None, rank, world, dev_index, cfg, clip, on_dev, profile=True)
             par = (stats.get("device_ms_searches", 0.0) + stats.get("device_ms_cells", 0.0)) / 1e3
             if 0 < par < dt_last:
                 ser = dt_last - par
@@ -886,8 +888,8 @@ def window_shard_bench(torch, lib, shard, dist, rank, world, dev_index, backend,
                                  "device_ms": {"searches": stats.get("device_ms_searches"), "cells": stats.get("device_ms_cells"),
                                                "search_launches": stats.get("search_launches"), "cell_launches": stats.get("cell_launches")},
                                  "predicted_speedup": {str(n): round(dt_last / (ser + par / n), 2) for n in (2, 4, 8)},
-                                 "what": "T(N) = serial + shardable / N with both terms measured in the last N = 1 pass (searches + cost cells by HIP events on the "
-                                         "context's stream; serial = wall time of the pass minus that); exchange not included"}
+                                 "what": "T(N) = serial + shardable / N with both terms measured in one more N = 1 pass after the timed ones (searches + cost cells by HIP "
+                                         "events on the context's stream; serial = wall time of that pass minus that); exchange not included"}
             if paced_check:
                 # the same stream through the encoder-paced put / get interface: same types, same cost cells
                 la = lib.Lookahead(cfg, device=dev_index, max_frames=0)

@@ -265,38 +265,6 @@ __device__ __forceinline__ Px4 avg_px4( const Px4 &x, const Px4 &y, const uint16
     return r;
 }
 
-// Four quarter-pel samples at lowres position (x..x+3, y) displaced by (mvx,mvy): rounded average of
-// two of the four half-pel planes (both taps coincide for full/half-pel phases, so the code path is
-// branch free).  p0 = plane 0 at the block origin; plane k is plane_elems*k further.
-template <typename T>
-__device__ __forceinline__ Px4 qpel_px4( const T *p0, int plane_elems, int stride, int x, int y, int mvx, int mvy )
-{
-    int fx = mvx & 3, fy = mvy & 3;
-    int ix = x + ( mvx >> 2 ), iy = y + ( mvy >> 2 );
-    int pa = ( fx ? 1 : 0 ) + ( fy == 2 ? 2 : 0 );
-    int pb = ( fx == 2 ? 1 : 0 ) + ( fy ? 2 : 0 );
-    const T *a = p0 + (size_t)pa * plane_elems + ( iy + ( fy == 3 ) ) * stride + ix;
-    const T *b = p0 + (size_t)pb * plane_elems + iy * stride + ix + ( fx == 3 );
-    return avg_px4( load_px4( a ), load_px4( b ), (const T *)nullptr );
-}
-
-// Same samples addressed as element offsets from a wave-uniform base (the start of the frame's four-plane
-// allocation): lane_off = this lane's 4 samples of the block at zero displacement, in plane 0.
-// The plane pair of each of the 16 quarter-pel phases comes from two 32-bit lookup constants.
-template <typename T>
-__device__ __forceinline__ Px4 qpel_px4_at( const T *ubase, int plane_elems, int stride, int lane_off, int mvx, int mvy )
-{
-    const int fx = mvx & 3, fy = mvy & 3;
-    const int sh = 2 * ( fx | ( fy << 2 ) );
-    // pa = (fx ? 1 : 0) + (fy == 2 ? 2 : 0), pb = (fx == 2 ? 1 : 0) + (fy ? 2 : 0), two bits per phase
-    const unsigned pa = ( 0x54FE5454u >> sh ) & 3u, pb = ( 0xBABABA10u >> sh ) & 3u;
-    const int o = lane_off + mad24( mvy >> 2, stride, mvx >> 2 );
-    // plane_elems exceeds the SIGNED 24-bit range from 8K pictures on (3904 x 2224 = 8.7 M samples per padded lowres
-    // plane): the unsigned 24-bit multiply covers every size x264hip_open accepts (plane_elems < 2^24)
-    const int oa = (int)__umul24( pa, (unsigned)plane_elems ) + o + ( fy == 3 ? stride : 0 );
-    const int ob = (int)__umul24( pb, (unsigned)plane_elems ) + o + ( fx == 3 );
-    return avg_px4( load_px4_at( ubase, oa ), load_px4_at( ubase, ob ), (const T *)nullptr );
-}
 // ---- block metrics on the 16-lane layout -----------------------------------------------------------
 // {v.lo + v.hi, v.lo - v.hi}: the one butterfly of the horizontal transform that crosses register halves,
 // as a single VOP3P multiply-add with operand-half selection (hi*{1,-1} + lo)

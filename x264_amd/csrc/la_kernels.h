@@ -574,8 +574,14 @@ __device__ __forceinline__ int intra_pred_px( const IntraEdges &E, int mode, int
 // one wave wide on purpose: beside the search kernel, whose waves fill the register files, a single free wave slot is all such a
 // workgroup needs (four-wave workgroups measured 5 % slower end to end with eight contexts in flight).  A workgroup per block made
 // the launch dispatch-bound (1.3 M workgroups for 160 frames of 1080p).
+// MODES (3: DC / H / V, subme <= 1; 10: all) is a template parameter and the mode loop is unrolled: every pass's case body is then
+// straight-line code and the LDS reads of the next mode are issued under the transform of the current one (INTRA_UNROLL=0: the loop as
+// a loop, one uniform switch per pass -- round 4's form, for A/B runs).
+#ifndef INTRA_UNROLL
+#define INTRA_UNROLL 1
+#endif
 #define INTRA_BLOCKS_PER_WG 8
-template <typename T>
+template <typename T, int MODES>
 __global__ __launch_bounds__( 64 ) void intra_kernel( LaP P, const PutDesc *descs, PutDesc single )
 {
     const PutDesc D = descs ? load_uniform( descs + blockIdx.z ) : single;
@@ -588,7 +594,6 @@ __global__ __launch_bounds__( 64 ) void intra_kernel( LaP P, const PutDesc *desc
     const int wg = (int)( blockIdx.x & 7 ) * (int)( gridDim.x >> 3 ) + (int)( blockIdx.x >> 3 );
     const int g = lane >> 4, l = lane & 15, q = l >> 2;
     const int tx = ( q & 1 ) * 4, row = ( q >> 1 ) * 4 + ( l & 3 );
-    const int n_modes = P.subme > 1 ? 10 : 3;
     IntraEdges &E = E4[g];
     for( int it = 0; it < INTRA_BLOCKS_PER_WG; it += 4 )
     {
@@ -623,7 +628,12 @@ __global__ __launch_bounds__( 64 ) void intra_kernel( LaP P, const PutDesc *desc
         }
         __syncthreads();
         int best = COST_MAX_I;
-        for( int mode = 0; mode < n_modes; mode++ )
+#if INTRA_UNROLL
+#pragma unroll
+#else
+#pragma nounroll
+#endif
+        for( int mode = 0; mode < MODES; mode++ )
         {
             int pr[4];
 #pragma unroll

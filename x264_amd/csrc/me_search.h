@@ -124,7 +124,7 @@ __device__ __forceinline__ int strip_off( int c, int row16, int strip_elems )
 {
     return mad24( c >> 3, strip_elems, ( c & 7 ) + row16 );
 }
-// the quarter-pel samples of device_common.h's qpel_px4_at, eight per lane, out of the strip copy: sbase = strips of plane 0,
+// eight quarter-pel samples per lane out of the strip copy (rounded average of two of the four half-pel planes): sbase = strips of plane 0,
 // cx0 / row16 = padded column of the block and strip-row offset of this lane's row at zero displacement (taps: strip_layout.h)
 template <typename T>
 __device__ __forceinline__ Px8 qpel_px8_strips( const T *sbase, int plane_elems, int strip_elems, int cx0, int row16, int mvx, int mvy )

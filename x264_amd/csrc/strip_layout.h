@@ -26,7 +26,8 @@ ME_HD int read_off( int c, int row16, int strip_elems )
 }
 // the two taps of the quarter-pel sample run at (mvx, mvy) quarter-pels, as offsets into the strips of the FOUR half-pel planes (plane
 // p's strips start at p * 2 * plane_elems).  o = read_off() of the full-pel part of the vector: ( cx0 + ( mvx >> 2 ), row16 + 16 *
-// ( mvy >> 2 ) ).  The plane pair of each of the 16 phases comes from two 32-bit lookup constants (device_common.h qpel_px4_at); the
+// ( mvy >> 2 ) ).  The plane pair of each of the 16 phases comes from two 32-bit lookup constants (two bits per phase:
+// pa = (fx ? 1 : 0) + (fy == 2 ? 2 : 0), pb = (fx == 2 ? 1 : 0) + (fy ? 2 : 0), common/mc.c:198-212's x264_hpel_ref0 / ref1); the
 // partner column / row is +1 / +16 samples inside the same strip.
 ME_HD void qpel_taps( int plane_elems, int o, int mvx, int mvy, int &oa, int &ob )
 {

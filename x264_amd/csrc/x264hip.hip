@@ -707,7 +707,10 @@ static int launch_ingest_t( x264hip_ctx *ctx, const PutDesc *descs_dev, const Pu
         aq_auto_kernel<<<n, 1024, 0, ctx->stream>>>( descs_dev, single, ctx->n_mb, p.aq_mode, p.aq_strength, ctx->luts_dev );
     aq_reduce_kernel<<<n, 1024, 0, ctx->stream>>>( descs_dev, single, ctx->n_mb );
     const int intra_wgs = ( ( ctx->n_mb + INTRA_BLOCKS_PER_WG - 1 ) / INTRA_BLOCKS_PER_WG + 7 ) / 8 * 8;
-    KPROF( X264HIP_KPROF_INTRA, n, ( intra_kernel<T><<<dim3( intra_wgs, 1, n ), 64, 0, ctx->stream>>>( P, descs_dev, single ) ) );
+    if( P.subme > 1 )
+        KPROF( X264HIP_KPROF_INTRA, n, ( intra_kernel<T, 10><<<dim3( intra_wgs, 1, n ), 64, 0, ctx->stream>>>( P, descs_dev, single ) ) );
+    else
+        KPROF( X264HIP_KPROF_INTRA, n, ( intra_kernel<T, 3><<<dim3( intra_wgs, 1, n ), 64, 0, ctx->stream>>>( P, descs_dev, single ) ) );
     HIPCK( hipGetLastError() );
     HIPCK( hipEventRecord( ctx->ev_ingest, ctx->stream ) );
     return X264HIP_OK;

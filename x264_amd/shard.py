@@ -557,7 +557,7 @@ class HipAdapter:
 
 
 def run_window_shard(torch, lib, dist, rank, world, dev_index, cfg, dev_clip, exchange_on_device, qp_offsets=False, broadcast_input=False, vbv=False,
-                     loopback=False):
+                     loopback=False, profile=False):
     """One pass of ONE stream over `world` ranks: returns (outputs on rank 0 | None, seconds, WindowShard.stats).
     dev_clip: [F, H, W] tensor of the whole clip resident on this rank's GPU (the same content on every rank), or, with
     broadcast_input, the clip on rank 0 and an uninitialised tensor of the same shape elsewhere: the pictures are then broadcast inside the
@@ -592,7 +592,8 @@ def run_window_shard(torch, lib, dist, rank, world, dev_index, cfg, dev_clip, ex
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        lib.search_profile(L, la.ctx_handle(), 1)  # HIP events around the search and cell launches of this pass (the work the shard spreads)
+        if profile:  # HIP events around the search and cell launches of this pass (the work the shard spreads): two events per launch and a
+            lib.search_profile(L, la.ctx_handle(), 1)  # stream sync per 1024 pairs -- not in a pass whose time is reported
         t0 = time.perf_counter()
         outs = None
         if rank == 0:
@@ -609,9 +610,10 @@ def run_window_shard(torch, lib, dist, rank, world, dev_index, cfg, dev_clip, ex
         dt = time.perf_counter() - t0
         if loopback:
             ws.loopback_verify(lambda: torch.cuda.synchronize())
-        ms_s, nl_s, n_s = lib.search_profile(L, la.ctx_handle(), -1)
-        ms_c, nl_c, n_c = lib.cell_profile(L, la.ctx_handle())
-        ws.stats.update(device_ms_searches=round(ms_s, 3), search_launches=nl_s, device_ms_cells=round(ms_c, 3), cell_launches=nl_c, cells_in_launches=n_c)
+        if profile:
+            ms_s, nl_s, n_s = lib.search_profile(L, la.ctx_handle(), -1)
+            ms_c, nl_c, n_c = lib.cell_profile(L, la.ctx_handle())
+            ws.stats.update(device_ms_searches=round(ms_s, 3), search_launches=nl_s, device_ms_cells=round(ms_c, 3), cell_launches=nl_c, cells_in_launches=n_c)
         counters = np.zeros(16, np.uint64)
         import ctypes as C
         lib._ck(L.x264hip_counters(la.ctx_handle(), counters.ctypes.data_as(C.c_void_p), 16), "counters")
