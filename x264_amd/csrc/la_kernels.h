@@ -576,7 +576,8 @@ __device__ __forceinline__ int intra_pred_px( const IntraEdges &E, int mode, int
 // the launch dispatch-bound (1.3 M workgroups for 160 frames of 1080p).
 // MODES (3: DC / H / V, subme <= 1; 10: all) is a template parameter and the mode loop is unrolled: every pass's case body is then
 // straight-line code and the LDS reads of the next mode are issued under the transform of the current one (INTRA_UNROLL=0: the loop as
-// a loop, one uniform switch per pass -- round 4's form, for A/B runs).
+// a loop, one uniform switch per pass -- round 4's form, for A/B runs: 0.526 ms against 0.336 ms for 160 frames of 1080p,
+// scripts/r05_intra.sh).
 #ifndef INTRA_UNROLL
 #define INTRA_UNROLL 1
 #endif

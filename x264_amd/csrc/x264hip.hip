@@ -913,7 +913,11 @@ static int prof_drain( x264hip_ctx *ctx )
         for( int i = 0; i < ctx->prof_used; i += 2 )
         {
             float ms = 0;
-            HIPCK( hipEventElapsedTime( &ms, ctx->prof_ev[i], ctx->prof_ev[i + 1] ) );
+            if( hipEventElapsedTime( &ms, ctx->prof_ev[i], ctx->prof_ev[i + 1] ) != hipSuccess )
+            {
+                (void)hipGetLastError(); // a pair whose second event was never recorded (its launch failed half way): not a measurement
+                continue;
+            }
             const int k = ctx->prof_n[i / 2];
             const int kind = i / 2 < (int)ctx->prof_kind.size() ? ctx->prof_kind[i / 2] : -1;
             if( kind >= 0 ) { ctx->kprof_ms[kind] += ms; ctx->kprof_launches[kind]++; ctx->kprof_units[kind] += (uint64_t)k; }
