@@ -635,6 +635,11 @@ int  x264hip_lookahead_reset( x264hip_lookahead *la ); /* start a new sequence o
 /* pictures put but not yet returned by get_frame (the lookahead's share of x264_encoder_delayed_frames, encoder.c:4480-4500) */
 int  x264hip_lookahead_delayed_frames( x264hip_lookahead *la );
 x264hip_ctx *x264hip_lookahead_ctx( x264hip_lookahead *la ); /* NULL for plugin backends */
+/* The cell classes ( cell_allowed[d0 * (bframes + 2) + d1] ) and field classes ( bit d - 1 of mask_l0 / mask_l1 ) the decisions of a
+ * lookahead with these parameters can ever ask for -- what x264hip_lookahead_open states to its context (x264hip_spec_classes).  Pure
+ * host arithmetic, no device: with B-pyramid a run of B-frames is always split at its middle frame (slicetype.c:1062-1095,
+ * :1120-1160, :1922-1933), which rules out most of the triangle for long runs. */
+int  x264hip_lookahead_classes( const x264hip_la_params *params, unsigned char *cell_allowed, unsigned *mask_l0, unsigned *mask_l1 );
 int  x264hip_lookahead_delay( x264hip_lookahead *la );       /* h->frames.i_delay */
 /* forced_type: X264_TYPE_AUTO (0) normally */
 int  x264hip_lookahead_put_frame( x264hip_lookahead *la, const void *luma, int stride, int is_device, int forced_type );

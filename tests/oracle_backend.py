@@ -27,6 +27,7 @@ class OracleBackend:
                                     do_edges=cfg.get("do_edges", 1))
         self.slots = {}
         self.n_eval = 0
+        self.requested = set()
         self.on_prefetch = None
         self.spec_used = self.searched_here = 0   # unweighted fields taken from the speculative store / searched by this backend itself
         # window shard (x264_amd/shard.py), mirroring the device context: fields known by name only (searched on the owner rank),
@@ -110,6 +111,7 @@ class OracleBackend:
         o, cfg = self.o, self.ocfg
         B, F0, F1 = self.slots[sb], self.slots[s0], self.slots[s1]
         self.n_eval += 1
+        self.requested.add((int(d0), int(d1)))  # the cell classes the decisions asked for (held against x264hip_lookahead_classes)
         if d0 == 0 and d1 == 0:
             lc, rows, rows_i, co = o.cell(cfg, B["planes"], None, None, 128, None, None, None, None, None, B["intra"], B["inv"],
                                           bool(with_intra), alias_intra=True)

@@ -114,6 +114,43 @@ def test_lookahead_matches_reference(preset, opts, over, depth, ckw, nf):
         assert np.array_equal(ca[m], ref["cost_aq"][k][:nb, :nb][m]), ("i_cost_est_aq", k, o.frame)
         assert np.array_equal(o.qp_offset, ref["qp_offset"][k]), ("f_qp_offset", k, o.frame, o.type)
     assert be.n_eval > (0 if cfg["rc_is_cqp"] else nf)  # constant QP: only the intra cells of weighted P candidates
+    _check_classes(cfg, be)
+
+
+def _check_classes(cfg, be):
+    """what x264hip_lookahead_open tells its device context about this flow (x264hip_lookahead_classes -> x264hip_spec_classes): every cell
+    the decisions asked the backend for lies inside it"""
+    ok, m0, m1 = lib.lookahead_classes(cfg)
+    outside = sorted(c for c in be.requested if not ok[c[0], c[1]])
+    assert not outside, ("cells the lookahead ruled out were requested", outside, cfg["bframes"], cfg["b_pyramid"], cfg["b_adapt"])
+    for d0, d1 in be.requested:
+        assert (not d0 or m0 >> (d0 - 1) & 1) and (not d1 or m1 >> (d1 - 1) & 1), (d0, d1, m0, m1)
+
+
+@pytest.mark.parametrize("b_adapt", [0, 1, 2])
+@pytest.mark.parametrize("bframes,pyr", [(2, 2), (3, 1), (3, 2), (4, 2), (5, 1), (6, 2), (7, 2), (8, 1), (8, 2), (16, 2), (5, 0)])
+def test_requested_cell_classes_stay_inside_the_statement(bframes, pyr, b_adapt):
+    """The lookahead states ahead of time which (d0, d1) cells its decisions can ask for (with B-pyramid: the middle frame of a run of
+    B-frames and pairs inside one half; slicetype.c:1062-1095, :1120-1160, :1922-1933) so that nothing else is speculated on the device.
+    Every request of whole runs over the oracle backend must lie inside, whatever the run lengths the content produces."""
+    W, H = 64, 48
+    nf = 44
+    seen = set()
+    for seed, ckw in ((5, dict(pan=(2, 1))), (6, dict(scene_cuts=(9, 30), fade=(14, 8, 0.6, 6))), (7, dict(pan=(0, 0), noise=2))):
+        cfg = lib.la_config(W, H, "medium", bframes=bframes, b_adapt=b_adapt, b_pyramid=pyr, rc_lookahead=20, keyint_max=60, frame_refs=6)
+        frames = make_clip(W, H, nf, seed=seed, **ckw)
+        be = OracleBackend(cfg)
+        la = lib.Lookahead(cfg, backend=be.struct)
+        try:
+            outs = la.run(frames)
+        finally:
+            la.close()
+        assert len(outs) == nf
+        _check_classes(cfg, be)
+        seen |= be.requested
+    if pyr and bframes >= 4:
+        ok, _, _ = lib.lookahead_classes(cfg)
+        assert ok.sum() < (bframes + 1) * (bframes + 2) // 2 + 1  # the statement does rule classes out
 
 
 @pytest.mark.parametrize("paced", [True, False])
@@ -227,6 +264,7 @@ def test_every_preset_and_tune(preset):
             la.close()
         assert [o.frame for o in outs] == list(ref["idx"]), (preset, tune)
         assert [o.type for o in outs] == list(ref["type"]), (preset, tune)
+        _check_classes(cfg, be)
         nb = cfg["bframes"] + 2
         for k, o in enumerate(outs):
             ce = np.array([[o.cost_est[i][j] for j in range(nb)] for i in range(nb)])

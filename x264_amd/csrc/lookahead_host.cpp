@@ -1180,6 +1180,41 @@ extern "C" int x264hip_lookahead_open_backend( x264hip_lookahead **out, const x2
     return X264HIP_OK;
 }
 
+/* The cell and field classes this flow can ask for under a configuration (what x264hip_lookahead_open states through
+ * x264hip_spec_classes; pure host arithmetic).  With B-pyramid every walk over a run of B-frames -- add_bframe_costs, mbtree_ops and the
+ * costs ahead of time -- splits the run at the same middle frame: between anchors `len` apart the middle frame sees
+ * ( len / 2, len - len / 2 ) and every other B-frame two references inside one half.  Everything else -- most of the triangle for long
+ * runs -- need never be speculated.  Without B-pyramid every B cell of the triangle can be asked for.  (Picture types forced by the
+ * caller can put a B-reference somewhere else; the cells that follow from it are then evaluated on demand, x264hip_spec_classes.) */
+extern "C" int x264hip_lookahead_classes( const x264hip_la_params *params, unsigned char *cell_allowed, unsigned *mask_l0, unsigned *mask_l1 )
+{
+    if( !params || !cell_allowed || !mask_l0 || !mask_l1 || params->dev.bframes < 0 || params->dev.bframes > X264HIP_BFRAME_MAX ) return X264HIP_EINVAL;
+    const int bf = params->dev.bframes, ns = bf + 2;
+    memset( cell_allowed, 0, (size_t)ns * ns );
+    unsigned l0 = 0, l1 = 0;
+    auto allow = [&]( int d0, int d1 ) {
+        cell_allowed[d0 * ns + d1] = 1;
+        if( d0 ) l0 |= 1u << ( d0 - 1 );
+        if( d1 ) l1 |= 1u << ( d1 - 1 );
+    };
+    allow( 0, 0 );
+    for( int d = 1; d <= bf + 1; d++ ) allow( d, 0 );
+    for( int len = 2; len <= bf + 1; len++ )
+    {
+        if( params->b_pyramid && len > 2 )
+        {
+            const int h0 = len / 2, h1 = len - len / 2;
+            allow( h0, h1 );
+            for( int k = 1; k < h0; k++ ) allow( k, h0 - k );
+            for( int k = 1; k < h1; k++ ) allow( k, h1 - k );
+        }
+        else
+            for( int k = 1; k < len; k++ ) allow( k, len - k );
+    }
+    *mask_l0 = l0; *mask_l1 = l1;
+    return X264HIP_OK;
+}
+
 extern "C" int x264hip_lookahead_open( x264hip_lookahead **out, int device, const x264hip_la_params *params )
 {
     if( !out || !params ) return X264HIP_EINVAL;
@@ -1193,25 +1228,12 @@ extern "C" int x264hip_lookahead_open( x264hip_lookahead **out, int device, cons
     rc = x264hip_lookahead_open_backend( out, &p, &be );
     if( rc ) { x264hip_close( ctx ); return rc; }
     ( *out )->L.ctx = ctx;
-    if( p.b_pyramid && p.dev.bframes > 1 )
     {
-        // The cells this flow can ask for (add_bframe_costs, mbtree_ops and the costs ahead of time all split a run of B-frames at the
-        // same middle frame): between anchors `len` apart the middle frame sees ( len / 2, len - len / 2 ) and every other B-frame
-        // two references inside one half.  Everything else -- most of the triangle for long runs -- need never be speculated.
-        const int bf = p.dev.bframes, ns = bf + 2;
-        std::vector<unsigned char> ok( (size_t)ns * ns, 0 );
-        unsigned l1 = 0;
-        auto allow = [&]( int d0, int d1 ) { ok[d0 * ns + d1] = 1; if( d1 ) l1 |= 1u << ( d1 - 1 ); };
-        allow( 0, 0 );
-        for( int d = 1; d <= bf + 1; d++ ) allow( d, 0 );
-        for( int len = 2; len <= bf + 1; len++ )
-        {
-            const int h0 = len > 2 ? len / 2 : len, h1 = len > 2 ? len - len / 2 : len;
-            if( len > 2 ) allow( h0, h1 );
-            for( int k = 1; k < h0; k++ ) allow( k, h0 - k );
-            for( int k = 1; k < h1; k++ ) allow( k, h1 - k );
-        }
-        x264hip_spec_classes( ctx, ok.data(), ~0u, l1 );
+        const int ns = p.dev.bframes + 2;
+        std::vector<unsigned char> ok( (size_t)ns * ns );
+        unsigned l0 = 0, l1 = 0;
+        x264hip_lookahead_classes( &p, ok.data(), &l0, &l1 );
+        x264hip_spec_classes( ctx, ok.data(), l0, l1 );
     }
     return X264HIP_OK;
 }

@@ -692,6 +692,18 @@ def make_la_params(cfg, cost_mv=None, max_frames=0):
     return p
 
 
+def lookahead_classes(cfg):
+    """x264hip_lookahead_classes: (cell_allowed[ns][ns] uint8, mask_l0, mask_l1) -- the cell / field classes the decisions of a lookahead
+    with this configuration can ever ask for (pure host arithmetic, no device)"""
+    L = load()
+    p = make_la_params(cfg)
+    ns = cfg["bframes"] + 2
+    ok = np.zeros((ns, ns), np.uint8)
+    m0, m1 = C.c_uint(0), C.c_uint(0)
+    _ck(L.x264hip_lookahead_classes(C.byref(p), _p(ok), C.byref(m0), C.byref(m1)), "lookahead_classes")
+    return ok, m0.value, m1.value
+
+
 class Lookahead:
     """x264hip_lookahead: put frames in display order, get frames back in coded order with their types."""
 
