@@ -237,14 +237,17 @@ def test_every_form_of_the_search_kernel_gives_the_same_lookahead():
     ctx = mp.get_context("spawn")
     got = {}
     for name, env in (("default", {}), ("rows", {"X264HIP_SEARCH": "rows"}),
-                      ("latency", {"X264HIP_LAT_WAVES": "1000000"}), ("split ingest", {"X264HIP_INGEST": "split"})):
+                      ("latency", {"X264HIP_LAT_WAVES": "1000000"}), ("split ingest", {"X264HIP_INGEST": "split"}),
+                      ("mbtree lists in LDS", {"X264HIP_MBT": "lds"}), ("mbtree per level", {"X264HIP_MBT": "levels"})):
         q = ctx.Queue()
         p = ctx.Process(target=_kernel_form_worker, args=(env, q))
         p.start()
         got[name] = q.get(timeout=600)
         p.join(timeout=120)
         assert p.exitcode == 0, name
-    for name in ("rows", "latency", "split ingest"):  # the last: planes + strip copy from two kernels instead of lowres_tiles_kernel
+    # split ingest: planes + strip copy from two kernels instead of lowres_tiles_kernel; the MB-tree forms: every queued list on one workgroup
+    # with its accumulators in LDS / a launch per level instead of counter barriers (f_qp_offset is part of what is compared)
+    for name in ("rows", "latency", "split ingest", "mbtree lists in LDS", "mbtree per level"):
         assert got[name] == got["default"], name
 
 

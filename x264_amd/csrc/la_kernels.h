@@ -1993,18 +1993,32 @@ __global__ __launch_bounds__( 256 ) void mbtree_level_kernel( LaP P, const MbtOp
 // flight.  The host maps the accumulators of the call onto the LDS slots (least-recently-used; MBT_LDS_LOAD / MBT_LDS_STORE steps
 // move an accumulator in and out) and writes every touched accumulator back at the end, so the global buffers hold what the
 // multi-workgroup kernel would have left there.
+//
+// Round 5: the lists of a launch side by side, list g on workgroup g (x264hip.hip, the queued form).  What counts there is not the latency
+// of a call -- the lists run beside the searches, nothing waits for them -- but what they take from the searches: a list on the
+// multi-workgroup kernel holds its CUs for milliseconds (every step a round of returning global atomics and a barrier through memory),
+// here for a few hundred microseconds, and the L2's atomic units stay out of it.
 #define MBT_LDS_UNROLL 8
-__global__ __launch_bounds__( 1024 ) void mbtree_lds_kernel( LaP P, const MbtOpDev *ops, int n_ops, const AqLuts *luts )
+__global__ __launch_bounds__( 1024 ) void mbtree_lds_kernel( LaP P, const MbtOpDev *ops, MbtGroups G, const AqLuts *luts )
 {
     extern __shared__ __attribute__( ( aligned( 16 ) ) ) int mbt_acc[];
     const int W = P.mb_w, H = P.mb_h, n_mb = W * H;
     const int tid = threadIdx.x, NT = blockDim.x;
-    for( int k = 0; k < n_ops; k++ )
+    const int k_end = G.beg[blockIdx.x + 1];
+    for( int k = G.beg[blockIdx.x]; k < k_end; k++ )
     {
         const MbtOpDev o = ops[k];
         int *A_b = mbt_acc + o.lds_b * n_mb, *A_p0 = mbt_acc + o.lds_p0 * n_mb, *A_p1 = mbt_acc + o.lds_p1 * n_mb;
+        if( o.type == MBT_NOP )
+            continue; // (uniform: nothing was written, no barrier needed)
         if( o.type == 0 )
-            for( int i = tid; i < n_mb; i += NT ) A_b[i] = 0;
+        {
+            // lds_b < 0: an accumulator that never entered LDS (a frame nothing refers to): its global buffer is cleared for later readers
+            if( o.lds_b < 0 )
+                for( int i = tid; i < n_mb; i += NT ) o.prop_b[i] = 0;
+            else
+                for( int i = tid; i < n_mb; i += NT ) A_b[i] = 0;
+        }
         else if( o.type == MBT_LDS_LOAD )
             for( int i = tid; i < n_mb; i += NT ) A_b[i] = o.prop_b[i];
         else if( o.type == MBT_LDS_STORE )
@@ -2041,7 +2055,7 @@ __global__ __launch_bounds__( 1024 ) void mbtree_lds_kernel( LaP P, const MbtOpD
                 }
             }
         }
-        else
+        else if( o.type == 2 )
         {
             for( int i = tid; i < n_mb; i += NT )
             {

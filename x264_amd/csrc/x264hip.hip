@@ -214,6 +214,7 @@ struct x264hip_ctx
     uint32_t field_spec[2][X264HIP_BFRAME_MAX + 1] = { { 0 } };  // speculative searches / cells per class (X264HIP_TRACE_CLASSES prints them next to the requests)
     uint32_t cell_spec[( X264HIP_BFRAME_MAX + 2 ) * ( X264HIP_BFRAME_MAX + 2 )] = { 0 };
     uint32_t n_requests = 0;
+    bool mbt_q_lds = false;           // the lists queued for the next MB-tree launch are in the one-workgroup LDS form (mbtree_lds_kernel)
     static const uint32_t LEARN_REQUESTS = 400;
     // ... and what the caller can say ahead of time about its flow (x264hip_spec_classes): classes outside these are never speculated
     uint8_t cell_allowed[( X264HIP_BFRAME_MAX + 2 ) * ( X264HIP_BFRAME_MAX + 2 )];
@@ -1677,8 +1678,21 @@ static int mbt_flush( x264hip_ctx *ctx )
     // wave slots on a chip full of search waves that live for a millisecond, thirty times per flush, where the barrier form takes its
     // CUs once; one context alone: 19 900 either way.  (No MB-tree at all: 36 100 / 27 800 -- the propagation is a tenth of the device work.)
     static const bool spin_form = !( getenv( "X264HIP_MBT" ) && !strcmp( getenv( "X264HIP_MBT" ), "levels" ) );
+    const bool lds_form = ctx->mbt_q_lds;
+    ctx->mbt_q_lds = false;
     if( skip_kernel )
         ;
+    else if( lds_form )
+    {
+        static bool attr_set = false;
+        if( !attr_set )
+        {
+            HIPCK( hipFuncSetAttribute( (const void *)mbtree_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 ) );
+            attr_set = true;
+        }
+        const int lds_slots = std::min( 6, (int)( ( 156 * 1024 ) / ( (size_t)ctx->n_mb * sizeof( int ) ) ) );
+        mbtree_lds_kernel<<<G.n, 1024, (size_t)lds_slots * ctx->n_mb * sizeof( int ), ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], G, ctx->luts_dev );
+    }
     else if( spin_form )
         mbtree_kernel<<<G.n * mbt_wgs, mbt_threads, 0, ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], G, mbt_wgs, ctx->luts_dev,
                                                                         ctx->mbt_bar + (size_t)r * MBT_MAX_GROUPS * 4,
@@ -1829,6 +1843,118 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
             if( rc ) return rc;
         }
         MbtOpDev *dh = ctx->mbt_host[ctx->mbt_q_ring] + ctx->mbt_q.beg[bank];
+        // The form of the launch: every list on several workgroups that meet at counter barriers and add into the bank with global atomics
+        // (mbtree_kernel, the default), or on ONE workgroup with the accumulators in play in LDS (mbtree_lds_kernel, X264HIP_MBT=lds;
+        // pictures whose accumulators fit three at a time: the two anchors of a mini-GOP and its B-reference).  Measured, 1080p slow+dia
+        // (scripts/r05_mbt_lds.sh, two runs each): eight contexts 37 200 / 36 100 frames/s in LDS against 36 100 / 38 000, one context
+        // 26 900 / 27 000 against 27 700 / 27 800 -- the lists take a tenth of the device whichever way they are walked (18 M macroblock
+        // steps per 160-frame pass, each a round trip with a handful of instructions behind it: what they cost is the registers and wave
+        // slots they hold while they wait), and one workgroup per list is the longer chain for the one stream that ends on it.
+        static const bool want_lds = getenv( "X264HIP_MBT" ) && !strcmp( getenv( "X264HIP_MBT" ), "lds" );
+        const int lds_slots = std::min( 6, (int)( ( 156 * 1024 ) / ( (size_t)ctx->n_mb * sizeof( int ) ) ) );
+        const bool in_lds = want_lds && lds_slots >= 3 && ( ctx->mbt_q.n == 0 || ctx->mbt_q_lds );
+        if( in_lds )
+        {
+            // steps in the caller's order; accumulators (identified by their buffer in the bank) mapped onto LDS slots, least recently
+            // used out.  A cleared accumulator costs nothing until a step adds to it (then its slot is cleared in LDS); one that never
+            // enters LDS -- a frame nothing refers to -- has its buffer cleared at the end, for whoever reads it afterwards.
+            std::vector<MbtOpDev> L;
+            std::vector<int *> held( lds_slots, nullptr ), zero_pending;
+            std::vector<int> stamp( lds_slots, 0 );
+            std::vector<std::pair<int, int>> fin;
+            int clock = 0;
+            auto find = [&]( int *acc ) { for( int c = 0; c < lds_slots; c++ ) if( held[c] == acc ) return c; return -1; };
+            auto move_op = [&]( int type, int *acc, int slot ) {
+                MbtOpDev d;
+                memset( &d, 0, sizeof( d ) );
+                d.type = type; d.prop_b = acc; d.lds_b = slot;
+                L.push_back( d );
+            };
+            auto hold = [&]( int *acc, int pin0, int pin1 ) {
+                int c = find( acc );
+                if( c < 0 )
+                {
+                    for( int q = 0; q < lds_slots && c < 0; q++ )
+                        if( !held[q] && q != pin0 && q != pin1 ) c = q;
+                    for( int q = 0; q < lds_slots && !( c >= 0 && !held[c] ); q++ )
+                        if( held[q] && q != pin0 && q != pin1 && ( c < 0 || stamp[q] < stamp[c] ) ) c = q;
+                    if( held[c] ) move_op( MBT_LDS_STORE, held[c], c );
+                    held[c] = acc;
+                    auto z = std::find( zero_pending.begin(), zero_pending.end(), acc );
+                    if( z != zero_pending.end() )
+                    {
+                        zero_pending.erase( z );
+                        move_op( X264HIP_MBT_ZERO, acc, c );
+                    }
+                    else
+                        move_op( MBT_LDS_LOAD, acc, c );
+                }
+                stamp[c] = ++clock;
+                return c;
+            };
+            for( int i = 0; i < n; i++ )
+            {
+                const x264hip_mbtree_op &o = ops[i];
+                FrameSlot &b = ctx->slots[o.slot_b];
+                int *acc_b = mbt_bank_acc( ctx, bank, o.slot_b );
+                if( o.type == X264HIP_MBT_ZERO )
+                {
+                    b.prop_view = acc_b; // the frame's accumulator is what this list leaves in its bank
+                    const int c = find( acc_b );
+                    if( c >= 0 ) move_op( X264HIP_MBT_ZERO, acc_b, c );
+                    else if( std::find( zero_pending.begin(), zero_pending.end(), acc_b ) == zero_pending.end() ) zero_pending.push_back( acc_b );
+                    continue;
+                }
+                MbtOpDev d;
+                memset( &d, 0, sizeof( d ) );
+                d.type = o.type; d.referenced = o.referenced; d.bipred_weight = o.bipred_weight; d.fps_factor_i = o.fps_factor_i;
+                d.fps_factor = o.fps_factor; d.weightdelta = o.weightdelta; d.strength = o.strength;
+                d.b_bidir = o.dist_p1 > 0;
+                d.prop_b = acc_b; d.prop_p0 = mbt_bank_acc( ctx, bank, o.slot_p0 ); d.prop_p1 = mbt_bank_acc( ctx, bank, o.slot_p1 );
+                d.intra_cost = b.lowres_costs; d.inv_qscale = b.inv_qscale;
+                d.qp_aq = b.qp_aq; d.qp = b.qp;
+                d.lowres_costs = b.lowres_costs + (size_t)b.cell_at[o.dist_p0 * nstride + o.dist_p1] * ctx->n_mb;
+                if( o.type == X264HIP_MBT_FINISH )
+                {
+                    d.lds_b = hold( acc_b, -1, -1 );
+                    fin.push_back( std::make_pair( o.slot_b, (int)L.size() ) );
+                }
+                else
+                {
+                    d.mvq0 = b.mvq[0][o.dist_p0 - 1];
+                    d.mvq1 = o.dist_p1 > 0 ? b.mvq[1][o.dist_p1 - 1] : nullptr;
+                    int kb = -1;
+                    if( o.referenced ) kb = hold( acc_b, -1, -1 ); // its own total is read; an unreferenced B-frame has none
+                    const int k0 = hold( d.prop_p0, kb, -1 );
+                    const int k1 = d.b_bidir ? hold( d.prop_p1, kb, k0 ) : k0;
+                    d.lds_b = kb < 0 ? 0 : kb; d.lds_p0 = k0; d.lds_p1 = k1;
+                }
+                L.push_back( d );
+            }
+            for( int c = 0; c < lds_slots; c++ )
+                if( held[c] ) move_op( MBT_LDS_STORE, held[c], c );
+            for( int *acc : zero_pending )
+                move_op( X264HIP_MBT_ZERO, acc, -1 );
+            if( ctx->mbt_q.beg[bank] + (int)L.size() <= x264hip_ctx::MBT_CAP )
+            {
+                memcpy( dh, L.data(), L.size() * sizeof( MbtOpDev ) );
+                for( const auto &f : fin ) // ( frame slot, index of its FINISH step in the launch's table )
+                    ctx->mbt_q_finished.push_back( std::make_pair( f.first, ctx->mbt_q.beg[bank] + f.second ) );
+                ctx->mbt_q_lds = true;
+                ctx->mbt_q.beg[bank + 1] = ctx->mbt_q.beg[bank] + (int)L.size();
+                ctx->mbt_q.n = bank + 1;
+                return X264HIP_OK;
+            }
+            if( bank != 0 )
+            {
+                // the list with its moves does not fit behind the ones queued: they go first, this call starts the next launch
+                int rc = mbt_flush_at( ctx, __LINE__ );
+                if( rc ) return rc;
+                return x264hip_mbtree( ctx, ops, n );
+            }
+            // (a single list too long for the table with its moves: the multi-workgroup form below takes it as it is)
+        }
+        ctx->mbt_q_lds = false;
         // Step order on the device: every ZERO first (a buffer is always cleared before anything is added to it in the
         // reference's order too), then the rest in order.  A barrier is only needed where a step reads what earlier
         // steps accumulated: referenced PROPAGATEs and FINISH; runs of B-frame propagations overlap freely.
@@ -2015,7 +2141,10 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
                 attr_set = true;
             }
             HIPCK( upload_async( ctx, ctx->mbt_dev[r], dh, L.size() * sizeof( MbtOpDev ), ctx->stream2 ) );
-            mbtree_lds_kernel<<<1, 1024, (size_t)lds_slots * ctx->n_mb * sizeof( int ), ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], (int)L.size(), ctx->luts_dev );
+            MbtGroups G1;
+            memset( &G1, 0, sizeof( G1 ) );
+            G1.n = 1; G1.beg[1] = (int)L.size();
+            mbtree_lds_kernel<<<1, 1024, (size_t)lds_slots * ctx->n_mb * sizeof( int ), ctx->stream2>>>( ctx->P, ctx->mbt_dev[r], G1, ctx->luts_dev );
             HIPCK( hipGetLastError() );
             done_in_lds = true;
         }
