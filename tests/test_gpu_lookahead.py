@@ -238,7 +238,8 @@ def test_every_form_of_the_search_kernel_gives_the_same_lookahead():
     got = {}
     for name, env in (("default", {}), ("rows", {"X264HIP_SEARCH": "rows"}),
                       ("latency", {"X264HIP_LAT_WAVES": "1000000"}), ("split ingest", {"X264HIP_INGEST": "split"}),
-                      ("mbtree lists in LDS", {"X264HIP_MBT": "lds"}), ("mbtree per level", {"X264HIP_MBT": "levels"})):
+                      ("mbtree lists in LDS", {"X264HIP_MBT": "lds"}), ("mbtree per level", {"X264HIP_MBT": "levels"}),
+                      ("mbtree in small workgroups", {"X264HIP_MBT_THREADS": "256", "X264HIP_MBT_WGS": "3"})):
         q = ctx.Queue()
         p = ctx.Process(target=_kernel_form_worker, args=(env, q))
         p.start()
@@ -247,7 +248,7 @@ def test_every_form_of_the_search_kernel_gives_the_same_lookahead():
         assert p.exitcode == 0, name
     # split ingest: planes + strip copy from two kernels instead of lowres_tiles_kernel; the MB-tree forms: every queued list on one workgroup
     # with its accumulators in LDS / a launch per level instead of counter barriers (f_qp_offset is part of what is compared)
-    for name in ("rows", "latency", "split ingest", "mbtree lists in LDS", "mbtree per level"):
+    for name in ("rows", "latency", "split ingest", "mbtree lists in LDS", "mbtree per level", "mbtree in small workgroups"):
         assert got[name] == got["default"], name
 
 

@@ -1818,7 +1818,9 @@ __device__ __forceinline__ void mbt_propagate_mb( const MbtOpDev &o, int *ref0, 
     }
 }
 
+#ifndef MBT_UNROLL
 #define MBT_UNROLL 4
+#endif
 #define MBT_WGS 4   // workgroups per list at most (x264hip.hip: mbt_wgs_per_list)
 #define MBT_THREADS 1024
 #define MBT_MAX_GROUPS 48

@@ -1664,7 +1664,13 @@ static int mbt_flush( x264hip_ctx *ctx )
     const MbtGroups G = ctx->mbt_q;
     ctx->mbt_q.n = 0; ctx->mbt_q.beg[0] = 0; ctx->mbt_q_ring = -1;
     ctx->mbt_q_finished.clear();
-    static const int mbt_threads = getenv( "X264HIP_MBT_THREADS" ) ? std::max( 64, std::min( 1024, atoi( getenv( "X264HIP_MBT_THREADS" ) ) & ~63 ) ) : MBT_THREADS;
+    // Threads per workgroup: a list alone on the device wants its steps short (1024 threads: a step of 1080p is two rounds of loads); beside
+    // the searches of several contexts what counts is how little a waiting list holds.  Measured, 1080p slow+dia, 40 timed steps
+    // (scripts/r05_mbt_shape2.sh): eight contexts 38 000 frames/s at 1024, 38 400 at 512, 38 800 at 256; one context 27 800 / 26 500 /
+    // 23 500.  (No MB-tree at all: 40 700 -- the propagation costs the full device 6 %.)
+    static const int forced_threads = getenv( "X264HIP_MBT_THREADS" ) ? std::max( 64, std::min( 1024, atoi( getenv( "X264HIP_MBT_THREADS" ) ) & ~63 ) ) : 0;
+    const int open_contexts = std::max( 1, g_open_contexts[ctx->device & 63].load() );
+    const int mbt_threads = forced_threads ? forced_threads : open_contexts >= 4 ? 256 : open_contexts >= 2 ? 512 : MBT_THREADS;
     const int mbt_wgs = mbt_wgs_per_list( ctx, G.n );
     // inputs come from the main stream (cells, clamp kernels): order the MB-tree stream behind it
     HIPCK( hipEventRecord( ctx->ev_cross, ctx->stream ) );
