@@ -286,6 +286,90 @@ def test_me_search_batch(depth):
 
 
 @pytest.mark.parametrize("depth", [8, 10])
+def test_exhaustive_searches_wave_form_equals_scalar_form(depth):
+    """ESA / TESA requests run one per WAVE on the device (64 candidates per step, ordered compaction of the ads survivors, the SAD
+    stage's running thresholds as a prefix minimum across the lanes, rows loaded 16 / 8 samples at a time); the same header compiled for
+    the host runs them one candidate after the other (tests/tools/block_metrics_host.cpp, pinned to the recorded reference calls by
+    tests/test_me_full_host.py).  1 400 random requests -- every partition size, ranges 8 / 16 / 24, predictors all over the window
+    including its edges -- must give the same vector, cost and cost_mv both ways."""
+    import ctypes as C
+    import torch
+    from tests.test_block_metrics_host import _lib
+    from tests.test_me_full_host import MfHostReq, request_geometry
+    from tests.common import ME_SIZES
+    z = np.load(os.path.join(GOLD, "me_full_d%d.npz" % depth))
+    W, H, pw, ph, padh, padv, mv_range = (int(v) for v in z["geom"])
+    dt = np.uint8 if depth == 8 else np.uint16
+    vdt = np.uint8 if depth == 8 else np.int16
+    isz = 1 if depth == 8 else 2
+    hplanes = [np.ascontiguousarray(z["planes"][p]) for p in range(4)]
+    hframe = np.ascontiguousarray(z["fenc_frame"], dt)
+    hint = np.ascontiguousarray(z["integral"])
+    cost_mv = np.ascontiguousarray(z["cost_mv"])
+    centre = (cost_mv.size - 1) // 2
+    L = _lib()
+    fn = L.mf_host_u8 if depth == 8 else L.mf_host_u16
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(900 + depth)
+    reqs, want = [], []
+    for t in range(1400):
+        i_pixel = int(rng.integers(0, 7))
+        bw, bh = ME_SIZES[i_pixel]
+        mb_x, mb_y = int(rng.integers(0, W // 16)), int(rng.integers(0, H // 16))
+        xoff, yoff = int(rng.integers(0, 16 // bw)) * bw, int(rng.integers(0, 16 // bh)) * bh
+        me = 3 + (t & 1)
+        subme = int(rng.choice([1, 2, 5, 7]))
+        me_range = int(rng.choice([8, 16, 16, 24]))
+        call = [i_pixel, mb_x, mb_y, xoff, yoff]
+        smin, smax, lim_min, lim_max, sx, sy, org = request_geometry(z["geom"], call)
+        mvp = [int(rng.integers(smin[k], smax[k] + 1)) for k in range(2)]
+        n_mvc = int(rng.integers(0, 5))
+        mvc = np.zeros((4, 2), np.int16)
+        for i in range(n_mvc):
+            mvc[i] = [int(rng.integers(smin[k] - 8, smax[k] + 9)) for k in range(2)]
+        m = MfHostReq()
+        m.i_pixel, m.me_method, m.subpel_refine, m.me_range = i_pixel, me, subme, me_range
+        m.mbcmp_satd, m.fpelcmp_satd = 1, int(me == 4)
+        m.fenc = hframe.ctypes.data + (sy * hframe.shape[1] + sx) * hframe.itemsize
+        m.fenc_stride = hframe.shape[1]
+        for p_ in range(4):
+            m.ref[p_] = hplanes[p_].ctypes.data + org * hplanes[p_].itemsize
+        m.stride = pw
+        m.integral = hint.ctypes.data + org * 2
+        m.integral_lower = ph * pw
+        m.cost_mv = cost_mv.ctypes.data + 2 * centre
+        q = lib.MeRequest()
+        q.i_pixel, q.me_method, q.subpel_refine, q.me_range = i_pixel, me, subme, me_range
+        q.mbcmp_satd, q.fpelcmp_satd = 1, int(me == 4)
+        q.x, q.y = sx, sy
+        for k in range(2):
+            m.mvp[k] = q.mvp[k] = mvp[k]
+            m.spel_min[k] = q.spel_min[k] = smin[k]; m.spel_max[k] = q.spel_max[k] = smax[k]
+            m.lim_min[k] = q.lim_min[k] = lim_min[k]; m.lim_max[k] = q.lim_max[k] = lim_max[k]
+        q.n_mvc = n_mvc
+        for i in range(4):
+            q.mvc[i][0], q.mvc[i][1] = int(mvc[i][0]), int(mvc[i][1])
+        out = np.zeros(4, np.int32)
+        fn(C.byref(m), mvc.ctypes.data, n_mvc, out.ctypes.data)
+        reqs.append(q); want.append((out.copy(), subme))
+    planes = [torch.from_numpy(hplanes[p_].view(vdt)).cuda() for p_ in range(4)]
+    frame = torch.from_numpy(hframe.view(vdt)).cuda()
+    integral = torch.from_numpy(hint.view(np.int16)).cuda()
+    cmv = torch.from_numpy(cost_mv.view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    org0 = padv * pw + padh
+    ctx = lib.Context(64, 64, bit_depth=depth, max_frames=2, mv_range=32)
+    try:
+        got = ctx.me_search_batch(reqs, frame.data_ptr(), frame.shape[1], [p_.data_ptr() + org0 * isz for p_ in planes], pw,
+                                  integral.data_ptr() + org0 * 2, ph * pw, cmv.data_ptr() + 2 * centre)
+    finally:
+        ctx.close()
+    for k, (w, subme) in enumerate(want):
+        n = 4 if subme >= 2 else 3
+        assert np.array_equal(got[k][:n], w[:n]), (k, reqs[k].me_method, reqs[k].i_pixel, reqs[k].me_range, got[k].tolist(), w.tolist())
+
+
+@pytest.mark.parametrize("depth", [8, 10])
 def test_integral_init(depth):
     """x264hip_integral_init against the integral planes the reference built (x264_frame_filter, recorded in the golden file) and
     against plain box sums; then the TESA requests of the recording run on the DEVICE-built planes."""

@@ -51,16 +51,38 @@ BM_HD int mf_sad( const T *a, int sa, const T *b, int sb, int w, int h )
 #if defined( __HIP_DEVICE_COMPILE__ )
     if( sizeof( T ) == 1 )
     {
-        // four samples per load and per v_sad_u8 (every partition width is a multiple of four)
+        // A row per load where the row is 16 or 8 samples (one dwordx4 / dwordx2 at any byte alignment), four samples per v_sad_u8.  The
+        // load count is what these searches cost: a lane's candidate is its own address, and the L1's address unit takes 17-53 cycles per
+        // wave-load whatever its width (experiments/mem_rates) -- 16 row loads per 16x16 candidate instead of 64 dword loads.
+        typedef uint32_t u32x4_u __attribute__( ( ext_vector_type( 4 ), aligned( 1 ) ) );
+        typedef uint32_t u32x2_u __attribute__( ( ext_vector_type( 2 ), aligned( 1 ) ) );
         unsigned acc = 0;
-        for( int y = 0; y < h; y++ )
-            for( int x = 0; x < w; x += 4 )
+        if( w == 16 )
+        {
+            for( int y = 0; y < h; y++ )
             {
-                uint32_t wa, wb;
-                __builtin_memcpy( &wa, a + y*sa + x, 4 );
-                __builtin_memcpy( &wb, b + y*sb + x, 4 );
-                acc = __builtin_amdgcn_sad_u8( wa, wb, acc );
+                const u32x4_u wa = *(const u32x4_u *)( a + y*sa ), wb = *(const u32x4_u *)( b + y*sb );
+                acc = __builtin_amdgcn_sad_u8( wa.x, wb.x, acc ); acc = __builtin_amdgcn_sad_u8( wa.y, wb.y, acc );
+                acc = __builtin_amdgcn_sad_u8( wa.z, wb.z, acc ); acc = __builtin_amdgcn_sad_u8( wa.w, wb.w, acc );
             }
+            return (int)acc;
+        }
+        if( w == 8 )
+        {
+            for( int y = 0; y < h; y++ )
+            {
+                const u32x2_u wa = *(const u32x2_u *)( a + y*sa ), wb = *(const u32x2_u *)( b + y*sb );
+                acc = __builtin_amdgcn_sad_u8( wa.x, wb.x, acc ); acc = __builtin_amdgcn_sad_u8( wa.y, wb.y, acc );
+            }
+            return (int)acc;
+        }
+        for( int y = 0; y < h; y++ )
+        {
+            uint32_t wa, wb;
+            __builtin_memcpy( &wa, a + y*sa, 4 );
+            __builtin_memcpy( &wb, b + y*sb, 4 );
+            acc = __builtin_amdgcn_sad_u8( wa, wb, acc );
+        }
         return (int)acc;
     }
 #endif
@@ -197,6 +219,8 @@ struct CoopNone
     BM_HD unsigned long long ballot( bool p ) const { return p ? 1ull : 0ull; }
     BM_HD unsigned long long max64( unsigned long long v ) const { return v; }
     BM_HD int bcast( int v, int ) const { return v; }
+    // before = the smallest v among the lanes in front of this one (none here), all = the smallest v of all lanes
+    BM_HD void min_scan( int v, int &before, int &all ) const { before = 1 << 28; all = v; }
     BM_HD void sync() const {}
     BM_HD int16_t *xs() { return xs_; }
 };
@@ -523,9 +547,28 @@ __device__ __forceinline__ void mef_esa_scan_wave( Mef<T, true> *s, int min_x, i
         int acc = 0;
 #pragma unroll
         for( int y = 0; y < BH; y++ )
+        {
+            // (the row in one load where it is 16 or 8 bytes: see mf_sad)
+            if constexpr( sizeof( T ) == 1 && BW == 16 )
+            {
+                typedef uint32_t u32x4_u __attribute__( ( ext_vector_type( 4 ), aligned( 1 ) ) );
+                const u32x4_u w = *(const u32x4_u *)( b + (long)y * p->stride );
+                acc = (int)__builtin_amdgcn_sad_u8( fe[y][0].raw, w.x, (unsigned)acc ); acc = (int)__builtin_amdgcn_sad_u8( fe[y][1].raw, w.y, (unsigned)acc );
+                acc = (int)__builtin_amdgcn_sad_u8( fe[y][2].raw, w.z, (unsigned)acc ); acc = (int)__builtin_amdgcn_sad_u8( fe[y][3].raw, w.w, (unsigned)acc );
+            }
+            else if constexpr( sizeof( T ) == 1 && BW == 8 )
+            {
+                typedef uint32_t u32x2_u __attribute__( ( ext_vector_type( 2 ), aligned( 1 ) ) );
+                const u32x2_u w = *(const u32x2_u *)( b + (long)y * p->stride );
+                acc = (int)__builtin_amdgcn_sad_u8( fe[y][0].raw, w.x, (unsigned)acc ); acc = (int)__builtin_amdgcn_sad_u8( fe[y][1].raw, w.y, (unsigned)acc );
+            }
+            else
+            {
 #pragma unroll
-            for( int k = 0; k < BW / 4; k++ )
-                acc += sad_partial_px4( fe[y][k], load_px4( b + (long)y * p->stride + 4 * k ), (const T *)nullptr );
+                for( int k = 0; k < BW / 4; k++ )
+                    acc += sad_partial_px4( fe[y][k], load_px4( b + (long)y * p->stride + 4 * k ), (const T *)nullptr );
+            }
+        }
         const int c = acc + p->cost_mv[4 * ( min_x + col ) - p->mvp[0]] + p->cost_mv[4 * ( min_y + row ) - p->mvp[1]];
         const unsigned key = mef_wave_min_u32( base + lane < total ? ( (unsigned)c << 6 ) | (unsigned)lane : 0xFFFFFFFFu );
         const int cmin = (int)( key >> 6 );
@@ -868,21 +911,28 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
                         sad_mine = mf_sad( p->fenc, p->fenc_stride, p->ref[0] + (long)my * p->stride + min_x + xs[i], p->stride, s->bw, s->bh ) +
                                    p->cost_mv[4 * xs[i] - p->mvp[0]];
                     }
-                    const int n_chunk = xn - base < Coop::W ? xn - base : Coop::W;
-                    for( int k = 0; k < n_chunk; k++ )
+                    // The reference walks the chunk in order: a candidate stays if its SAD is below sad_thresh / 8 of the best SAD so far, and
+                    // becomes the best if it is below that.  sad_thresh / 8 >= 1.25, so whatever does not stay cannot be a new best either:
+                    // "the best so far" in front of candidate k is the minimum of bsad and of EVERY SAD in front of it -- a prefix minimum
+                    // across the lanes -- and the places of those that stay follow from a ballot, as in the ads stage.  (Lane after lane through
+                    // a broadcast this loop was a chain of ~500 LDS round trips per search.)
+                    int before, chunk_best;
+                    coop.min_scan( sad_mine, before, chunk_best );
+                    const int best_before = before < bsad ? before : bsad;
+                    const bool stay = i < xn && sad_mine < ( best_before * sad_thresh >> 3 );
+                    const unsigned long long m = coop.ballot( stay );
+                    if( stay )
                     {
-                        const int sad = coop.bcast( sad_mine, k );
-                        if( sad < bsad * sad_thresh >> 3 )
-                        {
-                            if( sad < bsad ) bsad = sad;
-                            mvsads[nmvsad].sad = sad + ycost; mvsads[nmvsad].mx = min_x + xs[base + k]; mvsads[nmvsad].my = my;
-                            nmvsad++;
-                        }
+                        const int at = nmvsad + mf_popc64( m & ( ( 1ull << coop.lane() ) - 1 ) );
+                        mvsads[at].sad = sad_mine + ycost; mvsads[at].mx = min_x + xs[i]; mvsads[at].my = my;
                     }
+                    nmvsad += mf_popc64( m );
+                    if( chunk_best < bsad ) bsad = chunk_best;
                 }
                 bsad += ycost;
             }
             // the survivors are thinned to half the range's worth before their full costs are taken (me.c:704-752)
+            coop.sync(); // the list was written a lane per entry
             nmvsad = mf_thin_survivors( coop, mvsads, nmvsad, bsad, bsad * sad_thresh >> 3, me_range >> 1 );
             for( int i = 0; i < nmvsad; i++ )
                 mef_try_f( s, mvsads[i].mx, mvsads[i].my );
@@ -945,6 +995,22 @@ struct CoopWave
         return v;
     }
     __device__ __forceinline__ int bcast( int v, int l ) const { return __shfl( v, l, 64 ); }
+    // prefix minimum across the wave without leaving the registers: the classic DPP scan (row shifts by 1, 2, 3, then 4 and 8 under bank
+    // masks, then the two row broadcasts), the exclusive form one wave shift further; lanes without a source keep the identity
+    __device__ __forceinline__ void min_scan( int v, int &before, int &all ) const
+    {
+        constexpr int ID = 1 << 28;
+        auto mn = []( int a, int b ) { return a < b ? a : b; };
+        int r = mn( v, __builtin_amdgcn_update_dpp( ID, v, 0x111, 0xF, 0xF, false ) );  // row_shr:1
+        r = mn( r, __builtin_amdgcn_update_dpp( ID, v, 0x112, 0xF, 0xF, false ) );      // row_shr:2
+        r = mn( r, __builtin_amdgcn_update_dpp( ID, v, 0x113, 0xF, 0xF, false ) );      // row_shr:3
+        r = mn( r, __builtin_amdgcn_update_dpp( ID, r, 0x114, 0xF, 0xE, false ) );      // row_shr:4, banks 1-3
+        r = mn( r, __builtin_amdgcn_update_dpp( ID, r, 0x118, 0xF, 0xC, false ) );      // row_shr:8, banks 2-3
+        r = mn( r, __builtin_amdgcn_update_dpp( ID, r, 0x142, 0xA, 0xF, false ) );      // row_bcast:15 into rows 1 and 3
+        r = mn( r, __builtin_amdgcn_update_dpp( ID, r, 0x143, 0xC, 0xF, false ) );      // row_bcast:31 into rows 2 and 3
+        before = __builtin_amdgcn_update_dpp( ID, r, 0x138, 0xF, 0xF, false );          // wave_shr:1
+        all = __builtin_amdgcn_readlane( r, 63 );
+    }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ int16_t *xs() { return xs_; }
 };
