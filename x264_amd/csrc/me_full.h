@@ -862,9 +862,18 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
             // candidate list of the SAD stage: in the request's scratch area (MF_TESA_ROWS_MAX x MF_TESA_WIDTH_MAX entries)
             mef_mvsad *mvsads = (mef_mvsad *)p->scratch;
             int16_t *xs = coop.xs();
-            uint16_t cost_fpel_mvx[MF_TESA_WIDTH_MAX + 4];
-            for( int x = 0; x < width; x++ )
-                cost_fpel_mvx[x] = p->cost_mv[4*( min_x + x ) - p->mvp[0]];
+            // the horizontal vector costs of the window's columns: a table for the one-thread form; a wave keeps the (at most three) columns each
+            // lane looks at in registers (a table indexed by the lane lives in scratch memory: a memory round trip per ads step)
+            static_assert( Coop::W == 1 || 3 * Coop::W >= MF_TESA_WIDTH_MAX, "three ads steps cover the widest window" );
+            uint16_t cost_fpel_mvx[Coop::W == 1 ? MF_TESA_WIDTH_MAX + 4 : 1];
+            int cmx_lane[3] = { 0, 0, 0 };
+            if( Coop::W == 1 )
+                for( int x = 0; x < width; x++ )
+                    cost_fpel_mvx[x] = p->cost_mv[4*( min_x + x ) - p->mvp[0]];
+            else
+                for( int k = 0; k < 3; k++ )
+                    if( k * Coop::W + coop.lane() < width )
+                        cmx_lane[k] = p->cost_mv[4*( min_x + k * Coop::W + coop.lane() ) - p->mvp[0]];
             int nmvsad = 0;
             int sad_thresh = me_range <= 16 ? 10 : me_range <= 24 ? 11 : 12;
             int bsad = mf_sad( p->fenc, p->fenc_stride, p->ref[0] + (long)s->bmy * p->stride + s->bmx, p->stride, s->bw, s->bh ) + mef_bits_f( s, s->bmx, s->bmy );
@@ -887,7 +896,8 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
                         bool keep = false;
                         if( i < width )
                         {
-                            int a = enc_dc[0] - sums[i], ads = mf_abs( a ) + cost_fpel_mvx[i];
+                            const int cmx = Coop::W == 1 ? cost_fpel_mvx[i] : base == 0 ? cmx_lane[0] : base == Coop::W ? cmx_lane[1] : cmx_lane[2];
+                            int a = enc_dc[0] - sums[i], ads = mf_abs( a ) + cmx;
                             if( ads_n == 2 ) ads += mf_abs( enc_dc[1] - sums[i + delta] );
                             else if( ads_n == 4 ) ads += mf_abs( enc_dc[1] - sums[i + 8] ) + mf_abs( enc_dc[2] - sums[i + delta] ) + mf_abs( enc_dc[3] - sums[i + delta + 8] );
                             keep = ads < thresh;
