@@ -877,9 +877,28 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
             int nmvsad = 0;
             int sad_thresh = me_range <= 16 ? 10 : me_range <= 24 ? 11 : 12;
             int bsad = mf_sad( p->fenc, p->fenc_stride, p->ref[0] + (long)s->bmy * p->stride + s->bmx, p->stride, s->bw, s->bh ) + mef_bits_f( s, s->bmx, s->bmy );
-            for( int my = min_y; my <= max_y; my++ )
+            // What a row reads before any of its decisions -- its vertical vector cost and, in a wave, the box sums of its first 64 columns --
+            // is requested while the row before it is still being worked on: a row is then one memory round trip (its SADs) instead of three.
+            struct RowAhead { int ycost, s0, s1, s2, s3; };
+            auto row_ahead = [&]( int my ) {
+                RowAhead r = { 0, 0, 0, 0, 0 };
+                r.ycost = p->cost_mv[4*my - p->mvp[1]];
+                const int i = coop.lane();
+                if( Coop::W > 1 && i < width )
+                {
+                    const uint16_t *sums = sums_base + min_x + (long)my * p->stride;
+                    r.s0 = sums[i];
+                    if( ads_n == 2 ) r.s1 = sums[i + delta];
+                    else if( ads_n == 4 ) { r.s1 = sums[i + 8]; r.s2 = sums[i + delta]; r.s3 = sums[i + delta + 8]; }
+                }
+                return r;
+            };
+            RowAhead row = row_ahead( min_y ), row_next = row;
+            for( int my = min_y; my <= max_y; my++, row = row_next )
             {
-                int ycost = p->cost_mv[4*my - p->mvp[1]];
+                if( my < max_y )
+                    row_next = row_ahead( my + 1 );
+                int ycost = row.ycost;
                 if( bsad <= ycost )
                     continue;
                 bsad -= ycost;
@@ -897,9 +916,19 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
                         if( i < width )
                         {
                             const int cmx = Coop::W == 1 ? cost_fpel_mvx[i] : base == 0 ? cmx_lane[0] : base == Coop::W ? cmx_lane[1] : cmx_lane[2];
-                            int a = enc_dc[0] - sums[i], ads = mf_abs( a ) + cmx;
-                            if( ads_n == 2 ) ads += mf_abs( enc_dc[1] - sums[i + delta] );
-                            else if( ads_n == 4 ) ads += mf_abs( enc_dc[1] - sums[i + 8] ) + mf_abs( enc_dc[2] - sums[i + delta] ) + mf_abs( enc_dc[3] - sums[i + delta + 8] );
+                            int ads;
+                            if( Coop::W > 1 && base == 0 )
+                            {
+                                ads = mf_abs( enc_dc[0] - row.s0 ) + cmx;
+                                if( ads_n == 2 ) ads += mf_abs( enc_dc[1] - row.s1 );
+                                else if( ads_n == 4 ) ads += mf_abs( enc_dc[1] - row.s1 ) + mf_abs( enc_dc[2] - row.s2 ) + mf_abs( enc_dc[3] - row.s3 );
+                            }
+                            else
+                            {
+                                ads = mf_abs( enc_dc[0] - sums[i] ) + cmx;
+                                if( ads_n == 2 ) ads += mf_abs( enc_dc[1] - sums[i + delta] );
+                                else if( ads_n == 4 ) ads += mf_abs( enc_dc[1] - sums[i + 8] ) + mf_abs( enc_dc[2] - sums[i + delta] ) + mf_abs( enc_dc[3] - sums[i + delta + 8] );
+                            }
                             keep = ads < thresh;
                         }
                         const unsigned long long m = coop.ballot( keep );
