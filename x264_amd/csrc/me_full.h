@@ -1058,8 +1058,13 @@ struct CoopWave
 // and the sub-pel refinement redundantly, their loads are broadcasts) and share the exhaustive scan: 64 candidates per step,
 // ordered compaction of the ads survivors, first-in-scan-order ties -- bit-exact with the one-thread form below, which remains
 // the device reference and serves DIA / HEX / UMH requests.
+// (MF_COOP_WAVES: waves per SIMD the register allocation aims at.  The wave's life is a chain of ~100 memory round trips, so more of
+// them resident hide more of it -- until the registers that no longer fit are memory traffic themselves.)
+#ifndef MF_COOP_WAVES
+#define MF_COOP_WAVES 5
+#endif
 template <typename T, int METHODS>
-__global__ __launch_bounds__( 64 ) void me_full_coop_kernel( const MfReq<T> *reqs, const int16_t *mvc, const int *n_mvc, const int *index, int n, int *out )
+__global__ __launch_bounds__( 64, MF_COOP_WAVES ) void me_full_coop_kernel( const MfReq<T> *reqs, const int16_t *mvc, const int *n_mvc, const int *index, int n, int *out )
 {
     __shared__ int16_t xs_lds[( METHODS & 2 ) ? MF_TESA_WIDTH_MAX + 64 : 2];
     if( (int)blockIdx.x >= n )
