@@ -579,9 +579,94 @@ __device__ __forceinline__ void mef_esa_scan_wave( Mef<T, true> *s, int min_x, i
         }
     }
 }
+// The same scan for 8-bit samples with v_qsad_pk_u16_u8: ONE instruction gives the SADs of four source samples against the four byte
+// positions of an 8-byte window -- four horizontally adjacent candidates at once, accumulated as four packed 16-bit sums (a 16x16 block
+// of 8-bit samples cannot exceed 65 280).  A lane takes four neighbouring candidates (the width of the window is a multiple of four, so
+// they share a row), a step 256 candidates: a quarter of the SAD instructions and of the steps of the form above.  The winner is the
+// smallest ( cost << 8 | place in the step ): the earliest candidate among equal costs, as scanning in order with strict '<' keeps.
+template <int BW, int BH>
+__device__ __forceinline__ void mef_esa_scan_wave_q( Mef<uint8_t, true> *s, int min_x, int min_y, int max_y, int width )
+{
+    typedef uint32_t u32x4_u __attribute__( ( ext_vector_type( 4 ), aligned( 1 ) ) );
+    typedef uint32_t u32x3_u __attribute__( ( ext_vector_type( 3 ), aligned( 1 ) ) );
+    typedef uint32_t u32x2_u __attribute__( ( ext_vector_type( 2 ), aligned( 1 ) ) );
+    typedef uint32_t u32x1_u __attribute__( ( aligned( 1 ) ) );
+    const MfReq<uint8_t> *p = s->p;
+    const int lane = threadIdx.x & 63;
+    uint32_t fe[BH][BW / 4];
+#pragma unroll
+    for( int y = 0; y < BH; y++ )
+#pragma unroll
+        for( int k = 0; k < BW / 4; k++ )
+            fe[y][k] = *(const u32x1_u *)( p->fenc + (long)y * p->fenc_stride + 4 * k );
+    const int total = ( max_y - min_y + 1 ) * width;
+    for( int base = 0; base < total; base += 256 )
+    {
+        const bool live = base + 4 * lane < total;
+        const int t = live ? base + 4 * lane : total - 4;
+        const int row = t / width, col = t - row * width;
+        const uint8_t *b = p->ref[0] + (long)( min_y + row ) * p->stride + min_x + col;
+        unsigned long long acc = 0;
+#pragma unroll
+        for( int y = 0; y < BH; y++ )
+        {
+            // the BW + 3 samples the four candidates' rows cover, as BW / 4 + 1 dwords (the last one's top byte belongs to nobody)
+            uint32_t w[BW / 4 + 1];
+            const uint8_t *r = b + (long)y * p->stride;
+            if constexpr( BW == 16 )
+            {
+                const u32x4_u v = *(const u32x4_u *)r;
+                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; w[4] = *(const u32x1_u *)( r + 16 );
+            }
+            else if constexpr( BW == 8 )
+            {
+                const u32x3_u v = *(const u32x3_u *)r;
+                w[0] = v.x; w[1] = v.y; w[2] = v.z;
+            }
+            else
+            {
+                const u32x2_u v = *(const u32x2_u *)r;
+                w[0] = v.x; w[1] = v.y;
+            }
+#pragma unroll
+            for( int k = 0; k < BW / 4; k++ )
+                acc = __builtin_amdgcn_qsad_pk_u16_u8( ( (unsigned long long)w[k + 1] << 32 ) | w[k], fe[y][k], acc );
+        }
+        const int ycost = p->cost_mv[4 * ( min_y + row ) - p->mvp[1]];
+        unsigned key = 0xFFFFFFFFu;
+#pragma unroll
+        for( int j = 3; j >= 0; j-- )
+        {
+            const int c = (int)( ( acc >> ( 16 * j ) ) & 0xFFFF ) + p->cost_mv[4 * ( min_x + col + j ) - p->mvp[0]] + ycost;
+            const unsigned kj = ( (unsigned)c << 8 ) | (unsigned)( 4 * lane + j );
+            key = kj < key ? kj : key;
+        }
+        key = mef_wave_min_u32( live ? key : 0xFFFFFFFFu );
+        const int cmin = (int)( key >> 8 );
+        if( cmin < s->bcost )
+        {
+            const int tt = base + (int)( key & 255 ), r2 = tt / width;
+            s->bcost = cmin; s->bmx = min_x + tt - r2 * width; s->bmy = min_y + r2;
+        }
+    }
+}
 template <typename T>
 __device__ __forceinline__ void mef_esa_scan_dispatch( Mef<T, true> *s, int min_x, int min_y, int max_y, int width )
 {
+    if constexpr( sizeof( T ) == 1 )
+    {
+        switch( s->p->i_pixel )
+        {
+            case 0: mef_esa_scan_wave_q<16, 16>( s, min_x, min_y, max_y, width ); break;
+            case 1: mef_esa_scan_wave_q<16, 8>( s, min_x, min_y, max_y, width ); break;
+            case 2: mef_esa_scan_wave_q<8, 16>( s, min_x, min_y, max_y, width ); break;
+            case 3: mef_esa_scan_wave_q<8, 8>( s, min_x, min_y, max_y, width ); break;
+            case 4: mef_esa_scan_wave_q<8, 4>( s, min_x, min_y, max_y, width ); break;
+            case 5: mef_esa_scan_wave_q<4, 8>( s, min_x, min_y, max_y, width ); break;
+            default: mef_esa_scan_wave_q<4, 4>( s, min_x, min_y, max_y, width ); break;
+        }
+        return;
+    }
     switch( s->p->i_pixel )
     {
         case 0: mef_esa_scan_wave<T, 16, 16>( s, min_x, min_y, max_y, width ); break;
