@@ -757,6 +757,7 @@ int  x264hip_shard_serve( x264hip_shard *s );                   /* ranks 1 .. wo
 #define X264HIP_SHARD_BYTES_L0 8
 #define X264HIP_SHARD_BYTES_SUMMARIES 9
 #define X264HIP_SHARD_BYTES_MAPS 10
+#define X264HIP_SHARD_MAPS_FETCHED_SPARE 11 /* of the maps fetched: the spare half of a cell evaluated both ways (the variant without the list-1 reference's vectors) */
 #define X264HIP_SHARD_STATS 12
 int  x264hip_shard_status( x264hip_shard *s );                   /* waits for everything enqueued; X264HIP_OK, this rank's first error, or X264HIP_EPEER */
 int  x264hip_shard_stats( x264hip_shard *s, uint64_t *out, int n );

@@ -116,6 +116,9 @@ def test_c_shard_two_ranks_on_one_gpu():
     print("C window shard, two ranks:", s0, s1)
     assert s1["fields_searched"] > 0 and s1["cells_evaluated"] > 0 and s0["cells_imported"] > 0 and s0["maps_fetched"] > 0
     assert s1["bytes_input_broadcast"] == NF * W * H  # every picture reached rank 1 exactly once
+    # some of the maps MB-tree read were the SPARE half of a cell evaluated both ways on its owner rank (the caller had asked for the variant
+    # without the list-1 reference's vectors): the 7-word FETCH record carried the spare flag across ranks
+    assert s0["maps_fetched_spare"] > 0, s0
 
 
 def test_c_shard_failing_rank_fails_everybody():

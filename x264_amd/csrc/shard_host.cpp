@@ -502,6 +502,7 @@ int before_mbtree( void *user, const x264hip_mbtree_op *ops, int n )
         {
             x264hip_cell_ref c = cells[k];
             c.with_ref1_l0 = missing[k] == 2 ? X264HIP_CELL_SPARE : 0; // the half of the cell that is wanted
+            if( missing[k] == 2 ) s->stats[X264HIP_SHARD_MAPS_FETCHED_SPARE]++;
             miss.push_back( c ); numbers.push_back( s->number_in[c.slot_b] );
         }
     if( miss.empty() ) return X264HIP_OK;

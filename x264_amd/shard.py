@@ -757,7 +757,7 @@ class HostStagedTransport:
 
 
 SHARD_STAT_NAMES = ("chunks", "fields_searched", "cells_evaluated", "l0_fields_exchanged", "cells_imported", "maps_fetched", "fetch_commands",
-                    "bytes_input_broadcast", "bytes_l0_received", "bytes_summaries", "bytes_maps", "reserved")
+                    "bytes_input_broadcast", "bytes_l0_received", "bytes_summaries", "bytes_maps", "maps_fetched_spare")
 
 
 class CShard:
