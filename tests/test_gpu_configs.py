@@ -286,12 +286,13 @@ def test_me_search_batch(depth):
 
 
 @pytest.mark.parametrize("depth", [8, 10])
-def test_exhaustive_searches_wave_form_equals_scalar_form(depth):
-    """ESA / TESA requests run one per WAVE on the device (64 candidates per step, ordered compaction of the ads survivors, the SAD
-    stage's running thresholds as a prefix minimum across the lanes, rows loaded 16 / 8 samples at a time); the same header compiled for
-    the host runs them one candidate after the other (tests/tools/block_metrics_host.cpp, pinned to the recorded reference calls by
-    tests/test_me_full_host.py).  1 400 random requests -- every partition size, ranges 8 / 16 / 24, predictors all over the window
-    including its edges -- must give the same vector, cost and cost_mv both ways."""
+def test_searches_wave_form_equals_scalar_form(depth):
+    """Main-encode search requests run one per WAVE on the device: block costs across the lanes, the candidates of a pattern's set
+    requested together, ESA 256 candidates per step (v_qsad_pk_u16_u8), TESA with ordered compaction of the ads survivors and the SAD
+    stage's running thresholds as a prefix minimum across the lanes.  The same header compiled for the host runs a request one candidate
+    after the other (tests/tools/block_metrics_host.cpp, pinned to the recorded reference calls by tests/test_me_full_host.py).  2 000
+    random requests -- all five methods, every partition size, ranges 8 / 16 / 24, predictors all over the window including its edges --
+    must give the same vector, cost and cost_mv both ways."""
     import ctypes as C
     import torch
     from tests.test_block_metrics_host import _lib
@@ -312,12 +313,12 @@ def test_exhaustive_searches_wave_form_equals_scalar_form(depth):
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     rng = np.random.default_rng(900 + depth)
     reqs, want = [], []
-    for t in range(1400):
+    for t in range(2000):
         i_pixel = int(rng.integers(0, 7))
         bw, bh = ME_SIZES[i_pixel]
         mb_x, mb_y = int(rng.integers(0, W // 16)), int(rng.integers(0, H // 16))
         xoff, yoff = int(rng.integers(0, 16 // bw)) * bw, int(rng.integers(0, 16 // bh)) * bh
-        me = 3 + (t & 1)
+        me = t % 5
         subme = int(rng.choice([1, 2, 5, 7]))
         me_range = int(rng.choice([8, 16, 16, 24]))
         call = [i_pixel, mb_x, mb_y, xoff, yoff]

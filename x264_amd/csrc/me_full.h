@@ -364,12 +364,54 @@ BM_HD int mef_in_range( const Mef<T, C> *s, int fx, int fy ) /* CHECK_MVRANGE */
 {
     return fx >= s->p->lim_min[0] && fx <= s->p->lim_max[0] && fy >= s->p->lim_min[1] && fy <= s->p->lim_max[1];
 }
+// The costs of N full-pel candidates that do not depend on each other.  In a wave every candidate's samples are requested before any
+// of them is reduced: the set is ONE memory round trip instead of N (a pattern search is a chain of ~50 such evaluations, and the chain
+// is what a request costs).
+template <int N, typename T, bool C>
+BM_HD void mef_costs_f( const Mef<T, C> *s, const int x[N], const int y[N], int c[N] )
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+    if( C )
+    {
+        const MfReq<T> *p = s->p;
+        Px4 r[N];
+#pragma unroll
+        for( int k = 0; k < N; k++ )
+            r[k] = load_px4( p->ref[0] + (long)( y[k] + s->l_row ) * p->stride + x[k] + s->l_col );
+#pragma unroll
+        for( int k = 0; k < N; k++ )
+        {
+            int v = p->fpelcmp_satd ? satd_partial_px4( s->l_f, r[k] ) : sad_partial_px4( s->l_f, r[k], (const T *)nullptr );
+            v = (int)wave_sum_u32( (unsigned)( s->l_active ? v : 0 ) );
+            c[k] = ( p->fpelcmp_satd ? v >> 1 : v ) + mef_bits_f( s, x[k], y[k] );
+        }
+        return;
+    }
+#endif
+    for( int k = 0; k < N; k++ )
+        c[k] = mef_cost_f( s, x[k], y[k] );
+}
+// ... and applied in order with strict '<' (COST_MV one after the other); candidates whose bit in `ok` is clear do not take part
+template <int N, typename T, bool C>
+BM_HD void mef_try_set( Mef<T, C> *s, const int x[N], const int y[N], unsigned ok = ~0u )
+{
+    int xx[N], yy[N], c[N];
+    for( int k = 0; k < N; k++ )
+    {
+        const bool on = ( ok >> k ) & 1;
+        xx[k] = on ? x[k] : s->bmx; yy[k] = on ? y[k] : s->bmy; // (a readable position for the ones left out)
+    }
+    mef_costs_f<N>( s, xx, yy, c );
+    for( int k = 0; k < N; k++ )
+        if( ( ( ok >> k ) & 1 ) && c[k] < s->bcost ) { s->bcost = c[k]; s->bmx = x[k]; s->bmy = y[k]; }
+}
 /* COST_MV_X4 relative to (omx, omy), candidates applied in order */
 template <typename T, bool C>
 BM_HD void mef_x4( Mef<T, C> *s, int omx, int omy, const int d[4][2] )
 {
-    for( int k = 0; k < 4; k++ )
-        mef_try_f( s, omx + d[k][0], omy + d[k][1] );
+    int x[4], y[4];
+    for( int k = 0; k < 4; k++ ) { x[k] = omx + d[k][0]; y[k] = omy + d[k][1]; }
+    mef_try_set<4>( s, x, y );
 }
 template <typename T, bool C>
 BM_HD void mef_cross( Mef<T, C> *s, int omx, int omy, int start, int x_max, int y_max ) /* CROSS, me.c:139-166 */
@@ -409,10 +451,12 @@ BM_HD void mef_hex2( Mef<T, C> *s, int me_range ) /* the HEX branch incl. the sq
     const int8_t square1[9][2] = { {0,0}, {0,-1}, {0,1}, {-1,0}, {1,0}, {-1,-1}, {-1,1}, {1,-1}, {1,1} };
     const int8_t first[6][2] = { {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2} };
     int bmx = s->bmx, bmy = s->bmy, bcost = s->bcost, dir = -1;
-    for( int k = 0; k < 6; k++ ) /* packed (cost<<3)+k+2 with COPY1_IF_LT: lowest cost, first on ties */
     {
-        int c = mef_cost_f( s, bmx + first[k][0], bmy + first[k][1] );
-        if( c < bcost ) { bcost = c; dir = k; }
+        int x[6], y[6], c[6];
+        for( int k = 0; k < 6; k++ ) { x[k] = bmx + first[k][0]; y[k] = bmy + first[k][1]; }
+        mef_costs_f<6>( s, x, y, c );
+        for( int k = 0; k < 6; k++ ) /* packed (cost<<3)+k+2 with COPY1_IF_LT: lowest cost, first on ties */
+            if( c[k] < bcost ) { bcost = c[k]; dir = k; }
     }
     if( dir >= 0 )
     {
@@ -421,11 +465,11 @@ BM_HD void mef_hex2( Mef<T, C> *s, int me_range ) /* the HEX branch incl. the sq
         for( int i = ( me_range >> 1 ) - 1; i > 0 && mef_in_range( s, bmx, bmy ); i-- )
         {
             int best = -1;
+            int x[3], y[3], c[3];
+            for( int k = 0; k < 3; k++ ) { x[k] = bmx + hex2[dir+k][0]; y[k] = bmy + hex2[dir+k][1]; }
+            mef_costs_f<3>( s, x, y, c );
             for( int k = 0; k < 3; k++ )
-            {
-                int c = mef_cost_f( s, bmx + hex2[dir+k][0], bmy + hex2[dir+k][1] );
-                if( c < bcost ) { bcost = c; best = k; }
-            }
+                if( c[k] < bcost ) { bcost = c[k]; best = k; }
             if( best < 0 )
                 break;
             dir += best - 1;
@@ -434,10 +478,12 @@ BM_HD void mef_hex2( Mef<T, C> *s, int me_range ) /* the HEX branch incl. the sq
         }
     }
     int sq = 0;
-    for( int k = 1; k <= 8; k++ )
     {
-        int c = mef_cost_f( s, bmx + square1[k][0], bmy + square1[k][1] );
-        if( c < bcost ) { bcost = c; sq = k; }
+        int x[8], y[8], c[8];
+        for( int k = 0; k < 8; k++ ) { x[k] = bmx + square1[k + 1][0]; y[k] = bmy + square1[k + 1][1]; }
+        mef_costs_f<8>( s, x, y, c );
+        for( int k = 0; k < 8; k++ )
+            if( c[k] < bcost ) { bcost = c[k]; sq = k + 1; }
     }
     s->bmx = bmx + square1[sq][0]; s->bmy = bmy + square1[sq][1]; s->bcost = bcost;
 }
@@ -771,11 +817,11 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
             do
             {
                 int best = -1, bmx = s->bmx, bmy = s->bmy;
+                int x[4], y[4], c[4];
+                for( int k = 0; k < 4; k++ ) { x[k] = bmx + d[k][0]; y[k] = bmy + d[k][1]; }
+                mef_costs_f<4>( s, x, y, c );
                 for( int k = 0; k < 4; k++ )
-                {
-                    int c = mef_cost_f( s, bmx + d[k][0], bmy + d[k][1] );
-                    if( c < s->bcost ) { s->bcost = c; best = k; }
-                }
+                    if( c[k] < s->bcost ) { s->bcost = c[k]; best = k; }
                 if( best < 0 )
                     break;
                 s->bmx = bmx + d[best][0]; s->bmy = bmy + d[best][1];
@@ -798,8 +844,9 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
                                                     { {-1,-2}, {1,-2}, {-2,-1}, {2,-1} }, { {-2,1}, {2,1}, {-1,2}, {1,2} },
                                                     { {-2,-2}, {-2,2}, {2,-2}, {2,2} } };
             auto probe = [&]( int cx, int cy, const int8_t ( *set )[2] ) {
-                for( int k = 0; k < 4; k++ )
-                    mef_try_f( s, cx + set[k][0], cy + set[k][1] );
+                int x[4], y[4];
+                for( int k = 0; k < 4; k++ ) { x[k] = cx + set[k][0]; y[k] = cy + set[k][1]; }
+                mef_try_set<4>( s, x, y );
             };
             const int area_class = (int)( ( 0x4332110u >> ( 4 * p->i_pixel ) ) & 15 ); // 16x16 0, 16x8 / 8x16 1, 8x8 2, 8x4 / 4x8 3, 4x4 4
             auto good_match = [&]( int limit16 ) { return s->bcost < ( limit16 >> area_class ); };
@@ -870,14 +917,19 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
                 {
                     const int room = imin( imin( mv_x_max - rx, rx - mv_x_min ), imin( mv_y_max - ry, ry - mv_y_min ) );
                     const bool clipped = 4 * ring > room;
-                    for( int j = 0; j < 16; j++ )
+                    for( int j0 = 0; j0 < 16; j0 += 8 ) // (two sets of eight: sixteen blocks of samples in flight do not fit the registers)
                     {
-                        const int row = ( j - 2 ) >> 1;
-                        const int dy = j < 2 ? ( j ? 4 : -4 ) : row - 3;
-                        const int ax = j < 2 ? 0 : ( row == 0 || row == 6 ) ? 2 : 4;
-                        const int mx = rx + ( ( j & 1 ) ? ax : -ax ) * ring, my = ry + dy * ring;
-                        if( !clipped || mef_in_range( s, mx, my ) )
-                            mef_try_f( s, mx, my );
+                        int x[8], y[8];
+                        unsigned ok = 0;
+                        for( int k = 0; k < 8; k++ )
+                        {
+                            const int j = j0 + k, row = ( j - 2 ) >> 1;
+                            const int dy = j < 2 ? ( j ? 4 : -4 ) : row - 3;
+                            const int ax = j < 2 ? 0 : ( row == 0 || row == 6 ) ? 2 : 4;
+                            x[k] = rx + ( ( j & 1 ) ? ax : -ax ) * ring; y[k] = ry + dy * ring;
+                            if( !clipped || mef_in_range( s, x[k], y[k] ) ) ok |= 1u << k;
+                        }
+                        mef_try_set<8>( s, x, y, ok );
                     }
                 } while( ++ring <= me_range >> 2 );
             }
