@@ -359,6 +359,44 @@ BM_HD int mef_cost_q( const Mef<T, C> *s, int qx, int qy, int use_mbcmp ) /* COS
     mf_mc_luma( pix, 16, s->p->ref, s->p->stride, qx, qy, s->bw, s->bh, NULL );
     return ( use_mbcmp ? mef_mbcmp( s, pix, 16 ) : mef_fpelcmp( s, pix, 16 ) ) + mef_bits_q( s, qx, qy );
 }
+// the same for N quarter-pel positions that do not depend on each other (see mef_costs_f): every tap of the set is requested before any
+// candidate is averaged and reduced
+template <int N, typename T, bool C>
+BM_HD void mef_costs_q( const Mef<T, C> *s, const int qx[N], const int qy[N], int use_mbcmp, int c[N] )
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+    if( C )
+    {
+        const MfReq<T> *p = s->p;
+        const int use_satd = use_mbcmp ? p->mbcmp_satd : p->fpelcmp_satd;
+        Px4 ra[N], rb[N];
+#pragma unroll
+        for( int k = 0; k < N; k++ )
+        {
+            const int fx = qx[k] & 3, fy = qy[k] & 3;
+            const long o = (long)( s->l_row + ( qy[k] >> 2 ) ) * p->stride + s->l_col + ( qx[k] >> 2 );
+            const int pa = ( fx ? 1 : 0 ) + ( fy == 2 ? 2 : 0 ), pb = ( fx == 2 ? 1 : 0 ) + ( fy ? 2 : 0 );
+            ra[k] = load_px4( p->ref[pa] + o + ( fy == 3 ? p->stride : 0 ) );
+            rb[k].a = rb[k].b = rb[k].raw = 0;
+            if( ( fx | fy ) & 1 )
+                rb[k] = load_px4( p->ref[pb] + o + ( fx == 3 ) );
+        }
+#pragma unroll
+        for( int k = 0; k < N; k++ )
+        {
+            Px4 r = ra[k];
+            if( ( qx[k] | qy[k] ) & 1 )
+                r = avg_px4( r, rb[k], (const T *)nullptr );
+            int v = use_satd ? satd_partial_px4( s->l_f, r ) : sad_partial_px4( s->l_f, r, (const T *)nullptr );
+            v = (int)wave_sum_u32( (unsigned)( s->l_active ? v : 0 ) );
+            c[k] = ( use_satd ? v >> 1 : v ) + mef_bits_q( s, qx[k], qy[k] );
+        }
+        return;
+    }
+#endif
+    for( int k = 0; k < N; k++ )
+        c[k] = mef_cost_q( s, qx[k], qy[k], use_mbcmp );
+}
 template <typename T, bool C>
 BM_HD int mef_in_range( const Mef<T, C> *s, int fx, int fy ) /* CHECK_MVRANGE */
 {
@@ -511,11 +549,11 @@ BM_HD void mef_refine_subpel( Mef<T, C> *s, int mv[2], int *cost, int *cost_mv, 
         for( int i = hpel_iters; i > 0; i-- )
         {
             int best = -1, omx = bmx, omy = bmy;
+            int x[4], y[4], c[4];
+            for( int k = 0; k < 4; k++ ) { x[k] = omx + d2[k][0]; y[k] = omy + d2[k][1]; }
+            mef_costs_q<4>( s, x, y, 0, c );
             for( int k = 0; k < 4; k++ )
-            {
-                int c = mef_cost_q( s, omx + d2[k][0], omy + d2[k][1], 0 );
-                if( c < bcost ) { bcost = c; best = k; }
-            }
+                if( c[k] < bcost ) { bcost = c[k]; best = k; }
             if( best < 0 )
                 break;
             bmx = omx + d2[best][0]; bmy = omy + d2[best][1];
@@ -532,12 +570,18 @@ BM_HD void mef_refine_subpel( Mef<T, C> *s, int mv[2], int *cost, int *cost_mv, 
             if( bmy <= p->spel_min[1] || bmy >= p->spel_max[1] || bmx <= p->spel_min[0] || bmx >= p->spel_max[0] )
                 break;
             int odir = bdir, omx = bmx, omy = bmy;
+            int x[4], y[4], c[4];
+            for( int k = 0; k < 4; k++ )
+            {
+                const bool back = ( k ^ 1 ) == odir; // the point the last step came from is not costed again (it is read, nothing more)
+                x[k] = back ? omx : omx + d1[k][0]; y[k] = back ? omy : omy + d1[k][1];
+            }
+            mef_costs_q<4>( s, x, y, 1, c );
             for( int k = 0; k < 4; k++ )
             {
                 if( ( k ^ 1 ) == odir )
                     continue;
-                int c = mef_cost_q( s, omx + d1[k][0], omy + d1[k][1], 1 );
-                if( c < bcost ) { bcost = c; bmx = omx + d1[k][0]; bmy = omy + d1[k][1]; bdir = k; }
+                if( c[k] < bcost ) { bcost = c[k]; bmx = x[k]; bmy = y[k]; bdir = k; }
             }
             if( bmx == omx && bmy == omy )
                 break;
@@ -546,11 +590,11 @@ BM_HD void mef_refine_subpel( Mef<T, C> *s, int mv[2], int *cost, int *cost_mv, 
     else if( bmy > p->spel_min[1] && bmy < p->spel_max[1] && bmx > p->spel_min[0] && bmx < p->spel_max[0] )
     {
         int omx = bmx, omy = bmy; /* subme 1: one quarter-pel diamond with fpelcmp */
+        int x[4], y[4], c[4];
+        for( int k = 0; k < 4; k++ ) { x[k] = omx + d1[k][0]; y[k] = omy + d1[k][1]; }
+        mef_costs_q<4>( s, x, y, 0, c );
         for( int k = 0; k < 4; k++ )
-        {
-            int c = mef_cost_q( s, omx + d1[k][0], omy + d1[k][1], 0 );
-            if( c < bcost ) { bcost = c; bmx = omx + d1[k][0]; bmy = omy + d1[k][1]; }
-        }
+            if( c[k] < bcost ) { bcost = c[k]; bmx = x[k]; bmy = y[k]; }
     }
     mv[0] = bmx; mv[1] = bmy; *cost = bcost;
     *cost_mv = mef_bits_q( s, bmx, bmy );
