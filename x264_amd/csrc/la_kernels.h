@@ -1818,6 +1818,9 @@ __device__ __forceinline__ void mbt_propagate_mb( const MbtOpDev &o, int *ref0, 
     }
 }
 
+// (macroblocks per thread with their loads in flight together.  8 / 16 measured against 4 with the workgroups sized by the number of open
+// contexts, scripts/r05_ab_libs.sh: eight contexts 39.0 k / 37.9 k and 38.1 k / 37.9 k frames/s against 38.8 k / 38.8 k, one context
+// 27.7 k and 26.0 k against 28.0 k -- no gain)
 #ifndef MBT_UNROLL
 #define MBT_UNROLL 4
 #endif
