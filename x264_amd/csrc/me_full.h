@@ -1,9 +1,12 @@
 // Main-encode motion search: x264_me_search_ref with DIA / HEX / UMH / ESA / TESA and refine_subpel
-// (encoder/me.c:182-798, :865-992) for any partition size, luma only, one reference, no weights -- as a FUNCTIONAL device baseline:
-// one thread per request, the search written as plain C++ (BM_HD: the same functions are compiled for the host by tests/tools and
-// checked against the oracle and the golden recordings of the reference without a GPU).  It exists so that the main-encode
-// search has a bit-exact device implementation to build the parallel version against (candidates across lanes, requests
-// across waves: DESIGN.md section 8); it is NOT tuned -- divergent control flow, per-thread interpolation buffers in scratch.
+// (encoder/me.c:182-798, :865-992) for any partition size, luma only, one reference, no weights.  The search is written once as plain
+// C++ (BM_HD): compiled for the host by tests/tools it is checked against the oracle and the recordings of the reference without a GPU,
+// one candidate after the other (Coop = CoopNone, C = false) -- and that scalar form also exists on the device (me_full_list_kernel,
+// X264HIP_ME_FULL_SCALAR=1) as the reference of the form that ships: a WAVE per request (me_full_coop_kernel, Coop = CoopWave, C = true).
+// There a block cost is computed across the 64 lanes (four samples per lane, a wave sum), the candidates of a pattern's set are
+// requested together (mef_costs_f / mef_costs_q: one memory round trip per set), the ESA scan takes 256 candidates per step with
+// v_qsad_pk_u16_u8 (8-bit) or 64 with a lane per candidate, and TESA keeps its ads survivors and its SAD-stage thresholds in scan order
+// through ballots and a DPP prefix minimum.  Rates and what bounds them: DESIGN.md section 3 (table) and section 8.
 #pragma once
 #include <stdint.h>
 
