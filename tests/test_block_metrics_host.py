@@ -28,7 +28,7 @@ def _lib():
     hdrs = [os.path.join(HERE, "..", "x264_amd", "csrc", h) for h in ("block_metrics.h", "dct_quant_block.h", "me_full.h", "integral.h")]
     if not os.path.exists(OUT) or max([os.path.getmtime(SRC)] + [os.path.getmtime(h) for h in hdrs]) > os.path.getmtime(OUT):
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", OUT, SRC])
     return C.CDLL(OUT)
 
 

@@ -53,6 +53,112 @@ static void mf_run( const MfHostReq *h, const int16_t *mvc, int n_mvc, int *out 
 extern "C" void mf_host_u8( const MfHostReq *h, const int16_t *mvc, int n_mvc, int *out ) { mf_run<uint8_t>( h, mvc, n_mvc, out ); }
 extern "C" void mf_host_u16( const MfHostReq *h, const int16_t *mvc, int n_mvc, int *out ) { mf_run<uint16_t>( h, mvc, n_mvc, out ); }
 
+// The cooperative form of the same search on the host: W threads stand for the lanes of a wave.  Every thread runs the whole request,
+// the collectives of the Coop interface (ballot, packed minimum, prefix minimum, broadcast) go through a shared slot array between two
+// barriers -- so the parts of me_full.h that are written for several lanes (the chunked scans, the ordered compaction of the ads
+// survivors, the SAD stage's thresholds as a prefix minimum, the survivor thinning) run without a GPU, against the one-thread form.
+#include <pthread.h>
+#include <thread>
+#include <vector>
+struct CoopShared
+{
+    pthread_barrier_t bar;
+    unsigned long long slot[64];
+    int16_t xs[MF_TESA_WIDTH_MAX + 64];
+};
+template <int LANES>
+struct CoopThreads
+{
+    static constexpr int W = LANES;
+    CoopShared *sh;
+    int l;
+    int lane() const { return l; }
+    void sync() const { pthread_barrier_wait( &sh->bar ); }
+    // every lane's value, as lane k's view of slot[k]
+    void share( unsigned long long v, unsigned long long *all ) const
+    {
+        sh->slot[l] = v;
+        sync();
+        for( int k = 0; k < W; k++ ) all[k] = sh->slot[k];
+        sync();
+    }
+    void argmin( int &cost, int &idx ) const
+    {
+        unsigned long long a[W], key;
+        share( ( (unsigned long long)(unsigned)cost << 32 ) | (unsigned)idx, a );
+        key = a[0];
+        for( int k = 1; k < W; k++ ) key = a[k] < key ? a[k] : key;
+        cost = (int)( key >> 32 ); idx = (int)(unsigned)key;
+    }
+    unsigned long long ballot( bool p ) const
+    {
+        unsigned long long a[W], m = 0;
+        share( p ? 1ull : 0ull, a );
+        for( int k = 0; k < W; k++ ) m |= a[k] << k;
+        return m;
+    }
+    unsigned long long max64( unsigned long long v ) const
+    {
+        unsigned long long a[W];
+        share( v, a );
+        for( int k = 0; k < W; k++ ) v = a[k] > v ? a[k] : v;
+        return v;
+    }
+    int bcast( int v, int k ) const
+    {
+        unsigned long long a[W];
+        share( (unsigned long long)(unsigned)v, a );
+        return (int)(unsigned)a[k];
+    }
+    void min_scan( int v, int &before, int &all ) const
+    {
+        unsigned long long a[W];
+        share( (unsigned long long)(unsigned)v, a );
+        before = 1 << 28; all = 1 << 28;
+        for( int k = 0; k < W; k++ )
+        {
+            const int x = (int)(unsigned)a[k];
+            if( k < l && x < before ) before = x;
+            if( x < all ) all = x;
+        }
+    }
+    int16_t *xs() { return sh->xs; }
+};
+template <typename T, int LANES>
+static int mf_run_lanes( const MfHostReq *h, const int16_t *mvc, int n_mvc, int *out )
+{
+    MfReq<T> r;
+    r.i_pixel = h->i_pixel; r.me_method = h->me_method; r.subpel_refine = h->subpel_refine; r.me_range = h->me_range;
+    r.mbcmp_satd = h->mbcmp_satd; r.fpelcmp_satd = h->fpelcmp_satd;
+    r.fenc = (const T *)h->fenc; r.fenc_stride = h->fenc_stride;
+    for( int k = 0; k < 4; k++ ) r.ref[k] = (const T *)h->ref[k];
+    r.stride = h->stride; r.integral = h->integral; r.integral_lower = h->integral_lower;
+    for( int k = 0; k < 2; k++ ) { r.mvp[k] = h->mvp[k]; r.lim_min[k] = h->lim_min[k]; r.lim_max[k] = h->lim_max[k]; r.spel_min[k] = h->spel_min[k]; r.spel_max[k] = h->spel_max[k]; }
+    r.cost_mv = h->cost_mv;
+    r.scratch = malloc( (size_t)MF_TESA_ROWS_MAX * MF_TESA_WIDTH_MAX * 12 );
+    CoopShared sh;
+    pthread_barrier_init( &sh.bar, nullptr, LANES );
+    int res[LANES][4];
+    std::vector<std::thread> th;
+    for( int l = 0; l < LANES; l++ )
+        th.emplace_back( [&, l]() {
+            CoopThreads<LANES> coop;
+            coop.sh = &sh; coop.l = l;
+            mefull::mf_me_search_full<T, CoopThreads<LANES>>( &r, (const int16_t( * )[2])mvc, n_mvc, res[l], coop );
+        } );
+    for( auto &t : th ) t.join();
+    pthread_barrier_destroy( &sh.bar );
+    free( r.scratch );
+    int same = 1;
+    for( int l = 1; l < LANES; l++ )
+        for( int k = 0; k < 4; k++ )
+            same &= res[l][k] == res[0][k]; // the lanes of a wave hold identical state at the end
+    for( int k = 0; k < 4; k++ ) out[k] = res[0][k];
+    return same;
+}
+extern "C" int mf_host_lanes_u8( const MfHostReq *h, const int16_t *mvc, int n_mvc, int *out ) { return mf_run_lanes<uint8_t, 8>( h, mvc, n_mvc, out ); }
+extern "C" int mf_host_lanes_u16( const MfHostReq *h, const int16_t *mvc, int n_mvc, int *out ) { return mf_run_lanes<uint16_t, 8>( h, mvc, n_mvc, out ); }
+
 // integral planes (x264_amd/csrc/integral.h): the two passes of the device kernels run as loops over host memory
 #include "../../x264_amd/csrc/integral.h"
 template <typename T>

@@ -1048,14 +1048,15 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
             int16_t *xs = coop.xs();
             // the horizontal vector costs of the window's columns: a table for the one-thread form; a wave keeps the (at most three) columns each
             // lane looks at in registers (a table indexed by the lane lives in scratch memory: a memory round trip per ads step)
-            static_assert( Coop::W == 1 || 3 * Coop::W >= MF_TESA_WIDTH_MAX, "three ads steps cover the widest window" );
+            // (NCH ads steps cover the widest window: three in a wave of 64; the thread-group form of the host tests has more, narrower ones)
+            constexpr int NCH = Coop::W == 1 ? 1 : ( MF_TESA_WIDTH_MAX + Coop::W - 1 ) / Coop::W;
             uint16_t cost_fpel_mvx[Coop::W == 1 ? MF_TESA_WIDTH_MAX + 4 : 1];
-            int cmx_lane[3] = { 0, 0, 0 };
+            int cmx_lane[NCH] = { 0 };
             if( Coop::W == 1 )
                 for( int x = 0; x < width; x++ )
                     cost_fpel_mvx[x] = p->cost_mv[4*( min_x + x ) - p->mvp[0]];
             else
-                for( int k = 0; k < 3; k++ )
+                for( int k = 0; k < NCH; k++ )
                     if( k * Coop::W + coop.lane() < width )
                         cmx_lane[k] = p->cost_mv[4*( min_x + k * Coop::W + coop.lane() ) - p->mvp[0]];
             int nmvsad = 0;
@@ -1099,7 +1100,10 @@ BM_HD void mf_me_search_full( const MfReq<T> *p, const int16_t (*mvc)[2], int n_
                         bool keep = false;
                         if( i < width )
                         {
-                            const int cmx = Coop::W == 1 ? cost_fpel_mvx[i] : base == 0 ? cmx_lane[0] : base == Coop::W ? cmx_lane[1] : cmx_lane[2];
+                            int cmx;
+                            if constexpr( Coop::W == 1 ) cmx = cost_fpel_mvx[i];
+                            else if constexpr( NCH == 3 ) cmx = base == 0 ? cmx_lane[0] : base == Coop::W ? cmx_lane[1] : cmx_lane[2]; // (selects, not an indexed array)
+                            else cmx = cmx_lane[base / Coop::W];
                             int ads;
                             if( Coop::W > 1 && base == 0 )
                             {
