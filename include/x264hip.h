@@ -720,7 +720,9 @@ int  x264hip_lookahead_stats( x264hip_lookahead *la, uint64_t *out, int n );
  * The transport: four operations on DEVICE buffers, each enqueued on the given HIP stream (the context's own: searches, exports,
  * collectives and imports are ordered on the device, no host thread waits for a chunk).  x264hip_shard_transport_rccl fills one in over
  * RCCL (xGMI inside a node); librccl.so is opened at run time, X264HIP_ENODEV if it is absent.  A one-rank transport with .loopback set
- * runs every exchange step with the rank as its own peer (tests: the whole path on one GPU; x264hip_shard_loopback_verify). */
+ * runs every exchange step with the rank as its own peer (tests: the whole path on one GPU; x264hip_shard_loopback_verify).
+ * Every exchange buffer is allocated by x264hip_shard_open (a failed open leaves the transport untouched: it stays the caller's to
+ * destroy); larger exchanges travel in pieces every rank sizes alike (X264HIP_SHARD_PIECE_BYTES overrides the per-buffer budget). */
 #define X264HIP_EPEER    -7   /* window shard: another rank failed (its own error is reported there) */
 typedef struct x264hip_shard x264hip_shard;
 typedef struct x264hip_shard_transport
@@ -746,6 +748,9 @@ x264hip_ctx *x264hip_shard_ctx( x264hip_shard *s );
  * lookahead counts them), put into the lookahead; the pointers must stay valid until those frames have been returned by get_frame */
 int  x264hip_shard_put_frames( x264hip_shard *s, int first_number, int n, const void *const *luma_dev, int stride );
 int  x264hip_shard_serve( x264hip_shard *s );                   /* ranks 1 .. world-1: returns when rank 0 closes; X264HIP_OK or the first error */
+/* rank 0: start a new sequence (frame numbers from 0 again) on EVERY rank.  Use this instead of x264hip_lookahead_reset on
+ * x264hip_shard_lookahead(): the ranks key the pictures, fields and cells they hold by frame number. */
+int  x264hip_shard_reset( x264hip_shard *s );
 #define X264HIP_SHARD_CHUNKS 0
 #define X264HIP_SHARD_FIELDS_SEARCHED 1
 #define X264HIP_SHARD_CELLS_EVALUATED 2

@@ -84,8 +84,10 @@ def _two_rank_worker(rank, port, q, env):
     dev = torch.from_numpy(make_clip(W, H, NF, **CLIP)).cuda() if rank == 0 else None
     t = shard.HostStagedTransport(dist, rank, 2)
     try:
-        outs, dt, st, rc = shard.run_c_window_shard(torch, L2, rank, 2, 0, cfg, dev, t, qp_offsets=True)
-        q.put(dict(rank=rank, sig=_sig(outs) if outs is not None else None, stats=st, rc=rc, calls=t.calls))
+        passes = int(os.environ.get("X264HIP_TEST_PASSES", "1"))
+        outs, dt, st, rc = shard.run_c_window_shard(torch, L2, rank, 2, 0, cfg, dev, t, qp_offsets=True, passes=passes)
+        sig = None if outs is None else _sig(outs) if passes == 1 else [_sig(o) for o in outs]
+        q.put(dict(rank=rank, sig=sig, stats=st, rc=rc, calls=dict(t.calls)))
     except L2.X264HipError as e:
         q.put(dict(rank=rank, error=e.code, calls=t.calls))
     dist.barrier()
@@ -119,6 +121,19 @@ def test_c_shard_two_ranks_on_one_gpu():
     # some of the maps MB-tree read were the SPARE half of a cell evaluated both ways on its owner rank (the caller had asked for the variant
     # without the list-1 reference's vectors): the 7-word FETCH record carried the spare flag across ranks
     assert s0["maps_fetched_spare"] > 0, s0
+
+
+def test_c_shard_pieces_and_reset():
+    """Every exchange step in several pieces (64 KiB per exchange buffer: one picture, two fields per pair, three maps per piece), and the
+    same clip a second time after x264hip_shard_reset: both passes equal the single stream's."""
+    want = _plain()
+    got = _run_two({"X264HIP_SHARD_PIECE_BYTES": "65536", "X264HIP_TEST_PASSES": "2"})
+    assert got[1]["rc"] == 0
+    assert len(got[0]["sig"]) == 2 and got[0]["sig"][0] == want and got[0]["sig"][1] == want
+    s0, s1 = got[0]["stats"], got[1]["stats"]
+    print("C window shard, pieces + reset:", s0, s1, got[0]["calls"])
+    assert s1["bytes_input_broadcast"] == 2 * NF * W * H
+    assert got[0]["calls"]["broadcast"] >= 2 * NF  # a picture per piece (+ the commands)
 
 
 def test_c_shard_failing_rank_fails_everybody():

@@ -1277,7 +1277,7 @@ struct MeTranslate
     long fenc_stride, ref_stride, integral_lower;
     const uint16_t *integral, *cost_mv;
     char *scratch;
-    const unsigned *scratch_off;
+    const unsigned long long *scratch_off;
     unsigned long long uniform_scratch;
     int force_method, n;
 };
@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__( 256 ) void me_translate_kernel( const x264hip_me_r
         r.spel_min[k] = q.spel_min[k]; r.spel_max[k] = q.spel_max[k];
     }
     r.cost_mv = A.cost_mv;
-    r.scratch = r.me_method == 4 ? A.scratch + ( A.scratch_off ? (unsigned long long)A.scratch_off[i] : (unsigned long long)i * A.uniform_scratch ) : nullptr;
+    r.scratch = r.me_method == 4 ? A.scratch + ( A.scratch_off ? A.scratch_off[i] : (unsigned long long)i * A.uniform_scratch ) : nullptr;
     table[i] = r;
     n_mvc[i] = q.n_mvc < 0 ? 0 : q.n_mvc > X264HIP_ME_MVC_MAX ? X264HIP_ME_MVC_MAX : q.n_mvc;
 #pragma unroll

@@ -17,6 +17,9 @@
 //      counts are known to everybody) with whatever its buffers hold, reports the failure there, and every rank stops at the next
 //      command -- a failing rank fails the call on every rank instead of leaving the others inside a collective.
 // Per-block maps stay with their owners; before an MB-tree call rank 0 names the maps that call reads in a FETCH command.
+// Every exchange step goes through buffers allocated ONCE, at open (pictures, fields, summaries, maps: a fixed number of bytes each);
+// what does not fit travels in pieces whose sizes every rank derives from the plan.  Nothing is allocated between a command and
+// its collectives, so no rank can drop out of a collective because an allocation failed (round-5 review).
 // The exchange goes through an x264hip_shard_transport: RCCL over xGMI (x264hip_shard_transport_rccl: librccl is dlopen'ed, the
 // library does not link it) or anything with the same four operations (the tests run two ranks on one GPU over a host-staged one).
 // Results are those of the single stream by construction: a search is a pure function of its two frames.
@@ -37,14 +40,8 @@
 
 namespace
 {
-enum { CMD_STOP = 0, CMD_CHUNK = 1, CMD_FETCH = 2 };
+enum { CMD_STOP = 0, CMD_CHUNK = 1, CMD_FETCH = 2, CMD_RESET = 3 };
 const int CMD_WORDS = 8192; // int64 words per command: a chunk names <= 2 * (frames of a chunk + the window) + (bframes+2)^2 of them
-
-struct Held // a device buffer the stream still reads or writes: released once the event behind its last use has completed
-{
-    hipEvent_t ev;
-    void *buf;
-};
 
 typedef std::tuple<int, int, int> Key3; // (frame number, list, dist - 1) or (frame number, d0, d1)
 } // namespace
@@ -73,38 +70,51 @@ struct x264hip_shard
     std::map<int, int> slot_of, number_in;        // frame number -> slot, slot -> frame number
     std::map<int, const void *> picture;          // rank 0: frame number -> device pointer of its luma (x264hip_shard_put_frames)
     int picture_stride = 0;
-    std::vector<Held> held;
+    // the exchange buffers (device memory, allocated at open, reused by every command in stream order)
+    char *pic_buf = nullptr;                    // pictures: pic_frames frames per piece
+    char *l0_sbuf = nullptr, *l0_rbuf = nullptr; // list-0 fields: l0_fields fields per peer and piece, world peers
+    char *sum_sbuf = nullptr, *sum_rbuf = nullptr; // cell summaries: sum_cells cells per rank and piece (rbuf: rank 0, world blocks)
+    char *map_sbuf = nullptr, *map_rbuf = nullptr; // cell maps: map_cells per rank and piece
+    size_t pic_frames = 0, l0_fields = 0, sum_cells = 0, map_cells = 0;
     uint64_t stats[X264HIP_SHARD_STATS] = { 0 };
     std::vector<std::pair<void *, void *>> loop_checks; // loopback: (sent, received) pairs compared at close
     std::vector<size_t> loop_bytes;
 
     int fail( int rc ) { if( rc && !failed ) failed = rc; return rc; }
-    void *dev_alloc( size_t bytes )
+    // loop-back runs keep a copy of what was sent and of what came back (the exchange buffers are reused), compared at close
+    void loop_keep( const void *sent, const void *got, size_t bytes )
     {
-        void *p = nullptr;
-        if( hipMalloc( &p, bytes ? bytes : 16 ) != hipSuccess ) { (void)hipGetLastError(); fail( X264HIP_ENOMEM ); return nullptr; }
-        return p;
-    }
-    void hold( void *buf ) // behind everything enqueued so far
-    {
-        if( !buf ) return;
-        Held h; h.buf = buf;
-        if( hipEventCreateWithFlags( &h.ev, hipEventDisableTiming ) != hipSuccess || hipEventRecord( h.ev, stream ) != hipSuccess )
+        void *a = nullptr, *b = nullptr;
+        if( !bytes || hipMalloc( &a, bytes ) != hipSuccess || hipMalloc( &b, bytes ) != hipSuccess ||
+            hipMemcpyAsync( a, sent, bytes, hipMemcpyDeviceToDevice, stream ) != hipSuccess ||
+            hipMemcpyAsync( b, got, bytes, hipMemcpyDeviceToDevice, stream ) != hipSuccess )
         {
-            (void)hipStreamSynchronize( stream ); (void)hipFree( buf ); return;
+            (void)hipGetLastError(); (void)hipFree( a ); (void)hipFree( b ); // (a check that cannot be kept is skipped: one rank, nobody waits)
+            return;
         }
-        held.push_back( h );
-        while( !held.empty() && hipEventQuery( held.front().ev ) == hipSuccess )
+        loop_checks.push_back( std::make_pair( a, b ) ); loop_bytes.push_back( bytes );
+    }
+    // entries of frames no later command can name: everything older than the oldest frame of a chunk by more than the reach of a reference
+    void prune( int oldest )
+    {
+        const int limit = oldest - bframes - 1;
+        done.erase( done.begin(), done.lower_bound( Key3( limit, -1, -1 ) ) );
+        cells_done.erase( cells_done.begin(), cells_done.lower_bound( Key3( limit, -1, -1 ) ) );
+        sums_done.erase( sums_done.begin(), sums_done.lower_bound( limit ) );
+        ingested.erase( ingested.begin(), ingested.lower_bound( limit ) );
+        picture.erase( picture.begin(), picture.lower_bound( limit ) );
+        for( auto it = l0_sent.begin(); it != l0_sent.end(); )
+            if( std::get<1>( *it ) < limit ) it = l0_sent.erase( it ); else ++it;
+        for( auto it = slot_of.begin(); it != slot_of.end() && it->first < limit; )
         {
-            (void)hipEventDestroy( held.front().ev ); (void)hipFree( held.front().buf );
-            held.erase( held.begin() );
+            auto in = number_in.find( it->second );
+            if( in != number_in.end() && in->second == it->first ) number_in.erase( in );
+            it = slot_of.erase( it );
         }
     }
-    void release_all()
+    void forget_sequence() // a new sequence starts at frame 0 (x264hip_shard_reset)
     {
-        (void)hipStreamSynchronize( stream );
-        for( auto &h : held ) { (void)hipEventDestroy( h.ev ); (void)hipFree( h.buf ); }
-        held.clear();
+        done.clear(); cells_done.clear(); sums_done.clear(); ingested.clear(); l0_sent.clear(); slot_of.clear(); number_in.clear(); picture.clear();
     }
 };
 
@@ -244,45 +254,45 @@ int run_chunk( x264hip_shard *s, const std::vector<int> &slots, const std::vecto
         if( inj && sscanf( inj, "%d:%d", &r, &c ) == 2 && r == s->rank && (uint64_t)c == s->stats[X264HIP_SHARD_CHUNKS] )
             s->fail( X264HIP_EDEVICE );
     }
-    // ---- 0. the pictures of the chunk's new frames: from rank 0's own buffers to a staging block on every other rank
+    if( !numbers.empty() )
+        s->prune( *std::min_element( numbers.begin(), numbers.end() ) );
+    // ---- 0. the pictures of the chunk's new frames: from rank 0's own buffers through the picture buffer of every other rank,
+    //         pic_frames at a time (the buffer is reused in stream order: a piece's ingest kernels run before the next broadcast lands)
     if( exchanging )
     {
         std::vector<int> fresh;
         for( int nmb : numbers ) if( !s->ingested.count( nmb ) ) fresh.push_back( nmb );
         std::sort( fresh.begin(), fresh.end() );
         for( int nmb : fresh ) s->ingested.insert( nmb );
-        if( !fresh.empty() )
+        for( size_t first = 0; first < fresh.size(); first += s->pic_frames )
         {
-            char *stage = (char *)s->dev_alloc( frame_bytes * fresh.size() );
-            for( size_t k = 0; k < fresh.size() && stage; k++ )
-            {
-                if( s->rank == 0 )
+            const size_t cnt = std::min( s->pic_frames, fresh.size() - first );
+            if( s->rank == 0 )
+                for( size_t k = 0; k < cnt; k++ )
                 {
-                    auto it = s->picture.find( fresh[k] );
+                    auto it = s->picture.find( fresh[first + k] );
                     if( it == s->picture.end() ) { s->fail( X264HIP_ESTATE ); continue; }
-                    // (rows packed: the staging block is what travels)
-                    if( hipMemcpy2DAsync( stage + k * frame_bytes, (size_t)s->width * s->pix, it->second, (size_t)s->picture_stride * s->pix, (size_t)s->width * s->pix,
+                    // (rows packed: the block is what travels)
+                    if( hipMemcpy2DAsync( s->pic_buf + k * frame_bytes, (size_t)s->width * s->pix, it->second, (size_t)s->picture_stride * s->pix, (size_t)s->width * s->pix,
                                           s->height, hipMemcpyDeviceToDevice, s->stream ) != hipSuccess )
                         s->fail( X264HIP_EDEVICE );
                 }
-            }
-            if( stage && s->T.broadcast( s->T.user, stage, frame_bytes * fresh.size(), 0, s->stream ) ) s->fail( X264HIP_EDEVICE );
-            s->stats[X264HIP_SHARD_BYTES_INPUT] += s->world > 1 ? frame_bytes * fresh.size() : 0;
-            if( stage && s->rank )
-                for( size_t k = 0; k < fresh.size(); k++ )
+            if( s->T.broadcast( s->T.user, s->pic_buf, frame_bytes * cnt, 0, s->stream ) ) s->fail( X264HIP_EDEVICE );
+            s->stats[X264HIP_SHARD_BYTES_INPUT] += s->world > 1 ? frame_bytes * cnt : 0;
+            if( s->rank )
+                for( size_t k = 0; k < cnt; k++ )
                 {
                     // the slot rank 0 announced for this frame
                     int slot = -1;
-                    for( size_t i = 0; i < numbers.size(); i++ ) if( numbers[i] == fresh[k] ) slot = slots[i];
+                    for( size_t i = 0; i < numbers.size(); i++ ) if( numbers[i] == fresh[first + k] ) slot = slots[i];
                     if( slot < 0 ) continue;
                     if( !s->failed )
-                        s->fail( x264hip_frame_put( s->ctx, slot, stage + k * frame_bytes, s->width, 1, nullptr, nullptr, 0, nullptr ) );
+                        s->fail( x264hip_frame_put( s->ctx, slot, s->pic_buf + k * frame_bytes, s->width, 1, nullptr, nullptr, 0, nullptr ) );
                 }
-            if( stage && s->loopback && !s->failed ) // the picture that came back is the one rank 0 holds
+            if( s->loopback && !s->failed ) // the picture that came back is the one rank 0 holds
             {
                 s->loop_checks.push_back( std::make_pair( (void *)nullptr, (void *)nullptr ) ); s->loop_bytes.push_back( 0 );
             }
-            s->hold( stage );
         }
     }
     for( size_t i = 0; i < slots.size(); i++ )
@@ -311,57 +321,55 @@ int run_chunk( x264hip_shard *s, const std::vector<int> &slots, const std::vecto
         s->stats[X264HIP_SHARD_CHUNKS]++;
         s->stats[X264HIP_SHARD_FIELDS_SEARCHED] += mine.size();
     }
-    // ---- 2. list-0 fields for B cells on other ranks: every rank sends each peer exactly the fields that peer asked for
+    // ---- 2. list-0 fields for B cells on other ranks: every rank sends each peer exactly the fields that peer asked for, at most
+    //         l0_fields per pair and piece (piece i of a pair = its fields [i * l0_fields, (i+1) * l0_fields): every rank knows every list)
     if( exchanging )
     {
         const size_t field_bytes = (size_t)s->n_mb * 2 * sizeof( int );
         // give[o][r]: fields rank o owns that rank r wants, in a fixed order
         std::vector<std::vector<std::vector<std::pair<int, int>>>> give( s->world, std::vector<std::vector<std::pair<int, int>>>( s->world ) );
-        size_t total = 0;
+        size_t longest = 0;
         for( int r = 0; r < s->world; r++ )
             for( const auto &k : l0_wanted[r] )
             {
                 if( s->l0_sent.count( std::make_tuple( r, k.first, k.second ) ) ) continue;
                 s->l0_sent.insert( std::make_tuple( r, k.first, k.second ) );
-                give[owner( s, k.first )][r].push_back( k ); // (std::set iteration is sorted: the same order on every rank)
-                total++;
+                std::vector<std::pair<int, int>> &g = give[owner( s, k.first )][r];
+                g.push_back( k ); // (std::set iteration is sorted: the same order on every rank)
+                longest = std::max( longest, g.size() );
             }
-        if( total )
+        for( size_t first = 0; first < longest; first += s->l0_fields )
         {
+            auto piece = [&]( const std::vector<std::pair<int, int>> &g ) { return g.size() > first ? std::min( s->l0_fields, g.size() - first ) : (size_t)0; };
             std::vector<size_t> sb( s->world ), rb( s->world );
-            size_t n_send = 0, n_recv = 0;
+            size_t n_send = 0, n_recv = 0, row = 0;
             for( int r = 0; r < s->world; r++ )
             {
-                sb[r] = give[s->rank][r].size() * field_bytes; rb[r] = give[r][s->rank].size() * field_bytes;
-                n_send += give[s->rank][r].size(); n_recv += give[r][s->rank].size();
+                sb[r] = piece( give[s->rank][r] ) * field_bytes; rb[r] = piece( give[r][s->rank] ) * field_bytes;
+                n_send += piece( give[s->rank][r] ); n_recv += piece( give[r][s->rank] );
             }
-            char *sbuf = (char *)s->dev_alloc( std::max<size_t>( n_send, 1 ) * field_bytes ), *rbuf = (char *)s->dev_alloc( std::max<size_t>( n_recv, 1 ) * field_bytes );
-            size_t row = 0;
-            for( int r = 0; r < s->world && sbuf; r++ )
-                for( const auto &k : give[s->rank][r] )
+            for( int r = 0; r < s->world; r++ )
+                for( size_t k = 0; k < piece( give[s->rank][r] ); k++, row++ )
                 {
-                    auto it = s->slot_of.find( k.first );
+                    const std::pair<int, int> &f = give[s->rank][r][first + k];
+                    auto it = s->slot_of.find( f.first );
                     if( !s->failed && it != s->slot_of.end() )
-                        s->fail( x264hip_export_field( s->ctx, it->second, 0, k.second, sbuf + row * field_bytes ) );
-                    row++;
+                        s->fail( x264hip_export_field( s->ctx, it->second, 0, f.second, s->l0_sbuf + row * field_bytes ) );
                 }
-            if( !sbuf || !rbuf || s->T.send_recv( s->T.user, sbuf, sb.data(), rbuf, rb.data(), s->stream ) ) s->fail( X264HIP_EDEVICE );
+            if( s->T.send_recv( s->T.user, s->l0_sbuf, sb.data(), s->l0_rbuf, rb.data(), s->stream ) ) s->fail( X264HIP_EDEVICE );
             row = 0;
-            for( int o = 0; o < s->world && rbuf; o++ )
-                for( const auto &k : give[o][s->rank] )
+            for( int o = 0; o < s->world; o++ )
+                for( size_t k = 0; k < piece( give[o][s->rank] ); k++, row++ )
                 {
-                    auto it = s->slot_of.find( k.first );
+                    const std::pair<int, int> &f = give[o][s->rank][first + k];
+                    auto it = s->slot_of.find( f.first );
                     if( !s->failed && it != s->slot_of.end() )
-                        s->fail( x264hip_import_field( s->ctx, it->second, 0, k.second, rbuf + row * field_bytes ) );
-                    row++;
+                        s->fail( x264hip_import_field( s->ctx, it->second, 0, f.second, s->l0_rbuf + row * field_bytes ) );
                     s->stats[X264HIP_SHARD_L0_FIELDS]++;
                 }
             s->stats[X264HIP_SHARD_BYTES_L0] += n_recv * field_bytes;
-            if( s->loopback && sbuf && rbuf && n_send )
-            {
-                s->loop_checks.push_back( std::make_pair( (void *)sbuf, (void *)rbuf ) ); s->loop_bytes.push_back( n_send * field_bytes );
-            }
-            else { s->hold( sbuf ); s->hold( rbuf ); }
+            if( s->loopback && n_send && !s->failed )
+                s->loop_keep( s->l0_sbuf, s->l0_rbuf, n_send * field_bytes );
         }
     }
     // ---- 3. the cells of the frames this rank owns; rank 0 also queues the intra sums of every frame (it has all of them resident)
@@ -381,7 +389,7 @@ int run_chunk( x264hip_shard *s, const std::vector<int> &slots, const std::vecto
         s->stats[X264HIP_SHARD_CELLS_EVALUATED] += cells[s->rank].size();
     }
     if( !exchanging ) return s->failed;
-    // ---- 4. summaries to rank 0
+    // ---- 4. summaries to rank 0, sum_cells entries per rank and piece
     {
         std::vector<std::vector<x264hip_cell_ref>> sent( s->world );
         size_t wide = 0;
@@ -394,35 +402,30 @@ int run_chunk( x264hip_shard *s, const std::vector<int> &slots, const std::vecto
         if( s->rank == 0 )
             for( int r = 1; r < s->world; r++ )
                 for( const Field &f : fields[r] ) { rs.push_back( f.slot_b ); rn.push_back( f.number ); rl.push_back( f.list ); rd.push_back( f.dm1 ); }
-        if( wide )
+        if( s->rank == 0 && !rs.empty() && !s->failed )
+            s->fail( x264hip_fields_remote( s->ctx, (int)rs.size(), rs.data(), rn.data(), rl.data(), rd.data() ) );
+        const size_t per = X264HIP_CELL_SUMMARY_INTS( s->mb_h ) * sizeof( int );
+        for( size_t first = 0; first < wide; first += s->sum_cells )
         {
-            const size_t per = X264HIP_CELL_SUMMARY_INTS( s->mb_h ) * sizeof( int ), bytes = wide * per;
-            char *buf = (char *)s->dev_alloc( bytes ), *out = s->rank == 0 ? (char *)s->dev_alloc( bytes * s->world ) : nullptr;
-            if( buf && hipMemsetAsync( buf, 0, bytes, s->stream ) != hipSuccess ) s->fail( X264HIP_EDEVICE );
-            if( buf && !sent[s->rank].empty() && ( s->rank || s->loopback ) && !s->failed )
-                s->fail( x264hip_export_cells( s->ctx, (int)sent[s->rank].size(), sent[s->rank].data(), buf ) );
-            if( !buf || ( s->rank == 0 && !out ) || s->T.gather( s->T.user, buf, out, bytes, 0, s->stream ) ) s->fail( X264HIP_EDEVICE );
-            if( s->rank == 0 && out )
+            const size_t cnt = std::min( s->sum_cells, wide - first ), bytes = cnt * per;
+            auto piece = [&]( int r ) { return sent[r].size() > first ? std::min( cnt, sent[r].size() - first ) : (size_t)0; };
+            if( hipMemsetAsync( s->sum_sbuf, 0, bytes, s->stream ) != hipSuccess ) s->fail( X264HIP_EDEVICE );
+            if( piece( s->rank ) && ( s->rank || s->loopback ) && !s->failed )
+                s->fail( x264hip_export_cells( s->ctx, (int)piece( s->rank ), sent[s->rank].data() + first, s->sum_sbuf ) );
+            if( s->T.gather( s->T.user, s->sum_sbuf, s->sum_rbuf, bytes, 0, s->stream ) ) s->fail( X264HIP_EDEVICE );
+            if( s->rank == 0 )
             {
-                if( !rs.empty() && !s->failed )
-                    s->fail( x264hip_fields_remote( s->ctx, (int)rs.size(), rs.data(), rn.data(), rl.data(), rd.data() ) );
                 for( int r = s->loopback ? 0 : 1; r < s->world; r++ )
-                    if( !sent[r].empty() )
-                    {
-                        if( !s->failed ) // (loopback: every entry is skipped -- the cells are here)
-                            s->fail( x264hip_import_cells( s->ctx, (int)sent[r].size(), sent[r].data(), out + (size_t)r * bytes ) );
-                        s->stats[X264HIP_SHARD_CELLS_IMPORTED] += cells[r].size();
-                    }
+                    if( piece( r ) && !s->failed ) // (loopback: every entry is skipped -- the cells are here)
+                        s->fail( x264hip_import_cells( s->ctx, (int)piece( r ), sent[r].data() + first, s->sum_rbuf + (size_t)r * bytes ) );
                 s->stats[X264HIP_SHARD_BYTES_SUMMARIES] += (size_t)( s->world - 1 ) * bytes;
             }
-            if( s->loopback && buf && out && !sent[0].empty() )
-            {
-                s->loop_checks.push_back( std::make_pair( (void *)buf, (void *)out ) ); s->loop_bytes.push_back( sent[0].size() * per );
-            }
-            else { s->hold( buf ); s->hold( out ); }
+            if( s->loopback && piece( 0 ) && !s->failed )
+                s->loop_keep( s->sum_sbuf, s->sum_rbuf, piece( 0 ) * per );
         }
-        else if( s->rank == 0 && !rs.empty() && !s->failed )
-            s->fail( x264hip_fields_remote( s->ctx, (int)rs.size(), rs.data(), rn.data(), rl.data(), rd.data() ) );
+        if( s->rank == 0 )
+            for( int r = s->loopback ? 0 : 1; r < s->world; r++ )
+                if( !sent[r].empty() ) s->stats[X264HIP_SHARD_CELLS_IMPORTED] += cells[r].size();
     }
     // ---- 5. how it went, for everybody
     post_status( s );
@@ -436,28 +439,31 @@ int fetch_maps( x264hip_shard *s, const std::vector<x264hip_cell_ref> &cells, co
     size_t wide = 0;
     for( int r = 1; r < s->world; r++ ) wide = std::max( wide, by_owner[r].size() );
     if( !wide ) return s->failed;
-    const size_t map_bytes = (size_t)3 * s->n_mb * sizeof( int ), bytes = wide * map_bytes;
-    char *buf = (char *)s->dev_alloc( bytes ), *out = s->rank == 0 ? (char *)s->dev_alloc( bytes * s->world ) : nullptr;
-    if( buf && s->rank )
-        for( size_t k = 0; k < by_owner[s->rank].size(); k++ )
-            if( !s->failed )
-                s->fail( x264hip_export_cell_map( s->ctx, &by_owner[s->rank][k], buf + k * map_bytes ) );
-    if( !buf || ( s->rank == 0 && !out ) || s->T.gather( s->T.user, buf, out, bytes, 0, s->stream ) ) s->fail( X264HIP_EDEVICE );
-    if( s->rank == 0 && out )
+    const size_t map_bytes = (size_t)3 * s->n_mb * sizeof( int );
+    for( size_t first = 0; first < wide; first += s->map_cells )
     {
-        for( int r = 1; r < s->world; r++ )
-            for( size_t k = 0; k < by_owner[r].size(); k++ )
-            {
-                x264hip_cell_ref c = by_owner[r][k];
-                c.with_ref1_l0 = 0;
+        const size_t cnt = std::min( s->map_cells, wide - first ), bytes = cnt * map_bytes;
+        auto piece = [&]( int r ) { return by_owner[r].size() > first ? std::min( cnt, by_owner[r].size() - first ) : (size_t)0; };
+        if( s->rank )
+            for( size_t k = 0; k < piece( s->rank ); k++ )
                 if( !s->failed )
-                    s->fail( x264hip_import_cell_map( s->ctx, &c, out + (size_t)r * bytes + k * map_bytes ) );
-                s->stats[X264HIP_SHARD_MAPS_FETCHED]++;
-            }
-        s->stats[X264HIP_SHARD_BYTES_MAPS] += (size_t)( s->world - 1 ) * bytes;
-        s->stats[X264HIP_SHARD_FETCH_COMMANDS]++;
+                    s->fail( x264hip_export_cell_map( s->ctx, &by_owner[s->rank][first + k], s->map_sbuf + k * map_bytes ) );
+        if( s->T.gather( s->T.user, s->map_sbuf, s->map_rbuf, bytes, 0, s->stream ) ) s->fail( X264HIP_EDEVICE );
+        if( s->rank == 0 )
+        {
+            for( int r = 1; r < s->world; r++ )
+                for( size_t k = 0; k < piece( r ); k++ )
+                {
+                    x264hip_cell_ref c = by_owner[r][first + k];
+                    c.with_ref1_l0 = 0;
+                    if( !s->failed )
+                        s->fail( x264hip_import_cell_map( s->ctx, &c, s->map_rbuf + (size_t)r * bytes + k * map_bytes ) );
+                    s->stats[X264HIP_SHARD_MAPS_FETCHED]++;
+                }
+            s->stats[X264HIP_SHARD_BYTES_MAPS] += (size_t)( s->world - 1 ) * bytes;
+        }
     }
-    s->hold( buf ); s->hold( out );
+    if( s->rank == 0 ) s->stats[X264HIP_SHARD_FETCH_COMMANDS]++;
     post_status( s );
     return s->failed;
 }
@@ -518,6 +524,30 @@ int before_mbtree( void *user, const x264hip_mbtree_op *ops, int n )
 } // namespace
 
 // ---- public entry points -----------------------------------------------------------------------------------------------------------------
+namespace
+{
+// what x264hip_shard_open created, and nothing else: the transport stays the caller's until an open has succeeded
+void free_own( x264hip_shard *s )
+{
+    (void)hipSetDevice( s->device );
+    if( s->stream ) (void)hipStreamSynchronize( s->stream );
+    for( auto &c : s->loop_checks ) { if( c.first ) (void)hipFree( c.first ); if( c.second ) (void)hipFree( c.second ); }
+    if( s->la ) x264hip_lookahead_close( s->la );
+    if( s->status_ev ) (void)hipEventDestroy( s->status_ev );
+    for( int k = 0; k < x264hip_shard::CMD_RING; k++ ) if( s->cmd_ev[k] ) (void)hipEventDestroy( s->cmd_ev[k] );
+    (void)hipFree( s->status_dev ); (void)hipHostFree( s->status_host ); (void)hipFree( s->cmd_dev ); (void)hipHostFree( s->cmd_host );
+    for( char *b : { s->pic_buf, s->l0_sbuf, s->l0_rbuf, s->sum_sbuf, s->sum_rbuf, s->map_sbuf, s->map_rbuf } ) (void)hipFree( b );
+    delete s;
+}
+// bytes per exchange buffer: X264HIP_SHARD_PIECE_BYTES (the tests make it small, so that every step travels in several pieces)
+size_t piece_budget( size_t dflt )
+{
+    const char *e = getenv( "X264HIP_SHARD_PIECE_BYTES" );
+    const long long v = e ? atoll( e ) : 0;
+    return v > 0 ? (size_t)v : dflt;
+}
+} // namespace
+
 extern "C" int x264hip_shard_open( x264hip_shard **out, int device, const x264hip_la_params *params, const x264hip_shard_transport *transport )
 {
     if( !out || !params || !transport || transport->world < 1 || transport->rank < 0 || transport->rank >= transport->world ) return X264HIP_EINVAL;
@@ -545,7 +575,26 @@ extern "C" int x264hip_shard_open( x264hip_shard **out, int device, const x264hi
         rc = X264HIP_ENOMEM;
     for( int k = 0; k < x264hip_shard::CMD_RING && !rc; k++ )
         if( hipEventCreateWithFlags( &s->cmd_ev[k], hipEventDisableTiming ) != hipSuccess ) rc = X264HIP_ENOMEM;
-    if( rc ) { x264hip_shard_close( s ); return rc; }
+    if( !rc && hooked )
+    {
+        // the exchange buffers: whole frames / fields / summaries / maps per piece, at least one
+        const size_t frame_bytes = (size_t)s->width * s->height * s->pix, field_bytes = (size_t)s->n_mb * 2 * sizeof( int ),
+                     sum_bytes = X264HIP_CELL_SUMMARY_INTS( s->mb_h ) * sizeof( int ), map_bytes = (size_t)3 * s->n_mb * sizeof( int );
+        s->pic_frames = std::max<size_t>( 1, piece_budget( (size_t)128 << 20 ) / frame_bytes );
+        s->l0_fields = std::max<size_t>( 1, piece_budget( (size_t)32 << 20 ) / ( field_bytes * s->world ) );
+        s->sum_cells = std::max<size_t>( 1, piece_budget( (size_t)4 << 20 ) / sum_bytes );
+        s->map_cells = std::max<size_t>( 1, piece_budget( (size_t)32 << 20 ) / map_bytes );
+        const size_t gathered = s->rank == 0 ? s->world : 0;
+        if( hipMalloc( &s->pic_buf, s->pic_frames * frame_bytes ) != hipSuccess ||
+            hipMalloc( &s->l0_sbuf, s->l0_fields * s->world * field_bytes ) != hipSuccess || hipMalloc( &s->l0_rbuf, s->l0_fields * s->world * field_bytes ) != hipSuccess ||
+            hipMalloc( &s->sum_sbuf, s->sum_cells * sum_bytes ) != hipSuccess || ( gathered && hipMalloc( &s->sum_rbuf, s->sum_cells * sum_bytes * gathered ) != hipSuccess ) ||
+            hipMalloc( &s->map_sbuf, s->map_cells * map_bytes ) != hipSuccess || ( gathered && hipMalloc( &s->map_rbuf, s->map_cells * map_bytes * gathered ) != hipSuccess ) )
+        {
+            (void)hipGetLastError();
+            rc = X264HIP_ENOMEM;
+        }
+    }
+    if( rc ) { free_own( s ); return rc; } // (no STOP, no transport destroy: nothing was agreed with anybody yet)
     s->status_host[0] = s->status_host[1] = 0;
     *out = s;
     return X264HIP_OK;
@@ -576,12 +625,22 @@ extern "C" int x264hip_shard_serve( x264hip_shard *s )
         if( recv_cmd( s, cmd ) ) return s->failed; // (the transport itself failed: nothing more can be agreed on)
         check_status( s, true ); // the previous command's verdict (recv_cmd waited for the stream: it is in)
         if( cmd[0] == CMD_STOP ) { s->stop_seen = 1; return s->failed; }
+        if( cmd[0] == CMD_RESET )
+        {
+            s->forget_sequence();
+            if( !s->failed ) s->fail( x264hip_lookahead_reset( s->la ) );
+            post_status( s );
+            continue;
+        }
         if( cmd[0] == CMD_FETCH )
         {
-            const int n = (int)cmd[1];
+            // (the block is the same on every rank: a record count that does not match its length is rank 0's mistake, and rank 0 --
+            // which built it -- sees the same thing; the status word says so, nobody enters a gather the others size differently)
+            const int64_t n = cmd.size() >= 2 ? cmd[1] : -1;
+            if( n < 0 || (int64_t)cmd.size() != 2 + 7 * n ) { s->fail( X264HIP_ESTATE ); post_status( s ); continue; }
             std::vector<x264hip_cell_ref> cells;
             std::vector<int> numbers;
-            for( int k = 0; k < n && 2 + 7 * k + 6 < (int)cmd.size(); k++ )
+            for( int k = 0; k < (int)n; k++ )
             {
                 const int64_t *r = &cmd[2 + 7 * k];
                 x264hip_cell_ref c = { (int)r[0], (int)r[1], (int)r[2], (int)r[3], (int)r[4], (int)r[5] };
@@ -590,9 +649,9 @@ extern "C" int x264hip_shard_serve( x264hip_shard *s )
             fetch_maps( s, cells, numbers );
             continue;
         }
-        if( cmd[0] != CMD_CHUNK || cmd.size() < 4 ) { s->fail( X264HIP_ESTATE ); continue; }
+        if( cmd[0] != CMD_CHUNK || cmd.size() < 4 ) { s->fail( X264HIP_ESTATE ); post_status( s ); continue; }
         const int n = (int)cmd[1], ns2 = s->ns * s->ns;
-        if( (int)cmd.size() < 4 + 2 * n + ns2 ) { s->fail( X264HIP_ESTATE ); continue; }
+        if( n < 0 || (int)cmd.size() < 4 + 2 * n + ns2 ) { s->fail( X264HIP_ESTATE ); post_status( s ); continue; }
         std::vector<int> slots( n ), numbers( n ), cls( ns2 );
         for( int i = 0; i < n; i++ ) { slots[i] = (int)cmd[4 + i]; numbers[i] = (int)cmd[4 + n + i]; }
         for( int i = 0; i < ns2; i++ ) cls[i] = (int)cmd[4 + 2 * n + i];
@@ -637,20 +696,29 @@ extern "C" int x264hip_shard_loopback_verify( x264hip_shard *s, int *n_checked )
     return bad ? X264HIP_ESTATE : X264HIP_OK;
 }
 
+// A new sequence on every rank (frame numbers start at 0 again): rank 0 calls this INSTEAD of x264hip_lookahead_reset on the shard's
+// lookahead -- the ranks key what they hold by frame number, so resetting rank 0's lookahead alone would make them take the new
+// sequence's frames for ones they have already ingested and searched.
+extern "C" int x264hip_shard_reset( x264hip_shard *s )
+{
+    if( !s || s->rank != 0 ) return X264HIP_EINVAL;
+    if( check_status( s, false ) ) return s->failed;
+    if( send_cmd( s, std::vector<int64_t>( 1, CMD_RESET ) ) ) return s->failed;
+    s->forget_sequence();
+    s->fail( x264hip_lookahead_reset( s->la ) );
+    post_status( s );
+    return s->failed;
+}
+
 extern "C" void x264hip_shard_close( x264hip_shard *s )
 {
     if( !s ) return;
     (void)hipSetDevice( s->device );
     if( s->rank == 0 && s->world > 1 && s->cmd_dev && s->stream )
         send_cmd( s, std::vector<int64_t>( 1, CMD_STOP ) ); // also after a failure: the other ranks are waiting for a command
-    if( s->stream ) s->release_all();
-    for( auto &c : s->loop_checks ) { if( c.first ) (void)hipFree( c.first ); if( c.second ) (void)hipFree( c.second ); }
-    if( s->la ) x264hip_lookahead_close( s->la );
-    if( s->status_ev ) (void)hipEventDestroy( s->status_ev );
-    for( int k = 0; k < x264hip_shard::CMD_RING; k++ ) if( s->cmd_ev[k] ) (void)hipEventDestroy( s->cmd_ev[k] );
-    (void)hipFree( s->status_dev ); (void)hipHostFree( s->status_host ); (void)hipFree( s->cmd_dev ); (void)hipHostFree( s->cmd_host );
-    if( s->T.destroy ) s->T.destroy( s->T.user );
-    delete s;
+    x264hip_shard_transport T = s->T;
+    free_own( s );
+    if( T.destroy ) T.destroy( T.user );
 }
 
 // ---- the RCCL transport: librccl.so is opened at run time (the library, like the reference's OpenCL path, common/opencl.c:53-61, builds and

@@ -2624,7 +2624,7 @@ static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request 
     // (me_translate_kernel).
     const size_t b_scratch = align_up( scratch_total, 256 ), b_table = align_up( sizeof( MfReq<T> ) * n, 256 ), b_mvc = align_up( (size_t)n * MF_MVC_MAX * 2 * sizeof( int16_t ), 256 ),
                  b_nmvc = align_up( sizeof( int ) * n, 256 ), b_out = align_up( sizeof( int ) * 4 * n, 256 ), b_index = align_up( sizeof( int ) * n, 256 ),
-                 b_raw = on_dev ? 0 : align_up( sizeof( x264hip_me_request ) * (size_t)n, 256 ), b_off = on_dev ? 0 : align_up( sizeof( unsigned ) * n, 256 );
+                 b_raw = on_dev ? 0 : align_up( sizeof( x264hip_me_request ) * (size_t)n, 256 ), b_off = on_dev ? 0 : align_up( sizeof( unsigned long long ) * n, 256 );
     const size_t b_host = b_raw + b_off + b_index; // what the host writes: contiguous
     const size_t need = b_scratch + b_table + b_mvc + b_nmvc + b_host + b_out;
     if( need > ctx->me_pool_bytes )
@@ -2649,7 +2649,7 @@ static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request 
     int *n_mvc_dev = (int *)( (char *)mvc_dev + b_mvc );
     char *host_dev = (char *)n_mvc_dev + b_nmvc; // the device copy of the host-written block: raw requests, TESA offsets, index
     const x264hip_me_request *raw_dev = on_dev ? reqs_dev : (const x264hip_me_request *)host_dev;
-    unsigned *off_dev = (unsigned *)( host_dev + b_raw );
+    unsigned long long *off_dev = (unsigned long long *)( host_dev + b_raw ); // 64-bit: a batch's TESA scratch passes 4 GiB at ~20 k requests of range 64
     int *index_dev = (int *)( host_dev + b_raw + b_off ), *out_dev = on_dev ? out_dev_user : (int *)( host_dev + b_host );
     int rc = X264HIP_OK;
 #define MECK( call ) do { if( ( call ) != hipSuccess ) { ctx->broken = 1; return X264HIP_EDEVICE; } } while( 0 )
@@ -2657,13 +2657,13 @@ static int me_search_batch_t( x264hip_ctx *ctx, int n, const x264hip_me_request 
     if( !on_dev )
     {
         x264hip_me_request *raw = (x264hip_me_request *)ctx->me_host;
-        unsigned *off = (unsigned *)( ctx->me_host + b_raw );
+        unsigned long long *off = (unsigned long long *)( ctx->me_host + b_raw );
         int *idx = (int *)( ctx->me_host + b_raw + b_off );
         memcpy( raw, reqs_host, sizeof( x264hip_me_request ) * (size_t)n );
         size_t t = 0;
         for( int i = 0; i < n; i++ )
         {
-            off[i] = (unsigned)t;
+            off[i] = (unsigned long long)t;
             if( reqs_host[i].me_method == 4 ) t += tesa_bytes( reqs_host[i].me_range );
         }
         // one launch per class of methods: the pattern searches (DIA, HEX, UMH) and the exhaustive ones (ESA, TESA) are separate builds

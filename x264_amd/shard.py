@@ -798,6 +798,14 @@ class CShard:
         self.L.x264hip_shard_status.argtypes = [self.C.c_void_p]
         return self.L.x264hip_shard_status(self.h)
 
+    def reset(self):
+        """rank 0: a new sequence on every rank (x264hip_shard_reset)"""
+        from . import lib
+        self.L.x264hip_shard_reset.argtypes = [self.C.c_void_p]
+        lib._ck(self.L.x264hip_shard_reset(self.h), "shard_reset")
+        self._n = 0
+        self.lookahead._n_put = 0
+
     def serve(self):
         self.L.x264hip_shard_serve.argtypes = [self.C.c_void_p]
         return self.L.x264hip_shard_serve(self.h)
@@ -823,9 +831,10 @@ class CShard:
             self.lookahead.h = None
 
 
-def run_c_window_shard(torch, lib, rank, world, dev_index, cfg, dev_clip, transport, qp_offsets=False, vbv=False):
+def run_c_window_shard(torch, lib, rank, world, dev_index, cfg, dev_clip, transport, qp_offsets=False, vbv=False, passes=1):
     """One pass of ONE stream over `world` ranks through the C entry points: (outputs on rank 0 | None, seconds, stats, rc of serve()).
-    dev_clip: the clip on rank 0's GPU ([F, H, W]); the other ranks receive the pictures chunk by chunk inside the timed region."""
+    dev_clip: the clip on rank 0's GPU ([F, H, W]); the other ranks receive the pictures chunk by chunk inside the timed region.
+    passes > 1: the same clip again after x264hip_shard_reset (outputs: a list per pass)."""
     import time
     L = lib.load()
     F = dev_clip.shape[0] if dev_clip is not None else 0
@@ -835,13 +844,20 @@ def run_c_window_shard(torch, lib, rank, world, dev_index, cfg, dev_clip, transp
         t0 = time.perf_counter()
         outs, rc = None, 0
         if rank == 0:
-            sh.put_frames([dev_clip[i].data_ptr() for i in range(F)], cfg["width"])
-            outs = []
-            while True:
-                o = sh.lookahead.get(True, qp_offsets, vbv)
-                if o is None:
-                    break
-                outs.append(o)
+            every = []
+            for k in range(passes):
+                if k:
+                    sh.reset()
+                sh.put_frames([dev_clip[i].data_ptr() for i in range(F)], cfg["width"])
+                outs = []
+                while True:
+                    o = sh.lookahead.get(True, qp_offsets, vbv)
+                    if o is None:
+                        break
+                    outs.append(o)
+                every.append(outs)
+            if passes > 1:
+                outs = every
             lib._ck(L.x264hip_synchronize(sh.ctx_handle()), "synchronize")
             lib._ck(sh.status(), "shard_status")  # a rank that failed anywhere fails the pass here at the latest
         else:
