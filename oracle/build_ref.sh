@@ -13,8 +13,15 @@
 #   3. oracle/ref_harness.c (our own file) which #includes encoder/analyse.c of the reference so the
 #      static slicetype/me functions are reachable, linked into libx264ref{8,10}.so.
 #
+#   4. the same 8-bit sources once more under a configuration whose only difference is HAVE_OPENCL (configure run without
+#      --disable-opencl: "#define HAVE_OPENCL (BIT_DEPTH==8)", configure:1479-1491), with OUR translation unit
+#      x264_amd/csrc/slicetype_hip.c standing in for the two files the reference adds in that build (encoder/slicetype-cl.c,
+#      common/opencl.c; Makefile:254): libx264ref8hip.so is the unmodified reference encoder whose accelerator hook
+#      (encoder/slicetype.c:878-897) calls libx264hip.so.  No OpenCL code, header stand-in or generated file is involved:
+#      the reference's own extras/cl.h supplies the types its structs name.
+#
 # Products: oracle/_ref/libx264ref8.so, oracle/_ref/libx264ref10.so  (C-ABI, used via ctypes by
-# tests/ and by bench.py's cpu_baseline leg only).
+# tests/ and by bench.py's cpu_baseline leg only), oracle/_ref/libx264ref8hip.so (tests only).
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 REF="${X264_REF:-/root/reference}"
@@ -68,4 +75,27 @@ for depth in 8 10; do
     gcc $CFLAGS -DHIGH_BIT_DEPTH=$hbd -DBIT_DEPTH=$depth -I"$HERE" -Werror=implicit-function-declaration -c "$HERE/ref_harness.c" -o "$OUT/obj/ref_harness-$depth.o"
     gcc -shared -o "$OUT/libx264ref$depth.so" "$OUT/obj/ref_harness-$depth.o" $OBJS $COMMON_OBJS -lm -lpthread
 done
-echo "build_ref: built $OUT/libx264ref8.so $OUT/libx264ref10.so"
+# ---- 4. the reference with its accelerator hook bound to libx264hip.so
+mkdir -p "$OUT/cfg_hip"
+if [ ! -f "$OUT/cfg_hip/config.h" ]; then
+    (cd "$OUT/cfg_hip" && "$REF/configure" --disable-asm --disable-avs --disable-swscale \
+        --disable-lavf --disable-ffms --disable-gpac --disable-lsmash --enable-static --enable-pic \
+        --disable-cli > configure.log 2>&1) || { cat "$OUT/cfg_hip/configure.log"; exit 1; }
+fi
+grep -q 'define HAVE_OPENCL (BIT_DEPTH==8)' "$OUT/cfg_hip/config.h" || { echo "build_ref: configure did not enable the accelerator seam" >&2; exit 1; }
+CFLAGS_HIP="${CFLAGS/-I$OUT\/cfg /-I$OUT/cfg_hip }"
+pids=()
+CFLAGS_SAVE="$CFLAGS"; CFLAGS="$CFLAGS_HIP"
+OBJS=""
+for s in $SRCS_X; do
+    o="$OUT/obj/$(echo "$s" | tr '/' '_' | sed 's/\.c$//')-8hip.o"
+    compile "$s" "$o" "-DHIGH_BIT_DEPTH=0 -DBIT_DEPTH=8"
+    OBJS="$OBJS $o"
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+REPO="$(dirname "$HERE")"
+gcc $CFLAGS -DHIGH_BIT_DEPTH=0 -DBIT_DEPTH=8 -I"$REPO/include" -Wall -Werror=implicit-function-declaration -c "$REPO/x264_amd/csrc/slicetype_hip.c" -o "$OUT/obj/slicetype_hip-8.o"
+gcc $CFLAGS -DHIGH_BIT_DEPTH=0 -DBIT_DEPTH=8 -I"$HERE" -Werror=implicit-function-declaration -c "$HERE/ref_harness.c" -o "$OUT/obj/ref_harness-8hip.o"
+gcc -shared -o "$OUT/libx264ref8hip.so" "$OUT/obj/ref_harness-8hip.o" "$OUT/obj/slicetype_hip-8.o" $OBJS $COMMON_OBJS -lm -lpthread -ldl
+CFLAGS="$CFLAGS_SAVE"
+echo "build_ref: built $OUT/libx264ref8.so $OUT/libx264ref10.so $OUT/libx264ref8hip.so"

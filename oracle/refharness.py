@@ -11,12 +11,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 MAT = 18 * 18  # (X264_BFRAME_MAX+2)^2
 
 
-def lib_path(bit_depth=8):
-    return os.path.join(_HERE, "_ref", "libx264ref%d.so" % bit_depth)
+def lib_path(bit_depth=8, seam=False):
+    """seam=True: the 8-bit reference built with its accelerator hook bound to libx264hip.so (x264_amd/csrc/slicetype_hip.c in place of
+    encoder/slicetype-cl.c / common/opencl.c; oracle/build_ref.sh step 4)"""
+    return os.path.join(_HERE, "_ref", "libx264ref%d%s.so" % (bit_depth, "hip" if seam else ""))
 
 
-def available(bit_depth=8):
-    return os.path.exists(lib_path(bit_depth))
+def available(bit_depth=8, seam=False):
+    return os.path.exists(lib_path(bit_depth, seam))
 
 
 def _ptr(a):
@@ -24,8 +26,8 @@ def _ptr(a):
 
 
 class Ref:
-    def __init__(self, width, height, preset="medium", tune="", opts="", bit_depth=8):
-        self.lib = C.CDLL(lib_path(bit_depth))
+    def __init__(self, width, height, preset="medium", tune="", opts="", bit_depth=8, seam=False):
+        self.lib = C.CDLL(lib_path(bit_depth, seam))
         L = self.lib
         L.rh_open.restype = C.c_void_p
         L.rh_open.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
@@ -125,6 +127,30 @@ class Ref:
         r = self.lib.rh_get_cell(self.ctx, idx, d0, d1, _ptr(lc), _ptr(rows), _ptr(summ))
         assert r == 0
         return lc, rows, tuple(int(x) for x in summ)
+
+    def accel_state(self):
+        """1 = slicetype_frame_cost goes through the accelerator hook, 0 = C path (never asked for, or fell back at open), -1 = the hook failed"""
+        return int(self.lib.rh_accel_state(self.ctx))
+
+    def encode_run(self, luma_frames, chroma=None):
+        """A whole x264_encoder_encode run.  Returns dict(frame, type, cost, cost_aq, map_crc [n, 8], bytes, stream_crc, seconds), frames in
+        coded order (see rh_encode_run in ref_harness.c for what the CRCs cover)."""
+        fr = np.ascontiguousarray(luma_frames, dtype=self.dtype)
+        n = fr.shape[0]
+        luma_only = 1
+        if chroma is not None:
+            cb, cr = (np.ascontiguousarray(c, dtype=self.dtype).reshape(n, -1) for c in chroma)
+            fr = np.ascontiguousarray(np.concatenate([fr.reshape(n, -1), cb, cr], axis=1))
+            luma_only = 0
+        frame, typ, nbytes = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        cost, cost_aq = np.zeros((n, 18, 18), np.int32), np.zeros((n, 18, 18), np.int32)
+        crc = np.zeros((n, 8), np.uint32)
+        stream, sec = C.c_uint32(0), C.c_double(0)
+        f = self.lib.rh_encode_run
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+        r = f(self.ctx, _ptr(fr), n, luma_only, _ptr(frame), _ptr(typ), _ptr(cost), _ptr(cost_aq), _ptr(crc), _ptr(nbytes), C.byref(stream), C.byref(sec))
+        assert r == n, (r, n)
+        return dict(frame=frame, type=typ, cost=cost, cost_aq=cost_aq, map_crc=crc, bytes=nbytes, stream_crc=int(stream.value), seconds=sec.value)
 
     def lookahead_run(self, luma_frames, with_qp_offsets=False, forced_types=None, with_vbv=False, rc_cells=None, pts=None, chroma=None, quant_offsets=None):
         """rc_cells: [n, 2] (b-p0, p1-b) per OUTPUT index -> also runs the real x264_rc_analyse_slice on every leaving frame
