@@ -330,7 +330,7 @@ def cpu_baseline(cfg, frames, preset, opts, lookahead_threads=None):
     return dict(value=round(n / dt, 2), unit="frames/s", cores=1, kind="port", sample="%d frames %dx%d, oracle restatement, 1 thread" % (n, cfg["width"], cfg["height"]))
 
 
-def make_clip_device(torch, W, H, F, seed, bit_depth=8, scene_cuts=(), pan=(5, 3), noise=3, texture=0.18, fade=None):
+def make_clip_device(torch, W, H, F, seed, bit_depth=8, scene_cuts=(), pan=(5, 3), noise=3, texture=0.18, fade=None, still=None):
     """The synthetic recipe of x264_amd/synth.py (smooth random field, per-frame pan, +-noise, inversion at scene cuts) generated
     on the device with torch: used for the 4K workload, where the numpy generator would take longer than the benchmark."""
     g = torch.Generator(device="cuda").manual_seed(seed)
@@ -345,8 +345,10 @@ def make_clip_device(torch, W, H, F, seed, bit_depth=8, scene_cuts=(), pan=(5, 3
     cuts = sorted(set(int(c) for c in scene_cuts))
     scale, maxv = 1 << (bit_depth - 8), (1 << bit_depth) - 1
     out = torch.empty((F, H, W), dtype=torch.uint8 if bit_depth == 8 else torch.int16, device="cuda")
+    from x264_amd.synth import pan_offsets
+    offs = pan_offsets(F, pan, still)
     for i in range(F):
-        dx, dy = (pan[0] * i) % 256, (pan[1] * i) % 128
+        dx, dy = offs[i]
         img = field[dy:dy + H, dx:dx + W]
         if sum(1 for c in cuts if c <= i) & 1:
             img = 255.0 - img
@@ -511,11 +513,11 @@ def main():
     for sgi in range(S):
         if args.device_clip or sgi > 0:
             # only the first segment is generated on the host (the CPU baseline runs on it); the others come from the same recipe on the device
-            dv = make_clip_device(torch, W, H, F, 100 + rank * S + sgi, args.bit_depth, scene_cuts=(F // 3, F // 3 + 47), fade=(2 * F // 3, 10, 0.6, 12))
+            dv = make_clip_device(torch, W, H, F, 100 + rank * S + sgi, args.bit_depth, scene_cuts=(F // 3, F // 3 + 47), fade=(2 * F // 3, 10, 0.6, 12), still=(2 * F // 3 - 2, 16))
             fr = None
         else:
             fr = make_clip(W, H, F, seed=100 + rank * S + sgi, bit_depth=args.bit_depth, scene_cuts=(F // 3, F // 3 + 47), fade=(2 * F // 3, 10, 0.6, 12),
-                           pan=(5, 3))
+                           pan=(5, 3), still=(2 * F // 3 - 2, 16))
             dv = torch.from_numpy(fr).cuda(dev_index)
         seg_frames.append(fr); seg_dev.append(dv)
     frames = seg_frames[0]

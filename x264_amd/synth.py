@@ -15,8 +15,22 @@ def _box5(a, axis):
     return out / 5.0
 
 
+def pan_offsets(n_frames, pan, still=None):
+    """Offset of the sampling window per frame: pan[0] / pan[1] samples further every frame; inside still = (start, length) the camera
+    all but stops (one sample per frame horizontally) -- a fade over a fast pan is hidden from the lookahead's weight analysis, which
+    compares frames without motion compensation (encoder/slicetype.c:191-222), and real fades mostly sit on quiet shots."""
+    dx = dy = 0
+    out = []
+    for i in range(n_frames):
+        out.append((dx % 256, dy % 128))
+        slow = still is not None and still[0] <= i + 1 < still[0] + still[1]
+        dx += 1 if slow else pan[0]
+        dy += 0 if slow else pan[1]
+    return out
+
+
 def make_clip(width, height, n_frames, seed=1, bit_depth=8, scene_cuts=(), fade=None, noise=3, pan=(3, 2),
-              texture=0.18):
+              texture=0.18, still=None):
     """Return uint8/uint16 array [n_frames, height, width] of luma samples.
 
     scene_cuts: frame indices at which the picture is inverted (a hard cut).
@@ -24,6 +38,7 @@ def make_clip(width, height, n_frames, seed=1, bit_depth=8, scene_cuts=(), fade=
     texture: share of white noise mixed into the smooth field.
     fade: (start, length, gain_end, offset_end) -- linear fade applied over [start, start+length) and
           held afterwards.
+    still: (start, length) -- frames during which the pan slows to one sample per frame (see pan_offsets).
     """
     rng = np.random.default_rng(seed)
     fh, fw = height + 128 + 8, width + 256 + 8
@@ -39,8 +54,9 @@ def make_clip(width, height, n_frames, seed=1, bit_depth=8, scene_cuts=(), fade=
     frames = np.empty((n_frames, height, width), dtype=np.uint8 if bit_depth == 8 else np.uint16)
     scale = 1 << (bit_depth - 8)
     maxv = (1 << bit_depth) - 1
+    offs = pan_offsets(n_frames, pan, still)
     for i in range(n_frames):
-        dx, dy = (pan[0] * i) % 256, (pan[1] * i) % 128
+        dx, dy = offs[i]
         img = field[dy:dy + height, dx:dx + width].copy()
         inverted = sum(1 for c in cuts if c <= i) & 1
         if inverted:
