@@ -510,14 +510,18 @@ def main():
     S = max(1, args.inflight)
     # every (rank, segment) gets its own part of the synthetic sequence (different seed = different content)
     seg_frames, seg_dev = [], []
+    # the camera all but stops under the fade (x264_amd/synth.py pan_offsets): the lookahead's weight analysis then keeps its weights and
+    # the weighted searches are part of the timed region.  X264HIP_BENCH_NO_STILL=1: the clip of rounds 1-5 (the fade under a fast pan,
+    # no weight ever kept) for comparisons with their figures
+    still = None if os.environ.get("X264HIP_BENCH_NO_STILL") else (2 * F // 3 - 2, 16)
     for sgi in range(S):
         if args.device_clip or sgi > 0:
             # only the first segment is generated on the host (the CPU baseline runs on it); the others come from the same recipe on the device
-            dv = make_clip_device(torch, W, H, F, 100 + rank * S + sgi, args.bit_depth, scene_cuts=(F // 3, F // 3 + 47), fade=(2 * F // 3, 10, 0.6, 12), still=(2 * F // 3 - 2, 16))
+            dv = make_clip_device(torch, W, H, F, 100 + rank * S + sgi, args.bit_depth, scene_cuts=(F // 3, F // 3 + 47), fade=(2 * F // 3, 10, 0.6, 12), still=still)
             fr = None
         else:
             fr = make_clip(W, H, F, seed=100 + rank * S + sgi, bit_depth=args.bit_depth, scene_cuts=(F // 3, F // 3 + 47), fade=(2 * F // 3, 10, 0.6, 12),
-                           pan=(5, 3), still=(2 * F // 3 - 2, 16))
+                           pan=(5, 3), still=still)
             dv = torch.from_numpy(fr).cuda(dev_index)
         seg_frames.append(fr); seg_dev.append(dv)
     frames = seg_frames[0]
@@ -548,7 +552,11 @@ def main():
     prof_ms = prof_launches = prof_searches = 0
     la_stats = np.zeros(8, np.uint64)
     dev_counters = np.zeros(16, np.uint64)
+    wspec = np.zeros(4, np.uint64)
     for la in las:
+        wb = np.zeros(4, np.uint64)
+        lib._ck(la.L.x264hip_weighted_stats(la.ctx_handle(), wb.ctypes.data_as(ctypes.c_void_p)), "weighted_stats")
+        wspec += wb
         cbuf = np.zeros(16, np.uint64)
         lib._ck(la.L.x264hip_counters(la.ctx_handle(), cbuf.ctypes.data_as(ctypes.c_void_p), 16), "counters")
         dev_counters += cbuf
@@ -570,6 +578,7 @@ def main():
     # the search kernel alone: one context, nothing else in flight (what the rocprofv3 counter passes in profiles/ measure as well);
     # in the timed region several contexts launch concurrently, which stretches every launch
     solo = None
+    solo_lat = None
     kernel_times = None
     if not args.no_check:
         lib.search_profile(las[0].L, las[0].ctx_handle(), 3)  # | 2: an event pair around every ingest and cell kernel as well
@@ -577,6 +586,7 @@ def main():
         las[0].run(device_ptrs=wl.seg_ptrs[0], stride=W, paced=args.paced)
         kernel_times = lib.kernel_profile(las[0].L, las[0].ctx_handle())
         cms_, cnl_, ncell_ = lib.cell_profile(las[0].L, las[0].ctx_handle())
+        solo_lat = lib.search_profile_latency(las[0].L, las[0].ctx_handle())
         ms_, nl_, ns_ = lib.search_profile(las[0].L, las[0].ctx_handle(), 0)
         if ms_ > 0 and ns_:
             solo = (ms_, nl_, ns_)
@@ -648,6 +658,9 @@ def main():
                    {"achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5), "what": "launches of the timed region (no solo pass: --no-check)",
                     "launches": prof_launches, "searches": prof_searches, "avg_launch_ms": round(prof_ms / max(prof_launches, 1), 4),
                     "us_per_search": round(prof_ms * 1e3 / max(prof_searches, 1), 3), "traffic": traffic}),
+                **({"small_launches": {"what": "the search launches of the same pass that cannot fill the chip (fewer waves than wave slots: as long as their dependency chain): "
+                                                 "the weighted searches of the fade, one batch per submission (x264hip_prefetch_weighted_fields)",
+                                                "launches": solo_lat[1], "searches": solo_lat[2], "ms": round(solo_lat[0], 4)}} if solo_lat and solo_lat[1] else {}),
                 **{"traffic_source": tsrc,
                    "concurrent": {"what": "the launches of the timed region: %d contexts launching at once, every launch stretched by the others (sum of launch "
                                           "durations / step time = %.2f)" % (S, prof_ms / max(dt * 1e3, 1e-9)),
@@ -669,6 +682,8 @@ def main():
                                            "unclaimed_field_share": round(1.0 - float(dev_counters[2]) / max(float(dev_counters[0]) - float(dev_counters[13]), 1.0), 4),
                                            "unused_cell_share": round(1.0 - float(dev_counters[4]) / max(float(dev_counters[5]), 1.0), 4),
                                            "note": "counters since the contexts were opened (warm-up, timed steps)"},
+                                "weighted_speculation": {"searches_enqueued": int(wspec[0]), "fields_taken_over": int(wspec[1]), "cells_evaluated": int(wspec[2]), "b_cells_used": int(wspec[3]),
+                                                         "what": "x264hip_prefetch_weighted_fields: the searches (and P cells) of the pairs whose weight the analysis keeps, ahead of the requests"},
                                 "host_ms": {"frame_cost": round(la_stats[4] / 1e6, 2), "weights_analyse": round(la_stats[5] / 1e6, 2),
                                             "prefetch_mbtree": round(la_stats[6] / 1e6, 2), "api_total": round(la_stats[7] / 1e6, 2)}},
         }
@@ -726,12 +741,91 @@ def main():
                 res["segments_value"] = res["value"]
                 res.update(value=window["value"], scaling="strong", ms_per_step=round(window["seconds"] * 1e3, 3))
                 res["config"] = {"workload": window["workload"], "parallelism": "window x%d" % world}
+        if world == 1 and not args.no_extra and still is not None:
+            # ---- the clip of rounds 1-5 (the same recipe with the fade under the full pan: the weight analysis never keeps a weight there), for
+            # comparisons with their figures: what the kept weights of the default clip cost is the difference
+            try:
+                dev5 = [make_clip_device(torch, W, H, F, 100 + sgi, args.bit_depth, scene_cuts=(F // 3, F // 3 + 47), fade=(2 * F // 3, 10, 0.6, 12)) for sgi in range(S)]
+                wl5 = Workload(torch, lib, shard, cfg, dev_index, 0, S, F, dev5, False)
+                try:
+                    dt5, o5 = wl5.timed(args.steps, args.warmup)
+                    st5 = sum((la.stats() for la in wl5.las), np.zeros(8, np.uint64))
+                finally:
+                    wl5.close()
+                res["round5_clip"] = {"what": "the same workload on the clip of rounds 1-5 (fade under a 5 x 3 samples per frame pan: no weight is ever kept, no weighted search runs)",
+                                      "value": round(S * F * args.steps / dt5, 2), "unit": "frames/s", "ms_per_step": round(dt5 / args.steps * 1e3, 3),
+                                      "weights_analysed": int(st5[2]), "weights_kept": int(st5[3])}
+                del dev5
+            except Exception as e:  # pragma: no cover
+                res["round5_clip"] = {"error": repr(e)}
+        if world == 1 and not args.no_extra:
+            # ---- what a caller with HOST pictures gets (x264_encoder_encode is handed host buffers, encoder/encoder.c:3368-3454,
+            # common/frame.c:445-447): the same segments, the clips in pinned host memory, through the same put / get calls.  The pictures
+            # cross PCIe inside the timed region (W x H samples each), on the contexts' DMA streams; `value` above is NOT this figure.
+            try:
+                frame_bytes = W * H * (1 if args.bit_depth == 8 else 2)
+                hp = torch.empty(256 << 20, dtype=torch.uint8).pin_memory()
+                dp = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+                dp.copy_(hp, non_blocking=True); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(8):
+                    dp.copy_(hp, non_blocking=True)
+                torch.cuda.synchronize()
+                pcie_peak = 8 * hp.numel() / (time.perf_counter() - t0) / 1e9
+                del hp, dp
+                host_clips = [dv.cpu().pin_memory() for dv in seg_dev]
+                wlh = Workload(torch, lib, shard, cfg, dev_index, 0, S, F, host_clips, False)
+                try:
+                    steps_h = max(2, args.steps // 2)
+                    dth, oh = wlh.timed(steps_h, 1)
+                    for sgi in range(S):
+                        assert outputs_signature(oh[sgi], nb) == outputs_signature(outs_all[sgi], nb), "host-fed segment %d differs from the device-resident pass" % sgi
+                    hstat = np.zeros(3, np.uint64)
+                    for la in wlh.las:
+                        b = np.zeros(3, np.uint64)
+                        lib._ck(la.L.x264hip_host_transfer_stats(la.ctx_handle(), b.ctypes.data_as(ctypes.c_void_p)), "host_transfer_stats")
+                        hstat += b
+                finally:
+                    wlh.close()
+                fps_h = S * F * steps_h / dth
+                # one stream, encoder-paced, from host buffers: pinned, and plain pageable memory (staged through the library's pinned ring)
+                one = {}
+                for key_h, clip_h in (("pinned", host_clips[0]), ("pageable", seg_dev[0].cpu())):
+                    w1 = Workload(torch, lib, shard, cfg, dev_index, 0, 1, F, [clip_h], True)
+                    try:
+                        dt1, o1 = w1.timed(2, 1, paced=True)
+                        assert outputs_signature(o1[0], nb) == outputs_signature(outs_all[0], nb), "paced host-fed stream differs"
+                        one[key_h] = round(F * 2 / dt1, 2)
+                    finally:
+                        w1.close()
+                bound = min(res["value"], pcie_peak * 1e9 / frame_bytes)
+                res["host_fed"] = {"what": "the headline's segments with every picture in pinned HOST memory: %d x %d frames per step through x264hip_lookahead_put_frames "
+                                           "(host pointers), H2D on the contexts' DMA streams inside the timed region" % (S, F),
+                                   "fps": round(fps_h, 2), "pcie_GBps": round(fps_h * frame_bytes / 1e9, 2), "pcie_peak_GBps": round(pcie_peak, 2),
+                                   "pcie_peak_what": "a plain pinned-to-device copy loop (8 x 256 MiB) on this box",
+                                   "pcie_bound_fps": round(pcie_peak * 1e9 / frame_bytes, 1), "share_of_min_value_pcie_bound": round(fps_h / bound, 3),
+                                   "pictures_direct_from_pinned": int(hstat[1]), "pictures_staged": int(hstat[2]),
+                                   "single_stream_paced_fps": one, "checked": "types + every cost cell == the device-resident passes"}
+                del host_clips
+            except Exception as e:  # pragma: no cover
+                res["host_fed"] = {"error": repr(e)}
         if world == 1 and not args.no_extra and (W, H) == (1920, 1080):
             # the other single-GPU forms of the BASELINE configurations, clips generated on the device, each with the same check as
             # the headline (the batched passes that were timed == one encoder-paced pass: frame types and every cost cell)
-            def other_config(key, what, cfg_x, Fx, Sx, steps_x, depth_x=8, cuts=None):
+            def other_config(key, what, cfg_x, Fx, Sx, steps_x, depth_x=8, cuts=None, fixture=None):
+                """fixture = (name of a tests/golden/fullsize_*.npz, its clip as upscaled_clip() arguments): segment 0 runs the clip the
+                real reference decided in the build container, and its coded order, slice types and every cost cell must equal the fixture's"""
                 try:
                     devx = [make_clip_device(torch, cfg_x["width"], cfg_x["height"], Fx, 300 + sgi, depth_x, scene_cuts=cuts if cuts is not None else (Fx // 3,)) for sgi in range(Sx)]
+                    fix = None
+                    if fixture is not None:
+                        import zlib
+                        from x264_amd.synth import upscaled_clip
+                        fix = np.load(os.path.join(ROOT, "tests", "golden", "fullsize_%s.npz" % fixture[0]))
+                        clip0 = upscaled_clip(cfg_x["width"], cfg_x["height"], Fx, depth_x, **fixture[1])
+                        assert all(zlib.crc32(clip0[k].tobytes()) == int(fix["frame_crc"][k]) for k in (0, Fx // 2, Fx - 1)), "the fixture's clip did not regenerate"
+                        devx[0] = torch.from_numpy(clip0.view(np.int16) if depth_x > 8 else clip0).cuda(dev_index)
+                        del clip0
                     wlx = Workload(torch, lib, shard, cfg_x, dev_index, 0, Sx, Fx, devx, False)
                     try:
                         dtx, ox = wlx.timed(steps_x, 1)
@@ -740,21 +834,30 @@ def main():
                         nbx = cfg_x["bframes"] + 2
                         for sgi in range(Sx):
                             assert outputs_signature(ox[sgi], nbx) == outputs_signature(opx[sgi], nbx), "%s: batched and paced passes disagree" % key
+                        if fix is not None:
+                            o0 = ox[0]
+                            assert [o.frame for o in o0] == [int(v) for v in fix["idx"]] and [o.type for o in o0] == [int(v) for v in fix["type"]], "%s: decisions differ from the reference's fixture" % key
+                            for k, o in enumerate(o0):
+                                assert all(o.cost_est[i][j] == int(fix["cost"][k][i][j]) for i in range(nbx) for j in range(nbx)), "%s: cost cells of output %d differ from the reference's fixture" % (key, k)
                     finally:
                         wlx.close()
                     del devx
-                    res[key] = {"workload": what + ", %d segment(s) of %d frames in flight, clips generated on the device" % (Sx, Fx),
+                    res[key] = {"workload": what + ", %d segment(s) of %d frames in flight, clips generated on the device" % (Sx, Fx) +
+                                            (" (segment 0: the clip of tests/golden/fullsize_%s.npz)" % fixture[0] if fixture else ""),
                                 "value": round(Sx * Fx * steps_x / dtx, 2), "unit": "frames/s", "paced_fps": round(Sx * Fx / dtp, 2),
-                                "checked": "batched == paced (types + cost cells)"}
+                                "checked": "batched == paced (types + cost cells)" + ("; segment 0 == the real reference's decisions and cost cells (fixture)" if fixture else "")}
                 except Exception as e:  # pragma: no cover
                     res[key] = {"error": str(e)}
-            # BASELINE configs[2]: 3840x2160, --preset slower --me umh --merange 32 (the lookahead searches with HEX, range 32, b-adapt 2, rc-lookahead 60)
+            from tests.golden.make_golden import FULL_SIZE_CASES
+            # BASELINE configs[2]: 3840x2160, --preset slower --me umh --merange 32 (the lookahead searches with HEX, range 32, b-adapt 2, rc-lookahead 60);
+            # 96 frames per segment: the 60-frame window fills and slides under the trellis
             other_config("configs2_4k", "3840x2160 8-bit, --preset slower --me umh --merange 32 (BASELINE configs[2])",
-                         lib.la_config(3840, 2160, "slower", bit_depth=8, me="umh", me_range=32), 64, S, 4)
+                         lib.la_config(3840, 2160, "slower", bit_depth=8, me="umh", me_range=32), 96, S, 3)
             # BASELINE configs[4] on one GPU: 7680x4320 10-bit, --preset veryslow --me tesa (HEX with SATD full-pel costs, bframes 8, b-adapt 2,
-            # rc-lookahead 60); a dozen frames per segment: the window never fills, every frame is decided at the flush
-            other_config("configs4_8k_1gpu", "7680x4320 10-bit, --preset veryslow --me tesa (BASELINE configs[4], one GPU; a dozen frames per segment never fill the 60-frame window: every frame is decided at the flush)",
-                         lib.la_config(7680, 4320, "veryslow", bit_depth=10, me="tesa"), 12, 4, 6, depth_x=10, cuts=(7,))
+            # rc-lookahead 60); 72 frames per segment: the window fills and slides (288 GB of HBM hold two such segments with room to spare)
+            c4 = FULL_SIZE_CASES["configs4_8k_10bit"]
+            other_config("configs4_8k_1gpu", "7680x4320 10-bit, --preset veryslow --me tesa (BASELINE configs[4], one GPU; the 60-frame window fills and slides)",
+                         lib.la_config(7680, 4320, "veryslow", bit_depth=10, me="tesa"), c4[7], 2, 2, depth_x=10, cuts=(47,), fixture=("configs4_8k_10bit", c4[6]))
             # ONE stream alone on the GPU (one context, one host thread: what a single encoder instance sees), batched and
             # encoder-paced, for configs[1] and configs[2]; same check as above
             res["single_stream"] = {}

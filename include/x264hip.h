@@ -126,9 +126,15 @@ int  x264hip_flush( x264hip_ctx *ctx );
  * Resets the slot's search/cost state like mc.c:471-481. */
 int  x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, int stride, int is_device,
                         const void *cb, const void *cr, int cstride, const uint16_t *inv_qscale );
-/* The same for n frames whose luma already sits in device memory (all with the same stride): one launch per ingest
- * kernel instead of one per frame. */
+/* The same for n frames (all with the same stride): one launch per ingest kernel instead of one per frame.  The pointers are device
+ * pointers or -- all of them, luma only -- HOST pointers, which is what x264_encoder_encode is handed (encoder/encoder.c:3368-3454,
+ * common/frame.c:445-447): the pictures then travel on a DMA stream of the context's own, sixteen to a group, and each group's ingest
+ * kernels run behind its copies while the next group is on its way; nothing waits for the compute stream.  Buffers the DMA engines can
+ * read where they are (hipHostMalloc / hipHostRegister: the caller's choice) are copied from there, pageable ones through a ring of
+ * pinned staging copies (a memcpy per picture).  x264hip_frame_put with is_device == 0 takes the same road for one picture.
+ * x264hip_host_transfer_stats: bytes copied so far, pictures taken as they were / through the ring. */
 int  x264hip_frame_put_batch( x264hip_ctx *ctx, int n, const int *slots, const void *const *luma_dev, int stride );
+int  x264hip_host_transfer_stats( x264hip_ctx *ctx, uint64_t out[3] );
 /* same with the 4:2:0 chroma planes of every frame (device pointers; both arrays NULL = luma only) */
 int  x264hip_frame_put_batch_yuv( x264hip_ctx *ctx, int n, const int *slots, const void *const *luma_dev, int stride,
                                   const void *const *cb_dev, const void *const *cr_dev, int cstride );
@@ -160,6 +166,16 @@ int  x264hip_weight_cost( x264hip_ctx *ctx, int slot_fenc, int slot_ref, const x
  * return at once.  A later x264hip_weight_cost() for the same frames (and the same weight, or NULL) is answered
  * from these results without a launch; anything else is computed on demand as before.  Never changes results. */
 int  x264hip_prefetch_weight_costs( x264hip_ctx *ctx, int n, const int *slot_fenc, const int *slot_ref, const x264hip_weight *w );
+/* The searches a P request would make WITH a weight, ahead of the request (encoder/slicetype.c:855-867: the first request of a list-0
+ * field as a P frame brings the weight x264_weights_analyse arrives at, :284-501 -- a function of the two pictures, which a caller who
+ * has their totals and the two cost sums can evaluate as soon as the sums are in): pair i = frame slot_fenc[i] searched on slot_ref[i]
+ * weighted by w[i], into a second list-0 field of that distance, and the P cell over it.  An x264hip_frame_cost call that first-triggers
+ * the field with the SAME weight takes both over without a launch; any other request ignores them.  The B cells that would read one of
+ * these fields -- as the frame's own list-0 field or as the list-1 reference's vectors (slicetype.c:629) -- are evaluated over them as
+ * well, into a second spare of the cell.  Never changes results.
+ * x264hip_weighted_stats: searches enqueued this way, fields a request took over, cells evaluated over them, B cells of those used. */
+int  x264hip_prefetch_weighted_fields( x264hip_ctx *ctx, int n, const int *slot_fenc, const int *slot_ref, const x264hip_weight *w );
+int  x264hip_weighted_stats( x264hip_ctx *ctx, uint64_t out[4] );
 
 /* getters (device -> host); sizes in elements: n_mb = mb_w*mb_h */
 int  x264hip_get_lowres( x264hip_ctx *ctx, int slot, int plane, void *dst, int dst_stride ); /* incl. 32 px border */
@@ -510,6 +526,9 @@ int  x264hip_counters( x264hip_ctx *ctx, uint64_t *out, int n );
 /* Per-launch HIP-event timing of the search kernel on the context's stream.  Returns the totals gathered
  * since profiling was last (re)enabled; enable = 1/0 switches it and clears the totals, -1 only reads. */
 int  x264hip_search_profile( x264hip_ctx *ctx, int enable, double *total_ms, uint64_t *launches, uint64_t *searches ); /* [0] searches [1] cells [2] cache hits [3] frames */
+/* ... and the launches among them that cannot fill the chip (fewer waves than the device has wave slots: as long as their dependency chain
+ * whatever runs them), for themselves; the totals above then hold the chip-filling launches of the throughput kernel only.  Read before x264hip_search_profile, which resets both. */
+int  x264hip_search_profile_latency( x264hip_ctx *ctx, double *total_ms, uint64_t *launches, uint64_t *searches );
 /* The same window's totals for the cost cell launches (cell kernels + their sums): together with the searches, the device work a
  * window shard spreads over ranks (bench.py: window_shard.amdahl). */
 int  x264hip_cell_profile( x264hip_ctx *ctx, double *total_ms, uint64_t *launches, uint64_t *cells );
@@ -600,6 +619,9 @@ typedef struct x264hip_backend
     /* contract of x264hip_flush: called when the last delayed frame of a flush has been handed out, so that no work the lookahead
      * asked for stays queued in the backend behind the end of the stream; may be NULL */
     int (*flush)( void *user );
+    /* contract of x264hip_prefetch_weighted_fields: the list-0 searches (and P cells) of the pairs whose weight the lookahead has found it
+     * will keep, ahead of the requests; may be NULL */
+    int (*prefetch_weighted_fields)( void *user, int n, const int *slot_fenc, const int *slot_ref, const x264hip_weight *w );
 } x264hip_backend;
 
 typedef struct x264hip_la_frame
@@ -643,7 +665,8 @@ int  x264hip_lookahead_classes( const x264hip_la_params *params, unsigned char *
 int  x264hip_lookahead_delay( x264hip_lookahead *la );       /* h->frames.i_delay */
 /* forced_type: X264_TYPE_AUTO (0) normally */
 int  x264hip_lookahead_put_frame( x264hip_lookahead *la, const void *luma, int stride, int is_device, int forced_type );
-/* n device-resident frames at once (display order, all X264_TYPE_AUTO): batched ingest when the backend supports it */
+/* n frames at once (display order, all X264_TYPE_AUTO): batched ingest when the backend supports it.  Device pointers, or -- with the
+ * HIP backend -- host pointers (x264hip_frame_put_batch: pinned buffers are read where they are, pageable ones staged) */
 int  x264hip_lookahead_put_frames( x264hip_lookahead *la, int n, const void *const *luma_dev, int stride );
 /* a whole clip of device-resident frames in one call: n frames put and every decided frame taken (out[n], coded order; *n_out of them),
  * paced != 0: one put and one get per frame like x264_encoder_encode (encoder/encoder.c:3300-3440), then the flush; else all frames

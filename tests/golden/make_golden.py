@@ -74,6 +74,9 @@ FULL_SIZE_CASES = {
     "configs3_4k_gop250": ("medium", "bframes=8,rc-lookahead=60", dict(bframes=8, rc_lookahead=60), 8, 3840, 2160,
                            dict(seed=61, pan=(1, 0), fade=(150, 60, 0.8, 8)), 250),
     "configs4_8k_10bit": ("veryslow", "me=tesa", dict(me="tesa"), 10, 7680, 4320, dict(seed=62, pan=(2, 1), scene_cuts=(47,)), 72),
+    # BASELINE configs[2]: the 60-frame window fills and slides under the b-adapt-2 trellis, HEX with range 32 (UMH capped, slicetype.c:50-59)
+    "configs2_4k_umh32": ("slower", "me=umh,merange=32", dict(me="umh", me_range=32), 8, 3840, 2160,
+                          dict(seed=63, pan=(3, 2), scene_cuts=(31,), fade=(50, 10, 0.7, 8)), 72),
 }
 
 

@@ -43,7 +43,10 @@ class OracleBackend:
                                   lib.MBTREE_FN(self._mbtree), lib.QP_OFFSETS_FN(self._qp), lib.PUT_BATCH_FN(0),
                                   lib.PREFETCH_WEIGHTS_FN(self._prefetch_weights) if speculative else lib.PREFETCH_WEIGHTS_FN(0),
                                   lib.RECALC_FN(self._recalc), lib.ROW_SATDS_FN(self._rows), lib.FRAME_PUT_YUV_FN(self._put_yuv), lib.ADD_QOFFS_FN(self._add_qoffs), lib.PUT_BATCH_YUV_FN(0),
-                                  lib.GOP_HINT_FN(self._gop_hint) if speculative else lib.GOP_HINT_FN(0))
+                                  lib.GOP_HINT_FN(self._gop_hint) if speculative else lib.GOP_HINT_FN(0), lib.FLUSH_FN(0),
+                                  lib.PREFETCH_WEIGHTS_FN(self._prefetch_weighted) if speculative else lib.PREFETCH_WEIGHTS_FN(0))
+        self.announced_fields = set()
+        self.weighted_searches = self.weighted_searches_predicted = 0
 
     def _gop_hint(self, user, anchor, period):
         self.gop_hints.append((anchor, period))
@@ -52,6 +55,13 @@ class OracleBackend:
     def _prefetch(self, user, slots, numbers, n):
         if self.on_prefetch is not None:  # window sharding (x264_amd/shard.py): the speculative searches of this chunk, spread over ranks
             self.on_prefetch([slots[i] for i in range(n)], [numbers[i] for i in range(n)])
+        return 0
+
+    def _prefetch_weighted(self, user, n, sf, sr, w):
+        """x264hip_prefetch_weighted_fields: remembered, and every weighted first-trigger search is held against it (_cost)"""
+        for i in range(n):
+            assert w[i].on
+            self.announced_fields.add((sf[i], sr[i], w[i].scale, w[i].denom, w[i].offset))
         return 0
 
     def _prefetch_weights(self, user, n, sf, sr, w):
@@ -121,6 +131,8 @@ class OracleBackend:
                 if w and w[0].on:
                     wt = OWeight(w[0].on, w[0].scale, w[0].denom, w[0].offset)
                     wplane = o.weight_plane(cfg, F0["planes"][0], wt)
+                    self.weighted_searches += 1
+                    self.weighted_searches_predicted += (sb, s0, w[0].scale, w[0].denom, w[0].offset) in self.announced_fields
                 if wt is None and ((0, d0 - 1) in B["spec"] or (0, d0 - 1) in B["remote"]):  # a speculative (possibly imported, possibly remote) field
                     if (0, d0 - 1) in B["spec"]:
                         B["fields"][(0, d0 - 1)] = B["spec"][(0, d0 - 1)]

@@ -371,6 +371,79 @@ def test_searches_wave_form_equals_scalar_form(depth):
 
 
 @pytest.mark.parametrize("depth", [8, 10])
+def test_searches_wave_form_equals_oracle(depth):
+    """The wave form of the main-encode searches DIRECTLY against the oracle (oracle/x264_oracle.c me_search_full, pinned to the real
+    reference by tests/test_me_full_vs_ref.py): 2 500 random requests per depth, half of them the exhaustive methods -- ESA through the
+    v_qsad_pk_u16_u8 scan (8-bit) and TESA with its survivor lists -- every partition size, ranges 8 / 16 / 24, predictors anywhere in the
+    window, up to four extra candidates.  (test_searches_wave_form_equals_scalar_form compares the wave form with the scalar form of the
+    same header; this one has no leg in common with the code under test.)"""
+    import torch
+    from oracle.oraclelib import Oracle
+    from tests.common import ME_SIZES, oracle_me_search
+    from tests.test_me_full_host import request_geometry
+    z = np.load(os.path.join(GOLD, "me_full_d%d.npz" % depth))
+    W, H, pw, ph, padh, padv, mv_range = (int(v) for v in z["geom"])
+    o = Oracle(depth)
+    dt = np.uint8 if depth == 8 else np.uint16
+    vdt = np.uint8 if depth == 8 else np.int16
+    isz = 1 if depth == 8 else 2
+    hplanes = [np.ascontiguousarray(z["planes"][p_], dt) for p_ in range(4)]
+    hframe = np.ascontiguousarray(z["fenc_frame"], dt)
+    hint = np.ascontiguousarray(z["integral"])
+    cost_mv = np.ascontiguousarray(z["cost_mv"])
+    centre = (cost_mv.size - 1) // 2
+    names = ["dia", "hex", "umh", "esa", "tesa"]
+    rng = np.random.default_rng(4100 + depth)
+    reqs, want = [], []
+    for t in range(2500):
+        me = (3, 4, 3, 4, 0, 1, 2, 3, 4, 2)[t % 10]
+        i_pixel = int(rng.integers(0, 7))
+        bw, bh = ME_SIZES[i_pixel]
+        mb_x, mb_y = int(rng.integers(0, W // 16)), int(rng.integers(0, H // 16))
+        xoff, yoff = int(rng.integers(0, 16 // bw)) * bw, int(rng.integers(0, 16 // bh)) * bh
+        subme = int(rng.choice([1, 2, 5, 7]))
+        me_range = int(rng.choice([8, 16, 16, 24]))
+        call = [i_pixel, mb_x, mb_y, xoff, yoff]
+        smin, smax, lim_min, lim_max, sx, sy, org = request_geometry(z["geom"], call)
+        mvp = [int(rng.integers(smin[k], smax[k] + 1)) for k in range(2)]
+        n_mvc = int(rng.integers(0, 5))
+        mvc = np.zeros((4, 2), np.int16)
+        for i in range(n_mvc):
+            mvc[i] = [int(rng.integers(smin[k] - 8, smax[k] + 9)) for k in range(2)]
+        fenc = np.zeros((16, 16), dt)
+        blk = hframe[sy:sy + bh, sx:sx + bw]
+        fenc[:blk.shape[0], :blk.shape[1]] = blk
+        full = call + [subme, me_range, mvp[0], mvp[1], n_mvc] + [int(v) for v in mvc.reshape(-1)]
+        want.append((oracle_me_search(o, names[me], hplanes, hint, cost_mv, z["geom"], fenc, full), subme))
+        q = lib.MeRequest()
+        q.i_pixel, q.me_method, q.subpel_refine, q.me_range = i_pixel, me, subme, me_range
+        q.mbcmp_satd, q.fpelcmp_satd = 1, int(me == 4)
+        q.x, q.y = sx, sy
+        for k in range(2):
+            q.mvp[k] = mvp[k]
+            q.spel_min[k], q.spel_max[k], q.lim_min[k], q.lim_max[k] = smin[k], smax[k], lim_min[k], lim_max[k]
+        q.n_mvc = n_mvc
+        for i in range(4):
+            q.mvc[i][0], q.mvc[i][1] = int(mvc[i][0]), int(mvc[i][1])
+        reqs.append(q)
+    planes = [torch.from_numpy(hplanes[p_].view(vdt)).cuda() for p_ in range(4)]
+    frame = torch.from_numpy(hframe.view(vdt)).cuda()
+    integral = torch.from_numpy(hint.view(np.int16)).cuda()
+    cmv = torch.from_numpy(cost_mv.view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    org0 = padv * pw + padh
+    ctx = lib.Context(64, 64, bit_depth=depth, max_frames=2, mv_range=32)
+    try:
+        got = ctx.me_search_batch(reqs, frame.data_ptr(), frame.shape[1], [p_.data_ptr() + org0 * isz for p_ in planes], pw,
+                                  integral.data_ptr() + org0 * 2, ph * pw, cmv.data_ptr() + 2 * centre)
+    finally:
+        ctx.close()
+    for k, (w, subme) in enumerate(want):
+        n = 4 if subme >= 2 else 3
+        assert np.array_equal(got[k][:n], w[:n]), (k, names[reqs[k].me_method], reqs[k].i_pixel, reqs[k].me_range, got[k].tolist(), w.tolist())
+
+
+@pytest.mark.parametrize("depth", [8, 10])
 def test_integral_init(depth):
     """x264hip_integral_init against the integral planes the reference built (x264_frame_filter, recorded in the golden file) and
     against plain box sums; then the TESA requests of the recording run on the DEVICE-built planes."""

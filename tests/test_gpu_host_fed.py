@@ -1,0 +1,50 @@
+"""Pictures handed over in HOST memory, the way x264_encoder_encode gets them (encoder/encoder.c:3368-3454, common/frame.c:445-447):
+x264hip_lookahead_put_frames / x264hip_frame_put_batch with host pointers -- pinned buffers read by the DMA engines where they are,
+pageable ones staged through the library's pinned ring -- and the one-picture road of x264hip_lookahead_put_frame( is_device = 0 ) give
+the decisions and cost cells of the device-resident run; nothing waits for the compute stream on the way in."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from x264_amd import lib
+from x264_amd.synth import make_clip
+
+pytestmark = pytest.mark.gpu
+
+
+def _sig(outs, nb):
+    return [(o.frame, o.type, [o.cost_est[i][j] for i in range(nb) for j in range(nb)]) for o in outs]
+
+
+@pytest.mark.parametrize("W,H,depth", [(704, 576, 8), (1280, 720, 10)])
+def test_host_pictures_equal_device_pictures(W, H, depth):
+    import torch
+    nf = 70
+    frames = make_clip(W, H, nf, seed=17, bit_depth=depth, scene_cuts=(31,), fade=(45, 8, 0.7, 6), pan=(4, 2))
+    cfg = lib.la_config(W, H, "medium", bit_depth=depth)
+    nb = cfg["bframes"] + 2
+    dev = torch.from_numpy(frames.view(np.int16) if depth > 8 else frames).cuda()
+    pinned = torch.from_numpy(frames.view(np.int16) if depth > 8 else frames).pin_memory()
+    pageable = np.ascontiguousarray(frames)
+    want = None
+    for name, ptrs in (("device", [dev[i].data_ptr() for i in range(nf)]), ("pinned", [pinned[i].data_ptr() for i in range(nf)]),
+                       ("pageable", [pageable[i].ctypes.data for i in range(nf)])):
+        for paced in (False, True):
+            la = lib.Lookahead(cfg, max_frames=nf + 4)
+            try:
+                outs = la.run(device_ptrs=ptrs, stride=W, paced=paced)
+                st = np.zeros(3, np.uint64)
+                lib._ck(la.L.x264hip_host_transfer_stats(la.ctx_handle(), st.ctypes.data_as(C.c_void_p)), "host_transfer_stats")
+            finally:
+                la.close()
+            if want is None:
+                want = _sig(outs, nb)
+            assert _sig(outs, nb) == want, (name, paced)
+            px = 1 if depth == 8 else 2
+            if name == "device":
+                assert tuple(st) == (0, 0, 0)
+            elif name == "pinned":
+                assert tuple(int(v) for v in st) == (nf * W * H * px, nf, 0)
+            else:
+                assert tuple(int(v) for v in st) == (nf * W * H * px, 0, nf)

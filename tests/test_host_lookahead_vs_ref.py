@@ -178,6 +178,10 @@ def test_speculative_weight_pairs_predict_every_request(paced):
         assert np.array_equal(got, c[:5, :5])
     assert be.weighted_requests > 0, "the clip was meant to exercise weightp"
     assert be.weighted_predicted == be.weighted_requests
+    # ... and every weighted SEARCH a P request triggered had been announced with that very weight before the request came
+    # (x264hip_prefetch_weighted_fields: the verdict of the weight analysis taken ahead of time for every queued pair)
+    assert be.weighted_searches > 0
+    assert be.weighted_searches_predicted == be.weighted_searches, (be.weighted_searches_predicted, be.weighted_searches)
 
 
 def _run_unpaced(la, frames):

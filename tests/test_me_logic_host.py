@@ -21,7 +21,18 @@ SRC = os.path.join(HERE, "tools", "me_logic_host.cpp")
 OUT = os.path.join(HERE, "tools", "_build", "libme_logic_host.so")
 
 
+_FUSED = [0]  # the build under test: me_logic.h's ME_FUSED_START (the default, 0, and the fused start set)
+
+
+@pytest.fixture(params=[0, 1], ids=["plain-start", "fused-start"], autouse=True)
+def _start_form(request):
+    _FUSED[0] = request.param
+    yield
+
+
 def _lib():
+    global OUT
+    OUT = os.path.join(HERE, "tools", "_build", "libme_logic_host%s.so" % ("_fused" if _FUSED[0] else ""))
     hdr = os.path.join(ROOT, "x264_amd", "csrc", "me_logic.h")
     hdr2 = os.path.join(ROOT, "x264_amd", "csrc", "strip_layout.h")
     from oracle import oraclelib
@@ -29,7 +40,7 @@ def _lib():
     olib = os.path.join(ROOT, "oracle", "liboracle.so")
     if not os.path.exists(OUT) or max(os.path.getmtime(SRC), os.path.getmtime(hdr), os.path.getmtime(hdr2), os.path.getmtime(olib)) > os.path.getmtime(OUT):
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "x264_amd", "csrc"), "-I" + os.path.join(ROOT, "oracle"),
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-DME_FUSED_START=%d" % _FUSED[0], "-I" + os.path.join(ROOT, "x264_amd", "csrc"), "-I" + os.path.join(ROOT, "oracle"),
                                "-o", OUT, SRC, olib, "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
     return C.CDLL(OUT)
 

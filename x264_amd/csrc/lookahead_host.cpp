@@ -57,6 +57,7 @@ struct LaFrame
     float weighted_cost_delta[BMAX + 2]; // f_weighted_cost_delta, frame.c:798
     bool prefetch_submitted = false;
     bool weights_prefetched = false;
+    int weight_group = 0;             // the speculative submission (flush_prefetch) that queued this frame's weight tests
     // VBV lookahead (slicetype.c:1224-1286): what the frames after this one are planned to be and to cost
     int planned_type[LOOKAHEAD_MAX + 1] = { T_AUTO };
     int planned_satd[LOOKAHEAD_MAX + 1] = { 0 };
@@ -160,6 +161,11 @@ struct Lookahead
         if( need( be.frame_cost( be.user, frames[p0]->slot, frames[p1]->slot, fenc->slot, b - p0, p1 - b, do_search, w, with_intra,
                                  ref1_valid, &out ) ) )
             return 0;
+        // The device has answered for a frame of the newest speculative submission: its cells are in, the cost sums of its weight tests
+        // were queued right behind them.  The verdicts are taken now and the searches of the pairs that keep a weight go out while the
+        // decisions are still busy elsewhere -- a request that brings such a weight then finds the field searched, not merely queued.
+        if( !weight_tests.empty() && fenc->weight_group >= weight_tests.front().group )
+            speculate_weighted_fields( fenc->weight_group );
         if( b == p1 )
             fenc->intra_mbs[b - p0] = out.intra_mbs;
         if( with_intra )
@@ -244,6 +250,30 @@ struct Lookahead
         return true;
     }
 
+    // Second half of x264_weights_analyse in lookahead mode (:371-470): the two cost sums, the verdict.  A function of the two pictures
+    // alone (the sums come from the backend), so it can also run ahead of the request (speculate_weighted_fields).
+    // 1 = the weight `out` is kept, 0 = none, -1 = the backend failed.  ratio: minscore / origscore (X264_WEIGHTP_FAKE).
+    int weight_verdict( LaFrame *fenc, LaFrame *ref, const x264hip_weight &guess, const x264hip_weight &cand, x264hip_weight &out, float &ratio )
+    {
+        int mindenom = guess.denom, minscale = guess.scale, minoff = 0, found = 0;
+        unsigned minscore = 0, origscore = 0;
+        if( need( be.weight_cost( be.user, fenc->slot, ref->slot, nullptr, &origscore ) ) ) return -1;
+        minscore = origscore;
+        if( !minscore ) return 0;
+        {
+            unsigned s = 0;
+            if( need( be.weight_cost( be.user, fenc->slot, ref->slot, &cand, &s ) ) ) return -1;
+            s += weight_header_cost( cand );
+            if( s < minscore ) { minscore = s; minscale = cand.scale; minoff = cand.offset; found = 1; }
+        }
+        while( mindenom > 0 && !( minscale & 1 ) ) { mindenom--; minscale >>= 1; }
+        if( !found || ( minscale == 1 << mindenom && minoff == 0 ) || (float)minscore / origscore > 0.998f )
+            return 0;
+        out.on = 1; out.scale = minscale; out.denom = mindenom; out.offset = minoff;
+        ratio = (float)minscore / origscore;
+        return 1;
+    }
+
     void weights_analyse( LaFrame *fenc, LaFrame *ref )
     {
         stats[2]++;
@@ -254,35 +284,63 @@ struct Lookahead
             wt.on = 0; wt.scale = 1; wt.denom = 0; wt.offset = 0;
             return;
         }
-        int mindenom = wt.denom, minscale = wt.scale, minoff = 0, found = 0;
         if( !fenc->intra_calculated )
         {
             LaFrame *one[1] = { fenc };
             frame_cost( one, 0, 0, 0 );
         }
         if( err ) { wt.on = 0; return; }
-        unsigned minscore = 0, origscore = 0;
         ScopeNs tm( stats[5] );
-        if( need( be.weight_cost( be.user, fenc->slot, ref->slot, nullptr, &origscore ) ) ) { wt.on = 0; return; }
-        minscore = origscore;
-        if( !minscore ) { wt.on = 0; wt.scale = 1; wt.denom = 0; wt.offset = 0; /* keeps the guessed values off */ return; }
+        // the weights the next requests will arrive at, searched before they are asked for (the sums they need are in by now)
+        speculate_weighted_fields( fenc->weight_group );
+        const x264hip_weight guess = wt;
+        float ratio = 0.f;
+        const int v = weight_verdict( fenc, ref, guess, cand, wt, ratio );
+        if( v <= 0 )
         {
-            const int cur_scale = cand.scale, i_off = cand.offset;
-            unsigned s = 0;
-            if( need( be.weight_cost( be.user, fenc->slot, ref->slot, &cand, &s ) ) ) { wt.on = 0; return; }
-            s += weight_header_cost( cand );
-            if( s < minscore ) { minscore = s; minscale = cur_scale; minoff = i_off; found = 1; }
-        }
-        while( mindenom > 0 && !( minscale & 1 ) ) { mindenom--; minscale >>= 1; }
-        if( !found || ( minscale == 1 << mindenom && minoff == 0 ) || (float)minscore / origscore > 0.998f )
-        {
-            wt.on = 0; wt.scale = 1; wt.denom = 0; wt.offset = 0;
+            wt.on = 0;
+            if( v == 0 ) { wt.scale = 1; wt.denom = 0; wt.offset = 0; }
             return;
         }
-        wt.on = 1; wt.scale = minscale; wt.denom = mindenom; wt.offset = minoff;
         stats[3]++;
         if( p.weightp < 0 ) // X264_WEIGHTP_FAKE (:462-463)
-            fenc->weighted_cost_delta[fenc->i_frame - ref->i_frame - 1] = (float)minscore / origscore;
+            fenc->weighted_cost_delta[fenc->i_frame - ref->i_frame - 1] = ratio;
+    }
+
+    // Every (frame, reference) pair whose weight test was queued with the last speculative submissions (flush_prefetch) and has not been
+    // decided yet: the verdict is a function of the two pictures, so it is taken now for all of them -- their sums arrived with the ones
+    // the current request is about to read -- and the pairs that keep a weight go to the backend as ONE batch of weighted searches
+    // (x264hip_prefetch_weighted_fields).  A P request that first-triggers such a field then finds it searched; which fields ARE first
+    // triggered by a P request is the caller's business, as ever (a field somebody asks for differently is searched on demand).
+    struct WeightTest { int f_frame, r_frame; x264hip_weight guess, cand; int group; };
+    std::vector<WeightTest> weight_tests; // (in submission order)
+    int weight_group_serial = 0;
+    void speculate_weighted_fields( int upto_group )
+    {
+        if( weight_tests.empty() || !be.prefetch_weighted_fields || err ) { weight_tests.clear(); return; }
+        std::vector<WeightTest> todo, later;
+        for( const WeightTest &t : weight_tests ) ( t.group <= upto_group ? todo : later ).push_back( t );
+        weight_tests.swap( later ); // (tests of a submission the device has not answered for yet wait for their turn)
+        if( todo.empty() ) return;
+        auto resident = [&]( int number ) -> LaFrame * {
+            if( last_nonb && last_nonb->i_frame == number ) return last_nonb;
+            for( LaFrame *f : next ) if( f->i_frame == number ) return f;
+            return nullptr;
+        };
+        std::vector<int> sf, sr;
+        std::vector<x264hip_weight> ws;
+        for( const WeightTest &t : todo )
+        {
+            LaFrame *f = resident( t.f_frame ), *r = resident( t.r_frame );
+            if( !f || !r ) continue;
+            x264hip_weight w = t.guess;
+            float ratio = 0.f;
+            const int v = weight_verdict( f, r, t.guess, t.cand, w, ratio );
+            if( v < 0 ) return;
+            if( v > 0 ) { sf.push_back( f->slot ); sr.push_back( r->slot ); ws.push_back( w ); }
+        }
+        if( !sf.empty() )
+            need( be.prefetch_weighted_fields( be.user, (int)sf.size(), sf.data(), sr.data(), ws.data() ) );
     }
 
     // =================================================================================================================
@@ -1058,10 +1116,12 @@ struct Lookahead
             for( int i = 0; i < upto; i++ ) res.push_back( next[i] );
             std::vector<int> sf, sr;
             std::vector<x264hip_weight> ws;
+            weight_group_serial++;
             for( LaFrame *f : res )
             {
                 if( f->weights_prefetched || f == last_nonb ) continue;
                 f->weights_prefetched = true;
+                f->weight_group = weight_group_serial;
                 for( LaFrame *r : res )
                 {
                     const int d = f->i_frame - r->i_frame;
@@ -1069,6 +1129,7 @@ struct Lookahead
                     x264hip_weight guess, cand;
                     if( !weight_candidate( f, r, guess, cand ) ) continue;
                     sf.push_back( f->slot ); sr.push_back( r->slot ); ws.push_back( cand );
+                    if( be.prefetch_weighted_fields ) weight_tests.push_back( WeightTest{ f->i_frame, r->i_frame, guess, cand, weight_group_serial } );
                 }
             }
             if( !sf.empty() && !err )
@@ -1108,6 +1169,10 @@ static int dev_put_batch( void *u, int n, const int *slots, const void *const *l
 }
 static int dev_gop_hint( void *u, int anchor, int period ) { return x264hip_gop_hint( (x264hip_ctx *)u, anchor, period ); }
 static int dev_flush( void *u ) { return x264hip_flush( (x264hip_ctx *)u ); }
+static int dev_prefetch_weighted_fields( void *u, int n, const int *sf, const int *sr, const x264hip_weight *w )
+{
+    return x264hip_prefetch_weighted_fields( (x264hip_ctx *)u, n, sf, sr, w );
+}
 static int dev_prefetch_weights( void *u, int n, const int *sf, const int *sr, const x264hip_weight *w )
 {
     return x264hip_prefetch_weight_costs( (x264hip_ctx *)u, n, sf, sr, w );
@@ -1224,7 +1289,7 @@ extern "C" int x264hip_lookahead_open( x264hip_lookahead **out, int device, cons
     x264hip_ctx *ctx = nullptr;
     int rc = x264hip_open( &ctx, device, &p.dev );
     if( rc ) return rc;
-    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch, dev_mbtree, dev_qp_offsets, dev_put_batch, dev_prefetch_weights, dev_recalc, dev_row_satds, dev_frame_put_yuv, dev_add_quant_offsets, dev_put_batch_yuv, dev_gop_hint, dev_flush };
+    x264hip_backend be = { ctx, dev_frame_put, dev_frame_stats, dev_weight_cost, dev_frame_cost, dev_prefetch, dev_mbtree, dev_qp_offsets, dev_put_batch, dev_prefetch_weights, dev_recalc, dev_row_satds, dev_frame_put_yuv, dev_add_quant_offsets, dev_put_batch_yuv, dev_gop_hint, dev_flush, dev_prefetch_weighted_fields };
     rc = x264hip_lookahead_open_backend( out, &p, &be );
     if( rc ) { x264hip_close( ctx ); return rc; }
     ( *out )->L.ctx = ctx;

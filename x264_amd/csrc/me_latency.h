@@ -167,10 +167,37 @@ struct WaveEval
         if( fpelcmp_satd ) total >>= 1;
         return wave_min_groups( ok && grp < N ? ( ( total + b ) << 3 ) | k : ME_PACK_MAX );
     }
+    // (the candidates of a set are evaluated side by side, one is as dear as eight: the answer only matters to me_logic.h's fused start)
     template <int N, class GEN>
-    __device__ __forceinline__ bool more_than_first( GEN ) const { return true; } // the candidates of a set are evaluated side by side
+    __device__ __forceinline__ bool more_than_first( GEN gen ) const
+    {
+        int x = 0, y = 0;
+        bool ok = false, wb = true;
+        gen( imin2( grp, N - 1 ), x, y, ok, wb );
+        return __builtin_amdgcn_ballot_w64( ok && grp >= 1 && grp < N ) != 0ull;
+    }
     template <int N, class GEN>
     __device__ __forceinline__ int qpel_set( int use_satd, GEN gen, int &cost0 ) const
+    {
+        bool ok;
+        const int total = qpel_totals<N>( use_satd, gen, ok );
+        cost0 = __builtin_amdgcn_readlane( total, 0 );
+        return wave_min_groups( ok && grp < N ? ( total << 3 ) | imin2( grp, N - 1 ) : ME_PACK_MAX );
+    }
+    // candidates 0..2 costed for themselves (groups 0..2), the cheapest of candidates 3..N-1 packed with k - 3
+    template <int N, class GEN>
+    __device__ __forceinline__ int qpel_fused( int use_satd, GEN gen, int &c0, int &c1, int &c2 ) const
+    {
+        bool ok;
+        const int total = qpel_totals<N>( use_satd, gen, ok );
+        c0 = __builtin_amdgcn_readlane( total, 0 ); c1 = __builtin_amdgcn_readlane( total, 8 ); c2 = __builtin_amdgcn_readlane( total, 16 );
+        if( N <= 3 )
+            return ME_PACK_MAX;
+        return wave_min_groups( ok && grp >= 3 && grp < N ? ( total << 3 ) | ( grp - 3 ) : ME_PACK_MAX );
+    }
+    // cost (metric + vector bits) of the candidate this lane's group works on, in every lane of the group
+    template <int N, class GEN>
+    __device__ __forceinline__ int qpel_totals( int use_satd, GEN gen, bool &ok_out ) const
     {
         const int k = imin2( grp, N - 1 );
         int x = 0, y = 0;
@@ -204,9 +231,8 @@ struct WaveEval
         }
         int total = reduce8( block_partial8<T>( f, r, use_satd ) );
         if( use_satd ) total >>= 1;
-        total += b;
-        cost0 = __builtin_amdgcn_readlane( total, 0 );
-        return wave_min_groups( ok && grp < N ? ( total << 3 ) | k : ME_PACK_MAX );
+        ok_out = ok;
+        return total + b;
     }
     // me_logic.h's shortcut for the quarter-pel diamond at a half-pel position: the window serves the ten taps as they are
     __device__ __forceinline__ int qpel_star5( int use_satd, int mvx, int mvy, bool inside ) const

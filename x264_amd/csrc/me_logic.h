@@ -27,7 +27,11 @@
 //               template <int N, class G> bool more_than_first( G gen )   false only if NO thread that shares this instruction stream has a
 //                                                         candidate k >= 1 of the set gen describes (may answer true when in doubt): lets the
 //                                                         caller evaluate candidate 0 alone
-// melogic::ScalarSets<E> implements the two set functions over E's scalar fpel( x, y ) / qpel( qx, qy, use_satd ) / bits( qx, qy ): the
+//               template <int N, class G> int qpel_fused( int use_satd, G gen, int &c0, int &c1, int &c2 )
+//                                                         N <= 8 quarter-pel candidates (full-pel ones given in quarter-pel units) costed together:
+//                                                         c0..c2 = the costs of candidates 0..2 (meaningful where the candidate takes part), the
+//                                                         result = the cheapest of candidates 3..N-1 packed with k - 3 (ME_PACK_MAX for N == 3)
+// melogic::ScalarSets<E> implements the set functions over E's scalar fpel( x, y ) / qpel( qx, qy, use_satd ) / bits( qx, qy ): the
 // host evaluators of the tests use it (candidates one after the other).
 #pragma once
 
@@ -38,6 +42,10 @@
 #define ME_COST_MAX ( 1 << 28 )
 #ifndef ME_QSTAR
 #define ME_QSTAR 1 // 0: the quarter-pel diamond always as a general set (A/B builds)
+#endif
+#ifndef ME_FUSED_START
+#define ME_FUSED_START 0 // 1: predictor, its rounding, the zero vector and the first diamond costed as ONE set where the predictor is the only start
+                         // candidate (bit-exact, tests/test_me_logic_host.py runs it; measured in round 6: no gain, see me_search.h)
 #endif
 
 struct MeCfg
@@ -183,6 +191,25 @@ struct ScalarSets
         }, c0 );
     }
     template <int N, class G>
+    int qpel_fused( int use_satd, G gen, int &c0, int &c1, int &c2 )
+    {
+        D &d = *static_cast<D *>( this );
+        int best = ME_PACK_MAX;
+        int c[3] = { ME_COST_MAX, ME_COST_MAX, ME_COST_MAX };
+        for( int k = 0; k < N; k++ )
+        {
+            int x = 0, y = 0;
+            bool ok = false, wb = true;
+            gen( k, x, y, ok, wb );
+            if( !ok ) continue;
+            const int v = d.qpel( x, y, use_satd ) + ( wb ? d.bits( x, y ) : 0 );
+            if( k < 3 ) c[k] = v;
+            else if( ( ( v << 3 ) | ( k - 3 ) ) < best ) best = ( v << 3 ) | ( k - 3 );
+        }
+        c0 = c[0]; c1 = c[1]; c2 = c[2];
+        return best;
+    }
+    template <int N, class G>
     int qpel_set( int use_satd, G gen, int &cost0 )
     {
         D &d = *static_cast<D *>( this );
@@ -211,6 +238,8 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
     int bpred_cost = ME_COST_MAX, bpred_mx = 0, bpred_my = 0;
     int pmvx, pmvy;
     int unused_c0 = 0;
+    bool have_first = false; // the first diamond has been costed with the start candidates: p_first
+    int p_first = ME_PACK_MAX;
     const Mv4 cand_x = mv4_of( mvcx ), cand_y = mv4_of( mvcy );
     ME_MARK( ev, 0 );
 
@@ -229,9 +258,44 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
             y = keep ? clip3( vy, 4 * L.fmin_y, 4 * L.fmax_y ) : pmvy;
             ok = k == 0 || keep; wb = true;
         };
-        // where motion is uniform every neighbour repeats the predictor and x264_predictor_clip drops them all: the predictor alone then
-        const int p = ev.template more_than_first<5>( start_set ) ? ev.template qpel_set<5>( C.fpelcmp_satd, start_set, pmv_cost )
-                                                                  : ev.template qpel_set<1>( C.fpelcmp_satd, start_set, pmv_cost );
+        // Where motion is uniform every neighbour repeats the predictor and x264_predictor_clip drops them all: the predictor alone.
+        // Then everything the search does next is known before anything has been costed: the predictor's full-pel rounding, the zero
+        // vector (me.c:258-275) and -- unless the zero vector wins -- the first diamond around the rounding (me.c:322-342).  One set
+        // of seven, one round of loads instead of three; the candidates are applied below in the reference's order all the same.
+        const bool many = ev.template more_than_first<5>( start_set );
+        if( ME_FUSED_START && !many )
+        {
+            bpred_mx = pmvx; bpred_my = pmvy;
+            bmx = ( pmvx + 2 ) >> 2; bmy = ( pmvy + 2 ) >> 2;
+            const int rbx = bmx, rby = bmy;
+            const bool need_round = ( ( pmvx | pmvy ) & 3 ) != 0;
+            const bool need_zero = ( pmvx | pmvy ) && ( bmx | bmy );
+            int c_pmv = 0, c_round = 0, c_zero = 0;
+            auto fused = [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
+                // 0 the predictor, 1 its rounding, 2 the zero vector, 3..6 the diamond around the rounding (full-pel points in quarter-pel units)
+                const int dx = k >= 3 ? dia_dx( k - 3 ) : 0, dy = k >= 3 ? dia_dy( k - 3 ) : 0;
+                x = k == 0 ? pmvx : k == 2 ? 0 : 4 * ( rbx + dx );
+                y = k == 0 ? pmvy : k == 2 ? 0 : 4 * ( rby + dy );
+                ok = k == 0 || ( k == 1 && need_round ) || ( k == 2 && need_zero ) || k >= 3;
+                wb = true;
+            };
+            p_first = C.hex ? ev.template qpel_fused<3>( C.fpelcmp_satd, fused, c_pmv, c_round, c_zero )
+                            : ev.template qpel_fused<7>( C.fpelcmp_satd, fused, c_pmv, c_round, c_zero );
+            bpred_cost = c_pmv;
+            bcost = bpred_cost;
+            if( need_round )
+            {
+                bcost = c_round;
+                if( need_zero && c_zero < c_round ) { bcost = c_zero; bmx = 0; bmy = 0; }
+            }
+            else if( need_zero && c_zero < bcost ) { bcost = c_zero; bmx = 0; bmy = 0; }
+            // (the predictor being the zero vector and cheaper than what stands: me.c:270-275 -- cannot hold here, bcost IS its cost then)
+            have_first = !C.hex && bmx == rbx && bmy == rby;
+        }
+        else
+        {
+        const int p = many ? ev.template qpel_set<5>( C.fpelcmp_satd, start_set, pmv_cost )
+                           : ev.template qpel_set<1>( C.fpelcmp_satd, start_set, pmv_cost );
 #ifdef ME_PROFILE
         {
             int kept = 0, single = ( ( pmvx | pmvy ) & 1 ) == 0, total = 1;
@@ -277,6 +341,7 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
         {
             bcost = pmv_cost; bmx = 0; bmy = 0;
         }
+        }
     }
     else
     {
@@ -312,9 +377,12 @@ ME_HD void search( const MeCfg &C, const MeLim &L, E &ev, int mvpx, int mvpy, in
         int iters = C.me_range;
         do
         {
-            const int p = ev.template fpel_set<4>( [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
-                x = bmx + dia_dx( k ); y = bmy + dia_dy( k ); ok = true; wb = true;
-            } );
+            int p = p_first;
+            if( !have_first )
+                p = ev.template fpel_set<4>( [&]( int k, int &x, int &y, bool &ok, bool &wb ) {
+                    x = bmx + dia_dx( k ); y = bmy + dia_dy( k ); ok = true; wb = true;
+                } );
+            have_first = false;
             if( pk_cost( p ) >= bcost )
                 break;
             bcost = pk_cost( p );

@@ -311,7 +311,7 @@ struct GroupEval
         return any( ok && slot >= 1 && slot < N );
     }
     template <int N, class G>
-    __device__ __forceinline__ int qpel_set( int use_satd, G gen, int &cost0 ) const
+    __device__ __forceinline__ int qpel_totals( int use_satd, G gen, bool &ok_out ) const
     {
         const int slot = N <= 4 ? ( S.slot & 3 ) : S.slot, k = imin2( slot, N - 1 );
         int x = 0, y = 0;
@@ -375,10 +375,30 @@ struct GroupEval
         }
         int total = reduce_slots<N>( S, c );
         if( use_satd ) total >>= 1;
-        total += b;
+        ok_out = ok;
+        return total + b;
+    }
+    template <int N, class G>
+    __device__ __forceinline__ int qpel_set( int use_satd, G gen, int &cost0 ) const
+    {
+        bool ok;
+        const int total = qpel_totals<N>( use_satd, gen, ok );
         cost0 = from_slot<0>( S, total );
         return pack_min<N>( total, ok );
     }
+    // candidates 0..2 costed for themselves, the cheapest of candidates 3..N-1 packed with k - 3 (me_logic.h: the start of a search
+    // whose only start candidate is the predictor)
+    template <int N, class G>
+    __device__ __forceinline__ int qpel_fused( int use_satd, G gen, int &c0, int &c1, int &c2 ) const
+    {
+        bool ok;
+        const int total = qpel_totals<N>( use_satd, gen, ok );
+        c0 = from_slot<0>( S, total ); c1 = from_slot<1>( S, total ); c2 = from_slot<2>( S, total );
+        if( N <= 3 )
+            return ME_PACK_MAX;
+        return min_slots<8>( ok && S.slot >= 3 && S.slot < N ? ( total << 3 ) | ( S.slot - 3 ) : ME_PACK_MAX );
+    }
+
     // The quarter-pel diamond around a vector at a half-pel position (both components even), its centre re-costed as candidate 0
     // (me_logic.h): each of the four neighbours is the rounded average of the centre's sample run and of the run at the half-pel
     // position two quarter-pels further on (get_ref, mc.c:218-249 with the tables of tables.c:183-184: one tap of an odd position is
@@ -442,6 +462,21 @@ __device__ __forceinline__ int from_group_below( int v, int lane )
 // WEIGHTED: every search of the launch reads a weighted copy of its reference (D.refw_strips, D.wt)
 #ifndef ME_MIN_WAVES
 #define ME_MIN_WAVES 4
+#endif
+// Round 6 measured three ways to take round trips out of a step (profiles/r06_search_ab.txt, r06_search_pmc_*.json): the granule of
+// the row below and the source block requested a step ahead (ME_POLL_AHEAD, ME_FENC_AHEAD: the wait for the row below 3 250 -> 1 900
+// cycles per step, the source load 1 200 -> 540 in the profiling build) and me_logic.h's fused start set (ME_FUSED_START).  None of them
+// moves the kernel: 3.35 against 3.30 us per search alone, 36-37 k against 38-39 k frames/s with eight contexts, 111 vector instructions
+// per block either way.  A wave that waits costs its slot, not issue cycles, and with eight launches in flight the slots are full of other
+// searches' waves.  They stay in the source, off (ME_SLACK: a wave starts that many blocks later than the vectors allow; no effect either).
+#ifndef ME_POLL_AHEAD
+#define ME_POLL_AHEAD 0 // 1: the granule of the row below requested a step ahead (0: three granules polled for at the start of every step)
+#endif
+#ifndef ME_SLACK
+#define ME_SLACK 0      // blocks a wave lets the wave below get ahead before it starts, beyond what its first block needs (ME_POLL_AHEAD builds)
+#endif
+#ifndef ME_FENC_AHEAD
+#define ME_FENC_AHEAD 0 // 1: the source block requested a step ahead
 #endif
 template <typename T, int HEX, int MODE, int WEIGHTED>
 __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, const SearchDesc<T> *descs, MeQueues Q, unsigned *tickets /* [ME_QUEUES * ME_QUEUE_STRIDE] */,
@@ -543,6 +578,70 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
     int r1 = 0, r2 = 0, r3 = 0; // packed vectors this group found in the last three steps
     int keep_mv = 0, keep_cost = 0; // lanes 0..3 of a group: the result of the block with x % 4 == lane, until the four leave together
     const int n_steps = W + 2 * ( ME_ROWS - 1 );
+#if ME_POLL_AHEAD
+    // The row below group 0 belongs to another wave.  A step needs its vectors at x - 1, x, x + 1; two of the three were the last step's
+    // x - 1 and x, so ONE new granule per step, and that one is requested a step ahead: the wave below holds an earlier ticket and is
+    // normally several blocks further on, so the granule carries the tag when it is looked at and the trip to the L2 (the loads
+    // bypass the L1) is hidden behind a whole block search.  Only a granule that does not carry the tag yet is polled for.
+    // Every lane requests the same granule (one address: one L2 request) and the tag test is scalar.
+    const unsigned long long *const below_row = mvq + ( by0 + 1 ) * W;
+    auto remote_granule = [&]( int x ) -> unsigned long long { return __hip_atomic_load( below_row + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ); };
+    bool timed_out = false;
+    auto remote_vector = [&]( int x, unsigned long long gq ) -> int { // the vector of granule x: gq if it carries the tag, else polled for
+        unsigned spins = 0;
+        while( (unsigned)__builtin_amdgcn_readfirstlane( (int)( gq >> 32 ) ) != tag )
+        {
+            if( ++spins > spin_limit )
+            {
+                timed_out = true;
+                return 0;
+            }
+            __builtin_amdgcn_s_sleep( 4 );
+#ifdef ME_PROFILE
+            pf_spins++;
+#endif
+            gq = remote_granule( x );
+        }
+        return __builtin_amdgcn_readfirstlane( (int)(unsigned)gq );
+    };
+    int rem_c = 0, rem_r = 0; // the remote row's vectors at the coming step's x and x + 1
+    unsigned long long g_next = 0;
+    if( below_is_remote )
+    {
+#if ME_SLACK
+        // start a few blocks later than the vectors allow: a wave that runs at the heels of the wave below waits for it in every step
+        (void)remote_vector( imax2( W - 1 - ME_SLACK, 0 ), remote_granule( imax2( W - 1 - ME_SLACK, 0 ) ) );
+#endif
+        rem_c = remote_vector( W - 1, remote_granule( W - 1 ) );
+        g_next = remote_granule( imax2( W - 2, 0 ) );
+        if( timed_out )
+        {
+            if( lane == 0 )
+                __hip_atomic_store( err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+            leave();
+            return;
+        }
+    }
+#endif
+#if ME_FENC_AHEAD
+    // the source block of a step is requested a step ahead (its position does not depend on anything found so far) and kept as loaded:
+    // unpacking it would wait for the load
+    const int frow16 = ( ( 8 * imax2( by, 0 ) + LA_PAD ) << 4 ) + LS.row16;
+    auto source_raw = [&]( int x ) -> uint4 {
+        const int o = strip_off( 8 * iclip3( x, 0, W - 1 ) + LA_PAD, frow16, strip_elems );
+        uint4 w = { 0, 0, 0, 0 };
+        if( sizeof( T ) == 1 ) { const uint2 h = gload_u64( fbase, (unsigned)o ); w.x = h.x; w.y = h.y; }
+        else { const uint2 h0 = gload_u64( fbase, 2u * (unsigned)o ), h1 = gload_u64( fbase, 2u * (unsigned)o + 8u ); w.x = h0.x; w.y = h0.y; w.z = h1.x; w.w = h1.y; }
+        return w;
+    };
+    auto source_px8 = [&]( const uint4 &w ) -> Px8 {
+        Px8 r;
+        if( sizeof( T ) == 1 ) { r.lo = px4_from_raw( w.x ); r.hi = px4_from_raw( w.y ); }
+        else { r.lo.a = w.x; r.lo.b = w.y; r.lo.raw = 0; r.hi.a = w.z; r.hi.b = w.w; r.hi.raw = 0; }
+        return r;
+    };
+    uint4 f_next = source_raw( W - 1 + 2 * g ); // (step 0: x = W - 1 + 2 g, clamped: only group 0 is inside the picture yet)
+#endif
     for( int t = 0; t < n_steps; t++ )
     {
         const int bx = W - 1 - ( t - 2 * g );
@@ -552,6 +651,28 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
 #endif
         // the row below: (x-1, y+1), (x, y+1), (x+1, y+1) are what the group below found one, two and three steps ago
         int below_left = from_group_below( r1, lane ), below = from_group_below( r2, lane ), below_right = from_group_below( r3, lane );
+#if ME_POLL_AHEAD
+        {
+            const int bx0 = W - 1 - t;
+            if( bx0 >= 0 && below_is_remote )
+            {
+                int rem_l = 0;
+                if( bx0 > 0 )
+                    rem_l = remote_vector( bx0 - 1, g_next );
+                if( timed_out )
+                {
+                    if( lane == 0 )
+                        __hip_atomic_store( err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+                    leave();
+                    return;
+                }
+                if( bx0 > 1 )
+                    g_next = remote_granule( bx0 - 2 );
+                if( g == 0 ) { below = rem_c; below_left = rem_l; below_right = rem_r; }
+                rem_r = rem_c; rem_c = rem_l;
+            }
+        }
+#else
         {
             const int bx0 = W - 1 - t;
             if( bx0 >= 0 && below_is_remote )
@@ -587,6 +708,11 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
                 if( g == 0 ) { below = w0; below_left = w1; below_right = w2; }
             }
         }
+#endif
+#if ME_FENC_AHEAD
+        const uint4 f_now = f_next;
+        f_next = source_raw( bx - 1 );
+#endif
         int mvx = 0, mvy = 0, cost = 0;
 #ifdef ME_PROFILE
         const unsigned long long pf_t1 = PF_NOW();
@@ -609,7 +735,11 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
                     mvpy = melogic::median3( mvcy[0], mvcy[1], mvcy[2] );
                 }
                 const int cx0 = 8 * bx + LA_PAD, row16 = ( 8 * by + LA_PAD ) << 4; // the block's row 0; this lane's row is LS.row16 further
+#if ME_FENC_AHEAD
+                const Px8 f = source_px8( f_now );
+#else
                 const Px8 f = load_px8_at( fbase, strip_off( cx0, row16 + LS.row16, strip_elems ) );
+#endif
                 bool done = false;
                 if( !( mvpx | mvpy ) )
                 {

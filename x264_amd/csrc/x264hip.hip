@@ -71,8 +71,8 @@ struct FrameSlot
     uint16_t *inv_qscale = nullptr;
     unsigned long long *frame_sums = nullptr;
     uint2 *mb_sums = nullptr;
-    unsigned long long *mvq[2][X264HIP_BFRAME_MAX + 1];
-    int *mvcost[2][X264HIP_BFRAME_MAX + 1];
+    unsigned long long *mvq[3][X264HIP_BFRAME_MAX + 1];   // [2]: a second list-0 field per distance, searched speculatively on a WEIGHTED
+    int *mvcost[3][X264HIP_BFRAME_MAX + 1];                 // reference (x264hip_prefetch_weighted_fields); a request that brings that weight swaps it in
     uint16_t *lowres_costs = nullptr; // [(bf+2)*(bf+2)][n_mb]
     int *row_satds = nullptr;         // [(bf+2)*(bf+2)][mb_h]
     int *blk = nullptr;               // [(bf+2)*(bf+2)][n_mb] unclamped block cost | b_intra << 30 per cell
@@ -85,6 +85,9 @@ struct FrameSlot
     // whether that frame has been searched as a P frame by then).  When both happen often the minority variant is speculated as well,
     // into the slot's one spare cell; a request for it copies map and sums over (no evaluation, no wait for an on-demand launch).
     std::vector<CellEntry> alts;      // [n_cells]: the speculative OTHER variant of B cell idx, evaluated into spare cell ctx->spare_at[idx]
+    // a B cell's THIRD evaluation (x264hip_prefetch_weighted_fields): over the speculative weighted list-0 field of this frame and / or of
+    // its list-1 reference, into the cell's second spare (ctx->spare2_at)
+    std::vector<CellEntry> alts2;
     std::vector<int> cell_at;         // [n_cells]: where the data of cell idx lives -- idx, or spare_at[idx] once the caller asked for the variant in the spare
     // host-side state of the device fields
     unsigned char field_ready[2][X264HIP_BFRAME_MAX + 1]; // searched (any variant) and complete on the stream
@@ -98,6 +101,10 @@ struct FrameSlot
     int pos_key = 0;                  // period * 32 + position, 0 = no expectation
     unsigned req_fields[2] = { 0, 0 };// bit d: (list, distance d + 1) requested
     std::vector<unsigned char> req_cells; // [(bf+2)*(bf+2)]
+    // the speculative weighted list-0 field of distance d + 1, if any: the weight it was searched with, its tag and batch; its P cell sits
+    // in the spare of cell ( d + 1, 0 ) (alts)
+    struct WSpec { unsigned char valid = 0; x264hip_weight w = { 0, 1, 0, 0 }; unsigned tag = 0, batch = 0; };
+    WSpec wspec[X264HIP_BFRAME_MAX + 1];
     int wplane_idx = -1;          // weighted-plane pool entry in use by this slot's current weighted search
     uint64_t sum = 0, ssd = 0;
     int stats_valid = 0;
@@ -137,6 +144,8 @@ struct x264hip_ctx
     int n_store = 0;                 // cell maps per slot: n_cells own places + one spare per B class + one nobody reads (spare_at of the other classes)
     int *cell_acc_host = nullptr;    // pinned [slots][n_cells][8]: sums of every cell evaluation, written by the device directly
     int *cell_alt_host = nullptr;    // pinned [slots][n_cells][8]: sums of the spare cells (FrameSlot alts)
+    int *cell_alt2_host = nullptr;   // pinned [slots][n_cells][8]: sums of the second spares (FrameSlot alts2)
+    std::vector<int> spare2_at;      // [n_cells]: storage index of the second spare of B cell idx
     DescRing cell_ring, put_ring, search_ring, xfer_ring;
     int xfer_cap = 2048;
     unsigned *err_host = nullptr;    // pinned: sticky in-kernel timeout flag, written by the device directly
@@ -179,7 +188,19 @@ struct x264hip_ctx
     struct WEntry { int slot_fenc = -1, slot_ref = -1; unsigned gen_fenc = 0, gen_ref = 0; x264hip_weight w; unsigned batch = 0; };
     std::vector<WEntry> wcache;      // [WCAP], entry 0 unused
     int wcache_next = 1;
-    char *staging = nullptr;         // pinned luma staging
+    char *staging = nullptr;         // pinned luma staging (entry 0 of the ring below)
+    // pictures handed over in HOST memory (x264hip_frame_put with is_device == 0, host pointers in x264hip_frame_put_batch*): a DMA
+    // stream of their own -- pinned buffers go straight from where they are, pageable ones through a ring of pinned staging copies --
+    // and the compute stream waits for an event behind the copies, never the host for the compute stream
+    static const int STAGE_RING = 4;
+    hipStream_t stream_h2d = nullptr;
+    hipEvent_t h2d_done = nullptr;
+    char *stage[4] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t stage_ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    bool stage_used[4] = { false, false, false, false };
+    int stage_next = 0;
+    uint64_t weighted_speculated = 0, weighted_claimed = 0, weighted_cells = 0, weighted_cells_used = 0; // x264hip_prefetch_weighted_fields: searches enqueued, fields a request took, P cells with them
+    uint64_t h2d_bytes = 0, h2d_direct = 0, h2d_staged = 0; // bytes copied, pictures taken from pinned memory as they were / through the ring
     char *chroma_staging = nullptr, *chroma_dev = nullptr; // host-buffer ingest with chroma: pinned + device copies of Cb and Cr (allocated on first use)
     size_t staging_bytes = 0;
     std::vector<char *> wplanes;     // weighted plane pool
@@ -198,6 +219,7 @@ struct x264hip_ctx
     std::vector<int> prof_n;
     int prof_on = 0, prof_used = 0;
     double prof_ms = 0; uint64_t prof_launches = 0, prof_searches = 0;
+    double prof_lat_ms = 0; uint64_t prof_lat_launches = 0, prof_lat_searches = 0; // the search launches that went to me_latency_kernel, for themselves
     double prof_cell_ms = 0; uint64_t prof_cell_launches = 0, prof_cells = 0; // the same for the cost cell launches (prof_n entries < 0)
     // prof_on & 2: an event pair around every kernel of the ingest and cell launches as well (x264hip_kernel_profile; class = X264HIP_KPROF_*)
     std::vector<int> prof_kind;       // parallel to prof_n: -1 = a search / cell launch as above, else the kernel class
@@ -350,9 +372,13 @@ static void free_all( x264hip_ctx *ctx )
         if( ctx->up_ev[i] ) (void)hipEventDestroy( ctx->up_ev[i] );
     if( ctx->stream_up ) (void)hipStreamDestroy( ctx->stream_up );
     (void)hipHostFree( ctx->cell_acc_host );
-    (void)hipHostFree( ctx->cell_alt_host );
+    (void)hipHostFree( ctx->cell_alt_host ); (void)hipHostFree( ctx->cell_alt2_host );
     (void)hipFree( ctx->wcost_dev );
     (void)hipHostFree( ctx->wcost_host ); (void)hipHostFree( ctx->staging );
+    for( int k = 1; k < x264hip_ctx::STAGE_RING; k++ ) if( ctx->stage[k] ) (void)hipHostFree( ctx->stage[k] );
+    for( int k = 0; k < x264hip_ctx::STAGE_RING; k++ ) if( ctx->stage_ev[k] ) (void)hipEventDestroy( ctx->stage_ev[k] );
+    if( ctx->h2d_done ) (void)hipEventDestroy( ctx->h2d_done );
+    if( ctx->stream_h2d ) (void)hipStreamDestroy( ctx->stream_h2d );
     if( ctx->chroma_staging ) (void)hipHostFree( ctx->chroma_staging );
     if( ctx->chroma_dev ) (void)hipFree( ctx->chroma_dev );
     for( auto e : ctx->prof_ev ) (void)hipEventDestroy( e );
@@ -491,11 +517,18 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         for( int d0 = 1; d0 <= p.bframes + 1; d0++ )
             for( int d1 = 1; d0 + d1 <= p.bframes + 1; d1++ )
                 n_b++;
-        ctx->spare_at.assign( ctx->n_cells, ctx->n_cells + n_b );
+        const int n_p = p.bframes + 1; // the P classes have a spare too: the cell over a speculative WEIGHTED field
+        ctx->spare_at.assign( ctx->n_cells, ctx->n_cells + n_b + n_p );
         for( int d0 = 1, k = 0; d0 <= p.bframes + 1; d0++ )
             for( int d1 = 1; d0 + d1 <= p.bframes + 1; d1++ )
                 ctx->spare_at[d0 * ns + d1] = ctx->n_cells + k++;
-        ctx->n_store = ctx->n_cells + n_b + 1;
+        for( int d0 = 1; d0 <= p.bframes + 1; d0++ )
+            ctx->spare_at[d0 * ns] = ctx->n_cells + n_b + d0 - 1;
+        ctx->n_store = ctx->n_cells + n_b + n_p + 1;
+        ctx->spare2_at.assign( ctx->n_cells, ctx->n_store - 1 );
+        for( int d0 = 1; d0 <= p.bframes + 1; d0++ )
+            for( int d1 = 1; d0 + d1 <= p.bframes + 1; d1++ )
+                ctx->spare2_at[d0 * ns + d1] = ctx->n_store++;
     }
     ctx->pos_frames.assign( x264hip_ctx::POS_KEYS, 0 );
     ctx->pos_field_req.assign( (size_t)x264hip_ctx::POS_KEYS * 2 * ( X264HIP_BFRAME_MAX + 1 ), 0 );
@@ -503,6 +536,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( hipHostMalloc( &ctx->cell_acc_host, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
     OPENCK( hipHostMalloc( &ctx->cell_alt_host, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
     memset( ctx->cell_alt_host, 0, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) );
+    OPENCK( hipHostMalloc( &ctx->cell_alt2_host, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
+    memset( ctx->cell_alt2_host, 0, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) );
     memset( ctx->cell_acc_host, 0, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) );
     OPENCK( hipHostMalloc( &ctx->err_host, sizeof( unsigned ) ) );
     *ctx->err_host = 0;
@@ -543,6 +578,11 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( ring_alloc( ctx->search_ring, (size_t)ctx->desc_cap * sizeof( SearchDesc<uint8_t> ) ) );
     ctx->staging_bytes = (size_t)p.width * p.height * ctx->psz;
     OPENCK( hipHostMalloc( &ctx->staging, ctx->staging_bytes ) );
+    ctx->stage[0] = ctx->staging;
+    OPENCK( hipStreamCreateWithFlags( &ctx->stream_h2d, hipStreamNonBlocking ) );
+    OPENCK( hipEventCreateWithFlags( &ctx->h2d_done, hipEventDisableTiming ) );
+    for( int k = 0; k < x264hip_ctx::STAGE_RING; k++ )
+        OPENCK( hipEventCreateWithFlags( &ctx->stage_ev[k], hipEventDisableTiming ) );
 
     const int nd = p.bframes + 1, nc = ( p.bframes + 2 ) * ( p.bframes + 2 );
     ctx->slots.resize( p.max_frames );
@@ -553,8 +593,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         const size_t o_luma = off; off += align_up( ctx->staging_bytes, 256 );
         const size_t o_inv = off; off += align_up( ctx->n_mb * sizeof( uint16_t ), 256 );
         const size_t o_mbs = off; off += align_up( ctx->n_mb * sizeof( uint2 ), 256 );
-        const size_t o_mvq = off; off += align_up( (size_t)2 * nd * ctx->n_mb * sizeof( unsigned long long ), 256 );
-        const size_t o_mvc = off; off += align_up( (size_t)2 * nd * ctx->n_mb * sizeof( int ), 256 );
+        const size_t o_mvq = off; off += align_up( (size_t)3 * nd * ctx->n_mb * sizeof( unsigned long long ), 256 );
+        const size_t o_mvc = off; off += align_up( (size_t)3 * nd * ctx->n_mb * sizeof( int ), 256 );
         // (more cells than the reference has: spare_at[idx] holds the speculative SECOND variant of B cell idx, see FrameSlot alts)
         const int nst = ctx->n_store;
         const size_t o_lc = off; off += align_up( (size_t)nst * ctx->n_mb * sizeof( uint16_t ), 256 );
@@ -571,7 +611,7 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         s.planes = base + o_planes; s.luma = base + o_luma; s.inv_qscale = (uint16_t *)( base + o_inv );
         s.frame_sums = ctx->stats_host + 2 * ( &s - &ctx->slots[0] ); // pinned: read by the host after a stream sync
         s.mb_sums = (uint2 *)( base + o_mbs );
-        for( int l = 0; l < 2; l++ )
+        for( int l = 0; l < 3; l++ )
             for( int d = 0; d < nd; d++ )
             {
                 s.mvq[l][d] = (unsigned long long *)( base + o_mvq ) + (size_t)( l * nd + d ) * ctx->n_mb;
@@ -585,6 +625,7 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         s.cell_work = (int *)( base + o_work );
         s.cells.assign( nc, CellEntry() );
         s.alts.assign( nc, CellEntry() );
+        s.alts2.assign( nc, CellEntry() );
         s.cell_at.resize( nc );
         for( int c = 0; c < nc; c++ ) s.cell_at[c] = c;
         s.req_cells.assign( nc, 0 );
@@ -735,6 +776,7 @@ static void slot_reset( x264hip_ctx *ctx, FrameSlot &s )
     s.pos_key = 0; s.req_fields[0] = s.req_fields[1] = 0;
     std::fill( s.req_cells.begin(), s.req_cells.end(), 0 );
     s.in_use = 1;
+    s.frame_no = -1; // (known again once the frame has been named in an x264hip_prefetch call)
     s.gen++;
     s.stats_valid = 0;
     memset( s.field_ready, 0, sizeof( s.field_ready ) );
@@ -743,9 +785,65 @@ static void slot_reset( x264hip_ctx *ctx, FrameSlot &s )
     memset( s.field_remote, 0, sizeof( s.field_remote ) );
     s.cells.assign( ctx->n_cells, CellEntry() );
     s.alts.assign( ctx->n_cells, CellEntry() );
+    s.alts2.assign( ctx->n_cells, CellEntry() );
     for( int c = 0; c < ctx->n_cells; c++ ) s.cell_at[c] = c;
     if( s.wplane_idx >= 0 ) { ctx->wplane_owner[s.wplane_idx] = -1; s.wplane_idx = -1; }
+    for( auto &ws : s.wspec ) ws = FrameSlot::WSpec();
     ctx->counters[3]++;
+}
+
+// ---- pictures from host memory ------------------------------------------------------------------------------------------------------
+// Is p something the DMA engines can read where it is (hipHostMalloc / hipHostRegister memory), or a device pointer, or plain pageable
+// host memory?  0 = pageable host, 1 = pinned host, 2 = device.
+static int pointer_kind( const void *p )
+{
+    hipPointerAttribute_t a;
+    if( hipPointerGetAttributes( &a, p ) != hipSuccess )
+    {
+        (void)hipGetLastError(); // (an unregistered host pointer is reported as an error)
+        return 0;
+    }
+    return a.type == hipMemoryTypeDevice ? 2 : a.type == hipMemoryTypeHost ? 1 : a.type == hipMemoryTypeManaged ? 2 : 0;
+}
+// Opens a group of host-to-device copies: the slots' luma buffers are read by the ingest kernels of their previous pictures
+// (ev_ingest stands behind the most recent ones), nothing else touches them.
+static int h2d_begin( x264hip_ctx *ctx )
+{
+    HIPCK( hipStreamWaitEvent( ctx->stream_h2d, ctx->ev_ingest, 0 ) );
+    return X264HIP_OK;
+}
+// one picture (width x height samples, `stride` samples per row in the caller's buffer) into the slot's luma buffer, on the DMA stream
+static int h2d_picture( x264hip_ctx *ctx, FrameSlot &s, const void *luma, int stride, int kind )
+{
+    const x264hip_params &p = ctx->p;
+    const size_t row = (size_t)p.width * ctx->psz;
+    if( kind == 1 )
+    {
+        HIPCK( hipMemcpy2DAsync( s.luma, row, luma, (size_t)stride * ctx->psz, row, p.height, hipMemcpyHostToDevice, ctx->stream_h2d ) );
+        ctx->h2d_direct++;
+    }
+    else
+    {
+        const int k = ctx->stage_next++ % x264hip_ctx::STAGE_RING;
+        if( !ctx->stage[k] && hipHostMalloc( &ctx->stage[k], ctx->staging_bytes ) != hipSuccess ) return X264HIP_ENOMEM;
+        if( ctx->stage_used[k] )
+            HIPCK( hipEventSynchronize( ctx->stage_ev[k] ) ); // the copy that last read this staging buffer (three pictures ago) is done
+        for( int y = 0; y < p.height; y++ )
+            memcpy( ctx->stage[k] + (size_t)y * row, (const char *)luma + (size_t)y * stride * ctx->psz, row );
+        HIPCK( hipMemcpyAsync( s.luma, ctx->stage[k], ctx->staging_bytes, hipMemcpyHostToDevice, ctx->stream_h2d ) );
+        HIPCK( hipEventRecord( ctx->stage_ev[k], ctx->stream_h2d ) );
+        ctx->stage_used[k] = true;
+        ctx->h2d_staged++;
+    }
+    ctx->h2d_bytes += ctx->staging_bytes;
+    return X264HIP_OK;
+}
+// closes the group: whatever the compute stream is given next runs behind the copies
+static int h2d_end( x264hip_ctx *ctx )
+{
+    HIPCK( hipEventRecord( ctx->h2d_done, ctx->stream_h2d ) );
+    HIPCK( hipStreamWaitEvent( ctx->stream, ctx->h2d_done, 0 ) );
+    return X264HIP_OK;
 }
 
 extern "C" int x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, int stride, int is_device, const void *cb, const void *cr,
@@ -766,20 +864,23 @@ extern "C" int x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, 
     const x264hip_params &p = ctx->p;
     const void *src = luma;
     int src_stride = stride;
+    if( is_device && pointer_kind( luma ) != 2 )
+        is_device = 0; // (the pointer's own attributes decide: a host buffer announced as device memory still takes the DMA road)
     if( !is_device )
     {
-        // make sure the staging buffer of the previous frame has been consumed
-        HIPCK( hipStreamSynchronize( ctx->stream ) );
-        const size_t row = (size_t)p.width * ctx->psz;
-        for( int y = 0; y < p.height; y++ )
-            memcpy( ctx->staging + (size_t)y * row, (const char *)luma + (size_t)y * stride * ctx->psz, row );
-        HIPCK( hipMemcpyAsync( s.luma, ctx->staging, ctx->staging_bytes, hipMemcpyHostToDevice, ctx->stream ) );
+        // the picture goes to the device on the DMA stream (from where it is if the caller's buffer is pinned, else through the staging
+        // ring); nobody waits for the compute stream
+        int rc = h2d_begin( ctx );
+        if( !rc ) rc = h2d_picture( ctx, s, luma, stride, pointer_kind( luma ) == 1 ? 1 : 0 );
+        if( !rc ) rc = h2d_end( ctx );
+        if( rc ) return rc;
         src = s.luma;
         src_stride = p.width;
         if( cb && cr )
         {
-            // the two chroma planes (4:2:0) follow through their own staging pair; the stream was drained above, so the device copy
-            // of the previous frame's chroma has been consumed
+            // the two chroma planes (4:2:0) follow through their own staging pair, which is reused picture after picture: the device copy
+            // of the previous picture's chroma has to have been consumed (AQ with chroma from host buffers is the occasional caller)
+            HIPCK( hipStreamSynchronize( ctx->stream ) );
             const int cw = p.chroma_format == 3 ? p.width : ( p.width + 1 ) >> 1, ch = p.chroma_format >= 2 ? p.height : ( p.height + 1 ) >> 1;
             const size_t crow = (size_t)cw * ctx->psz, cplane = crow * ch;
             if( !ctx->chroma_staging )
@@ -828,9 +929,19 @@ extern "C" int x264hip_frame_put_batch_yuv( x264hip_ctx *ctx, int n, const int *
         HIPCK( hipStreamWaitEvent( ctx->stream, ctx->ev_mbt_last, 0 ) );
     const x264hip_params &p = ctx->p;
     const int aq_on = p.aq_mode >= 1 && p.aq_strength != 0.f;
-    for( int o = 0; o < n; o += ctx->put_desc_cap )
+    // Pictures may also be HOST pointers (luma only): they travel on the DMA stream, sixteen to a group, and the ingest kernels of a
+    // group run behind its copies while the next group is still on its way
+    const int kind0 = pointer_kind( luma_dev[0] );
+    if( kind0 != 2 && cb_dev ) return X264HIP_EINVAL;
+    const int group = kind0 != 2 ? std::min( 16, ctx->put_desc_cap ) : ctx->put_desc_cap;
+    if( kind0 != 2 )
     {
-        const int m = std::min( n - o, ctx->put_desc_cap );
+        int rc = h2d_begin( ctx ); // (once per call: the slots of one call are distinct, a group's copies may overlap the previous group's kernels)
+        if( rc ) return rc;
+    }
+    for( int o = 0; o < n; o += group )
+    {
+        const int m = std::min( n - o, group );
         int ri = 0;
         if( ring_acquire( ctx->put_ring, &ri ) ) return X264HIP_EDEVICE;
         PutDesc *dh = (PutDesc *)ctx->put_ring.host[ri], *dd = (PutDesc *)ctx->put_ring.dev[ri];
@@ -839,7 +950,19 @@ extern "C" int x264hip_frame_put_batch_yuv( x264hip_ctx *ctx, int n, const int *
             if( !slot_ok( ctx, slots[o + i] ) || !luma_dev[o + i] ) return X264HIP_EINVAL;
             FrameSlot &s = ctx->slots[slots[o + i]];
             slot_reset( ctx, s );
+            if( kind0 != 2 )
+            {
+                int rc = h2d_picture( ctx, s, luma_dev[o + i], stride, pointer_kind( luma_dev[o + i] ) == 1 ? 1 : 0 );
+                if( rc ) return rc;
+                dh[i] = make_put_desc( ctx, s, s.luma, p.width, nullptr, nullptr, 0, aq_on );
+                continue;
+            }
             dh[i] = make_put_desc( ctx, s, luma_dev[o + i], stride, cb_dev ? cb_dev[o + i] : nullptr, cb_dev ? cr_dev[o + i] : nullptr, cstride, aq_on );
+        }
+        if( kind0 != 2 )
+        {
+            int rc = h2d_end( ctx );
+            if( rc ) return rc;
         }
         HIPCK( upload_async( ctx, dd, dh, (size_t)m * sizeof( PutDesc ), ctx->stream ) );
         PutDesc none;
@@ -922,6 +1045,7 @@ static int prof_drain( x264hip_ctx *ctx )
             const int k = ctx->prof_n[i / 2];
             const int kind = i / 2 < (int)ctx->prof_kind.size() ? ctx->prof_kind[i / 2] : -1;
             if( kind >= 0 ) { ctx->kprof_ms[kind] += ms; ctx->kprof_launches[kind]++; ctx->kprof_units[kind] += (uint64_t)k; }
+            else if( kind == -3 ) { ctx->prof_lat_ms += ms; ctx->prof_lat_launches++; ctx->prof_lat_searches += k; }
             else if( k < 0 ) { ctx->prof_cell_ms += ms; ctx->prof_cell_launches++; ctx->prof_cells += (uint64_t)-k; }
             else { ctx->prof_ms += ms; ctx->prof_launches++; ctx->prof_searches += k; }
         }
@@ -932,11 +1056,13 @@ static int prof_drain( x264hip_ctx *ctx )
     return X264HIP_OK;
 }
 
+static bool same_weight( const x264hip_weight &a, const x264hip_weight &b );
 struct SearchReq
 {
     int slot_b, slot_ref, list, dist_m1;
     WtD wt;
     unsigned keep_tag = 0; // non-zero: search under this tag (a field that so far existed on another rank only keeps its identity)
+    int to_spare = 0;      // a speculative weighted search: into the slot's second list-0 field of that distance, its tag into wspec
 };
 
 // wait for the stream, latch in-kernel timeouts (the flag lives in pinned host memory); every completed batch is now readable
@@ -998,8 +1124,14 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
     // (me_latency_kernel: a wave per search and block row, ~5 x shorter per block, ~3 x more instructions per block);
     // everything larger goes to the throughput kernel (me_rows_kernel).
     static const int lat_waves = getenv( "X264HIP_LAT_WAVES" ) ? atoi( getenv( "X264HIP_LAT_WAVES" ) ) : 4096;
-    const bool lat[2] = { (long long)n_plain * P.mb_h <= lat_waves, (long long)( n - n_plain ) * P.mb_h <= lat_waves };
+    // ... unless the device is shared: beside the launches of other contexts a small launch does not own the chip, what it leaves idle
+    // is theirs to fill, and the latency form's three-fold instruction count per block comes out of everybody's throughput (eight
+    // contexts, the 45 weighted searches of a fade per pass: 27.1 k against 26.0 k frames/s, profiles/r06_fade.txt)
+    static const bool lat_always = getenv( "X264HIP_LAT_ALWAYS" ) != nullptr;
+    const bool crowded = !lat_always && g_open_contexts[ctx->device & 63].load() >= 4;
+    const bool lat[2] = { !crowded && (long long)n_plain * P.mb_h <= lat_waves, !crowded && (long long)( n - n_plain ) * P.mb_h <= lat_waves };
     const bool rows[2] = { use_rows || !lat[0], use_rows || !lat[1] };
+    std::vector<int> spare_planes;
     for( int i = 0; i < n; i++ )
     {
         const SearchReq &r = reqs[order[i]];
@@ -1011,14 +1143,19 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         d.wt = r.wt;
         if( r.wt.on )
         {
-            if( b.wplane_idx < 0 ) b.wplane_idx = acquire_wplane( ctx, r.slot_b );
-            if( b.wplane_idx < 0 ) return X264HIP_ENOMEM;
-            T *wp = (T *)ctx->wplanes[b.wplane_idx];
+            // the weighted copy of the reference's plane 0 is read by this launch only: the speculative searches of a launch take one pool
+            // entry each and give it back at once (whoever takes it next writes it behind this launch, on the same stream)
+            int wi = r.to_spare ? acquire_wplane( ctx, r.slot_b ) : b.wplane_idx;
+            if( wi < 0 ) wi = b.wplane_idx = acquire_wplane( ctx, r.slot_b );
+            if( wi < 0 ) return X264HIP_ENOMEM;
+            T *wp = (T *)ctx->wplanes[wi];
             weight_strips_kernel<T><<<( P.plane_elems + 255 ) / 256, 256, 0, ctx->stream>>>( (const T *)rf.planes, wp, P.plane_elems, P.stride, r.wt, P.pixel_max );
             d.refw_strips = wp;
+            if( r.to_spare ) spare_planes.push_back( wi );
         }
-        d.mvq = b.mvq[r.list][r.dist_m1];
-        d.costs = b.mvcost[r.list][r.dist_m1];
+        const int fl = r.to_spare ? 2 : r.list;
+        d.mvq = b.mvq[fl][r.dist_m1];
+        d.costs = b.mvcost[fl][r.dist_m1];
         if( r.keep_tag )
             d.tag = r.keep_tag;
         else
@@ -1026,8 +1163,13 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
             d.tag = ctx->tag_serial++;
             if( !ctx->tag_serial ) ctx->tag_serial = 1;
         }
-        b.field_tag[r.list][r.dist_m1] = d.tag;
-        b.field_remote[r.list][r.dist_m1] = 0;
+        if( r.to_spare )
+            b.wspec[r.dist_m1].tag = d.tag;
+        else
+        {
+            b.field_tag[r.list][r.dist_m1] = d.tag;
+            b.field_remote[r.list][r.dist_m1] = 0;
+        }
         d.pad = 0;
         dh[i] = d;
     }
@@ -1043,7 +1185,11 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         }
         e0 = ctx->prof_ev[ctx->prof_used]; e1 = ctx->prof_ev[ctx->prof_used + 1];
         while( ctx->prof_kind.size() < ctx->prof_n.size() ) ctx->prof_kind.push_back( -1 );
-        ctx->prof_n.push_back( n ); ctx->prof_kind.push_back( -1 );
+        // (-1: a launch that can fill the chip -- more waves than the 4 096 wave slots -- on the throughput kernel: what the roofline is
+        //  about; -3: a small launch, as long as its dependency chain whatever runs it, counted for itself)
+        const int n_rg = ( P.mb_h + ME_ROWS - 1 ) / ME_ROWS;
+        const bool fills = ( !n_plain || ( rows[0] && (long long)n_plain * n_rg >= 4096 ) ) && ( n == n_plain || ( rows[1] && (long long)( n - n_plain ) * n_rg >= 4096 ) );
+        ctx->prof_n.push_back( n ); ctx->prof_kind.push_back( fills ? -1 : -3 );
         ctx->prof_used += 2;
     }
     HIPCK( hipEventRecord( e0, ctx->stream ) );
@@ -1089,6 +1235,7 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
     HIPCK( hipEventRecord( e1, ctx->stream ) );
     if( ring_commit( ctx->search_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
     HIPCK( hipGetLastError() );
+    for( int wi : spare_planes ) ctx->wplane_owner[wi] = -1;
     ctx->ev_valid = 1;
     ctx->last_n_search = n;
     ctx->last_n_blocks = n * ctx->n_mb;
@@ -1105,7 +1252,7 @@ static int launch_searches( x264hip_ctx *ctx, const std::vector<SearchReq> &reqs
 // Descriptor of the cell (slot_b, d0, d1) with the fields as they stand now.  kind: 0 intra sums only, 1 real cell.
 template <typename T>
 static CellArgs make_cell( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b, int d0, int d1, int with_intra, int ref1_l0_valid,
-                           int sums_only, int to_spare = 0 )
+                           int sums_only, int to_spare = 0, int wfield = 0 /* list 0 from the slot's speculative weighted field */ )
 {
     const LaP &P = ctx->P;
     FrameSlot &b = ctx->slots[slot_b], &f0 = ctx->slots[slot_p0], &f1 = ctx->slots[slot_p1];
@@ -1118,11 +1265,12 @@ static CellArgs make_cell( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_
     A.dist_scale_factor = intra_only ? 128 : ( ( d0 << 8 ) + ( ( d0 + d1 ) >> 1 ) ) / ( d0 + d1 );
     if( !intra_only )
     {
-        A.mvq0 = b.mvq[0][d0 - 1]; A.costs0 = b.mvcost[0][d0 - 1];
+        // wfield bit 0: list 0 from this frame's speculative weighted field, bit 1: the list-1 reference's vectors from ITS speculative weighted field
+        A.mvq0 = b.mvq[( wfield & 1 ) ? 2 : 0][d0 - 1]; A.costs0 = b.mvcost[( wfield & 1 ) ? 2 : 0][d0 - 1];
         if( b_bidir )
         {
             A.mvq1 = b.mvq[1][d1 - 1]; A.costs1 = b.mvcost[1][d1 - 1];
-            A.ref1_l0 = A.ref1_l0_valid ? f1.mvq[0][d0 + d1 - 1] : nullptr;
+            A.ref1_l0 = A.ref1_l0_valid ? f1.mvq[( wfield & 2 ) ? 2 : 0][d0 + d1 - 1] : nullptr;
             A.fenc0 = b.planes + 4 * ctx->plane_bytes; A.ref0_0 = f0.planes + 4 * ctx->plane_bytes; A.ref1_0 = f1.planes + 4 * ctx->plane_bytes;
         }
     }
@@ -1140,11 +1288,11 @@ static CellArgs make_cell( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_
     if( to_spare )
     {
         // the cell's spare: its own map, block words, row sums and sums; the intra row sums are the frame's (same values)
-        const int sp = ctx->spare_at[idx];
+        const int sp = to_spare == 2 ? ctx->spare2_at[idx] : ctx->spare_at[idx];
         A.lowres_costs = b.lowres_costs + (size_t)sp * ctx->n_mb;
         A.row_satds = b.row_satds + (size_t)sp * P.mb_h;
         A.blk = b.blk + (size_t)sp * ctx->n_mb;
-        A.acc = ctx->cell_alt_host + ( (size_t)slot_b * ctx->n_cells + idx ) * 8;
+        A.acc = ( to_spare == 2 ? ctx->cell_alt2_host : ctx->cell_alt_host ) + ( (size_t)slot_b * ctx->n_cells + idx ) * 8;
         A.acc_dev = b.cell_sums + (size_t)sp * 8;
         A.work = b.cell_work + (size_t)sp * 8;
     }
@@ -1163,6 +1311,7 @@ struct SpecCell
     int slot_p0, slot_p1, slot_b, d0, d1, sums_only, ref1_valid;
     int to_spare = 0;
     int dual = 0; // B cell with the list-1 reference's vectors: the outcome WITHOUT them is produced in the same pass, into the cell's spare
+    int wfield = 0; // P cell over the slot's speculative weighted list-0 field (into the cell's spare)
 };
 
 // one batch: all P cells, all B cells, then one reduction launch (a workgroup per cell)
@@ -1194,7 +1343,7 @@ static int launch_cells_t( x264hip_ctx *ctx, const std::vector<SpecCell> &cells 
         for( int i = 0; i < n; i++ )
         {
             const SpecCell &c = *ord[i];
-            dh[i] = make_cell<T>( ctx, c.slot_p0, c.slot_p1, c.slot_b, c.d0, c.d1, 1, c.ref1_valid, c.sums_only, c.to_spare );
+            dh[i] = make_cell<T>( ctx, c.slot_p0, c.slot_p1, c.slot_b, c.d0, c.d1, 1, c.ref1_valid, c.sums_only, c.to_spare, c.wfield );
             if( c.dual )
             {
                 const CellArgs S = make_cell<T>( ctx, c.slot_p0, c.slot_p1, c.slot_b, c.d0, c.d1, 1, 0, 0, 1 );
@@ -1424,7 +1573,7 @@ static int ensure_fields_local( x264hip_ctx *ctx, int slot_p0, int slot_p1, int 
 }
 
 template <typename T>
-static CellArgs make_cell( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b, int d0, int d1, int with_intra, int ref1_l0_valid, int sums_only, int to_spare );
+static CellArgs make_cell( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b, int d0, int d1, int with_intra, int ref1_l0_valid, int sums_only, int to_spare, int wfield );
 
 // The per-block map of a cell whose sums came from its owner rank, evaluated here after all (MB-tree reads it, so do
 // x264hip_frame_cost_recalculate and the getters): fields first, then the cell kernel; the sums are known already.
@@ -1492,10 +1641,24 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
         if( b_bidir && do_search[1] ) { ctx->field_req[1][d1 - 1]++; b.req_fields[1] |= 1u << ( d1 - 1 ); }
         if( do_search[0] )
         {
+            FrameSlot::WSpec &ws = b.wspec[d0 - 1];
             if( b.field_prefetched[0][d0 - 1] && !wt.on )
                 ctx->counters[2]++;
+            else if( wt.on && ws.valid && same_weight( ws.w, *w ) )
+            {
+                // the field was searched ahead of time on this very weighted reference (x264hip_prefetch_weighted_fields): it becomes the
+                // slot's list-0 field of this distance, the unweighted speculative one (and every cell evaluated over it) is left behind
+                int r = batch_wait( ctx, ws.batch );
+                if( r ) return r;
+                std::swap( b.mvq[0][d0 - 1], b.mvq[2][d0 - 1] );
+                std::swap( b.mvcost[0][d0 - 1], b.mvcost[2][d0 - 1] );
+                b.field_tag[0][d0 - 1] = ws.tag;
+                b.field_remote[0][d0 - 1] = 0;
+                ctx->weighted_claimed++;
+            }
             else
                 reqs.push_back( SearchReq{ slot_b, slot_p0, 0, d0 - 1, wt } );
+            ws.valid = 0;
             b.field_prefetched[0][d0 - 1] = 0;
             b.field_ready[0][d0 - 1] = 1;
         }
@@ -1529,23 +1692,27 @@ static int frame_cost_t( x264hip_ctx *ctx, int slot_p0, int slot_p1, int slot_b,
     const bool hit = e.valid && e.tag0 == t0 && e.tag1 == t1 && e.tagr == tr && ( !b_bidir || e.variant == ( ref1_l0_valid ? 1 : 0 ) );
     if( b_bidir )
         ctx->variant_req[idx][ref1_l0_valid ? 1 : 0]++;
-    if( !hit && b_bidir && b.alts[idx].valid && b.alts[idx].tag0 == t0 && b.alts[idx].tag1 == t1 && b.alts[idx].tagr == tr &&
-        b.alts[idx].variant == ( ref1_l0_valid ? 1 : 0 ) )
+    for( int which = 0; which < 2 && !hit && !intra_only; which++ )
     {
-        // the other variant was evaluated into the cell's spare: the spare becomes the cell (nothing to wait for beyond the batch that
-        // evaluated it) and the answer comes from its sums
-        CellEntry &a = b.alts[idx];
+        // another evaluation of this cell sits in one of its spares -- the other variant of a B cell (with / without the list-1 reference's
+        // vectors), or the cell over fields that were searched ahead of time on weighted references -- and it read exactly the fields
+        // the cell would read now: the spare becomes the cell (nothing to wait for beyond the batch that evaluated it) and the answer
+        // comes from its sums
+        CellEntry &a = which ? b.alts2[idx] : b.alts[idx];
+        if( !( a.valid && a.tag0 == t0 && a.tag1 == t1 && a.tagr == tr && ( !b_bidir || a.variant == ( ref1_l0_valid ? 1 : 0 ) ) ) )
+            continue;
         int r = batch_wait( ctx, a.batch );
         if( r ) return r;
-        b.cell_at[idx] = ctx->spare_at[idx]; // the spare IS the cell from now on: every reader goes through cell_at (no copy, no launch)
-        const int *ra = ctx->cell_alt_host + ( (size_t)slot_b * ctx->n_cells + idx ) * 8;
+        b.cell_at[idx] = which ? ctx->spare2_at[idx] : ctx->spare_at[idx]; // every reader goes through cell_at (no copy, no launch)
+        const int *ra = ( which ? ctx->cell_alt2_host : ctx->cell_alt_host ) + ( (size_t)slot_b * ctx->n_cells + idx ) * 8;
         out->cost_est = ra[0]; out->cost_est_aq = ra[1]; out->intra_mbs = ra[2];
         out->intra_cost_est = ra[3]; out->intra_cost_est_aq = ra[4];
         e.requested = 1; e.valid = 0;
         e.variant = a.variant;
         e.map_remote = a.map_remote; e.slot_p0 = a.slot_p0; e.slot_p1 = a.slot_p1; // (window shard: the spare's map may still be with its owner)
         a.valid = 0;
-        ctx->counters[4]++; ctx->counters[15]++; ctx->counters[1]++;
+        ctx->counters[4]++; ctx->counters[1]++;
+        if( which ) ctx->weighted_cells_used++; else ctx->counters[15]++;
         return X264HIP_OK;
     }
     const int was_valid = e.valid, was_requested = e.requested;
@@ -2337,6 +2504,102 @@ extern "C" int x264hip_prefetch_weight_costs( x264hip_ctx *ctx, int n, const int
     return batch_close( ctx );
 }
 
+// The list-0 searches a P request would make WITH a weight, ahead of the request: pair i = frame slot_fenc[i] searched on slot_ref[i]
+// weighted by w[i] (the weight x264_weights_analyse is going to arrive at -- the caller has the frame totals and the two cost sums it
+// needs, x264hip_prefetch_weight_costs).  Each goes into the frame's second list-0 field of that distance, and the P cell over it into
+// the spare of cell ( distance, 0 ); an x264hip_frame_cost call that first-triggers the field with the same weight takes both over
+// (no launch, no wait beyond this batch).  A request with another weight, or without one, ignores them.  Never changes results.
+extern "C" int x264hip_prefetch_weighted_fields( x264hip_ctx *ctx, int n, const int *slot_fenc, const int *slot_ref, const x264hip_weight *w )
+{
+    if( !ctx || n < 0 || ( n && ( !slot_fenc || !slot_ref || !w ) ) ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    std::vector<SearchReq> reqs;
+    std::vector<SpecCell> cells;
+    const int ns = ctx->p.bframes + 2;
+    for( int i = 0; i < n; i++ )
+    {
+        if( !slot_ok( ctx, slot_fenc[i] ) || !slot_ok( ctx, slot_ref[i] ) ) return X264HIP_EINVAL;
+        FrameSlot &b = ctx->slots[slot_fenc[i]], &r = ctx->slots[slot_ref[i]];
+        if( !b.in_use || !r.in_use || !w[i].on ) continue;
+        const int d = b.frame_no - r.frame_no; // (frame numbers: x264hip_prefetch)
+        if( b.frame_no < 0 || r.frame_no < 0 || d < 1 || d > ctx->p.bframes + 1 ) continue;
+        FrameSlot::WSpec &ws = b.wspec[d - 1];
+        if( b.field_ready[0][d - 1] || ws.valid || (int)reqs.size() >= ctx->desc_cap ) continue; // requested already / searched already
+        ws.valid = 1; ws.w = w[i]; ws.batch = ctx->batch_serial + 1;
+        SearchReq q{ slot_fenc[i], slot_ref[i], 0, d - 1, make_wt( ctx, &w[i] ) };
+        q.to_spare = 1;
+        reqs.push_back( q );
+    }
+    if( reqs.empty() ) return X264HIP_OK;
+    int rc = launch_searches( ctx, reqs );
+    if( rc ) return rc;
+    ctx->counters[0] -= reqs.size(); // (counted for themselves, not among the unweighted speculative searches)
+    ctx->weighted_speculated += reqs.size();
+    for( const SearchReq &q : reqs )
+    {
+        FrameSlot &b = ctx->slots[q.slot_b];
+        const int idx = ( q.dist_m1 + 1 ) * ns;
+        if( b.cells[idx].requested ) continue;
+        CellEntry &a = b.alts[idx];
+        a = CellEntry();
+        a.valid = 1; a.batch = ctx->batch_serial + 1; a.variant = 1;
+        a.tag0 = b.wspec[q.dist_m1].tag; a.tag1 = 0; a.tagr = 0;
+        SpecCell sc{ q.slot_ref, q.slot_b, q.slot_b, q.dist_m1 + 1, 0, 0, 0 };
+        sc.to_spare = 1; sc.wfield = 1;
+        cells.push_back( sc );
+    }
+    // ... and the B cells that read one of the new fields -- as the frame's own list-0 field (it was asked for as a P frame first, over
+    // that distance) or as the list-1 reference's vectors (slicetype.c:629; the reference, a P frame, keeps a weight) -- evaluated over
+    // them, into the cell's second spare.  Where both exist the cell is evaluated over both: under a fade every P request keeps a weight.
+    {
+        std::map<int, int> by_number;
+        for( int i = 0; i < (int)ctx->slots.size(); i++ )
+            if( ctx->slots[i].in_use && ctx->slots[i].frame_no >= 0 ) by_number[ctx->slots[i].frame_no] = i;
+        auto has_field = [&]( FrameSlot &f, int list, int dm1 ) { return ( f.field_ready[list][dm1] || f.field_prefetched[list][dm1] ) && !f.field_remote[list][dm1]; };
+        const unsigned fresh = ctx->batch_serial + 1;
+        for( auto &kv : by_number )
+        {
+            FrameSlot &b = ctx->slots[kv.second];
+            for( int d0 = 1; d0 <= ctx->p.bframes + 1; d0++ )
+                for( int d1 = 1; d0 + d1 <= ctx->p.bframes + 1; d1++ )
+                {
+                    const int idx = d0 * ns + d1;
+                    auto i0 = by_number.find( kv.first - d0 ), i1 = by_number.find( kv.first + d1 );
+                    if( i0 == by_number.end() || i1 == by_number.end() || !ctx->cell_allowed[idx] ) continue;
+                    FrameSlot &f1 = ctx->slots[i1->second];
+                    const bool wb = b.wspec[d0 - 1].valid, wr = f1.wspec[d0 + d1 - 1].valid;
+                    if( !( ( wb && b.wspec[d0 - 1].batch == fresh ) || ( wr && f1.wspec[d0 + d1 - 1].batch == fresh ) ) ) continue;
+                    if( b.cells[idx].requested || b.alts2[idx].valid || !has_field( b, 1, d1 - 1 ) ) continue;
+                    if( ( !wb && !has_field( b, 0, d0 - 1 ) ) || ( !wr && !has_field( f1, 0, d0 + d1 - 1 ) ) ) continue;
+                    CellEntry &a = b.alts2[idx];
+                    a = CellEntry();
+                    a.valid = 1; a.batch = fresh; a.variant = 1;
+                    a.tag0 = wb ? b.wspec[d0 - 1].tag : b.field_tag[0][d0 - 1];
+                    a.tag1 = b.field_tag[1][d1 - 1];
+                    a.tagr = wr ? f1.wspec[d0 + d1 - 1].tag : f1.field_tag[0][d0 + d1 - 1];
+                    SpecCell sc{ i0->second, i1->second, kv.second, d0, d1, 0, 1 };
+                    sc.to_spare = 2; sc.wfield = ( wb ? 1 : 0 ) | ( wr ? 2 : 0 );
+                    cells.push_back( sc );
+                }
+        }
+    }
+    if( !cells.empty() )
+    {
+        rc = ctx->p.bit_depth == 8 ? launch_cells_t<uint8_t>( ctx, cells ) : launch_cells_t<uint16_t>( ctx, cells );
+        if( rc ) return rc;
+        ctx->weighted_cells += cells.size();
+    }
+    return batch_close( ctx );
+}
+
+extern "C" int x264hip_weighted_stats( x264hip_ctx *ctx, uint64_t out[4] )
+{
+    if( !ctx || !out ) return X264HIP_EINVAL;
+    out[0] = ctx->weighted_speculated; out[1] = ctx->weighted_claimed; out[2] = ctx->weighted_cells; out[3] = ctx->weighted_cells_used;
+    return X264HIP_OK;
+}
+
 extern "C" int x264hip_weight_cost( x264hip_ctx *ctx, int slot_fenc, int slot_ref, const x264hip_weight *w, unsigned *cost )
 {
     if( !ctx || !cost || !slot_ok( ctx, slot_fenc ) || !slot_ok( ctx, slot_ref ) ) return X264HIP_EINVAL;
@@ -2468,6 +2731,7 @@ extern "C" int x264hip_search_profile( x264hip_ctx *ctx, int enable, double *tot
     if( enable >= 0 )
     {
         ctx->prof_ms = 0; ctx->prof_launches = 0; ctx->prof_searches = 0;
+        ctx->prof_lat_ms = 0; ctx->prof_lat_launches = 0; ctx->prof_lat_searches = 0;
         ctx->prof_cell_ms = 0; ctx->prof_cell_launches = 0; ctx->prof_cells = 0;
         for( int k = 0; k < X264HIP_KPROF_CLASSES; k++ ) { ctx->kprof_ms[k] = 0; ctx->kprof_launches[k] = 0; ctx->kprof_units[k] = 0; }
         ctx->prof_on = enable;
@@ -2478,6 +2742,21 @@ extern "C" int x264hip_search_profile( x264hip_ctx *ctx, int enable, double *tot
                 HIPCK( hipEventCreate( &e ) );
         }
     }
+    return X264HIP_OK;
+}
+
+// the search launches of the profiled region that cannot fill the chip (fewer waves than wave slots; me_latency_kernel runs them unless the device is shared);
+// call before x264hip_search_profile, which resets the totals
+extern "C" int x264hip_search_profile_latency( x264hip_ctx *ctx, double *total_ms, uint64_t *launches, uint64_t *searches )
+{
+    if( !ctx ) return X264HIP_EINVAL;
+    if( ctx->broken ) return X264HIP_EDEVICE;
+    if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE;
+    int rc = prof_drain( ctx );
+    if( rc ) return rc;
+    if( total_ms ) *total_ms = ctx->prof_lat_ms;
+    if( launches ) *launches = ctx->prof_lat_launches;
+    if( searches ) *searches = ctx->prof_lat_searches;
     return X264HIP_OK;
 }
 
@@ -2507,6 +2786,13 @@ extern "C" int x264hip_kernel_profile( x264hip_ctx *ctx, double *total_ms, uint6
         if( launches ) launches[k] = ctx->kprof_launches[k];
         if( units ) units[k] = ctx->kprof_units[k];
     }
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_host_transfer_stats( x264hip_ctx *ctx, uint64_t out[3] )
+{
+    if( !ctx || !out ) return X264HIP_EINVAL;
+    out[0] = ctx->h2d_bytes; out[1] = ctx->h2d_direct; out[2] = ctx->h2d_staged;
     return X264HIP_OK;
 }
 

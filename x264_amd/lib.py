@@ -106,6 +106,13 @@ def search_profile(L, ctx_handle, enable=-1):
     return ms.value, int(nl.value), int(ns.value)
 
 
+def search_profile_latency(L, ctx_handle):
+    """(total_ms, launches, searches) of the profiled search launches that ran on the latency form (read before search_profile resets)"""
+    ms, nl, ns = C.c_double(), C.c_uint64(), C.c_uint64()
+    _ck(L.x264hip_search_profile_latency(ctx_handle, C.byref(ms), C.byref(nl), C.byref(ns)), "search_profile_latency")
+    return ms.value, int(nl.value), int(ns.value)
+
+
 def kernel_profile(L, ctx_handle):
     """[(total_ms, launches, units)] per X264HIP_KPROF_* class (x264hip_kernel_profile; filled while x264hip_search_profile was on with bit 1 set)"""
     ms, nl, nu = (C.c_double * 6)(), (C.c_uint64 * 6)(), (C.c_uint64 * 6)()
@@ -464,7 +471,8 @@ class Backend(C.Structure):
                 ("mbtree", MBTREE_FN), ("get_qp_offsets", QP_OFFSETS_FN), ("frame_put_batch", PUT_BATCH_FN),
                 ("prefetch_weight_costs", PREFETCH_WEIGHTS_FN), ("frame_cost_recalculate", RECALC_FN),
                 ("get_row_satds", ROW_SATDS_FN), ("frame_put_yuv", FRAME_PUT_YUV_FN),
-                ("add_quant_offsets", ADD_QOFFS_FN), ("frame_put_batch_yuv", PUT_BATCH_YUV_FN), ("gop_hint", GOP_HINT_FN), ("flush", FLUSH_FN)]
+                ("add_quant_offsets", ADD_QOFFS_FN), ("frame_put_batch_yuv", PUT_BATCH_YUV_FN), ("gop_hint", GOP_HINT_FN), ("flush", FLUSH_FN),
+                ("prefetch_weighted_fields", PREFETCH_WEIGHTS_FN)]
 
 
 class Picture(C.Structure):
