@@ -2,7 +2,7 @@
 # usage (through gpurun, from the repo root): bash scripts/gpu_session.sh <tag> <stage...>
 # stages: parity (search + lookahead parity tests), suite (whole GPU suite), ab (short bench runs: default dispatch vs X264HIP_SEARCH=rows,
 # 8 / 1 contexts, batched and paced), prof (cycle breakdown of the search kernel from the -DME_PROFILE build), bench (default bench line),
-# stats (rocprofv3 kernel stats of the bench command), pmc (counter passes of the search kernel)
+# stats (rocprofv3 kernel stats of the bench command), stats1 (the same with one segment in flight), pmc (counter passes of the search kernel)
 cd "$GRAFT_REPO_ROOT" || exit 1
 tag=$1; shift
 out=gpurun_out/$tag
@@ -58,6 +58,11 @@ stats)
   cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
   mkdir -p ${out}_stats
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d ${out}_stats -o run -- python bench.py $short > ${out}_stats/bench.log 2>&1; echo "stats rc=$?" | tee -a $out/summary.txt ;;
+stats1)
+  # the same summary with ONE segment in flight: every kernel's own duration (no launches of other contexts stretching it)
+  cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+  mkdir -p ${out}_stats1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d ${out}_stats1 -o run -- python bench.py $short --inflight 1 > ${out}_stats1/bench.log 2>&1; echo "stats1 rc=$?" | tee -a $out/summary.txt ;;
 window)
   cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
   timeout 600 python scripts/window_profile.py $WINDOW_ARGS > $out/window.log 2>&1; grep -h '^{' $out/window.log | cut -c1-420 | tee -a $out/summary.txt

@@ -819,7 +819,11 @@ static int h2d_picture( x264hip_ctx *ctx, FrameSlot &s, const void *luma, int st
     const size_t row = (size_t)p.width * ctx->psz;
     if( kind == 1 )
     {
-        HIPCK( hipMemcpy2DAsync( s.luma, row, luma, (size_t)stride * ctx->psz, row, p.height, hipMemcpyHostToDevice, ctx->stream_h2d ) );
+        // (rows that follow each other in the caller's buffer are ONE transfer: the strided form goes row by row)
+        if( stride == p.width )
+            HIPCK( hipMemcpyAsync( s.luma, luma, ctx->staging_bytes, hipMemcpyHostToDevice, ctx->stream_h2d ) );
+        else
+            HIPCK( hipMemcpy2DAsync( s.luma, row, luma, (size_t)stride * ctx->psz, row, p.height, hipMemcpyHostToDevice, ctx->stream_h2d ) );
         ctx->h2d_direct++;
     }
     else
@@ -828,8 +832,11 @@ static int h2d_picture( x264hip_ctx *ctx, FrameSlot &s, const void *luma, int st
         if( !ctx->stage[k] && hipHostMalloc( &ctx->stage[k], ctx->staging_bytes ) != hipSuccess ) return X264HIP_ENOMEM;
         if( ctx->stage_used[k] )
             HIPCK( hipEventSynchronize( ctx->stage_ev[k] ) ); // the copy that last read this staging buffer (three pictures ago) is done
-        for( int y = 0; y < p.height; y++ )
-            memcpy( ctx->stage[k] + (size_t)y * row, (const char *)luma + (size_t)y * stride * ctx->psz, row );
+        if( stride == p.width )
+            memcpy( ctx->stage[k], luma, ctx->staging_bytes );
+        else
+            for( int y = 0; y < p.height; y++ )
+                memcpy( ctx->stage[k] + (size_t)y * row, (const char *)luma + (size_t)y * stride * ctx->psz, row );
         HIPCK( hipMemcpyAsync( s.luma, ctx->stage[k], ctx->staging_bytes, hipMemcpyHostToDevice, ctx->stream_h2d ) );
         HIPCK( hipEventRecord( ctx->stage_ev[k], ctx->stream_h2d ) );
         ctx->stage_used[k] = true;
