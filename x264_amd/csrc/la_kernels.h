@@ -664,6 +664,26 @@ __global__ __launch_bounds__( 256 ) void weight_strips_kernel( const T *__restri
         strips[strip_layout::row_off( k - 1, Y, rows ) + 8 + ( c & 7 )] = v; // ... and right half of strip k - 1
 }
 
+// The same for every weighted search of a launch at once (blockIdx.y = search): source plane, destination and weight come out of the
+// launch's own search descriptors (me_search.h SearchDesc: ref_strips is the strip copy behind the reference's four row-major planes,
+// refw_strips where the weighted copy goes).  A launch per weighted search -- 45 small kernels in a row for a fade -- cost each of them
+// the queueing of a kernel beside seven other contexts (156 us on average against 3 us alone, profiles/r06_bench_kernel_stats.csv).
+template <typename T, typename D>
+__global__ __launch_bounds__( 256 ) void weight_strips_multi_kernel( const D *__restrict__ descs, int n, int stride, int pixel_max )
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if( i >= n )
+        return;
+    const D &d = descs[blockIdx.y];
+    const T *src = d.ref_strips - 4 * (size_t)n; // plane 0, row-major: four planes of n samples, then their strip copies
+    T *strips = const_cast<T *>( d.refw_strips );
+    const int Y = i / stride, c = i - Y * stride, k = c >> 3, rows = n / stride;
+    const T v = (T)weight_px( src[i], d.wt, pixel_max );
+    strips[strip_layout::row_off( k, Y, rows ) + ( c & 7 )] = v;
+    if( k )
+        strips[strip_layout::row_off( k - 1, Y, rows ) + 8 + ( c & 7 )] = v;
+}
+
 // weight_cost_luma (slicetype.c:191-222): sum over blocks of min( mbcmp, intra_cost ).  256-thread workgroups, four
 // blocks per wave, sixteen per workgroup.  blockIdx.y picks the (fenc, ref, weight) job of a batch, blockIdx.z the
 // unweighted (0) or weighted (1) sum of a pair.  The workgroup that arrives last publishes the total to pinned host

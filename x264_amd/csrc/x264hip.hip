@@ -1156,8 +1156,7 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
             if( wi < 0 ) wi = b.wplane_idx = acquire_wplane( ctx, r.slot_b );
             if( wi < 0 ) return X264HIP_ENOMEM;
             T *wp = (T *)ctx->wplanes[wi];
-            weight_strips_kernel<T><<<( P.plane_elems + 255 ) / 256, 256, 0, ctx->stream>>>( (const T *)rf.planes, wp, P.plane_elems, P.stride, r.wt, P.pixel_max );
-            d.refw_strips = wp;
+            d.refw_strips = wp; // (filled by ONE launch for all the weighted searches of the table, below)
             if( r.to_spare ) spare_planes.push_back( wi );
         }
         const int fl = r.to_spare ? 2 : r.list;
@@ -1181,6 +1180,8 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
         dh[i] = d;
     }
     HIPCK( upload_async( ctx, dd, dh, (size_t)n * sizeof( SearchDesc<T> ), ctx->stream ) );
+    if( n > n_plain )
+        weight_strips_multi_kernel<T, SearchDesc<T>><<<dim3( ( P.plane_elems + 255 ) / 256, n - n_plain ), 256, 0, ctx->stream>>>( dd + n_plain, P.plane_elems, P.stride, P.pixel_max );
     // (the row tickets in sync_words are cleared by the last wave of the previous launch: me_search.h)
     hipEvent_t e0 = ctx->ev_start, e1 = ctx->ev_stop;
     if( ctx->prof_on )
