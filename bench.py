@@ -781,16 +781,20 @@ def main():
                     for sgi in range(S):
                         assert outputs_signature(oh[sgi], nb) == outputs_signature(outs_all[sgi], nb), "host-fed segment %d differs from the device-resident pass" % sgi
                     hstat = np.zeros(3, np.uint64)
+                    hstat2 = np.zeros(2, np.uint64)
                     for la in wlh.las:
                         b = np.zeros(3, np.uint64)
                         lib._ck(la.L.x264hip_host_transfer_stats(la.ctx_handle(), b.ctypes.data_as(ctypes.c_void_p)), "host_transfer_stats")
                         hstat += b
+                        b2 = np.zeros(2, np.uint64)
+                        lib._ck(la.L.x264hip_host_transfer_stats2(la.ctx_handle(), b2.ctypes.data_as(ctypes.c_void_p)), "host_transfer_stats2")
+                        hstat2 += b2
                 finally:
                     wlh.close()
                 fps_h = S * F * steps_h / dth
                 # one stream, encoder-paced, from host buffers: pinned, and plain pageable memory (staged through the library's pinned ring)
                 one = {}
-                for key_h, clip_h in (("pinned", host_clips[0]), ("pageable", seg_dev[0].cpu())):
+                for key_h, clip_h in (("device_resident", seg_dev[0]), ("pinned", host_clips[0]), ("pageable", seg_dev[0].cpu())):
                     w1 = Workload(torch, lib, shard, cfg, dev_index, 0, 1, F, [clip_h], True)
                     try:
                         dt1, o1 = w1.timed(2, 1, paced=True)
@@ -804,7 +808,7 @@ def main():
                                    "fps": round(fps_h, 2), "pcie_GBps": round(fps_h * frame_bytes / 1e9, 2), "pcie_peak_GBps": round(pcie_peak, 2),
                                    "pcie_peak_what": "a plain pinned-to-device copy loop (8 x 256 MiB) on this box",
                                    "pcie_bound_fps": round(pcie_peak * 1e9 / frame_bytes, 1), "share_of_min_value_pcie_bound": round(fps_h / bound, 3),
-                                   "pictures_direct_from_pinned": int(hstat[1]), "pictures_staged": int(hstat[2]),
+                                   "pictures_direct_from_pinned": int(hstat[1]), "pictures_staged": int(hstat[2]), "transfers_of_a_whole_group": int(hstat2[0]),
                                    "single_stream_paced_fps": one, "checked": "types + every cost cell == the device-resident passes"}
                 del host_clips
             except Exception as e:  # pragma: no cover

@@ -135,6 +135,10 @@ int  x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, int stride
  * x264hip_host_transfer_stats: bytes copied so far, pictures taken as they were / through the ring. */
 int  x264hip_frame_put_batch( x264hip_ctx *ctx, int n, const int *slots, const void *const *luma_dev, int stride );
 int  x264hip_host_transfer_stats( x264hip_ctx *ctx, uint64_t out[3] );
+/* how they travelled: out[0] = transfers that carried a whole group of pictures (pictures that follow each other in pinned memory cross
+ * PCIe as ONE transfer per group of sixteen), out[1] = single pictures fetched by a copy kernel on the compute stream (x264hip_frame_put:
+ * no DMA stream and no cross-stream event in front of the ingest kernels an encoder-paced caller waits for) */
+int  x264hip_host_transfer_stats2( x264hip_ctx *ctx, uint64_t out[2] );
 /* same with the 4:2:0 chroma planes of every frame (device pointers; both arrays NULL = luma only) */
 int  x264hip_frame_put_batch_yuv( x264hip_ctx *ctx, int n, const int *slots, const void *const *luma_dev, int stride,
                                   const void *const *cb_dev, const void *const *cr_dev, int cstride );

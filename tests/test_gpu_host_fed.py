@@ -36,6 +36,8 @@ def test_host_pictures_equal_device_pictures(W, H, depth):
                 outs = la.run(device_ptrs=ptrs, stride=W, paced=paced)
                 st = np.zeros(3, np.uint64)
                 lib._ck(la.L.x264hip_host_transfer_stats(la.ctx_handle(), st.ctypes.data_as(C.c_void_p)), "host_transfer_stats")
+                st2 = np.zeros(2, np.uint64)
+                lib._ck(la.L.x264hip_host_transfer_stats2(la.ctx_handle(), st2.ctypes.data_as(C.c_void_p)), "host_transfer_stats2")
             finally:
                 la.close()
             if want is None:
@@ -46,5 +48,8 @@ def test_host_pictures_equal_device_pictures(W, H, depth):
                 assert tuple(st) == (0, 0, 0)
             elif name == "pinned":
                 assert tuple(int(v) for v in st) == (nf * W * H * px, nf, 0)
+                # batched: the clip is one allocation, so every group of sixteen pictures is ONE transfer; paced: a copy kernel per picture
+                assert (int(st2[0]) >= nf // 16 and int(st2[1]) == 0) if not paced else int(st2[1]) == nf, (paced, st2)
             else:
                 assert tuple(int(v) for v in st) == (nf * W * H * px, 0, nf)
+                assert int(st2[0]) == 0 and (int(st2[1]) == nf if paced else True), (paced, st2)

@@ -37,19 +37,37 @@ def shim_path():
     return out
 
 
+class _library:
+    """$X264HIP_LIB names the library the seam opens -- for the runs inside the block only: whatever the variable held before is what the
+    tests that follow (and the processes they start) see again"""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __enter__(self):
+        self.before = os.environ.get("X264HIP_LIB")
+        os.environ["X264HIP_LIB"] = self.path
+
+    def __exit__(self, *exc):
+        if self.before is None:
+            os.environ.pop("X264HIP_LIB", None)
+        else:
+            os.environ["X264HIP_LIB"] = self.before
+
+
 def compare_runs(width, height, frames, preset, opts, lib, chroma=None):
     """the same encode twice in the seam build: hook off / hook on"""
-    os.environ["X264HIP_LIB"] = lib
     sep = "," if opts else ""
     outs = []
-    for accel in (0, 1):
-        r = refharness.Ref(width, height, preset, opts=opts + sep + "opencl=%d" % accel, seam=True)
-        try:
-            assert r.accel_state() == accel, "the encoder did not keep the accelerator hook (library or device missing?)"
-            outs.append(r.encode_run(frames, chroma))
-            assert r.accel_state() == accel
-        finally:
-            r.close()
+    with _library(lib):
+        for accel in (0, 1):
+            r = refharness.Ref(width, height, preset, opts=opts + sep + "opencl=%d" % accel, seam=True)
+            try:
+                assert r.accel_state() == accel, "the encoder did not keep the accelerator hook (library or device missing?)"
+                outs.append(r.encode_run(frames, chroma))
+                assert r.accel_state() == accel
+            finally:
+                r.close()
     a, b = outs
     assert a["frame"].tolist() == b["frame"].tolist()
     assert a["type"].tolist() == b["type"].tolist()
@@ -84,9 +102,9 @@ def test_reference_lookahead_on_level1_entries_equals_c_path(name, w, h, nf, pre
 
 def test_seam_falls_back_without_the_library():
     """no library to open: x264_opencl_load_library returns NULL and the encoder keeps its C path (encoder.c:1748-1752)"""
-    os.environ["X264HIP_LIB"] = "/nonexistent/libx264hip.so"
-    r = refharness.Ref(352, 288, "medium", opts="opencl=1", seam=True)
-    try:
-        assert r.accel_state() == 0
-    finally:
-        r.close()
+    with _library("/nonexistent/libx264hip.so"):
+        r = refharness.Ref(352, 288, "medium", opts="opencl=1", seam=True)
+        try:
+            assert r.accel_state() == 0
+        finally:
+            r.close()

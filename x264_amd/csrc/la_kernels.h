@@ -182,7 +182,11 @@ __device__ __forceinline__ void lowres_px4( const T *__restrict__ src, int src_s
         for( int i = 0; i < 4; i++ ) { o0[i] = e0; oh[i] = eh; ov[i] = ev; oc[i] = ec; }
     }
 }
-template <typename T>
+// NPR: how many of the four planes are also written ROW-MAJOR.  The searches and the B cells read the strip copy; of the row-major planes
+// only plane 0 has readers on the device (intra_kernel, weight_cost_kernel, the weighted strip copies): H, V and HV row-major are read by
+// x264hip_get_lowres alone, which rebuilds them from the strips when asked (strips_to_plane_kernel).  NPR = 1: 9 S written per frame
+// instead of 12 S (0.34 -> 0.28 ms per 160 frames of 1080p); NPR = 4 (X264HIP_ROWMAJOR=4): every plane at ingest, the round-5 form.
+template <typename T, int NPR>
 __global__ __launch_bounds__( 256 ) void lowres_tiles_kernel( const PutDesc *descs, PutDesc single, int width, int height,
                                                               int plane_elems, int stride, int lw, int lh )
 {
@@ -222,7 +226,7 @@ __global__ __launch_bounds__( 256 ) void lowres_tiles_kernel( const PutDesc *des
         {
             const size_t o = (size_t)Y * stride + X;
 #pragma unroll
-            for( int p = 0; p < 4; p++ )
+            for( int p = 0; p < NPR; p++ )
             {
                 T v[16];
                 __builtin_memcpy( v, &tile[p][r][c], 16 * sizeof( T ) );
@@ -253,6 +257,21 @@ __global__ __launch_bounds__( 256 ) void lowres_tiles_kernel( const PutDesc *des
             }
         }
     }
+}
+
+// row-major plane p of a frame rebuilt from its strip copy (x264hip_get_lowres for the H / V / HV planes): a thread per 8 samples
+template <typename T>
+__global__ __launch_bounds__( 256 ) void strips_to_plane_kernel( T *__restrict__ planes, int p, int plane_elems, int stride, int rows )
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x; // piece index: row Y, strip k
+    const int n_strips = stride >> 3;
+    if( i >= rows * n_strips )
+        return;
+    const int Y = i / n_strips, k = i - Y * n_strips;
+    const T *strips = planes + 4 * (size_t)plane_elems;
+    T v[8];
+    __builtin_memcpy( v, strips + 2 * (size_t)p * plane_elems + strip_layout::row_off( k, Y, rows ), 8 * sizeof( T ) );
+    __builtin_memcpy( planes + (size_t)p * plane_elems + (size_t)Y * stride + 8 * k, v, 8 * sizeof( T ) );
 }
 
 // plain x264_mc_functions_t.frame_init_lowres_core signature (mc.h:326-327): no borders, caller's layout

@@ -1240,7 +1240,7 @@ extern "C" int x264hip_lookahead_open_backend( x264hip_lookahead **out, const x2
     if( rc ) { delete la; return rc; }
     la->L.be = *backend;
     int n = params->dev.max_frames > 0 ? params->dev.max_frames : slots_needed( params );
-    for( int i = n - 1; i >= 0; i-- ) la->L.free_slots.push_back( i );
+    for( int i = 0; i < n; i++ ) la->L.free_slots.push_back( i ); // (taken from the front: the first picture gets slot 0)
     *out = la;
     return X264HIP_OK;
 }
@@ -1368,7 +1368,9 @@ extern "C" int x264hip_lookahead_delay( x264hip_lookahead *la ) { return la ? la
 static LaFrame *new_frame( Lookahead &L, int forced_type )
 {
     LaFrame *f = new LaFrame();
-    f->slot = L.free_slots.back(); L.free_slots.pop_back();
+    // the slot that has been free the longest: what MB-tree launch last worked on it is long over when its next picture arrives (the
+    // backend orders an ingest behind the launch that names its slot, x264hip.hip mbt_guard_slot)
+    f->slot = L.free_slots.front(); L.free_slots.erase( L.free_slots.begin() );
     f->i_frame = L.i_input++;
     // an unknown picture type is taken as AUTO (x264_frame_copy_picture, frame.c:392-400)
     f->i_forced_type = f->i_type = forced_type < T_AUTO || forced_type > T_KEYFRAME ? T_AUTO : forced_type;
@@ -1519,6 +1521,15 @@ extern "C" int x264hip_lookahead_put( x264hip_lookahead *la, const x264hip_pictu
     }
     L.next.push_back( f );
     L.pending_prefetch.push_back( f );
+    // (X264HIP_LA_PUT_FLUSH=1, measured in round 6 and left off: the speculative work for a picture submitted WITH the picture instead of at
+    //  the next decision.  Its searches then start a put earlier -- and every launch is a chain of W + 2 (H - 1) block searches on ONE
+    //  stream, one after the other: three launches per mini-GOP instead of one, 1 290 against 3 160 frames/s, profiles/r06_paced.txt)
+    static const bool put_flush = getenv( "X264HIP_LA_PUT_FLUSH" ) && atoi( getenv( "X264HIP_LA_PUT_FLUSH" ) ) == 1;
+    if( put_flush && !L.prefetch_hook && L.i_input > L.i_delay && !L.err ) // (a hooked lookahead -- the window shard -- keeps its chunks: a chunk is a round of collectives)
+    {
+        L.flush_prefetch();
+        if( L.err ) return L.err;
+    }
     return X264HIP_OK;
 }
 

@@ -267,6 +267,20 @@ struct WaveEval
 #define ME_LAT_ROWS 1
 #endif
 #define WIN_HAND_W 512 // widest row (blocks) handed over through LDS inside a workgroup (8K pictures: 480)
+// Round 6, measured and kept OFF: a row GUESSES the one vector it would have to wait for.  Block (x, y) needs the vector of (x - 1, y + 1),
+// which the row below finds two blocks after the last vector this row already holds: a row trails the row below by two block searches
+// plus a hand-off, H - 1 times along the chain.  Where motion is uniform that vector repeats its right-hand neighbour's, so with
+// -DME_LAT_SPEC=1 a step whose granule has not arrived searches on below_left := below and looks at the granule afterwards: the guess
+// held -> the result stands, one block search earlier than it could have started; it did not -> the block is searched again with the
+// real vector.  Bit-exact (a block is committed only when its neighbours are the real ones; the whole GPU parity suite ran on it), 75 %
+// of the steps of the bench clip guess and 8 % of the guesses miss -- and a launch of 25 searches takes 1 146 us instead of 984, the paced
+// stream 2 520 instead of 2 780 frames/s (profiles/r06_latency_ab.txt).  The chain is not W + 2 ( H - 1 ) times an average block: block
+// searches differ by a factor of ten (a block that ends at the zero test against one that walks the diamond), a row's pace is the row
+// below's, and the two blocks of distance are the slack that absorbs the differences; at one block every slow block below stalls every
+// row above it at once (cycles per step: the wait for the row below 2 110 -> 1 290, but everything else + 1 680).
+#ifndef ME_LAT_SPEC
+#define ME_LAT_SPEC 0
+#endif
 template <typename T, int HEX, int MODE, int WEIGHTED, int RW>
 __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_latency_kernel( LaP P, const SearchDesc<T> *descs, MeQueues Q,
                                                                           unsigned *tickets /* [ME_QUEUES * ME_QUEUE_STRIDE] */, unsigned *err_host /* pinned sticky timeout flag */,
@@ -276,7 +290,7 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_latency_kernel( La
     typedef WinGeo<T, NP> G;
     const int lane = lane_id();
 #ifdef ME_PROFILE
-    unsigned long long pf_wait = 0, pf_pre = 0, pf_search = 0, pf_store = 0, pf_spins = 0, pf_steps = 0;
+    unsigned long long pf_wait = 0, pf_pre = 0, pf_search = 0, pf_store = 0, pf_spins = 0, pf_steps = 0, pf_guess = 0, pf_miss = 0;
     unsigned long long pf_ph[5] = { 0, 0, 0, 0, 0 };
     const unsigned long long pf_begin = __builtin_amdgcn_s_memtime();
 #define PF_NOW() __builtin_amdgcn_s_memtime()
@@ -509,12 +523,22 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_latency_kernel( La
         // statements make them "used"), before the new requests go out, and the DMA goes out last.
         Px8 f = source_px8( f_next );
         asm volatile( "" : "+v"( f.lo.raw ), "+v"( f.hi.raw ), "+v"( f.lo.a ), "+v"( f.lo.b ), "+v"( f.hi.a ), "+v"( f.hi.b ) );
+        bool guessed = false; // this step searches on a guess of below_left and checks it afterwards (scalar)
         if( has_below && bx > 0 )
         {
             unsigned long long gq = g_next;
-            if( !__all( granule_ok( gq ) ) )
+            if( __all( granule_ok( gq ) ) )
+                below_left = granule_mv( gq );
+            else if( ME_LAT_SPEC )
+            {
+                guessed = true;
+                below_left = below;
+            }
+            else
+            {
                 gq = granule_spin( bx - 1 );
-            below_left = granule_mv( gq );
+                below_left = granule_mv( gq );
+            }
             // (kept in a scalar register: an asm result in a VGPR counts as divergent, and everything derived from it -- predictor,
             // candidates, the whole decision logic -- would be vector code again)
             asm volatile( "" : "+s"( below_left ) );
@@ -539,6 +563,9 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_latency_kernel( La
         unsigned long long pf_t2 = pf_t1, pf_t3 = pf_t1;
 #endif
         int mvx = 0, mvy = 0, cost = 0;
+        for( ;; )
+        {
+        mvx = 0; mvy = 0; cost = 0;
         if( la_visited( P, bx, by ) )
         {
             MeLim L;
@@ -611,6 +638,31 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_latency_kernel( La
                     cost += 5 * P.lambda;
             }
         }
+        if( !guessed )
+            break;
+        // the guess against the vector the row below has found by now (it is one block search ahead: normally there, else waited for)
+        {
+            unsigned long long gq = granule( bx - 1 );
+            if( !__all( granule_ok( gq ) ) )
+                gq = granule_spin( bx - 1 );
+            if( timed_out )
+                break;
+            int real = granule_mv( gq );
+            asm volatile( "" : "+s"( real ) );
+            guessed = false;
+#ifdef ME_PROFILE
+            pf_guess++;
+#endif
+            if( real == below_left )
+                break;
+#ifdef ME_PROFILE
+            pf_miss++;
+#endif
+            below_left = real;
+        }
+        }
+        if( timed_out )
+            break;
 #ifdef ME_PROFILE
         pf_t3 = PF_NOW();
 #endif
@@ -648,6 +700,7 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_latency_kernel( La
         atomicAdd( prof + 0, PF_NOW() - pf_begin ); atomicAdd( prof + 1, pf_wait ); atomicAdd( prof + 2, pf_pre ); atomicAdd( prof + 3, pf_search );
         atomicAdd( prof + 4, pf_store ); atomicAdd( prof + 5, pf_spins ); atomicAdd( prof + 6, pf_steps ); atomicAdd( prof + 7, 1ull );
         for( int i = 1; i < 5; i++ ) atomicAdd( prof + 7 + i, pf_ph[i] );
+        atomicAdd( prof + 26, pf_guess ); atomicAdd( prof + 27, pf_miss );
     }
 #endif
 }

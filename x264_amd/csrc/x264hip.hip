@@ -66,6 +66,9 @@ struct FrameSlot
 {
     int in_use = 0;
     int frame_no = -1;
+    int rowmajor_mask = 0;        // bit p: plane p exists row-major (plane 0 always; H / V / HV on demand, x264hip_get_lowres)
+    uint64_t mbt_last_use = 0;    // serial of the last MB-tree launch whose steps name this slot (0: none); mbt_queued: named by steps still in the queue
+    bool mbt_queued = false;
     char *planes = nullptr;       // padded planes base (4 planes)
     char *luma = nullptr;
     uint16_t *inv_qscale = nullptr;
@@ -163,6 +166,7 @@ struct x264hip_ctx
     hipEvent_t ev_cross = nullptr, ev_mbt_last = nullptr;
     hipEvent_t ev_ingest = nullptr;  // behind the most recent ingest kernels: frame totals are readable after it
     int mbt_next = 0, mbt_pending = 0;
+    uint64_t mbt_serial = 0, mbt_ring_serial[16] = { 0 }; // launches so far; the launch that last used ring entry r (its event: mbt_done[r])
     unsigned *mbt_bar = nullptr;      // device [MBT_RING][MBT_MAX_GROUPS][4]: barrier arrivals, unused, exits, unused; then one error word
     // step lists waiting for their launch (x264hip_mbtree queues, mbt_flush launches): list g of the queue is steps
     // [mbt_q.beg[g], mbt_q.beg[g+1]) of ring entry mbt_q_ring and adds into accumulator bank g
@@ -201,6 +205,16 @@ struct x264hip_ctx
     int stage_next = 0;
     uint64_t weighted_speculated = 0, weighted_claimed = 0, weighted_cells = 0, weighted_cells_used = 0; // x264hip_prefetch_weighted_fields: searches enqueued, fields a request took, P cells with them
     uint64_t h2d_bytes = 0, h2d_direct = 0, h2d_staged = 0; // bytes copied, pictures taken from pinned memory as they were / through the ring
+    // Pictures that follow each other in pinned host memory cross PCIe as ONE transfer per group of a batch (a 2 MB copy reaches 21 GB/s,
+    // a 33 MB one the link's 50+, profiles/r06_bench_kernel_stats_solo.csv): into a ring of device group buffers the ingest kernels read
+    // in place of the slots' own luma buffers.  h2d_group_free[k]: behind the ingest kernels that last read buffer k (compute stream).
+    // (six buffers of at most sixteen pictures or 64 MB: a wait for a buffer's last readers would hold up the device's ONE transfer queue)
+    static const int H2D_GROUPS = 6, H2D_GROUP_PICS = 16;
+    char *h2d_group[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t h2d_group_free[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    bool h2d_group_used[6] = { false, false, false, false, false, false };
+    int h2d_group_next = 0, h2d_group_pics = 16;
+    uint64_t h2d_merged = 0, h2d_by_kernel = 0; // transfers that carried a whole group; single pictures fetched by a copy kernel on the compute stream
     char *chroma_staging = nullptr, *chroma_dev = nullptr; // host-buffer ingest with chroma: pinned + device copies of Cb and Cr (allocated on first use)
     size_t staging_bytes = 0;
     std::vector<char *> wplanes;     // weighted plane pool
@@ -336,6 +350,34 @@ static int ring_commit( DescRing &r, int i, hipStream_t s )
 // contexts open on each device: the MB-tree launches size themselves so that the lists of every context fit the chip together
 #include <atomic>
 static std::atomic<int> g_open_contexts[64];
+// ONE host-to-device stream per device, shared by its contexts.  With a DMA stream per context the transfers of eight contexts share the
+// link: every context's pictures arrive late and together, all of them compute together, and link and device take turns (eight host-fed
+// segments: 88 ms per step = 46 ms of transfers + 43 ms of device work, gpurun_out/r06r).  In ONE queue the transfers of a context arrive
+// at the link's full rate, its kernels start while the next context's pictures are on their way, and the contexts fall out of step.
+#include <mutex>
+static std::mutex g_h2d_mutex;
+static std::mutex g_h2d_batch_mutex[64]; // a batch of host pictures is enqueued as a whole: the transfers of ONE context follow each other in the device's queue
+static hipStream_t g_h2d_stream[64];
+static int g_h2d_users[64];
+static int h2d_stream_acquire( int device, hipStream_t *out )
+{
+    std::lock_guard<std::mutex> lock( g_h2d_mutex );
+    const int d = device & 63;
+    if( !g_h2d_users[d] && hipStreamCreateWithFlags( &g_h2d_stream[d], hipStreamNonBlocking ) != hipSuccess ) return X264HIP_EDEVICE;
+    g_h2d_users[d]++;
+    *out = g_h2d_stream[d];
+    return X264HIP_OK;
+}
+static void h2d_stream_release( int device )
+{
+    std::lock_guard<std::mutex> lock( g_h2d_mutex );
+    const int d = device & 63;
+    if( g_h2d_users[d] > 0 && !--g_h2d_users[d] )
+    {
+        (void)hipStreamDestroy( g_h2d_stream[d] );
+        g_h2d_stream[d] = nullptr;
+    }
+}
 
 static void free_all( x264hip_ctx *ctx )
 {
@@ -378,7 +420,16 @@ static void free_all( x264hip_ctx *ctx )
     for( int k = 1; k < x264hip_ctx::STAGE_RING; k++ ) if( ctx->stage[k] ) (void)hipHostFree( ctx->stage[k] );
     for( int k = 0; k < x264hip_ctx::STAGE_RING; k++ ) if( ctx->stage_ev[k] ) (void)hipEventDestroy( ctx->stage_ev[k] );
     if( ctx->h2d_done ) (void)hipEventDestroy( ctx->h2d_done );
-    if( ctx->stream_h2d ) (void)hipStreamDestroy( ctx->stream_h2d );
+    for( int k = 0; k < x264hip_ctx::H2D_GROUPS; k++ )
+    {
+        if( ctx->h2d_group[k] ) (void)hipFree( ctx->h2d_group[k] );
+        if( ctx->h2d_group_free[k] ) (void)hipEventDestroy( ctx->h2d_group_free[k] );
+    }
+    if( ctx->stream_h2d )
+    {
+        (void)hipStreamSynchronize( ctx->stream_h2d ); // (shared with the device's other contexts: nothing of THIS context may still be queued on it)
+        h2d_stream_release( ctx->device );
+    }
     if( ctx->chroma_staging ) (void)hipHostFree( ctx->chroma_staging );
     if( ctx->chroma_dev ) (void)hipFree( ctx->chroma_dev );
     for( auto e : ctx->prof_ev ) (void)hipEventDestroy( e );
@@ -421,6 +472,8 @@ extern "C" void x264hip_close( x264hip_ctx *ctx )
         if( v[7] )
             fprintf( stderr, "ME_PROFILE search phases per step (group 0): start candidates %.0f pattern %.0f half-pel %.0f quarter-pel %.0f\n",
                      (double)v[8] / v[6], (double)v[9] / v[6], (double)v[10] / v[6], (double)v[11] / v[6] );
+        if( v[26] )
+            fprintf( stderr, "ME_PROFILE latency form: steps searched on a guessed below-left vector %.3f of all, guesses that missed %.3f\n", (double)v[26] / v[6], (double)v[27] / v[26] );
         if( v[7] && v[23] )
         {
             fprintf( stderr, "ME_PROFILE neighbour candidates kept per block, share of blocks (0..4):" );
@@ -579,10 +632,12 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     ctx->staging_bytes = (size_t)p.width * p.height * ctx->psz;
     OPENCK( hipHostMalloc( &ctx->staging, ctx->staging_bytes ) );
     ctx->stage[0] = ctx->staging;
-    OPENCK( hipStreamCreateWithFlags( &ctx->stream_h2d, hipStreamNonBlocking ) );
+    if( h2d_stream_acquire( ctx->device, &ctx->stream_h2d ) ) { ctx->stream_h2d = nullptr; OPENCK( hipErrorUnknown ); }
     OPENCK( hipEventCreateWithFlags( &ctx->h2d_done, hipEventDisableTiming ) );
     for( int k = 0; k < x264hip_ctx::STAGE_RING; k++ )
         OPENCK( hipEventCreateWithFlags( &ctx->stage_ev[k], hipEventDisableTiming ) );
+    for( int k = 0; k < x264hip_ctx::H2D_GROUPS; k++ )
+        OPENCK( hipEventCreateWithFlags( &ctx->h2d_group_free[k], hipEventDisableTiming ) );
 
     const int nd = p.bframes + 1, nc = ( p.bframes + 2 ) * ( p.bframes + 2 );
     ctx->slots.resize( p.max_frames );
@@ -650,7 +705,15 @@ extern "C" int x264hip_device_name( x264hip_ctx *ctx, char *buf, size_t cap )
 }
 
 static int mbt_flush( x264hip_ctx *ctx );
+// do the ingest kernels of this process write all four planes row-major?  (split ingest or X264HIP_ROWMAJOR=4; default: plane 0 only)
+static bool rowmajor_all_at_ingest()
+{
+    static const bool v = ( getenv( "X264HIP_INGEST" ) && !strcmp( getenv( "X264HIP_INGEST" ), "split" ) ) ||
+                          ( getenv( "X264HIP_ROWMAJOR" ) && atoi( getenv( "X264HIP_ROWMAJOR" ) ) == 4 );
+    return v;
+}
 static int mbt_flush_at( x264hip_ctx *ctx, int line );
+static int mbt_guard_slot( x264hip_ctx *ctx, const FrameSlot &s );
 extern "C" int x264hip_synchronize( x264hip_ctx *ctx )
 {
     if( !ctx ) return X264HIP_EINVAL;
@@ -732,8 +795,12 @@ static int launch_ingest_t( x264hip_ctx *ctx, const PutDesc *descs_dev, const Pu
     const float bias = 14.427f + 2 * ( p.bit_depth - 8 );
     static const bool split_ingest = getenv( "X264HIP_INGEST" ) && !strcmp( getenv( "X264HIP_INGEST" ), "split" );
     const int rows = ctx->lh + 2 * LA_PAD;
-    if( !split_ingest )
-        KPROF( X264HIP_KPROF_LOWRES, n, ( lowres_tiles_kernel<T><<<dim3( ( P.stride + LT_COLS - 1 ) / LT_COLS, ( rows + LT_ROWS - 1 ) / LT_ROWS, n ), 256, 0, ctx->stream>>>(
+    const bool rowmajor_all = rowmajor_all_at_ingest(); // A/B runs: H / V / HV row-major at ingest
+    if( !split_ingest && rowmajor_all )
+        KPROF( X264HIP_KPROF_LOWRES, n, ( lowres_tiles_kernel<T, 4><<<dim3( ( P.stride + LT_COLS - 1 ) / LT_COLS, ( rows + LT_ROWS - 1 ) / LT_ROWS, n ), 256, 0, ctx->stream>>>(
+            descs_dev, single, p.width, p.height, P.plane_elems, P.stride, ctx->lw, ctx->lh ) ) );
+    else if( !split_ingest )
+        KPROF( X264HIP_KPROF_LOWRES, n, ( lowres_tiles_kernel<T, 1><<<dim3( ( P.stride + LT_COLS - 1 ) / LT_COLS, ( rows + LT_ROWS - 1 ) / LT_ROWS, n ), 256, 0, ctx->stream>>>(
             descs_dev, single, p.width, p.height, P.plane_elems, P.stride, ctx->lw, ctx->lh ) ) );
     else
     {
@@ -760,6 +827,7 @@ static int launch_ingest_t( x264hip_ctx *ctx, const PutDesc *descs_dev, const Pu
 
 static void slot_reset( x264hip_ctx *ctx, FrameSlot &s )
 {
+    s.rowmajor_mask = rowmajor_all_at_ingest() ? 0xF : 1;
     if( s.in_use && s.pos_key )
     {
         // the frame that leaves this slot has been asked for everything it will ever be asked for: count it under its position
@@ -853,6 +921,54 @@ static int h2d_end( x264hip_ctx *ctx )
     return X264HIP_OK;
 }
 
+// One picture through a copy kernel on the compute stream; X264HIP_ESTATE: not possible for this buffer (the caller takes the DMA road).
+static int h2d_single_by_kernel( x264hip_ctx *ctx, FrameSlot &s, const void *luma, int stride, int kind )
+{
+    static const bool dma_only = getenv( "X264HIP_H2D" ) && !strcmp( getenv( "X264HIP_H2D" ), "dma" );
+    const x264hip_params &p = ctx->p;
+    if( dma_only || ( ctx->staging_bytes & 15 ) || ( (uintptr_t)s.luma & 15 ) ) return X264HIP_ESTATE;
+    const char *host = (const char *)luma;
+    int k = -1;
+    if( kind != 1 || stride != p.width || ( (uintptr_t)luma & 15 ) )
+    {
+        // pageable (or strided / unaligned) pictures: one memcpy into the pinned ring, read from there
+        if( kind == 1 && stride == p.width ) return X264HIP_ESTATE; // pinned but unaligned: the DMA engine takes it as it is
+        k = ctx->stage_next++ % x264hip_ctx::STAGE_RING;
+        if( !ctx->stage[k] && hipHostMalloc( &ctx->stage[k], ctx->staging_bytes ) != hipSuccess ) return X264HIP_ENOMEM;
+        if( ctx->stage_used[k] )
+            HIPCK( hipEventSynchronize( ctx->stage_ev[k] ) ); // the copy that last read this staging buffer is done
+        const size_t row = (size_t)p.width * ctx->psz;
+        if( stride == p.width )
+            memcpy( ctx->stage[k], luma, ctx->staging_bytes );
+        else
+            for( int y = 0; y < p.height; y++ )
+                memcpy( ctx->stage[k] + (size_t)y * row, (const char *)luma + (size_t)y * stride * ctx->psz, row );
+        host = ctx->stage[k];
+    }
+    void *mapped = nullptr;
+    if( hipHostGetDevicePointer( &mapped, (void *)host, 0 ) != hipSuccess || !mapped )
+    {
+        (void)hipGetLastError();
+        if( k >= 0 ) ctx->stage_next--;
+        return X264HIP_ESTATE;
+    }
+    const size_t n16 = ctx->staging_bytes / 16;
+    const int grid = (int)std::min<size_t>( ( n16 + 1023 ) / 1024, 512 );
+    copy16_kernel<4, false><<<grid, 256, 0, ctx->stream>>>( (const copy_v4u *)mapped, (copy_v4u *)s.luma, n16 );
+    HIPCK( hipGetLastError() );
+    if( k >= 0 )
+    {
+        HIPCK( hipEventRecord( ctx->stage_ev[k], ctx->stream ) );
+        ctx->stage_used[k] = true;
+        ctx->h2d_staged++;
+    }
+    else
+        ctx->h2d_direct++;
+    ctx->h2d_by_kernel++;
+    ctx->h2d_bytes += ctx->staging_bytes;
+    return X264HIP_OK;
+}
+
 extern "C" int x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, int stride, int is_device, const void *cb, const void *cr,
                                   int cstride, const uint16_t *inv_qscale )
 {
@@ -865,8 +981,10 @@ extern "C" int x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, 
         int rc = mbt_flush_at( ctx, __LINE__ );
         if( rc ) return rc;
     }
-    if( ctx->mbt_pending )
-        HIPCK( hipStreamWaitEvent( ctx->stream, ctx->ev_mbt_last, 0 ) ); // MB-tree steps may still read this slot's maps
+    {
+        int rc = mbt_guard_slot( ctx, s ); // MB-tree steps may still read this slot's maps
+        if( rc ) return rc;
+    }
     slot_reset( ctx, s );
     const x264hip_params &p = ctx->p;
     const void *src = luma;
@@ -875,11 +993,17 @@ extern "C" int x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, 
         is_device = 0; // (the pointer's own attributes decide: a host buffer announced as device memory still takes the DMA road)
     if( !is_device )
     {
-        // the picture goes to the device on the DMA stream (from where it is if the caller's buffer is pinned, else through the staging
-        // ring); nobody waits for the compute stream
-        int rc = h2d_begin( ctx );
-        if( !rc ) rc = h2d_picture( ctx, s, luma, stride, pointer_kind( luma ) == 1 ? 1 : 0 );
-        if( !rc ) rc = h2d_end( ctx );
+        // ONE picture: fetched by a copy kernel on the compute stream, which reads the caller's pinned buffer (or the pinned staging
+        // copy of a pageable one) across PCIe -- no DMA stream, no event between two streams in front of the ingest kernels, which
+        // are what an encoder-paced caller waits for (a 2 MB DMA transfer takes 98 us and two cross-stream waits; X264HIP_H2D=dma
+        // keeps that road).  Buffers the kernel cannot address (an odd size or alignment, no device mapping) take the DMA road.
+        int rc = h2d_single_by_kernel( ctx, s, luma, stride, pointer_kind( luma ) == 1 ? 1 : 0 );
+        if( rc == X264HIP_ESTATE )
+        {
+            rc = h2d_begin( ctx );
+            if( !rc ) rc = h2d_picture( ctx, s, luma, stride, pointer_kind( luma ) == 1 ? 1 : 0 );
+            if( !rc ) rc = h2d_end( ctx );
+        }
         if( rc ) return rc;
         src = s.luma;
         src_stride = p.width;
@@ -932,17 +1056,27 @@ extern "C" int x264hip_frame_put_batch_yuv( x264hip_ctx *ctx, int n, const int *
         int rc = mbt_flush_at( ctx, __LINE__ );
         if( rc ) return rc;
     }
-    if( ctx->mbt_pending )
-        HIPCK( hipStreamWaitEvent( ctx->stream, ctx->ev_mbt_last, 0 ) );
+    for( int i = 0; i < n; i++ )
+        if( slot_ok( ctx, slots[i] ) )
+        {
+            int rc = mbt_guard_slot( ctx, ctx->slots[slots[i]] );
+            if( rc ) return rc;
+        }
     const x264hip_params &p = ctx->p;
     const int aq_on = p.aq_mode >= 1 && p.aq_strength != 0.f;
     // Pictures may also be HOST pointers (luma only): they travel on the DMA stream, sixteen to a group, and the ingest kernels of a
     // group run behind its copies while the next group is still on its way
     const int kind0 = pointer_kind( luma_dev[0] );
     if( kind0 != 2 && cb_dev ) return X264HIP_EINVAL;
-    const int group = kind0 != 2 ? std::min( 16, ctx->put_desc_cap ) : ctx->put_desc_cap;
+    ctx->h2d_group_pics = (int)std::max<size_t>( 1, std::min<size_t>( x264hip_ctx::H2D_GROUP_PICS, ( (size_t)64 << 20 ) / ctx->staging_bytes ) );
+    const int group = kind0 != 2 ? std::min( ctx->h2d_group_pics, ctx->put_desc_cap ) : ctx->put_desc_cap;
+    static const bool no_merge = getenv( "X264HIP_H2D" ) && !strcmp( getenv( "X264HIP_H2D" ), "dma" ); // A/B runs: a transfer per picture
+    // (eight threads that enqueue their groups at the same moment would interleave them, and every context's pictures would arrive
+    //  late and together again: the lock is held while this call ENQUEUES -- microseconds per group, nothing waits for the device)
+    std::unique_lock<std::mutex> batch_lock( g_h2d_batch_mutex[ctx->device & 63], std::defer_lock );
     if( kind0 != 2 )
     {
+        batch_lock.lock();
         int rc = h2d_begin( ctx ); // (once per call: the slots of one call are distinct, a group's copies may overlap the previous group's kernels)
         if( rc ) return rc;
     }
@@ -952,11 +1086,44 @@ extern "C" int x264hip_frame_put_batch_yuv( x264hip_ctx *ctx, int n, const int *
         int ri = 0;
         if( ring_acquire( ctx->put_ring, &ri ) ) return X264HIP_EDEVICE;
         PutDesc *dh = (PutDesc *)ctx->put_ring.host[ri], *dd = (PutDesc *)ctx->put_ring.dev[ri];
+        // a group whose pictures follow each other in pinned memory is ONE transfer into a device group buffer, read there by the ingest kernels
+        int gk = -1;
+        if( kind0 == 1 && stride == p.width && m > 1 && !no_merge )
+        {
+            bool run = true;
+            for( int i = 1; i < m && run; i++ )
+                run = (const char *)luma_dev[o + i] == (const char *)luma_dev[o] + (size_t)i * ctx->staging_bytes;
+            // (one allocation: its first and last byte are pinned memory, so is everything between)
+            run = run && pointer_kind( (const char *)luma_dev[o] + (size_t)m * ctx->staging_bytes - 1 ) == 1;
+            if( run )
+            {
+                gk = ctx->h2d_group_next++ % x264hip_ctx::H2D_GROUPS;
+                if( !ctx->h2d_group[gk] && hipMalloc( &ctx->h2d_group[gk], (size_t)ctx->h2d_group_pics * ctx->staging_bytes ) != hipSuccess )
+                {
+                    (void)hipGetLastError();
+                    gk = -1; // no memory for the group buffer: picture by picture
+                }
+            }
+            if( gk >= 0 )
+            {
+                if( ctx->h2d_group_used[gk] )
+                    HIPCK( hipStreamWaitEvent( ctx->stream_h2d, ctx->h2d_group_free[gk], 0 ) );
+                HIPCK( hipMemcpyAsync( ctx->h2d_group[gk], luma_dev[o], (size_t)m * ctx->staging_bytes, hipMemcpyHostToDevice, ctx->stream_h2d ) );
+                ctx->h2d_merged++;
+                ctx->h2d_direct += m;
+                ctx->h2d_bytes += (size_t)m * ctx->staging_bytes;
+            }
+        }
         for( int i = 0; i < m; i++ )
         {
             if( !slot_ok( ctx, slots[o + i] ) || !luma_dev[o + i] ) return X264HIP_EINVAL;
             FrameSlot &s = ctx->slots[slots[o + i]];
             slot_reset( ctx, s );
+            if( gk >= 0 )
+            {
+                dh[i] = make_put_desc( ctx, s, ctx->h2d_group[gk] + (size_t)i * ctx->staging_bytes, p.width, nullptr, nullptr, 0, aq_on );
+                continue;
+            }
             if( kind0 != 2 )
             {
                 int rc = h2d_picture( ctx, s, luma_dev[o + i], stride, pointer_kind( luma_dev[o + i] ) == 1 ? 1 : 0 );
@@ -975,6 +1142,11 @@ extern "C" int x264hip_frame_put_batch_yuv( x264hip_ctx *ctx, int n, const int *
         PutDesc none;
         memset( &none, 0, sizeof( none ) );
         int rc = p.bit_depth == 8 ? launch_ingest_t<uint8_t>( ctx, dd, none, m ) : launch_ingest_t<uint16_t>( ctx, dd, none, m );
+        if( gk >= 0 )
+        {
+            HIPCK( hipEventRecord( ctx->h2d_group_free[gk], ctx->stream ) );
+            ctx->h2d_group_used[gk] = true;
+        }
         if( ring_commit( ctx->put_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
         if( rc ) return rc;
     }
@@ -1810,6 +1982,40 @@ static int mbt_ring_acquire( x264hip_ctx *ctx, int *r_out )
     return X264HIP_OK;
 }
 
+// A launch has been enqueued on ring entry r: the slots its steps name are in use until mbt_done[r] has passed.
+static void mbt_mark_launch( x264hip_ctx *ctx, int r )
+{
+    ctx->mbt_serial++;
+    ctx->mbt_ring_serial[r] = ctx->mbt_serial;
+    for( auto &f : ctx->slots )
+        if( f.mbt_queued ) { f.mbt_queued = false; f.mbt_last_use = ctx->mbt_serial; }
+}
+// A picture is about to be written into slot s (maps, factors, offsets: what MB-tree steps read and write).  Only a launch whose steps NAME
+// the slot can still be reading it -- and only that launch is waited for, on the device.  (Until round 6 every ingest waited for the most
+// recent MB-tree launch whatever it worked on: an encoder-paced stream spent the 200 us of every mini-GOP's propagation with the pictures
+// of the next one waiting in front of the device, profiles/r06_paced_trace.txt.)  A ring entry that has been taken over by a later launch
+// belongs to a launch that is complete (mbt_ring_acquire waits for it).
+static int mbt_guard_slot( x264hip_ctx *ctx, const FrameSlot &s )
+{
+    static const bool coarse = getenv( "X264HIP_MBT_GUARD" ) && !strcmp( getenv( "X264HIP_MBT_GUARD" ), "coarse" ); // A/B runs: the round-5 wait
+    if( !ctx->mbt_pending ) return X264HIP_OK;
+    if( coarse )
+    {
+        HIPCK( hipStreamWaitEvent( ctx->stream, ctx->ev_mbt_last, 0 ) );
+        return X264HIP_OK;
+    }
+    if( !s.mbt_last_use ) return X264HIP_OK;
+    for( int r = 0; r < x264hip_ctx::MBT_RING; r++ )
+        if( ctx->mbt_ring_serial[r] == s.mbt_last_use )
+        {
+            if( hipEventQuery( ctx->mbt_done[r] ) == hipSuccess ) return X264HIP_OK;
+            (void)hipGetLastError(); // (hipErrorNotReady is an answer, not a failure)
+            HIPCK( hipStreamWaitEvent( ctx->stream, ctx->mbt_done[r], 0 ) );
+            return X264HIP_OK;
+        }
+    return X264HIP_OK;
+}
+
 // Workgroups per list.  The workgroups of a list wait for each other at its barriers, so all of them have to be resident together:
 // with 1024 threads and 80 registers a CU holds one, and the lists of a launch of every open context must fit the chip at once
 // (otherwise workgroups that spin at a barrier could keep the ones they wait for off the CUs): a context's share of the CUs, divided
@@ -1914,6 +2120,7 @@ static int mbt_flush( x264hip_ctx *ctx )
     HIPCK( hipEventRecord( ctx->mbt_done[r], ctx->stream2 ) );
     HIPCK( hipEventRecord( ctx->ev_mbt_last, ctx->stream2 ) );
     ctx->mbt_pending++;
+    mbt_mark_launch( ctx, r );
     return X264HIP_OK;
 }
 // (X264HIP_TRACE_CLASSES: which call sites cut the MB-tree queue into launches, printed when the context closes)
@@ -1957,6 +2164,12 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
             int rc = ensure_cell_local( ctx, ops[i].slot_b, ops[i].dist_p0, ops[i].dist_p1 );
             if( rc ) return rc;
         }
+    // (mbt_guard_slot: the slots a list names belong to the launch that carries it until that launch's event has passed; marked where the
+    //  list joins a launch -- a flush on the way there launches OTHER lists)
+    auto name_slots = [&]() {
+        for( int i = 0; i < n; i++ )
+            ctx->slots[ops[i].slot_b].mbt_queued = ctx->slots[ops[i].slot_p0].mbt_queued = ctx->slots[ops[i].slot_p1].mbt_queued = true;
+    };
     // A list that clears every accumulator it reads before it adds to it (every list of a lookahead with frames in it,
     // slicetype.c:1108-1135) depends on the lists before it through nothing but the buffers: it is queued, gets an accumulator bank
     // of its own and runs beside the other lists of the launch.  Lists that carry state across calls (the lookahead-less form swaps
@@ -2124,6 +2337,7 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
                 ctx->mbt_q_lds = true;
                 ctx->mbt_q.beg[bank + 1] = ctx->mbt_q.beg[bank] + (int)L.size();
                 ctx->mbt_q.n = bank + 1;
+                name_slots();
                 return X264HIP_OK;
             }
             if( bank != 0 )
@@ -2173,12 +2387,14 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
             }
         ctx->mbt_q.beg[bank + 1] = ctx->mbt_q.beg[bank] + k;
         ctx->mbt_q.n = bank + 1;
+        name_slots();
         return X264HIP_OK;
     }
     // the immediate form: behind everything queued, on the slots' own accumulators -- contents that live in a bank move home first
     {
         int rc = mbt_flush_at( ctx, __LINE__ );
         if( rc ) return rc;
+        name_slots();
         for( int i = 0; i < n; i++ )
             for( int slot : { ops[i].slot_b, ops[i].slot_p0, ops[i].slot_p1 } )
             {
@@ -2347,6 +2563,7 @@ extern "C" int x264hip_mbtree( x264hip_ctx *ctx, const x264hip_mbtree_op *ops, i
     HIPCK( hipEventRecord( ctx->mbt_done[r], ctx->stream2 ) );
     HIPCK( hipEventRecord( ctx->ev_mbt_last, ctx->stream2 ) );
     ctx->mbt_pending++;
+    mbt_mark_launch( ctx, r );
     return X264HIP_OK;
 }
 
@@ -2649,6 +2866,17 @@ extern "C" int x264hip_get_lowres( x264hip_ctx *ctx, int slot, int plane, void *
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
     FrameSlot &s = ctx->slots[slot];
     const int w = ctx->lw + 2 * LA_PAD, h = ctx->lh + 2 * LA_PAD;
+    if( plane && !( s.rowmajor_mask & ( 1 << plane ) ) )
+    {
+        // the H / V / HV planes exist as strips only until somebody asks for them row-major (la_kernels.h lowres_tiles_kernel)
+        const int pieces = h * ( ctx->P.stride >> 3 );
+        if( ctx->p.bit_depth == 8 )
+            strips_to_plane_kernel<uint8_t><<<( pieces + 255 ) / 256, 256, 0, ctx->stream>>>( (uint8_t *)s.planes, plane, ctx->P.plane_elems, ctx->P.stride, h );
+        else
+            strips_to_plane_kernel<uint16_t><<<( pieces + 255 ) / 256, 256, 0, ctx->stream>>>( (uint16_t *)s.planes, plane, ctx->P.plane_elems, ctx->P.stride, h );
+        HIPCK( hipGetLastError() );
+        s.rowmajor_mask |= 1 << plane;
+    }
     HIPCK( hipMemcpy2DAsync( dst, (size_t)dst_stride * ctx->psz, s.planes + (size_t)plane * ctx->plane_bytes, (size_t)ctx->P.stride * ctx->psz,
                              (size_t)w * ctx->psz, h, hipMemcpyDeviceToHost, ctx->stream ) );
     HIPCK( hipStreamSynchronize( ctx->stream ) );
@@ -2801,6 +3029,13 @@ extern "C" int x264hip_host_transfer_stats( x264hip_ctx *ctx, uint64_t out[3] )
 {
     if( !ctx || !out ) return X264HIP_EINVAL;
     out[0] = ctx->h2d_bytes; out[1] = ctx->h2d_direct; out[2] = ctx->h2d_staged;
+    return X264HIP_OK;
+}
+
+extern "C" int x264hip_host_transfer_stats2( x264hip_ctx *ctx, uint64_t out[2] )
+{
+    if( !ctx || !out ) return X264HIP_EINVAL;
+    out[0] = ctx->h2d_merged; out[1] = ctx->h2d_by_kernel;
     return X264HIP_OK;
 }
 
