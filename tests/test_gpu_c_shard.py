@@ -136,6 +136,69 @@ def test_c_shard_pieces_and_reset():
     assert got[0]["calls"]["broadcast"] >= 2 * NF  # a picture per piece (+ the commands)
 
 
+def _both_protocols_worker(rank, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2")
+    import datetime
+    import torch
+    import torch.distributed as dist
+    from x264_amd import lib as L2, shard
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=2, timeout=datetime.timedelta(seconds=120))
+    cfg = L2.la_config(W, H, "medium", **OVER)
+    cfg["_frames"] = NF
+    clip = torch.from_numpy(make_clip(W, H, NF, **CLIP)).cuda()
+    # the C shard (x264hip_shard_*), its command blocks decoded on rank 0 as they pass through the transport
+    t = shard.HostStagedTransport(dist, rank, 2)
+    t.command_log = []
+    outs_c, _, st_c, rc = shard.run_c_window_shard(torch, L2, rank, 2, 0, cfg, clip if rank == 0 else None, t, qp_offsets=True)
+    dist.barrier()
+    # the Python orchestration (shard.WindowShard over the same context entry points), its commands as _send builds them
+    log_py = []
+    dev = clip.clone()
+    if rank:
+        dev.zero_()
+    outs_p, _, st_p = shard.run_window_shard(torch, L2, dist, rank, 2, 0, cfg, dev, exchange_on_device=False, qp_offsets=True, broadcast_input=True,
+                                             command_log=log_py)
+    q.put(dict(rank=rank, c=t.command_log, py=log_py, sig_c=None if outs_c is None else _sig(outs_c), sig_py=None if outs_p is None else _sig(outs_p),
+               st_c=st_c, st_py=st_p, rc=rc))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_python_and_c_shard_send_the_same_commands():
+    """x264_amd/shard.py keeps a Python orchestration of the window shard (what the CPU suite runs over the oracle backend) beside the C one
+    in shard_host.cpp (the product).  One window through both, two ranks each: every command rank 0 sends -- CHUNK (slots, frame numbers,
+    the class statement), FETCH (the maps MB-tree is about to read, spare halves flagged), STOP -- agrees word for word, and so do the
+    counts of what each rank then did (fields searched, cells evaluated, list-0 fields exchanged, maps fetched) and the results."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_both_protocols_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {g["rank"]: g for g in (q.get(timeout=600) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    g0, g1 = got[0], got[1]
+    assert g0["sig_c"] == g0["sig_py"] == _plain()
+    c, py = g0["c"], g0["py"]
+    kinds = lambda log: [w[0] for w in log]  # noqa: E731
+    print("commands: C %d, Python %d; kinds %s" % (len(c), len(py), sorted(set(kinds(c)))))
+    assert len(c) > 3 and 1 in kinds(c) and 2 in kinds(c) and kinds(c)[-1] == 0  # CHUNK, FETCH, ..., STOP
+    assert len(c) == len(py)
+    for k, (a, b) in enumerate(zip(c, py)):
+        assert a == b, (k, a[:8], b[:8])
+    assert g1["c"] == [] and g1["py"] == []  # only rank 0 commands
+    for r in (0, 1):
+        for name in ("chunks", "fields_searched", "cells_evaluated", "l0_fields_exchanged", "cells_imported", "maps_fetched", "fetch_commands",
+                     "bytes_input_broadcast", "bytes_l0_received", "bytes_summaries", "bytes_maps"):
+            assert got[r]["st_c"][name] == got[r]["st_py"][name], (r, name, got[r]["st_c"][name], got[r]["st_py"][name])
+
+
 def test_c_shard_failing_rank_fails_everybody():
     """rank 1 fails at its first chunk: it keeps the collectives going, the status word carries the failure, rank 0's calls fail with
     X264HIP_EPEER (-7) -- nobody is left inside a collective (the test would time out)"""

@@ -11,6 +11,7 @@
 // plus per-slot weighted copies of a reference's plane 0, taken from a small pool.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
@@ -208,12 +209,17 @@ struct x264hip_ctx
     // Pictures that follow each other in pinned host memory cross PCIe as ONE transfer per group of a batch (a 2 MB copy reaches 21 GB/s,
     // a 33 MB one the link's 50+, profiles/r06_bench_kernel_stats_solo.csv): into a ring of device group buffers the ingest kernels read
     // in place of the slots' own luma buffers.  h2d_group_free[k]: behind the ingest kernels that last read buffer k (compute stream).
-    // (six buffers of at most sixteen pictures or 64 MB: a wait for a buffer's last readers would hold up the device's ONE transfer queue)
-    static const int H2D_GROUPS = 6, H2D_GROUP_PICS = 16;
-    char *h2d_group[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-    hipEvent_t h2d_group_free[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-    bool h2d_group_used[6] = { false, false, false, false, false, false };
+    // Twelve buffers of at most sixteen pictures or 64 MB, allocated as they are first needed: a pass of 160 pictures finds a free
+    // buffer for every group.  A buffer whose last readers have not run yet is waited for by the HOST THREAD, outside the queue's lock:
+    // a device-side wait in the device's ONE transfer queue holds up every other context's pictures behind it (six buffers, waits in
+    // the queue: the link was busy 59 % of a host-fed step, gpurun_out/r06w).
+    static const int H2D_GROUPS = 12, H2D_GROUP_PICS = 16;
+    char *h2d_group[12] = {};
+    hipEvent_t h2d_group_free[12] = {};
+    bool h2d_group_used[12] = {};
     int h2d_group_next = 0, h2d_group_pics = 16;
+    // X264HIP_H2D_TRACE=1: host time of the host-picture calls -- waiting for the transfer queue's lock, holding it, between two calls
+    uint64_t h2d_t_wait = 0, h2d_t_hold = 0, h2d_t_prep = 0, h2d_t_between = 0, h2d_t_last = 0, h2d_calls = 0;
     uint64_t h2d_merged = 0, h2d_by_kernel = 0; // transfers that carried a whole group; single pictures fetched by a copy kernel on the compute stream
     char *chroma_staging = nullptr, *chroma_dev = nullptr; // host-buffer ingest with chroma: pinned + device copies of Cb and Cr (allocated on first use)
     size_t staging_bytes = 0;
@@ -379,8 +385,18 @@ static void h2d_stream_release( int device )
     }
 }
 
+static inline uint64_t host_now_ns()
+{
+    struct timespec ts;
+    clock_gettime( CLOCK_MONOTONIC, &ts );
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
 static void free_all( x264hip_ctx *ctx )
 {
+    if( ctx->h2d_calls && getenv( "X264HIP_H2D_TRACE" ) )
+        fprintf( stderr, "x264hip h2d trace: %llu calls, per call: before the lock %.3f ms, waiting for it %.3f ms, holding it %.3f ms, between calls %.3f ms\n",
+                 (unsigned long long)ctx->h2d_calls, ctx->h2d_t_prep / 1e6 / ctx->h2d_calls, ctx->h2d_t_wait / 1e6 / ctx->h2d_calls,
+                 ctx->h2d_t_hold / 1e6 / ctx->h2d_calls, ctx->h2d_t_between / 1e6 / ctx->h2d_calls );
     if( ctx->counted_open ) { g_open_contexts[ctx->device & 63]--; ctx->counted_open = false; }
     if( ctx->stream ) (void)hipStreamSynchronize( ctx->stream );
     for( auto &s : ctx->slots )
@@ -1052,6 +1068,7 @@ extern "C" int x264hip_frame_put_batch_yuv( x264hip_ctx *ctx, int n, const int *
         return X264HIP_EINVAL;
     if( ctx->broken ) return X264HIP_EDEVICE;
     if( hipSetDevice( ctx->device ) != hipSuccess ) return X264HIP_EDEVICE; // the current device is per host thread
+    const uint64_t t_enter = host_now_ns();
     {
         int rc = mbt_flush_at( ctx, __LINE__ );
         if( rc ) return rc;
@@ -1074,81 +1091,110 @@ extern "C" int x264hip_frame_put_batch_yuv( x264hip_ctx *ctx, int n, const int *
     // (eight threads that enqueue their groups at the same moment would interleave them, and every context's pictures would arrive
     //  late and together again: the lock is held while this call ENQUEUES -- microseconds per group, nothing waits for the device)
     std::unique_lock<std::mutex> batch_lock( g_h2d_batch_mutex[ctx->device & 63], std::defer_lock );
-    if( kind0 != 2 )
+    bool h2d_begun = false; // (the wait for the slots' last readers: once per call, and only when a picture goes into a slot's own buffer)
+    // ONE descriptor table per call (per put_desc_cap pictures): its groups' ingest launches read their part of it.  A table per group
+    // ran the ring of four dry at the fifth group of a 160-picture call, and the wait for the first group's ingest kernels -- behind
+    // seven other contexts' searches -- was made with the transfer queue's lock held: the link stood idle 40 % of a host-fed step
+    // (gpurun_out/r07b/timeline.txt).  Whatever this call may have to wait for, it waits for without the lock.
+    for( int o0 = 0; o0 < n; o0 += ctx->put_desc_cap )
     {
-        batch_lock.lock();
-        int rc = h2d_begin( ctx ); // (once per call: the slots of one call are distinct, a group's copies may overlap the previous group's kernels)
-        if( rc ) return rc;
-    }
-    for( int o = 0; o < n; o += group )
-    {
-        const int m = std::min( n - o, group );
+        const int n0 = std::min( n - o0, ctx->put_desc_cap );
         int ri = 0;
         if( ring_acquire( ctx->put_ring, &ri ) ) return X264HIP_EDEVICE;
-        PutDesc *dh = (PutDesc *)ctx->put_ring.host[ri], *dd = (PutDesc *)ctx->put_ring.dev[ri];
-        // a group whose pictures follow each other in pinned memory is ONE transfer into a device group buffer, read there by the ingest kernels
-        int gk = -1;
-        if( kind0 == 1 && stride == p.width && m > 1 && !no_merge )
+        PutDesc *const dh0 = (PutDesc *)ctx->put_ring.host[ri], *const dd0 = (PutDesc *)ctx->put_ring.dev[ri];
+        const uint64_t t_before = host_now_ns();
+        if( kind0 != 2 )
+            batch_lock.lock();
+        const uint64_t t_locked = host_now_ns();
+        int rc_launch = X264HIP_OK;
+        for( int o = o0; o < o0 + n0 && !rc_launch; o += group )
         {
-            bool run = true;
-            for( int i = 1; i < m && run; i++ )
-                run = (const char *)luma_dev[o + i] == (const char *)luma_dev[o] + (size_t)i * ctx->staging_bytes;
-            // (one allocation: its first and last byte are pinned memory, so is everything between)
-            run = run && pointer_kind( (const char *)luma_dev[o] + (size_t)m * ctx->staging_bytes - 1 ) == 1;
-            if( run )
+            const int m = std::min( o0 + n0 - o, group );
+            PutDesc *dh = dh0 + ( o - o0 ), *dd = dd0 + ( o - o0 );
+            // a group whose pictures follow each other in pinned memory is ONE transfer into a device group buffer, read there by the ingest kernels
+            int gk = -1;
+            if( kind0 == 1 && stride == p.width && m > 1 && !no_merge )
             {
-                gk = ctx->h2d_group_next++ % x264hip_ctx::H2D_GROUPS;
-                if( !ctx->h2d_group[gk] && hipMalloc( &ctx->h2d_group[gk], (size_t)ctx->h2d_group_pics * ctx->staging_bytes ) != hipSuccess )
+                bool run = true;
+                for( int i = 1; i < m && run; i++ )
+                    run = (const char *)luma_dev[o + i] == (const char *)luma_dev[o] + (size_t)i * ctx->staging_bytes;
+                // (one allocation: its first and last byte are pinned memory, so is everything between)
+                run = run && pointer_kind( (const char *)luma_dev[o] + (size_t)m * ctx->staging_bytes - 1 ) == 1;
+                if( run )
                 {
-                    (void)hipGetLastError();
-                    gk = -1; // no memory for the group buffer: picture by picture
+                    gk = ctx->h2d_group_next++ % x264hip_ctx::H2D_GROUPS;
+                    if( !ctx->h2d_group[gk] && hipMalloc( &ctx->h2d_group[gk], (size_t)ctx->h2d_group_pics * ctx->staging_bytes ) != hipSuccess )
+                    {
+                        (void)hipGetLastError();
+                        gk = -1; // no memory for the group buffer: picture by picture
+                    }
+                }
+                if( gk >= 0 )
+                {
+                    if( ctx->h2d_group_used[gk] && hipEventQuery( ctx->h2d_group_free[gk] ) != hipSuccess )
+                    {
+                        (void)hipGetLastError(); // (not ready is reported as an error)
+                        batch_lock.unlock();     // the other contexts' transfers go ahead meanwhile
+                        HIPCK( hipEventSynchronize( ctx->h2d_group_free[gk] ) );
+                        batch_lock.lock();
+                    }
+                    HIPCK( hipMemcpyAsync( ctx->h2d_group[gk], luma_dev[o], (size_t)m * ctx->staging_bytes, hipMemcpyHostToDevice, ctx->stream_h2d ) );
+                    ctx->h2d_merged++;
+                    ctx->h2d_direct += m;
+                    ctx->h2d_bytes += (size_t)m * ctx->staging_bytes;
                 }
             }
-            if( gk >= 0 )
+            for( int i = 0; i < m; i++ )
             {
-                if( ctx->h2d_group_used[gk] )
-                    HIPCK( hipStreamWaitEvent( ctx->stream_h2d, ctx->h2d_group_free[gk], 0 ) );
-                HIPCK( hipMemcpyAsync( ctx->h2d_group[gk], luma_dev[o], (size_t)m * ctx->staging_bytes, hipMemcpyHostToDevice, ctx->stream_h2d ) );
-                ctx->h2d_merged++;
-                ctx->h2d_direct += m;
-                ctx->h2d_bytes += (size_t)m * ctx->staging_bytes;
-            }
-        }
-        for( int i = 0; i < m; i++ )
-        {
-            if( !slot_ok( ctx, slots[o + i] ) || !luma_dev[o + i] ) return X264HIP_EINVAL;
-            FrameSlot &s = ctx->slots[slots[o + i]];
-            slot_reset( ctx, s );
-            if( gk >= 0 )
-            {
-                dh[i] = make_put_desc( ctx, s, ctx->h2d_group[gk] + (size_t)i * ctx->staging_bytes, p.width, nullptr, nullptr, 0, aq_on );
-                continue;
+                if( !slot_ok( ctx, slots[o + i] ) || !luma_dev[o + i] ) return X264HIP_EINVAL;
+                FrameSlot &s = ctx->slots[slots[o + i]];
+                slot_reset( ctx, s );
+                if( gk >= 0 )
+                {
+                    dh[i] = make_put_desc( ctx, s, ctx->h2d_group[gk] + (size_t)i * ctx->staging_bytes, p.width, nullptr, nullptr, 0, aq_on );
+                    continue;
+                }
+                if( kind0 != 2 )
+                {
+                    if( !h2d_begun )
+                    {
+                        int rc = h2d_begin( ctx ); // (the slots of one call are distinct, a group's copies may overlap the previous group's kernels)
+                        if( rc ) return rc;
+                        h2d_begun = true;
+                    }
+                    int rc = h2d_picture( ctx, s, luma_dev[o + i], stride, pointer_kind( luma_dev[o + i] ) == 1 ? 1 : 0 );
+                    if( rc ) return rc;
+                    dh[i] = make_put_desc( ctx, s, s.luma, p.width, nullptr, nullptr, 0, aq_on );
+                    continue;
+                }
+                dh[i] = make_put_desc( ctx, s, luma_dev[o + i], stride, cb_dev ? cb_dev[o + i] : nullptr, cb_dev ? cr_dev[o + i] : nullptr, cstride, aq_on );
             }
             if( kind0 != 2 )
             {
-                int rc = h2d_picture( ctx, s, luma_dev[o + i], stride, pointer_kind( luma_dev[o + i] ) == 1 ? 1 : 0 );
+                int rc = h2d_end( ctx );
                 if( rc ) return rc;
-                dh[i] = make_put_desc( ctx, s, s.luma, p.width, nullptr, nullptr, 0, aq_on );
-                continue;
             }
-            dh[i] = make_put_desc( ctx, s, luma_dev[o + i], stride, cb_dev ? cb_dev[o + i] : nullptr, cb_dev ? cr_dev[o + i] : nullptr, cstride, aq_on );
+            HIPCK( upload_async( ctx, dd, dh, (size_t)m * sizeof( PutDesc ), ctx->stream ) );
+            PutDesc none;
+            memset( &none, 0, sizeof( none ) );
+            rc_launch = p.bit_depth == 8 ? launch_ingest_t<uint8_t>( ctx, dd, none, m ) : launch_ingest_t<uint16_t>( ctx, dd, none, m );
+            if( gk >= 0 )
+            {
+                HIPCK( hipEventRecord( ctx->h2d_group_free[gk], ctx->stream ) );
+                ctx->h2d_group_used[gk] = true;
+            }
         }
-        if( kind0 != 2 )
+        if( batch_lock.owns_lock() )
         {
-            int rc = h2d_end( ctx );
-            if( rc ) return rc;
-        }
-        HIPCK( upload_async( ctx, dd, dh, (size_t)m * sizeof( PutDesc ), ctx->stream ) );
-        PutDesc none;
-        memset( &none, 0, sizeof( none ) );
-        int rc = p.bit_depth == 8 ? launch_ingest_t<uint8_t>( ctx, dd, none, m ) : launch_ingest_t<uint16_t>( ctx, dd, none, m );
-        if( gk >= 0 )
-        {
-            HIPCK( hipEventRecord( ctx->h2d_group_free[gk], ctx->stream ) );
-            ctx->h2d_group_used[gk] = true;
+            batch_lock.unlock();
+            const uint64_t t_done = host_now_ns();
+            ctx->h2d_calls++;
+            ctx->h2d_t_prep += t_before - t_enter; ctx->h2d_t_wait += t_locked - t_before; ctx->h2d_t_hold += t_done - t_locked;
+            if( ctx->h2d_t_last ) ctx->h2d_t_between += t_enter - ctx->h2d_t_last;
+            ctx->h2d_t_last = t_done;
         }
         if( ring_commit( ctx->put_ring, ri, ctx->stream ) ) return X264HIP_EDEVICE;
-        if( rc ) return rc;
+        if( rc_launch ) return rc_launch;
     }
     return X264HIP_OK;
 }

@@ -161,6 +161,8 @@ class WindowShard:
 
     def _send(self, cmd):
         import torch
+        if getattr(self, "command_log", None) is not None:
+            self.command_log.append([int(v) for v in cmd])  # (tests: held word for word against the C shard's commands)
         if self.world > 1:
             t = torch.tensor(cmd, dtype=torch.int64)
             self._bcast_cmd(torch.tensor([t.numel()], dtype=torch.int64))
@@ -557,7 +559,7 @@ class HipAdapter:
 
 
 def run_window_shard(torch, lib, dist, rank, world, dev_index, cfg, dev_clip, exchange_on_device, qp_offsets=False, broadcast_input=False, vbv=False,
-                     loopback=False, profile=False):
+                     loopback=False, profile=False, command_log=None):
     """One pass of ONE stream over `world` ranks: returns (outputs on rank 0 | None, seconds, WindowShard.stats).
     dev_clip: [F, H, W] tensor of the whole clip resident on this rank's GPU (the same content on every rank), or, with
     broadcast_input, the clip on rank 0 and an uninitialised tensor of the same shape elsewhere: the pictures are then broadcast inside the
@@ -580,6 +582,7 @@ def run_window_shard(torch, lib, dist, rank, world, dev_index, cfg, dev_clip, ex
         # until this timeout -- ten minutes, like the RCCL group's in bench.py -- instead of for ever.)
         cmd_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=10))
     ws = WindowShard(adapter, dist, rank, world, device=dev if (exchange_on_device and cmd_group is None) else None, cmd_group=cmd_group, loopback=loopback)
+    ws.command_log = command_log
     # every rank opens the same context geometry; only rank 0 drives its lookahead
     # (one rank without loopback: nothing to spread -- the context's own speculative submission does the same work in fewer, larger launches
     # and evaluates every B cell both ways in one pass, x264hip_prefetch)
@@ -681,6 +684,7 @@ class HostStagedTransport:
         self._fns = (BCAST(self._broadcast), SENDRECV(self._send_recv), GATHER(self._gather), ALLRED(self._allreduce))
         self.struct = Transport(None, rank, world, 0, self._fns[0], self._fns[1], self._fns[2], self._fns[3], DESTROY())
         self.calls = dict(broadcast=0, send_recv=0, gather=0, allreduce=0)
+        self.command_log = None  # a list: every command block rank 0 broadcasts is decoded into it (shard_host.cpp send_cmd: word 0 = words used)
 
     def _down(self, ptr, n, stream):
         import torch
@@ -705,8 +709,12 @@ class HostStagedTransport:
 
     def _broadcast(self, user, buf, n, root, stream):
         def go():
+            import torch
             self.calls["broadcast"] += 1
             t = self._down(buf, n, stream)
+            if self.command_log is not None and self.rank == root and n == SHARD_CMD_WORDS * 8:
+                w = t.view(torch.int64)
+                self.command_log.append(w[1:1 + int(w[0])].tolist())
             self.dist.broadcast(t, src=root)
             if self.rank != root:
                 self._up(buf, t, n)
@@ -756,6 +764,7 @@ class HostStagedTransport:
         return self._guard(go)
 
 
+SHARD_CMD_WORDS = 8192  # shard_host.cpp CMD_WORDS: a command travels as one block of that many int64 words
 SHARD_STAT_NAMES = ("chunks", "fields_searched", "cells_evaluated", "l0_fields_exchanged", "cells_imported", "maps_fetched", "fetch_commands",
                     "bytes_input_broadcast", "bytes_l0_received", "bytes_summaries", "bytes_maps", "maps_fetched_spare")
 
