@@ -558,6 +558,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     P.n_slices = std::max( 1, p.lookahead_slices );
 
 #define OPENCK( call ) do { if( ( call ) != hipSuccess ) { fprintf( stderr, "x264hip_open: %s failed\n", #call ); free_all( ctx ); delete ctx; return X264HIP_ENOMEM; } } while( 0 )
+    // (the main stream at high priority and the chip-filling search launches detoured to a low-priority stream, so that other contexts'
+    //  small kernels get freed wave slots first: 28.8 k against 33.8 k frames/s with eight contexts, gpurun_out/r07f -- not kept)
     OPENCK( hipStreamCreateWithFlags( &ctx->stream, hipStreamNonBlocking ) );
     OPENCK( hipEventCreate( &ctx->ev_start ) );
     OPENCK( hipEventCreate( &ctx->ev_stop ) );
@@ -1107,6 +1109,14 @@ extern "C" int x264hip_frame_put_batch_yuv( x264hip_ctx *ctx, int n, const int *
             batch_lock.lock();
         const uint64_t t_locked = host_now_ns();
         int rc_launch = X264HIP_OK;
+        // Beside other contexts the ingest kernels of the call are launched ONCE, behind its last transfer: a launch per group is five small
+        // kernels in stream order, each of which waits its turn among the other contexts' search waves (fifty launches per 160 pictures:
+        // a pass of twelve host-fed contexts took 145 ms, the link needs 72, gpurun_out/r07d) -- what a launch per group buys, kernels under
+        // the context's own transfers, the other contexts' work provides anyway.  A context alone on its device keeps the launch per group.
+        static const char *ingest_env = getenv( "X264HIP_H2D_INGEST" ); // "group" / "call": A/B runs
+        const bool ingest_once = kind0 != 2 && ( ingest_env ? !strcmp( ingest_env, "call" ) : g_open_contexts[ctx->device & 63].load() > 1 );
+        int used_groups[x264hip_ctx::H2D_GROUPS], n_used_groups = 0;
+        int launched = o0; // pictures of this call whose ingest kernels have been launched
         for( int o = o0; o < o0 + n0 && !rc_launch; o += group )
         {
             const int m = std::min( o0 + n0 - o, group );
@@ -1169,16 +1179,35 @@ extern "C" int x264hip_frame_put_batch_yuv( x264hip_ctx *ctx, int n, const int *
                 }
                 dh[i] = make_put_desc( ctx, s, luma_dev[o + i], stride, cb_dev ? cb_dev[o + i] : nullptr, cb_dev ? cr_dev[o + i] : nullptr, cstride, aq_on );
             }
+            if( ingest_once )
+            {
+                if( gk >= 0 && n_used_groups < x264hip_ctx::H2D_GROUPS ) used_groups[n_used_groups++] = gk;
+                if( o + group < o0 + n0 && n_used_groups < x264hip_ctx::H2D_GROUPS - 1 )
+                    continue; // (the launch comes with the call's last group -- or before the ring of group buffers would come round)
+            }
             if( kind0 != 2 )
             {
                 int rc = h2d_end( ctx );
                 if( rc ) return rc;
             }
-            HIPCK( upload_async( ctx, dd, dh, (size_t)m * sizeof( PutDesc ), ctx->stream ) );
+            // (ingest_once: everything since the last launch -- the groups' descriptors follow each other in the table)
+            PutDesc *const lh = ingest_once ? dh0 + ( launched - o0 ) : dh, *const ld = ingest_once ? dd0 + ( launched - o0 ) : dd;
+            const int lm = ingest_once ? o + m - launched : m;
+            HIPCK( upload_async( ctx, ld, lh, (size_t)lm * sizeof( PutDesc ), ctx->stream ) );
             PutDesc none;
             memset( &none, 0, sizeof( none ) );
-            rc_launch = p.bit_depth == 8 ? launch_ingest_t<uint8_t>( ctx, dd, none, m ) : launch_ingest_t<uint16_t>( ctx, dd, none, m );
-            if( gk >= 0 )
+            rc_launch = p.bit_depth == 8 ? launch_ingest_t<uint8_t>( ctx, ld, none, lm ) : launch_ingest_t<uint16_t>( ctx, ld, none, lm );
+            launched = o + m;
+            if( ingest_once )
+            {
+                for( int k = 0; k < n_used_groups; k++ )
+                {
+                    HIPCK( hipEventRecord( ctx->h2d_group_free[used_groups[k]], ctx->stream ) );
+                    ctx->h2d_group_used[used_groups[k]] = true;
+                }
+                n_used_groups = 0;
+            }
+            else if( gk >= 0 )
             {
                 HIPCK( hipEventRecord( ctx->h2d_group_free[gk], ctx->stream ) );
                 ctx->h2d_group_used[gk] = true;

@@ -496,6 +496,20 @@ class LaFrameOut(C.Structure):
                 ("intra_mbs", C.c_int * (BFRAME_MAX + 2))]
 
 
+class FrameOutList(list):
+    """the outputs of one x264hip_lookahead_run_frames call: a list of LaFrameOut views, and the block they live in as ONE numpy record
+    array (.records) -- a caller with eight threads summarising 160 frames each must not spend its time in per-frame Python"""
+
+    def __init__(self, array, count):
+        super().__init__(array[i] for i in range(count))
+        self.array = array
+        n = BFRAME_MAX + 2
+        dt = np.dtype([("frame", np.int32), ("type", np.int32), ("bframes", np.int32), ("keyframe", np.int32), ("cost_est", np.int32, (n, n)),
+                       ("cost_est_aq", np.int32, (n, n)), ("intra_mbs", np.int32, (n,))])
+        assert dt.itemsize == C.sizeof(LaFrameOut)
+        self.records = np.frombuffer(array, dtype=dt, count=count) if count else np.zeros(0, dt)
+
+
 # x264 presets relevant to the lookahead (common/base.c:489-609) and defaults (base.c:344-485)
 PRESETS = {
     "medium": dict(),
@@ -889,7 +903,7 @@ class Lookahead:
         outs = (LaFrameOut * n)()
         got = C.c_int(0)
         _ck(self.L.x264hip_lookahead_run_frames(self.h, n, arr, stride or self.cfg["width"], int(paced), outs, C.byref(got)), "lookahead_run_frames")
-        return [outs[i] for i in range(got.value)]
+        return FrameOutList(outs, got.value)
 
     def run(self, frames=None, device_ptrs=None, stride=None, paced=True, qp_offsets=False, forced_types=None, vbv=False, pts=None, chroma=None, quant_offsets=None):
         """Feed a whole clip.  paced=True interleaves put/get exactly like x264_encoder_encode; paced=False puts

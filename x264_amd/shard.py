@@ -31,6 +31,13 @@ def _bcell_max(ce):
 def summarize(outs, frame_offset=0):
     """[n,4] int32 rows (display frame number, slice type, cost of the chosen cell, bframes) from lookahead outputs."""
     rows = np.zeros((len(outs), 4), np.int32)
+    rec = getattr(outs, "records", None)
+    if rec is not None and len(rec) == len(outs):
+        # the outputs of one run_frames call as a record array: the same rows without a Python loop over the frames
+        ce, ty = rec["cost_est"], rec["type"]
+        cost = np.where(ty < 3, ce[:, 0, 0], np.where(ty == 3, np.maximum(ce[:, 1:, 0].max(axis=1), 0), np.maximum(ce[:, _BMASK].max(axis=1), 0)))
+        rows[:, 0] = rec["frame"] + frame_offset; rows[:, 1] = ty; rows[:, 2] = cost; rows[:, 3] = rec["bframes"]
+        return rows
     for k, o in enumerate(outs):
         ce = np.frombuffer(o.cost_est, dtype=np.int32).reshape(18, 18)  # the ctypes array, viewed in place
         if o.type < 3:
