@@ -581,15 +581,22 @@ def main():
     solo_lat = None
     kernel_times = None
     if not args.no_check:
-        lib.search_profile(las[0].L, las[0].ctx_handle(), 3)  # | 2: an event pair around every ingest and cell kernel as well
-        las[0].reset()
-        las[0].run(device_ptrs=wl.seg_ptrs[0], stride=W, paced=args.paced)
-        kernel_times = lib.kernel_profile(las[0].L, las[0].ctx_handle())
-        cms_, cnl_, ncell_ = lib.cell_profile(las[0].L, las[0].ctx_handle())
-        solo_lat = lib.search_profile_latency(las[0].L, las[0].ctx_handle())
-        ms_, nl_, ns_ = lib.search_profile(las[0].L, las[0].ctx_handle(), 0)
-        if ms_ > 0 and ns_:
-            solo = (ms_, nl_, ns_)
+        # three such passes, every kernel's least time: now and then something stretches a pass's kernel several-fold (a search launch of
+        # 13.8 ms beside 3.0-3.1 in the other passes of the same run, gpurun_out/r07h), and one pass alone would report that
+        for _ in range(3):
+            torch.cuda.synchronize()
+            lib.search_profile(las[0].L, las[0].ctx_handle(), 3)  # | 2: an event pair around every ingest and cell kernel as well
+            las[0].reset()
+            las[0].run(device_ptrs=wl.seg_ptrs[0], stride=W, paced=args.paced)
+            kt_ = lib.kernel_profile(las[0].L, las[0].ctx_handle())
+            cms_, cnl_, ncell_ = lib.cell_profile(las[0].L, las[0].ctx_handle())
+            sl_ = lib.search_profile_latency(las[0].L, las[0].ctx_handle())
+            ms_, nl_, ns_ = lib.search_profile(las[0].L, las[0].ctx_handle(), 0)
+            kernel_times = kt_ if kernel_times is None else [a if (a[0] <= b[0] or not b[1]) and a[1] else b for a, b in zip(kernel_times, kt_)]
+            if solo_lat is None or (sl_[1] and sl_[0] < solo_lat[0]):
+                solo_lat = sl_
+            if ms_ > 0 and ns_ and (solo is None or ms_ < solo[0]):
+                solo = (ms_, nl_, ns_)
     other_paced = not args.paced
     other_fps = None
     if not args.no_check:
@@ -651,7 +658,7 @@ def main():
                 {"bound": "hbm", "kernel": "me_rows_kernel", "peak": HBM_PEAK_GBS, "unit": "GB/s"},
                 **({"achieved": round(solo[2] * bytes_per_search / 1e9 / (solo[0] / 1e3), 2),
                     "frac": round(solo[2] * bytes_per_search / 1e9 / (solo[0] / 1e3) / HBM_PEAK_GBS, 5),
-                    "what": "one untimed pass of one segment alone on the GPU (no concurrent launches), HIP events on the library's stream",
+                    "what": "one untimed pass of one segment alone on the GPU (no concurrent launches; the fastest of three such passes), HIP events on the library's stream",
                     "launches": solo[1], "searches": solo[2], "avg_launch_ms": round(solo[0] / solo[1], 4), "us_per_search": round(solo[0] * 1e3 / solo[2], 3),
                     "traffic": None if traffic is None else round(traffic * (solo[2] / max(solo[1], 1)) / max(prof_searches / max(prof_launches, 1), 1))}
                    if solo is not None else
@@ -764,15 +771,20 @@ def main():
             # cross PCIe inside the timed region (W x H samples each), on the contexts' DMA streams; `value` above is NOT this figure.
             try:
                 frame_bytes = W * H * (1 if args.bit_depth == 8 else 2)
-                hp = torch.empty(256 << 20, dtype=torch.uint8).pin_memory()
+                # the link's own rate: a plain pinned-to-device copy loop, best of three buffers (where a pinned buffer lands among the host's
+                # memory nodes moves the figure by a third: 38.8 against 53.8 GB/s on two boxes of the same kind)
+                pcie_peak = 0.0
                 dp = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
-                dp.copy_(hp, non_blocking=True); torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(8):
-                    dp.copy_(hp, non_blocking=True)
-                torch.cuda.synchronize()
-                pcie_peak = 8 * hp.numel() / (time.perf_counter() - t0) / 1e9
-                del hp, dp
+                for _ in range(3):
+                    hp = torch.empty(256 << 20, dtype=torch.uint8).pin_memory()
+                    dp.copy_(hp, non_blocking=True); torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(8):
+                        dp.copy_(hp, non_blocking=True)
+                    torch.cuda.synchronize()
+                    pcie_peak = max(pcie_peak, 8 * hp.numel() / (time.perf_counter() - t0) / 1e9)
+                    del hp
+                del dp
                 host_clips = [dv.cpu().pin_memory() for dv in seg_dev]
                 def host_fed_run(Sh, steps_h):
                     """Sh of the segments in flight at a time, every picture from pinned host memory; checked against the device-resident passes"""
@@ -813,11 +825,12 @@ def main():
                         one[key_h] = round(F * 2 / dt1, 2)
                     finally:
                         w1.close()
+                pcie_peak = max(pcie_peak, fps_h * frame_bytes / 1e9)  # (the pictures' own rate is a lower bound of what the link can do)
                 bound = min(res["value"], pcie_peak * 1e9 / frame_bytes)
                 res["host_fed"] = {"what": "the headline's segments with every picture in pinned HOST memory: %d x %d frames per step through x264hip_lookahead_put_frames "
                                            "(host pointers), H2D on the contexts' DMA streams inside the timed region" % (S, F),
                                    "fps": round(fps_h, 2), "segments_in_flight": in_flight_h, "fps_by_segments_in_flight": by_inflight, "pcie_GBps": round(fps_h * frame_bytes / 1e9, 2), "pcie_peak_GBps": round(pcie_peak, 2),
-                                   "pcie_peak_what": "a plain pinned-to-device copy loop (8 x 256 MiB) on this box",
+                                   "pcie_peak_what": "a plain pinned-to-device copy loop (8 x 256 MiB, best of three buffers) on this box, or the pictures' own rate if that is higher",
                                    "pcie_bound_fps": round(pcie_peak * 1e9 / frame_bytes, 1), "share_of_min_value_pcie_bound": round(fps_h / bound, 3),
                                    "pictures_direct_from_pinned": int(hstat[1]), "pictures_staged": int(hstat[2]), "transfers_of_a_whole_group": int(hstat2[0]),
                                    "single_stream_paced_fps": one, "checked": "types + every cost cell == the device-resident passes"}
