@@ -128,8 +128,10 @@ int  x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, int stride
                         const void *cb, const void *cr, int cstride, const uint16_t *inv_qscale );
 /* The same for n frames (all with the same stride): one launch per ingest kernel instead of one per frame.  The pointers are device
  * pointers or -- all of them, luma only -- HOST pointers, which is what x264_encoder_encode is handed (encoder/encoder.c:3368-3454,
- * common/frame.c:445-447): the pictures then travel on a DMA stream of the context's own, sixteen to a group, and each group's ingest
- * kernels run behind its copies while the next group is on its way; nothing waits for the compute stream.  Buffers the DMA engines can
+ * common/frame.c:445-447): the pictures then travel on the device's transfer queue (one per device, shared by its contexts: a call's
+ * transfers follow each other at the link's full rate), sixteen to a group; a context alone on its device runs each group's ingest
+ * kernels behind its copies while the next group is on its way, beside other contexts they are launched once behind the call's last
+ * transfer; nothing waits for the compute stream, and nothing for the device under the queue's lock.  Buffers the DMA engines can
  * read where they are (hipHostMalloc / hipHostRegister: the caller's choice) are copied from there, pageable ones through a ring of
  * pinned staging copies (a memcpy per picture).  x264hip_frame_put with is_device == 0 takes the same road for one picture.
  * x264hip_host_transfer_stats: bytes copied so far, pictures taken as they were / through the ring. */

@@ -832,7 +832,10 @@ static int launch_ingest_t( x264hip_ctx *ctx, const PutDesc *descs_dev, const Pu
                                                                        p.aq_mode, 1.f / ( 1 << ( 2 * ( p.bit_depth - 8 ) ) ), p.chroma_format ) ) );
     if( p.aq_mode >= 2 && p.aq_strength != 0.f )
         aq_auto_kernel<<<n, 1024, 0, ctx->stream>>>( descs_dev, single, ctx->n_mb, p.aq_mode, p.aq_strength, ctx->luts_dev );
-    aq_reduce_kernel<<<n, 1024, 0, ctx->stream>>>( descs_dev, single, ctx->n_mb );
+    // (256 threads: beside other contexts' search waves a 1 024-thread workgroup waits for sixteen free wave slots on ONE compute unit --
+    //  3.5 ms on average for an 8 us kernel with eight contexts in flight, profiles/r05_bench_kernel_stats.csv -- and every frame's
+    //  ingest stands behind it)
+    aq_reduce_kernel<<<n, 256, 0, ctx->stream>>>( descs_dev, single, ctx->n_mb );
     const int intra_wgs = ( ( ctx->n_mb + INTRA_BLOCKS_PER_WG - 1 ) / INTRA_BLOCKS_PER_WG + 7 ) / 8 * 8;
     if( P.subme > 1 )
         KPROF( X264HIP_KPROF_INTRA, n, ( intra_kernel<T, 10><<<dim3( intra_wgs, 1, n ), 64, 0, ctx->stream>>>( P, descs_dev, single ) ) );
@@ -1473,7 +1476,10 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
                 Q.base[q] = (int)( (long long)count * q / ME_QUEUES ); // the ticket queues hand out searches; contiguous groups: the table is in frame order
             unsigned *tickets = ctx->sync_words + part * ME_QUEUES * ME_QUEUE_STRIDE;
             const int grid_rows = count * n_rowgroups, grid_lat = count * ( ( P.mb_h + ME_LAT_ROWS - 1 ) / ME_LAT_ROWS );
-#define ME_ARGS_ROWS P, dd + first, Q, tickets, ctx->err_host, 1u << 22, ctx->me_prof
+            // (spin limit: ~8 s of polling for a vector of the row below before a wave gives up and the context is marked broken; 2 s
+            //  were once not enough beside fifteen other contexts, gpurun_out/r07i -- nothing a wave waits for is that far away unless the
+            //  device itself stands still)
+#define ME_ARGS_ROWS P, dd + first, Q, tickets, ctx->err_host, 1u << 24, ctx->me_prof
 #define ME_LAUNCH( HEXV, MODEV ) do { \
                 if( rows[part] ) { \
                     if( part ) me_rows_kernel<T, HEXV, MODEV, 1><<<grid_rows, 64, 0, ctx->stream>>>( ME_ARGS_ROWS ); \
