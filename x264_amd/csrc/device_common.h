@@ -40,6 +40,25 @@ struct WtD
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// An in-kernel wait gave up: what it was waiting for, into the context's pinned error block (16 words: [0] which wait -- 2 a step of
+// me_rows_kernel, 3 / 4 the start / a step of me_latency_kernel --, then search, row (group), step or column, the tag waited for, the tag
+// last seen, the vector word last seen); word 0 goes last, the host looks at it first
+__device__ __forceinline__ void report_wait_timeout( unsigned *err_host, unsigned code, unsigned search, unsigned row, unsigned where, unsigned tag, unsigned long long seen )
+{
+    // (the FIRST wave to give up reports: the waves above it in the chain give up moments later, for its sake)
+    if( atomicAdd_system( err_host + 8, 1u ) != 0u )
+    {
+        __hip_atomic_store( err_host + 9, ( row << 16 ) | ( search & 0xFFFF ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM ); // the last one to give up
+        return;
+    }
+    __hip_atomic_store( err_host + 1, search, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+    __hip_atomic_store( err_host + 2, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+    __hip_atomic_store( err_host + 3, where, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+    __hip_atomic_store( err_host + 4, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+    __hip_atomic_store( err_host + 5, (unsigned)( seen >> 32 ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+    __hip_atomic_store( err_host + 6, (unsigned)seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+    __hip_atomic_store( err_host, code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM );
+}
 
 // ---- DPP helpers ---------------------------------------------------------------------------------
 template <int CTRL>

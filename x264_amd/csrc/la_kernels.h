@@ -693,7 +693,7 @@ __global__ __launch_bounds__( 256 ) void weight_strips_multi_kernel( const D *__
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if( i >= n )
         return;
-    const D &d = descs[blockIdx.y];
+    const D d = load_uniform( descs + blockIdx.y );
     const T *src = d.ref_strips - 4 * (size_t)n; // plane 0, row-major: four planes of n samples, then their strip copies
     T *strips = const_cast<T *>( d.refw_strips );
     const int Y = i / stride, c = i - Y * stride, k = c >> 3, rows = n / stride;
@@ -2051,7 +2051,7 @@ __global__ __launch_bounds__( 1024 ) void mbtree_lds_kernel( LaP P, const MbtOpD
     const int k_end = G.beg[blockIdx.x + 1];
     for( int k = G.beg[blockIdx.x]; k < k_end; k++ )
     {
-        const MbtOpDev o = ops[k];
+        const MbtOpDev o = load_uniform( ops + k );
         int *A_b = mbt_acc + o.lds_b * n_mb, *A_p0 = mbt_acc + o.lds_p0 * n_mb, *A_p1 = mbt_acc + o.lds_p1 * n_mb;
         if( o.type == MBT_NOP )
             continue; // (uniform: nothing was written, no barrier needed)

@@ -484,7 +484,7 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_latency_kernel( La
     if( timed_out )
     {
         if( lane == 0 )
-            __hip_atomic_store( err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+            report_wait_timeout( err_host, 3u, (unsigned)si, (unsigned)by, (unsigned)W, tag, 0ull );
         me_dma_drain();
         leave();
         return;
@@ -684,7 +684,7 @@ __global__ __launch_bounds__( 64 * RW, ME_MIN_WAVES ) void me_latency_kernel( La
 #endif
     }
     if( timed_out && lane == 0 )
-        __hip_atomic_store( err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+        report_wait_timeout( err_host, 4u, (unsigned)si, (unsigned)by, (unsigned)W, tag, 0ull );
     if( !timed_out )
     {
         if( leader )

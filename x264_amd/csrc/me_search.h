@@ -694,7 +694,20 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
                     if( ++spins > spin_limit )
                     {
                         if( lane == 0 )
-                            __hip_atomic_store( err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+                        {
+                            // what other kinds of access see at the same address, the unit this wave runs on, its queue's ticket counter
+                            unsigned long long expect = ~0ull;
+                            (void)__hip_atomic_compare_exchange_strong( const_cast<unsigned long long *>( gp ), &expect, ~0ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+                            const unsigned long long sys = __hip_atomic_load( gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+                            int qq = 0;
+                            for( int k = 0; k < ME_QUEUES; k++ )
+                                if( s >= Q.base[k] && s < Q.base[k + 1] ) qq = k;
+                            err_host[10] = (unsigned)xcc_id() | ( (unsigned)qq << 8 ) | ( (unsigned)home << 16 );
+                            err_host[11] = (unsigned)( expect >> 32 ); err_host[12] = (unsigned)expect;
+                            err_host[13] = (unsigned)( sys >> 32 ); err_host[14] = (unsigned)sys;
+                            err_host[15] = __hip_atomic_load( &tickets[qq * ME_QUEUE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+                            report_wait_timeout( err_host, 2u, (unsigned)s, (unsigned)j, ( (unsigned)t << 16 ) | (unsigned)bx0, tag, gq );
+                        }
                         leave();
                         return;
                     }

@@ -610,8 +610,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     OPENCK( hipHostMalloc( &ctx->cell_alt2_host, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) ) );
     memset( ctx->cell_alt2_host, 0, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) );
     memset( ctx->cell_acc_host, 0, (size_t)p.max_frames * ctx->n_cells * 8 * sizeof( int ) );
-    OPENCK( hipHostMalloc( &ctx->err_host, sizeof( unsigned ) ) );
-    *ctx->err_host = 0;
+    OPENCK( hipHostMalloc( &ctx->err_host, 16 * sizeof( unsigned ) ) ); // (report_wait_timeout, device_common.h)
+    memset( ctx->err_host, 0, 16 * sizeof( unsigned ) );
     OPENCK( hipHostMalloc( &ctx->stats_host, (size_t)p.max_frames * 2 * sizeof( unsigned long long ) ) );
     // (MB-tree launches on the main stream instead, no cross-stream waits at all: 20 700 frames/s against 21 400, eight contexts)
     OPENCK( hipStreamCreateWithFlags( &ctx->stream2, hipStreamNonBlocking ) );
@@ -707,6 +707,12 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
         memset( s.field_prefetched, 0, sizeof( s.field_prefetched ) );
         memset( s.field_remote, 0, sizeof( s.field_remote ) );
     }
+    // hipMemset of device memory returns before the fill has run (it is ordered on the NULL stream, which the context's own streams --
+    // hipStreamNonBlocking -- do not wait for): without this wait the fill of a slot could land AFTER the slot's first search had begun to
+    // publish its vectors there, and the waves that wait for those vectors waited until the spin limit.  Seen as an "in-kernel wait timed
+    // out" once in some five runs of the bench, always within the first launches of freshly opened contexts, a granule of the row below
+    // reading zero by every kind of access (gpurun_out/r07r-r07t; rounds 1-6 were lucky, or slower to start).
+    OPENCK( hipStreamSynchronize( nullptr ) );
 #undef OPENCK
     g_open_contexts[ctx->device & 63]++; ctx->counted_open = true;
     *out = ctx;
@@ -1322,6 +1328,16 @@ struct SearchReq
     int to_spare = 0;      // a speculative weighted search: into the slot's second list-0 field of that distance, its tag into wspec
 };
 
+static void report_timeout( x264hip_ctx *ctx )
+{
+    if( ctx->broken ) return; // (said once)
+    const volatile unsigned *e = ctx->err_host;
+    fprintf( stderr, "x264hip: in-kernel wait timed out: wait %u, search %u of the launch, row (group) %u, step/column 0x%x, waited for tag %u, last saw tag %u vector 0x%08x; "
+                     "%u waves gave up, the last one row (group) %u of search %u; contexts open on the device: %d\n", e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[8], e[9] >> 16, e[9] & 0xFFFF,
+             g_open_contexts[ctx->device & 63].load() );
+    fprintf( stderr, "x264hip:   (last writer's view) xcc %u, queue %u, home %u; the same granule by compare-exchange: tag %u vector 0x%08x, by a system-scope load: tag %u vector 0x%08x; "
+                     "queue's ticket counter %u\n", e[10] & 255, ( e[10] >> 8 ) & 255, e[10] >> 16, e[11], e[12], e[13], e[14], e[15] );
+}
 // wait for the stream, latch in-kernel timeouts (the flag lives in pinned host memory); every completed batch is now readable
 static int sync_stream( x264hip_ctx *ctx )
 {
@@ -1329,6 +1345,7 @@ static int sync_stream( x264hip_ctx *ctx )
     ctx->batch_synced = ctx->batch_serial;
     if( *(volatile unsigned *)ctx->err_host )
     {
+        report_timeout( ctx );
         ctx->broken = 1;
         return X264HIP_ETIMEOUT;
     }
@@ -1351,6 +1368,7 @@ static int batch_wait( x264hip_ctx *ctx, unsigned b )
     if( b > ctx->batch_synced ) ctx->batch_synced = b;
     if( *(volatile unsigned *)ctx->err_host )
     {
+        report_timeout( ctx );
         ctx->broken = 1;
         return X264HIP_ETIMEOUT;
     }
@@ -3795,7 +3813,7 @@ extern "C" int x264hip_ads_batch( x264hip_ctx *ctx, int n, const x264hip_ads_cal
     HIPCK( hipMemcpy( st.at( i_calls ), calls, (size_t)n * sizeof( VtAdsCall ), hipMemcpyHostToDevice ) );
     HIPCK( hipMemcpy( st.at( i_sums ), sums, n_sums * 2, hipMemcpyHostToDevice ) );
     HIPCK( hipMemcpy( st.at( i_cost ), cost_mvx, n_cost * 2, hipMemcpyHostToDevice ) );
-    HIPCK( hipMemset( st.at( i_mvs ), 0, n_mvs * 2 ) );
+    HIPCK( hipMemsetAsync( st.at( i_mvs ), 0, n_mvs * 2, ctx->stream ) ); // (on the kernel's stream: hipMemset does not wait for itself)
     vt_ads_kernel<<<n, 64, 0, ctx->stream>>>( n, (const VtAdsCall *)st.at( i_calls ), (const uint16_t *)st.at( i_sums ), (const uint16_t *)st.at( i_cost ),
                                              (int16_t *)st.at( i_mvs ), (int *)st.at( i_cnt ) );
     HIPCK( hipGetLastError() );
@@ -4408,7 +4426,7 @@ extern "C" int x264hip_spec_cells( x264hip_ctx *ctx, int n, const x264hip_cell_r
 
 __global__ __launch_bounds__( 64 ) void export_cells_kernel( const CellXfer *__restrict__ x, int mb_h, int *__restrict__ dst )
 {
-    const CellXfer X = x[blockIdx.x];
+    const CellXfer X = load_uniform( x + blockIdx.x );
     int *d = dst + (size_t)blockIdx.x * X264HIP_CELL_SUMMARY_INTS( mb_h );
     if( threadIdx.x < 8 ) d[threadIdx.x] = threadIdx.x < 5 ? X.acc_dev[threadIdx.x] : 0;
     for( int i = threadIdx.x; i < mb_h; i += 64 )
@@ -4419,7 +4437,7 @@ __global__ __launch_bounds__( 64 ) void export_cells_kernel( const CellXfer *__r
 }
 __global__ __launch_bounds__( 64 ) void import_cells_kernel( const CellXfer *__restrict__ x, int mb_h, const int *__restrict__ src )
 {
-    const CellXfer X = x[blockIdx.x];
+    const CellXfer X = load_uniform( x + blockIdx.x );
     if( X.skip ) return;
     const int *s = src + (size_t)blockIdx.x * X264HIP_CELL_SUMMARY_INTS( mb_h );
     if( threadIdx.x < 5 )
