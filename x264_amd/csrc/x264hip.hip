@@ -712,7 +712,8 @@ extern "C" int x264hip_open( x264hip_ctx **out, int device, const x264hip_params
     // publish its vectors there, and the waves that wait for those vectors waited until the spin limit.  Seen as an "in-kernel wait timed
     // out" once in some five runs of the bench, always within the first launches of freshly opened contexts, a granule of the row below
     // reading zero by every kind of access (gpurun_out/r07r-r07t; rounds 1-6 were lucky, or slower to start).
-    OPENCK( hipStreamSynchronize( nullptr ) );
+    if( !getenv( "X264HIP_NO_OPEN_SYNC" ) ) // (the switch: to see tests/test_gpu_fresh_contexts.py fail without the wait)
+        OPENCK( hipStreamSynchronize( nullptr ) );
 #undef OPENCK
     g_open_contexts[ctx->device & 63]++; ctx->counted_open = true;
     *out = ctx;
