@@ -535,6 +535,11 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
     const bool row_ok = by >= 0;
 
     __shared__ uint16_t tab_window[2 * ME_TAB_HALF];
+#ifdef ME_LDS_PAD
+    // (A/B builds: LDS nobody reads, to hold the number of resident waves per SIMD below what the registers allow)
+    __shared__ unsigned me_lds_pad[ME_LDS_PAD / 4];
+    if( spin_limit == 0xFFFFFFFFu ) me_lds_pad[lane] = 0;
+#endif
     {
         const int centre = 2 * 4 * P.mv_range; // P.cost_mv is centred: valid differences are -centre .. +centre
         for( int i = lane; i < 2 * ME_TAB_HALF; i += 64 )
