@@ -104,7 +104,9 @@ typedef struct x264hip_mbtree_op
 
 /* ---- context ---------------------------------------------------------------------------------
  * Replaces x264_opencl_lookahead_init / _delete (encoder/encoder.c:1744-1753, 4208-4209,
- * common/opencl.c:411) as the device bring-up of the coarse lookahead hook. */
+ * common/opencl.c:411) as the device bring-up of the coarse lookahead hook.
+ * The context works on non-blocking streams of its own; x264hip_open returns when its buffers are initialised (it waits for the
+ * device's NULL stream, where those fills are ordered -- and with them for whatever the caller has queued there). */
 int  x264hip_open( x264hip_ctx **out, int device, const x264hip_params *params );
 void x264hip_close( x264hip_ctx *ctx );
 const char *x264hip_strerror( int code );
