@@ -125,6 +125,8 @@ int  x264hip_flush( x264hip_ctx *ctx );
  * (encoder/slicetype-cl.c:129-282).  slot is the caller's frame handle in [0, max_frames).
  * luma may be a host or a device pointer (is_device).  cb/cr are optional 4:2:0 planes used only by
  * AQ; inv_qscale (mb_w*mb_h, Q8) overrides the AQ result when not NULL.
+ * A device picture is read on the context's own (non-blocking) stream, which waits for no stream of the caller's: the picture must be
+ * complete when the call is made, and stay untouched until the frame's ingest has run (x264hip_synchronize, or any result of the frame).
  * Resets the slot's search/cost state like mc.c:471-481. */
 int  x264hip_frame_put( x264hip_ctx *ctx, int slot, const void *luma, int stride, int is_device,
                         const void *cb, const void *cr, int cstride, const uint16_t *inv_qscale );
