@@ -1066,16 +1066,30 @@ __global__ __launch_bounds__( 64 ) void cell_b_kernel( LaP P, const CellArgs *de
     };
     int od[4], om[4];
     taps( qd0, qd1, od ); taps( qm0, qm1, om );
-    const Px8 d0a = load_px8_at( s0base, od[0] ), d0b = load_px8_at( s0base, od[1] ), d1a = load_px8_at( s1base, od[2] ), d1b = load_px8_at( s1base, od[3] );
-    const Px8 m0a = load_px8_at( s0base, om[0] ), m0b = load_px8_at( s0base, om[1] ), m1a = load_px8_at( s1base, om[2] ), m1b = load_px8_at( s1base, om[3] );
+    // Where none of the wave's eight blocks has a direct-style vector the candidate IS the zero candidate (both taps of a zero vector are
+    // the block itself in plane 0, and the rounded average of a run with itself is the run); where none has a searched vector the third
+    // candidate is never looked at (mv_nz below).  Wave-uniform tests: still picture areas cost a third of a moving one's B cell.
+    const bool any_d = __builtin_amdgcn_ballot_w64( ( qd0 | qd1 ) != 0 ) != 0ull, any_m = __builtin_amdgcn_ballot_w64( ( qm0 | qm1 ) != 0 ) != 0ull;
+    Px8 d0a = z0, d0b = z0, d1a = z1, d1b = z1, m0a = z0, m0b = z0, m1a = z1, m1b = z1;
+    if( any_d )
+    {
+        d0a = load_px8_at( s0base, od[0] ); d0b = load_px8_at( s0base, od[1] ); d1a = load_px8_at( s1base, od[2] ); d1b = load_px8_at( s1base, od[3] );
+    }
+    if( any_m )
+    {
+        m0a = load_px8_at( s0base, om[0] ); m0b = load_px8_at( s0base, om[1] ); m1a = load_px8_at( s1base, om[2] ); m1b = load_px8_at( s1base, om[3] );
+    }
     auto avg8 = [&]( const Px8 &a, const Px8 &b ) -> Px8 {
         Px8 r;
         r.lo = avg_px4( a.lo, b.lo, (const T *)nullptr ); r.hi = avg_px4( a.hi, b.hi, (const T *)nullptr );
         return r;
     };
     const int v_zero = block_cost8<T>( f, mix( z0, z1 ), P.mbcmp_satd );
-    const int v_dmv = block_cost8<T>( f, mix( avg8( d0a, d0b ), avg8( d1a, d1b ) ), P.mbcmp_satd );
-    const int v_mv = block_cost8<T>( f, mix( avg8( m0a, m0b ), avg8( m1a, m1b ) ), P.mbcmp_satd );
+    int v_dmv = v_zero, v_mv = v_zero;
+    if( any_d )
+        v_dmv = block_cost8<T>( f, mix( avg8( d0a, d0b ), avg8( d1a, d1b ) ), P.mbcmp_satd );
+    if( any_m )
+        v_mv = block_cost8<T>( f, mix( avg8( m0a, m0b ), avg8( m1a, m1b ) ), P.mbcmp_satd );
     // lane k collects the costs of block k (any lane of group k holds them) and chooses
     const int back = ( imin2( lane, 7 ) << 3 ) << 2; // ds_bpermute address of lane 8 k
     const int c_dmv = __builtin_amdgcn_ds_bpermute( back, v_dmv ), c_zero = __builtin_amdgcn_ds_bpermute( back, v_zero ), c_mv = __builtin_amdgcn_ds_bpermute( back, v_mv );
