@@ -579,7 +579,9 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
     const bool below_is_remote = (bool)__builtin_amdgcn_readfirstlane( (int)has_below );
     const int zero_bits = P.cost_mv[0];
 
+#ifndef ME_REMAT
     const LaneSlots LS = make_lane_slots( lane );
+#endif
     int r1 = 0, r2 = 0, r3 = 0; // packed vectors this group found in the last three steps
     int keep_mv = 0, keep_cost = 0; // lanes 0..3 of a group: the result of the block with x % 4 == lane, until the four leave together
     const int n_steps = W + 2 * ( ME_ROWS - 1 );
@@ -649,6 +651,15 @@ __global__ __launch_bounds__( 64, ME_MIN_WAVES ) void me_rows_kernel( LaP P, con
 #endif
     for( int t = 0; t < n_steps; t++ )
     {
+#ifdef ME_REMAT
+        // (A/B builds: the lane-derived constants of a step rebuilt here, behind an opaque copy of the lane id, instead of living in registers
+        //  across the loop: 96 registers and no spill under ME_MIN_WAVES=5 -- and five waves per SIMD no faster than four: 3.25 against
+        //  3.18-3.27 us per search, profiles/r06_search_order_latency.txt)
+        int lane_r = lane;
+        asm volatile( "" : "+v"( lane_r ) );
+        const LaneSlots LS = make_lane_slots( lane_r );
+        const int g = lane_r >> 3;
+#endif
         const int bx = W - 1 - ( t - 2 * g );
         const bool active = row_ok && bx >= 0 && bx < W;
 #ifdef ME_PROFILE
