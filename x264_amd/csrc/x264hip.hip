@@ -153,6 +153,7 @@ struct x264hip_ctx
     DescRing cell_ring, put_ring, search_ring, xfer_ring;
     int xfer_cap = 2048;
     unsigned *err_host = nullptr;    // pinned: sticky in-kernel timeout flag, written by the device directly
+    int launches_since_big = 1000;   // search launches since the last one that could fill the chip (launch_searches_t: which form a small one takes)
     int put_desc_cap = 256;
     int cell_desc_cap = 0;
     unsigned batch_serial = 0, batch_synced = 0;
@@ -1414,7 +1415,17 @@ static int launch_searches_t( x264hip_ctx *ctx, const std::vector<SearchReq> &re
     // is theirs to fill, and the latency form's three-fold instruction count per block comes out of everybody's throughput (eight
     // contexts, the 45 weighted searches of a fade per pass: 27.1 k against 26.0 k frames/s, profiles/r06_fade.txt)
     static const bool lat_always = getenv( "X264HIP_LAT_ALWAYS" ) != nullptr;
-    const bool crowded = !lat_always && g_open_contexts[ctx->device & 63].load() >= 4;
+    // ... and only where the device is kept full: a context that has just sent a chip-filling launch is one of several working through
+    // whole segments (the weighted searches of its fade follow within a launch or two).  A context whose launches are ALL small is an
+    // encoder-paced stream -- a frame's searches per launch, its caller waiting for them -- and beside other such streams the device
+    // is not full: there the latency form's shorter chain is what counts (eight paced streams 7.6 k -> 8.0 k frames/s, four 5.8 k -> 6.5 k,
+    // gpurun_out/r08k).
+    {
+        const int n_rg = ( P.mb_h + ME_ROWS - 1 ) / ME_ROWS;
+        if( (long long)std::max( n_plain, n - n_plain ) * n_rg >= 4096 ) ctx->launches_since_big = 0;
+        else if( ctx->launches_since_big < 1000 ) ctx->launches_since_big++;
+    }
+    const bool crowded = !lat_always && g_open_contexts[ctx->device & 63].load() >= 4 && ctx->launches_since_big <= 4;
     const bool lat[2] = { !crowded && (long long)n_plain * P.mb_h <= lat_waves, !crowded && (long long)( n - n_plain ) * P.mb_h <= lat_waves };
     const bool rows[2] = { use_rows || !lat[0], use_rows || !lat[1] };
     std::vector<int> spare_planes;
